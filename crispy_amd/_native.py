@@ -1,0 +1,72 @@
+"""ctypes binding of crispy_amd/libcrispy_hip.so (the C ABI declared in include/crispy_hip.h).
+
+There is no Python or CPU fallback: if the shared library is missing, or no gfx950 device is
+present, the failure is raised to the caller."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcrispy_hip.so")
+
+RN_FRAME = 480
+RN_WEIGHT_BYTES = 87503
+RN_TAPS = 72
+RN_DBG_FLOATS = 4304
+LAYOUT_TBF = 0
+LAYOUT_BTF = 1
+
+# every symbol include/crispy_hip.h declares (checked by tests/test_abi.py)
+RN_SYMBOLS = (
+    "crispy_last_error", "crispy_version", "crispy_device_count",
+    "crispy_rn_create", "crispy_rn_destroy", "crispy_rn_reset", "crispy_rn_n_streams",
+    "crispy_rn_process", "crispy_rn_process_device", "crispy_rn_synchronize",
+    "crispy_rn_set_timing", "crispy_rn_last_kernel_ms",
+    "crispy_rn_debug_capture", "crispy_rn_debug_read",
+)
+
+
+class CrispyError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"crispy_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libcrispy_hip.so (built by `__graft_entry__.build()` / `make -C crispy_amd/csrc`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  crispy_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    f32p = C.POINTER(C.c_float)
+    L.crispy_last_error.restype = C.c_char_p
+    L.crispy_version.restype = C.c_char_p
+    L.crispy_device_count.restype = C.c_int
+    L.crispy_rn_create.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.crispy_rn_destroy.argtypes = [C.c_void_p]
+    L.crispy_rn_destroy.restype = None
+    L.crispy_rn_reset.argtypes = [C.c_void_p, C.c_int]
+    L.crispy_rn_n_streams.argtypes = [C.c_void_p]
+    L.crispy_rn_process.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.crispy_rn_process_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_int, C.c_int, C.c_void_p]
+    L.crispy_rn_synchronize.argtypes = [C.c_void_p]
+    L.crispy_rn_set_timing.argtypes = [C.c_void_p, C.c_int]
+    L.crispy_rn_last_kernel_ms.argtypes = [C.c_void_p, f32p, f32p]
+    L.crispy_rn_debug_capture.argtypes = [C.c_void_p, C.c_int]
+    L.crispy_rn_debug_read.argtypes = [C.c_void_p, C.c_int, f32p, C.c_size_t]
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise CrispyError(rc, lib().crispy_last_error().decode("utf-8", "replace"))

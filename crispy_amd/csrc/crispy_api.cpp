@@ -1,0 +1,423 @@
+// crispy_api.cpp -- extern "C" boundary of libcrispy_hip.so (see include/crispy_hip.h).
+//
+// Host side of the batched RNNoise path: owns the per-stream state tensors in HBM, the device
+// tables, the repacked weights and the workspace; enqueues high-pass -> frame -> history-roll
+// kernels per chunk of frames.  No CPU compute path exists here: without a gfx950 device every
+// constructor fails.
+#include "../../include/crispy_hip.h"
+#include "rn_common.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace crispy;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess)                                                                  \
+      return fail(_e == hipErrorOutOfMemory ? CRISPY_ERR_OOM : CRISPY_ERR_HIP, "%s: %s", #expr, \
+                  hipGetErrorString(_e));                                                  \
+  } while (0)
+
+constexpr int kChunkFrames = 250;
+
+bool device_is_gfx950(int dev) {
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+  return std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+}
+
+void build_tables(RnTables* t) {
+  const double pi = 3.14159265358979323846;
+  for (int i = 0; i < RN_FRAME; ++i) {
+    const double s = std::sin(.5 * pi * (i + .5) / RN_FRAME);
+    t->half_window[i] = (float)std::sin(.5 * pi * s * s);
+  }
+  for (int i = 0; i < RN_NB; ++i)
+    for (int j = 0; j < RN_NB; ++j) {
+      double v = std::cos((i + .5) * j * pi / RN_NB);
+      if (j == 0) v *= std::sqrt(.5);
+      t->dct[i * RN_NB + j] = (float)v;
+    }
+  for (int i = 0; i < 208; ++i)
+    t->tansig[i] = i <= 200 ? (float)(std::floor(std::tanh(0.04 * i) * 1e6 + 0.5) / 1e6) : 1.f;
+  for (int k = 0; k < RN_WINDOW; ++k) {
+    t->w960[k].x = (float)std::cos(-2.0 * pi * k / RN_WINDOW);
+    t->w960[k].y = (float)std::sin(-2.0 * pi * k / RN_WINDOW);
+  }
+}
+
+// [K][rows] int8 (row stride `stride`, column offset `col0`) -> dwords [ceil(K/4)][rows]
+void pack_matrix(uint32_t* dst, const int8_t* src, int K, int rows, int stride, int col0 = 0) {
+  const int k4n = (K + 3) / 4;
+  for (int k4 = 0; k4 < k4n; ++k4)
+    for (int r = 0; r < rows; ++r) {
+      uint32_t w = 0;
+      for (int q = 0; q < 4; ++q) {
+        const int k = 4 * k4 + q;
+        const uint8_t byte = k < K ? (uint8_t)src[(size_t)k * stride + col0 + r] : 0;
+        w |= (uint32_t)byte << (8 * q);
+      }
+      dst[(size_t)k4 * rows + r] = w;
+    }
+}
+
+void pack_bias(uint32_t* dst, const int8_t* src, int n) {
+  for (int i = 0; i < n; ++i) {
+    const float f = (float)src[i];
+    std::memcpy(&dst[i], &f, 4);
+  }
+}
+
+void pack_weights(std::vector<uint32_t>& out, const int8_t* w) {
+  out.assign(RnPack::END, 0);
+  uint32_t* p = out.data();
+  pack_matrix(p + RnPack::ID_W, w + RnBlob::ID_W, 42, 24, 24);
+  pack_matrix(p + RnPack::VG_W, w + RnBlob::VG_W, 24, 72, 72);
+  pack_matrix(p + RnPack::VG_R, w + RnBlob::VG_R, 24, 72, 72);
+  pack_matrix(p + RnPack::VO_W, w + RnBlob::VO_W, 24, 1, 1);
+  pack_matrix(p + RnPack::NG_W, w + RnBlob::NG_W, 90, 144, 144);
+  pack_matrix(p + RnPack::NG_R, w + RnBlob::NG_R, 48, 144, 144);
+  pack_matrix(p + RnPack::DG_W, w + RnBlob::DG_W, 114, 288, 288);
+  pack_matrix(p + RnPack::DG_R, w + RnBlob::DG_R, 96, 288, 288);
+  pack_matrix(p + RnPack::DO_W, w + RnBlob::DO_W, 96, 22, 22);
+  pack_bias(p + RnPack::ID_B, w + RnBlob::ID_B, 24);
+  pack_bias(p + RnPack::VG_B, w + RnBlob::VG_B, 72);
+  pack_bias(p + RnPack::VO_B, w + RnBlob::VO_B, 1);
+  pack_bias(p + RnPack::NG_B, w + RnBlob::NG_B, 144);
+  pack_bias(p + RnPack::DG_B, w + RnBlob::DG_B, 288);
+  pack_bias(p + RnPack::DO_B, w + RnBlob::DO_B, 22);
+}
+
+}  // namespace
+
+struct crispy_rn {
+  int device = 0;
+  int B = 0;
+  hipStream_t stream = nullptr;
+  // constants
+  RnTables* d_tab = nullptr;
+  uint32_t* d_wpack = nullptr;
+  // state
+  float* d_hp_mem = nullptr;
+  float* d_synth = nullptr;
+  float* d_ceps = nullptr;
+  float* d_lastg = nullptr;
+  float* d_rnn = nullptr;
+  float* d_last_gain = nullptr;
+  int* d_last_period = nullptr;
+  int* d_memid = nullptr;
+  // workspace
+  float* d_xhp = nullptr;
+  long xhp_stride = 0;
+  float* d_dbg = nullptr;
+  // host-pointer staging
+  float* d_stage_in = nullptr;
+  float* d_stage_out = nullptr;
+  float* d_stage_vad = nullptr;
+  size_t stage_frames = 0;
+  // timing
+  bool timing = false;
+  std::vector<hipEvent_t> ev;  // per chunk: total_begin, frame_begin, frame_end, total_end
+  size_t ev_used = 0;
+};
+
+namespace {
+
+void free_all(crispy_rn* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  void* ptrs[] = {h->d_tab, h->d_wpack, h->d_hp_mem, h->d_synth, h->d_ceps, h->d_lastg, h->d_rnn,
+                  h->d_last_gain, h->d_last_period, h->d_memid, h->d_xhp, h->d_dbg, h->d_stage_in,
+                  h->d_stage_out, h->d_stage_vad};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int zero_state(crispy_rn* h, int stream) {
+  const int b0 = stream < 0 ? 0 : stream;
+  const size_t n = stream < 0 ? (size_t)h->B : 1;
+  hipStream_t s = h->stream;
+  HIP_TRY(hipMemsetAsync(h->d_hp_mem + (size_t)b0 * 2, 0, n * 2 * sizeof(float), s));
+  HIP_TRY(hipMemsetAsync(h->d_synth + (size_t)b0 * 480, 0, n * 480 * sizeof(float), s));
+  HIP_TRY(hipMemsetAsync(h->d_ceps + (size_t)b0 * 176, 0, n * 176 * sizeof(float), s));
+  HIP_TRY(hipMemsetAsync(h->d_lastg + (size_t)b0 * RN_NB, 0, n * RN_NB * sizeof(float), s));
+  HIP_TRY(hipMemsetAsync(h->d_rnn + (size_t)b0 * 168, 0, n * 168 * sizeof(float), s));
+  HIP_TRY(hipMemsetAsync(h->d_last_gain + b0, 0, n * sizeof(float), s));
+  HIP_TRY(hipMemsetAsync(h->d_last_period + b0, 0, n * sizeof(int), s));
+  HIP_TRY(hipMemsetAsync(h->d_memid + b0, 0, n * sizeof(int), s));
+  if (stream < 0) {
+    HIP_TRY(hipMemsetAsync(h->d_xhp, 0, (size_t)h->B * h->xhp_stride * sizeof(float), s));
+  } else {
+    HIP_TRY(hipMemsetAsync(h->d_xhp + (size_t)b0 * h->xhp_stride, 0, RN_HIST * sizeof(float), s));
+  }
+  return CRISPY_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* crispy_last_error(void) { return g_last_error.c_str(); }
+
+const char* crispy_version(void) { return "crispy_hip 0.1.0 gfx950"; }
+
+int crispy_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  int ok = 0;
+  for (int d = 0; d < n; ++d)
+    if (device_is_gfx950(d)) ++ok;
+  return ok;
+}
+
+int crispy_rn_create(const int8_t* weights, size_t nbytes, int n_streams, int device, crispy_rn** out) {
+  if (!out) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_create: out is NULL");
+  *out = nullptr;
+  if (!weights || nbytes != (size_t)RN_WEIGHT_BYTES)
+    return fail(CRISPY_ERR_BAD_MODEL, "crispy_rn_create: weights must be a %d-byte blob (got %zu)",
+                RN_WEIGHT_BYTES, weights ? nbytes : (size_t)0);
+  if (n_streams <= 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_create: n_streams must be > 0");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(CRISPY_ERR_NO_DEVICE, "crispy_rn_create: no HIP device (this library has no CPU path)");
+  if (device < 0 || device >= ndev)
+    return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_create: device %d out of range [0,%d)", device, ndev);
+  if (!device_is_gfx950(device))
+    return fail(CRISPY_ERR_NO_DEVICE, "crispy_rn_create: device %d is not gfx950 (MI355X)", device);
+
+  crispy_rn* h = new (std::nothrow) crispy_rn();
+  if (!h) return fail(CRISPY_ERR_OOM, "crispy_rn_create: host allocation failed");
+  h->device = device;
+  h->B = n_streams;
+  h->xhp_stride = (long)(kChunkFrames + RN_HIST_FRAMES) * RN_FRAME;
+  int rc = CRISPY_OK;
+  auto body = [&]() -> int {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    const size_t B = (size_t)n_streams;
+    HIP_TRY(hipMalloc(&h->d_tab, sizeof(RnTables)));
+    HIP_TRY(hipMalloc(&h->d_wpack, sizeof(uint32_t) * RnPack::END));
+    HIP_TRY(hipMalloc(&h->d_hp_mem, B * 2 * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_synth, B * 480 * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_ceps, B * 176 * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_lastg, B * RN_NB * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_rnn, B * 168 * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_last_gain, B * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_last_period, B * sizeof(int)));
+    HIP_TRY(hipMalloc(&h->d_memid, B * sizeof(int)));
+    HIP_TRY(hipMalloc(&h->d_xhp, B * h->xhp_stride * sizeof(float)));
+    RnTables* tab = new RnTables();
+    build_tables(tab);
+    hipError_t e = hipMemcpy(h->d_tab, tab, sizeof(RnTables), hipMemcpyHostToDevice);
+    delete tab;
+    HIP_TRY(e);
+    std::vector<uint32_t> pack;
+    pack_weights(pack, weights);
+    HIP_TRY(hipMemcpy(h->d_wpack, pack.data(), sizeof(uint32_t) * pack.size(), hipMemcpyHostToDevice));
+    int z = zero_state(h, -1);
+    if (z != CRISPY_OK) return z;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return CRISPY_OK;
+  };
+  rc = body();
+  if (rc != CRISPY_OK) {
+    std::string keep = g_last_error;
+    free_all(h);
+    g_last_error = keep;
+    return rc;
+  }
+  *out = h;
+  return CRISPY_OK;
+}
+
+void crispy_rn_destroy(crispy_rn* h) { free_all(h); }
+
+int crispy_rn_n_streams(const crispy_rn* h) { return h ? h->B : 0; }
+
+int crispy_rn_reset(crispy_rn* h, int stream) {
+  if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_reset: NULL handle");
+  if (stream < -1 || stream >= h->B)
+    return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_reset: stream %d out of range", stream);
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = zero_state(h, stream);
+  if (rc != CRISPY_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return CRISPY_OK;
+}
+
+int crispy_rn_process_device(crispy_rn* h, const float* d_in, float* d_out, float* d_vad, float* d_taps,
+                             int n_frames, crispy_rn_layout layout, void* hip_stream) {
+  if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_process_device: NULL handle");
+  if (n_frames < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_process_device: n_frames < 0");
+  if (n_frames == 0) return CRISPY_OK;
+  if (!d_in || !d_out) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_process_device: NULL audio pointer");
+  if (layout != CRISPY_RN_LAYOUT_TBF && layout != CRISPY_RN_LAYOUT_BTF)
+    return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_process_device: unknown layout %d", (int)layout);
+  if (((uintptr_t)d_in | (uintptr_t)d_out) & 15)
+    return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_process_device: audio pointers must be 16-byte aligned");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
+
+  RnArgs a{};
+  a.B = h->B;
+  a.stride_t = layout == CRISPY_RN_LAYOUT_TBF ? (long)h->B * RN_FRAME : (long)RN_FRAME;
+  a.stride_b = layout == CRISPY_RN_LAYOUT_TBF ? (long)RN_FRAME : (long)n_frames * RN_FRAME;
+  a.xhp = h->d_xhp;
+  a.xhp_stride = h->xhp_stride;
+  a.hp_mem = h->d_hp_mem;
+  a.synth = h->d_synth;
+  a.ceps = h->d_ceps;
+  a.lastg = h->d_lastg;
+  a.rnn = h->d_rnn;
+  a.last_gain = h->d_last_gain;
+  a.last_period = h->d_last_period;
+  a.memid = h->d_memid;
+  a.tab = h->d_tab;
+  a.wpack = h->d_wpack;
+
+  if (h->timing) h->ev_used = 0;
+  for (int t0 = 0; t0 < n_frames; t0 += kChunkFrames) {
+    const int T = (n_frames - t0) < kChunkFrames ? (n_frames - t0) : kChunkFrames;
+    a.T = T;
+    a.in = d_in + (long)t0 * a.stride_t;
+    a.out = d_out + (long)t0 * a.stride_t;
+    a.vad = d_vad ? d_vad + (long)t0 * h->B : nullptr;
+    a.taps = d_taps ? d_taps + (long)t0 * h->B * RN_TAPS : nullptr;
+    a.dbg = (t0 + T == n_frames) ? h->d_dbg : nullptr;
+    hipEvent_t* e = nullptr;
+    if (h->timing) {
+      while (h->ev.size() < h->ev_used + 4) {
+        hipEvent_t ne;
+        HIP_TRY(hipEventCreate(&ne));
+        h->ev.push_back(ne);
+      }
+      e = &h->ev[h->ev_used];
+      h->ev_used += 4;
+      HIP_TRY(hipEventRecord(e[0], s));
+    }
+    HIP_TRY(rn_launch_highpass(a, s));
+    if (e) HIP_TRY(hipEventRecord(e[1], s));
+    HIP_TRY(rn_launch_frames(a, s));
+    if (e) HIP_TRY(hipEventRecord(e[2], s));
+    HIP_TRY(rn_launch_roll_history(a, s));
+    if (e) HIP_TRY(hipEventRecord(e[3], s));
+  }
+  return CRISPY_OK;
+}
+
+int crispy_rn_process(crispy_rn* h, const float* in, float* out, float* vad, int n_frames,
+                      crispy_rn_layout layout) {
+  if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_process: NULL handle");
+  if (n_frames < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_process: n_frames < 0");
+  if (n_frames == 0) return CRISPY_OK;
+  if (!in || !out) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_process: NULL audio pointer");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t n = (size_t)n_frames * h->B * RN_FRAME;
+  if (h->stage_frames < (size_t)n_frames) {
+    if (h->d_stage_in) (void)hipFree(h->d_stage_in);
+    if (h->d_stage_out) (void)hipFree(h->d_stage_out);
+    if (h->d_stage_vad) (void)hipFree(h->d_stage_vad);
+    h->d_stage_in = h->d_stage_out = h->d_stage_vad = nullptr;
+    h->stage_frames = 0;
+    HIP_TRY(hipMalloc(&h->d_stage_in, n * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_stage_out, n * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_stage_vad, (size_t)n_frames * h->B * sizeof(float)));
+    h->stage_frames = (size_t)n_frames;
+  }
+  HIP_TRY(hipMemcpyAsync(h->d_stage_in, in, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  int rc = crispy_rn_process_device(h, h->d_stage_in, h->d_stage_out, vad ? h->d_stage_vad : nullptr,
+                                    nullptr, n_frames, layout, nullptr);
+  if (rc != CRISPY_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(out, h->d_stage_out, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  if (vad)
+    HIP_TRY(hipMemcpyAsync(vad, h->d_stage_vad, (size_t)n_frames * h->B * sizeof(float),
+                           hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return CRISPY_OK;
+}
+
+int crispy_rn_synchronize(crispy_rn* h) {
+  if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_synchronize: NULL handle");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return CRISPY_OK;
+}
+
+int crispy_rn_set_timing(crispy_rn* h, int enable) {
+  if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_set_timing: NULL handle");
+  h->timing = enable != 0;
+  h->ev_used = 0;
+  return CRISPY_OK;
+}
+
+int crispy_rn_last_kernel_ms(crispy_rn* h, float* frame_kernel_ms, float* total_ms) {
+  if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_last_kernel_ms: NULL handle");
+  if (!h->timing || h->ev_used == 0)
+    return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_last_kernel_ms: no timed call recorded");
+  HIP_TRY(hipSetDevice(h->device));
+  float fk = 0.f, tot = 0.f;
+  for (size_t i = 0; i + 3 < h->ev_used; i += 4) {
+    HIP_TRY(hipEventSynchronize(h->ev[i + 3]));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev[i + 1], h->ev[i + 2]));
+    fk += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 3]));
+    tot += ms;
+  }
+  if (frame_kernel_ms) *frame_kernel_ms = fk;
+  if (total_ms) *total_ms = tot;
+  return CRISPY_OK;
+}
+
+int crispy_rn_debug_capture(crispy_rn* h, int enable) {
+  if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_debug_capture: NULL handle");
+  HIP_TRY(hipSetDevice(h->device));
+  if (enable && !h->d_dbg) {
+    HIP_TRY(hipMalloc(&h->d_dbg, (size_t)h->B * RN_DBG_FLOATS * sizeof(float)));
+    HIP_TRY(hipMemset(h->d_dbg, 0, (size_t)h->B * RN_DBG_FLOATS * sizeof(float)));
+  } else if (!enable && h->d_dbg) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipFree(h->d_dbg));
+    h->d_dbg = nullptr;
+  }
+  return CRISPY_OK;
+}
+
+int crispy_rn_debug_read(crispy_rn* h, int stream, float* dst, size_t n_floats) {
+  if (!h || !dst) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_debug_read: NULL argument");
+  if (!h->d_dbg) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_debug_read: capture not enabled");
+  if (stream < 0 || stream >= h->B || n_floats > (size_t)RN_DBG_FLOATS)
+    return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_debug_read: bad stream/size");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(dst, h->d_dbg + (size_t)stream * RN_DBG_FLOATS, n_floats * sizeof(float),
+                    hipMemcpyDeviceToHost));
+  return CRISPY_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,98 @@
+// rn_common.h -- shared host/device declarations for the batched RNNoise path (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace crispy {
+
+constexpr int RN_FRAME = 480;
+constexpr int RN_WINDOW = 960;
+constexpr int RN_NFREQ = 481;
+constexpr int RN_NB = 22;
+constexpr int RN_NFEAT = 42;
+constexpr int RN_PITCH_BUF = 1728;
+constexpr int RN_HIST = 1920;          // 4 frames of high-passed history kept per stream
+constexpr int RN_HIST_FRAMES = 4;
+constexpr int RN_TAPS = 72;
+constexpr int RN_WEIGHT_BYTES = 87503;
+constexpr int RN_DBG_FLOATS = 4304;    // mirrors oracle RNO_DBG_*
+
+// Device tables (built on the host in double precision, one copy per handle).
+struct RnTables {
+  float half_window[RN_FRAME];
+  float dct[RN_NB * RN_NB];   // dct[j*22+i] = cos((j+.5) i pi/22), column 0 scaled by sqrt(.5)
+  float tansig[208];          // tanh(0.04 i) rounded to 6 decimals, i = 0..200
+  float2 w960[RN_WINDOW];     // exp(-2 pi i k / 960)
+};
+
+// Flat blob offsets.
+struct RnBlob {
+  static constexpr int ID_W = 0, ID_B = ID_W + 42 * 24;
+  static constexpr int VG_W = ID_B + 24, VG_R = VG_W + 24 * 72, VG_B = VG_R + 24 * 72;
+  static constexpr int VO_W = VG_B + 72, VO_B = VO_W + 24;
+  static constexpr int NG_W = VO_B + 1, NG_R = NG_W + 90 * 144, NG_B = NG_R + 48 * 144;
+  static constexpr int DG_W = NG_B + 144, DG_R = DG_W + 114 * 288, DG_B = DG_R + 96 * 288;
+  static constexpr int DO_W = DG_B + 288, DO_B = DO_W + 96 * 22;
+  static constexpr int END = DO_B + 22;
+};
+static_assert(RnBlob::END == RN_WEIGHT_BYTES, "blob layout");
+
+// Repacked weights: every matrix [K][rows] int8 becomes dwords [ceil(K/4)][rows] holding the
+// four k-consecutive weights of one row, so that lane == row reads one coalesced dword per
+// four MACs.  Biases are widened to float.  Offsets are in dwords from the pack base.
+constexpr int rn_k4(int k) { return (k + 3) / 4; }
+struct RnPack {
+  // matrices (dword offsets)
+  static constexpr int k4(int k) { return rn_k4(k); }
+  static constexpr int ID_W = 0;                              // K=42  rows=24
+  static constexpr int VG_W = ID_W + rn_k4(42) * 24;             // K=24  rows=72
+  static constexpr int VG_R = VG_W + rn_k4(24) * 72;             // K=24  rows=72
+  static constexpr int VO_W = VG_R + rn_k4(24) * 72;             // K=24  rows=1
+  static constexpr int NG_W = VO_W + rn_k4(24) * 1;              // K=90  rows=144
+  static constexpr int NG_R = NG_W + rn_k4(90) * 144;            // K=48  rows=144
+  static constexpr int DG_W = NG_R + rn_k4(48) * 144;            // K=114 rows=288
+  static constexpr int DG_R = DG_W + rn_k4(114) * 288;           // K=96  rows=288
+  static constexpr int DO_W = DG_R + rn_k4(96) * 288;            // K=96  rows=22
+  static constexpr int MAT_END = DO_W + rn_k4(96) * 22;
+  // float biases (dword offsets)
+  static constexpr int ID_B = MAT_END;
+  static constexpr int VG_B = ID_B + 24;
+  static constexpr int VO_B = VG_B + 72;
+  static constexpr int NG_B = VO_B + 1;
+  static constexpr int DG_B = NG_B + 144;
+  static constexpr int DO_B = DG_B + 288;
+  static constexpr int END = DO_B + 22;
+};
+
+// Kernel arguments of one enqueue (chunk of T frames for all B streams).
+struct RnArgs {
+  // audio
+  const float* in;      // caller layout
+  float* out;           // caller layout
+  long stride_t, stride_b;  // element strides of (frame, stream) in `in`/`out`
+  float* vad;           // [T][B] or null
+  float* taps;          // [T][B][72] or null
+  float* dbg;           // [B][RN_DBG_FLOATS] or null (last frame of the call)
+  int T, B;
+  // workspace: high-passed signal, per stream contiguous: [B][xhp_stride], first RN_HIST = history
+  float* xhp;
+  long xhp_stride;
+  // persistent per-stream state (HBM)
+  float* hp_mem;        // [B][2]
+  float* synth;         // [B][480]
+  float* ceps;          // [B][8*22]
+  float* lastg;         // [B][22]
+  float* rnn;           // [B][168]
+  float* last_gain;     // [B]
+  int* last_period;     // [B]
+  int* memid;           // [B]
+  // constants
+  const RnTables* tab;
+  const uint32_t* wpack;
+};
+
+hipError_t rn_launch_highpass(const RnArgs& a, hipStream_t s);
+hipError_t rn_launch_frames(const RnArgs& a, hipStream_t s);
+hipError_t rn_launch_roll_history(const RnArgs& a, hipStream_t s);
+
+}  // namespace crispy

@@ -1,0 +1,1017 @@
+// rn_kernels.hip -- batched RNNoise frame pipeline for MI355X (gfx950, wave64).
+//
+// Replaces nnnoiseless::DenoiseState::process_frame (reference call site
+// src-tauri/src/audio.rs:268) for B independent streams.  Algorithm: SURVEY.md Appendix A.
+//
+// Mapping
+//   rn_highpass_kernel   one LANE per stream: the biquad is a strict 480-step recurrence with
+//                        f32 state rounding, so it is run sequentially per stream, 64 streams per
+//                        wave, and its output is written to a per-stream contiguous history
+//                        (xhp) that the frame kernel reads coalesced.
+//   rn_frame_kernel      one WAVE per stream, persistent over the T frames of a call.  The wave
+//                        keeps its stream's spectra / pitch buffers / GRU state in LDS; HBM sees
+//                        only the 480 in + 480 out samples per frame plus L2-resident re-reads of
+//                        the high-passed history.  64-thread workgroups: every barrier is a
+//                        single-wave barrier.
+//   rn_roll_history      keeps the last 4 high-passed frames for the next call.
+//
+// The analysis window [x_prev, x_cur] and the 1728-sample pitch buffer of the reference are both
+// windows of the same high-passed signal, so neither is stored as state: they are views of xhp.
+#include "rn_common.h"
+
+namespace crispy {
+namespace {
+
+constexpr int WAVE = 64;
+
+// Opus band edges in units of 4 bins (Appendix A.1).
+__device__ __constant__ unsigned char c_eband[RN_NB] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  10, 12,
+                                                         14, 16, 20, 24, 28, 34, 40, 48, 60, 78, 100};
+// band of each 4-bin chunk (100 chunks cover bins 0..399)
+__device__ __constant__ unsigned char c_chunk_band[100] = {
+    0,  1,  2,  3,  4,  5,  6,  7,  8,  8,  9,  9,  10, 10, 11, 11, 12, 12, 12, 12,
+    13, 13, 13, 13, 14, 14, 14, 14, 15, 15, 15, 15, 15, 15, 16, 16, 16, 16, 16, 16,
+    17, 17, 17, 17, 17, 17, 17, 17, 18, 18, 18, 18, 18, 18, 18, 18, 18, 18, 18, 18,
+    19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 20, 20,
+    20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20};
+__device__ __constant__ int c_second_check[16] = {0, 0, 3, 2, 3, 2, 5, 2, 3, 2, 3, 2, 5, 2, 3, 2};
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 480-point complex FFT, in place in LDS, one wave.  Stockham passes with register staging:
+// every lane reads the inputs of its butterflies, the wave synchronises, every lane writes.
+// ---------------------------------------------------------------------------------------------
+template <int R>
+__device__ __forceinline__ void butterfly(const float2 (&v)[R], float2 (&o)[R]);
+
+template <>
+__device__ __forceinline__ void butterfly<2>(const float2 (&v)[2], float2 (&o)[2]) {
+  o[0] = cadd(v[0], v[1]);
+  o[1] = csub(v[0], v[1]);
+}
+template <>
+__device__ __forceinline__ void butterfly<4>(const float2 (&v)[4], float2 (&o)[4]) {
+  const float2 s0 = cadd(v[0], v[2]), d0 = csub(v[0], v[2]);
+  const float2 s1 = cadd(v[1], v[3]), d1 = csub(v[1], v[3]);
+  o[0] = cadd(s0, s1);
+  o[2] = csub(s0, s1);
+  o[1] = make_float2(d0.x + d1.y, d0.y - d1.x);  // d0 - i d1
+  o[3] = make_float2(d0.x - d1.y, d0.y + d1.x);  // d0 + i d1
+}
+template <>
+__device__ __forceinline__ void butterfly<3>(const float2 (&v)[3], float2 (&o)[3]) {
+  const float2 t = cadd(v[1], v[2]), d = csub(v[1], v[2]);
+  o[0] = cadd(v[0], t);
+  const float2 a = make_float2(v[0].x - 0.5f * t.x, v[0].y - 0.5f * t.y);
+  const float s = 0.86602540378443864676f;
+  const float2 b = make_float2(s * d.x, s * d.y);
+  o[1] = make_float2(a.x + b.y, a.y - b.x);  // a - i b
+  o[2] = make_float2(a.x - b.y, a.y + b.x);  // a + i b
+}
+template <>
+__device__ __forceinline__ void butterfly<5>(const float2 (&v)[5], float2 (&o)[5]) {
+  const float c1 = 0.30901699437494742410f, s1 = 0.95105651629515357212f;
+  const float c2 = -0.80901699437494742410f, s2 = 0.58778525229247312917f;
+  const float2 t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]);
+  const float2 t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
+  o[0] = make_float2(v[0].x + t1.x + t2.x, v[0].y + t1.y + t2.y);
+  const float2 a1 = make_float2(v[0].x + c1 * t1.x + c2 * t2.x, v[0].y + c1 * t1.y + c2 * t2.y);
+  const float2 a2 = make_float2(v[0].x + c2 * t1.x + c1 * t2.x, v[0].y + c2 * t1.y + c1 * t2.y);
+  const float2 b1 = make_float2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
+  const float2 b2 = make_float2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
+  o[1] = make_float2(a1.x + b1.y, a1.y - b1.x);
+  o[4] = make_float2(a1.x - b1.y, a1.y + b1.x);
+  o[2] = make_float2(a2.x + b2.y, a2.y - b2.x);
+  o[3] = make_float2(a2.x - b2.y, a2.y + b2.x);
+}
+
+template <int R, int NS>
+__device__ __forceinline__ void fft_pass(float2* buf, const float2* __restrict__ w960, int lane) {
+  constexpr int M = 480 / R;
+  constexpr int NBF = (M + WAVE - 1) / WAVE;
+  float2 o[NBF][R];
+#pragma unroll
+  for (int nb = 0; nb < NBF; ++nb) {
+    const int j = lane + WAVE * nb;
+    if (j < M) {
+      const int k = j % NS;
+      float2 v[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float2 x = buf[j + r * M];
+        if (NS > 1 && r > 0) x = cmul(x, w960[k * r * (960 / (NS * R))]);
+        v[r] = x;
+      }
+      butterfly<R>(v, o[nb]);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int nb = 0; nb < NBF; ++nb) {
+    const int j = lane + WAVE * nb;
+    if (j < M) {
+      const int k = j % NS;
+      const int j0 = (j / NS) * NS * R + k;
+#pragma unroll
+      for (int r = 0; r < R; ++r) buf[j0 + r * NS] = o[nb][r];
+    }
+  }
+  __syncthreads();
+}
+
+// forward DFT of the 480 complex points in buf (unscaled, natural order); caller synchronised
+__device__ __forceinline__ void fft480(float2* buf, const float2* __restrict__ w960, int lane) {
+  fft_pass<4, 1>(buf, w960, lane);
+  fft_pass<4, 4>(buf, w960, lane);
+  fft_pass<2, 16>(buf, w960, lane);
+  fft_pass<3, 32>(buf, w960, lane);
+  fft_pass<5, 96>(buf, w960, lane);
+}
+
+// buf holds Z = FFT480(x[2n] + i x[2n+1]); turn it into X[0..480] = DFT960(x)/960 in place.
+__device__ __forceinline__ void real_fwd_post(float2* buf, const float2* __restrict__ w960, int lane) {
+  const float scale = 1.0f / 960.0f;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int k = lane + WAVE * m;
+    if (k <= 240) {
+      const float2 zk = buf[k];
+      const float2 zn = (k == 0) ? zk : buf[480 - k];
+      // X[k]
+      float2 zc = cconj(zn);
+      float2 fe = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
+      float2 d = make_float2(0.5f * (zk.x - zc.x), 0.5f * (zk.y - zc.y));
+      float2 t = cmul(w960[k], make_float2(d.y, -d.x));
+      const float2 xk = make_float2((fe.x + t.x) * scale, (fe.y + t.y) * scale);
+      // X[480-k]
+      zc = cconj(zk);
+      fe = make_float2(0.5f * (zn.x + zc.x), 0.5f * (zn.y + zc.y));
+      d = make_float2(0.5f * (zn.x - zc.x), 0.5f * (zn.y - zc.y));
+      t = cmul(w960[480 - k], make_float2(d.y, -d.x));
+      const float2 xn = make_float2((fe.x + t.x) * scale, (fe.y + t.y) * scale);
+      buf[k] = xk;
+      buf[480 - k] = xn;
+    }
+  }
+  __syncthreads();
+}
+
+// buf holds X[0..480]; replace it by conj(Z) with Z[k] = (X[k]+conj X[480-k]) + i w^-k (X[k]-conj X[480-k])
+// so that a forward FFT yields conj of the interleaved time signal.
+__device__ __forceinline__ void real_inv_pre(float2* buf, const float2* __restrict__ w960, int lane) {
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int k = lane + WAVE * m;
+    if (k <= 240) {
+      const float2 a = buf[k];
+      const float2 bn = buf[480 - k];
+      float2 b = cconj(bn);
+      float2 fe = cadd(a, b);
+      float2 fo = cmul(csub(a, b), cconj(w960[k]));
+      const float2 zk = make_float2(fe.x - fo.y, -(fe.y + fo.x));
+      b = cconj(a);
+      fe = cadd(bn, b);
+      fo = cmul(csub(bn, b), cconj(w960[480 - k]));
+      const float2 zn = make_float2(fe.x - fo.y, -(fe.y + fo.x));
+      buf[k] = zk;
+      if (k > 0) buf[480 - k] = zn;
+    }
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Opus-band helpers (Appendix A.3 step 2).  `part` is 200 floats of scratch.
+// ---------------------------------------------------------------------------------------------
+template <bool CORR>
+__device__ __forceinline__ void band_sums(const float2* X, const float2* P, float* part, float* E,
+                                          int lane) {
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int c = lane + WAVE * m;
+    if (c < 100) {
+      const int i = c_chunk_band[c];
+      const int e0 = c_eband[i];
+      const int bs = (c_eband[i + 1] - e0) * 4;
+      const int q = c - e0;
+      float lo = 0.f, hi = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const float frac = (float)(4 * q + jj) / (float)bs;
+        const float2 x = X[4 * c + jj];
+        float tmp;
+        if (CORR) {
+          const float2 p = P[4 * c + jj];
+          tmp = x.x * p.x;
+          tmp += x.y * p.y;
+        } else {
+          tmp = x.x * x.x;
+          tmp += x.y * x.y;
+        }
+        lo += (1.f - frac) * tmp;
+        hi += frac * tmp;
+      }
+      part[c] = lo;
+      part[100 + c] = hi;
+    }
+  }
+  __syncthreads();
+  if (lane < RN_NB) {
+    const int i = lane;
+    float sum = 0.f;
+    if (i > 0)
+      for (int c = c_eband[i - 1]; c < c_eband[i]; ++c) sum += part[100 + c];
+    if (i < RN_NB - 1)
+      for (int c = c_eband[i]; c < c_eband[i + 1]; ++c) sum += part[c];
+    if (i == 0 || i == RN_NB - 1) sum *= 2.f;
+    E[i] = sum;
+  }
+  __syncthreads();
+}
+
+// per-bin interpolation of 22 band values (bins >= 400 are zero)
+__device__ __forceinline__ float interp_gain(const float* v, int bin) {
+  if (bin >= 400) return 0.f;
+  const int c = bin >> 2;
+  const int i = c_chunk_band[c];
+  const int e0 = c_eband[i];
+  const int bs = (c_eband[i + 1] - e0) * 4;
+  const float frac = (float)(bin - 4 * e0) / (float)bs;
+  return (1.f - frac) * v[i] + frac * v[i + 1];
+}
+
+// ---------------------------------------------------------------------------------------------
+// RNN (Appendix A.3 step 6): lane == output row, weights as packed int8 dwords from L2.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float tansig_approx(float x, const float* __restrict__ table) {
+  if (!(x < 8.f)) return 1.f;
+  if (!(x > -8.f)) return -1.f;
+  float sign = 1.f;
+  if (x < 0.f) { x = -x; sign = -1.f; }
+  const int i = (int)floorf(.5f + 25.f * x);
+  x -= .04f * i;
+  float y = table[i];
+  const float dy = 1.f - y * y;
+  y = y + x * dy * (1.f - y * x);
+  return sign * y;
+}
+__device__ __forceinline__ float sigmoid_approx(float x, const float* __restrict__ table) {
+  return .5f + .5f * tansig_approx(.5f * x, table);
+}
+
+// acc += sum_k W[k][row] * x[k]; x lives in LDS, is 16-byte aligned and zero padded to 4*k4
+__device__ __forceinline__ float dot_i8(const uint32_t* __restrict__ Wp, int rows, int row,
+                                        const float* x, int k4n, float acc) {
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (int k4 = 0; k4 < k4n; ++k4) {
+    const uint32_t w = Wp[k4 * rows + row];
+    const float4 xv = x4[k4];
+    acc = fmaf((float)(int)(int8_t)(w & 0xff), xv.x, acc);
+    acc = fmaf((float)(int)(int8_t)((w >> 8) & 0xff), xv.y, acc);
+    acc = fmaf((float)(int)(int8_t)((w >> 16) & 0xff), xv.z, acc);
+    acc = fmaf((float)((int)w >> 24), xv.w, acc);
+  }
+  return acc;
+}
+
+// One GRU layer.  in_vec[K=M] and state[N] in LDS (zero padded to multiples of 4); pre = scratch
+// of 3N floats, hr = scratch of N (padded) floats.  ReLU candidate activation.
+template <int M, int N>
+__device__ __forceinline__ void gru_layer(const uint32_t* __restrict__ W, const uint32_t* __restrict__ U,
+                                          const float* __restrict__ bias, const float* in_vec,
+                                          float* state, float* pre, float* zbuf, float* hr,
+                                          const float* __restrict__ tansig, int lane) {
+  constexpr int ROWS = 3 * N;
+  constexpr int MK4 = (M + 3) / 4, NK4 = (N + 3) / 4;
+  const float S = 1.f / 256.f;
+  for (int row = lane; row < ROWS; row += WAVE) {
+    float acc = bias[row];
+    acc = dot_i8(W, ROWS, row, in_vec, MK4, acc);
+    if (row < 2 * N) acc = dot_i8(U, ROWS, row, state, NK4, acc);
+    pre[row] = acc;
+  }
+  __syncthreads();
+  for (int i = lane; i < N; i += WAVE) {
+    const float z = sigmoid_approx(S * pre[i], tansig);
+    const float r = sigmoid_approx(S * pre[N + i], tansig);
+    zbuf[i] = z;
+    hr[i] = state[i] * r;
+  }
+  __syncthreads();
+  for (int i = lane; i < N; i += WAVE) {
+    float acc = pre[2 * N + i];
+    acc = dot_i8(U, ROWS, 2 * N + i, hr, NK4, acc);
+    float c = S * acc;
+    c = c < 0.f ? 0.f : c;
+    const float z = zbuf[i];
+    state[i] = z * state[i] + (1.f - z) * c;
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS layout of one wave (floats)
+// ---------------------------------------------------------------------------------------------
+struct alignas(16) RnLds {
+  float2 X[482];        // analysis spectrum, later the synthesis buffer
+  float2 P[482];        // pitch-frame spectrum; before that: lp[864] whitened half-rate buffer
+  float S[704];         // scratch: x4/y4 | band partial sums | yy_lookup | fine xcorr
+  float synth[480];
+  float ceps[8 * 22];
+  float rnn_state[168]; // vad 24 | noise 48 | denoise 96
+  float feat[44];
+  float dense[24];
+  float gru_in[116];
+  float pre[288];
+  float zbuf[96];
+  float hr[96];
+  float Ex[24], Ep[24], Exp[24], g[24], lastg[24], r[24], tmp22[24], Ly[24];
+};
+
+// top-2 bookkeeping of find_best_pitch as an ordering on (num, den, idx)
+struct Cand {
+  float num, den;
+  int idx;
+};
+__device__ __forceinline__ bool cand_better(const Cand& a, const Cand& b) {
+  const float l = a.num * b.den, r = b.num * a.den;
+  return (l > r) || (!(r > l) && a.idx < b.idx);
+}
+__device__ __forceinline__ Cand wave_best(Cand c) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    Cand o;
+    o.num = __shfl_xor(c.num, off, WAVE);
+    o.den = __shfl_xor(c.den, off, WAVE);
+    o.idx = __shfl_xor(c.idx, off, WAVE);
+    if (cand_better(o, c)) c = o;
+  }
+  c.num = __shfl(c.num, 0, WAVE);
+  c.den = __shfl(c.den, 0, WAVE);
+  c.idx = __shfl(c.idx, 0, WAVE);
+  return c;
+}
+
+// =============================================================================================
+// frame kernel: one wave per stream, loops over the T frames of the call
+// =============================================================================================
+__global__ __launch_bounds__(WAVE) void rn_frame_kernel(RnArgs a) {
+  __shared__ RnLds L;
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x;
+  if (b >= a.B) return;
+  const RnTables* __restrict__ tab = a.tab;
+  const float2* __restrict__ w960 = tab->w960;
+  const float* __restrict__ hw = tab->half_window;
+  const float* __restrict__ tansig = tab->tansig;
+  const uint32_t* __restrict__ wp = a.wpack;
+  const float* __restrict__ wpf = reinterpret_cast<const float*>(a.wpack);
+  const float* xs = a.xhp + (long)b * a.xhp_stride;
+
+  // ---- load per-stream state ----
+  for (int i = lane; i < 480; i += WAVE) L.synth[i] = a.synth[(long)b * 480 + i];
+  for (int i = lane; i < 176; i += WAVE) L.ceps[i] = a.ceps[(long)b * 176 + i];
+  for (int i = lane; i < 168; i += WAVE) L.rnn_state[i] = a.rnn[(long)b * 168 + i];
+  if (lane < 24) {
+    L.lastg[lane] = lane < RN_NB ? a.lastg[(long)b * RN_NB + lane] : 0.f;
+    L.g[lane] = 0.f;
+  }
+  if (lane < 2) L.feat[42 + lane] = 0.f;
+  if (lane < 2) L.gru_in[114 + lane] = 0.f;
+  int memid = a.memid[b];
+  int last_period = a.last_period[b];
+  float last_gain = a.last_gain[b];
+  __syncthreads();
+
+  float* lp = reinterpret_cast<float*>(L.P);  // 864 floats, aliases P until the pitch frame
+  float* Xf = reinterpret_cast<float*>(L.X);
+
+  for (int t = 0; t < a.T; ++t) {
+    const float* xw = xs + (long)(t + 3) * RN_FRAME;  // [x_prev, x_cur]
+    const float* pb = xs + (long)t * RN_FRAME + 672;  // 1728-sample pitch buffer ending at x_cur
+
+    // ---- 1. frame_analysis: window, 960-point real FFT, band energies ----
+    for (int n = lane; n < 480; n += WAVE) {
+      const float2 v = *reinterpret_cast<const float2*>(xw + 2 * n);
+      const int i0 = 2 * n, i1 = 2 * n + 1;
+      const float w0 = i0 < 480 ? hw[i0] : hw[959 - i0];
+      const float w1 = i1 < 480 ? hw[i1] : hw[959 - i1];
+      L.X[n] = make_float2(v.x * w0, v.y * w1);
+    }
+    __syncthreads();
+    fft480(L.X, w960, lane);
+    real_fwd_post(L.X, w960, lane);
+    band_sums<false>(L.X, nullptr, L.S, L.Ex, lane);
+
+    // ---- 2. pitch: half-rate, LPC whitening ----
+    for (int i = lane; i < 864; i += WAVE) {
+      const float x1 = pb[2 * i], x2 = pb[2 * i + 1];
+      const float x0 = i > 0 ? pb[2 * i - 1] : 0.f;
+      lp[i] = .5f * (.5f * (x0 + x2) + x1);
+    }
+    __syncthreads();
+    float lpc2[5];
+    {
+      float ac[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int i = lane; i < 864; i += WAVE) {
+        const float v = lp[i];
+        ac[0] = fmaf(v, v, ac[0]);
+#pragma unroll
+        for (int k = 1; k <= 4; ++k)
+          if (i >= k) ac[k] = fmaf(v, lp[i - k], ac[k]);
+      }
+#pragma unroll
+      for (int k = 0; k <= 4; ++k) ac[k] = wave_sum(ac[k]);
+      ac[0] *= 1.0001f;
+#pragma unroll
+      for (int k = 1; k <= 4; ++k) ac[k] -= ac[k] * (.008f * k) * (.008f * k);
+      float lpc[4] = {0.f, 0.f, 0.f, 0.f};
+      float error = ac[0];
+      if (ac[0] != 0.f) {
+        bool done = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (!done) {
+            float rr = 0.f;
+#pragma unroll
+            for (int j = 0; j < i; ++j) rr += lpc[j] * ac[i - j];
+            rr += ac[i + 1];
+            const float r = -rr / error;
+            lpc[i] = r;
+#pragma unroll
+            for (int j = 0; j < (i + 1) >> 1; ++j) {
+              const float t1 = lpc[j], t2 = lpc[i - 1 - j];
+              lpc[j] = t1 + r * t2;
+              lpc[i - 1 - j] = t2 + r * t1;
+            }
+            error = error - r * r * error;
+            if (error < .001f * ac[0]) done = true;
+          }
+        }
+      }
+      float tmp = 1.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        tmp = .9f * tmp;
+        lpc[i] = lpc[i] * tmp;
+      }
+      lpc2[0] = lpc[0] + .8f;
+      lpc2[1] = lpc[1] + .8f * lpc[0];
+      lpc2[2] = lpc[2] + .8f * lpc[1];
+      lpc2[3] = lpc[3] + .8f * lpc[2];
+      lpc2[4] = .8f * lpc[3];
+    }
+    {
+      // 5-tap FIR in place: each lane filters 14 consecutive samples from registers
+      const int base = lane * 14;
+      float w[19];
+#pragma unroll
+      for (int q = 0; q < 19; ++q) {
+        const int idx = base - 5 + q;
+        w[q] = (idx >= 0 && idx < 864) ? lp[idx] : 0.f;
+      }
+      float y[14];
+#pragma unroll
+      for (int q = 0; q < 14; ++q) {
+        float sum = w[q + 5];
+        sum = fmaf(lpc2[0], w[q + 4], sum);
+        sum = fmaf(lpc2[1], w[q + 3], sum);
+        sum = fmaf(lpc2[2], w[q + 2], sum);
+        sum = fmaf(lpc2[3], w[q + 1], sum);
+        sum = fmaf(lpc2[4], w[q], sum);
+        y[q] = sum;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 14; ++q)
+        if (base + q < 864) lp[base + q] = y[q];
+      __syncthreads();
+    }
+
+    // ---- 3. pitch_search: 4x-decimated coarse search over 147 lags ----
+    float* x4 = L.S;        // 240
+    float* y4 = L.S + 240;  // 387
+    for (int j = lane; j < 240; j += WAVE) x4[j] = lp[384 + 2 * j];
+    for (int j = lane; j < 387; j += WAVE) y4[j] = lp[2 * j];
+    __syncthreads();
+    int best0, best1;
+    {
+      float xc[3] = {0.f, 0.f, 0.f};
+      {
+        const float4* xv4 = reinterpret_cast<const float4*>(x4);
+        const float* yp0 = y4 + lane;
+        const float* yp1 = y4 + min(lane + WAVE, 146);
+        const float* yp2 = y4 + min(lane + 2 * WAVE, 146);
+#pragma unroll 2
+        for (int j4 = 0; j4 < 60; ++j4) {
+          const float4 xv = xv4[j4];
+          const int j = 4 * j4;
+          xc[0] = fmaf(xv.x, yp0[j], xc[0]);
+          xc[1] = fmaf(xv.x, yp1[j], xc[1]);
+          xc[2] = fmaf(xv.x, yp2[j], xc[2]);
+          xc[0] = fmaf(xv.y, yp0[j + 1], xc[0]);
+          xc[1] = fmaf(xv.y, yp1[j + 1], xc[1]);
+          xc[2] = fmaf(xv.y, yp2[j + 1], xc[2]);
+          xc[0] = fmaf(xv.z, yp0[j + 2], xc[0]);
+          xc[1] = fmaf(xv.z, yp1[j + 2], xc[1]);
+          xc[2] = fmaf(xv.z, yp2[j + 2], xc[2]);
+          xc[0] = fmaf(xv.w, yp0[j + 3], xc[0]);
+          xc[1] = fmaf(xv.w, yp1[j + 3], xc[1]);
+          xc[2] = fmaf(xv.w, yp2[j + 3], xc[2]);
+        }
+      }
+      // running energy Syy of find_best_pitch, captured at this lane's lags
+      float part = 0.f;
+      for (int j = lane; j < 240; j += WAVE) part = fmaf(y4[j], y4[j], part);
+      float Syy = 1.f + wave_sum(part);
+      float syy[3] = {1.f, 1.f, 1.f};
+      for (int i = 0; i < 147; ++i) {
+        if ((i & 63) == lane) {
+          if ((i >> 6) == 0) syy[0] = Syy;
+          else if ((i >> 6) == 1) syy[1] = Syy;
+          else syy[2] = Syy;
+        }
+        const float ya = y4[i + 240], yb = y4[i];
+        Syy += ya * ya - yb * yb;
+        Syy = fmaxf(1.f, Syy);
+      }
+      // this lane's best two candidates, in lag order
+      Cand c0 = {-1.f, 0.f, 1 << 20}, c1 = {-1.f, 0.f, 1 << 20};
+      int nvalid = 0;
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) {
+        const int lag = lane + WAVE * rr;
+        if (lag < 147 && xc[rr] > 0.f) {
+          const float x16 = xc[rr] * 1e-12f;
+          const Cand c = {x16 * x16, syy[rr], lag};
+          ++nvalid;
+          if (cand_better(c, c0)) { c1 = c0; c0 = c; }
+          else if (cand_better(c, c1)) c1 = c;
+        }
+      }
+      int total_valid = nvalid;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) total_valid += __shfl_xor(total_valid, off, WAVE);
+      const Cand w0 = wave_best(c0);
+      // second best: the winner's lane offers its runner-up
+      const Cand mine = (c0.idx == w0.idx) ? c1 : c0;
+      const Cand w1 = wave_best(mine);
+      if (total_valid == 0) { best0 = 0; best1 = 1; }
+      else if (total_valid == 1) { best0 = w0.idx; best1 = 0; }
+      else { best0 = w0.idx; best1 = w1.idx; }
+    }
+    __syncthreads();
+
+    // ---- 4. fine search at half rate around the two coarse candidates ----
+    float* fine = L.S;  // 294 (+2 guard) correlation values, zero where not evaluated
+    for (int i = lane; i < 296; i += WAVE) fine[i] = 0.f;
+    __syncthreads();
+    int pitch_index;
+    {
+      const int ca = 2 * min(best0, best1), cb = 2 * max(best0, best1);
+      Cand bestc = {-1.f, 0.f, 0};
+      bool any = false;
+      for (int pass = 0; pass < 2; ++pass) {
+        const int cen = pass == 0 ? ca : cb;
+        for (int d = -2; d <= 2; ++d) {
+          const int i = cen + d;
+          if (i < 0 || i >= 294) continue;
+          if (pass == 1 && abs(i - ca) <= 2) continue;
+          float sxy = 0.f, syy = 0.f;
+          for (int j = lane; j < 480; j += WAVE) {
+            const float yv = lp[i + j];
+            sxy = fmaf(lp[384 + j], yv, sxy);
+            syy = fmaf(yv, yv, syy);
+          }
+          sxy = wave_sum(sxy);
+          syy = fmaxf(1.f, 1.f + wave_sum(syy));
+          const float xv = fmaxf(-1.f, sxy);
+          if (lane == 0) fine[i] = xv;
+          if (xv > 0.f) {
+            const float x16 = xv * 1e-12f;
+            const Cand c = {x16 * x16, syy, i};
+            if (!any || cand_better(c, bestc)) { bestc = c; any = true; }
+          }
+        }
+      }
+      __syncthreads();
+      const int bp = any ? bestc.idx : 0;
+      int offset = 0;
+      if (bp > 0 && bp < 293) {
+        const float fa = fine[bp - 1], fb = fine[bp], fc = fine[bp + 1];
+        if ((fc - fa) > .7f * (fb - fa)) offset = 1;
+        else if ((fa - fc) > .7f * (fb - fc)) offset = -1;
+      }
+      pitch_index = 768 - (2 * bp - offset);
+    }
+    __syncthreads();
+    if (a.dbg && t == a.T - 1) {
+      float* D = a.dbg + (long)b * RN_DBG_FLOATS;
+      for (int i = lane; i < 962; i += WAVE) D[0 + i] = Xf[i];
+      if (lane < RN_NB) D[962 + lane] = L.Ex[lane];
+      for (int i = lane; i < 864; i += WAVE) D[984 + i] = lp[i];
+      if (lane == 0) D[1848] = (float)pitch_index;
+      for (int i = lane; i < 480; i += WAVE) D[3824 + i] = xw[480 + i];
+    }
+
+    // ---- 5. remove_doubling at half rate (maxperiod 384, minperiod 30, N 480) ----
+    float pitch_gain;
+    {
+      const float* x = lp + 384;
+      int T0 = pitch_index / 2;
+      const int prev_period = last_period / 2;
+      if (T0 >= 384) T0 = 383;
+      int T = T0;
+      float xx = 0.f, xy = 0.f;
+      for (int j = lane; j < 480; j += WAVE) {
+        const float v = x[j];
+        xx = fmaf(v, v, xx);
+        xy = fmaf(v, x[j - T0], xy);
+      }
+      xx = wave_sum(xx);
+      xy = wave_sum(xy);
+      // yy_lookup[m] = max(0, xx + sum_{q<=m} (x[-q]^2 - x[480-q]^2)) via a wave prefix sum
+      float* yyl = L.S + 296;  // 385 entries
+      {
+        float loc[6];
+        float run = 0.f;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          const int m = 6 * lane + 1 + q;
+          const float u = x[-m], v = x[480 - m];
+          run += u * u - v * v;
+          loc[q] = run;
+        }
+        float incl = run;
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+          const float o = __shfl_up(incl, off, WAVE);
+          if (lane >= off) incl += o;
+        }
+        const float excl = incl - run;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) yyl[6 * lane + 1 + q] = fmaxf(0.f, xx + (excl + loc[q]));
+        if (lane == 0) yyl[0] = xx;
+      }
+      __syncthreads();
+      float yy = yyl[T0];
+      float best_xy = xy, best_yy = yy;
+      const float g0 = xy / sqrtf(1.f + xx * yy);
+      float g = g0;
+      for (int k = 2; k <= 15; ++k) {
+        const int T1 = (2 * T0 + k) / (2 * k);
+        if (T1 < 30) break;
+        int T1b;
+        if (k == 2) T1b = (T1 + T0 > 384) ? T0 : T0 + T1;
+        else T1b = (2 * c_second_check[k] * T0 + k) / (2 * k);
+        float s1 = 0.f, s2 = 0.f;
+        for (int j = lane; j < 480; j += WAVE) {
+          const float v = x[j];
+          s1 = fmaf(v, x[j - T1], s1);
+          s2 = fmaf(v, x[j - T1b], s2);
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        const float xyk = .5f * (s1 + s2);
+        const float yyk = .5f * (yyl[T1] + yyl[T1b]);
+        const float g1 = xyk / sqrtf(1.f + xx * yyk);
+        float cont;
+        if (abs(T1 - prev_period) <= 1) cont = last_gain;
+        else if (abs(T1 - prev_period) <= 2 && 5 * k * k < T0) cont = .5f * last_gain;
+        else cont = 0.f;
+        float thresh = fmaxf(.3f, .7f * g0 - cont);
+        if (T1 < 90) thresh = fmaxf(.4f, .85f * g0 - cont);
+        else if (T1 < 60) thresh = fmaxf(.5f, .9f * g0 - cont);
+        if (g1 > thresh) { best_xy = xyk; best_yy = yyk; T = T1; g = g1; }
+      }
+      best_xy = fmaxf(0.f, best_xy);
+      float pg = (best_yy <= best_xy) ? 1.f : best_xy / (best_yy + 1.f);
+      float xc3[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float s = 0.f;
+        const int lag = T + k - 1;
+        for (int j = lane; j < 480; j += WAVE) s = fmaf(x[j], x[j - lag], s);
+        xc3[k] = wave_sum(s);
+      }
+      int offset = 0;
+      if ((xc3[2] - xc3[0]) > .7f * (xc3[1] - xc3[0])) offset = 1;
+      else if ((xc3[0] - xc3[2]) > .7f * (xc3[1] - xc3[2])) offset = -1;
+      if (pg > g) pg = g;
+      pitch_index = 2 * T + offset;
+      if (pitch_index < 60) pitch_index = 60;
+      pitch_gain = pg;
+      last_period = pitch_index;
+      last_gain = pg;
+    }
+    __syncthreads();
+
+    // ---- 6. pitch frame: window, FFT, band energy / correlation ----
+    {
+      const float* pp = pb + (768 - pitch_index);
+      for (int n = lane; n < 480; n += WAVE) {
+        const int i0 = 2 * n, i1 = 2 * n + 1;
+        const float w0 = i0 < 480 ? hw[i0] : hw[959 - i0];
+        const float w1 = i1 < 480 ? hw[i1] : hw[959 - i1];
+        L.P[n] = make_float2(pp[i0] * w0, pp[i1] * w1);
+      }
+    }
+    __syncthreads();
+    fft480(L.P, w960, lane);
+    real_fwd_post(L.P, w960, lane);
+    band_sums<false>(L.P, nullptr, L.S, L.Ep, lane);
+    band_sums<true>(L.X, L.P, L.S, L.Exp, lane);
+
+    // ---- 7. features (Appendix A.3 step 5) ----
+    if (lane < RN_NB) {
+      L.Exp[lane] = L.Exp[lane] / sqrtf(.001f + L.Ex[lane] * L.Ep[lane]);
+      L.Ly[lane] = log10f(1e-2f + L.Ex[lane]);
+    }
+    __syncthreads();
+    const float dct_norm = 0.30151134457776363f;  // sqrt(2/22)
+    if (lane < 6) {
+      float sum = 0.f;
+      for (int j = 0; j < RN_NB; ++j) sum = fmaf(L.Exp[j], tab->dct[j * RN_NB + lane], sum);
+      float v = sum * dct_norm;
+      if (lane == 0) v -= 1.3f;
+      if (lane == 1) v -= 0.9f;
+      L.feat[34 + lane] = v;
+    }
+    if (lane == 6) L.feat[40] = .01f * (float)(pitch_index - 300);
+    float E = 0.f;
+    {
+      float logMax = -2.f, follow = -2.f;
+      for (int i = 0; i < RN_NB; ++i) {
+        float ly = L.Ly[i];
+        ly = fmaxf(logMax - 7.f, fmaxf(follow - 1.5f, ly));
+        logMax = fmaxf(logMax, ly);
+        follow = fmaxf(follow - 1.5f, ly);
+        E += L.Ex[i];
+        if (lane == i) L.tmp22[i] = ly;
+      }
+    }
+    __syncthreads();
+    const bool silence = E < 0.04f;
+    float vad_prob = 0.f;
+    if (silence) {
+      if (lane < RN_NFEAT) L.feat[lane] = 0.f;
+      if (lane < RN_NB) L.g[lane] = 0.f;
+      __syncthreads();
+    } else {
+      if (lane < RN_NB) {
+        float sum = 0.f;
+        for (int j = 0; j < RN_NB; ++j) sum = fmaf(L.tmp22[j], tab->dct[j * RN_NB + lane], sum);
+        float v = sum * dct_norm;
+        if (lane == 0) v -= 12.f;
+        if (lane == 1) v -= 4.f;
+        L.feat[lane] = v;
+        L.ceps[memid * RN_NB + lane] = v;
+      }
+      __syncthreads();
+      {
+        const int m1 = (memid < 1) ? 8 + memid - 1 : memid - 1;
+        const int m2 = (memid < 2) ? 8 + memid - 2 : memid - 2;
+        if (lane < 6) {
+          const float c0 = L.ceps[memid * RN_NB + lane];
+          const float c1 = L.ceps[m1 * RN_NB + lane];
+          const float c2 = L.ceps[m2 * RN_NB + lane];
+          L.feat[lane] = c0 + c1 + c2;
+          L.feat[RN_NB + lane] = c0 - c2;
+          L.feat[RN_NB + 6 + lane] = c0 - 2.f * c1 + c2;
+        }
+        memid = (memid + 1 == 8) ? 0 : memid + 1;
+      }
+      {
+        // spectral variability: lane = 8*i + j holds ||ceps_i - ceps_j||^2
+        const int ci = lane >> 3, cj = lane & 7;
+        float dist = 0.f;
+        for (int k = 0; k < RN_NB; ++k) {
+          const float d = L.ceps[ci * RN_NB + k] - L.ceps[cj * RN_NB + k];
+          dist = fmaf(d, d, dist);
+        }
+        float md = (ci == cj) ? 1e15f : dist;
+        md = fminf(md, __shfl_xor(md, 1, WAVE));
+        md = fminf(md, __shfl_xor(md, 2, WAVE));
+        md = fminf(md, __shfl_xor(md, 4, WAVE));
+        float sv = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sv += __shfl(md, 8 * i, WAVE);
+        if (lane == 0) L.feat[41] = sv / 8.f - 2.1f;
+      }
+      __syncthreads();
+
+      // ---- 8. RNN ----
+      const float S = 1.f / 256.f;
+      if (lane < 24) {
+        float acc = wpf[RnPack::ID_B + lane];
+        acc = dot_i8(wp + RnPack::ID_W, 24, lane, L.feat, RnPack::k4(42), acc);
+        L.dense[lane] = tansig_approx(S * acc, tansig);
+      }
+      __syncthreads();
+      gru_layer<24, 24>(wp + RnPack::VG_W, wp + RnPack::VG_R, wpf + RnPack::VG_B, L.dense,
+                        L.rnn_state, L.pre, L.zbuf, L.hr, tansig, lane);
+      if (lane == 0) {
+        float acc = wpf[RnPack::VO_B];
+        acc = dot_i8(wp + RnPack::VO_W, 1, 0, L.rnn_state, RnPack::k4(24), acc);
+        L.tmp22[23] = sigmoid_approx(S * acc, tansig);
+      }
+      for (int i = lane; i < 90; i += WAVE)
+        L.gru_in[i] = i < 24 ? L.dense[i] : (i < 48 ? L.rnn_state[i - 24] : L.feat[i - 48]);
+      if (lane < 2) L.gru_in[90 + lane] = 0.f;
+      __syncthreads();
+      vad_prob = L.tmp22[23];
+      gru_layer<90, 48>(wp + RnPack::NG_W, wp + RnPack::NG_R, wpf + RnPack::NG_B, L.gru_in,
+                        L.rnn_state + 24, L.pre, L.zbuf, L.hr, tansig, lane);
+      for (int i = lane; i < 114; i += WAVE)
+        L.gru_in[i] = i < 72 ? L.rnn_state[i] : L.feat[i - 72];
+      if (lane < 2) L.gru_in[114 + lane] = 0.f;
+      __syncthreads();
+      gru_layer<114, 96>(wp + RnPack::DG_W, wp + RnPack::DG_R, wpf + RnPack::DG_B, L.gru_in,
+                         L.rnn_state + 72, L.pre, L.zbuf, L.hr, tansig, lane);
+      if (lane < RN_NB) {
+        float acc = wpf[RnPack::DO_B + lane];
+        acc = dot_i8(wp + RnPack::DO_W, RN_NB, lane, L.rnn_state + 72, RnPack::k4(96), acc);
+        L.g[lane] = sigmoid_approx(S * acc, tansig);
+      }
+      __syncthreads();
+
+      // ---- 9. pitch_filter + gain application (Appendix A.3 step 7) ----
+      if (lane < RN_NB) {
+        const float ex = L.Exp[lane], gg = L.g[lane];
+        float r;
+        if (ex > gg) r = 1.f;
+        else r = (ex * ex) * (1.f - gg * gg) / (.001f + (gg * gg) * (1.f - ex * ex));
+        r = sqrtf(fminf(1.f, fmaxf(0.f, r)));
+        r *= sqrtf(L.Ex[lane] / (1e-8f + L.Ep[lane]));
+        L.r[lane] = r;
+      }
+      if (lane == RN_NB) L.r[RN_NB] = 0.f;
+      __syncthreads();
+      for (int i = lane; i < RN_NFREQ; i += WAVE) {
+        const float rf = interp_gain(L.r, i);
+        float2 x = L.X[i];
+        const float2 p = L.P[i];
+        x.x = fmaf(rf, p.x, x.x);
+        x.y = fmaf(rf, p.y, x.y);
+        L.X[i] = x;
+      }
+      __syncthreads();
+      band_sums<false>(L.X, nullptr, L.S, L.tmp22, lane);  // newE
+      if (lane < RN_NB) {
+        L.r[lane] = sqrtf(L.Ex[lane] / (1e-8f + L.tmp22[lane]));  // norm
+        const float gg = fmaxf(L.g[lane], .6f * L.lastg[lane]);
+        L.g[lane] = gg;
+        L.lastg[lane] = gg;
+      }
+      if (lane == RN_NB) L.g[RN_NB] = 0.f;
+      __syncthreads();
+      for (int i = lane; i < RN_NFREQ; i += WAVE) {
+        const float nf = interp_gain(L.r, i);
+        const float gf = interp_gain(L.g, i);
+        float2 x = L.X[i];
+        x.x *= nf; x.y *= nf;
+        x.x *= gf; x.y *= gf;
+        L.X[i] = x;
+      }
+      __syncthreads();
+    }
+
+    // ---- taps / debug ----
+    if (a.taps) {
+      float* tp = a.taps + ((long)t * a.B + b) * RN_TAPS;
+      if (lane < RN_NFEAT) tp[lane] = L.feat[lane];
+      if (lane < RN_NB) tp[42 + lane] = L.g[lane];
+      if (lane == 0) {
+        tp[64] = (float)pitch_index;
+        tp[65] = pitch_gain;
+        tp[66] = vad_prob;
+        tp[67] = silence ? 1.f : 0.f;
+        tp[68] = tp[69] = tp[70] = tp[71] = 0.f;
+      }
+    }
+    if (a.vad && lane == 0) a.vad[(long)t * a.B + b] = vad_prob;
+    if (a.dbg && t == a.T - 1) {
+      float* D = a.dbg + (long)b * RN_DBG_FLOATS;
+      const float* Pf = reinterpret_cast<const float*>(L.P);
+      for (int i = lane; i < 962; i += WAVE) D[1856 + i] = Pf[i];
+      if (lane < RN_NB) { D[2818 + lane] = L.Ep[lane]; D[2840 + lane] = L.Exp[lane]; }
+      for (int i = lane; i < 962; i += WAVE) D[2862 + i] = Xf[i];
+    }
+    __syncthreads();
+
+    // ---- 10. frame_synthesis: inverse FFT, window, overlap-add ----
+    real_inv_pre(L.X, w960, lane);
+    fft480(L.X, w960, lane);
+    {
+      float* o = a.out + (long)t * a.stride_t + (long)b * a.stride_b;
+      for (int n = lane; n < 240; n += WAVE) {
+        const float2 z = L.X[n];
+        const int i0 = 2 * n, i1 = 2 * n + 1;
+        float2 ov;
+        ov.x = fmaf(z.x, hw[i0], L.synth[i0]);
+        ov.y = fmaf(-z.y, hw[i1], L.synth[i1]);
+        *reinterpret_cast<float2*>(o + i0) = ov;
+      }
+      __syncthreads();
+      for (int n = lane; n < 240; n += WAVE) {
+        const float2 z = L.X[240 + n];
+        const int i0 = 2 * n, i1 = 2 * n + 1;
+        L.synth[i0] = z.x * hw[479 - i0];
+        L.synth[i1] = -z.y * hw[479 - i1];
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- store per-stream state ----
+  for (int i = lane; i < 480; i += WAVE) a.synth[(long)b * 480 + i] = L.synth[i];
+  for (int i = lane; i < 176; i += WAVE) a.ceps[(long)b * 176 + i] = L.ceps[i];
+  for (int i = lane; i < 168; i += WAVE) a.rnn[(long)b * 168 + i] = L.rnn_state[i];
+  if (lane < RN_NB) a.lastg[(long)b * RN_NB + lane] = L.lastg[lane];
+  if (lane == 0) {
+    a.memid[b] = memid;
+    a.last_period[b] = last_period;
+    a.last_gain[b] = last_gain;
+  }
+}
+
+// =============================================================================================
+// high-pass: one lane per stream, strictly sequential (Appendix A.3 step 1, double products)
+// =============================================================================================
+__global__ __launch_bounds__(WAVE) void rn_highpass_kernel(RnArgs a) {
+  const int b = blockIdx.x * WAVE + threadIdx.x;
+  if (b >= a.B) return;
+  const double a0 = (double)-1.99599f, a1 = (double)0.99600f;
+  const double b0 = (double)-2.f, b1 = (double)1.f;
+  float m0 = a.hp_mem[2 * b], m1 = a.hp_mem[2 * b + 1];
+  float* dst = a.xhp + (long)b * a.xhp_stride + RN_HIST;
+  for (int t = 0; t < a.T; ++t) {
+    const float4* src = reinterpret_cast<const float4*>(a.in + (long)t * a.stride_t + (long)b * a.stride_b);
+    float4* d4 = reinterpret_cast<float4*>(dst + (long)t * RN_FRAME);
+    for (int i4 = 0; i4 < RN_FRAME / 4; ++i4) {
+      const float4 xv = src[i4];
+      const float xin[4] = {xv.x, xv.y, xv.z, xv.w};
+      float yo[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float xi = xin[q];
+        const float yi = xi + m0;
+        const double dx = (double)xi, dy = (double)yi;
+        m0 = (float)__dadd_rn((double)m1, __dsub_rn(__dmul_rn(b0, dx), __dmul_rn(a0, dy)));
+        m1 = (float)__dsub_rn(__dmul_rn(b1, dx), __dmul_rn(a1, dy));
+        yo[q] = yi;
+      }
+      d4[i4] = make_float4(yo[0], yo[1], yo[2], yo[3]);
+    }
+  }
+  a.hp_mem[2 * b] = m0;
+  a.hp_mem[2 * b + 1] = m1;
+}
+
+// keep the last RN_HIST high-passed samples of every stream at the front of its xhp row
+__global__ __launch_bounds__(256) void rn_roll_history_kernel(RnArgs a) {
+  const int b = blockIdx.x;
+  float* row = a.xhp + (long)b * a.xhp_stride;
+  const long src = (long)a.T * RN_FRAME;
+  float v[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int i = threadIdx.x + 256 * q;
+    v[q] = i < RN_HIST ? row[src + i] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int i = threadIdx.x + 256 * q;
+    if (i < RN_HIST) row[i] = v[q];
+  }
+}
+
+}  // namespace
+
+hipError_t rn_launch_highpass(const RnArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(rn_highpass_kernel, dim3((a.B + WAVE - 1) / WAVE), dim3(WAVE), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t rn_launch_frames(const RnArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(rn_frame_kernel, dim3(a.B), dim3(WAVE), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t rn_launch_roll_history(const RnArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(rn_roll_history_kernel, dim3(a.B), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace crispy

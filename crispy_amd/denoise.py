@@ -1,0 +1,224 @@
+"""Host-side mirror of the reference's RNNoise surface, backed by the HIP library.
+
+* `DenoiseState`        -- nnnoiseless::DenoiseState for B streams at once
+                           (`new`: src-tauri/src/audio.rs:229, `process_frame`: audio.rs:268).
+* `RnnNoiseProcessor`   -- the adapter of audio.rs:202-315 (`push_sample`, x32768, clamp, volume,
+                           first-frame drop, optional input LinearResampler), batched: one
+                           processor object drives B streams that are pushed in lock step.
+* `LinearResampler`     -- audio.rs:73-134.
+
+All arithmetic of `process_frame` runs in libcrispy_hip.so on the GPU; nothing here falls back
+to a CPU implementation."""
+from __future__ import annotations
+
+import ctypes as C
+from collections import deque
+from typing import Optional
+
+import numpy as np
+
+from . import _native as N
+
+FRAME_SIZE = N.RN_FRAME  # nnnoiseless::FRAME_SIZE
+
+
+class DenoiseState:
+    """B independent `DenoiseState`s living in HBM.
+
+    `process_frame(out, inp)` keeps the reference's argument order and returns the VAD
+    probabilities; arrays are [B, 480] (or [480] when B == 1), f32 in int16 range."""
+
+    def __init__(self, weights: np.ndarray, n_streams: int = 1, device: int = 0):
+        w = np.ascontiguousarray(weights, dtype=np.int8)
+        self._h = C.c_void_p()
+        self.n_streams = int(n_streams)
+        self.device = int(device)
+        N.check(N.lib().crispy_rn_create(w.ctypes.data_as(C.c_void_p), w.size, self.n_streams,
+                                         self.device, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            N.lib().crispy_rn_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- reference-shaped single tick ------------------------------------------------------
+    def process_frame(self, output: np.ndarray, input: np.ndarray):
+        x = np.ascontiguousarray(input, dtype=np.float32)
+        if x.size != self.n_streams * FRAME_SIZE:
+            raise ValueError(f"process_frame: expected {self.n_streams}x{FRAME_SIZE} samples, got {x.size}")
+        if output.dtype != np.float32 or not output.flags["C_CONTIGUOUS"] or output.size != x.size:
+            raise ValueError("process_frame: output must be a contiguous float32 array of the input's size")
+        vad = np.empty(self.n_streams, dtype=np.float32)
+        N.check(N.lib().crispy_rn_process(self._h, x.ctypes.data, output.ctypes.data, vad.ctypes.data,
+                                          1, N.LAYOUT_TBF))
+        return float(vad[0]) if self.n_streams == 1 else vad
+
+    # -- batched host arrays ---------------------------------------------------------------
+    def process(self, x: np.ndarray, layout: str = "tbf"):
+        """x: [T, B, 480] ('tbf') or [B, T, 480] ('btf') -> (out like x, vad [T, B])."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        lay = N.LAYOUT_TBF if layout == "tbf" else N.LAYOUT_BTF
+        if x.ndim != 3 or x.shape[2] != FRAME_SIZE:
+            raise ValueError("process: x must be [T,B,480] or [B,T,480]")
+        T = x.shape[0] if layout == "tbf" else x.shape[1]
+        Bn = x.shape[1] if layout == "tbf" else x.shape[0]
+        if Bn != self.n_streams:
+            raise ValueError(f"process: {Bn} streams given, handle has {self.n_streams}")
+        out = np.empty_like(x)
+        vad = np.empty((T, Bn), dtype=np.float32)
+        N.check(N.lib().crispy_rn_process(self._h, x.ctypes.data, out.ctypes.data, vad.ctypes.data, T, lay))
+        return out, vad
+
+    # -- device-resident tensors (torch is only the allocator here) --------------------------
+    def process_device(self, d_in: int, d_out: int, n_frames: int, d_vad: int = 0, d_taps: int = 0,
+                       layout: str = "tbf", stream: int = 0):
+        lay = N.LAYOUT_TBF if layout == "tbf" else N.LAYOUT_BTF
+        N.check(N.lib().crispy_rn_process_device(self._h, d_in, d_out, d_vad or None, d_taps or None,
+                                                 int(n_frames), lay, stream or None))
+
+    def synchronize(self):
+        N.check(N.lib().crispy_rn_synchronize(self._h))
+
+    def reset(self, stream: int = -1):
+        N.check(N.lib().crispy_rn_reset(self._h, int(stream)))
+
+    def set_timing(self, enable: bool):
+        N.check(N.lib().crispy_rn_set_timing(self._h, int(enable)))
+
+    def last_kernel_ms(self):
+        a, b = C.c_float(), C.c_float()
+        N.check(N.lib().crispy_rn_last_kernel_ms(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def debug_capture(self, enable: bool):
+        N.check(N.lib().crispy_rn_debug_capture(self._h, int(enable)))
+
+    def debug_read(self, stream: int) -> np.ndarray:
+        d = np.empty(N.RN_DBG_FLOATS, dtype=np.float32)
+        N.check(N.lib().crispy_rn_debug_read(self._h, int(stream), d.ctypes.data_as(C.POINTER(C.c_float)), d.size))
+        return d
+
+
+class LinearResampler:
+    """Streaming 2-tap linear interpolation resampler (audio.rs:73-134)."""
+
+    def __init__(self, input_rate: float, output_rate: float):
+        self.input_rate = np.float32(input_rate)
+        self.output_rate = np.float32(output_rate)
+        self.last_sample = np.float32(0.0)
+        self.has_last = False
+        self.input_pos = 0.0
+        self.next_output_pos = 0.0
+
+    def rates(self):
+        return float(self.input_rate), float(self.output_rate)
+
+    def set_rates(self, input_rate: float, output_rate: float):
+        self.__init__(input_rate, output_rate)
+
+    def process_sample(self, sample, emit):
+        sample = np.float32(sample)
+        if abs(self.input_rate - self.output_rate) < 1.0:
+            emit(sample)
+            return
+        if not self.has_last:
+            self.last_sample = sample
+            self.has_last = True
+            self.input_pos = 0.0
+            self.next_output_pos = 0.0
+            return
+        self.input_pos += 1.0
+        step = float(np.float32(self.input_rate / self.output_rate))
+        while self.next_output_pos <= self.input_pos:
+            t = np.float32(self.next_output_pos - (self.input_pos - 1.0))
+            t = np.float32(min(max(t, np.float32(0.0)), np.float32(1.0)))
+            emit(np.float32(self.last_sample + (sample - self.last_sample) * t))
+            self.next_output_pos += step
+        self.last_sample = sample
+
+
+class RnnNoiseProcessor:
+    """audio.rs:202-315 for B lock-stepped streams: `push_sample(samples[B])` returns None or an
+    array [n, B] of denoised samples (n = 480 per completed frame), scaled and clamped exactly
+    as the reference does (x32768 in, /32768 + clamp(-1, 1) * volume out, first frame dropped)."""
+
+    def __init__(self, weights: np.ndarray, input_rate: float, output_rate: float, volume: float,
+                 n_streams: int = 1, device: int = 0):
+        if abs(input_rate - 48000.0) >= 1.0:
+            self.input_rate = 48000.0
+            self.input_resamplers: Optional[list] = [LinearResampler(input_rate, 48000.0) for _ in range(n_streams)]
+        else:
+            self.input_rate = float(input_rate)
+            self.input_resamplers = None
+        self.output_rate = float(output_rate)
+        self.volume = float(min(max(volume, 0.0), 1.0))
+        self.n_streams = n_streams
+        self.first_frame = True
+        self.max_output_len = int(self.input_rate)
+        self.denoise = DenoiseState(weights, n_streams, device)
+        self.input_buf: deque = deque()
+        self.output_buf: deque = deque()
+        self.resample_pos = 0.0
+
+    def set_volume(self, volume: float):
+        self.volume = float(min(max(volume, 0.0), 1.0))
+
+    def produced_rate_hz(self) -> float:
+        return self.input_rate
+
+    def push_sample(self, samples) -> Optional[np.ndarray]:
+        samples = np.atleast_1d(np.asarray(samples, dtype=np.float32))
+        if samples.size != self.n_streams:
+            raise ValueError("push_sample: one sample per stream")
+        rows = []
+        if self.input_resamplers is not None:
+            per_stream = [[] for _ in range(self.n_streams)]
+            for b, rs in enumerate(self.input_resamplers):
+                rs.process_sample(samples[b], per_stream[b].append)
+            for k in range(len(per_stream[0])):  # lock-stepped streams emit equal counts
+                rows.append(np.array([per_stream[b][k] for b in range(self.n_streams)], dtype=np.float32))
+        else:
+            rows.append(samples)
+        acc = []
+        for row in rows:
+            if len(self.input_buf) >= self.max_output_len:
+                self.input_buf.popleft()
+            self.input_buf.append(row)
+            if len(self.input_buf) >= FRAME_SIZE:
+                frame = np.stack([self.input_buf.popleft() for _ in range(FRAME_SIZE)], axis=1)  # [B,480]
+                frame = np.ascontiguousarray(frame * np.float32(32768.0))
+                out = np.empty_like(frame)
+                self.denoise.process_frame(out, frame)
+                out = np.clip(out / np.float32(32768.0), -1.0, 1.0).astype(np.float32) * np.float32(self.volume)
+                if self.first_frame:
+                    self.first_frame = False
+                    continue
+                for i in range(FRAME_SIZE):
+                    if len(self.output_buf) >= self.max_output_len:
+                        self.output_buf.popleft()
+                    self.output_buf.append(out[:, i])
+                acc.append(out.T)
+        if not acc:
+            return None
+        return np.concatenate(acc, axis=0)
+
+    def next_sample(self) -> np.ndarray:
+        zero = np.zeros(self.n_streams, dtype=np.float32)
+        if len(self.output_buf) < 2:
+            return zero
+        step = self.input_rate / self.output_rate
+        while self.resample_pos >= 1.0:
+            self.output_buf.popleft()
+            self.resample_pos -= 1.0
+            if len(self.output_buf) < 2:
+                return zero
+        s0, s1 = self.output_buf[0], self.output_buf[1]
+        frac = np.float32(self.resample_pos)
+        self.resample_pos += step
+        return (s0 + (s1 - s0) * frac).astype(np.float32)

@@ -1,0 +1,122 @@
+/*
+ * crispy_hip.h -- C ABI of libcrispy_hip.so: the MI355X (gfx950) implementation of crispy's
+ * audio compute hot path.  Plain pointers and sizes only; no C++/torch types cross this line.
+ *
+ * Every entry point names the reference interface it replaces (paths are into sleep3r/crispy):
+ *
+ *   RNNoise   nnnoiseless::DenoiseState::{new, process_frame}
+ *               ctor       src-tauri/src/audio.rs:229
+ *               call site  src-tauri/src/audio.rs:268   (480-sample f32 frames, int16 range)
+ *               state reset on model hot-swap          src-tauri/src/audio.rs:942-967
+ *   ASR       transcribe_rs::SpeechModel::transcribe (whisper_cpp::WhisperEngine)
+ *               load       src-tauri/src/managers/transcription.rs:138-141
+ *               call sites src-tauri/src/managers/transcription.rs:183-185, 213-215
+ *
+ * Conventions
+ *   - every function returns CRISPY_OK (0) or a negative crispy_status; nothing throws or
+ *     aborts across the boundary (the reference builds with panic=abort, Cargo.toml:10-20);
+ *     crispy_last_error() returns a thread-local message for the last failure.
+ *   - a handle is not re-entrant: the caller serialises calls on one handle, exactly as the
+ *     reference does with Arc<Mutex<NsState>> (audio.rs:693) / Mutex<Option<engine>>
+ *     (managers/transcription.rs:27).  Different handles may be used from different threads.
+ *   - there is NO CPU fallback: without a gfx950 device every create/load call fails with
+ *     CRISPY_ERR_NO_DEVICE.
+ */
+#ifndef CRISPY_HIP_H
+#define CRISPY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum crispy_status {
+  CRISPY_OK = 0,
+  CRISPY_ERR_INVALID_ARG = -1,
+  CRISPY_ERR_NO_DEVICE = -2,
+  CRISPY_ERR_HIP = -3,
+  CRISPY_ERR_OOM = -4,
+  CRISPY_ERR_BAD_MODEL = -5,
+  CRISPY_ERR_UNSUPPORTED = -6
+} crispy_status;
+
+#define CRISPY_RN_FRAME_SIZE 480      /* nnnoiseless::FRAME_SIZE (audio.rs:4) */
+#define CRISPY_RN_WEIGHT_BYTES 87503  /* SURVEY.md Appendix A.5 */
+#define CRISPY_RN_TAPS 72
+
+/* Sample layouts of the batched frame tensors handed to crispy_rn_process*. */
+typedef enum crispy_rn_layout {
+  CRISPY_RN_LAYOUT_TBF = 0, /* [n_frames][n_streams][480]: one 10 ms tick of every stream is contiguous */
+  CRISPY_RN_LAYOUT_BTF = 1  /* [n_streams][n_frames][480]: one stream's audio is contiguous */
+} crispy_rn_layout;
+
+typedef struct crispy_rn crispy_rn;
+
+/* Message for the most recent failure on the calling thread ("" if none). */
+const char *crispy_last_error(void);
+/* "crispy_hip <version> gfx950" */
+const char *crispy_version(void);
+/* Number of usable gfx950 devices (0 when there is none; never fails). */
+int crispy_device_count(void);
+
+/*
+ * DenoiseState::new() for n_streams independent streams (audio.rs:229).
+ * weights: flat int8 blob of CRISPY_RN_WEIGHT_BYTES bytes, layer order input_dense, vad_gru,
+ * vad_output, noise_gru, denoise_gru, denoise_output; per layer input weights [in][out]
+ * (GRU [in][3N], gates z,r,h), recurrent weights [N][3N], bias.  The blob built into
+ * nnnoiseless is not redistributable from here, so weights are always explicit.
+ * All state starts at zero, as DenoiseState::new() does.
+ */
+int crispy_rn_create(const int8_t *weights, size_t nbytes, int n_streams, int device,
+                     crispy_rn **out);
+void crispy_rn_destroy(crispy_rn *h);
+
+/* Fresh DenoiseState for one stream (stream >= 0) or all of them (stream == -1):
+ * what audio.rs:955-965 does by replacing the processor. */
+int crispy_rn_reset(crispy_rn *h, int stream);
+
+int crispy_rn_n_streams(const crispy_rn *h);
+
+/*
+ * process_frame for every stream, n_frames consecutive frames each (audio.rs:268).
+ * in/out are HOST pointers to n_frames*n_streams*480 floats in `layout`; samples are f32 in
+ * int16 range (the x32768 / /32768, clamp, volume and first-frame drop of audio.rs:261-278 stay
+ * with the caller).  vad (nullable) receives the value process_frame returns,
+ * [n_frames][n_streams].  Copies through a staging buffer; returns when `out` is complete.
+ */
+int crispy_rn_process(crispy_rn *h, const float *in, float *out, float *vad, int n_frames,
+                      crispy_rn_layout layout);
+
+/*
+ * Same, with DEVICE pointers (HBM-resident audio, no PCIe in the call).  Work is enqueued on
+ * hip_stream (a hipStream_t, NULL = the handle's own stream) and the call returns without
+ * waiting.  taps (nullable) receives CRISPY_RN_TAPS floats per frame and stream
+ * [n_frames][n_streams][72]: features[42], gains[22], pitch_index, pitch_gain, vad, silence.
+ */
+int crispy_rn_process_device(crispy_rn *h, const float *d_in, float *d_out, float *d_vad,
+                             float *d_taps, int n_frames, crispy_rn_layout layout,
+                             void *hip_stream);
+
+/* Block until everything enqueued on the handle's own stream has finished. */
+int crispy_rn_synchronize(crispy_rn *h);
+
+/*
+ * Time the frame kernels of the next crispy_rn_process_device call with hipEvents recorded on
+ * the launch stream (bench.py's roofline leg).  After that call and a synchronize,
+ * crispy_rn_last_kernel_ms returns the device time of the dominant kernel (rn_frame_kernel) and
+ * of the whole enqueue (high-pass + frame + history roll) in milliseconds.
+ */
+int crispy_rn_set_timing(crispy_rn *h, int enable);
+int crispy_rn_last_kernel_ms(crispy_rn *h, float *frame_kernel_ms, float *total_ms);
+
+/* Developer aid for parity debugging: copy the per-stage debug capture of stream `stream`
+ * for the LAST frame of the most recent call (layout mirrors oracle RNO_DBG_*). */
+int crispy_rn_debug_capture(crispy_rn *h, int enable);
+int crispy_rn_debug_read(crispy_rn *h, int stream, float *dst, size_t n_floats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRISPY_HIP_H */
