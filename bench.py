@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: batched RNNoise (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path (high-pass -> frame kernel -> history roll, i.e. one
+`crispy_rn_process_device` call) over one batch of synthetic 48 kHz audio that is already
+resident in HBM: `--streams` concurrent streams (default 4096) x `--frames` consecutive 10 ms
+frames (default 100 = 1 s of audio per stream).  Metric: concurrent real-time 48 kHz streams per
+GPU = frames/s / 100, summed over ranks (streams shard with no data-path collective).
+
+The JSON line also carries
+  roofline      HBM roofline of the dominant kernel (rn_frame_kernel): algorithmic bytes per launch
+                (3840 B per stream-frame) / its average duration measured with hipEvents on the
+                launch stream, against the 8 TB/s HBM3E peak.
+  cpu_baseline  the C oracle (CPU restatement of the reference algorithm; the reference's Rust crates
+                cannot be built here) timed on this box's host cores on a bounded sample, rank 0, N=1.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BYTES_PER_STREAM_FRAME = 3840  # 480 f32 in + 480 f32 out
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(n_threads: int, frames_per_thread: int):
+    """Oracle (kind 'port') on host cores: independent streams, one per thread."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+
+    from crispy_amd import synthetic_weights, synth_audio
+    from tests import oracle_lib as O
+
+    # prefer a -march=native build of the same source for the baseline; fall back to the generic one
+    lib_path = None
+    try:
+        out = os.path.join(ROOT, "gpurun_out", "liboracle_native.so")
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.run(["gcc", "-O3", "-march=native", "-fPIC", "-std=c99", "-ffp-contract=off", "-shared",
+                        "-o", out, os.path.join(ROOT, "oracle", "rnnoise_oracle.c"), "-lm"],
+                       check=True, capture_output=True)
+        lib_path = out
+    except Exception:
+        pass
+    if lib_path:
+        import ctypes as C
+        L = C.CDLL(lib_path)
+        f32p = C.POINTER(C.c_float)
+        L.rno_create.restype = C.c_void_p
+        L.rno_create.argtypes = [C.c_void_p, C.c_size_t]
+        L.rno_process_frames.argtypes = [C.c_void_p, f32p, f32p, C.c_int, f32p]
+        L.rno_destroy.argtypes = [C.c_void_p]
+    else:
+        L = O.lib()
+    w = synthetic_weights(0)
+    xs = [np.ascontiguousarray(synth_audio.stream_np(b, frames_per_thread, silent=False) * np.float32(32768.0))
+          for b in range(n_threads)]
+    handles = [L.rno_create(w.ctypes.data, w.size) for _ in range(n_threads)]
+    outs = [np.empty_like(x) for x in xs]
+
+    def run(i):
+        L.rno_process_frames(handles[i], O.fp(outs[i]), O.fp(xs[i]), frames_per_thread, None)
+
+    with ThreadPoolExecutor(n_threads) as ex:
+        list(ex.map(run, range(n_threads)))  # warm
+        t0 = time.perf_counter()
+        list(ex.map(run, range(n_threads)))
+        dt = time.perf_counter() - t0
+    for h in handles:
+        L.rno_destroy(h)
+    fps = n_threads * frames_per_thread / dt
+    return {"value": fps / 100.0, "unit": "concurrent real-time 48 kHz streams", "cores": n_threads,
+            "kind": "port",
+            "sample": f"{n_threads} streams x {frames_per_thread} frames (tone+noise), C oracle "
+                      f"{'-O3 -march=native' if lib_path else '-O2'}, one stream per thread, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=4096, help="streams per GPU")
+    ap.add_argument("--frames", type=int, default=100, help="frames per stream per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from crispy_amd import synthetic_weights, synth_audio
+    from crispy_amd.denoise import DenoiseState
+
+    B, T = args.streams, args.frames
+    weights = synthetic_weights(0)
+    ds = DenoiseState(weights, B, local_rank)   # fails loudly without libcrispy_hip.so / gfx950
+    # streams shard by stream id: rank r owns [r*B, (r+1)*B); no data-path collective
+    d_in = synth_audio.batch_torch(B, T, dev, first_stream=rank * B, seed=0)
+    d_out = torch.empty_like(d_in)
+    torch.cuda.synchronize()
+
+    def step():
+        ds.process_device(d_in.data_ptr(), d_out.data_ptr(), T)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    ds.synchronize()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ds.synchronize()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # dominant-kernel duration, measured live with hipEvents on the launch stream
+    ds.set_timing(True)
+    k_ms = []
+    for _ in range(3):
+        step()
+        ds.synchronize()
+        k_ms.append(ds.last_kernel_ms())
+    ds.set_timing(False)
+    launches = (T + 249) // 250
+    frame_ms = sum(k[0] for k in k_ms) / len(k_ms) / launches
+    total_ms = sum(k[1] for k in k_ms) / len(k_ms)
+    finite = bool(torch.isfinite(d_out).all().item())
+
+    frames_total = world * B * T * args.steps
+    fps = frames_total / dt
+    if rank == 0:
+        alg_bytes = BYTES_PER_STREAM_FRAME * B * min(T, 250)
+        achieved = alg_bytes / (frame_ms * 1e-3) / 1e9
+        line = {
+            "metric": "concurrent real-time 48 kHz streams/GPU (RNNoise)",
+            "value": fps / 100.0,
+            "unit": "concurrent real-time 48 kHz streams (whole job)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Batched RNNoise: {B} concurrent 48 kHz mono streams per GPU x {T} frames per step "
+                                   f"(BASELINE configs[1]), seeded synthetic int8 weights",
+                       "streams_per_gpu": B, "frames_per_step": T, "sharding": f"streams x{world}, no collective",
+                       "frames_per_s": fps, "output_finite": finite},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "rn_frame_kernel", "kernel_ms": frame_ms, "enqueue_ms": total_ms,
+                         "alg_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            ncores = os.cpu_count() or 1
+            nthreads = max(1, min(ncores, 32))
+            line["cpu_baseline"] = cpu_baseline(nthreads, 2500)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

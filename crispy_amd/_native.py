@@ -27,6 +27,8 @@ RN_SYMBOLS = (
 )
 
 
+ALL_SYMBOLS = RN_SYMBOLS
+
 class CrispyError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"crispy_hip error {code}: {msg}")

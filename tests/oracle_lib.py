@@ -15,6 +15,7 @@ _LIB = None
 
 FRAME = 480
 TAPS = 72
+DBG_FLOATS = 4304
 WEIGHT_BYTES = 87503
 
 
@@ -38,6 +39,7 @@ def lib():
         L.rno_process_frame.argtypes = [C.c_void_p, f32p, f32p]
         L.rno_process_frames.argtypes = [C.c_void_p, f32p, f32p, C.c_int, f32p]
         L.rno_last_taps.argtypes = [C.c_void_p, f32p]
+        L.rno_last_debug.argtypes = [C.c_void_p, f32p]
         L.rno_forward_transform.argtypes = [f32p, f32p, f32p]
         L.rno_inverse_transform.argtypes = [f32p, f32p, f32p]
         L.rno_biquad.argtypes = [f32p, f32p, f32p, C.c_int]
@@ -77,9 +79,12 @@ class OracleDenoiseState:
             raise RuntimeError("rno_create failed")
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().rno_destroy(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().rno_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
 
     def reset(self):
         lib().rno_reset(self._h)
@@ -95,6 +100,11 @@ class OracleDenoiseState:
         t = np.empty(TAPS, dtype=np.float32)
         lib().rno_last_taps(self._h, fp(t))
         return t
+
+    def debug(self):
+        d = np.empty(DBG_FLOATS, dtype=np.float32)
+        lib().rno_last_debug(self._h, fp(d))
+        return d
 
     def process(self, x: np.ndarray, with_taps: bool = False):
         """x: [n_frames, 480] -> out [n_frames, 480], vad [n_frames] (, taps [n_frames, 72])."""

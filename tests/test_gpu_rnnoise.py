@@ -1,0 +1,235 @@
+"""GPU parity tests (run on the MI355X box with -m gpu): the HIP path behind the C ABI against the
+CPU oracle on identical seeded inputs, against the committed golden vectors, and through
+size-independent properties at BASELINE size.
+
+Tolerance (BASELINE.json north_star: denoised PCM within 1e-4 relative): per stream,
+max |gpu - oracle| <= 1e-4 * max |oracle|  (+ 1e-3 absolute, samples are in int16 range)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "rnnoise_golden.npz")
+REL = 1e-4
+
+
+def _mk(weights, B):
+    from crispy_amd.denoise import DenoiseState
+    return DenoiseState(weights, B, 0)   # raises if libcrispy_hip.so or the gfx950 device is missing
+
+
+def _assert_pcm_close(out, ref, what=""):
+    peak = np.abs(ref).max()
+    err = np.abs(out - ref).max()
+    assert err <= REL * peak + 1e-3, f"{what}: err {err} vs peak {peak}"
+
+
+def test_native_library_is_the_one_running():
+    from crispy_amd import _native as N
+    assert os.path.exists(N.LIB_PATH)
+    assert N.lib().crispy_device_count() >= 1
+    import subprocess
+    maps = open(f"/proc/{os.getpid()}/maps").read()
+    assert "libcrispy_hip.so" in maps
+
+
+@pytest.mark.parametrize("case", ["seed0", "seed1", "seed2", "silence", "tone440", "whisper_quiet"])
+def test_golden_vectors(case):
+    G = np.load(GOLD)
+    w = G["weights" + case[-1]] if case.startswith("seed") else G["weights0"]
+    x = G[f"{case}/x"]
+    ds = _mk(w, 1)
+    out, vad = ds.process(x[:, None, :])
+    _assert_pcm_close(out[:, 0], G[f"{case}/out"], case)
+    assert np.abs(vad[:, 0] - G[f"{case}/vad"]).max() < 1e-4
+
+
+def test_parity_mixed_batch_with_taps(oracle, weights0):
+    """12 different streams x 60 frames incl. a silent stream and the cfg-1 clip: PCM, VAD, features,
+    gains and pitch against the oracle."""
+    import torch
+    from crispy_amd import synth_audio as SA
+    B, T = 12, 60
+    x = SA.batch_np(B, T) * np.float32(32768.0)
+    x[:, 1] = SA.cfg1_clip(T).reshape(T, 480) * 32768.0
+    ds = _mk(weights0, B)
+    dev = torch.device("cuda:0")
+    d_in = torch.from_numpy(x).to(dev)
+    d_out = torch.empty_like(d_in)
+    d_taps = torch.zeros(T, B, 72, device=dev)
+    d_vad = torch.zeros(T, B, device=dev)
+    torch.cuda.synchronize()
+    ds.process_device(d_in.data_ptr(), d_out.data_ptr(), T, d_vad.data_ptr(), d_taps.data_ptr())
+    ds.synchronize()
+    out, taps, vad = d_out.cpu().numpy(), d_taps.cpu().numpy(), d_vad.cpu().numpy()
+    n_pitch_ok = 0
+    for b in range(B):
+        ro, rv, rt = oracle.OracleDenoiseState(weights0).process(x[:, b], with_taps=True)
+        _assert_pcm_close(out[:, b], ro, f"stream {b}")
+        assert np.abs(vad[:, b] - rv).max() < 1e-4
+        assert np.abs(taps[:, b, 42:64] - rt[:, 42:64]).max() < 1e-4          # gains
+        assert np.abs(taps[:, b, :42] - rt[:, :42]).max() <= 1e-4 * max(1.0, np.abs(rt[:, :42]).max())
+        assert np.array_equal(taps[:, b, 67], rt[:, 67])                      # silence flags
+        n_pitch_ok += int((taps[:, b, 64] == rt[:, 64]).sum())
+    assert n_pitch_ok >= 0.99 * B * T
+
+
+def test_cfg1_single_clip_through_the_adapter(oracle, weights0):
+    """BASELINE cfg 1 (shortened to 3 s): the RnnNoiseProcessor adapter (x32768, clamp, volume,
+    first-frame drop: audio.rs:261-278) over the HIP path equals the same adapter over the oracle."""
+    from crispy_amd import synth_audio as SA
+    from crispy_amd.denoise import RnnNoiseProcessor
+    T = 300
+    clip = SA.cfg1_clip(T)
+    # batched host call = what push_sample does frame by frame
+    ds = _mk(weights0, 1)
+    out, _ = ds.process((clip * np.float32(32768.0)).reshape(T, 1, 480))
+    got = (np.clip(out[:, 0] / np.float32(32768.0), -1, 1) * np.float32(0.8))[1:]
+    ro, _ = oracle.OracleDenoiseState(weights0).process(clip * np.float32(32768.0))
+    want = (np.clip(ro / np.float32(32768.0), -1, 1) * np.float32(0.8))[1:]
+    assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max() + 1e-7
+    # and literally sample by sample for the first 5 frames
+    proc = RnnNoiseProcessor(weights0, 48000.0, 48000.0, 0.8, 1, 0)
+    chunks = []
+    for s in clip[:480 * 5]:
+        r = proc.push_sample([s])
+        if r is not None:
+            chunks.append(r[:, 0])
+    got2 = np.concatenate(chunks)
+    assert got2.shape == (480 * 4,)     # first frame dropped
+    assert np.abs(got2 - want[:4].ravel()).max() <= 1e-4 * np.abs(want).max() + 1e-7
+
+
+def test_chunked_calls_equal_one_call(weights0):
+    """State carried across calls (history roll, GRU/cepstral state): ragged call sizes,
+    including ones shorter than the 4-frame history and ones that cross the internal 250-frame chunk."""
+    from crispy_amd import synth_audio as SA
+    B, T = 5, 300
+    x = SA.batch_np(B, T) * np.float32(32768.0)
+    a, va = _mk(weights0, B).process(x)
+    ds = _mk(weights0, B)
+    outs, vads, t0 = [], [], 0
+    for n in (1, 2, 3, 1, 7, 250, 36):
+        o, v = ds.process(np.ascontiguousarray(x[t0:t0 + n]))
+        outs.append(o); vads.append(v); t0 += n
+    assert t0 == T
+    assert np.array_equal(np.concatenate(outs), a) and np.array_equal(np.concatenate(vads), va)
+
+
+def test_layouts_and_host_device_entry_points_agree(weights0):
+    import torch
+    from crispy_amd import synth_audio as SA
+    B, T = 6, 9
+    x = SA.batch_np(B, T) * np.float32(32768.0)
+    a, va = _mk(weights0, B).process(x, "tbf")
+    b, vb = _mk(weights0, B).process(np.ascontiguousarray(x.transpose(1, 0, 2)), "btf")
+    assert np.array_equal(a, b.transpose(1, 0, 2)) and np.array_equal(va, vb)
+    ds = _mk(weights0, B)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.empty_like(d_in)
+    torch.cuda.synchronize()
+    ds.process_device(d_in.data_ptr(), d_out.data_ptr(), T)
+    ds.synchronize()
+    assert np.array_equal(d_out.cpu().numpy(), a)
+
+
+def test_streams_are_independent_and_reset_is_per_stream(weights0):
+    from crispy_amd import synth_audio as SA
+    T = 20
+    x = SA.batch_np(4, T) * np.float32(32768.0)
+    ref, _ = _mk(weights0, 4).process(x)
+    for b in range(4):      # stream b alone gives the same samples as inside the batch
+        solo, _ = _mk(weights0, 1).process(np.ascontiguousarray(x[:, b:b + 1]))
+        assert np.array_equal(solo[:, 0], ref[:, b])
+    ds = _mk(weights0, 4)
+    ds.process(x)
+    ds.reset(2)             # audio.rs:955-965: a fresh DenoiseState for one stream only
+    again, _ = ds.process(x)
+    assert np.array_equal(again[:, 2], ref[:, 2])
+    assert not np.array_equal(again[:, 1], ref[:, 1])
+    ds.reset(-1)
+    again, _ = ds.process(x)
+    assert np.array_equal(again, ref)
+
+
+def test_single_frame_process_frame_semantics(oracle, weights0):
+    """DenoiseState::process_frame(out, in) -> vad, one 480-sample frame at a time (audio.rs:268)."""
+    from crispy_amd import synth_audio as SA
+    x = (SA.stream_np(2, 8) * np.float32(32768.0)).reshape(8, 480)
+    ds = _mk(weights0, 1)
+    st = oracle.OracleDenoiseState(weights0)
+    for t in range(8):
+        out = np.empty(480, np.float32)
+        vad = ds.process_frame(out, x[t])
+        ro, rv = st.process_frame(x[t])
+        _assert_pcm_close(out, ro, f"frame {t}")
+        assert abs(vad - rv) < 1e-4
+    with pytest.raises(ValueError):
+        ds.process_frame(np.empty(480, np.float32), x[0][:100])
+
+
+def test_error_paths_on_device(weights0):
+    from crispy_amd import _native as N
+    ds = _mk(weights0, 2)
+    with pytest.raises(N.CrispyError):
+        ds.reset(5)
+    with pytest.raises(N.CrispyError):
+        _mk(weights0, 2).__class__(weights0, 2, 99)   # device out of range
+    assert N.lib().crispy_rn_process(ds._h, None, None, None, 1, 0) == -1
+    assert N.lib().crispy_rn_process(ds._h, None, None, None, 0, 0) == 0    # empty input is a no-op
+
+
+def test_full_size_properties_4096_streams(weights0):
+    """BASELINE cfg 2 size (4096 streams), properties that need no oracle run:
+    * every 10th stream is digital silence -> output exactly zero, VAD zero;
+    * streams fed identical audio produce identical output wherever they sit in the batch;
+    * a sample of 16 streams matches solo runs bit for bit; everything is finite and within int16 range."""
+    import torch
+    from crispy_amd import synth_audio as SA
+    B, T = 4096, 25
+    dev = torch.device("cuda:0")
+    d_in = SA.batch_torch(B, T, dev, seed=3)
+    d_in[:, 1000] = d_in[:, 17]
+    d_in[:, 4095] = d_in[:, 17]
+    d_out = torch.empty_like(d_in)
+    d_vad = torch.empty(T, B, device=dev)
+    ds = _mk(weights0, B)
+    torch.cuda.synchronize()
+    ds.process_device(d_in.data_ptr(), d_out.data_ptr(), T, d_vad.data_ptr())
+    ds.synchronize()
+    out, vad = d_out.cpu().numpy(), d_vad.cpu().numpy()
+    assert np.isfinite(out).all() and np.abs(out).max() < 40000
+    silent = np.arange(B) % 10 == 9
+    assert np.all(out[:, silent] == 0.0) and np.all(vad[:, silent] == 0.0)
+    assert np.array_equal(out[:, 1000], out[:, 17]) and np.array_equal(out[:, 4095], out[:, 17])
+    x = d_in.cpu().numpy()
+    pick = [0, 1, 63, 64, 65, 511, 1023, 1024, 2047, 2048, 3000, 3071, 3072, 4000, 4094, 4095]
+    solo, _ = _mk(weights0, len(pick)).process(np.ascontiguousarray(x[:, pick]))
+    assert np.array_equal(solo, out[:, pick])
+    e_in = (x[5:] ** 2).sum()
+    assert (out[5:] ** 2).sum() <= 1.05 * e_in       # gains <= 1: the denoiser never adds energy
+
+
+def test_sampled_oracle_parity_at_full_size(oracle, weights0):
+    """4096-stream batch, 40 frames: 24 sampled streams against the oracle."""
+    import torch
+    from crispy_amd import synth_audio as SA
+    B, T = 4096, 40
+    dev = torch.device("cuda:0")
+    d_in = SA.batch_torch(B, T, dev, seed=11)
+    d_out = torch.empty_like(d_in)
+    ds = _mk(weights0, B)
+    torch.cuda.synchronize()
+    ds.process_device(d_in.data_ptr(), d_out.data_ptr(), T)
+    ds.synchronize()
+    pick = list(range(0, B, 171))
+    x = d_in[:, pick].cpu().numpy()
+    out = d_out[:, pick].cpu().numpy()
+    bad = 0
+    for i, b in enumerate(pick):
+        ro, _ = oracle.OracleDenoiseState(weights0).process(np.ascontiguousarray(x[:, i]))
+        err = np.abs(out[:, i] - ro).max()
+        if err > REL * np.abs(ro).max() + 1e-3:
+            bad += 1
+    assert bad == 0, f"{bad}/{len(pick)} sampled streams out of tolerance"

@@ -1,0 +1,232 @@
+"""CPU tests of the RNNoise oracle (oracle/rnnoise_oracle.c): every stage against an independent
+numpy/scipy formulation, the whole frame against the committed golden vectors, and the
+properties SURVEY.md Appendix A.4 derives."""
+import os
+
+import numpy as np
+import pytest
+import scipy.fft
+import scipy.signal
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "rnnoise_golden.npz")
+EBAND = np.array([0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 34, 40, 48, 60, 78, 100])
+
+
+def test_forward_transform_matches_numpy(oracle):
+    rng = np.random.default_rng(1)
+    for _ in range(3):
+        x = rng.standard_normal(960).astype(np.float32) * 1000
+        re, im = np.empty(481, np.float32), np.empty(481, np.float32)
+        oracle.lib().rno_forward_transform(oracle.fp(re), oracle.fp(im), oracle.fp(x))
+        ref = np.fft.rfft(x.astype(np.float64)) / 960.0   # Appendix A.1: forward is DFT/960
+        assert np.abs((re + 1j * im) - ref).max() <= 2e-6 * np.abs(ref).max()
+        assert im[0] == 0.0 and abs(im[480]) <= 1e-6 * np.abs(ref).max()
+
+
+def test_inverse_transform_is_unscaled_inverse(oracle):
+    rng = np.random.default_rng(2)
+    X = (rng.standard_normal(481) + 1j * rng.standard_normal(481))
+    X[0] = X[0].real
+    X[480] = X[480].real
+    re, im = X.real.astype(np.float32), X.imag.astype(np.float32)
+    y = np.empty(960, np.float32)
+    oracle.lib().rno_inverse_transform(oracle.fp(y), oracle.fp(re), oracle.fp(im))
+    ref = np.fft.irfft(re.astype(np.float64) + 1j * im.astype(np.float64), 960) * 960.0
+    assert np.abs(y - ref).max() <= 2e-6 * np.abs(ref).max()
+
+
+def test_fft_round_trip_identity(oracle):
+    x = np.random.default_rng(3).standard_normal(960).astype(np.float32)
+    re, im, y = np.empty(481, np.float32), np.empty(481, np.float32), np.empty(960, np.float32)
+    oracle.lib().rno_forward_transform(oracle.fp(re), oracle.fp(im), oracle.fp(x))
+    oracle.lib().rno_inverse_transform(oracle.fp(y), oracle.fp(re), oracle.fp(im))
+    assert np.abs(y - x).max() < 5e-6
+
+
+def test_window_is_power_complementary(oracle):
+    w = np.empty(480, np.float32)
+    oracle.lib().rno_half_window(oracle.fp(w))
+    i = np.arange(480)
+    ref = np.sin(0.5 * np.pi * np.sin(0.5 * np.pi * (i + 0.5) / 480) ** 2)
+    assert np.abs(w - ref).max() < 1e-7
+    assert np.abs(w.astype(np.float64) ** 2 + w[::-1].astype(np.float64) ** 2 - 1.0).max() < 1e-6
+
+
+def test_biquad_matches_scipy_lfilter(oracle):
+    rng = np.random.default_rng(4)
+    x = (rng.standard_normal(4800) * 3000 + 500).astype(np.float32)   # with a DC offset
+    y = np.empty_like(x)
+    mem = np.zeros(2, np.float32)
+    for k in range(10):   # state carried across calls
+        oracle.lib().rno_biquad(oracle.fp(y[480 * k:]), oracle.fp(mem), oracle.fp(x[480 * k:]), 480)
+    b = [1.0, -2.0, 1.0]
+    a = [1.0, float(np.float32(-1.99599)), float(np.float32(0.996))]
+    ref = scipy.signal.lfilter(b, a, x.astype(np.float64))
+    assert np.abs(y - ref).max() <= 2e-4 * np.abs(ref).max()   # f32 state rounding of the reference
+    assert abs(np.mean(y[2400:])) < 0.05 * 500                # DC is removed
+
+
+def band_energy_np(X):
+    E = np.zeros(22)
+    for i in range(21):
+        bs = (EBAND[i + 1] - EBAND[i]) * 4
+        for j in range(bs):
+            frac = j / bs
+            t = abs(X[EBAND[i] * 4 + j]) ** 2
+            E[i] += (1 - frac) * t
+            E[i + 1] += frac * t
+    E[0] *= 2
+    E[21] *= 2
+    return E
+
+
+def test_band_energy_and_interp(oracle):
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal(481) + 1j * rng.standard_normal(481)
+    re, im = X.real.astype(np.float32), X.imag.astype(np.float32)
+    E = np.empty(22, np.float32)
+    oracle.lib().rno_band_energy(oracle.fp(E), oracle.fp(re), oracle.fp(im))
+    assert np.allclose(E, band_energy_np(re.astype(np.float64) + 1j * im.astype(np.float64)), rtol=1e-5)
+    g = np.empty(481, np.float32)
+    v = rng.uniform(0, 1, 22).astype(np.float32)
+    oracle.lib().rno_interp_band_gain(oracle.fp(g), oracle.fp(v))
+    assert np.all(g[400:] == 0.0)                       # Appendix A.4: nothing above 20 kHz
+    for i in range(21):
+        assert g[EBAND[i] * 4] == pytest.approx(v[i], rel=1e-6)
+    ones = np.ones(22, np.float32)
+    oracle.lib().rno_interp_band_gain(oracle.fp(g), oracle.fp(ones))
+    assert np.allclose(g[:400], 1.0, atol=1e-6)
+
+
+def test_dct_is_orthonormal_dct2(oracle):
+    x = np.random.default_rng(6).standard_normal(22).astype(np.float32)
+    y = np.empty(22, np.float32)
+    oracle.lib().rno_dct(oracle.fp(y), oracle.fp(x))
+    ref = scipy.fft.dct(x.astype(np.float64), type=2, norm="ortho")
+    assert np.abs(y - ref).max() < 1e-5
+
+
+def test_tansig_sigmoid_approx(oracle):
+    xs = np.linspace(-9, 9, 2001).astype(np.float32)
+    t = np.array([oracle.lib().rno_tansig_approx(float(v)) for v in xs])
+    s = np.array([oracle.lib().rno_sigmoid_approx(float(v)) for v in xs])
+    assert np.abs(t - np.tanh(xs.astype(np.float64))).max() < 2e-4     # table lookup + 2nd-order step
+    assert np.abs(s - 1 / (1 + np.exp(-xs.astype(np.float64)))).max() < 2e-4
+    assert oracle.lib().rno_tansig_approx(8.0) == 1.0 and oracle.lib().rno_tansig_approx(-8.0) == -1.0
+    assert oracle.lib().rno_tansig_approx(float("nan")) == 1.0         # reversed test catches NaN first
+    assert oracle.lib().rno_tansig_approx(0.0) == 0.0
+
+
+def _unpack(w):
+    from crispy_amd.rnn_weights import LAYERS, blob_offsets
+    offs, _ = blob_offsets()
+    out = {}
+    for name, kind, n_in, n_out in LAYERS:
+        cols = n_out if kind == "dense" else 3 * n_out
+        d = {"W": w[offs[name]["W"][0]:][:n_in * cols].reshape(n_in, cols).astype(np.float64),
+             "b": w[offs[name]["b"][0]:][:cols].astype(np.float64)}
+        if kind == "gru":
+            d["U"] = w[offs[name]["U"][0]:][:n_out * cols].reshape(n_out, cols).astype(np.float64)
+        out[name] = d
+    return out
+
+
+def test_compute_rnn_matches_numpy_gru(oracle, weights0):
+    """Independent float64 re-derivation of dense+GRU stack (Appendix A.3 step 6) with exact tanh/sigmoid:
+    the oracle's table activations differ by < 2e-4 each, so states agree to ~1e-3."""
+    P = _unpack(weights0)
+    S = 1 / 256.0
+    sig = lambda v: 1 / (1 + np.exp(-v))
+
+    def gru(p, h, x, n):
+        a = p["b"] + x @ p["W"]
+        z = sig(S * (a[:n] + h @ p["U"][:, :n]))
+        r = sig(S * (a[n:2 * n] + h @ p["U"][:, n:2 * n]))
+        c = np.maximum(0, S * (a[2 * n:] + (h * r) @ p["U"][:, 2 * n:]))
+        return z * h + (1 - z) * c
+
+    rng = np.random.default_rng(7)
+    state = np.zeros(168, np.float32)
+    hv, hn, hd = np.zeros(24), np.zeros(48), np.zeros(96)
+    for _ in range(5):
+        f = rng.standard_normal(42).astype(np.float32)
+        g, vad = np.empty(22, np.float32), np.empty(1, np.float32)
+        oracle.lib().rno_compute_rnn(weights0.ctypes.data, oracle.fp(state), oracle.fp(g), oracle.fp(vad), oracle.fp(f))
+        f64 = f.astype(np.float64)
+        d = np.tanh(S * (P["input_dense"]["b"] + f64 @ P["input_dense"]["W"]))
+        hv = gru(P["vad_gru"], hv, d, 24)
+        v = sig(S * (P["vad_output"]["b"] + hv @ P["vad_output"]["W"]))
+        hn = gru(P["noise_gru"], hn, np.concatenate([d, hv, f64]), 48)
+        hd = gru(P["denoise_gru"], hd, np.concatenate([hv, hn, f64]), 96)
+        gg = sig(S * (P["denoise_output"]["b"] + hd @ P["denoise_output"]["W"]))
+        assert np.abs(state - np.concatenate([hv, hn, hd])).max() < 3e-3
+        assert np.abs(g - gg).max() < 2e-3 and abs(vad[0] - v[0]) < 2e-3
+
+
+def test_pitch_search_finds_period(oracle):
+    """A 200 Hz harmonic signal at 48 kHz has a 240-sample period = 120 at half rate."""
+    t = np.arange(1728) / 48000.0
+    x = sum(np.sin(2 * np.pi * 200 * h * t) / h for h in (1, 2, 3)).astype(np.float32) * 5000
+    lp = np.empty(864, np.float32)
+    oracle.lib().rno_pitch_downsample(oracle.fp(x), oracle.fp(lp))
+    xv = np.ascontiguousarray(lp[384:])
+    idx = oracle.lib().rno_pitch_search(oracle.fp(xv), oracle.fp(lp), 960, 588)
+    pitch_index = 768 - idx
+    T0 = oracle.C.c_int(pitch_index) if hasattr(oracle, "C") else None
+    import ctypes as C
+    T0 = C.c_int(pitch_index)
+    g = oracle.lib().rno_remove_doubling(oracle.fp(lp), 768, 60, 960, C.byref(T0), 0, 0.0)
+    assert T0.value % 240 in (0, 1, 239) and T0.value >= 60, T0.value
+    assert g > 0.8
+
+
+def test_quiet_input_is_pure_delay_of_highpassed_signal(oracle, weights0):
+    """Appendix A.4: on the silence branch (E < 0.04) X is untouched, so out[n] = HP(in)[n-480]."""
+    T = 12
+    t = np.arange(T * 480) / 48000.0
+    x = (1e-3 * np.sin(2 * np.pi * 300 * t)).astype(np.float32)
+    out, vad, taps = oracle.OracleDenoiseState(weights0).process(x, with_taps=True)
+    assert np.all(taps[:, 67] == 1.0) and np.all(vad == 0.0)
+    hp = np.empty_like(x)
+    mem = np.zeros(2, np.float32)
+    oracle.lib().rno_biquad(oracle.fp(hp), oracle.fp(mem), oracle.fp(x), x.size)
+    assert np.abs(out.ravel()[480:] - hp[:-480]).max() < 2e-6 * np.abs(hp).max() + 1e-9
+    assert np.all(out[0] == 0.0) or np.abs(out[0]).max() < 1e-9    # the frame the adapter drops (audio.rs:275)
+
+
+def test_state_reset_and_determinism(oracle, weights0):
+    from crispy_amd import synth_audio
+    x = synth_audio.stream_np(3, 10) * np.float32(32768)
+    st = oracle.OracleDenoiseState(weights0)
+    a, va = st.process(x)
+    st.reset()
+    b, vb = st.process(x)
+    assert np.array_equal(a, b) and np.array_equal(va, vb)
+
+
+def test_gains_bounded_and_output_attenuated(oracle, weights0):
+    from crispy_amd import synth_audio
+    x = synth_audio.stream_np(5, 30) * np.float32(32768)
+    out, vad, taps = oracle.OracleDenoiseState(weights0).process(x, with_taps=True)
+    g = taps[:, 42:64]
+    assert g.min() >= 0.0 and g.max() <= 1.0 and np.all((vad >= 0) & (vad <= 1))
+    assert np.isfinite(out).all()
+    assert np.sqrt((out[5:] ** 2).mean()) <= 1.05 * np.sqrt((x.reshape(-1, 480)[5:] ** 2).mean())
+
+
+@pytest.mark.parametrize("case", ["seed0", "seed1", "seed2", "silence", "tone440", "whisper_quiet"])
+def test_oracle_reproduces_golden(oracle, case):
+    """Regression pin of the oracle against the committed vectors (made by make_rnnoise_golden.py)."""
+    G = np.load(GOLD)
+    w = G["weights" + case[-1]] if case.startswith("seed") else G["weights0"]
+    out, vad, taps = oracle.OracleDenoiseState(w).process(G[f"{case}/x"], with_taps=True)
+    assert np.array_equal(out, G[f"{case}/out"])
+    assert np.array_equal(vad, G[f"{case}/vad"])
+    assert np.array_equal(taps, G[f"{case}/taps"])
+
+
+def test_golden_weights_match_generator():
+    from crispy_amd import synthetic_weights
+    G = np.load(GOLD)
+    for s in (0, 1, 2):
+        assert np.array_equal(G[f"weights{s}"], synthetic_weights(s))

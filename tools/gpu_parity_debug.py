@@ -18,7 +18,7 @@ for b in range(B):
     st = O.OracleDenoiseState(w)
     o, v, tp = st.process(x[:, b], with_taps=True)
     ref_out[:, b] = o; ref_taps[:, b] = tp
-    d = np.empty(4304, np.float32); O.lib().rno_last_debug(st._h, O.fp(d)); ref_dbg[b] = d
+    ref_dbg[b] = st.debug()
 
 dev = torch.device("cuda:0")
 ds = DenoiseState(w, B, 0)
