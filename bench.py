@@ -151,7 +151,9 @@ def main():
         ds.synchronize()
         k_ms.append(ds.last_kernel_ms())
     ds.set_timing(False)
-    launches = (T + 249) // 250
+    from crispy_amd import _native as N
+    fpl = N.lib().crispy_rn_frames_per_launch()          # frames covered by one rn_frame_kernel launch
+    launches = sum((min(250, T - t0) + fpl - 1) // fpl for t0 in range(0, T, 250))
     frame_ms = sum(k[0] for k in k_ms) / len(k_ms) / launches
     total_ms = sum(k[1] for k in k_ms) / len(k_ms)
     finite = bool(torch.isfinite(d_out).all().item())
@@ -159,7 +161,7 @@ def main():
     frames_total = world * B * T * args.steps
     fps = frames_total / dt
     if rank == 0:
-        alg_bytes = BYTES_PER_STREAM_FRAME * B * min(T, 250)
+        alg_bytes = BYTES_PER_STREAM_FRAME * B * min(T, fpl)
         achieved = alg_bytes / (frame_ms * 1e-3) / 1e9
         line = {
             "metric": "concurrent real-time 48 kHz streams/GPU (RNNoise)",
@@ -175,7 +177,8 @@ def main():
                        "frames_per_s": fps, "output_finite": finite},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "rn_frame_kernel", "kernel_ms": frame_ms, "enqueue_ms": total_ms,
+                         "kernel": "rn_frame_kernel", "kernel_ms": frame_ms, "launches_per_step": launches,
+                         "enqueue_ms": total_ms,
                          "alg_bytes_per_launch": alg_bytes},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -39,7 +39,8 @@ int fail(int code, const char* fmt, ...) {
                   hipGetErrorString(_e));                                                  \
   } while (0)
 
-constexpr int kChunkFrames = 250;
+constexpr int kChunkFrames = 250;   // workspace bound: frames of high-passed signal kept per call segment
+constexpr int kSubFrames = 25;      // pipeline grain: high-pass of sub-chunk i+1 overlaps the frame kernel of sub-chunk i
 
 bool device_is_gfx950(int dev) {
   hipDeviceProp_t prop;
@@ -64,6 +65,15 @@ void build_tables(RnTables* t) {
   for (int k = 0; k < RN_WINDOW; ++k) {
     t->w960[k].x = (float)std::cos(-2.0 * pi * k / RN_WINDOW);
     t->w960[k].y = (float)std::sin(-2.0 * pi * k / RN_WINDOW);
+  }
+  static const int eband[RN_NB] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 34, 40, 48, 60, 78, 100};
+  for (int i = 0; i < 24; ++i) t->eband[i] = i < RN_NB ? eband[i] : 100;
+  for (int i = 0; i < RN_NB - 1; ++i) {
+    const int bs = (eband[i + 1] - eband[i]) * 4;
+    for (int j = 0; j < bs; ++j) {
+      t->bin_band[eband[i] * 4 + j] = i;
+      t->bin_frac[eband[i] * 4 + j] = (float)j / (float)bs;   // same f32 division as the reference
+    }
   }
 }
 
@@ -115,6 +125,9 @@ struct crispy_rn {
   int device = 0;
   int B = 0;
   hipStream_t stream = nullptr;
+  hipStream_t hp_stream = nullptr;   // helper stream: the latency-bound high-pass runs beside the frame kernel
+  hipEvent_t ev_begin = nullptr;
+  std::vector<hipEvent_t> ev_hp;     // one per sub-chunk: high-pass done
   // constants
   RnTables* d_tab = nullptr;
   uint32_t* d_wpack = nullptr;
@@ -130,6 +143,7 @@ struct crispy_rn {
   // workspace
   float* d_xhp = nullptr;
   long xhp_stride = 0;
+  float2* d_pspec = nullptr;
   float* d_dbg = nullptr;
   // host-pointer staging
   float* d_stage_in = nullptr;
@@ -138,8 +152,9 @@ struct crispy_rn {
   size_t stage_frames = 0;
   // timing
   bool timing = false;
-  std::vector<hipEvent_t> ev;  // per chunk: total_begin, frame_begin, frame_end, total_end
+  std::vector<hipEvent_t> ev;  // per segment: begin, (frame_begin, frame_end) x sub-chunks, end
   size_t ev_used = 0;
+  std::vector<int> seg_subs;   // sub-chunks of every timed segment
 };
 
 namespace {
@@ -149,11 +164,14 @@ void free_all(crispy_rn* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->d_tab, h->d_wpack, h->d_hp_mem, h->d_synth, h->d_ceps, h->d_lastg, h->d_rnn,
-                  h->d_last_gain, h->d_last_period, h->d_memid, h->d_xhp, h->d_dbg, h->d_stage_in,
+                  h->d_last_gain, h->d_last_period, h->d_memid, h->d_xhp, h->d_pspec, h->d_dbg, h->d_stage_in,
                   h->d_stage_out, h->d_stage_vad};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->ev_hp) (void)hipEventDestroy(e);
+  if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
+  if (h->hp_stream) { (void)hipStreamSynchronize(h->hp_stream); (void)hipStreamDestroy(h->hp_stream); }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -219,6 +237,8 @@ int crispy_rn_create(const int8_t* weights, size_t nbytes, int n_streams, int de
   auto body = [&]() -> int {
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&h->hp_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_begin, hipEventDisableTiming));
     const size_t B = (size_t)n_streams;
     HIP_TRY(hipMalloc(&h->d_tab, sizeof(RnTables)));
     HIP_TRY(hipMalloc(&h->d_wpack, sizeof(uint32_t) * RnPack::END));
@@ -231,6 +251,7 @@ int crispy_rn_create(const int8_t* weights, size_t nbytes, int n_streams, int de
     HIP_TRY(hipMalloc(&h->d_last_period, B * sizeof(int)));
     HIP_TRY(hipMalloc(&h->d_memid, B * sizeof(int)));
     HIP_TRY(hipMalloc(&h->d_xhp, B * h->xhp_stride * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_pspec, B * 482 * sizeof(float2)));
     RnTables* tab = new RnTables();
     build_tables(tab);
     hipError_t e = hipMemcpy(h->d_tab, tab, sizeof(RnTables), hipMemcpyHostToDevice);
@@ -258,6 +279,8 @@ int crispy_rn_create(const int8_t* weights, size_t nbytes, int n_streams, int de
 void crispy_rn_destroy(crispy_rn* h) { free_all(h); }
 
 int crispy_rn_n_streams(const crispy_rn* h) { return h ? h->B : 0; }
+
+int crispy_rn_frames_per_launch(void) { return kSubFrames; }
 
 int crispy_rn_reset(crispy_rn* h, int stream) {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_reset: NULL handle");
@@ -289,6 +312,7 @@ int crispy_rn_process_device(crispy_rn* h, const float* d_in, float* d_out, floa
   a.stride_b = layout == CRISPY_RN_LAYOUT_TBF ? (long)RN_FRAME : (long)n_frames * RN_FRAME;
   a.xhp = h->d_xhp;
   a.xhp_stride = h->xhp_stride;
+  a.pspec = h->d_pspec;
   a.hp_mem = h->d_hp_mem;
   a.synth = h->d_synth;
   a.ceps = h->d_ceps;
@@ -300,32 +324,59 @@ int crispy_rn_process_device(crispy_rn* h, const float* d_in, float* d_out, floa
   a.tab = h->d_tab;
   a.wpack = h->d_wpack;
 
-  if (h->timing) h->ev_used = 0;
+  if (h->timing) { h->ev_used = 0; h->seg_subs.clear(); }
   for (int t0 = 0; t0 < n_frames; t0 += kChunkFrames) {
     const int T = (n_frames - t0) < kChunkFrames ? (n_frames - t0) : kChunkFrames;
-    a.T = T;
-    a.in = d_in + (long)t0 * a.stride_t;
-    a.out = d_out + (long)t0 * a.stride_t;
-    a.vad = d_vad ? d_vad + (long)t0 * h->B : nullptr;
-    a.taps = d_taps ? d_taps + (long)t0 * h->B * RN_TAPS : nullptr;
-    a.dbg = (t0 + T == n_frames) ? h->d_dbg : nullptr;
+    // The high-pass of this segment may start once everything already enqueued on `s` is done
+    // (producer of d_in, previous segment's frame kernels and history roll).
+    HIP_TRY(hipEventRecord(h->ev_begin, s));
+    HIP_TRY(hipStreamWaitEvent(h->hp_stream, h->ev_begin, 0));
+    const int n_sub = (T + kSubFrames - 1) / kSubFrames;
+    while ((int)h->ev_hp.size() < n_sub) {
+      hipEvent_t ne;
+      HIP_TRY(hipEventCreateWithFlags(&ne, hipEventDisableTiming));
+      h->ev_hp.push_back(ne);
+    }
     hipEvent_t* e = nullptr;
     if (h->timing) {
-      while (h->ev.size() < h->ev_used + 4) {
+      while (h->ev.size() < h->ev_used + 2 + 2 * (size_t)n_sub) {
         hipEvent_t ne;
         HIP_TRY(hipEventCreate(&ne));
         h->ev.push_back(ne);
       }
       e = &h->ev[h->ev_used];
-      h->ev_used += 4;
+      h->ev_used += 2 + 2 * (size_t)n_sub;
       HIP_TRY(hipEventRecord(e[0], s));
     }
-    HIP_TRY(rn_launch_highpass(a, s));
-    if (e) HIP_TRY(hipEventRecord(e[1], s));
-    HIP_TRY(rn_launch_frames(a, s));
-    if (e) HIP_TRY(hipEventRecord(e[2], s));
+    // high-pass sub-chunks back to back on the helper stream
+    for (int i = 0; i < n_sub; ++i) {
+      const int ts = i * kSubFrames;
+      RnArgs sa = a;
+      sa.T = (T - ts) < kSubFrames ? (T - ts) : kSubFrames;
+      sa.in = d_in + (long)(t0 + ts) * a.stride_t;
+      sa.xhp = h->d_xhp + (long)ts * RN_FRAME;   // row pointer shifted by the frames already filtered
+      HIP_TRY(rn_launch_highpass(sa, h->hp_stream));
+      HIP_TRY(hipEventRecord(h->ev_hp[i], h->hp_stream));
+    }
+    // frame kernels on the caller's stream, each gated on its own sub-chunk's high-pass
+    for (int i = 0; i < n_sub; ++i) {
+      const int ts = i * kSubFrames;
+      RnArgs sa = a;
+      sa.T = (T - ts) < kSubFrames ? (T - ts) : kSubFrames;
+      sa.out = d_out + (long)(t0 + ts) * a.stride_t;
+      sa.vad = d_vad ? d_vad + (long)(t0 + ts) * h->B : nullptr;
+      sa.taps = d_taps ? d_taps + (long)(t0 + ts) * h->B * RN_TAPS : nullptr;
+      sa.dbg = (t0 + ts + sa.T == n_frames) ? h->d_dbg : nullptr;
+      sa.xhp = h->d_xhp + (long)ts * RN_FRAME;
+      HIP_TRY(hipStreamWaitEvent(s, h->ev_hp[i], 0));
+      if (e) HIP_TRY(hipEventRecord(e[1 + 2 * i], s));
+      HIP_TRY(rn_launch_frames(sa, s));
+      if (e) HIP_TRY(hipEventRecord(e[2 + 2 * i], s));
+    }
+    a.T = T;
     HIP_TRY(rn_launch_roll_history(a, s));
-    if (e) HIP_TRY(hipEventRecord(e[3], s));
+    if (e) HIP_TRY(hipEventRecord(e[1 + 2 * n_sub], s));
+    if (h->timing) h->seg_subs.push_back(n_sub);
   }
   return CRISPY_OK;
 }
@@ -372,6 +423,7 @@ int crispy_rn_set_timing(crispy_rn* h, int enable) {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_set_timing: NULL handle");
   h->timing = enable != 0;
   h->ev_used = 0;
+  h->seg_subs.clear();
   return CRISPY_OK;
 }
 
@@ -381,13 +433,18 @@ int crispy_rn_last_kernel_ms(crispy_rn* h, float* frame_kernel_ms, float* total_
     return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_last_kernel_ms: no timed call recorded");
   HIP_TRY(hipSetDevice(h->device));
   float fk = 0.f, tot = 0.f;
-  for (size_t i = 0; i + 3 < h->ev_used; i += 4) {
-    HIP_TRY(hipEventSynchronize(h->ev[i + 3]));
+  size_t i = 0;
+  for (int n_sub : h->seg_subs) {
+    const size_t last = i + 1 + 2 * (size_t)n_sub;
+    HIP_TRY(hipEventSynchronize(h->ev[last]));
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, h->ev[i + 1], h->ev[i + 2]));
-    fk += ms;
-    HIP_TRY(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 3]));
+    for (int k = 0; k < n_sub; ++k) {
+      HIP_TRY(hipEventElapsedTime(&ms, h->ev[i + 1 + 2 * k], h->ev[i + 2 + 2 * k]));
+      fk += ms;
+    }
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev[i], h->ev[last]));
     tot += ms;
+    i = last + 1;
   }
   if (frame_kernel_ms) *frame_kernel_ms = fk;
   if (total_ms) *total_ms = tot;

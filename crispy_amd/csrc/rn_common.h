@@ -23,6 +23,9 @@ struct RnTables {
   float dct[RN_NB * RN_NB];   // dct[j*22+i] = cos((j+.5) i pi/22), column 0 scaled by sqrt(.5)
   float tansig[208];          // tanh(0.04 i) rounded to 6 decimals, i = 0..200
   float2 w960[RN_WINDOW];     // exp(-2 pi i k / 960)
+  float bin_frac[400];        // position of bin inside its Opus band, j / band_size
+  int bin_band[400];          // band index of every bin below 20 kHz
+  int eband[24];              // band edges in 4-bin chunks (22 used)
 };
 
 // Flat blob offsets.
@@ -77,6 +80,7 @@ struct RnArgs {
   // workspace: high-passed signal, per stream contiguous: [B][xhp_stride], first RN_HIST = history
   float* xhp;
   long xhp_stride;
+  float2* pspec;        // [B][482] pitch-frame spectrum parked in L2 between its FFT and the comb filter
   // persistent per-stream state (HBM)
   float* hp_mem;        // [B][2]
   float* synth;         // [B][480]

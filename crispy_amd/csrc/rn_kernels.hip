@@ -24,16 +24,15 @@ namespace {
 
 constexpr int WAVE = 64;
 
-// Opus band edges in units of 4 bins (Appendix A.1).
-__device__ __constant__ unsigned char c_eband[RN_NB] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  10, 12,
-                                                         14, 16, 20, 24, 28, 34, 40, 48, 60, 78, 100};
-// band of each 4-bin chunk (100 chunks cover bins 0..399)
-__device__ __constant__ unsigned char c_chunk_band[100] = {
-    0,  1,  2,  3,  4,  5,  6,  7,  8,  8,  9,  9,  10, 10, 11, 11, 12, 12, 12, 12,
-    13, 13, 13, 13, 14, 14, 14, 14, 15, 15, 15, 15, 15, 15, 16, 16, 16, 16, 16, 16,
-    17, 17, 17, 17, 17, 17, 17, 17, 18, 18, 18, 18, 18, 18, 18, 18, 18, 18, 18, 18,
-    19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 20, 20,
-    20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20};
+// In-kernel stage stamps (diagnostic build only: make PROFILE=1 -> libcrispy_hip_prof.so).
+#ifdef RN_PROFILE
+#define RN_PROF_DECL long long prof_[24] = {0}; long long tprev_ = clock64();
+#define STAMP(k) { const long long tn_ = clock64(); prof_[k] += tn_ - tprev_; tprev_ = tn_; }
+#else
+#define RN_PROF_DECL
+#define STAMP(k)
+#endif
+
 __device__ __constant__ int c_second_check[16] = {0, 0, 3, 2, 3, 2, 5, 2, 3, 2, 3, 2, 5, 2, 3, 2};
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
@@ -43,10 +42,20 @@ __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
 
+// DPP lane permutations (gfx9 family): no LDS crossbar round trip, one VALU op per step.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+// sum over the 64 lanes, result uniform (read from lane 63 into an SGPR)
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
-  return v;
+  v += dpp_mov<0xB1>(v);        // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);        // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);       // row_half_mirror
+  v += dpp_mov<0x140>(v);       // row_mirror: every lane of a 16-lane row holds the row sum
+  v += dpp_mov<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_mov<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -193,23 +202,25 @@ __device__ __forceinline__ void real_inv_pre(float2* buf, const float2* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
-// Opus-band helpers (Appendix A.3 step 2).  `part` is 200 floats of scratch.
+// Opus-band helpers (Appendix A.3 step 2).  `part` is 200 floats of scratch; e0/e1/em1 are this
+// lane's band edges (band = lane) in 4-bin chunks, loaded once per kernel.
 // ---------------------------------------------------------------------------------------------
-template <bool CORR>
+struct BandEdges {
+  int em1, e0, e1;
+};
+
+template <bool CORR, bool PGLOBAL>
 __device__ __forceinline__ void band_sums(const float2* X, const float2* P, float* part, float* E,
-                                          int lane) {
+                                          const RnTables* __restrict__ tab, const BandEdges& be, int lane) {
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
     const int c = lane + WAVE * m;
     if (c < 100) {
-      const int i = c_chunk_band[c];
-      const int e0 = c_eband[i];
-      const int bs = (c_eband[i + 1] - e0) * 4;
-      const int q = c - e0;
+      const float4 fr = *reinterpret_cast<const float4*>(tab->bin_frac + 4 * c);
+      const float f[4] = {fr.x, fr.y, fr.z, fr.w};
       float lo = 0.f, hi = 0.f;
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
-        const float frac = (float)(4 * q + jj) / (float)bs;
         const float2 x = X[4 * c + jj];
         float tmp;
         if (CORR) {
@@ -220,8 +231,8 @@ __device__ __forceinline__ void band_sums(const float2* X, const float2* P, floa
           tmp = x.x * x.x;
           tmp += x.y * x.y;
         }
-        lo += (1.f - frac) * tmp;
-        hi += frac * tmp;
+        lo += (1.f - f[jj]) * tmp;
+        hi += f[jj] * tmp;
       }
       part[c] = lo;
       part[100 + c] = hi;
@@ -229,27 +240,20 @@ __device__ __forceinline__ void band_sums(const float2* X, const float2* P, floa
   }
   __syncthreads();
   if (lane < RN_NB) {
-    const int i = lane;
     float sum = 0.f;
-    if (i > 0)
-      for (int c = c_eband[i - 1]; c < c_eband[i]; ++c) sum += part[100 + c];
-    if (i < RN_NB - 1)
-      for (int c = c_eband[i]; c < c_eband[i + 1]; ++c) sum += part[c];
-    if (i == 0 || i == RN_NB - 1) sum *= 2.f;
-    E[i] = sum;
+    if (lane > 0)
+      for (int c = be.em1; c < be.e0; ++c) sum += part[100 + c];
+    if (lane < RN_NB - 1)
+      for (int c = be.e0; c < be.e1; ++c) sum += part[c];
+    if (lane == 0 || lane == RN_NB - 1) sum *= 2.f;
+    E[lane] = sum;
   }
   __syncthreads();
 }
 
 // per-bin interpolation of 22 band values (bins >= 400 are zero)
-__device__ __forceinline__ float interp_gain(const float* v, int bin) {
-  if (bin >= 400) return 0.f;
-  const int c = bin >> 2;
-  const int i = c_chunk_band[c];
-  const int e0 = c_eband[i];
-  const int bs = (c_eband[i + 1] - e0) * 4;
-  const float frac = (float)(bin - 4 * e0) / (float)bs;
-  return (1.f - frac) * v[i] + frac * v[i + 1];
+__device__ __forceinline__ float interp_gain(const float* v, int band, float frac) {
+  return (1.f - frac) * v[band] + frac * v[band + 1];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -271,48 +275,67 @@ __device__ __forceinline__ float sigmoid_approx(float x, const float* __restrict
   return .5f + .5f * tansig_approx(.5f * x, table);
 }
 
-// acc += sum_k W[k][row] * x[k]; x lives in LDS, is 16-byte aligned and zero padded to 4*k4
+__device__ __forceinline__ float mac4_i8(uint32_t w, float4 xv, float acc) {
+  acc = fmaf((float)(int)(int8_t)(w & 0xff), xv.x, acc);
+  acc = fmaf((float)(int)(int8_t)((w >> 8) & 0xff), xv.y, acc);
+  acc = fmaf((float)(int)(int8_t)((w >> 16) & 0xff), xv.z, acc);
+  acc = fmaf((float)((int)w >> 24), xv.w, acc);
+  return acc;
+}
+
+// acc += sum_k W[k][row] * x[k]; x lives in LDS, 16-byte aligned, zero padded to 4*K4.
+// Loads are issued eight at a time so that one L2 round trip covers 32 MACs.
+template <int K4>
 __device__ __forceinline__ float dot_i8(const uint32_t* __restrict__ Wp, int rows, int row,
-                                        const float* x, int k4n, float acc) {
+                                        const float* x, float acc) {
   const float4* x4 = reinterpret_cast<const float4*>(x);
-  for (int k4 = 0; k4 < k4n; ++k4) {
-    const uint32_t w = Wp[k4 * rows + row];
-    const float4 xv = x4[k4];
-    acc = fmaf((float)(int)(int8_t)(w & 0xff), xv.x, acc);
-    acc = fmaf((float)(int)(int8_t)((w >> 8) & 0xff), xv.y, acc);
-    acc = fmaf((float)(int)(int8_t)((w >> 16) & 0xff), xv.z, acc);
-    acc = fmaf((float)((int)w >> 24), xv.w, acc);
+  const uint32_t* p = Wp + row;
+  constexpr int BLK = 8;
+#pragma unroll 1
+  for (int k0 = 0; k0 + BLK <= K4; k0 += BLK) {
+    uint32_t w[BLK];
+#pragma unroll
+    for (int q = 0; q < BLK; ++q) w[q] = p[(k0 + q) * rows];
+#pragma unroll
+    for (int q = 0; q < BLK; ++q) acc = mac4_i8(w[q], x4[k0 + q], acc);
+  }
+  constexpr int REM = K4 % BLK;
+  if (REM) {
+    constexpr int k0 = K4 - REM;
+    uint32_t w[REM ? REM : 1];
+#pragma unroll
+    for (int q = 0; q < REM; ++q) w[q] = p[(k0 + q) * rows];
+#pragma unroll
+    for (int q = 0; q < REM; ++q) acc = mac4_i8(w[q], x4[k0 + q], acc);
   }
   return acc;
 }
 
-// One GRU layer.  in_vec[K=M] and state[N] in LDS (zero padded to multiples of 4); pre = scratch
-// of 3N floats, hr = scratch of N (padded) floats.  ReLU candidate activation.
+// One GRU layer (ReLU candidate).  in_vec[M] and state[N] in LDS, zero padded to multiples of 4;
+// zbuf / hr: N floats of scratch each.
 template <int M, int N>
 __device__ __forceinline__ void gru_layer(const uint32_t* __restrict__ W, const uint32_t* __restrict__ U,
                                           const float* __restrict__ bias, const float* in_vec,
-                                          float* state, float* pre, float* zbuf, float* hr,
+                                          float* state, float* zbuf, float* hr,
                                           const float* __restrict__ tansig, int lane) {
   constexpr int ROWS = 3 * N;
   constexpr int MK4 = (M + 3) / 4, NK4 = (N + 3) / 4;
   const float S = 1.f / 256.f;
-  for (int row = lane; row < ROWS; row += WAVE) {
+  // update (z) and reset (r) gates: rows [0, 2N)
+  for (int row = lane; row < 2 * N; row += WAVE) {
     float acc = bias[row];
-    acc = dot_i8(W, ROWS, row, in_vec, MK4, acc);
-    if (row < 2 * N) acc = dot_i8(U, ROWS, row, state, NK4, acc);
-    pre[row] = acc;
+    acc = dot_i8<MK4>(W, ROWS, row, in_vec, acc);
+    acc = dot_i8<NK4>(U, ROWS, row, state, acc);
+    const float s = sigmoid_approx(S * acc, tansig);
+    if (row < N) zbuf[row] = s;
+    else hr[row - N] = state[row - N] * s;
   }
   __syncthreads();
+  // candidate rows [2N, 3N): recurrent part sees h*r
   for (int i = lane; i < N; i += WAVE) {
-    const float z = sigmoid_approx(S * pre[i], tansig);
-    const float r = sigmoid_approx(S * pre[N + i], tansig);
-    zbuf[i] = z;
-    hr[i] = state[i] * r;
-  }
-  __syncthreads();
-  for (int i = lane; i < N; i += WAVE) {
-    float acc = pre[2 * N + i];
-    acc = dot_i8(U, ROWS, 2 * N + i, hr, NK4, acc);
+    float acc = bias[2 * N + i];
+    acc = dot_i8<MK4>(W, ROWS, 2 * N + i, in_vec, acc);
+    acc = dot_i8<NK4>(U, ROWS, 2 * N + i, hr, acc);
     float c = S * acc;
     c = c < 0.f ? 0.f : c;
     const float z = zbuf[i];
@@ -322,23 +345,26 @@ __device__ __forceinline__ void gru_layer(const uint32_t* __restrict__ W, const 
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS layout of one wave (floats)
+// LDS of one wave: 10 176 bytes, so that 16 waves (= 16 streams) are resident per CU.
+//   A   pitch phase: scratch (x4|y4, fine xcorr, yy_lookup)      then: analysis spectrum X / synthesis
+//   Bb  pitch phase: lp[864] whitened half-rate buffer            then: pitch spectrum P (parked in L2
+//       after its band sums), RNN vectors, band partial sums
+//   U   band partial sums while A and Bb both hold spectra | Ly, tmp22, g, r
 // ---------------------------------------------------------------------------------------------
 struct alignas(16) RnLds {
-  float2 X[482];        // analysis spectrum, later the synthesis buffer
-  float2 P[482];        // pitch-frame spectrum; before that: lp[864] whitened half-rate buffer
-  float S[704];         // scratch: x4/y4 | band partial sums | yy_lookup | fine xcorr
-  float synth[480];
+  float2 A[482];
+  float2 Bb[482];
+  float U[200];
   float ceps[8 * 22];
-  float rnn_state[168]; // vad 24 | noise 48 | denoise 96
-  float feat[44];
-  float dense[24];
-  float gru_in[116];
-  float pre[288];
-  float zbuf[96];
-  float hr[96];
-  float Ex[24], Ep[24], Exp[24], g[24], lastg[24], r[24], tmp22[24], Ly[24];
+  float rnn_state[168];  // vad 24 | noise 48 | denoise 96
+  float Ex[24], Ep[24], Exp[24];
 };
+static_assert(sizeof(RnLds) <= 10240, "16 workgroups per CU need <= 10 KB of LDS each");
+
+// offsets (floats) inside Bb while it serves the RNN
+constexpr int RB_FEAT = 0, RB_DENSE = 44, RB_IN = 68, RB_Z = 184, RB_HR = 280, RB_PART = 384;
+// offsets inside U outside band_sums
+constexpr int U_LY = 0, U_TMP = 24, U_G = 48, U_R = 72, U_VAD = 96;
 
 // top-2 bookkeeping of find_best_pitch as an ordering on (num, den, idx)
 struct Cand {
@@ -367,59 +393,66 @@ __device__ __forceinline__ Cand wave_best(Cand c) {
 // =============================================================================================
 // frame kernel: one wave per stream, loops over the T frames of the call
 // =============================================================================================
-__global__ __launch_bounds__(WAVE) void rn_frame_kernel(RnArgs a) {
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) void rn_frame_kernel(RnArgs a) {
   __shared__ RnLds L;
-  const int lane = threadIdx.x;
+  const int lane0 = threadIdx.x;
   const int b = blockIdx.x;
   if (b >= a.B) return;
-  const RnTables* __restrict__ tab = a.tab;
-  const float2* __restrict__ w960 = tab->w960;
-  const float* __restrict__ hw = tab->half_window;
-  const float* __restrict__ tansig = tab->tansig;
-  const uint32_t* __restrict__ wp = a.wpack;
-  const float* __restrict__ wpf = reinterpret_cast<const float*>(a.wpack);
+  int lane = lane0;
+  const RnTables* tab = a.tab;
   const float* xs = a.xhp + (long)b * a.xhp_stride;
+  float2* pg = a.pspec + (long)b * 482;
 
   // ---- load per-stream state ----
-  for (int i = lane; i < 480; i += WAVE) L.synth[i] = a.synth[(long)b * 480 + i];
   for (int i = lane; i < 176; i += WAVE) L.ceps[i] = a.ceps[(long)b * 176 + i];
   for (int i = lane; i < 168; i += WAVE) L.rnn_state[i] = a.rnn[(long)b * 168 + i];
-  if (lane < 24) {
-    L.lastg[lane] = lane < RN_NB ? a.lastg[(long)b * RN_NB + lane] : 0.f;
-    L.g[lane] = 0.f;
+  float2 synth[4];  // overlap-add tail, samples (2n, 2n+1) for n = lane + 64 m
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int n = lane + WAVE * m;
+    synth[m] = n < 240 ? *reinterpret_cast<const float2*>(a.synth + (long)b * 480 + 2 * n) : make_float2(0.f, 0.f);
   }
-  if (lane < 2) L.feat[42 + lane] = 0.f;
-  if (lane < 2) L.gru_in[114 + lane] = 0.f;
+  float lastg = lane < RN_NB ? a.lastg[(long)b * RN_NB + lane] : 0.f;
+  BandEdges be;
+  {
+    const int i = min(lane, RN_NB - 1);
+    be.e0 = tab->eband[i];
+    be.e1 = tab->eband[i + 1];
+    be.em1 = tab->eband[max(i - 1, 0)];
+  }
   int memid = a.memid[b];
   int last_period = a.last_period[b];
   float last_gain = a.last_gain[b];
   __syncthreads();
 
-  float* lp = reinterpret_cast<float*>(L.P);  // 864 floats, aliases P until the pitch frame
-  float* Xf = reinterpret_cast<float*>(L.X);
+  float* lp = reinterpret_cast<float*>(L.Bb);  // 864 floats during the pitch phase
+  float* Sa = reinterpret_cast<float*>(L.A);   // pitch-phase scratch
+  float* Rb = reinterpret_cast<float*>(L.Bb);  // RNN vectors after the pitch spectrum is parked
+  float* Xf = reinterpret_cast<float*>(L.A);
 
+  RN_PROF_DECL
   for (int t = 0; t < a.T; ++t) {
+    // Launder the lane id and the table / weight base pointers once per frame: every per-lane table
+    // address is loop-invariant, and without this the compiler hoists ~250 of them out of the frame
+    // loop into registers (429 VGPR+AGPR, one wave per SIMD).  Opaque values keep them per-frame.
+    lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const RnTables* tabv = a.tab;
+    const uint32_t* wp = a.wpack;
+    asm volatile("" : "+s"(tabv), "+s"(wp)::"memory");
+    const RnTables* __restrict__ tab = tabv;
+    const float2* __restrict__ w960 = tab->w960;
+    const float* __restrict__ hw = tab->half_window;
+    const float* __restrict__ tansig = tab->tansig;
+    const float* __restrict__ wpf = reinterpret_cast<const float*>(wp);
     const float* xw = xs + (long)(t + 3) * RN_FRAME;  // [x_prev, x_cur]
     const float* pb = xs + (long)t * RN_FRAME + 672;  // 1728-sample pitch buffer ending at x_cur
 
-    // ---- 1. frame_analysis: window, 960-point real FFT, band energies ----
-    for (int n = lane; n < 480; n += WAVE) {
-      const float2 v = *reinterpret_cast<const float2*>(xw + 2 * n);
-      const int i0 = 2 * n, i1 = 2 * n + 1;
-      const float w0 = i0 < 480 ? hw[i0] : hw[959 - i0];
-      const float w1 = i1 < 480 ? hw[i1] : hw[959 - i1];
-      L.X[n] = make_float2(v.x * w0, v.y * w1);
-    }
-    __syncthreads();
-    fft480(L.X, w960, lane);
-    real_fwd_post(L.X, w960, lane);
-    band_sums<false>(L.X, nullptr, L.S, L.Ex, lane);
-
-    // ---- 2. pitch: half-rate, LPC whitening ----
+    // ---- 1. pitch: half-rate, LPC whitening (lp in Bb) ----
     for (int i = lane; i < 864; i += WAVE) {
-      const float x1 = pb[2 * i], x2 = pb[2 * i + 1];
+      const float2 v = *reinterpret_cast<const float2*>(pb + 2 * i);
       const float x0 = i > 0 ? pb[2 * i - 1] : 0.f;
-      lp[i] = .5f * (.5f * (x0 + x2) + x1);
+      lp[i] = .5f * (.5f * (x0 + v.y) + v.x);
     }
     __syncthreads();
     float lpc2[5];
@@ -499,12 +532,14 @@ __global__ __launch_bounds__(WAVE) void rn_frame_kernel(RnArgs a) {
         if (base + q < 864) lp[base + q] = y[q];
       __syncthreads();
     }
+    STAMP(0)
 
-    // ---- 3. pitch_search: 4x-decimated coarse search over 147 lags ----
-    float* x4 = L.S;        // 240
-    float* y4 = L.S + 240;  // 387
+    // ---- 2. pitch_search: 4x-decimated coarse search over 147 lags (scratch in A) ----
+    float* x4 = Sa;        // 240
+    float* y4 = Sa + 240;  // 387 (+ guard to 392)
+    float* pre = Sa;       // 392: exclusive prefix sums of y4^2, written after x4/y4 are dead (aliases them)
     for (int j = lane; j < 240; j += WAVE) x4[j] = lp[384 + 2 * j];
-    for (int j = lane; j < 387; j += WAVE) y4[j] = lp[2 * j];
+    for (int j = lane; j < 392; j += WAVE) y4[j] = j < 387 ? lp[2 * j] : 0.f;
     __syncthreads();
     int best0, best1;
     {
@@ -532,21 +567,32 @@ __global__ __launch_bounds__(WAVE) void rn_frame_kernel(RnArgs a) {
           xc[2] = fmaf(xv.w, yp2[j + 3], xc[2]);
         }
       }
-      // running energy Syy of find_best_pitch, captured at this lane's lags
-      float part = 0.f;
-      for (int j = lane; j < 240; j += WAVE) part = fmaf(y4[j], y4[j], part);
-      float Syy = 1.f + wave_sum(part);
-      float syy[3] = {1.f, 1.f, 1.f};
-      for (int i = 0; i < 147; ++i) {
-        if ((i & 63) == lane) {
-          if ((i >> 6) == 0) syy[0] = Syy;
-          else if ((i >> 6) == 1) syy[1] = Syy;
-          else syy[2] = Syy;
+      STAMP(1)
+      // Syy of find_best_pitch: Syy(lag) = 1 + sum_{j=lag}^{lag+239} y4[j]^2 from a wave prefix sum.
+      // (the reference's running update is the same quantity; its max(1, .) clamp only guards rounding)
+      {
+        float loc[7];
+        float run = 0.f;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+          const int j = 7 * lane + q;
+          const float v = j < 392 ? y4[j] : 0.f;
+          loc[q] = run;          // exclusive
+          run = fmaf(v, v, run);
         }
-        const float ya = y4[i + 240], yb = y4[i];
-        Syy += ya * ya - yb * yb;
-        Syy = fmaxf(1.f, Syy);
+        float incl = run;
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+          const float o = __shfl_up(incl, off, WAVE);
+          if (lane >= off) incl += o;
+        }
+        const float excl = incl - run;
+        __syncthreads();  // every lane has read its y4 values before pre overwrites the region
+#pragma unroll
+        for (int q = 0; q < 7; ++q)
+          if (7 * lane + q < 392) pre[7 * lane + q] = excl + loc[q];
       }
+      __syncthreads();
       // this lane's best two candidates, in lag order
       Cand c0 = {-1.f, 0.f, 1 << 20}, c1 = {-1.f, 0.f, 1 << 20};
       int nvalid = 0;
@@ -554,28 +600,27 @@ __global__ __launch_bounds__(WAVE) void rn_frame_kernel(RnArgs a) {
       for (int rr = 0; rr < 3; ++rr) {
         const int lag = lane + WAVE * rr;
         if (lag < 147 && xc[rr] > 0.f) {
+          const float syy = fmaxf(1.f, 1.f + (pre[lag + 240] - pre[lag]));
           const float x16 = xc[rr] * 1e-12f;
-          const Cand c = {x16 * x16, syy[rr], lag};
+          const Cand c = {x16 * x16, syy, lag};
           ++nvalid;
           if (cand_better(c, c0)) { c1 = c0; c0 = c; }
           else if (cand_better(c, c1)) c1 = c;
         }
       }
-      int total_valid = nvalid;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) total_valid += __shfl_xor(total_valid, off, WAVE);
+      const int total_valid = __popcll(__ballot(nvalid > 0)) == 0 ? 0 : (int)wave_sum((float)nvalid);
       const Cand w0 = wave_best(c0);
-      // second best: the winner's lane offers its runner-up
-      const Cand mine = (c0.idx == w0.idx) ? c1 : c0;
+      const Cand mine = (c0.idx == w0.idx) ? c1 : c0;   // the winner's lane offers its runner-up
       const Cand w1 = wave_best(mine);
       if (total_valid == 0) { best0 = 0; best1 = 1; }
       else if (total_valid == 1) { best0 = w0.idx; best1 = 0; }
       else { best0 = w0.idx; best1 = w1.idx; }
     }
     __syncthreads();
+    STAMP(2)
 
-    // ---- 4. fine search at half rate around the two coarse candidates ----
-    float* fine = L.S;  // 294 (+2 guard) correlation values, zero where not evaluated
+    // ---- 3. fine search at half rate around the two coarse candidates ----
+    float* fine = Sa;  // 294 (+2 guard) correlation values, zero where not evaluated
     for (int i = lane; i < 296; i += WAVE) fine[i] = 0.f;
     __syncthreads();
     int pitch_index;
@@ -617,16 +662,17 @@ __global__ __launch_bounds__(WAVE) void rn_frame_kernel(RnArgs a) {
       pitch_index = 768 - (2 * bp - offset);
     }
     __syncthreads();
+    STAMP(3)
     if (a.dbg && t == a.T - 1) {
       float* D = a.dbg + (long)b * RN_DBG_FLOATS;
-      for (int i = lane; i < 962; i += WAVE) D[0 + i] = Xf[i];
-      if (lane < RN_NB) D[962 + lane] = L.Ex[lane];
       for (int i = lane; i < 864; i += WAVE) D[984 + i] = lp[i];
       if (lane == 0) D[1848] = (float)pitch_index;
+#ifndef RN_PROFILE
       for (int i = lane; i < 480; i += WAVE) D[3824 + i] = xw[480 + i];
+#endif
     }
 
-    // ---- 5. remove_doubling at half rate (maxperiod 384, minperiod 30, N 480) ----
+    // ---- 4. remove_doubling at half rate (maxperiod 384, minperiod 30, N 480) ----
     float pitch_gain;
     {
       const float* x = lp + 384;
@@ -643,7 +689,7 @@ __global__ __launch_bounds__(WAVE) void rn_frame_kernel(RnArgs a) {
       xx = wave_sum(xx);
       xy = wave_sum(xy);
       // yy_lookup[m] = max(0, xx + sum_{q<=m} (x[-q]^2 - x[480-q]^2)) via a wave prefix sum
-      float* yyl = L.S + 296;  // 385 entries
+      float* yyl = Sa + 296;  // 385 entries
       {
         float loc[6];
         float run = 0.f;
@@ -697,7 +743,7 @@ __global__ __launch_bounds__(WAVE) void rn_frame_kernel(RnArgs a) {
         if (g1 > thresh) { best_xy = xyk; best_yy = yyk; T = T1; g = g1; }
       }
       best_xy = fmaxf(0.f, best_xy);
-      float pg = (best_yy <= best_xy) ? 1.f : best_xy / (best_yy + 1.f);
+      float pgv = (best_yy <= best_xy) ? 1.f : best_xy / (best_yy + 1.f);
       float xc3[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
@@ -709,37 +755,74 @@ __global__ __launch_bounds__(WAVE) void rn_frame_kernel(RnArgs a) {
       int offset = 0;
       if ((xc3[2] - xc3[0]) > .7f * (xc3[1] - xc3[0])) offset = 1;
       else if ((xc3[0] - xc3[2]) > .7f * (xc3[1] - xc3[2])) offset = -1;
-      if (pg > g) pg = g;
+      if (pgv > g) pgv = g;
       pitch_index = 2 * T + offset;
       if (pitch_index < 60) pitch_index = 60;
-      pitch_gain = pg;
+      pitch_gain = pgv;
       last_period = pitch_index;
-      last_gain = pg;
+      last_gain = pgv;
     }
     __syncthreads();
+    STAMP(4)
 
-    // ---- 6. pitch frame: window, FFT, band energy / correlation ----
+    // ---- 5. frame_analysis: window, 960-point real FFT (in A), band energies (partials in Bb) ----
+    for (int n = lane; n < 480; n += WAVE) {
+      const float2 v = *reinterpret_cast<const float2*>(xw + 2 * n);
+      const int i0 = 2 * n, i1 = 2 * n + 1;
+      const float w0 = i0 < 480 ? hw[i0] : hw[959 - i0];
+      const float w1 = i1 < 480 ? hw[i1] : hw[959 - i1];
+      L.A[n] = make_float2(v.x * w0, v.y * w1);
+    }
+    __syncthreads();
+    fft480(L.A, w960, lane);
+    real_fwd_post(L.A, w960, lane);
+    STAMP(5)
+    band_sums<false, false>(L.A, nullptr, Rb, L.Ex, tab, be, lane);
+    STAMP(6)
+    if (a.dbg && t == a.T - 1) {
+      float* D = a.dbg + (long)b * RN_DBG_FLOATS;
+      for (int i = lane; i < 962; i += WAVE) D[0 + i] = Xf[i];
+      if (lane < RN_NB) D[962 + lane] = L.Ex[lane];
+    }
+
+    // ---- 6. pitch frame: window, FFT (in Bb), band energy / correlation (partials in U) ----
     {
       const float* pp = pb + (768 - pitch_index);
       for (int n = lane; n < 480; n += WAVE) {
         const int i0 = 2 * n, i1 = 2 * n + 1;
         const float w0 = i0 < 480 ? hw[i0] : hw[959 - i0];
         const float w1 = i1 < 480 ? hw[i1] : hw[959 - i1];
-        L.P[n] = make_float2(pp[i0] * w0, pp[i1] * w1);
+        L.Bb[n] = make_float2(pp[i0] * w0, pp[i1] * w1);
       }
     }
     __syncthreads();
-    fft480(L.P, w960, lane);
-    real_fwd_post(L.P, w960, lane);
-    band_sums<false>(L.P, nullptr, L.S, L.Ep, lane);
-    band_sums<true>(L.X, L.P, L.S, L.Exp, lane);
+    fft480(L.Bb, w960, lane);
+    real_fwd_post(L.Bb, w960, lane);
+    STAMP(7)
+    band_sums<false, false>(L.Bb, nullptr, L.U, L.Ep, tab, be, lane);
+    band_sums<true, false>(L.A, L.Bb, L.U, L.Exp, tab, be, lane);
+    // park P in L2 (read back by the comb filter); Bb becomes the RNN workspace
+    for (int i = lane; i < RN_NFREQ; i += WAVE) pg[i] = L.Bb[i];
+    if (a.dbg && t == a.T - 1) {
+      float* D = a.dbg + (long)b * RN_DBG_FLOATS;
+      const float* Pf = reinterpret_cast<const float*>(L.Bb);
+      for (int i = lane; i < 962; i += WAVE) D[1856 + i] = Pf[i];
+    }
+    __syncthreads();
+    STAMP(8)
 
     // ---- 7. features (Appendix A.3 step 5) ----
     if (lane < RN_NB) {
       L.Exp[lane] = L.Exp[lane] / sqrtf(.001f + L.Ex[lane] * L.Ep[lane]);
-      L.Ly[lane] = log10f(1e-2f + L.Ex[lane]);
+      L.U[U_LY + lane] = log10f(1e-2f + L.Ex[lane]);
     }
+    if (lane < 2) { Rb[RB_FEAT + 42 + lane] = 0.f; }
     __syncthreads();
+    if (a.dbg && t == a.T - 1 && lane < RN_NB) {
+      float* D = a.dbg + (long)b * RN_DBG_FLOATS;
+      D[2818 + lane] = L.Ep[lane];
+      D[2840 + lane] = L.Exp[lane];
+    }
     const float dct_norm = 0.30151134457776363f;  // sqrt(2/22)
     if (lane < 6) {
       float sum = 0.f;
@@ -747,36 +830,36 @@ __global__ __launch_bounds__(WAVE) void rn_frame_kernel(RnArgs a) {
       float v = sum * dct_norm;
       if (lane == 0) v -= 1.3f;
       if (lane == 1) v -= 0.9f;
-      L.feat[34 + lane] = v;
+      Rb[RB_FEAT + 34 + lane] = v;
     }
-    if (lane == 6) L.feat[40] = .01f * (float)(pitch_index - 300);
+    if (lane == 6) Rb[RB_FEAT + 40] = .01f * (float)(pitch_index - 300);
     float E = 0.f;
     {
       float logMax = -2.f, follow = -2.f;
       for (int i = 0; i < RN_NB; ++i) {
-        float ly = L.Ly[i];
+        float ly = L.U[U_LY + i];
         ly = fmaxf(logMax - 7.f, fmaxf(follow - 1.5f, ly));
         logMax = fmaxf(logMax, ly);
         follow = fmaxf(follow - 1.5f, ly);
         E += L.Ex[i];
-        if (lane == i) L.tmp22[i] = ly;
+        if (lane == i) L.U[U_TMP + i] = ly;
       }
     }
     __syncthreads();
     const bool silence = E < 0.04f;
     float vad_prob = 0.f;
     if (silence) {
-      if (lane < RN_NFEAT) L.feat[lane] = 0.f;
-      if (lane < RN_NB) L.g[lane] = 0.f;
+      if (lane < RN_NFEAT) Rb[RB_FEAT + lane] = 0.f;
+      if (lane < RN_NB) L.U[U_G + lane] = 0.f;
       __syncthreads();
     } else {
       if (lane < RN_NB) {
         float sum = 0.f;
-        for (int j = 0; j < RN_NB; ++j) sum = fmaf(L.tmp22[j], tab->dct[j * RN_NB + lane], sum);
+        for (int j = 0; j < RN_NB; ++j) sum = fmaf(L.U[U_TMP + j], tab->dct[j * RN_NB + lane], sum);
         float v = sum * dct_norm;
         if (lane == 0) v -= 12.f;
         if (lane == 1) v -= 4.f;
-        L.feat[lane] = v;
+        Rb[RB_FEAT + lane] = v;
         L.ceps[memid * RN_NB + lane] = v;
       }
       __syncthreads();
@@ -787,9 +870,9 @@ __global__ __launch_bounds__(WAVE) void rn_frame_kernel(RnArgs a) {
           const float c0 = L.ceps[memid * RN_NB + lane];
           const float c1 = L.ceps[m1 * RN_NB + lane];
           const float c2 = L.ceps[m2 * RN_NB + lane];
-          L.feat[lane] = c0 + c1 + c2;
-          L.feat[RN_NB + lane] = c0 - c2;
-          L.feat[RN_NB + 6 + lane] = c0 - 2.f * c1 + c2;
+          Rb[RB_FEAT + lane] = c0 + c1 + c2;
+          Rb[RB_FEAT + RN_NB + lane] = c0 - c2;
+          Rb[RB_FEAT + RN_NB + 6 + lane] = c0 - 2.f * c1 + c2;
         }
         memid = (memid + 1 == 8) ? 0 : memid + 1;
       }
@@ -808,91 +891,100 @@ __global__ __launch_bounds__(WAVE) void rn_frame_kernel(RnArgs a) {
         float sv = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) sv += __shfl(md, 8 * i, WAVE);
-        if (lane == 0) L.feat[41] = sv / 8.f - 2.1f;
+        if (lane == 0) Rb[RB_FEAT + 41] = sv / 8.f - 2.1f;
       }
       __syncthreads();
+      STAMP(9)
 
-      // ---- 8. RNN ----
+      // ---- 8. RNN (vectors in Bb) ----
       const float S = 1.f / 256.f;
+      float* feat = Rb + RB_FEAT;
+      float* dense = Rb + RB_DENSE;
+      float* gin = Rb + RB_IN;
       if (lane < 24) {
         float acc = wpf[RnPack::ID_B + lane];
-        acc = dot_i8(wp + RnPack::ID_W, 24, lane, L.feat, RnPack::k4(42), acc);
-        L.dense[lane] = tansig_approx(S * acc, tansig);
+        acc = dot_i8<rn_k4(42)>(wp + RnPack::ID_W, 24, lane, feat, acc);
+        dense[lane] = tansig_approx(S * acc, tansig);
       }
       __syncthreads();
-      gru_layer<24, 24>(wp + RnPack::VG_W, wp + RnPack::VG_R, wpf + RnPack::VG_B, L.dense,
-                        L.rnn_state, L.pre, L.zbuf, L.hr, tansig, lane);
+      gru_layer<24, 24>(wp + RnPack::VG_W, wp + RnPack::VG_R, wpf + RnPack::VG_B, dense,
+                        L.rnn_state, Rb + RB_Z, Rb + RB_HR, tansig, lane);
       if (lane == 0) {
         float acc = wpf[RnPack::VO_B];
-        acc = dot_i8(wp + RnPack::VO_W, 1, 0, L.rnn_state, RnPack::k4(24), acc);
-        L.tmp22[23] = sigmoid_approx(S * acc, tansig);
+        acc = dot_i8<rn_k4(24)>(wp + RnPack::VO_W, 1, 0, L.rnn_state, acc);
+        L.U[U_VAD] = sigmoid_approx(S * acc, tansig);
       }
-      for (int i = lane; i < 90; i += WAVE)
-        L.gru_in[i] = i < 24 ? L.dense[i] : (i < 48 ? L.rnn_state[i - 24] : L.feat[i - 48]);
-      if (lane < 2) L.gru_in[90 + lane] = 0.f;
+      for (int i = lane; i < 92; i += WAVE)
+        gin[i] = i < 24 ? dense[i] : (i < 48 ? L.rnn_state[i - 24] : (i < 90 ? feat[i - 48] : 0.f));
       __syncthreads();
-      vad_prob = L.tmp22[23];
-      gru_layer<90, 48>(wp + RnPack::NG_W, wp + RnPack::NG_R, wpf + RnPack::NG_B, L.gru_in,
-                        L.rnn_state + 24, L.pre, L.zbuf, L.hr, tansig, lane);
-      for (int i = lane; i < 114; i += WAVE)
-        L.gru_in[i] = i < 72 ? L.rnn_state[i] : L.feat[i - 72];
-      if (lane < 2) L.gru_in[114 + lane] = 0.f;
+      vad_prob = L.U[U_VAD];
+      STAMP(10)
+      gru_layer<90, 48>(wp + RnPack::NG_W, wp + RnPack::NG_R, wpf + RnPack::NG_B, gin,
+                        L.rnn_state + 24, Rb + RB_Z, Rb + RB_HR, tansig, lane);
+      STAMP(11)
+      for (int i = lane; i < 116; i += WAVE)
+        gin[i] = i < 72 ? L.rnn_state[i] : (i < 114 ? feat[i - 72] : 0.f);
       __syncthreads();
-      gru_layer<114, 96>(wp + RnPack::DG_W, wp + RnPack::DG_R, wpf + RnPack::DG_B, L.gru_in,
-                         L.rnn_state + 72, L.pre, L.zbuf, L.hr, tansig, lane);
+      gru_layer<114, 96>(wp + RnPack::DG_W, wp + RnPack::DG_R, wpf + RnPack::DG_B, gin,
+                         L.rnn_state + 72, Rb + RB_Z, Rb + RB_HR, tansig, lane);
       if (lane < RN_NB) {
         float acc = wpf[RnPack::DO_B + lane];
-        acc = dot_i8(wp + RnPack::DO_W, RN_NB, lane, L.rnn_state + 72, RnPack::k4(96), acc);
-        L.g[lane] = sigmoid_approx(S * acc, tansig);
+        acc = dot_i8<rn_k4(96)>(wp + RnPack::DO_W, RN_NB, lane, L.rnn_state + 72, acc);
+        L.U[U_G + lane] = sigmoid_approx(S * acc, tansig);
       }
       __syncthreads();
+      STAMP(12)
 
       // ---- 9. pitch_filter + gain application (Appendix A.3 step 7) ----
       if (lane < RN_NB) {
-        const float ex = L.Exp[lane], gg = L.g[lane];
+        const float ex = L.Exp[lane], gg = L.U[U_G + lane];
         float r;
         if (ex > gg) r = 1.f;
         else r = (ex * ex) * (1.f - gg * gg) / (.001f + (gg * gg) * (1.f - ex * ex));
         r = sqrtf(fminf(1.f, fmaxf(0.f, r)));
         r *= sqrtf(L.Ex[lane] / (1e-8f + L.Ep[lane]));
-        L.r[lane] = r;
+        L.U[U_R + lane] = r;
       }
-      if (lane == RN_NB) L.r[RN_NB] = 0.f;
       __syncthreads();
-      for (int i = lane; i < RN_NFREQ; i += WAVE) {
-        const float rf = interp_gain(L.r, i);
-        float2 x = L.X[i];
-        const float2 p = L.P[i];
+      for (int i = lane; i < 400; i += WAVE) {
+        const float rf = interp_gain(L.U + U_R, tab->bin_band[i], tab->bin_frac[i]);
+        float2 x = L.A[i];
+        const float2 p = pg[i];
         x.x = fmaf(rf, p.x, x.x);
         x.y = fmaf(rf, p.y, x.y);
-        L.X[i] = x;
+        L.A[i] = x;
       }
       __syncthreads();
-      band_sums<false>(L.X, nullptr, L.S, L.tmp22, lane);  // newE
+      band_sums<false, false>(L.A, nullptr, Rb + RB_PART, L.Ep, tab, be, lane);  // newE (Ep is dead)
       if (lane < RN_NB) {
-        L.r[lane] = sqrtf(L.Ex[lane] / (1e-8f + L.tmp22[lane]));  // norm
-        const float gg = fmaxf(L.g[lane], .6f * L.lastg[lane]);
-        L.g[lane] = gg;
-        L.lastg[lane] = gg;
+        L.U[U_R + lane] = sqrtf(L.Ex[lane] / (1e-8f + L.Ep[lane]));  // norm
+        const float gg = fmaxf(L.U[U_G + lane], .6f * lastg);
+        L.U[U_G + lane] = gg;
+        lastg = gg;
       }
-      if (lane == RN_NB) L.g[RN_NB] = 0.f;
       __syncthreads();
       for (int i = lane; i < RN_NFREQ; i += WAVE) {
-        const float nf = interp_gain(L.r, i);
-        const float gf = interp_gain(L.g, i);
-        float2 x = L.X[i];
-        x.x *= nf; x.y *= nf;
-        x.x *= gf; x.y *= gf;
-        L.X[i] = x;
+        float2 x = make_float2(0.f, 0.f);
+        if (i < 400) {
+          const int band = tab->bin_band[i];
+          const float frac = tab->bin_frac[i];
+          const float nf = interp_gain(L.U + U_R, band, frac);
+          const float gf = interp_gain(L.U + U_G, band, frac);
+          x = L.A[i];
+          x.x *= nf; x.y *= nf;
+          x.x *= gf; x.y *= gf;
+        }
+        L.A[i] = x;
       }
       __syncthreads();
     }
+    STAMP(13)
 
     // ---- taps / debug ----
     if (a.taps) {
       float* tp = a.taps + ((long)t * a.B + b) * RN_TAPS;
-      if (lane < RN_NFEAT) tp[lane] = L.feat[lane];
-      if (lane < RN_NB) tp[42 + lane] = L.g[lane];
+      if (lane < RN_NFEAT) tp[lane] = Rb[RB_FEAT + lane];
+      if (lane < RN_NB) tp[42 + lane] = L.U[U_G + lane];
       if (lane == 0) {
         tp[64] = (float)pitch_index;
         tp[65] = pitch_gain;
@@ -904,42 +996,51 @@ __global__ __launch_bounds__(WAVE) void rn_frame_kernel(RnArgs a) {
     if (a.vad && lane == 0) a.vad[(long)t * a.B + b] = vad_prob;
     if (a.dbg && t == a.T - 1) {
       float* D = a.dbg + (long)b * RN_DBG_FLOATS;
-      const float* Pf = reinterpret_cast<const float*>(L.P);
-      for (int i = lane; i < 962; i += WAVE) D[1856 + i] = Pf[i];
-      if (lane < RN_NB) { D[2818 + lane] = L.Ep[lane]; D[2840 + lane] = L.Exp[lane]; }
       for (int i = lane; i < 962; i += WAVE) D[2862 + i] = Xf[i];
     }
     __syncthreads();
 
     // ---- 10. frame_synthesis: inverse FFT, window, overlap-add ----
-    real_inv_pre(L.X, w960, lane);
-    fft480(L.X, w960, lane);
+    real_inv_pre(L.A, w960, lane);
+    fft480(L.A, w960, lane);
+    STAMP(14)
     {
       float* o = a.out + (long)t * a.stride_t + (long)b * a.stride_b;
-      for (int n = lane; n < 240; n += WAVE) {
-        const float2 z = L.X[n];
-        const int i0 = 2 * n, i1 = 2 * n + 1;
-        float2 ov;
-        ov.x = fmaf(z.x, hw[i0], L.synth[i0]);
-        ov.y = fmaf(-z.y, hw[i1], L.synth[i1]);
-        *reinterpret_cast<float2*>(o + i0) = ov;
-      }
-      __syncthreads();
-      for (int n = lane; n < 240; n += WAVE) {
-        const float2 z = L.X[240 + n];
-        const int i0 = 2 * n, i1 = 2 * n + 1;
-        L.synth[i0] = z.x * hw[479 - i0];
-        L.synth[i1] = -z.y * hw[479 - i1];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int n = lane + WAVE * m;
+        if (n < 240) {
+          const float2 z = L.A[n];
+          const float2 z2 = L.A[240 + n];
+          const int i0 = 2 * n, i1 = 2 * n + 1;
+          float2 ov;
+          ov.x = fmaf(z.x, hw[i0], synth[m].x);
+          ov.y = fmaf(-z.y, hw[i1], synth[m].y);
+          *reinterpret_cast<float2*>(o + i0) = ov;
+          synth[m].x = z2.x * hw[479 - i0];
+          synth[m].y = -z2.y * hw[479 - i1];
+        }
       }
     }
     __syncthreads();
+    STAMP(15)
   }
 
+#ifdef RN_PROFILE
+  if (a.dbg && lane == 0) {
+    float* D = a.dbg + (long)b * RN_DBG_FLOATS;
+    for (int k = 0; k < 24; ++k) D[3824 + k] = (float)prof_[k];
+  }
+#endif
   // ---- store per-stream state ----
-  for (int i = lane; i < 480; i += WAVE) a.synth[(long)b * 480 + i] = L.synth[i];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int n = lane + WAVE * m;
+    if (n < 240) *reinterpret_cast<float2*>(a.synth + (long)b * 480 + 2 * n) = synth[m];
+  }
   for (int i = lane; i < 176; i += WAVE) a.ceps[(long)b * 176 + i] = L.ceps[i];
   for (int i = lane; i < 168; i += WAVE) a.rnn[(long)b * 168 + i] = L.rnn_state[i];
-  if (lane < RN_NB) a.lastg[(long)b * RN_NB + lane] = L.lastg[lane];
+  if (lane < RN_NB) a.lastg[(long)b * RN_NB + lane] = lastg;
   if (lane == 0) {
     a.memid[b] = memid;
     a.last_period[b] = last_period;

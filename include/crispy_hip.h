@@ -79,6 +79,10 @@ int crispy_rn_reset(crispy_rn *h, int stream);
 
 int crispy_rn_n_streams(const crispy_rn *h);
 
+/* Frames each rn_frame_kernel launch covers: a call of n frames is enqueued as ceil(n / this) launches
+ * whose high-pass runs one launch ahead on a helper stream (bench.py's per-launch roofline uses it). */
+int crispy_rn_frames_per_launch(void);
+
 /*
  * process_frame for every stream, n_frames consecutive frames each (audio.rs:268).
  * in/out are HOST pointers to n_frames*n_streams*480 floats in `layout`; samples are f32 in
