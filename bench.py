@@ -162,6 +162,15 @@ def main():
     fps = frames_total / dt
     if rank == 0:
         alg_bytes = BYTES_PER_STREAM_FRAME * B * min(T, fpl)
+        # HBM traffic per launch from the committed PMC passes (rocprofv3 cannot run inside this process);
+        # only quoted when it was measured on this exact launch shape.
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_v2_pmc_hbm.json")))
+            if pm["config"] == {"streams": B, "frames_per_launch": min(T, fpl)}:
+                traffic = pm["rn_frame_kernel"]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         achieved = alg_bytes / (frame_ms * 1e-3) / 1e9
         line = {
             "metric": "concurrent real-time 48 kHz streams/GPU (RNNoise)",
@@ -176,7 +185,7 @@ def main():
                        "streams_per_gpu": B, "frames_per_step": T, "sharding": f"streams x{world}, no collective",
                        "frames_per_s": fps, "output_finite": finite},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "rn_frame_kernel", "kernel_ms": frame_ms, "launches_per_step": launches,
                          "enqueue_ms": total_ms,
                          "alg_bytes_per_launch": alg_bytes},
