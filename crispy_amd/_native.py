@@ -28,7 +28,9 @@ RN_SYMBOLS = (
 )
 
 
-ALL_SYMBOLS = RN_SYMBOLS
+MEL_SYMBOLS = ("crispy_mel_create", "crispy_mel_destroy", "crispy_mel_compute",
+               "crispy_mel_compute_device", "crispy_mel_synchronize")
+ALL_SYMBOLS = RN_SYMBOLS + MEL_SYMBOLS
 
 class CrispyError(RuntimeError):
     def __init__(self, code: int, msg: str):
@@ -48,6 +50,14 @@ def lib() -> C.CDLL:
         raise FileNotFoundError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  crispy_amd has no CPU fallback.")
+    # PyTorch wheels bundle their own libamdhip64.so.7.  If this library pulled in /opt/rocm's copy
+    # first, a later `import torch` would load a second HIP runtime into the process and find no GPU.
+    # Loading torch first makes both share one runtime (same SONAME), and torch tensors' device
+    # pointers are then directly usable by the *_device entry points.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     f32p = C.POINTER(C.c_float)
     L.crispy_last_error.restype = C.c_char_p
@@ -66,6 +76,13 @@ def lib() -> C.CDLL:
     L.crispy_rn_last_kernel_ms.argtypes = [C.c_void_p, f32p, f32p]
     L.crispy_rn_debug_capture.argtypes = [C.c_void_p, C.c_int]
     L.crispy_rn_debug_read.argtypes = [C.c_void_p, C.c_int, f32p, C.c_size_t]
+    L.crispy_mel_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.crispy_mel_destroy.argtypes = [C.c_void_p]
+    L.crispy_mel_destroy.restype = None
+    L.crispy_mel_compute.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_void_p]
+    L.crispy_mel_compute_device.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_void_p,
+                                            C.c_void_p, C.c_void_p]
+    L.crispy_mel_synchronize.argtypes = [C.c_void_p]
     _lib = L
     return L
 

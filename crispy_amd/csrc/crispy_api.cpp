@@ -5,6 +5,7 @@
 // kernels per chunk of frames.  No CPU compute path exists here: without a gfx950 device every
 // constructor fails.
 #include "../../include/crispy_hip.h"
+#include "api_util.h"
 #include "rn_common.h"
 
 #include <cmath>
@@ -19,34 +20,8 @@ using namespace crispy;
 
 namespace {
 
-thread_local std::string g_last_error;
-
-int fail(int code, const char* fmt, ...) {
-  char buf[512];
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(buf, sizeof(buf), fmt, ap);
-  va_end(ap);
-  g_last_error = buf;
-  return code;
-}
-
-#define HIP_TRY(expr)                                                                      \
-  do {                                                                                     \
-    hipError_t _e = (expr);                                                                \
-    if (_e != hipSuccess)                                                                  \
-      return fail(_e == hipErrorOutOfMemory ? CRISPY_ERR_OOM : CRISPY_ERR_HIP, "%s: %s", #expr, \
-                  hipGetErrorString(_e));                                                  \
-  } while (0)
-
 constexpr int kChunkFrames = 250;   // workspace bound: frames of high-passed signal kept per call segment
 constexpr int kSubFrames = 25;      // pipeline grain: high-pass of sub-chunk i+1 overlaps the frame kernel of sub-chunk i
-
-bool device_is_gfx950(int dev) {
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
-  return std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
-}
 
 void build_tables(RnTables* t) {
   const double pi = 3.14159265358979323846;
@@ -200,7 +175,7 @@ int zero_state(crispy_rn* h, int stream) {
 
 extern "C" {
 
-const char* crispy_last_error(void) { return g_last_error.c_str(); }
+const char* crispy_last_error(void) { return last_error_cstr(); }
 
 const char* crispy_version(void) { return "crispy_hip 0.1.0 gfx950"; }
 
@@ -220,13 +195,10 @@ int crispy_rn_create(const int8_t* weights, size_t nbytes, int n_streams, int de
     return fail(CRISPY_ERR_BAD_MODEL, "crispy_rn_create: weights must be a %d-byte blob (got %zu)",
                 RN_WEIGHT_BYTES, weights ? nbytes : (size_t)0);
   if (n_streams <= 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_create: n_streams must be > 0");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-    return fail(CRISPY_ERR_NO_DEVICE, "crispy_rn_create: no HIP device (this library has no CPU path)");
-  if (device < 0 || device >= ndev)
-    return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_create: device %d out of range [0,%d)", device, ndev);
-  if (!device_is_gfx950(device))
-    return fail(CRISPY_ERR_NO_DEVICE, "crispy_rn_create: device %d is not gfx950 (MI355X)", device);
+  {
+    const int rc0 = check_device(device, "crispy_rn_create");
+    if (rc0 != CRISPY_OK) return rc0;
+  }
 
   crispy_rn* h = new (std::nothrow) crispy_rn();
   if (!h) return fail(CRISPY_ERR_OOM, "crispy_rn_create: host allocation failed");
@@ -267,10 +239,9 @@ int crispy_rn_create(const int8_t* weights, size_t nbytes, int n_streams, int de
   };
   rc = body();
   if (rc != CRISPY_OK) {
-    std::string keep = g_last_error;
+    const std::string keep = last_error_cstr();
     free_all(h);
-    g_last_error = keep;
-    return rc;
+    return fail(rc, "%s", keep.c_str());
   }
   *out = h;
   return CRISPY_OK;

@@ -80,3 +80,19 @@ def batch_torch(n_streams: int, n_frames: int, device, first_stream: int = 0, se
         x[silent] = 0.0
         out[t0:t1] = x.view(n_streams, t1 - t0, FRAME).transpose(0, 1)
     return out
+
+
+def clip16k_np(seed: int, n_samples: int = 480000) -> np.ndarray:
+    """Seeded 16 kHz test clip in +-1 for the ASR path (BASELINE cfg 3): sum of chirps with a syllabic
+    envelope plus coloured noise.  Deterministic across machines (numpy PCG64)."""
+    rng = np.random.default_rng(1000 + seed)
+    t = np.arange(n_samples, dtype=np.float64) / 16000.0
+    x = np.zeros(n_samples, dtype=np.float64)
+    for _ in range(4):
+        f0, f1 = rng.uniform(100, 1500), rng.uniform(100, 3500)
+        ph = 2 * np.pi * (f0 * t + 0.5 * (f1 - f0) * t * t / max(t[-1], 1e-3))
+        x += rng.uniform(0.05, 0.25) * np.sin(ph + rng.uniform(0, 6.28))
+    env = 0.55 + 0.45 * np.sin(2 * np.pi * rng.uniform(2.0, 5.0) * t + rng.uniform(0, 6.28))
+    noise = rng.standard_normal(n_samples)
+    noise = np.convolve(noise, np.ones(4) / 4.0, mode="same")
+    return (x * env + 0.03 * noise).astype(np.float32)

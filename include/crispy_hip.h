@@ -120,6 +120,38 @@ int crispy_rn_last_kernel_ms(crispy_rn *h, float *frame_kernel_ms, float *total_
 int crispy_rn_debug_capture(crispy_rn *h, int enable);
 int crispy_rn_debug_read(crispy_rn *h, int stream, float *dst, size_t n_floats);
 
+/* ------------------------------------------------------------------------------------------
+ * Log-mel front end of the ASR path: whisper.cpp `log_mel_spectrogram`, the first stage of
+ * transcribe_rs::SpeechModel::transcribe (managers/transcription.rs:183-185, 213-215).
+ * 16 kHz f32 PCM in +-1 -> [n_mel][3000] f32 per clip (the frames the encoder consumes):
+ * reflect-pad 200, periodic Hann 400, hop 160, power spectrum, mel filters, log10,
+ * clamp to (clip max - 8), (x + 4) / 4.  
+ * ------------------------------------------------------------------------------------------ */
+#define CRISPY_MEL_FRAMES 3000
+#define CRISPY_MEL_BINS 201
+
+typedef struct crispy_mel crispy_mel;
+
+/* filters: [n_mel][201] f32, the mel filter bank whisper.cpp reads from the model file
+ * (n_mel = 80, or 128 for large-v3). */
+int crispy_mel_create(const float *filters, int n_mel, int device, crispy_mel **out);
+void crispy_mel_destroy(crispy_mel *h);
+
+/* HOST pointers: pcm [batch][pcm_stride], n_samples[batch] (1..480000 each, the 30 s chunking of
+ * commands/transcription.rs:249-302 stays with the caller), out [batch][n_mel][3000].
+ * Returns when `out` is complete. */
+int crispy_mel_compute(crispy_mel *h, const float *pcm, long pcm_stride, const int *n_samples,
+                       int batch, float *out);
+
+/* DEVICE pcm / outputs (n_samples stays a host array); enqueued on hip_stream (NULL = the handle's
+ * stream) without waiting.  d_out [batch][n_mel][3000] and/or d_out_t [batch][3002][n_mel]
+ * (frame-major, one zero frame of padding on both sides: the layout the encoder's first
+ * convolution consumes); either may be NULL. */
+int crispy_mel_compute_device(crispy_mel *h, const float *d_pcm, long pcm_stride,
+                              const int *n_samples, int batch, float *d_out, float *d_out_t,
+                              void *hip_stream);
+int crispy_mel_synchronize(crispy_mel *h);
+
 #ifdef __cplusplus
 }
 #endif
