@@ -30,7 +30,9 @@ RN_SYMBOLS = (
 
 MEL_SYMBOLS = ("crispy_mel_create", "crispy_mel_destroy", "crispy_mel_compute",
                "crispy_mel_compute_device", "crispy_mel_synchronize")
-ALL_SYMBOLS = RN_SYMBOLS + MEL_SYMBOLS
+ASR_SYMBOLS = ("crispy_asr_create", "crispy_asr_set_tensor", "crispy_asr_finalize", "crispy_asr_free",
+               "crispy_asr_hparams_get", "crispy_asr_encode", "crispy_asr_encode_device", "crispy_asr_synchronize")
+ALL_SYMBOLS = RN_SYMBOLS + MEL_SYMBOLS + ASR_SYMBOLS
 
 class CrispyError(RuntimeError):
     def __init__(self, code: int, msg: str):
@@ -83,6 +85,15 @@ def lib() -> C.CDLL:
     L.crispy_mel_compute_device.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_void_p,
                                             C.c_void_p, C.c_void_p]
     L.crispy_mel_synchronize.argtypes = [C.c_void_p]
+    L.crispy_asr_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.crispy_asr_set_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
+    L.crispy_asr_finalize.argtypes = [C.c_void_p]
+    L.crispy_asr_free.argtypes = [C.c_void_p]
+    L.crispy_asr_free.restype = None
+    L.crispy_asr_hparams_get.argtypes = [C.c_void_p, C.c_void_p]
+    L.crispy_asr_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_void_p]
+    L.crispy_asr_encode_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.crispy_asr_synchronize.argtypes = [C.c_void_p]
     _lib = L
     return L
 

@@ -63,3 +63,61 @@ class LogMel:
 
     def synchronize(self):
         N.check(N.lib().crispy_mel_synchronize(self._h))
+
+
+class WhisperModel:
+    """Model container + engine on the GPU (`WhisperEngine::load` + `SpeechModel::transcribe`,
+    managers/transcription.rs:138-141, 183-185).  Tensors are given by name in PyTorch layout."""
+
+    def __init__(self, hp, weights: dict, filters: np.ndarray | None = None, device: int = 0):
+        from .whisper_weights import tensor_shapes
+
+        f = whisper_mel_filters(hp.n_mels) if filters is None else np.ascontiguousarray(filters, dtype=np.float32)
+        self.hp = hp
+        self._h = C.c_void_p()
+        hpa = (C.c_int * 10)(*hp.as_ints())
+        N.check(N.lib().crispy_asr_create(hpa, f.ctypes.data, device, C.byref(self._h)))
+        for name, shape in tensor_shapes(hp).items():
+            if name not in weights:
+                raise KeyError(f"missing tensor {name}")
+            w = np.ascontiguousarray(weights[name], dtype=np.float32)
+            if w.shape != tuple(shape):
+                raise ValueError(f"{name}: shape {w.shape}, expected {tuple(shape)}")
+            N.check(N.lib().crispy_asr_set_tensor(self._h, name.encode(), w.ctypes.data, w.size))
+        N.check(N.lib().crispy_asr_finalize(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            N.lib().crispy_asr_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _pack(clips):
+        if isinstance(clips, np.ndarray) and clips.ndim == 2:
+            return np.ascontiguousarray(clips, dtype=np.float32), np.full(clips.shape[0], clips.shape[1], np.int32)
+        clips = [np.ascontiguousarray(c, dtype=np.float32).ravel() for c in clips]
+        lens = np.array([c.size for c in clips], dtype=np.int32)
+        pcm = np.zeros((len(clips), int(lens.max())), dtype=np.float32)
+        for i, c in enumerate(clips):
+            pcm[i, :c.size] = c
+        return pcm, lens
+
+    def encode(self, clips) -> np.ndarray:
+        """PCM clips (16 kHz, <= 30 s each) -> encoder output [B, 1500, d]."""
+        pcm, lens = self._pack(clips)
+        out = np.empty((pcm.shape[0], self.hp.n_audio_ctx, self.hp.n_audio_state), dtype=np.float32)
+        N.check(N.lib().crispy_asr_encode(self._h, pcm.ctypes.data, pcm.shape[1], lens.ctypes.data, pcm.shape[0],
+                                          out.ctypes.data))
+        return out
+
+    def encode_device(self, d_mel_t: int, batch: int, d_out: int, stream: int = 0):
+        N.check(N.lib().crispy_asr_encode_device(self._h, d_mel_t, batch, d_out, stream or None))
+
+    def synchronize(self):
+        N.check(N.lib().crispy_asr_synchronize(self._h))

@@ -32,4 +32,26 @@ struct MelArgs {
 
 hipError_t mel_launch(const MelArgs& a, int batch, hipStream_t s);
 
+// C[M,N] = A[M,K] . W[N,K]^T (+bias) (GELU) (+residual) (+rowtab[m % period]); all f32, row-major.
+// A may be a strided view (lda < K): rows overlap, which is how the two convolutions are expressed.
+struct GemmArgs {
+  const float* A; long lda; long strideA;     // strideA/strideC/strideR: per-batch element strides (grid z)
+  const float* W; long ldw;
+  float* C; long ldc; long strideC;
+  const float* bias;
+  const float* residual; long ldr; long strideR;
+  const float* rowtab; int rowtab_period;
+  int M, N, K;
+  int gelu;
+};
+hipError_t gemm_f32_nt(const GemmArgs& g, int batch, hipStream_t s);
+hipError_t layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, long rows, int D, hipStream_t s);
+hipError_t attn_encoder_f32(const float* qkv, float* out, int B, int T, int D, int heads, hipStream_t s);
+hipError_t attn_decoder_f32(const float* q, long ldq, const float* kv, long kv_batch_stride, long ldkv, int koff,
+                            int voff, int n_keys, float* out, long ldo, int B, int heads, hipStream_t s);
+hipError_t embed_tokens_f32(const int* tokens, const float* tok_emb, const float* pos_emb, int pos, float* x, int B,
+                            int D, hipStream_t s);
+hipError_t argmax_f32(const float* logits, const unsigned char* mask, int V, int* tokens_out, float* best, int B,
+                      hipStream_t s);
+
 }  // namespace crispy

@@ -1,0 +1,428 @@
+// whisper_api.cpp -- extern "C" Whisper entry points (include/crispy_hip.h): model container,
+// encoder, greedy decoder.  Replaces transcribe_rs::whisper_cpp::WhisperEngine::{load, transcribe}
+// (reference: src-tauri/src/managers/transcription.rs:138-141, 183-185).
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/crispy_hip.h"
+#include "api_util.h"
+#include "asr_common.h"
+
+using namespace crispy;
+
+namespace {
+
+struct Tensor {
+  float* d = nullptr;
+  size_t n = 0;
+  bool set = false;
+};
+
+struct EncLayer {
+  const float *ln1_w, *ln1_b, *qkv_w, *qkv_b, *out_w, *out_b, *ln2_w, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+};
+struct DecLayer {
+  const float *ln1_w, *ln1_b, *qkv_w, *qkv_b, *out_w, *out_b;
+  const float *lnx_w, *lnx_b, *xq_w, *xq_b, *xkv_w, *xkv_b, *xout_w, *xout_b;
+  const float *ln2_w, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+};
+
+}  // namespace
+
+struct crispy_asr {
+  int device = 0;
+  crispy_asr_hparams hp{};
+  hipStream_t stream = nullptr;
+  crispy_mel* mel = nullptr;
+  std::map<std::string, Tensor> tensors;   // as named by the model file
+  std::vector<float*> derived;             // fused / reordered copies owned by the handle
+  bool finalized = false;
+  // resolved pointers
+  const float *conv1_w = nullptr, *conv1_b = nullptr, *conv2_w = nullptr, *conv2_b = nullptr, *enc_pos = nullptr;
+  const float *ln_post_w = nullptr, *ln_post_b = nullptr;
+  std::vector<EncLayer> enc;
+  const float *tok_emb = nullptr, *dec_pos = nullptr, *dec_ln_w = nullptr, *dec_ln_b = nullptr;
+  std::vector<DecLayer> dec;
+  unsigned char* d_suppress = nullptr;      // [n_vocab] tokens never emitted by the greedy decoder
+  unsigned char* d_suppress_first = nullptr;  // additionally suppressed at the first sampled position
+  // workspace (grown on demand)
+  int cap_batch = 0;
+  float *w_melt = nullptr, *w_pcm = nullptr, *w_h1 = nullptr, *w_x = nullptr, *w_xn = nullptr, *w_qkv = nullptr,
+        *w_att = nullptr, *w_h = nullptr, *w_enc = nullptr;
+  long cap_pcm_stride = 0;
+  // decoder workspace
+  int dcap_batch = 0;
+  float *d_xkv = nullptr, *d_selfkv = nullptr, *d_dx = nullptr, *d_dxn = nullptr, *d_dq = nullptr, *d_datt = nullptr,
+        *d_dh = nullptr, *d_logits = nullptr, *d_best = nullptr;
+  int* d_tok = nullptr;
+  int* d_tokens_all = nullptr;
+};
+
+namespace {
+
+void add_spec(std::map<std::string, size_t>& spec, const std::string& name, size_t n) { spec[name] = n; }
+
+std::map<std::string, size_t> expected_tensors(const crispy_asr_hparams& hp) {
+  std::map<std::string, size_t> s;
+  const size_t d = hp.n_audio_state, dt = hp.n_text_state;
+  add_spec(s, "encoder.conv1.weight", d * hp.n_mels * 3);
+  add_spec(s, "encoder.conv1.bias", d);
+  add_spec(s, "encoder.conv2.weight", d * d * 3);
+  add_spec(s, "encoder.conv2.bias", d);
+  add_spec(s, "encoder.positional_embedding", (size_t)hp.n_audio_ctx * d);
+  for (int i = 0; i < hp.n_audio_layer; ++i) {
+    const std::string p = "encoder.blocks." + std::to_string(i) + ".";
+    add_spec(s, p + "attn_ln.weight", d); add_spec(s, p + "attn_ln.bias", d);
+    add_spec(s, p + "attn.query.weight", d * d); add_spec(s, p + "attn.query.bias", d);
+    add_spec(s, p + "attn.key.weight", d * d);
+    add_spec(s, p + "attn.value.weight", d * d); add_spec(s, p + "attn.value.bias", d);
+    add_spec(s, p + "attn.out.weight", d * d); add_spec(s, p + "attn.out.bias", d);
+    add_spec(s, p + "mlp_ln.weight", d); add_spec(s, p + "mlp_ln.bias", d);
+    add_spec(s, p + "mlp.0.weight", 4 * d * d); add_spec(s, p + "mlp.0.bias", 4 * d);
+    add_spec(s, p + "mlp.2.weight", 4 * d * d); add_spec(s, p + "mlp.2.bias", d);
+  }
+  add_spec(s, "encoder.ln_post.weight", d); add_spec(s, "encoder.ln_post.bias", d);
+  add_spec(s, "decoder.token_embedding.weight", (size_t)hp.n_vocab * dt);
+  add_spec(s, "decoder.positional_embedding", (size_t)hp.n_text_ctx * dt);
+  for (int i = 0; i < hp.n_text_layer; ++i) {
+    const std::string p = "decoder.blocks." + std::to_string(i) + ".";
+    for (const char* a : {"attn", "cross_attn"}) {
+      const std::string q = p + a;
+      add_spec(s, q + "_ln.weight", dt); add_spec(s, q + "_ln.bias", dt);
+      add_spec(s, q + ".query.weight", dt * dt); add_spec(s, q + ".query.bias", dt);
+      add_spec(s, q + ".key.weight", dt * dt);
+      add_spec(s, q + ".value.weight", dt * dt); add_spec(s, q + ".value.bias", dt);
+      add_spec(s, q + ".out.weight", dt * dt); add_spec(s, q + ".out.bias", dt);
+    }
+    add_spec(s, p + "mlp_ln.weight", dt); add_spec(s, p + "mlp_ln.bias", dt);
+    add_spec(s, p + "mlp.0.weight", 4 * dt * dt); add_spec(s, p + "mlp.0.bias", 4 * dt);
+    add_spec(s, p + "mlp.2.weight", 4 * dt * dt); add_spec(s, p + "mlp.2.bias", dt);
+  }
+  add_spec(s, "decoder.ln.weight", dt); add_spec(s, "decoder.ln.bias", dt);
+  return s;
+}
+
+int upload(crispy_asr* h, const std::vector<float>& host, const float** out) {
+  float* d = nullptr;
+  HIP_TRY(hipMalloc(&d, host.size() * sizeof(float)));
+  h->derived.push_back(d);
+  HIP_TRY(hipMemcpy(d, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+  *out = d;
+  return CRISPY_OK;
+}
+
+int download(const Tensor& t, std::vector<float>& host) {
+  host.resize(t.n);
+  HIP_TRY(hipMemcpy(host.data(), t.d, t.n * sizeof(float), hipMemcpyDeviceToHost));
+  return CRISPY_OK;
+}
+
+const float* T(crispy_asr* h, const std::string& name) { return h->tensors[name].d; }
+
+// [co][ci][3] -> [co][kk*ci_n + ci]: K order (tap, channel) matches three consecutive frame-major rows
+int reorder_conv(crispy_asr* h, const std::string& name, int co_n, int ci_n, const float** out) {
+  std::vector<float> src, dst((size_t)co_n * ci_n * 3);
+  int rc = download(h->tensors[name], src);
+  if (rc != CRISPY_OK) return rc;
+  for (int co = 0; co < co_n; ++co)
+    for (int ci = 0; ci < ci_n; ++ci)
+      for (int kk = 0; kk < 3; ++kk) dst[((size_t)co * 3 + kk) * ci_n + ci] = src[((size_t)co * ci_n + ci) * 3 + kk];
+  return upload(h, dst, out);
+}
+
+// concatenate row blocks of [d][d] weights (and biases; a missing bias is zeros)
+int fuse_rows(crispy_asr* h, const std::vector<std::string>& wnames, const std::vector<std::string>& bnames, int d,
+              const float** w_out, const float** b_out) {
+  std::vector<float> W, Bv;
+  for (size_t i = 0; i < wnames.size(); ++i) {
+    std::vector<float> t;
+    int rc = download(h->tensors[wnames[i]], t);
+    if (rc != CRISPY_OK) return rc;
+    W.insert(W.end(), t.begin(), t.end());
+    if (!bnames[i].empty()) {
+      rc = download(h->tensors[bnames[i]], t);
+      if (rc != CRISPY_OK) return rc;
+      Bv.insert(Bv.end(), t.begin(), t.end());
+    } else {
+      Bv.insert(Bv.end(), (size_t)d, 0.f);
+    }
+  }
+  int rc = upload(h, W, w_out);
+  if (rc != CRISPY_OK) return rc;
+  return upload(h, Bv, b_out);
+}
+
+void free_ws(crispy_asr* h) {
+  for (float** p : {&h->w_melt, &h->w_pcm, &h->w_h1, &h->w_x, &h->w_xn, &h->w_qkv, &h->w_att, &h->w_h, &h->w_enc})
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+  h->cap_batch = 0;
+  h->cap_pcm_stride = 0;
+}
+void free_dec_ws(crispy_asr* h) {
+  for (float** p : {&h->d_xkv, &h->d_selfkv, &h->d_dx, &h->d_dxn, &h->d_dq, &h->d_datt, &h->d_dh, &h->d_logits, &h->d_best})
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (h->d_tok) { (void)hipFree(h->d_tok); h->d_tok = nullptr; }
+  if (h->d_tokens_all) { (void)hipFree(h->d_tokens_all); h->d_tokens_all = nullptr; }
+  h->dcap_batch = 0;
+}
+
+int reserve_enc(crispy_asr* h, int batch) {
+  if (batch <= h->cap_batch) return CRISPY_OK;
+  free_ws(h);
+  const size_t B = batch, d = h->hp.n_audio_state, Tn = h->hp.n_audio_ctx;
+  HIP_TRY(hipMalloc(&h->w_melt, B * (MEL_FRAMES + 2) * h->hp.n_mels * sizeof(float)));
+  HIP_TRY(hipMalloc(&h->w_h1, B * (MEL_FRAMES + 1) * d * sizeof(float)));
+  HIP_TRY(hipMalloc(&h->w_x, B * Tn * d * sizeof(float)));
+  HIP_TRY(hipMalloc(&h->w_xn, B * Tn * d * sizeof(float)));
+  HIP_TRY(hipMalloc(&h->w_qkv, B * Tn * 3 * d * sizeof(float)));
+  HIP_TRY(hipMalloc(&h->w_att, B * Tn * d * sizeof(float)));
+  HIP_TRY(hipMalloc(&h->w_h, B * Tn * 4 * d * sizeof(float)));
+  HIP_TRY(hipMalloc(&h->w_enc, B * Tn * d * sizeof(float)));
+  // zero padding rows of the frame-major buffers are written once
+  HIP_TRY(hipMemset(h->w_melt, 0, B * (MEL_FRAMES + 2) * h->hp.n_mels * sizeof(float)));
+  HIP_TRY(hipMemset(h->w_h1, 0, B * (MEL_FRAMES + 1) * d * sizeof(float)));
+  h->cap_batch = batch;
+  return CRISPY_OK;
+}
+
+GemmArgs gemm(const float* A, long lda, const float* W, long ldw, float* C, long ldc, const float* bias, int M, int N,
+              int K) {
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.bias = bias;
+  g.M = M; g.N = N; g.K = K;
+  return g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int crispy_asr_create(const crispy_asr_hparams* hp, const float* mel_filters, int device, crispy_asr** out) {
+  if (!out) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_create: out is NULL");
+  *out = nullptr;
+  if (!hp || !mel_filters) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_create: NULL argument");
+  if (hp->n_audio_ctx != 1500 || hp->n_audio_state <= 0 || hp->n_audio_state % 64 || hp->n_audio_state > 1280 ||
+      hp->n_audio_head * 64 != hp->n_audio_state || hp->n_text_head * 64 != hp->n_text_state ||
+      hp->n_text_state % 64 || hp->n_text_state > 1280 || hp->n_audio_layer <= 0 || hp->n_text_layer <= 0 ||
+      hp->n_text_ctx <= 0 || hp->n_text_ctx > 448 || hp->n_vocab <= 0 || (hp->n_mels != 80 && hp->n_mels != 128) ||
+      (hp->n_mels * 3) % 16)
+    return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_create: unsupported hyper-parameters (head dim must be 64, ctx 1500/<=448)");
+  int rc = check_device(device, "crispy_asr_create");
+  if (rc != CRISPY_OK) return rc;
+  crispy_asr* h = new (std::nothrow) crispy_asr();
+  if (!h) return fail(CRISPY_ERR_OOM, "crispy_asr_create: host allocation failed");
+  h->device = device;
+  h->hp = *hp;
+  auto body = [&]() -> int {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    int r = crispy_mel_create(mel_filters, hp->n_mels, device, &h->mel);
+    if (r != CRISPY_OK) return r;
+    for (const auto& kv : expected_tensors(*hp)) {
+      Tensor t;
+      t.n = kv.second;
+      HIP_TRY(hipMalloc(&t.d, t.n * sizeof(float)));
+      h->tensors[kv.first] = t;
+    }
+    return CRISPY_OK;
+  };
+  rc = body();
+  if (rc != CRISPY_OK) {
+    const std::string keep = last_error_cstr();
+    crispy_asr_free(h);
+    return fail(rc, "%s", keep.c_str());
+  }
+  *out = h;
+  return CRISPY_OK;
+}
+
+void crispy_asr_free(crispy_asr* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (auto& kv : h->tensors)
+    if (kv.second.d) (void)hipFree(kv.second.d);
+  for (float* p : h->derived) (void)hipFree(p);
+  if (h->d_suppress) (void)hipFree(h->d_suppress);
+  if (h->d_suppress_first) (void)hipFree(h->d_suppress_first);
+  free_ws(h);
+  free_dec_ws(h);
+  if (h->mel) crispy_mel_destroy(h->mel);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int crispy_asr_set_tensor(crispy_asr* h, const char* name, const float* data, size_t n_elems) {
+  if (!h || !name || !data) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_set_tensor: NULL argument");
+  if (h->finalized) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_set_tensor: model already finalized");
+  auto it = h->tensors.find(name);
+  if (it == h->tensors.end()) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_set_tensor: unknown tensor '%s'", name);
+  if (it->second.n != n_elems)
+    return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_set_tensor: '%s' has %zu elements, expected %zu", name, n_elems,
+                it->second.n);
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemcpy(it->second.d, data, n_elems * sizeof(float), hipMemcpyHostToDevice));
+  it->second.set = true;
+  return CRISPY_OK;
+}
+
+int crispy_asr_finalize(crispy_asr* h) {
+  if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_finalize: NULL handle");
+  if (h->finalized) return CRISPY_OK;
+  for (const auto& kv : h->tensors)
+    if (!kv.second.set) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_finalize: tensor '%s' was never set", kv.first.c_str());
+  HIP_TRY(hipSetDevice(h->device));
+  const int d = h->hp.n_audio_state, dt = h->hp.n_text_state;
+  int rc;
+  if ((rc = reorder_conv(h, "encoder.conv1.weight", d, h->hp.n_mels, &h->conv1_w)) != CRISPY_OK) return rc;
+  if ((rc = reorder_conv(h, "encoder.conv2.weight", d, d, &h->conv2_w)) != CRISPY_OK) return rc;
+  h->conv1_b = T(h, "encoder.conv1.bias");
+  h->conv2_b = T(h, "encoder.conv2.bias");
+  h->enc_pos = T(h, "encoder.positional_embedding");
+  h->ln_post_w = T(h, "encoder.ln_post.weight");
+  h->ln_post_b = T(h, "encoder.ln_post.bias");
+  h->enc.resize(h->hp.n_audio_layer);
+  for (int i = 0; i < h->hp.n_audio_layer; ++i) {
+    const std::string p = "encoder.blocks." + std::to_string(i) + ".";
+    EncLayer& L = h->enc[i];
+    L.ln1_w = T(h, p + "attn_ln.weight"); L.ln1_b = T(h, p + "attn_ln.bias");
+    rc = fuse_rows(h, {p + "attn.query.weight", p + "attn.key.weight", p + "attn.value.weight"},
+                   {p + "attn.query.bias", "", p + "attn.value.bias"}, d, &L.qkv_w, &L.qkv_b);
+    if (rc != CRISPY_OK) return rc;
+    L.out_w = T(h, p + "attn.out.weight"); L.out_b = T(h, p + "attn.out.bias");
+    L.ln2_w = T(h, p + "mlp_ln.weight"); L.ln2_b = T(h, p + "mlp_ln.bias");
+    L.fc1_w = T(h, p + "mlp.0.weight"); L.fc1_b = T(h, p + "mlp.0.bias");
+    L.fc2_w = T(h, p + "mlp.2.weight"); L.fc2_b = T(h, p + "mlp.2.bias");
+  }
+  h->tok_emb = T(h, "decoder.token_embedding.weight");
+  h->dec_pos = T(h, "decoder.positional_embedding");
+  h->dec_ln_w = T(h, "decoder.ln.weight");
+  h->dec_ln_b = T(h, "decoder.ln.bias");
+  h->dec.resize(h->hp.n_text_layer);
+  for (int i = 0; i < h->hp.n_text_layer; ++i) {
+    const std::string p = "decoder.blocks." + std::to_string(i) + ".";
+    DecLayer& L = h->dec[i];
+    L.ln1_w = T(h, p + "attn_ln.weight"); L.ln1_b = T(h, p + "attn_ln.bias");
+    rc = fuse_rows(h, {p + "attn.query.weight", p + "attn.key.weight", p + "attn.value.weight"},
+                   {p + "attn.query.bias", "", p + "attn.value.bias"}, dt, &L.qkv_w, &L.qkv_b);
+    if (rc != CRISPY_OK) return rc;
+    L.out_w = T(h, p + "attn.out.weight"); L.out_b = T(h, p + "attn.out.bias");
+    L.lnx_w = T(h, p + "cross_attn_ln.weight"); L.lnx_b = T(h, p + "cross_attn_ln.bias");
+    L.xq_w = T(h, p + "cross_attn.query.weight"); L.xq_b = T(h, p + "cross_attn.query.bias");
+    rc = fuse_rows(h, {p + "cross_attn.key.weight", p + "cross_attn.value.weight"}, {"", p + "cross_attn.value.bias"},
+                   dt, &L.xkv_w, &L.xkv_b);
+    if (rc != CRISPY_OK) return rc;
+    L.xout_w = T(h, p + "cross_attn.out.weight"); L.xout_b = T(h, p + "cross_attn.out.bias");
+    L.ln2_w = T(h, p + "mlp_ln.weight"); L.ln2_b = T(h, p + "mlp_ln.bias");
+    L.fc1_w = T(h, p + "mlp.0.weight"); L.fc1_b = T(h, p + "mlp.0.bias");
+    L.fc2_w = T(h, p + "mlp.2.weight"); L.fc2_b = T(h, p + "mlp.2.bias");
+  }
+  HIP_TRY(hipMalloc(&h->d_suppress, h->hp.n_vocab));
+  HIP_TRY(hipMalloc(&h->d_suppress_first, h->hp.n_vocab));
+  HIP_TRY(hipMemset(h->d_suppress, 0, h->hp.n_vocab));
+  HIP_TRY(hipMemset(h->d_suppress_first, 0, h->hp.n_vocab));
+  h->finalized = true;
+  return CRISPY_OK;
+}
+
+int crispy_asr_hparams_get(const crispy_asr* h, crispy_asr_hparams* out) {
+  if (!h || !out) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_hparams_get: NULL argument");
+  *out = h->hp;
+  return CRISPY_OK;
+}
+
+// mel (frame-major, padded) -> encoder output [B][1500][d]
+int crispy_asr_encode_device(crispy_asr* h, const float* d_mel_t, int batch, float* d_out, void* hip_stream) {
+  if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_encode_device: NULL handle");
+  if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_encode_device: model not finalized");
+  if (batch < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_encode_device: batch < 0");
+  if (batch == 0) return CRISPY_OK;
+  if (!d_mel_t || !d_out) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_encode_device: NULL argument");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
+  int rc = reserve_enc(h, batch);
+  if (rc != CRISPY_OK) return rc;
+  const int d = h->hp.n_audio_state, Tn = h->hp.n_audio_ctx, nm = h->hp.n_mels, H = h->hp.n_audio_head;
+  const long rows = (long)batch * Tn;
+  // conv1 (k3, p1) + GELU: rows t of the padded frame-major mel are 3*n_mels contiguous floats
+  {
+    GemmArgs g = gemm(d_mel_t, nm, h->conv1_w, 3L * nm, h->w_h1 + d, d, h->conv1_b, MEL_FRAMES, d, 3 * nm);
+    g.strideA = (long)(MEL_FRAMES + 2) * nm;
+    g.strideC = (long)(MEL_FRAMES + 1) * d;
+    g.gelu = 1;
+    HIP_TRY(gemm_f32_nt(g, batch, s));
+  }
+  // conv2 (k3, s2, p1) + GELU + positional embedding: row t' = frames 2t'-1 .. 2t'+1 of h1 (one zero row in front)
+  {
+    GemmArgs g = gemm(h->w_h1, 2L * d, h->conv2_w, 3L * d, h->w_x, d, h->conv2_b, Tn, d, 3 * d);
+    g.strideA = (long)(MEL_FRAMES + 1) * d;
+    g.strideC = (long)Tn * d;
+    g.gelu = 1;
+    g.rowtab = h->enc_pos;
+    g.rowtab_period = Tn;
+    HIP_TRY(gemm_f32_nt(g, batch, s));
+  }
+  for (const EncLayer& L : h->enc) {
+    HIP_TRY(layernorm_f32(h->w_x, L.ln1_w, L.ln1_b, h->w_xn, rows, d, s));
+    HIP_TRY(gemm_f32_nt(gemm(h->w_xn, d, L.qkv_w, d, h->w_qkv, 3L * d, L.qkv_b, (int)rows, 3 * d, d), 1, s));
+    HIP_TRY(attn_encoder_f32(h->w_qkv, h->w_att, batch, Tn, d, H, s));
+    {
+      GemmArgs g = gemm(h->w_att, d, L.out_w, d, h->w_x, d, L.out_b, (int)rows, d, d);
+      g.residual = h->w_x; g.ldr = d;
+      HIP_TRY(gemm_f32_nt(g, 1, s));
+    }
+    HIP_TRY(layernorm_f32(h->w_x, L.ln2_w, L.ln2_b, h->w_xn, rows, d, s));
+    {
+      GemmArgs g = gemm(h->w_xn, d, L.fc1_w, d, h->w_h, 4L * d, L.fc1_b, (int)rows, 4 * d, d);
+      g.gelu = 1;
+      HIP_TRY(gemm_f32_nt(g, 1, s));
+    }
+    {
+      GemmArgs g = gemm(h->w_h, 4L * d, L.fc2_w, 4L * d, h->w_x, d, L.fc2_b, (int)rows, d, 4 * d);
+      g.residual = h->w_x; g.ldr = d;
+      HIP_TRY(gemm_f32_nt(g, 1, s));
+    }
+  }
+  HIP_TRY(layernorm_f32(h->w_x, h->ln_post_w, h->ln_post_b, d_out, rows, d, s));
+  return CRISPY_OK;
+}
+
+// PCM (host) -> log-mel -> encoder output (host); one call per batch of <= 30 s clips
+int crispy_asr_encode(crispy_asr* h, const float* pcm, long pcm_stride, const int* n_samples, int batch, float* out) {
+  if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_encode: NULL handle");
+  if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_encode: model not finalized");
+  if (batch < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_encode: batch < 0");
+  if (batch == 0) return CRISPY_OK;
+  if (!pcm || !n_samples || !out) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_encode: NULL argument");
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = reserve_enc(h, batch);
+  if (rc != CRISPY_OK) return rc;
+  if (!h->w_pcm || pcm_stride > h->cap_pcm_stride) {
+    if (h->w_pcm) (void)hipFree(h->w_pcm);
+    h->w_pcm = nullptr;
+    HIP_TRY(hipMalloc(&h->w_pcm, (size_t)h->cap_batch * pcm_stride * sizeof(float)));
+    h->cap_pcm_stride = pcm_stride;
+  }
+  HIP_TRY(hipMemcpyAsync(h->w_pcm, pcm, (size_t)batch * pcm_stride * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  rc = crispy_mel_compute_device(h->mel, h->w_pcm, pcm_stride, n_samples, batch, nullptr, h->w_melt, h->stream);
+  if (rc != CRISPY_OK) return rc;
+  rc = crispy_asr_encode_device(h, h->w_melt, batch, h->w_enc, h->stream);
+  if (rc != CRISPY_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(out, h->w_enc, (size_t)batch * h->hp.n_audio_ctx * h->hp.n_audio_state * sizeof(float),
+                         hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return CRISPY_OK;
+}
+
+int crispy_asr_synchronize(crispy_asr* h) {
+  if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_synchronize: NULL handle");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return CRISPY_OK;
+}
+
+}  // extern "C"

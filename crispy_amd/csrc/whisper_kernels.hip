@@ -1,0 +1,391 @@
+// whisper_kernels.hip -- Whisper encoder/decoder building blocks for MI355X (gfx950).
+//
+// Replaces the whisper.cpp compute graph behind transcribe_rs::SpeechModel::transcribe
+// (reference call sites src-tauri/src/managers/transcription.rs:183-185, 213-215);
+// architecture: SURVEY.md Appendix B.2.
+//
+// Round-1 numerics: f32 end to end on the f32-input matrix cores (v_mfma_f32_32x32x2_f32: exact f32
+// products, f32 accumulation, 157 TFLOP/s peak) so that parity with the fp32 oracle is limited only by
+// summation order.  bf16 operands are a later, separately validated step.
+//
+//   gemm_f32_nt_kernel     C[M,N] = A[M,K] . W[N,K]^T (+bias) (GELU) (+residual | +row-periodic table)
+//                          128x128x16 tiles, 4 waves x (2x2) MFMA 32x32 tiles, LDS double buffer,
+//                          A may be a strided *view* (lda < K): both Whisper convolutions run as GEMMs
+//                          over overlapping rows of the frame-major activation without an im2col copy.
+//   layernorm_kernel       one wave per row.
+//   attn_enc_kernel        flash-style non-causal attention, one wave per 32 queries, S^T = K.Q^T so the
+//                          softmax statistics are per lane and P^T feeds the P.V MFMAs from registers.
+//   attn_dec_kernel        one wave per (clip, head): a single query against a KV cache / cross KV.
+#include "asr_common.h"
+
+namespace crispy {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int GB_M = 128, GB_N = 128, GB_K = 16, GB_LD = 20;  // LDS row stride 20 floats: conflict-free b128 reads
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
+// row index of accumulator register r for this lane (32x32 MFMA C/D layout)
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+__global__ __launch_bounds__(256) void gemm_f32_nt_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float As[2][GB_M * GB_LD];
+  __shared__ __attribute__((aligned(16))) float Ws[2][GB_N * GB_LD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int bz = blockIdx.z;
+  const float* __restrict__ A = g.A + (long)bz * g.strideA;
+  const float* __restrict__ W = g.W;
+  float* __restrict__ C = g.C + (long)bz * g.strideC;
+  const int m0 = blockIdx.y * GB_M, n0 = blockIdx.x * GB_N;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+  // staging: thread loads float4 #q of row (tid>>2) + 64*h, k-offset 4*(tid&3)
+  const int lr = tid >> 2, lk = (tid & 3) * 4;
+  float4 ra[2], rw[2];
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int m = m0 + lr + 64 * h, n = n0 + lr + 64 * h;
+      ra[h] = (m < g.M) ? *reinterpret_cast<const float4*>(A + (long)m * g.lda + k0 + lk) : make_float4(0, 0, 0, 0);
+      rw[h] = (n < g.N) ? *reinterpret_cast<const float4*>(W + (long)n * g.ldw + k0 + lk) : make_float4(0, 0, 0, 0);
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      *reinterpret_cast<float4*>(&As[buf][(lr + 64 * h) * GB_LD + lk]) = ra[h];
+      *reinterpret_cast<float4*>(&Ws[buf][(lr + 64 * h) * GB_LD + lk]) = rw[h];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = g.K / GB_K;
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+  const int li = lane & 31, lh = lane >> 5;
+  for (int kb = 0; kb < nk; ++kb) {
+    const int buf = kb & 1;
+    if (kb + 1 < nk) load_tiles((kb + 1) * GB_K);
+    // operands: MFMA step s contracts the k-pair (s, s+8) of this 16-wide block; lane half lh owns k = 8*lh + s
+    float a[2][8], w[2][8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float4* pa = reinterpret_cast<const float4*>(&As[buf][(wm + 32 * i + li) * GB_LD + 8 * lh]);
+      const float4* pw = reinterpret_cast<const float4*>(&Ws[buf][(wn + 32 * i + li) * GB_LD + 8 * lh]);
+      const float4 a0 = pa[0], a1 = pa[1], w0 = pw[0], w1 = pw[1];
+      a[i][0] = a0.x; a[i][1] = a0.y; a[i][2] = a0.z; a[i][3] = a0.w;
+      a[i][4] = a1.x; a[i][5] = a1.y; a[i][6] = a1.z; a[i][7] = a1.w;
+      w[i][0] = w0.x; w[i][1] = w0.y; w[i][2] = w0.z; w[i][3] = w0.w;
+      w[i][4] = w1.x; w[i][5] = w1.y; w[i][6] = w1.z; w[i][7] = w1.w;
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], w[j][s], acc[i][j], 0, 0, 0);
+    if (kb + 1 < nk) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn + 32 * j + li;
+      if (n >= g.N) continue;
+      const float bias = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm + 32 * i + acc_row(r, lane);
+        if (m >= g.M) continue;
+        float v = acc[i][j][r] + bias;
+        if (g.gelu) v = gelu_erf(v);
+        if (g.residual) v += g.residual[(long)bz * g.strideR + (long)m * g.ldr + n];
+        if (g.rowtab) v += g.rowtab[(long)(m % g.rowtab_period) * g.N + n];
+        C[(long)m * g.ldc + n] = v;
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over the last dimension (eps 1e-5), one wave per row; D <= 1280, multiple of 64
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ y,
+                                                        long rows, int D) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + row * D;
+  float v[20];
+  const int per = D / 64;
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < 20; ++q)
+    if (q < per) { v[q] = xr[lane + 64 * q]; s += v[q]; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  const float mean = s / (float)D;
+  float s2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < 20; ++q)
+    if (q < per) { const float d = v[q] - mean; s2 = fmaf(d, d, s2); }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s2 += __shfl_xor(s2, off, 64);
+  const float rstd = 1.f / sqrtf(s2 / (float)D + 1e-5f);
+  float* yr = y + row * D;
+#pragma unroll
+  for (int q = 0; q < 20; ++q)
+    if (q < per) {
+      const int c = lane + 64 * q;
+      yr[c] = (v[q] - mean) * rstd * gamma[c] + beta[c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Encoder self-attention (non-causal), head dim 64.  qkv: [B][T][3*D] with q | k | v column blocks.
+// grid (ceil(T/128), heads, B), 4 waves, wave = 32 queries.
+//   S^T[key][q] = sum_d K[key][d] Q[q][d]    (A = K rows, B = Q^T; MFMA step s contracts d = s and s+32)
+//   O^T[d][q]  += sum_key V[key][d] P^T[key][q]   (A = V^T, B = P^T straight from the S^T accumulator:
+//                register r of lane half h is key (r&3) + 8(r>>2) + 4h, exactly the k-pair of step r)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_enc_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                       int T, int D) {
+  __shared__ float stage[4][32 * 65];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  if (q0 >= T) return;
+  const long ld = 3L * D;
+  const float* base = qkv + (long)b * T * ld;
+  const float* Qp = base + h * 64;
+  const float* Kp = base + D + h * 64;
+  const float* Vp = base + 2 * D + h * 64;
+
+  // Q operand: lane (q = li, half lh) holds Q[q][32*lh + s], s = 0..31, pre-scaled by 1/8 (exact)
+  float qreg[32];
+  {
+    const int q = min(q0 + li, T - 1);
+    const float4* p = reinterpret_cast<const float4*>(Qp + (long)q * ld + 32 * lh);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float4 t = p[c];
+      qreg[4 * c] = t.x * 0.125f; qreg[4 * c + 1] = t.y * 0.125f;
+      qreg[4 * c + 2] = t.z * 0.125f; qreg[4 * c + 3] = t.w * 0.125f;
+    }
+  }
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m_run = -1e30f, l_run = 0.f;
+
+  for (int k0 = 0; k0 < T; k0 += 32) {
+    // ---- S^T tile ----
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    {
+      const int key = min(k0 + li, T - 1);
+      const float4* p = reinterpret_cast<const float4*>(Kp + (long)key * ld + 32 * lh);
+      float kreg[32];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const float4 t = p[c];
+        kreg[4 * c] = t.x; kreg[4 * c + 1] = t.y; kreg[4 * c + 2] = t.z; kreg[4 * c + 3] = t.w;
+      }
+#pragma unroll
+      for (int st = 0; st < 32; ++st) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[st], qreg[st], s, 0, 0, 0);
+    }
+    // ---- online softmax over this lane's 16 keys + the partner half's 16 ----
+    float mloc = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + acc_row(r, lane);
+      if (key >= T) s[r] = -1e30f;
+      mloc = fmaxf(mloc, s[r]);
+    }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float m_new = fmaxf(m_run, mloc);
+    const float alpha = __expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = __expf(s[r] - m_new);
+      s[r] = p;
+      psum += p;
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    // ---- O^T += V^T . P^T ----
+    {
+      float v0[16], v1[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = min(k0 + acc_row(r, lane), T - 1);
+        const float* vp = Vp + (long)key * ld;
+        v0[r] = vp[li];
+        v1[r] = vp[32 + li];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[r], s[r], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[r], s[r], o1, 0, 0, 0);
+      }
+    }
+  }
+  // ---- normalise, transpose through LDS, store rows of 64 floats ----
+  const float inv = 1.f / l_run;
+  float* st = stage[wave];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int d = acc_row(r, lane);
+    st[li * 65 + d] = o0[r] * inv;
+    st[li * 65 + 32 + d] = o1[r] * inv;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int idx = lane; idx < 32 * 64; idx += 64) {
+    const int q = idx >> 6, d = idx & 63;
+    if (q0 + q < T) out[((long)b * T + q0 + q) * D + h * 64 + d] = st[q * 65 + d];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Decoder attention for ONE query per (clip, head): scores against n_keys cached keys, softmax, P.V.
+// q: [B][D] (row stride ldq), K/V: [B][n_ctx][ldkv] with this head's 64 columns at koff/voff + h*64.
+// grid (heads, B), one wave.  Memory-bound on the cached K/V.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void attn_dec_kernel(const float* __restrict__ q, long ldq,
+                                                      const float* __restrict__ kv, long kv_batch_stride,
+                                                      long ldkv, int koff, int voff, int n_keys,
+                                                      float* __restrict__ out, long ldo) {
+  __shared__ float p_s[1536];
+  __shared__ float q_s[64];
+  const int lane = threadIdx.x, h = blockIdx.x, b = blockIdx.y;
+  q_s[lane] = q[(long)b * ldq + h * 64 + lane] * 0.125f;
+  __syncthreads();
+  const float* Kb = kv + (long)b * kv_batch_stride + koff + h * 64;
+  const float* Vb = kv + (long)b * kv_batch_stride + voff + h * 64;
+  float mloc = -1e30f;
+  for (int k = lane; k < n_keys; k += 64) {
+    const float4* kp = reinterpret_cast<const float4*>(Kb + (long)k * ldkv);
+    float sacc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const float4 t = kp[c];
+      sacc = fmaf(t.x, q_s[4 * c], sacc);
+      sacc = fmaf(t.y, q_s[4 * c + 1], sacc);
+      sacc = fmaf(t.z, q_s[4 * c + 2], sacc);
+      sacc = fmaf(t.w, q_s[4 * c + 3], sacc);
+    }
+    p_s[k] = sacc;
+    mloc = fmaxf(mloc, sacc);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mloc = fmaxf(mloc, __shfl_xor(mloc, off, 64));
+  float lsum = 0.f;
+  for (int k = lane; k < n_keys; k += 64) {
+    const float p = __expf(p_s[k] - mloc);
+    p_s[k] = p;
+    lsum += p;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) lsum += __shfl_xor(lsum, off, 64);
+  __syncthreads();
+  float acc = 0.f;  // lane = output dim
+  for (int k = 0; k < n_keys; ++k) acc = fmaf(p_s[k], Vb[(long)k * ldkv + lane], acc);
+  out[(long)b * ldo + h * 64 + lane] = acc / lsum;
+}
+
+// token + positional embedding for one decode step: x[b][:] = tok_emb[token[b]] + pos_emb[pos]
+__global__ __launch_bounds__(256) void embed_kernel(const int* __restrict__ tokens, const float* __restrict__ tok_emb,
+                                                    const float* __restrict__ pos_emb, int pos, float* __restrict__ x,
+                                                    int D) {
+  const int b = blockIdx.x;
+  const int tok = tokens[b];
+  for (int c = threadIdx.x; c < D; c += 256) x[(long)b * D + c] = tok_emb[(long)tok * D + c] + pos_emb[(long)pos * D + c];
+}
+
+// greedy pick: argmax over the vocabulary with a suppression mask (mask[v] != 0 -> -inf); ties -> lowest id
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, const unsigned char* __restrict__ mask,
+                                                     int V, int* __restrict__ tokens_out, float* __restrict__ best_logit) {
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  const int b = blockIdx.x;
+  const float* lg = logits + (long)b * V;
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int v = threadIdx.x; v < V; v += 256) {
+    const float x = (mask && mask[v]) ? -INFINITY : lg[v];
+    if (x > bv || (x == bv && v < bi)) { bv = x; bi = v; }
+  }
+  sv[threadIdx.x] = bv;
+  si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) {
+      const float ov = sv[threadIdx.x + off];
+      const int oi = si[threadIdx.x + off];
+      if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) { sv[threadIdx.x] = ov; si[threadIdx.x] = oi; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    tokens_out[b] = si[0];
+    if (best_logit) best_logit[b] = sv[0];
+  }
+}
+
+}  // namespace
+
+hipError_t gemm_f32_nt(const GemmArgs& g, int batch, hipStream_t s) {
+  dim3 grid((g.N + GB_N - 1) / GB_N, (g.M + GB_M - 1) / GB_M, batch);
+  hipLaunchKernelGGL(gemm_f32_nt_kernel, grid, dim3(256), 0, s, g);
+  return hipGetLastError();
+}
+hipError_t layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, long rows, int D,
+                         hipStream_t s) {
+  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, gamma, beta, y, rows, D);
+  return hipGetLastError();
+}
+hipError_t attn_encoder_f32(const float* qkv, float* out, int B, int T, int D, int heads, hipStream_t s) {
+  hipLaunchKernelGGL(attn_enc_kernel, dim3((T + 127) / 128, heads, B), dim3(256), 0, s, qkv, out, T, D);
+  return hipGetLastError();
+}
+hipError_t attn_decoder_f32(const float* q, long ldq, const float* kv, long kv_batch_stride, long ldkv, int koff,
+                            int voff, int n_keys, float* out, long ldo, int B, int heads, hipStream_t s) {
+  hipLaunchKernelGGL(attn_dec_kernel, dim3(heads, B), dim3(64), 0, s, q, ldq, kv, kv_batch_stride, ldkv, koff, voff,
+                     n_keys, out, ldo);
+  return hipGetLastError();
+}
+hipError_t embed_tokens_f32(const int* tokens, const float* tok_emb, const float* pos_emb, int pos, float* x, int B,
+                            int D, hipStream_t s) {
+  hipLaunchKernelGGL(embed_kernel, dim3(B), dim3(256), 0, s, tokens, tok_emb, pos_emb, pos, x, D);
+  return hipGetLastError();
+}
+hipError_t argmax_f32(const float* logits, const unsigned char* mask, int V, int* tokens_out, float* best, int B,
+                      hipStream_t s) {
+  hipLaunchKernelGGL(argmax_kernel, dim3(B), dim3(256), 0, s, logits, mask, V, tokens_out, best);
+  return hipGetLastError();
+}
+
+}  // namespace crispy

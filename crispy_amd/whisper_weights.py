@@ -1,0 +1,123 @@
+"""Whisper model description: hyper-parameters, tensor inventory (whisper.cpp / OpenAI names, PyTorch
+layouts) and a seeded synthetic weight generator.
+
+No Whisper weights exist in this environment; tests and the benchmark use
+random-init models of the real architecture.  The same named tensors are what
+`crispy_asr_set_tensor` expects and what a GGML model file carries (Appendix B.5)."""
+from __future__ import annotations
+
+import zlib
+from collections import OrderedDict
+from dataclasses import asdict, dataclass
+
+import numpy as np
+
+
+@dataclass(frozen=True)
+class HParams:
+    n_vocab: int = 51865
+    n_audio_ctx: int = 1500
+    n_audio_state: int = 384
+    n_audio_head: int = 6
+    n_audio_layer: int = 4
+    n_text_ctx: int = 448
+    n_text_state: int = 384
+    n_text_head: int = 6
+    n_text_layer: int = 4
+    n_mels: int = 80
+
+    @staticmethod
+    def tiny():
+        return HParams()
+
+    @staticmethod
+    def base():
+        return HParams(n_audio_state=512, n_audio_head=8, n_audio_layer=6, n_text_state=512, n_text_head=8,
+                       n_text_layer=6)
+
+    def as_ints(self):
+        return [int(v) for v in asdict(self).values()]
+
+
+# special tokens of the multilingual vocabulary
+TOK_EOT, TOK_SOT, TOK_EN, TOK_TRANSCRIBE, TOK_NOTIMESTAMPS = 50257, 50258, 50259, 50359, 50363
+
+
+def tensor_shapes(hp: HParams) -> "OrderedDict[str, tuple]":
+    d, dt = hp.n_audio_state, hp.n_text_state
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+    s["encoder.conv1.weight"] = (d, hp.n_mels, 3)
+    s["encoder.conv1.bias"] = (d,)
+    s["encoder.conv2.weight"] = (d, d, 3)
+    s["encoder.conv2.bias"] = (d,)
+    s["encoder.positional_embedding"] = (hp.n_audio_ctx, d)
+
+    def attn(prefix, dim):
+        s[prefix + ".query.weight"] = (dim, dim)
+        s[prefix + ".query.bias"] = (dim,)
+        s[prefix + ".key.weight"] = (dim, dim)
+        s[prefix + ".value.weight"] = (dim, dim)
+        s[prefix + ".value.bias"] = (dim,)
+        s[prefix + ".out.weight"] = (dim, dim)
+        s[prefix + ".out.bias"] = (dim,)
+
+    def ln(prefix, dim):
+        s[prefix + ".weight"] = (dim,)
+        s[prefix + ".bias"] = (dim,)
+
+    def mlp(prefix, dim):
+        s[prefix + ".mlp.0.weight"] = (4 * dim, dim)
+        s[prefix + ".mlp.0.bias"] = (4 * dim,)
+        s[prefix + ".mlp.2.weight"] = (dim, 4 * dim)
+        s[prefix + ".mlp.2.bias"] = (dim,)
+
+    for i in range(hp.n_audio_layer):
+        p = f"encoder.blocks.{i}"
+        ln(p + ".attn_ln", d)
+        attn(p + ".attn", d)
+        ln(p + ".mlp_ln", d)
+        mlp(p, d)
+    ln("encoder.ln_post", d)
+    s["decoder.token_embedding.weight"] = (hp.n_vocab, dt)
+    s["decoder.positional_embedding"] = (hp.n_text_ctx, dt)
+    for i in range(hp.n_text_layer):
+        p = f"decoder.blocks.{i}"
+        ln(p + ".attn_ln", dt)
+        attn(p + ".attn", dt)
+        ln(p + ".cross_attn_ln", dt)
+        attn(p + ".cross_attn", dt)
+        ln(p + ".mlp_ln", dt)
+        mlp(p, dt)
+    ln("decoder.ln", dt)
+    return s
+
+
+def sinusoids(length: int, channels: int) -> np.ndarray:
+    """Whisper's fixed encoder position table: concat(sin, cos) of geometric timescales."""
+    inc = np.log(10000.0) / (channels // 2 - 1)
+    inv = np.exp(-inc * np.arange(channels // 2))
+    t = np.arange(length)[:, None] * inv[None, :]
+    return np.concatenate([np.sin(t), np.cos(t)], axis=1).astype(np.float32)
+
+
+def synthetic_whisper_weights(hp: HParams, seed: int = 0) -> "OrderedDict[str, np.ndarray]":
+    """Seeded random-init model; every tensor has its own stream (seed, crc32(name)), so the result
+    does not depend on generation order and is identical on every machine (numpy PCG64)."""
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for name, shape in tensor_shapes(hp).items():
+        rng = np.random.default_rng([seed, zlib.crc32(name.encode())])
+        if name == "encoder.positional_embedding":
+            w = sinusoids(shape[0], shape[1])
+        elif name.endswith("_ln.weight") or name.endswith("ln_post.weight") or name == "decoder.ln.weight":
+            w = 1.0 + 0.1 * rng.standard_normal(shape)
+        elif name.endswith(".bias"):
+            w = 0.02 * rng.standard_normal(shape)
+        elif name == "decoder.token_embedding.weight":
+            w = 0.05 * rng.standard_normal(shape)
+        elif name == "decoder.positional_embedding":
+            w = 0.02 * rng.standard_normal(shape)
+        else:  # linear / conv: fan-in scaling keeps activations O(1) through the stack
+            fan_in = int(np.prod(shape[1:]))
+            w = rng.standard_normal(shape) / np.sqrt(fan_in)
+        out[name] = np.ascontiguousarray(w, dtype=np.float32)
+    return out

@@ -152,6 +152,41 @@ int crispy_mel_compute_device(crispy_mel *h, const float *d_pcm, long pcm_stride
                               void *hip_stream);
 int crispy_mel_synchronize(crispy_mel *h);
 
+/* ------------------------------------------------------------------------------------------
+ * Whisper engine: replaces transcribe_rs::whisper_cpp::WhisperEngine behind `SpeechModel`
+ *   load        managers/transcription.rs:138-141   WhisperEngine::load(&model_path)
+ *   transcribe  managers/transcription.rs:183-185   engine.transcribe(&audio, &TranscribeOptions::default())
+ * Architecture: SURVEY.md Appendix B.2 (pre-LN transformer, head dim 64, 1500 audio positions).
+ * Round-1 numerics are f32 end to end on the f32-input matrix cores.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct crispy_asr crispy_asr;
+
+/* The hyper-parameter block of a whisper.cpp model file, minus ftype. */
+typedef struct crispy_asr_hparams {
+  int n_vocab, n_audio_ctx, n_audio_state, n_audio_head, n_audio_layer;
+  int n_text_ctx, n_text_state, n_text_head, n_text_layer, n_mels;
+} crispy_asr_hparams;
+
+/* Model container.  Tensors are set by their model-file names ("encoder.conv1.weight",
+ * "decoder.blocks.3.cross_attn.query.bias", ...) as f32 host arrays in PyTorch layout
+ * ([out][in], conv [out][in][3]); crispy_asr_finalize checks completeness and builds the fused
+ * device layouts.  mel_filters: [n_mels][201]. */
+int crispy_asr_create(const crispy_asr_hparams *hp, const float *mel_filters, int device,
+                      crispy_asr **out);
+int crispy_asr_set_tensor(crispy_asr *h, const char *name, const float *data, size_t n_elems);
+int crispy_asr_finalize(crispy_asr *h);
+void crispy_asr_free(crispy_asr *h);
+int crispy_asr_hparams_get(const crispy_asr *h, crispy_asr_hparams *out);
+
+/* Stage entry points (parity tests): PCM (host, <= 30 s per clip) -> encoder output
+ * [batch][1500][n_audio_state] (host), and the device-resident variant that starts from the
+ * frame-major padded log-mel produced by crispy_mel_compute_device (d_out_t). */
+int crispy_asr_encode(crispy_asr *h, const float *pcm, long pcm_stride, const int *n_samples,
+                      int batch, float *out);
+int crispy_asr_encode_device(crispy_asr *h, const float *d_mel_t, int batch, float *d_out,
+                             void *hip_stream);
+int crispy_asr_synchronize(crispy_asr *h);
+
 #ifdef __cplusplus
 }
 #endif
