@@ -31,7 +31,8 @@ RN_SYMBOLS = (
 MEL_SYMBOLS = ("crispy_mel_create", "crispy_mel_destroy", "crispy_mel_compute",
                "crispy_mel_compute_device", "crispy_mel_synchronize")
 ASR_SYMBOLS = ("crispy_asr_create", "crispy_asr_set_tensor", "crispy_asr_finalize", "crispy_asr_free",
-               "crispy_asr_hparams_get", "crispy_asr_encode", "crispy_asr_encode_device", "crispy_asr_synchronize")
+               "crispy_asr_hparams_get", "crispy_asr_encode", "crispy_asr_encode_device", "crispy_asr_synchronize",
+               "crispy_asr_set_suppress", "crispy_asr_decode_greedy_device", "crispy_asr_transcribe_tokens")
 ALL_SYMBOLS = RN_SYMBOLS + MEL_SYMBOLS + ASR_SYMBOLS
 
 class CrispyError(RuntimeError):
@@ -94,6 +95,11 @@ def lib() -> C.CDLL:
     L.crispy_asr_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_void_p]
     L.crispy_asr_encode_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.crispy_asr_synchronize.argtypes = [C.c_void_p]
+    L.crispy_asr_set_suppress.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.crispy_asr_decode_greedy_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p]
+    L.crispy_asr_transcribe_tokens.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_void_p,
+                                               C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 

@@ -121,3 +121,36 @@ class WhisperModel:
 
     def synchronize(self):
         N.check(N.lib().crispy_asr_synchronize(self._h))
+
+    def set_suppress(self, ids, first_only: bool = False):
+        a = np.ascontiguousarray(ids, dtype=np.int32)
+        N.check(N.lib().crispy_asr_set_suppress(self._h, a.ctypes.data, a.size, int(first_only)))
+
+    def set_default_suppression(self):
+        """whisper.cpp's no-timestamps greedy masks: every id above <|endoftext|> is never emitted;
+        blank (220) and EOT are not allowed as the first token [UPSTREAM-RECALL, SURVEY Appendix B.4]."""
+        from .whisper_weights import TOK_EOT
+        self.set_suppress(np.arange(TOK_EOT + 1, self.hp.n_vocab))
+        self.set_suppress([220, TOK_EOT], first_only=True)
+
+    def decode_greedy_device(self, d_enc: int, batch: int, prompt, max_new: int):
+        p = np.ascontiguousarray(prompt, dtype=np.int32)
+        toks = np.empty((batch, max_new), dtype=np.int32)
+        n = np.empty(batch, dtype=np.int32)
+        lg = np.empty((batch, max_new), dtype=np.float32)
+        N.check(N.lib().crispy_asr_decode_greedy_device(self._h, d_enc, batch, p.ctypes.data, p.size, max_new,
+                                                        toks.ctypes.data, n.ctypes.data, lg.ctypes.data))
+        return toks, n, lg
+
+    def transcribe_tokens(self, clips, prompt, max_new: int):
+        """`SpeechModel::transcribe` up to token ids for a batch of <= 30 s clips."""
+        if len(clips) == 0:
+            return np.zeros((0, max_new), np.int32), np.zeros(0, np.int32)
+        pcm, lens = self._pack(clips)
+        p = np.ascontiguousarray(prompt, dtype=np.int32)
+        toks = np.empty((pcm.shape[0], max_new), dtype=np.int32)
+        n = np.empty(pcm.shape[0], dtype=np.int32)
+        N.check(N.lib().crispy_asr_transcribe_tokens(self._h, pcm.ctypes.data, pcm.shape[1], lens.ctypes.data,
+                                                     pcm.shape[0], p.ctypes.data, p.size, max_new,
+                                                     toks.ctypes.data, n.ctypes.data))
+        return toks, n

@@ -60,6 +60,8 @@ struct crispy_asr {
         *d_dh = nullptr, *d_logits = nullptr, *d_best = nullptr;
   int* d_tok = nullptr;
   int* d_tokens_all = nullptr;
+  int eot = 50257;
+  std::vector<unsigned char> sup_all, sup_first;   // host copies of the two suppression lists
 };
 
 namespace {
@@ -423,6 +425,190 @@ int crispy_asr_synchronize(crispy_asr* h) {
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return CRISPY_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+int reserve_dec(crispy_asr* h, int batch, int max_tokens) {
+  if (batch <= h->dcap_batch) return CRISPY_OK;
+  free_dec_ws(h);
+  const size_t B = batch, dt = h->hp.n_text_state, L = h->hp.n_text_layer, Tn = h->hp.n_audio_ctx,
+               C = h->hp.n_text_ctx, V = h->hp.n_vocab;
+  (void)max_tokens;
+  HIP_TRY(hipMalloc(&h->d_xkv, L * B * Tn * 2 * dt * sizeof(float)));
+  HIP_TRY(hipMalloc(&h->d_selfkv, L * B * C * 2 * dt * sizeof(float)));
+  HIP_TRY(hipMalloc(&h->d_dx, B * dt * sizeof(float)));
+  HIP_TRY(hipMalloc(&h->d_dxn, B * dt * sizeof(float)));
+  HIP_TRY(hipMalloc(&h->d_dq, B * dt * sizeof(float)));
+  HIP_TRY(hipMalloc(&h->d_datt, B * dt * sizeof(float)));
+  HIP_TRY(hipMalloc(&h->d_dh, B * 4 * dt * sizeof(float)));
+  HIP_TRY(hipMalloc(&h->d_logits, B * V * sizeof(float)));
+  HIP_TRY(hipMalloc(&h->d_best, B * C * sizeof(float)));
+  HIP_TRY(hipMalloc(&h->d_tok, B * sizeof(int)));
+  HIP_TRY(hipMalloc(&h->d_tokens_all, B * C * sizeof(int)));
+  h->dcap_batch = batch;
+  return CRISPY_OK;
+}
+
+// one decoder step for all clips: token ids in h->d_tok at position `pos`; leaves logits in h->d_logits
+int decoder_step(crispy_asr* h, int batch, int pos, bool want_logits, hipStream_t s) {
+  const int dt = h->hp.n_text_state, H = h->hp.n_text_head, Tn = h->hp.n_audio_ctx, C = h->hp.n_text_ctx,
+            V = h->hp.n_vocab;
+  HIP_TRY(embed_tokens_f32(h->d_tok, h->tok_emb, h->dec_pos, pos, h->d_dx, batch, dt, s));
+  for (size_t l = 0; l < h->dec.size(); ++l) {
+    const DecLayer& L = h->dec[l];
+    float* selfkv = h->d_selfkv + l * (size_t)batch * C * 2 * dt;
+    const float* xkv = h->d_xkv + l * (size_t)batch * Tn * 2 * dt;
+    // causal self-attention against the cache
+    HIP_TRY(layernorm_f32(h->d_dx, L.ln1_w, L.ln1_b, h->d_dxn, batch, dt, s));
+    HIP_TRY(gemm_f32_nt(gemm(h->d_dxn, dt, L.qkv_w, dt, h->d_dq, dt, L.qkv_b, batch, dt, dt), 1, s));
+    // k | v of this position go straight into the cache row (b, pos)
+    HIP_TRY(gemm_f32_nt(gemm(h->d_dxn, dt, L.qkv_w + (size_t)dt * dt, dt, selfkv + (size_t)pos * 2 * dt, (long)C * 2 * dt,
+                             L.qkv_b + dt, batch, 2 * dt, dt), 1, s));
+    HIP_TRY(attn_decoder_f32(h->d_dq, dt, selfkv, (long)C * 2 * dt, 2L * dt, 0, dt, pos + 1, h->d_datt, dt, batch, H, s));
+    {
+      GemmArgs g = gemm(h->d_datt, dt, L.out_w, dt, h->d_dx, dt, L.out_b, batch, dt, dt);
+      g.residual = h->d_dx; g.ldr = dt;
+      HIP_TRY(gemm_f32_nt(g, 1, s));
+    }
+    // cross-attention over the encoder output (K | V precomputed once per clip)
+    HIP_TRY(layernorm_f32(h->d_dx, L.lnx_w, L.lnx_b, h->d_dxn, batch, dt, s));
+    HIP_TRY(gemm_f32_nt(gemm(h->d_dxn, dt, L.xq_w, dt, h->d_dq, dt, L.xq_b, batch, dt, dt), 1, s));
+    HIP_TRY(attn_decoder_f32(h->d_dq, dt, xkv, (long)Tn * 2 * dt, 2L * dt, 0, dt, Tn, h->d_datt, dt, batch, H, s));
+    {
+      GemmArgs g = gemm(h->d_datt, dt, L.xout_w, dt, h->d_dx, dt, L.xout_b, batch, dt, dt);
+      g.residual = h->d_dx; g.ldr = dt;
+      HIP_TRY(gemm_f32_nt(g, 1, s));
+    }
+    // MLP
+    HIP_TRY(layernorm_f32(h->d_dx, L.ln2_w, L.ln2_b, h->d_dxn, batch, dt, s));
+    {
+      GemmArgs g = gemm(h->d_dxn, dt, L.fc1_w, dt, h->d_dh, 4L * dt, L.fc1_b, batch, 4 * dt, dt);
+      g.gelu = 1;
+      HIP_TRY(gemm_f32_nt(g, 1, s));
+    }
+    {
+      GemmArgs g = gemm(h->d_dh, 4L * dt, L.fc2_w, 4L * dt, h->d_dx, dt, L.fc2_b, batch, dt, 4 * dt);
+      g.residual = h->d_dx; g.ldr = dt;
+      HIP_TRY(gemm_f32_nt(g, 1, s));
+    }
+  }
+  if (want_logits) {
+    HIP_TRY(layernorm_f32(h->d_dx, h->dec_ln_w, h->dec_ln_b, h->d_dxn, batch, dt, s));
+    HIP_TRY(gemm_f32_nt(gemm(h->d_dxn, dt, h->tok_emb, dt, h->d_logits, V, nullptr, batch, V, dt), 1, s));
+  }
+  return CRISPY_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int crispy_asr_set_suppress(crispy_asr* h, const int* ids, int n, int first_only) {
+  if (!h || (n > 0 && !ids)) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_set_suppress: NULL argument");
+  if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_set_suppress: model not finalized");
+  std::vector<unsigned char> m(h->hp.n_vocab, 0);
+  for (int i = 0; i < n; ++i) {
+    if (ids[i] < 0 || ids[i] >= h->hp.n_vocab)
+      return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_set_suppress: token id %d out of range", ids[i]);
+    m[ids[i]] = 1;
+  }
+  if (h->sup_all.empty()) h->sup_all.assign(h->hp.n_vocab, 0);
+  if (h->sup_first.empty()) h->sup_first.assign(h->hp.n_vocab, 0);
+  (first_only ? h->sup_first : h->sup_all) = m;
+  std::vector<unsigned char> first(h->hp.n_vocab);
+  for (int v = 0; v < h->hp.n_vocab; ++v) first[v] = h->sup_all[v] | h->sup_first[v];   // first position: both lists
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemcpy(h->d_suppress, h->sup_all.data(), h->sup_all.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->d_suppress_first, first.data(), first.size(), hipMemcpyHostToDevice));
+  return CRISPY_OK;
+}
+
+int crispy_asr_decode_greedy_device(crispy_asr* h, const float* d_enc, int batch, const int* prompt, int n_prompt,
+                                    int max_new, int* tokens_out, int* n_out, float* logits_out) {
+  if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_decode_greedy_device: NULL handle");
+  if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_decode_greedy_device: model not finalized");
+  if (batch < 0 || max_new < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_decode_greedy_device: negative size");
+  if (batch == 0 || max_new == 0) return CRISPY_OK;
+  if (!d_enc || !prompt || n_prompt <= 0 || !tokens_out)
+    return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_decode_greedy_device: NULL argument");
+  if (n_prompt + max_new > h->hp.n_text_ctx)
+    return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_decode_greedy_device: %d prompt + %d new tokens exceed n_text_ctx %d",
+                n_prompt, max_new, h->hp.n_text_ctx);
+  for (int i = 0; i < n_prompt; ++i)
+    if (prompt[i] < 0 || prompt[i] >= h->hp.n_vocab)
+      return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_decode_greedy_device: prompt token %d out of range", prompt[i]);
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  int rc = reserve_dec(h, batch, n_prompt + max_new);
+  if (rc != CRISPY_OK) return rc;
+  const int dt = h->hp.n_text_state, Tn = h->hp.n_audio_ctx, V = h->hp.n_vocab, C = h->hp.n_text_ctx;
+  // cross K | V of every layer, once per clip
+  for (size_t l = 0; l < h->dec.size(); ++l) {
+    float* xkv = h->d_xkv + l * (size_t)batch * Tn * 2 * dt;
+    HIP_TRY(gemm_f32_nt(gemm(d_enc, dt, h->dec[l].xkv_w, dt, xkv, 2L * dt, h->dec[l].xkv_b, batch * Tn, 2 * dt, dt), 1, s));
+  }
+  std::vector<int> tok(batch);
+  int pos = 0;
+  for (int i = 0; i < n_prompt; ++i, ++pos) {
+    std::fill(tok.begin(), tok.end(), prompt[i]);
+    HIP_TRY(hipMemcpyAsync(h->d_tok, tok.data(), sizeof(int) * batch, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));  // tok is reused by the next iteration
+    rc = decoder_step(h, batch, pos, i == n_prompt - 1, s);
+    if (rc != CRISPY_OK) return rc;
+  }
+  for (int i = 0; i < max_new; ++i, ++pos) {
+    // pick from the logits of the previous step, then feed the pick back
+    const unsigned char* mask = (i == 0) ? h->d_suppress_first : h->d_suppress;
+    HIP_TRY(argmax_f32(h->d_logits, mask, V, h->d_tok, h->d_best + (size_t)i * batch, batch, s));
+    HIP_TRY(hipMemcpyAsync(h->d_tokens_all + (size_t)i * batch, h->d_tok, sizeof(int) * batch, hipMemcpyDeviceToDevice, s));
+    if (i + 1 < max_new) {
+      rc = decoder_step(h, batch, pos, true, s);
+      if (rc != CRISPY_OK) return rc;
+    }
+  }
+  std::vector<int> all((size_t)max_new * batch);
+  std::vector<float> best((size_t)max_new * batch);
+  HIP_TRY(hipMemcpyAsync(all.data(), h->d_tokens_all, all.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(best.data(), h->d_best, best.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  (void)C;
+  for (int b = 0; b < batch; ++b) {
+    int n = max_new;
+    for (int i = 0; i < max_new; ++i) {
+      tokens_out[(size_t)b * max_new + i] = all[(size_t)i * batch + b];
+      if (logits_out) logits_out[(size_t)b * max_new + i] = best[(size_t)i * batch + b];
+      if (n == max_new && all[(size_t)i * batch + b] == h->eot) n = i;
+    }
+    if (n_out) n_out[b] = n;
+  }
+  return CRISPY_OK;
+}
+
+int crispy_asr_transcribe_tokens(crispy_asr* h, const float* pcm, long pcm_stride, const int* n_samples, int batch,
+                                 const int* prompt, int n_prompt, int max_new, int* tokens_out, int* n_out) {
+  if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_tokens: NULL handle");
+  if (batch == 0) return CRISPY_OK;   // managers/transcription.rs:175-177: empty audio -> empty text
+  if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_transcribe_tokens: model not finalized");
+  if (!pcm || !n_samples || !tokens_out || !prompt)
+    return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_tokens: NULL argument");
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = reserve_enc(h, batch);
+  if (rc != CRISPY_OK) return rc;
+  if (!h->w_pcm || pcm_stride > h->cap_pcm_stride) {
+    if (h->w_pcm) (void)hipFree(h->w_pcm);
+    h->w_pcm = nullptr;
+    HIP_TRY(hipMalloc(&h->w_pcm, (size_t)h->cap_batch * pcm_stride * sizeof(float)));
+    h->cap_pcm_stride = pcm_stride;
+  }
+  HIP_TRY(hipMemcpyAsync(h->w_pcm, pcm, (size_t)batch * pcm_stride * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  rc = crispy_mel_compute_device(h->mel, h->w_pcm, pcm_stride, n_samples, batch, nullptr, h->w_melt, h->stream);
+  if (rc != CRISPY_OK) return rc;
+  rc = crispy_asr_encode_device(h, h->w_melt, batch, h->w_enc, h->stream);
+  if (rc != CRISPY_OK) return rc;
+  return crispy_asr_decode_greedy_device(h, h->w_enc, batch, prompt, n_prompt, max_new, tokens_out, n_out, nullptr);
 }
 
 }  // extern "C"

@@ -187,6 +187,28 @@ int crispy_asr_encode_device(crispy_asr *h, const float *d_mel_t, int batch, flo
                              void *hip_stream);
 int crispy_asr_synchronize(crispy_asr *h);
 
+/* Greedy decoding (north_star: greedy; the sampling strategy transcribe-rs 0.3.11 selects is
+ * unverifiable here).  Token ids listed with first_only = 0 are never
+ * emitted; those with first_only = 1 only at the first sampled position (whisper's suppress_blank).
+ * Nothing is suppressed until this is called. */
+int crispy_asr_set_suppress(crispy_asr *h, const int *ids, int n, int first_only);
+
+/* d_enc: DEVICE encoder output [batch][1500][n_text_state]; prompt: host token ids fed to every
+ * clip (<|startoftranscript|>, language, <|transcribe|>, <|notimestamps|>); up to max_new tokens
+ * are picked by argmax over f32 logits (ties: lowest id).  tokens_out [batch][max_new] (host),
+ * n_out[b] = number of tokens before the first EOT (host, nullable), logits_out (host, nullable)
+ * the logit of every pick. */
+int crispy_asr_decode_greedy_device(crispy_asr *h, const float *d_enc, int batch, const int *prompt,
+                                    int n_prompt, int max_new, int *tokens_out, int *n_out,
+                                    float *logits_out);
+
+/* SpeechModel::transcribe up to token ids: PCM (host) -> log-mel -> encoder -> greedy decoder.
+ * batch == 0 is the empty-audio no-op of managers/transcription.rs:175-177.  Detokenisation needs
+ * the vocabulary of a real model file and stays with the caller in this round. */
+int crispy_asr_transcribe_tokens(crispy_asr *h, const float *pcm, long pcm_stride,
+                                 const int *n_samples, int batch, const int *prompt, int n_prompt,
+                                 int max_new, int *tokens_out, int *n_out);
+
 #ifdef __cplusplus
 }
 #endif

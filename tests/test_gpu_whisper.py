@@ -71,3 +71,74 @@ def test_asr_container_errors(tiny):
     hpa = (C.c_int * 10)(*HParams(n_audio_state=100).as_ints())
     f = np.zeros((80, 201), np.float32)
     assert N.lib().crispy_asr_create(hpa, f.ctypes.data, 0, C.byref(h)) == -5
+
+
+def test_greedy_decode_matches_hf_golden(model):
+    """Token ids identical to HuggingFace greedy decoding with the same weights; logits of the picks agree."""
+    from crispy_amd import synth_audio
+    G = np.load(GOLD)
+    x = synth_audio.clip16k_np(0, 464000)
+    toks, n = model.transcribe_tokens([x], G["prompt"].tolist(), 12)
+    assert toks[0].tolist() == G["greedy_tokens"].tolist()
+    assert n[0] == 12     # no EOT with random weights
+
+
+def test_greedy_decode_batch_matches_oracle(tiny, model, oracle):
+    """Three different clips decoded together: ids equal to the float64 oracle's greedy ids wherever the
+    oracle's top-2 margin is resolvable in f32 (> 1e-3), pick logits within 1e-3."""
+    import torch
+    from crispy_amd import synth_audio
+    from crispy_amd.mel_filters import whisper_mel_filters
+    from oracle import whisper_oracle as WO
+    hp, W = tiny
+    prompt = [50258, 50259, 50359, 50363]
+    clips = [synth_audio.clip16k_np(60 + i, n) for i, n in enumerate((200000, 480000, 90000))]
+    enc = model.encode(clips)
+    d_enc = torch.from_numpy(enc).cuda()
+    torch.cuda.synchronize()
+    toks, n, lg = model.decode_greedy_device(d_enc.data_ptr(), 3, prompt, 5)
+    F = whisper_mel_filters(80)
+    for b, c in enumerate(clips):
+        ref_enc = WO.encoder_forward(W, hp, oracle.oracle_logmel(c, F))
+        rt, rb, rm = WO.greedy_decode(W, hp, ref_enc, prompt, 5)
+        for i in range(5):
+            if rm[i] > 1e-3:
+                assert toks[b, i] == rt[i], (b, i, toks[b], rt, rm)
+                assert abs(lg[b, i] - rb[i]) < 1e-3
+            else:
+                break
+
+
+def test_suppression_masks_and_batch_invariance(tiny, model):
+    from crispy_amd import synth_audio
+    from crispy_amd.asr import WhisperModel
+    hp, W = tiny
+    prompt = [50258, 50259, 50359, 50363]
+    clips = [synth_audio.clip16k_np(70 + i, 120000) for i in range(4)]
+    free, _ = model.transcribe_tokens(clips, prompt, 6)
+    m2 = WhisperModel(hp, W)
+    banned = np.unique(free)
+    m2.set_suppress(banned)                       # never emit what the free run emitted
+    sup, _ = m2.transcribe_tokens(clips, prompt, 6)
+    assert not np.isin(sup, banned).any()
+    m2.set_suppress([])                           # clear; ban the first pick at the first position only
+    m2.set_suppress([int(free[0, 0])], first_only=True)
+    fo, _ = m2.transcribe_tokens(clips[:1], prompt, 6)
+    assert fo[0, 0] != free[0, 0]
+    solo, _ = model.transcribe_tokens(clips[2:3], prompt, 6)
+    assert np.array_equal(solo[0], free[2])       # a clip decodes the same alone and inside a batch
+    empty_t, empty_n = model.transcribe_tokens([], prompt, 6)
+    assert empty_t.shape == (0, 6)                # managers/transcription.rs:175-177: empty audio -> nothing
+    m2.set_default_suppression()
+    d, _ = m2.transcribe_tokens(clips[:2], prompt, 6)
+    assert d.max() <= 50257 and d[0, 0] not in (220, 50257)
+
+
+def test_decode_argument_checks(model):
+    from crispy_amd import _native as N
+    import torch
+    d_enc = torch.zeros(1, 1500, 384, device="cuda")
+    with pytest.raises(N.CrispyError):
+        model.decode_greedy_device(d_enc.data_ptr(), 1, [50258], 448)      # prompt + new > n_text_ctx
+    with pytest.raises(N.CrispyError):
+        model.decode_greedy_device(d_enc.data_ptr(), 1, [60000], 4)        # token id out of range
