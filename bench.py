@@ -84,6 +84,64 @@ def cpu_baseline(n_threads: int, frames_per_thread: int):
                       f"{'-O3 -march=native' if lib_path else '-O2'}, one stream per thread, {dt:.1f} s"}
 
 
+def asr_leg(local_rank: int, clips: int = 64, new_tokens: int = 32):
+    """Second half of the headline metric: Whisper-tiny RTFx on one GPU (BASELINE configs[2]/[3]):
+    `clips` x 30 s of 16 kHz audio resident in HBM -> log-mel -> encoder -> greedy decode of
+    `new_tokens` tokens (random-init weights never emit EOT, so the decode length is fixed)."""
+    import numpy as np
+    import torch
+
+    from crispy_amd.asr import LogMel, WhisperModel
+    from crispy_amd.whisper_weights import HParams, synthetic_whisper_weights
+
+    hp = HParams.tiny()
+    model = WhisperModel(hp, synthetic_whisper_weights(hp, 0), device=local_rank)
+    lm = LogMel(hp.n_mels, device=local_rank)
+    dev = torch.device("cuda", local_rank)
+    g = torch.Generator(device=dev).manual_seed(0)
+    pcm = torch.randn(clips, 480000, generator=g, device=dev) * 0.1
+    melt = torch.zeros(clips, 3002, hp.n_mels, device=dev)
+    enc = torch.empty(clips, 1500, hp.n_audio_state, device=dev)
+    lens = np.full(clips, 480000)
+    prompt = [50258, 50259, 50359, 50363]
+    torch.cuda.synchronize()
+
+    def mel():
+        lm.compute_device(pcm.data_ptr(), 480000, lens, 0, melt.data_ptr())
+        lm.synchronize()
+
+    def encode():
+        model.encode_device(melt.data_ptr(), clips, enc.data_ptr())
+        model.synchronize()
+
+    def decode():
+        model.decode_greedy_device(enc.data_ptr(), clips, prompt, new_tokens)
+
+    times = {}
+    for name, fn, reps in (("logmel", mel, 5), ("encoder", encode, 3), ("decode", decode, 1)):
+        fn()  # warm-up
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        times[name] = (time.perf_counter() - t0) / reps
+    audio_s = clips * 30.0
+    enc_flops = clips * 36.9e9          # SURVEY.md 8d: Whisper-tiny encoder per 30 s clip
+    total = sum(times.values())
+    return {
+        "model": "whisper-tiny architecture, seeded random-init weights, f32 on f32-input MFMA",
+        "clips": clips, "audio_seconds": audio_s, "new_tokens": new_tokens,
+        "logmel_ms": times["logmel"] * 1e3, "encoder_ms": times["encoder"] * 1e3,
+        "decode_ms": times["decode"] * 1e3, "decode_ms_per_token": times["decode"] * 1e3 / new_tokens,
+        "rtfx_logmel_encoder": audio_s / (times["logmel"] + times["encoder"]),
+        "rtfx_end_to_end": audio_s / total,
+        "logmel_roofline": {"bound": "hbm", "achieved": clips * 2.88e6 / times["logmel"] / 1e9, "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": clips * 2.88e6 / times["logmel"] / 1e9 / HBM_PEAK_GBS},
+        "encoder_roofline": {"bound": "mfma", "achieved": enc_flops / times["encoder"] / 1e12, "peak": 157.3,
+                             "unit": "TFLOP/s", "frac": enc_flops / times["encoder"] / 1e12 / 157.3,
+                             "note": "peak = dense f32-input MFMA (v_mfma_f32_32x32x2_f32)"},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,6 +150,7 @@ def main():
     ap.add_argument("--streams", type=int, default=4096, help="streams per GPU")
     ap.add_argument("--frames", type=int, default=100, help="frames per stream per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-asr", action="store_true", help="skip the Whisper-tiny leg of the metric")
     args = ap.parse_args()
 
     import torch
@@ -194,6 +253,10 @@ def main():
             ncores = os.cpu_count() or 1
             nthreads = max(1, min(ncores, 32))
             line["cpu_baseline"] = cpu_baseline(nthreads, 2500)
+        if world == 1 and not args.no_asr:
+            del d_in, d_out
+            torch.cuda.empty_cache()
+            line["asr"] = asr_leg(local_rank)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -32,7 +32,8 @@ MEL_SYMBOLS = ("crispy_mel_create", "crispy_mel_destroy", "crispy_mel_compute",
                "crispy_mel_compute_device", "crispy_mel_synchronize")
 ASR_SYMBOLS = ("crispy_asr_create", "crispy_asr_set_tensor", "crispy_asr_finalize", "crispy_asr_free",
                "crispy_asr_hparams_get", "crispy_asr_encode", "crispy_asr_encode_device", "crispy_asr_synchronize",
-               "crispy_asr_set_suppress", "crispy_asr_decode_greedy_device", "crispy_asr_transcribe_tokens")
+               "crispy_asr_set_suppress", "crispy_asr_decode_greedy_device", "crispy_asr_transcribe_tokens",
+               "crispy_asr_load", "crispy_asr_token_text", "crispy_asr_transcribe", "crispy_asr_free_result")
 ALL_SYMBOLS = RN_SYMBOLS + MEL_SYMBOLS + ASR_SYMBOLS
 
 class CrispyError(RuntimeError):
@@ -98,6 +99,11 @@ def lib() -> C.CDLL:
     L.crispy_asr_set_suppress.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     L.crispy_asr_decode_greedy_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                                   C.c_void_p, C.c_void_p, C.c_void_p]
+    L.crispy_asr_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.crispy_asr_token_text.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
+    L.crispy_asr_transcribe.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.crispy_asr_free_result.argtypes = [C.c_void_p]
+    L.crispy_asr_free_result.restype = None
     L.crispy_asr_transcribe_tokens.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_void_p,
                                                C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     _lib = L

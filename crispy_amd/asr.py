@@ -154,3 +154,51 @@ class WhisperModel:
                                                      pcm.shape[0], p.ctypes.data, p.size, max_new,
                                                      toks.ctypes.data, n.ctypes.data))
         return toks, n
+
+
+class WhisperEngine(WhisperModel):
+    """`WhisperEngine::load(&model_path)` + `transcribe(&audio, &TranscribeOptions::default())`
+    (managers/transcription.rs:138-141, 183-185) over a whisper.cpp GGML model file."""
+
+    def __init__(self, model_path: str, device: int = 0):  # noqa: super().__init__ is the tensor-by-tensor path
+        from .whisper_weights import HParams
+
+        self._h = C.c_void_p()
+        N.check(N.lib().crispy_asr_load(str(model_path).encode(), device, C.byref(self._h)))
+        hpa = (C.c_int * 10)()
+        N.check(N.lib().crispy_asr_hparams_get(self._h, hpa))
+        self.hp = HParams(*[int(v) for v in hpa])
+
+    def token_text(self, token: int) -> bytes:
+        p, n = C.c_char_p(), C.c_size_t()
+        N.check(N.lib().crispy_asr_token_text(self._h, int(token), C.byref(p), C.byref(n)))
+        return C.string_at(p, n.value)
+
+    def transcribe(self, audio: np.ndarray, max_new_tokens: int = 0, translate: bool = False):
+        """One chunk (<= 480000 samples at 16 kHz) -> (text, token ids); empty audio -> ("", [])."""
+        a = np.ascontiguousarray(audio, dtype=np.float32).ravel()
+        opts = (C.c_int * 3)(0, int(translate), int(max_new_tokens))
+        res = C.c_void_p()
+        N.check(N.lib().crispy_asr_transcribe(self._h, a.ctypes.data if a.size else None, a.size, opts, C.byref(res)))
+        try:
+            text_p = C.cast(res, C.POINTER(C.c_char_p))[0]
+            tok_p = C.cast(res.value + 8, C.POINTER(C.POINTER(C.c_int)))[0]
+            n_tok = C.cast(res.value + 16, C.POINTER(C.c_int))[0]
+            text = text_p.decode("utf-8", "replace") if text_p else ""
+            tokens = [int(tok_p[i]) for i in range(n_tok)]
+        finally:
+            N.lib().crispy_asr_free_result(res)
+        return text, tokens
+
+
+def transcribe_recording(engine: "WhisperEngine", pcm16k: np.ndarray, max_new_tokens: int = 0) -> str:
+    """The chunker of `run_transcription` (commands/transcription.rs:249-302, 363-400, 468): hard 30 s cuts,
+    the final partial chunk passed as is, chunk texts trimmed and joined with a single space."""
+    parts = []
+    x = np.ascontiguousarray(pcm16k, dtype=np.float32).ravel()
+    for t0 in range(0, x.size, CHUNK_SAMPLES):
+        text, _ = engine.transcribe(x[t0:t0 + CHUNK_SAMPLES], max_new_tokens)
+        text = text.strip()
+        if text:
+            parts.append(text)
+    return " ".join(parts)

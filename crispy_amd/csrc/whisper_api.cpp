@@ -2,6 +2,7 @@
 // encoder, greedy decoder.  Replaces transcribe_rs::whisper_cpp::WhisperEngine::{load, transcribe}
 // (reference: src-tauri/src/managers/transcription.rs:138-141, 183-185).
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <new>
@@ -62,6 +63,7 @@ struct crispy_asr {
   int* d_tokens_all = nullptr;
   int eot = 50257;
   std::vector<unsigned char> sup_all, sup_first;   // host copies of the two suppression lists
+  std::vector<std::string> vocab;                  // token byte strings of a loaded model file
 };
 
 namespace {
@@ -219,6 +221,7 @@ int crispy_asr_create(const crispy_asr_hparams* hp, const float* mel_filters, in
   if (!h) return fail(CRISPY_ERR_OOM, "crispy_asr_create: host allocation failed");
   h->device = device;
   h->hp = *hp;
+  h->eot = hp->n_vocab >= 51865 ? 50257 : 50256;   // multilingual vocabularies shift the specials by one
   auto body = [&]() -> int {
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -609,6 +612,185 @@ int crispy_asr_transcribe_tokens(crispy_asr* h, const float* pcm, long pcm_strid
   rc = crispy_asr_encode_device(h, h->w_melt, batch, h->w_enc, h->stream);
   if (rc != CRISPY_OK) return rc;
   return crispy_asr_decode_greedy_device(h, h->w_enc, batch, prompt, n_prompt, max_new, tokens_out, n_out, nullptr);
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// whisper.cpp GGML model file [UPSTREAM-RECALL]:
+//   u32 magic 0x67676d6c | 11 x i32 hparams (.., n_mels, ftype) | i32 n_mel, i32 n_fft, f32 filters
+//   | i32 n_tokens, then (u32 len, bytes) per token | tensors until EOF:
+//   i32 n_dims, i32 name_len, i32 ttype, i32 ne[n_dims] (innermost first), name, data.
+// f32 (ttype 0) and f16 (ttype 1) tensors are supported; quantised catalog files are SURVEY 8(f) rank 4.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct FileReader {
+  FILE* f = nullptr;
+  ~FileReader() { if (f) fclose(f); }
+  bool read(void* dst, size_t n) { return fread(dst, 1, n, f) == n; }
+};
+
+float half_to_float(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000) << 16;
+  uint32_t exp = (h >> 10) & 0x1f, man = h & 0x3ff, bits;
+  if (exp == 0) {
+    if (man == 0) bits = sign;
+    else {
+      exp = 127 - 15 + 1;
+      while (!(man & 0x400)) { man <<= 1; --exp; }
+      bits = sign | (exp << 23) | ((man & 0x3ff) << 13);
+    }
+  } else if (exp == 31) bits = sign | 0x7f800000u | (man << 13);
+  else bits = sign | ((exp + 127 - 15) << 23) | (man << 13);
+  float out;
+  std::memcpy(&out, &bits, 4);
+  return out;
+}
+
+}  // namespace
+
+struct crispy_asr_result_impl {
+  crispy_asr_result pub;
+  std::string text;
+  std::vector<int> tokens;
+};
+
+extern "C" {
+
+int crispy_asr_load(const char* model_path, int device, crispy_asr** out) {
+  if (!out) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_load: out is NULL");
+  *out = nullptr;
+  if (!model_path) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_load: NULL path");
+  FileReader r;
+  r.f = fopen(model_path, "rb");
+  if (!r.f) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_load: cannot open '%s'", model_path);
+  uint32_t magic = 0;
+  int32_t hpv[11];
+  if (!r.read(&magic, 4) || magic != 0x67676d6c)
+    return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_load: '%s' is not a ggml whisper model (bad magic)", model_path);
+  if (!r.read(hpv, sizeof(hpv))) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_load: truncated header");
+  crispy_asr_hparams hp;
+  hp.n_vocab = hpv[0]; hp.n_audio_ctx = hpv[1]; hp.n_audio_state = hpv[2]; hp.n_audio_head = hpv[3];
+  hp.n_audio_layer = hpv[4]; hp.n_text_ctx = hpv[5]; hp.n_text_state = hpv[6]; hp.n_text_head = hpv[7];
+  hp.n_text_layer = hpv[8]; hp.n_mels = hpv[9];
+  int32_t fm = 0, ff = 0;
+  if (!r.read(&fm, 4) || !r.read(&ff, 4) || fm != hp.n_mels || ff != MEL_BINS)
+    return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_load: mel filter block is %d x %d, expected %d x %d", fm, ff, hp.n_mels,
+                MEL_BINS);
+  std::vector<float> filters((size_t)fm * ff);
+  if (!r.read(filters.data(), filters.size() * 4)) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_load: truncated filters");
+  int32_t n_tok = 0;
+  if (!r.read(&n_tok, 4) || n_tok < 0 || n_tok > hp.n_vocab + 1024)
+    return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_load: bad vocabulary size %d", n_tok);
+  std::vector<std::string> vocab(n_tok);
+  for (int i = 0; i < n_tok; ++i) {
+    uint32_t len = 0;
+    if (!r.read(&len, 4) || len > 4096) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_load: bad token %d", i);
+    vocab[i].resize(len);
+    if (len && !r.read(&vocab[i][0], len)) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_load: truncated vocabulary");
+  }
+  crispy_asr* h = nullptr;
+  int rc = crispy_asr_create(&hp, filters.data(), device, &h);
+  if (rc != CRISPY_OK) return rc;
+  h->vocab = std::move(vocab);
+  auto bail = [&](int code) {
+    const std::string keep = last_error_cstr();
+    crispy_asr_free(h);
+    return fail(code, "%s", keep.c_str());
+  };
+  std::vector<float> buf;
+  std::vector<uint16_t> hbuf;
+  for (;;) {
+    int32_t n_dims = 0, name_len = 0, ttype = 0;
+    if (!r.read(&n_dims, 4)) break;  // clean EOF
+    if (!r.read(&name_len, 4) || !r.read(&ttype, 4) || n_dims < 1 || n_dims > 4 || name_len <= 0 || name_len > 256) {
+      fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_load: corrupt tensor header");
+      return bail(CRISPY_ERR_BAD_MODEL);
+    }
+    int32_t ne[4] = {1, 1, 1, 1};
+    size_t n = 1;
+    for (int i = 0; i < n_dims; ++i) {
+      if (!r.read(&ne[i], 4) || ne[i] <= 0) { fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_load: corrupt tensor shape"); return bail(CRISPY_ERR_BAD_MODEL); }
+      n *= (size_t)ne[i];
+    }
+    std::string name(name_len, '\0');
+    if (!r.read(&name[0], name_len)) { fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_load: truncated tensor name"); return bail(CRISPY_ERR_BAD_MODEL); }
+    buf.resize(n);
+    if (ttype == 0) {
+      if (!r.read(buf.data(), n * 4)) { fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_load: truncated data of '%s'", name.c_str()); return bail(CRISPY_ERR_BAD_MODEL); }
+    } else if (ttype == 1) {
+      hbuf.resize(n);
+      if (!r.read(hbuf.data(), n * 2)) { fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_load: truncated data of '%s'", name.c_str()); return bail(CRISPY_ERR_BAD_MODEL); }
+      for (size_t i = 0; i < n; ++i) buf[i] = half_to_float(hbuf[i]);
+    } else {
+      fail(CRISPY_ERR_UNSUPPORTED, "crispy_asr_load: tensor '%s' has ggml type %d; only f32 (0) and f16 (1) are supported "
+           "(quantised catalog models are not implemented yet)", name.c_str(), ttype);
+      return bail(CRISPY_ERR_UNSUPPORTED);
+    }
+    rc = crispy_asr_set_tensor(h, name.c_str(), buf.data(), n);
+    if (rc != CRISPY_OK) return bail(rc);
+  }
+  rc = crispy_asr_finalize(h);
+  if (rc != CRISPY_OK) return bail(rc);
+  *out = h;
+  return CRISPY_OK;
+}
+
+int crispy_asr_token_text(const crispy_asr* h, int token, const char** text, size_t* len) {
+  if (!h || !text || !len) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_token_text: NULL argument");
+  if (token < 0 || token >= (int)h->vocab.size())
+    return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_token_text: token %d has no vocabulary entry", token);
+  *text = h->vocab[token].data();
+  *len = h->vocab[token].size();
+  return CRISPY_OK;
+}
+
+int crispy_asr_transcribe(crispy_asr* h, const float* pcm16k, size_t n, const crispy_asr_opts* opts,
+                          crispy_asr_result** out) {
+  if (!out) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe: out is NULL");
+  *out = nullptr;
+  if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe: NULL handle");
+  crispy_asr_result_impl* res = new (std::nothrow) crispy_asr_result_impl();
+  if (!res) return fail(CRISPY_ERR_OOM, "crispy_asr_transcribe: host allocation failed");
+  auto finish = [&]() {
+    res->pub.text = res->text.c_str();
+    res->pub.tokens = res->tokens.data();
+    res->pub.n_tokens = (int)res->tokens.size();
+    *out = &res->pub;
+    return CRISPY_OK;
+  };
+  if (n == 0) return finish();                       // managers/transcription.rs:175-177
+  if (!pcm16k) { delete res; return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe: NULL audio"); }
+  if (n > 480000) { delete res; return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe: %zu samples; the caller chunks at 480000 (commands/transcription.rs:249-302)", n); }
+  // special tokens [UPSTREAM-RECALL, whisper.cpp vocab]: sot = eot + 1; multilingual files carry 99 (+extra)
+  // language tokens, then translate, transcribe, solm, prev, nosp, notimestamps
+  const bool multilingual = h->hp.n_vocab >= 51865;
+  const int extra = multilingual ? h->hp.n_vocab - 51865 : 0;
+  const int sot = h->eot + 1;
+  std::vector<int> prompt = {sot};
+  if (multilingual) {
+    prompt.push_back(opts && opts->language_token > 0 ? opts->language_token : sot + 1);   // <|en|>
+    prompt.push_back((opts && opts->translate ? sot + 100 : sot + 101) + extra);
+  }
+  prompt.push_back(sot + 105 + extra);                                                      // <|notimestamps|>
+  int max_new = opts && opts->max_new_tokens > 0 ? opts->max_new_tokens : h->hp.n_text_ctx / 2;
+  if ((int)prompt.size() + max_new > h->hp.n_text_ctx) max_new = h->hp.n_text_ctx - (int)prompt.size();
+  std::vector<int> toks(max_new);
+  int n_out = 0;
+  const int ns = (int)n;
+  int rc = crispy_asr_transcribe_tokens(h, pcm16k, (long)n, &ns, 1, prompt.data(), (int)prompt.size(), max_new,
+                                        toks.data(), &n_out);
+  if (rc != CRISPY_OK) { delete res; return rc; }
+  res->tokens.assign(toks.begin(), toks.begin() + n_out);
+  for (int t : res->tokens)
+    if (t < h->eot && t < (int)h->vocab.size()) res->text += h->vocab[t];
+  return finish();
+}
+
+void crispy_asr_free_result(crispy_asr_result* r) {
+  if (!r) return;
+  delete reinterpret_cast<crispy_asr_result_impl*>(r);   // pub is the first member
 }
 
 }  // extern "C"

@@ -209,6 +209,35 @@ int crispy_asr_transcribe_tokens(crispy_asr *h, const float *pcm, long pcm_strid
                                  const int *n_samples, int batch, const int *prompt, int n_prompt,
                                  int max_new, int *tokens_out, int *n_out);
 
+/* WhisperEngine::load(&model_path) (managers/transcription.rs:138-141): parse a whisper.cpp GGML
+ * model file (hparams, mel filters, vocabulary, f32 / f16 tensors) and build a finalized engine.
+ * Quantised files (q4_1 / q5_0 catalog entries, managers/model.rs:99,137) -> CRISPY_ERR_UNSUPPORTED. */
+int crispy_asr_load(const char *model_path, int device, crispy_asr **out);
+
+/* Byte string of one vocabulary entry of a loaded model file (not NUL-terminated). */
+int crispy_asr_token_text(const crispy_asr *h, int token, const char **text, size_t *len);
+
+/* TranscribeOptions::default() (managers/transcription.rs:184): language unset, transcribe task. */
+typedef struct crispy_asr_opts {
+  int language_token;  /* 0 = <|en|> (auto-detection is not implemented) */
+  int translate;       /* 0 = transcribe */
+  int max_new_tokens;  /* 0 = n_text_ctx / 2 */
+} crispy_asr_opts;
+
+/* Library-owned result of one transcribe call; release with crispy_asr_free_result. */
+typedef struct crispy_asr_result {
+  const char *text;    /* UTF-8, NUL-terminated, untrimmed (the caller trims: transcription.rs:187) */
+  const int *tokens;   /* the greedy token ids before <|endoftext|> */
+  int n_tokens;
+} crispy_asr_result;
+
+/* engine.transcribe(&audio, &TranscribeOptions::default()) for ONE chunk of <= 480000 samples
+ * (16 kHz f32, host).  n == 0 returns an empty result (transcription.rs:175-177).  Needs a model
+ * loaded from a file (vocabulary) for text; tokens are always returned. */
+int crispy_asr_transcribe(crispy_asr *h, const float *pcm16k, size_t n, const crispy_asr_opts *opts,
+                          crispy_asr_result **out);
+void crispy_asr_free_result(crispy_asr_result *r);
+
 #ifdef __cplusplus
 }
 #endif

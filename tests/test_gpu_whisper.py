@@ -142,3 +142,75 @@ def test_decode_argument_checks(model):
         model.decode_greedy_device(d_enc.data_ptr(), 1, [50258], 448)      # prompt + new > n_text_ctx
     with pytest.raises(N.CrispyError):
         model.decode_greedy_device(d_enc.data_ptr(), 1, [60000], 4)        # token id out of range
+
+
+@pytest.fixture(scope="module")
+def ggml_file(tiny, tmp_path_factory):
+    from crispy_amd.ggml_io import synthetic_vocab, write_ggml
+    from crispy_amd.mel_filters import whisper_mel_filters
+    hp, W = tiny
+    path = tmp_path_factory.mktemp("ggml") / "ggml-tiny-synth.bin"
+    write_ggml(str(path), hp, W, whisper_mel_filters(80), synthetic_vocab(hp.n_vocab), f16=False)
+    return path
+
+
+def test_ggml_model_file_load_and_text(tiny, model, ggml_file):
+    """WhisperEngine::load(path) + transcribe(): same tokens as the tensor-by-tensor container, text =
+    concatenated vocabulary pieces; the chunker joins trimmed chunk texts with one space."""
+    from crispy_amd import synth_audio
+    from crispy_amd.asr import WhisperEngine, transcribe_recording
+    hp, W = tiny
+    eng = WhisperEngine(str(ggml_file))
+    assert eng.hp == hp
+    assert eng.token_text(123) == b" w123"
+    x = synth_audio.clip16k_np(0, 464000)
+    text, toks = eng.transcribe(x, max_new_tokens=6)
+    ref, _ = model.transcribe_tokens([x], [50258, 50259, 50359, 50363], 6)
+    assert toks == ref[0].tolist()
+    assert text == "".join(f" w{t}" for t in toks)
+    assert eng.transcribe(np.zeros(0, np.float32)) == ("", [])           # transcription.rs:175-177
+    long = np.concatenate([x, synth_audio.clip16k_np(1, 100000)])       # 35.25 s -> two chunks
+    joined = transcribe_recording(eng, long, max_new_tokens=3)
+    t1, _ = eng.transcribe(long[:480000], 3)
+    t2, _ = eng.transcribe(long[480000:], 3)
+    assert joined == t1.strip() + " " + t2.strip()
+
+
+def test_ggml_f16_file_and_bad_files(tiny, tmp_path):
+    from crispy_amd import _native as N, synth_audio
+    from crispy_amd.asr import WhisperEngine
+    from crispy_amd.ggml_io import synthetic_vocab, write_ggml
+    from crispy_amd.mel_filters import whisper_mel_filters
+    hp, W = tiny
+    p16 = tmp_path / "f16.bin"
+    write_ggml(str(p16), hp, W, whisper_mel_filters(80), synthetic_vocab(hp.n_vocab), f16=True)
+    eng = WhisperEngine(str(p16))
+    W16 = {k: (v.astype(np.float16).astype(np.float32) if v.ndim >= 2 and "positional" not in k else v) for k, v in W.items()}
+    from crispy_amd.asr import WhisperModel
+    ref_model = WhisperModel(hp, W16)
+    x = synth_audio.clip16k_np(3, 200000)
+    _, toks = eng.transcribe(x, max_new_tokens=4)
+    ref, _ = ref_model.transcribe_tokens([x], [50258, 50259, 50359, 50363], 4)
+    assert toks == ref[0].tolist()                      # f16 storage == weights rounded to f16, computed in f32
+    bad = tmp_path / "bad.bin"
+    bad.write_bytes(b"not a model file at all")
+    with pytest.raises(N.CrispyError) as e:
+        WhisperEngine(str(bad))
+    assert e.value.code == -5
+    with pytest.raises(N.CrispyError):
+        WhisperEngine(str(tmp_path / "missing.bin"))
+    trunc = tmp_path / "trunc.bin"
+    trunc.write_bytes(p16.read_bytes()[:5_000_000])
+    with pytest.raises(N.CrispyError):
+        WhisperEngine(str(trunc))
+    # a quantised tensor type is refused with UNSUPPORTED, not misread
+    raw = bytearray(p16.read_bytes()[:2_000_000])
+    q = tmp_path / "quant.bin"
+    import struct
+    idx = raw.find(b"encoder.conv1.bias")
+    assert idx > 0
+    struct.pack_into("<i", raw, idx - 4 * 2 - 4, 3)    # ttype field of that tensor header -> q4_1
+    q.write_bytes(bytes(raw))
+    with pytest.raises(N.CrispyError) as e:
+        WhisperEngine(str(q))
+    assert e.value.code in (-6, -5)
