@@ -214,3 +214,29 @@ def test_ggml_f16_file_and_bad_files(tiny, tmp_path):
     with pytest.raises(N.CrispyError) as e:
         WhisperEngine(str(q))
     assert e.value.code in (-6, -5)
+
+
+def test_whisper_base_architecture_parity(oracle):
+    """BASELINE cfg 5 uses Whisper-base (d 512, 6+6 layers, 8 heads): encoder and first greedy picks vs the oracle."""
+    import torch
+    from crispy_amd import synth_audio
+    from crispy_amd.asr import WhisperModel
+    from crispy_amd.mel_filters import whisper_mel_filters
+    from crispy_amd.whisper_weights import HParams, synthetic_whisper_weights
+    from oracle import whisper_oracle as WO
+    hp = HParams.base()
+    W = synthetic_whisper_weights(hp, 1)
+    m = WhisperModel(hp, W)
+    x = synth_audio.clip16k_np(80, 300000)
+    enc = m.encode([x])[0]
+    ref = WO.encoder_forward(W, hp, oracle.oracle_logmel(x, whisper_mel_filters(80)))
+    assert enc.shape == (1500, 512)
+    assert np.abs(enc - ref).max() <= 1e-4 * np.abs(ref).max()
+    prompt = [50258, 50259, 50359, 50363]
+    toks, _ = m.transcribe_tokens([x], prompt, 3)
+    rt, rb, rm = WO.greedy_decode(W, hp, ref, prompt, 3)
+    for i in range(3):
+        if rm[i] > 1e-3:
+            assert toks[0, i] == rt[i]
+        else:
+            break
