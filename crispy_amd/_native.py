@@ -34,7 +34,9 @@ ASR_SYMBOLS = ("crispy_asr_create", "crispy_asr_set_tensor", "crispy_asr_finaliz
                "crispy_asr_hparams_get", "crispy_asr_encode", "crispy_asr_encode_device", "crispy_asr_synchronize",
                "crispy_asr_set_suppress", "crispy_asr_decode_greedy_device", "crispy_asr_transcribe_tokens",
                "crispy_asr_load", "crispy_asr_token_text", "crispy_asr_transcribe", "crispy_asr_free_result")
-ALL_SYMBOLS = RN_SYMBOLS + MEL_SYMBOLS + ASR_SYMBOLS
+RS_SYMBOLS = ("crispy_resampler_create", "crispy_resampler_destroy", "crispy_resampler_out_len",
+              "crispy_resampler_process_device", "crispy_resampler_synchronize")
+ALL_SYMBOLS = RN_SYMBOLS + MEL_SYMBOLS + ASR_SYMBOLS + RS_SYMBOLS
 
 class CrispyError(RuntimeError):
     def __init__(self, code: int, msg: str):
@@ -106,6 +108,14 @@ def lib() -> C.CDLL:
     L.crispy_asr_free_result.restype = None
     L.crispy_asr_transcribe_tokens.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_void_p,
                                                C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.crispy_resampler_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.crispy_resampler_destroy.argtypes = [C.c_void_p]
+    L.crispy_resampler_destroy.restype = None
+    L.crispy_resampler_out_len.argtypes = [C.c_long]
+    L.crispy_resampler_out_len.restype = C.c_long
+    L.crispy_resampler_process_device.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_float,
+                                                  C.c_int, C.c_void_p, C.c_long, C.c_void_p]
+    L.crispy_resampler_synchronize.argtypes = [C.c_void_p]
     _lib = L
     return L
 

@@ -180,3 +180,142 @@ int crispy_mel_synchronize(crispy_mel* h) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// 48 -> 16 kHz resampler
+// ---------------------------------------------------------------------------------------------
+struct crispy_resampler {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  float* d_w = nullptr;     // [684][1040] circulant operator
+  float* d_a = nullptr;     // [rows][1040]
+  float* d_y = nullptr;     // [rows][684]
+  long cap_rows = 0;
+};
+
+extern "C" {
+
+long crispy_resampler_out_len(long n_in) {
+  if (n_in <= 0) return 0;
+  const long n_pad = (n_in + RS_CHUNK - 1) / RS_CHUNK * RS_CHUNK;   // last chunk zero-padded (transcription.rs:347-351)
+  return n_pad / RS_FFT_IN * RS_FFT_OUT;
+}
+
+int crispy_resampler_create(int device, crispy_resampler** out) {
+  if (!out) return fail(CRISPY_ERR_INVALID_ARG, "crispy_resampler_create: out is NULL");
+  *out = nullptr;
+  int rc = check_device(device, "crispy_resampler_create");
+  if (rc != CRISPY_OK) return rc;
+  // windowed-sinc anti-aliasing filter and its band-limited circular impulse response g[2052], in double
+  const double pi = 3.14159265358979323846;
+  const int NI = RS_FFT_IN, NO = RS_FFT_OUT, N2 = 2 * RS_FFT_IN;
+  std::vector<double> ft(NI);
+  {
+    const double cutoff = std::pow(0.4, 16.0 / NI) * NO / NI;
+    double sum = 0.0;
+    for (int n = 0; n < NI; ++n) {
+      const double x = (double)n / NI;
+      double w = 0.35875 - 0.48829 * std::cos(2 * pi * x) + 0.14128 * std::cos(4 * pi * x) - 0.01168 * std::cos(6 * pi * x);
+      w *= w;
+      const double t = (n - NI / 2) * cutoff;
+      const double sinc = t == 0.0 ? 1.0 : std::sin(pi * t) / (pi * t);
+      ft[n] = w * sinc;
+      sum += ft[n];
+    }
+    for (int n = 0; n < NI; ++n) ft[n] = ft[n] / sum / (double)N2;
+  }
+  std::vector<double> Fr(NO), Fi(NO);
+  for (int k = 0; k < NO; ++k) {
+    double re = 0, im = 0;
+    for (int n = 0; n < NI; ++n) {
+      const double th = -2.0 * pi * (double)((long)k * n % N2) / N2;
+      re += ft[n] * std::cos(th);
+      im += ft[n] * std::sin(th);
+    }
+    Fr[k] = re; Fi[k] = im;
+  }
+  std::vector<double> g(N2);
+  for (int m = 0; m < N2; ++m) {
+    double acc = Fr[0];
+    for (int k = 1; k < NO; ++k) {
+      const double th = 2.0 * pi * (double)((long)k * m % N2) / N2;
+      acc += 2.0 * (Fr[k] * std::cos(th) - Fi[k] * std::sin(th));
+    }
+    g[m] = acc;
+  }
+  std::vector<float> W((size_t)RS_N * RS_K, 0.f);
+  for (int n = 0; n < RS_N; ++n)
+    for (int j = 0; j < NI; ++j) W[(size_t)n * RS_K + j] = (float)g[((3 * n - j) % N2 + N2) % N2];
+  crispy_resampler* h = new (std::nothrow) crispy_resampler();
+  if (!h) return fail(CRISPY_ERR_OOM, "crispy_resampler_create: host allocation failed");
+  h->device = device;
+  auto body = [&]() -> int {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc(&h->d_w, W.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(h->d_w, W.data(), W.size() * sizeof(float), hipMemcpyHostToDevice));
+    return CRISPY_OK;
+  };
+  rc = body();
+  if (rc != CRISPY_OK) { crispy_resampler_destroy(h); return rc; }
+  *out = h;
+  return CRISPY_OK;
+}
+
+void crispy_resampler_destroy(crispy_resampler* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (void* p : {(void*)h->d_w, (void*)h->d_a, (void*)h->d_y})
+    if (p) (void)hipFree(p);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int crispy_resampler_process_device(crispy_resampler* h, const float* d_in, long in_stride, long n_in, int batch,
+                                    float scale, int wav_s16, float* d_out, long out_stride, void* hip_stream) {
+  if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_resampler_process_device: NULL handle");
+  if (batch < 0 || n_in < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_resampler_process_device: negative size");
+  const long n_out = crispy_resampler_out_len(n_in);
+  if (batch == 0 || n_out == 0) return CRISPY_OK;
+  if (!d_in || !d_out || in_stride < n_in || out_stride < n_out)
+    return fail(CRISPY_ERR_INVALID_ARG, "crispy_resampler_process_device: bad pointer or stride");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
+  const int n_blk = (int)(n_out / RS_FFT_OUT);
+  // bounded workspace: process the streams in groups
+  const long max_rows = 1L << 17;   // 131072 rows: 545 MB of A + 359 MB of Y
+  int group = (int)(max_rows / n_blk);
+  if (group < 1) group = 1;
+  if (group > batch) group = batch;
+  const long rows_cap = (long)group * n_blk;
+  if (rows_cap > h->cap_rows) {
+    if (h->d_a) (void)hipFree(h->d_a);
+    if (h->d_y) (void)hipFree(h->d_y);
+    h->d_a = h->d_y = nullptr;
+    h->cap_rows = 0;
+    HIP_TRY(hipMalloc(&h->d_a, (size_t)rows_cap * RS_K * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_y, (size_t)rows_cap * RS_N * sizeof(float)));
+    h->cap_rows = rows_cap;
+  }
+  for (int b0 = 0; b0 < batch; b0 += group) {
+    const int nb = (batch - b0) < group ? (batch - b0) : group;
+    const long rows = (long)nb * n_blk;
+    HIP_TRY(rs_prep(d_in + (long)b0 * in_stride, in_stride, n_in, scale, wav_s16, h->d_a, nb, n_blk, s));
+    GemmArgs g{};
+    g.A = h->d_a; g.lda = RS_K; g.W = h->d_w; g.ldw = RS_K; g.C = h->d_y; g.ldc = RS_N;
+    g.M = (int)rows; g.N = RS_N; g.K = RS_K;
+    HIP_TRY(gemm_f32_nt(g, 1, s));
+    HIP_TRY(rs_ola(h->d_y, d_out + (long)b0 * out_stride, out_stride, nb, n_blk, s));
+  }
+  return CRISPY_OK;
+}
+
+int crispy_resampler_synchronize(crispy_resampler* h) {
+  if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_resampler_synchronize: NULL handle");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return CRISPY_OK;
+}
+
+}  // extern "C"

@@ -51,6 +51,14 @@ hipError_t attn_decoder_f32(const float* q, long ldq, const float* kv, long kv_b
                             int voff, int n_keys, float* out, long ldo, int B, int heads, hipStream_t s);
 hipError_t embed_tokens_f32(const int* tokens, const float* tok_emb, const float* pos_emb, int pos, float* x, int B,
                             int D, hipStream_t s);
+// 48 -> 16 kHz resampler (rubato FftFixedIn(.., 1024, 1, 1) geometry)
+constexpr int RS_FFT_IN = 1026, RS_FFT_OUT = 342, RS_CHUNK = 1024;
+constexpr int RS_K = 1040;   // 1026 padded to the GEMM's k granularity
+constexpr int RS_N = 684;    // 342 outputs + 342 of overlap per block
+hipError_t rs_prep(const float* in, long in_stride, long n_in, float scale, int wav_s16, float* A, int batch,
+                   int n_blk, hipStream_t s);
+hipError_t rs_ola(const float* Y, float* out, long out_stride, int batch, int n_blk, hipStream_t s);
+
 hipError_t argmax_f32(const float* logits, const unsigned char* mask, int V, int* tokens_out, float* best, int B,
                       hipStream_t s);
 

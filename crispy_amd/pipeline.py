@@ -1,0 +1,96 @@
+"""End-to-end hot path of BASELINE cfg 4: denoise -> (WAV s16 hand-off) -> 48->16 kHz -> log-mel -> Whisper.
+
+Mirrors the product's data flow: `RnnNoiseProcessor` output (audio.rs:270-278: /32768, clamp,
+first frame dropped) -> s16 WAV (recording.rs:101-118) -> `run_transcription` (commands/transcription.rs:
+channel 0 /32768, rubato 48->16 kHz in 1024-sample chunks, hard 30 s chunks, greedy transcribe, join).
+Everything between the 48 kHz input tensor and the token ids stays in HBM."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+from .asr import CHUNK_SAMPLES, LogMel, WhisperModel
+from .denoise import FRAME_SIZE, DenoiseState
+
+
+class Resampler48to16:
+    """rubato FftFixedIn(48000 -> 16000, chunk 1024) on the GPU (device tensors in, device tensors out)."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        N.check(N.lib().crispy_resampler_create(device, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            N.lib().crispy_resampler_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def out_len(n_in: int) -> int:
+        return int(N.lib().crispy_resampler_out_len(int(n_in)))
+
+    def process_device(self, d_in: int, in_stride: int, n_in: int, batch: int, d_out: int, out_stride: int,
+                       scale: float = 1.0, handoff: int = 0, stream: int = 0):
+        N.check(N.lib().crispy_resampler_process_device(self._h, d_in, in_stride, n_in, batch, scale, handoff,
+                                                        d_out, out_stride, stream or None))
+
+    def synchronize(self):
+        N.check(N.lib().crispy_resampler_synchronize(self._h))
+
+
+class DenoiseTranscribePipeline:
+    """B streams of 48 kHz audio -> greedy token ids per 30 s chunk, all on one GPU."""
+
+    def __init__(self, rn_weights: np.ndarray, whisper: WhisperModel, n_streams: int, device: int = 0,
+                 wav_handoff: bool = True):
+        import torch
+
+        self.torch = torch
+        self.dev = torch.device("cuda", device)
+        self.B = n_streams
+        self.ds = DenoiseState(rn_weights, n_streams, device)
+        self.rs = Resampler48to16(device)
+        self.whisper = whisper
+        self.lm = LogMel(whisper.hp.n_mels, device=device)
+        self.handoff = 2 if wav_handoff else 1
+
+    def run(self, d_in48, prompt, max_new: int):
+        """d_in48: torch float32 [B, T, 480] on the device, int16-range samples (x32768 already applied).
+        Returns (tokens [B, n_chunks, max_new], pcm16k [B, n16] on the device)."""
+        torch = self.torch
+        B, T, _ = d_in48.shape
+        assert B == self.B and d_in48.is_contiguous()
+        den = torch.empty_like(d_in48)
+        torch.cuda.synchronize()
+        self.ds.process_device(d_in48.data_ptr(), den.data_ptr(), T, layout="btf")
+        self.ds.synchronize()
+        n48 = (T - 1) * FRAME_SIZE                       # first frame dropped (audio.rs:275-278)
+        n16 = Resampler48to16.out_len(n48)
+        pcm16 = torch.zeros(B, max(n16, 1), device=self.dev)
+        den_flat = den.view(B, T * FRAME_SIZE)
+        self.rs.process_device(den_flat.data_ptr() + 4 * FRAME_SIZE, T * FRAME_SIZE, n48, B, pcm16.data_ptr(),
+                               pcm16.shape[1], scale=1.0 / 32768.0, handoff=self.handoff)
+        self.rs.synchronize()
+        n_chunks = max(1, -(-n16 // CHUNK_SAMPLES))
+        hp = self.whisper.hp
+        toks = np.zeros((B, n_chunks, max_new), dtype=np.int32)
+        melt = torch.zeros(B, 3002, hp.n_mels, device=self.dev)
+        enc = torch.empty(B, hp.n_audio_ctx, hp.n_audio_state, device=self.dev)
+        for c in range(n_chunks):
+            lo = c * CHUNK_SAMPLES
+            n = min(CHUNK_SAMPLES, n16 - lo)
+            self.lm.compute_device(pcm16.data_ptr() + 4 * lo, pcm16.shape[1], np.full(B, n), 0, melt.data_ptr())
+            self.lm.synchronize()
+            self.whisper.encode_device(melt.data_ptr(), B, enc.data_ptr())
+            self.whisper.synchronize()
+            t, _, _ = self.whisper.decode_greedy_device(enc.data_ptr(), B, prompt, max_new)
+            toks[:, c] = t
+        return toks, pcm16[:, :n16]

@@ -238,6 +238,27 @@ int crispy_asr_transcribe(crispy_asr *h, const float *pcm16k, size_t n, const cr
                           crispy_asr_result **out);
 void crispy_asr_free_result(crispy_asr_result *r);
 
+/* ------------------------------------------------------------------------------------------
+ * 48 kHz -> 16 kHz resampler between the denoiser and the ASR front end:
+ * rubato FftFixedIn::<f32>::new(48000, 16000, 1024, 1, 1) as driven by
+ * commands/transcription.rs:198-208, 314-357 (1024-sample chunks, last one zero-padded, the tail
+ * shorter than one 1026-sample FFT block is never flushed), optionally preceded by the s16 WAV
+ * hand-off of recording.rs:101-118 / commands/transcription.rs:306-313.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct crispy_resampler crispy_resampler;
+int crispy_resampler_create(int device, crispy_resampler **out);
+void crispy_resampler_destroy(crispy_resampler *h);
+/* 16 kHz samples produced for n_in 48 kHz samples: floor(ceil(n_in/1024)*1024 / 1026) * 342. */
+long crispy_resampler_out_len(long n_in);
+/* DEVICE pointers: d_in [batch][in_stride] (n_in valid samples each), d_out [batch][out_stride].
+ * Every input sample is multiplied by `scale` first (1/32768 after the denoiser).  wav_s16: 0 = nothing
+ * else, 1 = clamp(-1,1) (audio.rs:272), 2 = clamp, x32767 truncated to s16, /32768 (the WAV hand-off).
+ * Enqueued on hip_stream (NULL = own stream). */
+int crispy_resampler_process_device(crispy_resampler *h, const float *d_in, long in_stride, long n_in,
+                                    int batch, float scale, int wav_s16, float *d_out,
+                                    long out_stride, void *hip_stream);
+int crispy_resampler_synchronize(crispy_resampler *h);
+
 #ifdef __cplusplus
 }
 #endif
