@@ -52,19 +52,19 @@ void build_tables(RnTables* t) {
   }
 }
 
-// [K][rows] int8 (row stride `stride`, column offset `col0`) -> dwords [ceil(K/4)][rows]
-void pack_matrix(uint32_t* dst, const int8_t* src, int K, int rows, int stride, int col0 = 0) {
-  const int k4n = (K + 3) / 4;
-  for (int k4 = 0; k4 < k4n; ++k4)
-    for (int r = 0; r < rows; ++r) {
-      uint32_t w = 0;
-      for (int q = 0; q < 4; ++q) {
-        const int k = 4 * k4 + q;
-        const uint8_t byte = k < K ? (uint8_t)src[(size_t)k * stride + col0 + r] : 0;
-        w |= (uint32_t)byte << (8 * q);
+// [K][rows] int8 (row stride `stride`) -> f16 [ceil(K/8)][rows][8]; dst in 16-byte units (4 dwords)
+void pack_matrix(uint32_t* dst, const int8_t* src, int K, int rows, int stride) {
+  const int k8n = (K + 7) / 8;
+  uint16_t* h = reinterpret_cast<uint16_t*>(dst);
+  for (int k8 = 0; k8 < k8n; ++k8)
+    for (int r = 0; r < rows; ++r)
+      for (int q = 0; q < 8; ++q) {
+        const int k = 8 * k8 + q;
+        const _Float16 v = (_Float16)(float)(k < K ? src[(size_t)k * stride + r] : 0);
+        uint16_t bits;
+        std::memcpy(&bits, &v, 2);
+        h[((size_t)k8 * rows + r) * 8 + q] = bits;
       }
-      dst[(size_t)k4 * rows + r] = w;
-    }
 }
 
 void pack_bias(uint32_t* dst, const int8_t* src, int n) {
@@ -77,15 +77,15 @@ void pack_bias(uint32_t* dst, const int8_t* src, int n) {
 void pack_weights(std::vector<uint32_t>& out, const int8_t* w) {
   out.assign(RnPack::END, 0);
   uint32_t* p = out.data();
-  pack_matrix(p + RnPack::ID_W, w + RnBlob::ID_W, 42, 24, 24);
-  pack_matrix(p + RnPack::VG_W, w + RnBlob::VG_W, 24, 72, 72);
-  pack_matrix(p + RnPack::VG_R, w + RnBlob::VG_R, 24, 72, 72);
-  pack_matrix(p + RnPack::VO_W, w + RnBlob::VO_W, 24, 1, 1);
-  pack_matrix(p + RnPack::NG_W, w + RnBlob::NG_W, 90, 144, 144);
-  pack_matrix(p + RnPack::NG_R, w + RnBlob::NG_R, 48, 144, 144);
-  pack_matrix(p + RnPack::DG_W, w + RnBlob::DG_W, 114, 288, 288);
-  pack_matrix(p + RnPack::DG_R, w + RnBlob::DG_R, 96, 288, 288);
-  pack_matrix(p + RnPack::DO_W, w + RnBlob::DO_W, 96, 22, 22);
+  pack_matrix(p + 4 * RnPack::ID_W, w + RnBlob::ID_W, 42, 24, 24);
+  pack_matrix(p + 4 * RnPack::VG_W, w + RnBlob::VG_W, 24, 72, 72);
+  pack_matrix(p + 4 * RnPack::VG_R, w + RnBlob::VG_R, 24, 72, 72);
+  pack_matrix(p + 4 * RnPack::VO_W, w + RnBlob::VO_W, 24, 1, 1);
+  pack_matrix(p + 4 * RnPack::NG_W, w + RnBlob::NG_W, 90, 144, 144);
+  pack_matrix(p + 4 * RnPack::NG_R, w + RnBlob::NG_R, 48, 144, 144);
+  pack_matrix(p + 4 * RnPack::DG_W, w + RnBlob::DG_W, 114, 288, 288);
+  pack_matrix(p + 4 * RnPack::DG_R, w + RnBlob::DG_R, 96, 288, 288);
+  pack_matrix(p + 4 * RnPack::DO_W, w + RnBlob::DO_W, 96, 22, 22);
   pack_bias(p + RnPack::ID_B, w + RnBlob::ID_B, 24);
   pack_bias(p + RnPack::VG_B, w + RnBlob::VG_B, 72);
   pack_bias(p + RnPack::VO_B, w + RnBlob::VO_B, 1);

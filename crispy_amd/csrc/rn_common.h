@@ -40,31 +40,30 @@ struct RnBlob {
 };
 static_assert(RnBlob::END == RN_WEIGHT_BYTES, "blob layout");
 
-// Repacked weights: every matrix [K][rows] int8 becomes dwords [ceil(K/4)][rows] holding the
-// four k-consecutive weights of one row, so that lane == row reads one coalesced dword per
-// four MACs.  Biases are widened to float.  Offsets are in dwords from the pack base.
-constexpr int rn_k4(int k) { return (k + 3) / 4; }
+// Repacked weights: every matrix [K][rows] int8 becomes f16 (int8 values are exact in f16) in units of
+// 8 halfs = 16 bytes, laid out [ceil(K/8)][rows][8]: lane == row reads one coalesced 16-byte vector per
+// 8 MACs and each MAC is a single v_fma_mix_f32.  Biases are widened to float.
+// Matrix offsets are in 16-byte units from the pack base, bias offsets in floats from the pack base.
+constexpr int rn_k8(int k) { return (k + 7) / 8; }
 struct RnPack {
-  // matrices (dword offsets)
-  static constexpr int k4(int k) { return rn_k4(k); }
-  static constexpr int ID_W = 0;                              // K=42  rows=24
-  static constexpr int VG_W = ID_W + rn_k4(42) * 24;             // K=24  rows=72
-  static constexpr int VG_R = VG_W + rn_k4(24) * 72;             // K=24  rows=72
-  static constexpr int VO_W = VG_R + rn_k4(24) * 72;             // K=24  rows=1
-  static constexpr int NG_W = VO_W + rn_k4(24) * 1;              // K=90  rows=144
-  static constexpr int NG_R = NG_W + rn_k4(90) * 144;            // K=48  rows=144
-  static constexpr int DG_W = NG_R + rn_k4(48) * 144;            // K=114 rows=288
-  static constexpr int DG_R = DG_W + rn_k4(114) * 288;           // K=96  rows=288
-  static constexpr int DO_W = DG_R + rn_k4(96) * 288;            // K=96  rows=22
-  static constexpr int MAT_END = DO_W + rn_k4(96) * 22;
-  // float biases (dword offsets)
-  static constexpr int ID_B = MAT_END;
+  static constexpr int ID_W = 0;                               // K=42  rows=24
+  static constexpr int VG_W = ID_W + rn_k8(42) * 24;           // K=24  rows=72
+  static constexpr int VG_R = VG_W + rn_k8(24) * 72;           // K=24  rows=72
+  static constexpr int VO_W = VG_R + rn_k8(24) * 72;           // K=24  rows=1
+  static constexpr int NG_W = VO_W + rn_k8(24) * 1;            // K=90  rows=144
+  static constexpr int NG_R = NG_W + rn_k8(90) * 144;          // K=48  rows=144
+  static constexpr int DG_W = NG_R + rn_k8(48) * 144;          // K=114 rows=288
+  static constexpr int DG_R = DG_W + rn_k8(114) * 288;         // K=96  rows=288
+  static constexpr int DO_W = DG_R + rn_k8(96) * 288;          // K=96  rows=22
+  static constexpr int MAT_END = DO_W + rn_k8(96) * 22;        // 16-byte units
+  // float biases (offsets in floats)
+  static constexpr int ID_B = MAT_END * 4;
   static constexpr int VG_B = ID_B + 24;
   static constexpr int VO_B = VG_B + 72;
   static constexpr int NG_B = VO_B + 1;
   static constexpr int DG_B = NG_B + 144;
   static constexpr int DO_B = DG_B + 288;
-  static constexpr int END = DO_B + 22;
+  static constexpr int END = DO_B + 22;                        // total size in dwords
 };
 
 // Kernel arguments of one enqueue (chunk of T frames for all B streams).

@@ -275,57 +275,63 @@ __device__ __forceinline__ float sigmoid_approx(float x, const float* __restrict
   return .5f + .5f * tansig_approx(.5f * x, table);
 }
 
-__device__ __forceinline__ float mac4_i8(uint32_t w, float4 xv, float acc) {
-  acc = fmaf((float)(int)(int8_t)(w & 0xff), xv.x, acc);
-  acc = fmaf((float)(int)(int8_t)((w >> 8) & 0xff), xv.y, acc);
-  acc = fmaf((float)(int)(int8_t)((w >> 16) & 0xff), xv.z, acc);
-  acc = fmaf((float)((int)w >> 24), xv.w, acc);
-  return acc;
-}
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
-// acc += sum_k W[k][row] * x[k]; x lives in LDS, 16-byte aligned, zero padded to 4*K4.
-// Loads are issued eight at a time so that one L2 round trip covers 32 MACs.
-template <int K4>
-__device__ __forceinline__ float dot_i8(const uint32_t* __restrict__ Wp, int rows, int row,
-                                        const float* x, float acc) {
+// acc += sum_k W[k][row] * x[k].  Weights: f16 [K8][rows][8] (16 bytes per lane per 8 MACs, each MAC one
+// v_fma_mix_f32); x lives in LDS, 16-byte aligned, zero padded to 8*K8.  Four 16-byte loads are kept in
+// flight so that one L2 round trip covers 32 MACs.
+template <int K8>
+__device__ __forceinline__ float dot_h(const h8* __restrict__ Wp, int rows, int row, const float* x, float acc) {
   const float4* x4 = reinterpret_cast<const float4*>(x);
-  const uint32_t* p = Wp + row;
-  constexpr int BLK = 8;
+  const h8* p = Wp + row;
+  constexpr int BLK = 4;
 #pragma unroll 1
-  for (int k0 = 0; k0 + BLK <= K4; k0 += BLK) {
-    uint32_t w[BLK];
+  for (int k0 = 0; k0 + BLK <= K8; k0 += BLK) {
+    h8 w[BLK];
 #pragma unroll
     for (int q = 0; q < BLK; ++q) w[q] = p[(k0 + q) * rows];
 #pragma unroll
-    for (int q = 0; q < BLK; ++q) acc = mac4_i8(w[q], x4[k0 + q], acc);
+    for (int q = 0; q < BLK; ++q) {
+      const float4 a = x4[2 * (k0 + q)], b = x4[2 * (k0 + q) + 1];
+      acc = fmaf((float)w[q][0], a.x, acc); acc = fmaf((float)w[q][1], a.y, acc);
+      acc = fmaf((float)w[q][2], a.z, acc); acc = fmaf((float)w[q][3], a.w, acc);
+      acc = fmaf((float)w[q][4], b.x, acc); acc = fmaf((float)w[q][5], b.y, acc);
+      acc = fmaf((float)w[q][6], b.z, acc); acc = fmaf((float)w[q][7], b.w, acc);
+    }
   }
-  constexpr int REM = K4 % BLK;
+  constexpr int REM = K8 % BLK;
   if (REM) {
-    constexpr int k0 = K4 - REM;
-    uint32_t w[REM ? REM : 1];
+    constexpr int k0 = K8 - REM;
+    h8 w[REM ? REM : 1];
 #pragma unroll
     for (int q = 0; q < REM; ++q) w[q] = p[(k0 + q) * rows];
 #pragma unroll
-    for (int q = 0; q < REM; ++q) acc = mac4_i8(w[q], x4[k0 + q], acc);
+    for (int q = 0; q < REM; ++q) {
+      const float4 a = x4[2 * (k0 + q)], b = x4[2 * (k0 + q) + 1];
+      acc = fmaf((float)w[q][0], a.x, acc); acc = fmaf((float)w[q][1], a.y, acc);
+      acc = fmaf((float)w[q][2], a.z, acc); acc = fmaf((float)w[q][3], a.w, acc);
+      acc = fmaf((float)w[q][4], b.x, acc); acc = fmaf((float)w[q][5], b.y, acc);
+      acc = fmaf((float)w[q][6], b.z, acc); acc = fmaf((float)w[q][7], b.w, acc);
+    }
   }
   return acc;
 }
 
-// One GRU layer (ReLU candidate).  in_vec[M] and state[N] in LDS, zero padded to multiples of 4;
+// One GRU layer (ReLU candidate).  in_vec[M] and state[N] in LDS, zero padded to multiples of 8;
 // zbuf / hr: N floats of scratch each.
 template <int M, int N>
-__device__ __forceinline__ void gru_layer(const uint32_t* __restrict__ W, const uint32_t* __restrict__ U,
+__device__ __forceinline__ void gru_layer(const h8* __restrict__ W, const h8* __restrict__ U,
                                           const float* __restrict__ bias, const float* in_vec,
                                           float* state, float* zbuf, float* hr,
                                           const float* __restrict__ tansig, int lane) {
   constexpr int ROWS = 3 * N;
-  constexpr int MK4 = (M + 3) / 4, NK4 = (N + 3) / 4;
+  constexpr int MK8 = (M + 7) / 8, NK8 = (N + 7) / 8;
   const float S = 1.f / 256.f;
   // update (z) and reset (r) gates: rows [0, 2N)
   for (int row = lane; row < 2 * N; row += WAVE) {
     float acc = bias[row];
-    acc = dot_i8<MK4>(W, ROWS, row, in_vec, acc);
-    acc = dot_i8<NK4>(U, ROWS, row, state, acc);
+    acc = dot_h<MK8>(W, ROWS, row, in_vec, acc);
+    acc = dot_h<NK8>(U, ROWS, row, state, acc);
     const float s = sigmoid_approx(S * acc, tansig);
     if (row < N) zbuf[row] = s;
     else hr[row - N] = state[row - N] * s;
@@ -334,8 +340,8 @@ __device__ __forceinline__ void gru_layer(const uint32_t* __restrict__ W, const 
   // candidate rows [2N, 3N): recurrent part sees h*r
   for (int i = lane; i < N; i += WAVE) {
     float acc = bias[2 * N + i];
-    acc = dot_i8<MK4>(W, ROWS, 2 * N + i, in_vec, acc);
-    acc = dot_i8<NK4>(U, ROWS, 2 * N + i, hr, acc);
+    acc = dot_h<MK8>(W, ROWS, 2 * N + i, in_vec, acc);
+    acc = dot_h<NK8>(U, ROWS, 2 * N + i, hr, acc);
     float c = S * acc;
     c = c < 0.f ? 0.f : c;
     const float z = zbuf[i];
@@ -362,7 +368,7 @@ struct alignas(16) RnLds {
 static_assert(sizeof(RnLds) <= 10240, "16 workgroups per CU need <= 10 KB of LDS each");
 
 // offsets (floats) inside Bb while it serves the RNN
-constexpr int RB_FEAT = 0, RB_DENSE = 44, RB_IN = 68, RB_Z = 184, RB_HR = 280, RB_PART = 384;
+constexpr int RB_FEAT = 0, RB_DENSE = 48, RB_IN = 72, RB_Z = 192, RB_HR = 288, RB_PART = 384;
 // offsets inside U outside band_sums
 constexpr int U_LY = 0, U_TMP = 24, U_G = 48, U_R = 72, U_VAD = 96;
 
@@ -438,13 +444,14 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     lane = lane0;
     asm volatile("" : "+v"(lane));
     const RnTables* tabv = a.tab;
-    const uint32_t* wp = a.wpack;
-    asm volatile("" : "+s"(tabv), "+s"(wp)::"memory");
+    const uint32_t* wpraw = a.wpack;
+    asm volatile("" : "+s"(tabv), "+s"(wpraw)::"memory");
+    const h8* wp = reinterpret_cast<const h8*>(wpraw);
     const RnTables* __restrict__ tab = tabv;
     const float2* __restrict__ w960 = tab->w960;
     const float* __restrict__ hw = tab->half_window;
     const float* __restrict__ tansig = tab->tansig;
-    const float* __restrict__ wpf = reinterpret_cast<const float*>(wp);
+    const float* __restrict__ wpf = reinterpret_cast<const float*>(wpraw);
     const float* xw = xs + (long)(t + 3) * RN_FRAME;  // [x_prev, x_cur]
     const float* pb = xs + (long)t * RN_FRAME + 672;  // 1728-sample pitch buffer ending at x_cur
 
@@ -816,7 +823,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
       L.Exp[lane] = L.Exp[lane] / sqrtf(.001f + L.Ex[lane] * L.Ep[lane]);
       L.U[U_LY + lane] = log10f(1e-2f + L.Ex[lane]);
     }
-    if (lane < 2) { Rb[RB_FEAT + 42 + lane] = 0.f; }
+    if (lane < 6) { Rb[RB_FEAT + 42 + lane] = 0.f; }
     __syncthreads();
     if (a.dbg && t == a.T - 1 && lane < RN_NB) {
       float* D = a.dbg + (long)b * RN_DBG_FLOATS;
@@ -903,7 +910,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
       float* gin = Rb + RB_IN;
       if (lane < 24) {
         float acc = wpf[RnPack::ID_B + lane];
-        acc = dot_i8<rn_k4(42)>(wp + RnPack::ID_W, 24, lane, feat, acc);
+        acc = dot_h<rn_k8(42)>(wp + RnPack::ID_W, 24, lane, feat, acc);
         dense[lane] = tansig_approx(S * acc, tansig);
       }
       __syncthreads();
@@ -911,10 +918,10 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                         L.rnn_state, Rb + RB_Z, Rb + RB_HR, tansig, lane);
       if (lane == 0) {
         float acc = wpf[RnPack::VO_B];
-        acc = dot_i8<rn_k4(24)>(wp + RnPack::VO_W, 1, 0, L.rnn_state, acc);
+        acc = dot_h<rn_k8(24)>(wp + RnPack::VO_W, 1, 0, L.rnn_state, acc);
         L.U[U_VAD] = sigmoid_approx(S * acc, tansig);
       }
-      for (int i = lane; i < 92; i += WAVE)
+      for (int i = lane; i < 96; i += WAVE)
         gin[i] = i < 24 ? dense[i] : (i < 48 ? L.rnn_state[i - 24] : (i < 90 ? feat[i - 48] : 0.f));
       __syncthreads();
       vad_prob = L.U[U_VAD];
@@ -922,14 +929,14 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
       gru_layer<90, 48>(wp + RnPack::NG_W, wp + RnPack::NG_R, wpf + RnPack::NG_B, gin,
                         L.rnn_state + 24, Rb + RB_Z, Rb + RB_HR, tansig, lane);
       STAMP(11)
-      for (int i = lane; i < 116; i += WAVE)
+      for (int i = lane; i < 120; i += WAVE)
         gin[i] = i < 72 ? L.rnn_state[i] : (i < 114 ? feat[i - 72] : 0.f);
       __syncthreads();
       gru_layer<114, 96>(wp + RnPack::DG_W, wp + RnPack::DG_R, wpf + RnPack::DG_B, gin,
                          L.rnn_state + 72, Rb + RB_Z, Rb + RB_HR, tansig, lane);
       if (lane < RN_NB) {
         float acc = wpf[RnPack::DO_B + lane];
-        acc = dot_i8<rn_k4(96)>(wp + RnPack::DO_W, RN_NB, lane, L.rnn_state + 72, acc);
+        acc = dot_h<rn_k8(96)>(wp + RnPack::DO_W, RN_NB, lane, L.rnn_state + 72, acc);
         L.U[U_G + lane] = sigmoid_approx(S * acc, tansig);
       }
       __syncthreads();
