@@ -621,7 +621,8 @@ int crispy_asr_transcribe_tokens(crispy_asr* h, const float* pcm, long pcm_strid
 //   u32 magic 0x67676d6c | 11 x i32 hparams (.., n_mels, ftype) | i32 n_mel, i32 n_fft, f32 filters
 //   | i32 n_tokens, then (u32 len, bytes) per token | tensors until EOF:
 //   i32 n_dims, i32 name_len, i32 ttype, i32 ne[n_dims] (innermost first), name, data.
-// f32 (ttype 0) and f16 (ttype 1) tensors are supported; quantised catalog files are SURVEY 8(f) rank 4.
+// f32 / f16 tensors are taken as is; q4_0, q4_1, q5_0, q5_1, q8_0 blocks (the catalog's medium-q4_1 and
+// large-v3-q5_0 files, managers/model.rs:99,137) are de-quantised to f32 at load time.
 // ---------------------------------------------------------------------------------------------
 namespace {
 
@@ -646,6 +647,49 @@ float half_to_float(uint16_t h) {
   float out;
   std::memcpy(&out, &bits, 4);
   return out;
+}
+
+
+// ggml block-quantised rows -> f32 [UPSTREAM-RECALL ggml-quants]: blocks of 32 weights along the innermost
+// dimension; d (and m) are f16; low nibbles are elements 0..15 of the block, high nibbles 16..31; q5 adds a
+// fifth bit per element from the 32-bit mask qh.
+struct QuantInfo { int block_bytes; };
+bool quant_info(int ttype, QuantInfo* qi) {
+  switch (ttype) {
+    case 2: qi->block_bytes = 2 + 16; return true;           // q4_0
+    case 3: qi->block_bytes = 2 + 2 + 16; return true;       // q4_1
+    case 6: qi->block_bytes = 2 + 4 + 16; return true;       // q5_0
+    case 7: qi->block_bytes = 2 + 2 + 4 + 16; return true;   // q5_1
+    case 8: qi->block_bytes = 2 + 32; return true;           // q8_0
+    default: return false;
+  }
+}
+void dequant_block(int ttype, const uint8_t* b, float* y) {
+  auto h = [&](const uint8_t* p) { uint16_t v; std::memcpy(&v, p, 2); return half_to_float(v); };
+  if (ttype == 2) {
+    const float d = h(b); const uint8_t* qs = b + 2;
+    for (int j = 0; j < 16; ++j) { y[j] = ((qs[j] & 0x0F) - 8) * d; y[j + 16] = ((qs[j] >> 4) - 8) * d; }
+  } else if (ttype == 3) {
+    const float d = h(b), m = h(b + 2); const uint8_t* qs = b + 4;
+    for (int j = 0; j < 16; ++j) { y[j] = (qs[j] & 0x0F) * d + m; y[j + 16] = (qs[j] >> 4) * d + m; }
+  } else if (ttype == 6) {
+    const float d = h(b); uint32_t qh; std::memcpy(&qh, b + 2, 4); const uint8_t* qs = b + 6;
+    for (int j = 0; j < 16; ++j) {
+      const int x0 = (qs[j] & 0x0F) | (((qh >> j) & 1) << 4);
+      const int x1 = (qs[j] >> 4) | (((qh >> (j + 16)) & 1) << 4);
+      y[j] = (x0 - 16) * d; y[j + 16] = (x1 - 16) * d;
+    }
+  } else if (ttype == 7) {
+    const float d = h(b), m = h(b + 2); uint32_t qh; std::memcpy(&qh, b + 4, 4); const uint8_t* qs = b + 8;
+    for (int j = 0; j < 16; ++j) {
+      const int x0 = (qs[j] & 0x0F) | (((qh >> j) & 1) << 4);
+      const int x1 = (qs[j] >> 4) | (((qh >> (j + 16)) & 1) << 4);
+      y[j] = x0 * d + m; y[j + 16] = x1 * d + m;
+    }
+  } else {  // q8_0
+    const float d = h(b); const int8_t* qs = reinterpret_cast<const int8_t*>(b + 2);
+    for (int j = 0; j < 32; ++j) y[j] = qs[j] * d;
+  }
 }
 
 }  // namespace
@@ -701,6 +745,7 @@ int crispy_asr_load(const char* model_path, int device, crispy_asr** out) {
   };
   std::vector<float> buf;
   std::vector<uint16_t> hbuf;
+  std::vector<uint8_t> qbuf;
   for (;;) {
     int32_t n_dims = 0, name_len = 0, ttype = 0;
     if (!r.read(&n_dims, 4)) break;  // clean EOF
@@ -724,9 +769,16 @@ int crispy_asr_load(const char* model_path, int device, crispy_asr** out) {
       if (!r.read(hbuf.data(), n * 2)) { fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_load: truncated data of '%s'", name.c_str()); return bail(CRISPY_ERR_BAD_MODEL); }
       for (size_t i = 0; i < n; ++i) buf[i] = half_to_float(hbuf[i]);
     } else {
-      fail(CRISPY_ERR_UNSUPPORTED, "crispy_asr_load: tensor '%s' has ggml type %d; only f32 (0) and f16 (1) are supported "
-           "(quantised catalog models are not implemented yet)", name.c_str(), ttype);
-      return bail(CRISPY_ERR_UNSUPPORTED);
+      QuantInfo qi;
+      if (!quant_info(ttype, &qi) || ne[0] % 32 != 0) {
+        fail(CRISPY_ERR_UNSUPPORTED, "crispy_asr_load: tensor '%s' has ggml type %d (supported: f32 0, f16 1, q4_0 2, "
+             "q4_1 3, q5_0 6, q5_1 7, q8_0 8; rows must be multiples of 32)", name.c_str(), ttype);
+        return bail(CRISPY_ERR_UNSUPPORTED);
+      }
+      const size_t n_blocks = n / 32;
+      qbuf.resize(n_blocks * qi.block_bytes);
+      if (!r.read(qbuf.data(), qbuf.size())) { fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_load: truncated data of '%s'", name.c_str()); return bail(CRISPY_ERR_BAD_MODEL); }
+      for (size_t bi = 0; bi < n_blocks; ++bi) dequant_block(ttype, qbuf.data() + bi * qi.block_bytes, buf.data() + bi * 32);
     }
     rc = crispy_asr_set_tensor(h, name.c_str(), buf.data(), n);
     if (rc != CRISPY_OK) return bail(rc);

@@ -240,3 +240,25 @@ def test_whisper_base_architecture_parity(oracle):
             assert toks[0, i] == rt[i]
         else:
             break
+
+
+@pytest.mark.parametrize("kind", ["q5_0", "q4_1", "q8_0", "q4_0", "q5_1"])
+def test_quantised_ggml_files_load(tiny, tmp_path, kind):
+    """The catalog ships q4_1 / q5_0 files (managers/model.rs:99,137): blocks are de-quantised at load; the
+    engine then equals a model built from the same de-quantised weights."""
+    from crispy_amd import synth_audio
+    from crispy_amd.asr import WhisperEngine, WhisperModel
+    from crispy_amd.ggml_io import synthetic_vocab, write_ggml_quantized
+    from crispy_amd.mel_filters import whisper_mel_filters
+    hp, W = tiny
+    path = tmp_path / f"tiny-{kind}.bin"
+    deq = write_ggml_quantized(str(path), hp, W, whisper_mel_filters(80), synthetic_vocab(hp.n_vocab), kind)
+    eng = WhisperEngine(str(path))
+    ref = WhisperModel(hp, deq)
+    x = synth_audio.clip16k_np(4, 150000)
+    a = eng.encode([x])
+    b = ref.encode([x])
+    assert np.array_equal(a, b)
+    _, toks = eng.transcribe(x, max_new_tokens=4)
+    rt, _ = ref.transcribe_tokens([x], [50258, 50259, 50359, 50363], 4)
+    assert toks == rt[0].tolist()
