@@ -43,14 +43,17 @@ struct GemmArgs {
   const float* rowtab; int rowtab_period;
   int M, N, K;
   int gelu;
+  const int* c_off_dev; long c_off_scale;     // optional: C += (*c_off_dev) * c_off_scale (decoder KV-cache slot)
 };
 hipError_t gemm_f32_nt(const GemmArgs& g, int batch, hipStream_t s);
 hipError_t layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, long rows, int D, hipStream_t s);
 hipError_t attn_encoder_f32(const float* qkv, float* out, int B, int T, int D, int heads, hipStream_t s);
 hipError_t attn_decoder_f32(const float* q, long ldq, const float* kv, long kv_batch_stride, long ldkv, int koff,
-                            int voff, int n_keys, float* out, long ldo, int B, int heads, hipStream_t s);
-hipError_t embed_tokens_f32(const int* tokens, const float* tok_emb, const float* pos_emb, int pos, float* x, int B,
-                            int D, hipStream_t s);
+                            int voff, int n_keys_base, const int* pos_dev, float* out, long ldo, int B, int heads,
+                            hipStream_t s);
+hipError_t embed_tokens_f32(const int* tokens, const float* tok_emb, const float* pos_emb, int pos, const int* pos_dev,
+                            float* x, int B, int D, hipStream_t s);
+hipError_t advance_counters(int* pos_dev, int* step_dev, hipStream_t s);
 // 48 -> 16 kHz resampler (rubato FftFixedIn(.., 1024, 1, 1) geometry)
 constexpr int RS_FFT_IN = 1026, RS_FFT_OUT = 342, RS_CHUNK = 1024;
 constexpr int RS_K = 1040;   // 1026 padded to the GEMM's k granularity
@@ -59,7 +62,7 @@ hipError_t rs_prep(const float* in, long in_stride, long n_in, float scale, int 
                    int n_blk, hipStream_t s);
 hipError_t rs_ola(const float* Y, float* out, long out_stride, int batch, int n_blk, hipStream_t s);
 
-hipError_t argmax_f32(const float* logits, const unsigned char* mask, int V, int* tokens_out, float* best, int B,
-                      hipStream_t s);
+hipError_t argmax_f32(const float* logits, const unsigned char* mask, const unsigned char* mask_first,
+                      const int* step_dev, int V, int* tokens_out, int* tokens_all, float* best, int B, hipStream_t s);
 
 }  // namespace crispy

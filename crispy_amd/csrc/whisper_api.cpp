@@ -61,6 +61,9 @@ struct crispy_asr {
         *d_dh = nullptr, *d_logits = nullptr, *d_best = nullptr;
   int* d_tok = nullptr;
   int* d_tokens_all = nullptr;
+  int* d_counters = nullptr;                 // [0] position, [1] generation step (device-side, advanced in-graph)
+  hipGraphExec_t dec_graph = nullptr;        // one captured decode step, replayed per generated token
+  int dec_graph_batch = 0;
   int eot = 50257;
   std::vector<unsigned char> sup_all, sup_first;   // host copies of the two suppression lists
   std::vector<std::string> vocab;                  // token byte strings of a loaded model file
@@ -171,6 +174,8 @@ void free_dec_ws(crispy_asr* h) {
     if (*p) { (void)hipFree(*p); *p = nullptr; }
   if (h->d_tok) { (void)hipFree(h->d_tok); h->d_tok = nullptr; }
   if (h->d_tokens_all) { (void)hipFree(h->d_tokens_all); h->d_tokens_all = nullptr; }
+  if (h->d_counters) { (void)hipFree(h->d_counters); h->d_counters = nullptr; }
+  if (h->dec_graph) { (void)hipGraphExecDestroy(h->dec_graph); h->dec_graph = nullptr; h->dec_graph_batch = 0; }
   h->dcap_batch = 0;
 }
 
@@ -451,15 +456,20 @@ int reserve_dec(crispy_asr* h, int batch, int max_tokens) {
   HIP_TRY(hipMalloc(&h->d_best, B * C * sizeof(float)));
   HIP_TRY(hipMalloc(&h->d_tok, B * sizeof(int)));
   HIP_TRY(hipMalloc(&h->d_tokens_all, B * C * sizeof(int)));
+  HIP_TRY(hipMalloc(&h->d_counters, 2 * sizeof(int)));
   h->dcap_batch = batch;
   return CRISPY_OK;
 }
 
-// one decoder step for all clips: token ids in h->d_tok at position `pos`; leaves logits in h->d_logits
-int decoder_step(crispy_asr* h, int batch, int pos, bool want_logits, hipStream_t s) {
+// one decoder step for all clips: token ids in h->d_tok; leaves logits in h->d_logits.
+// dev_pos = false: the position is the host value `pos` (prompt tokens).
+// dev_pos = true : the position is read from h->d_counters[0] by the kernels, so the identical launch
+//                  sequence can be captured once in a hipGraph and replayed for every generated token.
+int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logits, hipStream_t s) {
   const int dt = h->hp.n_text_state, H = h->hp.n_text_head, Tn = h->hp.n_audio_ctx, C = h->hp.n_text_ctx,
             V = h->hp.n_vocab;
-  HIP_TRY(embed_tokens_f32(h->d_tok, h->tok_emb, h->dec_pos, pos, h->d_dx, batch, dt, s));
+  const int* pos_dev = dev_pos ? h->d_counters : nullptr;
+  HIP_TRY(embed_tokens_f32(h->d_tok, h->tok_emb, h->dec_pos, pos, pos_dev, h->d_dx, batch, dt, s));
   for (size_t l = 0; l < h->dec.size(); ++l) {
     const DecLayer& L = h->dec[l];
     float* selfkv = h->d_selfkv + l * (size_t)batch * C * 2 * dt;
@@ -467,10 +477,15 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool want_logits, hipStream_
     // causal self-attention against the cache
     HIP_TRY(layernorm_f32(h->d_dx, L.ln1_w, L.ln1_b, h->d_dxn, batch, dt, s));
     HIP_TRY(gemm_f32_nt(gemm(h->d_dxn, dt, L.qkv_w, dt, h->d_dq, dt, L.qkv_b, batch, dt, dt), 1, s));
-    // k | v of this position go straight into the cache row (b, pos)
-    HIP_TRY(gemm_f32_nt(gemm(h->d_dxn, dt, L.qkv_w + (size_t)dt * dt, dt, selfkv + (size_t)pos * 2 * dt, (long)C * 2 * dt,
-                             L.qkv_b + dt, batch, 2 * dt, dt), 1, s));
-    HIP_TRY(attn_decoder_f32(h->d_dq, dt, selfkv, (long)C * 2 * dt, 2L * dt, 0, dt, pos + 1, h->d_datt, dt, batch, H, s));
+    {
+      // k | v of this position go straight into the cache row (b, pos)
+      GemmArgs g = gemm(h->d_dxn, dt, L.qkv_w + (size_t)dt * dt, dt, selfkv + (dev_pos ? 0 : (size_t)pos * 2 * dt),
+                        (long)C * 2 * dt, L.qkv_b + dt, batch, 2 * dt, dt);
+      if (dev_pos) { g.c_off_dev = h->d_counters; g.c_off_scale = 2L * dt; }
+      HIP_TRY(gemm_f32_nt(g, 1, s));
+    }
+    HIP_TRY(attn_decoder_f32(h->d_dq, dt, selfkv, (long)C * 2 * dt, 2L * dt, 0, dt, dev_pos ? 1 : pos + 1, pos_dev,
+                             h->d_datt, dt, batch, H, s));
     {
       GemmArgs g = gemm(h->d_datt, dt, L.out_w, dt, h->d_dx, dt, L.out_b, batch, dt, dt);
       g.residual = h->d_dx; g.ldr = dt;
@@ -479,7 +494,7 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool want_logits, hipStream_
     // cross-attention over the encoder output (K | V precomputed once per clip)
     HIP_TRY(layernorm_f32(h->d_dx, L.lnx_w, L.lnx_b, h->d_dxn, batch, dt, s));
     HIP_TRY(gemm_f32_nt(gemm(h->d_dxn, dt, L.xq_w, dt, h->d_dq, dt, L.xq_b, batch, dt, dt), 1, s));
-    HIP_TRY(attn_decoder_f32(h->d_dq, dt, xkv, (long)Tn * 2 * dt, 2L * dt, 0, dt, Tn, h->d_datt, dt, batch, H, s));
+    HIP_TRY(attn_decoder_f32(h->d_dq, dt, xkv, (long)Tn * 2 * dt, 2L * dt, 0, dt, Tn, nullptr, h->d_datt, dt, batch, H, s));
     {
       GemmArgs g = gemm(h->d_datt, dt, L.xout_w, dt, h->d_dx, dt, L.xout_b, batch, dt, dt);
       g.residual = h->d_dx; g.ldr = dt;
@@ -502,6 +517,17 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool want_logits, hipStream_
     HIP_TRY(layernorm_f32(h->d_dx, h->dec_ln_w, h->dec_ln_b, h->d_dxn, batch, dt, s));
     HIP_TRY(gemm_f32_nt(gemm(h->d_dxn, dt, h->tok_emb, dt, h->d_logits, V, nullptr, batch, V, dt), 1, s));
   }
+  return CRISPY_OK;
+}
+
+// pick a token from the current logits (step-aware suppression), record it, run the next step on it,
+// advance the device counters: the body of one generated token
+int generation_body(crispy_asr* h, int batch, hipStream_t s) {
+  HIP_TRY(argmax_f32(h->d_logits, h->d_suppress, h->d_suppress_first, h->d_counters + 1, h->hp.n_vocab, h->d_tok,
+                     h->d_tokens_all, h->d_best, batch, s));
+  int rc = decoder_step(h, batch, 0, true, true, s);
+  if (rc != CRISPY_OK) return rc;
+  HIP_TRY(advance_counters(h->d_counters, h->d_counters + 1, s));
   return CRISPY_OK;
 }
 
@@ -559,19 +585,31 @@ int crispy_asr_decode_greedy_device(crispy_asr* h, const float* d_enc, int batch
     std::fill(tok.begin(), tok.end(), prompt[i]);
     HIP_TRY(hipMemcpyAsync(h->d_tok, tok.data(), sizeof(int) * batch, hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));  // tok is reused by the next iteration
-    rc = decoder_step(h, batch, pos, i == n_prompt - 1, s);
+    rc = decoder_step(h, batch, pos, false, i == n_prompt - 1, s);
     if (rc != CRISPY_OK) return rc;
   }
-  for (int i = 0; i < max_new; ++i, ++pos) {
-    // pick from the logits of the previous step, then feed the pick back
-    const unsigned char* mask = (i == 0) ? h->d_suppress_first : h->d_suppress;
-    HIP_TRY(argmax_f32(h->d_logits, mask, V, h->d_tok, h->d_best + (size_t)i * batch, batch, s));
-    HIP_TRY(hipMemcpyAsync(h->d_tokens_all + (size_t)i * batch, h->d_tok, sizeof(int) * batch, hipMemcpyDeviceToDevice, s));
-    if (i + 1 < max_new) {
-      rc = decoder_step(h, batch, pos, true, s);
-      if (rc != CRISPY_OK) return rc;
+  const int counters[2] = {pos, 0};
+  HIP_TRY(hipMemcpyAsync(h->d_counters, counters, sizeof(counters), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (max_new > 1) {
+    if (!h->dec_graph || h->dec_graph_batch != batch) {
+      if (h->dec_graph) { (void)hipGraphExecDestroy(h->dec_graph); h->dec_graph = nullptr; }
+      hipGraph_t graph = nullptr;
+      HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      rc = generation_body(h, batch, s);
+      const hipError_t ce = hipStreamEndCapture(s, &graph);
+      if (rc != CRISPY_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+      HIP_TRY(ce);
+      const hipError_t ie = hipGraphInstantiate(&h->dec_graph, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      HIP_TRY(ie);
+      h->dec_graph_batch = batch;
     }
+    for (int i = 0; i + 1 < max_new; ++i) HIP_TRY(hipGraphLaunch(h->dec_graph, s));
   }
+  // the last pick needs no further decoder step
+  HIP_TRY(argmax_f32(h->d_logits, h->d_suppress, h->d_suppress_first, h->d_counters + 1, V, h->d_tok, h->d_tokens_all,
+                     h->d_best, batch, s));
   std::vector<int> all((size_t)max_new * batch);
   std::vector<float> best((size_t)max_new * batch);
   HIP_TRY(hipMemcpyAsync(all.data(), h->d_tokens_all, all.size() * sizeof(int), hipMemcpyDeviceToHost, s));

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(GemmArgs g) {
   const int bz = blockIdx.z;
   const float* __restrict__ A = g.A + (long)bz * g.strideA;
   const float* __restrict__ W = g.W;
-  float* __restrict__ C = g.C + (long)bz * g.strideC;
+  float* __restrict__ C = g.C + (long)bz * g.strideC + (g.c_off_dev ? (long)(*g.c_off_dev) * g.c_off_scale : 0L);
   const int m0 = blockIdx.y * GB_M, n0 = blockIdx.x * GB_N;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
 
@@ -118,6 +118,80 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(GemmArgs g) {
         C[(long)m * g.ldc + n] = v;
       }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Skinny GEMM for the decoder (M <= 64 rows = clips of one decode step): latency-, not FLOP-bound.
+// One workgroup per 32 output columns; the 4 waves split K four ways and feed the MFMA straight from
+// global memory (both operands are K-contiguous rows, so a lane's operands are 16 contiguous floats per
+// 32-wide K chunk: step s contracts k = s and k = s + 16); partial tiles are summed through LDS.
+// No LDS staging, no barriers in the K loop, next chunk's loads issued before the current MFMAs.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_skinny_f32_kernel(GemmArgs g) {
+  __shared__ float red[4][64 * 33];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.x * 32;
+  const float* __restrict__ A = g.A;
+  const float* __restrict__ W = g.W;
+  float* __restrict__ C = g.C + (g.c_off_dev ? (long)(*g.c_off_dev) * g.c_off_scale : 0L);
+  const int kper = g.K / 4;                 // K range of this wave (multiple of 32)
+  const int kbeg = wave * kper;
+  const int n = min(n0 + li, g.N - 1);
+  const bool r0ok = li < g.M, r1ok = 32 + li < g.M;
+  const float* wrow = W + (long)n * g.ldw + kbeg + 16 * lh;
+  const float* a0row = A + (long)min(li, g.M - 1) * g.lda + kbeg + 16 * lh;
+  const float* a1row = A + (long)min(32 + li, g.M - 1) * g.lda + kbeg + 16 * lh;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  float4 w[4], a0[4], a1[4];
+  auto load = [&](int kc) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      w[q] = *reinterpret_cast<const float4*>(wrow + kc + 4 * q);
+      a0[q] = r0ok ? *reinterpret_cast<const float4*>(a0row + kc + 4 * q) : make_float4(0, 0, 0, 0);
+      a1[q] = r1ok ? *reinterpret_cast<const float4*>(a1row + kc + 4 * q) : make_float4(0, 0, 0, 0);
+    }
+  };
+  load(0);
+  for (int kc = 0; kc < kper; kc += 32) {
+    float4 cw[4], ca0[4], ca1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { cw[q] = w[q]; ca0[q] = a0[q]; ca1[q] = a1[q]; }
+    if (kc + 32 < kper) load(kc + 32);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float wv[4] = {cw[q].x, cw[q].y, cw[q].z, cw[q].w};
+      const float x0[4] = {ca0[q].x, ca0[q].y, ca0[q].z, ca0[q].w};
+      const float x1[4] = {ca1[q].x, ca1[q].y, ca1[q].z, ca1[q].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[e], wv[e], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[e], wv[e], acc1, 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = acc_row(r, lane);
+    red[wave][row * 33 + li] = acc0[r];
+    red[wave][(32 + row) * 33 + li] = acc1[r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int idx = tid + 256 * q;
+    const int m = idx >> 5, c = idx & 31;
+    const int nn = n0 + c;
+    if (m < g.M && nn < g.N) {
+      float v = red[0][m * 33 + c] + red[1][m * 33 + c] + red[2][m * 33 + c] + red[3][m * 33 + c];
+      v += g.bias ? g.bias[nn] : 0.f;
+      if (g.gelu) v = gelu_erf(v);
+      if (g.residual) v += g.residual[(long)m * g.ldr + nn];
+      C[(long)m * g.ldc + nn] = v;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -272,65 +346,129 @@ __global__ __launch_bounds__(256) void attn_enc_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------------
 // Decoder attention for ONE query per (clip, head): scores against n_keys cached keys, softmax, P.V.
 // q: [B][D] (row stride ldq), K/V: [B][n_ctx][ldkv] with this head's 64 columns at koff/voff + h*64.
-// grid (heads, B), one wave.  Memory-bound on the cached K/V.
+// grid (heads, B), 4 waves: the keys are split four ways (flash-decoding style) and the partial
+// (max, sum, P.V) triples are merged through LDS.  n_keys = n_keys_base + *pos_dev (graph replay keeps
+// the launch arguments fixed while the position advances on the device).  Memory-bound on K/V.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void attn_dec_kernel(const float* __restrict__ q, long ldq,
-                                                      const float* __restrict__ kv, long kv_batch_stride,
-                                                      long ldkv, int koff, int voff, int n_keys,
-                                                      float* __restrict__ out, long ldo) {
+__global__ __launch_bounds__(256) void attn_dec_kernel(const float* __restrict__ q, long ldq,
+                                                       const float* __restrict__ kv, long kv_batch_stride,
+                                                       long ldkv, int koff, int voff, int n_keys_base,
+                                                       const int* __restrict__ pos_dev, float* __restrict__ out, long ldo) {
   __shared__ float p_s[1536];
-  __shared__ float q_s[64];
-  const int lane = threadIdx.x, h = blockIdx.x, b = blockIdx.y;
-  q_s[lane] = q[(long)b * ldq + h * 64 + lane] * 0.125f;
+  __shared__ __attribute__((aligned(16))) float q_s[64];
+  __shared__ float part_o[4][64];
+  __shared__ float part_m[4], part_l[4];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int n_keys = n_keys_base + (pos_dev ? *pos_dev : 0);
+  if (tid < 64) q_s[tid] = q[(long)b * ldq + h * 64 + tid] * 0.125f;
   __syncthreads();
   const float* Kb = kv + (long)b * kv_batch_stride + koff + h * 64;
   const float* Vb = kv + (long)b * kv_batch_stride + voff + h * 64;
+  const int per = (n_keys + 3) / 4;
+  const int k_lo = wave * per, k_hi = min(n_keys, k_lo + per);
+  // scores: 16 lanes share one key row (coalesced 256-byte reads, 4 keys per wave instruction), the
+  // 16 partial dot products are summed inside the DPP row
   float mloc = -1e30f;
-  for (int k = lane; k < n_keys; k += 64) {
-    const float4* kp = reinterpret_cast<const float4*>(Kb + (long)k * ldkv);
-    float sacc = 0.f;
+  {
+    const int c = lane & 15, sub = lane >> 4;
+    const float4 qv = *reinterpret_cast<const float4*>(&q_s[4 * c]);
+    for (int kb = k_lo; kb < k_hi; kb += 16) {          // 4 independent 1-KB loads in flight per wave
+      float sacc[4];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      const float4 t = kp[c];
-      sacc = fmaf(t.x, q_s[4 * c], sacc);
-      sacc = fmaf(t.y, q_s[4 * c + 1], sacc);
-      sacc = fmaf(t.z, q_s[4 * c + 2], sacc);
-      sacc = fmaf(t.w, q_s[4 * c + 3], sacc);
+      for (int u = 0; u < 4; ++u) {
+        const int k = kb + 4 * u + sub;
+        sacc[u] = 0.f;
+        if (k < k_hi) {
+          const float4 t = *reinterpret_cast<const float4*>(Kb + (long)k * ldkv + 4 * c);
+          sacc[u] = t.x * qv.x;
+          sacc[u] = fmaf(t.y, qv.y, sacc[u]);
+          sacc[u] = fmaf(t.z, qv.z, sacc[u]);
+          sacc[u] = fmaf(t.w, qv.w, sacc[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float v = sacc[u];
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));
+        const int k = kb + 4 * u + sub;
+        if (k < k_hi) {
+          if (c == 0) p_s[k] = v;
+          mloc = fmaxf(mloc, v);
+        }
+      }
     }
-    p_s[k] = sacc;
-    mloc = fmaxf(mloc, sacc);
   }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) mloc = fmaxf(mloc, __shfl_xor(mloc, off, 64));
   float lsum = 0.f;
-  for (int k = lane; k < n_keys; k += 64) {
+  for (int k = k_lo + lane; k < k_hi; k += 64) {
     const float p = __expf(p_s[k] - mloc);
     p_s[k] = p;
     lsum += p;
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) lsum += __shfl_xor(lsum, off, 64);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // lane = output dim; two interleaved accumulators shorten the dependent chain
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int k = k_lo;
+  for (; k + 7 < k_hi; k += 8) {                        // 8 independent 256-byte row reads in flight
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = Vb[(long)(k + u) * ldkv + lane];
+    a0 = fmaf(p_s[k], v[0], a0); a1 = fmaf(p_s[k + 1], v[1], a1);
+    a2 = fmaf(p_s[k + 2], v[2], a2); a3 = fmaf(p_s[k + 3], v[3], a3);
+    a0 = fmaf(p_s[k + 4], v[4], a0); a1 = fmaf(p_s[k + 5], v[5], a1);
+    a2 = fmaf(p_s[k + 6], v[6], a2); a3 = fmaf(p_s[k + 7], v[7], a3);
+  }
+  for (; k < k_hi; ++k) a0 = fmaf(p_s[k], Vb[(long)k * ldkv + lane], a0);
+  part_o[wave][lane] = (a0 + a1) + (a2 + a3);
+  if (lane == 0) { part_m[wave] = mloc; part_l[wave] = lsum; }
   __syncthreads();
-  float acc = 0.f;  // lane = output dim
-  for (int k = 0; k < n_keys; ++k) acc = fmaf(p_s[k], Vb[(long)k * ldkv + lane], acc);
-  out[(long)b * ldo + h * 64 + lane] = acc / lsum;
+  if (wave == 0) {
+    const float m = fmaxf(fmaxf(part_m[0], part_m[1]), fmaxf(part_m[2], part_m[3]));
+    float o = 0.f, l = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float sc = __expf(part_m[w] - m);   // empty partitions have m = -1e30 -> scale 0
+      o = fmaf(part_o[w][lane], sc, o);
+      l = fmaf(part_l[w], sc, l);
+    }
+    out[(long)b * ldo + h * 64 + lane] = o / l;
+  }
 }
 
 // token + positional embedding for one decode step: x[b][:] = tok_emb[token[b]] + pos_emb[pos]
 __global__ __launch_bounds__(256) void embed_kernel(const int* __restrict__ tokens, const float* __restrict__ tok_emb,
-                                                    const float* __restrict__ pos_emb, int pos, float* __restrict__ x,
-                                                    int D) {
+                                                    const float* __restrict__ pos_emb, int pos,
+                                                    const int* __restrict__ pos_dev, float* __restrict__ x, int D) {
   const int b = blockIdx.x;
   const int tok = tokens[b];
+  if (pos_dev) pos = *pos_dev;
   for (int c = threadIdx.x; c < D; c += 256) x[(long)b * D + c] = tok_emb[(long)tok * D + c] + pos_emb[(long)pos * D + c];
 }
 
 // greedy pick: argmax over the vocabulary with a suppression mask (mask[v] != 0 -> -inf); ties -> lowest id
 __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, const unsigned char* __restrict__ mask,
-                                                     int V, int* __restrict__ tokens_out, float* __restrict__ best_logit) {
+                                                     const unsigned char* __restrict__ mask_first,
+                                                     const int* __restrict__ step_dev, int V, int* __restrict__ tokens_out,
+                                                     int* __restrict__ tokens_all, float* __restrict__ best_logit) {
   __shared__ float sv[256];
   __shared__ int si[256];
   const int b = blockIdx.x;
+  const int step = step_dev ? *step_dev : 0;
+  if (step == 0 && mask_first) mask = mask_first;
   const float* lg = logits + (long)b * V;
   float bv = -INFINITY;
   int bi = 0x7fffffff;
@@ -351,13 +489,23 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ l
   }
   if (threadIdx.x == 0) {
     tokens_out[b] = si[0];
-    if (best_logit) best_logit[b] = sv[0];
+    if (tokens_all) tokens_all[(long)step * gridDim.x + b] = si[0];
+    if (best_logit) best_logit[(long)step * gridDim.x + b] = sv[0];
   }
+}
+
+// end of a decode step: position and step counters advance on the device (graph-replay friendly)
+__global__ void advance_kernel(int* __restrict__ pos_dev, int* __restrict__ step_dev) {
+  if (threadIdx.x == 0) { *pos_dev += 1; *step_dev += 1; }
 }
 
 }  // namespace
 
 hipError_t gemm_f32_nt(const GemmArgs& g, int batch, hipStream_t s) {
+  if (batch == 1 && g.M <= 64 && g.K % 128 == 0 && !g.rowtab) {   // one decode step: latency-bound shape
+    hipLaunchKernelGGL(gemm_skinny_f32_kernel, dim3((g.N + 31) / 32), dim3(256), 0, s, g);
+    return hipGetLastError();
+  }
   dim3 grid((g.N + GB_N - 1) / GB_N, (g.M + GB_M - 1) / GB_M, batch);
   hipLaunchKernelGGL(gemm_f32_nt_kernel, grid, dim3(256), 0, s, g);
   return hipGetLastError();
@@ -372,19 +520,25 @@ hipError_t attn_encoder_f32(const float* qkv, float* out, int B, int T, int D, i
   return hipGetLastError();
 }
 hipError_t attn_decoder_f32(const float* q, long ldq, const float* kv, long kv_batch_stride, long ldkv, int koff,
-                            int voff, int n_keys, float* out, long ldo, int B, int heads, hipStream_t s) {
-  hipLaunchKernelGGL(attn_dec_kernel, dim3(heads, B), dim3(64), 0, s, q, ldq, kv, kv_batch_stride, ldkv, koff, voff,
-                     n_keys, out, ldo);
+                            int voff, int n_keys_base, const int* pos_dev, float* out, long ldo, int B, int heads,
+                            hipStream_t s) {
+  hipLaunchKernelGGL(attn_dec_kernel, dim3(heads, B), dim3(256), 0, s, q, ldq, kv, kv_batch_stride, ldkv, koff, voff,
+                     n_keys_base, pos_dev, out, ldo);
   return hipGetLastError();
 }
-hipError_t embed_tokens_f32(const int* tokens, const float* tok_emb, const float* pos_emb, int pos, float* x, int B,
-                            int D, hipStream_t s) {
-  hipLaunchKernelGGL(embed_kernel, dim3(B), dim3(256), 0, s, tokens, tok_emb, pos_emb, pos, x, D);
+hipError_t embed_tokens_f32(const int* tokens, const float* tok_emb, const float* pos_emb, int pos, const int* pos_dev,
+                            float* x, int B, int D, hipStream_t s) {
+  hipLaunchKernelGGL(embed_kernel, dim3(B), dim3(256), 0, s, tokens, tok_emb, pos_emb, pos, pos_dev, x, D);
   return hipGetLastError();
 }
-hipError_t argmax_f32(const float* logits, const unsigned char* mask, int V, int* tokens_out, float* best, int B,
-                      hipStream_t s) {
-  hipLaunchKernelGGL(argmax_kernel, dim3(B), dim3(256), 0, s, logits, mask, V, tokens_out, best);
+hipError_t argmax_f32(const float* logits, const unsigned char* mask, const unsigned char* mask_first,
+                      const int* step_dev, int V, int* tokens_out, int* tokens_all, float* best, int B, hipStream_t s) {
+  hipLaunchKernelGGL(argmax_kernel, dim3(B), dim3(256), 0, s, logits, mask, mask_first, step_dev, V, tokens_out,
+                     tokens_all, best);
+  return hipGetLastError();
+}
+hipError_t advance_counters(int* pos_dev, int* step_dev, hipStream_t s) {
+  hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, s, pos_dev, step_dev);
   return hipGetLastError();
 }
 
