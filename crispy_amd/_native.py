@@ -33,7 +33,8 @@ MEL_SYMBOLS = ("crispy_mel_create", "crispy_mel_destroy", "crispy_mel_compute",
 ASR_SYMBOLS = ("crispy_asr_create", "crispy_asr_set_tensor", "crispy_asr_finalize", "crispy_asr_free",
                "crispy_asr_hparams_get", "crispy_asr_encode", "crispy_asr_encode_device", "crispy_asr_synchronize",
                "crispy_asr_set_suppress", "crispy_asr_decode_greedy_device", "crispy_asr_transcribe_tokens",
-               "crispy_asr_load", "crispy_asr_token_text", "crispy_asr_transcribe", "crispy_asr_free_result")
+               "crispy_asr_load", "crispy_asr_token_text", "crispy_asr_transcribe", "crispy_asr_free_result",
+               "crispy_asr_decode_greedy_lang_device", "crispy_asr_detect_language_device")
 RS_SYMBOLS = ("crispy_resampler_create", "crispy_resampler_destroy", "crispy_resampler_out_len",
               "crispy_resampler_process_device", "crispy_resampler_synchronize")
 ALL_SYMBOLS = RN_SYMBOLS + MEL_SYMBOLS + ASR_SYMBOLS + RS_SYMBOLS
@@ -106,6 +107,9 @@ def lib() -> C.CDLL:
     L.crispy_asr_transcribe.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]
     L.crispy_asr_free_result.argtypes = [C.c_void_p]
     L.crispy_asr_free_result.restype = None
+    L.crispy_asr_decode_greedy_lang_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                                       C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.crispy_asr_detect_language_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.crispy_asr_transcribe_tokens.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_void_p,
                                                C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.crispy_resampler_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]

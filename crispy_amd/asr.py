@@ -142,6 +142,21 @@ class WhisperModel:
                                                         toks.ctypes.data, n.ctypes.data, lg.ctypes.data))
         return toks, n, lg
 
+    def detect_language_device(self, d_enc: int, batch: int) -> np.ndarray:
+        """Language token per clip (whisper.cpp auto-detection)."""
+        out = np.empty(batch, dtype=np.int32)
+        N.check(N.lib().crispy_asr_detect_language_device(self._h, d_enc, batch, out.ctypes.data))
+        return out
+
+    def decode_greedy_lang_device(self, d_enc: int, batch: int, prompt, lang_tokens, max_new: int):
+        p = np.ascontiguousarray(prompt, dtype=np.int32)
+        lt = np.ascontiguousarray(lang_tokens, dtype=np.int32)
+        toks = np.empty((batch, max_new), dtype=np.int32)
+        n = np.empty(batch, dtype=np.int32)
+        N.check(N.lib().crispy_asr_decode_greedy_lang_device(self._h, d_enc, batch, p.ctypes.data, p.size,
+                                                             lt.ctypes.data, max_new, toks.ctypes.data, n.ctypes.data, None))
+        return toks, n
+
     def transcribe_tokens(self, clips, prompt, max_new: int):
         """`SpeechModel::transcribe` up to token ids for a batch of <= 30 s clips."""
         if len(clips) == 0:
@@ -174,16 +189,18 @@ class WhisperEngine(WhisperModel):
         N.check(N.lib().crispy_asr_token_text(self._h, int(token), C.byref(p), C.byref(n)))
         return C.string_at(p, n.value)
 
-    def transcribe(self, audio: np.ndarray, max_new_tokens: int = 0, translate: bool = False):
-        """One chunk (<= 480000 samples at 16 kHz) -> (text, token ids); empty audio -> ("", [])."""
+    def transcribe(self, audio: np.ndarray, max_new_tokens: int = 0, translate: bool = False, language_token: int = 0):
+        """One chunk (<= 480000 samples at 16 kHz) -> (text, token ids); empty audio -> ("", []).
+        language_token = 0 auto-detects, as `TranscribeOptions::default()` does."""
         a = np.ascontiguousarray(audio, dtype=np.float32).ravel()
-        opts = (C.c_int * 3)(0, int(translate), int(max_new_tokens))
+        opts = (C.c_int * 3)(int(language_token), int(translate), int(max_new_tokens))
         res = C.c_void_p()
         N.check(N.lib().crispy_asr_transcribe(self._h, a.ctypes.data if a.size else None, a.size, opts, C.byref(res)))
         try:
             text_p = C.cast(res, C.POINTER(C.c_char_p))[0]
             tok_p = C.cast(res.value + 8, C.POINTER(C.POINTER(C.c_int)))[0]
             n_tok = C.cast(res.value + 16, C.POINTER(C.c_int))[0]
+            self.last_language_token = int(C.cast(res.value + 20, C.POINTER(C.c_int))[0])
             text = text_p.decode("utf-8", "replace") if text_p else ""
             tokens = [int(tok_p[i]) for i in range(n_tok)]
         finally:

@@ -50,6 +50,7 @@ struct crispy_asr {
   std::vector<DecLayer> dec;
   unsigned char* d_suppress = nullptr;      // [n_vocab] tokens never emitted by the greedy decoder
   unsigned char* d_suppress_first = nullptr;  // additionally suppressed at the first sampled position
+  unsigned char* d_lang_mask = nullptr;       // everything but the language tokens (auto-detection)
   // workspace (grown on demand)
   int cap_batch = 0;
   float *w_melt = nullptr, *w_pcm = nullptr, *w_h1 = nullptr, *w_x = nullptr, *w_xn = nullptr, *w_qkv = nullptr,
@@ -259,6 +260,7 @@ void crispy_asr_free(crispy_asr* h) {
   for (float* p : h->derived) (void)hipFree(p);
   if (h->d_suppress) (void)hipFree(h->d_suppress);
   if (h->d_suppress_first) (void)hipFree(h->d_suppress_first);
+  if (h->d_lang_mask) (void)hipFree(h->d_lang_mask);
   free_ws(h);
   free_dec_ws(h);
   if (h->mel) crispy_mel_destroy(h->mel);
@@ -557,6 +559,13 @@ int crispy_asr_set_suppress(crispy_asr* h, const int* ids, int n, int first_only
 
 int crispy_asr_decode_greedy_device(crispy_asr* h, const float* d_enc, int batch, const int* prompt, int n_prompt,
                                     int max_new, int* tokens_out, int* n_out, float* logits_out) {
+  return crispy_asr_decode_greedy_lang_device(h, d_enc, batch, prompt, n_prompt, nullptr, max_new, tokens_out, n_out,
+                                              logits_out);
+}
+
+int crispy_asr_decode_greedy_lang_device(crispy_asr* h, const float* d_enc, int batch, const int* prompt, int n_prompt,
+                                         const int* lang_tokens, int max_new, int* tokens_out, int* n_out,
+                                         float* logits_out) {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_decode_greedy_device: NULL handle");
   if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_decode_greedy_device: model not finalized");
   if (batch < 0 || max_new < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_decode_greedy_device: negative size");
@@ -583,6 +592,12 @@ int crispy_asr_decode_greedy_device(crispy_asr* h, const float* d_enc, int batch
   int pos = 0;
   for (int i = 0; i < n_prompt; ++i, ++pos) {
     std::fill(tok.begin(), tok.end(), prompt[i]);
+    if (i == 1 && lang_tokens)      // per-clip language token (auto-detected or caller supplied)
+      for (int b = 0; b < batch; ++b) {
+        if (lang_tokens[b] < 0 || lang_tokens[b] >= h->hp.n_vocab)
+          return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_decode_greedy_device: language token %d out of range", lang_tokens[b]);
+        tok[b] = lang_tokens[b];
+      }
     HIP_TRY(hipMemcpyAsync(h->d_tok, tok.data(), sizeof(int) * batch, hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));  // tok is reused by the next iteration
     rc = decoder_step(h, batch, pos, false, i == n_prompt - 1, s);
@@ -625,6 +640,42 @@ int crispy_asr_decode_greedy_device(crispy_asr* h, const float* d_enc, int batch
     }
     if (n_out) n_out[b] = n;
   }
+  return CRISPY_OK;
+}
+
+// whisper.cpp `whisper_lang_auto_detect`: feed <|startoftranscript|> alone and take the most probable
+// language token [UPSTREAM-RECALL].  English-only vocabularies have nothing to detect.
+int crispy_asr_detect_language_device(crispy_asr* h, const float* d_enc, int batch, int* lang_tokens_out) {
+  if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_detect_language_device: NULL handle");
+  if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_detect_language_device: model not finalized");
+  if (batch < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_detect_language_device: batch < 0");
+  if (batch == 0) return CRISPY_OK;
+  if (!d_enc || !lang_tokens_out) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_detect_language_device: NULL argument");
+  if (h->hp.n_vocab < 51865) return fail(CRISPY_ERR_UNSUPPORTED, "crispy_asr_detect_language_device: English-only vocabulary");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  int rc = reserve_dec(h, batch, 1);
+  if (rc != CRISPY_OK) return rc;
+  const int dt = h->hp.n_text_state, Tn = h->hp.n_audio_ctx, V = h->hp.n_vocab;
+  for (size_t l = 0; l < h->dec.size(); ++l) {
+    float* xkv = h->d_xkv + l * (size_t)batch * Tn * 2 * dt;
+    HIP_TRY(gemm_f32_nt(gemm(d_enc, dt, h->dec[l].xkv_w, dt, xkv, 2L * dt, h->dec[l].xkv_b, batch * Tn, 2 * dt, dt), 1, s));
+  }
+  const int sot = h->eot + 1, n_lang = 99 + (V - 51865);
+  std::vector<int> tok(batch, sot);
+  HIP_TRY(hipMemcpyAsync(h->d_tok, tok.data(), sizeof(int) * batch, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  rc = decoder_step(h, batch, 0, false, true, s);
+  if (rc != CRISPY_OK) return rc;
+  if (!h->d_lang_mask) {
+    std::vector<unsigned char> m(V, 1);
+    for (int t = sot + 1; t < sot + 1 + n_lang && t < V; ++t) m[t] = 0;
+    HIP_TRY(hipMalloc(&h->d_lang_mask, V));
+    HIP_TRY(hipMemcpy(h->d_lang_mask, m.data(), V, hipMemcpyHostToDevice));
+  }
+  HIP_TRY(argmax_f32(h->d_logits, h->d_lang_mask, nullptr, nullptr, V, h->d_tok, nullptr, nullptr, batch, s));
+  HIP_TRY(hipMemcpyAsync(lang_tokens_out, h->d_tok, sizeof(int) * batch, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
   return CRISPY_OK;
 }
 
@@ -736,6 +787,7 @@ struct crispy_asr_result_impl {
   crispy_asr_result pub;
   std::string text;
   std::vector<int> tokens;
+  int language_token = 0;
 };
 
 extern "C" {
@@ -847,6 +899,7 @@ int crispy_asr_transcribe(crispy_asr* h, const float* pcm16k, size_t n, const cr
     res->pub.text = res->text.c_str();
     res->pub.tokens = res->tokens.data();
     res->pub.n_tokens = (int)res->tokens.size();
+    res->pub.language_token = res->language_token;
     *out = &res->pub;
     return CRISPY_OK;
   };
@@ -869,8 +922,33 @@ int crispy_asr_transcribe(crispy_asr* h, const float* pcm16k, size_t n, const cr
   std::vector<int> toks(max_new);
   int n_out = 0;
   const int ns = (int)n;
-  int rc = crispy_asr_transcribe_tokens(h, pcm16k, (long)n, &ns, 1, prompt.data(), (int)prompt.size(), max_new,
-                                        toks.data(), &n_out);
+  // log-mel + encoder, then (multilingual, language unset = TranscribeOptions::default()) language detection
+  int rc = reserve_enc(h, 1);
+  if (rc != CRISPY_OK) { delete res; return rc; }
+  {
+    auto stage = [&]() -> int {
+      HIP_TRY(hipSetDevice(h->device));
+      if (!h->w_pcm || (long)n > h->cap_pcm_stride) {
+        if (h->w_pcm) (void)hipFree(h->w_pcm);
+        h->w_pcm = nullptr;
+        HIP_TRY(hipMalloc(&h->w_pcm, (size_t)h->cap_batch * n * sizeof(float)));
+        h->cap_pcm_stride = (long)n;
+      }
+      HIP_TRY(hipMemcpyAsync(h->w_pcm, pcm16k, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+      return CRISPY_OK;
+    };
+    rc = stage();
+    if (rc == CRISPY_OK) rc = crispy_mel_compute_device(h->mel, h->w_pcm, (long)n, &ns, 1, nullptr, h->w_melt, h->stream);
+    if (rc == CRISPY_OK) rc = crispy_asr_encode_device(h, h->w_melt, 1, h->w_enc, h->stream);
+    int lang = 0;
+    const bool detect = multilingual && !(opts && opts->language_token > 0);
+    if (rc == CRISPY_OK && detect) rc = crispy_asr_detect_language_device(h, h->w_enc, 1, &lang);
+    if (rc == CRISPY_OK)
+      rc = crispy_asr_decode_greedy_lang_device(h, h->w_enc, 1, prompt.data(), (int)prompt.size(), detect ? &lang : nullptr,
+                                                max_new, toks.data(), &n_out, nullptr);
+    if (rc == CRISPY_OK && detect) res->language_token = lang;
+    else if (multilingual) res->language_token = prompt[1];
+  }
   if (rc != CRISPY_OK) { delete res; return rc; }
   res->tokens.assign(toks.begin(), toks.begin() + n_out);
   for (int t : res->tokens)

@@ -205,6 +205,15 @@ int crispy_asr_decode_greedy_device(crispy_asr *h, const float *d_enc, int batch
 /* SpeechModel::transcribe up to token ids: PCM (host) -> log-mel -> encoder -> greedy decoder.
  * batch == 0 is the empty-audio no-op of managers/transcription.rs:175-177.  Detokenisation needs
  * the vocabulary of a real model file and stays with the caller in this round. */
+/* Same with a per-clip token for prompt position 1 (lang_tokens[batch], host, nullable). */
+int crispy_asr_decode_greedy_lang_device(crispy_asr *h, const float *d_enc, int batch, const int *prompt,
+                                         int n_prompt, const int *lang_tokens, int max_new,
+                                         int *tokens_out, int *n_out, float *logits_out);
+
+/* whisper.cpp language auto-detection: <|startoftranscript|> alone, arg-max over the language tokens.
+ * lang_tokens_out[batch] (host).  English-only vocabularies -> CRISPY_ERR_UNSUPPORTED. */
+int crispy_asr_detect_language_device(crispy_asr *h, const float *d_enc, int batch, int *lang_tokens_out);
+
 int crispy_asr_transcribe_tokens(crispy_asr *h, const float *pcm, long pcm_stride,
                                  const int *n_samples, int batch, const int *prompt, int n_prompt,
                                  int max_new, int *tokens_out, int *n_out);
@@ -219,7 +228,7 @@ int crispy_asr_token_text(const crispy_asr *h, int token, const char **text, siz
 
 /* TranscribeOptions::default() (managers/transcription.rs:184): language unset, transcribe task. */
 typedef struct crispy_asr_opts {
-  int language_token;  /* 0 = <|en|> (auto-detection is not implemented) */
+  int language_token;  /* 0 = auto-detect (what TranscribeOptions::default() leaves to whisper.cpp); else the token id */
   int translate;       /* 0 = transcribe */
   int max_new_tokens;  /* 0 = n_text_ctx / 2 */
 } crispy_asr_opts;
@@ -229,6 +238,7 @@ typedef struct crispy_asr_result {
   const char *text;    /* UTF-8, NUL-terminated, untrimmed (the caller trims: transcription.rs:187) */
   const int *tokens;   /* the greedy token ids before <|endoftext|> */
   int n_tokens;
+  int language_token;  /* the language token used (detected or given); 0 for English-only vocabularies */
 } crispy_asr_result;
 
 /* engine.transcribe(&audio, &TranscribeOptions::default()) for ONE chunk of <= 480000 samples

@@ -164,7 +164,7 @@ def test_ggml_model_file_load_and_text(tiny, model, ggml_file):
     assert eng.hp == hp
     assert eng.token_text(123) == b" w123"
     x = synth_audio.clip16k_np(0, 464000)
-    text, toks = eng.transcribe(x, max_new_tokens=6)
+    text, toks = eng.transcribe(x, max_new_tokens=6, language_token=50259)
     ref, _ = model.transcribe_tokens([x], [50258, 50259, 50359, 50363], 6)
     assert toks == ref[0].tolist()
     assert text == "".join(f" w{t}" for t in toks)
@@ -189,7 +189,7 @@ def test_ggml_f16_file_and_bad_files(tiny, tmp_path):
     from crispy_amd.asr import WhisperModel
     ref_model = WhisperModel(hp, W16)
     x = synth_audio.clip16k_np(3, 200000)
-    _, toks = eng.transcribe(x, max_new_tokens=4)
+    _, toks = eng.transcribe(x, max_new_tokens=4, language_token=50259)
     ref, _ = ref_model.transcribe_tokens([x], [50258, 50259, 50359, 50363], 4)
     assert toks == ref[0].tolist()                      # f16 storage == weights rounded to f16, computed in f32
     bad = tmp_path / "bad.bin"
@@ -259,6 +259,42 @@ def test_quantised_ggml_files_load(tiny, tmp_path, kind):
     a = eng.encode([x])
     b = ref.encode([x])
     assert np.array_equal(a, b)
-    _, toks = eng.transcribe(x, max_new_tokens=4)
+    _, toks = eng.transcribe(x, max_new_tokens=4, language_token=50259)
     rt, _ = ref.transcribe_tokens([x], [50258, 50259, 50359, 50363], 4)
     assert toks == rt[0].tolist()
+
+
+def test_language_auto_detection(tiny, model, ggml_file, oracle):
+    """TranscribeOptions::default() leaves the language unset: whisper.cpp feeds <|startoftranscript|> alone and
+    takes the arg-max over the 99 language tokens; the detected token then replaces prompt position 1."""
+    import torch
+    from crispy_amd import synth_audio
+    from crispy_amd.asr import WhisperEngine
+    from crispy_amd.mel_filters import whisper_mel_filters
+    from oracle import whisper_oracle as WO
+    hp, W = tiny
+    clips = [synth_audio.clip16k_np(90 + i, 100000 + 50000 * i) for i in range(4)]
+    enc = model.encode(clips)
+    d_enc = torch.from_numpy(enc).cuda()
+    torch.cuda.synchronize()
+    lang = model.detect_language_device(d_enc.data_ptr(), 4)
+    assert ((lang >= 50259) & (lang < 50259 + 99)).all()
+    F = whisper_mel_filters(80)
+    for b, c in enumerate(clips):
+        ref_enc = WO.encoder_forward(W, hp, oracle.oracle_logmel(c, F))
+        lg = WO.decoder_logits(W, hp, ref_enc, [50258])[-1][50259:50259 + 99]
+        top2 = np.sort(lg)[-2:]
+        if top2[1] - top2[0] > 1e-3:
+            assert lang[b] == 50259 + int(np.argmax(lg))
+    # per-clip language tokens feed prompt position 1
+    prompt = [50258, 50259, 50359, 50363]
+    toks, _ = model.decode_greedy_lang_device(d_enc.data_ptr(), 4, prompt, lang, 4)
+    for b in range(4):
+        solo, _, _ = model.decode_greedy_device(d_enc[b:b + 1].contiguous().data_ptr(), 1, [50258, int(lang[b]), 50359, 50363], 4)
+        assert np.array_equal(solo[0], toks[b])
+    # the single-chunk entry point auto-detects by default and reports what it used
+    eng = WhisperEngine(str(ggml_file))
+    _, t_auto = eng.transcribe(clips[1], max_new_tokens=4)
+    assert eng.last_language_token == lang[1]
+    _, t_expl = eng.transcribe(clips[1], max_new_tokens=4, language_token=int(lang[1]))
+    assert t_auto == t_expl
