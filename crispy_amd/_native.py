@@ -21,10 +21,10 @@ LAYOUT_BTF = 1
 RN_SYMBOLS = (
     "crispy_last_error", "crispy_version", "crispy_device_count",
     "crispy_rn_create", "crispy_rn_destroy", "crispy_rn_reset", "crispy_rn_n_streams",
-    "crispy_rn_frames_per_launch",
+    "crispy_rn_frames_per_launch", "crispy_rn_set_pipeline",
     "crispy_rn_process", "crispy_rn_process_device", "crispy_rn_synchronize",
     "crispy_rn_set_timing", "crispy_rn_last_kernel_ms",
-    "crispy_rn_debug_capture", "crispy_rn_debug_read",
+    "crispy_rn_debug_capture", "crispy_rn_debug_read", "crispy_rn_stage_rnn_device",
 )
 
 
@@ -81,6 +81,8 @@ def lib() -> C.CDLL:
     L.crispy_rn_synchronize.argtypes = [C.c_void_p]
     L.crispy_rn_set_timing.argtypes = [C.c_void_p, C.c_int]
     L.crispy_rn_last_kernel_ms.argtypes = [C.c_void_p, f32p, f32p]
+    L.crispy_rn_stage_rnn_device.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_void_p]
+    L.crispy_rn_set_pipeline.argtypes = [C.c_void_p, C.c_int]
     L.crispy_rn_debug_capture.argtypes = [C.c_void_p, C.c_int]
     L.crispy_rn_debug_read.argtypes = [C.c_void_p, C.c_int, f32p, C.c_size_t]
     L.crispy_mel_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]

@@ -23,6 +23,7 @@ namespace crispy {
 namespace {
 
 constexpr int WAVE = 64;
+constexpr int RN_SYNTH_GROUP = 5;   // frames per synthesis workgroup (plus one warm-up frame)
 
 // In-kernel stage stamps (diagnostic build only: make PROFILE=1 -> libcrispy_hip_prof.so).
 #ifdef RN_PROFILE
@@ -357,15 +358,18 @@ __device__ __forceinline__ void gru_layer(const h8* __restrict__ W, const h8* __
 //       after its band sums), RNN vectors, band partial sums
 //   U   band partial sums while A and Bb both hold spectra | Ly, tmp22, g, r
 // ---------------------------------------------------------------------------------------------
-struct alignas(16) RnLds {
+// The synthesis kernel (MODE 2) needs one spectrum buffer and 800 B of band scratch only: 5.7 KB, so up to
+// 28 of its (stream, frame-group) workgroups are resident per CU.
+template <int MODE>
+struct alignas(16) RnLdsT {
   float2 A[482];
-  float2 Bb[482];
+  float2 Bb[MODE == 2 ? 100 : 482];
   float U[200];
-  float ceps[8 * 22];
-  float rnn_state[168];  // vad 24 | noise 48 | denoise 96
+  float ceps[MODE == 2 ? 4 : 8 * 22];
+  float rnn_state[MODE == 2 ? 4 : 168];  // vad 24 | noise 48 | denoise 96
   float Ex[24], Ep[24], Exp[24];
 };
-static_assert(sizeof(RnLds) <= 10240, "16 workgroups per CU need <= 10 KB of LDS each");
+static_assert(sizeof(RnLdsT<0>) <= 10240, "16 workgroups per CU need <= 10 KB of LDS each");
 
 // offsets (floats) inside Bb while it serves the RNN
 constexpr int RB_FEAT = 0, RB_DENSE = 48, RB_IN = 72, RB_Z = 192, RB_HR = 288, RB_PART = 384;
@@ -399,24 +403,30 @@ __device__ __forceinline__ Cand wave_best(Cand c) {
 // =============================================================================================
 // frame kernel: one wave per stream, loops over the T frames of the call
 // =============================================================================================
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) void rn_frame_kernel(RnArgs a) {
-  __shared__ RnLds L;
+// MODE 0: fused frame (analysis, in-wave gain network, synthesis).
+// MODE 1: analysis only -- stops after the 42 features and parks X, P, band energies for the synthesis kernel.
+// MODE 2: synthesis only -- gains come from the stream-batched MFMA gain network (rn_rnn_kernel.hip).
+template <int MODE>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void rn_frame_kernel(RnArgs a) {
+  __shared__ RnLdsT<MODE> L;
   const int lane0 = threadIdx.x;
   const int b = blockIdx.x;
   if (b >= a.B) return;
   int lane = lane0;
   const RnTables* tab = a.tab;
   const float* xs = a.xhp + (long)b * a.xhp_stride;
-  float2* pg = a.pspec + (long)b * 482;
 
   // ---- load per-stream state ----
-  for (int i = lane; i < 176; i += WAVE) L.ceps[i] = a.ceps[(long)b * 176 + i];
-  for (int i = lane; i < 168; i += WAVE) L.rnn_state[i] = a.rnn[(long)b * 168 + i];
+  if constexpr (MODE != 2) {
+    for (int i = lane; i < 176; i += WAVE) L.ceps[i] = a.ceps[(long)b * 176 + i];
+    for (int i = lane; i < 168; i += WAVE) L.rnn_state[i] = a.rnn[(long)b * 168 + i];
+  }
   float2 synth[4];  // overlap-add tail, samples (2n, 2n+1) for n = lane + 64 m
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     const int n = lane + WAVE * m;
-    synth[m] = n < 240 ? *reinterpret_cast<const float2*>(a.synth + (long)b * 480 + 2 * n) : make_float2(0.f, 0.f);
+    const bool first_group = (MODE != 2) || blockIdx.y == 0;
+    synth[m] = (n < 240 && first_group) ? *reinterpret_cast<const float2*>(a.synth + (long)b * 480 + 2 * n) : make_float2(0.f, 0.f);
   }
   float lastg = lane < RN_NB ? a.lastg[(long)b * RN_NB + lane] : 0.f;
   BandEdges be;
@@ -436,8 +446,18 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
   float* Rb = reinterpret_cast<float*>(L.Bb);  // RNN vectors after the pitch spectrum is parked
   float* Xf = reinterpret_cast<float*>(L.A);
 
+  // MODE 2 runs over (stream, group of RN_SYNTH_GROUP frames): synthesis has no cross-frame dependency except
+  // the overlap-add tail, which a group obtains by re-synthesising the frame before its first one (warm-up,
+  // nothing written).  5x more independent waves than streams hide the per-wave latency.
+  int t_first = 0, t_out = 0, t_last = a.T;
+  if constexpr (MODE == 2) {
+    t_out = blockIdx.y * RN_SYNTH_GROUP;
+    t_first = t_out > 0 ? t_out - 1 : 0;
+    t_last = min(a.T, t_out + RN_SYNTH_GROUP);
+    if (t_out >= a.T) return;
+  }
   RN_PROF_DECL
-  for (int t = 0; t < a.T; ++t) {
+  for (int t = t_first; t < t_last; ++t) {
     // Launder the lane id and the table / weight base pointers once per frame: every per-lane table
     // address is loop-invariant, and without this the compiler hoists ~250 of them out of the frame
     // loop into registers (429 VGPR+AGPR, one wave per SIMD).  Opaque values keep them per-frame.
@@ -452,9 +472,15 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     const float* __restrict__ hw = tab->half_window;
     const float* __restrict__ tansig = tab->tansig;
     const float* __restrict__ wpf = reinterpret_cast<const float*>(wpraw);
+    float2* pg = a.pspec + (MODE == 0 ? (long)b : (long)t * a.B + b) * 482;
     const float* xw = xs + (long)(t + 3) * RN_FRAME;  // [x_prev, x_cur]
     const float* pb = xs + (long)t * RN_FRAME + 672;  // 1728-sample pitch buffer ending at x_cur
 
+    int pitch_index = 0;
+    float pitch_gain = 0.f;
+    bool silence = false;
+    float vad_prob = 0.f;
+    if constexpr (MODE != 2) {
     // ---- 1. pitch: half-rate, LPC whitening (lp in Bb) ----
     for (int i = lane; i < 864; i += WAVE) {
       const float2 v = *reinterpret_cast<const float2*>(pb + 2 * i);
@@ -630,7 +656,6 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     float* fine = Sa;  // 294 (+2 guard) correlation values, zero where not evaluated
     for (int i = lane; i < 296; i += WAVE) fine[i] = 0.f;
     __syncthreads();
-    int pitch_index;
     {
       const int ca = 2 * min(best0, best1), cb = 2 * max(best0, best1);
       Cand bestc = {-1.f, 0.f, 0};
@@ -680,7 +705,6 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     }
 
     // ---- 4. remove_doubling at half rate (maxperiod 384, minperiod 30, N 480) ----
-    float pitch_gain;
     {
       const float* x = lp + 384;
       int T0 = pitch_index / 2;
@@ -853,8 +877,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
       }
     }
     __syncthreads();
-    const bool silence = E < 0.04f;
-    float vad_prob = 0.f;
+    silence = E < 0.04f;
     if (silence) {
       if (lane < RN_NFEAT) Rb[RB_FEAT + lane] = 0.f;
       if (lane < RN_NB) L.U[U_G + lane] = 0.f;
@@ -902,7 +925,41 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
       }
       __syncthreads();
       STAMP(9)
+    }
+    }  // MODE != 2
 
+    if constexpr (MODE == 1) {
+      // ---- hand-off to the batched gain network and the synthesis kernel ----
+      const long fr = (long)t * a.B + b;
+      for (int i = lane; i < RN_NFREQ; i += WAVE) a.xspec[fr * 482 + i] = L.A[i];
+      if (lane < RNN_FEAT_LD) a.feat[fr * RNN_FEAT_LD + lane] = lane < RN_NFEAT ? Rb[RB_FEAT + lane] : 0.f;
+      float* rc = a.rec + fr * RN_REC_LD;
+      if (lane < RN_NB) { rc[lane] = L.Ex[lane]; rc[22 + lane] = L.Ep[lane]; rc[44 + lane] = L.Exp[lane]; }
+      if (lane == 0) {
+        rc[66] = (float)pitch_index;
+        rc[67] = pitch_gain;
+        a.silent[fr] = silence ? 1 : 0;
+      }
+      __syncthreads();
+      continue;
+    }
+    if constexpr (MODE == 2) {
+      const long fr = (long)t * a.B + b;
+      const float* rc = a.rec + fr * RN_REC_LD;
+      for (int i = lane; i < RN_NFREQ; i += WAVE) L.A[i] = a.xspec[fr * 482 + i];
+      if (lane < RN_NB) {
+        L.Ex[lane] = rc[lane]; L.Ep[lane] = rc[22 + lane]; L.Exp[lane] = rc[44 + lane];
+        L.U[U_G + lane] = a.g_raw[fr * RNN_GAIN_LD + lane];
+      }
+      pitch_index = (int)rc[66];
+      pitch_gain = rc[67];
+      silence = a.silent[fr] != 0;
+      vad_prob = a.vadbuf[fr];
+      __syncthreads();
+    }
+
+    if (!silence) {
+      if constexpr (MODE == 0) {
       // ---- 8. RNN (vectors in Bb) ----
       const float S = 1.f / 256.f;
       float* feat = Rb + RB_FEAT;
@@ -941,6 +998,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
       }
       __syncthreads();
       STAMP(12)
+      }  // MODE == 0
 
       // ---- 9. pitch_filter + gain application (Appendix A.3 step 7) ----
       if (lane < RN_NB) {
@@ -962,10 +1020,12 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         L.A[i] = x;
       }
       __syncthreads();
-      band_sums<false, false>(L.A, nullptr, Rb + RB_PART, L.Ep, tab, be, lane);  // newE (Ep is dead)
+      band_sums<false, false>(L.A, nullptr, Rb + (MODE == 2 ? 0 : RB_PART), L.Ep, tab, be, lane);  // newE (Ep is dead)
       if (lane < RN_NB) {
         L.U[U_R + lane] = sqrtf(L.Ex[lane] / (1e-8f + L.Ep[lane]));  // norm
-        const float gg = fmaxf(L.U[U_G + lane], .6f * lastg);
+        float gg;
+        if constexpr (MODE == 2) gg = a.g_smooth[((long)t * a.B + b) * RNN_GAIN_LD + lane];   // smoothing state lives in the gain-network kernel
+        else gg = fmaxf(L.U[U_G + lane], .6f * lastg);
         L.U[U_G + lane] = gg;
         lastg = gg;
       }
@@ -988,9 +1048,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     STAMP(13)
 
     // ---- taps / debug ----
-    if (a.taps) {
+    if (a.taps && t >= t_out) {
       float* tp = a.taps + ((long)t * a.B + b) * RN_TAPS;
-      if (lane < RN_NFEAT) tp[lane] = Rb[RB_FEAT + lane];
+      if (lane < RN_NFEAT) tp[lane] = MODE == 2 ? a.feat[((long)t * a.B + b) * RNN_FEAT_LD + lane] : Rb[MODE == 2 ? 0 : RB_FEAT + lane];
       if (lane < RN_NB) tp[42 + lane] = L.U[U_G + lane];
       if (lane == 0) {
         tp[64] = (float)pitch_index;
@@ -1000,7 +1060,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         tp[68] = tp[69] = tp[70] = tp[71] = 0.f;
       }
     }
-    if (a.vad && lane == 0) a.vad[(long)t * a.B + b] = vad_prob;
+    if (a.vad && lane == 0 && t >= t_out) a.vad[(long)t * a.B + b] = vad_prob;
     if (a.dbg && t == a.T - 1) {
       float* D = a.dbg + (long)b * RN_DBG_FLOATS;
       for (int i = lane; i < 962; i += WAVE) D[2862 + i] = Xf[i];
@@ -1023,7 +1083,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
           float2 ov;
           ov.x = fmaf(z.x, hw[i0], synth[m].x);
           ov.y = fmaf(-z.y, hw[i1], synth[m].y);
-          *reinterpret_cast<float2*>(o + i0) = ov;
+          if (t >= t_out) *reinterpret_cast<float2*>(o + i0) = ov;
           synth[m].x = z2.x * hw[479 - i0];
           synth[m].y = -z2.y * hw[479 - i1];
         }
@@ -1039,19 +1099,25 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     for (int k = 0; k < 24; ++k) D[3824 + k] = (float)prof_[k];
   }
 #endif
-  // ---- store per-stream state ----
+  // ---- store per-stream state (each kernel of the staged pipeline owns its part) ----
+  if (MODE == 0 || (MODE == 2 && t_last == a.T)) {
 #pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    const int n = lane + WAVE * m;
-    if (n < 240) *reinterpret_cast<float2*>(a.synth + (long)b * 480 + 2 * n) = synth[m];
+    for (int m = 0; m < 4; ++m) {
+      const int n = lane + WAVE * m;
+      if (n < 240) *reinterpret_cast<float2*>(a.synth + (long)b * 480 + 2 * n) = synth[m];
+    }
   }
-  for (int i = lane; i < 176; i += WAVE) a.ceps[(long)b * 176 + i] = L.ceps[i];
-  for (int i = lane; i < 168; i += WAVE) a.rnn[(long)b * 168 + i] = L.rnn_state[i];
-  if (lane < RN_NB) a.lastg[(long)b * RN_NB + lane] = lastg;
-  if (lane == 0) {
-    a.memid[b] = memid;
-    a.last_period[b] = last_period;
-    a.last_gain[b] = last_gain;
+  if constexpr (MODE != 2) {
+    for (int i = lane; i < 176; i += WAVE) a.ceps[(long)b * 176 + i] = L.ceps[i];
+    if (lane == 0) {
+      a.memid[b] = memid;
+      a.last_period[b] = last_period;
+      a.last_gain[b] = last_gain;
+    }
+  }
+  if constexpr (MODE == 0) {
+    for (int i = lane; i < 168; i += WAVE) a.rnn[(long)b * 168 + i] = L.rnn_state[i];
+    if (lane < RN_NB) a.lastg[(long)b * RN_NB + lane] = lastg;
   }
 }
 
@@ -1114,7 +1180,15 @@ hipError_t rn_launch_highpass(const RnArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 hipError_t rn_launch_frames(const RnArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(rn_frame_kernel, dim3(a.B), dim3(WAVE), 0, s, a);
+  hipLaunchKernelGGL(rn_frame_kernel<0>, dim3(a.B), dim3(WAVE), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t rn_launch_analysis(const RnArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(rn_frame_kernel<1>, dim3(a.B), dim3(WAVE), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t rn_launch_synthesis(const RnArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(rn_frame_kernel<2>, dim3(a.B, (a.T + RN_SYNTH_GROUP - 1) / RN_SYNTH_GROUP), dim3(WAVE), 0, s, a);
   return hipGetLastError();
 }
 hipError_t rn_launch_roll_history(const RnArgs& a, hipStream_t s) {
