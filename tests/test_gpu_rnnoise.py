@@ -300,3 +300,21 @@ def test_staged_and_fused_pipelines_agree(oracle, weights0):
         m.set_pipeline(i % 2 == 0)
         parts.append(m.process(np.ascontiguousarray(x[t0:t1]))[0])
     assert np.abs(np.concatenate(parts) - of).max() <= 1e-5 * peak
+
+
+@pytest.mark.parametrize("staged", [False, True])
+def test_long_run_no_drift(oracle, weights0, staged):
+    """10 s of audio (1000 frames, 40 launches, 4 internal 250-frame segments): recurrent state (GRUs, pitch
+    continuity, cepstral ring, OLA) must not drift away from the oracle; checked on the LAST second."""
+    from crispy_amd import synth_audio as SA
+    B, T = 6, 1000
+    x = SA.batch_np(B, T, first_stream=40) * np.float32(32768.0)
+    ds = _mk(weights0, B)
+    ds.set_pipeline(staged)
+    out, vad = ds.process(x)
+    for b in range(B):
+        ro, rv = oracle.OracleDenoiseState(weights0).process(x[:, b])
+        peak = max(np.abs(ro).max(), 1.0)
+        tail_err = np.abs(out[900:, b] - ro[900:]).max() / peak
+        assert tail_err <= 1e-4, (b, tail_err)
+        assert np.abs(vad[900:, b] - rv[900:]).max() < 1e-4
