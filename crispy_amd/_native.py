@@ -34,7 +34,8 @@ ASR_SYMBOLS = ("crispy_asr_create", "crispy_asr_set_tensor", "crispy_asr_finaliz
                "crispy_asr_hparams_get", "crispy_asr_encode", "crispy_asr_encode_device", "crispy_asr_synchronize",
                "crispy_asr_set_suppress", "crispy_asr_decode_greedy_device", "crispy_asr_transcribe_tokens",
                "crispy_asr_load", "crispy_asr_token_text", "crispy_asr_transcribe", "crispy_asr_free_result",
-               "crispy_asr_decode_greedy_lang_device", "crispy_asr_detect_language_device")
+               "crispy_asr_decode_greedy_lang_device", "crispy_asr_detect_language_device",
+               "crispy_asr_transcribe_batch")
 RS_SYMBOLS = ("crispy_resampler_create", "crispy_resampler_destroy", "crispy_resampler_out_len",
               "crispy_resampler_process_device", "crispy_resampler_synchronize")
 ALL_SYMBOLS = RN_SYMBOLS + MEL_SYMBOLS + ASR_SYMBOLS + RS_SYMBOLS
@@ -107,6 +108,7 @@ def lib() -> C.CDLL:
     L.crispy_asr_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
     L.crispy_asr_token_text.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
     L.crispy_asr_transcribe.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.crispy_asr_transcribe_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.crispy_asr_free_result.argtypes = [C.c_void_p]
     L.crispy_asr_free_result.restype = None
     L.crispy_asr_decode_greedy_lang_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,

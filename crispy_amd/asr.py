@@ -208,6 +208,33 @@ class WhisperEngine(WhisperModel):
         return text, tokens
 
 
+def _read_result(res) -> tuple:
+    text_p = C.cast(res, C.POINTER(C.c_char_p))[0]
+    tok_p = C.cast(res.value + 8, C.POINTER(C.POINTER(C.c_int)))[0]
+    n_tok = C.cast(res.value + 16, C.POINTER(C.c_int))[0]
+    lang = int(C.cast(res.value + 20, C.POINTER(C.c_int))[0])
+    return (text_p.decode("utf-8", "replace") if text_p else "", [int(tok_p[i]) for i in range(n_tok)], lang)
+
+
+def transcribe_batch(engine: "WhisperEngine", clips, max_new_tokens: int = 0, language_token: int = 0):
+    """`crispy_asr_transcribe_batch`: a list of chunks (each <= 30 s, empty allowed) -> [(text, tokens, language)]."""
+    arrs = [np.ascontiguousarray(c, dtype=np.float32).ravel() for c in clips]
+    nb = len(arrs)
+    ptrs = (C.c_void_p * max(nb, 1))(*[a.ctypes.data if a.size else None for a in arrs])
+    lens = (C.c_size_t * max(nb, 1))(*[a.size for a in arrs])
+    res = (C.c_void_p * max(nb, 1))()
+    opts = (C.c_int * 3)(int(language_token), 0, int(max_new_tokens))
+    N.check(N.lib().crispy_asr_transcribe_batch(engine._h, ptrs, lens, nb, opts, res))
+    out = []
+    for i in range(nb):
+        r = C.c_void_p(res[i])
+        try:
+            out.append(_read_result(r))
+        finally:
+            N.lib().crispy_asr_free_result(r)
+    return out
+
+
 def transcribe_recording(engine: "WhisperEngine", pcm16k: np.ndarray, max_new_tokens: int = 0) -> str:
     """The chunker of `run_transcription` (commands/transcription.rs:249-302, 363-400, 468): hard 30 s cuts,
     the final partial chunk passed as is, chunk texts trimmed and joined with a single space."""

@@ -956,6 +956,97 @@ int crispy_asr_transcribe(crispy_asr* h, const float* pcm16k, size_t n, const cr
   return finish();
 }
 
+// engine.transcribe for a batch of chunks at once: one log-mel + encoder + (language detection) + decoder pass
+// over all clips; results[i] is library-owned (crispy_asr_free_result each).
+int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const size_t* n, int batch,
+                                const crispy_asr_opts* opts, crispy_asr_result** results) {
+  if (!h || !results) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: NULL argument");
+  if (batch < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: batch < 0");
+  for (int i = 0; i < batch; ++i) results[i] = nullptr;
+  if (batch == 0) return CRISPY_OK;
+  if (!pcm || !n) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: NULL argument");
+  if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_transcribe_batch: model not finalized");
+  // empty clips produce empty results without touching the GPU (managers/transcription.rs:175-177)
+  std::vector<int> live;
+  size_t stride = 1;
+  for (int i = 0; i < batch; ++i) {
+    if (n[i] > 480000) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: clip %d has %zu samples (> 480000)", i, n[i]);
+    if (n[i] > 0) {
+      if (!pcm[i]) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: clip %d is NULL", i);
+      live.push_back(i);
+      if (n[i] > stride) stride = n[i];
+    }
+  }
+  std::vector<crispy_asr_result_impl*> impl(batch, nullptr);
+  auto cleanup = [&]() { for (auto* r : impl) delete r; for (int i = 0; i < batch; ++i) results[i] = nullptr; };
+  for (int i = 0; i < batch; ++i) {
+    impl[i] = new (std::nothrow) crispy_asr_result_impl();
+    if (!impl[i]) { cleanup(); return fail(CRISPY_ERR_OOM, "crispy_asr_transcribe_batch: host allocation failed"); }
+  }
+  const int nb = (int)live.size();
+  if (nb > 0) {
+    const bool multilingual = h->hp.n_vocab >= 51865;
+    const int extra = multilingual ? h->hp.n_vocab - 51865 : 0;
+    const int sot = h->eot + 1;
+    std::vector<int> prompt = {sot};
+    if (multilingual) {
+      prompt.push_back(opts && opts->language_token > 0 ? opts->language_token : sot + 1);
+      prompt.push_back((opts && opts->translate ? sot + 100 : sot + 101) + extra);
+    }
+    prompt.push_back(sot + 105 + extra);
+    int max_new = opts && opts->max_new_tokens > 0 ? opts->max_new_tokens : h->hp.n_text_ctx / 2;
+    if ((int)prompt.size() + max_new > h->hp.n_text_ctx) max_new = h->hp.n_text_ctx - (int)prompt.size();
+    std::vector<float> packed((size_t)nb * stride, 0.f);
+    std::vector<int> lens(nb), lang(nb, 0), toks((size_t)nb * max_new), n_out(nb, 0);
+    for (int k = 0; k < nb; ++k) {
+      std::memcpy(packed.data() + (size_t)k * stride, pcm[live[k]], n[live[k]] * sizeof(float));
+      lens[k] = (int)n[live[k]];
+    }
+    auto run = [&]() -> int {
+      HIP_TRY(hipSetDevice(h->device));
+      int rc = reserve_enc(h, nb);
+      if (rc != CRISPY_OK) return rc;
+      if (!h->w_pcm || (long)stride > h->cap_pcm_stride) {
+        if (h->w_pcm) (void)hipFree(h->w_pcm);
+        h->w_pcm = nullptr;
+        HIP_TRY(hipMalloc(&h->w_pcm, (size_t)h->cap_batch * stride * sizeof(float)));
+        h->cap_pcm_stride = (long)stride;
+      }
+      HIP_TRY(hipMemcpyAsync(h->w_pcm, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+      rc = crispy_mel_compute_device(h->mel, h->w_pcm, (long)stride, lens.data(), nb, nullptr, h->w_melt, h->stream);
+      if (rc != CRISPY_OK) return rc;
+      rc = crispy_asr_encode_device(h, h->w_melt, nb, h->w_enc, h->stream);
+      if (rc != CRISPY_OK) return rc;
+      const bool detect = multilingual && !(opts && opts->language_token > 0);
+      if (detect) {
+        rc = crispy_asr_detect_language_device(h, h->w_enc, nb, lang.data());
+        if (rc != CRISPY_OK) return rc;
+      } else if (multilingual) {
+        std::fill(lang.begin(), lang.end(), prompt[1]);
+      }
+      return crispy_asr_decode_greedy_lang_device(h, h->w_enc, nb, prompt.data(), (int)prompt.size(),
+                                                  detect ? lang.data() : nullptr, max_new, toks.data(), n_out.data(), nullptr);
+    };
+    const int rc = run();
+    if (rc != CRISPY_OK) { cleanup(); return rc; }
+    for (int k = 0; k < nb; ++k) {
+      crispy_asr_result_impl* r = impl[live[k]];
+      r->tokens.assign(toks.begin() + (size_t)k * max_new, toks.begin() + (size_t)k * max_new + n_out[k]);
+      r->language_token = lang[k];
+      for (int t : r->tokens)
+        if (t < h->eot && t < (int)h->vocab.size()) r->text += h->vocab[t];
+    }
+  }
+  for (int i = 0; i < batch; ++i) {
+    impl[i]->pub.text = impl[i]->text.c_str();
+    impl[i]->pub.tokens = impl[i]->tokens.data();
+    impl[i]->pub.n_tokens = (int)impl[i]->tokens.size();
+    impl[i]->pub.language_token = impl[i]->language_token;
+    results[i] = &impl[i]->pub;
+  }
+  return CRISPY_OK;
+}
+
 void crispy_asr_free_result(crispy_asr_result* r) {
   if (!r) return;
   delete reinterpret_cast<crispy_asr_result_impl*>(r);   // pub is the first member

@@ -85,6 +85,8 @@ def batch_torch(n_streams: int, n_frames: int, device, first_stream: int = 0, se
 def clip16k_np(seed: int, n_samples: int = 480000) -> np.ndarray:
     """Seeded 16 kHz test clip in +-1 for the ASR path (BASELINE cfg 3): sum of chirps with a syllabic
     envelope plus coloured noise.  Deterministic across machines (numpy PCG64)."""
+    if n_samples <= 0:
+        return np.zeros(0, dtype=np.float32)
     rng = np.random.default_rng(1000 + seed)
     t = np.arange(n_samples, dtype=np.float64) / 16000.0
     x = np.zeros(n_samples, dtype=np.float64)

@@ -262,6 +262,11 @@ typedef struct crispy_asr_result {
  * loaded from a file (vocabulary) for text; tokens are always returned. */
 int crispy_asr_transcribe(crispy_asr *h, const float *pcm16k, size_t n, const crispy_asr_opts *opts,
                           crispy_asr_result **out);
+/* The same for `batch` chunks at once (pcm[i]: host pointer to n[i] <= 480000 samples, n[i] == 0 allowed):
+ * one log-mel + encoder + language-detection + decoder pass over all clips.  results[batch] receives one
+ * library-owned result per clip (free each); on failure every results[i] is NULL. */
+int crispy_asr_transcribe_batch(crispy_asr *h, const float *const *pcm, const size_t *n, int batch,
+                                const crispy_asr_opts *opts, crispy_asr_result **results);
 void crispy_asr_free_result(crispy_asr_result *r);
 
 /* ------------------------------------------------------------------------------------------

@@ -298,3 +298,16 @@ def test_language_auto_detection(tiny, model, ggml_file, oracle):
     assert eng.last_language_token == lang[1]
     _, t_expl = eng.transcribe(clips[1], max_new_tokens=4, language_token=int(lang[1]))
     assert t_auto == t_expl
+
+
+def test_transcribe_batch_equals_single_calls(ggml_file):
+    from crispy_amd import synth_audio
+    from crispy_amd.asr import WhisperEngine, transcribe_batch
+    eng = WhisperEngine(str(ggml_file))
+    clips = [synth_audio.clip16k_np(110 + i, n) for i, n in enumerate((80000, 0, 480000, 1234))]
+    got = transcribe_batch(eng, clips, max_new_tokens=5)
+    assert len(got) == 4 and got[1] == ("", [], 0)
+    for i in (0, 2, 3):
+        text, toks = eng.transcribe(clips[i], max_new_tokens=5)
+        assert got[i][0] == text and got[i][1] == toks and got[i][2] == eng.last_language_token
+    assert transcribe_batch(eng, []) == []
