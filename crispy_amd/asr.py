@@ -246,3 +246,18 @@ def transcribe_recording(engine: "WhisperEngine", pcm16k: np.ndarray, max_new_to
         if text:
             parts.append(text)
     return " ".join(parts)
+
+
+def transcribe_with_timestamps(engine: "WhisperEngine", audio: np.ndarray, chunk_offset_seconds: float,
+                               max_new_tokens: int = 0):
+    """`TranscriptionManager::transcribe_with_timestamps` (managers/transcription.rs:200-249) for an engine that
+    returns no segments: empty audio or empty trimmed text -> []; otherwise one segment spanning the chunk,
+    (offset, offset + len/16000, trimmed text)."""
+    a = np.ascontiguousarray(audio, dtype=np.float32).ravel()
+    if a.size == 0:
+        return []
+    text, _ = engine.transcribe(a, max_new_tokens)
+    text = text.strip()
+    if not text:
+        return []
+    return [(float(chunk_offset_seconds), float(chunk_offset_seconds) + a.size / 16000.0, text)]

@@ -318,3 +318,40 @@ def test_long_run_no_drift(oracle, weights0, staged):
         tail_err = np.abs(out[900:, b] - ro[900:]).max() / peak
         assert tail_err <= 1e-4, (b, tail_err)
         assert np.abs(vad[900:, b] - rv[900:]).max() < 1e-4
+
+
+def test_adapter_playback_and_input_resampler(oracle, weights0):
+    """RnnNoiseProcessor beyond push_sample (audio.rs:216-240, 297-314): a 44.1 kHz device goes through the input
+    LinearResampler to 48 kHz before framing; next_sample() interpolates the output ring at input_rate/output_rate."""
+    from crispy_amd import synth_audio as SA
+    from crispy_amd.denoise import LinearResampler, RnnNoiseProcessor
+    x48 = SA.stream_np(7, 12, silent=False)
+    # (a) 44.1 kHz input: emulate the adapter with the oracle behind the same resampler
+    n441 = int(len(x48) * 44100 / 48000)
+    x441 = np.interp(np.arange(n441) * (48000 / 44100), np.arange(len(x48)), x48).astype(np.float32)
+    proc = RnnNoiseProcessor(weights0, 44100.0, 48000.0, 1.0, 1, 0)
+    assert proc.produced_rate_hz() == 48000.0
+    got = []
+    for s in x441:
+        r = proc.push_sample([s])
+        if r is not None:
+            got.append(r[:, 0])
+    got = np.concatenate(got)
+    rs = LinearResampler(44100.0, 48000.0)
+    ups = []
+    for s in x441:
+        rs.process_sample(s, ups.append)
+    ups = np.array(ups, np.float32)
+    nfr = len(ups) // 480
+    ref, _ = oracle.OracleDenoiseState(weights0).process(ups[:nfr * 480] * np.float32(32768.0))
+    want = np.clip(ref / np.float32(32768.0), -1, 1)[1:].ravel()
+    assert got.shape == want.shape and np.abs(got - want).max() <= 1e-4 * np.abs(want).max() + 1e-7
+    # (b) playback: output_rate 24 kHz -> every second sample of the ring, linearly interpolated
+    proc = RnnNoiseProcessor(weights0, 48000.0, 24000.0, 1.0, 1, 0)
+    assert np.all(proc.next_sample() == 0)                      # fewer than two samples buffered
+    for s in x48[:480 * 3]:
+        proc.push_sample([s])
+    ring = np.array([v[0] for v in proc.output_buf])
+    assert ring.size == 960                                     # 3 frames pushed, the first one dropped
+    play = np.array([proc.next_sample()[0] for _ in range(200)])
+    assert np.allclose(play, ring[0:400:2], atol=1e-7)

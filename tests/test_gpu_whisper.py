@@ -311,3 +311,15 @@ def test_transcribe_batch_equals_single_calls(ggml_file):
         text, toks = eng.transcribe(clips[i], max_new_tokens=5)
         assert got[i][0] == text and got[i][1] == toks and got[i][2] == eng.last_language_token
     assert transcribe_batch(eng, []) == []
+
+
+def test_transcribe_with_timestamps_fallback(ggml_file):
+    """managers/transcription.rs:236-249: no segments from the engine -> one segment covering the chunk."""
+    from crispy_amd import synth_audio
+    from crispy_amd.asr import WhisperEngine, transcribe_with_timestamps
+    eng = WhisperEngine(str(ggml_file))
+    x = synth_audio.clip16k_np(7, 160000)
+    segs = transcribe_with_timestamps(eng, x, 30.0, max_new_tokens=3)
+    text, _ = eng.transcribe(x, 3)
+    assert segs == [(30.0, 40.0, text.strip())]
+    assert transcribe_with_timestamps(eng, np.zeros(0, np.float32), 0.0) == []
