@@ -1,7 +1,8 @@
 """Host-side mirror of the reference's ASR surface (transcribe-rs `SpeechModel::transcribe`,
 reference call sites src-tauri/src/managers/transcription.rs:183-185), backed by the HIP library.
 
-Round 1 covers the log-mel front end (`LogMel`); the encoder / decoder follow."""
+`LogMel` (whisper.cpp log_mel_spectrogram), `WhisperModel` (tensor-by-tensor container: encoder, greedy decoder,
+language detection), `WhisperEngine` (GGML model file + text), and the reference's chunker / timestamp fallback."""
 from __future__ import annotations
 
 import ctypes as C
