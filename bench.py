@@ -181,8 +181,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    # CRISPY_BENCH_FORCE_DIST=1 exercises the RCCL path with a single rank (what can be tested on a 1-GPU box)
+    use_dist = world > 1 or os.environ.get("CRISPY_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
@@ -208,7 +213,7 @@ def main():
         ds.process_device(d_in.data_ptr(), d_out.data_ptr(), T)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -216,6 +221,12 @@ def main():
     ds.synchronize()
     torch.cuda.synchronize()
     barrier()
+    if use_dist:
+        # RCCL prints its version banner to C stdout when the communicator comes up (first collective above);
+        # push it out now on every rank so that rank 0's JSON line is the last thing on stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -280,8 +291,8 @@ def main():
             del d_in, d_out
             torch.cuda.empty_cache()
             line["asr"] = asr_leg(local_rank)
-        print(json.dumps(line))
-    if world > 1:
+        print(json.dumps(line), flush=True)
+    if use_dist:
         dist.destroy_process_group()
 
 
