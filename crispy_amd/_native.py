@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcrispy_hip.so")
+# CRISPY_HIP_LIB: developer override to A/B another build of the same HIP library (tools/ab_variants.sh)
+LIB_PATH = os.environ.get("CRISPY_HIP_LIB") or os.path.join(_HERE, "libcrispy_hip.so")
 
 RN_FRAME = 480
 RN_WEIGHT_BYTES = 87503

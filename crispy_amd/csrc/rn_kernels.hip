@@ -278,75 +278,164 @@ __device__ __forceinline__ float sigmoid_approx(float x, const float* __restrict
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
-// acc += sum_k W[k][row] * x[k].  Weights: f16 [K8][rows][8] (16 bytes per lane per 8 MACs, each MAC one
-// v_fma_mix_f32); x lives in LDS, 16-byte aligned, zero padded to 8*K8.  Four 16-byte loads are kept in
-// flight so that one L2 round trip covers 32 MACs.
-template <int K8>
-__device__ __forceinline__ float dot_h(const h8* __restrict__ Wp, int rows, int row, const float* x, float acc) {
-  const float4* x4 = reinterpret_cast<const float4*>(x);
-  const h8* p = Wp + row;
-  constexpr int BLK = 4;
-#pragma unroll 1
-  for (int k0 = 0; k0 + BLK <= K8; k0 += BLK) {
-    h8 w[BLK];
+// acc[r] += sum_k W[k][row[r]] * xa[k] + sum_k U[k][row[r]] * xb[k].  Weights: f16 [K8][rows][8] (16 bytes per lane
+// per 8 MACs, each MAC one v_fma_mix_f32); xa / xb live in LDS, 16-byte aligned, zero padded to 8*K8.
+//  * The weight stream comes from L2 (~0.6 us per dependent round trip at this occupancy), so the k-loop is fully
+//    unrolled over the concatenated [W | U] rows in blocks of 16-byte loads, with the next block issued before
+//    the current one is consumed (8 KB per wave in flight; 16 KB measured slower: spills).
+//  * Buffer loads: one resource descriptor for the whole pack (4 SGPRs), voffset = row*16 (one VGPR), the matrix /
+//    k-row offset as a scalar -- no per-load 64-bit vector address arithmetic.
+//  * sched_barrier pins the issue order (prefetch, then for every k-step: LDS reads of step k+1, FMAs of step k);
+//    left alone the scheduler hoists every load of a block to its top and spills.
+//  * Two accumulators: dependent v_fma_mix_f32 need a wait state in between.
+typedef unsigned int rn_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ h8 wload(__amdgpu_buffer_rsrc_t rs, int row16, int off_h8) {
+  return __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rs, row16, off_h8 * 16, 0));
+}
+// NR rows per lane (row[r], r < NR) share every activation read: the broadcast ds_read_b128 moves 1 KB through the
+// LDS return path for 16 bytes of information, so rows are batched against it.
+// Block sizes (RN_BLKn for n rows per lane) are the largest that keep the kernel out of scratch inside the frame
+// loop.  That is a correctness matter, not only speed: this compiler places VGPR spill stores of a join block
+// *before* the block's exec restore, so a value spilled right after a divergent region (e.g. `if (lane == 0)`) is
+// saved for the active lanes only and reloaded as garbage in the others.  tests/test_build_resources.py pins the
+// scratch size.
+template <int MK8, int NK8, int ROWS, int NR>
+__device__ __forceinline__ void dotn_h(__amdgpu_buffer_rsrc_t rs, int w_off, int u_off, const int (&row)[NR],
+                                       const float* xa, const float* xb, float (&acc)[NR]) {
+  constexpr int K8 = MK8 + NK8;
+#ifndef RN_BLK3
+#define RN_BLK3 1
+#define RN_BLK2 2
+#define RN_BLK1 4
+#endif
+  constexpr int BLK = NR >= 3 ? RN_BLK3 : (NR == 2 ? RN_BLK2 : RN_BLK1);
+  constexpr int NBLK = (K8 + BLK - 1) / BLK;
+  int row16[NR];
 #pragma unroll
-    for (int q = 0; q < BLK; ++q) w[q] = p[(k0 + q) * rows];
+  for (int r = 0; r < NR; ++r) row16[r] = row[r] * 16;
+  // opaque per call: the activation reads are invariant across calls with the same vectors, and keeping them
+  // (up to 54 float4) in registers spills.  (An integer, so that the pointers stay LDS pointers.)
+  int xo = 0;
+  asm volatile("" : "+v"(xo));
+  const float4* xa4 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(xa) + xo);
+  const float4* xb4 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(xb) + xo);
+  h8 w[2][BLK][NR];
+  float4 xc0 = MK8 > 0 ? xa4[0] : xb4[0], xc1 = MK8 > 0 ? xa4[1] : xb4[1], xn0 = xc0, xn1 = xc1;
+#pragma unroll
+  for (int q = 0; q < BLK; ++q)
+    if (q < K8) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+        w[0][q][r] = wload(rs, row16[r], q < MK8 ? w_off + q * ROWS : u_off + (q - MK8) * ROWS);
+    }
+  float acc1[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) acc1[r] = 0.f;
+#pragma unroll
+  for (int blk = 0; blk < NBLK; ++blk) {
+    if (blk + 1 < NBLK) {
+#pragma unroll
+      for (int q = 0; q < BLK; ++q) {
+        const int k = (blk + 1) * BLK + q;
+        if (k < K8) {
+#pragma unroll
+          for (int r = 0; r < NR; ++r)
+            w[(blk + 1) & 1][q][r] = wload(rs, row16[r], k < MK8 ? w_off + k * ROWS : u_off + (k - MK8) * ROWS);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < BLK; ++q) {
-      const float4 a = x4[2 * (k0 + q)], b = x4[2 * (k0 + q) + 1];
-      acc = fmaf((float)w[q][0], a.x, acc); acc = fmaf((float)w[q][1], a.y, acc);
-      acc = fmaf((float)w[q][2], a.z, acc); acc = fmaf((float)w[q][3], a.w, acc);
-      acc = fmaf((float)w[q][4], b.x, acc); acc = fmaf((float)w[q][5], b.y, acc);
-      acc = fmaf((float)w[q][6], b.z, acc); acc = fmaf((float)w[q][7], b.w, acc);
+      const int k = blk * BLK + q;
+      if (k < K8) {
+        if (k + 1 < K8) {
+          xn0 = k + 1 < MK8 ? xa4[2 * (k + 1)] : xb4[2 * (k + 1 - MK8)];
+          xn1 = k + 1 < MK8 ? xa4[2 * (k + 1) + 1] : xb4[2 * (k + 1 - MK8) + 1];
+        }
+        // a side-effecting node the accumulators flow through: sched_barrier alone orders only the memory
+        // operations, the FMAs would all sink below the last load of the row
+#pragma unroll
+        for (int r = 0; r < NR; ++r) asm volatile("" : "+v"(acc[r]), "+v"(acc1[r]));
+        __builtin_amdgcn_sched_barrier(0);
+        const float xs[8] = {xc0.x, xc0.y, xc0.z, xc0.w, xc1.x, xc1.y, xc1.z, xc1.w};
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            acc[r] = fmaf((float)w[blk & 1][q][r][e], xs[e], acc[r]);
+            acc1[r] = fmaf((float)w[blk & 1][q][r][e + 1], xs[e + 1], acc1[r]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        xc0 = xn0;
+        xc1 = xn1;
+      }
     }
   }
-  constexpr int REM = K8 % BLK;
-  if (REM) {
-    constexpr int k0 = K8 - REM;
-    h8 w[REM ? REM : 1];
 #pragma unroll
-    for (int q = 0; q < REM; ++q) w[q] = p[(k0 + q) * rows];
-#pragma unroll
-    for (int q = 0; q < REM; ++q) {
-      const float4 a = x4[2 * (k0 + q)], b = x4[2 * (k0 + q) + 1];
-      acc = fmaf((float)w[q][0], a.x, acc); acc = fmaf((float)w[q][1], a.y, acc);
-      acc = fmaf((float)w[q][2], a.z, acc); acc = fmaf((float)w[q][3], a.w, acc);
-      acc = fmaf((float)w[q][4], b.x, acc); acc = fmaf((float)w[q][5], b.y, acc);
-      acc = fmaf((float)w[q][6], b.z, acc); acc = fmaf((float)w[q][7], b.w, acc);
-    }
-  }
-  return acc;
+  for (int r = 0; r < NR; ++r) acc[r] += acc1[r];
+}
+template <int K8, int ROWS>
+__device__ __forceinline__ float dot_h(__amdgpu_buffer_rsrc_t rs, int w_off, int row, const float* x, float acc0) {
+  const int rows[1] = {row};
+  float acc[1] = {acc0};
+  dotn_h<K8, 0, ROWS, 1>(rs, w_off, w_off, rows, x, x, acc);
+  return acc[0];
 }
 
 // One GRU layer (ReLU candidate).  in_vec[M] and state[N] in LDS, zero padded to multiples of 8;
-// zbuf / hr: N floats of scratch each.
+// zbuf / hr: N floats of scratch each.  w_off / u_off: 16-byte offsets of the two matrices in the weight pack.
 template <int M, int N>
-__device__ __forceinline__ void gru_layer(const h8* __restrict__ W, const h8* __restrict__ U,
+__device__ __forceinline__ void gru_layer(__amdgpu_buffer_rsrc_t rs, int w_off, int u_off,
                                           const float* __restrict__ bias, const float* in_vec,
                                           float* state, float* zbuf, float* hr,
                                           const float* __restrict__ tansig, int lane) {
   constexpr int ROWS = 3 * N;
   constexpr int MK8 = (M + 7) / 8, NK8 = (N + 7) / 8;
+  constexpr int NRZ = (2 * N + WAVE - 1) / WAVE, NRC = (N + WAVE - 1) / WAVE;
   const float S = 1.f / 256.f;
-  // update (z) and reset (r) gates: rows [0, 2N)
-  for (int row = lane; row < 2 * N; row += WAVE) {
-    float acc = bias[row];
-    acc = dot_h<MK8>(W, ROWS, row, in_vec, acc);
-    acc = dot_h<NK8>(U, ROWS, row, state, acc);
-    const float s = sigmoid_approx(S * acc, tansig);
-    if (row < N) zbuf[row] = s;
-    else hr[row - N] = state[row - N] * s;
+  // update (z) and reset (r) gates: rows [0, 2N), all of them in one pass over the activations
+  {
+    int rows[NRZ];
+    float acc[NRZ];
+#pragma unroll
+    for (int r = 0; r < NRZ; ++r) {
+      rows[r] = min(lane + WAVE * r, 2 * N - 1);
+      acc[r] = bias[rows[r]];
+    }
+    dotn_h<MK8, NK8, ROWS, NRZ>(rs, w_off, u_off, rows, in_vec, state, acc);
+#pragma unroll
+    for (int r = 0; r < NRZ; ++r) {
+      const int row = lane + WAVE * r;
+      if (row < 2 * N) {
+        const float s = sigmoid_approx(S * acc[r], tansig);
+        if (row < N) zbuf[row] = s;
+        else hr[row - N] = state[row - N] * s;
+      }
+    }
   }
   __syncthreads();
   // candidate rows [2N, 3N): recurrent part sees h*r
-  for (int i = lane; i < N; i += WAVE) {
-    float acc = bias[2 * N + i];
-    acc = dot_h<MK8>(W, ROWS, 2 * N + i, in_vec, acc);
-    acc = dot_h<NK8>(U, ROWS, 2 * N + i, hr, acc);
-    float c = S * acc;
-    c = c < 0.f ? 0.f : c;
-    const float z = zbuf[i];
-    state[i] = z * state[i] + (1.f - z) * c;
+  {
+    int rows[NRC];
+    float acc[NRC];
+#pragma unroll
+    for (int r = 0; r < NRC; ++r) {
+      rows[r] = 2 * N + min(lane + WAVE * r, N - 1);
+      acc[r] = bias[rows[r]];
+    }
+    dotn_h<MK8, NK8, ROWS, NRC>(rs, w_off, u_off, rows, in_vec, hr, acc);
+#pragma unroll
+    for (int r = 0; r < NRC; ++r) {
+      const int i = lane + WAVE * r;
+      if (i < N) {
+        float c = S * acc[r];
+        c = c < 0.f ? 0.f : c;
+        const float z = zbuf[i];
+        state[i] = z * state[i] + (1.f - z) * c;
+      }
+    }
   }
   __syncthreads();
 }
@@ -421,12 +510,17 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
     for (int i = lane; i < 176; i += WAVE) L.ceps[i] = a.ceps[(long)b * 176 + i];
     for (int i = lane; i < 168; i += WAVE) L.rnn_state[i] = a.rnn[(long)b * 168 + i];
   }
-  float2 synth[4];  // overlap-add tail, samples (2n, 2n+1) for n = lane + 64 m
+  // Overlap-add tail, samples (2n, 2n+1) for n = lane + 64 m.  The fused kernel keeps it in the state buffer
+  // (L2) and touches it once per frame: eight VGPRs that would otherwise be live across the whole frame loop
+  // are what pushed the kernel into scratch spills.  The synthesis kernel (low pressure) keeps it in registers.
+  float2 synth[4];
+  float* synth_g = a.synth + (long)b * 480;
+  if constexpr (MODE == 2) {
 #pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    const int n = lane + WAVE * m;
-    const bool first_group = (MODE != 2) || blockIdx.y == 0;
-    synth[m] = (n < 240 && first_group) ? *reinterpret_cast<const float2*>(a.synth + (long)b * 480 + 2 * n) : make_float2(0.f, 0.f);
+    for (int m = 0; m < 4; ++m) {
+      const int n = lane + WAVE * m;
+      synth[m] = (n < 240 && blockIdx.y == 0) ? *reinterpret_cast<const float2*>(synth_g + 2 * n) : make_float2(0.f, 0.f);
+    }
   }
   float lastg = lane < RN_NB ? a.lastg[(long)b * RN_NB + lane] : 0.f;
   BandEdges be;
@@ -463,10 +557,18 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
     // loop into registers (429 VGPR+AGPR, one wave per SIMD).  Opaque values keep them per-frame.
     lane = lane0;
     asm volatile("" : "+v"(lane));
-    const RnTables* tabv = a.tab;
-    const uint32_t* wpraw = a.wpack;
-    asm volatile("" : "+s"(tabv), "+s"(wpraw)::"memory");
-    const h8* wp = reinterpret_cast<const h8*>(wpraw);
+    // The laundered values are typed as address-space-1 pointers: laundering a generic pointer hides that it is
+    // global, and every table / weight access then becomes a FLAT load (counts on lgkmcnt too, so it serialises
+    // with the LDS traffic, and cannot use the SGPR-base + lane-offset form).
+    typedef const __attribute__((address_space(1))) RnTables* GTabPtr;
+    typedef const __attribute__((address_space(1))) uint32_t* GWordPtr;
+    GTabPtr tabg = (GTabPtr)a.tab;
+    GWordPtr wpg = (GWordPtr)a.wpack;
+    asm volatile("" : "+s"(tabg), "+s"(wpg)::"memory");
+    const RnTables* tabv = (const RnTables*)tabg;
+    const uint32_t* wpraw = (const uint32_t*)wpg;
+    // buffer resource over the weight pack (f16 matrices first, f32 biases behind them)
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(wpraw), 0, RnPack::END * 4, 0x00020000);
     const RnTables* __restrict__ tab = tabv;
     const float2* __restrict__ w960 = tab->w960;
     const float* __restrict__ hw = tab->half_window;
@@ -967,15 +1069,15 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
       float* gin = Rb + RB_IN;
       if (lane < 24) {
         float acc = wpf[RnPack::ID_B + lane];
-        acc = dot_h<rn_k8(42)>(wp + RnPack::ID_W, 24, lane, feat, acc);
+        acc = dot_h<rn_k8(42), 24>(wrs, RnPack::ID_W, lane, feat, acc);
         dense[lane] = tansig_approx(S * acc, tansig);
       }
       __syncthreads();
-      gru_layer<24, 24>(wp + RnPack::VG_W, wp + RnPack::VG_R, wpf + RnPack::VG_B, dense,
+      gru_layer<24, 24>(wrs, RnPack::VG_W, RnPack::VG_R, wpf + RnPack::VG_B, dense,
                         L.rnn_state, Rb + RB_Z, Rb + RB_HR, tansig, lane);
       if (lane == 0) {
         float acc = wpf[RnPack::VO_B];
-        acc = dot_h<rn_k8(24)>(wp + RnPack::VO_W, 1, 0, L.rnn_state, acc);
+        acc = dot_h<rn_k8(24), 1>(wrs, RnPack::VO_W, 0, L.rnn_state, acc);
         L.U[U_VAD] = sigmoid_approx(S * acc, tansig);
       }
       for (int i = lane; i < 96; i += WAVE)
@@ -983,17 +1085,17 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
       __syncthreads();
       vad_prob = L.U[U_VAD];
       STAMP(10)
-      gru_layer<90, 48>(wp + RnPack::NG_W, wp + RnPack::NG_R, wpf + RnPack::NG_B, gin,
+      gru_layer<90, 48>(wrs, RnPack::NG_W, RnPack::NG_R, wpf + RnPack::NG_B, gin,
                         L.rnn_state + 24, Rb + RB_Z, Rb + RB_HR, tansig, lane);
       STAMP(11)
       for (int i = lane; i < 120; i += WAVE)
         gin[i] = i < 72 ? L.rnn_state[i] : (i < 114 ? feat[i - 72] : 0.f);
       __syncthreads();
-      gru_layer<114, 96>(wp + RnPack::DG_W, wp + RnPack::DG_R, wpf + RnPack::DG_B, gin,
+      gru_layer<114, 96>(wrs, RnPack::DG_W, RnPack::DG_R, wpf + RnPack::DG_B, gin,
                          L.rnn_state + 72, Rb + RB_Z, Rb + RB_HR, tansig, lane);
       if (lane < RN_NB) {
         float acc = wpf[RnPack::DO_B + lane];
-        acc = dot_h<rn_k8(96)>(wp + RnPack::DO_W, RN_NB, lane, L.rnn_state + 72, acc);
+        acc = dot_h<rn_k8(96), RN_NB>(wrs, RnPack::DO_W, lane, L.rnn_state + 72, acc);
         L.U[U_G + lane] = sigmoid_approx(S * acc, tansig);
       }
       __syncthreads();
@@ -1069,6 +1171,14 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
 
     // ---- 10. frame_synthesis: inverse FFT, window, overlap-add ----
     real_inv_pre(L.A, w960, lane);
+    if constexpr (MODE == 0) {
+      // issued ahead of the inverse FFT, consumed after it
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int n = lane + WAVE * m;
+        synth[m] = n < 240 ? *reinterpret_cast<const float2*>(synth_g + 2 * n) : make_float2(0.f, 0.f);
+      }
+    }
     fft480(L.A, w960, lane);
     STAMP(14)
     {
@@ -1086,6 +1196,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
           if (t >= t_out) *reinterpret_cast<float2*>(o + i0) = ov;
           synth[m].x = z2.x * hw[479 - i0];
           synth[m].y = -z2.y * hw[479 - i1];
+          if constexpr (MODE == 0) *reinterpret_cast<float2*>(synth_g + i0) = synth[m];
         }
       }
     }
@@ -1100,11 +1211,11 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
   }
 #endif
   // ---- store per-stream state (each kernel of the staged pipeline owns its part) ----
-  if (MODE == 0 || (MODE == 2 && t_last == a.T)) {
+  if (MODE == 2 && t_last == a.T) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int n = lane + WAVE * m;
-      if (n < 240) *reinterpret_cast<float2*>(a.synth + (long)b * 480 + 2 * n) = synth[m];
+      if (n < 240) *reinterpret_cast<float2*>(synth_g + 2 * n) = synth[m];
     }
   }
   if constexpr (MODE != 2) {
