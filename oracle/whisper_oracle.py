@@ -113,3 +113,212 @@ def greedy_decode(weights, hp, enc_out, prompt, n_new, suppress=None, eot=50257)
         if t == eot:
             break
     return picks, best, margin
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Timestamp-mode decoding (whisper.cpp `whisper_full` with `no_timestamps = false`, its default) -- the path
+# that produces `segments` for managers/transcription.rs:223-233.
+#
+# Two rule flavours:
+#   RULES_OPENAI   openai-whisper `ApplyTimestampRules` as carried by HuggingFace's
+#                  `WhisperTimeStampLogitsProcessor`; PINNED by tests/golden/whisper_tiny_golden.npz (ts_*).
+#   RULES_WCPP     whisper.cpp `whisper_process_logits` [UPSTREAM-RECALL, source not vendored]: no forced
+#                  initial timestamp, timestamps may repeat the last one (`< last` suppressed instead of
+#                  `<= last` after a closed pair), monotonicity only once a token > <|0.00|> was sampled.
+# Common to both: <|notimestamps|> suppressed, timestamps come in pairs except before EOT, the first
+# timestamp is at most `max_initial_ts` (1.0 s = index 50), and a timestamp is forced when the probability
+# mass of all timestamps exceeds the most probable text token.
+# ---------------------------------------------------------------------------------------------------------
+RULES_WCPP = 0
+RULES_OPENAI = 1
+
+
+class DecoderCache:
+    """KV-cached incremental decoder (float64); `step(token)` returns the logits of the new position.
+    Same arithmetic as `decoder_logits`, restated so that 200-token windows finish in seconds."""
+
+    def __init__(self, weights, hp, enc_out):
+        self.W = _f64(weights)
+        self.hp = hp
+        enc = enc_out.astype(np.float64)
+        self.xk, self.xv, self.k, self.v = [], [], [], []
+        for i in range(hp.n_text_layer):
+            p = f"decoder.blocks.{i}.cross_attn"
+            self.xk.append(enc @ self.W[p + ".key.weight"].T)
+            self.xv.append(enc @ self.W[p + ".value.weight"].T + self.W[p + ".value.bias"])
+            self.k.append(np.zeros((0, hp.n_text_state)))
+            self.v.append(np.zeros((0, hp.n_text_state)))
+        self.pos = 0
+
+    def _att(self, q, k, v):
+        H = self.hp.n_text_head
+        dh = q.shape[-1] // H
+        out = np.empty_like(q)
+        for h in range(H):
+            sl = slice(h * dh, (h + 1) * dh)
+            s = (k[:, sl] @ q[sl]) / np.sqrt(dh)
+            s = np.exp(s - s.max())
+            out[sl] = (s / s.sum()) @ v[:, sl]
+        return out
+
+    def step(self, token):
+        W = self.W
+        x = W["decoder.token_embedding.weight"][int(token)] + W["decoder.positional_embedding"][self.pos]
+        for i in range(self.hp.n_text_layer):
+            p = f"decoder.blocks.{i}"
+            xn = _ln(x, W[p + ".attn_ln.weight"], W[p + ".attn_ln.bias"])
+            q = xn @ W[p + ".attn.query.weight"].T + W[p + ".attn.query.bias"]
+            self.k[i] = np.vstack([self.k[i], xn @ W[p + ".attn.key.weight"].T])
+            self.v[i] = np.vstack([self.v[i], xn @ W[p + ".attn.value.weight"].T + W[p + ".attn.value.bias"]])
+            x = x + self._att(q, self.k[i], self.v[i]) @ W[p + ".attn.out.weight"].T + W[p + ".attn.out.bias"]
+            xn = _ln(x, W[p + ".cross_attn_ln.weight"], W[p + ".cross_attn_ln.bias"])
+            q = xn @ W[p + ".cross_attn.query.weight"].T + W[p + ".cross_attn.query.bias"]
+            x = x + self._att(q, self.xk[i], self.xv[i]) @ W[p + ".cross_attn.out.weight"].T + W[p + ".cross_attn.out.bias"]
+            xn = _ln(x, W[p + ".mlp_ln.weight"], W[p + ".mlp_ln.bias"])
+            x = x + _gelu(xn @ W[p + ".mlp.0.weight"].T + W[p + ".mlp.0.bias"]) @ W[p + ".mlp.2.weight"].T + W[p + ".mlp.2.bias"]
+        self.pos += 1
+        x = _ln(x, W["decoder.ln.weight"], W["decoder.ln.bias"])
+        return x @ W["decoder.token_embedding.weight"].T
+
+
+def special_tokens(n_vocab, eot=50257):
+    """whisper.cpp vocabulary layout [UPSTREAM-RECALL]: sot = eot+1, 99 (+extra) languages, translate,
+    transcribe, solm, prev, nosp, notimestamps, then the 1501 timestamps <|0.00|> ... <|30.00|>."""
+    multilingual = n_vocab >= 51865
+    extra = n_vocab - 51865 if multilingual else 0
+    sot = eot + 1
+    if multilingual:
+        d = dict(sot=sot, lang0=sot + 1, n_lang=99 + extra, translate=sot + 100 + extra, transcribe=sot + 101 + extra,
+                 solm=sot + 102 + extra, prev=sot + 103 + extra, nosp=sot + 104 + extra, not_=sot + 105 + extra)
+    else:   # English-only files have no language / task tokens
+        d = dict(sot=sot, lang0=sot + 1, n_lang=0, translate=sot + 1, transcribe=sot + 2, solm=sot + 3, prev=sot + 4,
+                 nosp=sot + 5, not_=sot + 6)
+    d["beg"] = d["not_"] + 1
+    d["eot"] = eot
+    return d
+
+
+def timestamp_rules(lg, seq, sp, rules, suppress=None, suppress_first=None, max_initial_ts=50):
+    """Masked copy of the logits `lg` for the next pick, given the tokens `seq` sampled so far in this window.
+    Returns (masked logits, index of the most probable timestamp token)."""
+    lg = np.array(lg, dtype=np.float64)
+    beg, eot = sp["beg"], sp["eot"]
+    if suppress is not None and len(suppress):
+        lg[np.asarray(suppress, dtype=np.int64)] = -np.inf
+    if len(seq) == 0 and suppress_first is not None and len(suppress_first):
+        lg[np.asarray(suppress_first, dtype=np.int64)] = -np.inf
+    lg[sp["not_"]] = -np.inf
+    last_ts = len(seq) >= 1 and seq[-1] >= beg
+    pen_ts = len(seq) < 2 or seq[-2] >= beg
+    if last_ts:
+        if pen_ts:
+            lg[beg:] = -np.inf
+        else:
+            lg[:eot] = -np.inf
+    if rules == RULES_OPENAI:
+        ts = [t for t in seq if t >= beg]
+        if ts:
+            last = ts[-1] if (last_ts and not pen_ts) else ts[-1] + 1
+            lg[beg:last] = -np.inf
+        if len(seq) == 0:
+            lg[:beg] = -np.inf
+            if max_initial_ts is not None:
+                lg[beg + max_initial_ts + 1:] = -np.inf
+    else:
+        if len(seq) == 0 and max_initial_ts is not None and max_initial_ts > 0:
+            lg[beg + max_initial_ts + 1:] = -np.inf
+        ts = [t for t in seq if t > beg]          # whisper.cpp: has_ts / seek_delta only move on tokens > <|0.00|>
+        if ts:
+            lg[beg:ts[-1]] = -np.inf
+    tsl = lg[beg:]
+    tid = beg + int(np.argmax(tsl)) if np.isfinite(tsl.max()) else beg
+    m = tsl.max()
+    lse_ts = m + np.log(np.exp(tsl - m).sum()) if np.isfinite(m) else -np.inf
+    if lse_ts > lg[:beg].max():
+        lg[:beg] = -np.inf
+    return lg, tid
+
+
+def decode_window(step_logits, prompt, sp, rules, n_max, seek, seek_end, suppress=None, suppress_first=None,
+                  max_initial_ts=50):
+    """One whisper_full window [UPSTREAM-RECALL]: greedy picks under the timestamp rules until EOT, n_max tokens
+    or a timestamp within 1 s of the end of the audio.  `step_logits(token)` feeds one token and returns the next
+    logits.  Returns dict(tokens, tids, result_len, seek_delta, margins)."""
+    lg = None
+    for t in prompt:
+        lg = step_logits(t)
+    beg, eot = sp["beg"], sp["eot"]
+    toks, tids, margins = [], [], []
+    has_ts, seek_delta, result_len = False, 3000, 0
+    for i in range(n_max):
+        ml, tid = timestamp_rules(lg, toks, sp, rules, suppress, suppress_first, max_initial_ts)
+        t = int(np.argmax(ml))
+        top2 = np.partition(ml, -2)[-2:]
+        margins.append(float(top2[1] - top2[0]))
+        toks.append(t)
+        tids.append(tid if t < beg else t)
+        if t > beg:
+            seek_delta = 2 * (t - beg)
+            result_len = i + 1
+            has_ts = True
+        if t == eot or (has_ts and seek + seek_delta + 100 >= seek_end):
+            if t == eot and result_len == 0:
+                result_len = i + 1            # no temperature fallback here: keep what was decoded
+            break
+        lg = step_logits(t)
+    else:
+        if result_len == 0:
+            result_len = len(toks)
+    return dict(tokens=toks, tids=tids, result_len=result_len, seek_delta=seek_delta, margins=margins)
+
+
+def window_segments(win, seek, sp, token_text):
+    """Segments of one window as whisper_full builds them [UPSTREAM-RECALL]: text between timestamp tokens,
+    t0 / t1 in centiseconds (mel frames) relative to the clip."""
+    beg, eot = sp["beg"], sp["eot"]
+    toks = win["tokens"][:win["result_len"]]
+    tids = win["tids"][:win["result_len"]]
+    segs = []
+    if not toks:
+        return segs
+    t0 = seek + 2 * (tids[0] - beg)
+    text = b""
+    i = 0
+    while i < len(toks):
+        if toks[i] < eot:
+            text += token_text(toks[i])
+        if toks[i] > beg:
+            t1 = seek + 2 * (tids[i] - beg)
+            if text:
+                segs.append((t0, t1, text))
+            text = b""
+            while i < len(toks) and toks[i] > beg:
+                i += 1
+            i -= 1
+            t0 = t1
+        i += 1
+    if text:
+        segs.append((t0, seek + win["seek_delta"], text))
+    return segs
+
+
+def transcribe_timestamps(weights, hp, mel_window, n_samples, prompt, rules, token_text, n_max=None,
+                          suppress=None, suppress_first=None, eot=50257, max_windows=8):
+    """whisper_full's seek loop over one clip (<= 30 s): `mel_window(seek)` returns the [n_mels, 3000] log-mel
+    window starting at mel frame `seek`.  Returns (segments, all kept tokens, windows)."""
+    sp = special_tokens(hp.n_vocab, eot)
+    n_max = hp.n_text_ctx // 2 - 4 if n_max is None else n_max
+    seek, seek_end = 0, n_samples // 160
+    segs, kept, wins = [], [], []
+    if seek_end < 100:                         # whisper.cpp: "input is too short" -> nothing
+        return segs, kept, wins
+    while seek + 100 < seek_end and len(wins) < max_windows:
+        enc = encoder_forward(weights, hp, mel_window(seek))
+        dc = DecoderCache(weights, hp, enc)
+        win = decode_window(dc.step, prompt, sp, rules, n_max, seek, seek_end, suppress, suppress_first)
+        win["seek"] = seek
+        wins.append(win)
+        segs += window_segments(win, seek, sp, token_text)
+        kept += win["tokens"][:win["result_len"]]
+        seek += win["seek_delta"]
+    return segs, kept, wins

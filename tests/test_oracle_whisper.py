@@ -64,3 +64,65 @@ def test_causal_mask_prefix_invariance(tiny, enc_out):
     a = WO.decoder_logits(W, hp, enc_out, [50258, 50259, 50359, 50363, 11, 22])
     b = WO.decoder_logits(W, hp, enc_out, [50258, 50259, 50359, 50363, 99, 77])
     assert np.abs(a[:4] - b[:4]).max() < 1e-10 and np.abs(a[4] - b[4]).max() > 1e-3
+
+
+TS_GOLD = os.path.join(os.path.dirname(__file__), "golden", "whisper_tiny_ts_golden.npz")
+
+
+def test_cached_decoder_equals_full_decoder(tiny, enc_out):
+    from oracle import whisper_oracle as WO
+    hp, W = tiny
+    toks = [50258, 50259, 50359, 100, 200, 300]
+    ref = WO.decoder_logits(W, hp, enc_out, toks)
+    dc = WO.DecoderCache(W, hp, enc_out)
+    for i, t in enumerate(toks):
+        assert np.abs(dc.step(t) - ref[i]).max() < 1e-10
+
+
+def test_timestamp_rules_match_hf_processor_golden(tiny, enc_out):
+    """RULES_OPENAI of the oracle reproduces, token for token, greedy decoding through HuggingFace's
+    WhisperTimeStampLogitsProcessor (tests/golden/make_whisper_ts_golden.py) -- 40 picks incl. the forced first
+    timestamp, pairs, monotonic timestamps and the probability-mass rule."""
+    from oracle import whisper_oracle as WO
+    hp, W = tiny
+    G = np.load(TS_GOLD)
+    sp = WO.special_tokens(hp.n_vocab)
+    assert (sp["not_"], sp["beg"], sp["transcribe"]) == (50363, 50364, 50359)
+    dc = WO.DecoderCache(W, hp, enc_out)                     # enc_out is clip16k_np(0, 464000), golden clip 0
+    win = WO.decode_window(dc.step, G["prompt"].tolist(), sp, WO.RULES_OPENAI, 40, 0, 10 ** 9,
+                           G["suppress"], G["suppress_first"])
+    assert win["tokens"] == G["c0_tokens"].tolist()
+    assert np.allclose(win["margins"], G["c0_margins"], atol=2e-3)
+
+
+def test_timestamp_rule_flavours_and_segments(tiny):
+    from oracle import whisper_oracle as WO
+    hp, _ = tiny
+    sp = WO.special_tokens(hp.n_vocab)
+    beg, eot = sp["beg"], sp["eot"]
+    rng = np.random.default_rng(3)
+    lg = rng.standard_normal(hp.n_vocab)
+    # first pick: OPENAI forces a timestamp <= 1.00 s; whisper.cpp only caps timestamps at 1.00 s
+    m, _ = WO.timestamp_rules(lg, [], sp, WO.RULES_OPENAI)
+    assert np.isneginf(m[:beg]).all() and np.isneginf(m[beg + 51:]).all() and np.isfinite(m[beg:beg + 51]).all()
+    lg2 = lg.copy(); lg2[100] = 50.0                       # one dominant text token
+    m, _ = WO.timestamp_rules(lg2, [], sp, WO.RULES_WCPP)
+    assert int(np.argmax(m)) == 100 and np.isneginf(m[beg + 51:]).all()
+    # after a lone timestamp: text only; after text + timestamp: timestamp or EOT only
+    m, _ = WO.timestamp_rules(lg, [beg + 10], sp, WO.RULES_WCPP)
+    assert np.isneginf(m[beg:]).all()
+    lg3 = lg.copy(); lg3[eot] = 50.0                      # EOT dominant, so the mass rule does not remove it
+    m, _ = WO.timestamp_rules(lg3, [beg + 10, 7, beg + 20], sp, WO.RULES_WCPP)
+    assert np.isneginf(m[:eot]).all() and np.isfinite(m[eot])
+    assert np.isneginf(m[beg:beg + 20]).all() and np.isfinite(m[beg + 20])          # may repeat the last one
+    m, _ = WO.timestamp_rules(lg, [beg + 10, 7, beg + 20, beg + 20], sp, WO.RULES_OPENAI)
+    assert np.isneginf(m[beg:beg + 21]).all()                                         # closed pair: strictly later
+    m, _ = WO.timestamp_rules(lg, [beg + 10, 7, beg + 20, beg + 20], sp, WO.RULES_WCPP)
+    assert np.isneginf(m[beg:beg + 20]).all()
+    # segments: "<|0.20|> a b <|1.00|><|1.00|> c <|2.50|>" then an open tail "d" that result_len drops
+    text = lambda t: b" w%d" % t
+    win = dict(tokens=[beg + 10, 1, 2, beg + 50, beg + 50, 3, beg + 125, 4, eot], result_len=7, seek_delta=250,
+               tids=[beg + 10, beg, beg, beg + 50, beg + 50, beg, beg + 125, beg, beg])
+    assert WO.window_segments(win, 1000, sp, text) == [(1020, 1100, b" w1 w2"), (1100, 1250, b" w3")]
+    win = dict(tokens=[5, 6, eot], tids=[beg + 3, beg, beg], result_len=3, seek_delta=3000)
+    assert WO.window_segments(win, 0, sp, text) == [(6, 3000, b" w5 w6")]
