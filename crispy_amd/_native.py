@@ -30,16 +30,33 @@ RN_SYMBOLS = (
 
 
 MEL_SYMBOLS = ("crispy_mel_create", "crispy_mel_destroy", "crispy_mel_compute",
-               "crispy_mel_compute_device", "crispy_mel_synchronize")
+               "crispy_mel_compute_device", "crispy_mel_window_device", "crispy_mel_synchronize")
 ASR_SYMBOLS = ("crispy_asr_create", "crispy_asr_set_tensor", "crispy_asr_finalize", "crispy_asr_free",
                "crispy_asr_hparams_get", "crispy_asr_encode", "crispy_asr_encode_device", "crispy_asr_synchronize",
                "crispy_asr_set_suppress", "crispy_asr_decode_greedy_device", "crispy_asr_transcribe_tokens",
                "crispy_asr_load", "crispy_asr_token_text", "crispy_asr_transcribe", "crispy_asr_free_result",
                "crispy_asr_decode_greedy_lang_device", "crispy_asr_detect_language_device",
-               "crispy_asr_transcribe_batch")
+               "crispy_asr_transcribe_batch", "crispy_asr_decode_timestamps_device")
 RS_SYMBOLS = ("crispy_resampler_create", "crispy_resampler_destroy", "crispy_resampler_out_len",
               "crispy_resampler_process_device", "crispy_resampler_synchronize")
 ALL_SYMBOLS = RN_SYMBOLS + MEL_SYMBOLS + ASR_SYMBOLS + RS_SYMBOLS
+
+class AsrOpts(C.Structure):
+    """crispy_asr_opts"""
+    _fields_ = [("language_token", C.c_int), ("translate", C.c_int), ("max_new_tokens", C.c_int),
+                ("no_timestamps", C.c_int)]
+
+
+class AsrSegment(C.Structure):
+    """crispy_asr_segment"""
+    _fields_ = [("t0", C.c_float), ("t1", C.c_float), ("text", C.c_char_p)]
+
+
+class AsrResult(C.Structure):
+    """crispy_asr_result"""
+    _fields_ = [("text", C.c_char_p), ("tokens", C.POINTER(C.c_int)), ("n_tokens", C.c_int),
+                ("language_token", C.c_int), ("n_segments", C.c_int), ("segments", C.POINTER(AsrSegment))]
+
 
 class CrispyError(RuntimeError):
     def __init__(self, code: int, msg: str):
@@ -112,6 +129,10 @@ def lib() -> C.CDLL:
     L.crispy_asr_transcribe_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.crispy_asr_free_result.argtypes = [C.c_void_p]
     L.crispy_asr_free_result.restype = None
+    L.crispy_asr_decode_timestamps_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                                      C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                      C.c_void_p]
+    L.crispy_mel_window_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.crispy_asr_decode_greedy_lang_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                                        C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.crispy_asr_detect_language_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]

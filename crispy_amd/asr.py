@@ -62,6 +62,13 @@ class LogMel:
         N.check(N.lib().crispy_mel_compute_device(self._h, d_pcm, pcm_stride, lens.ctypes.data, lens.size,
                                                   d_out or None, d_out_t or None, stream or None))
 
+    def window_device(self, clip_idx, seek, d_out: int = 0, d_out_t: int = 0, stream: int = 0):
+        """Later 30 s windows (whisper_full's seek loop) of the clips of the last compute_device call."""
+        ci = np.ascontiguousarray(clip_idx, dtype=np.int32)
+        sk = np.ascontiguousarray(seek, dtype=np.int32)
+        N.check(N.lib().crispy_mel_window_device(self._h, ci.ctypes.data, sk.ctypes.data, ci.size, d_out or None,
+                                                 d_out_t or None, stream or None))
+
     def synchronize(self):
         N.check(N.lib().crispy_mel_synchronize(self._h))
 
@@ -158,6 +165,22 @@ class WhisperModel:
                                                              lt.ctypes.data, max_new, toks.ctypes.data, n.ctypes.data, None))
         return toks, n
 
+    def decode_timestamps_device(self, d_enc: int, batch: int, prompt, max_new: int, rules: int = 0, lang_tokens=None,
+                                 seek=None, seek_end=None):
+        """One decoding window per clip under the timestamp rules (rules 0 = whisper.cpp, 1 = openai / HF flavour)
+        -> (tokens [B, max_new], most probable timestamp token per step [B, max_new], picks per clip [B])."""
+        p = np.ascontiguousarray(prompt, dtype=np.int32)
+        opt = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+        lt, sk, se = opt(lang_tokens), opt(seek), opt(seek_end)
+        ptr = lambda a: None if a is None else a.ctypes.data
+        toks = np.empty((batch, max_new), dtype=np.int32)
+        tids = np.empty((batch, max_new), dtype=np.int32)
+        n = np.empty(batch, dtype=np.int32)
+        N.check(N.lib().crispy_asr_decode_timestamps_device(self._h, d_enc, batch, p.ctypes.data, p.size, ptr(lt), int(rules),
+                                                            ptr(sk), ptr(se), max_new, toks.ctypes.data, tids.ctypes.data,
+                                                            n.ctypes.data))
+        return toks, tids, n
+
     def transcribe_tokens(self, clips, prompt, max_new: int):
         """`SpeechModel::transcribe` up to token ids for a batch of <= 30 s clips."""
         if len(clips) == 0:
@@ -190,47 +213,55 @@ class WhisperEngine(WhisperModel):
         N.check(N.lib().crispy_asr_token_text(self._h, int(token), C.byref(p), C.byref(n)))
         return C.string_at(p, n.value)
 
-    def transcribe(self, audio: np.ndarray, max_new_tokens: int = 0, translate: bool = False, language_token: int = 0):
+    def transcribe(self, audio: np.ndarray, max_new_tokens: int = 0, translate: bool = False, language_token: int = 0,
+                   timestamps: bool = False):
         """One chunk (<= 480000 samples at 16 kHz) -> (text, token ids); empty audio -> ("", []).
-        language_token = 0 auto-detects, as `TranscribeOptions::default()` does."""
+        language_token = 0 auto-detects, as `TranscribeOptions::default()` does.  timestamps = True is whisper.cpp's
+        default decoding mode (timestamp tokens, seek loop); its segments are kept in `self.last_segments` as
+        (t0 seconds, t1 seconds, text)."""
         a = np.ascontiguousarray(audio, dtype=np.float32).ravel()
-        opts = (C.c_int * 3)(int(language_token), int(translate), int(max_new_tokens))
+        opts = N.AsrOpts(int(language_token), int(translate), int(max_new_tokens), 0 if timestamps else 1)
         res = C.c_void_p()
-        N.check(N.lib().crispy_asr_transcribe(self._h, a.ctypes.data if a.size else None, a.size, opts, C.byref(res)))
+        N.check(N.lib().crispy_asr_transcribe(self._h, a.ctypes.data if a.size else None, a.size, C.byref(opts),
+                                              C.byref(res)))
         try:
-            text_p = C.cast(res, C.POINTER(C.c_char_p))[0]
-            tok_p = C.cast(res.value + 8, C.POINTER(C.POINTER(C.c_int)))[0]
-            n_tok = C.cast(res.value + 16, C.POINTER(C.c_int))[0]
-            self.last_language_token = int(C.cast(res.value + 20, C.POINTER(C.c_int))[0])
-            text = text_p.decode("utf-8", "replace") if text_p else ""
-            tokens = [int(tok_p[i]) for i in range(n_tok)]
+            text, tokens, self.last_language_token, self.last_segments = _read_result(res)
         finally:
             N.lib().crispy_asr_free_result(res)
         return text, tokens
 
+    def transcribe_segments(self, audio: np.ndarray, max_new_tokens: int = 0, language_token: int = 0):
+        """`engine.transcribe(..)` with whisper.cpp's default options -> (text, [(t0, t1, text)], token ids)."""
+        text, tokens = self.transcribe(audio, max_new_tokens, False, language_token, timestamps=True)
+        return text, self.last_segments, tokens
+
 
 def _read_result(res) -> tuple:
-    text_p = C.cast(res, C.POINTER(C.c_char_p))[0]
-    tok_p = C.cast(res.value + 8, C.POINTER(C.POINTER(C.c_int)))[0]
-    n_tok = C.cast(res.value + 16, C.POINTER(C.c_int))[0]
-    lang = int(C.cast(res.value + 20, C.POINTER(C.c_int))[0])
-    return (text_p.decode("utf-8", "replace") if text_p else "", [int(tok_p[i]) for i in range(n_tok)], lang)
+    r = C.cast(res, C.POINTER(N.AsrResult)).contents
+    text = r.text.decode("utf-8", "replace") if r.text else ""
+    tokens = [int(r.tokens[i]) for i in range(r.n_tokens)]
+    segs = [(float(r.segments[i].t0), float(r.segments[i].t1), (r.segments[i].text or b"").decode("utf-8", "replace"))
+            for i in range(r.n_segments)]
+    return text, tokens, int(r.language_token), segs
 
 
-def transcribe_batch(engine: "WhisperEngine", clips, max_new_tokens: int = 0, language_token: int = 0):
-    """`crispy_asr_transcribe_batch`: a list of chunks (each <= 30 s, empty allowed) -> [(text, tokens, language)]."""
+def transcribe_batch(engine: "WhisperEngine", clips, max_new_tokens: int = 0, language_token: int = 0,
+                     timestamps: bool = False, with_segments: bool = False):
+    """`crispy_asr_transcribe_batch`: a list of chunks (each <= 30 s, empty allowed) -> [(text, tokens, language)]
+    (+ segments with with_segments)."""
     arrs = [np.ascontiguousarray(c, dtype=np.float32).ravel() for c in clips]
     nb = len(arrs)
     ptrs = (C.c_void_p * max(nb, 1))(*[a.ctypes.data if a.size else None for a in arrs])
     lens = (C.c_size_t * max(nb, 1))(*[a.size for a in arrs])
     res = (C.c_void_p * max(nb, 1))()
-    opts = (C.c_int * 3)(int(language_token), 0, int(max_new_tokens))
-    N.check(N.lib().crispy_asr_transcribe_batch(engine._h, ptrs, lens, nb, opts, res))
+    opts = N.AsrOpts(int(language_token), 0, int(max_new_tokens), 0 if timestamps else 1)
+    N.check(N.lib().crispy_asr_transcribe_batch(engine._h, ptrs, lens, nb, C.byref(opts), res))
     out = []
     for i in range(nb):
         r = C.c_void_p(res[i])
         try:
-            out.append(_read_result(r))
+            full = _read_result(r)
+            out.append(full if with_segments else full[:3])
         finally:
             N.lib().crispy_asr_free_result(r)
     return out
@@ -250,15 +281,19 @@ def transcribe_recording(engine: "WhisperEngine", pcm16k: np.ndarray, max_new_to
 
 
 def transcribe_with_timestamps(engine: "WhisperEngine", audio: np.ndarray, chunk_offset_seconds: float,
-                               max_new_tokens: int = 0):
-    """`TranscriptionManager::transcribe_with_timestamps` (managers/transcription.rs:200-249) for an engine that
-    returns no segments: empty audio or empty trimmed text -> []; otherwise one segment spanning the chunk,
-    (offset, offset + len/16000, trimmed text)."""
+                               max_new_tokens: int = 0, use_segments: bool = False):
+    """`TranscriptionManager::transcribe_with_timestamps` (managers/transcription.rs:200-249): empty audio or empty
+    trimmed text -> []; with segments from the engine (use_segments, :223-240) every non-blank segment shifted by
+    the chunk offset, text untrimmed; otherwise (:242-248, what the reference reports for Whisper) one segment
+    spanning the chunk, (offset, offset + len/16000, trimmed text)."""
     a = np.ascontiguousarray(audio, dtype=np.float32).ravel()
     if a.size == 0:
         return []
-    text, _ = engine.transcribe(a, max_new_tokens)
+    text, _ = engine.transcribe(a, max_new_tokens, timestamps=use_segments)
     text = text.strip()
     if not text:
         return []
+    if use_segments and engine.last_segments:
+        return [(float(chunk_offset_seconds) + t0, float(chunk_offset_seconds) + t1, st)
+                for t0, t1, st in engine.last_segments if st.strip()]
     return [(float(chunk_offset_seconds), float(chunk_offset_seconds) + a.size / 16000.0, text)]

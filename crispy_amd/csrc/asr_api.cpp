@@ -23,19 +23,23 @@ struct crispy_mel {
   float* d_raw = nullptr;
   int* d_max = nullptr;
   float* d_out = nullptr;
+  int* d_idx = nullptr;     // [2][cap_batch]: clip index | seek of a window call
+  int last_batch = 0;       // clips whose raw frames d_raw / d_max currently hold
 };
 
 namespace {
 
 int mel_reserve(crispy_mel* h, int batch, long stride, bool need_pcm, bool need_out) {
   if (batch > h->cap_batch) {
-    for (void* p : {(void*)h->d_n, (void*)h->d_raw, (void*)h->d_max, (void*)h->d_out})
+    for (void* p : {(void*)h->d_n, (void*)h->d_raw, (void*)h->d_max, (void*)h->d_out, (void*)h->d_idx})
       if (p) (void)hipFree(p);
-    h->d_n = nullptr; h->d_raw = nullptr; h->d_max = nullptr; h->d_out = nullptr;
+    h->d_n = nullptr; h->d_raw = nullptr; h->d_max = nullptr; h->d_out = nullptr; h->d_idx = nullptr;
+    h->last_batch = 0;
     if (h->d_pcm) { (void)hipFree(h->d_pcm); h->d_pcm = nullptr; h->cap_stride = 0; }
     h->cap_batch = 0;
-    const size_t elems = (size_t)batch * h->n_mel * MEL_FRAMES;
+    const size_t elems = (size_t)batch * h->n_mel * MEL_RAW_FRAMES;
     HIP_TRY(hipMalloc(&h->d_n, sizeof(int) * batch));
+    HIP_TRY(hipMalloc(&h->d_idx, sizeof(int) * 2 * batch));
     HIP_TRY(hipMalloc(&h->d_max, sizeof(int) * batch));
     HIP_TRY(hipMalloc(&h->d_raw, sizeof(float) * elems));
     h->cap_batch = batch;
@@ -118,7 +122,7 @@ void crispy_mel_destroy(crispy_mel* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (void* p : {(void*)h->d_tab, (void*)h->d_pcm, (void*)h->d_n, (void*)h->d_raw, (void*)h->d_max, (void*)h->d_out})
+  for (void* p : {(void*)h->d_tab, (void*)h->d_pcm, (void*)h->d_n, (void*)h->d_raw, (void*)h->d_max, (void*)h->d_out, (void*)h->d_idx})
     if (p) (void)hipFree(p);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -149,6 +153,7 @@ int crispy_mel_compute_device(crispy_mel* h, const float* d_pcm, long pcm_stride
   a.out = d_out;
   a.out_t = d_out_t;
   HIP_TRY(mel_launch(a, batch, s));
+  h->last_batch = batch;
   return CRISPY_OK;
 }
 
@@ -169,6 +174,35 @@ int crispy_mel_compute(crispy_mel* h, const float* pcm, long pcm_stride, const i
   HIP_TRY(hipMemcpyAsync(out, h->d_out, sizeof(float) * (size_t)batch * h->n_mel * MEL_FRAMES, hipMemcpyDeviceToHost,
                          h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  return CRISPY_OK;
+}
+
+int crispy_mel_window_device(crispy_mel* h, const int* clip_idx, const int* seek, int n, float* d_out,
+                             float* d_out_t, void* hip_stream) {
+  if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_mel_window_device: NULL handle");
+  if (n < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_mel_window_device: n < 0");
+  if (n == 0) return CRISPY_OK;
+  if (!clip_idx || !seek || (!d_out && !d_out_t)) return fail(CRISPY_ERR_INVALID_ARG, "crispy_mel_window_device: NULL argument");
+  if (n > h->cap_batch || h->last_batch == 0)
+    return fail(CRISPY_ERR_INVALID_ARG, "crispy_mel_window_device: %d windows, but the last crispy_mel_compute_device call held %d clips",
+                n, h->last_batch);
+  for (int k = 0; k < n; ++k)
+    if (clip_idx[k] < 0 || clip_idx[k] >= h->last_batch || seek[k] < 0 || seek[k] > MEL_FRAMES)
+      return fail(CRISPY_ERR_INVALID_ARG, "crispy_mel_window_device: window %d = (clip %d, seek %d) out of range", k, clip_idx[k], seek[k]);
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
+  HIP_TRY(hipMemcpyAsync(h->d_idx, clip_idx, sizeof(int) * n, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->d_idx + h->cap_batch, seek, sizeof(int) * n, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));     // the host arrays may be reused by the caller
+  MelArgs a{};
+  a.n_mel = h->n_mel;
+  a.raw = h->d_raw;
+  a.clip_max = h->d_max;
+  a.out = d_out;
+  a.out_t = d_out_t;
+  a.clip_idx = h->d_idx;
+  a.seek = h->d_idx + h->cap_batch;
+  HIP_TRY(mel_window_launch(a, n, s));
   return CRISPY_OK;
 }
 

@@ -8,6 +8,7 @@ namespace crispy {
 constexpr int MEL_FRAMES = 3000;   // frames the encoder consumes (30 s)
 constexpr int MEL_TILE = 64;
 constexpr int MEL_TILES = 47;      // 3008 frames computed: the clip maximum also sees the tail frames
+constexpr int MEL_RAW_FRAMES = MEL_TILE * MEL_TILES;   // all of them are kept: later windows (seek > 0) read frames >= 3000
 constexpr int MEL_BINS = 201;
 constexpr int MEL_MAX_MELS = 128;
 
@@ -24,13 +25,18 @@ struct MelArgs {
   const int* n_samples;    // [batch] (device)
   int n_mel;
   const MelTables* tab;
-  float* raw;              // [batch][n_mel][3000] log10 values before normalisation
+  float* raw;              // [batch][n_mel][3008] log10 values before normalisation
   int* clip_max;           // [batch] order-preserving int key of the clip maximum
   float* out;              // [batch][n_mel][3000] or null
   float* out_t;            // [batch][3002][n_mel] zero padded frame-major copy or null
+  // window mode (mel_window_launch): output k is clip clip_idx[k] starting at mel frame seek[k]; frames past the
+  // computed range are pure zero padding (log10 floor), the normalisation uses the clip-wide maximum
+  const int* clip_idx;
+  const int* seek;
 };
 
 hipError_t mel_launch(const MelArgs& a, int batch, hipStream_t s);
+hipError_t mel_window_launch(const MelArgs& a, int n, hipStream_t s);
 
 // C[M,N] = A[M,K] . W[N,K]^T (+bias) (GELU) (+residual) (+rowtab[m % period]); all f32, row-major.
 // A may be a strided view (lda < K): rows overlap, which is how the two convolutions are expressed.
@@ -61,6 +67,31 @@ constexpr int RS_N = 684;    // 342 outputs + 342 of overlap per block
 hipError_t rs_prep(const float* in, long in_stride, long n_in, float scale, int wav_s16, float* A, int batch,
                    int n_blk, hipStream_t s);
 hipError_t rs_ola(const float* Y, float* out, long out_stride, int batch, int n_blk, hipStream_t s);
+
+// Greedy pick under the timestamp rules (whisper.cpp whisper_process_logits / openai ApplyTimestampRules; the
+// semantics are restated in oracle/whisper_oracle.py: timestamp_rules).  One decoding window per clip.
+constexpr int TS_RULES_WCPP = 0, TS_RULES_OPENAI = 1;
+struct TsState {
+  int last, prev;      // the two most recent picks of this window (-1: none)
+  int n;               // picks so far
+  int last_ts;         // most recent timestamp token that moves the monotonic bound (-1: none)
+  int done;            // EOT sampled, or (whisper.cpp) a timestamp within 1 s of the end of the audio
+  int seek, seek_end;  // window start and audio length in mel frames
+  int pad;
+};
+struct TsPickArgs {
+  const float* logits;                 // [B][V]
+  const unsigned char* mask;           // [V] suppressed at every position (nullable)
+  const unsigned char* mask_first;     // [V] suppressed at the first position (union with mask; nullable)
+  TsState* st;                         // [B]
+  int V, beg, eot, not_tok, rules, max_initial_ts;
+  int* tokens_out;                     // [B] the pick (fed to the next decoder step)
+  int* tokens_all;                     // [steps][B]
+  int* tids_all;                       // [steps][B] most probable timestamp token at that step
+  const int* step_dev;
+  int* done_count;                     // number of clips that are done
+};
+hipError_t ts_pick(const TsPickArgs& a, int B, hipStream_t s);
 
 hipError_t argmax_f32(const float* logits, const unsigned char* mask, const unsigned char* mask_first,
                       const int* step_dev, int V, int* tokens_out, int* tokens_all, float* best, int B, hipStream_t s);

@@ -99,25 +99,26 @@ __global__ __launch_bounds__(256) void mel_frames_kernel(MelArgs a) {
   for (int idx = threadIdx.x; idx < a.n_mel * MEL_TILE; idx += 256) {
     const int m = idx >> 6, f = idx & 63;
     const int t = t0 + f;
-    if (t < MEL_FRAMES) a.raw[((long)b * a.n_mel + m) * MEL_FRAMES + t] = tile[m * 65 + f];
+    a.raw[((long)b * a.n_mel + m) * MEL_RAW_FRAMES + t] = tile[m * 65 + f];
   }
 }
 
 __global__ __launch_bounds__(256) void mel_finish_kernel(MelArgs a) {
-  const int b = blockIdx.y;
+  const int k = blockIdx.y;                        // output index
+  const int b = a.clip_idx ? a.clip_idx[k] : k;    // clip whose raw frames / maximum are used
+  const int seek = a.seek ? a.seek[k] : 0;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   const long total = (long)a.n_mel * MEL_FRAMES;
   if (idx >= total) return;
+  const int m = (int)(idx / MEL_FRAMES), t = (int)(idx % MEL_FRAMES);
   const double mmax = (double)float_from_key(a.clip_max[b]) - 8.0;
-  const long o = (long)b * total + idx;
-  double v = (double)a.raw[o];
+  const int src = seek + t;
+  // frames >= 3002 are zeros only (clips are <= 30 s): log10(1e-10)
+  double v = src < MEL_RAW_FRAMES ? (double)a.raw[((long)b * a.n_mel + m) * MEL_RAW_FRAMES + src] : -10.0;
   if (v < mmax) v = mmax;
   const float r = (float)((v + 4.0) / 4.0);
-  if (a.out) a.out[o] = r;
-  if (a.out_t) {
-    const int m = (int)(idx / MEL_FRAMES), t = (int)(idx % MEL_FRAMES);
-    a.out_t[((long)b * (MEL_FRAMES + 2) + t + 1) * a.n_mel + m] = r;
-  }
+  if (a.out) a.out[(long)k * total + idx] = r;
+  if (a.out_t) a.out_t[((long)k * (MEL_FRAMES + 2) + t + 1) * a.n_mel + m] = r;
 }
 
 }  // namespace
@@ -131,6 +132,12 @@ hipError_t mel_launch(const MelArgs& a, int batch, hipStream_t s) {
   if (e != hipSuccess) return e;
   const long total = (long)a.n_mel * MEL_FRAMES;
   hipLaunchKernelGGL(mel_finish_kernel, dim3((unsigned)((total + 255) / 256), batch), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t mel_window_launch(const MelArgs& a, int n, hipStream_t s) {
+  const long total = (long)a.n_mel * MEL_FRAMES;
+  hipLaunchKernelGGL(mel_finish_kernel, dim3((unsigned)((total + 255) / 256), n), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 

@@ -65,12 +65,23 @@ struct crispy_asr {
   int* d_counters = nullptr;                 // [0] position, [1] generation step (device-side, advanced in-graph)
   hipGraphExec_t dec_graph = nullptr;        // one captured decode step, replayed per generated token
   int dec_graph_batch = 0;
+  // timestamp-mode decoding (whisper.cpp no_timestamps = false)
+  TsState* d_ts_state = nullptr;             // [dcap_batch]
+  int* d_tids_all = nullptr;                 // [n_text_ctx][dcap_batch]
+  int* d_done_count = nullptr;
+  unsigned char* d_ts_mask = nullptr;        // [n_vocab] whisper.cpp's always-suppressed specials
+  unsigned char* d_ts_mask_first = nullptr;  // ... plus suppress_blank (" " and EOT) at the first position
+  hipGraphExec_t ts_graph = nullptr;
+  int ts_graph_batch = 0, ts_graph_rules = -1;
+  const unsigned char *ts_graph_mask = nullptr;
   int eot = 50257;
   std::vector<unsigned char> sup_all, sup_first;   // host copies of the two suppression lists
   std::vector<std::string> vocab;                  // token byte strings of a loaded model file
 };
 
 namespace {
+
+int build_ts_masks(crispy_asr* h);   // defined with the timestamp-mode code below
 
 void add_spec(std::map<std::string, size_t>& spec, const std::string& name, size_t n) { spec[name] = n; }
 
@@ -177,6 +188,10 @@ void free_dec_ws(crispy_asr* h) {
   if (h->d_tokens_all) { (void)hipFree(h->d_tokens_all); h->d_tokens_all = nullptr; }
   if (h->d_counters) { (void)hipFree(h->d_counters); h->d_counters = nullptr; }
   if (h->dec_graph) { (void)hipGraphExecDestroy(h->dec_graph); h->dec_graph = nullptr; h->dec_graph_batch = 0; }
+  if (h->ts_graph) { (void)hipGraphExecDestroy(h->ts_graph); h->ts_graph = nullptr; h->ts_graph_batch = 0; }
+  if (h->d_ts_state) { (void)hipFree(h->d_ts_state); h->d_ts_state = nullptr; }
+  if (h->d_tids_all) { (void)hipFree(h->d_tids_all); h->d_tids_all = nullptr; }
+  if (h->d_done_count) { (void)hipFree(h->d_done_count); h->d_done_count = nullptr; }
   h->dcap_batch = 0;
 }
 
@@ -260,6 +275,8 @@ void crispy_asr_free(crispy_asr* h) {
   for (float* p : h->derived) (void)hipFree(p);
   if (h->d_suppress) (void)hipFree(h->d_suppress);
   if (h->d_suppress_first) (void)hipFree(h->d_suppress_first);
+  if (h->d_ts_mask) (void)hipFree(h->d_ts_mask);
+  if (h->d_ts_mask_first) (void)hipFree(h->d_ts_mask_first);
   if (h->d_lang_mask) (void)hipFree(h->d_lang_mask);
   free_ws(h);
   free_dec_ws(h);
@@ -337,6 +354,7 @@ int crispy_asr_finalize(crispy_asr* h) {
   HIP_TRY(hipMalloc(&h->d_suppress_first, h->hp.n_vocab));
   HIP_TRY(hipMemset(h->d_suppress, 0, h->hp.n_vocab));
   HIP_TRY(hipMemset(h->d_suppress_first, 0, h->hp.n_vocab));
+  { const int mrc = build_ts_masks(h); if (mrc != CRISPY_OK) return mrc; }
   h->finalized = true;
   return CRISPY_OK;
 }
@@ -459,6 +477,9 @@ int reserve_dec(crispy_asr* h, int batch, int max_tokens) {
   HIP_TRY(hipMalloc(&h->d_tok, B * sizeof(int)));
   HIP_TRY(hipMalloc(&h->d_tokens_all, B * C * sizeof(int)));
   HIP_TRY(hipMalloc(&h->d_counters, 2 * sizeof(int)));
+  HIP_TRY(hipMalloc(&h->d_ts_state, B * sizeof(TsState)));
+  HIP_TRY(hipMalloc(&h->d_tids_all, B * C * sizeof(int)));
+  HIP_TRY(hipMalloc(&h->d_done_count, sizeof(int)));
   h->dcap_batch = batch;
   return CRISPY_OK;
 }
@@ -518,6 +539,149 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
   if (want_logits) {
     HIP_TRY(layernorm_f32(h->d_dx, h->dec_ln_w, h->dec_ln_b, h->d_dxn, batch, dt, s));
     HIP_TRY(gemm_f32_nt(gemm(h->d_dxn, dt, h->tok_emb, dt, h->d_logits, V, nullptr, batch, V, dt), 1, s));
+  }
+  return CRISPY_OK;
+}
+
+// special token ids [UPSTREAM-RECALL, whisper.cpp vocab]: sot = eot + 1; multilingual files carry 99 (+extra)
+// language tokens, then translate, transcribe, solm, prev, nosp, notimestamps and the 1501 timestamps
+struct Special {
+  int sot, lang0, n_lang, translate, transcribe, solm, prev, nosp, not_, beg;
+  bool multilingual;
+};
+Special special_tokens(const crispy_asr* h) {
+  Special sp{};
+  sp.multilingual = h->hp.n_vocab >= 51865;
+  const int extra = sp.multilingual ? h->hp.n_vocab - 51865 : 0;
+  sp.sot = h->eot + 1;
+  sp.lang0 = sp.sot + 1;
+  if (sp.multilingual) {
+    sp.n_lang = 99 + extra;
+    sp.translate = sp.sot + 100 + extra;
+  } else {
+    sp.n_lang = 0;
+    sp.translate = sp.sot + 1;
+  }
+  sp.transcribe = sp.translate + 1;
+  sp.solm = sp.translate + 2;
+  sp.prev = sp.translate + 3;
+  sp.nosp = sp.translate + 4;
+  sp.not_ = sp.translate + 5;
+  sp.beg = sp.not_ + 1;
+  return sp;
+}
+
+// cross K | V of every layer once per window, then the prompt tokens one position at a time (the language
+// token may differ per clip); leaves the logits of the last prompt position in h->d_logits
+int prefill(crispy_asr* h, const float* d_enc, int batch, const int* prompt, int n_prompt, const int* lang_tokens,
+            hipStream_t s, int* pos_out) {
+  const int dt = h->hp.n_text_state, Tn = h->hp.n_audio_ctx;
+  for (size_t l = 0; l < h->dec.size(); ++l) {
+    float* xkv = h->d_xkv + l * (size_t)batch * Tn * 2 * dt;
+    HIP_TRY(gemm_f32_nt(gemm(d_enc, dt, h->dec[l].xkv_w, dt, xkv, 2L * dt, h->dec[l].xkv_b, batch * Tn, 2 * dt, dt), 1, s));
+  }
+  std::vector<int> tok(batch);
+  int pos = 0;
+  for (int i = 0; i < n_prompt; ++i, ++pos) {
+    std::fill(tok.begin(), tok.end(), prompt[i]);
+    if (i == 1 && lang_tokens)      // per-clip language token (auto-detected or caller supplied)
+      for (int b = 0; b < batch; ++b) {
+        if (lang_tokens[b] < 0 || lang_tokens[b] >= h->hp.n_vocab)
+          return fail(CRISPY_ERR_INVALID_ARG, "decode: language token %d out of range", lang_tokens[b]);
+        tok[b] = lang_tokens[b];
+      }
+    HIP_TRY(hipMemcpyAsync(h->d_tok, tok.data(), sizeof(int) * batch, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));  // tok is reused by the next iteration
+    const int rc = decoder_step(h, batch, pos, false, i == n_prompt - 1, s);
+    if (rc != CRISPY_OK) return rc;
+  }
+  *pos_out = pos;
+  return CRISPY_OK;
+}
+
+TsPickArgs ts_args(crispy_asr* h, int rules, const unsigned char* mask, const unsigned char* mask_first) {
+  const Special sp = special_tokens(h);
+  TsPickArgs a{};
+  a.logits = h->d_logits;
+  a.mask = mask;
+  a.mask_first = mask_first;
+  a.st = h->d_ts_state;
+  a.V = h->hp.n_vocab;
+  a.beg = sp.beg;
+  a.eot = h->eot;
+  a.not_tok = sp.not_;
+  a.rules = rules;
+  a.max_initial_ts = 50;     // whisper.cpp max_initial_ts = 1.0 s at 0.02 s per timestamp; HF/openai: 50
+  a.tokens_out = h->d_tok;
+  a.tokens_all = h->d_tokens_all;
+  a.tids_all = h->d_tids_all;
+  a.step_dev = h->d_counters + 1;
+  a.done_count = h->d_done_count;
+  return a;
+}
+
+// One decoding window per clip under the timestamp rules (oracle/whisper_oracle.py: decode_window).
+// tokens_out / tids_out: [batch][max_new]; n_out[b] = picks up to and including the one that ended the window.
+int decode_ts(crispy_asr* h, const float* d_enc, int batch, const int* prompt, int n_prompt, const int* lang_tokens,
+              int rules, const int* seek, const int* seek_end, int max_new, const unsigned char* mask,
+              const unsigned char* mask_first, int* tokens_out, int* tids_out, int* n_out) {
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  int rc = reserve_dec(h, batch, n_prompt + max_new);
+  if (rc != CRISPY_OK) return rc;
+  int pos = 0;
+  rc = prefill(h, d_enc, batch, prompt, n_prompt, lang_tokens, s, &pos);
+  if (rc != CRISPY_OK) return rc;
+  std::vector<TsState> st(batch);
+  for (int b = 0; b < batch; ++b) st[b] = TsState{-1, -1, 0, -1, 0, seek ? seek[b] : 0, seek_end ? seek_end[b] : (1 << 30), 0};
+  const int counters[2] = {pos, 0};
+  HIP_TRY(hipMemcpyAsync(h->d_counters, counters, sizeof(counters), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->d_ts_state, st.data(), sizeof(TsState) * batch, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(h->d_done_count, 0, sizeof(int), s));
+  HIP_TRY(hipStreamSynchronize(s));
+  const TsPickArgs pa = ts_args(h, rules, mask, mask_first);
+  int steps_run = 1;      // picks made = decoder steps replayed + the final pick
+  if (max_new > 1) {
+    if (!h->ts_graph || h->ts_graph_batch != batch || h->ts_graph_rules != rules || h->ts_graph_mask != mask) {
+      if (h->ts_graph) { (void)hipGraphExecDestroy(h->ts_graph); h->ts_graph = nullptr; }
+      hipGraph_t graph = nullptr;
+      HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      hipError_t pe = ts_pick(pa, batch, s);
+      rc = pe == hipSuccess ? decoder_step(h, batch, 0, true, true, s) : CRISPY_OK;
+      if (pe == hipSuccess && rc == CRISPY_OK) pe = advance_counters(h->d_counters, h->d_counters + 1, s);
+      const hipError_t ce = hipStreamEndCapture(s, &graph);
+      if (rc != CRISPY_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+      HIP_TRY(pe);
+      HIP_TRY(ce);
+      const hipError_t ie = hipGraphInstantiate(&h->ts_graph, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      HIP_TRY(ie);
+      h->ts_graph_batch = batch; h->ts_graph_rules = rules; h->ts_graph_mask = mask;
+    }
+    int done = 0;
+    for (int i = 0; i + 1 < max_new; ++i) {
+      HIP_TRY(hipGraphLaunch(h->ts_graph, s));
+      ++steps_run;
+      if ((i & 7) == 7) {   // every 8 tokens: have all windows ended?
+        HIP_TRY(hipMemcpyAsync(&done, h->d_done_count, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (done >= batch) break;
+      }
+    }
+  }
+  HIP_TRY(ts_pick(pa, batch, s));   // the last pick needs no further decoder step
+  std::vector<int> all((size_t)steps_run * batch), tids((size_t)steps_run * batch);
+  HIP_TRY(hipMemcpyAsync(all.data(), h->d_tokens_all, all.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(tids.data(), h->d_tids_all, tids.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(st.data(), h->d_ts_state, sizeof(TsState) * batch, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  for (int b = 0; b < batch; ++b) {
+    const int n = st[b].n < max_new ? st[b].n : max_new;
+    for (int i = 0; i < max_new; ++i) {
+      tokens_out[(size_t)b * max_new + i] = i < n ? all[(size_t)i * batch + b] : h->eot;
+      if (tids_out) tids_out[(size_t)b * max_new + i] = i < n ? tids[(size_t)i * batch + b] : pa.beg;
+    }
+    if (n_out) n_out[b] = n;
   }
   return CRISPY_OK;
 }
@@ -582,27 +746,10 @@ int crispy_asr_decode_greedy_lang_device(crispy_asr* h, const float* d_enc, int 
   hipStream_t s = h->stream;
   int rc = reserve_dec(h, batch, n_prompt + max_new);
   if (rc != CRISPY_OK) return rc;
-  const int dt = h->hp.n_text_state, Tn = h->hp.n_audio_ctx, V = h->hp.n_vocab, C = h->hp.n_text_ctx;
-  // cross K | V of every layer, once per clip
-  for (size_t l = 0; l < h->dec.size(); ++l) {
-    float* xkv = h->d_xkv + l * (size_t)batch * Tn * 2 * dt;
-    HIP_TRY(gemm_f32_nt(gemm(d_enc, dt, h->dec[l].xkv_w, dt, xkv, 2L * dt, h->dec[l].xkv_b, batch * Tn, 2 * dt, dt), 1, s));
-  }
-  std::vector<int> tok(batch);
+  const int V = h->hp.n_vocab;
   int pos = 0;
-  for (int i = 0; i < n_prompt; ++i, ++pos) {
-    std::fill(tok.begin(), tok.end(), prompt[i]);
-    if (i == 1 && lang_tokens)      // per-clip language token (auto-detected or caller supplied)
-      for (int b = 0; b < batch; ++b) {
-        if (lang_tokens[b] < 0 || lang_tokens[b] >= h->hp.n_vocab)
-          return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_decode_greedy_device: language token %d out of range", lang_tokens[b]);
-        tok[b] = lang_tokens[b];
-      }
-    HIP_TRY(hipMemcpyAsync(h->d_tok, tok.data(), sizeof(int) * batch, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));  // tok is reused by the next iteration
-    rc = decoder_step(h, batch, pos, false, i == n_prompt - 1, s);
-    if (rc != CRISPY_OK) return rc;
-  }
+  rc = prefill(h, d_enc, batch, prompt, n_prompt, lang_tokens, s, &pos);
+  if (rc != CRISPY_OK) return rc;
   const int counters[2] = {pos, 0};
   HIP_TRY(hipMemcpyAsync(h->d_counters, counters, sizeof(counters), hipMemcpyHostToDevice, s));
   HIP_TRY(hipStreamSynchronize(s));
@@ -630,7 +777,6 @@ int crispy_asr_decode_greedy_lang_device(crispy_asr* h, const float* d_enc, int 
   HIP_TRY(hipMemcpyAsync(all.data(), h->d_tokens_all, all.size() * sizeof(int), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(best.data(), h->d_best, best.size() * sizeof(float), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  (void)C;
   for (int b = 0; b < batch; ++b) {
     int n = max_new;
     for (int i = 0; i < max_new; ++i) {
@@ -641,6 +787,29 @@ int crispy_asr_decode_greedy_lang_device(crispy_asr* h, const float* d_enc, int 
     if (n_out) n_out[b] = n;
   }
   return CRISPY_OK;
+}
+
+int crispy_asr_decode_timestamps_device(crispy_asr* h, const float* d_enc, int batch, const int* prompt, int n_prompt,
+                                        const int* lang_tokens, int rules, const int* seek, const int* seek_end,
+                                        int max_new, int* tokens_out, int* tids_out, int* n_out) {
+  if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_decode_timestamps_device: NULL handle");
+  if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_decode_timestamps_device: model not finalized");
+  if (batch < 0 || max_new < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_decode_timestamps_device: negative size");
+  if (batch == 0 || max_new == 0) return CRISPY_OK;
+  if (!d_enc || !prompt || n_prompt <= 0 || !tokens_out)
+    return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_decode_timestamps_device: NULL argument");
+  if (rules != TS_RULES_WCPP && rules != TS_RULES_OPENAI)
+    return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_decode_timestamps_device: rules must be 0 (whisper.cpp) or 1 (openai)");
+  if (n_prompt + max_new > h->hp.n_text_ctx)
+    return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_decode_timestamps_device: %d prompt + %d new tokens exceed n_text_ctx %d",
+                n_prompt, max_new, h->hp.n_text_ctx);
+  if (special_tokens(h).beg + 1501 > h->hp.n_vocab)
+    return fail(CRISPY_ERR_UNSUPPORTED, "crispy_asr_decode_timestamps_device: vocabulary of %d has no timestamp tokens", h->hp.n_vocab);
+  for (int i = 0; i < n_prompt; ++i)
+    if (prompt[i] < 0 || prompt[i] >= h->hp.n_vocab)
+      return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_decode_timestamps_device: prompt token %d out of range", prompt[i]);
+  return decode_ts(h, d_enc, batch, prompt, n_prompt, lang_tokens, rules, seek, seek_end, max_new, h->d_suppress,
+                   h->d_suppress_first, tokens_out, tids_out, n_out);
 }
 
 // whisper.cpp `whisper_lang_auto_detect`: feed <|startoftranscript|> alone and take the most probable
@@ -783,12 +952,94 @@ void dequant_block(int ttype, const uint8_t* b, float* y) {
 
 }  // namespace
 
+namespace {
+
 struct crispy_asr_result_impl {
   crispy_asr_result pub;
   std::string text;
   std::vector<int> tokens;
   int language_token = 0;
+  std::vector<std::string> seg_text;
+  std::vector<float> seg_t0, seg_t1;
+  std::vector<crispy_asr_segment> segs;
 };
+
+// whisper.cpp's always-suppressed specials (whisper_process_logits [UPSTREAM-RECALL]): sot, nosp, translate,
+// transcribe, prev, solm, every language token; suppress_blank adds " " and EOT at the first position.
+int build_ts_masks(crispy_asr* h) {
+  const Special sp = special_tokens(h);
+  const int V = h->hp.n_vocab;
+  std::vector<unsigned char> m(V, 0);
+  for (int t : {sp.sot, sp.nosp, sp.translate, sp.transcribe, sp.prev, sp.solm})
+    if (t >= 0 && t < V) m[t] = 1;
+  for (int t = sp.lang0; t < sp.lang0 + sp.n_lang && t < V; ++t) m[t] = 1;
+  std::vector<unsigned char> f = m;
+  int blank = 220;                                  // " " in both GPT-2 vocabularies
+  for (size_t t = 0; t < h->vocab.size(); ++t)
+    if (h->vocab[t] == " ") { blank = (int)t; break; }
+  if (blank < V) f[blank] = 1;
+  if (h->eot < V) f[h->eot] = 1;
+  if (!h->d_ts_mask) HIP_TRY(hipMalloc(&h->d_ts_mask, V));
+  if (!h->d_ts_mask_first) HIP_TRY(hipMalloc(&h->d_ts_mask_first, V));
+  HIP_TRY(hipMemcpy(h->d_ts_mask, m.data(), V, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->d_ts_mask_first, f.data(), V, hipMemcpyHostToDevice));
+  return CRISPY_OK;
+}
+
+// whisper_full's bookkeeping over the picks of one window (oracle/whisper_oracle.py: decode_window):
+// how many tokens are kept and how far the window advances
+void window_bookkeeping(const int* toks, int n, int max_new, int beg, int eot, int seek, int seek_end, int* result_len,
+                        int* seek_delta) {
+  bool has_ts = false, ended = false;
+  int sd = 3000, rl = 0;
+  for (int i = 0; i < n; ++i) {
+    const int t = toks[i];
+    if (t > beg) { sd = 2 * (t - beg); rl = i + 1; has_ts = true; }
+    if (t == eot || (has_ts && seek + sd + 100 >= seek_end)) {
+      if (t == eot && rl == 0) rl = i + 1;          // no temperature fallback: keep what was decoded
+      ended = true;
+      break;
+    }
+  }
+  if (!ended && rl == 0) rl = n;
+  (void)max_new;
+  *result_len = rl;
+  *seek_delta = sd;
+}
+
+// segments of one window as whisper_full builds them (oracle: window_segments); times in seconds
+void window_segments(const crispy_asr* h, const int* toks, const int* tids, int n, int beg, int seek, int seek_delta,
+                     crispy_asr_result_impl* r) {
+  if (n <= 0) return;
+  auto piece = [&](int t) -> std::string { return t < (int)h->vocab.size() ? h->vocab[t] : std::string(); };
+  int t0 = seek + 2 * (tids[0] - beg);
+  std::string text;
+  for (int i = 0; i < n; ++i) {
+    if (toks[i] < h->eot) text += piece(toks[i]);
+    if (toks[i] > beg) {
+      const int t1 = seek + 2 * (tids[i] - beg);
+      if (!text.empty()) { r->seg_t0.push_back(t0 / 100.f); r->seg_t1.push_back(t1 / 100.f); r->seg_text.push_back(text); }
+      text.clear();
+      while (i < n && toks[i] > beg) ++i;
+      --i;
+      t0 = t1;
+    }
+  }
+  if (!text.empty()) { r->seg_t0.push_back(t0 / 100.f); r->seg_t1.push_back((seek + seek_delta) / 100.f); r->seg_text.push_back(text); }
+}
+
+void publish(crispy_asr_result_impl* r) {
+  r->segs.resize(r->seg_text.size());
+  for (size_t i = 0; i < r->segs.size(); ++i) r->segs[i] = crispy_asr_segment{r->seg_t0[i], r->seg_t1[i], r->seg_text[i].c_str()};
+  r->pub.text = r->text.c_str();
+  r->pub.tokens = r->tokens.data();
+  r->pub.n_tokens = (int)r->tokens.size();
+  r->pub.language_token = r->language_token;
+  r->pub.n_segments = (int)r->segs.size();
+  r->pub.segments = r->segs.empty() ? nullptr : r->segs.data();
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -893,71 +1144,16 @@ int crispy_asr_transcribe(crispy_asr* h, const float* pcm16k, size_t n, const cr
   if (!out) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe: out is NULL");
   *out = nullptr;
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe: NULL handle");
-  crispy_asr_result_impl* res = new (std::nothrow) crispy_asr_result_impl();
-  if (!res) return fail(CRISPY_ERR_OOM, "crispy_asr_transcribe: host allocation failed");
-  auto finish = [&]() {
-    res->pub.text = res->text.c_str();
-    res->pub.tokens = res->tokens.data();
-    res->pub.n_tokens = (int)res->tokens.size();
-    res->pub.language_token = res->language_token;
-    *out = &res->pub;
-    return CRISPY_OK;
-  };
-  if (n == 0) return finish();                       // managers/transcription.rs:175-177
-  if (!pcm16k) { delete res; return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe: NULL audio"); }
-  if (n > 480000) { delete res; return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe: %zu samples; the caller chunks at 480000 (commands/transcription.rs:249-302)", n); }
-  // special tokens [UPSTREAM-RECALL, whisper.cpp vocab]: sot = eot + 1; multilingual files carry 99 (+extra)
-  // language tokens, then translate, transcribe, solm, prev, nosp, notimestamps
-  const bool multilingual = h->hp.n_vocab >= 51865;
-  const int extra = multilingual ? h->hp.n_vocab - 51865 : 0;
-  const int sot = h->eot + 1;
-  std::vector<int> prompt = {sot};
-  if (multilingual) {
-    prompt.push_back(opts && opts->language_token > 0 ? opts->language_token : sot + 1);   // <|en|>
-    prompt.push_back((opts && opts->translate ? sot + 100 : sot + 101) + extra);
-  }
-  prompt.push_back(sot + 105 + extra);                                                      // <|notimestamps|>
-  int max_new = opts && opts->max_new_tokens > 0 ? opts->max_new_tokens : h->hp.n_text_ctx / 2;
-  if ((int)prompt.size() + max_new > h->hp.n_text_ctx) max_new = h->hp.n_text_ctx - (int)prompt.size();
-  std::vector<int> toks(max_new);
-  int n_out = 0;
-  const int ns = (int)n;
-  // log-mel + encoder, then (multilingual, language unset = TranscribeOptions::default()) language detection
-  int rc = reserve_enc(h, 1);
-  if (rc != CRISPY_OK) { delete res; return rc; }
-  {
-    auto stage = [&]() -> int {
-      HIP_TRY(hipSetDevice(h->device));
-      if (!h->w_pcm || (long)n > h->cap_pcm_stride) {
-        if (h->w_pcm) (void)hipFree(h->w_pcm);
-        h->w_pcm = nullptr;
-        HIP_TRY(hipMalloc(&h->w_pcm, (size_t)h->cap_batch * n * sizeof(float)));
-        h->cap_pcm_stride = (long)n;
-      }
-      HIP_TRY(hipMemcpyAsync(h->w_pcm, pcm16k, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
-      return CRISPY_OK;
-    };
-    rc = stage();
-    if (rc == CRISPY_OK) rc = crispy_mel_compute_device(h->mel, h->w_pcm, (long)n, &ns, 1, nullptr, h->w_melt, h->stream);
-    if (rc == CRISPY_OK) rc = crispy_asr_encode_device(h, h->w_melt, 1, h->w_enc, h->stream);
-    int lang = 0;
-    const bool detect = multilingual && !(opts && opts->language_token > 0);
-    if (rc == CRISPY_OK && detect) rc = crispy_asr_detect_language_device(h, h->w_enc, 1, &lang);
-    if (rc == CRISPY_OK)
-      rc = crispy_asr_decode_greedy_lang_device(h, h->w_enc, 1, prompt.data(), (int)prompt.size(), detect ? &lang : nullptr,
-                                                max_new, toks.data(), &n_out, nullptr);
-    if (rc == CRISPY_OK && detect) res->language_token = lang;
-    else if (multilingual) res->language_token = prompt[1];
-  }
-  if (rc != CRISPY_OK) { delete res; return rc; }
-  res->tokens.assign(toks.begin(), toks.begin() + n_out);
-  for (int t : res->tokens)
-    if (t < h->eot && t < (int)h->vocab.size()) res->text += h->vocab[t];
-  return finish();
+  if (n > 0 && !pcm16k) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe: NULL audio");
+  return crispy_asr_transcribe_batch(h, &pcm16k, &n, 1, opts, out);
 }
 
-// engine.transcribe for a batch of chunks at once: one log-mel + encoder + (language detection) + decoder pass
-// over all clips; results[i] is library-owned (crispy_asr_free_result each).
+// engine.transcribe for a batch of chunks at once; results[i] is library-owned (crispy_asr_free_result each).
+//   no_timestamps = 1: prompt [sot, lang, task, <|notimestamps|>], one window, plain greedy arg-max.
+//   no_timestamps = 0 (whisper.cpp's default, what TranscribeOptions::default() runs): whisper_full's seek loop
+//     [UPSTREAM-RECALL] -- windows of 30 s starting at `seek`, greedy picks under the timestamp rules, the window
+//     advances to the last closed timestamp pair, segments are cut at timestamp tokens.  Not reproduced: the
+//     temperature fallback (sampled re-decoding when the entropy / log-probability thresholds reject a window).
 int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const size_t* n, int batch,
                                 const crispy_asr_opts* opts, crispy_asr_result** results) {
   if (!h || !results) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: NULL argument");
@@ -970,7 +1166,9 @@ int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const si
   std::vector<int> live;
   size_t stride = 1;
   for (int i = 0; i < batch; ++i) {
-    if (n[i] > 480000) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: clip %d has %zu samples (> 480000)", i, n[i]);
+    if (n[i] > 480000)
+      return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: clip %d has %zu samples; the caller chunks at 480000 "
+                  "(commands/transcription.rs:249-302)", i, n[i]);
     if (n[i] > 0) {
       if (!pcm[i]) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: clip %d is NULL", i);
       live.push_back(i);
@@ -985,23 +1183,24 @@ int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const si
   }
   const int nb = (int)live.size();
   if (nb > 0) {
-    const bool multilingual = h->hp.n_vocab >= 51865;
-    const int extra = multilingual ? h->hp.n_vocab - 51865 : 0;
-    const int sot = h->eot + 1;
-    std::vector<int> prompt = {sot};
-    if (multilingual) {
-      prompt.push_back(opts && opts->language_token > 0 ? opts->language_token : sot + 1);
-      prompt.push_back((opts && opts->translate ? sot + 100 : sot + 101) + extra);
+    const Special sp = special_tokens(h);
+    const bool timestamps = !(opts && opts->no_timestamps) && sp.beg + 1501 <= h->hp.n_vocab;
+    std::vector<int> prompt = {sp.sot};
+    if (sp.multilingual) {
+      prompt.push_back(opts && opts->language_token > 0 ? opts->language_token : sp.lang0);   // <|en|>
+      prompt.push_back(opts && opts->translate ? sp.translate : sp.transcribe);
     }
-    prompt.push_back(sot + 105 + extra);
-    int max_new = opts && opts->max_new_tokens > 0 ? opts->max_new_tokens : h->hp.n_text_ctx / 2;
+    if (!timestamps) prompt.push_back(sp.not_);
+    int max_new = opts && opts->max_new_tokens > 0 ? opts->max_new_tokens
+                                                   : (timestamps ? h->hp.n_text_ctx / 2 - 4 : h->hp.n_text_ctx / 2);
     if ((int)prompt.size() + max_new > h->hp.n_text_ctx) max_new = h->hp.n_text_ctx - (int)prompt.size();
     std::vector<float> packed((size_t)nb * stride, 0.f);
-    std::vector<int> lens(nb), lang(nb, 0), toks((size_t)nb * max_new), n_out(nb, 0);
+    std::vector<int> lens(nb), lang(nb, 0);
     for (int k = 0; k < nb; ++k) {
       std::memcpy(packed.data() + (size_t)k * stride, pcm[live[k]], n[live[k]] * sizeof(float));
       lens[k] = (int)n[live[k]];
     }
+    const bool detect = sp.multilingual && !(opts && opts->language_token > 0);
     auto run = [&]() -> int {
       HIP_TRY(hipSetDevice(h->device));
       int rc = reserve_enc(h, nb);
@@ -1017,31 +1216,72 @@ int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const si
       if (rc != CRISPY_OK) return rc;
       rc = crispy_asr_encode_device(h, h->w_melt, nb, h->w_enc, h->stream);
       if (rc != CRISPY_OK) return rc;
-      const bool detect = multilingual && !(opts && opts->language_token > 0);
       if (detect) {
         rc = crispy_asr_detect_language_device(h, h->w_enc, nb, lang.data());
         if (rc != CRISPY_OK) return rc;
-      } else if (multilingual) {
+      } else if (sp.multilingual) {
         std::fill(lang.begin(), lang.end(), prompt[1]);
       }
-      return crispy_asr_decode_greedy_lang_device(h, h->w_enc, nb, prompt.data(), (int)prompt.size(),
+      for (int k = 0; k < nb; ++k) impl[live[k]]->language_token = lang[k];
+      if (!timestamps) {
+        std::vector<int> toks((size_t)nb * max_new), n_out(nb, 0);
+        rc = crispy_asr_decode_greedy_lang_device(h, h->w_enc, nb, prompt.data(), (int)prompt.size(),
                                                   detect ? lang.data() : nullptr, max_new, toks.data(), n_out.data(), nullptr);
+        if (rc != CRISPY_OK) return rc;
+        for (int k = 0; k < nb; ++k) {
+          crispy_asr_result_impl* r = impl[live[k]];
+          r->tokens.assign(toks.begin() + (size_t)k * max_new, toks.begin() + (size_t)k * max_new + n_out[k]);
+          for (int t : r->tokens)
+            if (t < h->eot && t < (int)h->vocab.size()) r->text += h->vocab[t];
+        }
+        return CRISPY_OK;
+      }
+      // ---- whisper_full's seek loop, all clips in lock step ----
+      std::vector<int> seek(nb, 0), seek_end(nb);
+      for (int k = 0; k < nb; ++k) seek_end[k] = lens[k] / 160;
+      for (int round = 0; round < 16; ++round) {
+        std::vector<int> act;
+        for (int k = 0; k < nb; ++k)
+          if (seek_end[k] >= 100 && seek[k] + 100 < seek_end[k]) act.push_back(k);   // < 1 s left: whisper.cpp stops
+        if (act.empty()) break;
+        const int na = (int)act.size();
+        if (!(round == 0 && na == nb)) {     // round 0 with every clip active: the encoder output is already there
+          std::vector<int> sk(na);
+          for (int a = 0; a < na; ++a) sk[a] = seek[act[a]];
+          rc = crispy_mel_window_device(h->mel, act.data(), sk.data(), na, nullptr, h->w_melt, h->stream);
+          if (rc != CRISPY_OK) return rc;
+          rc = crispy_asr_encode_device(h, h->w_melt, na, h->w_enc, h->stream);
+          if (rc != CRISPY_OK) return rc;
+        }
+        std::vector<int> a_lang(na), a_seek(na), a_end(na), toks((size_t)na * max_new), tids((size_t)na * max_new), n_out(na, 0);
+        for (int a = 0; a < na; ++a) { a_lang[a] = lang[act[a]]; a_seek[a] = seek[act[a]]; a_end[a] = seek_end[act[a]]; }
+        rc = decode_ts(h, h->w_enc, na, prompt.data(), (int)prompt.size(), sp.multilingual ? a_lang.data() : nullptr,
+                       TS_RULES_WCPP, a_seek.data(), a_end.data(), max_new, h->d_ts_mask, h->d_ts_mask_first, toks.data(),
+                       tids.data(), n_out.data());
+        if (rc != CRISPY_OK) return rc;
+        for (int a = 0; a < na; ++a) {
+          const int k = act[a];
+          crispy_asr_result_impl* r = impl[live[k]];
+          const int* tk = toks.data() + (size_t)a * max_new;
+          int result_len = 0, seek_delta = 3000;
+          window_bookkeeping(tk, n_out[a], max_new, sp.beg, h->eot, seek[k], seek_end[k], &result_len, &seek_delta);
+          window_segments(h, tk, tids.data() + (size_t)a * max_new, result_len, sp.beg, seek[k], seek_delta, r);
+          for (int i = 0; i < result_len; ++i)
+            if (tk[i] != h->eot) r->tokens.push_back(tk[i]);
+          seek[k] += seek_delta;
+        }
+      }
+      for (int k = 0; k < nb; ++k) {
+        crispy_asr_result_impl* r = impl[live[k]];
+        for (const std::string& t : r->seg_text) r->text += t;
+      }
+      return CRISPY_OK;
     };
     const int rc = run();
     if (rc != CRISPY_OK) { cleanup(); return rc; }
-    for (int k = 0; k < nb; ++k) {
-      crispy_asr_result_impl* r = impl[live[k]];
-      r->tokens.assign(toks.begin() + (size_t)k * max_new, toks.begin() + (size_t)k * max_new + n_out[k]);
-      r->language_token = lang[k];
-      for (int t : r->tokens)
-        if (t < h->eot && t < (int)h->vocab.size()) r->text += h->vocab[t];
-    }
   }
   for (int i = 0; i < batch; ++i) {
-    impl[i]->pub.text = impl[i]->text.c_str();
-    impl[i]->pub.tokens = impl[i]->tokens.data();
-    impl[i]->pub.n_tokens = (int)impl[i]->tokens.size();
-    impl[i]->pub.language_token = impl[i]->language_token;
+    publish(impl[i]);
     results[i] = &impl[i]->pub;
   }
   return CRISPY_OK;

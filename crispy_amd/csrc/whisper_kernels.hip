@@ -494,6 +494,98 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ l
   }
 }
 
+
+// greedy pick under the timestamp rules: one 256-thread block per clip, two passes over the logits
+__global__ __launch_bounds__(256) void ts_pick_kernel(TsPickArgs a) {
+  __shared__ float s_v[2][256];
+  __shared__ int s_i[2][256];
+  __shared__ float s_sum[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int step = a.step_dev ? *a.step_dev : 0;
+  TsState st = a.st[b];
+  if (st.done) {   // finished window: keep feeding EOT so that the batch stays in lock step
+    if (tid == 0) {
+      a.tokens_out[b] = a.eot;
+      a.tokens_all[(long)step * gridDim.x + b] = a.eot;
+      a.tids_all[(long)step * gridDim.x + b] = a.beg;
+    }
+    return;
+  }
+  const float* lg = a.logits + (long)b * a.V;
+  const unsigned char* mask = (st.n == 0 && a.mask_first) ? a.mask_first : a.mask;
+  const bool last_ts = st.n >= 1 && st.last >= a.beg;
+  const bool pen_ts = st.n < 2 || st.prev >= a.beg;
+  // timestamps below `ts_lo` and above `ts_hi` are not allowed
+  int ts_lo = a.beg, ts_hi = a.V - 1;
+  if (st.last_ts >= 0) ts_lo = (a.rules == TS_RULES_OPENAI && !(last_ts && !pen_ts)) ? st.last_ts + 1 : st.last_ts;
+  const bool initial = st.n == 0;
+  if (initial && a.max_initial_ts > 0) ts_hi = a.beg + a.max_initial_ts;
+  const bool no_text = (last_ts && !pen_ts) || (initial && a.rules == TS_RULES_OPENAI);   // text = ids < eot resp. < beg
+  const bool no_ts = last_ts && pen_ts;
+  auto masked = [&](int v) -> bool {
+    if (mask && mask[v]) return true;
+    if (v == a.not_tok) return true;
+    if (v >= a.beg) return no_ts || v < ts_lo || v > ts_hi;
+    if (last_ts && !pen_ts && v < a.eot) return true;        // after "text <|t|>": a timestamp or EOT only
+    if (initial && a.rules == TS_RULES_OPENAI) return true;  // the first pick is a timestamp
+    return false;
+  };
+  (void)no_text;
+  float tv = -INFINITY, xv = -INFINITY;   // best text (v < beg) and best timestamp
+  int ti = 0x7fffffff, xi = 0x7fffffff;
+  for (int v = tid; v < a.V; v += 256) {
+    if (masked(v)) continue;
+    const float x = lg[v];
+    if (v < a.beg) { if (x > tv || (x == tv && v < ti)) { tv = x; ti = v; } }
+    else { if (x > xv || (x == xv && v < xi)) { xv = x; xi = v; } }
+  }
+  s_v[0][tid] = tv; s_i[0][tid] = ti; s_v[1][tid] = xv; s_i[1][tid] = xi;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const float ov = s_v[q][tid + off];
+        const int oi = s_i[q][tid + off];
+        if (ov > s_v[q][tid] || (ov == s_v[q][tid] && oi < s_i[q][tid])) { s_v[q][tid] = ov; s_i[q][tid] = oi; }
+      }
+    }
+    __syncthreads();
+  }
+  const float max_text = s_v[0][0], max_ts = s_v[1][0];
+  const int arg_text = s_i[0][0], arg_ts = s_i[1][0];
+  // log-sum-exp of the allowed timestamp logits
+  float sum = 0.f;
+  if (max_ts > -INFINITY)
+    for (int v = a.beg + tid; v < a.V; v += 256)
+      if (!masked(v)) sum += expf(lg[v] - max_ts);
+  s_sum[tid] = sum;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) s_sum[tid] += s_sum[tid + off];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const float lse_ts = max_ts > -INFINITY ? max_ts + logf(s_sum[0]) : -INFINITY;
+    int pick;
+    if (lse_ts > max_text) pick = arg_ts;                       // timestamps carry more mass than any text token
+    else pick = (max_ts > max_text) ? arg_ts : arg_text;        // plain arg-max, ties -> lowest id (text ids are lower)
+    if (pick == 0x7fffffff) pick = a.eot;                       // everything masked: cannot happen with sane masks
+    const int tsid = pick >= a.beg ? pick : (max_ts > -INFINITY ? arg_ts : a.beg);
+    a.tokens_out[b] = pick;
+    a.tokens_all[(long)step * gridDim.x + b] = pick;
+    a.tids_all[(long)step * gridDim.x + b] = tsid;
+    st.prev = st.last;
+    st.last = pick;
+    st.n += 1;
+    if (a.rules == TS_RULES_OPENAI ? pick >= a.beg : pick > a.beg) st.last_ts = pick;
+    bool done = pick == a.eot;
+    if (a.rules == TS_RULES_WCPP && st.last_ts >= 0 && st.seek + 2 * (st.last_ts - a.beg) + 100 >= st.seek_end) done = true;
+    if (done) { st.done = 1; atomicAdd(a.done_count, 1); }
+    a.st[b] = st;
+  }
+}
+
 // end of a decode step: position and step counters advance on the device (graph-replay friendly)
 __global__ void advance_kernel(int* __restrict__ pos_dev, int* __restrict__ step_dev) {
   if (threadIdx.x == 0) { *pos_dev += 1; *step_dev += 1; }
@@ -535,6 +627,10 @@ hipError_t argmax_f32(const float* logits, const unsigned char* mask, const unsi
                       const int* step_dev, int V, int* tokens_out, int* tokens_all, float* best, int B, hipStream_t s) {
   hipLaunchKernelGGL(argmax_kernel, dim3(B), dim3(256), 0, s, logits, mask, mask_first, step_dev, V, tokens_out,
                      tokens_all, best);
+  return hipGetLastError();
+}
+hipError_t ts_pick(const TsPickArgs& a, int B, hipStream_t s) {
+  hipLaunchKernelGGL(ts_pick_kernel, dim3(B), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 hipError_t advance_counters(int* pos_dev, int* step_dev, hipStream_t s) {

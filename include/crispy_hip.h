@@ -166,6 +166,11 @@ int crispy_mel_compute(crispy_mel *h, const float *pcm, long pcm_stride, const i
 int crispy_mel_compute_device(crispy_mel *h, const float *d_pcm, long pcm_stride,
                               const int *n_samples, int batch, float *d_out, float *d_out_t,
                               void *hip_stream);
+/* Later 30 s windows of the clips of the LAST crispy_mel_compute_device call (whisper_full's seek loop): output
+ * k is clip clip_idx[k] starting at mel frame seek[k] (0..3000; both host arrays), normalised with that clip's
+ * maximum; frames past the end of the computed range are zero padding.  Same output layouts. */
+int crispy_mel_window_device(crispy_mel *h, const int *clip_idx, const int *seek, int n, float *d_out,
+                             float *d_out_t, void *hip_stream);
 int crispy_mel_synchronize(crispy_mel *h);
 
 /* ------------------------------------------------------------------------------------------
@@ -226,6 +231,20 @@ int crispy_asr_decode_greedy_lang_device(crispy_asr *h, const float *d_enc, int 
                                          int n_prompt, const int *lang_tokens, int max_new,
                                          int *tokens_out, int *n_out, float *logits_out);
 
+/* One decoding window per clip under the timestamp rules (whisper.cpp `whisper_process_logits`, which ports
+ * openai-whisper's ApplyTimestampRules): <|notimestamps|> suppressed, timestamps in pairs except before EOT,
+ * non-decreasing, first one <= 1.00 s, and a timestamp is forced once the probability mass of all timestamps
+ * exceeds the most probable text token.  rules: 0 = whisper.cpp flavour [UPSTREAM-RECALL] (the window also
+ * ends at a timestamp within 1 s of seek_end), 1 = openai / HuggingFace flavour (forced first timestamp,
+ * strictly later after a closed pair; pinned by tests/golden/whisper_tiny_ts_golden.npz).  prompt without
+ * <|notimestamps|>; seek / seek_end [batch] (host, nullable): window start and audio length in mel frames.
+ * tokens_out / tids_out [batch][max_new] (tids: the most probable timestamp token at every step, nullable),
+ * n_out[b] = picks up to and including the one that ended the window.  Uses the crispy_asr_set_suppress masks. */
+int crispy_asr_decode_timestamps_device(crispy_asr *h, const float *d_enc, int batch, const int *prompt,
+                                        int n_prompt, const int *lang_tokens, int rules, const int *seek,
+                                        const int *seek_end, int max_new, int *tokens_out, int *tids_out,
+                                        int *n_out);
+
 /* whisper.cpp language auto-detection: <|startoftranscript|> alone, arg-max over the language tokens.
  * lang_tokens_out[batch] (host).  English-only vocabularies -> CRISPY_ERR_UNSUPPORTED. */
 int crispy_asr_detect_language_device(crispy_asr *h, const float *d_enc, int batch, int *lang_tokens_out);
@@ -235,8 +254,9 @@ int crispy_asr_transcribe_tokens(crispy_asr *h, const float *pcm, long pcm_strid
                                  int max_new, int *tokens_out, int *n_out);
 
 /* WhisperEngine::load(&model_path) (managers/transcription.rs:138-141): parse a whisper.cpp GGML
- * model file (hparams, mel filters, vocabulary, f32 / f16 tensors) and build a finalized engine.
- * Quantised files (q4_1 / q5_0 catalog entries, managers/model.rs:99,137) -> CRISPY_ERR_UNSUPPORTED. */
+ * model file (hparams, mel filters, vocabulary, tensors) and build a finalized engine.  f32 / f16 tensors are
+ * taken as they are; q4_0 / q4_1 / q5_0 / q5_1 / q8_0 blocks (catalog entries managers/model.rs:99,137) are
+ * de-quantised to f32 at load time. */
 int crispy_asr_load(const char *model_path, int device, crispy_asr **out);
 
 /* Byte string of one vocabulary entry of a loaded model file (not NUL-terminated). */
@@ -246,20 +266,33 @@ int crispy_asr_token_text(const crispy_asr *h, int token, const char **text, siz
 typedef struct crispy_asr_opts {
   int language_token;  /* 0 = auto-detect (what TranscribeOptions::default() leaves to whisper.cpp); else the token id */
   int translate;       /* 0 = transcribe */
-  int max_new_tokens;  /* 0 = n_text_ctx / 2 */
+  int max_new_tokens;  /* 0 = whisper.cpp's per-window limit (n_text_ctx / 2 - 4; n_text_ctx / 2 without timestamps) */
+  int no_timestamps;   /* 0 = whisper.cpp's default: timestamp tokens, 30 s windows advancing to the last closed
+                          timestamp pair (whisper_full's seek loop), segments in the result.
+                          1 = <|notimestamps|> prompt, one window, plain greedy arg-max, no segments. */
 } crispy_asr_opts;
+
+/* One segment of the result (managers/transcription.rs:223-233: `seg.start`, `seg.end`, `seg.text`),
+ * seconds relative to the start of the chunk. */
+typedef struct crispy_asr_segment {
+  float t0, t1;
+  const char *text;    /* UTF-8, NUL-terminated, untrimmed */
+} crispy_asr_segment;
 
 /* Library-owned result of one transcribe call; release with crispy_asr_free_result. */
 typedef struct crispy_asr_result {
   const char *text;    /* UTF-8, NUL-terminated, untrimmed (the caller trims: transcription.rs:187) */
-  const int *tokens;   /* the greedy token ids before <|endoftext|> */
+  const int *tokens;   /* the kept token ids (timestamp tokens included in timestamp mode), without <|endoftext|> */
   int n_tokens;
   int language_token;  /* the language token used (detected or given); 0 for English-only vocabularies */
+  int n_segments;      /* 0 with no_timestamps (the reference then falls back to one segment, transcription.rs:236-249) */
+  const crispy_asr_segment *segments;
 } crispy_asr_result;
 
 /* engine.transcribe(&audio, &TranscribeOptions::default()) for ONE chunk of <= 480000 samples
  * (16 kHz f32, host).  n == 0 returns an empty result (transcription.rs:175-177).  Needs a model
- * loaded from a file (vocabulary) for text; tokens are always returned. */
+ * loaded from a file (vocabulary) for text; tokens are always returned.  opts == NULL is
+ * TranscribeOptions::default(): language auto-detected, transcribe, timestamps on. */
 int crispy_asr_transcribe(crispy_asr *h, const float *pcm16k, size_t n, const crispy_asr_opts *opts,
                           crispy_asr_result **out);
 /* The same for `batch` chunks at once (pcm[i]: host pointer to n[i] <= 480000 samples, n[i] == 0 allowed):

@@ -89,9 +89,11 @@ static void fft(float *in, int N, float *out) {
   }
 }
 
-/* out: [n_mel][3000]; returns 0, or -1 on bad arguments */
-int wlo_logmel(const float *samples, int n_samples, const float *filters, int n_mel, float *out) {
+/* out: [n_mel][3000] = frames [seek, seek + 3000) of the clip's log-mel (whisper_full's later windows read the
+ * same normalised spectrogram at an offset); returns 0, or -1 on bad arguments */
+int wlo_logmel_window(const float *samples, int n_samples, const float *filters, int n_mel, int seek, float *out) {
   if (!samples || n_samples <= 0 || n_samples > 30 * WL_SAMPLE_RATE || !filters || n_mel <= 0 || !out) return -1;
+  if (seek < 0 || seek > WL_FRAMES) return -1;
   init();
   const long pad1 = 30L * WL_SAMPLE_RATE, pad2 = WL_N_FFT / 2;
   const long n_pad = n_samples + pad1 + 2 * pad2;
@@ -125,11 +127,16 @@ int wlo_logmel(const float *samples, int n_samples, const float *filters, int n_
   mmax -= 8.0;
   for (int j = 0; j < n_mel; j++)
     for (int t = 0; t < WL_FRAMES; t++) {
-      double v = t < n_len ? mel[j * n_len + t] : mmax;
+      double v = seek + t < n_len ? mel[j * n_len + seek + t] : mmax;
       if (v < mmax) v = mmax;
       out[j * WL_FRAMES + t] = (float)((v + 4.0) / 4.0);
     }
   free(mel);
   free(x);
   return 0;
+}
+
+/* the window the encoder consumes first: frames [0, 3000) */
+int wlo_logmel(const float *samples, int n_samples, const float *filters, int n_mel, float *out) {
+  return wlo_logmel_window(samples, n_samples, filters, n_mel, 0, out);
 }

@@ -303,7 +303,7 @@ def window_segments(win, seek, sp, token_text):
 
 
 def transcribe_timestamps(weights, hp, mel_window, n_samples, prompt, rules, token_text, n_max=None,
-                          suppress=None, suppress_first=None, eot=50257, max_windows=8):
+                          suppress=None, suppress_first=None, eot=50257, max_windows=16):
     """whisper_full's seek loop over one clip (<= 30 s): `mel_window(seek)` returns the [n_mels, 3000] log-mel
     window starting at mel frame `seek`.  Returns (segments, all kept tokens, windows)."""
     sp = special_tokens(hp.n_vocab, eot)

@@ -60,6 +60,8 @@ def lib():
         L.rno_compute_rnn.argtypes = [C.c_void_p, f32p, f32p, f32p, f32p]
         L.wlo_logmel.restype = C.c_int
         L.wlo_logmel.argtypes = [f32p, C.c_int, f32p, C.c_int, f32p]
+        L.wlo_logmel_window.restype = C.c_int
+        L.wlo_logmel_window.argtypes = [f32p, C.c_int, f32p, C.c_int, C.c_int, f32p]
         _LIB = L
     return _LIB
 
@@ -124,12 +126,12 @@ class OracleDenoiseState:
         return out, vad, taps
 
 
-def oracle_logmel(x: np.ndarray, filters: np.ndarray) -> np.ndarray:
-    """oracle/logmel_oracle.c: one clip (<= 480000 samples) -> [n_mel, 3000]."""
+def oracle_logmel(x: np.ndarray, filters: np.ndarray, seek: int = 0) -> np.ndarray:
+    """oracle/logmel_oracle.c: one clip (<= 480000 samples) -> [n_mel, 3000], frames [seek, seek + 3000)."""
     x = np.ascontiguousarray(x, dtype=np.float32)
     f = np.ascontiguousarray(filters, dtype=np.float32)
     out = np.empty((f.shape[0], 3000), dtype=np.float32)
-    rc = lib().wlo_logmel(fp(x), x.size, fp(f), f.shape[0], fp(out))
+    rc = lib().wlo_logmel_window(fp(x), x.size, fp(f), f.shape[0], int(seek), fp(out))
     if rc != 0:
-        raise ValueError("wlo_logmel rejected its arguments")
+        raise ValueError("wlo_logmel_window rejected its arguments")
     return out

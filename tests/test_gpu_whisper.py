@@ -323,3 +323,143 @@ def test_transcribe_with_timestamps_fallback(ggml_file):
     text, _ = eng.transcribe(x, 3)
     assert segs == [(30.0, 40.0, text.strip())]
     assert transcribe_with_timestamps(eng, np.zeros(0, np.float32), 0.0) == []
+
+
+TS_GOLD = os.path.join(os.path.dirname(__file__), "golden", "whisper_tiny_ts_golden.npz")
+
+
+def test_timestamp_rules_match_hf_processor_golden(model):
+    """crispy_asr_decode_timestamps_device, openai flavour: token for token what HuggingFace's
+    WhisperTimeStampLogitsProcessor picks on the same weights (40 picks, two clips decoded together)."""
+    import torch
+    from crispy_amd import synth_audio
+    G = np.load(TS_GOLD)
+    clips = [synth_audio.clip16k_np(int(G[f"c{i}_clip"][0]), int(G[f"c{i}_clip"][1])) for i in range(2)]
+    d_enc = torch.from_numpy(model.encode(clips)).cuda()
+    torch.cuda.synchronize()
+    try:
+        model.set_suppress(G["suppress"])
+        model.set_suppress(G["suppress_first"], first_only=True)
+        toks, tids, n = model.decode_timestamps_device(d_enc.data_ptr(), 2, G["prompt"], 40, rules=1)
+    finally:
+        model.set_suppress([]); model.set_suppress([], first_only=True)
+    for i in range(2):
+        ref = G[f"c{i}_tokens"]
+        assert n[i] == len(ref)
+        assert toks[i, :len(ref)].tolist() == ref.tolist(), (i, toks[i], ref, G[f"c{i}_margins"])
+    beg = 50364
+    assert (tids >= beg).all() and (tids[toks >= beg] == toks[toks >= beg]).all()
+
+
+def _wcpp_masks(hp):
+    from oracle import whisper_oracle as WO
+    sp = WO.special_tokens(hp.n_vocab)
+    sup = [sp["sot"], sp["nosp"], sp["translate"], sp["transcribe"], sp["prev"], sp["solm"]]
+    sup += list(range(sp["lang0"], sp["lang0"] + sp["n_lang"]))
+    return sp, sorted(sup), [220, sp["eot"]]
+
+
+def test_timestamp_window_whispercpp_flavour_matches_oracle(tiny, model, oracle):
+    """One whisper_full window with the whisper.cpp rule flavour (no forced first timestamp, end of window at a
+    timestamp within 1 s of the end of the audio) against the float64 oracle, two clips with different lengths."""
+    import torch
+    from crispy_amd import synth_audio
+    from crispy_amd.mel_filters import whisper_mel_filters
+    from oracle import whisper_oracle as WO
+    hp, W = tiny
+    sp, sup, sup_first = _wcpp_masks(hp)
+    prompt = [sp["sot"], sp["lang0"], sp["transcribe"]]
+    clips = [synth_audio.clip16k_np(31, 72000), synth_audio.clip16k_np(32, 300000)]
+    seek_end = [c.size // 160 for c in clips]
+    d_enc = torch.from_numpy(model.encode(clips)).cuda()
+    torch.cuda.synchronize()
+    try:
+        model.set_suppress(sup)
+        model.set_suppress(sup_first, first_only=True)
+        toks, tids, n = model.decode_timestamps_device(d_enc.data_ptr(), 2, prompt, 24, rules=0, seek=[0, 0], seek_end=seek_end)
+    finally:
+        model.set_suppress([]); model.set_suppress([], first_only=True)
+    F = whisper_mel_filters(80)
+    for b, c in enumerate(clips):
+        enc = WO.encoder_forward(W, hp, oracle.oracle_logmel(c, F))
+        dc = WO.DecoderCache(W, hp, enc)
+        win = WO.decode_window(dc.step, prompt, sp, WO.RULES_WCPP, 24, 0, seek_end[b], sup, sup_first)
+        k = len(win["tokens"])
+        ok = int(np.argmax(np.array(win["margins"]) < 1e-3)) if (np.array(win["margins"]) < 1e-3).any() else k
+        assert toks[b, :ok].tolist() == win["tokens"][:ok], (b, toks[b], win)
+        assert tids[b, :ok].tolist() == win["tids"][:ok]
+        if ok == k:
+            assert n[b] == k
+
+
+def test_mel_windows_match_oracle(oracle):
+    """crispy_mel_window_device: later 30 s windows of the same normalised spectrogram (whisper_full's seek loop)."""
+    import torch
+    from crispy_amd import synth_audio
+    from crispy_amd.asr import LogMel
+    from crispy_amd.mel_filters import whisper_mel_filters
+    F = whisper_mel_filters(80)
+    clips = [synth_audio.clip16k_np(40, 480000), synth_audio.clip16k_np(41, 100000)]
+    pcm = np.zeros((2, 480000), np.float32)
+    for i, c in enumerate(clips):
+        pcm[i, :c.size] = c
+    lm = LogMel(80)
+    d_pcm = torch.from_numpy(pcm).cuda()
+    d_out = torch.empty(3, 80, 3000, device="cuda")
+    lm.compute_device(d_pcm.data_ptr(), 480000, np.array([480000, 100000], np.int32), d_out=d_out.data_ptr())
+    lm.synchronize()
+    lm.window_device([1, 0], [200, 2990], d_out=d_out.data_ptr())     # at most as many windows as clips per call
+    lm.window_device([0], [1234], d_out=d_out[2].data_ptr())
+    lm.synchronize()
+    got = d_out.cpu().numpy()
+    for k, (ci, seek) in enumerate(((1, 200), (0, 2990), (0, 1234))):
+        ref = oracle.oracle_logmel(clips[ci], F, seek)
+        assert np.abs(got[k] - ref).max() < 1e-4, (k, np.abs(got[k] - ref).max())
+    with pytest.raises(Exception):
+        lm.window_device([2], [0], d_out=d_out.data_ptr())        # only two clips were computed
+    with pytest.raises(Exception):
+        lm.window_device([0], [3001], d_out=d_out.data_ptr())
+
+
+def test_transcribe_segments_follow_whisper_full_seek_loop(tiny, ggml_file, oracle):
+    """crispy_asr_transcribe with whisper.cpp's default options (timestamps on): windows, kept tokens, segment
+    times and texts equal the oracle's restatement of whisper_full's seek loop; batch == single calls; clips
+    under 1 s give nothing."""
+    from crispy_amd import synth_audio
+    from crispy_amd.asr import WhisperEngine, transcribe_batch, transcribe_with_timestamps
+    from crispy_amd.mel_filters import whisper_mel_filters
+    from oracle import whisper_oracle as WO
+    hp, W = tiny
+    eng = WhisperEngine(str(ggml_file))
+    sp, sup, sup_first = _wcpp_masks(hp)
+    F = whisper_mel_filters(80)
+    x = synth_audio.clip16k_np(51, 56000)                       # 3.5 s
+    text, segs, toks = eng.transcribe_segments(x, max_new_tokens=10, language_token=sp["lang0"])
+    rsegs, rkept, wins = WO.transcribe_timestamps(W, hp, lambda seek: oracle.oracle_logmel(x, F, seek), x.size,
+                                                  [sp["sot"], sp["lang0"], sp["transcribe"]], WO.RULES_WCPP,
+                                                  eng.token_text, n_max=10, suppress=sup, suppress_first=sup_first,
+                                                  max_windows=16)
+    assert min(min(w["margins"]) for w in wins) > 1e-3, "test clip has an f32-unresolvable pick; choose another seed"
+    assert len(wins) >= 2
+    assert toks == [t for t in rkept if t != sp["eot"]]
+    assert [(round(a * 100), round(b * 100), s) for a, b, s in segs] == [(a, b, s.decode()) for a, b, s in rsegs]
+    assert text == "".join(s for _, _, s in segs)
+    # the manager-level mirror shifts segments by the chunk offset and drops blank ones (transcription.rs:223-240)
+    shifted = transcribe_with_timestamps(eng, x, 30.0, max_new_tokens=10, use_segments=True)
+    _, auto_segs, _ = eng.transcribe_segments(x, max_new_tokens=10)           # language auto-detected, as the mirror does
+    assert shifted == [(30.0 + a, 30.0 + b, s) for a, b, s in auto_segs if s.strip()] and len(shifted) >= 1
+    # batch == single calls; a clip under 1 s is "too short" for whisper.cpp
+    clips = [x, synth_audio.clip16k_np(52, 15000), np.zeros(0, np.float32), synth_audio.clip16k_np(53, 90000)]
+    got = transcribe_batch(eng, clips, max_new_tokens=10, language_token=sp["lang0"], timestamps=True, with_segments=True)
+    assert got[0] == (text, toks, sp["lang0"], segs)
+    assert got[1][:2] == ("", []) and got[1][3] == [] and got[2] == ("", [], 0, [])
+    t3, s3, k3 = eng.transcribe_segments(clips[3], max_new_tokens=10, language_token=sp["lang0"])
+    assert got[3] == (t3, k3, sp["lang0"], s3)
+    # opts == NULL is TranscribeOptions::default(): timestamps on, language detected
+    import ctypes as C
+    from crispy_amd import _native as N
+    res = C.c_void_p()
+    N.check(N.lib().crispy_asr_transcribe(eng._h, x.ctypes.data, x.size, None, C.byref(res)))
+    r = C.cast(res, C.POINTER(N.AsrResult)).contents
+    assert r.language_token >= sp["lang0"] and r.n_tokens > 0 and r.n_segments >= 1
+    N.lib().crispy_asr_free_result(res)
