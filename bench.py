@@ -136,13 +136,18 @@ def asr_leg(local_rank: int, clips: int = 64, new_tokens: int = 32):
         t0 = time.perf_counter()
         e1 = WO.encoder_forward(W, hp, O.oracle_logmel(x1, whisper_mel_filters(hp.n_mels)))
         t_enc = time.perf_counter() - t0
+        dc = WO.DecoderCache(W, hp, e1)
+        for t in prompt[:-1]:
+            dc.step(t)
         t0 = time.perf_counter()
-        WO.greedy_decode(W, hp, e1, prompt, 2)
-        t_tok = (time.perf_counter() - t0) / 2
+        tok = prompt[-1]
+        for _ in range(4):
+            tok = int(np.argmax(dc.step(tok)))
+        t_tok = (time.perf_counter() - t0) / 4
         cpu = {"value": 30.0 / (t_enc + new_tokens * t_tok), "unit": "x real time (end to end, same token count)",
                "cores": os.cpu_count(), "kind": "port",
-               "sample": f"1 clip of 30 s: oracle log-mel + float64 numpy encoder {t_enc:.1f} s, decoder {t_tok:.2f} s/token "
-                         f"(no KV cache) extrapolated to {new_tokens} tokens"}
+               "sample": f"1 clip of 30 s: oracle log-mel + float64 numpy encoder {t_enc:.1f} s, KV-cached numpy decoder "
+                         f"{t_tok * 1e3:.0f} ms/token extrapolated to {new_tokens} tokens"}
     except Exception as e:  # the baseline is a reported extra, never a reason to lose the GPU numbers
         cpu = {"error": str(e)}
     audio_s = clips * 30.0

@@ -94,6 +94,7 @@ struct TsPickArgs {
 hipError_t ts_pick(const TsPickArgs& a, int B, hipStream_t s);
 
 hipError_t argmax_f32(const float* logits, const unsigned char* mask, const unsigned char* mask_first,
-                      const int* step_dev, int V, int* tokens_out, int* tokens_all, float* best, int B, hipStream_t s);
+                      const int* step_dev, int V, int* tokens_out, int* tokens_all, float* best, int B, hipStream_t s,
+                      int eot = -1, int* finished = nullptr, int* done_count = nullptr);
 
 }  // namespace crispy

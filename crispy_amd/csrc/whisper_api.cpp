@@ -69,6 +69,7 @@ struct crispy_asr {
   TsState* d_ts_state = nullptr;             // [dcap_batch]
   int* d_tids_all = nullptr;                 // [n_text_ctx][dcap_batch]
   int* d_done_count = nullptr;
+  int* d_finished = nullptr;                 // [dcap_batch] plain greedy decoding: clip has produced its EOT
   unsigned char* d_ts_mask = nullptr;        // [n_vocab] whisper.cpp's always-suppressed specials
   unsigned char* d_ts_mask_first = nullptr;  // ... plus suppress_blank (" " and EOT) at the first position
   hipGraphExec_t ts_graph = nullptr;
@@ -192,6 +193,7 @@ void free_dec_ws(crispy_asr* h) {
   if (h->d_ts_state) { (void)hipFree(h->d_ts_state); h->d_ts_state = nullptr; }
   if (h->d_tids_all) { (void)hipFree(h->d_tids_all); h->d_tids_all = nullptr; }
   if (h->d_done_count) { (void)hipFree(h->d_done_count); h->d_done_count = nullptr; }
+  if (h->d_finished) { (void)hipFree(h->d_finished); h->d_finished = nullptr; }
   h->dcap_batch = 0;
 }
 
@@ -480,6 +482,7 @@ int reserve_dec(crispy_asr* h, int batch, int max_tokens) {
   HIP_TRY(hipMalloc(&h->d_ts_state, B * sizeof(TsState)));
   HIP_TRY(hipMalloc(&h->d_tids_all, B * C * sizeof(int)));
   HIP_TRY(hipMalloc(&h->d_done_count, sizeof(int)));
+  HIP_TRY(hipMalloc(&h->d_finished, B * sizeof(int)));
   h->dcap_batch = batch;
   return CRISPY_OK;
 }
@@ -690,7 +693,7 @@ int decode_ts(crispy_asr* h, const float* d_enc, int batch, const int* prompt, i
 // advance the device counters: the body of one generated token
 int generation_body(crispy_asr* h, int batch, hipStream_t s) {
   HIP_TRY(argmax_f32(h->d_logits, h->d_suppress, h->d_suppress_first, h->d_counters + 1, h->hp.n_vocab, h->d_tok,
-                     h->d_tokens_all, h->d_best, batch, s));
+                     h->d_tokens_all, h->d_best, batch, s, h->eot, h->d_finished, h->d_done_count));
   int rc = decoder_step(h, batch, 0, true, true, s);
   if (rc != CRISPY_OK) return rc;
   HIP_TRY(advance_counters(h->d_counters, h->d_counters + 1, s));
@@ -752,7 +755,10 @@ int crispy_asr_decode_greedy_lang_device(crispy_asr* h, const float* d_enc, int 
   if (rc != CRISPY_OK) return rc;
   const int counters[2] = {pos, 0};
   HIP_TRY(hipMemcpyAsync(h->d_counters, counters, sizeof(counters), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(h->d_done_count, 0, sizeof(int), s));
+  HIP_TRY(hipMemsetAsync(h->d_finished, 0, sizeof(int) * batch, s));
   HIP_TRY(hipStreamSynchronize(s));
+  int steps_run = 1;      // picks made: replayed decoder steps + the final pick
   if (max_new > 1) {
     if (!h->dec_graph || h->dec_graph_batch != batch) {
       if (h->dec_graph) { (void)hipGraphExecDestroy(h->dec_graph); h->dec_graph = nullptr; }
@@ -767,15 +773,24 @@ int crispy_asr_decode_greedy_lang_device(crispy_asr* h, const float* d_enc, int 
       HIP_TRY(ie);
       h->dec_graph_batch = batch;
     }
-    for (int i = 0; i + 1 < max_new; ++i) HIP_TRY(hipGraphLaunch(h->dec_graph, s));
+    int done = 0;
+    for (int i = 0; i + 1 < max_new; ++i) {
+      HIP_TRY(hipGraphLaunch(h->dec_graph, s));
+      ++steps_run;
+      if ((i & 7) == 7) {   // every 8 tokens: has every clip produced its EOT?  (nothing after it is returned)
+        HIP_TRY(hipMemcpyAsync(&done, h->d_done_count, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (done >= batch) break;
+      }
+    }
   }
   // the last pick needs no further decoder step
   HIP_TRY(argmax_f32(h->d_logits, h->d_suppress, h->d_suppress_first, h->d_counters + 1, V, h->d_tok, h->d_tokens_all,
-                     h->d_best, batch, s));
-  std::vector<int> all((size_t)max_new * batch);
-  std::vector<float> best((size_t)max_new * batch);
-  HIP_TRY(hipMemcpyAsync(all.data(), h->d_tokens_all, all.size() * sizeof(int), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(best.data(), h->d_best, best.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+                     h->d_best, batch, s, h->eot, h->d_finished, h->d_done_count));
+  std::vector<int> all((size_t)max_new * batch, h->eot);
+  std::vector<float> best((size_t)max_new * batch, 0.f);
+  HIP_TRY(hipMemcpyAsync(all.data(), h->d_tokens_all, (size_t)steps_run * batch * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(best.data(), h->d_best, (size_t)steps_run * batch * sizeof(float), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   for (int b = 0; b < batch; ++b) {
     int n = max_new;

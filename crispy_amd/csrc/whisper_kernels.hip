@@ -463,7 +463,8 @@ __global__ __launch_bounds__(256) void embed_kernel(const int* __restrict__ toke
 __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, const unsigned char* __restrict__ mask,
                                                      const unsigned char* __restrict__ mask_first,
                                                      const int* __restrict__ step_dev, int V, int* __restrict__ tokens_out,
-                                                     int* __restrict__ tokens_all, float* __restrict__ best_logit) {
+                                                     int* __restrict__ tokens_all, float* __restrict__ best_logit,
+                                                     int eot, int* __restrict__ finished, int* __restrict__ done_count) {
   __shared__ float sv[256];
   __shared__ int si[256];
   const int b = blockIdx.x;
@@ -491,6 +492,8 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ l
     tokens_out[b] = si[0];
     if (tokens_all) tokens_all[(long)step * gridDim.x + b] = si[0];
     if (best_logit) best_logit[(long)step * gridDim.x + b] = sv[0];
+    // first EOT of this clip: the host polls done_count and stops replaying the step graph once every clip has one
+    if (finished && si[0] == eot && !finished[b]) { finished[b] = 1; atomicAdd(done_count, 1); }
   }
 }
 
@@ -624,9 +627,10 @@ hipError_t embed_tokens_f32(const int* tokens, const float* tok_emb, const float
   return hipGetLastError();
 }
 hipError_t argmax_f32(const float* logits, const unsigned char* mask, const unsigned char* mask_first,
-                      const int* step_dev, int V, int* tokens_out, int* tokens_all, float* best, int B, hipStream_t s) {
+                      const int* step_dev, int V, int* tokens_out, int* tokens_all, float* best, int B, hipStream_t s,
+                      int eot, int* finished, int* done_count) {
   hipLaunchKernelGGL(argmax_kernel, dim3(B), dim3(256), 0, s, logits, mask, mask_first, step_dev, V, tokens_out,
-                     tokens_all, best);
+                     tokens_all, best, eot, finished, done_count);
   return hipGetLastError();
 }
 hipError_t ts_pick(const TsPickArgs& a, int B, hipStream_t s) {

@@ -132,6 +132,12 @@ def test_suppression_masks_and_batch_invariance(tiny, model):
     m2.set_default_suppression()
     d, _ = m2.transcribe_tokens(clips[:2], prompt, 6)
     assert d.max() <= 50257 and d[0, 0] not in (220, 50257)
+    # EOT handling: clip 0 may only say EOT or its free first pick, so it ends at once or never; a batch whose clips
+    # have all produced EOT stops replaying the decoder (polled every 8 tokens) and pads the rest with EOT
+    m2.set_suppress([], first_only=True)
+    m2.set_suppress(np.setdiff1d(np.arange(hp.n_vocab), [50257]))
+    t, n = m2.transcribe_tokens(clips[:3], prompt, 40)
+    assert (t == 50257).all() and (n == 0).all()
 
 
 def test_decode_argument_checks(model):
