@@ -263,10 +263,17 @@ def main():
         # HBM traffic per launch from the committed PMC passes (rocprofv3 cannot run inside this process);
         # only quoted when it was measured on this exact launch shape.
         traffic = None
+        valu = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_v2_pmc_hbm.json")))
-            if pm["config"] == {"streams": B, "frames_per_launch": min(T, fpl)}:
-                traffic = pm["rn_frame_kernel"]["hbm_bytes_per_launch"]
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc.json")))
+            if (pm["config"]["streams"], pm["config"]["frames_per_launch"]) == (B, min(T, fpl)):
+                fk = pm["rn_frame_kernel"]
+                traffic = fk["hbm_bytes_per_launch"]
+                # what actually bounds this kernel: VALU issue slots.  SQ_ACTIVE_INST_VALU counts 4-cycle issue
+                # slots; 1024 SIMDs; priced against the live kernel time at the 2.4 GHz peak clock.
+                valu = {"insts_per_stream_frame": fk["per_stream_frame"]["valu"],
+                        "issue_frac": fk["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * frame_ms * 1e-3 * 2.4e9),
+                        "source": "profiles/r01b_pmc.json (rocprofv3 --pmc SQ_ACTIVE_INST_VALU), live kernel time"}
         except Exception:
             pass
         achieved = alg_bytes / (frame_ms * 1e-3) / 1e9
@@ -286,7 +293,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "rn_frame_kernel", "kernel_ms": frame_ms, "launches_per_step": launches,
                          "enqueue_ms": total_ms,
-                         "alg_bytes_per_launch": alg_bytes},
+                         "alg_bytes_per_launch": alg_bytes, "valu": valu},
         }
         if world == 1 and not args.no_cpu_baseline:
             ncores = os.cpu_count() or 1

@@ -1,0 +1,37 @@
+#!/bin/bash
+# Run ON THE GPU BOX (via gpurun): kernel-trace statistics of the default bench and PMC passes over the RNNoise
+# frame kernel.  Counter passes are separate runs with no trace domains, as the pool requires.
+#   tools/collect_profiles.sh <tag>        -> gpurun_out/<tag>_*  (+ <tag>_pmc.json summary)
+set -u
+tag=${1:-prof}
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+out=$PWD/gpurun_out
+mkdir -p $out
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_trace.log 2>&1
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+           "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" "SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
+           "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_INSTS_SMEM SQ_WAVES"; do
+  name=$(echo $grp | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --pmc $grp --output-format csv -d $out/${tag}_pmc_$name -- python tools/pmc_frame.py > $out/${tag}_pmc_$name.log 2>&1
+done
+python - "$out" "$tag" <<'PY'
+import csv, glob, json, os, sys
+out, tag = sys.argv[1], sys.argv[2]
+acc = {}
+for f in glob.glob(os.path.join(out, f"{tag}_pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "rn_" not in k:
+            continue
+        short = "rn_frame_kernel" if "rn_frame_kernel" in k else ("rn_highpass_kernel" if "highpass" in k else ("rn_roll_history_kernel" if "roll" in k else k[:40]))
+        d = acc.setdefault(short, {}).setdefault(r["Counter_Name"], [])
+        d.append(float(r["Counter_Value"]))
+summ = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
+for k, cs in summ.items():
+    cs["_dispatches_seen"] = max(len(v) for v in acc[k].values())
+json.dump(summ, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1)
+print(json.dumps(summ.get("rn_frame_kernel", {}), indent=1))
+PY
+f=$(find $out/${tag}_trace -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && cp "$f" $out/${tag}_kernel_stats.csv && head -12 "$f"
