@@ -489,6 +489,44 @@ __device__ __forceinline__ Cand wave_best(Cand c) {
   return c;
 }
 
+// Inner products of x[0, 480) with NL lagged windows of the same LDS buffer, reduced over the wave:
+// sxy[q] = sum_j x[j] y_q[j], and with SQ also syy[q] = sum_j y_q[j]^2.  xr / yr[q] already include the lane
+// offset, so every read is one ds_read_b32 with an immediate offset (64 m); the NL (or 2 NL) accumulation chains
+// and their DPP reductions are independent, which is what hides the LDS and cross-lane latencies -- the loops
+// these replace did one dependent wave reduction per lag.
+template <int NL, bool SQ>
+__device__ __forceinline__ void lag_dots(const float* xr, const float* const (&yr)[NL], int lane, float (&sxy)[NL],
+                                         float (&syy)[NL]) {
+  float xv[8];
+#pragma unroll
+  for (int m = 0; m < 7; ++m) xv[m] = xr[WAVE * m];
+#pragma unroll
+  for (int q = 0; q < NL; ++q) { sxy[q] = 0.f; syy[q] = 0.f; }
+#pragma unroll
+  for (int q = 0; q < NL; ++q) {
+#pragma unroll
+    for (int m = 0; m < 7; ++m) {
+      const float y = yr[q][WAVE * m];
+      sxy[q] = fmaf(xv[m], y, sxy[q]);
+      if (SQ) syy[q] = fmaf(y, y, syy[q]);
+    }
+  }
+  if (lane < 32) {   // j = 448 + lane < 480
+    xv[7] = xr[WAVE * 7];
+#pragma unroll
+    for (int q = 0; q < NL; ++q) {
+      const float y = yr[q][WAVE * 7];
+      sxy[q] = fmaf(xv[7], y, sxy[q]);
+      if (SQ) syy[q] = fmaf(y, y, syy[q]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NL; ++q) {
+    sxy[q] = wave_sum(sxy[q]);
+    if (SQ) syy[q] = wave_sum(syy[q]);
+  }
+}
+
 // =============================================================================================
 // frame kernel: one wave per stream, loops over the T frames of the call
 // =============================================================================================
@@ -762,25 +800,29 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
       const int ca = 2 * min(best0, best1), cb = 2 * max(best0, best1);
       Cand bestc = {-1.f, 0.f, 0};
       bool any = false;
-      for (int pass = 0; pass < 2; ++pass) {
-        const int cen = pass == 0 ? ca : cb;
-        for (int d = -2; d <= 2; ++d) {
-          const int i = cen + d;
-          if (i < 0 || i >= 294) continue;
-          if (pass == 1 && abs(i - ca) <= 2) continue;
-          float sxy = 0.f, syy = 0.f;
-          for (int j = lane; j < 480; j += WAVE) {
-            const float yv = lp[i + j];
-            sxy = fmaf(lp[384 + j], yv, sxy);
-            syy = fmaf(yv, yv, syy);
-          }
-          sxy = wave_sum(sxy);
-          syy = fmaxf(1.f, 1.f + wave_sum(syy));
-          const float xv = fmaxf(-1.f, sxy);
-          if (lane == 0) fine[i] = xv;
+      // all (up to) ten lags ca-2..ca+2, cb-2..cb+2 in one pass; skipped ones are computed at lag 0 and ignored
+      int lagi[10];
+      bool use[10];
+      const float* yr[10];
+#pragma unroll
+      for (int q = 0; q < 10; ++q) {
+        const int pass = q / 5, d = q % 5 - 2;
+        const int i = (pass == 0 ? ca : cb) + d;
+        use[q] = !(i < 0 || i >= 294) && !(pass == 1 && abs(i - ca) <= 2);
+        lagi[q] = use[q] ? i : 0;
+        yr[q] = lp + lagi[q] + lane;
+      }
+      float sxy[10], syy[10];
+      lag_dots<10, true>(lp + 384 + lane, yr, lane, sxy, syy);
+#pragma unroll
+      for (int q = 0; q < 10; ++q) {
+        if (use[q]) {
+          const float syq = fmaxf(1.f, 1.f + syy[q]);
+          const float xv = fmaxf(-1.f, sxy[q]);
+          if (lane == 0) fine[lagi[q]] = xv;
           if (xv > 0.f) {
             const float x16 = xv * 1e-12f;
-            const Cand c = {x16 * x16, syy, i};
+            const Cand c = {x16 * x16, syq, lagi[q]};
             if (!any || cand_better(c, bestc)) { bestc = c; any = true; }
           }
         }
@@ -813,14 +855,14 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
       const int prev_period = last_period / 2;
       if (T0 >= 384) T0 = 383;
       int T = T0;
-      float xx = 0.f, xy = 0.f;
-      for (int j = lane; j < 480; j += WAVE) {
-        const float v = x[j];
-        xx = fmaf(v, v, xx);
-        xy = fmaf(v, x[j - T0], xy);
+      float xx, xy;
+      {
+        const float* yr[2] = {x + lane, x - T0 + lane};
+        float sa[2], sb[2];
+        lag_dots<2, false>(x + lane, yr, lane, sa, sb);
+        xx = sa[0];
+        xy = sa[1];
       }
-      xx = wave_sum(xx);
-      xy = wave_sum(xy);
       // yy_lookup[m] = max(0, xx + sum_{q<=m} (x[-q]^2 - x[480-q]^2)) via a wave prefix sum
       float* yyl = Sa + 296;  // 385 entries
       {
@@ -849,41 +891,73 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
       float best_xy = xy, best_yy = yy;
       const float g0 = xy / sqrtf(1.f + xx * yy);
       float g = g0;
-      for (int k = 2; k <= 15; ++k) {
-        const int T1 = (2 * T0 + k) / (2 * k);
-        if (T1 < 30) break;
-        int T1b;
-        if (k == 2) T1b = (T1 + T0 > 384) ? T0 : T0 + T1;
-        else T1b = (2 * c_second_check[k] * T0 + k) / (2 * k);
-        float s1 = 0.f, s2 = 0.f;
-        for (int j = lane; j < 480; j += WAVE) {
-          const float v = x[j];
-          s1 = fmaf(v, x[j - T1], s1);
-          s2 = fmaf(v, x[j - T1b], s2);
+      // The candidate lags depend on T0 only, so the (up to) 28 inner products are taken in chunks of four k
+      // (eight lags) with independent accumulation chains and reductions; T1 falls with k, so the reference's
+      // `break` at T1 < 30 is a prefix: a chunk is skipped when its first k is already out, and the sequential
+      // threshold logic below runs on the stored sums.
+      float xyk_[14], yyk_[14];
+      int T1_[14];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k0 = 2 + 4 * c;
+        if ((2 * T0 + k0) / (2 * k0) >= 30) {
+          constexpr int NKC = 4;
+          const float* yr[2 * NKC];
+          int t1[NKC], t1b[NKC];
+#pragma unroll
+          for (int q = 0; q < NKC; ++q) {
+            const int k = k0 + q;
+            t1[q] = 0; t1b[q] = 0;
+            if (k <= 15) {
+              const int T1 = (2 * T0 + k) / (2 * k);
+              if (T1 >= 30) {
+                t1[q] = T1;
+                if (k == 2) t1b[q] = (T1 + T0 > 384) ? T0 : T0 + T1;
+                else t1b[q] = (2 * c_second_check[k] * T0 + k) / (2 * k);
+              }
+            }
+            yr[2 * q] = x - t1[q] + lane;
+            yr[2 * q + 1] = x - t1b[q] + lane;
+          }
+          float sa[2 * NKC], sb[2 * NKC];
+          lag_dots<2 * NKC, false>(x + lane, yr, lane, sa, sb);
+#pragma unroll
+          for (int q = 0; q < NKC; ++q) {
+            if (k0 + q <= 15) {
+              T1_[k0 + q - 2] = t1[q];
+              xyk_[k0 + q - 2] = .5f * (sa[2 * q] + sa[2 * q + 1]);
+              yyk_[k0 + q - 2] = .5f * (yyl[t1[q]] + yyl[t1b[q]]);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (k0 + q <= 15) { T1_[k0 + q - 2] = 0; xyk_[k0 + q - 2] = 0.f; yyk_[k0 + q - 2] = 0.f; }
         }
-        s1 = wave_sum(s1);
-        s2 = wave_sum(s2);
-        const float xyk = .5f * (s1 + s2);
-        const float yyk = .5f * (yyl[T1] + yyl[T1b]);
-        const float g1 = xyk / sqrtf(1.f + xx * yyk);
-        float cont;
-        if (abs(T1 - prev_period) <= 1) cont = last_gain;
-        else if (abs(T1 - prev_period) <= 2 && 5 * k * k < T0) cont = .5f * last_gain;
-        else cont = 0.f;
-        float thresh = fmaxf(.3f, .7f * g0 - cont);
-        if (T1 < 90) thresh = fmaxf(.4f, .85f * g0 - cont);
-        else if (T1 < 60) thresh = fmaxf(.5f, .9f * g0 - cont);
-        if (g1 > thresh) { best_xy = xyk; best_yy = yyk; T = T1; g = g1; }
+      }
+#pragma unroll
+      for (int k = 2; k <= 15; ++k) {
+        const int T1 = T1_[k - 2];
+        if (T1 >= 30) {       // (zero marks k past the reference's break)
+          const float xyk = xyk_[k - 2], yyk = yyk_[k - 2];
+          const float g1 = xyk / sqrtf(1.f + xx * yyk);
+          float cont;
+          if (abs(T1 - prev_period) <= 1) cont = last_gain;
+          else if (abs(T1 - prev_period) <= 2 && 5 * k * k < T0) cont = .5f * last_gain;
+          else cont = 0.f;
+          float thresh = fmaxf(.3f, .7f * g0 - cont);
+          if (T1 < 90) thresh = fmaxf(.4f, .85f * g0 - cont);
+          else if (T1 < 60) thresh = fmaxf(.5f, .9f * g0 - cont);
+          if (g1 > thresh) { best_xy = xyk; best_yy = yyk; T = T1; g = g1; }
+        }
       }
       best_xy = fmaxf(0.f, best_xy);
       float pgv = (best_yy <= best_xy) ? 1.f : best_xy / (best_yy + 1.f);
       float xc3[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        float s = 0.f;
-        const int lag = T + k - 1;
-        for (int j = lane; j < 480; j += WAVE) s = fmaf(x[j], x[j - lag], s);
-        xc3[k] = wave_sum(s);
+      {
+        const float* yr[3] = {x - (T - 1) + lane, x - T + lane, x - (T + 1) + lane};
+        float sb[3];
+        lag_dots<3, false>(x + lane, yr, lane, xc3, sb);
       }
       int offset = 0;
       if ((xc3[2] - xc3[0]) > .7f * (xc3[1] - xc3[0])) offset = 1;

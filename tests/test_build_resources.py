@@ -1,12 +1,13 @@
-"""Register / scratch budget of the RNNoise kernels (cross-compiled here, no GPU needed).
+"""Register / LDS / scratch budget of the RNNoise kernels (cross-compiled here, no GPU needed).
 
-The frame kernel is sized for 4 waves per SIMD (<= 128 VGPRs) and 16 workgroups per CU (<= 10 KB LDS).  Scratch
-inside the frame loop is a *correctness* hazard with this compiler (spill stores of a join block are emitted
-before its exec restore, see rn_kernels.hip: dotn_h), so the scratch size is pinned: the 12 bytes allowed are
-loop-invariant LDS addresses spilled in the prologue under a full exec mask."""
+The frame kernel is sized for 4 waves per SIMD (<= 128 VGPRs) and 16 workgroups per CU (<= 10 KB LDS).
+Spills inside the frame loop are a *correctness* hazard with this compiler: VGPR spill stores of a join block
+are emitted before the block's exec restore, so a value spilled right after a divergent region is saved for
+the active lanes only (see rn_kernels.hip: dotn_h).  Loop-invariant values spilled once in the prologue, under
+a full exec mask, are fine -- so the invariant checked on the ISA is "no scratch store after the first loop
+header" (reloads inside the loop are harmless)."""
 import os
 import re
-import shutil
 import subprocess
 
 import pytest
@@ -18,9 +19,10 @@ HIPCC = "/opt/rocm/bin/hipcc"
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_frame_kernel_resource_budget(tmp_path):
     src = os.path.join(ROOT, "crispy_amd", "csrc", "rn_kernels.hip")
+    asm = tmp_path / "rn.s"
     out = subprocess.run(
-        [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function",
-         "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", str(tmp_path / "rn.o")],
+        [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "--cuda-device-only", "-S",
+         "-Rpass-analysis=kernel-resource-usage", src, "-o", str(asm)],
         capture_output=True, text=True, timeout=600, cwd=os.path.dirname(src))
     assert out.returncode == 0, out.stderr[-2000:]
     res = {}
@@ -36,8 +38,13 @@ def test_frame_kernel_resource_budget(tmp_path):
             res[cur][m.group(1).strip()] = int(m.group(2))
     frame = {k: v for k, v in res.items() if "rn_frame_kernel" in k}
     assert len(frame) == 3, list(res)
+    text = asm.read_text()
     for name, r in frame.items():
         assert r["VGPRs"] + r.get("AGPRs", 0) <= 128, (name, r)
         assert r["LDS Size"] <= 10240, (name, r)
-        limit = 12 if "ILi0E" in name else 0
-        assert r["ScratchSize"] <= limit, (name, r)
+        assert r["ScratchSize"] <= 64, (name, r)
+        body = text[text.index(name + ":"):]
+        body = body[:body.index("s_endpgm")]
+        loop = body.find("=>This Loop Header: Depth=1")     # the frame loop (the prologue's copy loops are "Inner")
+        assert loop > 0, name
+        assert "scratch_store" not in body[loop:], f"{name}: VGPR spill store inside the frame loop"
