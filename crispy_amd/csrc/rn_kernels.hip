@@ -463,7 +463,7 @@ static_assert(sizeof(RnLdsT<0>) <= 10240, "16 workgroups per CU need <= 10 KB of
 // offsets (floats) inside Bb while it serves the RNN
 constexpr int RB_FEAT = 0, RB_DENSE = 48, RB_IN = 72, RB_Z = 192, RB_HR = 288, RB_PART = 384;
 // offsets inside U outside band_sums
-constexpr int U_LY = 0, U_TMP = 24, U_G = 48, U_R = 72, U_VAD = 96;
+constexpr int U_LY = 0, U_G = 48, U_R = 72, U_VAD = 96;
 
 // top-2 bookkeeping of find_best_pitch as an ordering on (num, den, idx)
 struct Cand {
@@ -1019,6 +1019,14 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
     STAMP(8)
 
     // ---- 7. features (Appendix A.3 step 5) ----
+    // this lane's column of the DCT table serves both transforms; issued first so that the L2 round trip
+    // overlaps the band normalisation below
+    float dctc[RN_NB];
+    {
+      const float* __restrict__ dcol = tab->dct + min(lane, RN_NB - 1);
+#pragma unroll
+      for (int j = 0; j < RN_NB; ++j) dctc[j] = dcol[j * RN_NB];
+    }
     if (lane < RN_NB) {
       L.Exp[lane] = L.Exp[lane] / sqrtf(.001f + L.Ex[lane] * L.Ep[lane]);
       L.U[U_LY + lane] = log10f(1e-2f + L.Ex[lane]);
@@ -1031,44 +1039,51 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
       D[2840 + lane] = L.Exp[lane];
     }
     const float dct_norm = 0.30151134457776363f;  // sqrt(2/22)
-    if (lane < 6) {
-      float sum = 0.f;
-      for (int j = 0; j < RN_NB; ++j) sum = fmaf(L.Exp[j], tab->dct[j * RN_NB + lane], sum);
-      float v = sum * dct_norm;
-      if (lane == 0) v -= 1.3f;
-      if (lane == 1) v -= 0.9f;
-      Rb[RB_FEAT + 34 + lane] = v;
-    }
-    if (lane == 6) Rb[RB_FEAT + 40] = .01f * (float)(pitch_index - 300);
     float E = 0.f;
+    float se = 0.f, sl = 0.f;
     {
+      // The band follower is a 22-step recurrence: every lane runs it on broadcast reads and feeds its own DCT
+      // sums on the way -- of the followed log energies (22 coefficients) and of the band correlation (6), which
+      // share this lane's table column.
       float logMax = -2.f, follow = -2.f;
+#pragma unroll
       for (int i = 0; i < RN_NB; ++i) {
         float ly = L.U[U_LY + i];
         ly = fmaxf(logMax - 7.f, fmaxf(follow - 1.5f, ly));
         logMax = fmaxf(logMax, ly);
         follow = fmaxf(follow - 1.5f, ly);
         E += L.Ex[i];
-        if (lane == i) L.U[U_TMP + i] = ly;
+        sl = fmaf(ly, dctc[i], sl);
+        se = fmaf(L.Exp[i], dctc[i], se);
+        if (i % 4 == 3) {   // bound the live ranges: all 66 broadcast reads hoisted to the top would spill
+          asm volatile("" : "+v"(sl), "+v"(se), "+v"(E), "+v"(logMax), "+v"(follow));
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
-    __syncthreads();
-    silence = E < 0.04f;
-    if (silence) {
-      if (lane < RN_NFEAT) Rb[RB_FEAT + lane] = 0.f;
-      if (lane < RN_NB) L.U[U_G + lane] = 0.f;
-      __syncthreads();
-    } else {
-      if (lane < RN_NB) {
-        float sum = 0.f;
-        for (int j = 0; j < RN_NB; ++j) sum = fmaf(L.U[U_TMP + j], tab->dct[j * RN_NB + lane], sum);
-        float v = sum * dct_norm;
+    {
+      if (lane < 6) {
+        float v = se * dct_norm;
+        if (lane == 0) v -= 1.3f;
+        if (lane == 1) v -= 0.9f;
+        Rb[RB_FEAT + 34 + lane] = v;
+      }
+      if (lane == 6) Rb[RB_FEAT + 40] = .01f * (float)(pitch_index - 300);
+      silence = E < 0.04f;
+      if (!silence && lane < RN_NB) {
+        float v = sl * dct_norm;
         if (lane == 0) v -= 12.f;
         if (lane == 1) v -= 4.f;
         Rb[RB_FEAT + lane] = v;
         L.ceps[memid * RN_NB + lane] = v;
       }
+    }
+    __syncthreads();
+    if (silence) {
+      if (lane < RN_NFEAT) Rb[RB_FEAT + lane] = 0.f;
+      if (lane < RN_NB) L.U[U_G + lane] = 0.f;
       __syncthreads();
+    } else {
       {
         const int m1 = (memid < 1) ? 8 + memid - 1 : memid - 1;
         const int m2 = (memid < 2) ? 8 + memid - 2 : memid - 2;
@@ -1083,20 +1098,21 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
         memid = (memid + 1 == 8) ? 0 : memid + 1;
       }
       {
-        // spectral variability: lane = 8*i + j holds ||ceps_i - ceps_j||^2
+        // spectral variability: lane = 8*i + j holds ||ceps_i - ceps_j||^2; min over j within each group of 8
+        // lanes and the sum over the 8 groups by DPP (every lane of a group ends up with the group minimum, so
+        // the wave sum counts each minimum eight times)
         const int ci = lane >> 3, cj = lane & 7;
         float dist = 0.f;
+#pragma unroll
         for (int k = 0; k < RN_NB; ++k) {
           const float d = L.ceps[ci * RN_NB + k] - L.ceps[cj * RN_NB + k];
           dist = fmaf(d, d, dist);
         }
         float md = (ci == cj) ? 1e15f : dist;
-        md = fminf(md, __shfl_xor(md, 1, WAVE));
-        md = fminf(md, __shfl_xor(md, 2, WAVE));
-        md = fminf(md, __shfl_xor(md, 4, WAVE));
-        float sv = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) sv += __shfl(md, 8 * i, WAVE);
+        md = fminf(md, dpp_mov<0xB1>(md));     // quad_perm [1,0,3,2]
+        md = fminf(md, dpp_mov<0x4E>(md));     // quad_perm [2,3,0,1]
+        md = fminf(md, dpp_mov<0x141>(md));    // row_half_mirror: the other quad of the group of 8
+        const float sv = wave_sum(md) * .125f;
         if (lane == 0) Rb[RB_FEAT + 41] = sv / 8.f - 2.1f;
       }
       __syncthreads();
