@@ -1193,28 +1193,65 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
       }  // MODE == 0
 
       // ---- 9. pitch_filter + gain application (Appendix A.3 step 7) ----
-      if (lane < RN_NB) {
-        const float ex = L.Exp[lane], gg = L.U[U_G + lane];
-        float r;
-        if (ex > gg) r = 1.f;
-        else r = (ex * ex) * (1.f - gg * gg) / (.001f + (gg * gg) * (1.f - ex * ex));
-        r = sqrtf(fminf(1.f, fmaxf(0.f, r)));
-        r *= sqrtf(L.Ex[lane] / (1e-8f + L.Ep[lane]));
-        L.U[U_R + lane] = r;
+      // Pair layout: lane handles bins (2p, 2p+1), p = lane + 64 m -- one ds_read_b128 / one 16-byte global load
+      // per pair at a 16-byte lane stride (conflict-free, coalesced), and a pair never straddles a band (edges are
+      // multiples of 4 bins).  The new band energies are summed from the registers of the comb-filter pass.
+      // (Keeping X in registers up to the final gains as well costs 16 VGPRs across two barriers and spills.)
+      float2 fq[4];
+      int bq[4];
+      {
+        float4 pq[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {       // parked pitch spectrum and the per-bin tables: issued before r is ready
+          const int pidx = min(lane + WAVE * m, 199);
+          pq[m] = *reinterpret_cast<const float4*>(pg + 2 * pidx);
+          fq[m] = *reinterpret_cast<const float2*>(tab->bin_frac + 2 * pidx);
+          bq[m] = tab->bin_band[2 * pidx];
+        }
+        if (lane < RN_NB) {
+          const float ex = L.Exp[lane], gg = L.U[U_G + lane];
+          float r;
+          if (ex > gg) r = 1.f;
+          else r = (ex * ex) * (1.f - gg * gg) / (.001f + (gg * gg) * (1.f - ex * ex));
+          r = sqrtf(fminf(1.f, fmaxf(0.f, r)));
+          r *= sqrtf(L.Ex[lane] / (1e-8f + L.Ep[lane]));
+          L.U[U_R + lane] = r;
+        }
+        __syncthreads();
+        float* part = Rb + (MODE == 2 ? 0 : RB_PART);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int pidx = lane + WAVE * m;
+          if (pidx < 200) {
+            const float r0 = L.U[U_R + bq[m]], r1 = L.U[U_R + bq[m] + 1];
+            const float rf0 = (1.f - fq[m].x) * r0 + fq[m].x * r1;
+            const float rf1 = (1.f - fq[m].y) * r0 + fq[m].y * r1;
+            float4 x = *reinterpret_cast<const float4*>(L.A + 2 * pidx);
+            x.x = fmaf(rf0, pq[m].x, x.x);
+            x.y = fmaf(rf0, pq[m].y, x.y);
+            x.z = fmaf(rf1, pq[m].z, x.z);
+            x.w = fmaf(rf1, pq[m].w, x.w);
+            *reinterpret_cast<float4*>(L.A + 2 * pidx) = x;
+            float e0 = x.x * x.x; e0 += x.y * x.y;
+            float e1 = x.z * x.z; e1 += x.w * x.w;
+            float lo = (1.f - fq[m].x) * e0 + (1.f - fq[m].y) * e1;
+            float hi = fq[m].x * e0 + fq[m].y * e1;
+            lo += dpp_mov<0xB1>(lo);        // the other pair of this 4-bin chunk sits in the neighbouring lane
+            hi += dpp_mov<0xB1>(hi);
+            if ((lane & 1) == 0) { part[pidx >> 1] = lo; part[100 + (pidx >> 1)] = hi; }
+          }
+        }
       }
       __syncthreads();
-      for (int i = lane; i < 400; i += WAVE) {
-        const float rf = interp_gain(L.U + U_R, tab->bin_band[i], tab->bin_frac[i]);
-        float2 x = L.A[i];
-        const float2 p = pg[i];
-        x.x = fmaf(rf, p.x, x.x);
-        x.y = fmaf(rf, p.y, x.y);
-        L.A[i] = x;
-      }
-      __syncthreads();
-      band_sums<false, false>(L.A, nullptr, Rb + (MODE == 2 ? 0 : RB_PART), L.Ep, tab, be, lane);  // newE (Ep is dead)
-      if (lane < RN_NB) {
-        L.U[U_R + lane] = sqrtf(L.Ex[lane] / (1e-8f + L.Ep[lane]));  // norm
+      if (lane < RN_NB) {        // new band energies (Ep is dead), then the renormalisation and the smoothed gains
+        float* part = Rb + (MODE == 2 ? 0 : RB_PART);
+        float sum = 0.f;
+        if (lane > 0)
+          for (int c = be.em1; c < be.e0; ++c) sum += part[100 + c];
+        if (lane < RN_NB - 1)
+          for (int c = be.e0; c < be.e1; ++c) sum += part[c];
+        if (lane == 0 || lane == RN_NB - 1) sum *= 2.f;
+        L.U[U_R + lane] = sqrtf(L.Ex[lane] / (1e-8f + sum));  // norm
         float gg;
         if constexpr (MODE == 2) gg = a.g_smooth[((long)t * a.B + b) * RNN_GAIN_LD + lane];   // smoothing state lives in the gain-network kernel
         else gg = fmaxf(L.U[U_G + lane], .6f * lastg);
@@ -1222,19 +1259,21 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
         lastg = gg;
       }
       __syncthreads();
-      for (int i = lane; i < RN_NFREQ; i += WAVE) {
-        float2 x = make_float2(0.f, 0.f);
-        if (i < 400) {
-          const int band = tab->bin_band[i];
-          const float frac = tab->bin_frac[i];
-          const float nf = interp_gain(L.U + U_R, band, frac);
-          const float gf = interp_gain(L.U + U_G, band, frac);
-          x = L.A[i];
-          x.x *= nf; x.y *= nf;
-          x.x *= gf; x.y *= gf;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int pidx = lane + WAVE * m;
+        if (pidx < 200) {
+          const float n0 = L.U[U_R + bq[m]], n1 = L.U[U_R + bq[m] + 1];
+          const float g0 = L.U[U_G + bq[m]], g1 = L.U[U_G + bq[m] + 1];
+          const float nf0 = (1.f - fq[m].x) * n0 + fq[m].x * n1, nf1 = (1.f - fq[m].y) * n0 + fq[m].y * n1;
+          const float gf0 = (1.f - fq[m].x) * g0 + fq[m].x * g1, gf1 = (1.f - fq[m].y) * g0 + fq[m].y * g1;
+          float4 x = *reinterpret_cast<const float4*>(L.A + 2 * pidx);
+          x.x *= nf0; x.y *= nf0; x.z *= nf1; x.w *= nf1;
+          x.x *= gf0; x.y *= gf0; x.z *= gf1; x.w *= gf1;
+          *reinterpret_cast<float4*>(L.A + 2 * pidx) = x;
         }
-        L.A[i] = x;
       }
+      for (int i = 400 + lane; i < RN_NFREQ; i += WAVE) L.A[i] = make_float2(0.f, 0.f);   // above 20 kHz
       __syncthreads();
     }
     STAMP(13)
