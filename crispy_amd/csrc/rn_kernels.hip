@@ -27,8 +27,11 @@ constexpr int RN_SYNTH_GROUP = 5;   // frames per synthesis workgroup (plus one 
 
 // In-kernel stage stamps (diagnostic build only: make PROFILE=1 -> libcrispy_hip_prof.so).
 #ifdef RN_PROFILE
-#define RN_PROF_DECL long long prof_[24] = {0}; long long tprev_ = clock64();
-#define STAMP(k) { const long long tn_ = clock64(); prof_[k] += tn_ - tprev_; tprev_ = tn_; }
+// Stage stamps accumulate straight into the debug buffer (one lane, global read-modify-write): 24 counters in
+// registers pushed the frame loop into scratch, which this compiler does not handle safely (see dotn_h).
+#define RN_PROF_DECL long long tprev_ = clock64(); \
+  float* profp_ = a.dbg ? a.dbg + (long)blockIdx.x * RN_DBG_FLOATS + 3824 : nullptr;
+#define STAMP(k) { const long long tn_ = clock64(); if (profp_ && threadIdx.x == 0) profp_[k] += (float)(tn_ - tprev_); tprev_ = tn_; }
 #else
 #define RN_PROF_DECL
 #define STAMP(k)
@@ -210,46 +213,65 @@ struct BandEdges {
   int em1, e0, e1;
 };
 
-template <bool CORR, bool PGLOBAL>
-__device__ __forceinline__ void band_sums(const float2* X, const float2* P, float* part, float* E,
-                                          const RnTables* __restrict__ tab, const BandEdges& be, int lane) {
+// Band energies in the pair layout of the comb-filter stage: lane handles bins (2p, 2p+1), p = lane + 64 m, with
+// one ds_read_b128 per spectrum; the two pairs of a 4-bin chunk are neighbouring lanes (one DPP add), even lanes
+// write the chunk partials, 22 lanes add them up (deterministic, no atomics).  With CORR the same pass also yields
+// the band correlation Re(X P*) against a second spectrum and parks S in global memory from the registers.
+//   E[band]  of S            -> Eout
+//   C[band]  of (Xc, S)      -> Cout   (CORR)
+template <bool CORR>
+__device__ __forceinline__ void band_pairs(const float2* S, const float2* Xc, float* part, float* Eout, float* Cout,
+                                           float2* park, const RnTables* __restrict__ tab, const BandEdges& be,
+                                           int lane) {
+  float clo[4], chi[4];
 #pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    const int c = lane + WAVE * m;
-    if (c < 100) {
-      const float4 fr = *reinterpret_cast<const float4*>(tab->bin_frac + 4 * c);
-      const float f[4] = {fr.x, fr.y, fr.z, fr.w};
-      float lo = 0.f, hi = 0.f;
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const float2 x = X[4 * c + jj];
-        float tmp;
-        if (CORR) {
-          const float2 p = P[4 * c + jj];
-          tmp = x.x * p.x;
-          tmp += x.y * p.y;
-        } else {
-          tmp = x.x * x.x;
-          tmp += x.y * x.y;
-        }
-        lo += (1.f - f[jj]) * tmp;
-        hi += f[jj] * tmp;
+  for (int m = 0; m < 4; ++m) {
+    const int pidx = lane + WAVE * m;
+    clo[m] = 0.f; chi[m] = 0.f;
+    if (pidx < 200) {
+      const float2 f = *reinterpret_cast<const float2*>(tab->bin_frac + 2 * pidx);
+      const float4 sv = *reinterpret_cast<const float4*>(S + 2 * pidx);
+      float e0 = sv.x * sv.x; e0 += sv.y * sv.y;
+      float e1 = sv.z * sv.z; e1 += sv.w * sv.w;
+      float lo = (1.f - f.x) * e0 + (1.f - f.y) * e1;
+      float hi = f.x * e0 + f.y * e1;
+      lo += dpp_mov<0xB1>(lo);
+      hi += dpp_mov<0xB1>(hi);
+      if ((lane & 1) == 0) { part[pidx >> 1] = lo; part[100 + (pidx >> 1)] = hi; }
+      if (CORR) {
+        const float4 xv = *reinterpret_cast<const float4*>(Xc + 2 * pidx);
+        float c0 = xv.x * sv.x; c0 += xv.y * sv.y;
+        float c1 = xv.z * sv.z; c1 += xv.w * sv.w;
+        float l2 = (1.f - f.x) * c0 + (1.f - f.y) * c1;
+        float h2 = f.x * c0 + f.y * c1;
+        clo[m] = l2 + dpp_mov<0xB1>(l2);
+        chi[m] = h2 + dpp_mov<0xB1>(h2);
+        if (park) *reinterpret_cast<float4*>(park + 2 * pidx) = sv;
       }
-      part[c] = lo;
-      part[100 + c] = hi;
     }
   }
-  __syncthreads();
-  if (lane < RN_NB) {
-    float sum = 0.f;
-    if (lane > 0)
-      for (int c = be.em1; c < be.e0; ++c) sum += part[100 + c];
-    if (lane < RN_NB - 1)
-      for (int c = be.e0; c < be.e1; ++c) sum += part[c];
-    if (lane == 0 || lane == RN_NB - 1) sum *= 2.f;
-    E[lane] = sum;
+  auto band_total = [&](float* out) {
+    __syncthreads();
+    if (lane < RN_NB) {
+      float sum = 0.f;
+      if (lane > 0)
+        for (int c = be.em1; c < be.e0; ++c) sum += part[100 + c];
+      if (lane < RN_NB - 1)
+        for (int c = be.e0; c < be.e1; ++c) sum += part[c];
+      if (lane == 0 || lane == RN_NB - 1) sum *= 2.f;
+      out[lane] = sum;
+    }
+    __syncthreads();
+  };
+  band_total(Eout);
+  if (CORR) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int pidx = lane + WAVE * m;
+      if (pidx < 200 && (lane & 1) == 0) { part[pidx >> 1] = clo[m]; part[100 + (pidx >> 1)] = chi[m]; }
+    }
+    band_total(Cout);
   }
-  __syncthreads();
 }
 
 // per-bin interpolation of 22 band values (bins >= 400 are zero)
@@ -984,7 +1006,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
     fft480(L.A, w960, lane);
     real_fwd_post(L.A, w960, lane);
     STAMP(5)
-    band_sums<false, false>(L.A, nullptr, Rb, L.Ex, tab, be, lane);
+    band_pairs<false>(L.A, nullptr, Rb, L.Ex, nullptr, nullptr, tab, be, lane);
     STAMP(6)
     if (a.dbg && t == a.T - 1) {
       float* D = a.dbg + (long)b * RN_DBG_FLOATS;
@@ -1006,10 +1028,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
     fft480(L.Bb, w960, lane);
     real_fwd_post(L.Bb, w960, lane);
     STAMP(7)
-    band_sums<false, false>(L.Bb, nullptr, L.U, L.Ep, tab, be, lane);
-    band_sums<true, false>(L.A, L.Bb, L.U, L.Exp, tab, be, lane);
-    // park P in L2 (read back by the comb filter); Bb becomes the RNN workspace
-    for (int i = lane; i < RN_NFREQ; i += WAVE) pg[i] = L.Bb[i];
+    // band energy of P, band correlation with X, and P parked in L2 from the same registers (read back by the comb
+    // filter, which needs bins < 400 only); Bb becomes the RNN workspace
+    band_pairs<true>(L.Bb, L.A, L.U, L.Ep, L.Exp, pg, tab, be, lane);
     if (a.dbg && t == a.T - 1) {
       float* D = a.dbg + (long)b * RN_DBG_FLOATS;
       const float* Pf = reinterpret_cast<const float*>(L.Bb);
@@ -1333,12 +1354,6 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
     STAMP(15)
   }
 
-#ifdef RN_PROFILE
-  if (a.dbg && lane == 0) {
-    float* D = a.dbg + (long)b * RN_DBG_FLOATS;
-    for (int k = 0; k < 24; ++k) D[3824 + k] = (float)prof_[k];
-  }
-#endif
   // ---- store per-stream state (each kernel of the staged pipeline owns its part) ----
   if (MODE == 2 && t_last == a.T) {
 #pragma unroll

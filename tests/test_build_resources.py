@@ -17,12 +17,13 @@ HIPCC = "/opt/rocm/bin/hipcc"
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-def test_frame_kernel_resource_budget(tmp_path):
+@pytest.mark.parametrize("extra", [[], ["-DRN_PROFILE"]], ids=["product", "diagnostic"])
+def test_frame_kernel_resource_budget(tmp_path, extra):
     src = os.path.join(ROOT, "crispy_amd", "csrc", "rn_kernels.hip")
     asm = tmp_path / "rn.s"
     out = subprocess.run(
         [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "--cuda-device-only", "-S",
-         "-Rpass-analysis=kernel-resource-usage", src, "-o", str(asm)],
+         "-Rpass-analysis=kernel-resource-usage", *extra, src, "-o", str(asm)],
         capture_output=True, text=True, timeout=600, cwd=os.path.dirname(src))
     assert out.returncode == 0, out.stderr[-2000:]
     res = {}
