@@ -650,15 +650,23 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
       lp[i] = .5f * (.5f * (x0 + v.y) + v.x);
     }
     __syncthreads();
+    // Each lane owns 14 consecutive half-rate samples (plus a 5-sample halo) in registers: the same window feeds
+    // the autocorrelation partial sums (lags 0..4) and, once the LPC is known, the 5-tap FIR -- no second pass of
+    // LDS reads.  Samples outside [0, 864) are zero, which is also what the reference's `i >= k` guard amounts to.
     float lpc2[5];
+    const int base = lane * 14;
+    float w[19];
+#pragma unroll
+    for (int q = 0; q < 19; ++q) {
+      const int idx = base - 5 + q;
+      w[q] = (idx >= 0 && idx < 864) ? lp[idx] : 0.f;
+    }
     {
       float ac[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-      for (int i = lane; i < 864; i += WAVE) {
-        const float v = lp[i];
-        ac[0] = fmaf(v, v, ac[0]);
 #pragma unroll
-        for (int k = 1; k <= 4; ++k)
-          if (i >= k) ac[k] = fmaf(v, lp[i - k], ac[k]);
+      for (int q = 0; q < 14; ++q) {
+#pragma unroll
+        for (int k = 0; k <= 4; ++k) ac[k] = fmaf(w[q + 5], w[q + 5 - k], ac[k]);
       }
 #pragma unroll
       for (int k = 0; k <= 4; ++k) ac[k] = wave_sum(ac[k]);
@@ -702,14 +710,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
       lpc2[4] = .8f * lpc[3];
     }
     {
-      // 5-tap FIR in place: each lane filters 14 consecutive samples from registers
-      const int base = lane * 14;
-      float w[19];
-#pragma unroll
-      for (int q = 0; q < 19; ++q) {
-        const int idx = base - 5 + q;
-        w[q] = (idx >= 0 && idx < 864) ? lp[idx] : 0.f;
-      }
+      // 5-tap FIR in place from the register window
       float y[14];
 #pragma unroll
       for (int q = 0; q < 14; ++q) {
@@ -744,7 +745,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
         const float* yp0 = y4 + lane;
         const float* yp1 = y4 + min(lane + WAVE, 146);
         const float* yp2 = y4 + min(lane + 2 * WAVE, 146);
-#pragma unroll 2
+#pragma unroll 4
         for (int j4 = 0; j4 < 60; ++j4) {
           const float4 xv = xv4[j4];
           const int j = 4 * j4;
