@@ -153,6 +153,39 @@ __device__ __forceinline__ void fft480(float2* buf, const float2* __restrict__ w
   fft_pass<5, 96>(buf, w960, lane);
 }
 
+// The same transform with the first pass (radix 4, stride 1) fed by a loader instead of LDS: in(j, r) returns point
+// j + 120 r.  The analysis transforms window their input straight from global memory this way, which saves the
+// separate "window -> LDS -> barrier -> read back" phase.  buf must be free (caller synchronised).
+template <class In>
+__device__ __forceinline__ void fft480_from(float2* buf, In in, const float2* __restrict__ w960, int lane) {
+  {
+    float2 o[2][4];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int j = lane + WAVE * nb;
+      if (j < 120) {
+        float2 v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = in(j, r);
+        butterfly<4>(v, o[nb]);
+      }
+    }
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int j = lane + WAVE * nb;
+      if (j < 120) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) buf[4 * j + r] = o[nb][r];
+      }
+    }
+    __syncthreads();
+  }
+  fft_pass<4, 4>(buf, w960, lane);
+  fft_pass<2, 16>(buf, w960, lane);
+  fft_pass<3, 32>(buf, w960, lane);
+  fft_pass<5, 96>(buf, w960, lane);
+}
+
 // buf holds Z = FFT480(x[2n] + i x[2n+1]); turn it into X[0..480] = DFT960(x)/960 in place.
 __device__ __forceinline__ void real_fwd_post(float2* buf, const float2* __restrict__ w960, int lane) {
   const float scale = 1.0f / 960.0f;
@@ -996,15 +1029,14 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
     STAMP(4)
 
     // ---- 5. frame_analysis: window, 960-point real FFT (in A), band energies (partials in Bb) ----
-    for (int n = lane; n < 480; n += WAVE) {
+    // complex point n = (x[2n], x[2n+1]) times the window; points >= 240 sit in the mirrored half of the window
+    fft480_from(L.A, [&](int j, int r) {
+      const int n = j + 120 * r;
       const float2 v = *reinterpret_cast<const float2*>(xw + 2 * n);
-      const int i0 = 2 * n, i1 = 2 * n + 1;
-      const float w0 = i0 < 480 ? hw[i0] : hw[959 - i0];
-      const float w1 = i1 < 480 ? hw[i1] : hw[959 - i1];
-      L.A[n] = make_float2(v.x * w0, v.y * w1);
-    }
-    __syncthreads();
-    fft480(L.A, w960, lane);
+      const float w0 = r < 2 ? hw[2 * n] : hw[959 - 2 * n];
+      const float w1 = r < 2 ? hw[2 * n + 1] : hw[958 - 2 * n];
+      return make_float2(v.x * w0, v.y * w1);
+    }, w960, lane);
     real_fwd_post(L.A, w960, lane);
     STAMP(5)
     band_pairs<false>(L.A, nullptr, Rb, L.Ex, nullptr, nullptr, tab, be, lane);
@@ -1018,15 +1050,13 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
     // ---- 6. pitch frame: window, FFT (in Bb), band energy / correlation (partials in U) ----
     {
       const float* pp = pb + (768 - pitch_index);
-      for (int n = lane; n < 480; n += WAVE) {
-        const int i0 = 2 * n, i1 = 2 * n + 1;
-        const float w0 = i0 < 480 ? hw[i0] : hw[959 - i0];
-        const float w1 = i1 < 480 ? hw[i1] : hw[959 - i1];
-        L.Bb[n] = make_float2(pp[i0] * w0, pp[i1] * w1);
-      }
+      fft480_from(L.Bb, [&](int j, int r) {
+        const int n = j + 120 * r;
+        const float w0 = r < 2 ? hw[2 * n] : hw[959 - 2 * n];
+        const float w1 = r < 2 ? hw[2 * n + 1] : hw[958 - 2 * n];
+        return make_float2(pp[2 * n] * w0, pp[2 * n + 1] * w1);
+      }, w960, lane);
     }
-    __syncthreads();
-    fft480(L.Bb, w960, lane);
     real_fwd_post(L.Bb, w960, lane);
     STAMP(7)
     // band energy of P, band correlation with X, and P parked in L2 from the same registers (read back by the comb
