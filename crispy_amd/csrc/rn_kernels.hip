@@ -110,6 +110,24 @@ __device__ __forceinline__ void butterfly<5>(const float2 (&v)[5], float2 (&o)[5
   o[3] = make_float2(a2.x - b2.y, a2.y + b2.x);
 }
 
+template <>
+__device__ __forceinline__ void butterfly<8>(const float2 (&v)[8], float2 (&o)[8]) {
+  // two radix-4 transforms of the even / odd inputs, then the w8^k twiddles (1, (1-i)/sqrt2, -i, (-1-i)/sqrt2)
+  const float2 ev[4] = {v[0], v[2], v[4], v[6]}, od[4] = {v[1], v[3], v[5], v[7]};
+  float2 e[4], d[4];
+  butterfly<4>(ev, e);
+  butterfly<4>(od, d);
+  const float h = 0.70710678118654752f;
+  const float2 t0 = d[0];
+  const float2 t1 = make_float2((d[1].x + d[1].y) * h, (d[1].y - d[1].x) * h);
+  const float2 t2 = make_float2(d[2].y, -d[2].x);
+  const float2 t3 = make_float2((d[3].y - d[3].x) * h, -(d[3].x + d[3].y) * h);
+  o[0] = cadd(e[0], t0); o[4] = csub(e[0], t0);
+  o[1] = cadd(e[1], t1); o[5] = csub(e[1], t1);
+  o[2] = cadd(e[2], t2); o[6] = csub(e[2], t2);
+  o[3] = cadd(e[3], t3); o[7] = csub(e[3], t3);
+}
+
 template <int R, int NS>
 __device__ __forceinline__ void fft_pass(float2* buf, const float2* __restrict__ w960, int lane) {
   constexpr int M = 480 / R;
@@ -147,8 +165,7 @@ __device__ __forceinline__ void fft_pass(float2* buf, const float2* __restrict__
 // forward DFT of the 480 complex points in buf (unscaled, natural order); caller synchronised
 __device__ __forceinline__ void fft480(float2* buf, const float2* __restrict__ w960, int lane) {
   fft_pass<4, 1>(buf, w960, lane);
-  fft_pass<4, 4>(buf, w960, lane);
-  fft_pass<2, 16>(buf, w960, lane);
+  fft_pass<8, 4>(buf, w960, lane);      // 480 = 4 . 8 . 3 . 5: four LDS round trips instead of five (4 . 4 . 2 . 3 . 5)
   fft_pass<3, 32>(buf, w960, lane);
   fft_pass<5, 96>(buf, w960, lane);
 }
@@ -180,8 +197,7 @@ __device__ __forceinline__ void fft480_from(float2* buf, In in, const float2* __
     }
     __syncthreads();
   }
-  fft_pass<4, 4>(buf, w960, lane);
-  fft_pass<2, 16>(buf, w960, lane);
+  fft_pass<8, 4>(buf, w960, lane);
   fft_pass<3, 32>(buf, w960, lane);
   fft_pass<5, 96>(buf, w960, lane);
 }
