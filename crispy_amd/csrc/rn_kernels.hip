@@ -788,28 +788,32 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
     __syncthreads();
     int best0, best1;
     {
+      // lane owns the three consecutive lags 3*lane + {0,1,2} (lanes 0..48): the y window slides through registers,
+      // one new LDS read per step instead of three (lane stride 3 floats: conflict-free), x broadcast as float4
       float xc[3] = {0.f, 0.f, 0.f};
       {
         const float4* xv4 = reinterpret_cast<const float4*>(x4);
-        const float* yp0 = y4 + lane;
-        const float* yp1 = y4 + min(lane + WAVE, 146);
-        const float* yp2 = y4 + min(lane + 2 * WAVE, 146);
+        const float* yp = y4 + 3 * min(lane, 48);      // reads reach y4[3*48 + 2 + 239] = y4[385] < 387
+        float y0 = yp[0], y1 = yp[1];
 #pragma unroll 4
         for (int j4 = 0; j4 < 60; ++j4) {
           const float4 xv = xv4[j4];
           const int j = 4 * j4;
-          xc[0] = fmaf(xv.x, yp0[j], xc[0]);
-          xc[1] = fmaf(xv.x, yp1[j], xc[1]);
-          xc[2] = fmaf(xv.x, yp2[j], xc[2]);
-          xc[0] = fmaf(xv.y, yp0[j + 1], xc[0]);
-          xc[1] = fmaf(xv.y, yp1[j + 1], xc[1]);
-          xc[2] = fmaf(xv.y, yp2[j + 1], xc[2]);
-          xc[0] = fmaf(xv.z, yp0[j + 2], xc[0]);
-          xc[1] = fmaf(xv.z, yp1[j + 2], xc[1]);
-          xc[2] = fmaf(xv.z, yp2[j + 2], xc[2]);
-          xc[0] = fmaf(xv.w, yp0[j + 3], xc[0]);
-          xc[1] = fmaf(xv.w, yp1[j + 3], xc[1]);
-          xc[2] = fmaf(xv.w, yp2[j + 3], xc[2]);
+          const float y2 = yp[j + 2], y3 = yp[j + 3], y4v = yp[j + 4], y5 = yp[j + 5];
+          xc[0] = fmaf(xv.x, y0, xc[0]);
+          xc[1] = fmaf(xv.x, y1, xc[1]);
+          xc[2] = fmaf(xv.x, y2, xc[2]);
+          xc[0] = fmaf(xv.y, y1, xc[0]);
+          xc[1] = fmaf(xv.y, y2, xc[1]);
+          xc[2] = fmaf(xv.y, y3, xc[2]);
+          xc[0] = fmaf(xv.z, y2, xc[0]);
+          xc[1] = fmaf(xv.z, y3, xc[1]);
+          xc[2] = fmaf(xv.z, y4v, xc[2]);
+          xc[0] = fmaf(xv.w, y3, xc[0]);
+          xc[1] = fmaf(xv.w, y4v, xc[1]);
+          xc[2] = fmaf(xv.w, y5, xc[2]);
+          y0 = y4v;
+          y1 = y5;
         }
       }
       STAMP(1)
@@ -843,7 +847,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
       int nvalid = 0;
 #pragma unroll
       for (int rr = 0; rr < 3; ++rr) {
-        const int lag = lane + WAVE * rr;
+        const int lag = 3 * lane + rr;
         if (lag < 147 && xc[rr] > 0.f) {
           const float syy = fmaxf(1.f, 1.f + (pre[lag + 240] - pre[lag]));
           const float x16 = xc[rr] * 1e-12f;
