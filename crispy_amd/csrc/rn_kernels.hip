@@ -1224,6 +1224,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
 
     if (!silence) {
       if constexpr (MODE == 0) {
+      lane = lane0;
+      asm volatile("" : "+v"(lane));   // (lane re-laundered: per-lane addresses of later stages are otherwise computed early / shared with earlier
+      // stages and stay live across the gain network, which is where registers are scarcest)
       // ---- 8. RNN (vectors in Bb) ----
       const float S = 1.f / 256.f;
       float* feat = Rb + RB_FEAT;
@@ -1264,6 +1267,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
       STAMP(12)
       }  // MODE == 0
 
+      lane = lane0;
+      asm volatile("" : "+v"(lane));
       // ---- 9. pitch_filter + gain application (Appendix A.3 step 7) ----
       // Pair layout: lane handles bins (2p, 2p+1), p = lane + 64 m -- one ds_read_b128 / one 16-byte global load
       // per pair at a 16-byte lane stride (conflict-free, coalesced), and a pair never straddles a band (edges are
@@ -1370,6 +1375,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
     }
     __syncthreads();
 
+    lane = lane0;
+    asm volatile("" : "+v"(lane));
     // ---- 10. frame_synthesis: inverse FFT, window, overlap-add ----
     real_inv_pre(L.A, w960, lane);
     if constexpr (MODE == 0) {

@@ -1,1 +1,1 @@
-export CRISPY_HIP_LIB=$PWD/crispy_amd/csrc/build/variants/lib_$1.so; timeout 600 python -m pytest tests/test_gpu_rnnoise.py -x -q -m gpu 2>&1 | grep -E "^E|Error|FAILED" | head -8; B=6 T=20 timeout 300 python tools/gpu_parity_debug.py 2>&1 | grep -E "^b[0-9]|mismatch" | head -14
+for v in "$@"; do echo "== $v"; export CRISPY_HIP_LIB=$PWD/crispy_amd/csrc/build/variants/lib_$v.so; BS=4096 T=100 python tools/sweep_streams.py 2>&1 | grep "B="; done
