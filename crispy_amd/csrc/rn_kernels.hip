@@ -331,19 +331,43 @@ __device__ __forceinline__ float interp_gain(const float* v, int band, float fra
 // ---------------------------------------------------------------------------------------------
 // RNN (Appendix A.3 step 6): lane == output row, weights as packed int8 dwords from L2.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float tansig_approx(float x, const float* __restrict__ table) {
-  if (!(x < 8.f)) return 1.f;
-  if (!(x > -8.f)) return -1.f;
+// The 201-entry tanh table lives in four registers per lane (lane l holds T[l], T[64+l], T[128+l], T[192+l]) for the
+// duration of the gain network; a lookup is four ds_bpermute (LDS crossbar, no memory access) and a select instead
+// of a dependent global load (~1 us at this occupancy, six of them per frame on the critical path).
+// ds_bpermute returns 0 for source lanes that are masked off, so activations are evaluated with ALL lanes active and
+// only the stores are predicated.
+struct TansigTab {
+  float t[4];
+  __device__ __forceinline__ void load(const float* __restrict__ table, int lane) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] = table[min(64 * q + lane, 200)];
+  }
+  __device__ __forceinline__ float at(int i) const {
+    const int addr = (i & 63) << 2;
+    const float v0 = __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(t[0])));
+    const float v1 = __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(t[1])));
+    const float v2 = __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(t[2])));
+    const float v3 = __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(t[3])));
+    const int q = i >> 6;
+    return q == 0 ? v0 : (q == 1 ? v1 : (q == 2 ? v2 : v3));
+  }
+};
+__device__ __forceinline__ float tansig_approx(float x, const TansigTab& table) {
+  const float x0 = x;
   float sign = 1.f;
   if (x < 0.f) { x = -x; sign = -1.f; }
+  x = fminf(x, 8.f);                       // keeps the index in range; the clamp result is selected below
   const int i = (int)floorf(.5f + 25.f * x);
   x -= .04f * i;
-  float y = table[i];
+  float y = table.at(i);
   const float dy = 1.f - y * y;
   y = y + x * dy * (1.f - y * x);
-  return sign * y;
+  y = sign * y;
+  if (!(x0 < 8.f)) y = 1.f;
+  if (!(x0 > -8.f)) y = -1.f;
+  return y;
 }
-__device__ __forceinline__ float sigmoid_approx(float x, const float* __restrict__ table) {
+__device__ __forceinline__ float sigmoid_approx(float x, const TansigTab& table) {
   return .5f + .5f * tansig_approx(.5f * x, table);
 }
 
@@ -461,7 +485,7 @@ template <int M, int N>
 __device__ __forceinline__ void gru_layer(__amdgpu_buffer_rsrc_t rs, int w_off, int u_off,
                                           const float* __restrict__ bias, const float* in_vec,
                                           float* state, float* zbuf, float* hr,
-                                          const float* __restrict__ tansig, int lane) {
+                                          const TansigTab& tansig, int lane) {
   constexpr int ROWS = 3 * N;
   constexpr int MK8 = (M + 7) / 8, NK8 = (N + 7) / 8;
   constexpr int NRZ = (2 * N + WAVE - 1) / WAVE, NRC = (N + WAVE - 1) / WAVE;
@@ -479,8 +503,8 @@ __device__ __forceinline__ void gru_layer(__amdgpu_buffer_rsrc_t rs, int w_off, 
 #pragma unroll
     for (int r = 0; r < NRZ; ++r) {
       const int row = lane + WAVE * r;
+      const float s = sigmoid_approx(S * acc[r], tansig);     // all lanes (table lookup by bpermute)
       if (row < 2 * N) {
-        const float s = sigmoid_approx(S * acc[r], tansig);
         if (row < N) zbuf[row] = s;
         else hr[row - N] = state[row - N] * s;
       }
@@ -681,7 +705,6 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
     const RnTables* __restrict__ tab = tabv;
     const float2* __restrict__ w960 = tab->w960;
     const float* __restrict__ hw = tab->half_window;
-    const float* __restrict__ tansig = tab->tansig;
     const float* __restrict__ wpf = reinterpret_cast<const float*>(wpraw);
     float2* pg = a.pspec + (MODE == 0 ? (long)b : (long)t * a.B + b) * 482;
     const float* xw = xs + (long)(t + 3) * RN_FRAME;  // [x_prev, x_cur]
@@ -1232,18 +1255,28 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
       float* feat = Rb + RB_FEAT;
       float* dense = Rb + RB_DENSE;
       float* gin = Rb + RB_IN;
-      if (lane < 24) {
-        float acc = wpf[RnPack::ID_B + lane];
-        acc = dot_h<rn_k8(42), 24>(wrs, RnPack::ID_W, lane, feat, acc);
-        dense[lane] = tansig_approx(S * acc, tansig);
+      TansigTab tansig;
+      tansig.load(tab->tansig, lane);
+      {
+        float acc = 0.f;
+        if (lane < 24) {
+          acc = wpf[RnPack::ID_B + lane];
+          acc = dot_h<rn_k8(42), 24>(wrs, RnPack::ID_W, lane, feat, acc);
+        }
+        const float d = tansig_approx(S * acc, tansig);
+        if (lane < 24) dense[lane] = d;
       }
       __syncthreads();
       gru_layer<24, 24>(wrs, RnPack::VG_W, RnPack::VG_R, wpf + RnPack::VG_B, dense,
                         L.rnn_state, Rb + RB_Z, Rb + RB_HR, tansig, lane);
-      if (lane == 0) {
-        float acc = wpf[RnPack::VO_B];
-        acc = dot_h<rn_k8(24), 1>(wrs, RnPack::VO_W, 0, L.rnn_state, acc);
-        L.U[U_VAD] = sigmoid_approx(S * acc, tansig);
+      {
+        float acc = 0.f;
+        if (lane == 0) {
+          acc = wpf[RnPack::VO_B];
+          acc = dot_h<rn_k8(24), 1>(wrs, RnPack::VO_W, 0, L.rnn_state, acc);
+        }
+        const float v = sigmoid_approx(S * acc, tansig);
+        if (lane == 0) L.U[U_VAD] = v;
       }
       for (int i = lane; i < 96; i += WAVE)
         gin[i] = i < 24 ? dense[i] : (i < 48 ? L.rnn_state[i - 24] : (i < 90 ? feat[i - 48] : 0.f));
@@ -1258,10 +1291,14 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
       __syncthreads();
       gru_layer<114, 96>(wrs, RnPack::DG_W, RnPack::DG_R, wpf + RnPack::DG_B, gin,
                          L.rnn_state + 72, Rb + RB_Z, Rb + RB_HR, tansig, lane);
-      if (lane < RN_NB) {
-        float acc = wpf[RnPack::DO_B + lane];
-        acc = dot_h<rn_k8(96), RN_NB>(wrs, RnPack::DO_W, lane, L.rnn_state + 72, acc);
-        L.U[U_G + lane] = sigmoid_approx(S * acc, tansig);
+      {
+        float acc = 0.f;
+        if (lane < RN_NB) {
+          acc = wpf[RnPack::DO_B + lane];
+          acc = dot_h<rn_k8(96), RN_NB>(wrs, RnPack::DO_W, lane, L.rnn_state + 72, acc);
+        }
+        const float gv = sigmoid_approx(S * acc, tansig);
+        if (lane < RN_NB) L.U[U_G + lane] = gv;
       }
       __syncthreads();
       STAMP(12)
