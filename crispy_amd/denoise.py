@@ -231,3 +231,51 @@ class RnnNoiseProcessor:
         frac = np.float32(self.resample_pos)
         self.resample_pos += step
         return (s0 + (s1 - s0) * frac).astype(np.float32)
+
+
+REC_SAMPLE_RATE = 48000          # recording::SAMPLE_RATE (recording.rs:8)
+
+
+class CaptureBuffers:
+    """`push_mono_to_buffers` (audio.rs:682-730), the per-sample glue of the capture callback: feed the mono sample
+    to the noise suppressor (or pass it through when none is active), resample whatever it produced to the 48 kHz
+    recording rate with the caller's `LinearResampler` -- re-configured only when a rate changed by >= 1 Hz --,
+    append to the recording ring (10 s cap, oldest dropped), and accumulate the level meter's sum / count
+    (`rms()` is the `(sum / frames).sqrt()` of audio.rs:780)."""
+
+    def __init__(self):
+        self.rec_resampler = LinearResampler(float(REC_SAMPLE_RATE), float(REC_SAMPLE_RATE))
+        self.rec_buffer = deque()
+        self.max_len = REC_SAMPLE_RATE * 10
+        self.sum = np.float32(0.0)
+        self.frames = np.float32(0.0)
+
+    def push_mono(self, mono: float, ns: "Optional[RnnNoiseProcessor]", raw_input_rate_hz: float) -> None:
+        mono = np.float32(mono)
+        if ns is not None:
+            produced_rate = ns.produced_rate_hz()
+            out = ns.push_sample([mono])
+            samples = None if out is None else out[:, 0]
+        else:
+            produced_rate = float(raw_input_rate_hz)
+            samples = np.array([mono], dtype=np.float32)
+        if samples is not None:
+            cur_in, cur_out = self.rec_resampler.rates()
+            if abs(cur_in - produced_rate) >= 1.0 or abs(cur_out - REC_SAMPLE_RATE) >= 1.0:
+                self.rec_resampler.set_rates(produced_rate, float(REC_SAMPLE_RATE))
+            emitted = []
+            for s in samples:
+                self.rec_resampler.process_sample(s, emitted.append)
+            for o in emitted:
+                if len(self.rec_buffer) >= self.max_len:
+                    self.rec_buffer.popleft()
+                self.rec_buffer.append(np.float32(o))
+        self.sum = np.float32(self.sum + mono * mono)
+        self.frames = np.float32(self.frames + np.float32(1.0))
+
+    def rms(self) -> float:
+        return float(np.sqrt(self.sum / self.frames)) if self.frames > 0 else 0.0
+
+    def reset_level(self) -> None:
+        self.sum = np.float32(0.0)
+        self.frames = np.float32(0.0)

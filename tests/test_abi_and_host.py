@@ -142,3 +142,24 @@ def test_resampler_interpolates_linearly():
     out = _run(LinearResampler(24000.0, 48000.0), 50, lambda i: float(i))
     d = np.diff(out[2:])
     assert np.allclose(d, 0.5, atol=1e-5)
+
+
+def test_capture_buffers_passthrough_ring_and_level():
+    """push_mono_to_buffers without a noise suppressor (audio.rs:682-730): the raw sample goes through the recording
+    resampler, the ring holds at most 10 s at 48 kHz, the level meter accumulates mono^2."""
+    from crispy_amd.denoise import CaptureBuffers, REC_SAMPLE_RATE
+    cb = CaptureBuffers()
+    x = (np.arange(96, dtype=np.float32) % 7 - 3) / 8
+    for s in x:
+        cb.push_mono(s, None, 16000.0)                # a 16 kHz device: three recorded samples per input sample
+    assert cb.rec_resampler.rates() == (16000.0, 48000.0)
+    assert len(cb.rec_buffer) in (3 * 96, 3 * 96 - 1, 3 * 96 - 2, 3 * 96 - 3)   # linear interpolation lags one sample
+    assert abs(cb.rms() - float(np.sqrt(np.mean(x.astype(np.float64) ** 2)))) < 1e-6
+    cb.reset_level()
+    assert cb.rms() == 0.0
+    cb2 = CaptureBuffers()
+    cb2.max_len = 100                                   # the reference's cap is SAMPLE_RATE * 10; same eviction rule
+    for i in range(250):
+        cb2.push_mono(i / 250.0, None, float(REC_SAMPLE_RATE))
+    assert len(cb2.rec_buffer) == 100 and abs(cb2.rec_buffer[-1] - 249 / 250.0) < 1e-6 and abs(cb2.rec_buffer[0] - 150 / 250.0) < 1e-6
+    assert CaptureBuffers().max_len == 480000

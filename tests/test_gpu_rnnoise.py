@@ -355,3 +355,20 @@ def test_adapter_playback_and_input_resampler(oracle, weights0):
     assert ring.size == 960                                     # 3 frames pushed, the first one dropped
     play = np.array([proc.next_sample()[0] for _ in range(200)])
     assert np.allclose(play, ring[0:400:2], atol=1e-7)
+
+
+def test_capture_callback_glue_with_the_denoiser(oracle, weights0):
+    """push_mono_to_buffers with an active RnnNoise suppressor (audio.rs:682-730): what lands in the recording ring
+    is the adapter's output (48 kHz -> no recording resampling), the level meter sees the raw input."""
+    from crispy_amd import synth_audio as SA
+    from crispy_amd.denoise import CaptureBuffers, RnnNoiseProcessor
+    x = SA.stream_np(9, 6, silent=False)
+    proc = RnnNoiseProcessor(weights0, 48000.0, 48000.0, 1.0, 1, 0)
+    cb = CaptureBuffers()
+    for s in x:
+        cb.push_mono(s, proc, 48000.0)
+    ref, _ = oracle.OracleDenoiseState(weights0).process(x * np.float32(32768.0))
+    want = np.clip(ref / np.float32(32768.0), -1, 1)[1:].ravel()          # first frame dropped by the adapter
+    got = np.array(cb.rec_buffer, np.float32)
+    assert got.shape == want.shape and np.abs(got - want).max() <= 1e-4 * np.abs(want).max() + 1e-7
+    assert abs(cb.rms() - float(np.sqrt(np.mean(x.astype(np.float64) ** 2)))) < 1e-5
