@@ -49,3 +49,21 @@ def test_frame_kernel_resource_budget(tmp_path, extra):
         loop = body.find("=>This Loop Header: Depth=1")     # the frame loop (the prologue's copy loops are "Inner")
         assert loop > 0, name
         assert "scratch_store" not in body[loop:], f"{name}: VGPR spill store inside the frame loop"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_mfma_gain_network_kernel_spills_only_in_the_prologue(tmp_path):
+    """rn_rnn_kernel keeps its weight fragments in 256 VGPRs and spills a few loop-invariant values; the same rule
+    applies: no spill store inside the frame loop."""
+    src = os.path.join(ROOT, "crispy_amd", "csrc", "rn_rnn_kernel.hip")
+    asm = tmp_path / "rnn.s"
+    out = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function",
+                          "--cuda-device-only", "-S", src, "-o", str(asm)],
+                         capture_output=True, text=True, timeout=600, cwd=os.path.dirname(src))
+    assert out.returncode == 0, out.stderr[-2000:]
+    text = asm.read_text()
+    body = text[text.index("rn_rnn_kernel"):]
+    body = body[:body.index("s_endpgm")]
+    loop = body.find("=>This Loop Header: Depth=1")
+    assert loop > 0
+    assert "scratch_store" not in body[loop:]
