@@ -251,28 +251,30 @@ def main():
         k_ms.append(ds.last_kernel_ms())
     ds.set_timing(False)
     from crispy_amd import _native as N
-    fpl = N.lib().crispy_rn_frames_per_launch()          # frames covered by one rn_frame_kernel launch
-    launches = sum((min(250, T - t0) + fpl - 1) // fpl for t0 in range(0, T, 250))
+    # rn_frame_kernel launches per step (a call starts with short launches of 3, 8, 21 frames, then 25 per launch);
+    # per-launch figures below are averages over them: algorithmic bytes of a step / launches, kernel time / launches
+    launches = N.lib().crispy_rn_n_launches(T)
     frame_ms = sum(k[0] for k in k_ms) / len(k_ms) / launches
     total_ms = sum(k[1] for k in k_ms) / len(k_ms)
     finite = bool(torch.isfinite(d_out).all().item())
 
     fps = frames_total / dt
     if rank == 0:
-        alg_bytes = BYTES_PER_STREAM_FRAME * B * min(T, fpl)
+        alg_bytes = BYTES_PER_STREAM_FRAME * B * T / launches
         # HBM traffic per launch from the committed PMC passes (rocprofv3 cannot run inside this process);
         # only quoted when it was measured on this exact launch shape.
         traffic = None
         valu = None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc.json")))
-            if (pm["config"]["streams"], pm["config"]["frames_per_launch"]) == (B, min(T, fpl)):
+            if pm["config"]["streams"] == B:
                 fk = pm["rn_frame_kernel"]
-                traffic = fk["hbm_bytes_per_launch"]
+                sf = B * T / launches                        # stream-frames per (average) launch
+                traffic = int(fk["hbm_bytes_per_stream_frame"] * sf)
                 # what actually bounds this kernel: VALU issue slots.  SQ_ACTIVE_INST_VALU counts 4-cycle issue
                 # slots; 1024 SIMDs; priced against the live kernel time at the 2.4 GHz peak clock.
                 valu = {"insts_per_stream_frame": fk["per_stream_frame"]["valu"],
-                        "issue_frac": fk["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * frame_ms * 1e-3 * 2.4e9),
+                        "issue_frac": fk["valu_active_quads_per_stream_frame"] * sf * 4 / (1024 * frame_ms * 1e-3 * 2.4e9),
                         "source": "profiles/r01b_pmc.json (rocprofv3 --pmc SQ_ACTIVE_INST_VALU), live kernel time"}
         except Exception:
             pass

@@ -22,7 +22,7 @@ LAYOUT_BTF = 1
 RN_SYMBOLS = (
     "crispy_last_error", "crispy_version", "crispy_device_count",
     "crispy_rn_create", "crispy_rn_destroy", "crispy_rn_reset", "crispy_rn_n_streams",
-    "crispy_rn_frames_per_launch", "crispy_rn_set_pipeline",
+    "crispy_rn_frames_per_launch", "crispy_rn_n_launches", "crispy_rn_set_pipeline",
     "crispy_rn_process", "crispy_rn_process_device", "crispy_rn_synchronize",
     "crispy_rn_set_timing", "crispy_rn_last_kernel_ms",
     "crispy_rn_debug_capture", "crispy_rn_debug_read", "crispy_rn_stage_rnn_device",

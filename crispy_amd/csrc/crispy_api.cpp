@@ -25,6 +25,21 @@ namespace {
 constexpr int kChunkFrames = 250;   // workspace bound: frames of high-passed signal kept per call segment
 constexpr int kSubFrames = 25;      // pipeline grain: high-pass of sub-chunk i+1 overlaps the frame kernel of sub-chunk i
 
+// Frames of sub-chunk `index` of a segment with `remaining` frames left.  The high-pass recurrence of the first
+// sub-chunk cannot overlap anything (the previous call still reads xhp), so the segment starts with a short
+// sub-chunk and ramps up: the high-pass runs ~2.9x faster per frame than the frame kernel, so every next sub-chunk
+// (<= 2.7x the previous one) is filtered while the previous one is being processed.  3, 8, 21, 25, 25, ...
+inline int sub_frames(int index, int remaining) {
+  static const int ramp[3] = {3, 8, 21};
+  const int want = index < 3 ? ramp[index] : kSubFrames;
+  return remaining < want ? remaining : want;
+}
+inline int count_subs(int T) {
+  int n = 0;
+  for (int done = 0; done < T; ++n) done += sub_frames(n, T - done);
+  return n;
+}
+
 void build_tables(RnTables* t) {
   const double pi = 3.14159265358979323846;
   for (int i = 0; i < RN_FRAME; ++i) {
@@ -335,6 +350,11 @@ void crispy_rn_destroy(crispy_rn* h) { free_all(h); }
 int crispy_rn_n_streams(const crispy_rn* h) { return h ? h->B : 0; }
 
 int crispy_rn_frames_per_launch(void) { return kSubFrames; }
+int crispy_rn_n_launches(int n_frames) {
+  int n = 0;
+  for (int t0 = 0; t0 < n_frames; t0 += kChunkFrames) n += count_subs(n_frames - t0 < kChunkFrames ? n_frames - t0 : kChunkFrames);
+  return n;
+}
 
 int crispy_rn_set_pipeline(crispy_rn* h, int staged) {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_set_pipeline: NULL handle");
@@ -398,7 +418,7 @@ int crispy_rn_process_device(crispy_rn* h, const float* d_in, float* d_out, floa
     // (producer of d_in, previous segment's frame kernels and history roll).
     HIP_TRY(hipEventRecord(h->ev_begin, s));
     HIP_TRY(hipStreamWaitEvent(h->hp_stream, h->ev_begin, 0));
-    const int n_sub = (T + kSubFrames - 1) / kSubFrames;
+    const int n_sub = count_subs(T);
     while ((int)h->ev_hp.size() < n_sub) {
       hipEvent_t ne;
       HIP_TRY(hipEventCreateWithFlags(&ne, hipEventDisableTiming));
@@ -416,20 +436,19 @@ int crispy_rn_process_device(crispy_rn* h, const float* d_in, float* d_out, floa
       HIP_TRY(hipEventRecord(e[0], s));
     }
     // high-pass sub-chunks back to back on the helper stream
-    for (int i = 0; i < n_sub; ++i) {
-      const int ts = i * kSubFrames;
+    for (int i = 0, ts = 0; i < n_sub; ++i) {
       RnArgs sa = a;
-      sa.T = (T - ts) < kSubFrames ? (T - ts) : kSubFrames;
+      sa.T = sub_frames(i, T - ts);
       sa.in = d_in + (long)(t0 + ts) * a.stride_t;
       sa.xhp = h->d_xhp + (long)ts * RN_FRAME;   // row pointer shifted by the frames already filtered
       HIP_TRY(rn_launch_highpass(sa, h->hp_stream));
       HIP_TRY(hipEventRecord(h->ev_hp[i], h->hp_stream));
+      ts += sa.T;
     }
     // frame kernels on the caller's stream, each gated on its own sub-chunk's high-pass
-    for (int i = 0; i < n_sub; ++i) {
-      const int ts = i * kSubFrames;
+    for (int i = 0, ts = 0; i < n_sub; ++i) {
       RnArgs sa = a;
-      sa.T = (T - ts) < kSubFrames ? (T - ts) : kSubFrames;
+      sa.T = sub_frames(i, T - ts);
       sa.out = d_out + (long)(t0 + ts) * a.stride_t;
       sa.vad = d_vad ? d_vad + (long)(t0 + ts) * h->B : nullptr;
       sa.taps = d_taps ? d_taps + (long)(t0 + ts) * h->B * RN_TAPS : nullptr;
@@ -452,6 +471,7 @@ int crispy_rn_process_device(crispy_rn* h, const float* d_in, float* d_out, floa
         HIP_TRY(rn_launch_frames(sa, s));
       }
       if (e) HIP_TRY(hipEventRecord(e[2 + 2 * i], s));
+      ts += sa.T;
     }
     a.T = T;
     HIP_TRY(rn_launch_roll_history(a, s));
