@@ -18,6 +18,7 @@ done
 python - "$out" "$tag" <<'PY'
 import csv, glob, json, os, sys
 out, tag = sys.argv[1], sys.argv[2]
+B, T, CALLS = 4096, 25, 2            # tools/pmc_frame.py: 2 calls of 25 frames over 4096 streams
 acc = {}
 for f in glob.glob(os.path.join(out, f"{tag}_pmc_*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
@@ -27,11 +28,15 @@ for f in glob.glob(os.path.join(out, f"{tag}_pmc_*", "**", "*counter_collection.
         short = "rn_frame_kernel" if "rn_frame_kernel" in k else ("rn_highpass_kernel" if "highpass" in k else ("rn_roll_history_kernel" if "roll" in k else k[:40]))
         d = acc.setdefault(short, {}).setdefault(r["Counter_Name"], [])
         d.append(float(r["Counter_Value"]))
-summ = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
-for k, cs in summ.items():
-    cs["_dispatches_seen"] = max(len(v) for v in acc[k].values())
-json.dump(summ, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1)
-print(json.dumps(summ.get("rn_frame_kernel", {}), indent=1))
+# totals over all dispatches of the run (launch sizes differ: 3, 8, 14 frames per call), and per stream-frame
+n_sf = B * T * CALLS
+summ = {}
+for k, cs in acc.items():
+    summ[k] = {"dispatches": max(len(v) for v in cs.values()), "total": {c: sum(v) for c, v in cs.items()},
+               "per_stream_frame": {c: sum(v) / n_sf for c, v in cs.items()}}
+json.dump({"streams": B, "frames_per_call": T, "calls": CALLS, "stream_frames": n_sf, "kernels": summ},
+          open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1)
+print(json.dumps(summ.get("rn_frame_kernel", {}).get("per_stream_frame", {}), indent=1))
 PY
 f=$(find $out/${tag}_trace -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" $out/${tag}_kernel_stats.csv && head -12 "$f"
