@@ -459,44 +459,61 @@ __global__ __launch_bounds__(256) void embed_kernel(const int* __restrict__ toke
   for (int c = threadIdx.x; c < D; c += 256) x[(long)b * D + c] = tok_emb[(long)tok * D + c] + pos_emb[(long)pos * D + c];
 }
 
-// greedy pick: argmax over the vocabulary with a suppression mask (mask[v] != 0 -> -inf); ties -> lowest id
-__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, const unsigned char* __restrict__ mask,
-                                                     const unsigned char* __restrict__ mask_first,
-                                                     const int* __restrict__ step_dev, int V, int* __restrict__ tokens_out,
-                                                     int* __restrict__ tokens_all, float* __restrict__ best_logit,
-                                                     int eot, int* __restrict__ finished, int* __restrict__ done_count) {
-  __shared__ float sv[256];
-  __shared__ int si[256];
-  const int b = blockIdx.x;
+// greedy pick: argmax over the vocabulary with a suppression mask (mask[v] != 0 -> -inf); ties -> lowest id.
+// One 1024-thread block per clip; every thread walks the row in float4 / uchar4 steps with four loads in flight
+// (the 256-thread, one-float-per-iteration version ran at 0.1 TB/s: 118 us for 64 x 51865 logits).
+__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, const unsigned char* __restrict__ mask,
+                                                      const unsigned char* __restrict__ mask_first,
+                                                      const int* __restrict__ step_dev, int V, int* __restrict__ tokens_out,
+                                                      int* __restrict__ tokens_all, float* __restrict__ best_logit,
+                                                      int eot, int* __restrict__ finished, int* __restrict__ done_count) {
+  __shared__ float sv[16];
+  __shared__ int si[16];
+  const int b = blockIdx.x, tid = threadIdx.x;
   const int step = step_dev ? *step_dev : 0;
   if (step == 0 && mask_first) mask = mask_first;
   const float* lg = logits + (long)b * V;
   float bv = -INFINITY;
   int bi = 0x7fffffff;
-  for (int v = threadIdx.x; v < V; v += 256) {
-    const float x = (mask && mask[v]) ? -INFINITY : lg[v];
+  auto consider = [&](float x, int v) {
     if (x > bv || (x == bv && v < bi)) { bv = x; bi = v; }
+  };
+  // rows start 4-byte aligned only (V is odd): scalar head up to the first 16-byte boundary, vector body, scalar tail
+  const int head = (int)(((16 - ((size_t)lg & 15)) & 15) >> 2);
+  if (tid < head && tid < V) consider((mask && mask[tid]) ? -INFINITY : lg[tid], tid);
+  const int nvec = (V - head) >> 2;
+  const float4* lg4 = reinterpret_cast<const float4*>(lg + head);
+#pragma unroll 4
+  for (int q = tid; q < nvec; q += 1024) {
+    const float4 x = lg4[q];
+    const int v0 = head + 4 * q;
+    unsigned char m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+    if (mask) { m0 = mask[v0]; m1 = mask[v0 + 1]; m2 = mask[v0 + 2]; m3 = mask[v0 + 3]; }
+    consider(m0 ? -INFINITY : x.x, v0);
+    consider(m1 ? -INFINITY : x.y, v0 + 1);
+    consider(m2 ? -INFINITY : x.z, v0 + 2);
+    consider(m3 ? -INFINITY : x.w, v0 + 3);
   }
-  sv[threadIdx.x] = bv;
-  si[threadIdx.x] = bi;
+  for (int v = head + 4 * nvec + tid; v < V; v += 1024) consider((mask && mask[v]) ? -INFINITY : lg[v], v);
+  // wave arg-max (ties -> lowest id), then the 16 wave results
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(bv, off, 64);
+    const int oi = __shfl_xor(bi, off, 64);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if ((tid & 63) == 0) { sv[tid >> 6] = bv; si[tid >> 6] = bi; }
   __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (threadIdx.x < off) {
-      const float ov = sv[threadIdx.x + off];
-      const int oi = si[threadIdx.x + off];
-      if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) { sv[threadIdx.x] = ov; si[threadIdx.x] = oi; }
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    tokens_out[b] = si[0];
-    if (tokens_all) tokens_all[(long)step * gridDim.x + b] = si[0];
-    if (best_logit) best_logit[(long)step * gridDim.x + b] = sv[0];
+  if (tid == 0) {
+    for (int w = 1; w < 16; ++w)
+      if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+    tokens_out[b] = bi;
+    if (tokens_all) tokens_all[(long)step * gridDim.x + b] = bi;
+    if (best_logit) best_logit[(long)step * gridDim.x + b] = bv;
     // first EOT of this clip: the host polls done_count and stops replaying the step graph once every clip has one
-    if (finished && si[0] == eot && !finished[b]) { finished[b] = 1; atomicAdd(done_count, 1); }
+    if (finished && bi == eot && !finished[b]) { finished[b] = 1; atomicAdd(done_count, 1); }
   }
 }
-
 
 // greedy pick under the timestamp rules: one 256-thread block per clip, two passes over the logits
 __global__ __launch_bounds__(256) void ts_pick_kernel(TsPickArgs a) {
@@ -629,7 +646,7 @@ hipError_t embed_tokens_f32(const int* tokens, const float* tok_emb, const float
 hipError_t argmax_f32(const float* logits, const unsigned char* mask, const unsigned char* mask_first,
                       const int* step_dev, int V, int* tokens_out, int* tokens_all, float* best, int B, hipStream_t s,
                       int eot, int* finished, int* done_count) {
-  hipLaunchKernelGGL(argmax_kernel, dim3(B), dim3(256), 0, s, logits, mask, mask_first, step_dev, V, tokens_out,
+  hipLaunchKernelGGL(argmax_kernel, dim3(B), dim3(1024), 0, s, logits, mask, mask_first, step_dev, V, tokens_out,
                      tokens_all, best, eot, finished, done_count);
   return hipGetLastError();
 }
