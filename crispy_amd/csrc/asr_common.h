@@ -50,6 +50,14 @@ struct GemmArgs {
   int M, N, K;
   int gelu;
   const int* c_off_dev; long c_off_scale;     // optional: C += (*c_off_dev) * c_off_scale (decoder KV-cache slot)
+  // Skinny (decode-step) path only:
+  //  * LayerNorm folded into the GEMM: W holds gamma-scaled rows, ln_s[n] = sum_k W[n][k], ln_c[n] = sum_k beta_k
+  //    W0[n][k] + bias[n]; A is the *un-normalised* input, whose row mean / rstd are accumulated from the operands the
+  //    kernel loads anyway, and C = rstd_m (A.W^T - mean_m ln_s[n]) + ln_c[n].  Saves the LayerNorm launch.
+  //  * split output: columns >= n_split go to C2 (+ c_off_dev offset) with leading dimension ldc2 -- q and k|v of a
+  //    decoder self-attention block in one launch.
+  const float* ln_s; const float* ln_c;
+  float* C2; long ldc2; int n_split;
 };
 hipError_t gemm_f32_nt(const GemmArgs& g, int batch, hipStream_t s);
 hipError_t layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, long rows, int D, hipStream_t s);

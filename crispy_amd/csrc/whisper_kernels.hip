@@ -129,12 +129,16 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(GemmArgs g) {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gemm_skinny_f32_kernel(GemmArgs g) {
   __shared__ float red[4][64 * 33];
+  __shared__ float rstat[4][64][2];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, lh = lane >> 5;
   const int n0 = blockIdx.x * 32;
   const float* __restrict__ A = g.A;
   const float* __restrict__ W = g.W;
-  float* __restrict__ C = g.C + (g.c_off_dev ? (long)(*g.c_off_dev) * g.c_off_scale : 0L);
+  const bool second = g.C2 && n0 >= g.n_split;      // split output: a workgroup's 32 columns go to one destination
+  const long coff = g.c_off_dev ? (long)(*g.c_off_dev) * g.c_off_scale : 0L;
+  float* __restrict__ C = second ? g.C2 + coff - g.n_split : g.C + (g.C2 ? 0L : coff);
+  const long ldc = second ? g.ldc2 : g.ldc;
   const int kper = g.K / 4;                 // K range of this wave (multiple of 32)
   const int kbeg = wave * kper;
   const int n = min(n0 + li, g.N - 1);
@@ -145,6 +149,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_f32_kernel(GemmArgs g) {
   f32x16 acc0, acc1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;   // row sums / sums of squares of this lane's share (LN folding)
   float4 w[4], a0[4], a1[4];
   auto load = [&](int kc) {
 #pragma unroll
@@ -169,6 +174,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_f32_kernel(GemmArgs g) {
       for (int e = 0; e < 4; ++e) {
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[e], wv[e], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[e], wv[e], acc1, 0, 0, 0);
+        if (g.ln_s) {
+          s0 += x0[e]; q0 = fmaf(x0[e], x0[e], q0);
+          s1 += x1[e]; q1 = fmaf(x1[e], x1[e], q1);
+        }
       }
     }
   }
@@ -178,6 +187,15 @@ __global__ __launch_bounds__(256) void gemm_skinny_f32_kernel(GemmArgs g) {
     red[wave][row * 33 + li] = acc0[r];
     red[wave][(32 + row) * 33 + li] = acc1[r];
   }
+  if (g.ln_s) {
+    // the two half-waves hold the two 16-wide halves of every 32-wide K chunk of rows li / 32 + li
+    s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);
+    s1 += __shfl_xor(s1, 32, 64); q1 += __shfl_xor(q1, 32, 64);
+    if (lh == 0) {
+      rstat[wave][li][0] = s0; rstat[wave][li][1] = q0;
+      rstat[wave][32 + li][0] = s1; rstat[wave][32 + li][1] = q1;
+    }
+  }
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
@@ -186,10 +204,19 @@ __global__ __launch_bounds__(256) void gemm_skinny_f32_kernel(GemmArgs g) {
     const int nn = n0 + c;
     if (m < g.M && nn < g.N) {
       float v = red[0][m * 33 + c] + red[1][m * 33 + c] + red[2][m * 33 + c] + red[3][m * 33 + c];
-      v += g.bias ? g.bias[nn] : 0.f;
+      if (g.ln_s) {
+        const float sum = rstat[0][m][0] + rstat[1][m][0] + rstat[2][m][0] + rstat[3][m][0];
+        const float sq = rstat[0][m][1] + rstat[1][m][1] + rstat[2][m][1] + rstat[3][m][1];
+        const float mean = sum / (float)g.K;
+        const float var = fmaxf(sq / (float)g.K - mean * mean, 0.f);
+        const float rstd = 1.f / sqrtf(var + 1e-5f);
+        v = rstd * (v - mean * g.ln_s[nn]) + g.ln_c[nn];
+      } else {
+        v += g.bias ? g.bias[nn] : 0.f;
+      }
       if (g.gelu) v = gelu_erf(v);
       if (g.residual) v += g.residual[(long)m * g.ldr + nn];
-      C[(long)m * g.ldc + nn] = v;
+      C[(long)m * ldc + nn] = v;
     }
   }
 }
