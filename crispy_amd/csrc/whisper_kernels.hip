@@ -377,14 +377,18 @@ __global__ __launch_bounds__(256) void attn_enc_kernel(const float* __restrict__
 // (max, sum, P.V) triples are merged through LDS.  n_keys = n_keys_base + *pos_dev (graph replay keeps
 // the launch arguments fixed while the position advances on the device).  Memory-bound on K/V.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_dec_kernel(const float* __restrict__ q, long ldq,
+#ifndef AD_WAVES_N
+#define AD_WAVES_N 16
+#endif
+constexpr int AD_WAVES = AD_WAVES_N;   // key partitions per (clip, head): 1.2 GB of cross K|V per step want many loads in flight
+__global__ __launch_bounds__(64 * AD_WAVES) void attn_dec_kernel(const float* __restrict__ q, long ldq,
                                                        const float* __restrict__ kv, long kv_batch_stride,
                                                        long ldkv, int koff, int voff, int n_keys_base,
                                                        const int* __restrict__ pos_dev, float* __restrict__ out, long ldo) {
   __shared__ float p_s[1536];
   __shared__ __attribute__((aligned(16))) float q_s[64];
-  __shared__ float part_o[4][64];
-  __shared__ float part_m[4], part_l[4];
+  __shared__ float part_o[AD_WAVES][64];
+  __shared__ float part_m[AD_WAVES], part_l[AD_WAVES];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int h = blockIdx.x, b = blockIdx.y;
   const int n_keys = n_keys_base + (pos_dev ? *pos_dev : 0);
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(256) void attn_dec_kernel(const float* __restrict__
   __syncthreads();
   const float* Kb = kv + (long)b * kv_batch_stride + koff + h * 64;
   const float* Vb = kv + (long)b * kv_batch_stride + voff + h * 64;
-  const int per = (n_keys + 3) / 4;
+  const int per = (n_keys + AD_WAVES - 1) / AD_WAVES;
   const int k_lo = wave * per, k_hi = min(n_keys, k_lo + per);
   // scores: 16 lanes share one key row (coalesced 256-byte reads, 4 keys per wave instruction), the
   // 16 partial dot products are summed inside the DPP row
@@ -400,10 +404,11 @@ __global__ __launch_bounds__(256) void attn_dec_kernel(const float* __restrict__
   {
     const int c = lane & 15, sub = lane >> 4;
     const float4 qv = *reinterpret_cast<const float4*>(&q_s[4 * c]);
-    for (int kb = k_lo; kb < k_hi; kb += 16) {          // 4 independent 1-KB loads in flight per wave
-      float sacc[4];
+    constexpr int SU = 8;                                  // independent 1-KB loads in flight per wave
+    for (int kb = k_lo; kb < k_hi; kb += 4 * SU) {
+      float sacc[SU];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < SU; ++u) {
         const int k = kb + 4 * u + sub;
         sacc[u] = 0.f;
         if (k < k_hi) {
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(256) void attn_dec_kernel(const float* __restrict__
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < SU; ++u) {
         float v = sacc[u];
         v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));
         v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));
@@ -464,10 +469,12 @@ __global__ __launch_bounds__(256) void attn_dec_kernel(const float* __restrict__
   if (lane == 0) { part_m[wave] = mloc; part_l[wave] = lsum; }
   __syncthreads();
   if (wave == 0) {
-    const float m = fmaxf(fmaxf(part_m[0], part_m[1]), fmaxf(part_m[2], part_m[3]));
+    float m = part_m[0];
+#pragma unroll
+    for (int w = 1; w < AD_WAVES; ++w) m = fmaxf(m, part_m[w]);
     float o = 0.f, l = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < AD_WAVES; ++w) {
       const float sc = __expf(part_m[w] - m);   // empty partitions have m = -1e30 -> scale 0
       o = fmaf(part_o[w][lane], sc, o);
       l = fmaf(part_l[w], sc, l);
@@ -661,7 +668,7 @@ hipError_t attn_encoder_f32(const float* qkv, float* out, int B, int T, int D, i
 hipError_t attn_decoder_f32(const float* q, long ldq, const float* kv, long kv_batch_stride, long ldkv, int koff,
                             int voff, int n_keys_base, const int* pos_dev, float* out, long ldo, int B, int heads,
                             hipStream_t s) {
-  hipLaunchKernelGGL(attn_dec_kernel, dim3(heads, B), dim3(256), 0, s, q, ldq, kv, kv_batch_stride, ldkv, koff, voff,
+  hipLaunchKernelGGL(attn_dec_kernel, dim3(heads, B), dim3(64 * AD_WAVES), 0, s, q, ldq, kv, kv_batch_stride, ldkv, koff, voff,
                      n_keys_base, pos_dev, out, ldo);
   return hipGetLastError();
 }
