@@ -549,11 +549,14 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
   }
 }
 
-// greedy pick under the timestamp rules: one 256-thread block per clip, two passes over the logits
-__global__ __launch_bounds__(256) void ts_pick_kernel(TsPickArgs a) {
-  __shared__ float s_v[2][256];
-  __shared__ int s_i[2][256];
-  __shared__ float s_sum[256];
+// greedy pick under the timestamp rules: one 1024-thread block per clip.  Plain text tokens [0, eot) are either all
+// subject to the suppression mask only or not allowed at all (uniform per clip and step), so they are scanned in
+// float4 steps or skipped; the ~1600 special and timestamp ids take the per-id rule path; the log-sum-exp of the
+// allowed timestamps is a second pass over 1501 values.
+__global__ __launch_bounds__(1024) void ts_pick_kernel(TsPickArgs a) {
+  __shared__ float s_v[2][16];
+  __shared__ int s_i[2][16];
+  __shared__ float s_sum[16];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int step = a.step_dev ? *a.step_dev : 0;
   TsState st = a.st[b];
@@ -574,53 +577,71 @@ __global__ __launch_bounds__(256) void ts_pick_kernel(TsPickArgs a) {
   if (st.last_ts >= 0) ts_lo = (a.rules == TS_RULES_OPENAI && !(last_ts && !pen_ts)) ? st.last_ts + 1 : st.last_ts;
   const bool initial = st.n == 0;
   if (initial && a.max_initial_ts > 0) ts_hi = a.beg + a.max_initial_ts;
-  const bool no_text = (last_ts && !pen_ts) || (initial && a.rules == TS_RULES_OPENAI);   // text = ids < eot resp. < beg
   const bool no_ts = last_ts && pen_ts;
-  auto masked = [&](int v) -> bool {
+  const bool forced_ts = initial && a.rules == TS_RULES_OPENAI;      // the first pick is a timestamp
+  const bool text_allowed = !(last_ts && !pen_ts) && !forced_ts;     // ids < eot
+  auto masked = [&](int v) -> bool {                                 // ids >= eot (EOT, specials, timestamps)
     if (mask && mask[v]) return true;
     if (v == a.not_tok) return true;
     if (v >= a.beg) return no_ts || v < ts_lo || v > ts_hi;
-    if (last_ts && !pen_ts && v < a.eot) return true;        // after "text <|t|>": a timestamp or EOT only
-    if (initial && a.rules == TS_RULES_OPENAI) return true;  // the first pick is a timestamp
-    return false;
+    return forced_ts;
   };
-  (void)no_text;
   float tv = -INFINITY, xv = -INFINITY;   // best text (v < beg) and best timestamp
   int ti = 0x7fffffff, xi = 0x7fffffff;
-  for (int v = tid; v < a.V; v += 256) {
+  auto text = [&](float x, int v) { if (x > tv || (x == tv && v < ti)) { tv = x; ti = v; } };
+  if (text_allowed) {
+    const int head = min((int)(((16 - ((size_t)lg & 15)) & 15) >> 2), a.eot);
+    if (tid < head) text((mask && mask[tid]) ? -INFINITY : lg[tid], tid);
+    const int nvec = (a.eot - head) >> 2;
+    const float4* lg4 = reinterpret_cast<const float4*>(lg + head);
+#pragma unroll 4
+    for (int q = tid; q < nvec; q += 1024) {
+      const float4 x = lg4[q];
+      const int v0 = head + 4 * q;
+      unsigned char m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+      if (mask) { m0 = mask[v0]; m1 = mask[v0 + 1]; m2 = mask[v0 + 2]; m3 = mask[v0 + 3]; }
+      text(m0 ? -INFINITY : x.x, v0);
+      text(m1 ? -INFINITY : x.y, v0 + 1);
+      text(m2 ? -INFINITY : x.z, v0 + 2);
+      text(m3 ? -INFINITY : x.w, v0 + 3);
+    }
+    for (int v = head + 4 * nvec + tid; v < a.eot; v += 1024) text((mask && mask[v]) ? -INFINITY : lg[v], v);
+  }
+  for (int v = a.eot + tid; v < a.V; v += 1024) {
     if (masked(v)) continue;
     const float x = lg[v];
-    if (v < a.beg) { if (x > tv || (x == tv && v < ti)) { tv = x; ti = v; } }
-    else { if (x > xv || (x == xv && v < xi)) { xv = x; xi = v; } }
+    if (v < a.beg) text(x, v);
+    else if (x > xv || (x == xv && v < xi)) { xv = x; xi = v; }
   }
-  s_v[0][tid] = tv; s_i[0][tid] = ti; s_v[1][tid] = xv; s_i[1][tid] = xi;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (tid < off) {
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const float ov = s_v[q][tid + off];
-        const int oi = s_i[q][tid + off];
-        if (ov > s_v[q][tid] || (ov == s_v[q][tid] && oi < s_i[q][tid])) { s_v[q][tid] = ov; s_i[q][tid] = oi; }
-      }
-    }
-    __syncthreads();
+  for (int off = 32; off > 0; off >>= 1) {
+    float ov = __shfl_xor(tv, off, 64); int oi = __shfl_xor(ti, off, 64);
+    if (ov > tv || (ov == tv && oi < ti)) { tv = ov; ti = oi; }
+    ov = __shfl_xor(xv, off, 64); oi = __shfl_xor(xi, off, 64);
+    if (ov > xv || (ov == xv && oi < xi)) { xv = ov; xi = oi; }
   }
-  const float max_text = s_v[0][0], max_ts = s_v[1][0];
-  const int arg_text = s_i[0][0], arg_ts = s_i[1][0];
+  if ((tid & 63) == 0) { s_v[0][tid >> 6] = tv; s_i[0][tid >> 6] = ti; s_v[1][tid >> 6] = xv; s_i[1][tid >> 6] = xi; }
+  __syncthreads();
+  float max_text = s_v[0][0], max_ts = s_v[1][0];
+  int arg_text = s_i[0][0], arg_ts = s_i[1][0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) {
+    if (s_v[0][w] > max_text || (s_v[0][w] == max_text && s_i[0][w] < arg_text)) { max_text = s_v[0][w]; arg_text = s_i[0][w]; }
+    if (s_v[1][w] > max_ts || (s_v[1][w] == max_ts && s_i[1][w] < arg_ts)) { max_ts = s_v[1][w]; arg_ts = s_i[1][w]; }
+  }
   // log-sum-exp of the allowed timestamp logits
   float sum = 0.f;
   if (max_ts > -INFINITY)
-    for (int v = a.beg + tid; v < a.V; v += 256)
+    for (int v = a.beg + tid; v < a.V; v += 1024)
       if (!masked(v)) sum += expf(lg[v] - max_ts);
-  s_sum[tid] = sum;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  if ((tid & 63) == 0) s_sum[tid >> 6] = sum;
   __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (tid < off) s_sum[tid] += s_sum[tid + off];
-    __syncthreads();
-  }
   if (tid == 0) {
-    const float lse_ts = max_ts > -INFINITY ? max_ts + logf(s_sum[0]) : -INFINITY;
+    float tot = 0.f;
+    for (int w = 0; w < 16; ++w) tot += s_sum[w];
+    const float lse_ts = max_ts > -INFINITY ? max_ts + logf(tot) : -INFINITY;
     int pick;
     if (lse_ts > max_text) pick = arg_ts;                       // timestamps carry more mass than any text token
     else pick = (max_ts > max_text) ? arg_ts : arg_text;        // plain arg-max, ties -> lowest id (text ids are lower)
@@ -685,7 +706,7 @@ hipError_t argmax_f32(const float* logits, const unsigned char* mask, const unsi
   return hipGetLastError();
 }
 hipError_t ts_pick(const TsPickArgs& a, int B, hipStream_t s) {
-  hipLaunchKernelGGL(ts_pick_kernel, dim3(B), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(ts_pick_kernel, dim3(B), dim3(1024), 0, s, a);
   return hipGetLastError();
 }
 hipError_t advance_counters(int* pos_dev, int* step_dev, hipStream_t s) {
