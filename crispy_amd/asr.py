@@ -130,6 +130,11 @@ class WhisperModel:
     def synchronize(self):
         N.check(N.lib().crispy_asr_synchronize(self._h))
 
+    def set_precision(self, mode: int):
+        """0: f32 operands (default, the mode the oracle parity is pinned in); 1: f16 operands / f32 accumulation for
+        the encoder GEMMs (whisper.cpp's ggml numerics)."""
+        N.check(N.lib().crispy_asr_set_precision(self._h, int(mode)))
+
     def set_suppress(self, ids, first_only: bool = False):
         a = np.ascontiguousarray(ids, dtype=np.int32)
         N.check(N.lib().crispy_asr_set_suppress(self._h, a.ctypes.data, a.size, int(first_only)))

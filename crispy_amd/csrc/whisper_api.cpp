@@ -24,6 +24,7 @@ struct Tensor {
 };
 
 struct EncLayer {
+  const void *qkv_wh = nullptr, *out_wh = nullptr, *fc1_wh = nullptr, *fc2_wh = nullptr;   // f16 copies (precision mode 1)
   const float *ln1_w, *ln1_b, *qkv_w, *qkv_b, *out_w, *out_b, *ln2_w, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
 };
 struct DecLayer {
@@ -48,6 +49,8 @@ struct crispy_asr {
   // resolved pointers
   const float *conv1_w = nullptr, *conv1_b = nullptr, *conv2_w = nullptr, *conv2_b = nullptr, *enc_pos = nullptr;
   const float *ln_post_w = nullptr, *ln_post_b = nullptr;
+  const void* conv2_wh = nullptr;            // f16 copy of the reordered conv2 kernel (precision mode 1)
+  int enc_precision = 0;                     // 0: f32 operands (default), 1: f16 operands for the encoder GEMMs
   std::vector<EncLayer> enc;
   const float *tok_emb = nullptr, *dec_pos = nullptr, *dec_ln_w = nullptr, *dec_ln_b = nullptr;
   const float *logit_lw = nullptr, *logit_ls = nullptr, *logit_lc = nullptr;   // final LayerNorm folded into the logits GEMM
@@ -405,6 +408,36 @@ int crispy_asr_hparams_get(const crispy_asr* h, crispy_asr_hparams* out) {
 }
 
 // mel (frame-major, padded) -> encoder output [B][1500][d]
+int crispy_asr_set_precision(crispy_asr* h, int mode) {
+  if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_set_precision: NULL handle");
+  if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_set_precision: model not finalized");
+  if (mode != 0 && mode != 1) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_set_precision: mode must be 0 (f32) or 1 (f16 encoder GEMM operands)");
+  HIP_TRY(hipSetDevice(h->device));
+  if (mode == 1 && !h->conv2_wh) {
+    // f16 copies of the encoder GEMM weights, made on the device once
+    const size_t d = h->hp.n_audio_state;
+    auto half_copy = [&](const float* w, size_t n, const void** out) -> int {
+      void* p = nullptr;
+      HIP_TRY(hipMalloc(&p, n * 2));
+      h->derived.push_back(reinterpret_cast<float*>(p));
+      HIP_TRY(convert_f32_to_f16(w, p, (long)n, h->stream));
+      *out = p;
+      return CRISPY_OK;
+    };
+    int rc = half_copy(h->conv2_w, d * 3 * d, &h->conv2_wh);
+    for (EncLayer& L : h->enc) {
+      if (rc == CRISPY_OK) rc = half_copy(L.qkv_w, 3 * d * d, &L.qkv_wh);
+      if (rc == CRISPY_OK) rc = half_copy(L.out_w, d * d, &L.out_wh);
+      if (rc == CRISPY_OK) rc = half_copy(L.fc1_w, 4 * d * d, &L.fc1_wh);
+      if (rc == CRISPY_OK) rc = half_copy(L.fc2_w, 4 * d * d, &L.fc2_wh);
+    }
+    if (rc != CRISPY_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  h->enc_precision = mode;
+  return CRISPY_OK;
+}
+
 int crispy_asr_encode_device(crispy_asr* h, const float* d_mel_t, int batch, float* d_out, void* hip_stream) {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_encode_device: NULL handle");
   if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_encode_device: model not finalized");
@@ -417,6 +450,11 @@ int crispy_asr_encode_device(crispy_asr* h, const float* d_mel_t, int batch, flo
   if (rc != CRISPY_OK) return rc;
   const int d = h->hp.n_audio_state, Tn = h->hp.n_audio_ctx, nm = h->hp.n_mels, H = h->hp.n_audio_head;
   const long rows = (long)batch * Tn;
+  // encoder GEMM: f16 operands when the mode is on and an f16 copy of the weight exists (K multiple of 32)
+  auto egemm = [&](const GemmArgs& g, const void* wh, int nb) -> hipError_t {
+    if (h->enc_precision == 1 && wh && g.K % 32 == 0) return gemm_f16_nt(g, wh, nb, s);
+    return gemm_f32_nt(g, nb, s);
+  };
   // conv1 (k3, p1) + GELU: rows t of the padded frame-major mel are 3*n_mels contiguous floats
   {
     GemmArgs g = gemm(d_mel_t, nm, h->conv1_w, 3L * nm, h->w_h1 + d, d, h->conv1_b, MEL_FRAMES, d, 3 * nm);
@@ -433,27 +471,27 @@ int crispy_asr_encode_device(crispy_asr* h, const float* d_mel_t, int batch, flo
     g.gelu = 1;
     g.rowtab = h->enc_pos;
     g.rowtab_period = Tn;
-    HIP_TRY(gemm_f32_nt(g, batch, s));
+    HIP_TRY(egemm(g, h->conv2_wh, batch));
   }
   for (const EncLayer& L : h->enc) {
     HIP_TRY(layernorm_f32(h->w_x, L.ln1_w, L.ln1_b, h->w_xn, rows, d, s));
-    HIP_TRY(gemm_f32_nt(gemm(h->w_xn, d, L.qkv_w, d, h->w_qkv, 3L * d, L.qkv_b, (int)rows, 3 * d, d), 1, s));
+    HIP_TRY(egemm(gemm(h->w_xn, d, L.qkv_w, d, h->w_qkv, 3L * d, L.qkv_b, (int)rows, 3 * d, d), L.qkv_wh, 1));
     HIP_TRY(attn_encoder_f32(h->w_qkv, h->w_att, batch, Tn, d, H, s));
     {
       GemmArgs g = gemm(h->w_att, d, L.out_w, d, h->w_x, d, L.out_b, (int)rows, d, d);
       g.residual = h->w_x; g.ldr = d;
-      HIP_TRY(gemm_f32_nt(g, 1, s));
+      HIP_TRY(egemm(g, L.out_wh, 1));
     }
     HIP_TRY(layernorm_f32(h->w_x, L.ln2_w, L.ln2_b, h->w_xn, rows, d, s));
     {
       GemmArgs g = gemm(h->w_xn, d, L.fc1_w, d, h->w_h, 4L * d, L.fc1_b, (int)rows, 4 * d, d);
       g.gelu = 1;
-      HIP_TRY(gemm_f32_nt(g, 1, s));
+      HIP_TRY(egemm(g, L.fc1_wh, 1));
     }
     {
       GemmArgs g = gemm(h->w_h, 4L * d, L.fc2_w, 4L * d, h->w_x, d, L.fc2_b, (int)rows, d, 4 * d);
       g.residual = h->w_x; g.ldr = d;
-      HIP_TRY(gemm_f32_nt(g, 1, s));
+      HIP_TRY(egemm(g, L.fc2_wh, 1));
     }
   }
   HIP_TRY(layernorm_f32(h->w_x, h->ln_post_w, h->ln_post_b, d_out, rows, d, s));

@@ -211,6 +211,12 @@ int crispy_asr_encode_device(crispy_asr *h, const float *d_mel_t, int batch, flo
                              void *hip_stream);
 int crispy_asr_synchronize(crispy_asr *h);
 
+/* Encoder GEMM operand precision.  0 (default): f32 operands on the f32-input matrix cores -- what the parity tests
+ * against the float64 oracle pin to 1e-4.  1: f16 operands with f32 accumulation (weights stored as f16, activations
+ * rounded to f16 on the way into LDS) -- the numerics of whisper.cpp's ggml matrix products [UPSTREAM-RECALL], on
+ * v_mfma_f32_32x32x16_f16; attention, LayerNorm, the convolution stem's first layer and the decoder stay f32. */
+int crispy_asr_set_precision(crispy_asr *h, int mode);
+
 /* Greedy decoding (north_star: greedy; the sampling strategy transcribe-rs 0.3.11 selects is
  * unverifiable here).  Token ids listed with first_only = 0 are never
  * emitted; those with first_only = 1 only at the first sampled position (whisper's suppress_blank).

@@ -469,3 +469,30 @@ def test_transcribe_segments_follow_whisper_full_seek_loop(tiny, ggml_file, orac
     r = C.cast(res, C.POINTER(N.AsrResult)).contents
     assert r.language_token >= sp["lang0"] and r.n_tokens > 0 and r.n_segments >= 1
     N.lib().crispy_asr_free_result(res)
+
+
+def test_f16_operand_encoder_mode(tiny, model):
+    """crispy_asr_set_precision(1): encoder GEMMs with f16 operands / f32 accumulation (whisper.cpp's ggml numerics).
+    Tolerance: 5e-3 of the peak against the f32 mode (f16 rounding of weights and activations, observed ~1e-3);
+    greedy picks stay the same wherever the f32 top-2 margin is resolvable at that error (> 0.05)."""
+    from crispy_amd import synth_audio
+    G = np.load(GOLD)
+    x = synth_audio.clip16k_np(0, 464000)
+    ref = model.encode([x])
+    try:
+        model.set_precision(1)
+        got = model.encode([x])
+        toks, n = model.transcribe_tokens([x], G["prompt"].tolist(), 12)
+    finally:
+        model.set_precision(0)
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    assert 0 < err < 5e-3, err                       # different from f32 (the mode is on) and close to it
+    for i, (t, want, margin) in enumerate(zip(toks[0], G["greedy_tokens"], G["greedy_margin"])):
+        if margin > 0.05:
+            assert t == want, (i, toks[0], G["greedy_tokens"], G["greedy_margin"])
+        else:
+            break
+    again = model.encode([x])
+    assert np.array_equal(again, ref)                # back in f32 mode: bit-identical to before
+    with pytest.raises(Exception):
+        model.set_precision(2)

@@ -8,6 +8,7 @@ B = int(os.environ.get("B", 64)); NEW = int(os.environ.get("NEW", 32))
 hp = HParams.tiny() if os.environ.get("MODEL", "tiny") == "tiny" else HParams.base()
 W = synthetic_whisper_weights(hp, 0)
 m = WhisperModel(hp, W)
+m.set_precision(int(os.environ.get("PREC", 0)))   # 1: f16 operands for the encoder GEMMs
 lm = LogMel(hp.n_mels)
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(0)
