@@ -63,6 +63,7 @@ hipError_t gemm_f32_nt(const GemmArgs& g, int batch, hipStream_t s);
 // f16-operand variant (whisper_gemm_f16.hip): A f32 rounded to f16 on the way into LDS, Wh an f16 copy of W [N][ldw]
 hipError_t gemm_f16_nt(const GemmArgs& g, const void* Wh, int batch, hipStream_t s);
 hipError_t convert_f32_to_f16(const float* src, void* dst, long n, hipStream_t s);
+hipError_t attn_encoder_f16(const float* qkv, float* out, int B, int T, int D, int heads, hipStream_t s);
 hipError_t layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, long rows, int D, hipStream_t s);
 hipError_t attn_encoder_f32(const float* qkv, float* out, int B, int T, int D, int heads, hipStream_t s);
 hipError_t attn_decoder_f32(const float* q, long ldq, const float* kv, long kv_batch_stride, long ldkv, int koff,

@@ -476,7 +476,8 @@ int crispy_asr_encode_device(crispy_asr* h, const float* d_mel_t, int batch, flo
   for (const EncLayer& L : h->enc) {
     HIP_TRY(layernorm_f32(h->w_x, L.ln1_w, L.ln1_b, h->w_xn, rows, d, s));
     HIP_TRY(egemm(gemm(h->w_xn, d, L.qkv_w, d, h->w_qkv, 3L * d, L.qkv_b, (int)rows, 3 * d, d), L.qkv_wh, 1));
-    HIP_TRY(attn_encoder_f32(h->w_qkv, h->w_att, batch, Tn, d, H, s));
+    if (h->enc_precision == 1) HIP_TRY(attn_encoder_f16(h->w_qkv, h->w_att, batch, Tn, d, H, s));
+    else HIP_TRY(attn_encoder_f32(h->w_qkv, h->w_att, batch, Tn, d, H, s));
     {
       GemmArgs g = gemm(h->w_att, d, L.out_w, d, h->w_x, d, L.out_b, (int)rows, d, d);
       g.residual = h->w_x; g.ldr = d;

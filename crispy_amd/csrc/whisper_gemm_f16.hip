@@ -117,6 +117,122 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_kernel(GemmArgs g, const _Flo
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Encoder self-attention with f16 operands (same mode switch).  Same decomposition as attn_enc_kernel
+// (whisper_kernels.hip): wave = 32 queries, S^T = K.Q^T per 32-key tile, online softmax in f32 per lane,
+// O^T += V^T.P^T with P^T taken straight from the S^T accumulator registers.  With 16-deep MFMAs a tile is 4 + 4
+// instructions instead of 32 + 32.  The contraction order of the second product is free, so k-slot (lane half lh,
+// element e) of step ks is *defined* as the key held in this lane's S^T register 8 ks + e: no cross-lane exchange
+// of probabilities, V is simply gathered in that key order.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_enc_f16_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                           int T, int D) {
+  __shared__ float stage[4][32 * 65];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  if (q0 >= T) return;
+  const long ld = 3L * D;
+  const float* base = qkv + (long)b * T * ld;
+  const float* Qp = base + h * 64;
+  const float* Kp = base + D + h * 64;
+  const float* Vp = base + 2 * D + h * 64;
+
+  auto load8 = [](const float* p, float scale) {      // 8 consecutive floats -> half8
+    const float4 a = *reinterpret_cast<const float4*>(p), c = *reinterpret_cast<const float4*>(p + 4);
+    half8 r;
+    r[0] = (_Float16)(a.x * scale); r[1] = (_Float16)(a.y * scale); r[2] = (_Float16)(a.z * scale); r[3] = (_Float16)(a.w * scale);
+    r[4] = (_Float16)(c.x * scale); r[5] = (_Float16)(c.y * scale); r[6] = (_Float16)(c.z * scale); r[7] = (_Float16)(c.w * scale);
+    return r;
+  };
+  // Q operand of k-step ks: Q[q = li][16 ks + 8 lh .. + 7], pre-scaled by 1/8 (exact)
+  half8 qh[4];
+  {
+    const int q = min(q0 + li, T - 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qh[ks] = load8(Qp + (long)q * ld + 16 * ks + 8 * lh, 0.125f);
+  }
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m_run = -1e30f, l_run = 0.f;
+
+  for (int k0 = 0; k0 < T; k0 += 32) {
+    // ---- S^T tile: rows = keys (li), columns = queries ----
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    {
+      const int key = min(k0 + li, T - 1);
+      half8 kh[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) kh[ks] = load8(Kp + (long)key * ld + 16 * ks + 8 * lh, 1.f);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[ks], qh[ks], s, 0, 0, 0);
+    }
+    // V gather issued before the softmax arithmetic: register r of this lane is key (r&3) + 8(r>>2) + 4 lh
+    float v0[16], v1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = min(k0 + acc_row_h(r, lane), T - 1);
+      const float* vp = Vp + (long)key * ld;
+      v0[r] = vp[li];
+      v1[r] = vp[32 + li];
+    }
+    // ---- online softmax over this lane's 16 keys + the partner half's 16 ----
+    float mloc = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + acc_row_h(r, lane);
+      if (key >= T) s[r] = -1e30f;
+      mloc = fmaxf(mloc, s[r]);
+    }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float m_new = fmaxf(m_run, mloc);
+    const float alpha = __expf(m_run - m_new);
+    float psum = 0.f;
+    half8 ph[2], vh0[2], vh1[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = __expf(s[r] - m_new);
+      psum += p;
+      ph[r >> 3][r & 7] = (_Float16)p;
+      vh0[r >> 3][r & 7] = (_Float16)v0[r];
+      vh1[r >> 3][r & 7] = (_Float16)v1[r];
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    // ---- O^T += V^T . P^T, k-slot (lh, e) of step ks = the key of register 8 ks + e ----
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh0[ks], ph[ks], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh1[ks], ph[ks], o1, 0, 0, 0);
+    }
+  }
+  // ---- normalise, transpose through LDS, store rows of 64 floats ----
+  const float inv = 1.f / l_run;
+  float* st = stage[wave];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int d = acc_row_h(r, lane);
+    st[li * 65 + d] = o0[r] * inv;
+    st[li * 65 + 32 + d] = o1[r] * inv;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int idx = lane; idx < 32 * 64; idx += 64) {
+    const int q = idx >> 6, d = idx & 63;
+    if (q0 + q < T) out[((long)b * T + q0 + q) * D + h * 64 + d] = st[q * 65 + d];
+  }
+}
+
 __global__ void f32_to_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, long n) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) dst[i] = (_Float16)src[i];
@@ -128,6 +244,10 @@ __global__ void f32_to_f16_kernel(const float* __restrict__ src, _Float16* __res
 hipError_t gemm_f16_nt(const GemmArgs& g, const void* Wh, int batch, hipStream_t s) {
   dim3 grid((g.N + HB_N - 1) / HB_N, (g.M + HB_M - 1) / HB_M, batch);
   hipLaunchKernelGGL(gemm_f16_nt_kernel, grid, dim3(256), 0, s, g, reinterpret_cast<const _Float16*>(Wh));
+  return hipGetLastError();
+}
+hipError_t attn_encoder_f16(const float* qkv, float* out, int B, int T, int D, int heads, hipStream_t s) {
+  hipLaunchKernelGGL(attn_enc_f16_kernel, dim3((T + 127) / 128, heads, B), dim3(256), 0, s, qkv, out, T, D);
   return hipGetLastError();
 }
 hipError_t convert_f32_to_f16(const float* src, void* dst, long n, hipStream_t s) {
