@@ -69,6 +69,10 @@ hipError_t attn_encoder_f32(const float* qkv, float* out, int B, int T, int D, i
 hipError_t attn_decoder_f32(const float* q, long ldq, const float* kv, long kv_batch_stride, long ldkv, int koff,
                             int voff, int n_keys_base, const int* pos_dev, float* out, long ldo, int B, int heads,
                             hipStream_t s);
+// the same kernel over an f16 K|V buffer (cross-attention in precision mode 1)
+hipError_t attn_decoder_kv16(const float* q, long ldq, const void* kv, long kv_batch_stride, long ldkv, int koff,
+                             int voff, int n_keys_base, const int* pos_dev, float* out, long ldo, int B, int heads,
+                             hipStream_t s);
 hipError_t embed_tokens_f32(const int* tokens, const float* tok_emb, const float* pos_emb, int pos, const int* pos_dev,
                             float* x, int B, int D, hipStream_t s);
 hipError_t advance_counters(int* pos_dev, int* step_dev, hipStream_t s);

@@ -77,6 +77,7 @@ struct crispy_asr {
   int* d_tids_all = nullptr;                 // [n_text_ctx][dcap_batch]
   int* d_done_count = nullptr;
   int* d_finished = nullptr;                 // [dcap_batch] plain greedy decoding: clip has produced its EOT
+  void* d_xkv_h = nullptr;                   // f16 copy of the cross K|V (precision mode 1)
   unsigned char* d_ts_mask = nullptr;        // [n_vocab] whisper.cpp's always-suppressed specials
   unsigned char* d_ts_mask_first = nullptr;  // ... plus suppress_blank (" " and EOT) at the first position
   hipGraphExec_t ts_graph = nullptr;
@@ -227,6 +228,7 @@ void free_dec_ws(crispy_asr* h) {
   if (h->d_tids_all) { (void)hipFree(h->d_tids_all); h->d_tids_all = nullptr; }
   if (h->d_done_count) { (void)hipFree(h->d_done_count); h->d_done_count = nullptr; }
   if (h->d_finished) { (void)hipFree(h->d_finished); h->d_finished = nullptr; }
+  if (h->d_xkv_h) { (void)hipFree(h->d_xkv_h); h->d_xkv_h = nullptr; }
   h->dcap_batch = 0;
 }
 
@@ -434,6 +436,10 @@ int crispy_asr_set_precision(crispy_asr* h, int mode) {
     if (rc != CRISPY_OK) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
   }
+  if (h->enc_precision != mode) {   // the captured decode steps bake the cross-attention kernel in
+    if (h->dec_graph) { (void)hipGraphExecDestroy(h->dec_graph); h->dec_graph = nullptr; h->dec_graph_batch = 0; }
+    if (h->ts_graph) { (void)hipGraphExecDestroy(h->ts_graph); h->ts_graph = nullptr; h->ts_graph_batch = 0; }
+  }
   h->enc_precision = mode;
   return CRISPY_OK;
 }
@@ -559,6 +565,7 @@ int reserve_dec(crispy_asr* h, int batch, int max_tokens) {
   HIP_TRY(hipMalloc(&h->d_tids_all, B * C * sizeof(int)));
   HIP_TRY(hipMalloc(&h->d_done_count, sizeof(int)));
   HIP_TRY(hipMalloc(&h->d_finished, B * sizeof(int)));
+  HIP_TRY(hipMalloc(&h->d_xkv_h, L * B * Tn * 2 * dt * 2));
   h->dcap_batch = batch;
   return CRISPY_OK;
 }
@@ -610,7 +617,11 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
       HIP_TRY(layernorm_f32(h->d_dx, L.lnx_w, L.lnx_b, h->d_dxn, batch, dt, s));
       HIP_TRY(gemm_f32_nt(gemm(h->d_dxn, dt, L.xq_w, dt, h->d_dq, dt, L.xq_b, batch, dt, dt), 1, s));
     }
-    HIP_TRY(attn_decoder_f32(h->d_dq, dt, xkv, (long)Tn * 2 * dt, 2L * dt, 0, dt, Tn, nullptr, h->d_datt, dt, batch, H, s));
+    if (h->enc_precision == 1)
+      HIP_TRY(attn_decoder_kv16(h->d_dq, dt, reinterpret_cast<const char*>(h->d_xkv_h) + l * (size_t)batch * Tn * 2 * dt * 2,
+                                (long)Tn * 2 * dt, 2L * dt, 0, dt, Tn, nullptr, h->d_datt, dt, batch, H, s));
+    else
+      HIP_TRY(attn_decoder_f32(h->d_dq, dt, xkv, (long)Tn * 2 * dt, 2L * dt, 0, dt, Tn, nullptr, h->d_datt, dt, batch, H, s));
     {
       GemmArgs g = gemm(h->d_datt, dt, L.xout_w, dt, h->d_dx, dt, L.xout_b, batch, dt, dt);
       g.residual = h->d_dx; g.ldr = dt;
@@ -677,12 +688,23 @@ Special special_tokens(const crispy_asr* h) {
 
 // cross K | V of every layer once per window, then the prompt tokens one position at a time (the language
 // token may differ per clip); leaves the logits of the last prompt position in h->d_logits
-int prefill(crispy_asr* h, const float* d_enc, int batch, const int* prompt, int n_prompt, const int* lang_tokens,
-            hipStream_t s, int* pos_out) {
+// cross K | V of every layer, once per window (f16 mode: the decode steps stream an f16 copy of it)
+int compute_cross_kv(crispy_asr* h, const float* d_enc, int batch, hipStream_t s) {
   const int dt = h->hp.n_text_state, Tn = h->hp.n_audio_ctx;
   for (size_t l = 0; l < h->dec.size(); ++l) {
     float* xkv = h->d_xkv + l * (size_t)batch * Tn * 2 * dt;
     HIP_TRY(gemm_f32_nt(gemm(d_enc, dt, h->dec[l].xkv_w, dt, xkv, 2L * dt, h->dec[l].xkv_b, batch * Tn, 2 * dt, dt), 1, s));
+  }
+  if (h->enc_precision == 1)
+    HIP_TRY(convert_f32_to_f16(h->d_xkv, h->d_xkv_h, (long)h->dec.size() * batch * Tn * 2 * dt, s));
+  return CRISPY_OK;
+}
+
+int prefill(crispy_asr* h, const float* d_enc, int batch, const int* prompt, int n_prompt, const int* lang_tokens,
+            hipStream_t s, int* pos_out) {
+  {
+    const int rc = compute_cross_kv(h, d_enc, batch, s);
+    if (rc != CRISPY_OK) return rc;
   }
   std::vector<int> tok(batch);
   int pos = 0;
@@ -941,11 +963,9 @@ int crispy_asr_detect_language_device(crispy_asr* h, const float* d_enc, int bat
   hipStream_t s = h->stream;
   int rc = reserve_dec(h, batch, 1);
   if (rc != CRISPY_OK) return rc;
-  const int dt = h->hp.n_text_state, Tn = h->hp.n_audio_ctx, V = h->hp.n_vocab;
-  for (size_t l = 0; l < h->dec.size(); ++l) {
-    float* xkv = h->d_xkv + l * (size_t)batch * Tn * 2 * dt;
-    HIP_TRY(gemm_f32_nt(gemm(d_enc, dt, h->dec[l].xkv_w, dt, xkv, 2L * dt, h->dec[l].xkv_b, batch * Tn, 2 * dt, dt), 1, s));
-  }
+  const int V = h->hp.n_vocab;
+  rc = compute_cross_kv(h, d_enc, batch, s);
+  if (rc != CRISPY_OK) return rc;
   const int sot = h->eot + 1, n_lang = 99 + (V - 51865);
   std::vector<int> tok(batch, sot);
   HIP_TRY(hipMemcpyAsync(h->d_tok, tok.data(), sizeof(int) * batch, hipMemcpyHostToDevice, s));

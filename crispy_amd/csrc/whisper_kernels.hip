@@ -381,8 +381,18 @@ __global__ __launch_bounds__(256) void attn_enc_kernel(const float* __restrict__
 #define AD_WAVES_N 16
 #endif
 constexpr int AD_WAVES = AD_WAVES_N;   // key partitions per (clip, head): 1.2 GB of cross K|V per step want many loads in flight
+template <class KV> __device__ __forceinline__ float4 ld4(const KV* p);
+template <> __device__ __forceinline__ float4 ld4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ __forceinline__ float4 ld4<_Float16>(const _Float16* p) {
+  typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+  const half4 h = *reinterpret_cast<const half4*>(p);
+  return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+}
+// KV = float (self-attention cache, default cross K|V) or _Float16 (cross K|V in precision mode 1: half the bytes of
+// the stream that dominates a decode step; whisper.cpp keeps its KV caches in f16 as well)
+template <class KV>
 __global__ __launch_bounds__(64 * AD_WAVES) void attn_dec_kernel(const float* __restrict__ q, long ldq,
-                                                       const float* __restrict__ kv, long kv_batch_stride,
+                                                       const KV* __restrict__ kv, long kv_batch_stride,
                                                        long ldkv, int koff, int voff, int n_keys_base,
                                                        const int* __restrict__ pos_dev, float* __restrict__ out, long ldo) {
   __shared__ float p_s[1536];
@@ -394,8 +404,8 @@ __global__ __launch_bounds__(64 * AD_WAVES) void attn_dec_kernel(const float* __
   const int n_keys = n_keys_base + (pos_dev ? *pos_dev : 0);
   if (tid < 64) q_s[tid] = q[(long)b * ldq + h * 64 + tid] * 0.125f;
   __syncthreads();
-  const float* Kb = kv + (long)b * kv_batch_stride + koff + h * 64;
-  const float* Vb = kv + (long)b * kv_batch_stride + voff + h * 64;
+  const KV* Kb = kv + (long)b * kv_batch_stride + koff + h * 64;
+  const KV* Vb = kv + (long)b * kv_batch_stride + voff + h * 64;
   const int per = (n_keys + AD_WAVES - 1) / AD_WAVES;
   const int k_lo = wave * per, k_hi = min(n_keys, k_lo + per);
   // scores: 16 lanes share one key row (coalesced 256-byte reads, 4 keys per wave instruction), the
@@ -412,7 +422,7 @@ __global__ __launch_bounds__(64 * AD_WAVES) void attn_dec_kernel(const float* __
         const int k = kb + 4 * u + sub;
         sacc[u] = 0.f;
         if (k < k_hi) {
-          const float4 t = *reinterpret_cast<const float4*>(Kb + (long)k * ldkv + 4 * c);
+          const float4 t = ld4<KV>(Kb + (long)k * ldkv + 4 * c);
           sacc[u] = t.x * qv.x;
           sacc[u] = fmaf(t.y, qv.y, sacc[u]);
           sacc[u] = fmaf(t.z, qv.z, sacc[u]);
@@ -458,13 +468,13 @@ __global__ __launch_bounds__(64 * AD_WAVES) void attn_dec_kernel(const float* __
   for (; k + 7 < k_hi; k += 8) {                        // 8 independent 256-byte row reads in flight
     float v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = Vb[(long)(k + u) * ldkv + lane];
+    for (int u = 0; u < 8; ++u) v[u] = (float)Vb[(long)(k + u) * ldkv + lane];
     a0 = fmaf(p_s[k], v[0], a0); a1 = fmaf(p_s[k + 1], v[1], a1);
     a2 = fmaf(p_s[k + 2], v[2], a2); a3 = fmaf(p_s[k + 3], v[3], a3);
     a0 = fmaf(p_s[k + 4], v[4], a0); a1 = fmaf(p_s[k + 5], v[5], a1);
     a2 = fmaf(p_s[k + 6], v[6], a2); a3 = fmaf(p_s[k + 7], v[7], a3);
   }
-  for (; k < k_hi; ++k) a0 = fmaf(p_s[k], Vb[(long)k * ldkv + lane], a0);
+  for (; k < k_hi; ++k) a0 = fmaf(p_s[k], (float)Vb[(long)k * ldkv + lane], a0);
   part_o[wave][lane] = (a0 + a1) + (a2 + a3);
   if (lane == 0) { part_m[wave] = mloc; part_l[wave] = lsum; }
   __syncthreads();
@@ -689,8 +699,15 @@ hipError_t attn_encoder_f32(const float* qkv, float* out, int B, int T, int D, i
 hipError_t attn_decoder_f32(const float* q, long ldq, const float* kv, long kv_batch_stride, long ldkv, int koff,
                             int voff, int n_keys_base, const int* pos_dev, float* out, long ldo, int B, int heads,
                             hipStream_t s) {
-  hipLaunchKernelGGL(attn_dec_kernel, dim3(heads, B), dim3(64 * AD_WAVES), 0, s, q, ldq, kv, kv_batch_stride, ldkv, koff, voff,
+  hipLaunchKernelGGL(attn_dec_kernel<float>, dim3(heads, B), dim3(64 * AD_WAVES), 0, s, q, ldq, kv, kv_batch_stride, ldkv, koff, voff,
                      n_keys_base, pos_dev, out, ldo);
+  return hipGetLastError();
+}
+hipError_t attn_decoder_kv16(const float* q, long ldq, const void* kv, long kv_batch_stride, long ldkv, int koff,
+                             int voff, int n_keys_base, const int* pos_dev, float* out, long ldo, int B, int heads,
+                             hipStream_t s) {
+  hipLaunchKernelGGL(attn_dec_kernel<_Float16>, dim3(heads, B), dim3(64 * AD_WAVES), 0, s, q, ldq,
+                     reinterpret_cast<const _Float16*>(kv), kv_batch_stride, ldkv, koff, voff, n_keys_base, pos_dev, out, ldo);
   return hipGetLastError();
 }
 hipError_t embed_tokens_f32(const int* tokens, const float* tok_emb, const float* pos_emb, int pos, const int* pos_dev,
