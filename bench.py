@@ -121,13 +121,20 @@ def asr_leg(local_rank: int, clips: int = 64, new_tokens: int = 32):
     def decode():
         model.decode_greedy_device(enc.data_ptr(), clips, prompt, new_tokens)
 
-    times = {}
-    for name, fn, reps in (("logmel", mel, 5), ("encoder", encode, 3), ("decode", decode, 1)):
-        fn()  # warm-up
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        times[name] = (time.perf_counter() - t0) / reps
+    def measure():
+        t = {}
+        for name, fn, reps in (("logmel", mel, 5), ("encoder", encode, 3), ("decode", decode, 1)):
+            fn()  # warm-up
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            t[name] = (time.perf_counter() - t0) / reps
+        return t
+
+    times = measure()                      # default precision: f32 operands, the mode the oracle parity is pinned in
+    model.set_precision(1)                 # opt-in: f16 operands / f32 accumulation (whisper.cpp's ggml numerics)
+    times16 = measure()
+    model.set_precision(0)
     # CPU beside it: the float64 numpy oracle (BLAS on the host cores) on ONE 30 s clip, encoder + 2 greedy steps
     cpu = None
     try:
@@ -162,6 +169,11 @@ def asr_leg(local_rank: int, clips: int = 64, new_tokens: int = 32):
         "clips": clips, "audio_seconds": audio_s, "new_tokens": new_tokens,
         "logmel_ms": times["logmel"] * 1e3, "encoder_ms": times["encoder"] * 1e3,
         "decode_ms": times["decode"] * 1e3, "decode_ms_per_token": times["decode"] * 1e3 / new_tokens,
+        "f16_operand_mode": {"note": "crispy_asr_set_precision(1): encoder GEMMs + attention on v_mfma_f32_32x32x16_f16, f16 cross K|V; "
+                                     "tolerance-checked against the f32 mode (tests/test_gpu_whisper.py), not the headline",
+                             "encoder_ms": times16["encoder"] * 1e3, "decode_ms": times16["decode"] * 1e3,
+                             "rtfx_end_to_end": audio_s / sum(times16.values()),
+                             "encoder_tflops": enc_flops / times16["encoder"] / 1e12},
         "rtfx_logmel_encoder": audio_s / (times["logmel"] + times["encoder"]),
         "rtfx_end_to_end": audio_s / total,
         "logmel_roofline": {"bound": "hbm", "achieved": clips * 2.88e6 / times["logmel"] / 1e9, "peak": HBM_PEAK_GBS,
