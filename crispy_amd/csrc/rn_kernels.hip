@@ -70,11 +70,6 @@ template <int R>
 __device__ __forceinline__ void butterfly(const float2 (&v)[R], float2 (&o)[R]);
 
 template <>
-__device__ __forceinline__ void butterfly<2>(const float2 (&v)[2], float2 (&o)[2]) {
-  o[0] = cadd(v[0], v[1]);
-  o[1] = csub(v[0], v[1]);
-}
-template <>
 __device__ __forceinline__ void butterfly<4>(const float2 (&v)[4], float2 (&o)[4]) {
   const float2 s0 = cadd(v[0], v[2]), d0 = csub(v[0], v[2]);
   const float2 s1 = cadd(v[1], v[3]), d1 = csub(v[1], v[3]);
@@ -321,11 +316,6 @@ __device__ __forceinline__ void band_pairs(const float2* S, const float2* Xc, fl
     }
     band_total(Cout);
   }
-}
-
-// per-bin interpolation of 22 band values (bins >= 400 are zero)
-__device__ __forceinline__ float interp_gain(const float* v, int band, float frac) {
-  return (1.f - frac) * v[band] + frac * v[band + 1];
 }
 
 // ---------------------------------------------------------------------------------------------
