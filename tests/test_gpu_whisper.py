@@ -496,3 +496,34 @@ def test_f16_operand_encoder_mode(tiny, model):
     assert np.array_equal(again, ref)                # back in f32 mode: bit-identical to before
     with pytest.raises(Exception):
         model.set_precision(2)
+
+
+def test_large_v3_turbo_dimensions_parity(oracle):
+    """The catalog's large-v3-turbo (managers/model.rs:74-148) has d = 1280, 20 heads, 128 mel bins, 4 decoder layers
+    and a 51866-token vocabulary.  The layer count of the encoder is cut to 2 here (the per-layer code path is the
+    same) so that the float64 oracle finishes in seconds; everything dimension-dependent -- 128-mel conv stem, K = 1280
+    and 5120 GEMMs, 20-head attention, LayerNorm at D = 1280, the extra language token -- runs at full size."""
+    from crispy_amd import synth_audio
+    from crispy_amd.asr import WhisperModel
+    from crispy_amd.mel_filters import whisper_mel_filters
+    from crispy_amd.whisper_weights import HParams, synthetic_whisper_weights
+    from oracle import whisper_oracle as WO
+    hp = HParams(n_vocab=51866, n_audio_state=1280, n_audio_head=20, n_audio_layer=2, n_text_state=1280, n_text_head=20,
+                 n_text_layer=4, n_mels=128)
+    W = synthetic_whisper_weights(hp, 2)
+    m = WhisperModel(hp, W)
+    x = synth_audio.clip16k_np(90, 200000)
+    enc = m.encode([x])[0]
+    ref = WO.encoder_forward(W, hp, oracle.oracle_logmel(x, whisper_mel_filters(128)))
+    assert enc.shape == (1500, 1280)
+    assert np.abs(enc - ref).max() <= 1e-4 * np.abs(ref).max()
+    sp = WO.special_tokens(hp.n_vocab)
+    assert (sp["n_lang"], sp["transcribe"], sp["not_"], sp["beg"]) == (100, 50360, 50364, 50365)
+    prompt = [sp["sot"], sp["lang0"], sp["transcribe"], sp["not_"]]
+    toks, _ = m.transcribe_tokens([x], prompt, 3)
+    rt, rb, rm = WO.greedy_decode(W, hp, ref, prompt, 3)
+    for i in range(3):
+        if rm[i] > 1e-3:
+            assert toks[0, i] == rt[i]
+        else:
+            break
