@@ -294,23 +294,36 @@ __global__ __launch_bounds__(256) void attn_enc_kernel(const float* __restrict__
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m_run = -1e30f, l_run = 0.f;
 
+  // K rows of the next tile are loaded while the current tile's P.V MFMAs run, V rows before the softmax arithmetic:
+  // with two waves per SIMD an exposed HBM/L2 round trip per product left the matrix pipe 40 % idle
+  float kreg[32];
+  auto load_k = [&](int k0) {
+    const int key = min(k0 + li, T - 1);
+    const float4* p = reinterpret_cast<const float4*>(Kp + (long)key * ld + 32 * lh);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float4 t = p[c];
+      kreg[4 * c] = t.x; kreg[4 * c + 1] = t.y; kreg[4 * c + 2] = t.z; kreg[4 * c + 3] = t.w;
+    }
+  };
+  load_k(0);
   for (int k0 = 0; k0 < T; k0 += 32) {
     // ---- S^T tile ----
     f32x16 s;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
-    {
-      const int key = min(k0 + li, T - 1);
-      const float4* p = reinterpret_cast<const float4*>(Kp + (long)key * ld + 32 * lh);
-      float kreg[32];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const float4 t = p[c];
-        kreg[4 * c] = t.x; kreg[4 * c + 1] = t.y; kreg[4 * c + 2] = t.z; kreg[4 * c + 3] = t.w;
-      }
+    for (int st = 0; st < 32; ++st) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[st], qreg[st], s, 0, 0, 0);
+    // V rows of this tile and K rows of the next one go out now
+    float v0[16], v1[16];
 #pragma unroll
-      for (int st = 0; st < 32; ++st) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[st], qreg[st], s, 0, 0, 0);
+    for (int r = 0; r < 16; ++r) {
+      const int key = min(k0 + acc_row(r, lane), T - 1);
+      const float* vp = Vp + (long)key * ld;
+      v0[r] = vp[li];
+      v1[r] = vp[32 + li];
     }
+    if (k0 + 32 < T) load_k(k0 + 32);
     // ---- online softmax over this lane's 16 keys + the partner half's 16 ----
     float mloc = -1e30f;
 #pragma unroll
@@ -335,20 +348,10 @@ __global__ __launch_bounds__(256) void attn_enc_kernel(const float* __restrict__
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
     // ---- O^T += V^T . P^T ----
-    {
-      float v0[16], v1[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = min(k0 + acc_row(r, lane), T - 1);
-        const float* vp = Vp + (long)key * ld;
-        v0[r] = vp[li];
-        v1[r] = vp[32 + li];
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[r], s[r], o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[r], s[r], o1, 0, 0, 0);
-      }
+    for (int r = 0; r < 16; ++r) {
+      o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[r], s[r], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[r], s[r], o1, 0, 0, 0);
     }
   }
   // ---- normalise, transpose through LDS, store rows of 64 floats ----
