@@ -59,6 +59,7 @@ struct GemmArgs {
   const float* ln_s; const float* ln_c;
   float* C2; long ldc2; int n_split;
 };
+constexpr int SKINNY_MAX_M = 512;   // decode steps with up to this many clips use the skinny kernel (row blocks of 64)
 hipError_t gemm_f32_nt(const GemmArgs& g, int batch, hipStream_t s);
 // f16-operand variant (whisper_gemm_f16.hip): A f32 rounded to f16 on the way into LDS, Wh an f16 copy of W [N][ldw]
 hipError_t gemm_f16_nt(const GemmArgs& g, const void* Wh, int batch, hipStream_t s);

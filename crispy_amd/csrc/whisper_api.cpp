@@ -578,9 +578,9 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
   const int dt = h->hp.n_text_state, H = h->hp.n_text_head, Tn = h->hp.n_audio_ctx, C = h->hp.n_text_ctx,
             V = h->hp.n_vocab;
   const int* pos_dev = dev_pos ? h->d_counters : nullptr;
-  // <= 64 clips: the projections run on the skinny kernel, which folds the preceding LayerNorm in and writes q and
+  // <= SKINNY_MAX_M clips: the projections run on the skinny kernel (row blocks of 64 clips), which folds the preceding LayerNorm in and writes q and
   // k|v of the self-attention block from one launch (17 launches fewer per step on Whisper-tiny)
-  const bool fold = batch <= 64 && dt % 128 == 0;
+  const bool fold = batch <= SKINNY_MAX_M && dt % 128 == 0;
   HIP_TRY(embed_tokens_f32(h->d_tok, h->tok_emb, h->dec_pos, pos, pos_dev, h->d_dx, batch, dt, s));
   for (size_t l = 0; l < h->dec.size(); ++l) {
     const DecLayer& L = h->dec[l];

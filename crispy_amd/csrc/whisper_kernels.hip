@@ -133,6 +133,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_f32_kernel(GemmArgs g) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, lh = lane >> 5;
   const int n0 = blockIdx.x * 32;
+  const int mb = blockIdx.y * 64;            // row block: more than 64 clips per step run as extra workgroups (W stays in L2)
   const float* __restrict__ A = g.A;
   const float* __restrict__ W = g.W;
   const bool second = g.C2 && n0 >= g.n_split;      // split output: a workgroup's 32 columns go to one destination
@@ -142,10 +143,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_f32_kernel(GemmArgs g) {
   const int kper = g.K / 4;                 // K range of this wave (multiple of 32)
   const int kbeg = wave * kper;
   const int n = min(n0 + li, g.N - 1);
-  const bool r0ok = li < g.M, r1ok = 32 + li < g.M;
+  const bool r0ok = mb + li < g.M, r1ok = mb + 32 + li < g.M;
   const float* wrow = W + (long)n * g.ldw + kbeg + 16 * lh;
-  const float* a0row = A + (long)min(li, g.M - 1) * g.lda + kbeg + 16 * lh;
-  const float* a1row = A + (long)min(32 + li, g.M - 1) * g.lda + kbeg + 16 * lh;
+  const float* a0row = A + (long)min(mb + li, g.M - 1) * g.lda + kbeg + 16 * lh;
+  const float* a1row = A + (long)min(mb + 32 + li, g.M - 1) * g.lda + kbeg + 16 * lh;
   f32x16 acc0, acc1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
@@ -200,13 +201,14 @@ __global__ __launch_bounds__(256) void gemm_skinny_f32_kernel(GemmArgs g) {
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const int idx = tid + 256 * q;
-    const int m = idx >> 5, c = idx & 31;
+    const int ml = idx >> 5, c = idx & 31;      // ml: row inside this 64-row block
+    const int m = mb + ml;
     const int nn = n0 + c;
     if (m < g.M && nn < g.N) {
-      float v = red[0][m * 33 + c] + red[1][m * 33 + c] + red[2][m * 33 + c] + red[3][m * 33 + c];
+      float v = red[0][ml * 33 + c] + red[1][ml * 33 + c] + red[2][ml * 33 + c] + red[3][ml * 33 + c];
       if (g.ln_s) {
-        const float sum = rstat[0][m][0] + rstat[1][m][0] + rstat[2][m][0] + rstat[3][m][0];
-        const float sq = rstat[0][m][1] + rstat[1][m][1] + rstat[2][m][1] + rstat[3][m][1];
+        const float sum = rstat[0][ml][0] + rstat[1][ml][0] + rstat[2][ml][0] + rstat[3][ml][0];
+        const float sq = rstat[0][ml][1] + rstat[1][ml][1] + rstat[2][ml][1] + rstat[3][ml][1];
         const float mean = sum / (float)g.K;
         const float var = fmaxf(sq / (float)g.K - mean * mean, 0.f);
         const float rstd = 1.f / sqrtf(var + 1e-5f);
@@ -682,8 +684,8 @@ __global__ void advance_kernel(int* __restrict__ pos_dev, int* __restrict__ step
 }  // namespace
 
 hipError_t gemm_f32_nt(const GemmArgs& g, int batch, hipStream_t s) {
-  if (batch == 1 && g.M <= 64 && g.K % 128 == 0 && !g.rowtab) {   // one decode step: latency-bound shape
-    hipLaunchKernelGGL(gemm_skinny_f32_kernel, dim3((g.N + 31) / 32), dim3(256), 0, s, g);
+  if (batch == 1 && g.M <= SKINNY_MAX_M && g.K % 128 == 0 && !g.rowtab) {   // one decode step: latency-bound shape
+    hipLaunchKernelGGL(gemm_skinny_f32_kernel, dim3((g.N + 31) / 32, (g.M + 63) / 64), dim3(256), 0, s, g);
     return hipGetLastError();
   }
   dim3 grid((g.N + GB_N - 1) / GB_N, (g.M + GB_M - 1) / GB_M, batch);

@@ -527,3 +527,22 @@ def test_large_v3_turbo_dimensions_parity(oracle):
             assert toks[0, i] == rt[i]
         else:
             break
+
+
+def test_decode_batches_beyond_64_clips(model):
+    """More than 64 clips per decode step run as extra 64-row blocks of the skinny projection kernel (LayerNorm fold,
+    split q / k|v output included): 70 clips decoded together give exactly -- tokens and the f32 logits of the picks --
+    what they give in two smaller batches."""
+    import torch
+    from crispy_amd import synth_audio
+    prompt = [50258, 50259, 50359, 50363]
+    clips = [synth_audio.clip16k_np(200 + i, 40000 + 1000 * i) for i in range(70)]
+    d_enc = torch.from_numpy(model.encode(clips)).cuda()
+    torch.cuda.synchronize()
+    esz = d_enc[0].numel() * 4
+    all_t, _, all_l = model.decode_greedy_device(d_enc.data_ptr(), 70, prompt, 6)
+    a_t, _, a_l = model.decode_greedy_device(d_enc.data_ptr(), 40, prompt, 6)
+    b_t, _, b_l = model.decode_greedy_device(d_enc.data_ptr() + 40 * esz, 30, prompt, 6)
+    assert np.array_equal(all_t, np.concatenate([a_t, b_t]))
+    assert np.array_equal(all_l, np.concatenate([a_l, b_l]))
+    assert len(np.unique(all_l[:, 0])) > 60          # the clips are different: so are the logits of their first pick

@@ -21,7 +21,7 @@ from crispy_amd.whisper_weights import HParams, synthetic_whisper_weights
 
 rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 local = int(os.environ.get("LOCAL_RANK", 0))
-TOTAL = int(os.environ.get("STREAMS", 1024 * world)); SUB = int(os.environ.get("SUB", 64)); NEW = int(os.environ.get("NEW", 32))
+TOTAL = int(os.environ.get("STREAMS", 1024 * world)); SUB = int(os.environ.get("SUB", 256)); NEW = int(os.environ.get("NEW", 32))
 hp = HParams.base() if os.environ.get("MODEL", "base") == "base" else HParams.tiny()
 if world > 1:
     import torch.distributed as dist
