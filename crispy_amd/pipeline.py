@@ -91,6 +91,11 @@ class DenoiseTranscribePipeline:
             self.lm.synchronize()
             self.whisper.encode_device(melt.data_ptr(), B, enc.data_ptr())
             self.whisper.synchronize()
-            t, _, _ = self.whisper.decode_greedy_device(enc.data_ptr(), B, prompt, max_new)
-            toks[:, c] = t
+            # decode in groups of <= 512 clips: that is the range of the fused decode-step kernels (skinny projections
+            # with the LayerNorm folded in); larger steps fall back to the general GEMM + separate LayerNorm launches
+            esz = enc[0].numel() * 4
+            for b0 in range(0, B, 512):
+                nb = min(512, B - b0)
+                t, _, _ = self.whisper.decode_greedy_device(enc.data_ptr() + b0 * esz, nb, prompt, max_new)
+                toks[b0:b0 + nb, c] = t
         return toks, pcm16[:, :n16]

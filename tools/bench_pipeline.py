@@ -11,7 +11,9 @@ from crispy_amd.whisper_weights import HParams, synthetic_whisper_weights
 B = int(os.environ.get("B", 1024)); T = int(os.environ.get("T", 3001)); NEW = int(os.environ.get("NEW", 32))
 dev = torch.device("cuda:0")
 hp = HParams.tiny()
-pipe = DenoiseTranscribePipeline(synthetic_weights(0), WhisperModel(hp, synthetic_whisper_weights(hp, 0)), B)
+wm = WhisperModel(hp, synthetic_whisper_weights(hp, 0))
+wm.set_precision(int(os.environ.get("PREC", 0)))     # 1: f16-operand encoder / cross K|V
+pipe = DenoiseTranscribePipeline(synthetic_weights(0), wm, B)
 x = synth_audio.batch_torch(B, T, dev).transpose(0, 1).contiguous()     # [B, T, 480] (BTF)
 torch.cuda.synchronize()
 prompt = [50258, 50259, 50359, 50363]
