@@ -23,6 +23,9 @@ namespace crispy {
 namespace {
 
 constexpr int WAVE = 64;
+#ifndef RN_TAIL_REGS
+#define RN_TAIL_REGS 1   // 1: the fused kernel keeps the overlap-add tail in registers across frames
+#endif
 constexpr int RN_SYNTH_GROUP = 5;   // frames per synthesis workgroup (plus one warm-up frame)
 
 // In-kernel stage stamps (diagnostic build only: make PROFILE=1 -> libcrispy_hip_prof.so).
@@ -638,11 +641,12 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
   // are what pushed the kernel into scratch spills.  The synthesis kernel (low pressure) keeps it in registers.
   float2 synth[4];
   float* synth_g = a.synth + (long)b * 480;
-  if constexpr (MODE == 2) {
+  constexpr bool TAIL_REGS = MODE == 2 || RN_TAIL_REGS;
+  if constexpr (TAIL_REGS) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int n = lane + WAVE * m;
-      synth[m] = (n < 240 && blockIdx.y == 0) ? *reinterpret_cast<const float2*>(synth_g + 2 * n) : make_float2(0.f, 0.f);
+      synth[m] = (n < 240 && (MODE != 2 || blockIdx.y == 0)) ? *reinterpret_cast<const float2*>(synth_g + 2 * n) : make_float2(0.f, 0.f);
     }
   }
   float lastg = lane < RN_NB ? a.lastg[(long)b * RN_NB + lane] : 0.f;
@@ -1406,7 +1410,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
     asm volatile("" : "+v"(lane));
     // ---- 10. frame_synthesis: inverse FFT, window, overlap-add ----
     real_inv_pre(L.A, w960, lane);
-    if constexpr (MODE == 0) {
+    if constexpr (!TAIL_REGS) {
       // issued ahead of the inverse FFT, consumed after it
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
@@ -1431,7 +1435,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
           if (t >= t_out) *reinterpret_cast<float2*>(o + i0) = ov;
           synth[m].x = z2.x * hw[479 - i0];
           synth[m].y = -z2.y * hw[479 - i1];
-          if constexpr (MODE == 0) *reinterpret_cast<float2*>(synth_g + i0) = synth[m];
+          if constexpr (!TAIL_REGS) *reinterpret_cast<float2*>(synth_g + i0) = synth[m];
         }
       }
     }
@@ -1440,7 +1444,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
   }
 
   // ---- store per-stream state (each kernel of the staged pipeline owns its part) ----
-  if (MODE == 2 && t_last == a.T) {
+  if (TAIL_REGS && (MODE != 2 || t_last == a.T)) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int n = lane + WAVE * m;
