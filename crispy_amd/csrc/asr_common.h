@@ -58,8 +58,13 @@ struct GemmArgs {
   //    decoder self-attention block in one launch.
   const float* ln_s; const float* ln_c;
   float* C2; long ldc2; int n_split;
+  // Tiled kernel only: head-major store for the cross K|V projection.  Row m = (clip b, frame t) with hm_rows frames
+  // per clip, column n = (K or V, head, dim): element goes to C[((b * 2 + kv) * heads + head) * hm_rows * 64 + t * 64
+  // + dim], so that one (clip, head) K or V block is a contiguous [hm_rows][64] run for the decode-step attention.
+  int hm_rows, hm_width;                      // hm_rows = 0: plain row-major C;  hm_width = model width (N = 2 * width)
+  int tiled;                                  // != 0: run the 128 x 128 tiled kernel even for a decode-step shape
 };
-constexpr int SKINNY_MAX_M = 512;   // decode steps with up to this many clips use the skinny kernel (row blocks of 64)
+constexpr int SKINNY_MAX_M = 512;   // decode steps with up to this many clips use the skinny kernel (row blocks of 32)
 hipError_t gemm_f32_nt(const GemmArgs& g, int batch, hipStream_t s);
 // f16-operand variant (whisper_gemm_f16.hip): A f32 rounded to f16 on the way into LDS, Wh an f16 copy of W [N][ldw]
 hipError_t gemm_f16_nt(const GemmArgs& g, const void* Wh, int batch, hipStream_t s);
@@ -67,12 +72,12 @@ hipError_t convert_f32_to_f16(const float* src, void* dst, long n, hipStream_t s
 hipError_t attn_encoder_f16(const float* qkv, float* out, int B, int T, int D, int heads, hipStream_t s);
 hipError_t layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, long rows, int D, hipStream_t s);
 hipError_t attn_encoder_f32(const float* qkv, float* out, int B, int T, int D, int heads, hipStream_t s);
-hipError_t attn_decoder_f32(const float* q, long ldq, const float* kv, long kv_batch_stride, long ldkv, int koff,
-                            int voff, int n_keys_base, const int* pos_dev, float* out, long ldo, int B, int heads,
+hipError_t attn_decoder_f32(const float* q, long ldq, const float* kv, long kv_batch_stride, long ldkv, long head_stride,
+                            long koff, long voff, int n_keys_base, const int* pos_dev, float* out, long ldo, int B, int heads,
                             hipStream_t s);
 // the same kernel over an f16 K|V buffer (cross-attention in precision mode 1)
-hipError_t attn_decoder_kv16(const float* q, long ldq, const void* kv, long kv_batch_stride, long ldkv, int koff,
-                             int voff, int n_keys_base, const int* pos_dev, float* out, long ldo, int B, int heads,
+hipError_t attn_decoder_kv16(const float* q, long ldq, const void* kv, long kv_batch_stride, long ldkv, long head_stride,
+                             long koff, long voff, int n_keys_base, const int* pos_dev, float* out, long ldo, int B, int heads,
                              hipStream_t s);
 hipError_t embed_tokens_f32(const int* tokens, const float* tok_emb, const float* pos_emb, int pos, const int* pos_dev,
                             float* x, int B, int D, hipStream_t s);

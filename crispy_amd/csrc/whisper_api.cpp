@@ -578,7 +578,7 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
   const int dt = h->hp.n_text_state, H = h->hp.n_text_head, Tn = h->hp.n_audio_ctx, C = h->hp.n_text_ctx,
             V = h->hp.n_vocab;
   const int* pos_dev = dev_pos ? h->d_counters : nullptr;
-  // <= SKINNY_MAX_M clips: the projections run on the skinny kernel (row blocks of 64 clips), which folds the preceding LayerNorm in and writes q and
+  // <= SKINNY_MAX_M clips: the projections run on the skinny kernel (row blocks of 32 clips), which folds the preceding LayerNorm in and writes q and
   // k|v of the self-attention block from one launch (17 launches fewer per step on Whisper-tiny)
   const bool fold = batch <= SKINNY_MAX_M && dt % 128 == 0;
   HIP_TRY(embed_tokens_f32(h->d_tok, h->tok_emb, h->dec_pos, pos, pos_dev, h->d_dx, batch, dt, s));
@@ -601,7 +601,7 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
       if (dev_pos) { g.c_off_dev = h->d_counters; g.c_off_scale = 2L * dt; }
       HIP_TRY(gemm_f32_nt(g, 1, s));
     }
-    HIP_TRY(attn_decoder_f32(h->d_dq, dt, selfkv, (long)C * 2 * dt, 2L * dt, 0, dt, dev_pos ? 1 : pos + 1, pos_dev,
+    HIP_TRY(attn_decoder_f32(h->d_dq, dt, selfkv, (long)C * 2 * dt, 2L * dt, 64, 0, dt, dev_pos ? 1 : pos + 1, pos_dev,
                              h->d_datt, dt, batch, H, s));
     {
       GemmArgs g = gemm(h->d_datt, dt, L.out_w, dt, h->d_dx, dt, L.out_b, batch, dt, dt);
@@ -619,9 +619,10 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
     }
     if (h->enc_precision == 1)
       HIP_TRY(attn_decoder_kv16(h->d_dq, dt, reinterpret_cast<const char*>(h->d_xkv_h) + l * (size_t)batch * Tn * 2 * dt * 2,
-                                (long)Tn * 2 * dt, 2L * dt, 0, dt, Tn, nullptr, h->d_datt, dt, batch, H, s));
+                                (long)Tn * 2 * dt, 64, 64L * Tn, 0, (long)Tn * dt, Tn, nullptr, h->d_datt, dt, batch, H, s));
     else
-      HIP_TRY(attn_decoder_f32(h->d_dq, dt, xkv, (long)Tn * 2 * dt, 2L * dt, 0, dt, Tn, nullptr, h->d_datt, dt, batch, H, s));
+      HIP_TRY(attn_decoder_f32(h->d_dq, dt, xkv, (long)Tn * 2 * dt, 64, 64L * Tn, 0, (long)Tn * dt, Tn, nullptr, h->d_datt, dt,
+                               batch, H, s));
     {
       GemmArgs g = gemm(h->d_datt, dt, L.xout_w, dt, h->d_dx, dt, L.xout_b, batch, dt, dt);
       g.residual = h->d_dx; g.ldr = dt;
@@ -646,13 +647,17 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
     }
   }
   if (want_logits) {
-    if (fold) {
+    // vocabulary projection: above 64 clips the 128 x 128 tiled kernel (behind a LayerNorm launch) beats the skinny
+    // kernel's 32-row blocks, which re-read the 80 MB embedding once per block (-3 % / -5 % per step at 128 / 512 clips)
+    if (fold && batch <= 64) {
       GemmArgs g = gemm(h->d_dx, dt, h->logit_lw, dt, h->d_logits, V, nullptr, batch, V, dt);
       g.ln_s = h->logit_ls; g.ln_c = h->logit_lc;
       HIP_TRY(gemm_f32_nt(g, 1, s));
     } else {
       HIP_TRY(layernorm_f32(h->d_dx, h->dec_ln_w, h->dec_ln_b, h->d_dxn, batch, dt, s));
-      HIP_TRY(gemm_f32_nt(gemm(h->d_dxn, dt, h->tok_emb, dt, h->d_logits, V, nullptr, batch, V, dt), 1, s));
+      GemmArgs g = gemm(h->d_dxn, dt, h->tok_emb, dt, h->d_logits, V, nullptr, batch, V, dt);
+      g.tiled = fold ? 1 : 0;
+      HIP_TRY(gemm_f32_nt(g, 1, s));
     }
   }
   return CRISPY_OK;
@@ -693,7 +698,10 @@ int compute_cross_kv(crispy_asr* h, const float* d_enc, int batch, hipStream_t s
   const int dt = h->hp.n_text_state, Tn = h->hp.n_audio_ctx;
   for (size_t l = 0; l < h->dec.size(); ++l) {
     float* xkv = h->d_xkv + l * (size_t)batch * Tn * 2 * dt;
-    HIP_TRY(gemm_f32_nt(gemm(d_enc, dt, h->dec[l].xkv_w, dt, xkv, 2L * dt, h->dec[l].xkv_b, batch * Tn, 2 * dt, dt), 1, s));
+    // head-major store: per clip [K | V][head][Tn][64], so the decode-step attention streams contiguous runs
+    GemmArgs g = gemm(d_enc, dt, h->dec[l].xkv_w, dt, xkv, 2L * dt, h->dec[l].xkv_b, batch * Tn, 2 * dt, dt);
+    g.hm_rows = Tn; g.hm_width = dt;
+    HIP_TRY(gemm_f32_nt(g, 1, s));
   }
   if (h->enc_precision == 1)
     HIP_TRY(convert_f32_to_f16(h->d_xkv, h->d_xkv_h, (long)h->dec.size() * batch * Tn * 2 * dt, s));

@@ -100,6 +100,9 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(GemmArgs g) {
   }
 
   // epilogue
+  const bool hm = g.hm_rows > 0;              // head-major store (cross K|V): see GemmArgs
+  int hm_b0 = 0, hm_t0 = 0;
+  if (hm) { hm_b0 = m0 / g.hm_rows; hm_t0 = m0 - hm_b0 * g.hm_rows; }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -107,101 +110,116 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(GemmArgs g) {
       const int n = n0 + wn + 32 * j + li;
       if (n >= g.N) continue;
       const float bias = g.bias ? g.bias[n] : 0.f;
+      long hm_col = 0;
+      if (hm) {
+        const int kv = n >= g.hm_width ? 1 : 0, rem = n - kv * g.hm_width;
+        hm_col = ((long)kv * g.hm_width + (long)(rem >> 6) * 64) * g.hm_rows + (rem & 63);
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm + 32 * i + acc_row(r, lane);
+        const int dm = wm + 32 * i + acc_row(r, lane);
+        const int m = m0 + dm;
         if (m >= g.M) continue;
         float v = acc[i][j][r] + bias;
         if (g.gelu) v = gelu_erf(v);
         if (g.residual) v += g.residual[(long)bz * g.strideR + (long)m * g.ldr + n];
         if (g.rowtab) v += g.rowtab[(long)(m % g.rowtab_period) * g.N + n];
-        C[(long)m * g.ldc + n] = v;
+        if (hm) {
+          int t = hm_t0 + dm, b = hm_b0;      // a 128-row tile crosses at most one clip boundary (hm_rows >= 128)
+          if (t >= g.hm_rows) { t -= g.hm_rows; ++b; }
+          C[(long)b * g.N * g.hm_rows + (long)t * 64 + hm_col] = v;
+        } else {
+          C[(long)m * g.ldc + n] = v;
+        }
       }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Skinny GEMM for the decoder (M <= 64 rows = clips of one decode step): latency-, not FLOP-bound.
-// One workgroup per 32 output columns; the 4 waves split K four ways and feed the MFMA straight from
+// Skinny GEMM for the decoder (M = clips of one decode step): latency-, not FLOP-bound.
+// One workgroup per 32 clips x 32 output columns; the 4 waves split K four ways and feed the MFMA straight from
 // global memory (both operands are K-contiguous rows, so a lane's operands are 16 contiguous floats per
 // 32-wide K chunk: step s contracts k = s and k = s + 16); partial tiles are summed through LDS.
-// No LDS staging, no barriers in the K loop, next chunk's loads issued before the current MFMAs.
+// No LDS staging, no barriers in the K loop.  The kernel is a chain of memory latencies, not of MFMAs (48 per wave
+// at K = 384): three K chunks of operands are requested before the first MFMA, so Whisper-tiny's K = 384
+// projections expose one round trip instead of three, and 32-row blocks put twice the workgroups on the chip
+// (24 for N = 384).  W is re-read per row block from L2.
 // ---------------------------------------------------------------------------------------------
+constexpr int SK_PF = 3;                       // K chunks (32 wide) in flight per wave
 __global__ __launch_bounds__(256) void gemm_skinny_f32_kernel(GemmArgs g) {
-  __shared__ float red[4][64 * 33];
-  __shared__ float rstat[4][64][2];
+  __shared__ float red[4][32 * 33];
+  __shared__ float rstat[4][32][2];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, lh = lane >> 5;
   const int n0 = blockIdx.x * 32;
-  const int mb = blockIdx.y * 64;            // row block: more than 64 clips per step run as extra workgroups (W stays in L2)
+  const int mb = blockIdx.y * 32;            // row block of 32 clips
   const float* __restrict__ A = g.A;
   const float* __restrict__ W = g.W;
   const bool second = g.C2 && n0 >= g.n_split;      // split output: a workgroup's 32 columns go to one destination
-  const long coff = g.c_off_dev ? (long)(*g.c_off_dev) * g.c_off_scale : 0L;
-  float* __restrict__ C = second ? g.C2 + coff - g.n_split : g.C + (g.C2 ? 0L : coff);
-  const long ldc = second ? g.ldc2 : g.ldc;
   const int kper = g.K / 4;                 // K range of this wave (multiple of 32)
   const int kbeg = wave * kper;
   const int n = min(n0 + li, g.N - 1);
-  const bool r0ok = mb + li < g.M, r1ok = mb + 32 + li < g.M;
+  const bool rok = mb + li < g.M;
   const float* wrow = W + (long)n * g.ldw + kbeg + 16 * lh;
-  const float* a0row = A + (long)min(mb + li, g.M - 1) * g.lda + kbeg + 16 * lh;
-  const float* a1row = A + (long)min(mb + 32 + li, g.M - 1) * g.lda + kbeg + 16 * lh;
-  f32x16 acc0, acc1;
+  const float* arow = A + (long)min(mb + li, g.M - 1) * g.lda + kbeg + 16 * lh;
+  f32x16 acc;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-  float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;   // row sums / sums of squares of this lane's share (LN folding)
-  float4 w[4], a0[4], a1[4];
-  auto load = [&](int kc) {
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float s0 = 0.f, q0 = 0.f;                 // row sum / sum of squares of this lane's share (LN folding)
+  float4 w[SK_PF][4], a[SK_PF][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      w[q] = *reinterpret_cast<const float4*>(wrow + kc + 4 * q);
-      a0[q] = r0ok ? *reinterpret_cast<const float4*>(a0row + kc + 4 * q) : make_float4(0, 0, 0, 0);
-      a1[q] = r1ok ? *reinterpret_cast<const float4*>(a1row + kc + 4 * q) : make_float4(0, 0, 0, 0);
+  for (int st = 0; st < SK_PF; ++st)
+    if (32 * st < kper) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        w[st][q] = *reinterpret_cast<const float4*>(wrow + 32 * st + 4 * q);
+        a[st][q] = rok ? *reinterpret_cast<const float4*>(arow + 32 * st + 4 * q) : make_float4(0, 0, 0, 0);
+      }
     }
-  };
-  load(0);
-  for (int kc = 0; kc < kper; kc += 32) {
-    float4 cw[4], ca0[4], ca1[4];
+  // the cache-slot offset is only needed by the epilogue: read it behind the operand requests
+  const long coff = g.c_off_dev ? (long)(*g.c_off_dev) * g.c_off_scale : 0L;
+  float* __restrict__ C = second ? g.C2 + coff - g.n_split : g.C + (g.C2 ? 0L : coff);
+  const long ldc = second ? g.ldc2 : g.ldc;
+  for (int kc0 = 0; kc0 < kper; kc0 += 32 * SK_PF) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { cw[q] = w[q]; ca0[q] = a0[q]; ca1[q] = a1[q]; }
-    if (kc + 32 < kper) load(kc + 32);
+    for (int st = 0; st < SK_PF; ++st) {
+      const int kc = kc0 + 32 * st;
+      if (kc < kper) {
+        float4 cw[4], ca[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float wv[4] = {cw[q].x, cw[q].y, cw[q].z, cw[q].w};
-      const float x0[4] = {ca0[q].x, ca0[q].y, ca0[q].z, ca0[q].w};
-      const float x1[4] = {ca1[q].x, ca1[q].y, ca1[q].z, ca1[q].w};
+        for (int q = 0; q < 4; ++q) { cw[q] = w[st][q]; ca[q] = a[st][q]; }
+        if (kc + 32 * SK_PF < kper) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[e], wv[e], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[e], wv[e], acc1, 0, 0, 0);
-        if (g.ln_s) {
-          s0 += x0[e]; q0 = fmaf(x0[e], x0[e], q0);
-          s1 += x1[e]; q1 = fmaf(x1[e], x1[e], q1);
+          for (int q = 0; q < 4; ++q) {
+            w[st][q] = *reinterpret_cast<const float4*>(wrow + kc + 32 * SK_PF + 4 * q);
+            a[st][q] = rok ? *reinterpret_cast<const float4*>(arow + kc + 32 * SK_PF + 4 * q) : make_float4(0, 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float wv[4] = {cw[q].x, cw[q].y, cw[q].z, cw[q].w};
+          const float xv[4] = {ca[q].x, ca[q].y, ca[q].z, ca[q].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[e], wv[e], acc, 0, 0, 0);
+            if (g.ln_s) { s0 += xv[e]; q0 = fmaf(xv[e], xv[e], q0); }
+          }
         }
       }
     }
   }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = acc_row(r, lane);
-    red[wave][row * 33 + li] = acc0[r];
-    red[wave][(32 + row) * 33 + li] = acc1[r];
-  }
+  for (int r = 0; r < 16; ++r) red[wave][acc_row(r, lane) * 33 + li] = acc[r];
   if (g.ln_s) {
-    // the two half-waves hold the two 16-wide halves of every 32-wide K chunk of rows li / 32 + li
+    // the two half-waves hold the two 16-wide halves of every 32-wide K chunk of row li
     s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);
-    s1 += __shfl_xor(s1, 32, 64); q1 += __shfl_xor(q1, 32, 64);
-    if (lh == 0) {
-      rstat[wave][li][0] = s0; rstat[wave][li][1] = q0;
-      rstat[wave][32 + li][0] = s1; rstat[wave][32 + li][1] = q1;
-    }
+    if (lh == 0) { rstat[wave][li][0] = s0; rstat[wave][li][1] = q0; }
   }
   __syncthreads();
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
+  for (int q = 0; q < 4; ++q) {
     const int idx = tid + 256 * q;
-    const int ml = idx >> 5, c = idx & 31;      // ml: row inside this 64-row block
+    const int ml = idx >> 5, c = idx & 31;      // ml: row inside this 32-row block
     const int m = mb + ml;
     const int nn = n0 + c;
     if (m < g.M && nn < g.N) {
@@ -398,19 +416,19 @@ template <> __device__ __forceinline__ float4 ld4<_Float16>(const _Float16* p) {
 template <class KV>
 __global__ __launch_bounds__(64 * AD_WAVES) void attn_dec_kernel(const float* __restrict__ q, long ldq,
                                                        const KV* __restrict__ kv, long kv_batch_stride,
-                                                       long ldkv, int koff, int voff, int n_keys_base,
+                                                       long ldkv, long head_stride, long koff, long voff, int n_keys_base,
                                                        const int* __restrict__ pos_dev, float* __restrict__ out, long ldo) {
   __shared__ float p_s[1536];
   __shared__ __attribute__((aligned(16))) float q_s[64];
-  __shared__ float part_o[AD_WAVES][64];
+  __shared__ __attribute__((aligned(16))) float part_o[AD_WAVES][64];
   __shared__ float part_m[AD_WAVES], part_l[AD_WAVES];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int h = blockIdx.x, b = blockIdx.y;
   const int n_keys = n_keys_base + (pos_dev ? *pos_dev : 0);
   if (tid < 64) q_s[tid] = q[(long)b * ldq + h * 64 + tid] * 0.125f;
   __syncthreads();
-  const KV* Kb = kv + (long)b * kv_batch_stride + koff + h * 64;
-  const KV* Vb = kv + (long)b * kv_batch_stride + voff + h * 64;
+  const KV* Kb = kv + (long)b * kv_batch_stride + koff + h * head_stride;
+  const KV* Vb = kv + (long)b * kv_batch_stride + voff + h * head_stride;
   const int per = (n_keys + AD_WAVES - 1) / AD_WAVES;
   const int k_lo = wave * per, k_hi = min(n_keys, k_lo + per);
   // scores: 16 lanes share one key row (coalesced 256-byte reads, 4 keys per wave instruction), the
@@ -467,20 +485,43 @@ __global__ __launch_bounds__(64 * AD_WAVES) void attn_dec_kernel(const float* __
   __builtin_amdgcn_s_waitcnt(0xc07f);
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  // lane = output dim; two interleaved accumulators shorten the dependent chain
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int k = k_lo;
-  for (; k + 7 < k_hi; k += 8) {                        // 8 independent 256-byte row reads in flight
-    float v[8];
+  // P.V with the same access shape as the scores: 16 lanes share one 256-byte V row (4 dims each), 4 rows per wave
+  // instruction, SU instructions (8 KB) in flight per wave -- the one-float-per-lane version kept 2 KB in flight and
+  // spent most of the kernel waiting on it.  The four key residues are summed across the DPP rows at the end.
+  {
+    const int c = lane & 15, sub = lane >> 4;
+    constexpr int SU = 8;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int kb = k_lo; kb < k_hi; kb += 4 * SU) {
+      float4 t[SU];
+      float p[SU];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = (float)Vb[(long)(k + u) * ldkv + lane];
-    a0 = fmaf(p_s[k], v[0], a0); a1 = fmaf(p_s[k + 1], v[1], a1);
-    a2 = fmaf(p_s[k + 2], v[2], a2); a3 = fmaf(p_s[k + 3], v[3], a3);
-    a0 = fmaf(p_s[k + 4], v[4], a0); a1 = fmaf(p_s[k + 5], v[5], a1);
-    a2 = fmaf(p_s[k + 6], v[6], a2); a3 = fmaf(p_s[k + 7], v[7], a3);
+      for (int u = 0; u < SU; ++u) {
+        const int k = kb + 4 * u + sub;
+        t[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        p[u] = 0.f;
+        if (k < k_hi) {
+          t[u] = ld4<KV>(Vb + (long)k * ldkv + 4 * c);
+          p[u] = p_s[k];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        acc.x = fmaf(p[u], t[u].x, acc.x);
+        acc.y = fmaf(p[u], t[u].y, acc.y);
+        acc.z = fmaf(p[u], t[u].z, acc.z);
+        acc.w = fmaf(p[u], t[u].w, acc.w);
+      }
+    }
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+      acc.x += __shfl_xor(acc.x, off, 64);
+      acc.y += __shfl_xor(acc.y, off, 64);
+      acc.z += __shfl_xor(acc.z, off, 64);
+      acc.w += __shfl_xor(acc.w, off, 64);
+    }
+    if (sub == 0) *reinterpret_cast<float4*>(&part_o[wave][4 * c]) = acc;
   }
-  for (; k < k_hi; ++k) a0 = fmaf(p_s[k], (float)Vb[(long)k * ldkv + lane], a0);
-  part_o[wave][lane] = (a0 + a1) + (a2 + a3);
   if (lane == 0) { part_m[wave] = mloc; part_l[wave] = lsum; }
   __syncthreads();
   if (wave == 0) {
@@ -684,8 +725,8 @@ __global__ void advance_kernel(int* __restrict__ pos_dev, int* __restrict__ step
 }  // namespace
 
 hipError_t gemm_f32_nt(const GemmArgs& g, int batch, hipStream_t s) {
-  if (batch == 1 && g.M <= SKINNY_MAX_M && g.K % 128 == 0 && !g.rowtab) {   // one decode step: latency-bound shape
-    hipLaunchKernelGGL(gemm_skinny_f32_kernel, dim3((g.N + 31) / 32, (g.M + 63) / 64), dim3(256), 0, s, g);
+  if (batch == 1 && g.M <= SKINNY_MAX_M && g.K % 128 == 0 && !g.rowtab && !g.tiled) {   // one decode step: latency-bound shape
+    hipLaunchKernelGGL(gemm_skinny_f32_kernel, dim3((g.N + 31) / 32, (g.M + 31) / 32), dim3(256), 0, s, g);
     return hipGetLastError();
   }
   dim3 grid((g.N + GB_N - 1) / GB_N, (g.M + GB_M - 1) / GB_M, batch);
@@ -701,18 +742,18 @@ hipError_t attn_encoder_f32(const float* qkv, float* out, int B, int T, int D, i
   hipLaunchKernelGGL(attn_enc_kernel, dim3((T + 127) / 128, heads, B), dim3(256), 0, s, qkv, out, T, D);
   return hipGetLastError();
 }
-hipError_t attn_decoder_f32(const float* q, long ldq, const float* kv, long kv_batch_stride, long ldkv, int koff,
-                            int voff, int n_keys_base, const int* pos_dev, float* out, long ldo, int B, int heads,
+hipError_t attn_decoder_f32(const float* q, long ldq, const float* kv, long kv_batch_stride, long ldkv, long head_stride,
+                            long koff, long voff, int n_keys_base, const int* pos_dev, float* out, long ldo, int B, int heads,
                             hipStream_t s) {
-  hipLaunchKernelGGL(attn_dec_kernel<float>, dim3(heads, B), dim3(64 * AD_WAVES), 0, s, q, ldq, kv, kv_batch_stride, ldkv, koff, voff,
+  hipLaunchKernelGGL(attn_dec_kernel<float>, dim3(heads, B), dim3(64 * AD_WAVES), 0, s, q, ldq, kv, kv_batch_stride, ldkv, head_stride, koff, voff,
                      n_keys_base, pos_dev, out, ldo);
   return hipGetLastError();
 }
-hipError_t attn_decoder_kv16(const float* q, long ldq, const void* kv, long kv_batch_stride, long ldkv, int koff,
-                             int voff, int n_keys_base, const int* pos_dev, float* out, long ldo, int B, int heads,
+hipError_t attn_decoder_kv16(const float* q, long ldq, const void* kv, long kv_batch_stride, long ldkv, long head_stride,
+                             long koff, long voff, int n_keys_base, const int* pos_dev, float* out, long ldo, int B, int heads,
                              hipStream_t s) {
   hipLaunchKernelGGL(attn_dec_kernel<_Float16>, dim3(heads, B), dim3(64 * AD_WAVES), 0, s, q, ldq,
-                     reinterpret_cast<const _Float16*>(kv), kv_batch_stride, ldkv, koff, voff, n_keys_base, pos_dev, out, ldo);
+                     reinterpret_cast<const _Float16*>(kv), kv_batch_stride, ldkv, head_stride, koff, voff, n_keys_base, pos_dev, out, ldo);
   return hipGetLastError();
 }
 hipError_t embed_tokens_f32(const int* tokens, const float* tok_emb, const float* pos_emb, int pos, const int* pos_dev,

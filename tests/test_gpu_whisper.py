@@ -530,9 +530,10 @@ def test_large_v3_turbo_dimensions_parity(oracle):
 
 
 def test_decode_batches_beyond_64_clips(model):
-    """More than 64 clips per decode step run as extra 64-row blocks of the skinny projection kernel (LayerNorm fold,
-    split q / k|v output included): 70 clips decoded together give exactly -- tokens and the f32 logits of the picks --
-    what they give in two smaller batches."""
+    """More than 32 clips per decode step run as extra 32-row blocks of the skinny projection kernel (LayerNorm fold,
+    split q / k|v output included); above 64 clips the vocabulary projection moves to the tiled kernel behind a
+    LayerNorm launch.  70 clips decoded together give the tokens they give in two smaller batches, and the f32 logits of
+    the picks to 1e-4 (different kernel, different summation order for the last projection only)."""
     import torch
     from crispy_amd import synth_audio
     prompt = [50258, 50259, 50359, 50363]
@@ -544,5 +545,5 @@ def test_decode_batches_beyond_64_clips(model):
     a_t, _, a_l = model.decode_greedy_device(d_enc.data_ptr(), 40, prompt, 6)
     b_t, _, b_l = model.decode_greedy_device(d_enc.data_ptr() + 40 * esz, 30, prompt, 6)
     assert np.array_equal(all_t, np.concatenate([a_t, b_t]))
-    assert np.array_equal(all_l, np.concatenate([a_l, b_l]))
+    np.testing.assert_allclose(all_l, np.concatenate([a_l, b_l]), rtol=1e-4, atol=1e-3)
     assert len(np.unique(all_l[:, 0])) > 60          # the clips are different: so are the logits of their first pick

@@ -4,7 +4,7 @@ import numpy as np, torch
 from crispy_amd.whisper_weights import HParams, synthetic_whisper_weights
 from crispy_amd.asr import WhisperModel
 hp = HParams.tiny(); m = WhisperModel(hp, synthetic_whisper_weights(hp, 0))
-B = 64
+B = int(os.environ.get("B", 64))
 enc = torch.randn(B, 1500, 384, device="cuda")
 torch.cuda.synchronize()
 m.decode_greedy_device(enc.data_ptr(), B, [50258, 50259, 50359, 50363], 33)
