@@ -267,7 +267,7 @@ def main():
         k_ms.append(ds.last_kernel_ms())
     ds.set_timing(False)
     from crispy_amd import _native as N
-    # rn_frame_kernel launches per step (a call starts with short launches of 3, 8, 21 frames, then 25 per launch);
+    # rn_frame_kernel launches per step (a call starts with short launches of 3 and 8 frames, then 12 per launch);
     # per-launch figures below are averages over them: algorithmic bytes of a step / launches, kernel time / launches
     launches = N.lib().crispy_rn_n_launches(T)
     frame_ms = sum(k[0] for k in k_ms) / len(k_ms) / launches
@@ -282,7 +282,7 @@ def main():
         traffic = None
         valu = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01d_pmc.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01f_pmc.json")))
             if pm["config"]["streams"] == B:
                 fk = pm["rn_frame_kernel"]
                 sf = B * T / launches                        # stream-frames per (average) launch
@@ -291,7 +291,7 @@ def main():
                 # slots; 1024 SIMDs; priced against the live kernel time at the 2.4 GHz peak clock.
                 valu = {"insts_per_stream_frame": fk["insts_per_stream_frame"]["valu"],
                         "issue_frac": fk["valu_active_quads_per_stream_frame"] * sf * 4 / (1024 * frame_ms * 1e-3 * 2.4e9),
-                        "source": "profiles/r01d_pmc.json (rocprofv3 --pmc SQ_ACTIVE_INST_VALU), live kernel time"}
+                        "source": "profiles/r01f_pmc.json (rocprofv3 --pmc SQ_ACTIVE_INST_VALU), live kernel time"}
         except Exception:
             pass
         achieved = alg_bytes / (frame_ms * 1e-3) / 1e9

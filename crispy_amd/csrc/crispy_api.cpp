@@ -23,15 +23,19 @@ using namespace crispy;
 namespace {
 
 constexpr int kChunkFrames = 250;   // workspace bound: frames of high-passed signal kept per call segment
-constexpr int kSubFrames = 25;      // pipeline grain: high-pass of sub-chunk i+1 overlaps the frame kernel of sub-chunk i
+// Pipeline grain: the high-pass of sub-chunk i+1 overlaps the frame kernel of sub-chunk i.  12 frames x 4096 streams of
+// high-passed signal are 94 MB, which the frame kernel still finds in the 256 MB Infinity Cache next to its history
+// re-reads: measured 10.48 ms per 100-frame step (spread 0.07) against 10.78 (spread 0.8) with 25-frame sub-chunks,
+// 12.3 ms with 56 and more (the kernel is sensitive to the latency of its window reads), 10.53 with 8.
+constexpr int kSubFrames = 12;
 
 // Frames of sub-chunk `index` of a segment with `remaining` frames left.  The high-pass recurrence of the first
 // sub-chunk cannot overlap anything (the previous call still reads xhp), so the segment starts with a short
 // sub-chunk and ramps up: the high-pass runs ~2.9x faster per frame than the frame kernel, so every next sub-chunk
-// (<= 2.7x the previous one) is filtered while the previous one is being processed.  3, 8, 21, 25, 25, ...
+// (<= 2.7x the previous one) is filtered while the previous one is being processed.  3, 8, 12, 12, ...
 inline int sub_frames(int index, int remaining) {
-  static const int ramp[3] = {3, 8, 21};
-  const int want = index < 3 ? ramp[index] : kSubFrames;
+  static const int ramp[2] = {3, 8};
+  const int want = index < 2 ? ramp[index] : kSubFrames;
   return remaining < want ? remaining : want;
 }
 inline int count_subs(int T) {

@@ -83,7 +83,8 @@ int crispy_rn_n_streams(const crispy_rn *h);
  * whose high-pass runs one launch ahead on a helper stream (bench.py's per-launch roofline uses it). */
 int crispy_rn_frames_per_launch(void);
 /* Number of rn_frame_kernel launches one call of n_frames makes: a segment (<= 250 frames) starts with short
- * sub-chunks (3, 8, 21 frames) so that the sequential high-pass of the first one is the only exposed one, then 25. */
+ * sub-chunks (3, 8 frames) so that the sequential high-pass of the first one is the only exposed one, then 12
+ * (94 MB of high-passed signal at 4096 streams: still in the Infinity Cache when the frame kernel reads it). */
 int crispy_rn_n_launches(int n_frames);
 
 /* Pipeline selection: 0 (default) runs the single fused frame kernel; staged != 0 (or the environment

@@ -15,7 +15,7 @@ ks = raw["kernels"]
 fk = ks["rn_frame_kernel"]
 p = {k: round(v, 3) for k, v in fk["per_stream_frame"].items()}
 
-# bench launches 100 frames over 4096 streams as 3 + 8 + 21 + 25 + 25 + 18: the average duration of a frame-kernel
+# bench launches 100 frames over 4096 streams as 3 + 8 + 7 x 12 + 5 (10 launches): the average duration of a frame-kernel
 # launch and the stream-frames it covers give the VALU issue fraction.
 avg_ns, calls = None, None
 stats = os.path.join(ROOT, "gpurun_out", f"{tag}_kernel_stats.csv")
@@ -23,7 +23,7 @@ if os.path.exists(stats):
     for r in csv.DictReader(open(stats)):
         if "rn_frame_kernel" in r["Name"]:
             avg_ns, calls = float(r["AverageNs"]), int(r["Calls"])
-frames_per_launch = 100.0 / 6.0
+frames_per_launch = 100.0 / 10.0
 issue = None
 if avg_ns:
     issue = p["SQ_ACTIVE_INST_VALU"] * 4 * 4096 * frames_per_launch / (1024 * avg_ns * 1e-9 * 2.4e9)
@@ -32,7 +32,7 @@ out = {
     "command": f"tools/collect_profiles.sh {tag}  (one `rocprofv3 --pmc <group> --output-format csv -- python "
                "tools/pmc_frame.py` run per counter group, no trace domains), then tools/summarize_pmc.py",
     "config": {"streams": raw["streams"], "frames_per_call": raw["frames_per_call"], "calls": raw["calls"],
-               "stream_frames": raw["stream_frames"], "launches": "3 + 8 + 14 frames per call (ramp-up sub-chunks)"},
+               "stream_frames": raw["stream_frames"], "launches": "3 + 8 + 12 + 2 frames per call (ramp-up sub-chunks)"},
     "units": "per_stream_frame = counter summed over all rn_frame_kernel dispatches / stream-frames. FETCH_SIZE / "
              "WRITE_SIZE in KiB; gfx950 correction: FETCH_SIZE reports half the bytes read (calibrated in "
              "r01_v2_pmc_hbm.json on rn_highpass_kernel, whose byte counts are known exactly; WRITE_SIZE exact). "
@@ -51,7 +51,7 @@ out = {
         "valu_issue_fraction": {
             "definition": "SQ_ACTIVE_INST_VALU * 4 cycles * stream-frames / (1024 SIMDs * kernel time * 2.4 GHz), "
                           f"kernel time from {tag}_bench_kernel_stats.csv "
-                          f"({(avg_ns or 0) / 1e6:.3f} ms avg per launch of 16.67 frames x 4096 streams)",
+                          f"({(avg_ns or 0) / 1e6:.3f} ms avg per launch of 10 frames x 4096 streams)",
             "value": None if issue is None else round(issue, 3)},
     },
 }
