@@ -146,6 +146,10 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(GemmArgs g) {
 // (24 for N = 384).  W is re-read per row block from L2.
 // ---------------------------------------------------------------------------------------------
 constexpr int SK_PF = 3;                       // K chunks (32 wide) in flight per wave
+// LN / GELU / RES are compile-time so that the epilogue operands (ln_s, ln_c or bias, residual) can be requested
+// up front, next to the first K chunks, from clamped (always valid) addresses: with run-time flags every one of them
+// sat behind its own branch in the epilogue and cost a serialized L2 round trip after the barrier.
+template <bool LN, bool GELU, bool RES>
 __global__ __launch_bounds__(256) void gemm_skinny_f32_kernel(GemmArgs g) {
   __shared__ float red[4][32 * 33];
   __shared__ float rstat[4][32][2];
@@ -159,7 +163,6 @@ __global__ __launch_bounds__(256) void gemm_skinny_f32_kernel(GemmArgs g) {
   const int kper = g.K / 4;                 // K range of this wave (multiple of 32)
   const int kbeg = wave * kper;
   const int n = min(n0 + li, g.N - 1);
-  const bool rok = mb + li < g.M;
   const float* wrow = W + (long)n * g.ldw + kbeg + 16 * lh;
   const float* arow = A + (long)min(mb + li, g.M - 1) * g.lda + kbeg + 16 * lh;
   f32x16 acc;
@@ -173,10 +176,18 @@ __global__ __launch_bounds__(256) void gemm_skinny_f32_kernel(GemmArgs g) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         w[st][q] = *reinterpret_cast<const float4*>(wrow + 32 * st + 4 * q);
-        a[st][q] = rok ? *reinterpret_cast<const float4*>(arow + 32 * st + 4 * q) : make_float4(0, 0, 0, 0);
+        a[st][q] = *reinterpret_cast<const float4*>(arow + 32 * st + 4 * q);   // rows >= M: clamped row, never stored
       }
     }
-  // the cache-slot offset is only needed by the epilogue: read it behind the operand requests
+  // epilogue operands of this thread's outputs: column ec of rows (tid >> 5) + 8 q
+  const int ec = min(tid & 31, g.N - 1 - n0), enn = n0 + ec;
+  float e_s = 0.f, e_c = 0.f, e_res[4] = {0.f, 0.f, 0.f, 0.f};
+  if (LN) { e_s = g.ln_s[enn]; e_c = g.ln_c[enn]; }
+  else if (g.bias) e_c = g.bias[enn];
+  if (RES) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) e_res[q] = g.residual[(long)min(mb + (tid >> 5) + 8 * q, g.M - 1) * g.ldr + enn];
+  }
   const long coff = g.c_off_dev ? (long)(*g.c_off_dev) * g.c_off_scale : 0L;
   float* __restrict__ C = second ? g.C2 + coff - g.n_split : g.C + (g.C2 ? 0L : coff);
   const long ldc = second ? g.ldc2 : g.ldc;
@@ -192,7 +203,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_f32_kernel(GemmArgs g) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             w[st][q] = *reinterpret_cast<const float4*>(wrow + kc + 32 * SK_PF + 4 * q);
-            a[st][q] = rok ? *reinterpret_cast<const float4*>(arow + kc + 32 * SK_PF + 4 * q) : make_float4(0, 0, 0, 0);
+            a[st][q] = *reinterpret_cast<const float4*>(arow + kc + 32 * SK_PF + 4 * q);
           }
         }
 #pragma unroll
@@ -202,7 +213,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_f32_kernel(GemmArgs g) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[e], wv[e], acc, 0, 0, 0);
-            if (g.ln_s) { s0 += xv[e]; q0 = fmaf(xv[e], xv[e], q0); }
+            if (LN) { s0 += xv[e]; q0 = fmaf(xv[e], xv[e], q0); }
           }
         }
       }
@@ -210,7 +221,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_f32_kernel(GemmArgs g) {
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wave][acc_row(r, lane) * 33 + li] = acc[r];
-  if (g.ln_s) {
+  if (LN) {
     // the two half-waves hold the two 16-wide halves of every 32-wide K chunk of row li
     s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);
     if (lh == 0) { rstat[wave][li][0] = s0; rstat[wave][li][1] = q0; }
@@ -218,27 +229,182 @@ __global__ __launch_bounds__(256) void gemm_skinny_f32_kernel(GemmArgs g) {
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const int idx = tid + 256 * q;
-    const int ml = idx >> 5, c = idx & 31;      // ml: row inside this 32-row block
+    const int ml = (tid >> 5) + 8 * q;          // row inside this 32-row block
     const int m = mb + ml;
-    const int nn = n0 + c;
-    if (m < g.M && nn < g.N) {
-      float v = red[0][ml * 33 + c] + red[1][ml * 33 + c] + red[2][ml * 33 + c] + red[3][ml * 33 + c];
-      if (g.ln_s) {
-        const float sum = rstat[0][ml][0] + rstat[1][ml][0] + rstat[2][ml][0] + rstat[3][ml][0];
-        const float sq = rstat[0][ml][1] + rstat[1][ml][1] + rstat[2][ml][1] + rstat[3][ml][1];
-        const float mean = sum / (float)g.K;
-        const float var = fmaxf(sq / (float)g.K - mean * mean, 0.f);
-        const float rstd = 1.f / sqrtf(var + 1e-5f);
-        v = rstd * (v - mean * g.ln_s[nn]) + g.ln_c[nn];
-      } else {
-        v += g.bias ? g.bias[nn] : 0.f;
+    float v = red[0][ml * 33 + ec] + red[1][ml * 33 + ec] + red[2][ml * 33 + ec] + red[3][ml * 33 + ec];
+    if (LN) {
+      const float sum = rstat[0][ml][0] + rstat[1][ml][0] + rstat[2][ml][0] + rstat[3][ml][0];
+      const float sq = rstat[0][ml][1] + rstat[1][ml][1] + rstat[2][ml][1] + rstat[3][ml][1];
+      const float mean = sum / (float)g.K;
+      const float var = fmaxf(sq / (float)g.K - mean * mean, 0.f);
+      const float rstd = 1.f / sqrtf(var + 1e-5f);
+      v = rstd * (v - mean * e_s) + e_c;
+    } else {
+      v += e_c;
+    }
+    if (GELU) v = gelu_erf(v);
+    if (RES) v += e_res[q];
+    if (m < g.M && n0 + (tid & 31) < g.N) C[(long)m * ldc + enn] = v;   // only the stores are predicated
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Vocabulary projection of a decode step with <= 64 clips: logits[64][V] = x[64][K] . E[V][K]^T, V ~ 51 865, K = 128 KCH.
+// The skinny kernel above spends a workgroup's life on one 32-column tile (request, wait, 96 MFMAs, reduce): 1621
+// short-lived workgroups, 62 us for 80 MB.  Here 256 persistent workgroups (one per CU) keep their share of x in registers for
+// the whole launch (it is the same for every tile), walk over the column tiles and request the next tile's rows of E
+// before the MFMAs of the current one; the cross-wave reduction is double-buffered, one barrier per tile.
+// Same operand order, LayerNorm fold and summation order as the skinny kernel, so the logits are bit-identical to it.
+// Measured 45 us (62 before).  Ablations on the GPU: without the stores 43.6, without the E loads 39.8, with neither
+// epilogue nor reduction 33 -- what is left is 7 tiles x 96 f32 MFMAs per wave at one wave per SIMD (2.6 us per
+// tile = 18 us) behind the launch and the prologue: the f32 matrix pipe, not memory, bounds this projection.
+// ---------------------------------------------------------------------------------------------
+template <int KCH>
+__global__ __launch_bounds__(256) void gemm_vocab_f32_kernel(GemmArgs g) {
+  __shared__ float red[2][4][64 * 33];
+  __shared__ float rstat[4][64][2];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int kbeg = wave * 32 * KCH;
+  const float* __restrict__ W = g.W;
+  const float* a0row = g.A + (long)min(li, g.M - 1) * g.lda + kbeg + 16 * lh;
+  const float* a1row = g.A + (long)min(32 + li, g.M - 1) * g.lda + kbeg + 16 * lh;
+  const int ntiles = (g.N + 31) / 32;
+  int tile = blockIdx.x;
+  float4 w[KCH][4];
+  float ls = 0.f, lc = 0.f;                  // epilogue operands of this thread's column, fetched with the tile
+  auto request = [&](int t) {
+    const float* wrow = W + (long)min(t * 32 + li, g.N - 1) * g.ldw + kbeg + 16 * lh;
+#pragma unroll
+    for (int c = 0; c < KCH; ++c)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w[c][q] = *reinterpret_cast<const float4*>(wrow + 32 * c + 4 * q);
+    const int nn = min(t * 32 + (tid & 31), g.N - 1);
+    ls = g.ln_s ? g.ln_s[nn] : 0.f;
+    lc = g.ln_s ? g.ln_c[nn] : g.bias ? g.bias[nn] : 0.f;
+  };
+  if (tile < ntiles) request(tile);
+  float4 a0[KCH][4], a1[KCH][4];
+  float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+  for (int c = 0; c < KCH; ++c)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      a0[c][q] = *reinterpret_cast<const float4*>(a0row + 32 * c + 4 * q);   // rows >= M: a clamped (valid) row, whose
+      a1[c][q] = *reinterpret_cast<const float4*>(a1row + 32 * c + 4 * q);   // outputs are never stored -- no branches
+    }
+  if (g.ln_s) {
+    // row statistics in the skinny kernel's order: chunk by chunk, element by element, then half-waves, then waves
+#pragma unroll
+    for (int c = 0; c < KCH; ++c)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float x0[4] = {a0[c][q].x, a0[c][q].y, a0[c][q].z, a0[c][q].w};
+        const float x1[4] = {a1[c][q].x, a1[c][q].y, a1[c][q].z, a1[c][q].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s0 += x0[e]; q0 = fmaf(x0[e], x0[e], q0);
+          s1 += x1[e]; q1 = fmaf(x1[e], x1[e], q1);
+        }
       }
-      if (g.gelu) v = gelu_erf(v);
-      if (g.residual) v += g.residual[(long)m * g.ldr + nn];
-      C[(long)m * ldc + nn] = v;
+    s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);
+    s1 += __shfl_xor(s1, 32, 64); q1 += __shfl_xor(q1, 32, 64);
+    if (lh == 0) {
+      rstat[wave][li][0] = s0; rstat[wave][li][1] = q0;
+      rstat[wave][32 + li][0] = s1; rstat[wave][32 + li][1] = q1;
     }
   }
+  __syncthreads();
+  float mean[8], rstd[8];                    // of the rows this thread finishes: ml = (tid >> 5) + 8 q, clamped
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int ml = min((tid >> 5) + 8 * q, g.M - 1);
+    mean[q] = 0.f; rstd[q] = 1.f;
+    if (g.ln_s) {
+      const float sum = rstat[0][ml][0] + rstat[1][ml][0] + rstat[2][ml][0] + rstat[3][ml][0];
+      const float sq = rstat[0][ml][1] + rstat[1][ml][1] + rstat[2][ml][1] + rstat[3][ml][1];
+      mean[q] = sum / (float)g.K;
+      const float var = fmaxf(sq / (float)g.K - mean[q] * mean[q], 0.f);
+      rstd[q] = 1.f / sqrtf(var + 1e-5f);
+    }
+  }
+  // Software pipeline over the tiles: the MFMAs of tile i and the epilogue of tile i - 1 (LDS reads of the other
+  // reduction buffer, LayerNorm fold, stores) sit in one basic block -- no branches: out-of-range rows / columns are
+  // clamped, so their threads recompute and re-store an in-range element with the identical value -- and are
+  // interleaved one epilogue row-step per six (KCH = 3) K steps, so the matrix pipe works in the shadow of the
+  // epilogue instead of after it.
+  const int cc = tid & 31;
+  auto epilogue_step = [&](int b, int t, float els, float elc, int q) {
+    const int ml = min((tid >> 5) + 8 * q, g.M - 1);
+    const int c = min(cc, g.N - 1 - t * 32);
+    float v = red[b][0][ml * 33 + c] + red[b][1][ml * 33 + c] + red[b][2][ml * 33 + c] + red[b][3][ml * 33 + c];
+    v = g.ln_s ? rstd[q] * (v - mean[q] * els) + elc : v + elc;
+    g.C[(long)ml * g.ldc + t * 32 + c] = v;
+  };
+  auto mfma_tile = [&](const float4 (&cw)[KCH][4], f32x16& acc0, f32x16& acc1, int eb, int et, float els, float elc, bool epi) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+    for (int c = 0; c < KCH; ++c)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float wv[4] = {cw[c][q].x, cw[c][q].y, cw[c][q].z, cw[c][q].w};
+        const float x0[4] = {a0[c][q].x, a0[c][q].y, a0[c][q].z, a0[c][q].w};
+        const float x1[4] = {a1[c][q].x, a1[c][q].y, a1[c][q].z, a1[c][q].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[e], wv[e], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[e], wv[e], acc1, 0, 0, 0);
+          const int step = (c * 4 + q) * 4 + e;                       // 0 .. 16 KCH - 1
+          if (epi && step % (2 * KCH) == 2 * KCH - 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            epilogue_step(eb, et, els, elc, step / (2 * KCH));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+  };
+  auto park = [&](int b, const f32x16& acc0, const f32x16& acc1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = acc_row(r, lane);
+      red[b][wave][row * 33 + li] = acc0[r];
+      red[b][wave][(32 + row) * 33 + li] = acc1[r];
+    }
+  };
+  if (tile >= ntiles) return;                // (the grid never exceeds the tile count)
+  const int G = gridDim.x;
+  float pls = ls, plc = lc;
+  int prev_tile = tile;
+  {
+    float4 cw[KCH][4];
+#pragma unroll
+    for (int c = 0; c < KCH; ++c)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cw[c][q] = w[c][q];
+    request(min(tile + G, ntiles - 1));
+    f32x16 acc0, acc1;
+    mfma_tile(cw, acc0, acc1, 0, 0, 0.f, 0.f, false);
+    park(0, acc0, acc1);
+    __syncthreads();
+  }
+  int buf = 1;
+  for (tile += G; tile < ntiles; tile += G, buf ^= 1) {
+    float4 cw[KCH][4];
+#pragma unroll
+    for (int c = 0; c < KCH; ++c)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cw[c][q] = w[c][q];
+    const float cls = ls, clc = lc;
+    request(min(tile + G, ntiles - 1));
+    f32x16 acc0, acc1;
+    mfma_tile(cw, acc0, acc1, buf ^ 1, prev_tile, pls, plc, true);
+    park(buf, acc0, acc1);
+    __syncthreads();     // red[buf] complete; every reader of red[buf ^ 1] is behind this barrier too
+    prev_tile = tile; pls = cls; plc = clc;
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) epilogue_step(buf ^ 1, prev_tile, pls, plc, q);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -725,8 +891,26 @@ __global__ void advance_kernel(int* __restrict__ pos_dev, int* __restrict__ step
 }  // namespace
 
 hipError_t gemm_f32_nt(const GemmArgs& g, int batch, hipStream_t s) {
+  if (batch == 1 && g.M <= 64 && g.N >= 8192 && (g.K == 384 || g.K == 512) && !g.rowtab && !g.tiled && !g.C2 && !g.gelu &&
+      !g.residual && !g.c_off_dev) {        // vocabulary projection of a decode step: persistent workgroups
+    const int wgs = min((g.N + 31) / 32, 256);      // 276 registers per lane: one workgroup per CU
+    if (g.K == 384) hipLaunchKernelGGL(gemm_vocab_f32_kernel<3>, dim3(wgs), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL(gemm_vocab_f32_kernel<4>, dim3(wgs), dim3(256), 0, s, g);
+    return hipGetLastError();
+  }
   if (batch == 1 && g.M <= SKINNY_MAX_M && g.K % 128 == 0 && !g.rowtab && !g.tiled) {   // one decode step: latency-bound shape
-    hipLaunchKernelGGL(gemm_skinny_f32_kernel, dim3((g.N + 31) / 32, (g.M + 31) / 32), dim3(256), 0, s, g);
+    const dim3 grid((g.N + 31) / 32, (g.M + 31) / 32), block(256);
+    const int kind = (g.ln_s ? 4 : 0) | (g.gelu ? 2 : 0) | (g.residual ? 1 : 0);
+    switch (kind) {
+      case 0: hipLaunchKernelGGL((gemm_skinny_f32_kernel<false, false, false>), grid, block, 0, s, g); break;
+      case 1: hipLaunchKernelGGL((gemm_skinny_f32_kernel<false, false, true>), grid, block, 0, s, g); break;
+      case 2: hipLaunchKernelGGL((gemm_skinny_f32_kernel<false, true, false>), grid, block, 0, s, g); break;
+      case 3: hipLaunchKernelGGL((gemm_skinny_f32_kernel<false, true, true>), grid, block, 0, s, g); break;
+      case 4: hipLaunchKernelGGL((gemm_skinny_f32_kernel<true, false, false>), grid, block, 0, s, g); break;
+      case 5: hipLaunchKernelGGL((gemm_skinny_f32_kernel<true, false, true>), grid, block, 0, s, g); break;
+      case 6: hipLaunchKernelGGL((gemm_skinny_f32_kernel<true, true, false>), grid, block, 0, s, g); break;
+      default: hipLaunchKernelGGL((gemm_skinny_f32_kernel<true, true, true>), grid, block, 0, s, g); break;
+    }
     return hipGetLastError();
   }
   dim3 grid((g.N + GB_N - 1) / GB_N, (g.M + GB_M - 1) / GB_M, batch);
