@@ -23,7 +23,7 @@ constexpr int HB_M = 128, HB_N = 128, HB_K = 32, HB_LD = 40;
 __device__ __forceinline__ float gelu_erf_h(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ int acc_row_h(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-__global__ __launch_bounds__(256) void gemm_f16_nt_kernel(GemmArgs g, const _Float16* __restrict__ Wh) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void gemm_f16_nt_kernel(GemmArgs g, const _Float16* __restrict__ Wh) {
   __shared__ __attribute__((aligned(16))) _Float16 As[2][HB_M * HB_LD];
   __shared__ __attribute__((aligned(16))) _Float16 Ws[2][HB_N * HB_LD];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -97,22 +97,39 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_kernel(GemmArgs g, const _Flo
     __syncthreads();
   }
 
+  // epilogue: residual / row-table operands of eight rows requested together from clamped addresses (see
+  // gemm_f32_nt_kernel), only the stores are predicated
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int n = n0 + wn + 32 * j + li;
-      if (n >= g.N) continue;
-      const float bias = g.bias ? g.bias[n] : 0.f;
+      const int nc = min(n, g.N - 1);
+      const float bias = g.bias ? g.bias[nc] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm + 32 * i + acc_row_h(r, lane);
-        if (m >= g.M) continue;
-        float v = acc[i][j][r] + bias;
-        if (g.gelu) v = gelu_erf_h(v);
-        if (g.residual) v += g.residual[(long)bz * g.strideR + (long)m * g.ldr + n];
-        if (g.rowtab) v += g.rowtab[(long)(m % g.rowtab_period) * g.N + n];
-        C[(long)m * g.ldc + n] = v;
+      for (int r0 = 0; r0 < 16; r0 += 8) {
+        float extra[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) extra[r] = 0.f;
+        if (g.residual) {
+          const float* rp = g.residual + (long)bz * g.strideR + nc;
+#pragma unroll
+          for (int r = 0; r < 8; ++r)
+            extra[r] = rp[(long)min(m0 + wm + 32 * i + acc_row_h(r0 + r, lane), g.M - 1) * g.ldr];
+        }
+        if (g.rowtab) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r)
+            extra[r] += g.rowtab[(long)(min(m0 + wm + 32 * i + acc_row_h(r0 + r, lane), g.M - 1) % g.rowtab_period) * g.N + nc];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int m = m0 + wm + 32 * i + acc_row_h(r0 + r, lane);
+          float v = acc[i][j][r0 + r] + bias;
+          if (g.gelu) v = gelu_erf_h(v);
+          v += extra[r];
+          if (m < g.M && n < g.N) C[(long)m * g.ldc + n] = v;
+        }
       }
     }
 }

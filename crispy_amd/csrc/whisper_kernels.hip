@@ -30,7 +30,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + er
 // row index of accumulator register r for this lane (32x32 MFMA C/D layout)
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-__global__ __launch_bounds__(256) void gemm_f32_nt_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void gemm_f32_nt_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float As[2][GB_M * GB_LD];
   __shared__ __attribute__((aligned(16))) float Ws[2][GB_N * GB_LD];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -99,7 +99,9 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  // epilogue
+  // epilogue.  The residual / row-table operands of a lane's 16 rows are requested together from clamped (always
+  // valid) addresses before any of them is used: one exposed round trip per 32 x 32 block instead of one per element
+  // (with a load, a wait and a store per row the short-K projections of the encoder spent their tail waiting on L2).
   const bool hm = g.hm_rows > 0;              // head-major store (cross K|V): see GemmArgs
   int hm_b0 = 0, hm_t0 = 0;
   if (hm) { hm_b0 = m0 / g.hm_rows; hm_t0 = m0 - hm_b0 * g.hm_rows; }
@@ -108,28 +110,44 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int n = n0 + wn + 32 * j + li;
-      if (n >= g.N) continue;
-      const float bias = g.bias ? g.bias[n] : 0.f;
+      const int nc = min(n, g.N - 1);
+      const float bias = g.bias ? g.bias[nc] : 0.f;
       long hm_col = 0;
       if (hm) {
-        const int kv = n >= g.hm_width ? 1 : 0, rem = n - kv * g.hm_width;
+        const int kv = nc >= g.hm_width ? 1 : 0, rem = nc - kv * g.hm_width;
         hm_col = ((long)kv * g.hm_width + (long)(rem >> 6) * 64) * g.hm_rows + (rem & 63);
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int dm = wm + 32 * i + acc_row(r, lane);
-        const int m = m0 + dm;
-        if (m >= g.M) continue;
-        float v = acc[i][j][r] + bias;
-        if (g.gelu) v = gelu_erf(v);
-        if (g.residual) v += g.residual[(long)bz * g.strideR + (long)m * g.ldr + n];
-        if (g.rowtab) v += g.rowtab[(long)(m % g.rowtab_period) * g.N + n];
-        if (hm) {
-          int t = hm_t0 + dm, b = hm_b0;      // a 128-row tile crosses at most one clip boundary (hm_rows >= 128)
-          if (t >= g.hm_rows) { t -= g.hm_rows; ++b; }
-          C[(long)b * g.N * g.hm_rows + (long)t * 64 + hm_col] = v;
-        } else {
-          C[(long)m * g.ldc + n] = v;
+      for (int r0 = 0; r0 < 16; r0 += 8) {     // eight rows at a time: enough loads in flight, 3 waves per SIMD kept
+        float extra[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) extra[r] = 0.f;
+        if (g.residual) {
+          const float* rp = g.residual + (long)bz * g.strideR + nc;
+#pragma unroll
+          for (int r = 0; r < 8; ++r)
+            extra[r] = rp[(long)min(m0 + wm + 32 * i + acc_row(r0 + r, lane), g.M - 1) * g.ldr];
+        }
+        if (g.rowtab) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r)
+            extra[r] += g.rowtab[(long)(min(m0 + wm + 32 * i + acc_row(r0 + r, lane), g.M - 1) % g.rowtab_period) * g.N + nc];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int dm = wm + 32 * i + acc_row(r0 + r, lane);
+          const int m = m0 + dm;
+          float v = acc[i][j][r0 + r] + bias;
+          if (g.gelu) v = gelu_erf(v);
+          v += extra[r];
+          if (m >= g.M || n >= g.N) continue;
+          if (hm) {
+            int t = hm_t0 + dm, b = hm_b0;      // a 128-row tile crosses at most one clip boundary (hm_rows >= 128)
+            if (t >= g.hm_rows) { t -= g.hm_rows; ++b; }
+            C[(long)b * g.N * g.hm_rows + (long)t * 64 + hm_col] = v;
+          } else {
+            C[(long)m * g.ldc + n] = v;
+          }
         }
       }
     }
