@@ -710,10 +710,23 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
     float vad_prob = 0.f;
     if constexpr (MODE != 2) {
     // ---- 1. pitch: half-rate, LPC whitening (lp in Bb) ----
-    for (int i = lane; i < 864; i += WAVE) {
-      const float2 v = *reinterpret_cast<const float2*>(pb + 2 * i);
-      const float x0 = i > 0 ? pb[2 * i - 1] : 0.f;
-      lp[i] = .5f * (.5f * (x0 + v.y) + v.x);
+    {
+      // all 14 x 2 window loads of a lane are requested before the first one is used (a `for (i = lane; ...)` loop
+      // with the bound test in it compiled to load - wait - load - wait per trip: 27 exposed round trips per frame)
+      float2 v[14];
+      float x0[14];
+#pragma unroll
+      for (int k = 0; k < 14; ++k) {
+        const int i = min(lane + WAVE * k, 863);
+        v[k] = *reinterpret_cast<const float2*>(pb + 2 * i);
+        x0[k] = pb[2 * i - 1];                      // i = 0 reads the (valid) sample before the buffer, zeroed below
+      }
+#pragma unroll
+      for (int k = 0; k < 14; ++k) {
+        const int i = lane + WAVE * k;
+        const float xm = i > 0 ? x0[k] : 0.f;
+        if (i < 864) lp[i] = .5f * (.5f * (xm + v[k].y) + v[k].x);
+      }
     }
     __syncthreads();
     // Each lane owns 14 consecutive half-rate samples (plus a 5-sample halo) in registers: the same window feeds
