@@ -131,16 +131,25 @@ __device__ __forceinline__ void fft_pass(float2* buf, const float2* __restrict__
   constexpr int M = 480 / R;
   constexpr int NBF = (M + WAVE - 1) / WAVE;
   float2 o[NBF][R];
+  // twiddles of every trip first (clamped butterfly index): one exposed table round trip per pass, not one per trip
+  float2 tw[NBF][R];
+  if (NS > 1) {
+#pragma unroll
+    for (int nb = 0; nb < NBF; ++nb) {
+      const int k = min(lane + WAVE * nb, M - 1) % NS;
+#pragma unroll
+      for (int r = 1; r < R; ++r) tw[nb][r] = w960[k * r * (960 / (NS * R))];
+    }
+  }
 #pragma unroll
   for (int nb = 0; nb < NBF; ++nb) {
     const int j = lane + WAVE * nb;
     if (j < M) {
-      const int k = j % NS;
       float2 v[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         float2 x = buf[j + r * M];
-        if (NS > 1 && r > 0) x = cmul(x, w960[k * r * (960 / (NS * R))]);
+        if (NS > 1 && r > 0) x = cmul(x, tw[nb][r]);
         v[r] = x;
       }
       butterfly<R>(v, o[nb]);
@@ -203,6 +212,14 @@ __device__ __forceinline__ void fft480_from(float2* buf, In in, const float2* __
 // buf holds Z = FFT480(x[2n] + i x[2n+1]); turn it into X[0..480] = DFT960(x)/960 in place.
 __device__ __forceinline__ void real_fwd_post(float2* buf, const float2* __restrict__ w960, int lane) {
   const float scale = 1.0f / 960.0f;
+  // table loads of all four trips first (clamped index): inside the `k <= 240` bodies each of them was a load - wait
+  float2 wk[4], wn[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int k = min(lane + WAVE * m, 240);
+    wk[m] = w960[k];
+    wn[m] = w960[480 - k];
+  }
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     const int k = lane + WAVE * m;
@@ -213,13 +230,13 @@ __device__ __forceinline__ void real_fwd_post(float2* buf, const float2* __restr
       float2 zc = cconj(zn);
       float2 fe = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
       float2 d = make_float2(0.5f * (zk.x - zc.x), 0.5f * (zk.y - zc.y));
-      float2 t = cmul(w960[k], make_float2(d.y, -d.x));
+      float2 t = cmul(wk[m], make_float2(d.y, -d.x));
       const float2 xk = make_float2((fe.x + t.x) * scale, (fe.y + t.y) * scale);
       // X[480-k]
       zc = cconj(zk);
       fe = make_float2(0.5f * (zn.x + zc.x), 0.5f * (zn.y + zc.y));
       d = make_float2(0.5f * (zn.x - zc.x), 0.5f * (zn.y - zc.y));
-      t = cmul(w960[480 - k], make_float2(d.y, -d.x));
+      t = cmul(wn[m], make_float2(d.y, -d.x));
       const float2 xn = make_float2((fe.x + t.x) * scale, (fe.y + t.y) * scale);
       buf[k] = xk;
       buf[480 - k] = xn;
@@ -231,6 +248,13 @@ __device__ __forceinline__ void real_fwd_post(float2* buf, const float2* __restr
 // buf holds X[0..480]; replace it by conj(Z) with Z[k] = (X[k]+conj X[480-k]) + i w^-k (X[k]-conj X[480-k])
 // so that a forward FFT yields conj of the interleaved time signal.
 __device__ __forceinline__ void real_inv_pre(float2* buf, const float2* __restrict__ w960, int lane) {
+  float2 wk[4], wn[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int k = min(lane + WAVE * m, 240);
+    wk[m] = w960[k];
+    wn[m] = w960[480 - k];
+  }
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     const int k = lane + WAVE * m;
@@ -239,11 +263,11 @@ __device__ __forceinline__ void real_inv_pre(float2* buf, const float2* __restri
       const float2 bn = buf[480 - k];
       float2 b = cconj(bn);
       float2 fe = cadd(a, b);
-      float2 fo = cmul(csub(a, b), cconj(w960[k]));
+      float2 fo = cmul(csub(a, b), cconj(wk[m]));
       const float2 zk = make_float2(fe.x - fo.y, -(fe.y + fo.x));
       b = cconj(a);
       fe = cadd(bn, b);
-      fo = cmul(csub(bn, b), cconj(w960[480 - k]));
+      fo = cmul(csub(bn, b), cconj(wn[m]));
       const float2 zn = make_float2(fe.x - fo.y, -(fe.y + fo.x));
       buf[k] = zk;
       if (k > 0) buf[480 - k] = zn;
@@ -271,12 +295,15 @@ __device__ __forceinline__ void band_pairs(const float2* S, const float2* Xc, fl
                                            float2* park, const RnTables* __restrict__ tab, const BandEdges& be,
                                            int lane) {
   float clo[4], chi[4];
+  float2 fr[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) fr[m] = *reinterpret_cast<const float2*>(tab->bin_frac + 2 * min(lane + WAVE * m, 199));
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     const int pidx = lane + WAVE * m;
     clo[m] = 0.f; chi[m] = 0.f;
     if (pidx < 200) {
-      const float2 f = *reinterpret_cast<const float2*>(tab->bin_frac + 2 * pidx);
+      const float2 f = fr[m];
       const float4 sv = *reinterpret_cast<const float4*>(S + 2 * pidx);
       float e0 = sv.x * sv.x; e0 += sv.y * sv.y;
       float e1 = sv.z * sv.z; e1 += sv.w * sv.w;
@@ -1435,19 +1462,26 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
     STAMP(14)
     {
       float* o = a.out + (long)t * a.stride_t + (long)b * a.stride_b;
+      float2 hwa[4], hwb[4];                  // window values of all four trips, requested together
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int n = min(lane + WAVE * m, 239);
+        hwa[m] = *reinterpret_cast<const float2*>(hw + 2 * n);          // hw[i0], hw[i1]
+        hwb[m] = *reinterpret_cast<const float2*>(hw + 478 - 2 * n);    // hw[479 - i1], hw[479 - i0]
+      }
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const int n = lane + WAVE * m;
         if (n < 240) {
           const float2 z = L.A[n];
           const float2 z2 = L.A[240 + n];
-          const int i0 = 2 * n, i1 = 2 * n + 1;
+          const int i0 = 2 * n;
           float2 ov;
-          ov.x = fmaf(z.x, hw[i0], synth[m].x);
-          ov.y = fmaf(-z.y, hw[i1], synth[m].y);
+          ov.x = fmaf(z.x, hwa[m].x, synth[m].x);
+          ov.y = fmaf(-z.y, hwa[m].y, synth[m].y);
           if (t >= t_out) *reinterpret_cast<float2*>(o + i0) = ov;
-          synth[m].x = z2.x * hw[479 - i0];
-          synth[m].y = -z2.y * hw[479 - i1];
+          synth[m].x = z2.x * hwb[m].y;
+          synth[m].y = -z2.y * hwb[m].x;
           if constexpr (!TAIL_REGS) *reinterpret_cast<float2*>(synth_g + i0) = synth[m];
         }
       }
