@@ -428,36 +428,35 @@ __global__ __launch_bounds__(256) void gemm_vocab_f32_kernel(GemmArgs g) {
 // ---------------------------------------------------------------------------------------------
 // LayerNorm over the last dimension (eps 1e-5), one wave per row; D <= 1280, multiple of 64
 // ---------------------------------------------------------------------------------------------
+template <int PER>     // PER = D / 64 columns per lane: compile-time, so the row is requested in one go (no branch per load)
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ y,
-                                                        long rows, int D) {
+                                                        long rows) {
+  constexpr int D = 64 * PER;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
   const float* xr = x + row * D;
-  float v[20];
-  const int per = D / 64;
+  float v[PER], gm[PER], bt[PER];
   float s = 0.f;
 #pragma unroll
-  for (int q = 0; q < 20; ++q)
-    if (q < per) { v[q] = xr[lane + 64 * q]; s += v[q]; }
+  for (int q = 0; q < PER; ++q) v[q] = xr[lane + 64 * q];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) { gm[q] = gamma[lane + 64 * q]; bt[q] = beta[lane + 64 * q]; }
+#pragma unroll
+  for (int q = 0; q < PER; ++q) s += v[q];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
   const float mean = s / (float)D;
   float s2 = 0.f;
 #pragma unroll
-  for (int q = 0; q < 20; ++q)
-    if (q < per) { const float d = v[q] - mean; s2 = fmaf(d, d, s2); }
+  for (int q = 0; q < PER; ++q) { const float d = v[q] - mean; s2 = fmaf(d, d, s2); }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s2 += __shfl_xor(s2, off, 64);
   const float rstd = 1.f / sqrtf(s2 / (float)D + 1e-5f);
   float* yr = y + row * D;
 #pragma unroll
-  for (int q = 0; q < 20; ++q)
-    if (q < per) {
-      const int c = lane + 64 * q;
-      yr[c] = (v[q] - mean) * rstd * gamma[c] + beta[c];
-    }
+  for (int q = 0; q < PER; ++q) yr[lane + 64 * q] = (v[q] - mean) * rstd * gm[q] + bt[q];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -937,7 +936,15 @@ hipError_t gemm_f32_nt(const GemmArgs& g, int batch, hipStream_t s) {
 }
 hipError_t layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, long rows, int D,
                          hipStream_t s) {
-  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, gamma, beta, y, rows, D);
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  switch (D) {     // the widths of the Whisper family (tiny ... large)
+    case 384: hipLaunchKernelGGL(layernorm_kernel<6>, grid, block, 0, s, x, gamma, beta, y, rows); break;
+    case 512: hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, x, gamma, beta, y, rows); break;
+    case 768: hipLaunchKernelGGL(layernorm_kernel<12>, grid, block, 0, s, x, gamma, beta, y, rows); break;
+    case 1024: hipLaunchKernelGGL(layernorm_kernel<16>, grid, block, 0, s, x, gamma, beta, y, rows); break;
+    case 1280: hipLaunchKernelGGL(layernorm_kernel<20>, grid, block, 0, s, x, gamma, beta, y, rows); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 hipError_t attn_encoder_f32(const float* qkv, float* out, int B, int T, int D, int heads, hipStream_t s) {
