@@ -1522,24 +1522,45 @@ __global__ __launch_bounds__(WAVE) void rn_highpass_kernel(RnArgs a) {
   const double b0 = (double)-2.f, b1 = (double)1.f;
   float m0 = a.hp_mem[2 * b], m1 = a.hp_mem[2 * b + 1];
   float* dst = a.xhp + (long)b * a.xhp_stride + RN_HIST;
-  for (int t = 0; t < a.T; ++t) {
-    const float4* src = reinterpret_cast<const float4*>(a.in + (long)t * a.stride_t + (long)b * a.stride_b);
-    float4* d4 = reinterpret_cast<float4*>(dst + (long)t * RN_FRAME);
-    for (int i4 = 0; i4 < RN_FRAME / 4; ++i4) {
-      const float4 xv = src[i4];
-      const float xin[4] = {xv.x, xv.y, xv.z, xv.w};
+  // The recurrence is a dependent chain of five operations per sample; what the lane must not also wait for is its
+  // input.  Blocks of 32 samples (8 float4) are requested one block ahead, across frame boundaries: with the load
+  // issued right in front of its use the kernel spent most of its time on one L1/L2 round trip per four samples.
+  constexpr int BLK = 8, NBLK = RN_FRAME / 4 / BLK;   // 15 blocks per frame
+  const long total = (long)a.T * NBLK;
+  auto block_ptr = [&](long k) {
+    const long t = k / NBLK, blk = k - t * NBLK;
+    return reinterpret_cast<const float4*>(a.in + t * a.stride_t + (long)b * a.stride_b) + blk * BLK;
+  };
+  float4 cur[BLK], nxt[BLK];
+  {
+    const float4* p = block_ptr(0);
+#pragma unroll
+    for (int q = 0; q < BLK; ++q) cur[q] = p[q];
+  }
+  for (long k = 0; k < total; ++k) {
+    {
+      const float4* p = block_ptr(k + 1 < total ? k + 1 : k);     // last block: a harmless re-read
+#pragma unroll
+      for (int q = 0; q < BLK; ++q) nxt[q] = p[q];
+    }
+    float4* d4 = reinterpret_cast<float4*>(dst) + k * BLK;          // frames are contiguous in xhp: block k of the call
+#pragma unroll
+    for (int q = 0; q < BLK; ++q) {
+      const float xin[4] = {cur[q].x, cur[q].y, cur[q].z, cur[q].w};
       float yo[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float xi = xin[q];
+      for (int e = 0; e < 4; ++e) {
+        const float xi = xin[e];
         const float yi = xi + m0;
         const double dx = (double)xi, dy = (double)yi;
         m0 = (float)__dadd_rn((double)m1, __dsub_rn(__dmul_rn(b0, dx), __dmul_rn(a0, dy)));
         m1 = (float)__dsub_rn(__dmul_rn(b1, dx), __dmul_rn(a1, dy));
-        yo[q] = yi;
+        yo[e] = yi;
       }
-      d4[i4] = make_float4(yo[0], yo[1], yo[2], yo[3]);
+      d4[q] = make_float4(yo[0], yo[1], yo[2], yo[3]);
     }
+#pragma unroll
+    for (int q = 0; q < BLK; ++q) cur[q] = nxt[q];
   }
   a.hp_mem[2 * b] = m0;
   a.hp_mem[2 * b + 1] = m1;
