@@ -1518,8 +1518,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
 __global__ __launch_bounds__(WAVE) void rn_highpass_kernel(RnArgs a) {
   const int b = blockIdx.x * WAVE + threadIdx.x;
   if (b >= a.B) return;
-  const double a0 = (double)-1.99599f, a1 = (double)0.99600f;
-  const double b0 = (double)-2.f, b1 = (double)1.f;
+  const double a0h = 0.5 * (double)-1.99599f, a1 = (double)0.99600f;   // b = (-2, 1) is folded into the two fmas
   float m0 = a.hp_mem[2 * b], m1 = a.hp_mem[2 * b + 1];
   float* dst = a.xhp + (long)b * a.xhp_stride + RN_HIST;
   // The recurrence is a dependent chain of five operations per sample; what the lane must not also wait for is its
@@ -1553,8 +1552,11 @@ __global__ __launch_bounds__(WAVE) void rn_highpass_kernel(RnArgs a) {
         const float xi = xin[e];
         const float yi = xi + m0;
         const double dx = (double)xi, dy = (double)yi;
-        m0 = (float)__dadd_rn((double)m1, __dsub_rn(__dmul_rn(b0, dx), __dmul_rn(a0, dy)));
-        m1 = (float)__dsub_rn(__dmul_rn(b1, dx), __dmul_rn(a1, dy));
+        // b0 dx - a0 dy = -2 (dx + (a0 / 2) dy): both products are exact in f64 (f32 x f32), scaling by 2 commutes
+        // with the rounding, so u and the fused add below round exactly where the reference's sub and add do
+        const double u = __fma_rn(a0h, dy, dx);
+        m0 = (float)__fma_rn(-2.0, u, (double)m1);
+        m1 = (float)__fma_rn(-a1, dy, dx);
         yo[e] = yi;
       }
       d4[q] = make_float4(yo[0], yo[1], yo[2], yo[3]);

@@ -75,6 +75,26 @@ def test_parity_mixed_batch_with_taps(oracle, weights0):
     assert n_pitch_ok >= 0.99 * B * T
 
 
+def test_highpass_stage_is_bit_exact(oracle, weights0):
+    """The high-pass biquad (f32 state rounding, f64 products: Appendix A.3 step 1) is the one stage of the frame that
+    is reproduced bit for bit -- the kernel keeps the reference's rounding points (products exact in f64, one rounding
+    per sub/add, f32 state), only fused and prefetched differently.  Checked on the last frame's high-passed signal of
+    five streams after 33 frames (debug capture slot 3824..4304)."""
+    from crispy_amd import synth_audio as SA
+    B, T = 5, 33
+    x = SA.batch_np(B, T) * np.float32(32768.0)
+    ds = _mk(weights0, B)
+    ds.debug_capture(True)
+    ds.process(x)
+    for b in range(B):
+        st = oracle.OracleDenoiseState(weights0)
+        st.process(x[:, b])
+        ref = st.debug()[3824:4304]
+        got = ds.debug_read(b)[3824:4304]
+        assert np.abs(ref).max() > 100.0
+        assert np.array_equal(got, ref), f"stream {b}: high-passed frame differs from the oracle"
+
+
 def test_cfg1_single_clip_through_the_adapter(oracle, weights0):
     """BASELINE cfg 1 (shortened to 3 s): the RnnNoiseProcessor adapter (x32768, clamp, volume,
     first-frame drop: audio.rs:261-278) over the HIP path equals the same adapter over the oracle."""
