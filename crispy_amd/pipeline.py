@@ -65,13 +65,24 @@ class DenoiseTranscribePipeline:
     def run(self, d_in48, prompt, max_new: int):
         """d_in48: torch float32 [B, T, 480] on the device, int16-range samples (x32768 already applied).
         Returns (tokens [B, n_chunks, max_new], pcm16k [B, n16] on the device)."""
+        import time
         torch = self.torch
         B, T, _ = d_in48.shape
         assert B == self.B and d_in48.is_contiguous()
         den = torch.empty_like(d_in48)
         torch.cuda.synchronize()
+        tm = self.timings = {"denoise": 0.0, "resample": 0.0, "logmel": 0.0, "encoder": 0.0, "decode": 0.0}
+        t_prev = time.perf_counter()
+
+        def lap(stage):          # every stage below ends in a synchronize: wall-clock laps are stage times
+            nonlocal t_prev
+            now = time.perf_counter()
+            tm[stage] += now - t_prev
+            t_prev = now
+
         self.ds.process_device(d_in48.data_ptr(), den.data_ptr(), T, layout="btf")
         self.ds.synchronize()
+        lap("denoise")
         n48 = (T - 1) * FRAME_SIZE                       # first frame dropped (audio.rs:275-278)
         n16 = Resampler48to16.out_len(n48)
         pcm16 = torch.zeros(B, max(n16, 1), device=self.dev)
@@ -79,6 +90,7 @@ class DenoiseTranscribePipeline:
         self.rs.process_device(den_flat.data_ptr() + 4 * FRAME_SIZE, T * FRAME_SIZE, n48, B, pcm16.data_ptr(),
                                pcm16.shape[1], scale=1.0 / 32768.0, handoff=self.handoff)
         self.rs.synchronize()
+        lap("resample")
         n_chunks = max(1, -(-n16 // CHUNK_SAMPLES))
         hp = self.whisper.hp
         toks = np.zeros((B, n_chunks, max_new), dtype=np.int32)
@@ -89,8 +101,10 @@ class DenoiseTranscribePipeline:
             n = min(CHUNK_SAMPLES, n16 - lo)
             self.lm.compute_device(pcm16.data_ptr() + 4 * lo, pcm16.shape[1], np.full(B, n), 0, melt.data_ptr())
             self.lm.synchronize()
+            lap("logmel")
             self.whisper.encode_device(melt.data_ptr(), B, enc.data_ptr())
             self.whisper.synchronize()
+            lap("encoder")
             # decode in groups of <= 512 clips: that is the range of the fused decode-step kernels (skinny projections
             # with the LayerNorm folded in); larger steps fall back to the general GEMM + separate LayerNorm launches
             esz = enc[0].numel() * 4
@@ -98,4 +112,5 @@ class DenoiseTranscribePipeline:
                 nb = min(512, B - b0)
                 t, _, _ = self.whisper.decode_greedy_device(enc.data_ptr() + b0 * esz, nb, prompt, max_new)
                 toks[b0:b0 + nb, c] = t
+            lap("decode")
         return toks, pcm16[:, :n16]

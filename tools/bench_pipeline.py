@@ -27,4 +27,5 @@ for rep in range(2):
 audio_s = B * (T - 1) * 480 / 48000.0
 print(f"cfg4 pipeline B={B} streams x {(T-1)/100:.0f} s: {dt*1e3:.1f} ms total -> {audio_s/dt:,.0f} x real time; "
       f"tokens {toks.shape}, 16 kHz samples per stream {pcm16.shape[1]}")
+print("stages (ms): " + ", ".join(f"{k} {v*1e3:.1f}" for k, v in pipe.timings.items()))
 print("finite:", bool(torch.isfinite(pcm16).all()), " distinct first tokens:", len(np.unique(toks[:, 0, 0])))
