@@ -379,7 +379,7 @@ int rno_pitch_search(const float *x_lp, const float *y, int len, int max_pitch) 
   int offset;
   float x_lp4[PITCH_FRAME_SIZE >> 2];
   float y_lp4[(PITCH_FRAME_SIZE + PITCH_MAX_PERIOD) >> 2];
-  float xcorr[PITCH_MAX_PERIOD >> 1];
+  float xcorr[PITCH_MAX_PERIOD >> 1] = {0};   /* pitch_xcorr fills the first max_pitch >> 2 entries */
   for (int j = 0; j < len >> 2; j++) x_lp4[j] = x_lp[2 * j];
   for (int j = 0; j < lag >> 2; j++) y_lp4[j] = y[2 * j];
   pitch_xcorr(x_lp4, y_lp4, xcorr, len >> 2, max_pitch >> 2);
