@@ -1479,7 +1479,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
           float2 ov;
           ov.x = fmaf(z.x, hwa[m].x, synth[m].x);
           ov.y = fmaf(-z.y, hwa[m].y, synth[m].y);
-          if (t >= t_out) *reinterpret_cast<float2*>(o + i0) = ov;
+          // the output is never read back here: non-temporal stores keep it from allocating in L2 next to the history
+          // window and the parked spectrum (-1.1 KB of fetches per stream-frame, time unchanged)
+          if (t >= t_out) { __builtin_nontemporal_store(ov.x, o + i0); __builtin_nontemporal_store(ov.y, o + i0 + 1); }
           synth[m].x = z2.x * hwb[m].y;
           synth[m].y = -z2.y * hwb[m].x;
           if constexpr (!TAIL_REGS) *reinterpret_cast<float2*>(synth_g + i0) = synth[m];
