@@ -1307,7 +1307,9 @@ int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const si
   if (batch == 0) return CRISPY_OK;
   if (!pcm || !n) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: NULL argument");
   if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_transcribe_batch: model not finalized");
-  // empty clips produce empty results without touching the GPU (managers/transcription.rs:175-177)
+  // empty clips produce empty results without touching the GPU (managers/transcription.rs:175-177); so do clips
+  // shorter than 1 s = 100 mel frames, which whisper.cpp's whisper_full refuses ("input is too short", returns no
+  // segments) [UPSTREAM-RECALL] -- the 168 samples the 48 -> 16 kHz resampler leaves past a 30 s chunk are such a clip
   std::vector<int> live;
   size_t stride = 1;
   for (int i = 0; i < batch; ++i) {
@@ -1316,6 +1318,7 @@ int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const si
                   "(commands/transcription.rs:249-302)", i, n[i]);
     if (n[i] > 0) {
       if (!pcm[i]) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: clip %d is NULL", i);
+      if (n[i] / 160 < 100) continue;
       live.push_back(i);
       if (n[i] > stride) stride = n[i];
     }

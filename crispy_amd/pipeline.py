@@ -93,12 +93,16 @@ class DenoiseTranscribePipeline:
         lap("resample")
         n_chunks = max(1, -(-n16 // CHUNK_SAMPLES))
         hp = self.whisper.hp
-        toks = np.zeros((B, n_chunks, max_new), dtype=np.int32)
+        toks = np.full((B, n_chunks, max_new), -1, dtype=np.int32)      # -1: no token (chunk skipped, see below)
         melt = torch.zeros(B, 3002, hp.n_mels, device=self.dev)
         enc = torch.empty(B, hp.n_audio_ctx, hp.n_audio_state, device=self.dev)
         for c in range(n_chunks):
             lo = c * CHUNK_SAMPLES
             n = min(CHUNK_SAMPLES, n16 - lo)
+            if n // 160 < 100:
+                # whisper.cpp refuses input shorter than 1 s (100 mel frames) and returns no segments: the few samples
+                # the resampler leaves past the last full 30 s chunk transcribe to nothing, as they do in the app
+                continue
             self.lm.compute_device(pcm16.data_ptr() + 4 * lo, pcm16.shape[1], np.full(B, n), 0, melt.data_ptr())
             self.lm.synchronize()
             lap("logmel")

@@ -300,7 +300,8 @@ typedef struct crispy_asr_result {
 } crispy_asr_result;
 
 /* engine.transcribe(&audio, &TranscribeOptions::default()) for ONE chunk of <= 480000 samples
- * (16 kHz f32, host).  n == 0 returns an empty result (transcription.rs:175-177).  Needs a model
+ * (16 kHz f32, host).  n == 0 returns an empty result (transcription.rs:175-177), and so does a chunk shorter than
+ * 1 s = 100 mel frames (n / 160 < 100): whisper.cpp's whisper_full refuses it and yields no segments.  Needs a model
  * loaded from a file (vocabulary) for text; tokens are always returned.  opts == NULL is
  * TranscribeOptions::default(): language auto-detected, transcribe, timestamps on. */
 int crispy_asr_transcribe(crispy_asr *h, const float *pcm16k, size_t n, const crispy_asr_opts *opts,
