@@ -499,8 +499,175 @@ __device__ __forceinline__ float dot_h(__amdgpu_buffer_rsrc_t rs, int w_off, int
   return acc[0];
 }
 
+#ifndef RN_GRU_MFMA
+#define RN_GRU_MFMA 1   // 1: the gain network's matrix-vector products run on v_mfma_f32_4x4x4_16B_f16 (below)
+#endif
+// ---- the same products on the matrix pipe, still one wave per stream and lane = output row ----
+// v_mfma_f32_4x4x4_16B_f16 is 16 independent 4x4x4 blocks; block b lives in lanes 4b..4b+3.  Its "A" rows carry the
+// activation vector split into three f16 terms (x = hi + lo + lo2 exactly: 3 x 11 significand bits), the same in every
+// block; its "B" columns carry four consecutive-k f16 weights of row = lane -- the 16-byte weight loads of the VALU
+// form feed two MFMAs unchanged.  D[i][j] of block b lands in lane 4b+j, register i: the lane of row r ends up with
+// the three term sums of *its* row in its own registers (register 3 = whatever the clamped fourth A row produced,
+// ignored).  int8 x f16-term products are exact in f32, so only the summation order differs from the VALU form.
+// 256 MACs per 8-cycle MFMA against 64 per 4-cycle v_fma_mix_f32, and the VALU issue slots go to the other three
+// waves of the SIMD (tools/micro/mfma4x4_matvec.hip checks the layout and the rates).
+// Activation images: f16 [3 terms][RN_IMG_LD], a term stride of 272 bytes keeps the three 16-byte broadcast reads
+// of a wave on different banks.
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float rn_f4 __attribute__((ext_vector_type(4)));
+constexpr int RN_IMG_LD = 136;
+__device__ __forceinline__ void split_store(_Float16* img, int i, float v) {
+  const _Float16 hi = (_Float16)v;
+  const float r1 = v - (float)hi;
+  const _Float16 lo = (_Float16)r1;
+  const _Float16 lo2 = (_Float16)(r1 - (float)lo);
+  img[i] = hi;
+  img[RN_IMG_LD + i] = lo;
+  img[2 * RN_IMG_LD + i] = lo2;
+}
+// toff: this lane's term offset in bytes (min(lane & 3, 2) * RN_IMG_LD * 2), opaque to the optimiser
+template <int MK8, int NK8, int ROWS, int NR>
+__device__ __forceinline__ void dotn_m(__amdgpu_buffer_rsrc_t rs, int w_off, int u_off, const int (&row)[NR],
+                                       const _Float16* xa, const _Float16* xb, int toff, float (&acc)[NR]) {
+  constexpr int K8 = MK8 + NK8;
+  constexpr int BLK = NR >= 3 ? RN_BLK3 : (NR == 2 ? RN_BLK2 : RN_BLK1);
+  constexpr int NBLK = (K8 + BLK - 1) / BLK;
+  constexpr int NC = NR >= 3 ? 1 : 2;   // accumulator chains per row: a dependent MFMA waits two more cycles
+  int row16[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) row16[r] = row[r] * 16;
+  asm volatile("" : "+v"(toff));
+  const h8* xa8 = reinterpret_cast<const h8*>(reinterpret_cast<const char*>(xa) + toff);
+  const h8* xb8 = reinterpret_cast<const h8*>(reinterpret_cast<const char*>(xb) + toff);
+  h8 w[2][BLK][NR];
+  h8 xc = MK8 > 0 ? xa8[0] : xb8[0], xn = xc;
+#pragma unroll
+  for (int q = 0; q < BLK; ++q)
+    if (q < K8) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+        w[0][q][r] = wload(rs, row16[r], q < MK8 ? w_off + q * ROWS : u_off + (q - MK8) * ROWS);
+    }
+  rn_f4 a4[NR][NC];
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) a4[r][c] = rn_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int blk = 0; blk < NBLK; ++blk) {
+    if (blk + 1 < NBLK) {
+#pragma unroll
+      for (int q = 0; q < BLK; ++q) {
+        const int k = (blk + 1) * BLK + q;
+        if (k < K8) {
+#pragma unroll
+          for (int r = 0; r < NR; ++r)
+            w[(blk + 1) & 1][q][r] = wload(rs, row16[r], k < MK8 ? w_off + k * ROWS : u_off + (k - MK8) * ROWS);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < BLK; ++q) {
+      const int k = blk * BLK + q;
+      if (k < K8) {
+        if (k + 1 < K8) xn = k + 1 < MK8 ? xa8[k + 1] : xb8[k + 1 - MK8];
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+          for (int c = 0; c < NC; ++c) asm volatile("" : "+v"(a4[r][c]));
+        __builtin_amdgcn_sched_barrier(0);
+        const h4 x0 = {xc[0], xc[1], xc[2], xc[3]}, x1 = {xc[4], xc[5], xc[6], xc[7]};
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const h8 wv = w[blk & 1][q][r];
+          a4[r][0] = __builtin_amdgcn_mfma_f32_4x4x4f16(x0, h4{wv[0], wv[1], wv[2], wv[3]}, a4[r][0], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const h8 wv = w[blk & 1][q][r];
+          a4[r][NC - 1] = __builtin_amdgcn_mfma_f32_4x4x4f16(x1, h4{wv[4], wv[5], wv[6], wv[7]}, a4[r][NC - 1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        xc = xn;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    float s = a4[r][0][0] + a4[r][0][1] + a4[r][0][2];
+    if (NC == 2) s += a4[r][1][0] + a4[r][1][1] + a4[r][1][2];
+    acc[r] += s;
+  }
+}
+template <int K8, int ROWS>
+__device__ __forceinline__ float dot_m(__amdgpu_buffer_rsrc_t rs, int w_off, int row, const _Float16* x, int toff,
+                                       float acc0) {
+  const int rows[1] = {row};
+  float acc[1] = {acc0};
+  dotn_m<K8, 0, ROWS, 1>(rs, w_off, w_off, rows, x, x, toff, acc);
+  return acc[0];
+}
+
 // One GRU layer (ReLU candidate).  in_vec[M] and state[N] in LDS, zero padded to multiples of 8;
 // zbuf / hr: N floats of scratch each.  w_off / u_off: 16-byte offsets of the two matrices in the weight pack.
+// MFMA form: in_img holds the split image of the layer input (caller), st_img receives the split image of the
+// state (gates pass) and then of h*r (candidate pass); zbuf as in the VALU form.  Every lane runs every MFMA (the
+// matrix pipe ignores nothing a predicate could express: rows are clamped, results are predicated).
+template <int M, int N>
+__device__ __forceinline__ void gru_layer_m(__amdgpu_buffer_rsrc_t rs, int w_off, int u_off,
+                                            const float* __restrict__ bias, const _Float16* in_img,
+                                            float* state, float* zbuf, _Float16* st_img, int toff,
+                                            const TansigTab& tansig, int lane) {
+  constexpr int ROWS = 3 * N;
+  constexpr int MK8 = (M + 7) / 8, NK8 = (N + 7) / 8;
+  constexpr int NRZ = (2 * N + WAVE - 1) / WAVE, NRC = (N + WAVE - 1) / WAVE;
+  const float S = 1.f / 256.f;
+  for (int i = lane; i < NK8 * 8; i += WAVE) split_store(st_img, i, i < N ? state[i] : 0.f);
+  __syncthreads();
+  {
+    int rows[NRZ];
+    float acc[NRZ];
+#pragma unroll
+    for (int r = 0; r < NRZ; ++r) {
+      rows[r] = min(lane + WAVE * r, 2 * N - 1);
+      acc[r] = bias[rows[r]];
+    }
+    dotn_m<MK8, NK8, ROWS, NRZ>(rs, w_off, u_off, rows, in_img, st_img, toff, acc);
+#pragma unroll
+    for (int r = 0; r < NRZ; ++r) {
+      const int row = lane + WAVE * r;
+      const float s = sigmoid_approx(S * acc[r], tansig);
+      if (row < 2 * N) {
+        if (row < N) zbuf[row] = s;
+        else split_store(st_img, row - N, state[row - N] * s);
+      }
+    }
+  }
+  __syncthreads();
+  {
+    int rows[NRC];
+    float acc[NRC];
+#pragma unroll
+    for (int r = 0; r < NRC; ++r) {
+      rows[r] = 2 * N + min(lane + WAVE * r, N - 1);
+      acc[r] = bias[rows[r]];
+    }
+    dotn_m<MK8, NK8, ROWS, NRC>(rs, w_off, u_off, rows, in_img, st_img, toff, acc);
+#pragma unroll
+    for (int r = 0; r < NRC; ++r) {
+      const int i = lane + WAVE * r;
+      if (i < N) {
+        float c = S * acc[r];
+        c = c < 0.f ? 0.f : c;
+        const float z = zbuf[i];
+        state[i] = z * state[i] + (1.f - z) * c;
+      }
+    }
+  }
+  __syncthreads();
+}
+
 template <int M, int N>
 __device__ __forceinline__ void gru_layer(__amdgpu_buffer_rsrc_t rs, int w_off, int u_off,
                                           const float* __restrict__ bias, const float* in_vec,
@@ -577,6 +744,9 @@ static_assert(sizeof(RnLdsT<0>) <= 10240, "16 workgroups per CU need <= 10 KB of
 
 // offsets (floats) inside Bb while it serves the RNN
 constexpr int RB_FEAT = 0, RB_DENSE = 48, RB_IN = 72, RB_Z = 192, RB_HR = 288, RB_PART = 384;
+// RB_IMG: two split f16 activation images (3 terms x RN_IMG_LD halves each = 2 x 204 floats) of the MFMA gain
+// network; shares the floats of RB_PART, which is only used after the network
+constexpr int RB_IMG = 384;
 // offsets inside U outside band_sums
 constexpr int U_LY = 0, U_G = 48, U_R = 72, U_VAD = 96;
 
@@ -1291,6 +1461,53 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
       float* gin = Rb + RB_IN;
       TansigTab tansig;
       tansig.load(tab->tansig, lane);
+#if RN_GRU_MFMA
+      // split f16 images of the layer inputs (in_img) and of the recurrent operand (st_img) behind the f32 vectors
+      _Float16* in_img = reinterpret_cast<_Float16*>(Rb + RB_IMG);
+      _Float16* st_img = in_img + 3 * RN_IMG_LD;
+      const int toff = min(lane & 3, 2) * (RN_IMG_LD * 2);
+      if (lane < 48) split_store(in_img, lane, feat[lane]);          // feat[42..47] = 0
+      __syncthreads();
+      {
+        const int row = min(lane, 23);
+        const float acc = dot_m<rn_k8(42), 24>(wrs, RnPack::ID_W, row, in_img, toff, wpf[RnPack::ID_B + row]);
+        const float d = tansig_approx(S * acc, tansig);
+        if (lane < 24) { dense[lane] = d; split_store(in_img, lane, d); }
+      }
+      __syncthreads();
+      gru_layer_m<24, 24>(wrs, RnPack::VG_W, RnPack::VG_R, wpf + RnPack::VG_B, in_img,
+                          L.rnn_state, Rb + RB_Z, st_img, toff, tansig, lane);
+      {
+        float acc = 0.f;
+        if (lane == 0) {
+          acc = wpf[RnPack::VO_B];
+          acc = dot_h<rn_k8(24), 1>(wrs, RnPack::VO_W, 0, L.rnn_state, acc);
+        }
+        const float v = sigmoid_approx(S * acc, tansig);
+        if (lane == 0) L.U[U_VAD] = v;
+      }
+      for (int i = lane; i < 96; i += WAVE)
+        split_store(in_img, i, i < 24 ? dense[i] : (i < 48 ? L.rnn_state[i - 24] : (i < 90 ? feat[i - 48] : 0.f)));
+      __syncthreads();
+      vad_prob = L.U[U_VAD];
+      STAMP(10)
+      gru_layer_m<90, 48>(wrs, RnPack::NG_W, RnPack::NG_R, wpf + RnPack::NG_B, in_img,
+                          L.rnn_state + 24, Rb + RB_Z, st_img, toff, tansig, lane);
+      STAMP(11)
+      for (int i = lane; i < 120; i += WAVE)
+        split_store(in_img, i, i < 72 ? L.rnn_state[i] : (i < 114 ? feat[i - 72] : 0.f));
+      __syncthreads();
+      gru_layer_m<114, 96>(wrs, RnPack::DG_W, RnPack::DG_R, wpf + RnPack::DG_B, in_img,
+                           L.rnn_state + 72, Rb + RB_Z, st_img, toff, tansig, lane);
+      for (int i = lane; i < 96; i += WAVE) split_store(st_img, i, L.rnn_state[72 + i]);
+      __syncthreads();
+      {
+        const int row = min(lane, RN_NB - 1);
+        const float acc = dot_m<rn_k8(96), RN_NB>(wrs, RnPack::DO_W, row, st_img, toff, wpf[RnPack::DO_B + row]);
+        const float gv = sigmoid_approx(S * acc, tansig);
+        if (lane < RN_NB) L.U[U_G + lane] = gv;
+      }
+#else
       {
         float acc = 0.f;
         if (lane < 24) {
@@ -1334,6 +1551,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
         const float gv = sigmoid_approx(S * acc, tansig);
         if (lane < RN_NB) L.U[U_G + lane] = gv;
       }
+#endif
       __syncthreads();
       STAMP(12)
       }  // MODE == 0

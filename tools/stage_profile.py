@@ -4,7 +4,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from crispy_amd import _native as N
-N.LIB_PATH = os.path.join(os.path.dirname(N.LIB_PATH), "libcrispy_hip_prof.so")
+N.LIB_PATH = os.environ.get("PROF_LIB") or os.path.join(os.path.dirname(N.LIB_PATH), "libcrispy_hip_prof.so")
 from crispy_amd import synthetic_weights, synth_audio
 from crispy_amd.denoise import DenoiseState
 B = int(os.environ.get("B", 1024)); T = int(os.environ.get("T", 50))
