@@ -88,6 +88,18 @@ void pack_matrix(uint32_t* dst, const int8_t* src, int K, int rows, int stride) 
       }
 }
 
+// [K][rows] int8 -> int8 [ceil(K/16)][rows][16] (zero padded in K); dst in 16-byte units
+void pack_matrix8(uint32_t* dst, const int8_t* src, int K, int rows, int stride) {
+  const int k16n = (K + 15) / 16;
+  int8_t* b = reinterpret_cast<int8_t*>(dst);
+  for (int k16 = 0; k16 < k16n; ++k16)
+    for (int r = 0; r < rows; ++r)
+      for (int q = 0; q < 16; ++q) {
+        const int k = 16 * k16 + q;
+        b[((size_t)k16 * rows + r) * 16 + q] = k < K ? src[(size_t)k * stride + r] : 0;
+      }
+}
+
 void pack_bias(uint32_t* dst, const int8_t* src, int n) {
   for (int i = 0; i < n; ++i) {
     const float f = (float)src[i];
@@ -96,7 +108,7 @@ void pack_bias(uint32_t* dst, const int8_t* src, int n) {
 }
 
 void pack_weights(std::vector<uint32_t>& out, const int8_t* w) {
-  out.assign(RnPack::END, 0);
+  out.assign(RnPack8::END, 0);
   uint32_t* p = out.data();
   pack_matrix(p + 4 * RnPack::ID_W, w + RnBlob::ID_W, 42, 24, 24);
   pack_matrix(p + 4 * RnPack::VG_W, w + RnBlob::VG_W, 24, 72, 72);
@@ -113,6 +125,14 @@ void pack_weights(std::vector<uint32_t>& out, const int8_t* w) {
   pack_bias(p + RnPack::NG_B, w + RnBlob::NG_B, 144);
   pack_bias(p + RnPack::DG_B, w + RnBlob::DG_B, 288);
   pack_bias(p + RnPack::DO_B, w + RnBlob::DO_B, 22);
+  pack_matrix8(p + 4 * RnPack8::ID_W, w + RnBlob::ID_W, 42, 24, 24);
+  pack_matrix8(p + 4 * RnPack8::VG_W, w + RnBlob::VG_W, 24, 72, 72);
+  pack_matrix8(p + 4 * RnPack8::VG_R, w + RnBlob::VG_R, 24, 72, 72);
+  pack_matrix8(p + 4 * RnPack8::NG_W, w + RnBlob::NG_W, 90, 144, 144);
+  pack_matrix8(p + 4 * RnPack8::NG_R, w + RnBlob::NG_R, 48, 144, 144);
+  pack_matrix8(p + 4 * RnPack8::DG_W, w + RnBlob::DG_W, 114, 288, 288);
+  pack_matrix8(p + 4 * RnPack8::DG_R, w + RnBlob::DG_R, 96, 288, 288);
+  pack_matrix8(p + 4 * RnPack8::DO_W, w + RnBlob::DO_W, 96, 22, 22);
 }
 
 
@@ -296,7 +316,7 @@ int crispy_rn_create(const int8_t* weights, size_t nbytes, int n_streams, int de
     HIP_TRY(hipEventCreateWithFlags(&h->ev_begin, hipEventDisableTiming));
     const size_t B = (size_t)n_streams;
     HIP_TRY(hipMalloc(&h->d_tab, sizeof(RnTables)));
-    HIP_TRY(hipMalloc(&h->d_wpack, sizeof(uint32_t) * RnPack::END));
+    HIP_TRY(hipMalloc(&h->d_wpack, sizeof(uint32_t) * RnPack8::END));
     HIP_TRY(hipMalloc(&h->d_hp_mem, B * 2 * sizeof(float)));
     HIP_TRY(hipMalloc(&h->d_synth, B * 480 * sizeof(float)));
     HIP_TRY(hipMalloc(&h->d_ceps, B * 176 * sizeof(float)));

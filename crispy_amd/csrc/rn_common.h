@@ -67,6 +67,24 @@ struct RnPack {
   static constexpr int END = DO_B + 22;                        // total size in dwords
 };
 
+// Second copy of the matrices for the int8 MFMA form of the gain network (rn_kernels.hip, RN_GRU_MFMA == 2):
+// the int8 values as they are, [ceil(K/16)][rows][16] -- lane == row reads one 16-byte vector per 16 MACs, half
+// the bytes of the f16 pack through the CU's vector L1, which is what bounds that stage.  Appended to the same
+// buffer; offsets in 16-byte units from the pack base.
+constexpr int rn_k16(int k) { return (k + 15) / 16; }
+struct RnPack8 {
+  static constexpr int ID_W = (RnPack::END + 3) / 4;             // K=42  rows=24
+  static constexpr int VG_W = ID_W + rn_k16(42) * 24;            // K=24  rows=72
+  static constexpr int VG_R = VG_W + rn_k16(24) * 72;            // K=24  rows=72
+  static constexpr int NG_W = VG_R + rn_k16(24) * 72;            // K=90  rows=144
+  static constexpr int NG_R = NG_W + rn_k16(90) * 144;           // K=48  rows=144
+  static constexpr int DG_W = NG_R + rn_k16(48) * 144;           // K=114 rows=288
+  static constexpr int DG_R = DG_W + rn_k16(114) * 288;          // K=96  rows=288
+  static constexpr int DO_W = DG_R + rn_k16(96) * 288;           // K=96  rows=22
+  static constexpr int MAT_END = DO_W + rn_k16(96) * 22;         // 16-byte units
+  static constexpr int END = MAT_END * 4;                        // total size of the buffer in dwords
+};
+
 // Kernel arguments of one enqueue (chunk of T frames for all B streams).
 struct RnArgs {
   // audio

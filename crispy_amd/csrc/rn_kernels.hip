@@ -392,6 +392,17 @@ __device__ __forceinline__ float sigmoid_approx(float x, const TansigTab& table)
 }
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+#ifndef RN_GRU_MFMA
+#define RN_GRU_MFMA 2   // 1: the gain network's matrix-vector products on v_mfma_f32_4x4x4_16B_f16; 2: on
+                        // v_mfma_i32_4x4x4_16B_i8 with int8 weights in memory (both below); 0: v_fma_mix_f32
+#endif
+// 16-byte weight loads per row in flight ahead of their use, for 3 / 2 / 1 rows per lane: the largest that keep
+// the frame loop free of spill stores (tests/test_build_resources.py)
+#ifndef RN_BLK3
+#define RN_BLK3 1
+#define RN_BLK2 (RN_GRU_MFMA == 2 ? 1 : 2)
+#define RN_BLK1 4
+#endif
 
 // acc[r] += sum_k W[k][row[r]] * xa[k] + sum_k U[k][row[r]] * xb[k].  Weights: f16 [K8][rows][8] (16 bytes per lane
 // per 8 MACs, each MAC one v_fma_mix_f32); xa / xb live in LDS, 16-byte aligned, zero padded to 8*K8.
@@ -418,11 +429,6 @@ template <int MK8, int NK8, int ROWS, int NR>
 __device__ __forceinline__ void dotn_h(__amdgpu_buffer_rsrc_t rs, int w_off, int u_off, const int (&row)[NR],
                                        const float* xa, const float* xb, float (&acc)[NR]) {
   constexpr int K8 = MK8 + NK8;
-#ifndef RN_BLK3
-#define RN_BLK3 1
-#define RN_BLK2 2
-#define RN_BLK1 4
-#endif
   constexpr int BLK = NR >= 3 ? RN_BLK3 : (NR == 2 ? RN_BLK2 : RN_BLK1);
   constexpr int NBLK = (K8 + BLK - 1) / BLK;
   int row16[NR];
@@ -499,9 +505,6 @@ __device__ __forceinline__ float dot_h(__amdgpu_buffer_rsrc_t rs, int w_off, int
   return acc[0];
 }
 
-#ifndef RN_GRU_MFMA
-#define RN_GRU_MFMA 1   // 1: the gain network's matrix-vector products run on v_mfma_f32_4x4x4_16B_f16 (below)
-#endif
 // ---- the same products on the matrix pipe, still one wave per stream and lane = output row ----
 // v_mfma_f32_4x4x4_16B_f16 is 16 independent 4x4x4 blocks; block b lives in lanes 4b..4b+3.  Its "A" rows carry the
 // activation vector split into three f16 terms (x = hi + lo + lo2 exactly: 3 x 11 significand bits), the same in every
@@ -611,6 +614,215 @@ __device__ __forceinline__ float dot_m(__amdgpu_buffer_rsrc_t rs, int w_off, int
 
 // One GRU layer (ReLU candidate).  in_vec[M] and state[N] in LDS, zero padded to multiples of 8;
 // zbuf / hr: N floats of scratch each.  w_off / u_off: 16-byte offsets of the two matrices in the weight pack.
+// ---- int8 form (RN_GRU_MFMA == 2) ----
+// The stage is bound by the weight stream through the CU's vector L1 (16 waves x 176 KB of f16 per frame = 71 B per
+// clock against 64), not by arithmetic, so the weights stay int8 in memory (RnPack8: 16 MACs per 16-byte load) and
+// the activations become *fixed point*: per vector one power-of-two scale 2^s with max|x| 2^s <= 2^30, q = rint(x 2^s),
+// and q's four signed base-256 digits ((q + 0x00808080) ^ 0x00808080, byte t = digit t) are the four "A" rows of
+// v_mfma_i32_4x4x4_16B_i8.  Register t of lane == row then holds sum_k digit_t(x_k) W[k][row] exactly (int32), and
+// sum_t 256^t 2^-s (float)D_t is the dot product to 2^-30 of the largest activation -- finer than the rounding of an
+// f32 accumulation of the same length.  The input part and the recurrent part of a GRU row have different scales,
+// so the accumulators are folded into the float result where the k loop crosses from one to the other.
+typedef int rn_i4 __attribute__((ext_vector_type(4)));
+constexpr int RN_IMG8_LD = 144;   // bytes per digit image (K <= 128), +16: the four 16-byte reads hit distinct banks
+__device__ __forceinline__ float wave_max(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  v = fmaxf(v, dpp_mov<0x140>(v));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 15)));   // rows 0..3 hold their own max
+  float m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+  m = fmaxf(m, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16)));
+  m = fmaxf(m, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)));
+  m = fmaxf(m, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48)));
+  return m;
+}
+// scale pair of a vector whose largest magnitude is m (wave-uniform): up = 2^s, dn = 2^-s
+struct RnScale { float up, dn; };
+__device__ __forceinline__ RnScale scale_of(float m) {
+  int eb = (__float_as_int(m) >> 23) & 0xff;       // m < 2^(eb - 126)
+  eb = min(max(eb, 64), 250);
+  RnScale r;
+  r.up = __int_as_float((283 - eb) << 23);         // 2^(30 - (eb - 126))
+  r.dn = __int_as_float((eb - 29) << 23);
+  return r;
+}
+__device__ __forceinline__ void digits_store(signed char* img, int i, float v, float up) {
+  const int q = __float2int_rn(v * up);
+  const unsigned r = ((unsigned)q + 0x00808080u) ^ 0x00808080u;
+  img[i] = (signed char)(r & 0xff);
+  img[RN_IMG8_LD + i] = (signed char)((r >> 8) & 0xff);
+  img[2 * RN_IMG8_LD + i] = (signed char)((r >> 16) & 0xff);
+  img[3 * RN_IMG8_LD + i] = (signed char)(r >> 24);
+}
+// image of the NPAD-long vector f(0..NPAD-1) (NPAD <= 128, a multiple of 16; f returns 0 in the padding)
+template <int NPAD, class F>
+__device__ __forceinline__ RnScale image_i8(signed char* img, int lane, F f) {
+  constexpr int NT = (NPAD + WAVE - 1) / WAVE;
+  float v[NT];
+  float m = 0.f;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int i = lane + WAVE * j;
+    v[j] = i < NPAD ? f(min(i, NPAD - 1)) : 0.f;
+    m = fmaxf(m, fabsf(v[j]));
+  }
+  const RnScale sc = scale_of(wave_max(m));
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int i = lane + WAVE * j;
+    if (i < NPAD) digits_store(img, i, v[j], sc.up);
+  }
+  return sc;
+}
+__device__ __forceinline__ rn_u4 wload8(__amdgpu_buffer_rsrc_t rs, int row16, int off16) {
+  return __builtin_amdgcn_raw_buffer_load_b128(rs, row16, off16 * 16, 0);
+}
+// acc[r] += sa sum_k W[k][row[r]] qa[k] + sb sum_k U[k][row[r]] qb[k]; toff = (lane & 3) * RN_IMG8_LD
+template <int MK16, int NK16, int ROWS, int NR>
+__device__ __forceinline__ void dotn_i(__amdgpu_buffer_rsrc_t rs, int w_off, int u_off, const int (&row)[NR],
+                                       const signed char* xa, const signed char* xb, int toff, float sa, float sb,
+                                       float (&acc)[NR]) {
+  constexpr int K16 = MK16 + NK16;
+  constexpr int BLK = NR >= 3 ? RN_BLK3 : (NR == 2 ? RN_BLK2 : RN_BLK1);
+  constexpr int NBLK = (K16 + BLK - 1) / BLK;
+  constexpr int NC = NR >= 3 ? 1 : 2;
+  int row16[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) row16[r] = row[r] * 16;
+  asm volatile("" : "+v"(toff));
+  const rn_u4* xa4 = reinterpret_cast<const rn_u4*>(xa + toff);
+  const rn_u4* xb4 = reinterpret_cast<const rn_u4*>(xb + toff);
+  rn_u4 w[2][BLK][NR];
+  rn_u4 xc = MK16 > 0 ? xa4[0] : xb4[0], xn = xc;
+#pragma unroll
+  for (int q = 0; q < BLK; ++q)
+    if (q < K16) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+        w[0][q][r] = wload8(rs, row16[r], q < MK16 ? w_off + q * ROWS : u_off + (q - MK16) * ROWS);
+    }
+  rn_i4 a4[NR][NC];
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) a4[r][c] = rn_i4{0, 0, 0, 0};
+  auto fold = [&](float s) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      rn_i4 d = a4[r][0];
+      if (NC == 2) d += a4[r][1];
+      float f = (float)d[0] * s;
+      f = fmaf((float)d[1], s * 256.f, f);
+      f = fmaf((float)d[2], s * 65536.f, f);
+      f = fmaf((float)d[3], s * 16777216.f, f);
+      acc[r] += f;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) a4[r][c] = rn_i4{0, 0, 0, 0};
+    }
+  };
+#pragma unroll
+  for (int blk = 0; blk < NBLK; ++blk) {
+    if (blk + 1 < NBLK) {
+#pragma unroll
+      for (int q = 0; q < BLK; ++q) {
+        const int k = (blk + 1) * BLK + q;
+        if (k < K16) {
+#pragma unroll
+          for (int r = 0; r < NR; ++r)
+            w[(blk + 1) & 1][q][r] = wload8(rs, row16[r], k < MK16 ? w_off + k * ROWS : u_off + (k - MK16) * ROWS);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < BLK; ++q) {
+      const int k = blk * BLK + q;
+      if (k < K16) {
+        if (k + 1 < K16) xn = k + 1 < MK16 ? xa4[k + 1] : xb4[k + 1 - MK16];
+        if (MK16 > 0 && NK16 > 0 && k == MK16) fold(sa);
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+          for (int c = 0; c < NC; ++c) asm volatile("" : "+v"(a4[r][c]));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+          for (int r = 0; r < NR; ++r)
+            a4[r][e % NC] = __builtin_amdgcn_mfma_i32_4x4x4i8((int)xc[e], (int)w[blk & 1][q][r][e], a4[r][e % NC], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        xc = xn;
+      }
+    }
+  }
+  fold(NK16 > 0 ? sb : sa);
+}
+template <int K16, int ROWS>
+__device__ __forceinline__ float dot_i(__amdgpu_buffer_rsrc_t rs, int w_off, int row, const signed char* x, int toff,
+                                       float s, float acc0) {
+  const int rows[1] = {row};
+  float acc[1] = {acc0};
+  dotn_i<K16, 0, ROWS, 1>(rs, w_off, w_off, rows, x, x, toff, s, s, acc);
+  return acc[0];
+}
+// in_img / sin: digit image and 2^-s of the layer input (caller); st_img: the state's image, then h*r's at the same
+// scale (|h r| <= |h|).
+template <int M, int N>
+__device__ __forceinline__ void gru_layer_i(__amdgpu_buffer_rsrc_t rs, int w_off, int u_off,
+                                            const float* __restrict__ bias, const signed char* in_img, float sin,
+                                            float* state, float* zbuf, signed char* st_img, int toff,
+                                            const TansigTab& tansig, int lane) {
+  constexpr int ROWS = 3 * N;
+  constexpr int MK16 = (M + 15) / 16, NK16 = (N + 15) / 16;
+  constexpr int NRZ = (2 * N + WAVE - 1) / WAVE, NRC = (N + WAVE - 1) / WAVE;
+  const float S = 1.f / 256.f;
+  const RnScale sst = image_i8<NK16 * 16>(st_img, lane, [&](int i) { return i < N ? state[min(i, N - 1)] : 0.f; });
+  __syncthreads();
+  {
+    int rows[NRZ];
+    float acc[NRZ];
+#pragma unroll
+    for (int r = 0; r < NRZ; ++r) {
+      rows[r] = min(lane + WAVE * r, 2 * N - 1);
+      acc[r] = bias[rows[r]];
+    }
+    dotn_i<MK16, NK16, ROWS, NRZ>(rs, w_off, u_off, rows, in_img, st_img, toff, sin, sst.dn, acc);
+#pragma unroll
+    for (int r = 0; r < NRZ; ++r) {
+      const int row = lane + WAVE * r;
+      const float s = sigmoid_approx(S * acc[r], tansig);
+      if (row < 2 * N) {
+        if (row < N) zbuf[row] = s;
+        else digits_store(st_img, row - N, state[row - N] * s, sst.up);
+      }
+    }
+  }
+  __syncthreads();
+  {
+    int rows[NRC];
+    float acc[NRC];
+#pragma unroll
+    for (int r = 0; r < NRC; ++r) {
+      rows[r] = 2 * N + min(lane + WAVE * r, N - 1);
+      acc[r] = bias[rows[r]];
+    }
+    dotn_i<MK16, NK16, ROWS, NRC>(rs, w_off, u_off, rows, in_img, st_img, toff, sin, sst.dn, acc);
+#pragma unroll
+    for (int r = 0; r < NRC; ++r) {
+      const int i = lane + WAVE * r;
+      if (i < N) {
+        float c = S * acc[r];
+        c = c < 0.f ? 0.f : c;
+        const float z = zbuf[i];
+        state[i] = z * state[i] + (1.f - z) * c;
+      }
+    }
+  }
+  __syncthreads();
+}
+
 // MFMA form: in_img holds the split image of the layer input (caller), st_img receives the split image of the
 // state (gates pass) and then of h*r (candidate pass); zbuf as in the VALU form.  Every lane runs every MFMA (the
 // matrix pipe ignores nothing a predicate could express: rows are clamped, results are predicated).
@@ -892,7 +1104,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
     const RnTables* tabv = (const RnTables*)tabg;
     const uint32_t* wpraw = (const uint32_t*)wpg;
     // buffer resource over the weight pack (f16 matrices first, f32 biases behind them)
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(wpraw), 0, RnPack::END * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(wpraw), 0, RnPack8::END * 4, 0x00020000);
     const RnTables* __restrict__ tab = tabv;
     const float2* __restrict__ w960 = tab->w960;
     const float* __restrict__ hw = tab->half_window;
@@ -1461,7 +1673,53 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
       float* gin = Rb + RB_IN;
       TansigTab tansig;
       tansig.load(tab->tansig, lane);
-#if RN_GRU_MFMA
+#if RN_GRU_MFMA == 2
+      // signed-digit int8 images of the layer inputs (in_img) and of the recurrent operand (st_img)
+      signed char* in_img = reinterpret_cast<signed char*>(Rb + RB_IMG);
+      signed char* st_img = in_img + 4 * RN_IMG8_LD;
+      const int toff = (lane & 3) * RN_IMG8_LD;
+      RnScale sc = image_i8<48>(in_img, lane, [&](int i) { return feat[i]; });            // feat[42..47] = 0
+      __syncthreads();
+      {
+        const int row = min(lane, 23);
+        const float acc = dot_i<rn_k16(42), 24>(wrs, RnPack8::ID_W, row, in_img, toff, sc.dn, wpf[RnPack::ID_B + row]);
+        const float d = tansig_approx(S * acc, tansig);
+        if (lane < 24) dense[lane] = d;
+      }
+      __syncthreads();
+      sc = image_i8<32>(in_img, lane, [&](int i) { return i < 24 ? dense[i] : 0.f; });
+      gru_layer_i<24, 24>(wrs, RnPack8::VG_W, RnPack8::VG_R, wpf + RnPack::VG_B, in_img, sc.dn,
+                          L.rnn_state, Rb + RB_Z, st_img, toff, tansig, lane);
+      {
+        float acc = 0.f;
+        if (lane == 0) {
+          acc = wpf[RnPack::VO_B];
+          acc = dot_h<rn_k8(24), 1>(wrs, RnPack::VO_W, 0, L.rnn_state, acc);
+        }
+        const float v = sigmoid_approx(S * acc, tansig);
+        if (lane == 0) L.U[U_VAD] = v;
+      }
+      sc = image_i8<96>(in_img, lane, [&](int i) {
+        return i < 24 ? dense[i] : (i < 48 ? L.rnn_state[i - 24] : (i < 90 ? feat[i - 48] : 0.f)); });
+      __syncthreads();
+      vad_prob = L.U[U_VAD];
+      STAMP(10)
+      gru_layer_i<90, 48>(wrs, RnPack8::NG_W, RnPack8::NG_R, wpf + RnPack::NG_B, in_img, sc.dn,
+                          L.rnn_state + 24, Rb + RB_Z, st_img, toff, tansig, lane);
+      STAMP(11)
+      sc = image_i8<128>(in_img, lane, [&](int i) { return i < 72 ? L.rnn_state[i] : (i < 114 ? feat[i - 72] : 0.f); });
+      __syncthreads();
+      gru_layer_i<114, 96>(wrs, RnPack8::DG_W, RnPack8::DG_R, wpf + RnPack::DG_B, in_img, sc.dn,
+                           L.rnn_state + 72, Rb + RB_Z, st_img, toff, tansig, lane);
+      sc = image_i8<96>(st_img, lane, [&](int i) { return L.rnn_state[72 + i]; });
+      __syncthreads();
+      {
+        const int row = min(lane, RN_NB - 1);
+        const float acc = dot_i<rn_k16(96), RN_NB>(wrs, RnPack8::DO_W, row, st_img, toff, sc.dn, wpf[RnPack::DO_B + row]);
+        const float gv = sigmoid_approx(S * acc, tansig);
+        if (lane < RN_NB) L.U[U_G + lane] = gv;
+      }
+#elif RN_GRU_MFMA == 1
       // split f16 images of the layer inputs (in_img) and of the recurrent operand (st_img) behind the f32 vectors
       _Float16* in_img = reinterpret_cast<_Float16*>(Rb + RB_IMG);
       _Float16* st_img = in_img + 3 * RN_IMG_LD;
