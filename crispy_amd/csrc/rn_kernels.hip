@@ -392,6 +392,14 @@ __device__ __forceinline__ float sigmoid_approx(float x, const TansigTab& table)
 }
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+// After the lane id has been laundered its range is unknown, every `table[lane + 64 k]` index is sign-extended and
+// the load takes a 64-bit VGPR address (ashr + 64-bit shift-add per load).  Stating the range lets the sign extension
+// fold away: SGPR base + 32-bit lane offset + immediate.  RN_LANE_RANGE_MASK selects the laundering sites it is
+// stated at (register allocation differs per site; the frame loop must stay free of spill stores).
+#ifndef RN_LANE_RANGE_MASK
+#define RN_LANE_RANGE_MASK 255
+#endif
+#define RN_LANE_RANGE(site) do { if ((RN_LANE_RANGE_MASK >> (site)) & 1) __builtin_assume((unsigned)lane < (unsigned)WAVE); } while (0)
 #ifndef RN_GRU_MFMA
 #define RN_GRU_MFMA 2   // 1: the gain network's matrix-vector products on v_mfma_f32_4x4x4_16B_f16; 2: on
                         // v_mfma_i32_4x4x4_16B_i8 with int8 weights in memory (both below); 0: v_fma_mix_f32
@@ -1093,6 +1101,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
     // loop into registers (429 VGPR+AGPR, one wave per SIMD).  Opaque values keep them per-frame.
     lane = lane0;
     asm volatile("" : "+v"(lane));
+    RN_LANE_RANGE(0);
     // The laundered values are typed as address-space-1 pointers: laundering a generic pointer hides that it is
     // global, and every table / weight access then becomes a FLAT load (counts on lgkmcnt too, so it serialises
     // with the LDS traffic, and cannot use the SGPR-base + lane-offset form).
@@ -1217,6 +1226,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
       __syncthreads();
     }
     STAMP(0)
+    lane = lane0;
+    asm volatile("" : "+v"(lane));
+    RN_LANE_RANGE(4);
 
     // ---- 2. pitch_search: 4x-decimated coarse search over 147 lags (scratch in A) ----
     float* x4 = Sa;        // 240
@@ -1486,6 +1498,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
     }
     __syncthreads();
     STAMP(4)
+    lane = lane0;
+    asm volatile("" : "+v"(lane));
+    RN_LANE_RANGE(5);
 
     // ---- 5. frame_analysis: window, 960-point real FFT (in A), band energies (partials in Bb) ----
     // complex point n = (x[2n], x[2n+1]) times the window; points >= 240 sit in the mirrored half of the window
@@ -1500,6 +1515,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
     STAMP(5)
     band_pairs<false>(L.A, nullptr, Rb, L.Ex, nullptr, nullptr, tab, be, lane);
     STAMP(6)
+    lane = lane0;
+    asm volatile("" : "+v"(lane));
+    RN_LANE_RANGE(6);
     if (a.dbg && t == a.T - 1) {
       float* D = a.dbg + (long)b * RN_DBG_FLOATS;
       for (int i = lane; i < 962; i += WAVE) D[0 + i] = Xf[i];
@@ -1528,6 +1546,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
     }
     __syncthreads();
     STAMP(8)
+    lane = lane0;
+    asm volatile("" : "+v"(lane));
+    RN_LANE_RANGE(7);
 
     // ---- 7. features (Appendix A.3 step 5) ----
     // this lane's column of the DCT table serves both transforms; issued first so that the L2 round trip
@@ -1665,6 +1686,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
       if constexpr (MODE == 0) {
       lane = lane0;
       asm volatile("" : "+v"(lane));   // (lane re-laundered: per-lane addresses of later stages are otherwise computed early / shared with earlier
+      RN_LANE_RANGE(1);
       // stages and stay live across the gain network, which is where registers are scarcest)
       // ---- 8. RNN (vectors in Bb) ----
       const float S = 1.f / 256.f;
@@ -1816,6 +1838,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
 
       lane = lane0;
       asm volatile("" : "+v"(lane));
+      RN_LANE_RANGE(2);
       // ---- 9. pitch_filter + gain application (Appendix A.3 step 7) ----
       // Pair layout: lane handles bins (2p, 2p+1), p = lane + 64 m -- one ds_read_b128 / one 16-byte global load
       // per pair at a 16-byte lane stride (conflict-free, coalesced), and a pair never straddles a band (edges are
@@ -1924,6 +1947,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
 
     lane = lane0;
     asm volatile("" : "+v"(lane));
+    RN_LANE_RANGE(3);
     // ---- 10. frame_synthesis: inverse FFT, window, overlap-add ----
     real_inv_pre(L.A, w960, lane);
     if constexpr (!TAIL_REGS) {
