@@ -45,6 +45,31 @@ def test_golden_vectors(case):
     assert np.abs(vad[:, 0] - G[f"{case}/vad"]).max() < 1e-4
 
 
+def test_level_extremes_through_the_fixed_point_gain_network(oracle, weights0):
+    """The gain network runs on int8 MFMAs with the activations as per-vector fixed point (rn_kernels.hip,
+    RN_GRU_MFMA == 2): streams at full scale (clipping square wave, +-32768 noise), with a large DC offset, at
+    1e-3 of full scale and a loud burst after near-silence must all stay inside the PCM tolerance."""
+    rng = np.random.default_rng(7)
+    T = 40
+    n = T * 480
+    t = np.arange(n) / 48000.0
+    sig = [
+        32767.0 * np.sign(np.sin(2 * np.pi * 173.0 * t)),                       # clipping square wave
+        rng.uniform(-32768, 32767, n),                                          # full-scale noise
+        20000.0 + 3000.0 * np.sin(2 * np.pi * 220.0 * t) + 500 * rng.standard_normal(n),   # DC offset
+        30.0 * np.sin(2 * np.pi * 300.0 * t) + 5.0 * rng.standard_normal(n),    # 1e-3 of full scale
+        np.where(t < 0.2, 0.5 * rng.standard_normal(n), 25000.0 * np.sin(2 * np.pi * 140.0 * t)),  # burst
+    ]
+    x = np.stack(sig, axis=0).astype(np.float32).reshape(len(sig), T, 480).transpose(1, 0, 2).copy()
+    ds = _mk(weights0, len(sig))
+    out, vad = ds.process(x)
+    assert np.isfinite(out).all()
+    for b in range(len(sig)):
+        ref, rvad = oracle.OracleDenoiseState(weights0).process(x[:, b])
+        _assert_pcm_close(out[:, b], ref, f"level case {b}")
+        assert np.abs(vad[:, b] - rvad).max() < 1e-4, b
+
+
 def test_parity_mixed_batch_with_taps(oracle, weights0):
     """12 different streams x 60 frames incl. a silent stream and the cfg-1 clip: PCM, VAD, features,
     gains and pitch against the oracle."""
