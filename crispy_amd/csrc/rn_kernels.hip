@@ -126,6 +126,38 @@ __device__ __forceinline__ void butterfly<8>(const float2 (&v)[8], float2 (&o)[8
   o[3] = cadd(e[3], t3); o[7] = csub(e[3], t3);
 }
 
+// Where element i of the Stockham sequence lives between two passes.  In natural order the stores of the first two
+// passes collide: a store is serviced in groups of 16 lanes over 32 banks, and `buf[4 j + r]` (radix 4, stride 1) puts
+// lanes j and j + 4, `buf[32 (j / 4) + (j % 4) + 4 r]` (radix 8, stride 4) all lanes with equal j % 4, on one bank
+// -- 4-way, 16 LDS cycles per store instead of 4.  Both hand-offs are private to two passes, so they use layouts
+// in which the store *and* the matching load are conflict-free (RN_FFT_SWIZZLE=0: natural order):
+//   pass 1 -> 2: element i at (i % 4) * 120 + i / 4  (the store becomes r * 120 + j: consecutive lanes; the load of
+//                butterfly j reads (j % 4) * 120 + j / 4 + 15 r: four 16-bank windows 0 / 48 / 32 / 16 apart)
+//   pass 2 -> 3: element i = 32 a + 4 r + m at i ^ ((a & 3) << 2): the four a of a 16-lane group spread over the
+//                four bank quarters; a 32-aligned run of the radix-3 load stays a permutation of one 32-block
+#ifndef RN_FFT_SWIZZLE
+#define RN_FFT_SWIZZLE 1
+#endif
+template <int R, int NS>
+__device__ __forceinline__ int fft_rd(int j, int r) {
+  constexpr int M = 480 / R;
+  if (RN_FFT_SWIZZLE && R == 8 && NS == 4) return (j & 3) * 120 + (j >> 2) + 15 * r;
+  if (RN_FFT_SWIZZLE && R == 3 && NS == 32) {
+    const int i = j + r * M;
+    return i ^ (((i >> 5) & 3) << 2);
+  }
+  return j + r * M;
+}
+template <int R, int NS>
+__device__ __forceinline__ int fft_wr(int j, int r) {
+  if (RN_FFT_SWIZZLE && R == 4 && NS == 1) return r * 120 + j;
+  if (RN_FFT_SWIZZLE && R == 8 && NS == 4) {
+    const int a = j >> 2, m = j & 3;
+    return 32 * a + m + 4 * (r ^ (a & 3));
+  }
+  const int k = j % NS;
+  return (j / NS) * NS * R + k + r * NS;
+}
 template <int R, int NS>
 __device__ __forceinline__ void fft_pass(float2* buf, const float2* __restrict__ w960, int lane) {
   constexpr int M = 480 / R;
@@ -148,7 +180,7 @@ __device__ __forceinline__ void fft_pass(float2* buf, const float2* __restrict__
       float2 v[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        float2 x = buf[j + r * M];
+        float2 x = buf[fft_rd<R, NS>(j, r)];
         if (NS > 1 && r > 0) x = cmul(x, tw[nb][r]);
         v[r] = x;
       }
@@ -160,10 +192,8 @@ __device__ __forceinline__ void fft_pass(float2* buf, const float2* __restrict__
   for (int nb = 0; nb < NBF; ++nb) {
     const int j = lane + WAVE * nb;
     if (j < M) {
-      const int k = j % NS;
-      const int j0 = (j / NS) * NS * R + k;
 #pragma unroll
-      for (int r = 0; r < R; ++r) buf[j0 + r * NS] = o[nb][r];
+      for (int r = 0; r < R; ++r) buf[fft_wr<R, NS>(j, r)] = o[nb][r];
     }
   }
   __syncthreads();
@@ -199,7 +229,7 @@ __device__ __forceinline__ void fft480_from(float2* buf, In in, const float2* __
       const int j = lane + WAVE * nb;
       if (j < 120) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) buf[4 * j + r] = o[nb][r];
+        for (int r = 0; r < 4; ++r) buf[fft_wr<4, 1>(j, r)] = o[nb][r];
       }
     }
     __syncthreads();
