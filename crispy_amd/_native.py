@@ -26,6 +26,7 @@ RN_SYMBOLS = (
     "crispy_rn_process", "crispy_rn_process_device", "crispy_rn_synchronize",
     "crispy_rn_set_timing", "crispy_rn_last_kernel_ms",
     "crispy_rn_debug_capture", "crispy_rn_debug_read", "crispy_rn_stage_rnn_device",
+    "crispy_host_register", "crispy_host_unregister",
 )
 
 
@@ -98,6 +99,8 @@ def lib() -> C.CDLL:
     L.crispy_rn_process_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_int, C.c_int, C.c_void_p]
     L.crispy_rn_synchronize.argtypes = [C.c_void_p]
+    L.crispy_host_register.argtypes = [C.c_void_p, C.c_size_t]
+    L.crispy_host_unregister.argtypes = [C.c_void_p]
     L.crispy_rn_set_timing.argtypes = [C.c_void_p, C.c_int]
     L.crispy_rn_last_kernel_ms.argtypes = [C.c_void_p, f32p, f32p]
     L.crispy_rn_stage_rnn_device.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_void_p]

@@ -15,7 +15,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace crispy;
@@ -228,6 +230,10 @@ struct crispy_rn {
   float* d_stage_out = nullptr;
   float* d_stage_vad = nullptr;
   size_t stage_frames = 0;
+  // pipelined host path: copy-in / compute / copy-out streams and per-piece events
+  hipStream_t h2d_stream = nullptr;
+  hipStream_t d2h_stream = nullptr;
+  std::vector<hipEvent_t> ev_in, ev_done;
   // timing
   bool timing = false;
   std::vector<hipEvent_t> ev;  // per segment: begin, (frame_begin, frame_end) x sub-chunks, end
@@ -249,6 +255,10 @@ void free_all(crispy_rn* h) {
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->ev_hp) (void)hipEventDestroy(e);
   if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
+  for (hipEvent_t e : h->ev_in) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->ev_done) (void)hipEventDestroy(e);
+  if (h->h2d_stream) { (void)hipStreamSynchronize(h->h2d_stream); (void)hipStreamDestroy(h->h2d_stream); }
+  if (h->d2h_stream) { (void)hipStreamSynchronize(h->d2h_stream); (void)hipStreamDestroy(h->d2h_stream); }
   if (h->hp_stream) { (void)hipStreamSynchronize(h->hp_stream); (void)hipStreamDestroy(h->hp_stream); }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -273,6 +283,9 @@ int zero_state(crispy_rn* h, int stream) {
   }
   return CRISPY_OK;
 }
+
+int process_device_impl(crispy_rn* h, const float* d_in, float* d_out, float* d_vad, float* d_taps, int n_frames,
+                        long stride_t, long stride_b, hipStream_t s);
 
 }  // namespace
 
@@ -409,11 +422,22 @@ int crispy_rn_process_device(crispy_rn* h, const float* d_in, float* d_out, floa
     return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_process_device: audio pointers must be 16-byte aligned");
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
+  const long stride_t = layout == CRISPY_RN_LAYOUT_TBF ? (long)h->B * RN_FRAME : (long)RN_FRAME;
+  const long stride_b = layout == CRISPY_RN_LAYOUT_TBF ? (long)RN_FRAME : (long)n_frames * RN_FRAME;
+  return process_device_impl(h, d_in, d_out, d_vad, d_taps, n_frames, stride_t, stride_b, s);
+}
 
+}  // extern "C"
+
+namespace {
+// n_frames frames of every stream with explicit element strides of (frame, stream): what the public entry point
+// derives from its layout argument, and what the pipelined host path calls per piece of a larger BTF tensor
+int process_device_impl(crispy_rn* h, const float* d_in, float* d_out, float* d_vad, float* d_taps, int n_frames,
+                        long stride_t, long stride_b, hipStream_t s) {
   RnArgs a{};
   a.B = h->B;
-  a.stride_t = layout == CRISPY_RN_LAYOUT_TBF ? (long)h->B * RN_FRAME : (long)RN_FRAME;
-  a.stride_b = layout == CRISPY_RN_LAYOUT_TBF ? (long)RN_FRAME : (long)n_frames * RN_FRAME;
+  a.stride_t = stride_t;
+  a.stride_b = stride_b;
   a.xhp = h->d_xhp;
   a.xhp_stride = h->xhp_stride;
   a.pspec = h->d_pspec;
@@ -504,6 +528,21 @@ int crispy_rn_process_device(crispy_rn* h, const float* d_in, float* d_out, floa
   }
   return CRISPY_OK;
 }
+}  // namespace
+
+extern "C" {
+
+int crispy_host_register(void* p, size_t bytes) {
+  if (!p || bytes == 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_host_register: NULL pointer or zero size");
+  HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
+  return CRISPY_OK;
+}
+
+int crispy_host_unregister(void* p) {
+  if (!p) return fail(CRISPY_ERR_INVALID_ARG, "crispy_host_unregister: NULL pointer");
+  HIP_TRY(hipHostUnregister(p));
+  return CRISPY_OK;
+}
 
 int crispy_rn_process(crispy_rn* h, const float* in, float* out, float* vad, int n_frames,
                       crispy_rn_layout layout) {
@@ -524,15 +563,93 @@ int crispy_rn_process(crispy_rn* h, const float* in, float* out, float* vad, int
     HIP_TRY(hipMalloc(&h->d_stage_vad, (size_t)n_frames * h->B * sizeof(float)));
     h->stage_frames = (size_t)n_frames;
   }
-  HIP_TRY(hipMemcpyAsync(h->d_stage_in, in, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  int rc = crispy_rn_process_device(h, h->d_stage_in, h->d_stage_out, vad ? h->d_stage_vad : nullptr,
-                                    nullptr, n_frames, layout, nullptr);
+  const size_t B = (size_t)h->B;
+  const size_t frame_bytes = B * RN_FRAME * sizeof(float);          // one frame of every stream
+  if (n * sizeof(float) < (size_t)(8u << 20)) {
+    // small calls (the single-stream process_frame drop-in): one copy in, one call, one copy out
+    HIP_TRY(hipMemcpyAsync(h->d_stage_in, in, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    int rc = crispy_rn_process_device(h, h->d_stage_in, h->d_stage_out, vad ? h->d_stage_vad : nullptr,
+                                      nullptr, n_frames, layout, nullptr);
+    if (rc != CRISPY_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(out, h->d_stage_out, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (vad)
+      HIP_TRY(hipMemcpyAsync(vad, h->d_stage_vad, (size_t)n_frames * h->B * sizeof(float),
+                             hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return CRISPY_OK;
+  }
+  // Large calls are cut into pieces of frames (~64 MB each, at least the 3 + 8 ramp of a call) that flow through
+  // three streams: copy-in of piece i + 1, frame kernels of piece i and copy-out of piece i - 1 overlap, so a call
+  // costs about one direction of PCIe traffic instead of in + compute + out.  From pageable memory a copy call blocks
+  // its host thread while the runtime stages it, so the copy-out side runs on its own thread; from registered memory
+  // (crispy_host_register) both directions are plain DMA.
+  int P = (int)((size_t)(64u << 20) / frame_bytes);
+  if (P < 11) P = 11;
+  if (P > n_frames) P = n_frames;
+  const int n_pieces = (n_frames + P - 1) / P;
+  if (!h->h2d_stream) HIP_TRY(hipStreamCreateWithFlags(&h->h2d_stream, hipStreamNonBlocking));
+  if (!h->d2h_stream) HIP_TRY(hipStreamCreateWithFlags(&h->d2h_stream, hipStreamNonBlocking));
+  while ((int)h->ev_in.size() < n_pieces) {
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+    h->ev_in.push_back(e0);
+    HIP_TRY(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+    h->ev_done.push_back(e1);
+  }
+  const bool tbf = layout == CRISPY_RN_LAYOUT_TBF;
+  const long stride_t = tbf ? (long)B * RN_FRAME : (long)RN_FRAME;
+  const long stride_b = tbf ? (long)RN_FRAME : (long)n_frames * RN_FRAME;
+  // piece [t0, t0 + T): contiguous in TBF, B rows of T * 480 floats at a pitch of n_frames * 480 in BTF
+  auto copy_piece = [&](float* dst, const float* src, int t0, int T, hipMemcpyKind kind, hipStream_t st) -> hipError_t {
+    if (tbf)
+      return hipMemcpyAsync(dst + (size_t)t0 * stride_t, src + (size_t)t0 * stride_t, (size_t)T * frame_bytes, kind, st);
+    const size_t pitch = (size_t)n_frames * RN_FRAME * sizeof(float);
+    return hipMemcpy2DAsync(dst + (size_t)t0 * RN_FRAME, pitch, src + (size_t)t0 * RN_FRAME, pitch,
+                            (size_t)T * RN_FRAME * sizeof(float), B, kind, st);
+  };
+  std::atomic<int> recorded{0};          // pieces whose "frame kernels done" event has been recorded by this call
+  std::atomic<bool> abort_flag{false};
+  hipError_t drain_err = hipSuccess;
+  std::thread drain([&]() {
+    if (hipSetDevice(h->device) != hipSuccess) { drain_err = hipErrorInvalidDevice; return; }
+    for (int i = 0; i < n_pieces; ++i) {
+      while (recorded.load(std::memory_order_acquire) <= i) {
+        if (abort_flag.load(std::memory_order_acquire)) return;
+        std::this_thread::yield();
+      }
+      const int t0 = i * P, T = (n_frames - t0) < P ? (n_frames - t0) : P;
+      hipError_t e = hipStreamWaitEvent(h->d2h_stream, h->ev_done[i], 0);
+      if (e == hipSuccess) e = copy_piece(out, h->d_stage_out, t0, T, hipMemcpyDeviceToHost, h->d2h_stream);
+      if (e == hipSuccess && vad)
+        e = hipMemcpyAsync(vad + (size_t)t0 * B, h->d_stage_vad + (size_t)t0 * B, (size_t)T * B * sizeof(float),
+                           hipMemcpyDeviceToHost, h->d2h_stream);
+      if (e != hipSuccess) { drain_err = e; return; }
+    }
+    drain_err = hipStreamSynchronize(h->d2h_stream);
+  });
+  int rc = CRISPY_OK;
+  hipError_t feed_err = hipSuccess;
+  for (int i = 0; i < n_pieces && rc == CRISPY_OK && feed_err == hipSuccess; ++i) {
+    const int t0 = i * P, T = (n_frames - t0) < P ? (n_frames - t0) : P;
+    feed_err = copy_piece(h->d_stage_in, in, t0, T, hipMemcpyHostToDevice, h->h2d_stream);
+    if (feed_err == hipSuccess) feed_err = hipEventRecord(h->ev_in[i], h->h2d_stream);
+    if (feed_err == hipSuccess) feed_err = hipStreamWaitEvent(h->stream, h->ev_in[i], 0);
+    if (feed_err != hipSuccess) break;
+    rc = process_device_impl(h, h->d_stage_in + (size_t)t0 * stride_t, h->d_stage_out + (size_t)t0 * stride_t,
+                             vad ? h->d_stage_vad + (size_t)t0 * B : nullptr, nullptr, T, stride_t, stride_b, h->stream);
+    if (rc != CRISPY_OK) break;
+    feed_err = hipEventRecord(h->ev_done[i], h->stream);
+    if (feed_err == hipSuccess) recorded.store(i + 1, std::memory_order_release);
+  }
+  if (rc != CRISPY_OK || feed_err != hipSuccess) abort_flag.store(true, std::memory_order_release);
+  drain.join();
+  (void)hipStreamSynchronize(h->h2d_stream);
+  (void)hipStreamSynchronize(h->stream);
   if (rc != CRISPY_OK) return rc;
-  HIP_TRY(hipMemcpyAsync(out, h->d_stage_out, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-  if (vad)
-    HIP_TRY(hipMemcpyAsync(vad, h->d_stage_vad, (size_t)n_frames * h->B * sizeof(float),
-                           hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (feed_err != hipSuccess)
+    return fail(CRISPY_ERR_HIP, "crispy_rn_process: copy-in / launch failed: %s", hipGetErrorString(feed_err));
+  if (drain_err != hipSuccess)
+    return fail(CRISPY_ERR_HIP, "crispy_rn_process: copy-out failed: %s", hipGetErrorString(drain_err));
   return CRISPY_OK;
 }
 

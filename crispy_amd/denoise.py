@@ -75,6 +75,27 @@ class DenoiseState:
         N.check(N.lib().crispy_rn_process(self._h, x.ctypes.data, out.ctypes.data, vad.ctypes.data, T, lay))
         return out, vad
 
+    @staticmethod
+    def register_host(arr: np.ndarray):
+        """Page-lock a host array the caller reuses across `process` calls (crispy_host_register): copies become DMA."""
+        N.check(N.lib().crispy_host_register(arr.ctypes.data, arr.nbytes))
+
+    @staticmethod
+    def unregister_host(arr: np.ndarray):
+        N.check(N.lib().crispy_host_unregister(arr.ctypes.data))
+
+    def process_into(self, x: np.ndarray, out: np.ndarray, vad: np.ndarray, layout: str = "tbf"):
+        """`process` into caller-owned (e.g. registered) arrays: x, out [T,B,480] / [B,T,480] float32 contiguous,
+        vad [T,B]."""
+        lay = N.LAYOUT_TBF if layout == "tbf" else N.LAYOUT_BTF
+        T = x.shape[0] if layout == "tbf" else x.shape[1]
+        Bn = x.shape[1] if layout == "tbf" else x.shape[0]
+        if x.dtype != np.float32 or out.dtype != np.float32 or not x.flags.c_contiguous or not out.flags.c_contiguous:
+            raise ValueError("process_into: float32 C-contiguous arrays required")
+        if Bn != self.n_streams or out.shape != x.shape or vad.shape != (T, Bn):
+            raise ValueError("process_into: shape mismatch")
+        N.check(N.lib().crispy_rn_process(self._h, x.ctypes.data, out.ctypes.data, vad.ctypes.data, T, lay))
+
     # -- device-resident tensors (torch is only the allocator here) --------------------------
     def process_device(self, d_in: int, d_out: int, n_frames: int, d_vad: int = 0, d_taps: int = 0,
                        layout: str = "tbf", stream: int = 0):

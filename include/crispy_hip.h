@@ -99,10 +99,23 @@ int crispy_rn_set_pipeline(crispy_rn *h, int staged);
  * in/out are HOST pointers to n_frames*n_streams*480 floats in `layout`; samples are f32 in
  * int16 range (the x32768 / /32768, clamp, volume and first-frame drop of audio.rs:261-278 stay
  * with the caller).  vad (nullable) receives the value process_frame returns,
- * [n_frames][n_streams].  Copies through a staging buffer; returns when `out` is complete.
+ * [n_frames][n_streams].  Copies through a device staging buffer; returns when `out` is complete.
+ * Calls above 8 MB are pipelined in pieces of frames: copy-in of piece i+1, the kernels of piece i and
+ * copy-out of piece i-1 overlap (the copy-out side on its own host thread, because copies from pageable
+ * memory block the calling thread), so a call costs about one direction of PCIe traffic.  Buffers registered
+ * with crispy_host_register are copied by DMA without the runtime's staging.
  */
 int crispy_rn_process(crispy_rn *h, const float *in, float *out, float *vad, int n_frames,
                       crispy_rn_layout layout);
+
+/*
+ * Page-lock (and later release) a host buffer the caller keeps across calls -- the ring buffers of
+ * RnnNoiseProcessor (audio.rs:205-207) or a recording the transcriber reads -- so that crispy_rn_process and
+ * crispy_asr_transcribe* copy it by DMA.  Thin wrappers over hipHostRegister / hipHostUnregister: a Rust host
+ * does not need to link HIP for them.  Optional: unregistered (pageable) buffers work everywhere.
+ */
+int crispy_host_register(void *p, size_t bytes);
+int crispy_host_unregister(void *p);
 
 /*
  * Same, with DEVICE pointers (HBM-resident audio, no PCIe in the call).  Work is enqueued on
