@@ -135,6 +135,12 @@ __device__ __forceinline__ void butterfly<8>(const float2 (&v)[8], float2 (&o)[8
 //                butterfly j reads (j % 4) * 120 + j / 4 + 15 r: four 16-bank windows 0 / 48 / 32 / 16 apart)
 //   pass 2 -> 3: element i = 32 a + 4 r + m at i ^ ((a & 3) << 2): the four a of a 16-lane group spread over the
 //                four bank quarters; a 32-aligned run of the radix-3 load stays a permutation of one 32-block
+#ifndef RN_PRIO_SPREAD
+#define RN_PRIO_SPREAD 1
+#endif
+#ifndef RN_STAGGER_TICKS
+#define RN_STAGGER_TICKS 0
+#endif
 #ifndef RN_FFT_SWIZZLE
 #define RN_FFT_SWIZZLE 1
 #endif
@@ -1077,6 +1083,36 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void 
   int lane = lane0;
   const RnTables* tab = a.tab;
   const float* xs = a.xhp + (long)b * a.xhp_stride;
+#if RN_PRIO_SPREAD
+  // Different issue priorities per wave slot, so that the four waves of a SIMD drift out of phase without anyone
+  // sleeping (0: off, 1: by wave slot, 2: by SIMD, 3: by slot + SIMD parity).  Measured over three alternating 30-step
+  // runs each: 1 -> 8.175 ms per step against 8.238 (-0.8 %), 2 and 3 -> no change.
+  if constexpr (MODE == 0) {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    const unsigned slot = hw & 3u, simd = (hw >> 4) & 3u;
+    const unsigned pr = RN_PRIO_SPREAD == 1 ? slot : (RN_PRIO_SPREAD == 2 ? simd : ((slot + simd) & 3u));
+    if (pr == 0) __builtin_amdgcn_s_setprio(0);
+    else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+  }
+#endif
+#if RN_STAGGER_TICKS > 0
+  // Experiment (off): the 16 waves of a CU run the same stages at the same time (they start together and execute the
+  // same instruction stream), so they want the vector L1 together in the gain network and the LDS together in the
+  // transforms.  A start offset per wave slot / SIMD de-phases them.  RN_STAGGER_TICKS: s_memtime ticks (10 ns)
+  // per step; the offset is (wave slot * 4 + SIMD) steps.  Measured: offsets up to 15 / 37 / 75 us cost +0.09 / +0.19 /
+  // +0.27 ms per 100-frame step where the idle tails of ten launches alone would cost 0.15 / 0.37 / 0.75 ms -- so
+  // de-phased waves do run ~6 % faster in steady state, but a launch of 12 frames is too short to pay for its tail.
+  if constexpr (MODE == 0) {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    const unsigned slot = hw & 15u, simd = (hw >> 4) & 3u;
+    const long long until = (long long)wall_clock64() + (long long)((slot & 3u) * 4u + simd) * RN_STAGGER_TICKS;
+    while ((long long)wall_clock64() < until) __builtin_amdgcn_s_sleep(32);
+  }
+#endif
 
   // ---- load per-stream state ----
   if constexpr (MODE != 2) {
