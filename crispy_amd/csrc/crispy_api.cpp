@@ -217,6 +217,15 @@ struct crispy_rn {
   float2* d_pspec = nullptr;
   // staged pipeline workspaces, one sub-chunk deep
   bool staged = false;
+  // Frames per high-pass launch.  A high-pass wave keeps the VALU of its SIMD ~35 % busy (nine dependent f64
+  // operations per sample) and a frame-kernel launch lasts as long as its slowest wave, so a sub-chunk's high-pass as
+  // one 0.3 ms kernel delays the four frame waves that share its SIMD by ~0.08 ms per launch (0.8 ms per 100-frame
+  // step, measured with CRISPY_RN_HP=upfront).  As kernels of two frames the 64 waves land on other SIMDs every
+  // ~50 us and the delay spreads: 8.17 -> 7.68 ms per step (1 frame: 7.83, 3: 8.07, 4: 8.15, 6: 8.0, whole: 8.17).
+  int hp_split = 2;
+  int hp_ahead = 0;          // > 0: the high-pass runs at most this many sub-chunks in front of the frame kernels
+  std::vector<hipEvent_t> ev_fr;   // one per sub-chunk: frame kernel done (only used with hp_ahead)
+  bool hp_upfront = false;   // diagnostic (CRISPY_RN_HP=upfront): every high-pass of a call segment first, on the main stream
   float2* d_xspec = nullptr;
   float* d_feat = nullptr;
   unsigned char* d_silent = nullptr;
@@ -254,6 +263,7 @@ void free_all(crispy_rn* h) {
     if (p) (void)hipFree(p);
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->ev_hp) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->ev_fr) (void)hipEventDestroy(e);
   if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
   for (hipEvent_t e : h->ev_in) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->ev_done) (void)hipEventDestroy(e);
@@ -351,6 +361,12 @@ int crispy_rn_create(const int8_t* weights, size_t nbytes, int n_streams, int de
     {
       const char* env = std::getenv("CRISPY_RN_PIPELINE");
       h->staged = env && std::strcmp(env, "staged") == 0;   // default: the single fused frame kernel
+      const char* hp = std::getenv("CRISPY_RN_HP");
+      h->hp_upfront = hp && std::strcmp(hp, "upfront") == 0;
+      const char* sp = std::getenv("CRISPY_RN_HP_SPLIT");
+      if (sp) h->hp_split = std::atoi(sp);   // 0: one kernel per sub-chunk
+      const char* ah = std::getenv("CRISPY_RN_HP_AHEAD");
+      h->hp_ahead = ah ? std::atoi(ah) : 0;
     }
     RnTables* tab = new RnTables();
     build_tables(tab);
@@ -483,16 +499,37 @@ int process_device_impl(crispy_rn* h, const float* d_in, float* d_out, float* d_
       h->ev_used += 2 + 2 * (size_t)n_sub;
       HIP_TRY(hipEventRecord(e[0], s));
     }
-    // high-pass sub-chunks back to back on the helper stream
-    for (int i = 0, ts = 0; i < n_sub; ++i) {
-      RnArgs sa = a;
-      sa.T = sub_frames(i, T - ts);
-      sa.in = d_in + (long)(t0 + ts) * a.stride_t;
-      sa.xhp = h->d_xhp + (long)ts * RN_FRAME;   // row pointer shifted by the frames already filtered
-      HIP_TRY(rn_launch_highpass(sa, h->hp_stream));
-      HIP_TRY(hipEventRecord(h->ev_hp[i], h->hp_stream));
-      ts += sa.T;
+    // high-pass sub-chunks on the helper stream, enqueued up to `hp_ahead` sub-chunks in front of the frame kernels
+    // (0: all of them back to back at once)
+    int hp_next = 0, hp_ts = 0;
+    while ((int)h->ev_fr.size() < n_sub) {
+      hipEvent_t ne;
+      HIP_TRY(hipEventCreateWithFlags(&ne, hipEventDisableTiming));
+      h->ev_fr.push_back(ne);
     }
+    auto enqueue_hp_until = [&](int last) -> int {
+      for (; hp_next <= last && hp_next < n_sub; ++hp_next) {
+        const int i = hp_next, ts = hp_ts;
+        RnArgs sa = a;
+        sa.T = sub_frames(i, T - ts);
+        sa.in = d_in + (long)(t0 + ts) * a.stride_t;
+        sa.xhp = h->d_xhp + (long)ts * RN_FRAME;   // row pointer shifted by the frames already filtered
+        hipStream_t hs = h->hp_upfront ? s : h->hp_stream;
+        if (h->hp_ahead > 0 && i >= h->hp_ahead) HIP_TRY(hipStreamWaitEvent(hs, h->ev_fr[i - h->hp_ahead], 0));
+        const int per = h->hp_split > 0 ? h->hp_split : sa.T;
+        for (int f0 = 0; f0 < sa.T; f0 += per) {
+          RnArgs pa = sa;
+          pa.T = (sa.T - f0) < per ? (sa.T - f0) : per;
+          pa.in = sa.in + (long)f0 * a.stride_t;
+          pa.xhp = sa.xhp + (long)f0 * RN_FRAME;
+          HIP_TRY(rn_launch_highpass(pa, hs));
+        }
+        HIP_TRY(hipEventRecord(h->ev_hp[i], hs));
+        hp_ts += sa.T;
+      }
+      return CRISPY_OK;
+    };
+    if (h->hp_ahead <= 0) { const int rc_hp = enqueue_hp_until(n_sub - 1); if (rc_hp != CRISPY_OK) return rc_hp; }
     // frame kernels on the caller's stream, each gated on its own sub-chunk's high-pass
     for (int i = 0, ts = 0; i < n_sub; ++i) {
       RnArgs sa = a;
@@ -502,6 +539,7 @@ int process_device_impl(crispy_rn* h, const float* d_in, float* d_out, float* d_
       sa.taps = d_taps ? d_taps + (long)(t0 + ts) * h->B * RN_TAPS : nullptr;
       sa.dbg = (t0 + ts + sa.T == n_frames) ? h->d_dbg : nullptr;
       sa.xhp = h->d_xhp + (long)ts * RN_FRAME;
+      if (h->hp_ahead > 0) { const int rc_hp = enqueue_hp_until(i + h->hp_ahead - 1); if (rc_hp != CRISPY_OK) return rc_hp; }
       HIP_TRY(hipStreamWaitEvent(s, h->ev_hp[i], 0));
       if (e) HIP_TRY(hipEventRecord(e[1 + 2 * i], s));
       if (h->staged && !sa.dbg) {
@@ -519,6 +557,7 @@ int process_device_impl(crispy_rn* h, const float* d_in, float* d_out, float* d_
         HIP_TRY(rn_launch_frames(sa, s));
       }
       if (e) HIP_TRY(hipEventRecord(e[2 + 2 * i], s));
+      if (h->hp_ahead > 0) HIP_TRY(hipEventRecord(h->ev_fr[i], s));
       ts += sa.T;
     }
     a.T = T;

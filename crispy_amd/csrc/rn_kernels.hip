@@ -135,6 +135,9 @@ __device__ __forceinline__ void butterfly<8>(const float2 (&v)[8], float2 (&o)[8
 //                butterfly j reads (j % 4) * 120 + j / 4 + 15 r: four 16-bank windows 0 / 48 / 32 / 16 apart)
 //   pass 2 -> 3: element i = 32 a + 4 r + m at i ^ ((a & 3) << 2): the four a of a 16-lane group spread over the
 //                four bank quarters; a 32-aligned run of the radix-3 load stays a permutation of one 32-block
+#ifndef RN_VGPR_CAP
+#define RN_VGPR_CAP
+#endif
 #ifndef RN_PRIO_SPREAD
 #define RN_PRIO_SPREAD 1
 #endif
@@ -1075,7 +1078,7 @@ __device__ __forceinline__ void lag_dots(const float* xr, const float* const (&y
 // MODE 1: analysis only -- stops after the 42 features and parks X, P, band energies for the synthesis kernel.
 // MODE 2: synthesis only -- gains come from the stream-batched MFMA gain network (rn_rnn_kernel.hip).
 template <int MODE>
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) void rn_frame_kernel(RnArgs a) {
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VGPR_CAP void rn_frame_kernel(RnArgs a) {
   __shared__ RnLdsT<MODE> L;
   const int lane0 = threadIdx.x;
   const int b = blockIdx.x;
