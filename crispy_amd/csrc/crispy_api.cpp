@@ -29,7 +29,10 @@ constexpr int kChunkFrames = 250;   // workspace bound: frames of high-passed si
 // high-passed signal are 94 MB, which the frame kernel still finds in the 256 MB Infinity Cache next to its history
 // re-reads: measured 10.48 ms per 100-frame step (spread 0.07) against 10.78 (spread 0.8) with 25-frame sub-chunks,
 // 12.3 ms with 56 and more (the kernel is sensitive to the latency of its window reads), 10.53 with 8.
-constexpr int kSubFrames = 12;
+#ifndef RN_SUB_FRAMES
+#define RN_SUB_FRAMES 12
+#endif
+constexpr int kSubFrames = RN_SUB_FRAMES;
 
 // Frames of sub-chunk `index` of a segment with `remaining` frames left.  The high-pass recurrence of the first
 // sub-chunk cannot overlap anything (the previous call still reads xhp), so the segment starts with a short
