@@ -25,10 +25,10 @@ using namespace crispy;
 namespace {
 
 constexpr int kChunkFrames = 250;   // workspace bound: frames of high-passed signal kept per call segment
-// Pipeline grain: the high-pass of sub-chunk i+1 overlaps the frame kernel of sub-chunk i.  12 frames x 4096 streams of
-// high-passed signal are 94 MB, which the frame kernel still finds in the 256 MB Infinity Cache next to its history
-// re-reads: measured 10.48 ms per 100-frame step (spread 0.07) against 10.78 (spread 0.8) with 25-frame sub-chunks,
-// 12.3 ms with 56 and more (the kernel is sensitive to the latency of its window reads), 10.53 with 8.
+// Pipeline grain: a frame-kernel launch covers one sub-chunk and is gated on that sub-chunk's high-pass, which runs
+// ahead on the helper stream.  Measured per 100-frame step with the final kernels (4096 streams): 8 -> 8.2 ms,
+// 10 -> 8.0, 12 -> 7.68, 16 -> 7.75, 20 -> 7.85, 30 -> 8.03; a longer ramp (3, 8, 20, 48) with 48-frame sub-chunks
+// shortens the frame-kernel sum by 1.5 % (five launch tails instead of ten) but waits 0.8 ms for the high-pass.
 #ifndef RN_SUB_FRAMES
 #define RN_SUB_FRAMES 12
 #endif
