@@ -338,7 +338,16 @@ int crispy_rn_create(const int8_t* weights, size_t nbytes, int n_streams, int de
   auto body = [&]() -> int {
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&h->hp_stream, hipStreamNonBlocking));
+    {
+      // The helper stream must not share a hardware queue with the main stream (the high-pass of the next
+      // sub-chunks has to run *beside* the frame kernel): HIP multiplexes streams of one priority over a small pool
+      // of hardware queues in creation order, and with other libraries' streams in the process (RCCL: measured 9.2 ms
+      // per step instead of 7.7) the two can land on the same one.  Queues are pooled per priority, so the helper
+      // stream gets the highest one -- which also suits it: its kernels are short and gate the frame kernels.
+      int least = 0, greatest = 0;
+      HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      HIP_TRY(hipStreamCreateWithPriority(&h->hp_stream, hipStreamNonBlocking, greatest));
+    }
     HIP_TRY(hipEventCreateWithFlags(&h->ev_begin, hipEventDisableTiming));
     const size_t B = (size_t)n_streams;
     HIP_TRY(hipMalloc(&h->d_tab, sizeof(RnTables)));
@@ -629,8 +638,13 @@ int crispy_rn_process(crispy_rn* h, const float* in, float* out, float* vad, int
   if (P < 11) P = 11;
   if (P > n_frames) P = n_frames;
   const int n_pieces = (n_frames + P - 1) / P;
-  if (!h->h2d_stream) HIP_TRY(hipStreamCreateWithFlags(&h->h2d_stream, hipStreamNonBlocking));
-  if (!h->d2h_stream) HIP_TRY(hipStreamCreateWithFlags(&h->d2h_stream, hipStreamNonBlocking));
+  if (!h->h2d_stream || !h->d2h_stream) {
+    // copy streams in the lowest-priority queue pool: never on the hardware queue of the main or the helper stream
+    int least = 0, greatest = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    if (!h->h2d_stream) HIP_TRY(hipStreamCreateWithPriority(&h->h2d_stream, hipStreamNonBlocking, least));
+    if (!h->d2h_stream) HIP_TRY(hipStreamCreateWithPriority(&h->d2h_stream, hipStreamNonBlocking, least));
+  }
   while ((int)h->ev_in.size() < n_pieces) {
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
