@@ -135,8 +135,19 @@ __device__ __forceinline__ void butterfly<8>(const float2 (&v)[8], float2 (&o)[8
 //                butterfly j reads (j % 4) * 120 + j / 4 + 15 r: four 16-bank windows 0 / 48 / 32 / 16 apart)
 //   pass 2 -> 3: element i = 32 a + 4 r + m at i ^ ((a & 3) << 2): the four a of a 16-lane group spread over the
 //                four bank quarters; a 32-aligned run of the radix-3 load stays a permutation of one 32-block
+// Register caps that let a high-pass wave run *beside* four frame waves of a SIMD instead of waiting for one of them
+// to finish: the frame kernel at 120 of its 128 registers (no spill store in the frame loop, same speed), the
+// high-pass kernel at 32 (two float4 blocks of input in flight instead of eight; 12 B of prologue scratch).
+// amdgpu_num_vgpr counts the unified VGPR + AGPR file on gfx950, so the attribute wants half the number (120 / 32
+// given directly are silently ignored).  Measured: 7.71 -> 7.585 ms per 100-frame step.
 #ifndef RN_VGPR_CAP
-#define RN_VGPR_CAP
+#define RN_VGPR_CAP __attribute__((amdgpu_num_vgpr(60)))
+#endif
+#ifndef RN_HP_BLK
+#define RN_HP_BLK 2
+#endif
+#ifndef RN_HP_VGPR_CAP
+#define RN_HP_VGPR_CAP __attribute__((amdgpu_num_vgpr(16)))
 #endif
 #ifndef RN_PRIO_SPREAD
 #define RN_PRIO_SPREAD 1
@@ -2086,16 +2097,16 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
 // =============================================================================================
 // high-pass: one lane per stream, strictly sequential (Appendix A.3 step 1, double products)
 // =============================================================================================
-__global__ __launch_bounds__(WAVE) void rn_highpass_kernel(RnArgs a) {
+__global__ __launch_bounds__(WAVE) RN_HP_VGPR_CAP void rn_highpass_kernel(RnArgs a) {
   const int b = blockIdx.x * WAVE + threadIdx.x;
   if (b >= a.B) return;
   const double a0h = 0.5 * (double)-1.99599f, a1 = (double)0.99600f;   // b = (-2, 1) is folded into the two fmas
   float m0 = a.hp_mem[2 * b], m1 = a.hp_mem[2 * b + 1];
   float* dst = a.xhp + (long)b * a.xhp_stride + RN_HIST;
   // The recurrence is a dependent chain of five operations per sample; what the lane must not also wait for is its
-  // input.  Blocks of 32 samples (8 float4) are requested one block ahead, across frame boundaries: with the load
+  // input.  Blocks of 4 RN_HP_BLK samples are requested one block ahead, across frame boundaries: with the load
   // issued right in front of its use the kernel spent most of its time on one L1/L2 round trip per four samples.
-  constexpr int BLK = 8, NBLK = RN_FRAME / 4 / BLK;   // 15 blocks per frame
+  constexpr int BLK = RN_HP_BLK, NBLK = RN_FRAME / 4 / BLK;   // blocks per frame
   const long total = (long)a.T * NBLK;
   auto block_ptr = [&](long k) {
     const long t = k / NBLK, blk = k - t * NBLK;

@@ -1,6 +1,7 @@
 """Register / LDS / scratch budget of the RNNoise kernels (cross-compiled here, no GPU needed).
 
-The frame kernel is sized for 4 waves per SIMD (<= 128 VGPRs) and 16 workgroups per CU (<= 10 KB LDS).
+The frame kernel is sized for 4 waves per SIMD (<= 120 VGPRs, leaving room for a 32-VGPR high-pass wave beside
+them) and 16 workgroups per CU (<= 10 KB LDS).
 Spills inside the frame loop are a *correctness* hazard with this compiler: VGPR spill stores of a join block
 are emitted before the block's exec restore, so a value spilled right after a divergent region is saved for
 the active lanes only (see rn_kernels.hip: dotn_h).  Loop-invariant values spilled once in the prologue, under
@@ -41,7 +42,8 @@ def test_frame_kernel_resource_budget(tmp_path, extra):
     assert len(frame) == 3, list(res)
     text = asm.read_text()
     for name, r in frame.items():
-        assert r["VGPRs"] + r.get("AGPRs", 0) <= 128, (name, r)
+        # 120, not 128: the 32-VGPR high-pass waves must fit as a fifth wave beside four frame waves of a SIMD
+        assert r["VGPRs"] + r.get("AGPRs", 0) <= 120, (name, r)
         assert r["LDS Size"] <= 10240, (name, r)
         assert r["ScratchSize"] <= 64, (name, r)
         body = text[text.index(name + ":"):]
@@ -49,6 +51,15 @@ def test_frame_kernel_resource_budget(tmp_path, extra):
         loop = body.find("=>This Loop Header: Depth=1")     # the frame loop (the prologue's copy loops are "Inner")
         assert loop > 0, name
         assert "scratch_store" not in body[loop:], f"{name}: VGPR spill store inside the frame loop"
+    hp = {k: v for k, v in res.items() if "rn_highpass_kernel" in k}
+    assert len(hp) == 1, list(res)
+    for name, r in hp.items():
+        assert r["VGPRs"] + r.get("AGPRs", 0) <= 32, (name, r)
+        body = text[text.index(name + ":"):]
+        body = body[:body.index("s_endpgm")]
+        loop = body.find("Loop Header")
+        assert loop > 0, name
+        assert "scratch_store" not in body[loop:], f"{name}: VGPR spill store inside the sample loop"
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
