@@ -334,6 +334,48 @@ struct BandEdges {
   int em1, e0, e1;
 };
 
+// Sum of one band's chunk partials (lane == band, lane < RN_NB): part[100 + c] for c in [em1, e0) -- the rising
+// half of the previous interval -- then part[c] for c in [e0, e1), doubled at the two edge bands.  The partials are
+// added in the reference's order but *read* RN_BAND_BATCH at a time: as plain `for (c = ...) sum += part[c]` loops
+// this compiled to one LDS round trip per chunk, up to 22 + 22 dependent trips per call (the widest bands), four
+// calls per frame.  Reads past a lane's range stay inside the workgroup's LDS and are replaced by 0.f, which leaves
+// the sum bit-identical.  Measured: 7.56 -> 7.43 ms per step although it adds ~700 VALU instructions per frame.
+#ifndef RN_BAND_BATCH
+#define RN_BAND_BATCH 8
+#endif
+__device__ __forceinline__ float band_sum(const float* part, const BandEdges& be, int lane) {
+  float sum = 0.f;
+#if RN_BAND_BATCH
+  const int n_hi = lane > 0 ? be.e0 - be.em1 : 0;
+  const int n_lo = lane < RN_NB - 1 ? be.e1 - be.e0 : 0;
+  const float* ph = part + 100 + be.em1;
+  const float* pl = part + be.e0;
+#pragma unroll
+  for (int base = 0; base < 24; base += RN_BAND_BATCH) {
+    float v[RN_BAND_BATCH];
+#pragma unroll
+    for (int k = 0; k < RN_BAND_BATCH; ++k) v[k] = ph[base + k];
+#pragma unroll
+    for (int k = 0; k < RN_BAND_BATCH; ++k) sum += base + k < n_hi ? v[k] : 0.f;
+  }
+#pragma unroll
+  for (int base = 0; base < 24; base += RN_BAND_BATCH) {
+    float v[RN_BAND_BATCH];
+#pragma unroll
+    for (int k = 0; k < RN_BAND_BATCH; ++k) v[k] = pl[base + k];
+#pragma unroll
+    for (int k = 0; k < RN_BAND_BATCH; ++k) sum += base + k < n_lo ? v[k] : 0.f;
+  }
+#else
+  if (lane > 0)
+    for (int c = be.em1; c < be.e0; ++c) sum += part[100 + c];
+  if (lane < RN_NB - 1)
+    for (int c = be.e0; c < be.e1; ++c) sum += part[c];
+#endif
+  if (lane == 0 || lane == RN_NB - 1) sum *= 2.f;
+  return sum;
+}
+
 // Band energies in the pair layout of the comb-filter stage: lane handles bins (2p, 2p+1), p = lane + 64 m, with
 // one ds_read_b128 per spectrum; the two pairs of a 4-bin chunk are neighbouring lanes (one DPP add), even lanes
 // write the chunk partials, 22 lanes add them up (deterministic, no atomics).  With CORR the same pass also yields
@@ -376,15 +418,7 @@ __device__ __forceinline__ void band_pairs(const float2* S, const float2* Xc, fl
   }
   auto band_total = [&](float* out) {
     __syncthreads();
-    if (lane < RN_NB) {
-      float sum = 0.f;
-      if (lane > 0)
-        for (int c = be.em1; c < be.e0; ++c) sum += part[100 + c];
-      if (lane < RN_NB - 1)
-        for (int c = be.e0; c < be.e1; ++c) sum += part[c];
-      if (lane == 0 || lane == RN_NB - 1) sum *= 2.f;
-      out[lane] = sum;
-    }
+    if (lane < RN_NB) out[lane] = band_sum(part, be, lane);
     __syncthreads();
   };
   band_total(Eout);
@@ -1314,8 +1348,25 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
     float* x4 = Sa;        // 240
     float* y4 = Sa + 240;  // 387 (+ guard to 392)
     float* pre = Sa;       // 392: exclusive prefix sums of y4^2, written after x4/y4 are dead (aliases them)
-    for (int j = lane; j < 240; j += WAVE) x4[j] = lp[384 + 2 * j];
-    for (int j = lane; j < 392; j += WAVE) y4[j] = j < 387 ? lp[2 * j] : 0.f;
+    {
+      // reads of all trips first (clamped indices): as `for (j = lane; ...) x4[j] = lp[...]` loops every trip was an
+      // LDS read - wait - write round trip, eleven in a row
+      float vx[4], vy[7];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) vx[m] = lp[384 + 2 * min(lane + WAVE * m, 239)];
+#pragma unroll
+      for (int m = 0; m < 7; ++m) vy[m] = lp[2 * min(lane + WAVE * m, 386)];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int j = lane + WAVE * m;
+        if (j < 240) x4[j] = vx[m];
+      }
+#pragma unroll
+      for (int m = 0; m < 7; ++m) {
+        const int j = lane + WAVE * m;
+        if (j < 392) y4[j] = j < 387 ? vy[m] : 0.f;
+      }
+    }
     __syncthreads();
     int best0, best1;
     {
@@ -1972,12 +2023,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
       __syncthreads();
       if (lane < RN_NB) {        // new band energies (Ep is dead), then the renormalisation and the smoothed gains
         float* part = Rb + (MODE == 2 ? 0 : RB_PART);
-        float sum = 0.f;
-        if (lane > 0)
-          for (int c = be.em1; c < be.e0; ++c) sum += part[100 + c];
-        if (lane < RN_NB - 1)
-          for (int c = be.e0; c < be.e1; ++c) sum += part[c];
-        if (lane == 0 || lane == RN_NB - 1) sum *= 2.f;
+        const float sum = band_sum(part, be, lane);
         L.U[U_R + lane] = sqrtf(L.Ex[lane] / (1e-8f + sum));  // norm
         float gg;
         if constexpr (MODE == 2) gg = a.g_smooth[((long)t * a.B + b) * RNN_GAIN_LD + lane];   // smoothing state lives in the gain-network kernel
