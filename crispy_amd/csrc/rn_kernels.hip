@@ -390,13 +390,18 @@ __device__ __forceinline__ void band_pairs(const float2* S, const float2* Xc, fl
   float2 fr[4];
 #pragma unroll
   for (int m = 0; m < 4; ++m) fr[m] = *reinterpret_cast<const float2*>(tab->bin_frac + 2 * min(lane + WAVE * m, 199));
+  // the spectrum pairs of all four trips first (clamped index): inside the `pidx < 200` bodies every trip was an LDS
+  // read - wait - use round trip
+  float4 svq[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) svq[m] = *reinterpret_cast<const float4*>(S + 2 * min(lane + WAVE * m, 199));
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     const int pidx = lane + WAVE * m;
     clo[m] = 0.f; chi[m] = 0.f;
     if (pidx < 200) {
       const float2 f = fr[m];
-      const float4 sv = *reinterpret_cast<const float4*>(S + 2 * pidx);
+      const float4 sv = svq[m];
       float e0 = sv.x * sv.x; e0 += sv.y * sv.y;
       float e1 = sv.z * sv.z; e1 += sv.w * sv.w;
       float lo = (1.f - f.x) * e0 + (1.f - f.y) * e1;
@@ -2032,15 +2037,25 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
         lastg = gg;
       }
       __syncthreads();
+      // band values and spectrum pairs of all four trips first (bq / indices are always valid: clamped where they
+      // were made), so that the trips do not each wait for their own LDS reads
+      float nq[4][2], gq[4][2];
+      float4 xq[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        nq[m][0] = L.U[U_R + bq[m]]; nq[m][1] = L.U[U_R + bq[m] + 1];
+        gq[m][0] = L.U[U_G + bq[m]]; gq[m][1] = L.U[U_G + bq[m] + 1];
+        xq[m] = *reinterpret_cast<const float4*>(L.A + 2 * min(lane + WAVE * m, 199));
+      }
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const int pidx = lane + WAVE * m;
         if (pidx < 200) {
-          const float n0 = L.U[U_R + bq[m]], n1 = L.U[U_R + bq[m] + 1];
-          const float g0 = L.U[U_G + bq[m]], g1 = L.U[U_G + bq[m] + 1];
+          const float n0 = nq[m][0], n1 = nq[m][1];
+          const float g0 = gq[m][0], g1 = gq[m][1];
           const float nf0 = (1.f - fq[m].x) * n0 + fq[m].x * n1, nf1 = (1.f - fq[m].y) * n0 + fq[m].y * n1;
           const float gf0 = (1.f - fq[m].x) * g0 + fq[m].x * g1, gf1 = (1.f - fq[m].y) * g0 + fq[m].y * g1;
-          float4 x = *reinterpret_cast<const float4*>(L.A + 2 * pidx);
+          float4 x = xq[m];
           x.x *= nf0; x.y *= nf0; x.z *= nf1; x.w *= nf1;
           x.x *= gf0; x.y *= gf0; x.z *= gf1; x.w *= gf1;
           *reinterpret_cast<float4*>(L.A + 2 * pidx) = x;
