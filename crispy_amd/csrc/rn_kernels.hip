@@ -155,6 +155,9 @@ __device__ __forceinline__ void butterfly<8>(const float2 (&v)[8], float2 (&o)[8
 #ifndef RN_STAGGER_TICKS
 #define RN_STAGGER_TICKS 0
 #endif
+#ifndef RN_RD_PARALLEL
+#define RN_RD_PARALLEL 1
+#endif
 #ifndef RN_FFT_SWIZZLE
 #define RN_FFT_SWIZZLE 1
 #endif
@@ -1598,6 +1601,40 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
             if (k0 + q <= 15) { T1_[k0 + q - 2] = 0; xyk_[k0 + q - 2] = 0.f; yyk_[k0 + q - 2] = 0.f; }
         }
       }
+#if RN_RD_PARALLEL
+      // The threshold test of candidate k depends on k, T0, g0 and the previous frame only, never on the running best,
+      // and the reference's loop keeps the *last* k that passes: so lane k - 2 evaluates candidate k (one square root
+      // and one division per lane instead of fourteen of each in every lane, one after the other) and the highest
+      // passing lane wins.  Same operations per candidate, bit-identical decisions.
+      {
+        int T1 = 0;
+        float xyk = 0.f, yyk = 0.f;
+#pragma unroll
+        for (int k = 2; k <= 15; ++k) {
+          const bool mine = lane == k - 2;
+          T1 = mine ? T1_[k - 2] : T1;
+          xyk = mine ? xyk_[k - 2] : xyk;
+          yyk = mine ? yyk_[k - 2] : yyk;
+        }
+        const int k = lane + 2;
+        const float g1 = xyk / sqrtf(1.f + xx * yyk);
+        float cont;
+        if (abs(T1 - prev_period) <= 1) cont = last_gain;
+        else if (abs(T1 - prev_period) <= 2 && 5 * k * k < T0) cont = .5f * last_gain;
+        else cont = 0.f;
+        float thresh = fmaxf(.3f, .7f * g0 - cont);
+        if (T1 < 90) thresh = fmaxf(.4f, .85f * g0 - cont);
+        else if (T1 < 60) thresh = fmaxf(.5f, .9f * g0 - cont);
+        const unsigned long long pass = __ballot(lane < 14 && T1 >= 30 && g1 > thresh);
+        if (pass != 0ull) {
+          const int w = 63 - __builtin_clzll(pass);   // wave-uniform: the largest k that passes
+          best_xy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xyk), w));
+          best_yy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(yyk), w));
+          T = __builtin_amdgcn_readlane(T1, w);
+          g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g1), w));
+        }
+      }
+#else
 #pragma unroll
       for (int k = 2; k <= 15; ++k) {
         const int T1 = T1_[k - 2];
@@ -1614,6 +1651,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
           if (g1 > thresh) { best_xy = xyk; best_yy = yyk; T = T1; g = g1; }
         }
       }
+#endif
       best_xy = fmaxf(0.f, best_xy);
       float pgv = (best_yy <= best_xy) ? 1.f : best_xy / (best_yy + 1.f);
       float xc3[3];
