@@ -185,33 +185,225 @@ def asr_leg(local_rank: int, clips: int = 64, new_tokens: int = 32):
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=4096, help="streams per GPU")
-    ap.add_argument("--frames", type=int, default=100, help="frames per stream per step")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-asr", action="store_true", help="skip the Whisper-tiny leg of the metric")
-    args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-
+def _dist_env():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    return rank, local_rank, world
+
+
+def _init_dist(backend: str, local_rank: int, world: int):
+    """torch.distributed over RCCL ("nccl") on the GPU box, gloo in the launcher's CPU dry run.  Returns
+    (dist module or None, world size AS THE BACKEND REPORTS IT)."""
     # CRISPY_BENCH_FORCE_DIST=1 exercises the RCCL path with a single rank (what can be tested on a 1-GPU box)
-    use_dist = world > 1 or os.environ.get("CRISPY_BENCH_FORCE_DIST") == "1"
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
+    if world <= 1 and os.environ.get("CRISPY_BENCH_FORCE_DIST") != "1":
+        return None, 1
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    if backend == "nccl":
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    else:
+        dist.init_process_group(backend)
+    return dist, dist.get_world_size()
+
+
+def _gather_ms(dist, ms: float, device=None):
+    """Per-rank elapsed milliseconds, rank order (one tiny all-gather; [ms] without a process group)."""
+    if dist is None:
+        return [ms]
+    import torch
+    t = torch.tensor([ms], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
+def _flush_c_stdout():
+    # RCCL prints its version banner to C stdout when the communicator comes up; push it out before the timed
+    # region on every rank so that rank 0's JSON line is the last thing on stdout
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+
+
+def dry_run(args):
+    """Launcher self-test (tests/test_sharding_gloo.py): the rank plumbing of a --gpus N job on CPU with gloo -- no
+    HIP library, no GPU, a "step" is a 5 ms sleep.  The line it prints is labelled as such and carries no value."""
+    rank, local_rank, world = _dist_env()
+    fail = os.environ.get("CRISPY_BENCH_DRY_FAIL_RANK")
+    if fail is not None and int(fail) == rank:
+        print(f"dry run: rank {rank} fails on request", file=sys.stderr)
+        sys.exit(3)
+    dist, world_reported = _init_dist("gloo", local_rank, world)
+    from crispy_amd.sharding import reduce_job_stats, shard_range
+    B, T = args.streams, args.frames
+    lo, hi = shard_range(world * B, rank, world)
+    for _ in range(args.warmup):
+        time.sleep(0.005)
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.005)
+    if dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    per_rank = _gather_ms(dist, dt * 1e3)
+    dt, frames_total = reduce_job_stats(dt, (hi - lo) * T * args.steps)
+    if rank == 0:
+        print(json.dumps({"metric": "launcher dry run (no GPU work)", "value": None, "unit": None,
+                          "n_gpus": world_reported, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": dt / args.steps * 1e3, "data": "dry-run", "scaling": "weak",
+                          "per_rank_ms": per_rank, "frames_total": frames_total,
+                          "config": {"workload": "launcher dry run", "streams_per_gpu": B, "frames_per_step": T,
+                                     "first_stream_of_rank0": lo}}), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+def cfg5(args):
+    """BASELINE configs[4]: Whisper-base full transcribe, 8192 streams sharded across 8 GPUs = 1024 x 30 s clips per
+    GPU (static shard by stream id, no data-path collective).  One step = one sub-batch of `--clips` clips resident
+    in HBM: log-mel -> encoder -> greedy decode of `--new-tokens` tokens (random-init weights never emit EOT, so the
+    decode length is fixed).  value = seconds of audio transcribed per wall second, whole job."""
+    import numpy as np
+    import torch
+
+    rank, local_rank, world = _dist_env()
+    dist, world_reported = _init_dist("nccl", local_rank, world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    from crispy_amd.asr import LogMel, WhisperModel
+    from crispy_amd.sharding import reduce_job_stats, shard_range
+    from crispy_amd.whisper_weights import HParams, synthetic_whisper_weights
+
+    hp = HParams.base()
+    SUB, NEW = args.clips, args.new_tokens
+    model = WhisperModel(hp, synthetic_whisper_weights(hp, 0), device=local_rank)
+    model.set_precision(args.precision)
+    lm = LogMel(hp.n_mels, device=local_rank)
+    lo, hi = shard_range(world * SUB * args.steps, rank, world)      # global clip ids this rank owns
+    g = torch.Generator(device=dev).manual_seed(1000 + lo)
+    pcm = torch.randn(SUB, 480000, generator=g, device=dev) * 0.1    # every sub-batch reuses one resident buffer
+    melt = torch.zeros(SUB, 3002, hp.n_mels, device=dev)
+    enc = torch.empty(SUB, 1500, hp.n_audio_state, device=dev)
+    lens = np.full(SUB, 480000)
+    prompt = [50258, 50259, 50359, 50363]
+    stage = {"logmel": 0.0, "encoder": 0.0, "decode": 0.0}
+
+    def step():
+        t0 = time.perf_counter()
+        lm.compute_device(pcm.data_ptr(), 480000, lens, 0, melt.data_ptr(), stream=0)
+        lm.synchronize()
+        t1 = time.perf_counter()
+        model.encode_device(melt.data_ptr(), SUB, enc.data_ptr())
+        model.synchronize()
+        t2 = time.perf_counter()
+        toks = model.decode_greedy_device(enc.data_ptr(), SUB, prompt, NEW)
+        t3 = time.perf_counter()
+        stage["logmel"] += t1 - t0
+        stage["encoder"] += t2 - t1
+        stage["decode"] += t3 - t2
+        return toks
+
+    def barrier():
+        if dist:
+            dist.barrier()
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    if dist:
+        _flush_c_stdout()
+        barrier()
+    for k in stage:
+        stage[k] = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        toks = step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    per_rank = _gather_ms(dist, dt * 1e3, dev)
+    dt, clips_total = reduce_job_stats(dt, SUB * args.steps, device=dev)
+    if rank == 0:
+        enc_flops = 87.4e9 * SUB * args.steps                     # SURVEY.md 8d: Whisper-base encoder per 30 s clip
+        peak = 157.3 if args.precision == 0 else 2500.0
+        ach = enc_flops / stage["encoder"] / 1e12
+        print(json.dumps({
+            "metric": "Whisper-base full transcribe RTFx (seconds of audio per wall second, whole job)",
+            "value": clips_total * 30.0 / dt, "unit": "x real time (whole job)",
+            "n_gpus": world_reported, "steps": args.steps, "warmup": max(1, args.warmup),
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == 0 else "f16 operands / f32 accumulate", "data": "synthetic",
+            "per_rank_ms": per_rank,
+            "config": {"workload": f"Whisper-base full transcribe (BASELINE configs[4]): {SUB * args.steps} x 30 s clips per "
+                                   f"GPU in sub-batches of {SUB}, {NEW} greedy tokens per clip, seeded random-init weights",
+                       "clips_per_gpu": SUB * args.steps, "clips_per_step": SUB, "new_tokens": NEW,
+                       "sharding": f"clips x{world_reported}, no collective", "clips_per_s": clips_total / dt,
+                       "stage_ms_per_step": {k: v / args.steps * 1e3 for k, v in stage.items()},
+                       "tokens_shape": list(np.asarray(toks).shape)},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                         "traffic": None, "kernel": "encoder GEMMs + attention (87.4 GFLOP per clip)",
+                         "note": "encoder wall time of rank 0 incl. launch gaps; peak = dense "
+                                 + ("f32-input MFMA" if args.precision == 0 else "f16 MFMA")},
+        }), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=("cfg2", "cfg5"), default="cfg2",
+                    help="cfg2 = batched RNNoise (BASELINE configs[1], the headline); cfg5 = Whisper-base full "
+                         "transcribe shards (BASELINE configs[4])")
+    ap.add_argument("--streams", type=int, default=4096, help="cfg2: streams per GPU")
+    ap.add_argument("--frames", type=int, default=100, help="cfg2: frames per stream per step")
+    ap.add_argument("--clips", type=int, default=256, help="cfg5: 30 s clips per step (sub-batch) per GPU")
+    ap.add_argument("--new-tokens", type=int, default=32, help="cfg5: greedy tokens per clip")
+    ap.add_argument("--precision", type=int, default=0, help="cfg5: 0 = f32 operands, 1 = f16 operands (ggml numerics)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-asr", action="store_true", help="skip the Whisper-tiny leg of the metric")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher self-test on CPU (gloo, no GPU work, no value); used by tests/test_sharding_gloo.py")
+    args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 4 if args.workload == "cfg5" else 10
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+
+    # One process per GPU.  Under a launcher (torch.distributed.run sets WORLD_SIZE) this process IS a rank; without
+    # one, --gpus N > 1 starts its own N ranks as fresh children BEFORE anything here has imported torch or touched
+    # the GPU (no exec), relays rank 0's JSON line and exits with the job's code.  N = 1 stays in-process, so
+    # `rocprofv3 ... -- python3 bench.py` profiles a single process.
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            from crispy_amd.launch import spawn_ranks
+            sys.exit(spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks; "
+              "refusing to report one as the other", file=sys.stderr)
+        sys.exit(2)
+    if args.dry_run:
+        return dry_run(args)
+    if args.workload == "cfg5":
+        return cfg5(args)
+    return cfg2(args)
+
+
+def cfg2(args):
+    import torch
+
+    rank, local_rank, world = _dist_env()
+    dist, world_reported = _init_dist("nccl", local_rank, world)
+    use_dist = dist is not None
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -243,10 +435,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     if use_dist:
-        # RCCL prints its version banner to C stdout when the communicator comes up (first collective above);
-        # push it out now on every rank so that rank 0's JSON line is the last thing on stdout
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
+        _flush_c_stdout()
         barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -255,6 +444,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    per_rank_ms = _gather_ms(dist, dt * 1e3, dev)
     # max time over ranks, frames summed over ranks (two tiny RCCL all-reduces)
     dt, frames_total = reduce_job_stats(dt, B * T * args.steps, device=dev)
 
@@ -299,13 +489,13 @@ def main():
             "metric": "concurrent real-time 48 kHz streams/GPU (RNNoise)",
             "value": fps / 100.0,
             "unit": "concurrent real-time 48 kHz streams (whole job)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world_reported, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic", "per_rank_ms": per_rank_ms,
             "config": {"workload": f"Batched RNNoise: {B} concurrent 48 kHz mono streams per GPU x {T} frames per step "
                                    f"(BASELINE configs[1]), seeded synthetic int8 weights",
-                       "streams_per_gpu": B, "frames_per_step": T, "sharding": f"streams x{world}, no collective",
+                       "streams_per_gpu": B, "frames_per_step": T, "sharding": f"streams x{world_reported}, no collective",
                        "frames_per_s": fps, "output_finite": finite},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -51,3 +51,64 @@ def test_two_rank_gloo_job_stats_and_assembly():
         assert elapsed == 1.5            # max over ranks
         assert frames == 1000            # all 10 streams x 100 frames
         assert sum(gathered, []) == [2.0 * i for i in range(10)]   # shards tile the stream ids in order
+
+
+# ---- bench.py's own launcher (crispy_amd/launch.py): `python bench.py --gpus 2` with no WORLD_SIZE starts 2 ranks ----
+import json
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(args, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")):
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, capture_output=True,
+                          text=True, timeout=300)
+
+
+def test_bench_gpus2_spawns_two_ranks_and_relays_rank0_json():
+    """The launcher path of `bench.py --gpus N` (gloo dry run: rank env plumbing, barrier, reductions, JSON relay)."""
+    r = _bench(["--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1", "--streams", "10", "--frames", "7"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = [ln for ln in r.stdout.splitlines() if ln.strip()][-1]
+    line = json.loads(last)                                   # rank 0's JSON line is the LAST stdout line
+    assert line["n_gpus"] == 2                                # as the process group reports it, not as --gpus says
+    assert len(line["per_rank_ms"]) == 2 and all(ms > 0 for ms in line["per_rank_ms"])
+    assert line["frames_total"] == 2 * 10 * 7 * 3             # weak scaling: both ranks' frames are summed
+    assert line["ms_per_step"] * 3 >= max(line["per_rank_ms"]) - 1e-6   # max over ranks
+    assert line["data"] == "dry-run" and line["value"] is None
+
+
+def test_bench_launcher_fails_when_a_rank_fails():
+    r = _bench(["--gpus", "2", "--dry-run", "--steps", "2"], {"CRISPY_BENCH_DRY_FAIL_RANK": "1"})
+    assert r.returncode == 3
+    assert not any(ln.startswith("{") for ln in r.stdout.splitlines())      # no JSON line from a failed job
+    assert "rank 1 exited with 3" in r.stderr
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    r = _bench(["--gpus", "2", "--dry-run"], {"WORLD_SIZE": "3", "RANK": "0"}, drop=())
+    assert r.returncode == 2 and "refusing" in r.stderr
+
+
+def test_bench_under_an_external_launcher_is_a_rank_not_a_parent():
+    """What the driver does: torch.distributed.run starts the ranks; bench.py must not spawn again."""
+    from crispy_amd.launch import free_port
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    jl = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(jl) == 1 and json.loads(jl[0])["n_gpus"] == 2
+
+
+def test_rank_env_contents():
+    from crispy_amd.launch import rank_env
+    e = rank_env(3, 8, 12345, base={})
+    assert (e["RANK"], e["LOCAL_RANK"], e["WORLD_SIZE"], e["MASTER_ADDR"], e["MASTER_PORT"]) == \
+        ("3", "3", "8", "127.0.0.1", "12345")
+    assert e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
