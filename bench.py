@@ -346,7 +346,7 @@ def cfg5(args):
                        "clips_per_gpu": SUB * args.steps, "clips_per_step": SUB, "new_tokens": NEW,
                        "sharding": f"clips x{world_reported}, no collective", "clips_per_s": clips_total / dt,
                        "stage_ms_per_step": {k: v / args.steps * 1e3 for k, v in stage.items()},
-                       "tokens_shape": list(np.asarray(toks).shape)},
+                       "tokens_shape": list(np.asarray(toks[0]).shape)},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                          "traffic": None, "kernel": "encoder GEMMs + attention (87.4 GFLOP per clip)",
                          "note": "encoder wall time of rank 0 incl. launch gaps; peak = dense "

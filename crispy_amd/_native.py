@@ -27,6 +27,7 @@ RN_SYMBOLS = (
     "crispy_rn_set_timing", "crispy_rn_last_kernel_ms",
     "crispy_rn_debug_capture", "crispy_rn_debug_read", "crispy_rn_stage_rnn_device",
     "crispy_host_register", "crispy_host_unregister",
+    "crispy_rn_weights_from_file", "crispy_rn_create_from_file", "crispy_selftest_exception_guard",
 )
 
 
@@ -37,10 +38,17 @@ ASR_SYMBOLS = ("crispy_asr_create", "crispy_asr_set_tensor", "crispy_asr_finaliz
                "crispy_asr_set_suppress", "crispy_asr_decode_greedy_device", "crispy_asr_transcribe_tokens",
                "crispy_asr_load", "crispy_asr_token_text", "crispy_asr_transcribe", "crispy_asr_free_result",
                "crispy_asr_decode_greedy_lang_device", "crispy_asr_detect_language_device",
-               "crispy_asr_transcribe_batch", "crispy_asr_decode_timestamps_device", "crispy_asr_set_precision")
+               "crispy_asr_transcribe_batch", "crispy_asr_decode_timestamps_device", "crispy_asr_set_precision",
+               "crispy_asr_vocab_specials")
 RS_SYMBOLS = ("crispy_resampler_create", "crispy_resampler_destroy", "crispy_resampler_out_len",
               "crispy_resampler_process_device", "crispy_resampler_synchronize")
 ALL_SYMBOLS = RN_SYMBOLS + MEL_SYMBOLS + ASR_SYMBOLS + RS_SYMBOLS
+
+class AsrSpecials(C.Structure):
+    """crispy_asr_specials"""
+    _fields_ = [(k, C.c_int) for k in ("eot", "sot", "lang0", "n_lang", "translate", "transcribe", "solm", "prev",
+                                       "nosp", "notimestamps", "beg", "multilingual")]
+
 
 class AsrOpts(C.Structure):
     """crispy_asr_opts"""
@@ -92,6 +100,10 @@ def lib() -> C.CDLL:
     L.crispy_device_count.restype = C.c_int
     L.crispy_rn_create.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.crispy_rn_destroy.argtypes = [C.c_void_p]
+    L.crispy_rn_weights_from_file.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t]
+    L.crispy_rn_create_from_file.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.crispy_selftest_exception_guard.argtypes = [C.c_int]
+    L.crispy_asr_vocab_specials.argtypes = [C.c_int, C.c_void_p]
     L.crispy_rn_destroy.restype = None
     L.crispy_rn_reset.argtypes = [C.c_void_p, C.c_int]
     L.crispy_rn_n_streams.argtypes = [C.c_void_p]

@@ -4,25 +4,43 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <exception>
+#include <new>
+#include <stdexcept>
 #include <string>
 
 namespace crispy {
 
 namespace {
-thread_local std::string g_last_error;
+// fixed storage: recording an error must not allocate (it is what runs after a std::bad_alloc)
+thread_local char g_last_error[768] = "";
 }
 
 int fail(int code, const char* fmt, ...) {
-  char buf[768];
+  char buf[sizeof(g_last_error)];      // fmt's arguments may point into g_last_error ("%s" of the previous message)
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(buf, sizeof(buf), fmt, ap);
   va_end(ap);
-  g_last_error = buf;
+  std::memcpy(g_last_error, buf, sizeof(buf));
   return code;
 }
 
-const char* last_error_cstr() { return g_last_error.c_str(); }
+const char* last_error_cstr() { return g_last_error; }
+
+int fail_exception(const char* where) noexcept {
+  try {
+    throw;
+  } catch (const std::bad_alloc&) {
+    return fail(CRISPY_ERR_OOM, "%s: host allocation failed (std::bad_alloc)", where);
+  } catch (const std::length_error& e) {
+    return fail(CRISPY_ERR_OOM, "%s: %s (std::length_error)", where, e.what());
+  } catch (const std::exception& e) {
+    return fail(CRISPY_ERR_HIP, "%s: unexpected C++ exception: %s", where, e.what());
+  } catch (...) {
+    return fail(CRISPY_ERR_HIP, "%s: unexpected non-standard C++ exception", where);
+  }
+}
 
 bool device_is_gfx950(int dev) {
   hipDeviceProp_t prop;

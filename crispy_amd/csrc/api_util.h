@@ -12,6 +12,10 @@ const char* last_error_cstr();
 // CRISPY_OK if `device` is a usable gfx950 device, else an error with `who` in the message.
 int check_device(int device, const char* who);
 bool device_is_gfx950(int dev);
+// Called from a catch (...) handler of an extern "C" entry point: classifies the exception in flight
+// (std::bad_alloc / std::length_error -> CRISPY_ERR_OOM, anything else -> CRISPY_ERR_HIP), records a message and
+// returns the status.  Never throws (the message buffer is a fixed thread-local array).
+int fail_exception(const char* where) noexcept;
 
 }  // namespace crispy
 
@@ -22,3 +26,8 @@ bool device_is_gfx950(int dev);
       return ::crispy::fail(_e == hipErrorOutOfMemory ? CRISPY_ERR_OOM : CRISPY_ERR_HIP, "%s: %s", #expr, \
                             hipGetErrorString(_e));                                                \
   } while (0)
+
+// Every extern "C" definition is a function-try-block closed by one of these: nothing unwinds into the caller
+// (the reference host builds with panic=abort, Cargo.toml:10-20; a C++ exception crossing the FFI is UB there).
+#define CRISPY_CATCH_RET(name) catch (...) { return ::crispy::fail_exception(name); }
+#define CRISPY_CATCH_VOID(name) catch (...) { (void)::crispy::fail_exception(name); }

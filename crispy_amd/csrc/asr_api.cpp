@@ -67,7 +67,7 @@ int mel_check_lengths(const int* n_samples, int batch, long stride) {
 
 extern "C" {
 
-int crispy_mel_create(const float* filters, int n_mel, int device, crispy_mel** out) {
+int crispy_mel_create(const float* filters, int n_mel, int device, crispy_mel** out) try {
   if (!out) return fail(CRISPY_ERR_INVALID_ARG, "crispy_mel_create: out is NULL");
   *out = nullptr;
   if (!filters || n_mel <= 0 || n_mel > MEL_MAX_MELS)
@@ -116,9 +116,9 @@ int crispy_mel_create(const float* filters, int n_mel, int device, crispy_mel** 
   if (rc != CRISPY_OK) { crispy_mel_destroy(h); return rc; }
   *out = h;
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_mel_create")
 
-void crispy_mel_destroy(crispy_mel* h) {
+void crispy_mel_destroy(crispy_mel* h) try {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -126,10 +126,10 @@ void crispy_mel_destroy(crispy_mel* h) {
     if (p) (void)hipFree(p);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
-}
+} CRISPY_CATCH_VOID("crispy_mel_destroy")
 
 int crispy_mel_compute_device(crispy_mel* h, const float* d_pcm, long pcm_stride, const int* n_samples,
-                              int batch, float* d_out, float* d_out_t, void* hip_stream) {
+                              int batch, float* d_out, float* d_out_t, void* hip_stream) try {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_mel_compute_device: NULL handle");
   if (batch < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_mel_compute_device: batch < 0");
   if (batch == 0) return CRISPY_OK;
@@ -155,10 +155,10 @@ int crispy_mel_compute_device(crispy_mel* h, const float* d_pcm, long pcm_stride
   HIP_TRY(mel_launch(a, batch, s));
   h->last_batch = batch;
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_mel_compute_device")
 
 int crispy_mel_compute(crispy_mel* h, const float* pcm, long pcm_stride, const int* n_samples, int batch,
-                       float* out) {
+                       float* out) try {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_mel_compute: NULL handle");
   if (batch < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_mel_compute: batch < 0");
   if (batch == 0) return CRISPY_OK;
@@ -175,10 +175,10 @@ int crispy_mel_compute(crispy_mel* h, const float* pcm, long pcm_stride, const i
                          h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_mel_compute")
 
 int crispy_mel_window_device(crispy_mel* h, const int* clip_idx, const int* seek, int n, float* d_out,
-                             float* d_out_t, void* hip_stream) {
+                             float* d_out_t, void* hip_stream) try {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_mel_window_device: NULL handle");
   if (n < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_mel_window_device: n < 0");
   if (n == 0) return CRISPY_OK;
@@ -204,14 +204,14 @@ int crispy_mel_window_device(crispy_mel* h, const int* clip_idx, const int* seek
   a.seek = h->d_idx + h->cap_batch;
   HIP_TRY(mel_window_launch(a, n, s));
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_mel_window_device")
 
-int crispy_mel_synchronize(crispy_mel* h) {
+int crispy_mel_synchronize(crispy_mel* h) try {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_mel_synchronize: NULL handle");
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_mel_synchronize")
 
 }  // extern "C"
 
@@ -229,13 +229,13 @@ struct crispy_resampler {
 
 extern "C" {
 
-long crispy_resampler_out_len(long n_in) {
+long crispy_resampler_out_len(long n_in) try {
   if (n_in <= 0) return 0;
   const long n_pad = (n_in + RS_CHUNK - 1) / RS_CHUNK * RS_CHUNK;   // last chunk zero-padded (transcription.rs:347-351)
   return n_pad / RS_FFT_IN * RS_FFT_OUT;
-}
+} CRISPY_CATCH_RET("crispy_resampler_out_len")
 
-int crispy_resampler_create(int device, crispy_resampler** out) {
+int crispy_resampler_create(int device, crispy_resampler** out) try {
   if (!out) return fail(CRISPY_ERR_INVALID_ARG, "crispy_resampler_create: out is NULL");
   *out = nullptr;
   int rc = check_device(device, "crispy_resampler_create");
@@ -294,9 +294,9 @@ int crispy_resampler_create(int device, crispy_resampler** out) {
   if (rc != CRISPY_OK) { crispy_resampler_destroy(h); return rc; }
   *out = h;
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_resampler_create")
 
-void crispy_resampler_destroy(crispy_resampler* h) {
+void crispy_resampler_destroy(crispy_resampler* h) try {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -304,10 +304,10 @@ void crispy_resampler_destroy(crispy_resampler* h) {
     if (p) (void)hipFree(p);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
-}
+} CRISPY_CATCH_VOID("crispy_resampler_destroy")
 
 int crispy_resampler_process_device(crispy_resampler* h, const float* d_in, long in_stride, long n_in, int batch,
-                                    float scale, int wav_s16, float* d_out, long out_stride, void* hip_stream) {
+                                    float scale, int wav_s16, float* d_out, long out_stride, void* hip_stream) try {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_resampler_process_device: NULL handle");
   if (batch < 0 || n_in < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_resampler_process_device: negative size");
   const long n_out = crispy_resampler_out_len(n_in);
@@ -343,13 +343,13 @@ int crispy_resampler_process_device(crispy_resampler* h, const float* d_in, long
     HIP_TRY(rs_ola(h->d_y, d_out + (long)b0 * out_stride, out_stride, nb, n_blk, s));
   }
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_resampler_process_device")
 
-int crispy_resampler_synchronize(crispy_resampler* h) {
+int crispy_resampler_synchronize(crispy_resampler* h) try {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_resampler_synchronize: NULL handle");
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_resampler_synchronize")
 
 }  // extern "C"

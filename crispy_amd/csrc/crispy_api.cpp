@@ -16,6 +16,7 @@
 #include <cstring>
 #include <new>
 #include <atomic>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -308,16 +309,122 @@ const char* crispy_last_error(void) { return last_error_cstr(); }
 
 const char* crispy_version(void) { return "crispy_hip 0.1.0 gfx950"; }
 
-int crispy_device_count(void) {
+int crispy_device_count(void) try {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   int ok = 0;
   for (int d = 0; d < n; ++d)
     if (device_is_gfx950(d)) ++ok;
   return ok;
-}
+} CRISPY_CATCH_RET("crispy_device_count")
 
-int crispy_rn_create(const int8_t* weights, size_t nbytes, int n_streams, int device, crispy_rn** out) {
+// ---- rnnoise-nu text model files (RnnModel::from_read upstream [UPSTREAM-RECALL, SURVEY Appendix A.7]) ----
+// "rnnoise-nu model file version 1\n", then whitespace-separated decimal integers: per layer `n_in n_out activation`
+// followed by its arrays; file order input_dense, vad_gru, noise_gru, denoise_gru, denoise_output, vad_output;
+// activation ids 0 tanh, 1 sigmoid, 2 ReLU.  The topology is fixed, so sizes and activations are checked,
+// not obeyed.  Output: the flat blob crispy_rn_create takes (layer order input_dense, vad_gru, vad_output,
+// noise_gru, denoise_gru, denoise_output).
+int crispy_rn_weights_from_file(const char* path, int8_t* blob, size_t blob_bytes) try {
+  if (!path || !blob) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_weights_from_file: NULL argument");
+  if (blob_bytes != (size_t)RN_WEIGHT_BYTES)
+    return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_weights_from_file: blob must hold %d bytes (got %zu)", RN_WEIGHT_BYTES,
+                blob_bytes);
+  FILE* f = std::fopen(path, "rb");
+  if (!f) return fail(CRISPY_ERR_BAD_MODEL, "crispy_rn_weights_from_file: cannot open '%s'", path);
+  struct Closer { FILE* f; ~Closer() { std::fclose(f); } } closer{f};
+  char header[64] = {0};
+  if (!std::fgets(header, sizeof(header), f)) return fail(CRISPY_ERR_BAD_MODEL, "crispy_rn_weights_from_file: empty file");
+  {
+    size_t n = std::strlen(header);
+    while (n && (header[n - 1] == '\n' || header[n - 1] == '\r' || header[n - 1] == ' ')) header[--n] = 0;
+  }
+  if (std::strcmp(header, "rnnoise-nu model file version 1") != 0)
+    return fail(CRISPY_ERR_BAD_MODEL, "crispy_rn_weights_from_file: not an rnnoise-nu model file (header '%.40s')", header);
+  struct Layer { const char* name; bool gru; int n_in, n_out, act; size_t off; };
+  // blob offsets follow the blob's layer order, the table follows the FILE's layer order
+  size_t off[6];
+  {
+    const int kind[6] = {0, 1, 0, 1, 1, 0}, nin[6] = {42, 24, 24, 90, 114, 96}, nout[6] = {24, 24, 1, 48, 96, 22};
+    size_t o = 0;
+    for (int i = 0; i < 6; ++i) {
+      off[i] = o;
+      o += kind[i] ? (size_t)nin[i] * 3 * nout[i] + (size_t)nout[i] * 3 * nout[i] + 3 * nout[i]
+                   : (size_t)nin[i] * nout[i] + nout[i];
+    }
+    if (o != (size_t)RN_WEIGHT_BYTES) return fail(CRISPY_ERR_HIP, "crispy_rn_weights_from_file: layout table is wrong");
+  }
+  const Layer layers[6] = {
+      {"input_dense", false, 42, 24, 0, off[0]},   {"vad_gru", true, 24, 24, 2, off[1]},
+      {"noise_gru", true, 90, 48, 2, off[3]},      {"denoise_gru", true, 114, 96, 2, off[4]},
+      {"denoise_output", false, 96, 22, 1, off[5]}, {"vad_output", false, 24, 1, 1, off[2]},
+  };
+  auto next_int = [&](long* v) -> bool {
+    int c;
+    do { c = std::fgetc(f); } while (c == ' ' || c == '\n' || c == '\r' || c == '\t');
+    if (c == EOF) return false;
+    bool neg = false;
+    if (c == '-' || c == '+') { neg = c == '-'; c = std::fgetc(f); }
+    if (c < '0' || c > '9') return false;
+    long x = 0;
+    int digits = 0;
+    while (c >= '0' && c <= '9') {
+      if (++digits > 9) return false;
+      x = x * 10 + (c - '0');
+      c = std::fgetc(f);
+    }
+    if (c != EOF && c != ' ' && c != '\n' && c != '\r' && c != '\t') return false;   // "12x", "1.5": not an integer
+    *v = neg ? -x : x;
+    return true;
+  };
+  for (const Layer& L : layers) {
+    long hdr[3];
+    for (long& v : hdr)
+      if (!next_int(&v)) return fail(CRISPY_ERR_BAD_MODEL, "crispy_rn_weights_from_file: truncated model file (%s header)", L.name);
+    if (hdr[0] != L.n_in || hdr[1] != L.n_out)
+      return fail(CRISPY_ERR_BAD_MODEL, "crispy_rn_weights_from_file: %s: expected %dx%d, file has %ldx%ld", L.name, L.n_in,
+                  L.n_out, hdr[0], hdr[1]);
+    if (hdr[2] != L.act)
+      return fail(CRISPY_ERR_BAD_MODEL, "crispy_rn_weights_from_file: %s: unsupported activation id %ld", L.name, hdr[2]);
+    const size_t count = L.gru ? (size_t)L.n_in * 3 * L.n_out + (size_t)L.n_out * 3 * L.n_out + 3 * L.n_out
+                               : (size_t)L.n_in * L.n_out + L.n_out;
+    for (size_t i = 0; i < count; ++i) {
+      long v;
+      if (!next_int(&v)) return fail(CRISPY_ERR_BAD_MODEL, "crispy_rn_weights_from_file: truncated model file (%s)", L.name);
+      if (v < -128 || v > 127)
+        return fail(CRISPY_ERR_BAD_MODEL, "crispy_rn_weights_from_file: %s: weight %ld out of int8 range", L.name, v);
+      blob[L.off + i] = (int8_t)v;
+    }
+  }
+  return CRISPY_OK;
+} CRISPY_CATCH_RET("crispy_rn_weights_from_file")
+
+int crispy_rn_create_from_file(const char* path, int n_streams, int device, crispy_rn** out) try {
+  if (!out) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_create_from_file: out is NULL");
+  *out = nullptr;
+  std::vector<int8_t> blob(RN_WEIGHT_BYTES);
+  const int rc = crispy_rn_weights_from_file(path, blob.data(), blob.size());
+  if (rc != CRISPY_OK) return rc;
+  return crispy_rn_create(blob.data(), blob.size(), n_streams, device, out);
+} CRISPY_CATCH_RET("crispy_rn_create_from_file")
+
+// Self-test of the exception guard every entry point is wrapped in (tests/test_abi_and_host.py): throws the
+// requested kind inside a guarded body and reports what the guard turned it into.
+int crispy_selftest_exception_guard(int kind) try {
+  switch (kind) {
+    case 1: throw std::bad_alloc();
+    case 2: throw std::length_error("vector::_M_default_append");
+    case 3: throw std::runtime_error("selftest");
+    case 4: throw 42;
+    case 5: {   // a real allocation failure, not a simulated one: more elements than any allocator can give
+      std::vector<double> v;
+      v.resize(v.max_size());
+      return (int)v.size();
+    }
+    default: return CRISPY_OK;
+  }
+} CRISPY_CATCH_RET("crispy_selftest_exception_guard")
+
+int crispy_rn_create(const int8_t* weights, size_t nbytes, int n_streams, int device, crispy_rn** out) try {
   if (!out) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_create: out is NULL");
   *out = nullptr;
   if (!weights || nbytes != (size_t)RN_WEIGHT_BYTES)
@@ -408,26 +515,26 @@ int crispy_rn_create(const int8_t* weights, size_t nbytes, int n_streams, int de
   }
   *out = h;
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_rn_create")
 
 void crispy_rn_destroy(crispy_rn* h) { free_all(h); }
 
 int crispy_rn_n_streams(const crispy_rn* h) { return h ? h->B : 0; }
 
 int crispy_rn_frames_per_launch(void) { return kSubFrames; }
-int crispy_rn_n_launches(int n_frames) {
+int crispy_rn_n_launches(int n_frames) try {
   int n = 0;
   for (int t0 = 0; t0 < n_frames; t0 += kChunkFrames) n += count_subs(n_frames - t0 < kChunkFrames ? n_frames - t0 : kChunkFrames);
   return n;
-}
+} CRISPY_CATCH_RET("crispy_rn_n_launches")
 
-int crispy_rn_set_pipeline(crispy_rn* h, int staged) {
+int crispy_rn_set_pipeline(crispy_rn* h, int staged) try {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_set_pipeline: NULL handle");
   h->staged = staged != 0;
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_rn_set_pipeline")
 
-int crispy_rn_reset(crispy_rn* h, int stream) {
+int crispy_rn_reset(crispy_rn* h, int stream) try {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_reset: NULL handle");
   if (stream < -1 || stream >= h->B)
     return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_reset: stream %d out of range", stream);
@@ -436,10 +543,10 @@ int crispy_rn_reset(crispy_rn* h, int stream) {
   if (rc != CRISPY_OK) return rc;
   HIP_TRY(hipStreamSynchronize(h->stream));
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_rn_reset")
 
 int crispy_rn_process_device(crispy_rn* h, const float* d_in, float* d_out, float* d_vad, float* d_taps,
-                             int n_frames, crispy_rn_layout layout, void* hip_stream) {
+                             int n_frames, crispy_rn_layout layout, void* hip_stream) try {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_process_device: NULL handle");
   if (n_frames < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_process_device: n_frames < 0");
   if (n_frames == 0) return CRISPY_OK;
@@ -453,7 +560,7 @@ int crispy_rn_process_device(crispy_rn* h, const float* d_in, float* d_out, floa
   const long stride_t = layout == CRISPY_RN_LAYOUT_TBF ? (long)h->B * RN_FRAME : (long)RN_FRAME;
   const long stride_b = layout == CRISPY_RN_LAYOUT_TBF ? (long)RN_FRAME : (long)n_frames * RN_FRAME;
   return process_device_impl(h, d_in, d_out, d_vad, d_taps, n_frames, stride_t, stride_b, s);
-}
+} CRISPY_CATCH_RET("crispy_rn_process_device")
 
 }  // extern "C"
 
@@ -583,20 +690,20 @@ int process_device_impl(crispy_rn* h, const float* d_in, float* d_out, float* d_
 
 extern "C" {
 
-int crispy_host_register(void* p, size_t bytes) {
+int crispy_host_register(void* p, size_t bytes) try {
   if (!p || bytes == 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_host_register: NULL pointer or zero size");
   HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_host_register")
 
-int crispy_host_unregister(void* p) {
+int crispy_host_unregister(void* p) try {
   if (!p) return fail(CRISPY_ERR_INVALID_ARG, "crispy_host_unregister: NULL pointer");
   HIP_TRY(hipHostUnregister(p));
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_host_unregister")
 
 int crispy_rn_process(crispy_rn* h, const float* in, float* out, float* vad, int n_frames,
-                      crispy_rn_layout layout) {
+                      crispy_rn_layout layout) try {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_process: NULL handle");
   if (n_frames < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_process: n_frames < 0");
   if (n_frames == 0) return CRISPY_OK;
@@ -666,7 +773,7 @@ int crispy_rn_process(crispy_rn* h, const float* in, float* out, float* vad, int
   std::atomic<int> recorded{0};          // pieces whose "frame kernels done" event has been recorded by this call
   std::atomic<bool> abort_flag{false};
   hipError_t drain_err = hipSuccess;
-  std::thread drain([&]() {
+  std::thread drain([&]() noexcept {
     if (hipSetDevice(h->device) != hipSuccess) { drain_err = hipErrorInvalidDevice; return; }
     for (int i = 0; i < n_pieces; ++i) {
       while (recorded.load(std::memory_order_acquire) <= i) {
@@ -683,6 +790,15 @@ int crispy_rn_process(crispy_rn* h, const float* in, float* out, float* vad, int
     }
     drain_err = hipStreamSynchronize(h->d2h_stream);
   });
+  // an exception between here and the join below (the thread constructor itself throws std::system_error before this
+  // line) must not destroy a joinable std::thread -- that is std::terminate, i.e. an abort of the Rust host
+  struct JoinOnUnwind {
+    std::thread& t;
+    std::atomic<bool>& stop;
+    ~JoinOnUnwind() {
+      if (t.joinable()) { stop.store(true, std::memory_order_release); t.join(); }
+    }
+  } join_on_unwind{drain, abort_flag};
   int rc = CRISPY_OK;
   hipError_t feed_err = hipSuccess;
   for (int i = 0; i < n_pieces && rc == CRISPY_OK && feed_err == hipSuccess; ++i) {
@@ -707,24 +823,24 @@ int crispy_rn_process(crispy_rn* h, const float* in, float* out, float* vad, int
   if (drain_err != hipSuccess)
     return fail(CRISPY_ERR_HIP, "crispy_rn_process: copy-out failed: %s", hipGetErrorString(drain_err));
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_rn_process")
 
-int crispy_rn_synchronize(crispy_rn* h) {
+int crispy_rn_synchronize(crispy_rn* h) try {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_synchronize: NULL handle");
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_rn_synchronize")
 
-int crispy_rn_set_timing(crispy_rn* h, int enable) {
+int crispy_rn_set_timing(crispy_rn* h, int enable) try {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_set_timing: NULL handle");
   h->timing = enable != 0;
   h->ev_used = 0;
   h->seg_subs.clear();
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_rn_set_timing")
 
-int crispy_rn_last_kernel_ms(crispy_rn* h, float* frame_kernel_ms, float* total_ms) {
+int crispy_rn_last_kernel_ms(crispy_rn* h, float* frame_kernel_ms, float* total_ms) try {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_last_kernel_ms: NULL handle");
   if (!h->timing || h->ev_used == 0)
     return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_last_kernel_ms: no timed call recorded");
@@ -746,10 +862,10 @@ int crispy_rn_last_kernel_ms(crispy_rn* h, float* frame_kernel_ms, float* total_
   if (frame_kernel_ms) *frame_kernel_ms = fk;
   if (total_ms) *total_ms = tot;
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_rn_last_kernel_ms")
 
 int crispy_rn_stage_rnn_device(crispy_rn* h, const float* d_feat, const unsigned char* d_silent, float* d_g_raw,
-                               float* d_g_smooth, float* d_vad, int n_frames, void* hip_stream) {
+                               float* d_g_smooth, float* d_vad, int n_frames, void* hip_stream) try {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_stage_rnn_device: NULL handle");
   if (n_frames < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_stage_rnn_device: n_frames < 0");
   if (n_frames == 0) return CRISPY_OK;
@@ -764,9 +880,9 @@ int crispy_rn_stage_rnn_device(crispy_rn* h, const float* d_feat, const unsigned
   a.tansig = reinterpret_cast<const float*>(reinterpret_cast<const char*>(h->d_tab) + offsetof(RnTables, tansig));
   HIP_TRY(rn_launch_rnn(a, hip_stream ? (hipStream_t)hip_stream : h->stream));
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_rn_stage_rnn_device")
 
-int crispy_rn_debug_capture(crispy_rn* h, int enable) {
+int crispy_rn_debug_capture(crispy_rn* h, int enable) try {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_debug_capture: NULL handle");
   HIP_TRY(hipSetDevice(h->device));
   if (enable && !h->d_dbg) {
@@ -778,9 +894,9 @@ int crispy_rn_debug_capture(crispy_rn* h, int enable) {
     h->d_dbg = nullptr;
   }
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_rn_debug_capture")
 
-int crispy_rn_debug_read(crispy_rn* h, int stream, float* dst, size_t n_floats) {
+int crispy_rn_debug_read(crispy_rn* h, int stream, float* dst, size_t n_floats) try {
   if (!h || !dst) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_debug_read: NULL argument");
   if (!h->d_dbg) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_debug_read: capture not enabled");
   if (stream < 0 || stream >= h->B || n_floats > (size_t)RN_DBG_FLOATS)
@@ -790,6 +906,6 @@ int crispy_rn_debug_read(crispy_rn* h, int stream, float* dst, size_t n_floats) 
   HIP_TRY(hipMemcpy(dst, h->d_dbg + (size_t)stream * RN_DBG_FLOATS, n_floats * sizeof(float),
                     hipMemcpyDeviceToHost));
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_rn_debug_read")
 
 }  // extern "C"

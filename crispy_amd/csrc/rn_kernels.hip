@@ -1055,7 +1055,8 @@ struct alignas(16) RnLdsT {
 static_assert(sizeof(RnLdsT<0>) <= 10240, "16 workgroups per CU need <= 10 KB of LDS each");
 
 // offsets (floats) inside Bb while it serves the RNN
-constexpr int RB_FEAT = 0, RB_DENSE = 48, RB_IN = 72, RB_Z = 192, RB_HR = 288, RB_PART = 384;
+constexpr int RB_FEAT = 0, RB_DENSE = 48, RB_IN = 72, RB_Z = 192, RB_PART = 384;
+[[maybe_unused]] constexpr int RB_HR = 288;
 // RB_IMG: two split f16 activation images (3 terms x RN_IMG_LD halves each = 2 x 204 floats) of the MFMA gain
 // network; shares the floats of RB_PART, which is only used after the network
 constexpr int RB_IMG = 384;
@@ -1866,7 +1867,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
       const float S = 1.f / 256.f;
       float* feat = Rb + RB_FEAT;
       float* dense = Rb + RB_DENSE;
-      float* gin = Rb + RB_IN;
+      [[maybe_unused]] float* gin = Rb + RB_IN;     // the f16 / VALU forms of the network (RN_GRU_MFMA 0, 1)
       TansigTab tansig;
       tansig.load(tab->tansig, lane);
 #if RN_GRU_MFMA == 2

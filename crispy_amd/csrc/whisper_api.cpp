@@ -263,7 +263,7 @@ GemmArgs gemm(const float* A, long lda, const float* W, long ldw, float* C, long
 
 extern "C" {
 
-int crispy_asr_create(const crispy_asr_hparams* hp, const float* mel_filters, int device, crispy_asr** out) {
+int crispy_asr_create(const crispy_asr_hparams* hp, const float* mel_filters, int device, crispy_asr** out) try {
   if (!out) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_create: out is NULL");
   *out = nullptr;
   if (!hp || !mel_filters) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_create: NULL argument");
@@ -302,9 +302,9 @@ int crispy_asr_create(const crispy_asr_hparams* hp, const float* mel_filters, in
   }
   *out = h;
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_asr_create")
 
-void crispy_asr_free(crispy_asr* h) {
+void crispy_asr_free(crispy_asr* h) try {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -321,9 +321,9 @@ void crispy_asr_free(crispy_asr* h) {
   if (h->mel) crispy_mel_destroy(h->mel);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
-}
+} CRISPY_CATCH_VOID("crispy_asr_free")
 
-int crispy_asr_set_tensor(crispy_asr* h, const char* name, const float* data, size_t n_elems) {
+int crispy_asr_set_tensor(crispy_asr* h, const char* name, const float* data, size_t n_elems) try {
   if (!h || !name || !data) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_set_tensor: NULL argument");
   if (h->finalized) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_set_tensor: model already finalized");
   auto it = h->tensors.find(name);
@@ -335,9 +335,9 @@ int crispy_asr_set_tensor(crispy_asr* h, const char* name, const float* data, si
   HIP_TRY(hipMemcpy(it->second.d, data, n_elems * sizeof(float), hipMemcpyHostToDevice));
   it->second.set = true;
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_asr_set_tensor")
 
-int crispy_asr_finalize(crispy_asr* h) {
+int crispy_asr_finalize(crispy_asr* h) try {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_finalize: NULL handle");
   if (h->finalized) return CRISPY_OK;
   for (const auto& kv : h->tensors)
@@ -402,16 +402,16 @@ int crispy_asr_finalize(crispy_asr* h) {
   { const int mrc = build_ts_masks(h); if (mrc != CRISPY_OK) return mrc; }
   h->finalized = true;
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_asr_finalize")
 
-int crispy_asr_hparams_get(const crispy_asr* h, crispy_asr_hparams* out) {
+int crispy_asr_hparams_get(const crispy_asr* h, crispy_asr_hparams* out) try {
   if (!h || !out) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_hparams_get: NULL argument");
   *out = h->hp;
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_asr_hparams_get")
 
 // mel (frame-major, padded) -> encoder output [B][1500][d]
-int crispy_asr_set_precision(crispy_asr* h, int mode) {
+int crispy_asr_set_precision(crispy_asr* h, int mode) try {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_set_precision: NULL handle");
   if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_set_precision: model not finalized");
   if (mode != 0 && mode != 1) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_set_precision: mode must be 0 (f32) or 1 (f16 encoder GEMM operands)");
@@ -443,9 +443,9 @@ int crispy_asr_set_precision(crispy_asr* h, int mode) {
   }
   h->enc_precision = mode;
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_asr_set_precision")
 
-int crispy_asr_encode_device(crispy_asr* h, const float* d_mel_t, int batch, float* d_out, void* hip_stream) {
+int crispy_asr_encode_device(crispy_asr* h, const float* d_mel_t, int batch, float* d_out, void* hip_stream) try {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_encode_device: NULL handle");
   if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_encode_device: model not finalized");
   if (batch < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_encode_device: batch < 0");
@@ -504,10 +504,10 @@ int crispy_asr_encode_device(crispy_asr* h, const float* d_mel_t, int batch, flo
   }
   HIP_TRY(layernorm_f32(h->w_x, h->ln_post_w, h->ln_post_b, d_out, rows, d, s));
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_asr_encode_device")
 
 // PCM (host) -> log-mel -> encoder output (host); one call per batch of <= 30 s clips
-int crispy_asr_encode(crispy_asr* h, const float* pcm, long pcm_stride, const int* n_samples, int batch, float* out) {
+int crispy_asr_encode(crispy_asr* h, const float* pcm, long pcm_stride, const int* n_samples, int batch, float* out) try {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_encode: NULL handle");
   if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_encode: model not finalized");
   if (batch < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_encode: batch < 0");
@@ -531,14 +531,14 @@ int crispy_asr_encode(crispy_asr* h, const float* pcm, long pcm_stride, const in
                          hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_asr_encode")
 
-int crispy_asr_synchronize(crispy_asr* h) {
+int crispy_asr_synchronize(crispy_asr* h) try {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_synchronize: NULL handle");
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_asr_synchronize")
 
 }  // extern "C"
 
@@ -664,25 +664,25 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
   return CRISPY_OK;
 }
 
-// special token ids [UPSTREAM-RECALL, whisper.cpp vocab]: sot = eot + 1; multilingual files carry 99 (+extra)
-// language tokens, then translate, transcribe, solm, prev, nosp, notimestamps and the 1501 timestamps
+// special token ids [UPSTREAM-RECALL, whisper.cpp `whisper_vocab` + the shift applied at load time]: the defaults are the
+// English-only layout (n_vocab 51864: eot 50256, sot 50257, translate 50357, transcribe 50358, solm 50359, prev 50360,
+// nosp 50361, notimestamps 50362, first timestamp 50363 -- the 99 language slots after sot are kept in the .en vocabulary
+// although no prompt uses them); a multilingual vocabulary (n_vocab >= 51865) moves eot / sot up by one and everything
+// after the language block by 1 + (number of languages - 99).
 struct Special {
-  int sot, lang0, n_lang, translate, transcribe, solm, prev, nosp, not_, beg;
+  int sot, lang0, n_lang, n_lang_slots, translate, transcribe, solm, prev, nosp, not_, beg;
   bool multilingual;
 };
-Special special_tokens(const crispy_asr* h) {
+Special vocab_specials(int n_vocab) {
   Special sp{};
-  sp.multilingual = h->hp.n_vocab >= 51865;
-  const int extra = sp.multilingual ? h->hp.n_vocab - 51865 : 0;
-  sp.sot = h->eot + 1;
+  sp.multilingual = n_vocab >= 51865;
+  const int extra = sp.multilingual ? n_vocab - 51865 : 0;     // large-v3: one more language
+  const int eot = sp.multilingual ? 50257 : 50256;
+  sp.sot = eot + 1;
   sp.lang0 = sp.sot + 1;
-  if (sp.multilingual) {
-    sp.n_lang = 99 + extra;
-    sp.translate = sp.sot + 100 + extra;
-  } else {
-    sp.n_lang = 0;
-    sp.translate = sp.sot + 1;
-  }
+  sp.n_lang = sp.multilingual ? 99 + extra : 0;                // languages a prompt / the detector can name
+  sp.n_lang_slots = 99 + extra;                                // ids between sot and translate (always suppressed)
+  sp.translate = sp.sot + 100 + extra;
   sp.transcribe = sp.translate + 1;
   sp.solm = sp.translate + 2;
   sp.prev = sp.translate + 3;
@@ -691,6 +691,7 @@ Special special_tokens(const crispy_asr* h) {
   sp.beg = sp.not_ + 1;
   return sp;
 }
+Special special_tokens(const crispy_asr* h) { return vocab_specials(h->hp.n_vocab); }
 
 // cross K | V of every layer once per window, then the prompt tokens one position at a time (the language
 // token may differ per clip); leaves the logits of the last prompt position in h->d_logits
@@ -836,7 +837,7 @@ int generation_body(crispy_asr* h, int batch, hipStream_t s) {
 
 extern "C" {
 
-int crispy_asr_set_suppress(crispy_asr* h, const int* ids, int n, int first_only) {
+int crispy_asr_set_suppress(crispy_asr* h, const int* ids, int n, int first_only) try {
   if (!h || (n > 0 && !ids)) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_set_suppress: NULL argument");
   if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_set_suppress: model not finalized");
   std::vector<unsigned char> m(h->hp.n_vocab, 0);
@@ -854,17 +855,17 @@ int crispy_asr_set_suppress(crispy_asr* h, const int* ids, int n, int first_only
   HIP_TRY(hipMemcpy(h->d_suppress, h->sup_all.data(), h->sup_all.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->d_suppress_first, first.data(), first.size(), hipMemcpyHostToDevice));
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_asr_set_suppress")
 
 int crispy_asr_decode_greedy_device(crispy_asr* h, const float* d_enc, int batch, const int* prompt, int n_prompt,
-                                    int max_new, int* tokens_out, int* n_out, float* logits_out) {
+                                    int max_new, int* tokens_out, int* n_out, float* logits_out) try {
   return crispy_asr_decode_greedy_lang_device(h, d_enc, batch, prompt, n_prompt, nullptr, max_new, tokens_out, n_out,
                                               logits_out);
-}
+} CRISPY_CATCH_RET("crispy_asr_decode_greedy_device")
 
 int crispy_asr_decode_greedy_lang_device(crispy_asr* h, const float* d_enc, int batch, const int* prompt, int n_prompt,
                                          const int* lang_tokens, int max_new, int* tokens_out, int* n_out,
-                                         float* logits_out) {
+                                         float* logits_out) try {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_decode_greedy_device: NULL handle");
   if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_decode_greedy_device: model not finalized");
   if (batch < 0 || max_new < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_decode_greedy_device: negative size");
@@ -934,11 +935,11 @@ int crispy_asr_decode_greedy_lang_device(crispy_asr* h, const float* d_enc, int 
     if (n_out) n_out[b] = n;
   }
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_asr_decode_greedy_lang_device")
 
 int crispy_asr_decode_timestamps_device(crispy_asr* h, const float* d_enc, int batch, const int* prompt, int n_prompt,
                                         const int* lang_tokens, int rules, const int* seek, const int* seek_end,
-                                        int max_new, int* tokens_out, int* tids_out, int* n_out) {
+                                        int max_new, int* tokens_out, int* tids_out, int* n_out) try {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_decode_timestamps_device: NULL handle");
   if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_decode_timestamps_device: model not finalized");
   if (batch < 0 || max_new < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_decode_timestamps_device: negative size");
@@ -957,11 +958,11 @@ int crispy_asr_decode_timestamps_device(crispy_asr* h, const float* d_enc, int b
       return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_decode_timestamps_device: prompt token %d out of range", prompt[i]);
   return decode_ts(h, d_enc, batch, prompt, n_prompt, lang_tokens, rules, seek, seek_end, max_new, h->d_suppress,
                    h->d_suppress_first, tokens_out, tids_out, n_out);
-}
+} CRISPY_CATCH_RET("crispy_asr_decode_timestamps_device")
 
 // whisper.cpp `whisper_lang_auto_detect`: feed <|startoftranscript|> alone and take the most probable
 // language token [UPSTREAM-RECALL].  English-only vocabularies have nothing to detect.
-int crispy_asr_detect_language_device(crispy_asr* h, const float* d_enc, int batch, int* lang_tokens_out) {
+int crispy_asr_detect_language_device(crispy_asr* h, const float* d_enc, int batch, int* lang_tokens_out) try {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_detect_language_device: NULL handle");
   if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_detect_language_device: model not finalized");
   if (batch < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_detect_language_device: batch < 0");
@@ -991,10 +992,10 @@ int crispy_asr_detect_language_device(crispy_asr* h, const float* d_enc, int bat
   HIP_TRY(hipMemcpyAsync(lang_tokens_out, h->d_tok, sizeof(int) * batch, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_asr_detect_language_device")
 
 int crispy_asr_transcribe_tokens(crispy_asr* h, const float* pcm, long pcm_stride, const int* n_samples, int batch,
-                                 const int* prompt, int n_prompt, int max_new, int* tokens_out, int* n_out) {
+                                 const int* prompt, int n_prompt, int max_new, int* tokens_out, int* n_out) try {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_tokens: NULL handle");
   if (batch == 0) return CRISPY_OK;   // managers/transcription.rs:175-177: empty audio -> empty text
   if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_transcribe_tokens: model not finalized");
@@ -1015,7 +1016,7 @@ int crispy_asr_transcribe_tokens(crispy_asr* h, const float* pcm, long pcm_strid
   rc = crispy_asr_encode_device(h, h->w_melt, batch, h->w_enc, h->stream);
   if (rc != CRISPY_OK) return rc;
   return crispy_asr_decode_greedy_device(h, h->w_enc, batch, prompt, n_prompt, max_new, tokens_out, n_out, nullptr);
-}
+} CRISPY_CATCH_RET("crispy_asr_transcribe_tokens")
 
 }  // extern "C"
 
@@ -1117,7 +1118,7 @@ int build_ts_masks(crispy_asr* h) {
   std::vector<unsigned char> m(V, 0);
   for (int t : {sp.sot, sp.nosp, sp.translate, sp.transcribe, sp.prev, sp.solm})
     if (t >= 0 && t < V) m[t] = 1;
-  for (int t = sp.lang0; t < sp.lang0 + sp.n_lang && t < V; ++t) m[t] = 1;
+  for (int t = sp.lang0; t < sp.lang0 + sp.n_lang_slots && t < V; ++t) m[t] = 1;
   std::vector<unsigned char> f = m;
   int blank = 220;                                  // " " in both GPT-2 vocabularies
   for (size_t t = 0; t < h->vocab.size(); ++t)
@@ -1188,7 +1189,7 @@ void publish(crispy_asr_result_impl* r) {
 
 extern "C" {
 
-int crispy_asr_load(const char* model_path, int device, crispy_asr** out) {
+int crispy_asr_load(const char* model_path, int device, crispy_asr** out) try {
   if (!out) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_load: out is NULL");
   *out = nullptr;
   if (!model_path) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_load: NULL path");
@@ -1210,6 +1211,8 @@ int crispy_asr_load(const char* model_path, int device, crispy_asr** out) {
                 MEL_BINS);
   std::vector<float> filters((size_t)fm * ff);
   if (!r.read(filters.data(), filters.size() * 4)) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_load: truncated filters");
+  if (hp.n_vocab <= 0 || hp.n_vocab > 65536)
+    return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_load: n_vocab %d is not a whisper vocabulary size", hp.n_vocab);
   int32_t n_tok = 0;
   if (!r.read(&n_tok, 4) || n_tok < 0 || n_tok > hp.n_vocab + 1024)
     return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_load: bad vocabulary size %d", n_tok);
@@ -1232,6 +1235,9 @@ int crispy_asr_load(const char* model_path, int device, crispy_asr** out) {
   std::vector<float> buf;
   std::vector<uint16_t> hbuf;
   std::vector<uint8_t> qbuf;
+  // a tensor is read only if the model needs it and the file's shape has exactly the element count the
+  // hyper-parameters imply: the buffers below are sized from this table, never from numbers a corrupt file supplies
+  const std::map<std::string, size_t> expect = expected_tensors(hp);
   for (;;) {
     int32_t n_dims = 0, name_len = 0, ttype = 0;
     if (!r.read(&n_dims, 4)) break;  // clean EOF
@@ -1240,13 +1246,27 @@ int crispy_asr_load(const char* model_path, int device, crispy_asr** out) {
       return bail(CRISPY_ERR_BAD_MODEL);
     }
     int32_t ne[4] = {1, 1, 1, 1};
-    size_t n = 1;
+    unsigned long long n64 = 1;          // <= (2^31)^4 would overflow: checked against 2^40 after every factor
     for (int i = 0; i < n_dims; ++i) {
       if (!r.read(&ne[i], 4) || ne[i] <= 0) { fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_load: corrupt tensor shape"); return bail(CRISPY_ERR_BAD_MODEL); }
-      n *= (size_t)ne[i];
+      n64 *= (unsigned long long)ne[i];
+      if (n64 > (1ull << 40)) { fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_load: corrupt tensor shape (element count overflows)"); return bail(CRISPY_ERR_BAD_MODEL); }
     }
+    const size_t n = (size_t)n64;
     std::string name(name_len, '\0');
     if (!r.read(&name[0], name_len)) { fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_load: truncated tensor name"); return bail(CRISPY_ERR_BAD_MODEL); }
+    {
+      const auto it = expect.find(name);
+      if (it == expect.end()) {
+        fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_load: unknown tensor '%s' in model file", name.c_str());
+        return bail(CRISPY_ERR_BAD_MODEL);
+      }
+      if (it->second != n) {
+        fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_load: tensor '%s' has %zu elements, the hyper-parameters imply %zu",
+             name.c_str(), n, it->second);
+        return bail(CRISPY_ERR_BAD_MODEL);
+      }
+    }
     buf.resize(n);
     if (ttype == 0) {
       if (!r.read(buf.data(), n * 4)) { fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_load: truncated data of '%s'", name.c_str()); return bail(CRISPY_ERR_BAD_MODEL); }
@@ -1273,25 +1293,35 @@ int crispy_asr_load(const char* model_path, int device, crispy_asr** out) {
   if (rc != CRISPY_OK) return bail(rc);
   *out = h;
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_asr_load")
 
-int crispy_asr_token_text(const crispy_asr* h, int token, const char** text, size_t* len) {
+int crispy_asr_vocab_specials(int n_vocab, crispy_asr_specials* out) try {
+  if (!out) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_vocab_specials: out is NULL");
+  if (n_vocab < 51864) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_vocab_specials: %d is not a whisper vocabulary size", n_vocab);
+  const Special sp = vocab_specials(n_vocab);
+  out->eot = sp.sot - 1; out->sot = sp.sot; out->lang0 = sp.lang0; out->n_lang = sp.n_lang;
+  out->translate = sp.translate; out->transcribe = sp.transcribe; out->solm = sp.solm; out->prev = sp.prev;
+  out->nosp = sp.nosp; out->notimestamps = sp.not_; out->beg = sp.beg; out->multilingual = sp.multilingual ? 1 : 0;
+  return CRISPY_OK;
+} CRISPY_CATCH_RET("crispy_asr_vocab_specials")
+
+int crispy_asr_token_text(const crispy_asr* h, int token, const char** text, size_t* len) try {
   if (!h || !text || !len) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_token_text: NULL argument");
   if (token < 0 || token >= (int)h->vocab.size())
     return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_token_text: token %d has no vocabulary entry", token);
   *text = h->vocab[token].data();
   *len = h->vocab[token].size();
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_asr_token_text")
 
 int crispy_asr_transcribe(crispy_asr* h, const float* pcm16k, size_t n, const crispy_asr_opts* opts,
-                          crispy_asr_result** out) {
+                          crispy_asr_result** out) try {
   if (!out) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe: out is NULL");
   *out = nullptr;
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe: NULL handle");
   if (n > 0 && !pcm16k) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe: NULL audio");
   return crispy_asr_transcribe_batch(h, &pcm16k, &n, 1, opts, out);
-}
+} CRISPY_CATCH_RET("crispy_asr_transcribe")
 
 // engine.transcribe for a batch of chunks at once; results[i] is library-owned (crispy_asr_free_result each).
 //   no_timestamps = 1: prompt [sot, lang, task, <|notimestamps|>], one window, plain greedy arg-max.
@@ -1300,7 +1330,7 @@ int crispy_asr_transcribe(crispy_asr* h, const float* pcm16k, size_t n, const cr
 //     advances to the last closed timestamp pair, segments are cut at timestamp tokens.  Not reproduced: the
 //     temperature fallback (sampled re-decoding when the entropy / log-probability thresholds reject a window).
 int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const size_t* n, int batch,
-                                const crispy_asr_opts* opts, crispy_asr_result** results) {
+                                const crispy_asr_opts* opts, crispy_asr_result** results) try {
   if (!h || !results) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: NULL argument");
   if (batch < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: batch < 0");
   for (int i = 0; i < batch; ++i) results[i] = nullptr;
@@ -1387,7 +1417,13 @@ int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const si
       // ---- whisper_full's seek loop, all clips in lock step ----
       std::vector<int> seek(nb, 0), seek_end(nb);
       for (int k = 0; k < nb; ++k) seek_end[k] = lens[k] / 160;
-      for (int round = 0; round < 16; ++round) {
+      // whisper.cpp loops until seek + 100 >= seek_end.  Every round advances every active clip by seek_delta >= 2
+      // (a closed pair ends on a timestamp strictly above <|0.00|>, otherwise the delta is the whole window), so
+      // 1500 rounds cover any 30 s clip; running out of them is reported, never a silently shorter transcript.
+      const int kMaxRounds = 1501;
+      for (int round = 0;; ++round) {
+        if (round >= kMaxRounds)
+          return fail(CRISPY_ERR_HIP, "crispy_asr_transcribe_batch: seek loop did not terminate after %d windows", kMaxRounds);
         std::vector<int> act;
         for (int k = 0; k < nb; ++k)
           if (seek_end[k] >= 100 && seek[k] + 100 < seek_end[k]) act.push_back(k);   // < 1 s left: whisper.cpp stops
@@ -1433,11 +1469,11 @@ int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const si
     results[i] = &impl[i]->pub;
   }
   return CRISPY_OK;
-}
+} CRISPY_CATCH_RET("crispy_asr_transcribe_batch")
 
-void crispy_asr_free_result(crispy_asr_result* r) {
+void crispy_asr_free_result(crispy_asr_result* r) try {
   if (!r) return;
   delete reinterpret_cast<crispy_asr_result_impl*>(r);   // pub is the first member
-}
+} CRISPY_CATCH_VOID("crispy_asr_free_result")
 
 }  // extern "C"

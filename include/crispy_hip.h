@@ -60,6 +60,12 @@ const char *crispy_last_error(void);
 const char *crispy_version(void);
 /* Number of usable gfx950 devices (0 when there is none; never fails). */
 int crispy_device_count(void);
+/* Self-test of the boundary's exception guard: every entry point is a function-try-block, so a C++ exception
+ * (std::bad_alloc from a std::vector, std::system_error from a std::thread ...) becomes a status code and a
+ * crispy_last_error() message instead of unwinding into a panic=abort host.  kind: 0 nothing, 1 std::bad_alloc,
+ * 2 std::length_error, 3 std::runtime_error, 4 a non-standard exception, 5 a real failing std::vector::resize.
+ * Returns what the guard made of it (CRISPY_ERR_OOM for 1, 2, 5; CRISPY_ERR_HIP for 3, 4; CRISPY_OK for 0). */
+int crispy_selftest_exception_guard(int kind);
 
 /*
  * DenoiseState::new() for n_streams independent streams (audio.rs:229).
@@ -72,6 +78,18 @@ int crispy_device_count(void);
 int crispy_rn_create(const int8_t *weights, size_t nbytes, int n_streams, int device,
                      crispy_rn **out);
 void crispy_rn_destroy(crispy_rn *h);
+
+/*
+ * Weights from an "rnnoise-nu model file version 1" text file -- the format nnnoiseless' RnnModel::from_read
+ * parses [UPSTREAM-RECALL] -- so that a host without a weight blob of its own (the reference constructs
+ * DenoiseState::new() with the model built into the crate, audio.rs:229; that blob cannot be redistributed from
+ * here) can point the library at a model file instead.  crispy_rn_weights_from_file fills `blob`
+ * (CRISPY_RN_WEIGHT_BYTES bytes, the layout crispy_rn_create takes) without touching a device; the topology is
+ * fixed, so a file whose layer sizes or activation ids differ, that is truncated, or that holds a value outside
+ * int8 is CRISPY_ERR_BAD_MODEL.  crispy_rn_create_from_file = parse + crispy_rn_create.
+ */
+int crispy_rn_weights_from_file(const char *path, int8_t *blob, size_t blob_bytes);
+int crispy_rn_create_from_file(const char *path, int n_streams, int device, crispy_rn **out);
 
 /* Fresh DenoiseState for one stream (stream >= 0) or all of them (stream == -1):
  * what audio.rs:955-965 does by replacing the processor. */
@@ -281,6 +299,16 @@ int crispy_asr_transcribe_tokens(crispy_asr *h, const float *pcm, long pcm_strid
  * taken as they are; q4_0 / q4_1 / q5_0 / q5_1 / q8_0 blocks (catalog entries managers/model.rs:99,137) are
  * de-quantised to f32 at load time. */
 int crispy_asr_load(const char *model_path, int device, crispy_asr **out);
+
+/* Special-token ids of a whisper.cpp vocabulary of n_vocab entries [UPSTREAM-RECALL: whisper_vocab]: English-only
+ * (51864): eot 50256, sot 50257, translate 50357, transcribe 50358, solm 50359, prev 50360, nosp 50361,
+ * notimestamps 50362, first timestamp 50363, no language in the prompt; multilingual (51865, 51866 = large-v3):
+ * everything one higher, and the tokens behind the language block one more per extra language.  Pure function,
+ * no device needed. */
+typedef struct crispy_asr_specials {
+  int eot, sot, lang0, n_lang, translate, transcribe, solm, prev, nosp, notimestamps, beg, multilingual;
+} crispy_asr_specials;
+int crispy_asr_vocab_specials(int n_vocab, crispy_asr_specials *out);
 
 /* Byte string of one vocabulary entry of a loaded model file (not NUL-terminated). */
 int crispy_asr_token_text(const crispy_asr *h, int token, const char **text, size_t *len);

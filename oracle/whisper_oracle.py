@@ -181,21 +181,34 @@ class DecoderCache:
         return x @ W["decoder.token_embedding.weight"].T
 
 
-def special_tokens(n_vocab, eot=50257):
-    """whisper.cpp vocabulary layout [UPSTREAM-RECALL]: sot = eot+1, 99 (+extra) languages, translate,
-    transcribe, solm, prev, nosp, notimestamps, then the 1501 timestamps <|0.00|> ... <|30.00|>."""
+def special_tokens(n_vocab, eot=None):
+    """whisper.cpp vocabulary layout [UPSTREAM-RECALL: `whisper_vocab` defaults + the shift applied when the model is
+    loaded].  The defaults are the English-only layout (n_vocab 51864): eot 50256, sot 50257, translate 50357,
+    transcribe 50358, solm 50359, prev 50360, nosp 50361, notimestamps 50362, <|0.00|> 50363 -- the 99 language
+    slots after sot stay in the .en vocabulary although no prompt names them.  A multilingual vocabulary
+    (n_vocab >= 51865) moves eot / sot up by one and everything behind the languages by 1 + (languages - 99)."""
     multilingual = n_vocab >= 51865
     extra = n_vocab - 51865 if multilingual else 0
+    if eot is None:
+        eot = 50257 if multilingual else 50256
     sot = eot + 1
-    if multilingual:
-        d = dict(sot=sot, lang0=sot + 1, n_lang=99 + extra, translate=sot + 100 + extra, transcribe=sot + 101 + extra,
-                 solm=sot + 102 + extra, prev=sot + 103 + extra, nosp=sot + 104 + extra, not_=sot + 105 + extra)
-    else:   # English-only files have no language / task tokens
-        d = dict(sot=sot, lang0=sot + 1, n_lang=0, translate=sot + 1, transcribe=sot + 2, solm=sot + 3, prev=sot + 4,
-                 nosp=sot + 5, not_=sot + 6)
-    d["beg"] = d["not_"] + 1
-    d["eot"] = eot
+    t = sot + 100 + extra
+    d = dict(sot=sot, lang0=sot + 1, n_lang=99 + extra if multilingual else 0, n_lang_slots=99 + extra,
+             translate=t, transcribe=t + 1, solm=t + 2, prev=t + 3, nosp=t + 4, not_=t + 5, beg=t + 6, eot=eot,
+             multilingual=multilingual)
     return d
+
+
+def default_prompt(n_vocab, lang_token=None, translate=False, no_timestamps=False):
+    """whisper_full's initial prompt: [sot] for English-only vocabularies, [sot, language, task] for multilingual
+    ones, + <|notimestamps|> when timestamps are off."""
+    sp = special_tokens(n_vocab)
+    p = [sp["sot"]]
+    if sp["multilingual"]:
+        p += [sp["lang0"] if lang_token is None else lang_token, sp["translate"] if translate else sp["transcribe"]]
+    if no_timestamps:
+        p.append(sp["not_"])
+    return p
 
 
 def timestamp_rules(lg, seq, sp, rules, suppress=None, suppress_first=None, max_initial_ts=50):
@@ -303,7 +316,7 @@ def window_segments(win, seek, sp, token_text):
 
 
 def transcribe_timestamps(weights, hp, mel_window, n_samples, prompt, rules, token_text, n_max=None,
-                          suppress=None, suppress_first=None, eot=50257, max_windows=16):
+                          suppress=None, suppress_first=None, eot=None, max_windows=1501):
     """whisper_full's seek loop over one clip (<= 30 s): `mel_window(seek)` returns the [n_mels, 3000] log-mel
     window starting at mel frame `seek`.  Returns (segments, all kept tokens, windows)."""
     sp = special_tokens(hp.n_vocab, eot)

@@ -550,3 +550,41 @@ def test_decode_batches_beyond_64_clips(model):
     assert np.array_equal(all_t, np.concatenate([a_t, b_t]))
     np.testing.assert_allclose(all_l, np.concatenate([a_l, b_l]), rtol=1e-4, atol=1e-3)
     assert len(np.unique(all_l[:, 0])) > 60          # the clips are different: so are the logits of their first pick
+
+
+def test_english_only_model_file_prompt_and_timestamps(oracle):
+    """an English-only vocabulary (n_vocab 51864, ggml-tiny.en / base.en) keeps the 99 language slots:
+    translate = sot + 100, prompt = [sot] (+ <|notimestamps|> = 50362), timestamps start at 50363.  The engine's
+    tokens must equal (a) the container decoded with that prompt and (b) the oracle's whisper_full restatement."""
+    import dataclasses
+    from crispy_amd import synth_audio
+    from crispy_amd.asr import LogMel, WhisperEngine, WhisperModel
+    from crispy_amd.ggml_io import synthetic_vocab, write_ggml
+    from crispy_amd.mel_filters import whisper_mel_filters
+    from crispy_amd.whisper_weights import HParams, synthetic_whisper_weights
+    from oracle import whisper_oracle as WO
+    import tempfile
+    hp = dataclasses.replace(HParams.tiny(), n_vocab=51864)
+    W = synthetic_whisper_weights(hp, 5)
+    sp = WO.special_tokens(hp.n_vocab)
+    assert (sp["eot"], sp["sot"], sp["not_"], sp["beg"]) == (50256, 50257, 50362, 50363)
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "ggml-tiny.en-synth.bin")
+        write_ggml(path, hp, W, whisper_mel_filters(80), synthetic_vocab(hp.n_vocab), f16=False)
+        eng = WhisperEngine(path)
+    x = synth_audio.clip16k_np(21, 200000)
+    # (a) <|notimestamps|> path: prompt [sot, not]
+    text, toks = eng.transcribe(x, max_new_tokens=6)
+    ref_model = WhisperModel(hp, W)
+    ref, _ = ref_model.transcribe_tokens([x], WO.default_prompt(hp.n_vocab, no_timestamps=True), 6)
+    assert toks == [t for t in ref[0].tolist() if t != sp["eot"]] and eng.last_language_token == 0
+    assert all(t < sp["eot"] or t > sp["not_"] for t in toks)          # specials 50256..50362 are never text
+    mel = oracle.oracle_logmel(x, whisper_mel_filters(80))
+    enc = WO.encoder_forward(W, hp, mel)
+    picks, _, margin = WO.greedy_decode(W, hp, enc, WO.default_prompt(hp.n_vocab, no_timestamps=True), 6, eot=sp["eot"])
+    assert min(margin) > 1e-3, "pick another seed: the oracle's own top-2 margin is too small to compare"
+    assert toks == [t for t in picks if t != sp["eot"]]
+    # (b) whisper.cpp's default: timestamp tokens; the first pick of a window is a timestamp >= 50363
+    text, segs, ttoks = eng.transcribe_segments(x, max_new_tokens=8)
+    assert ttoks and ttoks[0] >= sp["beg"]
+    assert all(t < sp["eot"] or t >= sp["beg"] for t in ttoks)
