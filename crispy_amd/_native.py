@@ -25,7 +25,7 @@ RN_SYMBOLS = (
     "crispy_rn_frames_per_launch", "crispy_rn_n_launches", "crispy_rn_set_pipeline",
     "crispy_rn_process", "crispy_rn_process_device", "crispy_rn_synchronize",
     "crispy_rn_set_timing", "crispy_rn_last_kernel_ms",
-    "crispy_rn_debug_capture", "crispy_rn_debug_read", "crispy_rn_stage_rnn_device",
+    "crispy_rn_debug_capture", "crispy_rn_debug_read", "crispy_rn_stage_rnn_device", "crispy_rn_stage_tansig_device",
     "crispy_host_register", "crispy_host_unregister",
     "crispy_rn_weights_from_file", "crispy_rn_create_from_file", "crispy_selftest_exception_guard",
 )
@@ -79,11 +79,22 @@ _lib = None
 def lib() -> C.CDLL:
     """Load libcrispy_hip.so (built by `__graft_entry__.build()` / `make -C crispy_amd/csrc`)."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    if _lib is None:
+        _lib = load_library(LIB_PATH)
+    return _lib
+
+
+def load_variant(name: str) -> C.CDLL:
+    """Another build of the same library next to the default one: libcrispy_hip_<name>.so (`make variants`:
+    gru0 / gru1 = the gain network of the frame kernel on v_fma_mix_f32 / f16 MFMA instead of int8 MFMA).  A separate
+    handle with its own state; parity tests run the same cases through every form."""
+    return load_library(os.path.join(_HERE, f"libcrispy_hip_{name}.so"))
+
+
+def load_library(path: str) -> C.CDLL:
+    if not os.path.exists(path):
         raise FileNotFoundError(
-            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  crispy_amd has no CPU fallback.")
     # PyTorch wheels bundle their own libamdhip64.so.7.  If this library pulled in /opt/rocm's copy
     # first, a later `import torch` would load a second HIP runtime into the process and find no GPU.
@@ -93,7 +104,7 @@ def lib() -> C.CDLL:
         import torch  # noqa: F401
     except ImportError:
         pass
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     f32p = C.POINTER(C.c_float)
     L.crispy_last_error.restype = C.c_char_p
     L.crispy_version.restype = C.c_char_p
@@ -116,6 +127,7 @@ def lib() -> C.CDLL:
     L.crispy_rn_set_timing.argtypes = [C.c_void_p, C.c_int]
     L.crispy_rn_last_kernel_ms.argtypes = [C.c_void_p, f32p, f32p]
     L.crispy_rn_stage_rnn_device.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_void_p]
+    L.crispy_rn_stage_tansig_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
     L.crispy_rn_set_pipeline.argtypes = [C.c_void_p, C.c_int]
     L.crispy_rn_debug_capture.argtypes = [C.c_void_p, C.c_int]
     L.crispy_rn_debug_read.argtypes = [C.c_void_p, C.c_int, f32p, C.c_size_t]
@@ -162,10 +174,9 @@ def lib() -> C.CDLL:
     L.crispy_resampler_process_device.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_float,
                                                   C.c_int, C.c_void_p, C.c_long, C.c_void_p]
     L.crispy_resampler_synchronize.argtypes = [C.c_void_p]
-    _lib = L
     return L
 
 
-def check(rc: int) -> None:
+def check(rc: int, L: "C.CDLL | None" = None) -> None:
     if rc != 0:
-        raise CrispyError(rc, lib().crispy_last_error().decode("utf-8", "replace"))
+        raise CrispyError(rc, (L or lib()).crispy_last_error().decode("utf-8", "replace"))

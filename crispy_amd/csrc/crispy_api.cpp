@@ -864,6 +864,16 @@ int crispy_rn_last_kernel_ms(crispy_rn* h, float* frame_kernel_ms, float* total_
   return CRISPY_OK;
 } CRISPY_CATCH_RET("crispy_rn_last_kernel_ms")
 
+int crispy_rn_stage_tansig_device(crispy_rn* h, const float* d_x, float* d_y, size_t n, int sigmoid, void* hip_stream) try {
+  if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_stage_tansig_device: NULL handle");
+  if (n == 0) return CRISPY_OK;
+  if (!d_x || !d_y) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_stage_tansig_device: NULL pointer");
+  if (n > ((size_t)1 << 40)) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_stage_tansig_device: n too large");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(rn_launch_tansig(h->d_tab, d_x, d_y, (long)n, sigmoid != 0, hip_stream ? (hipStream_t)hip_stream : h->stream));
+  return CRISPY_OK;
+} CRISPY_CATCH_RET("crispy_rn_stage_tansig_device")
+
 int crispy_rn_stage_rnn_device(crispy_rn* h, const float* d_feat, const unsigned char* d_silent, float* d_g_raw,
                                float* d_g_smooth, float* d_vad, int n_frames, void* hip_stream) try {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_stage_rnn_device: NULL handle");

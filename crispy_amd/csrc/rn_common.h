@@ -159,5 +159,6 @@ hipError_t rn_launch_frames(const RnArgs& a, hipStream_t s);            // fused
 hipError_t rn_launch_analysis(const RnArgs& a, hipStream_t s);          // staged: up to the 42 features
 hipError_t rn_launch_synthesis(const RnArgs& a, hipStream_t s);         // staged: comb filter, gains, inverse FFT, OLA
 hipError_t rn_launch_roll_history(const RnArgs& a, hipStream_t s);
+hipError_t rn_launch_tansig(const RnTables* tab, const float* x, float* y, long n, int sigmoid, hipStream_t s);
 
 }  // namespace crispy

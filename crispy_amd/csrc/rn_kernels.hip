@@ -2250,6 +2250,22 @@ __global__ __launch_bounds__(WAVE) RN_HP_VGPR_CAP void rn_highpass_kernel(RnArgs
   a.hp_mem[2 * b + 1] = m1;
 }
 
+// Stage entry point for parity tests: the frame kernel's own activation code (TansigTab in four registers per lane,
+// ds_bpermute lookups, the +-8 clamps) applied to n arbitrary arguments, so that every table cell and both clamps can
+// be bit-compared with the oracle's tansig_approx / sigmoid_approx.  All 64 lanes stay active (bpermute reads 0 from
+// masked lanes): the index is clamped, the store predicated.
+__global__ __launch_bounds__(WAVE) void rn_tansig_kernel(const RnTables* tab, const float* x, float* y, long n, int sigmoid) {
+  const int lane = threadIdx.x;
+  TansigTab tansig;
+  tansig.load(tab->tansig, lane);
+  for (long base = (long)blockIdx.x * WAVE; base < n; base += (long)gridDim.x * WAVE) {
+    const long i = base + lane;
+    const float v = x[i < n ? i : n - 1];
+    const float r = sigmoid ? sigmoid_approx(v, tansig) : tansig_approx(v, tansig);
+    if (i < n) y[i] = r;
+  }
+}
+
 // keep the last RN_HIST high-passed samples of every stream at the front of its xhp row
 __global__ __launch_bounds__(256) void rn_roll_history_kernel(RnArgs a) {
   const int b = blockIdx.x;
@@ -2285,6 +2301,11 @@ hipError_t rn_launch_analysis(const RnArgs& a, hipStream_t s) {
 }
 hipError_t rn_launch_synthesis(const RnArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(rn_frame_kernel<2>, dim3(a.B, (a.T + RN_SYNTH_GROUP - 1) / RN_SYNTH_GROUP), dim3(WAVE), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t rn_launch_tansig(const RnTables* tab, const float* x, float* y, long n, int sigmoid, hipStream_t s) {
+  const long blocks = (n + WAVE - 1) / WAVE;
+  hipLaunchKernelGGL(rn_tansig_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(WAVE), 0, s, tab, x, y, n, sigmoid);
   return hipGetLastError();
 }
 hipError_t rn_launch_roll_history(const RnArgs& a, hipStream_t s) {

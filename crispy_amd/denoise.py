@@ -28,17 +28,25 @@ class DenoiseState:
     `process_frame(out, inp)` keeps the reference's argument order and returns the VAD
     probabilities; arrays are [B, 480] (or [480] when B == 1), f32 in int16 range."""
 
-    def __init__(self, weights: np.ndarray, n_streams: int = 1, device: int = 0):
-        w = np.ascontiguousarray(weights, dtype=np.int8)
+    def __init__(self, weights, n_streams: int = 1, device: int = 0, lib=None):
+        """weights: the 87 503-byte int8 blob, or the path of an rnnoise-nu text model file
+        (`crispy_rn_create_from_file`).  lib: another build of the library (`_native.load_variant`), tests only."""
+        self._L = lib if lib is not None else N.lib()
         self._h = C.c_void_p()
         self.n_streams = int(n_streams)
         self.device = int(device)
-        N.check(N.lib().crispy_rn_create(w.ctypes.data_as(C.c_void_p), w.size, self.n_streams,
-                                         self.device, C.byref(self._h)))
+        if isinstance(weights, (str, bytes)) or hasattr(weights, "__fspath__"):
+            import os
+            N.check(self._L.crispy_rn_create_from_file(os.fsencode(weights), self.n_streams, self.device,
+                                                       C.byref(self._h)), self._L)
+            return
+        w = np.ascontiguousarray(weights, dtype=np.int8)
+        N.check(self._L.crispy_rn_create(w.ctypes.data_as(C.c_void_p), w.size, self.n_streams,
+                                         self.device, C.byref(self._h)), self._L)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
-            N.lib().crispy_rn_destroy(self._h)
+            self._L.crispy_rn_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -55,8 +63,8 @@ class DenoiseState:
         if output.dtype != np.float32 or not output.flags["C_CONTIGUOUS"] or output.size != x.size:
             raise ValueError("process_frame: output must be a contiguous float32 array of the input's size")
         vad = np.empty(self.n_streams, dtype=np.float32)
-        N.check(N.lib().crispy_rn_process(self._h, x.ctypes.data, output.ctypes.data, vad.ctypes.data,
-                                          1, N.LAYOUT_TBF))
+        N.check(self._L.crispy_rn_process(self._h, x.ctypes.data, output.ctypes.data, vad.ctypes.data,
+                                          1, N.LAYOUT_TBF), self._L)
         return float(vad[0]) if self.n_streams == 1 else vad
 
     # -- batched host arrays ---------------------------------------------------------------
@@ -72,7 +80,7 @@ class DenoiseState:
             raise ValueError(f"process: {Bn} streams given, handle has {self.n_streams}")
         out = np.empty_like(x)
         vad = np.empty((T, Bn), dtype=np.float32)
-        N.check(N.lib().crispy_rn_process(self._h, x.ctypes.data, out.ctypes.data, vad.ctypes.data, T, lay))
+        N.check(self._L.crispy_rn_process(self._h, x.ctypes.data, out.ctypes.data, vad.ctypes.data, T, lay), self._L)
         return out, vad
 
     @staticmethod
@@ -94,44 +102,48 @@ class DenoiseState:
             raise ValueError("process_into: float32 C-contiguous arrays required")
         if Bn != self.n_streams or out.shape != x.shape or vad.shape != (T, Bn):
             raise ValueError("process_into: shape mismatch")
-        N.check(N.lib().crispy_rn_process(self._h, x.ctypes.data, out.ctypes.data, vad.ctypes.data, T, lay))
+        N.check(self._L.crispy_rn_process(self._h, x.ctypes.data, out.ctypes.data, vad.ctypes.data, T, lay), self._L)
 
     # -- device-resident tensors (torch is only the allocator here) --------------------------
     def process_device(self, d_in: int, d_out: int, n_frames: int, d_vad: int = 0, d_taps: int = 0,
                        layout: str = "tbf", stream: int = 0):
         lay = N.LAYOUT_TBF if layout == "tbf" else N.LAYOUT_BTF
-        N.check(N.lib().crispy_rn_process_device(self._h, d_in, d_out, d_vad or None, d_taps or None,
-                                                 int(n_frames), lay, stream or None))
+        N.check(self._L.crispy_rn_process_device(self._h, d_in, d_out, d_vad or None, d_taps or None,
+                                                 int(n_frames), lay, stream or None), self._L)
 
     def stage_rnn_device(self, d_feat: int, d_silent: int, d_g_raw: int, d_g_smooth: int, n_frames: int, d_vad: int = 0):
         """The gain network alone on the matrix cores (stage entry point for parity tests)."""
-        N.check(N.lib().crispy_rn_stage_rnn_device(self._h, d_feat, d_silent, d_g_raw, d_g_smooth, d_vad or None,
-                                                   int(n_frames), None))
+        N.check(self._L.crispy_rn_stage_rnn_device(self._h, d_feat, d_silent, d_g_raw, d_g_smooth, d_vad or None,
+                                                   int(n_frames), None), self._L)
+
+    def stage_tansig_device(self, d_x: int, d_y: int, n: int, sigmoid: bool = False):
+        """tansig_approx / sigmoid_approx as the frame kernel evaluates them (stage entry point for parity tests)."""
+        N.check(self._L.crispy_rn_stage_tansig_device(self._h, d_x, d_y, int(n), int(sigmoid), None), self._L)
 
     def set_pipeline(self, staged: bool):
         """True: analysis -> batched MFMA gain network -> synthesis; False (default): single fused kernel."""
-        N.check(N.lib().crispy_rn_set_pipeline(self._h, int(staged)))
+        N.check(self._L.crispy_rn_set_pipeline(self._h, int(staged)), self._L)
 
     def synchronize(self):
-        N.check(N.lib().crispy_rn_synchronize(self._h))
+        N.check(self._L.crispy_rn_synchronize(self._h), self._L)
 
     def reset(self, stream: int = -1):
-        N.check(N.lib().crispy_rn_reset(self._h, int(stream)))
+        N.check(self._L.crispy_rn_reset(self._h, int(stream)), self._L)
 
     def set_timing(self, enable: bool):
-        N.check(N.lib().crispy_rn_set_timing(self._h, int(enable)))
+        N.check(self._L.crispy_rn_set_timing(self._h, int(enable)), self._L)
 
     def last_kernel_ms(self):
         a, b = C.c_float(), C.c_float()
-        N.check(N.lib().crispy_rn_last_kernel_ms(self._h, C.byref(a), C.byref(b)))
+        N.check(self._L.crispy_rn_last_kernel_ms(self._h, C.byref(a), C.byref(b)), self._L)
         return a.value, b.value
 
     def debug_capture(self, enable: bool):
-        N.check(N.lib().crispy_rn_debug_capture(self._h, int(enable)))
+        N.check(self._L.crispy_rn_debug_capture(self._h, int(enable)), self._L)
 
     def debug_read(self, stream: int) -> np.ndarray:
         d = np.empty(N.RN_DBG_FLOATS, dtype=np.float32)
-        N.check(N.lib().crispy_rn_debug_read(self._h, int(stream), d.ctypes.data_as(C.POINTER(C.c_float)), d.size))
+        N.check(self._L.crispy_rn_debug_read(self._h, int(stream), d.ctypes.data_as(C.POINTER(C.c_float)), d.size))
         return d
 
 

@@ -123,3 +123,57 @@ def save_rnnoise_nu_text(path: str, blob: np.ndarray) -> None:
             f.write(f"{n_in} {n_out} {act[name]}\n")
             for part, (off, cnt) in _OFFSETS[name].items():
                 f.write(" ".join(str(int(v)) for v in blob[off:off + cnt]) + "\n")
+
+
+EXTREME_KINDS = ("pos127", "neg127", "alt127", "zero", "bias_pos127", "bias_neg127", "heavy_tail", "row_saturating")
+
+
+def extreme_weights(kind: str, seed: int = 0) -> np.ndarray:
+    """Weight blobs at the corners of int8 (parity hardening: `synthetic_weights` keeps the GRUs in the linear part
+    of tansig_approx by construction, these do not).
+
+    pos127 / neg127     every weight and bias +127 / -127
+    alt127              +-127 alternating along the blob (sign = parity of the flat index)
+    zero                all zeros: gates 0.5, candidate 0, gains 0.5
+    bias_pos127 / bias_neg127   the seeded synthetic matrices with every bias +127 / -127 (gates pinned near 0.62 / 0.38
+                        before the inputs move them)
+    heavy_tail          "trained-like": Student-t (3 degrees of freedom) draws scaled so that ~2 % of the weights
+                        clip at +-127, biases N(0, 40)
+    row_saturating      synthetic matrices, but every 5th output row of every matrix is all +127 and every 7th all
+                        -127 (+-8 clamp of tansig_approx and table index 200 on those rows, ordinary rows beside them)
+    """
+    rng = np.random.default_rng(1000 + seed)
+    if kind == "pos127":
+        return np.full(BLOB_BYTES, 127, np.int8)
+    if kind == "neg127":
+        return np.full(BLOB_BYTES, -127, np.int8)
+    if kind == "alt127":
+        return np.where(np.arange(BLOB_BYTES) % 2 == 0, 127, -127).astype(np.int8)
+    if kind == "zero":
+        return np.zeros(BLOB_BYTES, np.int8)
+    blob = synthetic_weights(seed).copy()
+    if kind in ("bias_pos127", "bias_neg127"):
+        for name, _, _, _ in LAYERS:
+            off, cnt = _OFFSETS[name]["b"]
+            blob[off:off + cnt] = 127 if kind == "bias_pos127" else -127
+        return blob
+    if kind == "heavy_tail":
+        for name, k, n_in, n_out in LAYERS:
+            for part, (off, cnt) in _OFFSETS[name].items():
+                if part == "b":
+                    vals = rng.normal(0.0, 40.0, size=cnt)
+                else:
+                    vals = rng.standard_t(3, size=cnt) * 22.0
+                blob[off:off + cnt] = np.clip(np.rint(vals), -127, 127).astype(np.int8)
+        return blob
+    if kind == "row_saturating":
+        for name, k, n_in, n_out in LAYERS:
+            rows = n_out * (3 if k == "gru" else 1)
+            for part, (off, cnt) in _OFFSETS[name].items():
+                if part == "b":
+                    continue
+                m = blob[off:off + cnt].reshape(-1, rows)        # [K][rows]
+                m[:, 4::5] = 127
+                m[:, 6::7] = -127
+        return blob
+    raise ValueError(f"unknown kind {kind!r}")

@@ -166,6 +166,12 @@ int crispy_rn_stage_rnn_device(crispy_rn *h, const float *d_feat, const unsigned
                                float *d_g_raw, float *d_g_smooth, float *d_vad, int n_frames,
                                void *hip_stream);
 
+/* Stage entry point (parity tests): the activation functions of the gain network exactly as the frame kernel
+ * evaluates them (201-entry tanh table + interpolation, |x| >= 8 clamps; sigmoid != 0: 0.5 + 0.5 tansig(0.5 x)) on n
+ * arbitrary f32 arguments, DEVICE pointers.  Bit-compared with the oracle over every table cell and both clamps. */
+int crispy_rn_stage_tansig_device(crispy_rn *h, const float *d_x, float *d_y, size_t n, int sigmoid,
+                                  void *hip_stream);
+
 /* Developer aid for parity debugging: copy the per-stage debug capture of stream `stream`
  * for the LAST frame of the most recent call (layout mirrors oracle RNO_DBG_*). */
 int crispy_rn_debug_capture(crispy_rn *h, int enable);

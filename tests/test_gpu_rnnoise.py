@@ -471,3 +471,172 @@ def test_capture_callback_glue_with_the_denoiser(oracle, weights0):
     got = np.array(cb.rec_buffer, np.float32)
     assert got.shape == want.shape and np.abs(got - want).max() <= 1e-4 * np.abs(want).max() + 1e-7
     assert abs(cb.rms() - float(np.sqrt(np.mean(x.astype(np.float64) ** 2)))) < 1e-5
+
+
+# ---- parity hardening: weight extremes through every form of the gain network ----------------------
+XGOLD = os.path.join(os.path.dirname(__file__), "golden", "rnnoise_extreme_golden.npz")
+_VARIANTS = {}
+
+
+def _variant(name):
+    """None = the shipped library (int8 MFMA gain network); 'gru0' / 'gru1' = the v_fma_mix_f32 / f16-MFMA builds of the
+    same sources (`make variants`, built by __graft_entry__.build()); 'staged' = shipped library, staged pipeline
+    (bf16 3-way-split MFMA gain network batched over streams)."""
+    from crispy_amd import _native as N
+    if name in (None, "staged"):
+        return None
+    if name not in _VARIANTS:
+        _VARIANTS[name] = N.load_variant(name)
+    return _VARIANTS[name]
+
+
+@pytest.mark.parametrize("form", ["fused_i8", "staged", "gru0", "gru1"])
+@pytest.mark.parametrize("kind", ["pos127", "neg127", "alt127", "zero", "bias_pos127", "bias_neg127", "heavy_tail",
+                                  "row_saturating"])
+def test_weight_extremes_every_gain_network_form(oracle, kind, form):
+    """All-+127, all--127, alternating +-127, zero, saturated biases, a heavy-tailed trained-like draw and rows that
+    pin gates at the +-8 clamp: PCM, gains and VAD of every form of the gain network (int8-MFMA fixed point, f16
+    MFMA, v_fma_mix_f32, stream-batched bf16 MFMA) against the oracle -- 40 frames live, and the committed 12-frame
+    golden vectors."""
+    from crispy_amd import rnn_weights as RW
+    from crispy_amd.denoise import DenoiseState
+    from tests.golden.make_rnnoise_extreme_golden import inputs
+    import torch
+    w = RW.extreme_weights(kind)
+    L = _variant(None if form == "fused_i8" else form)
+    G = np.load(XGOLD)
+    # (1) golden vectors, one stream per input
+    names = ("tone", "loud")
+    xg = np.stack([G[f"x/{n}"] for n in names], axis=1)                  # [12, 2, 480]
+    ds = DenoiseState(w, 2, 0, lib=L)
+    ds.set_pipeline(form == "staged")
+    dev = torch.device("cuda:0")
+    d_in = torch.from_numpy(xg).to(dev)
+    d_out = torch.empty_like(d_in)
+    d_vad = torch.zeros(12, 2, device=dev)
+    d_taps = torch.zeros(12, 2, 72, device=dev)
+    torch.cuda.synchronize()
+    ds.process_device(d_in.data_ptr(), d_out.data_ptr(), 12, d_vad.data_ptr(), d_taps.data_ptr())
+    ds.synchronize()
+    out, vad, taps = d_out.cpu().numpy(), d_vad.cpu().numpy(), d_taps.cpu().numpy()
+    for i, n in enumerate(names):
+        _assert_pcm_close(out[:, i], G[f"{kind}/{n}/out"], f"{kind}/{form}/{n} golden")
+        assert np.abs(vad[:, i] - G[f"{kind}/{n}/vad"]).max() < 1e-4
+        assert np.abs(taps[:, i, 42:64] - G[f"{kind}/{n}/gains"]).max() < 1e-4
+    # (2) 40 frames live against the oracle, 5 different streams (incl. one that goes silent half way)
+    from crispy_amd import synth_audio as SA
+    T, B = 40, 5
+    x = SA.batch_np(B, T, first_stream=200) * np.float32(32768.0)
+    x[T // 2:, 3] = 0.0
+    ds = DenoiseState(w, B, 0, lib=L)
+    ds.set_pipeline(form == "staged")
+    o2, v2 = ds.process(x)
+    assert np.isfinite(o2).all()
+    for b in range(B):
+        ro, rv = oracle.OracleDenoiseState(w).process(x[:, b])
+        _assert_pcm_close(o2[:, b], ro, f"{kind}/{form} stream {b}")
+        assert np.abs(v2[:, b] - rv).max() < 1e-4, (kind, form, b)
+
+
+def test_tansig_and_sigmoid_every_table_cell_and_both_clamps(oracle, weights0):
+    """crispy_rn_stage_tansig_device = the frame kernel's activation code (table in registers, ds_bpermute lookups):
+    bit-compared with the oracle's tansig_approx / sigmoid_approx on (a) a dense sweep of [-9, 9] (every one of the
+    201 cells, 90 points per cell), (b) both sides of every cell boundary (|x| = (i + 0.5) / 25 and its f32
+    neighbours), (c) the +-8 clamps and their neighbours, (d) signed zero, subnormals, huge values, infinities, NaN."""
+    import torch
+    cells = (np.arange(0, 201) + 0.5) / 25.0
+    edge = np.concatenate([np.nextafter(cells.astype(np.float32), np.float32(0)), cells.astype(np.float32),
+                           np.nextafter(cells.astype(np.float32), np.float32(100))])
+    clamp = np.array([8.0, np.nextafter(np.float32(8), np.float32(0)), np.nextafter(np.float32(8), np.float32(9)),
+                      16.0, 15.999999, 16.000002], np.float32)
+    special = np.array([0.0, -0.0, 1e-45, -1e-45, 1e-38, 1e-20, 1e10, -1e10, 3.4e38, -3.4e38, np.inf, -np.inf, np.nan],
+                       np.float32)
+    sweep = np.linspace(-9.0, 9.0, 90 * 201 * 2 + 1).astype(np.float32)
+    xs = np.concatenate([sweep, edge, -edge, 2 * edge, -2 * edge, clamp, -clamp, special]).astype(np.float32)
+    ds = _mk(weights0, 1)
+    dev = torch.device("cuda:0")
+    d_x = torch.from_numpy(xs).to(dev)
+    d_y = torch.empty_like(d_x)
+    lib = oracle.lib()
+    for sigmoid, fn in ((False, lib.rno_tansig_approx), (True, lib.rno_sigmoid_approx)):
+        ds.stage_tansig_device(d_x.data_ptr(), d_y.data_ptr(), xs.size, sigmoid)
+        ds.synchronize()
+        got = d_y.cpu().numpy()
+        want = np.array([fn(float(v)) for v in xs], np.float32)
+        same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+        # +0 / -0 are the same value to every consumer of the activations
+        same |= (got == 0) & (want == 0)
+        bad = np.flatnonzero(~same)
+        assert bad.size == 0, (sigmoid, xs[bad[:8]], got[bad[:8]], want[bad[:8]])
+    # the sweep really visits every cell
+    idx = np.floor(0.5 + 25.0 * np.minimum(np.abs(sweep), 8.0)).astype(int)
+    assert set(idx.tolist()) == set(range(201))
+
+
+def test_create_from_rnnoise_nu_model_file(oracle, weights0, tmp_path):
+    """DenoiseState::new() has no arguments (audio.rs:229); the C ABI's counterpart for a host without a blob of its
+    own is crispy_rn_create_from_file over the rnnoise-nu text format: same results as the blob constructor."""
+    from crispy_amd import rnn_weights as RW, synth_audio as SA
+    from crispy_amd.denoise import DenoiseState
+    p = tmp_path / "model.txt"
+    RW.save_rnnoise_nu_text(str(p), weights0)
+    x = SA.batch_np(3, 15, first_stream=70) * np.float32(32768.0)
+    a, va = DenoiseState(str(p), 3, 0).process(x)
+    b, vb = DenoiseState(weights0, 3, 0).process(x)
+    assert np.array_equal(a, b) and np.array_equal(va, vb)
+
+
+# ---- BASELINE configs at full size (VERDICT r1 #3) ----------------------------------------------------------------
+def test_cfg1_full_length_clip_3000_frames_through_the_adapter(oracle, weights0):
+    """BASELINE configs[0] at its full size: one 30 s 48 kHz mono clip = 3000 frames pushed SAMPLE BY SAMPLE through
+    the RnnNoiseProcessor adapter (push_sample: x32768, process_frame per 480 samples, /32768, clamp, volume, first
+    frame dropped -- audio.rs:242-295) over the HIP path, against the same adapter arithmetic over the oracle's
+    process_frame loop."""
+    from crispy_amd import synth_audio as SA
+    from crispy_amd.denoise import RnnNoiseProcessor
+    T = 3000
+    clip = SA.cfg1_clip(T)
+    assert clip.size == 1_440_000
+    proc = RnnNoiseProcessor(weights0, 48000.0, 48000.0, 0.8, 1, 0)
+    chunks = []
+    for s in clip:
+        r = proc.push_sample([s])
+        if r is not None:
+            chunks.append(r[:, 0])
+    got = np.concatenate(chunks)
+    ro, _ = oracle.OracleDenoiseState(weights0).process(clip * np.float32(32768.0))
+    want = (np.clip(ro / np.float32(32768.0), -1, 1) * np.float32(0.8))[1:].ravel()
+    assert got.shape == want.shape == ((T - 1) * 480,)
+    assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max() + 1e-7
+    # the last second on its own (state after 29 s)
+    assert np.abs(got[-48000:] - want[-48000:]).max() <= 1e-4 * np.abs(want[-48000:]).max() + 1e-7
+
+
+def test_cfg2_full_size_4096_streams_x_1000_frames(oracle, weights0):
+    """BASELINE configs[1] at its full size: 4096 concurrent streams x 1000 frames (10 s) in one device-resident call;
+    24 sampled streams against the oracle on the LAST second (recurrent state after 900 frames), silent streams
+    exactly zero, everything finite."""
+    import torch
+    from crispy_amd import synth_audio as SA
+    B, T = 4096, 1000
+    dev = torch.device("cuda:0")
+    d_in = SA.batch_torch(B, T, dev, seed=21)                           # 7.9 GB
+    d_out = torch.empty_like(d_in)
+    ds = _mk(weights0, B)
+    torch.cuda.synchronize()
+    ds.process_device(d_in.data_ptr(), d_out.data_ptr(), T)
+    ds.synchronize()
+    assert bool(torch.isfinite(d_out).all())
+    silent = torch.arange(B, device=dev) % 10 == 9
+    assert float(d_out[:, silent].abs().max()) == 0.0
+    pick = list(range(5, B, 171))
+    assert len(pick) == 24
+    x = d_in[:, pick].cpu().numpy()
+    out = d_out[:, pick].cpu().numpy()
+    del d_in, d_out
+    torch.cuda.empty_cache()
+    for i, b in enumerate(pick):
+        ro, _ = oracle.OracleDenoiseState(weights0).process(np.ascontiguousarray(x[:, i]))
+        peak = max(float(np.abs(ro).max()), 1.0)
+        err = float(np.abs(out[900:, i] - ro[900:]).max())
+        assert err <= REL * peak + 1e-3, (b, err, peak)

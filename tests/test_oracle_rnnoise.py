@@ -230,3 +230,81 @@ def test_golden_weights_match_generator():
     G = np.load(GOLD)
     for s in (0, 1, 2):
         assert np.array_equal(G[f"weights{s}"], synthetic_weights(s))
+
+
+# ---- weight extremes (VERDICT r1 #2a): the oracle at the corners of int8 ---------------------------------------------
+XGOLD = os.path.join(os.path.dirname(__file__), "golden", "rnnoise_extreme_golden.npz")
+
+
+def test_extreme_weight_generator_shapes_and_corners():
+    from crispy_amd import rnn_weights as RW
+    for kind in RW.EXTREME_KINDS:
+        w = RW.extreme_weights(kind)
+        assert w.dtype == np.int8 and w.size == RW.BLOB_BYTES and np.array_equal(w, RW.extreme_weights(kind))
+    assert set(np.unique(RW.extreme_weights("alt127"))) == {-127, 127}
+    offs, _ = RW.blob_offsets()
+    o, c = offs["denoise_gru"]["b"]
+    assert np.all(RW.extreme_weights("bias_pos127")[o:o + c] == 127)
+    ht = RW.extreme_weights("heavy_tail")
+    assert 0.005 < np.mean(np.abs(ht) == 127) < 0.08                      # clipped tails, not a clipped bulk
+    rs = RW.extreme_weights("row_saturating")
+    o, c = offs["denoise_gru"]["W"]
+    m = rs[o:o + c].reshape(114, 288)
+    assert np.all(m[:, 4] == 127) and np.all(m[:, 6] == -127)
+
+
+@pytest.mark.parametrize("kind", ["pos127", "neg127", "alt127", "zero", "bias_pos127", "bias_neg127", "heavy_tail",
+                                  "row_saturating"])
+def test_oracle_reproduces_extreme_golden(oracle, kind):
+    from crispy_amd import rnn_weights as RW
+    G = np.load(XGOLD)
+    for name in ("tone", "loud"):
+        out, vad, taps = oracle.OracleDenoiseState(RW.extreme_weights(kind)).process(G[f"x/{name}"], with_taps=True)
+        assert np.array_equal(out, G[f"{kind}/{name}/out"])
+        assert np.array_equal(vad, G[f"{kind}/{name}/vad"])
+        assert np.array_equal(taps[:, 42:64], G[f"{kind}/{name}/gains"])
+
+
+@pytest.mark.parametrize("kind", ["pos127", "neg127", "alt127", "zero", "heavy_tail", "row_saturating"])
+def test_compute_rnn_at_weight_extremes_matches_float64_rederivation(oracle, kind):
+    """The same independent float64 GRU stack as above, with saturating weights: pre-activations reach |x| >> 8, so
+    the +-8 clamp and the last table cell of tansig_approx are what the oracle is checked on here."""
+    from crispy_amd import rnn_weights as RW
+    w = RW.extreme_weights(kind)
+    P = _unpack(w)
+    S = 1 / 256.0
+    sig = lambda v: 1 / (1 + np.exp(-np.clip(v, -700, 700)))
+
+    def gru(p, h, x, n):
+        a = p["b"] + x @ p["W"]
+        z = sig(S * (a[:n] + h @ p["U"][:, :n]))
+        r = sig(S * (a[n:2 * n] + h @ p["U"][:, n:2 * n]))
+        c = np.maximum(0, S * (a[2 * n:] + (h * r) @ p["U"][:, 2 * n:]))
+        return z * h + (1 - z) * c
+
+    rng = np.random.default_rng(3)
+    state = np.zeros(168, np.float32)
+    hv, hn, hd = np.zeros(24), np.zeros(48), np.zeros(96)
+    saturated = 0
+    for it in range(6):
+        f = (rng.standard_normal(42) * (1.0 + 3.0 * it)).astype(np.float32)      # features up to the ~20s, as real frames
+        g, vad = np.empty(22, np.float32), np.empty(1, np.float32)
+        oracle.lib().rno_compute_rnn(w.ctypes.data, oracle.fp(state), oracle.fp(g), oracle.fp(vad), oracle.fp(f))
+        f64 = f.astype(np.float64)
+        pre = S * (P["input_dense"]["b"] + f64 @ P["input_dense"]["W"])
+        saturated += int(np.sum(np.abs(pre) >= 8))
+        d = np.tanh(pre)
+        hv = gru(P["vad_gru"], hv, d, 24)
+        v = sig(S * (P["vad_output"]["b"] + hv @ P["vad_output"]["W"]))
+        hn = gru(P["noise_gru"], hn, np.concatenate([d, hv, f64]), 48)
+        hd = gru(P["denoise_gru"], hd, np.concatenate([hv, hn, f64]), 96)
+        gg = sig(S * (P["denoise_output"]["b"] + hd @ P["denoise_output"]["W"]))
+        ref = np.concatenate([hv, hn, hd])
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert np.isfinite(state).all()
+        assert np.abs(state - ref).max() < 5e-3 * scale, (kind, it)
+        assert np.abs(g - gg).max() < 3e-3 and abs(vad[0] - v[0]) < 3e-3
+        # re-synchronise the float64 copy: table activations differ by up to 2e-4 per step and ReLU GRUs amplify
+        hv, hn, hd = state[:24].astype(np.float64), state[24:72].astype(np.float64), state[72:].astype(np.float64)
+    if kind in ("pos127", "neg127", "alt127", "row_saturating"):
+        assert saturated > 0, "the case was meant to reach the +-8 clamp"
