@@ -464,19 +464,22 @@ struct TansigTab {
     return q == 0 ? v0 : (q == 1 ? v1 : (q == 2 ? v2 : v3));
   }
 };
+// Every product and sum is rounded on its own (__fmul_rn / __fadd_rn are never contracted into an FMA), in the
+// reference's order: the Rust crate does not fuse multiply-adds, and with this the function is bit-identical to the
+// oracle on every table cell and both clamps (tests/test_gpu_rnnoise.py::test_tansig_and_sigmoid_every_table_cell...).
 __device__ __forceinline__ float tansig_approx(float x, const TansigTab& table) {
   const float x0 = x;
   float sign = 1.f;
   if (x < 0.f) { x = -x; sign = -1.f; }
   x = fminf(x, 8.f);                       // keeps the index in range; the clamp result is selected below
-  const int i = (int)floorf(.5f + 25.f * x);
-  x -= .04f * i;
+  const int i = (int)floorf(__fadd_rn(.5f, __fmul_rn(25.f, x)));
+  x = __fsub_rn(x, __fmul_rn(.04f, (float)i));
   float y = table.at(i);
-  const float dy = 1.f - y * y;
-  y = y + x * dy * (1.f - y * x);
+  const float dy = __fsub_rn(1.f, __fmul_rn(y, y));
+  y = __fadd_rn(y, __fmul_rn(__fmul_rn(x, dy), __fsub_rn(1.f, __fmul_rn(y, x))));
   y = sign * y;
-  if (!(x0 < 8.f)) y = 1.f;
   if (!(x0 > -8.f)) y = -1.f;
+  if (!(x0 < 8.f)) y = 1.f;                // tested last: NaN takes this branch, as in the reference's `!(x < 8)` first
   return y;
 }
 __device__ __forceinline__ float sigmoid_approx(float x, const TansigTab& table) {

@@ -41,11 +41,12 @@ __device__ __forceinline__ float tansig_lds(float x, const float* table) {
   if (!(x > -8.f)) return -1.f;
   float sign = 1.f;
   if (x < 0.f) { x = -x; sign = -1.f; }
-  const int i = (int)floorf(.5f + 25.f * x);
-  x -= .04f * i;
+  // every product and sum rounded on its own, in the reference's order (see tansig_approx in rn_kernels.hip)
+  const int i = (int)floorf(__fadd_rn(.5f, __fmul_rn(25.f, x)));
+  x = __fsub_rn(x, __fmul_rn(.04f, (float)i));
   float y = table[i];
-  const float dy = 1.f - y * y;
-  y = y + x * dy * (1.f - y * x);
+  const float dy = __fsub_rn(1.f, __fmul_rn(y, y));
+  y = __fadd_rn(y, __fmul_rn(__fmul_rn(x, dy), __fsub_rn(1.f, __fmul_rn(y, x))));
   return sign * y;
 }
 __device__ __forceinline__ float sigmoid_lds(float x, const float* table) { return .5f + .5f * tansig_lds(.5f * x, table); }

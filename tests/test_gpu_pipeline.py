@@ -89,8 +89,5 @@ def test_end_to_end_pipeline_matches_oracle_chain(oracle):
         assert np.mean(np.abs(pcm16[b] - ref16) > 1e-5) < 0.01
         enc = WO.encoder_forward(W, hp, oracle.oracle_logmel(ref16, F))
         rt, rb, rm = WO.greedy_decode(W, hp, enc, prompt, 4)
-        for i in range(4):
-            if rm[i] > 1e-2:
-                assert toks[b, 0, i] == rt[i]
-            else:
-                break
+        from tests.test_gpu_whisper import assert_picks
+        assert_picks(toks[b, 0], rt, rm, 1e-2, 3, f"pipeline stream {b}")

@@ -12,6 +12,20 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "whisper_tiny_golden.npz")
 
 
+def assert_picks(got, ref, margin, thr, need, what=""):
+    """Greedy ids must equal the oracle's wherever the oracle's own top-2 margin exceeds `thr` (an f32 pipeline cannot
+    be asked to resolve less) -- and at least `need` picks must actually have been compared: a margin-gated loop that
+    compares nothing proves nothing (VERDICT r1, weak #3)."""
+    compared = 0
+    for i, (t, m) in enumerate(zip(ref, margin)):
+        if m <= thr:
+            break
+        assert int(got[i]) == int(t), (what, i, list(got), list(ref), list(margin))
+        compared += 1
+    assert compared >= need, (what, f"only {compared} picks had an oracle margin > {thr}", list(margin))
+    return compared
+
+
 @pytest.fixture(scope="module")
 def tiny():
     from crispy_amd.whisper_weights import HParams, synthetic_whisper_weights
@@ -101,12 +115,8 @@ def test_greedy_decode_batch_matches_oracle(tiny, model, oracle):
     for b, c in enumerate(clips):
         ref_enc = WO.encoder_forward(W, hp, oracle.oracle_logmel(c, F))
         rt, rb, rm = WO.greedy_decode(W, hp, ref_enc, prompt, 5)
-        for i in range(5):
-            if rm[i] > 1e-3:
-                assert toks[b, i] == rt[i], (b, i, toks[b], rt, rm)
-                assert abs(lg[b, i] - rb[i]) < 1e-3
-            else:
-                break
+        k = assert_picks(toks[b], rt, rm, 1e-3, 5, f"clip {b}")
+        assert np.abs(lg[b, :k] - np.array(rb[:k])).max() < 1e-3
 
 
 def test_suppression_masks_and_batch_invariance(tiny, model):
@@ -241,11 +251,7 @@ def test_whisper_base_architecture_parity(oracle):
     prompt = [50258, 50259, 50359, 50363]
     toks, _ = m.transcribe_tokens([x], prompt, 3)
     rt, rb, rm = WO.greedy_decode(W, hp, ref, prompt, 3)
-    for i in range(3):
-        if rm[i] > 1e-3:
-            assert toks[0, i] == rt[i]
-        else:
-            break
+    assert_picks(toks[0], rt, rm, 1e-3, 3, "whisper-base")
 
 
 @pytest.mark.parametrize("kind", ["q5_0", "q4_1", "q8_0", "q4_0", "q5_1"])
@@ -525,11 +531,7 @@ def test_large_v3_turbo_dimensions_parity(oracle):
     prompt = [sp["sot"], sp["lang0"], sp["transcribe"], sp["not_"]]
     toks, _ = m.transcribe_tokens([x], prompt, 3)
     rt, rb, rm = WO.greedy_decode(W, hp, ref, prompt, 3)
-    for i in range(3):
-        if rm[i] > 1e-3:
-            assert toks[0, i] == rt[i]
-        else:
-            break
+    assert_picks(toks[0], rt, rm, 1e-3, 3, "large-v3-turbo dims")
 
 
 def test_decode_batches_beyond_64_clips(model):
