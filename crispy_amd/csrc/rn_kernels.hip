@@ -464,19 +464,21 @@ struct TansigTab {
     return q == 0 ? v0 : (q == 1 ? v1 : (q == 2 ? v2 : v3));
   }
 };
-// Every product and sum is rounded on its own (__fmul_rn / __fadd_rn are never contracted into an FMA), in the
-// reference's order: the Rust crate does not fuse multiply-adds, and with this the function is bit-identical to the
-// oracle on every table cell and both clamps (tests/test_gpu_rnnoise.py::test_tansig_and_sigmoid_every_table_cell...).
+// Every product and sum is rounded on its own (`fp contract(off)`: hipcc contracts a * b + c into an FMA by default,
+// and HIP's __fmul_rn / __fadd_rn are plain operators that contract too), in the reference's order: the Rust crate does
+// not fuse multiply-adds, and with this the function is bit-identical to the oracle on every table cell and both
+// clamps (tests/test_gpu_rnnoise.py::test_tansig_and_sigmoid_every_table_cell...).
 __device__ __forceinline__ float tansig_approx(float x, const TansigTab& table) {
+#pragma clang fp contract(off)
   const float x0 = x;
   float sign = 1.f;
   if (x < 0.f) { x = -x; sign = -1.f; }
   x = fminf(x, 8.f);                       // keeps the index in range; the clamp result is selected below
-  const int i = (int)floorf(__fadd_rn(.5f, __fmul_rn(25.f, x)));
-  x = __fsub_rn(x, __fmul_rn(.04f, (float)i));
+  const int i = (int)floorf(.5f + 25.f * x);
+  x = x - .04f * (float)i;
   float y = table.at(i);
-  const float dy = __fsub_rn(1.f, __fmul_rn(y, y));
-  y = __fadd_rn(y, __fmul_rn(__fmul_rn(x, dy), __fsub_rn(1.f, __fmul_rn(y, x))));
+  const float dy = 1.f - y * y;
+  y = y + (x * dy) * (1.f - y * x);
   y = sign * y;
   if (!(x0 > -8.f)) y = -1.f;
   if (!(x0 < 8.f)) y = 1.f;                // tested last: NaN takes this branch, as in the reference's `!(x < 8)` first

@@ -37,16 +37,17 @@ struct alignas(16) RnnLds {
 };
 
 __device__ __forceinline__ float tansig_lds(float x, const float* table) {
+#pragma clang fp contract(off)
   if (!(x < 8.f)) return 1.f;
   if (!(x > -8.f)) return -1.f;
   float sign = 1.f;
   if (x < 0.f) { x = -x; sign = -1.f; }
   // every product and sum rounded on its own, in the reference's order (see tansig_approx in rn_kernels.hip)
-  const int i = (int)floorf(__fadd_rn(.5f, __fmul_rn(25.f, x)));
-  x = __fsub_rn(x, __fmul_rn(.04f, (float)i));
+  const int i = (int)floorf(.5f + 25.f * x);
+  x = x - .04f * (float)i;
   float y = table[i];
-  const float dy = __fsub_rn(1.f, __fmul_rn(y, y));
-  y = __fadd_rn(y, __fmul_rn(__fmul_rn(x, dy), __fsub_rn(1.f, __fmul_rn(y, x))));
+  const float dy = 1.f - y * y;
+  y = y + (x * dy) * (1.f - y * x);
   return sign * y;
 }
 __device__ __forceinline__ float sigmoid_lds(float x, const float* table) { return .5f + .5f * tansig_lds(.5f * x, table); }
