@@ -371,6 +371,7 @@ def main():
     ap.add_argument("--precision", type=int, default=0, help="cfg5: 0 = f32 operands, 1 = f16 operands (ggml numerics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-asr", action="store_true", help="skip the Whisper-tiny leg of the metric")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-stream process_frame latency leg")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher self-test on CPU (gloo, no GPU work, no value); used by tests/test_sharding_gloo.py")
     args = ap.parse_args()
@@ -507,6 +508,15 @@ def cfg2(args):
             ncores = os.cpu_count() or 1
             nthreads = max(1, min(ncores, 32))
             line["cpu_baseline"] = cpu_baseline(nthreads, 2500)
+        if world == 1 and not args.no_latency:
+            # the literal drop-in: ONE stream, ONE frame per call, host slices (audio.rs:260-268), from a C program
+            # compiled against include/crispy_hip.h; a child process, timed call by call
+            try:
+                from tests import c_dropin
+                x1 = (synth_audio.stream_np(11, 20, silent=False) * 32768.0).astype("float32").reshape(20, 480)
+                line["latency_us"] = c_dropin.run(weights, x1, timed_calls=10000)[2]
+            except Exception as e:     # a reported extra, never a reason to lose the headline
+                line["latency_us"] = {"error": str(e)[:300]}
         if world == 1 and not args.no_asr:
             del d_in, d_out
             torch.cuda.empty_cache()
