@@ -349,13 +349,13 @@ struct BandEdges {
 #ifndef RN_BAND_BATCH
 #define RN_BAND_BATCH 8
 #endif
-__device__ __forceinline__ float band_sum(const float* part, const BandEdges& be, int lane) {
+__device__ __forceinline__ float band_sum(const float* part_lo, const float* part_hi, const BandEdges& be, int lane) {
   float sum = 0.f;
 #if RN_BAND_BATCH
   const int n_hi = lane > 0 ? be.e0 - be.em1 : 0;
   const int n_lo = lane < RN_NB - 1 ? be.e1 - be.e0 : 0;
-  const float* ph = part + 100 + be.em1;
-  const float* pl = part + be.e0;
+  const float* ph = part_hi + be.em1;
+  const float* pl = part_lo + be.e0;
 #pragma unroll
   for (int base = 0; base < 24; base += RN_BAND_BATCH) {
     float v[RN_BAND_BATCH];
@@ -374,9 +374,9 @@ __device__ __forceinline__ float band_sum(const float* part, const BandEdges& be
   }
 #else
   if (lane > 0)
-    for (int c = be.em1; c < be.e0; ++c) sum += part[100 + c];
+    for (int c = be.em1; c < be.e0; ++c) sum += part_hi[c];
   if (lane < RN_NB - 1)
-    for (int c = be.e0; c < be.e1; ++c) sum += part[c];
+    for (int c = be.e0; c < be.e1; ++c) sum += part_lo[c];
 #endif
   if (lane == 0 || lane == RN_NB - 1) sum *= 2.f;
   return sum;
@@ -429,7 +429,7 @@ __device__ __forceinline__ void band_pairs(const float2* S, const float2* Xc, fl
   }
   auto band_total = [&](float* out) {
     __syncthreads();
-    if (lane < RN_NB) out[lane] = band_sum(part, be, lane);
+    if (lane < RN_NB) out[lane] = band_sum(part, part + 100, be, lane);
     __syncthreads();
   };
   band_total(Eout);
@@ -1062,14 +1062,30 @@ struct alignas(16) RnLdsT {
 };
 static_assert(sizeof(RnLdsT<0>) <= 10240, "16 workgroups per CU need <= 10 KB of LDS each");
 
-// offsets (floats) inside Bb while it serves the RNN
+// offsets (floats) inside Bb while it serves the RNN -- the staged kernels and the non-default forms of the in-wave
+// gain network (RN_GRU_MFMA 0 / 1), which park the pitch spectrum in global memory.  The default fused kernel keeps
+// P in Bb[0, 800) through the gain network and up to the comb filter instead (RN_P_LDS below).
 constexpr int RB_FEAT = 0, RB_DENSE = 48, RB_IN = 72, RB_Z = 192, RB_PART = 384;
 [[maybe_unused]] constexpr int RB_HR = 288;
 // RB_IMG: two split f16 activation images (3 terms x RN_IMG_LD halves each = 2 x 204 floats) of the MFMA gain
 // network; shares the floats of RB_PART, which is only used after the network
 constexpr int RB_IMG = 384;
-// offsets inside U outside band_sums
-constexpr int U_LY = 0, U_G = 48, U_R = 72, U_VAD = 96;
+// offsets inside U outside band_sums (Ly is dead once the features exist: U[48, 192) is free for the gain network)
+constexpr int U_G = 0, U_R = 24, U_VAD = 46, U_LY = 48;
+// ---- pitch spectrum kept in LDS (fused kernel, int8 gain network) ----
+// P used to be parked in global memory between its band sums and the comb filter (3.2 KB written and read back per
+// frame, 1.6 MB of L2 per XCD that the history window of the streams wants: profiles/r01q_pmc.json showed 15 KB of
+// L2-miss traffic per stream-frame against 3.84 KB algorithmic).  The comb filter needs bins < 400 only, so P stays
+// where its transform left it, Bb[0, 800) floats, and the gain network's 432 floats of workspace move into what is
+// dead at that point: the bins >= 400 of both spectra (never read after the band energies; X's are zeroed before the
+// inverse transform anyway) and the part of U behind the band values.
+//   Bb[800, 842) features   Bb[842, 938) z gates   Bb[938, 962) dense layer
+//   A [800, 944) digit image of the recurrent operand (4 x 144 B), then the rising-half band partials of the comb filter
+//   U [ 48, 192) digit image of the layer input (4 x 144 B; Ly before it), then the falling-half band partials
+#ifndef RN_P_LDS
+#define RN_P_LDS 1
+#endif
+constexpr int PL_FEAT = 800, PL_Z = 842, PL_DENSE = 938, PL_A_FREE = 800, PL_U_FREE = 48;
 
 // top-2 bookkeeping of find_best_pitch as an ordering on (num, den, idx)
 struct Cand {
@@ -1213,6 +1229,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
   float* lp = reinterpret_cast<float*>(L.Bb);  // 864 floats during the pitch phase
   float* Sa = reinterpret_cast<float*>(L.A);   // pitch-phase scratch
   float* Rb = reinterpret_cast<float*>(L.Bb);  // RNN vectors after the pitch spectrum is parked
+  constexpr bool P_LDS = MODE == 0 && RN_GRU_MFMA == 2 && RN_P_LDS;
+  constexpr int KB_FEAT = P_LDS ? PL_FEAT : RB_FEAT;
   float* Xf = reinterpret_cast<float*>(L.A);
 
   // MODE 2 runs over (stream, group of RN_SYNTH_GROUP frames): synthesis has no cross-frame dependency except
@@ -1721,7 +1739,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
     STAMP(7)
     // band energy of P, band correlation with X, and P parked in L2 from the same registers (read back by the comb
     // filter, which needs bins < 400 only); Bb becomes the RNN workspace
-    band_pairs<true>(L.Bb, L.A, L.U, L.Ep, L.Exp, pg, tab, be, lane);
+    band_pairs<true>(L.Bb, L.A, L.U, L.Ep, L.Exp, P_LDS ? nullptr : pg, tab, be, lane);
     if (a.dbg && t == a.T - 1) {
       float* D = a.dbg + (long)b * RN_DBG_FLOATS;
       const float* Pf = reinterpret_cast<const float*>(L.Bb);
@@ -1746,7 +1764,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
       L.Exp[lane] = L.Exp[lane] / sqrtf(.001f + L.Ex[lane] * L.Ep[lane]);
       L.U[U_LY + lane] = log10f(1e-2f + L.Ex[lane]);
     }
-    if (lane < 6) { Rb[RB_FEAT + 42 + lane] = 0.f; }
+    if (!P_LDS && lane < 6) { Rb[RB_FEAT + 42 + lane] = 0.f; }
     __syncthreads();
     if (a.dbg && t == a.T - 1 && lane < RN_NB) {
       float* D = a.dbg + (long)b * RN_DBG_FLOATS;
@@ -1781,21 +1799,21 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
         float v = se * dct_norm;
         if (lane == 0) v -= 1.3f;
         if (lane == 1) v -= 0.9f;
-        Rb[RB_FEAT + 34 + lane] = v;
+        Rb[KB_FEAT + 34 + lane] = v;
       }
-      if (lane == 6) Rb[RB_FEAT + 40] = .01f * (float)(pitch_index - 300);
+      if (lane == 6) Rb[KB_FEAT + 40] = .01f * (float)(pitch_index - 300);
       silence = E < 0.04f;
       if (!silence && lane < RN_NB) {
         float v = sl * dct_norm;
         if (lane == 0) v -= 12.f;
         if (lane == 1) v -= 4.f;
-        Rb[RB_FEAT + lane] = v;
+        Rb[KB_FEAT + lane] = v;
         L.ceps[memid * RN_NB + lane] = v;
       }
     }
     __syncthreads();
     if (silence) {
-      if (lane < RN_NFEAT) Rb[RB_FEAT + lane] = 0.f;
+      if (lane < RN_NFEAT) Rb[KB_FEAT + lane] = 0.f;
       if (lane < RN_NB) L.U[U_G + lane] = 0.f;
       __syncthreads();
     } else {
@@ -1806,9 +1824,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
           const float c0 = L.ceps[memid * RN_NB + lane];
           const float c1 = L.ceps[m1 * RN_NB + lane];
           const float c2 = L.ceps[m2 * RN_NB + lane];
-          Rb[RB_FEAT + lane] = c0 + c1 + c2;
-          Rb[RB_FEAT + RN_NB + lane] = c0 - c2;
-          Rb[RB_FEAT + RN_NB + 6 + lane] = c0 - 2.f * c1 + c2;
+          Rb[KB_FEAT + lane] = c0 + c1 + c2;
+          Rb[KB_FEAT + RN_NB + lane] = c0 - c2;
+          Rb[KB_FEAT + RN_NB + 6 + lane] = c0 - 2.f * c1 + c2;
         }
         memid = (memid + 1 == 8) ? 0 : memid + 1;
       }
@@ -1828,7 +1846,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
         md = fminf(md, dpp_mov<0x4E>(md));     // quad_perm [2,3,0,1]
         md = fminf(md, dpp_mov<0x141>(md));    // row_half_mirror: the other quad of the group of 8
         const float sv = wave_sum(md) * .125f;
-        if (lane == 0) Rb[RB_FEAT + 41] = sv / 8.f - 2.1f;
+        if (lane == 0) Rb[KB_FEAT + 41] = sv / 8.f - 2.1f;
       }
       __syncthreads();
       STAMP(9)
@@ -1839,7 +1857,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
       // ---- hand-off to the batched gain network and the synthesis kernel ----
       const long fr = (long)t * a.B + b;
       for (int i = lane; i < RN_NFREQ; i += WAVE) a.xspec[fr * 482 + i] = L.A[i];
-      if (lane < RNN_FEAT_LD) a.feat[fr * RNN_FEAT_LD + lane] = lane < RN_NFEAT ? Rb[RB_FEAT + lane] : 0.f;
+      if (lane < RNN_FEAT_LD) a.feat[fr * RNN_FEAT_LD + lane] = lane < RN_NFEAT ? Rb[KB_FEAT + lane] : 0.f;
       float* rc = a.rec + fr * RN_REC_LD;
       if (lane < RN_NB) { rc[lane] = L.Ex[lane]; rc[22 + lane] = L.Ep[lane]; rc[44 + lane] = L.Exp[lane]; }
       if (lane == 0) {
@@ -1873,17 +1891,18 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
       // stages and stay live across the gain network, which is where registers are scarcest)
       // ---- 8. RNN (vectors in Bb) ----
       const float S = 1.f / 256.f;
-      float* feat = Rb + RB_FEAT;
-      float* dense = Rb + RB_DENSE;
+      float* feat = Rb + KB_FEAT;
+      float* dense = Rb + (P_LDS ? PL_DENSE : RB_DENSE);
+      [[maybe_unused]] float* zbuf = Rb + (P_LDS ? PL_Z : RB_Z);
       [[maybe_unused]] float* gin = Rb + RB_IN;     // the f16 / VALU forms of the network (RN_GRU_MFMA 0, 1)
       TansigTab tansig;
       tansig.load(tab->tansig, lane);
 #if RN_GRU_MFMA == 2
       // signed-digit int8 images of the layer inputs (in_img) and of the recurrent operand (st_img)
-      signed char* in_img = reinterpret_cast<signed char*>(Rb + RB_IMG);
-      signed char* st_img = in_img + 4 * RN_IMG8_LD;
+      signed char* in_img = reinterpret_cast<signed char*>(P_LDS ? L.U + PL_U_FREE : Rb + RB_IMG);
+      signed char* st_img = P_LDS ? reinterpret_cast<signed char*>(Xf + PL_A_FREE) : in_img + 4 * RN_IMG8_LD;
       const int toff = (lane & 3) * RN_IMG8_LD;
-      RnScale sc = image_i8<48>(in_img, lane, [&](int i) { return feat[i]; });            // feat[42..47] = 0
+      RnScale sc = image_i8<48>(in_img, lane, [&](int i) { return i < RN_NFEAT ? feat[i] : 0.f; });
       __syncthreads();
       {
         const int row = min(lane, 23);
@@ -1894,7 +1913,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
       __syncthreads();
       sc = image_i8<32>(in_img, lane, [&](int i) { return i < 24 ? dense[i] : 0.f; });
       gru_layer_i<24, 24>(wrs, RnPack8::VG_W, RnPack8::VG_R, wpf + RnPack::VG_B, in_img, sc.dn,
-                          L.rnn_state, Rb + RB_Z, st_img, toff, tansig, lane);
+                          L.rnn_state, zbuf, st_img, toff, tansig, lane);
       {
         float acc = 0.f;
         if (lane == 0) {
@@ -1910,12 +1929,12 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
       vad_prob = L.U[U_VAD];
       STAMP(10)
       gru_layer_i<90, 48>(wrs, RnPack8::NG_W, RnPack8::NG_R, wpf + RnPack::NG_B, in_img, sc.dn,
-                          L.rnn_state + 24, Rb + RB_Z, st_img, toff, tansig, lane);
+                          L.rnn_state + 24, zbuf, st_img, toff, tansig, lane);
       STAMP(11)
       sc = image_i8<128>(in_img, lane, [&](int i) { return i < 72 ? L.rnn_state[i] : (i < 114 ? feat[i - 72] : 0.f); });
       __syncthreads();
       gru_layer_i<114, 96>(wrs, RnPack8::DG_W, RnPack8::DG_R, wpf + RnPack::DG_B, in_img, sc.dn,
-                           L.rnn_state + 72, Rb + RB_Z, st_img, toff, tansig, lane);
+                           L.rnn_state + 72, zbuf, st_img, toff, tansig, lane);
       sc = image_i8<96>(st_img, lane, [&](int i) { return L.rnn_state[72 + i]; });
       __syncthreads();
       {
@@ -2034,7 +2053,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
 #pragma unroll
         for (int m = 0; m < 4; ++m) {       // parked pitch spectrum and the per-bin tables: issued before r is ready
           const int pidx = min(lane + WAVE * m, 199);
-          pq[m] = *reinterpret_cast<const float4*>(pg + 2 * pidx);
+          pq[m] = P_LDS ? *reinterpret_cast<const float4*>(L.Bb + 2 * pidx) : *reinterpret_cast<const float4*>(pg + 2 * pidx);
           fq[m] = *reinterpret_cast<const float2*>(tab->bin_frac + 2 * pidx);
           bq[m] = tab->bin_band[2 * pidx];
         }
@@ -2048,7 +2067,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
           L.U[U_R + lane] = r;
         }
         __syncthreads();
-        float* part = Rb + (MODE == 2 ? 0 : RB_PART);
+        float* part = P_LDS ? Xf + PL_A_FREE : Rb + (MODE == 2 ? 0 : RB_PART);
+        float* part_hi = P_LDS ? L.U + PL_U_FREE : part + 100;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           const int pidx = lane + WAVE * m;
@@ -2068,14 +2088,15 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
             float hi = fq[m].x * e0 + fq[m].y * e1;
             lo += dpp_mov<0xB1>(lo);        // the other pair of this 4-bin chunk sits in the neighbouring lane
             hi += dpp_mov<0xB1>(hi);
-            if ((lane & 1) == 0) { part[pidx >> 1] = lo; part[100 + (pidx >> 1)] = hi; }
+            if ((lane & 1) == 0) { part[pidx >> 1] = lo; part_hi[pidx >> 1] = hi; }
           }
         }
       }
       __syncthreads();
       if (lane < RN_NB) {        // new band energies (Ep is dead), then the renormalisation and the smoothed gains
-        float* part = Rb + (MODE == 2 ? 0 : RB_PART);
-        const float sum = band_sum(part, be, lane);
+        const float* part = P_LDS ? Xf + PL_A_FREE : Rb + (MODE == 2 ? 0 : RB_PART);
+        const float* part_hi = P_LDS ? L.U + PL_U_FREE : part + 100;
+        const float sum = band_sum(part, part_hi, be, lane);
         L.U[U_R + lane] = sqrtf(L.Ex[lane] / (1e-8f + sum));  // norm
         float gg;
         if constexpr (MODE == 2) gg = a.g_smooth[((long)t * a.B + b) * RNN_GAIN_LD + lane];   // smoothing state lives in the gain-network kernel
@@ -2116,7 +2137,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
     // ---- taps / debug ----
     if (a.taps && t >= t_out) {
       float* tp = a.taps + ((long)t * a.B + b) * RN_TAPS;
-      if (lane < RN_NFEAT) tp[lane] = MODE == 2 ? a.feat[((long)t * a.B + b) * RNN_FEAT_LD + lane] : Rb[MODE == 2 ? 0 : RB_FEAT + lane];
+      if (lane < RN_NFEAT) tp[lane] = MODE == 2 ? a.feat[((long)t * a.B + b) * RNN_FEAT_LD + lane] : Rb[MODE == 2 ? 0 : KB_FEAT + lane];
       if (lane < RN_NB) tp[42 + lane] = L.U[U_G + lane];
       if (lane == 0) {
         tp[64] = (float)pitch_index;
