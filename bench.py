@@ -473,7 +473,7 @@ def cfg2(args):
         traffic = None
         valu = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01q_pmc.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r02a_pmc.json")))
             if pm["config"]["streams"] == B:
                 fk = pm["rn_frame_kernel"]
                 sf = B * T / launches                        # stream-frames per (average) launch
@@ -482,7 +482,7 @@ def cfg2(args):
                 # slots; 1024 SIMDs; priced against the live kernel time at the 2.4 GHz peak clock.
                 valu = {"insts_per_stream_frame": fk["insts_per_stream_frame"]["valu"],
                         "issue_frac": fk["valu_active_quads_per_stream_frame"] * sf * 4 / (1024 * frame_ms * 1e-3 * 2.4e9),
-                        "source": "profiles/r01q_pmc.json (rocprofv3 --pmc SQ_ACTIVE_INST_VALU), live kernel time"}
+                        "source": "profiles/r02a_pmc.json (rocprofv3 --pmc SQ_ACTIVE_INST_VALU), live kernel time"}
         except Exception:
             pass
         achieved = alg_bytes / (frame_ms * 1e-3) / 1e9
