@@ -3,6 +3,7 @@
 // (reference: src-tauri/src/managers/transcription.rs:138-141, 183-185).
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -51,6 +52,7 @@ struct crispy_asr {
   const float *ln_post_w = nullptr, *ln_post_b = nullptr;
   const void* conv2_wh = nullptr;            // f16 copy of the reordered conv2 kernel (precision mode 1)
   int enc_precision = 0;                     // 0: f32 operands (default), 1: f16 operands for the encoder GEMMs
+  int xcd_swizzle = 1;                       // mode 1 GEMMs: column tiles of a row tile on one XCD (CRISPY_ASR_XCD=0 turns it off)
   std::vector<EncLayer> enc;
   const float *tok_emb = nullptr, *dec_pos = nullptr, *dec_ln_w = nullptr, *dec_ln_b = nullptr;
   const float *logit_lw = nullptr, *logit_ls = nullptr, *logit_lc = nullptr;   // final LayerNorm folded into the logits GEMM
@@ -281,6 +283,7 @@ int crispy_asr_create(const crispy_asr_hparams* hp, const float* mel_filters, in
   h->device = device;
   h->hp = *hp;
   h->eot = hp->n_vocab >= 51865 ? 50257 : 50256;   // multilingual vocabularies shift the specials by one
+  if (const char* e = std::getenv("CRISPY_ASR_XCD")) h->xcd_swizzle = std::atoi(e) != 0;
   auto body = [&]() -> int {
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -480,6 +483,46 @@ int crispy_asr_encode_device(crispy_asr* h, const float* d_mel_t, int batch, flo
     g.rowtab_period = Tn;
     HIP_TRY(egemm(g, h->conv2_wh, batch));
   }
+  if (h->enc_precision == 1) {
+    // whisper.cpp's numerics with the bytes halved: every activation that only feeds a matrix product is stored as the
+    // f16 value the product would round it to anyway (LayerNorm output, q | k, V^T, attention output, MLP hidden
+    // layer); the residual stream stays f32.  The f16 buffers alias the f32 workspace of the default mode.
+    void* xn_h = h->w_xn;                                                   // [rows][d] f16
+    void* qk_h = h->w_qkv;                                                  // [rows][2 d] f16
+    void* vt_h = reinterpret_cast<_Float16*>(h->w_qkv) + rows * 2L * d;     // [batch][d][ENC_TP] f16
+    void* att_h = h->w_att;                                                 // [rows][d] f16
+    void* hid_h = h->w_h;                                                   // [rows][4 d] f16
+    const int swz = h->xcd_swizzle;
+    auto hg = [&](const void* A, long lda, const void* W, long ldw, void* C, long ldc, const float* bias, int N, int K) {
+      HGemmArgs g{};
+      g.A = reinterpret_cast<const _Float16*>(A); g.lda = lda; g.W = reinterpret_cast<const _Float16*>(W); g.ldw = ldw;
+      g.C = C; g.ldc = ldc; g.bias = bias; g.M = (int)rows; g.N = N; g.K = K; g.vt_T = Tn; g.xcd_swizzle = swz;
+      return g;
+    };
+    for (const EncLayer& L : h->enc) {
+      HIP_TRY(layernorm_f16out(h->w_x, L.ln1_w, L.ln1_b, xn_h, rows, d, s));
+      HIP_TRY(gemm_hh(hg(xn_h, d, L.qkv_wh, d, qk_h, 2L * d, L.qkv_b, 2 * d, d), HGEMM_F16, s));
+      HIP_TRY(gemm_hh(hg(xn_h, d, reinterpret_cast<const _Float16*>(L.qkv_wh) + 2L * d * d, d, vt_h, 0, L.qkv_b + 2 * d, d, d),
+                      HGEMM_VT, s));
+      HIP_TRY(attn_encoder_h(qk_h, vt_h, att_h, batch, Tn, d, H, s));
+      {
+        HGemmArgs g = hg(att_h, d, L.out_wh, d, h->w_x, d, L.out_b, d, d);
+        g.residual = h->w_x; g.ldr = d;
+        HIP_TRY(gemm_hh(g, HGEMM_RES, s));
+      }
+      HIP_TRY(layernorm_f16out(h->w_x, L.ln2_w, L.ln2_b, xn_h, rows, d, s));
+      {
+        HGemmArgs g = hg(xn_h, d, L.fc1_wh, d, hid_h, 4L * d, L.fc1_b, 4 * d, d);
+        g.gelu = 1;
+        HIP_TRY(gemm_hh(g, HGEMM_F16, s));
+      }
+      {
+        HGemmArgs g = hg(hid_h, 4L * d, L.fc2_wh, 4L * d, h->w_x, d, L.fc2_b, d, 4 * d);
+        g.residual = h->w_x; g.ldr = d;
+        HIP_TRY(gemm_hh(g, HGEMM_RES, s));
+      }
+    }
+  } else
   for (const EncLayer& L : h->enc) {
     HIP_TRY(layernorm_f32(h->w_x, L.ln1_w, L.ln1_b, h->w_xn, rows, d, s));
     HIP_TRY(egemm(gemm(h->w_xn, d, L.qkv_w, d, h->w_qkv, 3L * d, L.qkv_b, (int)rows, 3 * d, d), L.qkv_wh, 1));

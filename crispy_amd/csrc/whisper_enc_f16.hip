@@ -1,0 +1,426 @@
+// whisper_enc_f16.hip -- the Whisper encoder at the reference's precision on MI355X (gfx950): precision mode 1.
+//
+// whisper.cpp computes every matrix product with f16 operands and f32 accumulation (ggml mul_mat: f16 weights, the f32
+// activations converted to f16 on the way in) [UPSTREAM-RECALL].  An activation that ONLY feeds a matrix product can
+// therefore be stored already rounded -- same numbers, half the bytes: the LayerNorm outputs, q | k | v, the attention
+// output and the GELU'd MLP hidden layer live in HBM as f16; the residual stream, which is added to, stays f32.
+//
+//   layernorm_h_kernel     f32 row -> f16 row (statistics in f32)
+//   gemm_hh_kernel<EPI>    C = A[M,K] (f16) . W[N,K]^T (f16), f32 accumulation on v_mfma_f32_32x32x16_f16,
+//                          128 x 128 x 32 tiles, 4 waves x (2 x 2) MFMA tiles, double-buffered LDS (40-half rows).
+//                            EPI_F16   +bias (, GELU) -> f16 row-major                     (q | k, fc1)
+//                            EPI_RES   +bias +residual -> f32 row-major, in place          (attention out-proj, fc2)
+//                            EPI_VT    +bias -> f16 V^T[clip][head][64][ENC_TP]           (v, transposed for attention)
+//   attn_enc_h_kernel      flash-style attention on f16 q | k and V^T: wave = 32 queries, S^T = K.Q^T per 32-key tile,
+//                          softmax statistics per lane in f32 (one v_permlane32_swap per tile joins the two key halves),
+//                          P rounded to f16 straight from the S^T accumulator registers into the B operand of
+//                          O^T += V^T.P^T; the running maximum is only raised when a score exceeds it by 2^6 (a stale
+//                          maximum scales every probability of a row by the same power of two, which f16 rounding does
+//                          not see), so the 32 accumulator rescales per tile are rare.
+#include "asr_common.h"
+
+namespace crispy {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+constexpr int HH_M = 128, HH_N = 128, HH_K = 32, HH_LD = 40;
+
+__device__ __forceinline__ float gelu_erf_e(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+// row index of accumulator register r for this lane (32 x 32 MFMA C / D layout)
+__device__ __forceinline__ int acc_row_e(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+__device__ __forceinline__ half4 to_half4(float a, float b, float c, float d) {
+  const half2v lo = __builtin_convertvector(float2v{a, b}, half2v), hi = __builtin_convertvector(float2v{c, d}, half2v);
+  return half4{lo[0], lo[1], hi[0], hi[1]};
+}
+
+template <int PER>
+__global__ __launch_bounds__(256) void layernorm_h_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, _Float16* __restrict__ y,
+                                                          long rows) {
+  constexpr int D = 64 * PER;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + row * D;
+  float v[PER], gm[PER], bt[PER];
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) v[q] = xr[lane + 64 * q];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) { gm[q] = gamma[lane + 64 * q]; bt[q] = beta[lane + 64 * q]; }
+#pragma unroll
+  for (int q = 0; q < PER; ++q) s += v[q];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  const float mean = s / (float)D;
+  float s2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) { const float d = v[q] - mean; s2 = fmaf(d, d, s2); }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s2 += __shfl_xor(s2, off, 64);
+  const float rstd = 1.f / sqrtf(s2 / (float)D + 1e-5f);
+  _Float16* yr = y + row * D;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) yr[lane + 64 * q] = (_Float16)((v[q] - mean) * rstd * gm[q] + bt[q]);
+}
+
+enum { EPI_F16 = 0, EPI_RES = 1, EPI_VT = 2 };
+
+template <int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void gemm_hh_kernel(HGemmArgs g) {
+  __shared__ __attribute__((aligned(16))) _Float16 As[2][HH_M * HH_LD];
+  __shared__ __attribute__((aligned(16))) _Float16 Ws[2][HH_N * HH_LD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // Workgroups are dealt to the 8 XCDs round robin.  All column tiles of one row tile go to the same XCD (its L2 then
+  // serves the A tile to all of them, instead of eight L2s fetching it once each): linear id -> (xcd, slot) ->
+  // row tile = 8 (slot / n_tiles) + xcd, column tile = slot % n_tiles.  Row tiles past the matrix return at once.
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (g.xcd_swizzle) {
+    const int nt = gridDim.x;
+    const int lin = blockIdx.y * nt + blockIdx.x;
+    const int xcd = lin & 7, slot = lin >> 3;
+    by = 8 * (slot / nt) + xcd;
+    bx = slot % nt;
+    if (by * HH_M >= g.M) return;
+  }
+  const _Float16* __restrict__ A = g.A;
+  const _Float16* __restrict__ W = g.W;
+  const int m0 = by * HH_M, n0 = bx * HH_N;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+  // staging: 8 halfs (16 bytes) per thread and tile half: row (tid >> 2) + 64 h, k offset 8 (tid & 3).  Plain named
+  // registers and unconditional code: with the loads behind `if (kb + 1 < nk)` in a lambda over arrays the compiler
+  // kept the staging registers in SCRATCH (load - wait - scratch store, scratch load - LDS store: no prefetch at all).
+  const int sr = tid >> 2, sk = (tid & 3) * 8;
+  const int M = g.M, N = g.N;
+  const long lda = g.lda, ldw = g.ldw;
+  const _Float16* pa0 = A + (long)min(m0 + sr, M - 1) * lda + sk;        // clamped rows: their results are not stored
+  const _Float16* pa1 = A + (long)min(m0 + sr + 64, M - 1) * lda + sk;
+  const _Float16* pw0 = W + (long)min(n0 + sr, N - 1) * ldw + sk;
+  const _Float16* pw1 = W + (long)min(n0 + sr + 64, N - 1) * ldw + sk;
+  const int so0 = sr * HH_LD + sk, so1 = (sr + 64) * HH_LD + sk;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = g.K / HH_K;
+  uint4 ra0 = *reinterpret_cast<const uint4*>(pa0), ra1 = *reinterpret_cast<const uint4*>(pa1);
+  uint4 rw0 = *reinterpret_cast<const uint4*>(pw0), rw1 = *reinterpret_cast<const uint4*>(pw1);
+  *reinterpret_cast<uint4*>(&As[0][so0]) = ra0;
+  *reinterpret_cast<uint4*>(&As[0][so1]) = ra1;
+  *reinterpret_cast<uint4*>(&Ws[0][so0]) = rw0;
+  *reinterpret_cast<uint4*>(&Ws[0][so1]) = rw1;
+  __syncthreads();
+  const int li = lane & 31, lh = lane >> 5;
+  for (int kb = 0; kb < nk; ++kb) {
+    const int buf = kb & 1;
+    const int kn = min(kb + 1, nk - 1) * HH_K;      // the last trip re-requests its own block (never used)
+    ra0 = *reinterpret_cast<const uint4*>(pa0 + kn);
+    ra1 = *reinterpret_cast<const uint4*>(pa1 + kn);
+    rw0 = *reinterpret_cast<const uint4*>(pw0 + kn);
+    rw1 = *reinterpret_cast<const uint4*>(pw1 + kn);
+    // pin the requests here: left alone the scheduler sinks them below the MFMAs, right in front of the LDS stores
+    // that consume them (load - wait - store: the whole memory latency exposed once per k-block)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      half8 a[2], w[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = *reinterpret_cast<const half8*>(&As[buf][(wm + 32 * i + li) * HH_LD + 16 * ks + 8 * lh]);
+        w[i] = *reinterpret_cast<const half8*>(&Ws[buf][(wn + 32 * i + li) * HH_LD + 16 * ks + 8 * lh]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          // EPI_F16 wants a lane to own a ROW of C (four consecutive columns per register group -> 8-byte stores):
+          // D = W.A^T puts m in the lane and n in the registers.  The other two want a lane to own a COLUMN.
+          if (EPI == EPI_F16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[j], a[i], acc[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], w[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    *reinterpret_cast<uint4*>(&As[buf ^ 1][so0]) = ra0;
+    *reinterpret_cast<uint4*>(&As[buf ^ 1][so1]) = ra1;
+    *reinterpret_cast<uint4*>(&Ws[buf ^ 1][so0]) = rw0;
+    *reinterpret_cast<uint4*>(&Ws[buf ^ 1][so1]) = rw1;
+    __syncthreads();
+  }
+
+  if (EPI == EPI_F16) {
+    _Float16* __restrict__ C = reinterpret_cast<_Float16*>(g.C);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + wm + 32 * i + li;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float4 bq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = min(n0 + wn + 32 * j + 8 * q + 4 * lh, g.N - 4);
+          bq[q] = g.bias ? *reinterpret_cast<const float4*>(g.bias + n) : make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + wn + 32 * j + 8 * q + 4 * lh;
+          float v0 = acc[i][j][4 * q] + bq[q].x, v1 = acc[i][j][4 * q + 1] + bq[q].y;
+          float v2 = acc[i][j][4 * q + 2] + bq[q].z, v3 = acc[i][j][4 * q + 3] + bq[q].w;
+          if (g.gelu) { v0 = gelu_erf_e(v0); v1 = gelu_erf_e(v1); v2 = gelu_erf_e(v2); v3 = gelu_erf_e(v3); }
+          if (m < g.M && n < g.N) *reinterpret_cast<half4*>(C + (long)m * g.ldc + n) = to_half4(v0, v1, v2, v3);
+        }
+      }
+    }
+  } else if (EPI == EPI_RES) {
+    float* __restrict__ C = reinterpret_cast<float*>(g.C);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn + 32 * j + li;
+        const int nc = min(n, g.N - 1);
+        const float bias = g.bias ? g.bias[nc] : 0.f;
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0 += 8) {
+          float extra[8];
+#pragma unroll
+          for (int r = 0; r < 8; ++r)     // residual operands of eight rows requested together (clamped addresses)
+            extra[r] = g.residual[(long)min(m0 + wm + 32 * i + acc_row_e(r0 + r, lane), g.M - 1) * g.ldr + nc];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const int m = m0 + wm + 32 * i + acc_row_e(r0 + r, lane);
+            if (m < g.M && n < g.N) C[(long)m * g.ldc + n] = acc[i][j][r0 + r] + bias + extra[r];
+          }
+        }
+      }
+  } else {   // EPI_VT: column n = (head, dim), row m = (clip, t) -> Vt[((clip * heads + head) * 64 + dim) * ENC_TP + t]
+    _Float16* __restrict__ C = reinterpret_cast<_Float16*>(g.C);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn + 32 * j + li;
+        const int nc = min(n, g.N - 1);
+        const float bias = g.bias ? g.bias[nc] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int m = m0 + wm + 32 * i + 8 * q + 4 * lh;       // four consecutive rows; T % 4 == 0, so one clip
+          const int clip = m / g.vt_T, t = m - clip * g.vt_T;
+          const half4 v = to_half4(acc[i][j][4 * q] + bias, acc[i][j][4 * q + 1] + bias, acc[i][j][4 * q + 2] + bias,
+                                   acc[i][j][4 * q + 3] + bias);
+          if (m < g.M && n < g.N) *reinterpret_cast<half4*>(C + ((long)clip * g.N + nc) * ENC_TP + t) = v;
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Encoder self-attention, head dim 64, on f16 q | k (row-major [B * T][2 D]) and V^T ([B][heads][64][ENC_TP]).
+// grid (ceil(T / 128), heads, B), 4 waves, wave = 32 queries; out f16 [B * T][D].
+// ---------------------------------------------------------------------------------------------
+constexpr int AT_KLD = 72;    // halfs per K row in LDS (64 + 8): 16-lane b128 reads spread over all banks
+constexpr int AT_VLD = 36;    // halfs per V^T row in LDS (32 + 4): b64 reads of 16 rows hit 16 distinct bank pairs
+__global__ __launch_bounds__(256) void attn_enc_h_kernel(const _Float16* __restrict__ qk, const _Float16* __restrict__ vt,
+                                                         _Float16* __restrict__ out, int T, int D) {
+  // K and V^T tiles of 32 keys are staged once per workgroup (the four waves work on the same clip and head) and
+  // double buffered: the requests for tile i + 1 are in flight while tile i is computed, one barrier per tile.
+  __shared__ __attribute__((aligned(16))) _Float16 Ks[2][32 * AT_KLD];
+  __shared__ __attribute__((aligned(16))) _Float16 Vs[2][64 * AT_VLD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y, heads = gridDim.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const long ld = 2L * D;
+  const _Float16* Qp = qk + (long)b * T * ld + h * 64;
+  const _Float16* Kp = Qp + D;
+  const _Float16* Vp = vt + ((long)(b * heads + h) * 64) * ENC_TP;     // row d at Vp + d * ENC_TP
+  const float sc = 0.125f * 1.4426950408889634f;    // 1 / sqrt(64) and log2(e): the exponentials are taken in base 2
+
+  // staging roles: K tile = 32 rows x 8 chunks of 16 bytes, V^T tile = 64 rows x 4 chunks
+  const int krow = tid >> 3, kch = tid & 7, vrow = tid >> 2, vch = tid & 3;
+  const _Float16* kg = Kp + kch * 8;
+  const _Float16* vg = Vp + (long)vrow * ENC_TP + vch * 8;
+  auto kaddr = [&](int k0) { return kg + (long)min(k0 + krow, T - 1) * ld; };
+  uint4 rk = *reinterpret_cast<const uint4*>(kaddr(0));
+  uint4 rv = *reinterpret_cast<const uint4*>(vg);
+  const int kso = krow * AT_KLD + kch * 8, vso = vrow * AT_VLD + vch * 8;
+  *reinterpret_cast<uint4*>(&Ks[0][kso]) = rk;
+  *reinterpret_cast<uint2*>(&Vs[0][vso]) = make_uint2(rv.x, rv.y);
+  *reinterpret_cast<uint2*>(&Vs[0][vso + 4]) = make_uint2(rv.z, rv.w);
+
+  // Q operand of k-step ks: Q[q = li][16 ks + 8 lh .. + 7]
+  half8 qh[4];
+  {
+    const int q = min(q0 + li, T - 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qh[ks] = *reinterpret_cast<const half8*>(Qp + (long)q * ld + 16 * ks + 8 * lh);
+  }
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m_run = -1e30f, l_run = 0.f;      // m_run: integer, log2 units; l_run: this lane's keys only (halves joined at the end)
+  __syncthreads();
+
+  const int n_tiles = (T + 31) / 32;
+  for (int it = 0; it < n_tiles; ++it) {
+    const int k0 = it * 32, buf = it & 1;
+    {
+      const int kn = min(it + 1, n_tiles - 1) * 32;      // the last trip re-requests its own tile (never used)
+      rk = *reinterpret_cast<const uint4*>(kaddr(kn));
+      rv = *reinterpret_cast<const uint4*>(vg + kn);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- S^T tile: rows = keys (li), columns = queries ----
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const half8 kh = *reinterpret_cast<const half8*>(&Ks[buf][li * AT_KLD + 16 * ks + 8 * lh]);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s, 0, 0, 0);
+    }
+    const bool tail = k0 + 32 > T;          // wave-uniform: the last tile has keys past the end
+    if (tail) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (k0 + acc_row_e(r, lane) >= T) s[r] = -3e38f;
+    }
+    float mloc = fmaxf(fmaxf(s[0], s[1]), s[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) mloc = fmaxf(fmaxf(mloc, s[r]), s[r + 1]);
+    mloc = fmaxf(mloc, s[15]) * sc;
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mloc), __float_as_uint(mloc), false, false);
+      mloc = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    // Raise the reference exponent only when it is exceeded by more than 2^6 (p <= 128 fits f16 with room to spare),
+    // and keep it an INTEGER: 2^(t - m) with integer m has the mantissa of 2^t, so the f16 rounding of a probability
+    // does not depend on which tile last raised the reference -- the oracle rounds 2^(t - ceil(row max)) the same way.
+    if (__builtin_amdgcn_ballot_w64(mloc > m_run + 6.f) != 0ull) {
+      const float m_new = ceilf(fmaxf(m_run, mloc));
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+      m_run = m_new;
+    }
+    float psum = 0.f;
+    half8 ph[2];
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const float p0 = __builtin_amdgcn_exp2f(fmaf(s[r], sc, -m_run)), p1 = __builtin_amdgcn_exp2f(fmaf(s[r + 1], sc, -m_run));
+      psum += p0 + p1;
+      const half2v pp = __builtin_convertvector(float2v{p0, p1}, half2v);
+      ph[r >> 3][r & 7] = pp[0];
+      ph[r >> 3][(r & 7) + 1] = pp[1];
+    }
+    l_run += psum;
+    // ---- O^T += V^T . P^T: k-slot (lh, e) of step ks is the key of S^T register 8 ks + e, i.e. keys
+    // k0 + 16 ks + 4 lh + {0..3} and + 8 + {0..3}: two 8-byte runs of row d (li, 32 + li) ----
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const _Float16* r0 = &Vs[buf][li * AT_VLD + 16 * ks + 4 * lh];
+      const _Float16* r1 = r0 + 32 * AT_VLD;
+      half4 a0 = *reinterpret_cast<const half4*>(r0), a1 = *reinterpret_cast<const half4*>(r0 + 8);
+      half4 b0 = *reinterpret_cast<const half4*>(r1), b1 = *reinterpret_cast<const half4*>(r1 + 8);
+      if (tail) {   // V^T columns past the end hold whatever the buffer held: 0 x NaN must not reach the accumulators
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (k0 + 16 * ks + 4 * lh + e >= T) { a0[e] = (_Float16)0.f; b0[e] = (_Float16)0.f; }
+          if (k0 + 16 * ks + 4 * lh + 8 + e >= T) { a1[e] = (_Float16)0.f; b1[e] = (_Float16)0.f; }
+        }
+      }
+      const half8 v0 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      const half8 v1 = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+      o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, ph[ks], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, ph[ks], o1, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    *reinterpret_cast<uint4*>(&Ks[buf ^ 1][kso]) = rk;
+    *reinterpret_cast<uint2*>(&Vs[buf ^ 1][vso]) = make_uint2(rv.x, rv.y);
+    *reinterpret_cast<uint2*>(&Vs[buf ^ 1][vso + 4]) = make_uint2(rv.z, rv.w);
+    __syncthreads();
+  }
+  // ---- normalise; lane (li = query, lh) holds O[q][d] for d = acc_row(r) (+ 32 for o1): 8-byte stores ----
+  {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+    l_run = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+  }
+  const float inv = 1.f / l_run;
+  const int q = q0 + li;
+  if (q < T) {
+    _Float16* orow = out + ((long)b * T + q) * D + h * 64;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int d = 8 * g4 + 4 * lh;
+      *reinterpret_cast<half4*>(orow + d) = to_half4(o0[4 * g4] * inv, o0[4 * g4 + 1] * inv, o0[4 * g4 + 2] * inv, o0[4 * g4 + 3] * inv);
+      *reinterpret_cast<half4*>(orow + 32 + d) = to_half4(o1[4 * g4] * inv, o1[4 * g4 + 1] * inv, o1[4 * g4 + 2] * inv, o1[4 * g4 + 3] * inv);
+    }
+  }
+}
+
+__global__ void f32_to_f16_rows_kernel(const float* __restrict__ src, long lds, _Float16* __restrict__ dst, long ldd,
+                                       int cols, long rows) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long r = i / cols;
+  const int c = (int)(i - r * cols);
+  if (r < rows) dst[r * ldd + c] = (_Float16)src[r * lds + c];
+}
+
+}  // namespace
+
+hipError_t layernorm_f16out(const float* x, const float* gamma, const float* beta, void* y, long rows, int D,
+                            hipStream_t s) {
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  _Float16* yh = reinterpret_cast<_Float16*>(y);
+  switch (D) {
+    case 384: hipLaunchKernelGGL(layernorm_h_kernel<6>, grid, block, 0, s, x, gamma, beta, yh, rows); break;
+    case 512: hipLaunchKernelGGL(layernorm_h_kernel<8>, grid, block, 0, s, x, gamma, beta, yh, rows); break;
+    case 768: hipLaunchKernelGGL(layernorm_h_kernel<12>, grid, block, 0, s, x, gamma, beta, yh, rows); break;
+    case 1024: hipLaunchKernelGGL(layernorm_h_kernel<16>, grid, block, 0, s, x, gamma, beta, yh, rows); break;
+    case 1280: hipLaunchKernelGGL(layernorm_h_kernel<20>, grid, block, 0, s, x, gamma, beta, yh, rows); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// K % 32 == 0, rows of A and W 16-byte aligned, N % 4 == 0 (the caller checks)
+hipError_t gemm_hh(const HGemmArgs& g, int epi, hipStream_t s) {
+  const int nt = (g.N + HH_N - 1) / HH_N, mt = (g.M + HH_M - 1) / HH_M;
+  HGemmArgs a = g;
+  dim3 grid(nt, mt);
+  if (a.xcd_swizzle) grid.y = (unsigned)(((mt + 7) / 8) * 8);      // whole groups of eight row tiles
+  switch (epi) {
+    case EPI_F16: hipLaunchKernelGGL(gemm_hh_kernel<EPI_F16>, grid, dim3(256), 0, s, a); break;
+    case EPI_RES: hipLaunchKernelGGL(gemm_hh_kernel<EPI_RES>, grid, dim3(256), 0, s, a); break;
+    case EPI_VT: hipLaunchKernelGGL(gemm_hh_kernel<EPI_VT>, grid, dim3(256), 0, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t attn_encoder_h(const void* qk, const void* vt, void* out, int B, int T, int D, int heads, hipStream_t s) {
+  hipLaunchKernelGGL(attn_enc_h_kernel, dim3((T + 127) / 128, heads, B), dim3(256), 0, s,
+                     reinterpret_cast<const _Float16*>(qk), reinterpret_cast<const _Float16*>(vt),
+                     reinterpret_cast<_Float16*>(out), T, D);
+  return hipGetLastError();
+}
+
+hipError_t convert_rows_f32_to_f16(const float* src, long lds, void* dst, long ldd, int cols, long rows, hipStream_t s) {
+  const long n = rows * cols;
+  hipLaunchKernelGGL(f32_to_f16_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, lds,
+                     reinterpret_cast<_Float16*>(dst), ldd, cols, rows);
+  return hipGetLastError();
+}
+
+}  // namespace crispy

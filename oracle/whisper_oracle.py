@@ -10,8 +10,9 @@ ln_post; decoder with learned positions, causal self-attention, cross-attention,
 
 PARITY UNPINNED against the reference itself (cannot be built here).  Pinned instead against HuggingFace
 `WhisperForConditionalGeneration` (transformers) with identical seeded weights: tests/golden/make_whisper_golden.py
-and tests/test_oracle_whisper.py.  Known whisper.cpp deviations that are NOT restated: ggml's f16 GELU
-lookup table and f16 x f16 matmul operands (this oracle is the exact-arithmetic version of the graph).
+and tests/test_oracle_whisper.py.  `encoder_forward` is the exact-arithmetic version of the graph;
+`encoder_forward_f16` rounds the operands of every matrix product to f16 as ggml's mul_mat does (what precision
+mode 1 of the library implements).  Not restated: ggml's f16 GELU lookup table.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module."""
 from __future__ import annotations
@@ -75,6 +76,56 @@ def encoder_forward(weights, hp, mel, upto_layer=None):
     if upto_layer is None:
         x = _ln(x, W["encoder.ln_post.weight"], W["encoder.ln_post.bias"])
     return x
+
+
+def _h(a):
+    """Round to IEEE binary16 (round to nearest even) and come back: the value an f16 operand carries."""
+    return np.asarray(a, dtype=np.float32).astype(np.float16).astype(np.float64)
+
+
+def encoder_forward_f16(weights, hp, mel):
+    """The encoder with the numerics of whisper.cpp's ggml matrix products [UPSTREAM-RECALL] -- what precision mode 1 of
+    the library implements: every matrix product takes BOTH operands rounded to f16 (the 2-D weights, and the
+    activation that enters the product) and accumulates exactly (float64 here, f32 on the matrix cores; the difference
+    is ~1e-6 of the result); everything else -- biases, GELU, LayerNorm statistics, soft-max, the residual stream -- is
+    f32 / exact.  Rounding points, in graph order:
+      conv1   exact (its kernel is the one encoder matrix whose K is not a multiple of 32; the library keeps it f32)
+      conv2   GELU(conv1) and the conv2 kernel rounded
+      block   LN(x) rounded -> q, k, v products; q, k, v rounded (+bias first); soft-max probabilities rounded as
+              2^(t - m) with t = s log2(e) and an INTEGER reference exponent m (the mantissa of 2^t: the rounding does not
+              depend on m, which is what lets a tiled kernel reproduce it; the sum uses the unrounded values),
+              P.V on rounded operands, the normalised result rounded -> out projection; LN(x) rounded -> fc1;
+              GELU(fc1) rounded -> fc2
+      ln_post exact."""
+    W = _f64(weights)
+    x = mel.astype(np.float64)
+    xp = np.pad(x, ((0, 0), (1, 1)))
+    w1 = W["encoder.conv1.weight"]
+    h1 = sum(w1[:, :, k] @ xp[:, k:k + 3000] for k in range(3)) + W["encoder.conv1.bias"][:, None]
+    h1 = _h(_gelu(np.asarray(h1, dtype=np.float32).astype(np.float64)))        # stored f32 by conv1, rounded on the way into conv2
+    hp1 = np.pad(h1, ((0, 0), (1, 1)))
+    w2 = _h(W["encoder.conv2.weight"])
+    h2 = sum(w2[:, :, k] @ hp1[:, k:k + 3000:2][:, :1500] for k in range(3)) + W["encoder.conv2.bias"][:, None]
+    x = _gelu(h2).T + W["encoder.positional_embedding"]
+    H = hp.n_audio_head
+    for i in range(hp.n_audio_layer):
+        p = f"encoder.blocks.{i}"
+        xn = _h(_ln(x, W[p + ".attn_ln.weight"], W[p + ".attn_ln.bias"]))
+        q = _h(xn @ _h(W[p + ".attn.query.weight"]).T + W[p + ".attn.query.bias"])
+        k = _h(xn @ _h(W[p + ".attn.key.weight"]).T)
+        v = _h(xn @ _h(W[p + ".attn.value.weight"]).T + W[p + ".attn.value.bias"])
+        att = np.empty_like(q)
+        dh = q.shape[1] // H
+        for hh in range(H):
+            sl = slice(hh * dh, (hh + 1) * dh)
+            t = (q[:, sl] @ k[:, sl].T) / np.sqrt(dh) * np.log2(np.e)
+            pe = np.exp2(t - np.ceil(t.max(-1, keepdims=True)))      # integer reference exponent: the mantissa of 2^t
+            att[:, sl] = (_h(pe) @ v[:, sl]) / pe.sum(-1, keepdims=True)
+        x = x + _h(att) @ _h(W[p + ".attn.out.weight"]).T + W[p + ".attn.out.bias"]
+        xn = _h(_ln(x, W[p + ".mlp_ln.weight"], W[p + ".mlp_ln.bias"]))
+        hid = _h(_gelu(xn @ _h(W[p + ".mlp.0.weight"]).T + W[p + ".mlp.0.bias"]))
+        x = x + hid @ _h(W[p + ".mlp.2.weight"]).T + W[p + ".mlp.2.bias"]
+    return _ln(x, W["encoder.ln_post.weight"], W["encoder.ln_post.bias"])
 
 
 def decoder_logits(weights, hp, enc_out, tokens):

@@ -126,3 +126,22 @@ def test_timestamp_rule_flavours_and_segments(tiny):
     assert WO.window_segments(win, 1000, sp, text) == [(1020, 1100, b" w1 w2"), (1100, 1250, b" w3")]
     win = dict(tokens=[5, 6, eot], tids=[beg + 3, beg, beg], result_len=3, seek_delta=3000)
     assert WO.window_segments(win, 0, sp, text) == [(6, 3000, b" w5 w6")]
+
+
+def test_f16_operand_encoder_oracle_is_a_small_perturbation_of_the_exact_one(oracle):
+    """encoder_forward_f16 (operands of every matrix product rounded to f16, ggml's mul_mat numerics) against the exact
+    graph on two layers of the tiny architecture: different (the rounding is there) and close (it is only rounding)."""
+    import dataclasses
+    from crispy_amd import synth_audio
+    from crispy_amd.mel_filters import whisper_mel_filters
+    from crispy_amd.whisper_weights import HParams, synthetic_whisper_weights
+    from oracle import whisper_oracle as WO
+    hp = dataclasses.replace(HParams.tiny(), n_audio_layer=2)
+    W = synthetic_whisper_weights(hp, 0)
+    mel = oracle.oracle_logmel(synth_audio.clip16k_np(3, 100000), whisper_mel_filters(80))
+    a = WO.encoder_forward(W, hp, mel)
+    b = WO.encoder_forward_f16(W, hp, mel)
+    rel = np.abs(a - b).max() / np.abs(a).max()
+    assert 1e-4 < rel < 5e-3, rel
+    assert WO._h(1.0 + 2.0 ** -11) == 1.0 and WO._h(1.0 + 3 * 2.0 ** -11) == 1.0 + 2.0 ** -9    # round to nearest even
+    assert WO._h(70000.0) == np.inf                                                                # f16 range
