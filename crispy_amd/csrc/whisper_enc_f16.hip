@@ -71,8 +71,32 @@ __global__ __launch_bounds__(256) void layernorm_h_kernel(const float* __restric
 
 enum { EPI_F16 = 0, EPI_RES = 1, EPI_VT = 2 };
 
+// one k-block (32) of a wave's 64 x 64 output tile from the staged operand tiles
 template <int EPI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void gemm_hh_kernel(HGemmArgs g) {
+__device__ __forceinline__ void hh_compute(const _Float16* Asb, const _Float16* Wsb, f32x16 (&acc)[2][2], int wm, int wn,
+                                           int li, int lh) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    half8 a[2], w[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      a[i] = *reinterpret_cast<const half8*>(&Asb[(wm + 32 * i + li) * HH_LD + 16 * ks + 8 * lh]);
+      w[i] = *reinterpret_cast<const half8*>(&Wsb[(wn + 32 * i + li) * HH_LD + 16 * ks + 8 * lh]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        // EPI_F16 wants a lane to own a ROW of C (four consecutive columns per register group -> 8-byte stores):
+        // D = W.A^T puts m in the lane and n in the registers.  The other two want a lane to own a COLUMN.
+        if (EPI == EPI_F16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[j], a[i], acc[i][j], 0, 0, 0);
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], w[j], acc[i][j], 0, 0, 0);
+      }
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void gemm_hh_kernel(HGemmArgs g) {
   __shared__ __attribute__((aligned(16))) _Float16 As[2][HH_M * HH_LD];
   __shared__ __attribute__((aligned(16))) _Float16 Ws[2][HH_N * HH_LD];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -113,6 +137,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // One k-block of operands in flight per thread, four waves per SIMD.  (Two blocks in flight -- a second register
+  // set, 16 more VGPRs -- drop the kernel to three / two waves per SIMD and measured 18 % SLOWER: what hides the L2 /
+  // HBM round trip here is the number of resident waves.)
   const int nk = g.K / HH_K;
   uint4 ra0 = *reinterpret_cast<const uint4*>(pa0), ra1 = *reinterpret_cast<const uint4*>(pa1);
   uint4 rw0 = *reinterpret_cast<const uint4*>(pw0), rw1 = *reinterpret_cast<const uint4*>(pw1);
@@ -132,24 +159,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
     // pin the requests here: left alone the scheduler sinks them below the MFMAs, right in front of the LDS stores
     // that consume them (load - wait - store: the whole memory latency exposed once per k-block)
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      half8 a[2], w[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        a[i] = *reinterpret_cast<const half8*>(&As[buf][(wm + 32 * i + li) * HH_LD + 16 * ks + 8 * lh]);
-        w[i] = *reinterpret_cast<const half8*>(&Ws[buf][(wn + 32 * i + li) * HH_LD + 16 * ks + 8 * lh]);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          // EPI_F16 wants a lane to own a ROW of C (four consecutive columns per register group -> 8-byte stores):
-          // D = W.A^T puts m in the lane and n in the registers.  The other two want a lane to own a COLUMN.
-          if (EPI == EPI_F16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[j], a[i], acc[i][j], 0, 0, 0);
-          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], w[j], acc[i][j], 0, 0, 0);
-        }
-    }
+    hh_compute<EPI>(As[buf], Ws[buf], acc, wm, wn, li, lh);
     __builtin_amdgcn_sched_barrier(0);
     *reinterpret_cast<uint4*>(&As[buf ^ 1][so0]) = ra0;
     *reinterpret_cast<uint4*>(&As[buf ^ 1][so1]) = ra1;
@@ -182,24 +192,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
       }
     }
   } else if (EPI == EPI_RES) {
-    float* __restrict__ C = reinterpret_cast<float*>(g.C);
+    // wave-uniform tile base pointers + 32-bit lane offsets: 64-bit per-lane addresses for C and the residual pushed
+    // this epilogue into scratch at four waves per SIMD
+    float* __restrict__ Ct = reinterpret_cast<float*>(g.C) + (long)(m0 + wm) * g.ldc + (n0 + wn);
+    const float* __restrict__ Rt = g.residual + (long)(m0 + wm) * g.ldr + (n0 + wn);
+    const int ldc = (int)g.ldc, ldr = (int)g.ldr;
+    const int mrem = g.M - (m0 + wm);                 // rows of this wave's 64-row band that exist
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn + 32 * j + li;
-        const int nc = min(n, g.N - 1);
-        const float bias = g.bias ? g.bias[nc] : 0.f;
+        const int nl = 32 * j + li;
+        const bool nok = n0 + wn + nl < g.N;
+        const float bias = g.bias ? g.bias[min(n0 + wn + nl, g.N - 1)] : 0.f;
 #pragma unroll
-        for (int r0 = 0; r0 < 16; r0 += 8) {
-          float extra[8];
+        for (int r0 = 0; r0 < 16; r0 += 4) {
+          float extra[4];
 #pragma unroll
-          for (int r = 0; r < 8; ++r)     // residual operands of eight rows requested together (clamped addresses)
-            extra[r] = g.residual[(long)min(m0 + wm + 32 * i + acc_row_e(r0 + r, lane), g.M - 1) * g.ldr + nc];
+          for (int r = 0; r < 4; ++r)     // residual operands of four rows requested together (clamped rows)
+            extra[r] = Rt[min(32 * i + acc_row_e(r0 + r, lane), mrem - 1) * ldr + (nok ? nl : 0)];
 #pragma unroll
-          for (int r = 0; r < 8; ++r) {
-            const int m = m0 + wm + 32 * i + acc_row_e(r0 + r, lane);
-            if (m < g.M && n < g.N) C[(long)m * g.ldc + n] = acc[i][j][r0 + r] + bias + extra[r];
+          for (int r = 0; r < 4; ++r) {
+            const int ml = 32 * i + acc_row_e(r0 + r, lane);
+            if (ml < mrem && nok) Ct[ml * ldc + nl] = acc[i][j][r0 + r] + bias + extra[r];
           }
         }
       }

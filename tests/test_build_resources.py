@@ -78,3 +78,42 @@ def test_mfma_gain_network_kernel_spills_only_in_the_prologue(tmp_path):
     loop = body.find("=>This Loop Header: Depth=1")
     assert loop > 0
     assert "scratch_store" not in body[loop:]
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_f16_encoder_kernels_run_at_four_waves_per_simd_without_scratch(tmp_path):
+    """whisper_enc_f16.hip: what hides the L2 / HBM round trip of the f16 GEMM is the number of resident waves (a
+    second register set of operands in flight measured 18 % slower at three waves), and a spill in an epilogue full
+    of predicated stores is the exec-mask hazard described above -- so: <= 128 registers, no scratch, and the
+    global -> register requests of a k-block are issued BEFORE its MFMAs (they were once kept in scratch, and once
+    sunk below the MFMAs: both cost 2.4x)."""
+    src = os.path.join(ROOT, "crispy_amd", "csrc", "whisper_enc_f16.hip")
+    asm = tmp_path / "enc.s"
+    out = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S",
+                          "-Rpass-analysis=kernel-resource-usage", src, "-o", str(asm)],
+                         capture_output=True, text=True, timeout=600, cwd=os.path.dirname(src))
+    assert out.returncode == 0, out.stderr[-2000:]
+    res, cur = {}, None
+    for line in out.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = m.group(1)
+            res[cur] = {}
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
+        if m and cur:
+            res[cur][m.group(1).strip()] = int(m.group(2))
+    gem = {k: v for k, v in res.items() if "gemm_hh_kernel" in k}
+    assert len(gem) == 3, list(res)
+    text = asm.read_text()
+    for name, r in gem.items():
+        assert r["VGPRs"] + r.get("AGPRs", 0) <= 128 and r["ScratchSize"] == 0, (name, r)
+        body = text[text.index(name + ":"):]
+        body = body[:body.index("s_endpgm")]
+        loop = body[body.index("Loop Header: Depth=1"):]
+        loop = loop[:loop.index("s_barrier")]
+        first_load, first_mfma = loop.find("global_load_dwordx4"), loop.find("v_mfma")
+        assert 0 < first_load < first_mfma, f"{name}: operand requests are not issued ahead of the MFMAs"
+        assert loop.count("global_load_dwordx4") == 4 and loop.count("v_mfma_f32_32x32x16_f16") == 8
+    att = {k: v for k, v in res.items() if "attn_enc_h_kernel" in k}
+    assert len(att) == 1 and all(r["ScratchSize"] == 0 for r in att.values())
