@@ -73,18 +73,20 @@ hipError_t attn_encoder_f16(const float* qkv, float* out, int B, int T, int D, i
 // ---- precision mode 1, activations in f16 between the encoder kernels (whisper_enc_f16.hip) ----
 constexpr int ENC_TP = 1504;   // keys per V^T row: 1500 padded to whole 32-key tiles
 struct HGemmArgs {
-  const _Float16* A; long lda;      // [M][lda] f16
+  const _Float16* A; long lda;      // [M][lda] f16 (lda < K: overlapping rows, the convolutions as strided views)
   const _Float16* W; long ldw;      // [N][ldw] f16
-  void* C; long ldc;                // EPI_F16: f16 [M][ldc]; EPI_RES: f32 [M][ldc]; EPI_VT: f16 V^T [clip][N][ENC_TP]
+  void* C; long ldc;                // EPI_F16: f16 [M][ldc]; EPI_RES / EPI_TAB: f32 [M][ldc]; EPI_VT: f16 V^T [clip][N][ENC_TP]
+  long strideA, strideC;            // per-batch element strides (grid z)
   const float* bias;
   const float* residual; long ldr;  // EPI_RES
+  const float* rowtab; int rowtab_period;   // EPI_TAB: C = GELU(acc + bias) + rowtab[m % period][n]
   int M, N, K;
   int gelu;                         // EPI_F16
   int vt_T;                         // EPI_VT: rows per clip
   int xcd_swizzle;                  // all column tiles of a row tile on one XCD
 };
-constexpr int HGEMM_F16 = 0, HGEMM_RES = 1, HGEMM_VT = 2;
-hipError_t gemm_hh(const HGemmArgs& g, int epi, hipStream_t s);
+constexpr int HGEMM_F16 = 0, HGEMM_RES = 1, HGEMM_VT = 2, HGEMM_TAB = 3;
+hipError_t gemm_hh(const HGemmArgs& g, int epi, int batch, hipStream_t s);
 hipError_t layernorm_f16out(const float* x, const float* gamma, const float* beta, void* y, long rows, int D, hipStream_t s);
 hipError_t attn_encoder_h(const void* qk, const void* vt, void* out, int B, int T, int D, int heads, hipStream_t s);
 hipError_t convert_rows_f32_to_f16(const float* src, long lds, void* dst, long ldd, int cols, long rows, hipStream_t s);

@@ -51,6 +51,8 @@ struct crispy_asr {
   const float *conv1_w = nullptr, *conv1_b = nullptr, *conv2_w = nullptr, *conv2_b = nullptr, *enc_pos = nullptr;
   const float *ln_post_w = nullptr, *ln_post_b = nullptr;
   const void* conv2_wh = nullptr;            // f16 copy of the reordered conv2 kernel (precision mode 1)
+  const void* conv1_wh = nullptr;            // f16 conv1 kernel, rows zero-padded to conv1_kp columns
+  int conv1_kp = 0;
   int enc_precision = 0;                     // 0: f32 operands (default), 1: f16 operands for the encoder GEMMs
   int xcd_swizzle = 1;                       // mode 1 GEMMs: column tiles of a row tile on one XCD (CRISPY_ASR_XCD=0 turns it off)
   std::vector<EncLayer> enc;
@@ -431,6 +433,18 @@ int crispy_asr_set_precision(crispy_asr* h, int mode) try {
       return CRISPY_OK;
     };
     int rc = half_copy(h->conv2_w, d * 3 * d, &h->conv2_wh);
+    if (rc == CRISPY_OK) {
+      // conv1 kernel [d][3 n_mels] as f16 rows zero-padded to a multiple of 32 columns (3 * 80 = 240 -> 256): the
+      // padded operand columns of A read on into the next frames (finite values) and meet zeros here
+      const int k1 = 3 * h->hp.n_mels, k1p = (k1 + 31) / 32 * 32;
+      void* p = nullptr;
+      HIP_TRY(hipMalloc(&p, d * k1p * 2));
+      h->derived.push_back(reinterpret_cast<float*>(p));
+      HIP_TRY(hipMemsetAsync(p, 0, d * k1p * 2, h->stream));
+      HIP_TRY(convert_rows_f32_to_f16(h->conv1_w, k1, p, k1p, k1, (long)d, h->stream));
+      h->conv1_wh = p;
+      h->conv1_kp = k1p;
+    }
     for (EncLayer& L : h->enc) {
       if (rc == CRISPY_OK) rc = half_copy(L.qkv_w, 3 * d * d, &L.qkv_wh);
       if (rc == CRISPY_OK) rc = half_copy(L.out_w, d * d, &L.out_wh);
@@ -465,23 +479,54 @@ int crispy_asr_encode_device(crispy_asr* h, const float* d_mel_t, int batch, flo
     if (h->enc_precision == 1 && wh && g.K % 32 == 0) return gemm_f16_nt(g, wh, nb, s);
     return gemm_f32_nt(g, nb, s);
   };
-  // conv1 (k3, p1) + GELU: rows t of the padded frame-major mel are 3*n_mels contiguous floats
-  {
-    GemmArgs g = gemm(d_mel_t, nm, h->conv1_w, 3L * nm, h->w_h1 + d, d, h->conv1_b, MEL_FRAMES, d, 3 * nm);
-    g.strideA = (long)(MEL_FRAMES + 2) * nm;
-    g.strideC = (long)(MEL_FRAMES + 1) * d;
-    g.gelu = 1;
-    HIP_TRY(gemm_f32_nt(g, batch, s));
-  }
-  // conv2 (k3, s2, p1) + GELU + positional embedding: row t' = frames 2t'-1 .. 2t'+1 of h1 (one zero row in front)
-  {
-    GemmArgs g = gemm(h->w_h1, 2L * d, h->conv2_w, 3L * d, h->w_x, d, h->conv2_b, Tn, d, 3 * d);
-    g.strideA = (long)(MEL_FRAMES + 1) * d;
-    g.strideC = (long)Tn * d;
-    g.gelu = 1;
-    g.rowtab = h->enc_pos;
-    g.rowtab_period = Tn;
-    HIP_TRY(egemm(g, h->conv2_wh, batch));
+  if (h->enc_precision == 1) {
+    // The convolution stem on the f16 matrix cores too (ggml runs a convolution as im2col in f16 x f16 kernel): the
+    // frame-major mel is rounded to f16 once, conv1 writes GELU(h1) as f16 (it only feeds conv2), conv2 reads it as
+    // a strided view and writes the f32 residual stream.  The f16 buffers alias the hidden-layer / h1 workspace.
+    _Float16* mel_h = reinterpret_cast<_Float16*>(h->w_h);                 // [batch][3002][n_mels] (+ padding)
+    _Float16* h1_h = reinterpret_cast<_Float16*>(h->w_h1);                 // [batch][3001][d], row 0 of a clip = zeros
+    const long mel_n = (long)batch * (MEL_FRAMES + 2) * nm;
+    HIP_TRY(convert_f32_to_f16(d_mel_t, mel_h, mel_n, s));
+    HIP_TRY(hipMemsetAsync(mel_h + mel_n, 0, 64 * sizeof(_Float16), s));  // what the last row's padded columns read
+    HIP_TRY(hipMemset2DAsync(h1_h, (size_t)(MEL_FRAMES + 1) * d * 2, 0, (size_t)d * 2, batch, s));
+    {
+      HGemmArgs g{};
+      g.A = mel_h; g.lda = nm; g.strideA = (long)(MEL_FRAMES + 2) * nm;
+      g.W = reinterpret_cast<const _Float16*>(h->conv1_wh); g.ldw = h->conv1_kp;
+      g.C = h1_h + d; g.ldc = d; g.strideC = (long)(MEL_FRAMES + 1) * d;
+      g.bias = h->conv1_b; g.M = MEL_FRAMES; g.N = d; g.K = h->conv1_kp; g.gelu = 1;
+      HIP_TRY(gemm_hh(g, HGEMM_F16, batch, s));
+    }
+    {
+      HGemmArgs g{};
+      g.A = h1_h; g.lda = 2L * d; g.strideA = (long)(MEL_FRAMES + 1) * d;
+      g.W = reinterpret_cast<const _Float16*>(h->conv2_wh); g.ldw = 3L * d;
+      g.C = h->w_x; g.ldc = d; g.strideC = (long)Tn * d;
+      g.bias = h->conv2_b; g.M = Tn; g.N = d; g.K = 3 * d;
+      g.rowtab = h->enc_pos; g.rowtab_period = Tn;
+      HIP_TRY(gemm_hh(g, HGEMM_TAB, batch, s));
+    }
+  } else {
+    // conv1 (k3, p1) + GELU: rows t of the padded frame-major mel are 3*n_mels contiguous floats
+    // (the zero row in front of every clip's h1 is rewritten each call: precision mode 1 uses the same workspace as f16)
+    HIP_TRY(hipMemset2DAsync(h->w_h1, (size_t)(MEL_FRAMES + 1) * d * sizeof(float), 0, (size_t)d * sizeof(float), batch, s));
+    {
+      GemmArgs g = gemm(d_mel_t, nm, h->conv1_w, 3L * nm, h->w_h1 + d, d, h->conv1_b, MEL_FRAMES, d, 3 * nm);
+      g.strideA = (long)(MEL_FRAMES + 2) * nm;
+      g.strideC = (long)(MEL_FRAMES + 1) * d;
+      g.gelu = 1;
+      HIP_TRY(gemm_f32_nt(g, batch, s));
+    }
+    // conv2 (k3, s2, p1) + GELU + positional embedding: row t' = frames 2t'-1 .. 2t'+1 of h1 (one zero row in front)
+    {
+      GemmArgs g = gemm(h->w_h1, 2L * d, h->conv2_w, 3L * d, h->w_x, d, h->conv2_b, Tn, d, 3 * d);
+      g.strideA = (long)(MEL_FRAMES + 1) * d;
+      g.strideC = (long)Tn * d;
+      g.gelu = 1;
+      g.rowtab = h->enc_pos;
+      g.rowtab_period = Tn;
+      HIP_TRY(egemm(g, h->conv2_wh, batch));
+    }
   }
   if (h->enc_precision == 1) {
     // whisper.cpp's numerics with the bytes halved: every activation that only feeds a matrix product is stored as the
@@ -501,25 +546,25 @@ int crispy_asr_encode_device(crispy_asr* h, const float* d_mel_t, int batch, flo
     };
     for (const EncLayer& L : h->enc) {
       HIP_TRY(layernorm_f16out(h->w_x, L.ln1_w, L.ln1_b, xn_h, rows, d, s));
-      HIP_TRY(gemm_hh(hg(xn_h, d, L.qkv_wh, d, qk_h, 2L * d, L.qkv_b, 2 * d, d), HGEMM_F16, s));
+      HIP_TRY(gemm_hh(hg(xn_h, d, L.qkv_wh, d, qk_h, 2L * d, L.qkv_b, 2 * d, d), HGEMM_F16, 1, s));
       HIP_TRY(gemm_hh(hg(xn_h, d, reinterpret_cast<const _Float16*>(L.qkv_wh) + 2L * d * d, d, vt_h, 0, L.qkv_b + 2 * d, d, d),
-                      HGEMM_VT, s));
+                      HGEMM_VT, 1, s));
       HIP_TRY(attn_encoder_h(qk_h, vt_h, att_h, batch, Tn, d, H, s));
       {
         HGemmArgs g = hg(att_h, d, L.out_wh, d, h->w_x, d, L.out_b, d, d);
         g.residual = h->w_x; g.ldr = d;
-        HIP_TRY(gemm_hh(g, HGEMM_RES, s));
+        HIP_TRY(gemm_hh(g, HGEMM_RES, 1, s));
       }
       HIP_TRY(layernorm_f16out(h->w_x, L.ln2_w, L.ln2_b, xn_h, rows, d, s));
       {
         HGemmArgs g = hg(xn_h, d, L.fc1_wh, d, hid_h, 4L * d, L.fc1_b, 4 * d, d);
         g.gelu = 1;
-        HIP_TRY(gemm_hh(g, HGEMM_F16, s));
+        HIP_TRY(gemm_hh(g, HGEMM_F16, 1, s));
       }
       {
         HGemmArgs g = hg(hid_h, 4L * d, L.fc2_wh, 4L * d, h->w_x, d, L.fc2_b, d, 4 * d);
         g.residual = h->w_x; g.ldr = d;
-        HIP_TRY(gemm_hh(g, HGEMM_RES, s));
+        HIP_TRY(gemm_hh(g, HGEMM_RES, 1, s));
       }
     }
   } else

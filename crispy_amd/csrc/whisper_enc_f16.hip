@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void layernorm_h_kernel(const float* __restric
   for (int q = 0; q < PER; ++q) yr[lane + 64 * q] = (_Float16)((v[q] - mean) * rstd * gm[q] + bt[q]);
 }
 
-enum { EPI_F16 = 0, EPI_RES = 1, EPI_VT = 2 };
+enum { EPI_F16 = 0, EPI_RES = 1, EPI_VT = 2, EPI_TAB = 3 };
 
 // one k-block (32) of a wave's 64 x 64 output tile from the staged operand tiles
 template <int EPI>
@@ -112,7 +112,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void g
     bx = slot % nt;
     if (by * HH_M >= g.M) return;
   }
-  const _Float16* __restrict__ A = g.A;
+  const int bz = blockIdx.z;
+  const _Float16* __restrict__ A = g.A + (long)bz * g.strideA;
   const _Float16* __restrict__ W = g.W;
   const int m0 = by * HH_M, n0 = bx * HH_N;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void g
   }
 
   if (EPI == EPI_F16) {
-    _Float16* __restrict__ C = reinterpret_cast<_Float16*>(g.C);
+    _Float16* __restrict__ C = reinterpret_cast<_Float16*>(g.C) + (long)bz * g.strideC;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int m = m0 + wm + 32 * i + li;
@@ -194,8 +195,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void g
   } else if (EPI == EPI_RES) {
     // wave-uniform tile base pointers + 32-bit lane offsets: 64-bit per-lane addresses for C and the residual pushed
     // this epilogue into scratch at four waves per SIMD
-    float* __restrict__ Ct = reinterpret_cast<float*>(g.C) + (long)(m0 + wm) * g.ldc + (n0 + wn);
-    const float* __restrict__ Rt = g.residual + (long)(m0 + wm) * g.ldr + (n0 + wn);
+    float* __restrict__ Ct = reinterpret_cast<float*>(g.C) + (long)bz * g.strideC + (long)(m0 + wm) * g.ldc + (n0 + wn);
+    const float* __restrict__ Rt = g.residual + (long)bz * g.strideC + (long)(m0 + wm) * g.ldr + (n0 + wn);
     const int ldc = (int)g.ldc, ldr = (int)g.ldr;
     const int mrem = g.M - (m0 + wm);                 // rows of this wave's 64-row band that exist
 #pragma unroll
@@ -215,6 +216,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void g
           for (int r = 0; r < 4; ++r) {
             const int ml = 32 * i + acc_row_e(r0 + r, lane);
             if (ml < mrem && nok) Ct[ml * ldc + nl] = acc[i][j][r0 + r] + bias + extra[r];
+          }
+        }
+      }
+  } else if (EPI == EPI_TAB) {
+    // conv2: f32 out = GELU(acc + bias) + positional row (m % period); same addressing as EPI_RES
+    float* __restrict__ Ct = reinterpret_cast<float*>(g.C) + (long)bz * g.strideC + (long)(m0 + wm) * g.ldc + (n0 + wn);
+    const float* __restrict__ Tt = g.rowtab + (n0 + wn);
+    const int ldc = (int)g.ldc;
+    const int mrem = g.M - (m0 + wm);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int nl = 32 * j + li;
+        const bool nok = n0 + wn + nl < g.N;
+        const float bias = g.bias ? g.bias[min(n0 + wn + nl, g.N - 1)] : 0.f;
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0 += 4) {
+          float extra[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int mg = min(m0 + wm + 32 * i + acc_row_e(r0 + r, lane), g.M - 1) % g.rowtab_period;
+            extra[r] = Tt[mg * g.N + (nok ? nl : 0)];
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int ml = 32 * i + acc_row_e(r0 + r, lane);
+            if (ml < mrem && nok) Ct[ml * ldc + nl] = gelu_erf_e(acc[i][j][r0 + r] + bias) + extra[r];
           }
         }
       }
@@ -410,15 +439,16 @@ hipError_t layernorm_f16out(const float* x, const float* gamma, const float* bet
 }
 
 // K % 32 == 0, rows of A and W 16-byte aligned, N % 4 == 0 (the caller checks)
-hipError_t gemm_hh(const HGemmArgs& g, int epi, hipStream_t s) {
+hipError_t gemm_hh(const HGemmArgs& g, int epi, int batch, hipStream_t s) {
   const int nt = (g.N + HH_N - 1) / HH_N, mt = (g.M + HH_M - 1) / HH_M;
   HGemmArgs a = g;
-  dim3 grid(nt, mt);
+  dim3 grid(nt, mt, batch);
   if (a.xcd_swizzle) grid.y = (unsigned)(((mt + 7) / 8) * 8);      // whole groups of eight row tiles
   switch (epi) {
     case EPI_F16: hipLaunchKernelGGL(gemm_hh_kernel<EPI_F16>, grid, dim3(256), 0, s, a); break;
     case EPI_RES: hipLaunchKernelGGL(gemm_hh_kernel<EPI_RES>, grid, dim3(256), 0, s, a); break;
     case EPI_VT: hipLaunchKernelGGL(gemm_hh_kernel<EPI_VT>, grid, dim3(256), 0, s, a); break;
+    case EPI_TAB: hipLaunchKernelGGL(gemm_hh_kernel<EPI_TAB>, grid, dim3(256), 0, s, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -89,7 +89,7 @@ def encoder_forward_f16(weights, hp, mel):
     activation that enters the product) and accumulates exactly (float64 here, f32 on the matrix cores; the difference
     is ~1e-6 of the result); everything else -- biases, GELU, LayerNorm statistics, soft-max, the residual stream -- is
     f32 / exact.  Rounding points, in graph order:
-      conv1   exact (its kernel is the one encoder matrix whose K is not a multiple of 32; the library keeps it f32)
+      conv1   the log-mel frames and the conv1 kernel rounded (ggml: im2col in f16 x f16 kernel)
       conv2   GELU(conv1) and the conv2 kernel rounded
       block   LN(x) rounded -> q, k, v products; q, k, v rounded (+bias first); soft-max probabilities rounded as
               2^(t - m) with t = s log2(e) and an INTEGER reference exponent m (the mantissa of 2^t: the rounding does not
@@ -98,11 +98,11 @@ def encoder_forward_f16(weights, hp, mel):
               GELU(fc1) rounded -> fc2
       ln_post exact."""
     W = _f64(weights)
-    x = mel.astype(np.float64)
+    x = _h(mel)
     xp = np.pad(x, ((0, 0), (1, 1)))
-    w1 = W["encoder.conv1.weight"]
+    w1 = _h(W["encoder.conv1.weight"])
     h1 = sum(w1[:, :, k] @ xp[:, k:k + 3000] for k in range(3)) + W["encoder.conv1.bias"][:, None]
-    h1 = _h(_gelu(np.asarray(h1, dtype=np.float32).astype(np.float64)))        # stored f32 by conv1, rounded on the way into conv2
+    h1 = _h(_gelu(h1))
     hp1 = np.pad(h1, ((0, 0), (1, 1)))
     w2 = _h(W["encoder.conv2.weight"])
     h2 = sum(w2[:, :, k] @ hp1[:, k:k + 3000:2][:, :1500] for k in range(3)) + W["encoder.conv2.bias"][:, None]
