@@ -35,6 +35,27 @@ class HParams:
         return HParams(n_audio_state=512, n_audio_head=8, n_audio_layer=6, n_text_state=512, n_text_head=8,
                        n_text_layer=6)
 
+    # the models of the reference's catalog (src-tauri/src/managers/model.rs:74-148) at full depth
+    @staticmethod
+    def small():
+        return HParams(n_audio_state=768, n_audio_head=12, n_audio_layer=12, n_text_state=768, n_text_head=12,
+                       n_text_layer=12)
+
+    @staticmethod
+    def medium():
+        return HParams(n_audio_state=1024, n_audio_head=16, n_audio_layer=24, n_text_state=1024, n_text_head=16,
+                       n_text_layer=24)
+
+    @staticmethod
+    def large_v3():
+        return HParams(n_vocab=51866, n_audio_state=1280, n_audio_head=20, n_audio_layer=32, n_text_state=1280,
+                       n_text_head=20, n_text_layer=32, n_mels=128)
+
+    @staticmethod
+    def large_v3_turbo():
+        return HParams(n_vocab=51866, n_audio_state=1280, n_audio_head=20, n_audio_layer=32, n_text_state=1280,
+                       n_text_head=20, n_text_layer=4, n_mels=128)
+
     def as_ints(self):
         return [int(v) for v in asdict(self).values()]
 

@@ -628,3 +628,40 @@ def test_english_only_model_file_prompt_and_timestamps(oracle):
     text, segs, ttoks = eng.transcribe_segments(x, max_new_tokens=8)
     assert ttoks and ttoks[0] >= sp["beg"]
     assert all(t < sp["eot"] or t >= sp["beg"] for t in ttoks)
+
+
+@pytest.mark.parametrize("name", ["small", "medium", "large_v3"])
+def test_catalog_models_at_full_depth(oracle, name):
+    """The models the reference's catalog ships (managers/model.rs:74-148) at their FULL depth -- small (d 768, 12 + 12
+    layers), medium (d 1024, 24 + 24) and large-v3 (d 1280, 32 + 32, 128 mel bins, 51 866 tokens) -- with seeded
+    weights: the encoder output of one clip against the float64 oracle (all 1500 rows), and three greedy picks against
+    the oracle's KV-cached decoder wherever its own top-2 margin is resolvable."""
+    from crispy_amd import synth_audio
+    from crispy_amd.asr import WhisperModel
+    from crispy_amd.mel_filters import whisper_mel_filters
+    from crispy_amd.whisper_weights import HParams, synthetic_whisper_weights
+    from oracle import whisper_oracle as WO
+    hp = getattr(HParams, name)()
+    W = synthetic_whisper_weights(hp, 3)
+    m = WhisperModel(hp, W)
+    x = synth_audio.clip16k_np(77, 160000)
+    enc = m.encode([x])[0]
+    ref = WO.encoder_forward(W, hp, oracle.oracle_logmel(x, whisper_mel_filters(hp.n_mels)))
+    assert enc.shape == (1500, hp.n_audio_state)
+    err = np.abs(enc - ref).max() / np.abs(ref).max()
+    assert err <= 1e-4, (name, err)
+    sp = WO.special_tokens(hp.n_vocab)
+    prompt = WO.default_prompt(hp.n_vocab, no_timestamps=True)
+    toks, _ = m.transcribe_tokens([x], prompt, 3)
+    dc = WO.DecoderCache(W, hp, ref)
+    for t in prompt[:-1]:
+        dc.step(t)
+    tok, picks, margins = prompt[-1], [], []
+    for _ in range(3):
+        lg = dc.step(tok)
+        tok = int(np.argmax(lg))
+        top2 = np.partition(lg, -2)[-2:]
+        picks.append(tok)
+        margins.append(float(top2[1] - top2[0]))
+    assert_picks(toks[0], picks, margins, 1e-3, 3, name)
+    del m
