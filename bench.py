@@ -88,6 +88,60 @@ def cpu_baseline(n_threads: int, frames_per_thread: int):
                       f"{'-O3 -march=native' if lib_path else '-O2'}, one stream per thread, {dt:.1f} s"}
 
 
+def measure_traffic(B: int, T: int):
+    """HBM-side traffic of rn_frame_kernel measured on THIS box for THIS build: two separate `rocprofv3 --pmc` passes
+    (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950; no trace domains beside them) over a child process that
+    runs three steps of the bench shape (`bench.py --pmc-child`).  Corrections as MI355X_MICROARCH.md prescribes:
+    FETCH_SIZE reports half the bytes of wide coalesced reads on gfx950 (x2), WRITE_SIZE is exact; both in KiB.
+    Returns bytes per stream-frame, or raises."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        raise RuntimeError("rocprofv3 not found")
+    steps = 3
+    kib = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix=f"crispy_pmc_{ctr}_", dir="/tmp")
+        try:
+            r = subprocess.run([rocprof, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable,
+                                os.path.abspath(__file__), "--pmc-child", "--streams", str(B), "--frames", str(T),
+                                "--steps", str(steps)], capture_output=True, text=True, timeout=180, env=env, cwd="/tmp")
+            if r.returncode != 0:
+                raise RuntimeError(f"rocprofv3 --pmc {ctr} exited with {r.returncode}: {r.stderr[-300:]}")
+            tot, n = 0.0, 0
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "rn_frame_kernel" in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                        tot += float(row["Counter_Value"])
+                        n += 1
+            if n == 0:
+                raise RuntimeError(f"no rn_frame_kernel dispatch in the {ctr} pass")
+            kib[ctr] = tot
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    sf = float(B) * T * steps
+    return {"fetch_bytes": 2.0 * kib["FETCH_SIZE"] * 1024.0 / sf, "write_bytes": kib["WRITE_SIZE"] * 1024.0 / sf}
+
+
+def pmc_child(args):
+    """What `measure_traffic` profiles: `--steps` steps of the bench shape, nothing else, no output."""
+    import torch
+    from crispy_amd import synthetic_weights, synth_audio
+    from crispy_amd.denoise import DenoiseState
+    dev = torch.device("cuda", 0)
+    ds = DenoiseState(synthetic_weights(0), args.streams, 0)
+    d_in = synth_audio.batch_torch(args.streams, args.frames, dev, first_stream=0, seed=0)
+    d_out = torch.empty_like(d_in)
+    torch.cuda.synchronize()
+    for _ in range(args.steps):
+        ds.process_device(d_in.data_ptr(), d_out.data_ptr(), args.frames)
+    ds.synchronize()
+
+
 def asr_leg(local_rank: int, clips: int = 64, new_tokens: int = 32):
     """Second half of the headline metric: Whisper-tiny RTFx on one GPU (BASELINE configs[2]/[3]):
     `clips` x 30 s of 16 kHz audio resident in HBM -> log-mel -> encoder -> greedy decode of
@@ -378,6 +432,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-asr", action="store_true", help="skip the Whisper-tiny leg of the metric")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-stream process_frame latency leg")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not run the two rocprofv3 --pmc passes; roofline.traffic then comes from profiles/")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher self-test on CPU (gloo, no GPU work, no value); used by tests/test_sharding_gloo.py")
     args = ap.parse_args()
@@ -398,6 +455,8 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks; "
               "refusing to report one as the other", file=sys.stderr)
         sys.exit(2)
+    if args.pmc_child:
+        return pmc_child(args)
     if args.dry_run:
         return dry_run(args)
     if args.workload == "cfg5":
@@ -474,16 +533,29 @@ def cfg2(args):
     fps = frames_total / dt
     if rank == 0:
         alg_bytes = BYTES_PER_STREAM_FRAME * B * T / launches
-        # HBM traffic per launch from the committed PMC passes (rocprofv3 cannot run inside this process);
-        # only quoted when it was measured on this exact launch shape.
+        # HBM traffic per launch: measured live on this box by two rocprofv3 --pmc child passes (measure_traffic);
+        # if that is not possible the committed passes of the same launch shape are quoted and labelled as such.
         traffic = None
+        traffic_src = None
         valu = None
+        if world == 1 and not args.no_live_traffic:
+            try:
+                tr = measure_traffic(B, T)
+                traffic = int((tr["fetch_bytes"] + tr["write_bytes"]) * B * T / launches)
+                traffic_src = {"how": "live: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over "
+                                      "`bench.py --pmc-child` on this box; FETCH_SIZE x2 (gfx950), KiB -> bytes",
+                               "fetch_bytes_per_stream_frame": tr["fetch_bytes"],
+                               "write_bytes_per_stream_frame": tr["write_bytes"]}
+            except Exception as e:
+                traffic_src = {"how": "committed profile (live measurement failed)", "error": str(e)[:200]}
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r02a_pmc.json")))
             if pm["config"]["streams"] == B:
                 fk = pm["rn_frame_kernel"]
                 sf = B * T / launches                        # stream-frames per (average) launch
-                traffic = int(fk["hbm_bytes_per_stream_frame"] * sf)
+                if traffic is None:
+                    traffic = int(fk["hbm_bytes_per_stream_frame"] * sf)
+                    traffic_src = dict(traffic_src or {}, file="profiles/r02a_pmc.json")
                 # what actually bounds this kernel: VALU issue slots.  SQ_ACTIVE_INST_VALU counts 4-cycle issue
                 # slots; 1024 SIMDs; priced against the live kernel time at the 2.4 GHz peak clock.
                 valu = {"insts_per_stream_frame": fk["insts_per_stream_frame"]["valu"],
@@ -505,7 +577,7 @@ def cfg2(args):
                        "streams_per_gpu": B, "frames_per_step": T, "sharding": f"streams x{world_reported}, no collective",
                        "frames_per_s": fps, "output_finite": finite},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "rn_frame_kernel", "kernel_ms": frame_ms, "launches_per_step": launches,
                          "enqueue_ms": total_ms,
                          "alg_bytes_per_launch": alg_bytes, "valu": valu},
