@@ -91,3 +91,123 @@ def test_end_to_end_pipeline_matches_oracle_chain(oracle):
         rt, rb, rm = WO.greedy_decode(W, hp, enc, prompt, 4)
         from tests.test_gpu_whisper import assert_picks
         assert_picks(toks[b, 0], rt, rm, 1e-2, 3, f"pipeline stream {b}")
+
+
+# ---- BASELINE configs at full size ----------------------------------------------------------------
+def test_cfg3_logmel_and_encoder_at_64_full_length_clips(oracle):
+    """BASELINE configs[2]: log-mel STFT + Whisper-tiny encoder, batch 64 x 30 s clips.  Size-independent properties:
+    every clip of the batch equals its solo run bit for bit (batch independence of log-mel and encoder), two clips
+    against the oracle (log-mel 1e-4, encoder 1e-4 of the peak), everything finite."""
+    import torch
+    from crispy_amd import synth_audio
+    from crispy_amd.asr import LogMel, WhisperModel
+    from crispy_amd.mel_filters import whisper_mel_filters
+    from crispy_amd.whisper_weights import HParams, synthetic_whisper_weights
+    from oracle import whisper_oracle as WO
+    B = 64
+    hp = HParams.tiny()
+    W = synthetic_whisper_weights(hp, 0)
+    m = WhisperModel(hp, W)
+    lm = LogMel(hp.n_mels)
+    dev = torch.device("cuda:0")
+    pcm = np.stack([synth_audio.clip16k_np(500 + b, 480000) for b in range(B)])
+    d_pcm = torch.from_numpy(pcm).to(dev)
+    d_mel = torch.empty(B, hp.n_mels, 3000, device=dev)
+    d_melt = torch.zeros(B, 3002, hp.n_mels, device=dev)
+    d_enc = torch.empty(B, 1500, hp.n_audio_state, device=dev)
+    torch.cuda.synchronize()
+    lm.compute_device(d_pcm.data_ptr(), 480000, np.full(B, 480000), d_mel.data_ptr(), d_melt.data_ptr())
+    lm.synchronize()
+    m.encode_device(d_melt.data_ptr(), B, d_enc.data_ptr())
+    m.synchronize()
+    mel, enc = d_mel.cpu().numpy(), d_enc.cpu().numpy()
+    assert np.isfinite(mel).all() and np.isfinite(enc).all()
+    F = whisper_mel_filters(hp.n_mels)
+    for b in (0, 17, 63):
+        solo_mel = lm([pcm[b]])[0]
+        solo_enc = m.encode([pcm[b]])[0]
+        assert np.array_equal(solo_mel, mel[b]) and np.array_equal(solo_enc, enc[b]), b
+    for b in (5, 40):
+        rm = oracle.oracle_logmel(pcm[b], F)
+        assert np.abs(mel[b] - rm).max() <= 1e-4 * max(1.0, np.abs(rm).max())
+        re = WO.encoder_forward(W, hp, rm)
+        assert np.abs(enc[b] - re).max() <= 1e-4 * np.abs(re).max()
+
+
+def test_cfg4_full_size_1024_streams_x_30_s_end_to_end(oracle):
+    """BASELINE configs[3] at its full size: 1024 streams x 30 s of 48 kHz audio resident in HBM -> RNNoise -> adapter
+    scaling, first-frame drop, s16 WAV hand-off -> 48 -> 16 kHz -> 30 s chunk -> log-mel -> Whisper-tiny encoder ->
+    greedy ids.  (a) finite, silent streams stay silent; (b) sampled streams: the 16 kHz PCM and the token ids equal
+    a solo run of that stream through the same pipeline (batch independence); (c) three sampled streams against the
+    chained ORACLES on the first 3 s (denoise -> WAV -> resample; the resampler is causal, so a prefix is a prefix)."""
+    import torch
+    from crispy_amd import synth_audio, synthetic_weights
+    from crispy_amd.asr import WhisperModel
+    from crispy_amd.pipeline import DenoiseTranscribePipeline
+    from crispy_amd.whisper_weights import HParams, synthetic_whisper_weights
+    from oracle import resample_oracle as RO
+    B, T, NEW = 1024, 3001, 4
+    w = synthetic_weights(0)
+    hp = HParams.tiny()
+    wm = WhisperModel(hp, synthetic_whisper_weights(hp, 0))
+    pipe = DenoiseTranscribePipeline(w, wm, B)
+    dev = torch.device("cuda:0")
+    x = synth_audio.batch_torch(B, T, dev, seed=5).transpose(0, 1).contiguous()      # [B, T, 480], int16 range
+    prompt = [50258, 50259, 50359, 50363]
+    toks, pcm16 = pipe.run(x, prompt, NEW)
+    assert toks.shape == (B, 2, NEW) and pcm16.shape == (B, 480168)
+    assert bool(torch.isfinite(pcm16).all())
+    assert (toks[:, 0] >= 0).all() and (toks[:, 1] == -1).all()        # the 168 samples past 30 s transcribe to nothing
+    silent = np.arange(B) % 10 == 9
+    assert float(pcm16[torch.from_numpy(silent).to(dev)].abs().max()) == 0.0
+    pick = [0, 333, 1023]
+    solo = DenoiseTranscribePipeline(w, wm, 1)
+    for b in pick:
+        t1, p1 = solo.run(x[b:b + 1].contiguous(), prompt, NEW)
+        assert torch.equal(p1[0], pcm16[b]), b
+        assert np.array_equal(t1[0], toks[b]), (b, t1[0], toks[b])
+        solo.ds.reset()
+    xs = x[pick, :301].cpu().numpy()
+    got = pcm16[pick].cpu().numpy()
+    for i, b in enumerate(pick):
+        den, _ = oracle.OracleDenoiseState(w).process(xs[i])
+        a = np.clip(den[1:].ravel() / np.float32(32768.0), -1, 1)
+        ref16 = RO.resample_48k_to_16k(RO.wav_s16_roundtrip(a))
+        n = ref16.size - 400            # the oracle's last block saw zero padding where the GPU saw more audio
+        assert np.abs(got[i, :n] - ref16[:n]).max() <= 2e-4, b
+        assert np.mean(np.abs(got[i, :n] - ref16[:n]) > 1e-5) < 0.01
+
+
+def test_cfg5_one_shard_whisper_base_sub_batch_of_256_clips():
+    """BASELINE configs[4]: Whisper-base full transcribe, 8192 streams over 8 GPUs = 1024 clips per GPU in sub-batches
+    of 256 (bench.py --workload cfg5).  One sub-batch at full size: every sampled clip's encoder output and greedy ids
+    equal its solo run (the shards and the clips inside a shard are independent: no collective, no cross-talk), and
+    the block partition of the 8192 stream ids over 8 ranks tiles them exactly."""
+    import torch
+    from crispy_amd.asr import LogMel, WhisperModel
+    from crispy_amd.sharding import shard_range
+    from crispy_amd.whisper_weights import HParams, synthetic_whisper_weights
+    parts = [shard_range(8192, r, 8) for r in range(8)]
+    assert parts[0] == (0, 1024) and parts[-1] == (7168, 8192) and all(b[0] == a[1] for a, b in zip(parts, parts[1:]))
+    hp = HParams.base()
+    m = WhisperModel(hp, synthetic_whisper_weights(hp, 0))
+    lm = LogMel(hp.n_mels)
+    B, NEW = 256, 6
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(1000 + parts[3][0])            # rank 3's shard
+    pcm = torch.randn(B, 480000, generator=g, device=dev) * 0.1
+    melt = torch.zeros(B, 3002, hp.n_mels, device=dev)
+    enc = torch.empty(B, 1500, hp.n_audio_state, device=dev)
+    prompt = [50258, 50259, 50359, 50363]
+    torch.cuda.synchronize()
+    lm.compute_device(pcm.data_ptr(), 480000, np.full(B, 480000), 0, melt.data_ptr())
+    lm.synchronize()
+    m.encode_device(melt.data_ptr(), B, enc.data_ptr())
+    m.synchronize()
+    toks, n, lg = m.decode_greedy_device(enc.data_ptr(), B, prompt, NEW)
+    assert bool(torch.isfinite(enc).all()) and toks.shape == (B, NEW)
+    for b in (0, 100, 255):
+        e1 = m.encode([pcm[b].cpu().numpy()])[0]
+        assert np.array_equal(e1, enc[b].cpu().numpy()), b
+        t1, _ = m.transcribe_tokens([pcm[b].cpu().numpy()], prompt, NEW)
+        assert np.array_equal(t1[0], toks[b]), (b, t1[0], toks[b])
