@@ -33,7 +33,7 @@ constexpr int RN_SYNTH_GROUP = 5;   // frames per synthesis workgroup (plus one 
 // Stage stamps accumulate straight into the debug buffer (one lane, global read-modify-write): 24 counters in
 // registers pushed the frame loop into scratch, which this compiler does not handle safely (see dotn_h).
 #define RN_PROF_DECL long long tprev_ = clock64(); \
-  float* profp_ = a.dbg ? a.dbg + (long)blockIdx.x * RN_DBG_FLOATS + 3824 : nullptr;
+  float* profp_ = (DBG && a.dbg) ? a.dbg + (long)blockIdx.x * RN_DBG_FLOATS + 3824 : nullptr;
 #define STAMP(k) { const long long tn_ = clock64(); if (profp_ && threadIdx.x == 0) profp_[k] += (float)(tn_ - tprev_); tprev_ = tn_; }
 #else
 #define RN_PROF_DECL
@@ -1155,7 +1155,11 @@ __device__ __forceinline__ void lag_dots(const float* xr, const float* const (&y
 // MODE 0: fused frame (analysis, in-wave gain network, synthesis).
 // MODE 1: analysis only -- stops after the 42 features and parks X, P, band energies for the synthesis kernel.
 // MODE 2: synthesis only -- gains come from the stream-batched MFMA gain network (rn_rnn_kernel.hip).
-template <int MODE>
+// DBG: the per-stage debug capture of the last frame (crispy_rn_debug_capture) and the per-frame taps (features, gains,
+// pitch: parity tests) are a separate instantiation: the six
+// `a.dbg && t == a.T - 1` tests kept two more kernel arguments live across the frame loop, where the scalar registers
+// are already spilled into VGPR lanes (v_writelane / v_readlane are VALU instructions).
+template <int MODE, bool DBG>
 __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VGPR_CAP void rn_frame_kernel(RnArgs a) {
   __shared__ RnLdsT<MODE> L;
   const int lane0 = threadIdx.x;
@@ -1532,7 +1536,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
     }
     __syncthreads();
     STAMP(3)
-    if (a.dbg && t == a.T - 1) {
+    if (DBG && a.dbg && t == a.T - 1) {
       float* D = a.dbg + (long)b * RN_DBG_FLOATS;
       for (int i = lane; i < 864; i += WAVE) D[984 + i] = lp[i];
       if (lane == 0) D[1848] = (float)pitch_index;
@@ -1719,7 +1723,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
     lane = lane0;
     asm volatile("" : "+v"(lane));
     RN_LANE_RANGE(6);
-    if (a.dbg && t == a.T - 1) {
+    if (DBG && a.dbg && t == a.T - 1) {
       float* D = a.dbg + (long)b * RN_DBG_FLOATS;
       for (int i = lane; i < 962; i += WAVE) D[0 + i] = Xf[i];
       if (lane < RN_NB) D[962 + lane] = L.Ex[lane];
@@ -1740,7 +1744,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
     // band energy of P, band correlation with X, and P parked in L2 from the same registers (read back by the comb
     // filter, which needs bins < 400 only); Bb becomes the RNN workspace
     band_pairs<true>(L.Bb, L.A, L.U, L.Ep, L.Exp, P_LDS ? nullptr : pg, tab, be, lane);
-    if (a.dbg && t == a.T - 1) {
+    if (DBG && a.dbg && t == a.T - 1) {
       float* D = a.dbg + (long)b * RN_DBG_FLOATS;
       const float* Pf = reinterpret_cast<const float*>(L.Bb);
       for (int i = lane; i < 962; i += WAVE) D[1856 + i] = Pf[i];
@@ -1766,7 +1770,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
     }
     if (!P_LDS && lane < 6) { Rb[RB_FEAT + 42 + lane] = 0.f; }
     __syncthreads();
-    if (a.dbg && t == a.T - 1 && lane < RN_NB) {
+    if (DBG && a.dbg && t == a.T - 1 && lane < RN_NB) {
       float* D = a.dbg + (long)b * RN_DBG_FLOATS;
       D[2818 + lane] = L.Ep[lane];
       D[2840 + lane] = L.Exp[lane];
@@ -2135,7 +2139,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
     STAMP(13)
 
     // ---- taps / debug ----
-    if (a.taps && t >= t_out) {
+    if (DBG && a.taps && t >= t_out) {
       float* tp = a.taps + ((long)t * a.B + b) * RN_TAPS;
       if (lane < RN_NFEAT) tp[lane] = MODE == 2 ? a.feat[((long)t * a.B + b) * RNN_FEAT_LD + lane] : Rb[MODE == 2 ? 0 : KB_FEAT + lane];
       if (lane < RN_NB) tp[42 + lane] = L.U[U_G + lane];
@@ -2148,7 +2152,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
       }
     }
     if (a.vad && lane == 0 && t >= t_out) a.vad[(long)t * a.B + b] = vad_prob;
-    if (a.dbg && t == a.T - 1) {
+    if (DBG && a.dbg && t == a.T - 1) {
       float* D = a.dbg + (long)b * RN_DBG_FLOATS;
       for (int i = lane; i < 962; i += WAVE) D[2862 + i] = Xf[i];
     }
@@ -2321,15 +2325,18 @@ hipError_t rn_launch_highpass(const RnArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 hipError_t rn_launch_frames(const RnArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(rn_frame_kernel<0>, dim3(a.B), dim3(WAVE), 0, s, a);
+  if (a.dbg || a.taps) hipLaunchKernelGGL((rn_frame_kernel<0, true>), dim3(a.B), dim3(WAVE), 0, s, a);
+  else hipLaunchKernelGGL((rn_frame_kernel<0, false>), dim3(a.B), dim3(WAVE), 0, s, a);
   return hipGetLastError();
 }
 hipError_t rn_launch_analysis(const RnArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(rn_frame_kernel<1>, dim3(a.B), dim3(WAVE), 0, s, a);
+  if (a.dbg || a.taps) hipLaunchKernelGGL((rn_frame_kernel<1, true>), dim3(a.B), dim3(WAVE), 0, s, a);
+  else hipLaunchKernelGGL((rn_frame_kernel<1, false>), dim3(a.B), dim3(WAVE), 0, s, a);
   return hipGetLastError();
 }
 hipError_t rn_launch_synthesis(const RnArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(rn_frame_kernel<2>, dim3(a.B, (a.T + RN_SYNTH_GROUP - 1) / RN_SYNTH_GROUP), dim3(WAVE), 0, s, a);
+  if (a.dbg || a.taps) hipLaunchKernelGGL((rn_frame_kernel<2, true>), dim3(a.B, (a.T + RN_SYNTH_GROUP - 1) / RN_SYNTH_GROUP), dim3(WAVE), 0, s, a);
+  else hipLaunchKernelGGL((rn_frame_kernel<2, false>), dim3(a.B, (a.T + RN_SYNTH_GROUP - 1) / RN_SYNTH_GROUP), dim3(WAVE), 0, s, a);
   return hipGetLastError();
 }
 hipError_t rn_launch_tansig(const RnTables* tab, const float* x, float* y, long n, int sigmoid, hipStream_t s) {

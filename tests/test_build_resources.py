@@ -39,7 +39,7 @@ def test_frame_kernel_resource_budget(tmp_path, extra):
         if m and cur:
             res[cur][m.group(1).strip()] = int(m.group(2))
     frame = {k: v for k, v in res.items() if "rn_frame_kernel" in k}
-    assert len(frame) == 3, list(res)
+    assert len(frame) == 6, list(res)      # fused / analysis / synthesis, each with and without the diagnostic captures
     text = asm.read_text()
     for name, r in frame.items():
         # 120, not 128: the 32-VGPR high-pass waves must fit as a fifth wave beside four frame waves of a SIMD
