@@ -49,6 +49,8 @@ def test_frame_kernel_resource_budget(tmp_path, extra):
         body = text[text.index(name + ":"):]
         body = body[:body.index("s_endpgm")]
         loop = body.find("=>This Loop Header: Depth=1")     # the frame loop (the prologue's copy loops are "Inner")
+        if loop < 0:                                        # a frame loop without inner loops is labelled "Inner Loop Header"
+            loop = body.find("Loop Header: Depth=1")
         assert loop > 0, name
         assert "scratch_store" not in body[loop:], f"{name}: VGPR spill store inside the frame loop"
     hp = {k: v for k, v in res.items() if "rn_highpass_kernel" in k}
