@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void g
 // ---------------------------------------------------------------------------------------------
 constexpr int AT_KLD = 72;    // halfs per K row in LDS (64 + 8): 16-lane b128 reads spread over all banks
 constexpr int AT_VLD = 36;    // halfs per V^T row in LDS (32 + 4): b64 reads of 16 rows hit 16 distinct bank pairs
-__global__ __launch_bounds__(256) void attn_enc_h_kernel(const _Float16* __restrict__ qk, const _Float16* __restrict__ vt,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void attn_enc_h_kernel(const _Float16* __restrict__ qk, const _Float16* __restrict__ vt,
                                                          _Float16* __restrict__ out, int T, int D) {
   // K and V^T tiles of 32 keys are staged once per workgroup (the four waves work on the same clip and head) and
   // double buffered: the requests for tile i + 1 are in flight while tile i is computed, one barrier per tile.
