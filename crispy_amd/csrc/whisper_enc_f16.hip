@@ -19,6 +19,8 @@
 //                          not see), so the 32 accumulator rescales per tile are rare.
 #include "asr_common.h"
 
+#include <cstdlib>
+
 namespace crispy {
 namespace {
 
@@ -109,80 +111,11 @@ __device__ __forceinline__ void hh_compute(const _Float16* Asb, const _Float16* 
   }
 }
 
+// The epilogues, shared by the register-staged and the LDS-direct main loops.
 template <int EPI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void gemm_hh_kernel(HGemmArgs g) {
-  __shared__ __attribute__((aligned(16))) _Float16 As[2][HH_M * HH_LD];
-  __shared__ __attribute__((aligned(16))) _Float16 Ws[2][HH_N * HH_LD];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  // Workgroups are dealt to the 8 XCDs round robin.  All column tiles of one row tile go to the same XCD (its L2 then
-  // serves the A tile to all of them, instead of eight L2s fetching it once each): linear id -> (xcd, slot) ->
-  // row tile = 8 (slot / n_tiles) + xcd, column tile = slot % n_tiles.  Row tiles past the matrix return at once.
-  int bx = blockIdx.x, by = blockIdx.y;
-  if (g.xcd_swizzle) {
-    const int nt = gridDim.x;
-    const int lin = blockIdx.y * nt + blockIdx.x;
-    const int xcd = lin & 7, slot = lin >> 3;
-    by = 8 * (slot / nt) + xcd;
-    bx = slot % nt;
-    if (by * HH_M >= g.M) return;
-  }
-  const int bz = blockIdx.z;
-  const _Float16* __restrict__ A = g.A + (long)bz * g.strideA;
-  const _Float16* __restrict__ W = g.W;
-  const int m0 = by * HH_M, n0 = bx * HH_N;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-
-  // staging: 8 halfs (16 bytes) per thread and tile half: row (tid >> 2) + 64 h, k offset 8 (tid & 3).  Plain named
-  // registers and unconditional code: with the loads behind `if (kb + 1 < nk)` in a lambda over arrays the compiler
-  // kept the staging registers in SCRATCH (load - wait - scratch store, scratch load - LDS store: no prefetch at all).
-  const int sr = tid >> 2, sk = (tid & 3) * 8;
-  const int M = g.M, N = g.N;
-  const long lda = g.lda, ldw = g.ldw;
-  const _Float16* pa0 = A + (long)min(m0 + sr, M - 1) * lda + sk;        // clamped rows: their results are not stored
-  const _Float16* pa1 = A + (long)min(m0 + sr + 64, M - 1) * lda + sk;
-  const _Float16* pw0 = W + (long)min(n0 + sr, N - 1) * ldw + sk;
-  const _Float16* pw1 = W + (long)min(n0 + sr + 64, N - 1) * ldw + sk;
-  const int so0 = sr * HH_LD + sk, so1 = (sr + 64) * HH_LD + sk;
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // One k-block of operands in flight per thread, four waves per SIMD.  (Two blocks in flight -- a second register
-  // set, 16 more VGPRs -- drop the kernel to three / two waves per SIMD and measured 18 % SLOWER: what hides the L2 /
-  // HBM round trip here is the number of resident waves.)
-  const int nk = g.K / HH_K;
-  uint4 ra0 = *reinterpret_cast<const uint4*>(pa0), ra1 = *reinterpret_cast<const uint4*>(pa1);
-  uint4 rw0 = *reinterpret_cast<const uint4*>(pw0), rw1 = *reinterpret_cast<const uint4*>(pw1);
-  *reinterpret_cast<uint4*>(&As[0][so0]) = ra0;
-  *reinterpret_cast<uint4*>(&As[0][so1]) = ra1;
-  *reinterpret_cast<uint4*>(&Ws[0][so0]) = rw0;
-  *reinterpret_cast<uint4*>(&Ws[0][so1]) = rw1;
-  __syncthreads();
+__device__ __forceinline__ void hh_epilogue(const HGemmArgs& g, f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn, int lane,
+                                            int bz) {
   const int li = lane & 31, lh = lane >> 5;
-  for (int kb = 0; kb < nk; ++kb) {
-    const int buf = kb & 1;
-    const int kn = min(kb + 1, nk - 1) * HH_K;      // the last trip re-requests its own block (never used)
-    ra0 = *reinterpret_cast<const uint4*>(pa0 + kn);
-    ra1 = *reinterpret_cast<const uint4*>(pa1 + kn);
-    rw0 = *reinterpret_cast<const uint4*>(pw0 + kn);
-    rw1 = *reinterpret_cast<const uint4*>(pw1 + kn);
-    // pin the requests here: left alone the scheduler sinks them below the MFMAs, right in front of the LDS stores
-    // that consume them (load - wait - store: the whole memory latency exposed once per k-block)
-    __builtin_amdgcn_sched_barrier(0);
-    hh_compute<EPI>(As[buf], Ws[buf], acc, wm, wn, li, lh);
-    __builtin_amdgcn_sched_barrier(0);
-    *reinterpret_cast<uint4*>(&As[buf ^ 1][so0]) = ra0;
-    *reinterpret_cast<uint4*>(&As[buf ^ 1][so1]) = ra1;
-    *reinterpret_cast<uint4*>(&Ws[buf ^ 1][so0]) = rw0;
-    *reinterpret_cast<uint4*>(&Ws[buf ^ 1][so1]) = rw1;
-    __syncthreads();
-  }
-
   if (EPI == EPI_F16) {
     _Float16* __restrict__ C = reinterpret_cast<_Float16*>(g.C) + (long)bz * g.strideC;
 #pragma unroll
@@ -280,6 +213,287 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void g
         }
       }
   }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void gemm_hh_kernel(HGemmArgs g) {
+  __shared__ __attribute__((aligned(16))) _Float16 As[2][HH_M * HH_LD];
+  __shared__ __attribute__((aligned(16))) _Float16 Ws[2][HH_N * HH_LD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // Workgroups are dealt to the 8 XCDs round robin.  All column tiles of one row tile go to the same XCD (its L2 then
+  // serves the A tile to all of them, instead of eight L2s fetching it once each): linear id -> (xcd, slot) ->
+  // row tile = 8 (slot / n_tiles) + xcd, column tile = slot % n_tiles.  Row tiles past the matrix return at once.
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (g.xcd_swizzle) {
+    const int nt = gridDim.x;
+    const int lin = blockIdx.y * nt + blockIdx.x;
+    const int xcd = lin & 7, slot = lin >> 3;
+    by = 8 * (slot / nt) + xcd;
+    bx = slot % nt;
+    if (by * HH_M >= g.M) return;
+  }
+  const int bz = blockIdx.z;
+  const _Float16* __restrict__ A = g.A + (long)bz * g.strideA;
+  const _Float16* __restrict__ W = g.W;
+  const int m0 = by * HH_M, n0 = bx * HH_N;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+  // staging: 8 halfs (16 bytes) per thread and tile half: row (tid >> 2) + 64 h, k offset 8 (tid & 3).  Plain named
+  // registers and unconditional code: with the loads behind `if (kb + 1 < nk)` in a lambda over arrays the compiler
+  // kept the staging registers in SCRATCH (load - wait - scratch store, scratch load - LDS store: no prefetch at all).
+  const int sr = tid >> 2, sk = (tid & 3) * 8;
+  const int M = g.M, N = g.N;
+  const long lda = g.lda, ldw = g.ldw;
+  const _Float16* pa0 = A + (long)min(m0 + sr, M - 1) * lda + sk;        // clamped rows: their results are not stored
+  const _Float16* pa1 = A + (long)min(m0 + sr + 64, M - 1) * lda + sk;
+  const _Float16* pw0 = W + (long)min(n0 + sr, N - 1) * ldw + sk;
+  const _Float16* pw1 = W + (long)min(n0 + sr + 64, N - 1) * ldw + sk;
+  const int so0 = sr * HH_LD + sk, so1 = (sr + 64) * HH_LD + sk;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // One k-block of operands in flight per thread, four waves per SIMD.  (Two blocks in flight -- a second register
+  // set, 16 more VGPRs -- drop the kernel to three / two waves per SIMD and measured 18 % SLOWER: what hides the L2 /
+  // HBM round trip here is the number of resident waves.)
+  const int nk = g.K / HH_K;
+  uint4 ra0 = *reinterpret_cast<const uint4*>(pa0), ra1 = *reinterpret_cast<const uint4*>(pa1);
+  uint4 rw0 = *reinterpret_cast<const uint4*>(pw0), rw1 = *reinterpret_cast<const uint4*>(pw1);
+  *reinterpret_cast<uint4*>(&As[0][so0]) = ra0;
+  *reinterpret_cast<uint4*>(&As[0][so1]) = ra1;
+  *reinterpret_cast<uint4*>(&Ws[0][so0]) = rw0;
+  *reinterpret_cast<uint4*>(&Ws[0][so1]) = rw1;
+  __syncthreads();
+  const int li = lane & 31, lh = lane >> 5;
+  for (int kb = 0; kb < nk; ++kb) {
+    const int buf = kb & 1;
+    const int kn = min(kb + 1, nk - 1) * HH_K;      // the last trip re-requests its own block (never used)
+    ra0 = *reinterpret_cast<const uint4*>(pa0 + kn);
+    ra1 = *reinterpret_cast<const uint4*>(pa1 + kn);
+    rw0 = *reinterpret_cast<const uint4*>(pw0 + kn);
+    rw1 = *reinterpret_cast<const uint4*>(pw1 + kn);
+    // pin the requests here: left alone the scheduler sinks them below the MFMAs, right in front of the LDS stores
+    // that consume them (load - wait - store: the whole memory latency exposed once per k-block)
+    __builtin_amdgcn_sched_barrier(0);
+    hh_compute<EPI>(As[buf], Ws[buf], acc, wm, wn, li, lh);
+    __builtin_amdgcn_sched_barrier(0);
+    *reinterpret_cast<uint4*>(&As[buf ^ 1][so0]) = ra0;
+    *reinterpret_cast<uint4*>(&As[buf ^ 1][so1]) = ra1;
+    *reinterpret_cast<uint4*>(&Ws[buf ^ 1][so0]) = rw0;
+    *reinterpret_cast<uint4*>(&Ws[buf ^ 1][so1]) = rw1;
+    __syncthreads();
+  }
+
+  hh_epilogue<EPI>(g, acc, m0, n0, wm, wn, lane, bz);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Epilogue through LDS (LDS-direct kernel).  With a lane owning a row or a column of the MFMA tile, every store
+// instruction of the direct epilogues above touches 32 different rows with 8 or 16 bytes each, 16 to 64 instructions
+// per wave -- store-ISSUE bound: for the K = 384 GEMMs the store tail was longer than the main loop.  Here a wave
+// puts its 64 x 64 tile through a padded f32 image in LDS, 32 rows at a time, and reads it back row-contiguous:
+// every global instruction then moves whole 128 / 256-byte rows (8 or 4 rows per instruction, 16 bytes per lane).
+//   T: this wave's 32 x 68 floats (row-major outputs) or 64 x 36 floats (V^T) of LDS.
+// ---------------------------------------------------------------------------------------------
+constexpr int EP_LD = 68, EP_VLD = 36;
+template <int EPI>
+__device__ __forceinline__ void hd_epilogue(const HGemmArgs& g, f32x16 (&acc)[2][2], float* T, int m0, int n0, int wm, int wn,
+                                            int lane, int bz) {
+  const int li = lane & 31, lh = lane >> 5;
+  float bias[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bias[j] = g.bias ? g.bias[min(n0 + wn + 32 * j + li, g.N - 1)] : 0.f;
+  const int mrem = g.M - (m0 + wm), nrem = g.N - (n0 + wn);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    // ---- write: lane = column 32 j + li, register r = row 8 (r >> 2) + 4 lh + (r & 3) of this 32-row half ----
+    if (EPI == EPI_VT) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(T + (32 * j + li) * EP_VLD + 8 * q + 4 * lh) =
+              make_float4(acc[i][j][4 * q] + bias[j], acc[i][j][4 * q + 1] + bias[j], acc[i][j][4 * q + 2] + bias[j],
+                          acc[i][j][4 * q + 3] + bias[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][j][r] + bias[j];
+          if ((EPI == EPI_F16 && g.gelu) || EPI == EPI_TAB) v = gelu_erf_e(v);
+          T[acc_row_e(r, lane) * EP_LD + 32 * j + li] = v;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's image is complete (single-wave hand-off)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- read back row-contiguous and store ----
+    if (EPI == EPI_F16) {
+      _Float16* __restrict__ C = reinterpret_cast<_Float16*>(g.C) + (long)bz * g.strideC + (long)(m0 + wm + 32 * i) * g.ldc + (n0 + wn);
+      const int c8 = (lane & 7) * 8;                            // 8 lanes per row, 8 columns (16 bytes of f16) each
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int row = (lane >> 3) + 8 * p;
+        const float4 x0 = *reinterpret_cast<const float4*>(T + row * EP_LD + c8);
+        const float4 x1 = *reinterpret_cast<const float4*>(T + row * EP_LD + c8 + 4);
+        const half4 h0 = to_half4(x0.x, x0.y, x0.z, x0.w), h1 = to_half4(x1.x, x1.y, x1.z, x1.w);
+        const half8 hv = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+        if (32 * i + row < mrem && c8 < nrem) *reinterpret_cast<half8*>(C + (long)row * g.ldc + c8) = hv;
+      }
+    } else if (EPI == EPI_RES || EPI == EPI_TAB) {
+      float* __restrict__ C = reinterpret_cast<float*>(g.C) + (long)bz * g.strideC + (long)(m0 + wm + 32 * i) * g.ldc + (n0 + wn);
+      const int c4 = (lane & 15) * 4;                           // 16 lanes per row, 4 columns (16 bytes of f32) each
+      float4 ex[8];
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {                             // residual / positional operands requested together
+        const int row = (lane >> 4) + 4 * p;
+        const int rc = min(32 * i + row, mrem - 1), cc = min(c4, nrem - 4);
+        if (EPI == EPI_RES)
+          ex[p] = *reinterpret_cast<const float4*>(g.residual + (long)bz * g.strideC + (long)(m0 + wm + rc) * g.ldr + (n0 + wn) + cc);
+        else
+          ex[p] = *reinterpret_cast<const float4*>(g.rowtab + (long)((m0 + wm + rc) % g.rowtab_period) * g.N + (n0 + wn) + cc);
+      }
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int row = (lane >> 4) + 4 * p;
+        const float4 x = *reinterpret_cast<const float4*>(T + row * EP_LD + c4);
+        if (32 * i + row < mrem && c4 < nrem)
+          *reinterpret_cast<float4*>(C + (long)row * g.ldc + c4) = make_float4(x.x + ex[p].x, x.y + ex[p].y, x.z + ex[p].z, x.w + ex[p].w);
+      }
+    } else {   // EPI_VT: image row = column n (head, dim), 32 consecutive time steps of one clip (T % 32 == ... see below)
+      _Float16* __restrict__ C = reinterpret_cast<_Float16*>(g.C);
+      const int c4 = (lane & 7) * 4;                            // 8 lanes per row, 4 time steps (8 bytes of f16) each
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int nl = (lane >> 3) + 8 * p;                     // column of this wave's 64
+        const float4 x = *reinterpret_cast<const float4*>(T + nl * EP_VLD + c4);
+        const int m = m0 + wm + 32 * i + c4;                    // four consecutive rows; vt_T % 4 == 0, so one clip
+        const int clip = m / g.vt_T, t = m - clip * g.vt_T;
+        if (m < g.M && nl < nrem)
+          *reinterpret_cast<half4*>(C + ((long)clip * g.N + (n0 + wn + nl)) * ENC_TP + t) = to_half4(x.x, x.y, x.z, x.w);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // the image is read before the second half overwrites it
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same GEMM with LDS-direct operand loads and a three-stage pipeline (the default main loop).
+//
+// The register-staged loop above has one k-block of operands in flight per wave, issued at the top of the trip that
+// stores it to LDS at its end: 256 cycles of MFMAs (~1000 with the other three waves of the SIMD) against an L2 / HBM
+// round trip of several thousand under load -- matrix pipe 21 % busy.  Here global_load_lds_dwordx4 writes the operand
+// tiles straight into LDS (no staging registers, no ds_write), so a third LDS stage costs no VGPRs and the requests of
+// k-block kb + 2 are in flight while kb is multiplied:
+//   trip kb:  s_waitcnt vmcnt(4 | 0)   this wave's four requests of stage kb have landed (kb + 1 may be pending)
+//             s_barrier                 everyone's have; everyone has finished reading stage kb - 1
+//             request stage kb + 2      into the buffer stage kb - 1 occupied
+//             8 ds_read_b128 + 8 MFMAs from stage kb
+// LDS tile layout: 128 rows x 4 chunks of 16 bytes, unpadded (a wave-wide request writes 1 KB contiguously: lane L at
+// base + 16 L), chunk c of row r stored at slot c ^ ((r >> 1) & 3): the 8 lanes of a b128 read phase (consecutive
+// rows, one chunk) then cover all 32 banks.  The lane that fills slot (r, cs) simply requests chunk cs ^ ((r >> 1) & 3).
+// The operand reads are inline asm on purpose: the compiler orders every LDS read it can see behind the most recent
+// LDS-DMA request (`s_waitcnt vmcnt(0)`), which would serialise the stages; the counters are kept by hand instead.
+// ---------------------------------------------------------------------------------------------
+constexpr int HD_STAGES = 3, HD_TILE_BYTES = HH_M * HH_K * 2;     // 8 KB per operand tile
+template <int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void gemm_hd_kernel(HGemmArgs g) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[HD_STAGES * 2 * HD_TILE_BYTES];   // [stage][A | W]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (g.xcd_swizzle) {
+    const int nt = gridDim.x;
+    const int lin = blockIdx.y * nt + blockIdx.x;
+    const int xcd = lin & 7, slot = lin >> 3;
+    by = 8 * (slot / nt) + xcd;
+    bx = slot % nt;
+    if (by * HH_M >= g.M) return;
+  }
+  const int bz = blockIdx.z;
+  const _Float16* __restrict__ A = g.A + (long)bz * g.strideA;
+  const _Float16* __restrict__ W = g.W;
+  const int m0 = by * HH_M, n0 = bx * HH_N;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int li = lane & 31, lh = lane >> 5;
+
+  // ---- requests: wave w fills rows [32 w, 32 w + 32) of both tiles, two 1 KB wave-requests each ----
+  const _Float16* ga[2];
+  const _Float16* gw[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int r = 32 * wave + 16 * u + (lane >> 2);             // tile row this lane fills
+    const int c = (lane & 3) ^ ((r >> 1) & 3);                  // global chunk that belongs into slot (r, lane & 3)
+    ga[u] = A + (long)min(m0 + r, g.M - 1) * g.lda + 8 * c;     // clamped rows: their results are not stored
+    gw[u] = W + (long)min(n0 + r, g.N - 1) * g.ldw + 8 * c;
+  }
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  auto request = [&](int stage, int k0) {
+    unsigned char* base = smem + stage * (2 * HD_TILE_BYTES) + wave * 2048;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      __builtin_amdgcn_global_load_lds(ga[u] + k0, (lds_ptr)(base + 1024 * u), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(gw[u] + k0, (lds_ptr)(base + HD_TILE_BYTES + 1024 * u), 16, 0, 0);
+    }
+  };
+
+  // ---- operand read addresses (bytes inside a stage): row R = w? + 32 i + li, chunk 2 ks + lh, slot = chunk ^ swz ----
+  const int swz = (li >> 1) & 3;
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr)smem;
+  const unsigned a_ks0 = lds0 + (wm + li) * 64 + ((lh ^ swz) << 4);
+  const unsigned a_ks1 = lds0 + (wm + li) * 64 + (((2 + lh) ^ swz) << 4);
+  const unsigned w_ks0 = lds0 + HD_TILE_BYTES + (wn + li) * 64 + ((lh ^ swz) << 4);
+  const unsigned w_ks1 = lds0 + HD_TILE_BYTES + (wn + li) * 64 + (((2 + lh) ^ swz) << 4);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = g.K / HH_K;
+  request(0, 0);
+  if (nk > 1) request(1, HH_K);
+  int stage = 0;
+  for (int kb = 0; kb < nk; ++kb) {
+    if (kb + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0F74);      // vmcnt(4): the four requests of stage kb + 1 may be pending
+    else __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    if (kb + 2 < nk) {
+      const int s2 = stage + 2 >= HD_STAGES ? stage + 2 - HD_STAGES : stage + 2;
+      request(s2, (kb + 2) * HH_K);
+    }
+    const unsigned so = (unsigned)stage * (2 * HD_TILE_BYTES);
+    half8 a0[2], a1[2], w0[2], w1[2];          // [ks]
+    asm volatile("ds_read_b128 %0, %1" : "=v"(a0[0]) : "v"(a_ks0 + so));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(w0[0]) : "v"(w_ks0 + so));
+    asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(a1[0]) : "v"(a_ks0 + so));
+    asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(w1[0]) : "v"(w_ks0 + so));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(a0[1]) : "v"(a_ks1 + so));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(w0[1]) : "v"(w_ks1 + so));
+    asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(a1[1]) : "v"(a_ks1 + so));
+    asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(w1[1]) : "v"(w_ks1 + so));
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a0[0]), "+v"(w0[0]), "+v"(a1[0]), "+v"(w1[0]));
+#define HD_MFMA(i_, j_, av, wv) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, wv, acc[i_][j_], 0, 0, 0);
+    HD_MFMA(0, 0, a0[0], w0[0]) HD_MFMA(0, 1, a0[0], w1[0]) HD_MFMA(1, 0, a1[0], w0[0]) HD_MFMA(1, 1, a1[0], w1[0])
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0[1]), "+v"(w0[1]), "+v"(a1[1]), "+v"(w1[1]));
+    HD_MFMA(0, 0, a0[1], w0[1]) HD_MFMA(0, 1, a0[1], w1[1]) HD_MFMA(1, 0, a1[1], w0[1]) HD_MFMA(1, 1, a1[1], w1[1])
+#undef HD_MFMA
+    stage = stage + 1 == HD_STAGES ? 0 : stage + 1;
+  }
+  __builtin_amdgcn_s_barrier();          // every wave has read its last operands: the stages become epilogue images
+  hd_epilogue<EPI>(g, acc, reinterpret_cast<float*>(smem + wave * 12288), m0, n0, wm, wn, lane, bz);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -458,6 +672,17 @@ hipError_t gemm_hh(const HGemmArgs& g, int epi, int batch, hipStream_t s) {
   HGemmArgs a = g;
   dim3 grid(nt, mt, batch);
   if (a.xcd_swizzle) grid.y = (unsigned)(((mt + 7) / 8) * 8);      // whole groups of eight row tiles
+  static const bool direct = [] { const char* e = std::getenv("CRISPY_ASR_GEMM"); return !(e && e[0] == 'r'); }();   // "regs": the register-staged loop
+  if (direct) {
+    switch (epi) {
+      case EPI_F16: hipLaunchKernelGGL(gemm_hd_kernel<EPI_F16>, grid, dim3(256), 0, s, a); break;
+      case EPI_RES: hipLaunchKernelGGL(gemm_hd_kernel<EPI_RES>, grid, dim3(256), 0, s, a); break;
+      case EPI_VT: hipLaunchKernelGGL(gemm_hd_kernel<EPI_VT>, grid, dim3(256), 0, s, a); break;
+      case EPI_TAB: hipLaunchKernelGGL(gemm_hd_kernel<EPI_TAB>, grid, dim3(256), 0, s, a); break;
+      default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  }
   switch (epi) {
     case EPI_F16: hipLaunchKernelGGL(gemm_hh_kernel<EPI_F16>, grid, dim3(256), 0, s, a); break;
     case EPI_RES: hipLaunchKernelGGL(gemm_hh_kernel<EPI_RES>, grid, dim3(256), 0, s, a); break;

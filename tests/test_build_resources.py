@@ -118,4 +118,21 @@ def test_f16_encoder_kernels_run_at_four_waves_per_simd_without_scratch(tmp_path
         assert 0 < first_load < first_mfma, f"{name}: operand requests are not issued ahead of the MFMAs"
         assert loop.count("global_load_dwordx4") == 4 and loop.count("v_mfma_f32_32x32x16_f16") == 8
     att = {k: v for k, v in res.items() if "attn_enc_h_kernel" in k}
-    assert len(att) == 1 and all(r["ScratchSize"] == 0 for r in att.values())
+    assert len(att) == 1 and all(r["ScratchSize"] == 0 and r["VGPRs"] + r.get("AGPRs", 0) <= 128 for r in att.values())
+    # the LDS-direct main loop (default): three stages of 16 KB, no scratch, and between the barrier and the MFMAs of
+    # a k-block nothing but the hand-kept counters: four LDS-DMA requests, eight ds_read_b128, no vmcnt(0)
+    hd = {k: v for k, v in res.items() if "gemm_hd_kernel" in k}
+    assert len(hd) == 4, list(res)
+    for name, r in hd.items():
+        assert r["ScratchSize"] == 0 and r["LDS Size"] == 3 * 16384 and r["VGPRs"] + r.get("AGPRs", 0) <= 128, (name, r)
+        body = text[text.index(name + ":"):]
+        body = body[:body.index("s_endpgm")]
+        loop = body[body.index("Loop Header: Depth=1"):]
+        loop = loop[loop.index("s_barrier"):]
+        pos, at = [], 0
+        for _ in range(8):                                   # up to the eighth MFMA behind the trip's barrier
+            at = loop.index("v_mfma_f32_32x32x16_f16", at) + 1
+            pos.append(at)
+        seg = loop[:pos[-1]]
+        assert seg.count("ds_read_b128") == 8 and seg.count("global_load_lds_dwordx4") == 4, name
+        assert "vmcnt(0)" not in seg, f"{name}: a compiler-inserted vmcnt(0) serialises the stages"
