@@ -111,7 +111,7 @@ def test_f16_encoder_kernels_run_at_four_waves_per_simd_without_scratch(tmp_path
     for name, r in gem.items():
         assert r["VGPRs"] + r.get("AGPRs", 0) <= 128 and r["ScratchSize"] == 0, (name, r)
         body = text[text.index(name + ":"):]
-        body = body[:body.index("s_endpgm")]
+        body = body[:body.index(".Lfunc_end")]          # (an early-return path has its own s_endpgm)
         loop = body[body.index("Loop Header: Depth=1"):]
         loop = loop[:loop.index("s_barrier")]
         first_load, first_mfma = loop.find("global_load_dwordx4"), loop.find("v_mfma")
@@ -126,7 +126,7 @@ def test_f16_encoder_kernels_run_at_four_waves_per_simd_without_scratch(tmp_path
     for name, r in hd.items():
         assert r["ScratchSize"] == 0 and r["LDS Size"] == 3 * 16384 and r["VGPRs"] + r.get("AGPRs", 0) <= 128, (name, r)
         body = text[text.index(name + ":"):]
-        body = body[:body.index("s_endpgm")]
+        body = body[:body.index(".Lfunc_end")]          # (an early-return path has its own s_endpgm)
         loop = body[body.index("Loop Header: Depth=1"):]
         loop = loop[loop.index("s_barrier"):]
         pos, at = [], 0
