@@ -629,15 +629,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void a
     l_run = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
   }
   const float inv = 1.f / l_run;
-  const int q = q0 + li;
-  if (q < T) {
-    _Float16* orow = out + ((long)b * T + q) * D + h * 64;
+  // lane (li = query, lh) holds O[q][d] for d = acc_row(r) (+ 32 for o1).  Stored from here, every instruction would
+  // touch 32 rows with 16 bytes each (16 instructions per wave, store-issue bound); through a [32][64 + 8] f16 image in
+  // the K stage that is free now, a wave writes whole 128-byte rows, 8 rows per 16-byte-per-lane instruction.
+  __syncthreads();                                   // every wave has read its last K / V^T tile
+  _Float16* Timg = &Ks[0][0] + wave * (32 * AT_KLD);  // 4 x 4608 bytes = the two K stages
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const int d = 8 * g4 + 4 * lh;
-      *reinterpret_cast<half4*>(orow + d) = to_half4(o0[4 * g4] * inv, o0[4 * g4 + 1] * inv, o0[4 * g4 + 2] * inv, o0[4 * g4 + 3] * inv);
-      *reinterpret_cast<half4*>(orow + 32 + d) = to_half4(o1[4 * g4] * inv, o1[4 * g4 + 1] * inv, o1[4 * g4 + 2] * inv, o1[4 * g4 + 3] * inv);
-    }
+  for (int g4 = 0; g4 < 4; ++g4) {
+    const int d = 8 * g4 + 4 * lh;
+    *reinterpret_cast<half4*>(Timg + li * AT_KLD + d) = to_half4(o0[4 * g4] * inv, o0[4 * g4 + 1] * inv, o0[4 * g4 + 2] * inv, o0[4 * g4 + 3] * inv);
+    *reinterpret_cast<half4*>(Timg + li * AT_KLD + 32 + d) = to_half4(o1[4 * g4] * inv, o1[4 * g4 + 1] * inv, o1[4 * g4 + 2] * inv, o1[4 * g4 + 3] * inv);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int row = (lane >> 3) + 8 * p, c8 = (lane & 7) * 8;
+    const uint4 v = *reinterpret_cast<const uint4*>(Timg + row * AT_KLD + c8);
+    if (q0 + row < T) *reinterpret_cast<uint4*>(out + ((long)b * T + q0 + row) * D + h * 64 + c8) = v;
   }
 }
 
