@@ -93,5 +93,45 @@ __device__ __forceinline__ void pass(float2* buf, const float2* __restrict__ tw,
   wave_lds_sync();
 }
 
+// The same pass over NF transforms at once (buffers STRIDE complex numbers apart): the NF * M butterflies are spread
+// over the 64 lanes, so a radix with M = 40 or 50 butterflies no longer leaves lanes idle, and the two wave
+// synchronisations of a pass are paid once per NF transforms.
+template <int N, int R, int NS, int WN, int NF, int STRIDE>
+__device__ __forceinline__ void pass_batched(float2* buf, const float2* __restrict__ tw, int lane) {
+  constexpr int M = N / R;
+  constexpr int TOT = NF * M;
+  constexpr int NBF = (TOT + 63) / 64;
+  float2 o[NBF][R];
+#pragma unroll
+  for (int nb = 0; nb < NBF; ++nb) {
+    const int idx = min(lane + 64 * nb, TOT - 1);      // clamped: the extra lanes redo the last butterfly, stores are predicated
+    const int f = idx / M, j = idx - f * M;
+    const int k = j % NS;
+    const float2* b = buf + f * STRIDE;
+    float2 v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float2 x = b[j + r * M];
+      if (NS > 1 && r > 0) x = cmul(x, tw[k * r * (WN / (NS * R))]);
+      v[r] = x;
+    }
+    butterfly<R>(v, o[nb]);
+  }
+  wave_lds_sync();
+#pragma unroll
+  for (int nb = 0; nb < NBF; ++nb) {
+    const int idx = lane + 64 * nb;
+    if (idx < TOT) {
+      const int f = idx / M, j = idx - f * M;
+      const int k = j % NS;
+      const int j0 = (j / NS) * NS * R + k;
+      float2* b = buf + f * STRIDE;
+#pragma unroll
+      for (int r = 0; r < R; ++r) b[j0 + r * NS] = o[nb][r];
+    }
+  }
+  wave_lds_sync();
+}
+
 }  // namespace fftx
 }  // namespace crispy

@@ -29,78 +29,109 @@ __device__ __forceinline__ float float_from_key(int k) {
   return __int_as_float(k >= 0 ? k : (k ^ 0x7fffffff));
 }
 
+constexpr int MEL_NF = 4;        // frames a wave transforms at once
+constexpr int MEL_BS = 208;      // complex numbers between two frames' buffers (201 used)
 __global__ __launch_bounds__(256) void mel_frames_kernel(MelArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = blockIdx.y;
   const int t0 = blockIdx.x * MEL_TILE;
-  float2* buf = reinterpret_cast<float2*>(smem) + wave * 208;                       // 201 used
-  float* pw = reinterpret_cast<float*>(smem + 4 * 208 * sizeof(float2)) + wave * 208;  // 201 used
-  float* tile = reinterpret_cast<float*>(smem + 4 * 208 * (sizeof(float2) + sizeof(float)));  // [n_mel][65]
+  // per wave: MEL_NF transform buffers, MEL_NF power spectra (40 KB per workgroup: four workgroups per CU)
+  float2* buf = reinterpret_cast<float2*>(smem) + wave * (MEL_NF * MEL_BS);
+  float* pw = reinterpret_cast<float*>(smem + 4 * MEL_NF * MEL_BS * sizeof(float2)) + wave * (MEL_NF * MEL_BS);
   const float* __restrict__ x = a.pcm + (long)b * a.pcm_stride;
   const int n = a.n_samples[b];
   const MelTables* __restrict__ tab = a.tab;
   float wmax = -1e30f;
 
-  for (int fi = 0; fi < 16; ++fi) {
-    const int f = wave * 16 + fi;
-    const int t = t0 + f;
+  // A wave owns 16 consecutive frames and takes them MEL_NF at a time: every stage below runs over the MEL_NF frames at
+  // once (frame-major work items over the 64 lanes), so the radix-5 passes with their 40 butterflies per frame, the
+  // 101 spectrum pairs and the 80 mel bins fill the lanes, and a wave synchronisation is paid once per MEL_NF frames.
+  for (int fb = 0; fb < 16; fb += MEL_NF) {
+    const int f0 = wave * 16 + fb;
     // window + pack: z[m] = (h[2m] x[2m], h[2m+1] x[2m+1]); reflect at the start, zeros past the end
-    for (int m = lane; m < 200; m += 64) {
-      float v[2];
+    {
+      constexpr int TOT = MEL_NF * 200, NT = (TOT + 63) / 64;
+      float2 xv[NT], hv[NT];
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        int s = t * 160 + 2 * m + q - 200;
-        if (s < 0) s = -s;
-        v[q] = s < n ? x[s] * tab->hann[2 * m + q] : 0.f;
+      for (int it = 0; it < NT; ++it) {          // all requests of the stage first
+        const int idx = min(lane + 64 * it, TOT - 1);
+        const int f = idx / 200, m = idx - f * 200;
+        const int s0 = (t0 + f0 + f) * 160 + 2 * m - 200;
+        int sa = s0 < 0 ? -s0 : s0, sb = s0 + 1 < 0 ? -(s0 + 1) : s0 + 1;
+        xv[it].x = sa < n ? x[sa] : 0.f;
+        xv[it].y = sb < n ? x[sb] : 0.f;
+        hv[it] = *reinterpret_cast<const float2*>(tab->hann + 2 * m);
       }
-      buf[m] = make_float2(v[0], v[1]);
+#pragma unroll
+      for (int it = 0; it < NT; ++it) {
+        const int idx = lane + 64 * it;
+        if (idx < TOT) {
+          const int f = idx / 200, m = idx - f * 200;
+          buf[f * MEL_BS + m] = make_float2(xv[it].x * hv[it].x, xv[it].y * hv[it].y);
+        }
+      }
     }
     wave_lds_sync();
-    pass<200, 4, 1, 400>(buf, tab->w400, lane);
-    pass<200, 2, 4, 400>(buf, tab->w400, lane);
-    pass<200, 5, 8, 400>(buf, tab->w400, lane);
-    pass<200, 5, 40, 400>(buf, tab->w400, lane);
+    pass_batched<200, 4, 1, 400, MEL_NF, MEL_BS>(buf, tab->w400, lane);
+    pass_batched<200, 2, 4, 400, MEL_NF, MEL_BS>(buf, tab->w400, lane);
+    pass_batched<200, 5, 8, 400, MEL_NF, MEL_BS>(buf, tab->w400, lane);
+    pass_batched<200, 5, 40, 400, MEL_NF, MEL_BS>(buf, tab->w400, lane);
     // real post-processing of the pair (k, 200-k) and power spectrum
-    for (int k = lane; k <= 100; k += 64) {
-      const float2 zk = buf[k];
-      const float2 zn = (k == 0) ? zk : buf[200 - k];
-      float2 zc = cconj(zn);
-      float2 fe = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
-      float2 d = make_float2(0.5f * (zk.x - zc.x), 0.5f * (zk.y - zc.y));
-      float2 tt = cmul(tab->w400[k], make_float2(d.y, -d.x));
-      const float2 xk = cadd(fe, tt);
-      zc = cconj(zk);
-      fe = make_float2(0.5f * (zn.x + zc.x), 0.5f * (zn.y + zc.y));
-      d = make_float2(0.5f * (zn.x - zc.x), 0.5f * (zn.y - zc.y));
-      tt = cmul(tab->w400[200 - k], make_float2(d.y, -d.x));
-      const float2 xn = cadd(fe, tt);
-      pw[k] = xk.x * xk.x + xk.y * xk.y;
-      pw[200 - k] = xn.x * xn.x + xn.y * xn.y;
+    {
+      constexpr int TOT = MEL_NF * 101, NT = (TOT + 63) / 64;
+#pragma unroll
+      for (int it = 0; it < NT; ++it) {
+        const int idx = lane + 64 * it;
+        if (idx < TOT) {
+          const int f = idx / 101, k = idx - f * 101;
+          const float2* bf = buf + f * MEL_BS;
+          const float2 zk = bf[k];
+          const float2 zn = (k == 0) ? zk : bf[200 - k];
+          float2 zc = cconj(zn);
+          float2 fe = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
+          float2 d = make_float2(0.5f * (zk.x - zc.x), 0.5f * (zk.y - zc.y));
+          float2 tt = cmul(tab->w400[k], make_float2(d.y, -d.x));
+          const float2 xk = cadd(fe, tt);
+          zc = cconj(zk);
+          fe = make_float2(0.5f * (zn.x + zc.x), 0.5f * (zn.y + zc.y));
+          d = make_float2(0.5f * (zn.x - zc.x), 0.5f * (zn.y - zc.y));
+          tt = cmul(tab->w400[200 - k], make_float2(d.y, -d.x));
+          const float2 xn = cadd(fe, tt);
+          pw[f * MEL_BS + k] = xk.x * xk.x + xk.y * xk.y;
+          pw[f * MEL_BS + 200 - k] = xn.x * xn.x + xn.y * xn.y;
+        }
+      }
     }
     wave_lds_sync();
-    // sparse triangular filters, double accumulation, log10
+    // sparse triangular filters, double accumulation, log10: a lane takes one mel bin for the MEL_NF frames of the batch
+    // (one pass over the filter weights, MEL_NF independent accumulation chains) and stores the MEL_NF consecutive
+    // frames of its bin as one 16-byte piece -- no [n_mel][64] staging tile, which had cost half the resident waves
     for (int m = lane; m < a.n_mel; m += 64) {
       const int k0 = tab->f_start[m], len = tab->f_len[m];
       const float* __restrict__ w = tab->f_w + tab->f_off[m];
-      double sum = 0.0;
-      for (int q = 0; q < len; ++q) sum += (double)pw[k0 + q] * (double)w[q];
-      const float lv = (float)log10(sum > 1e-10 ? sum : 1e-10);
-      tile[m * 65 + f] = lv;
-      wmax = fmaxf(wmax, lv);
+      double sum[MEL_NF];
+#pragma unroll
+      for (int f = 0; f < MEL_NF; ++f) sum[f] = 0.0;
+      for (int q = 0; q < len; ++q) {
+        const double wq = (double)w[q];
+#pragma unroll
+        for (int f = 0; f < MEL_NF; ++f) sum[f] += (double)pw[f * MEL_BS + k0 + q] * wq;
+      }
+      float lv[MEL_NF];
+#pragma unroll
+      for (int f = 0; f < MEL_NF; ++f) {
+        lv[f] = (float)log10(sum[f] > 1e-10 ? sum[f] : 1e-10);
+        wmax = fmaxf(wmax, lv[f]);
+      }
+      static_assert(MEL_NF == 4, "one float4 per mel bin and batch");
+      *reinterpret_cast<float4*>(a.raw + ((long)b * a.n_mel + m) * MEL_RAW_FRAMES + t0 + f0) = make_float4(lv[0], lv[1], lv[2], lv[3]);
     }
     wave_lds_sync();
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off, 64));
   if (lane == 0) atomicMax(a.clip_max + b, float_order_key(wmax));
-  __syncthreads();
-  // coalesced store of the tile: rows of 64 frames
-  for (int idx = threadIdx.x; idx < a.n_mel * MEL_TILE; idx += 256) {
-    const int m = idx >> 6, f = idx & 63;
-    const int t = t0 + f;
-    a.raw[((long)b * a.n_mel + m) * MEL_RAW_FRAMES + t] = tile[m * 65 + f];
-  }
 }
 
 __global__ __launch_bounds__(256) void mel_finish_kernel(MelArgs a) {
@@ -126,7 +157,11 @@ __global__ __launch_bounds__(256) void mel_finish_kernel(MelArgs a) {
 hipError_t mel_launch(const MelArgs& a, int batch, hipStream_t s) {
   hipError_t e = hipMemsetAsync(a.clip_max, 0x80, sizeof(int) * batch, s);  // 0x80808080: below any key
   if (e != hipSuccess) return e;
-  const size_t smem = 4 * 208 * (sizeof(float2) + sizeof(float)) + (size_t)a.n_mel * 65 * sizeof(float);
+  const size_t smem = 4 * MEL_NF * MEL_BS * (sizeof(float2) + sizeof(float));
+  if (smem > 64 * 1024) {      // 128 mel bins: above the default dynamic-LDS limit (the CU has 160 KB)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(mel_frames_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+  }
   hipLaunchKernelGGL(mel_frames_kernel, dim3(MEL_TILES, batch), dim3(256), smem, s, a);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
