@@ -82,10 +82,12 @@ struct HGemmArgs {
   const float* rowtab; int rowtab_period;   // EPI_TAB: C = GELU(acc + bias) + rowtab[m % period][n]
   int M, N, K;
   int gelu;                         // EPI_F16
-  int vt_T;                         // EPI_VT: rows per clip
+  int vt_T;                         // EPI_VT / EPI_KVH: rows per clip
+  int kv_width;                     // EPI_KVH: model width dt (N = 2 dt); element (clip b, frame t; K|V, head, dim) goes to
+                                    //   C[((b * 2 + kv) * heads + head) * vt_T * 64 + t * 64 + dim] as f16
   int xcd_swizzle;                  // all column tiles of a row tile on one XCD
 };
-constexpr int HGEMM_F16 = 0, HGEMM_RES = 1, HGEMM_VT = 2, HGEMM_TAB = 3;
+constexpr int HGEMM_F16 = 0, HGEMM_RES = 1, HGEMM_VT = 2, HGEMM_TAB = 3, HGEMM_KVH = 4;
 hipError_t gemm_hh(const HGemmArgs& g, int epi, int batch, hipStream_t s);
 hipError_t layernorm_f16out(const float* x, const float* gamma, const float* beta, void* y, long rows, int D, hipStream_t s);
 hipError_t attn_encoder_h(const void* qk, const void* vt, void* out, int B, int T, int D, int heads, hipStream_t s);

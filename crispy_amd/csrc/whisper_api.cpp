@@ -31,6 +31,7 @@ struct EncLayer {
 struct DecLayer {
   const float *ln1_w, *ln1_b, *qkv_w, *qkv_b, *out_w, *out_b;
   const float *lnx_w, *lnx_b, *xq_w, *xq_b, *xkv_w, *xkv_b, *xout_w, *xout_b;
+  const void* xkv_wh = nullptr;              // f16 copy of the fused cross K|V projection (precision mode 1)
   const float *ln2_w, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
   // LayerNorm folded into the consuming projection (decode steps with <= 64 clips): gamma-scaled weights, their row
   // sums and beta.W + bias (GemmArgs::ln_s / ln_c)
@@ -451,6 +452,8 @@ int crispy_asr_set_precision(crispy_asr* h, int mode) try {
       if (rc == CRISPY_OK) rc = half_copy(L.fc1_w, 4 * d * d, &L.fc1_wh);
       if (rc == CRISPY_OK) rc = half_copy(L.fc2_w, 4 * d * d, &L.fc2_wh);
     }
+    for (DecLayer& L : h->dec)
+      if (rc == CRISPY_OK) rc = half_copy(L.xkv_w, 2 * (size_t)h->hp.n_text_state * h->hp.n_text_state, &L.xkv_wh);
     if (rc != CRISPY_OK) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
   }
@@ -786,6 +789,23 @@ Special special_tokens(const crispy_asr* h) { return vocab_specials(h->hp.n_voca
 // cross K | V of every layer, once per window (f16 mode: the decode steps stream an f16 copy of it)
 int compute_cross_kv(crispy_asr* h, const float* d_enc, int batch, hipStream_t s) {
   const int dt = h->hp.n_text_state, Tn = h->hp.n_audio_ctx;
+  if (h->enc_precision == 1 && h->dec[0].xkv_wh) {
+    // The reference's precision: the projection itself on the f16 matrix cores (encoder output and weights rounded
+    // to f16, f32 accumulation), written as f16 head-major straight from the epilogue.  (It used to run as an f32 GEMM
+    // followed by a conversion pass: 3.9 + 0.8 ms per layer at 256 Whisper-base clips, more than the whole encoder.)
+    const long n = (long)batch * Tn * dt;
+    _Float16* enc_h = reinterpret_cast<_Float16*>(h->d_xkv);       // the f32 cross K|V buffer is unused in this mode
+    HIP_TRY(convert_f32_to_f16(d_enc, enc_h, n, s));
+    for (size_t l = 0; l < h->dec.size(); ++l) {
+      HGemmArgs g{};
+      g.A = enc_h; g.lda = dt; g.W = reinterpret_cast<const _Float16*>(h->dec[l].xkv_wh); g.ldw = dt;
+      g.C = reinterpret_cast<_Float16*>(h->d_xkv_h) + l * (size_t)batch * Tn * 2 * dt;
+      g.bias = h->dec[l].xkv_b; g.M = batch * Tn; g.N = 2 * dt; g.K = dt; g.vt_T = Tn; g.kv_width = dt;
+      g.xcd_swizzle = h->xcd_swizzle;
+      HIP_TRY(gemm_hh(g, HGEMM_KVH, 1, s));
+    }
+    return CRISPY_OK;
+  }
   for (size_t l = 0; l < h->dec.size(); ++l) {
     float* xkv = h->d_xkv + l * (size_t)batch * Tn * 2 * dt;
     // head-major store: per clip [K | V][head][Tn][64], so the decode-step attention streams contiguous runs

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void layernorm_h_kernel(const float* __restric
   for (int q = 0; q < PER; ++q) yr[lane + 64 * q] = (_Float16)((v[q] - mean) * rstd * gm[q] + bt[q]);
 }
 
-enum { EPI_F16 = 0, EPI_RES = 1, EPI_VT = 2, EPI_TAB = 3 };
+enum { EPI_F16 = 0, EPI_RES = 1, EPI_VT = 2, EPI_TAB = 3, EPI_KVH = 4 };
 
 // one k-block (32) of a wave's 64 x 64 output tile from the staged operand tiles
 template <int EPI>
@@ -335,7 +335,25 @@ __device__ __forceinline__ void hd_epilogue(const HGemmArgs& g, f32x16 (&acc)[2]
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- read back row-contiguous and store ----
-    if (EPI == EPI_F16) {
+    if (EPI == EPI_KVH) {
+      // cross K | V, head-major: this wave's 64 columns are exactly one head of K or of V (wn and the tile origin are
+      // multiples of 64), a row is one frame of one clip -> 128 contiguous bytes at [clip][K|V][head][frame][64]
+      _Float16* __restrict__ C = reinterpret_cast<_Float16*>(g.C);
+      const int c8 = (lane & 7) * 8;
+      const int ncol = n0 + wn, kv = ncol / g.kv_width, head = (ncol - kv * g.kv_width) >> 6, heads = g.kv_width >> 6;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int row = (lane >> 3) + 8 * p;
+        const float4 x0 = *reinterpret_cast<const float4*>(T + row * EP_LD + c8);
+        const float4 x1 = *reinterpret_cast<const float4*>(T + row * EP_LD + c8 + 4);
+        const half4 h0 = to_half4(x0.x, x0.y, x0.z, x0.w), h1 = to_half4(x1.x, x1.y, x1.z, x1.w);
+        const half8 hv = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+        const int m = m0 + wm + 32 * i + row;
+        const int clip = m / g.vt_T, t = m - clip * g.vt_T;
+        if (m < g.M && ncol < g.N)
+          *reinterpret_cast<half8*>(C + ((((long)clip * 2 + kv) * heads + head) * g.vt_T + t) * 64 + c8) = hv;
+      }
+    } else if (EPI == EPI_F16) {
       _Float16* __restrict__ C = reinterpret_cast<_Float16*>(g.C) + (long)bz * g.strideC + (long)(m0 + wm + 32 * i) * g.ldc + (n0 + wn);
       const int c8 = (lane & 7) * 8;                            // 8 lanes per row, 8 columns (16 bytes of f16) each
 #pragma unroll
@@ -684,12 +702,13 @@ hipError_t gemm_hh(const HGemmArgs& g, int epi, int batch, hipStream_t s) {
   dim3 grid(nt, mt, batch);
   if (a.xcd_swizzle) grid.y = (unsigned)(((mt + 7) / 8) * 8);      // whole groups of eight row tiles
   static const bool direct = [] { const char* e = std::getenv("CRISPY_ASR_GEMM"); return !(e && e[0] == 'r'); }();   // "regs": the register-staged loop
-  if (direct) {
+  if (direct || epi == EPI_KVH) {
     switch (epi) {
       case EPI_F16: hipLaunchKernelGGL(gemm_hd_kernel<EPI_F16>, grid, dim3(256), 0, s, a); break;
       case EPI_RES: hipLaunchKernelGGL(gemm_hd_kernel<EPI_RES>, grid, dim3(256), 0, s, a); break;
       case EPI_VT: hipLaunchKernelGGL(gemm_hd_kernel<EPI_VT>, grid, dim3(256), 0, s, a); break;
       case EPI_TAB: hipLaunchKernelGGL(gemm_hd_kernel<EPI_TAB>, grid, dim3(256), 0, s, a); break;
+      case EPI_KVH: hipLaunchKernelGGL(gemm_hd_kernel<EPI_KVH>, grid, dim3(256), 0, s, a); break;
       default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
