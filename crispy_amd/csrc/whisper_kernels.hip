@@ -22,6 +22,7 @@ namespace crispy {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int GB_M = 128, GB_N = 128, GB_K = 16, GB_LD = 20;  // LDS row stride 20 floats: conflict-free b128 reads
 
@@ -164,13 +165,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
 // (24 for N = 384).  W is re-read per row block from L2.
 // ---------------------------------------------------------------------------------------------
 constexpr int SK_PF = 3;                       // K chunks (32 wide) in flight per wave
+constexpr int SK_WAVE_LDS = 2048;              // floats of LDS per wave (two 4 KB operand chunks; later the 32 x 33 partial tile)
+__device__ __forceinline__ void sk_wave_sync() {     // LDS traffic of one wave: in order, so a fence for the compiler and a wait
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0)
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+#ifndef SK_NW_LONG
+#define SK_NW_LONG 16                          // waves (K splits) of the long-K variant
+#endif
 // LN / GELU / RES are compile-time so that the epilogue operands (ln_s, ln_c or bias, residual) can be requested
 // up front, next to the first K chunks, from clamped (always valid) addresses: with run-time flags every one of them
 // sat behind its own branch in the epilogue and cost a serialized L2 round trip after the barrier.
-template <bool LN, bool GELU, bool RES>
-__global__ __launch_bounds__(256) void gemm_skinny_f32_kernel(GemmArgs g) {
-  __shared__ float red[4][32 * 33];
-  __shared__ float rstat[4][32][2];
+// NW = waves of a workgroup = ways K is split.  4 for the K = d projections; 16 for the MLP's second GEMM (K = 4 d):
+// with 4 waves that one ran four rounds of the memory latency on 24 workgroups (19.5 us at Whisper-tiny, three times
+// the other projections), with 16 it runs one like the rest.
+template <bool LN, bool GELU, bool RES, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_skinny_f32_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float sk_smem[];
+  // per wave 8 KB: the transposition area of its operand chunks (W, then A: 32 rows x 8 sixteen-byte pieces each); the
+  // wave's partial tile replaces it after the K loop
+  float (*red)[SK_WAVE_LDS] = reinterpret_cast<float (*)[SK_WAVE_LDS]>(sk_smem);
+  float (*rstat)[32][2] = reinterpret_cast<float (*)[32][2]>(sk_smem + NW * SK_WAVE_LDS);
+  constexpr int RP = 2 * NW, NQ = 32 / RP;     // epilogue: RP rows per pass, NQ passes
+  constexpr int PF = NW > 8 ? 2 : SK_PF;       // 16 waves: 128 registers per lane, two chunks in flight
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, lh = lane >> 5;
   const int n0 = blockIdx.x * 32;
@@ -178,67 +197,82 @@ __global__ __launch_bounds__(256) void gemm_skinny_f32_kernel(GemmArgs g) {
   const float* __restrict__ A = g.A;
   const float* __restrict__ W = g.W;
   const bool second = g.C2 && n0 >= g.n_split;      // split output: a workgroup's 32 columns go to one destination
-  const int kper = g.K / 4;                 // K range of this wave (multiple of 32)
+  const int kper = g.K / NW;                // K range of this wave (multiple of 32)
   const int kbeg = wave * kper;
-  const int n = min(n0 + li, g.N - 1);
-  const float* wrow = W + (long)n * g.ldw + kbeg + 16 * lh;
-  const float* arow = A + (long)min(mb + li, g.M - 1) * g.lda + kbeg + 16 * lh;
+  // Global loads are row-coalesced: 8 lanes take the 8 sixteen-byte pieces of one row's 32-wide K chunk (one 128-byte
+  // line), an instruction covers 8 rows, four cover the chunk.  (Loading in MFMA operand order -- lane = row, 16
+  // contiguous floats -- made every instruction touch 64 lines for 16 bytes each and the texture addresser, not the
+  // memory latency, set the pace: 19.5 us for K = 1536 on 24 workgroups.)  The chunk goes through the wave's LDS area
+  // to reach operand order; piece c of row r sits in slot c ^ (r & 7), so both the linear writes and the
+  // row-per-lane 16-byte reads are conflict-free.  Operand registers, MFMA order and results are those of the
+  // direct-load form.
+  const int lr = lane >> 3, lc = (lane & 7) ^ lr;
+  const float* wsrc[4];
+  const float* asrc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    wsrc[j] = W + (long)min(n0 + lr + 8 * j, g.N - 1) * g.ldw + kbeg + 4 * lc;
+    asrc[j] = A + (long)min(mb + lr + 8 * j, g.M - 1) * g.lda + kbeg + 4 * lc;   // rows >= M: clamped row, never stored
+  }
+  f32x4* stw = reinterpret_cast<f32x4*>(sk_smem + wave * SK_WAVE_LDS);
+  f32x4* sta = stw + 256;
+  int rslot[4];                              // slots of this lane's operand pieces 4 lh + q of row li
+#pragma unroll
+  for (int q = 0; q < 4; ++q) rslot[q] = li * 8 + ((4 * lh + q) ^ (li & 7));
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   float s0 = 0.f, q0 = 0.f;                 // row sum / sum of squares of this lane's share (LN folding)
-  float4 w[SK_PF][4], a[SK_PF][4];
-#pragma unroll
-  for (int st = 0; st < SK_PF; ++st)
-    if (32 * st < kper) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        w[st][q] = *reinterpret_cast<const float4*>(wrow + 32 * st + 4 * q);
-        a[st][q] = *reinterpret_cast<const float4*>(arow + 32 * st + 4 * q);   // rows >= M: clamped row, never stored
-      }
-    }
+  // the chunks in flight.  They are clang vectors, not HIP's float4: copies of the float4 struct between these
+  // arrays and LDS kept all six arrays in scratch (400 bytes per lane), whatever the loop structure
+  f32x4 w0[4], a0[4], w1[4], a1[4], w2[4], a2[4];
+#define SK_REQUEST(WR, AR, KO)                                            \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j) {                         \
+    WR[j] = *reinterpret_cast<const f32x4*>(wsrc[j] + (KO));             \
+    AR[j] = *reinterpret_cast<const f32x4*>(asrc[j] + (KO));             \
+  }
+  SK_REQUEST(w0, a0, 0)
+  if (PF > 1 && 32 < kper) { SK_REQUEST(w1, a1, 32) }
+  if (PF > 2 && 64 < kper) { SK_REQUEST(w2, a2, 64) }
   // epilogue operands of this thread's outputs: column ec of rows (tid >> 5) + 8 q
   const int ec = min(tid & 31, g.N - 1 - n0), enn = n0 + ec;
-  float e_s = 0.f, e_c = 0.f, e_res[4] = {0.f, 0.f, 0.f, 0.f};
+  float e_s = 0.f, e_c = 0.f, e_res[NQ];
   if (LN) { e_s = g.ln_s[enn]; e_c = g.ln_c[enn]; }
   else if (g.bias) e_c = g.bias[enn];
   if (RES) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) e_res[q] = g.residual[(long)min(mb + (tid >> 5) + 8 * q, g.M - 1) * g.ldr + enn];
+    for (int q = 0; q < NQ; ++q) e_res[q] = g.residual[(long)min(mb + (tid >> 5) + RP * q, g.M - 1) * g.ldr + enn];
   }
   const long coff = g.c_off_dev ? (long)(*g.c_off_dev) * g.c_off_scale : 0L;
   float* __restrict__ C = second ? g.C2 + coff - g.n_split : g.C + (g.C2 ? 0L : coff);
   const long ldc = second ? g.ldc2 : g.ldc;
-  for (int kc0 = 0; kc0 < kper; kc0 += 32 * SK_PF) {
-#pragma unroll
-    for (int st = 0; st < SK_PF; ++st) {
-      const int kc = kc0 + 32 * st;
-      if (kc < kper) {
-        float4 cw[4], ca[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { cw[q] = w[st][q]; ca[q] = a[st][q]; }
-        if (kc + 32 * SK_PF < kper) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            w[st][q] = *reinterpret_cast<const float4*>(wrow + kc + 32 * SK_PF + 4 * q);
-            a[st][q] = *reinterpret_cast<const float4*>(arow + kc + 32 * SK_PF + 4 * q);
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float wv[4] = {cw[q].x, cw[q].y, cw[q].z, cw[q].w};
-          const float xv[4] = {ca[q].x, ca[q].y, ca[q].z, ca[q].w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[e], wv[e], acc, 0, 0, 0);
-            if (LN) { s0 += xv[e]; q0 = fmaf(xv[e], xv[e], q0); }
-          }
-        }
-      }
-    }
+  // one chunk: registers -> LDS, request the chunk PF ahead into the same registers, LDS -> operand order, 16 MFMAs
+#define SK_CHUNK(WR, AR, KC)                                                                        \
+  {                                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) { stw[64 * j + lane] = WR[j]; sta[64 * j + lane] = AR[j]; } \
+    if ((KC) + 32 * PF < kper) { SK_REQUEST(WR, AR, (KC) + 32 * PF) }                               \
+    sk_wave_sync();                                                                                 \
+    f32x4 cw[4], ca[4];                                                                            \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) { cw[q] = stw[rslot[q]]; ca[q] = sta[rslot[q]]; } \
+    sk_wave_sync();                                                                                 \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                 \
+      const float wv[4] = {cw[q].x, cw[q].y, cw[q].z, cw[q].w};                                     \
+      const float xv[4] = {ca[q].x, ca[q].y, ca[q].z, ca[q].w};                                     \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                               \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[e], wv[e], acc, 0, 0, 0);                     \
+        if (LN) { s0 += xv[e]; q0 = fmaf(xv[e], xv[e], q0); }                                       \
+      }                                                                                             \
+    }                                                                                               \
   }
+  for (int kc0 = 0; kc0 < kper; kc0 += 32 * PF) {
+    SK_CHUNK(w0, a0, kc0)
+    if (PF > 1 && kc0 + 32 < kper) SK_CHUNK(w1, a1, kc0 + 32)
+    if (PF > 2 && kc0 + 64 < kper) SK_CHUNK(w2, a2, kc0 + 64)
+  }
+#undef SK_CHUNK
+#undef SK_REQUEST
 #pragma unroll
-  for (int r = 0; r < 16; ++r) red[wave][acc_row(r, lane) * 33 + li] = acc[r];
+  for (int r = 0; r < 16; ++r) red[wave][acc_row(r, lane) * 33 + li] = acc[r];     // own area: after the wave's last reads
   if (LN) {
     // the two half-waves hold the two 16-wide halves of every 32-wide K chunk of row li
     s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);
@@ -246,13 +280,16 @@ __global__ __launch_bounds__(256) void gemm_skinny_f32_kernel(GemmArgs g) {
   }
   __syncthreads();
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int ml = (tid >> 5) + 8 * q;          // row inside this 32-row block
+  for (int q = 0; q < NQ; ++q) {
+    const int ml = (tid >> 5) + RP * q;         // row inside this 32-row block
     const int m = mb + ml;
-    float v = red[0][ml * 33 + ec] + red[1][ml * 33 + ec] + red[2][ml * 33 + ec] + red[3][ml * 33 + ec];
+    float v = red[0][ml * 33 + ec];
+#pragma unroll
+    for (int w2 = 1; w2 < NW; ++w2) v += red[w2][ml * 33 + ec];      // fixed order: wave 0, 1, ...
     if (LN) {
-      const float sum = rstat[0][ml][0] + rstat[1][ml][0] + rstat[2][ml][0] + rstat[3][ml][0];
-      const float sq = rstat[0][ml][1] + rstat[1][ml][1] + rstat[2][ml][1] + rstat[3][ml][1];
+      float sum = rstat[0][ml][0], sq = rstat[0][ml][1];
+#pragma unroll
+      for (int w2 = 1; w2 < NW; ++w2) { sum += rstat[w2][ml][0]; sq += rstat[w2][ml][1]; }
       const float mean = sum / (float)g.K;
       const float var = fmaxf(sq / (float)g.K - mean * mean, 0.f);
       const float rstd = 1.f / sqrtf(var + 1e-5f);
@@ -916,17 +953,28 @@ hipError_t gemm_f32_nt(const GemmArgs& g, int batch, hipStream_t s) {
     return hipGetLastError();
   }
   if (batch == 1 && g.M <= SKINNY_MAX_M && g.K % 128 == 0 && !g.rowtab && !g.tiled) {   // one decode step: latency-bound shape
-    const dim3 grid((g.N + 31) / 32, (g.M + 31) / 32), block(256);
+    const dim3 grid((g.N + 31) / 32, (g.M + 31) / 32);
     const int kind = (g.ln_s ? 4 : 0) | (g.gelu ? 2 : 0) | (g.residual ? 1 : 0);
+    if (kind == 1 && g.K >= 1024 && g.K % (32 * SK_NW_LONG) == 0) {      // fc2: K = 4 d
+      constexpr size_t smem = SK_NW_LONG * (SK_WAVE_LDS + 64) * sizeof(float);
+      static const hipError_t attr = hipFuncSetAttribute(
+          reinterpret_cast<const void*>(gemm_skinny_f32_kernel<false, false, true, SK_NW_LONG>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (attr != hipSuccess) return attr;
+      hipLaunchKernelGGL((gemm_skinny_f32_kernel<false, false, true, SK_NW_LONG>), grid, dim3(64 * SK_NW_LONG), smem, s, g);
+      return hipGetLastError();
+    }
+    const dim3 block(256);
+    constexpr size_t smem = 4 * (SK_WAVE_LDS + 64) * sizeof(float);
     switch (kind) {
-      case 0: hipLaunchKernelGGL((gemm_skinny_f32_kernel<false, false, false>), grid, block, 0, s, g); break;
-      case 1: hipLaunchKernelGGL((gemm_skinny_f32_kernel<false, false, true>), grid, block, 0, s, g); break;
-      case 2: hipLaunchKernelGGL((gemm_skinny_f32_kernel<false, true, false>), grid, block, 0, s, g); break;
-      case 3: hipLaunchKernelGGL((gemm_skinny_f32_kernel<false, true, true>), grid, block, 0, s, g); break;
-      case 4: hipLaunchKernelGGL((gemm_skinny_f32_kernel<true, false, false>), grid, block, 0, s, g); break;
-      case 5: hipLaunchKernelGGL((gemm_skinny_f32_kernel<true, false, true>), grid, block, 0, s, g); break;
-      case 6: hipLaunchKernelGGL((gemm_skinny_f32_kernel<true, true, false>), grid, block, 0, s, g); break;
-      default: hipLaunchKernelGGL((gemm_skinny_f32_kernel<true, true, true>), grid, block, 0, s, g); break;
+      case 0: hipLaunchKernelGGL((gemm_skinny_f32_kernel<false, false, false, 4>), grid, block, smem, s, g); break;
+      case 1: hipLaunchKernelGGL((gemm_skinny_f32_kernel<false, false, true, 4>), grid, block, smem, s, g); break;
+      case 2: hipLaunchKernelGGL((gemm_skinny_f32_kernel<false, true, false, 4>), grid, block, smem, s, g); break;
+      case 3: hipLaunchKernelGGL((gemm_skinny_f32_kernel<false, true, true, 4>), grid, block, smem, s, g); break;
+      case 4: hipLaunchKernelGGL((gemm_skinny_f32_kernel<true, false, false, 4>), grid, block, smem, s, g); break;
+      case 5: hipLaunchKernelGGL((gemm_skinny_f32_kernel<true, false, true, 4>), grid, block, smem, s, g); break;
+      case 6: hipLaunchKernelGGL((gemm_skinny_f32_kernel<true, true, false, 4>), grid, block, smem, s, g); break;
+      default: hipLaunchKernelGGL((gemm_skinny_f32_kernel<true, true, true, 4>), grid, block, smem, s, g); break;
     }
     return hipGetLastError();
   }

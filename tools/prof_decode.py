@@ -4,6 +4,7 @@ import numpy as np, torch
 from crispy_amd.whisper_weights import HParams, synthetic_whisper_weights
 from crispy_amd.asr import WhisperModel
 hp = HParams.tiny(); m = WhisperModel(hp, synthetic_whisper_weights(hp, 0))
+m.set_precision(int(os.environ.get("PREC", 0)))
 B = int(os.environ.get("B", 64))
 enc = torch.randn(B, 1500, 384, device="cuda")
 torch.cuda.synchronize()
