@@ -759,6 +759,98 @@ __global__ __launch_bounds__(64 * AD_WAVES) void attn_dec_kernel(const float* __
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Cross-attention of a decode step over an f16 K|V (precision mode 1), <= 1536 keys: every byte is requested before
+// anything is computed.  A (clip, head) has 1500 keys x 128 bytes of K and as much of V; its 16 waves take 94 keys
+// each -- 12 KB of K and 12 KB of V, which is 48 + 48 registers per lane.  So a wave issues its 24 sixteen-byte loads
+// per lane back to back (8 lanes per key row, 8 keys per instruction: 1 KB per instruction), and the kernel is one
+// round trip to HBM with the whole K|V of the layer in flight, instead of the generic kernel's K pass, softmax, V pass
+// with 4 KB per wave in flight.  V does not wait for the scores; nothing goes through LDS but the 16 partial results.
+// Same partitioning and merge as attn_dec_kernel (per-wave max / sum / P.V merged by wave 0).
+// ---------------------------------------------------------------------------------------------
+constexpr int ADX_SLOTS = 12;                 // key slots of 8 keys per wave: 16 waves x 96 keys >= 1536
+__global__ __launch_bounds__(64 * AD_WAVES) void attn_dec_x16_kernel(const float* __restrict__ q, long ldq,
+                                                       const _Float16* __restrict__ kv, long kv_batch_stride,
+                                                       long ldkv, long head_stride, long koff, long voff, int n_keys,
+                                                       float* __restrict__ out, long ldo) {
+  typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+  __shared__ __attribute__((aligned(16))) float part_o[AD_WAVES][64];
+  __shared__ float part_m[AD_WAVES], part_l[AD_WAVES];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int c = lane & 7, r = lane >> 3;
+  const _Float16* Kb = kv + (long)b * kv_batch_stride + koff + h * head_stride + 8 * c;
+  const _Float16* Vb = kv + (long)b * kv_batch_stride + voff + h * head_stride + 8 * c;
+  const int per = (n_keys + AD_WAVES - 1) / AD_WAVES;
+  const int k_lo = wave * per, k_hi = min(n_keys, k_lo + per);
+  const int k_last = max(k_hi - 1, 0);          // clamp target of the slots past the partition (weight 0)
+  half8 kr[ADX_SLOTS], vr[ADX_SLOTS];
+#pragma unroll
+  for (int i = 0; i < ADX_SLOTS; ++i) kr[i] = *reinterpret_cast<const half8*>(Kb + (long)min(k_lo + 8 * i + r, k_last) * ldkv);
+#pragma unroll
+  for (int i = 0; i < ADX_SLOTS; ++i) vr[i] = *reinterpret_cast<const half8*>(Vb + (long)min(k_lo + 8 * i + r, k_last) * ldkv);
+  __builtin_amdgcn_sched_barrier(0);            // the scheduler would otherwise keep 9 loads in flight and interleave the rest
+  float qv[8];
+  {
+    const float4 q0 = *reinterpret_cast<const float4*>(q + (long)b * ldq + h * 64 + 8 * c);
+    const float4 q1 = *reinterpret_cast<const float4*>(q + (long)b * ldq + h * 64 + 8 * c + 4);
+    qv[0] = q0.x * 0.125f; qv[1] = q0.y * 0.125f; qv[2] = q0.z * 0.125f; qv[3] = q0.w * 0.125f;
+    qv[4] = q1.x * 0.125f; qv[5] = q1.y * 0.125f; qv[6] = q1.z * 0.125f; qv[7] = q1.w * 0.125f;
+  }
+  float sc[ADX_SLOTS];
+  float mloc = -1e30f;
+#pragma unroll
+  for (int i = 0; i < ADX_SLOTS; ++i) {
+    float v = (float)kr[i][0] * qv[0];
+#pragma unroll
+    for (int e = 1; e < 8; ++e) v = fmaf((float)kr[i][e], qv[e], v);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));    // lanes ^ 1
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));    // lanes ^ 2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));   // the other quad of the 8
+    const bool valid = k_lo + 8 * i + r < k_hi;
+    sc[i] = valid ? v : -1e30f;
+    mloc = fmaxf(mloc, sc[i]);
+  }
+#pragma unroll
+  for (int off = 8; off <= 32; off <<= 1) mloc = fmaxf(mloc, __shfl_xor(mloc, off, 64));
+  float lsum = 0.f;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int i = 0; i < ADX_SLOTS; ++i) {
+    const float pw = k_lo + 8 * i + r < k_hi ? __expf(sc[i] - mloc) : 0.f;
+    lsum += pw;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = fmaf(pw, (float)vr[i][e], acc[e]);
+  }
+#pragma unroll
+  for (int off = 8; off <= 32; off <<= 1) {
+    lsum += __shfl_xor(lsum, off, 64);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += __shfl_xor(acc[e], off, 64);
+  }
+  if (r == 0) {
+    *reinterpret_cast<float4*>(&part_o[wave][8 * c]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *reinterpret_cast<float4*>(&part_o[wave][8 * c + 4]) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  }
+  if (lane == 0) { part_m[wave] = mloc; part_l[wave] = lsum; }
+  __syncthreads();
+  if (wave == 0) {
+    float m = part_m[0];
+#pragma unroll
+    for (int w = 1; w < AD_WAVES; ++w) m = fmaxf(m, part_m[w]);
+    float o = 0.f, l = 0.f;
+#pragma unroll
+    for (int w = 0; w < AD_WAVES; ++w) {
+      const float scl = __expf(part_m[w] - m);   // empty partitions have m = -1e30 -> scale 0
+      o = fmaf(part_o[w][lane], scl, o);
+      l = fmaf(part_l[w], scl, l);
+    }
+    out[(long)b * ldo + h * 64 + lane] = o / l;
+  }
+}
+
 // token + positional embedding for one decode step: x[b][:] = tok_emb[token[b]] + pos_emb[pos]
 __global__ __launch_bounds__(256) void embed_kernel(const int* __restrict__ tokens, const float* __restrict__ tok_emb,
                                                     const float* __restrict__ pos_emb, int pos,
@@ -1009,6 +1101,11 @@ hipError_t attn_decoder_f32(const float* q, long ldq, const float* kv, long kv_b
 hipError_t attn_decoder_kv16(const float* q, long ldq, const void* kv, long kv_batch_stride, long ldkv, long head_stride,
                              long koff, long voff, int n_keys_base, const int* pos_dev, float* out, long ldo, int B, int heads,
                              hipStream_t s) {
+  if (!pos_dev && n_keys_base <= AD_WAVES * 8 * ADX_SLOTS && ldkv == 64 && AD_WAVES == 16) {   // cross-attention: all of K|V requested up front
+    hipLaunchKernelGGL(attn_dec_x16_kernel, dim3(heads, B), dim3(64 * AD_WAVES), 0, s, q, ldq,
+                       reinterpret_cast<const _Float16*>(kv), kv_batch_stride, ldkv, head_stride, koff, voff, n_keys_base, out, ldo);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(attn_dec_kernel<_Float16>, dim3(heads, B), dim3(64 * AD_WAVES), 0, s, q, ldq,
                      reinterpret_cast<const _Float16*>(kv), kv_batch_stride, ldkv, head_stride, koff, voff, n_keys_base, pos_dev, out, ldo);
   return hipGetLastError();
