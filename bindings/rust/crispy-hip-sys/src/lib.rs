@@ -157,6 +157,7 @@ extern "C" {
     pub fn crispy_asr_encode_device(h: *mut crispy_asr, d_mel_t: *const c_float, batch: c_int, d_out: *mut c_float, hip_stream: *mut c_void) -> c_int;
     pub fn crispy_asr_synchronize(h: *mut crispy_asr) -> c_int;
     pub fn crispy_asr_set_precision(h: *mut crispy_asr, mode: c_int) -> c_int;
+    pub fn crispy_asr_stage_logits_device(h: *mut crispy_asr, d_x: *const f32, batch: c_int, d_logits: *mut f32) -> c_int;
     pub fn crispy_asr_set_suppress(h: *mut crispy_asr, ids: *const c_int, n: c_int, first_only: c_int) -> c_int;
     pub fn crispy_asr_decode_greedy_device(h: *mut crispy_asr, d_enc: *const c_float, batch: c_int, prompt: *const c_int, n_prompt: c_int, max_new: c_int, tokens_out: *mut c_int, n_out: *mut c_int, logits_out: *mut c_float) -> c_int;
     pub fn crispy_asr_decode_greedy_lang_device(h: *mut crispy_asr, d_enc: *const c_float, batch: c_int, prompt: *const c_int, n_prompt: c_int, lang_tokens: *const c_int, max_new: c_int, tokens_out: *mut c_int, n_out: *mut c_int, logits_out: *mut c_float) -> c_int;

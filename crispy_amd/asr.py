@@ -135,6 +135,11 @@ class WhisperModel:
         the encoder GEMMs (whisper.cpp's ggml numerics)."""
         N.check(N.lib().crispy_asr_set_precision(self._h, int(mode)))
 
+    def stage_logits_device(self, d_x: int, batch: int, d_logits: int):
+        """Final LayerNorm + vocabulary projection of d_x [batch][n_text_state] into d_logits [batch][n_vocab] (device
+        pointers), in the current precision mode: the last block of a decoder step, for parity tests."""
+        N.check(N.lib().crispy_asr_stage_logits_device(self._h, d_x, batch, d_logits))
+
     def set_suppress(self, ids, first_only: bool = False):
         a = np.ascontiguousarray(ids, dtype=np.int32)
         N.check(N.lib().crispy_asr_set_suppress(self._h, a.ctypes.data, a.size, int(first_only)))

@@ -92,6 +92,11 @@ hipError_t gemm_hh(const HGemmArgs& g, int epi, int batch, hipStream_t s);
 hipError_t layernorm_f16out(const float* x, const float* gamma, const float* beta, void* y, long rows, int D, hipStream_t s);
 hipError_t attn_encoder_h(const void* qk, const void* vt, void* out, int B, int T, int D, int heads, hipStream_t s);
 hipError_t convert_rows_f32_to_f16(const float* src, long lds, void* dst, long ldd, int cols, long rows, hipStream_t s);
+// ---- precision mode 1, decode step (whisper_dec_f16.hip): vocabulary projection over a packed f16 embedding ----
+size_t vocab_f16_packed_bytes(int V, int K);
+hipError_t pack_vocab_f16(const float* E, void* dst, int V, int K, hipStream_t s);
+// logits[M][ldc] (f32) = x[M][ldx] (f16) . E^T, E packed by pack_vocab_f16; K in {384, 512, 768, 1024, 1280}
+hipError_t vocab_f16(const void* x, long ldx, const void* Ep, float* C, long ldc, int M, int N, int K, hipStream_t s);
 hipError_t layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, long rows, int D, hipStream_t s);
 hipError_t attn_encoder_f32(const float* qkv, float* out, int B, int T, int D, int heads, hipStream_t s);
 hipError_t attn_decoder_f32(const float* q, long ldq, const float* kv, long kv_batch_stride, long ldkv, long head_stride,

@@ -51,6 +51,7 @@ struct crispy_asr {
   // resolved pointers
   const float *conv1_w = nullptr, *conv1_b = nullptr, *conv2_w = nullptr, *conv2_b = nullptr, *enc_pos = nullptr;
   const float *ln_post_w = nullptr, *ln_post_b = nullptr;
+  const void* tok_emb_hp = nullptr;          // token embedding as f16 in MFMA operand order (precision mode 1: logits)
   const void* conv2_wh = nullptr;            // f16 copy of the reordered conv2 kernel (precision mode 1)
   const void* conv1_wh = nullptr;            // f16 conv1 kernel, rows zero-padded to conv1_kp columns
   int conv1_kp = 0;
@@ -455,6 +456,15 @@ int crispy_asr_set_precision(crispy_asr* h, int mode) try {
     for (DecLayer& L : h->dec)
       if (rc == CRISPY_OK) rc = half_copy(L.xkv_w, 2 * (size_t)h->hp.n_text_state * h->hp.n_text_state, &L.xkv_wh);
     if (rc != CRISPY_OK) return rc;
+    const int dt = h->hp.n_text_state;
+    if (dt == 384 || dt == 512 || dt == 768 || dt == 1024 || dt == 1280) {    // the widths the f16 logits kernel is built for
+      // token embedding for the logits: f16 (as the model file holds it), packed in MFMA operand order
+      void* p = nullptr;
+      HIP_TRY(hipMalloc(&p, vocab_f16_packed_bytes(h->hp.n_vocab, dt)));
+      h->derived.push_back(reinterpret_cast<float*>(p));
+      HIP_TRY(pack_vocab_f16(h->tok_emb, p, h->hp.n_vocab, dt, h->stream));
+      h->tok_emb_hp = p;
+    }
     HIP_TRY(hipStreamSynchronize(h->stream));
   }
   if (h->enc_precision != mode) {   // the captured decode steps bake the cross-attention kernel in
@@ -662,13 +672,37 @@ int reserve_dec(crispy_asr* h, int batch, int max_tokens) {
   return CRISPY_OK;
 }
 
+// the last block of a decoder step: final LayerNorm and vocabulary projection of h->d_dx into h->d_logits
+int decoder_logits(crispy_asr* h, int batch, hipStream_t s) {
+  const int dt = h->hp.n_text_state, V = h->hp.n_vocab;
+  const bool fold = batch <= SKINNY_MAX_M && dt % 128 == 0;
+  if (h->enc_precision == 1 && h->tok_emb_hp) {
+    // the reference's arithmetic: final LayerNorm in f32, rounded to f16, against the f16 embedding, f32 accumulation
+    HIP_TRY(layernorm_f16out(h->d_dx, h->dec_ln_w, h->dec_ln_b, h->d_dxn, batch, dt, s));
+    HIP_TRY(vocab_f16(h->d_dxn, dt, h->tok_emb_hp, h->d_logits, V, batch, V, dt, s));
+  } else {
+    // vocabulary projection: above 64 clips the 128 x 128 tiled kernel (behind a LayerNorm launch) beats the skinny
+    // kernel's 32-row blocks, which re-read the 80 MB embedding once per block (-3 % / -5 % per step at 128 / 512 clips)
+    if (fold && batch <= 64) {
+      GemmArgs g = gemm(h->d_dx, dt, h->logit_lw, dt, h->d_logits, V, nullptr, batch, V, dt);
+      g.ln_s = h->logit_ls; g.ln_c = h->logit_lc;
+      HIP_TRY(gemm_f32_nt(g, 1, s));
+    } else {
+      HIP_TRY(layernorm_f32(h->d_dx, h->dec_ln_w, h->dec_ln_b, h->d_dxn, batch, dt, s));
+      GemmArgs g = gemm(h->d_dxn, dt, h->tok_emb, dt, h->d_logits, V, nullptr, batch, V, dt);
+      g.tiled = fold ? 1 : 0;
+      HIP_TRY(gemm_f32_nt(g, 1, s));
+    }
+  }
+  return CRISPY_OK;
+}
+
 // one decoder step for all clips: token ids in h->d_tok; leaves logits in h->d_logits.
 // dev_pos = false: the position is the host value `pos` (prompt tokens).
 // dev_pos = true : the position is read from h->d_counters[0] by the kernels, so the identical launch
 //                  sequence can be captured once in a hipGraph and replayed for every generated token.
 int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logits, hipStream_t s) {
-  const int dt = h->hp.n_text_state, H = h->hp.n_text_head, Tn = h->hp.n_audio_ctx, C = h->hp.n_text_ctx,
-            V = h->hp.n_vocab;
+  const int dt = h->hp.n_text_state, H = h->hp.n_text_head, Tn = h->hp.n_audio_ctx, C = h->hp.n_text_ctx;
   const int* pos_dev = dev_pos ? h->d_counters : nullptr;
   // <= SKINNY_MAX_M clips: the projections run on the skinny kernel (row blocks of 32 clips), which folds the preceding LayerNorm in and writes q and
   // k|v of the self-attention block from one launch (17 launches fewer per step on Whisper-tiny)
@@ -738,20 +772,7 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
       HIP_TRY(gemm_f32_nt(g, 1, s));
     }
   }
-  if (want_logits) {
-    // vocabulary projection: above 64 clips the 128 x 128 tiled kernel (behind a LayerNorm launch) beats the skinny
-    // kernel's 32-row blocks, which re-read the 80 MB embedding once per block (-3 % / -5 % per step at 128 / 512 clips)
-    if (fold && batch <= 64) {
-      GemmArgs g = gemm(h->d_dx, dt, h->logit_lw, dt, h->d_logits, V, nullptr, batch, V, dt);
-      g.ln_s = h->logit_ls; g.ln_c = h->logit_lc;
-      HIP_TRY(gemm_f32_nt(g, 1, s));
-    } else {
-      HIP_TRY(layernorm_f32(h->d_dx, h->dec_ln_w, h->dec_ln_b, h->d_dxn, batch, dt, s));
-      GemmArgs g = gemm(h->d_dxn, dt, h->tok_emb, dt, h->d_logits, V, nullptr, batch, V, dt);
-      g.tiled = fold ? 1 : 0;
-      HIP_TRY(gemm_f32_nt(g, 1, s));
-    }
-  }
+  if (want_logits) return decoder_logits(h, batch, s);
   return CRISPY_OK;
 }
 
@@ -964,6 +985,26 @@ int crispy_asr_set_suppress(crispy_asr* h, const int* ids, int n, int first_only
   HIP_TRY(hipMemcpy(h->d_suppress_first, first.data(), first.size(), hipMemcpyHostToDevice));
   return CRISPY_OK;
 } CRISPY_CATCH_RET("crispy_asr_set_suppress")
+
+int crispy_asr_stage_logits_device(crispy_asr* h, const float* d_x, int batch, float* d_logits) try {
+  if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_stage_logits_device: NULL handle");
+  if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_stage_logits_device: model not finalized");
+  if (batch < 0 || batch > SKINNY_MAX_M) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_stage_logits_device: batch %d outside [0, %d]", batch, SKINNY_MAX_M);
+  if (batch == 0) return CRISPY_OK;
+  if (!d_x || !d_logits) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_stage_logits_device: NULL argument");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  int rc = reserve_dec(h, batch, 1);
+  if (rc != CRISPY_OK) return rc;
+  const int dt = h->hp.n_text_state, V = h->hp.n_vocab;
+  // through the decode step's own buffers, so that the code under test is decoder_step's last block
+  HIP_TRY(hipMemcpyAsync(h->d_dx, d_x, sizeof(float) * batch * dt, hipMemcpyDeviceToDevice, s));
+  rc = decoder_logits(h, batch, s);
+  if (rc != CRISPY_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(d_logits, h->d_logits, sizeof(float) * (size_t)batch * V, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return CRISPY_OK;
+} CRISPY_CATCH_RET("crispy_asr_stage_logits_device")
 
 int crispy_asr_decode_greedy_device(crispy_asr* h, const float* d_enc, int batch, const int* prompt, int n_prompt,
                                     int max_new, int* tokens_out, int* n_out, float* logits_out) try {

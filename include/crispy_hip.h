@@ -255,6 +255,12 @@ int crispy_asr_synchronize(crispy_asr *h);
  * v_mfma_f32_32x32x16_f16; attention, LayerNorm, the convolution stem's first layer and the decoder stay f32. */
 int crispy_asr_set_precision(crispy_asr *h, int mode);
 
+/* Stage entry point (parity tests): the last step of the decoder alone -- final LayerNorm and vocabulary projection
+ * of d_x [batch][n_text_state] (device, f32) into d_logits [batch][n_vocab] (device, f32), in the current precision
+ * mode.  Mode 1: LayerNorm output rounded to f16 against the f16 token embedding, f32 accumulation (ggml's mul_mat
+ * over whisper.cpp's f16 `decoder.token_embedding.weight`).  batch <= 512. */
+int crispy_asr_stage_logits_device(crispy_asr *h, const float *d_x, int batch, float *d_logits);
+
 /* Greedy decoding (north_star: greedy; the sampling strategy transcribe-rs 0.3.11 selects is
  * unverifiable here).  Token ids listed with first_only = 0 are never
  * emitted; those with first_only = 1 only at the first sampled position (whisper's suppress_blank).

@@ -146,6 +146,17 @@ def decoder_logits(weights, hp, enc_out, tokens):
     return x @ W["decoder.token_embedding.weight"].T
 
 
+def final_logits(weights, x, f16=False):
+    """The last block of a decoder step on its own: logits = LN(x) . E^T for decoder states x [n, d] (float64).
+    f16=True is the arithmetic of whisper.cpp's ggml graph [UPSTREAM-RECALL] for this product -- what precision mode 1 of
+    the library implements: the LayerNorm output (src1 of mul_mat) and the token embedding (an f16 tensor in every
+    ggml-model.bin) both rounded to f16, exact accumulation (f32 on the matrix cores)."""
+    W = _f64(weights)
+    xn = _ln(np.asarray(x, dtype=np.float64), W["decoder.ln.weight"], W["decoder.ln.bias"])
+    E = W["decoder.token_embedding.weight"]
+    return (_h(xn) @ _h(E).T) if f16 else (xn @ E.T)
+
+
 def greedy_decode(weights, hp, enc_out, prompt, n_new, suppress=None, eot=50257):
     """Greedy continuation of `prompt`: argmax of the last position's logits (ties -> lowest id), suppressed
     ids masked to -inf; stops after n_new tokens or at EOT.  Returns (tokens, logit of each pick, margin to

@@ -545,6 +545,49 @@ def test_f16_operand_mode_matches_the_f16_operand_oracle(tiny, model, oracle):
         assert rms16 < 0.7 * rms64, (seed, rms16, rms64)             # its own oracle, not the exact one
 
 
+@pytest.mark.parametrize("batch", [1, 64, 100])
+def test_vocabulary_projection_both_precision_modes(tiny, model, batch):
+    """crispy_asr_stage_logits_device = the last block of a decoder step (final LayerNorm + vocabulary projection),
+    against oracle/whisper_oracle.py::final_logits in ITS mode's arithmetic.  Mode 0: f32 operands, 1e-5 of the peak.
+    Mode 1 (whisper.cpp: f16 token embedding, ggml rounds the LayerNorm output to f16): the packed-embedding f16
+    kernel against the f16-rounding oracle.  The f32 LayerNorm lands within one f32 ulp of the f64 one, which moves
+    about 1 in 2000 of its outputs across an f16 rounding boundary (a 2^-11 relative step of one of 384 terms: about a
+    tenth of what the rounding of all 384 does to that row; measured: 3.7e-5 of the peak at the worst element, 1.0e-6
+    rms), so the bars are 1e-4 of the peak at the maximum and an rms
+    below a quarter of the rounding's own footprint (6e-5 rms of the peak: an unrounded path sits AT that footprint and
+    fails); batch 1 / 64 / 100 cover one partial row block, one full one and a second grid row."""
+    import torch
+    from oracle import whisper_oracle as WO
+    hp, W = tiny
+    rng = np.random.default_rng(7 + batch)
+    x = (rng.standard_normal((batch, hp.n_text_state)) * 2.0 + 0.3).astype(np.float32)
+    dev = torch.device("cuda:0")
+    d_x = torch.from_numpy(x).to(dev)
+    d_l = torch.empty((batch, hp.n_vocab), dtype=torch.float32, device=dev)
+    ref64 = WO.final_logits(W, x)
+    ref16 = WO.final_logits(W, x, f16=True)
+    peak = np.abs(ref64).max()
+    model.stage_logits_device(d_x.data_ptr(), batch, d_l.data_ptr())
+    got0 = d_l.cpu().numpy()
+    assert np.abs(got0 - ref64).max() / peak < 1e-5
+    try:
+        model.set_precision(1)
+        d_l.zero_()
+        model.stage_logits_device(d_x.data_ptr(), batch, d_l.data_ptr())
+        got1 = d_l.cpu().numpy()
+    finally:
+        model.set_precision(0)
+    gap = np.sqrt(np.mean((ref16 - ref64) ** 2)) / peak
+    err = np.abs(got1 - ref16).max() / peak
+    rms = np.sqrt(np.mean((got1 - ref16) ** 2)) / peak
+    assert gap > 4e-5, gap
+    assert err < 1e-4 and rms < 0.25 * gap, (err, rms, gap)
+    top2 = np.sort(ref16, 1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 1e-3 * peak           # rows whose pick is resolvable at that error
+    assert clear.sum() >= max(1, batch // 2), clear.sum()
+    assert np.array_equal(got1.argmax(1)[clear], ref16.argmax(1)[clear])
+
+
 def test_large_v3_turbo_dimensions_parity(oracle):
     """The catalog's large-v3-turbo (managers/model.rs:74-148) has d = 1280, 20 heads, 128 mel bins, 4 decoder layers
     and a 51866-token vocabulary.  The layer count of the encoder is cut to 2 here (the per-layer code path is the

@@ -145,3 +145,25 @@ def test_f16_operand_encoder_oracle_is_a_small_perturbation_of_the_exact_one(ora
     assert 1e-4 < rel < 5e-3, rel
     assert WO._h(1.0 + 2.0 ** -11) == 1.0 and WO._h(1.0 + 3 * 2.0 ** -11) == 1.0 + 2.0 ** -9    # round to nearest even
     assert WO._h(70000.0) == np.inf                                                                # f16 range
+
+
+def test_final_logits_is_the_decoders_last_block_and_its_f16_form_rounds_both_operands(tiny):
+    """oracle final_logits(x) = LN(x) . E^T: (a) on random decoder states it equals the direct formula; (b) the f16 form
+    differs from it by the rounding of both operands -- 6e-5 rms of the peak with the seeded Whisper-tiny weights --
+    and is what one gets from f16-rounded inputs in exact arithmetic (no other rounding point)."""
+    from oracle import whisper_oracle as WO
+    hp, W = tiny
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((5, hp.n_text_state)) * 2.0 + 0.3
+    g, b = W["decoder.ln.weight"].astype(np.float64), W["decoder.ln.bias"].astype(np.float64)
+    E = W["decoder.token_embedding.weight"].astype(np.float64)
+    mu = x.mean(-1, keepdims=True)
+    xn = (x - mu) / np.sqrt(((x - mu) ** 2).mean(-1, keepdims=True) + 1e-5) * g + b
+    ref = WO.final_logits(W, x)
+    assert np.allclose(ref, xn @ E.T, rtol=0, atol=1e-9 * np.abs(ref).max())
+    ref16 = WO.final_logits(W, x, f16=True)
+    xh = xn.astype(np.float32).astype(np.float16).astype(np.float64)
+    Eh = E.astype(np.float32).astype(np.float16).astype(np.float64)
+    assert np.array_equal(ref16, xh @ Eh.T)
+    gap = np.sqrt(np.mean((ref16 - ref) ** 2)) / np.abs(ref).max()
+    assert 4e-5 < gap < 3e-4, gap
