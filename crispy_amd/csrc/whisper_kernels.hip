@@ -172,9 +172,6 @@ __device__ __forceinline__ void sk_wave_sync() {     // LDS traffic of one wave:
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-#ifndef SK_NW_LONG
-#define SK_NW_LONG 16                          // waves (K splits) of the long-K variant
-#endif
 // LN / GELU / RES are compile-time so that the epilogue operands (ln_s, ln_c or bias, residual) can be requested
 // up front, next to the first K chunks, from clamped (always valid) addresses: with run-time flags every one of them
 // sat behind its own branch in the epilogue and cost a serialized L2 round trip after the barrier.
@@ -188,8 +185,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_f32_kernel(GemmArgs g) {
   // wave's partial tile replaces it after the K loop
   float (*red)[SK_WAVE_LDS] = reinterpret_cast<float (*)[SK_WAVE_LDS]>(sk_smem);
   float (*rstat)[32][2] = reinterpret_cast<float (*)[32][2]>(sk_smem + NW * SK_WAVE_LDS);
-  constexpr int RP = 2 * NW, NQ = 32 / RP;     // epilogue: RP rows per pass, NQ passes
-  constexpr int PF = NW > 8 ? 2 : SK_PF;       // 16 waves: 128 registers per lane, two chunks in flight
+  constexpr int ET = NW >= 16 ? 1024 : NW >= 8 ? 512 : 256;    // threads that finish outputs (12 waves: the first 512)
+  constexpr int RP = ET / 32, NQ = 32 / RP;    // epilogue: RP rows per pass, NQ passes
+  constexpr int PF = NW > 12 ? 2 : SK_PF;      // 16 waves: 128 registers per lane, two chunks in flight
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, lh = lane >> 5;
   const int n0 = blockIdx.x * 32;
@@ -241,7 +239,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_f32_kernel(GemmArgs g) {
   else if (g.bias) e_c = g.bias[enn];
   if (RES) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) e_res[q] = g.residual[(long)min(mb + (tid >> 5) + RP * q, g.M - 1) * g.ldr + enn];
+    for (int q = 0; q < NQ; ++q) e_res[q] = g.residual[(long)min(mb + min((tid >> 5) + RP * q, 31), g.M - 1) * g.ldr + enn];
   }
   const long coff = g.c_off_dev ? (long)(*g.c_off_dev) * g.c_off_scale : 0L;
   float* __restrict__ C = second ? g.C2 + coff - g.n_split : g.C + (g.C2 ? 0L : coff);
@@ -281,7 +279,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_f32_kernel(GemmArgs g) {
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    const int ml = (tid >> 5) + RP * q;         // row inside this 32-row block
+    const int ml = min((tid >> 5) + RP * q, 31);   // row inside this 32-row block (threads >= ET: clamped, not stored)
     const int m = mb + ml;
     float v = red[0][ml * 33 + ec];
 #pragma unroll
@@ -299,7 +297,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_f32_kernel(GemmArgs g) {
     }
     if (GELU) v = gelu_erf(v);
     if (RES) v += e_res[q];
-    if (m < g.M && n0 + (tid & 31) < g.N) C[(long)m * ldc + enn] = v;   // only the stores are predicated
+    if (tid < ET && m < g.M && n0 + (tid & 31) < g.N) C[(long)m * ldc + enn] = v;   // only the stores are predicated
   }
 }
 
@@ -1036,6 +1034,30 @@ __global__ void advance_kernel(int* __restrict__ pos_dev, int* __restrict__ step
 
 }  // namespace
 
+template <bool LN, bool GELU, bool RES, int NW>
+hipError_t sk_launch(dim3 grid, const GemmArgs& g, hipStream_t s) {
+  constexpr size_t smem = NW * (SK_WAVE_LDS + 64) * sizeof(float);
+  if (smem > 64 * 1024) {        // above the default dynamic-LDS limit (the CU has 160 KB); first called outside any capture
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_f32_kernel<LN, GELU, RES, NW>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (attr != hipSuccess) return attr;
+  }
+  hipLaunchKernelGGL((gemm_skinny_f32_kernel<LN, GELU, RES, NW>), grid, dim3(64 * NW), smem, s, g);
+  return hipGetLastError();
+}
+template <int NW>
+hipError_t sk_dispatch(int kind, dim3 grid, const GemmArgs& g, hipStream_t s) {
+  switch (kind) {
+    case 0: return sk_launch<false, false, false, NW>(grid, g, s);
+    case 1: return sk_launch<false, false, true, NW>(grid, g, s);
+    case 2: return sk_launch<false, true, false, NW>(grid, g, s);
+    case 3: return sk_launch<false, true, true, NW>(grid, g, s);
+    case 4: return sk_launch<true, false, false, NW>(grid, g, s);
+    case 5: return sk_launch<true, false, true, NW>(grid, g, s);
+    case 6: return sk_launch<true, true, false, NW>(grid, g, s);
+    default: return sk_launch<true, true, true, NW>(grid, g, s);
+  }
+}
 hipError_t gemm_f32_nt(const GemmArgs& g, int batch, hipStream_t s) {
   if (batch == 1 && g.M <= 64 && g.N >= 8192 && (g.K == 384 || g.K == 512) && !g.rowtab && !g.tiled && !g.C2 && !g.gelu &&
       !g.residual && !g.c_off_dev) {        // vocabulary projection of a decode step: persistent workgroups
@@ -1047,28 +1069,19 @@ hipError_t gemm_f32_nt(const GemmArgs& g, int batch, hipStream_t s) {
   if (batch == 1 && g.M <= SKINNY_MAX_M && g.K % 128 == 0 && !g.rowtab && !g.tiled) {   // one decode step: latency-bound shape
     const dim3 grid((g.N + 31) / 32, (g.M + 31) / 32);
     const int kind = (g.ln_s ? 4 : 0) | (g.gelu ? 2 : 0) | (g.residual ? 1 : 0);
-    if (kind == 1 && g.K >= 1024 && g.K % (32 * SK_NW_LONG) == 0) {      // fc2: K = 4 d
-      constexpr size_t smem = SK_NW_LONG * (SK_WAVE_LDS + 64) * sizeof(float);
-      static const hipError_t attr = hipFuncSetAttribute(
-          reinterpret_cast<const void*>(gemm_skinny_f32_kernel<false, false, true, SK_NW_LONG>),
-          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      if (attr != hipSuccess) return attr;
-      hipLaunchKernelGGL((gemm_skinny_f32_kernel<false, false, true, SK_NW_LONG>), grid, dim3(64 * SK_NW_LONG), smem, s, g);
-      return hipGetLastError();
+    // Ways to split K.  Up to 64 clips the launch is a handful of workgroups and one workgroup's latency is the
+    // launch's: the widest split the width allows (a wave is left with 1 to 5 chunks: 16 to 80 f32 MFMAs instead of
+    // 48 to 160).  Above that the chip is full and the extra partial tiles are only LDS traffic: 4 waves, except for
+    // the MLP's second GEMM (K = 4 d).
+    int nw = 4;
+    if (g.M <= 64) nw = g.K % 512 == 0 ? 16 : g.K % 384 == 0 ? 12 : g.K % 256 == 0 ? 8 : 4;
+    else if (kind == 1 && g.K >= 1024 && g.K % 512 == 0) nw = 16;
+    switch (nw) {
+      case 16: return sk_dispatch<16>(kind, grid, g, s);
+      case 12: return sk_dispatch<12>(kind, grid, g, s);
+      case 8: return sk_dispatch<8>(kind, grid, g, s);
+      default: return sk_dispatch<4>(kind, grid, g, s);
     }
-    const dim3 block(256);
-    constexpr size_t smem = 4 * (SK_WAVE_LDS + 64) * sizeof(float);
-    switch (kind) {
-      case 0: hipLaunchKernelGGL((gemm_skinny_f32_kernel<false, false, false, 4>), grid, block, smem, s, g); break;
-      case 1: hipLaunchKernelGGL((gemm_skinny_f32_kernel<false, false, true, 4>), grid, block, smem, s, g); break;
-      case 2: hipLaunchKernelGGL((gemm_skinny_f32_kernel<false, true, false, 4>), grid, block, smem, s, g); break;
-      case 3: hipLaunchKernelGGL((gemm_skinny_f32_kernel<false, true, true, 4>), grid, block, smem, s, g); break;
-      case 4: hipLaunchKernelGGL((gemm_skinny_f32_kernel<true, false, false, 4>), grid, block, smem, s, g); break;
-      case 5: hipLaunchKernelGGL((gemm_skinny_f32_kernel<true, false, true, 4>), grid, block, smem, s, g); break;
-      case 6: hipLaunchKernelGGL((gemm_skinny_f32_kernel<true, true, false, 4>), grid, block, smem, s, g); break;
-      default: hipLaunchKernelGGL((gemm_skinny_f32_kernel<true, true, true, 4>), grid, block, smem, s, g); break;
-    }
-    return hipGetLastError();
   }
   dim3 grid((g.N + GB_N - 1) / GB_N, (g.M + GB_M - 1) / GB_M, batch);
   hipLaunchKernelGGL(gemm_f32_nt_kernel, grid, dim3(256), 0, s, g);
