@@ -898,6 +898,7 @@ int crispy_rn_debug_capture(crispy_rn* h, int enable) try {
   if (enable && !h->d_dbg) {
     HIP_TRY(hipMalloc(&h->d_dbg, (size_t)h->B * RN_DBG_FLOATS * sizeof(float)));
     HIP_TRY(hipMemset(h->d_dbg, 0, (size_t)h->B * RN_DBG_FLOATS * sizeof(float)));
+    HIP_TRY(hipDeviceSynchronize());        // a NULL-stream memset is not ordered against the handle's non-blocking stream
   } else if (!enable && h->d_dbg) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipFree(h->d_dbg));

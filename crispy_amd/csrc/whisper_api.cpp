@@ -253,6 +253,11 @@ int reserve_enc(crispy_asr* h, int batch) {
   // zero padding rows of the frame-major buffers are written once
   HIP_TRY(hipMemset(h->w_melt, 0, B * (MEL_FRAMES + 2) * h->hp.n_mels * sizeof(float)));
   HIP_TRY(hipMemset(h->w_h1, 0, B * (MEL_FRAMES + 1) * d * sizeof(float)));
+  // hipMemset on device memory does not wait on the host, and it runs on the NULL stream, which the handle's
+  // non-blocking stream is not ordered against: without this the 1.5 GB memset of a 256-clip workspace was still
+  // clearing h1 while the first call's conv1 had already written the first clips (wrong encoder output for clips
+  // 0..7 of the first 256-clip call, intermittently: tests/test_gpu_pipeline.py cfg5)
+  HIP_TRY(hipDeviceSynchronize());
   h->cap_batch = batch;
   return CRISPY_OK;
 }
@@ -406,6 +411,7 @@ int crispy_asr_finalize(crispy_asr* h) try {
   HIP_TRY(hipMalloc(&h->d_suppress_first, h->hp.n_vocab));
   HIP_TRY(hipMemset(h->d_suppress, 0, h->hp.n_vocab));
   HIP_TRY(hipMemset(h->d_suppress_first, 0, h->hp.n_vocab));
+  HIP_TRY(hipDeviceSynchronize());          // NULL-stream memsets vs the handle's non-blocking stream (see reserve_enc)
   { const int mrc = build_ts_masks(h); if (mrc != CRISPY_OK) return mrc; }
   h->finalized = true;
   return CRISPY_OK;
