@@ -365,6 +365,7 @@ def cfg5(args):
     lens = np.full(SUB, 480000)
     prompt = [50258, 50259, 50359, 50363]
     stage = {"logmel": 0.0, "encoder": 0.0, "decode": 0.0}
+    torch.cuda.synchronize()             # the fills above ran on torch's stream; the handles use their own
 
     def step():
         t0 = time.perf_counter()

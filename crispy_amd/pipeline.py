@@ -86,6 +86,7 @@ class DenoiseTranscribePipeline:
         n48 = (T - 1) * FRAME_SIZE                       # first frame dropped (audio.rs:275-278)
         n16 = Resampler48to16.out_len(n48)
         pcm16 = torch.zeros(B, max(n16, 1), device=self.dev)
+        torch.cuda.synchronize()          # torch's fill runs on torch's stream; the handles' streams are not ordered against it
         den_flat = den.view(B, T * FRAME_SIZE)
         self.rs.process_device(den_flat.data_ptr() + 4 * FRAME_SIZE, T * FRAME_SIZE, n48, B, pcm16.data_ptr(),
                                pcm16.shape[1], scale=1.0 / 32768.0, handoff=self.handoff)

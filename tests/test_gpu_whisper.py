@@ -154,6 +154,7 @@ def test_decode_argument_checks(model):
     from crispy_amd import _native as N
     import torch
     d_enc = torch.zeros(1, 1500, 384, device="cuda")
+    torch.cuda.synchronize()
     with pytest.raises(N.CrispyError):
         model.decode_greedy_device(d_enc.data_ptr(), 1, [50258], 448)      # prompt + new > n_text_ctx
     with pytest.raises(N.CrispyError):
@@ -567,12 +568,14 @@ def test_vocabulary_projection_both_precision_modes(tiny, model, batch):
     ref64 = WO.final_logits(W, x)
     ref16 = WO.final_logits(W, x, f16=True)
     peak = np.abs(ref64).max()
+    torch.cuda.synchronize()
     model.stage_logits_device(d_x.data_ptr(), batch, d_l.data_ptr())
     got0 = d_l.cpu().numpy()
     assert np.abs(got0 - ref64).max() / peak < 1e-5
     try:
         model.set_precision(1)
         d_l.zero_()
+        torch.cuda.synchronize()                 # torch's stream is not ordered against the handle's
         model.stage_logits_device(d_x.data_ptr(), batch, d_l.data_ptr())
         got1 = d_l.cpu().numpy()
     finally:
