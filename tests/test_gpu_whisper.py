@@ -591,6 +591,43 @@ def test_vocabulary_projection_both_precision_modes(tiny, model, batch):
     assert np.array_equal(got1.argmax(1)[clear], ref16.argmax(1)[clear])
 
 
+@pytest.mark.parametrize("d,vocab", [(512, 51865), (768, 51865), (1024, 51865), (1280, 51866)])
+def test_vocabulary_projection_at_the_other_catalog_widths(d, vocab):
+    """The mode-1 logits kernel is built per model width (K-chunks per wave 8 / 12 / 16 / 20 for base / small / medium /
+    large; tiny's 6 is the test above): one-layer models of each width (the projection does not depend on the depth),
+    70 decoder states = a full 64-row block and a partial second grid row, against final_logits in both modes with
+    the bars of the Whisper-tiny test."""
+    import torch
+    from crispy_amd.asr import WhisperModel
+    from crispy_amd.whisper_weights import HParams, synthetic_whisper_weights
+    from oracle import whisper_oracle as WO
+    hp = HParams(n_vocab=vocab, n_audio_state=d, n_audio_head=d // 64, n_audio_layer=1, n_text_state=d, n_text_head=d // 64,
+                 n_text_layer=1, n_mels=128 if vocab == 51866 else 80)
+    W = synthetic_whisper_weights(hp, 4)
+    m = WhisperModel(hp, W)
+    batch = 70
+    rng = np.random.default_rng(d)
+    x = (rng.standard_normal((batch, d)) * 2.0 + 0.3).astype(np.float32)
+    dev = torch.device("cuda:0")
+    d_x = torch.from_numpy(x).to(dev)
+    d_l = torch.empty((batch, vocab), dtype=torch.float32, device=dev)
+    ref64 = WO.final_logits(W, x)
+    ref16 = WO.final_logits(W, x, f16=True)
+    peak = np.abs(ref64).max()
+    torch.cuda.synchronize()
+    m.stage_logits_device(d_x.data_ptr(), batch, d_l.data_ptr())
+    assert np.abs(d_l.cpu().numpy() - ref64).max() / peak < 1e-5
+    m.set_precision(1)
+    m.stage_logits_device(d_x.data_ptr(), batch, d_l.data_ptr())
+    got1 = d_l.cpu().numpy()
+    gap = np.sqrt(np.mean((ref16 - ref64) ** 2)) / peak
+    err = np.abs(got1 - ref16).max() / peak
+    rms = np.sqrt(np.mean((got1 - ref16) ** 2)) / peak
+    assert gap > 2e-5, gap
+    assert err < 1e-4 and rms < 0.25 * gap, (err, rms, gap)
+    m.close()
+
+
 def test_large_v3_turbo_dimensions_parity(oracle):
     """The catalog's large-v3-turbo (managers/model.rs:74-148) has d = 1280, 20 heads, 128 mel bins, 4 decoder layers
     and a 51866-token vocabulary.  The layer count of the encoder is cut to 2 here (the per-layer code path is the
