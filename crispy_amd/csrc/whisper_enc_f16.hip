@@ -418,8 +418,13 @@ __device__ __forceinline__ void hd_epilogue(const HGemmArgs& g, f32x16 (&acc)[2]
 //             request stage kb + 2      into the buffer stage kb - 1 occupied
 //             8 ds_read_b128 + 8 MFMAs from stage kb
 // LDS tile layout: 128 rows x 4 chunks of 16 bytes, unpadded (a wave-wide request writes 1 KB contiguously: lane L at
-// base + 16 L), chunk c of row r stored at slot c ^ ((r >> 1) & 3): the 8 lanes of a b128 read phase (consecutive
-// rows, one chunk) then cover all 32 banks.  The lane that fills slot (r, cs) simply requests chunk cs ^ ((r >> 1) & 3).
+// base + 16 L), chunk c of row r stored at slot c ^ ((r >> 2) & 3).  A ds_read_b128 is served in four groups of 16
+// NON-contiguous lanes ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32) against 64 banks = a 256-byte bank
+// row = four of these 64-byte tile rows: the lanes of a group sit on rows with r mod 4 = 0..3 four times over, and the four
+// rows of one residue have (r >> 2) & 3 all different ({0,3,1,2} / {1,2,0,3}), so the group covers the 16 slots of the
+// bank row exactly once.  (The first version XORed with (r >> 1) & 3, thought out for 8 consecutive lanes over 32
+// banks: measured SQ_LDS_BANK_CONFLICT = 45 % of SQ_LDS_IDX_ACTIVE, every operand read two-way conflicted.)
+// The lane that fills slot (r, cs) simply requests chunk cs ^ ((r >> 2) & 3).
 // The operand reads are inline asm on purpose: the compiler orders every LDS read it can see behind the most recent
 // LDS-DMA request (`s_waitcnt vmcnt(0)`), which would serialise the stages; the counters are kept by hand instead.
 // ---------------------------------------------------------------------------------------------
@@ -450,7 +455,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int r = 32 * wave + 16 * u + (lane >> 2);             // tile row this lane fills
-    const int c = (lane & 3) ^ ((r >> 1) & 3);                  // global chunk that belongs into slot (r, lane & 3)
+    const int c = (lane & 3) ^ ((r >> 2) & 3);                  // global chunk that belongs into slot (r, lane & 3)
     ga[u] = A + (long)min(m0 + r, g.M - 1) * g.lda + 8 * c;     // clamped rows: their results are not stored
     gw[u] = W + (long)min(n0 + r, g.N - 1) * g.ldw + 8 * c;
   }
@@ -465,7 +470,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
   };
 
   // ---- operand read addresses (bytes inside a stage): row R = w? + 32 i + li, chunk 2 ks + lh, slot = chunk ^ swz ----
-  const int swz = (li >> 1) & 3;
+  const int swz = (li >> 2) & 3;
   const unsigned lds0 = (unsigned)(size_t)(lds_ptr)smem;
   const unsigned a_ks0 = lds0 + (wm + li) * 64 + ((lh ^ swz) << 4);
   const unsigned a_ks1 = lds0 + (wm + li) * 64 + (((2 + lh) ^ swz) << 4);
