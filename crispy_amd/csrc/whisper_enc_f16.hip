@@ -683,6 +683,119 @@ __global__ void f32_to_f16_rows_kernel(const float* __restrict__ src, long lds, 
   if (r < rows) dst[r * ldd + c] = (_Float16)src[r * lds + c];
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The same loop over a 256 x 128 output tile: a wave owns 128 x 64 (acc[4][2]), so a trip around the k loop -- one
+// vmcnt wait, one barrier, the LDS round trip of the first operands -- carries 16 MFMAs instead of 8, and the bytes
+// requested per MFMA fall by a quarter (24 KB per 32-wide k-block for twice the outputs).  Ablations of the 128 x 128
+// kernel on the 256-clip Whisper-base encoder had put the cost there: twice the MFMAs per trip +32 % of the GEMM time,
+// every request served from L1 -13 %, LDS bank conflicts removed 0 % -- more than half of a trip is its fixed cost.
+// 72 KB of LDS (three stages of 16 + 8 KB), 2 workgroups per CU.  Same operand layout, swizzle and epilogue (the
+// wave's 128 rows go through the 32-row epilogue image as two 64-row halves).
+// ---------------------------------------------------------------------------------------------
+constexpr int HD2_M = 256, HD2_A_BYTES = HD2_M * HH_K * 2, HD2_STAGE_BYTES = HD2_A_BYTES + HD_TILE_BYTES;   // 16 + 8 KB
+template <int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_hd2_kernel(HGemmArgs g) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[HD_STAGES * HD2_STAGE_BYTES];   // [stage][A 256 rows | W 128 rows]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (g.xcd_swizzle) {
+    const int nt = gridDim.x;
+    const int lin = blockIdx.y * nt + blockIdx.x;
+    const int xcd = lin & 7, slot = lin >> 3;
+    by = 8 * (slot / nt) + xcd;
+    bx = slot % nt;
+    if (by * HD2_M >= g.M) return;
+  }
+  const int bz = blockIdx.z;
+  const _Float16* __restrict__ A = g.A + (long)bz * g.strideA;
+  const _Float16* __restrict__ W = g.W;
+  const int m0 = by * HD2_M, n0 = bx * HH_N;
+  const int wm = (wave >> 1) * 128, wn = (wave & 1) * 64;
+  const int li = lane & 31, lh = lane >> 5;
+
+  // ---- requests: wave w fills rows [64 w, 64 w + 64) of A (four 1 KB wave-requests) and [32 w, 32 w + 32) of W (two) ----
+  const _Float16* ga[4];
+  const _Float16* gw[2];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int r = 64 * wave + 16 * u + (lane >> 2);
+    ga[u] = A + (long)min(m0 + r, g.M - 1) * g.lda + 8 * ((lane & 3) ^ ((r >> 2) & 3));   // clamped rows: results not stored
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int r = 32 * wave + 16 * u + (lane >> 2);
+    gw[u] = W + (long)min(n0 + r, g.N - 1) * g.ldw + 8 * ((lane & 3) ^ ((r >> 2) & 3));
+  }
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  auto request = [&](int stage, int k0) {
+    unsigned char* base = smem + stage * HD2_STAGE_BYTES;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) __builtin_amdgcn_global_load_lds(ga[u] + k0, (lds_ptr)(base + wave * 4096 + 1024 * u), 16, 0, 0);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      __builtin_amdgcn_global_load_lds(gw[u] + k0, (lds_ptr)(base + HD2_A_BYTES + wave * 2048 + 1024 * u), 16, 0, 0);
+  };
+
+  const int swz = (li >> 2) & 3;
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr)smem;
+  const unsigned a_ks0 = lds0 + (wm + li) * 64 + ((lh ^ swz) << 4);
+  const unsigned a_ks1 = lds0 + (wm + li) * 64 + (((2 + lh) ^ swz) << 4);
+  const unsigned w_ks0 = lds0 + HD2_A_BYTES + (wn + li) * 64 + ((lh ^ swz) << 4);
+  const unsigned w_ks1 = lds0 + HD2_A_BYTES + (wn + li) * 64 + (((2 + lh) ^ swz) << 4);
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = g.K / HH_K;
+  request(0, 0);
+  if (nk > 1) request(1, HH_K);
+  int stage = 0;
+  for (int kb = 0; kb < nk; ++kb) {
+    if (kb + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0F76);      // vmcnt(6): the six requests of stage kb + 1 may be pending
+    else __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    if (kb + 2 < nk) {
+      const int s2 = stage + 2 >= HD_STAGES ? stage + 2 - HD_STAGES : stage + 2;
+      request(s2, (kb + 2) * HH_K);
+    }
+    const unsigned so = (unsigned)stage * HD2_STAGE_BYTES;
+    half8 a0[4], a1[4], w0[2], w1[2];          // a0 / w0: k sub-step 0, a1 / w1: sub-step 1; index = 32-row block
+    asm volatile("ds_read_b128 %0, %1" : "=v"(a0[0]) : "v"(a_ks0 + so));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(w0[0]) : "v"(w_ks0 + so));
+    asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(w0[1]) : "v"(w_ks0 + so));
+    asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(a0[1]) : "v"(a_ks0 + so));
+    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(a0[2]) : "v"(a_ks0 + so));
+    asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(a0[3]) : "v"(a_ks0 + so));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(a1[0]) : "v"(a_ks1 + so));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(w1[0]) : "v"(w_ks1 + so));
+    asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(w1[1]) : "v"(w_ks1 + so));
+    asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(a1[1]) : "v"(a_ks1 + so));
+    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(a1[2]) : "v"(a_ks1 + so));
+    asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(a1[3]) : "v"(a_ks1 + so));
+#define HD2_MFMA(i_, j_, av, wv) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, wv, acc[i_][j_], 0, 0, 0);
+    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a0[0]), "+v"(w0[0]), "+v"(w0[1]), "+v"(a0[1]));
+    HD2_MFMA(0, 0, a0[0], w0[0]) HD2_MFMA(0, 1, a0[0], w0[1]) HD2_MFMA(1, 0, a0[1], w0[0]) HD2_MFMA(1, 1, a0[1], w0[1])
+    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a0[2]), "+v"(a0[3]));
+    HD2_MFMA(2, 0, a0[2], w0[0]) HD2_MFMA(2, 1, a0[2], w0[1]) HD2_MFMA(3, 0, a0[3], w0[0]) HD2_MFMA(3, 1, a0[3], w0[1])
+    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a1[0]), "+v"(w1[0]), "+v"(w1[1]), "+v"(a1[1]));
+    HD2_MFMA(0, 0, a1[0], w1[0]) HD2_MFMA(0, 1, a1[0], w1[1]) HD2_MFMA(1, 0, a1[1], w1[0]) HD2_MFMA(1, 1, a1[1], w1[1])
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a1[2]), "+v"(a1[3]));
+    HD2_MFMA(2, 0, a1[2], w1[0]) HD2_MFMA(2, 1, a1[2], w1[1]) HD2_MFMA(3, 0, a1[3], w1[0]) HD2_MFMA(3, 1, a1[3], w1[1])
+#undef HD2_MFMA
+    stage = stage + 1 == HD_STAGES ? 0 : stage + 1;
+  }
+  __builtin_amdgcn_s_barrier();          // every wave has read its last operands: the stages become epilogue images
+  float* T = reinterpret_cast<float*>(smem + wave * 12288);
+  hd_epilogue<EPI>(g, reinterpret_cast<f32x16 (&)[2][2]>(acc[0]), T, m0, n0, wm, wn, lane, bz);
+  hd_epilogue<EPI>(g, reinterpret_cast<f32x16 (&)[2][2]>(acc[2]), T, m0, n0, wm + 64, wn, lane, bz);
+}
+
 }  // namespace
 
 hipError_t layernorm_f16out(const float* x, const float* gamma, const float* beta, void* y, long rows, int D,
@@ -707,6 +820,20 @@ hipError_t gemm_hh(const HGemmArgs& g, int epi, int batch, hipStream_t s) {
   dim3 grid(nt, mt, batch);
   if (a.xcd_swizzle) grid.y = (unsigned)(((mt + 7) / 8) * 8);      // whole groups of eight row tiles
   static const bool direct = [] { const char* e = std::getenv("CRISPY_ASR_GEMM"); return !(e && e[0] == 'r'); }();   // "regs": the register-staged loop
+  static const bool tall = [] { const char* e = std::getenv("CRISPY_ASR_GEMM"); return !(e && e[0] == 's'); }();     // "square": 128 x 128 tiles only
+  if ((direct || epi == EPI_KVH) && tall && g.M >= 4 * HD2_M) {      // 256 x 128 tiles
+    const int mt2 = (g.M + HD2_M - 1) / HD2_M;
+    dim3 grid2(nt, a.xcd_swizzle ? (unsigned)(((mt2 + 7) / 8) * 8) : (unsigned)mt2, batch);
+    switch (epi) {
+      case EPI_F16: hipLaunchKernelGGL(gemm_hd2_kernel<EPI_F16>, grid2, dim3(256), 0, s, a); break;
+      case EPI_RES: hipLaunchKernelGGL(gemm_hd2_kernel<EPI_RES>, grid2, dim3(256), 0, s, a); break;
+      case EPI_VT: hipLaunchKernelGGL(gemm_hd2_kernel<EPI_VT>, grid2, dim3(256), 0, s, a); break;
+      case EPI_TAB: hipLaunchKernelGGL(gemm_hd2_kernel<EPI_TAB>, grid2, dim3(256), 0, s, a); break;
+      case EPI_KVH: hipLaunchKernelGGL(gemm_hd2_kernel<EPI_KVH>, grid2, dim3(256), 0, s, a); break;
+      default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  }
   if (direct || epi == EPI_KVH) {
     switch (epi) {
       case EPI_F16: hipLaunchKernelGGL(gemm_hd_kernel<EPI_F16>, grid, dim3(256), 0, s, a); break;

@@ -136,3 +136,19 @@ def test_f16_encoder_kernels_run_at_four_waves_per_simd_without_scratch(tmp_path
         seg = loop[:pos[-1]]
         assert seg.count("ds_read_b128") == 8 and seg.count("global_load_lds_dwordx4") == 4, name
         assert "vmcnt(0)" not in seg, f"{name}: a compiler-inserted vmcnt(0) serialises the stages"
+    # the 256 x 128 tile form (M >= 1024 rows): three stages of 24 KB, two workgroups per CU, six LDS-DMA requests,
+    # twelve ds_read_b128 and sixteen MFMAs per trip, again without a compiler-inserted vmcnt(0)
+    hd2 = {k: v for k, v in res.items() if "gemm_hd2_kernel" in k}
+    assert len(hd2) == 5, list(res)
+    for name, r in hd2.items():
+        assert r["ScratchSize"] == 0 and r["LDS Size"] == 3 * 24576 and r["VGPRs"] + r.get("AGPRs", 0) <= 256, (name, r)
+        body = text[text.index(name + ":"):]
+        body = body[:body.index(".Lfunc_end")]
+        loop = body[body.index("Loop Header: Depth=1"):]
+        loop = loop[loop.index("s_barrier"):]
+        at = 0
+        for _ in range(16):
+            at = loop.index("v_mfma_f32_32x32x16_f16", at) + 1
+        seg = loop[:at]
+        assert seg.count("ds_read_b128") == 12 and seg.count("global_load_lds_dwordx4") == 6, name
+        assert "vmcnt(0)" not in seg, f"{name}: a compiler-inserted vmcnt(0) serialises the stages"
