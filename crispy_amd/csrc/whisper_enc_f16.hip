@@ -302,12 +302,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void g
 // ---------------------------------------------------------------------------------------------
 constexpr int EP_LD = 68, EP_VLD = 36;
 template <int EPI>
+// bias[j]: this lane's column 32 j + li of the wave's 64, requested by the caller BEFORE the k loop (requested here, the
+// load was an exposed L2 round trip in front of the first image pass: ~1.5 k of an epilogue's 15 k cycles, per call)
 __device__ __forceinline__ void hd_epilogue(const HGemmArgs& g, f32x16 (&acc)[2][2], float* T, int m0, int n0, int wm, int wn,
-                                            int lane, int bz) {
+                                            int lane, int bz, const float (&bias)[2]) {
   const int li = lane & 31, lh = lane >> 5;
-  float bias[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) bias[j] = g.bias ? g.bias[min(n0 + wn + 32 * j + li, g.N - 1)] : 0.f;
   const int mrem = g.M - (m0 + wm), nrem = g.N - (n0 + wn);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -488,6 +487,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
   const int nk = g.K / HH_K;
   request(0, 0);
   if (nk > 1) request(1, HH_K);
+  float bias[2];                             // epilogue operand, requested here (behind the first operand requests)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bias[j] = g.bias ? g.bias[min(n0 + wn + 32 * j + li, g.N - 1)] : 0.f;
   int stage = 0;
   for (int kb = 0; kb < nk; ++kb) {
     if (kb + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0F74);      // vmcnt(4): the four requests of stage kb + 1 may be pending
@@ -516,7 +518,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
     stage = stage + 1 == HD_STAGES ? 0 : stage + 1;
   }
   __builtin_amdgcn_s_barrier();          // every wave has read its last operands: the stages become epilogue images
-  hd_epilogue<EPI>(g, acc, reinterpret_cast<float*>(smem + wave * 12288), m0, n0, wm, wn, lane, bz);
+  hd_epilogue<EPI>(g, acc, reinterpret_cast<float*>(smem + wave * 12288), m0, n0, wm, wn, lane, bz, bias);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -755,6 +757,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
   const int nk = g.K / HH_K;
   request(0, 0);
   if (nk > 1) request(1, HH_K);
+  float bias[2];                             // epilogue operand, requested here (behind the first operand requests)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bias[j] = g.bias ? g.bias[min(n0 + wn + 32 * j + li, g.N - 1)] : 0.f;
   int stage = 0;
   for (int kb = 0; kb < nk; ++kb) {
     if (kb + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0F76);      // vmcnt(6): the six requests of stage kb + 1 may be pending
@@ -792,8 +797,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
   }
   __builtin_amdgcn_s_barrier();          // every wave has read its last operands: the stages become epilogue images
   float* T = reinterpret_cast<float*>(smem + wave * 12288);
-  hd_epilogue<EPI>(g, reinterpret_cast<f32x16 (&)[2][2]>(acc[0]), T, m0, n0, wm, wn, lane, bz);
-  hd_epilogue<EPI>(g, reinterpret_cast<f32x16 (&)[2][2]>(acc[2]), T, m0, n0, wm + 64, wn, lane, bz);
+  hd_epilogue<EPI>(g, reinterpret_cast<f32x16 (&)[2][2]>(acc[0]), T, m0, n0, wm, wn, lane, bz, bias);
+  hd_epilogue<EPI>(g, reinterpret_cast<f32x16 (&)[2][2]>(acc[2]), T, m0, n0, wm + 64, wn, lane, bz, bias);
 }
 
 }  // namespace
