@@ -301,106 +301,144 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void g
 //   T: this wave's 32 x 68 floats (row-major outputs) or 64 x 36 floats (V^T) of LDS.
 // ---------------------------------------------------------------------------------------------
 constexpr int EP_LD = 68, EP_VLD = 36;
+constexpr int EP_IMAGE_BYTES = 64 * EP_VLD * 4;      // 9216: the larger of the two image shapes (32 x 68 and 64 x 36 floats)
+__device__ __forceinline__ void ep_wave_sync() {     // this wave's LDS traffic has landed (single-wave hand-off)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0)
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// The three pieces of one 32-row pass.  rb = first row of the pass inside the wave's rows (m0 + wm is the wave's origin).
+// bias[j]: this lane's column 32 j + li of the wave's 64, requested by the caller above the k loop.
+//   ep_write     registers -> image: lane = column 32 j + li, register r = row 8 (r >> 2) + 4 lh + (r & 3)
 template <int EPI>
-// bias[j]: this lane's column 32 j + li of the wave's 64, requested by the caller BEFORE the k loop (requested here, the
-// load was an exposed L2 round trip in front of the first image pass: ~1.5 k of an epilogue's 15 k cycles, per call)
+__device__ __forceinline__ void ep_write(const HGemmArgs& g, const f32x16 (&acc)[2], float* T, int lane, const float (&bias)[2]) {
+  const int li = lane & 31, lh = lane >> 5;
+  if (EPI == EPI_VT) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(T + (32 * j + li) * EP_VLD + 8 * q + 4 * lh) =
+            make_float4(acc[j][4 * q] + bias[j], acc[j][4 * q + 1] + bias[j], acc[j][4 * q + 2] + bias[j], acc[j][4 * q + 3] + bias[j]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[j][r] + bias[j];
+        if ((EPI == EPI_F16 && g.gelu) || EPI == EPI_TAB) v = gelu_erf_e(v);
+        T[acc_row_e(r, lane) * EP_LD + 32 * j + li] = v;
+      }
+  }
+}
+//   ep_prefetch  EPI_RES / EPI_TAB: the residual / positional operands of the pass, requested together
+template <int EPI>
+__device__ __forceinline__ void ep_prefetch(const HGemmArgs& g, float4 (&ex)[8], int m0, int n0, int wm, int wn, int rb, int lane, int bz) {
+  if (EPI != EPI_RES && EPI != EPI_TAB) return;
+  const int mrem = g.M - (m0 + wm), nrem = g.N - (n0 + wn);
+  const int c4 = (lane & 15) * 4;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int row = (lane >> 4) + 4 * p;
+    const int rc = min(rb + row, mrem - 1), cc = min(c4, nrem - 4);
+    if (EPI == EPI_RES)
+      ex[p] = *reinterpret_cast<const float4*>(g.residual + (long)bz * g.strideC + (long)(m0 + wm + rc) * g.ldr + (n0 + wn) + cc);
+    else
+      ex[p] = *reinterpret_cast<const float4*>(g.rowtab + (long)((m0 + wm + rc) % g.rowtab_period) * g.N + (n0 + wn) + cc);
+  }
+}
+//   ep_store     image -> global, row-contiguous
+template <int EPI>
+__device__ __forceinline__ void ep_store(const HGemmArgs& g, const float* T, const float4 (&ex)[8], int m0, int n0, int wm, int wn,
+                                         int rb, int lane, int bz) {
+  const int mrem = g.M - (m0 + wm), nrem = g.N - (n0 + wn);
+  if (EPI == EPI_KVH) {
+    // cross K | V, head-major: this wave's 64 columns are exactly one head of K or of V (wn and the tile origin are
+    // multiples of 64), a row is one frame of one clip -> 128 contiguous bytes at [clip][K|V][head][frame][64]
+    _Float16* __restrict__ C = reinterpret_cast<_Float16*>(g.C);
+    const int c8 = (lane & 7) * 8;
+    const int ncol = n0 + wn, kv = ncol / g.kv_width, head = (ncol - kv * g.kv_width) >> 6, heads = g.kv_width >> 6;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = (lane >> 3) + 8 * p;
+      const float4 x0 = *reinterpret_cast<const float4*>(T + row * EP_LD + c8);
+      const float4 x1 = *reinterpret_cast<const float4*>(T + row * EP_LD + c8 + 4);
+      const half4 h0 = to_half4(x0.x, x0.y, x0.z, x0.w), h1 = to_half4(x1.x, x1.y, x1.z, x1.w);
+      const half8 hv = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+      const int m = m0 + wm + rb + row;
+      const int clip = m / g.vt_T, t = m - clip * g.vt_T;
+      if (m < g.M && ncol < g.N)
+        *reinterpret_cast<half8*>(C + ((((long)clip * 2 + kv) * heads + head) * g.vt_T + t) * 64 + c8) = hv;
+    }
+  } else if (EPI == EPI_F16) {
+    _Float16* __restrict__ C = reinterpret_cast<_Float16*>(g.C) + (long)bz * g.strideC + (long)(m0 + wm + rb) * g.ldc + (n0 + wn);
+    const int c8 = (lane & 7) * 8;                            // 8 lanes per row, 8 columns (16 bytes of f16) each
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = (lane >> 3) + 8 * p;
+      const float4 x0 = *reinterpret_cast<const float4*>(T + row * EP_LD + c8);
+      const float4 x1 = *reinterpret_cast<const float4*>(T + row * EP_LD + c8 + 4);
+      const half4 h0 = to_half4(x0.x, x0.y, x0.z, x0.w), h1 = to_half4(x1.x, x1.y, x1.z, x1.w);
+      const half8 hv = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+      if (rb + row < mrem && c8 < nrem) *reinterpret_cast<half8*>(C + (long)row * g.ldc + c8) = hv;
+    }
+  } else if (EPI == EPI_RES || EPI == EPI_TAB) {
+    float* __restrict__ C = reinterpret_cast<float*>(g.C) + (long)bz * g.strideC + (long)(m0 + wm + rb) * g.ldc + (n0 + wn);
+    const int c4 = (lane & 15) * 4;                           // 16 lanes per row, 4 columns (16 bytes of f32) each
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int row = (lane >> 4) + 4 * p;
+      const float4 x = *reinterpret_cast<const float4*>(T + row * EP_LD + c4);
+      if (rb + row < mrem && c4 < nrem)
+        *reinterpret_cast<float4*>(C + (long)row * g.ldc + c4) = make_float4(x.x + ex[p].x, x.y + ex[p].y, x.z + ex[p].z, x.w + ex[p].w);
+    }
+  } else {   // EPI_VT: image row = column n (head, dim), 32 consecutive time steps of one clip (T % 32 == ... see below)
+    _Float16* __restrict__ C = reinterpret_cast<_Float16*>(g.C);
+    const int c4 = (lane & 7) * 4;                            // 8 lanes per row, 4 time steps (8 bytes of f16) each
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int nl = (lane >> 3) + 8 * p;                     // column of this wave's 64
+      const float4 x = *reinterpret_cast<const float4*>(T + nl * EP_VLD + c4);
+      const int m = m0 + wm + rb + c4;                        // four consecutive rows; vt_T % 4 == 0, so one clip
+      const int clip = m / g.vt_T, t = m - clip * g.vt_T;
+      if (m < g.M && nl < nrem)
+        *reinterpret_cast<half4*>(C + ((long)clip * g.N + (n0 + wn + nl)) * ENC_TP + t) = to_half4(x.x, x.y, x.z, x.w);
+    }
+  }
+}
+// 64 x 64 wave tile, one image: write, hand-off, store, hand-off -- twice
+template <int EPI>
 __device__ __forceinline__ void hd_epilogue(const HGemmArgs& g, f32x16 (&acc)[2][2], float* T, int m0, int n0, int wm, int wn,
                                             int lane, int bz, const float (&bias)[2]) {
-  const int li = lane & 31, lh = lane >> 5;
-  const int mrem = g.M - (m0 + wm), nrem = g.N - (n0 + wn);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    // ---- write: lane = column 32 j + li, register r = row 8 (r >> 2) + 4 lh + (r & 3) of this 32-row half ----
-    if (EPI == EPI_VT) {
+    float4 ex[8];
+    ep_write<EPI>(g, acc[i], T, lane, bias);
+    ep_wave_sync();
+    ep_prefetch<EPI>(g, ex, m0, n0, wm, wn, 32 * i, lane, bz);       // (ahead of the image write it costs 12 - 18 registers: 128 is the budget here)
+    ep_store<EPI>(g, T, ex, m0, n0, wm, wn, 32 * i, lane, bz);
+    ep_wave_sync();                                  // the image is read before the second half overwrites it
+  }
+}
+// 128 x 64 wave tile, two images: the image of pass p + 1 is written BEFORE the hand-off of pass p, so a pass is one
+// LDS round trip instead of two (measured on the one-image form: 1 750 cycles from the first image write to the
+// hand-off and 1 790 from there to the last store -- each mostly queueing behind the other workgroup's k loop), and
+// the residual / positional operands of a pass are requested a whole pass ahead.
+template <int EPI>
+__device__ __forceinline__ void hd2_epilogue(const HGemmArgs& g, f32x16 (&acc)[4][2], float* T0, float* T1, int m0, int n0, int wm,
+                                             int wn, int lane, int bz, const float (&bias)[2]) {
+  float4 ex[2][8];
+  ep_prefetch<EPI>(g, ex[0], m0, n0, wm, wn, 0, lane, bz);
+  ep_write<EPI>(g, acc[0], T0, lane, bias);
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<float4*>(T + (32 * j + li) * EP_VLD + 8 * q + 4 * lh) =
-              make_float4(acc[i][j][4 * q] + bias[j], acc[i][j][4 * q + 1] + bias[j], acc[i][j][4 * q + 2] + bias[j],
-                          acc[i][j][4 * q + 3] + bias[j]);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = acc[i][j][r] + bias[j];
-          if ((EPI == EPI_F16 && g.gelu) || EPI == EPI_TAB) v = gelu_erf_e(v);
-          T[acc_row_e(r, lane) * EP_LD + 32 * j + li] = v;
-        }
+  for (int p = 0; p < 4; ++p) {
+    if (p + 1 < 4) {
+      ep_prefetch<EPI>(g, ex[(p + 1) & 1], m0, n0, wm, wn, 32 * (p + 1), lane, bz);
+      ep_write<EPI>(g, acc[p + 1], (p & 1) ? T0 : T1, lane, bias);     // its previous reader (pass p - 1) has issued its stores
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's image is complete (single-wave hand-off)
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- read back row-contiguous and store ----
-    if (EPI == EPI_KVH) {
-      // cross K | V, head-major: this wave's 64 columns are exactly one head of K or of V (wn and the tile origin are
-      // multiples of 64), a row is one frame of one clip -> 128 contiguous bytes at [clip][K|V][head][frame][64]
-      _Float16* __restrict__ C = reinterpret_cast<_Float16*>(g.C);
-      const int c8 = (lane & 7) * 8;
-      const int ncol = n0 + wn, kv = ncol / g.kv_width, head = (ncol - kv * g.kv_width) >> 6, heads = g.kv_width >> 6;
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int row = (lane >> 3) + 8 * p;
-        const float4 x0 = *reinterpret_cast<const float4*>(T + row * EP_LD + c8);
-        const float4 x1 = *reinterpret_cast<const float4*>(T + row * EP_LD + c8 + 4);
-        const half4 h0 = to_half4(x0.x, x0.y, x0.z, x0.w), h1 = to_half4(x1.x, x1.y, x1.z, x1.w);
-        const half8 hv = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-        const int m = m0 + wm + 32 * i + row;
-        const int clip = m / g.vt_T, t = m - clip * g.vt_T;
-        if (m < g.M && ncol < g.N)
-          *reinterpret_cast<half8*>(C + ((((long)clip * 2 + kv) * heads + head) * g.vt_T + t) * 64 + c8) = hv;
-      }
-    } else if (EPI == EPI_F16) {
-      _Float16* __restrict__ C = reinterpret_cast<_Float16*>(g.C) + (long)bz * g.strideC + (long)(m0 + wm + 32 * i) * g.ldc + (n0 + wn);
-      const int c8 = (lane & 7) * 8;                            // 8 lanes per row, 8 columns (16 bytes of f16) each
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int row = (lane >> 3) + 8 * p;
-        const float4 x0 = *reinterpret_cast<const float4*>(T + row * EP_LD + c8);
-        const float4 x1 = *reinterpret_cast<const float4*>(T + row * EP_LD + c8 + 4);
-        const half4 h0 = to_half4(x0.x, x0.y, x0.z, x0.w), h1 = to_half4(x1.x, x1.y, x1.z, x1.w);
-        const half8 hv = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-        if (32 * i + row < mrem && c8 < nrem) *reinterpret_cast<half8*>(C + (long)row * g.ldc + c8) = hv;
-      }
-    } else if (EPI == EPI_RES || EPI == EPI_TAB) {
-      float* __restrict__ C = reinterpret_cast<float*>(g.C) + (long)bz * g.strideC + (long)(m0 + wm + 32 * i) * g.ldc + (n0 + wn);
-      const int c4 = (lane & 15) * 4;                           // 16 lanes per row, 4 columns (16 bytes of f32) each
-      float4 ex[8];
-#pragma unroll
-      for (int p = 0; p < 8; ++p) {                             // residual / positional operands requested together
-        const int row = (lane >> 4) + 4 * p;
-        const int rc = min(32 * i + row, mrem - 1), cc = min(c4, nrem - 4);
-        if (EPI == EPI_RES)
-          ex[p] = *reinterpret_cast<const float4*>(g.residual + (long)bz * g.strideC + (long)(m0 + wm + rc) * g.ldr + (n0 + wn) + cc);
-        else
-          ex[p] = *reinterpret_cast<const float4*>(g.rowtab + (long)((m0 + wm + rc) % g.rowtab_period) * g.N + (n0 + wn) + cc);
-      }
-#pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        const int row = (lane >> 4) + 4 * p;
-        const float4 x = *reinterpret_cast<const float4*>(T + row * EP_LD + c4);
-        if (32 * i + row < mrem && c4 < nrem)
-          *reinterpret_cast<float4*>(C + (long)row * g.ldc + c4) = make_float4(x.x + ex[p].x, x.y + ex[p].y, x.z + ex[p].z, x.w + ex[p].w);
-      }
-    } else {   // EPI_VT: image row = column n (head, dim), 32 consecutive time steps of one clip (T % 32 == ... see below)
-      _Float16* __restrict__ C = reinterpret_cast<_Float16*>(g.C);
-      const int c4 = (lane & 7) * 4;                            // 8 lanes per row, 4 time steps (8 bytes of f16) each
-#pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        const int nl = (lane >> 3) + 8 * p;                     // column of this wave's 64
-        const float4 x = *reinterpret_cast<const float4*>(T + nl * EP_VLD + c4);
-        const int m = m0 + wm + 32 * i + c4;                    // four consecutive rows; vt_T % 4 == 0, so one clip
-        const int clip = m / g.vt_T, t = m - clip * g.vt_T;
-        if (m < g.M && nl < nrem)
-          *reinterpret_cast<half4*>(C + ((long)clip * g.N + (n0 + wn + nl)) * ENC_TP + t) = to_half4(x.x, x.y, x.z, x.w);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_s_waitcnt(0xc07f);          // the image is read before the second half overwrites it
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    ep_wave_sync();
+    ep_store<EPI>(g, (p & 1) ? T1 : T0, ex[p & 1], m0, n0, wm, wn, 32 * p, lane, bz);
   }
 }
 
@@ -796,9 +834,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     stage = stage + 1 == HD_STAGES ? 0 : stage + 1;
   }
   __builtin_amdgcn_s_barrier();          // every wave has read its last operands: the stages become epilogue images
-  float* T = reinterpret_cast<float*>(smem + wave * 12288);
-  hd_epilogue<EPI>(g, reinterpret_cast<f32x16 (&)[2][2]>(acc[0]), T, m0, n0, wm, wn, lane, bz, bias);
-  hd_epilogue<EPI>(g, reinterpret_cast<f32x16 (&)[2][2]>(acc[2]), T, m0, n0, wm + 64, wn, lane, bz, bias);
+  static_assert(4 * 2 * EP_IMAGE_BYTES <= HD_STAGES * HD2_STAGE_BYTES, "two epilogue images per wave");
+  float* T0 = reinterpret_cast<float*>(smem + wave * (2 * EP_IMAGE_BYTES));
+  hd2_epilogue<EPI>(g, acc, T0, T0 + EP_IMAGE_BYTES / 4, m0, n0, wm, wn, lane, bz, bias);
 }
 
 }  // namespace
