@@ -108,7 +108,6 @@ hipError_t attn_decoder_kv16(const float* q, long ldq, const void* kv, long kv_b
                              hipStream_t s);
 hipError_t embed_tokens_f32(const int* tokens, const float* tok_emb, const float* pos_emb, int pos, const int* pos_dev,
                             float* x, int B, int D, hipStream_t s);
-hipError_t advance_counters(int* pos_dev, int* step_dev, hipStream_t s);
 // 48 -> 16 kHz resampler (rubato FftFixedIn(.., 1024, 1, 1) geometry)
 constexpr int RS_FFT_IN = 1026, RS_FFT_OUT = 342, RS_CHUNK = 1024;
 constexpr int RS_K = 1040;   // 1026 padded to the GEMM's k granularity
@@ -128,6 +127,18 @@ struct TsState {
   int seek, seek_end;  // window start and audio length in mel frames
   int pad;
 };
+// A pick kernel that also starts the next decoder step (x != nullptr): counters = {position of the PREVIOUS step,
+// index of this pick, ticket}.  Every workgroup reads them when it starts; it embeds its clip's pick at position
+// counters[0] + 1 into x; the workgroup that finishes LAST (ticket) stores the new position and pick index -- all others
+// have read the old ones by then, and the kernels behind the pick read the new position.  One launch instead of three
+// (pick, embedding, counter kernel).
+struct StepFuse {
+  const float* tok_emb;                // [V][D]
+  const float* pos_emb;                // [n_text_ctx][D]
+  float* x;                            // [B][D] residual stream of the next step; nullptr: plain pick (step from step_dev)
+  int D;
+  int* counters;                       // {pos, step, ticket}
+};
 struct TsPickArgs {
   const float* logits;                 // [B][V]
   const unsigned char* mask;           // [V] suppressed at every position (nullable)
@@ -139,11 +150,12 @@ struct TsPickArgs {
   int* tids_all;                       // [steps][B] most probable timestamp token at that step
   const int* step_dev;
   int* done_count;                     // number of clips that are done
+  StepFuse fuse;
 };
 hipError_t ts_pick(const TsPickArgs& a, int B, hipStream_t s);
 
 hipError_t argmax_f32(const float* logits, const unsigned char* mask, const unsigned char* mask_first,
                       const int* step_dev, int V, int* tokens_out, int* tokens_all, float* best, int B, hipStream_t s,
-                      int eot = -1, int* finished = nullptr, int* done_count = nullptr);
+                      int eot = -1, int* finished = nullptr, int* done_count = nullptr, const StepFuse* fuse = nullptr);
 
 }  // namespace crispy

@@ -668,7 +668,7 @@ int reserve_dec(crispy_asr* h, int batch, int max_tokens) {
   HIP_TRY(hipMalloc(&h->d_best, B * C * sizeof(float)));
   HIP_TRY(hipMalloc(&h->d_tok, B * sizeof(int)));
   HIP_TRY(hipMalloc(&h->d_tokens_all, B * C * sizeof(int)));
-  HIP_TRY(hipMalloc(&h->d_counters, 2 * sizeof(int)));
+  HIP_TRY(hipMalloc(&h->d_counters, 4 * sizeof(int)));      // position, pick index, ticket of the fused pick, spare
   HIP_TRY(hipMalloc(&h->d_ts_state, B * sizeof(TsState)));
   HIP_TRY(hipMalloc(&h->d_tids_all, B * C * sizeof(int)));
   HIP_TRY(hipMalloc(&h->d_done_count, sizeof(int)));
@@ -707,13 +707,14 @@ int decoder_logits(crispy_asr* h, int batch, hipStream_t s) {
 // dev_pos = false: the position is the host value `pos` (prompt tokens).
 // dev_pos = true : the position is read from h->d_counters[0] by the kernels, so the identical launch
 //                  sequence can be captured once in a hipGraph and replayed for every generated token.
-int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logits, hipStream_t s) {
+int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logits, hipStream_t s, bool embedded = false) {
   const int dt = h->hp.n_text_state, H = h->hp.n_text_head, Tn = h->hp.n_audio_ctx, C = h->hp.n_text_ctx;
   const int* pos_dev = dev_pos ? h->d_counters : nullptr;
   // <= SKINNY_MAX_M clips: the projections run on the skinny kernel (row blocks of 32 clips), which folds the preceding LayerNorm in and writes q and
   // k|v of the self-attention block from one launch (17 launches fewer per step on Whisper-tiny)
   const bool fold = batch <= SKINNY_MAX_M && dt % 128 == 0;
-  HIP_TRY(embed_tokens_f32(h->d_tok, h->tok_emb, h->dec_pos, pos, pos_dev, h->d_dx, batch, dt, s));
+  if (!embedded)      // (a fused pick has written the residual stream already)
+    HIP_TRY(embed_tokens_f32(h->d_tok, h->tok_emb, h->dec_pos, pos, pos_dev, h->d_dx, batch, dt, s));
   for (size_t l = 0; l < h->dec.size(); ++l) {
     const DecLayer& L = h->dec[l];
     float* selfkv = h->d_selfkv + l * (size_t)batch * C * 2 * dt;
@@ -870,6 +871,10 @@ int prefill(crispy_asr* h, const float* d_enc, int batch, const int* prompt, int
   return CRISPY_OK;
 }
 
+StepFuse step_fuse(crispy_asr* h) {
+  return StepFuse{h->tok_emb, h->dec_pos, h->d_dx, h->hp.n_text_state, h->d_counters};
+}
+
 TsPickArgs ts_args(crispy_asr* h, int rules, const unsigned char* mask, const unsigned char* mask_first) {
   const Special sp = special_tokens(h);
   TsPickArgs a{};
@@ -905,7 +910,8 @@ int decode_ts(crispy_asr* h, const float* d_enc, int batch, const int* prompt, i
   if (rc != CRISPY_OK) return rc;
   std::vector<TsState> st(batch);
   for (int b = 0; b < batch; ++b) st[b] = TsState{-1, -1, 0, -1, 0, seek ? seek[b] : 0, seek_end ? seek_end[b] : (1 << 30), 0};
-  const int counters[2] = {pos, 0};
+  // {position of the previous step, index of the next pick, ticket}: the fused pick of a replay embeds at counters[0] + 1
+  const int counters[4] = {pos - 1, 0, 0, 0};
   HIP_TRY(hipMemcpyAsync(h->d_counters, counters, sizeof(counters), hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(h->d_ts_state, st.data(), sizeof(TsState) * batch, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemsetAsync(h->d_done_count, 0, sizeof(int), s));
@@ -917,9 +923,10 @@ int decode_ts(crispy_asr* h, const float* d_enc, int batch, const int* prompt, i
       if (h->ts_graph) { (void)hipGraphExecDestroy(h->ts_graph); h->ts_graph = nullptr; }
       hipGraph_t graph = nullptr;
       HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-      hipError_t pe = ts_pick(pa, batch, s);
-      rc = pe == hipSuccess ? decoder_step(h, batch, 0, true, true, s) : CRISPY_OK;
-      if (pe == hipSuccess && rc == CRISPY_OK) pe = advance_counters(h->d_counters, h->d_counters + 1, s);
+      TsPickArgs pf = pa;                     // the pick of a replay also embeds its token and moves the counters on
+      pf.fuse = step_fuse(h);
+      hipError_t pe = ts_pick(pf, batch, s);
+      rc = pe == hipSuccess ? decoder_step(h, batch, 0, true, true, s, true) : CRISPY_OK;
       const hipError_t ce = hipStreamEndCapture(s, &graph);
       if (rc != CRISPY_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
       HIP_TRY(pe);
@@ -960,12 +967,10 @@ int decode_ts(crispy_asr* h, const float* d_enc, int batch, const int* prompt, i
 // pick a token from the current logits (step-aware suppression), record it, run the next step on it,
 // advance the device counters: the body of one generated token
 int generation_body(crispy_asr* h, int batch, hipStream_t s) {
+  const StepFuse f = step_fuse(h);         // pick + embedding of the pick + counters in one launch
   HIP_TRY(argmax_f32(h->d_logits, h->d_suppress, h->d_suppress_first, h->d_counters + 1, h->hp.n_vocab, h->d_tok,
-                     h->d_tokens_all, h->d_best, batch, s, h->eot, h->d_finished, h->d_done_count));
-  int rc = decoder_step(h, batch, 0, true, true, s);
-  if (rc != CRISPY_OK) return rc;
-  HIP_TRY(advance_counters(h->d_counters, h->d_counters + 1, s));
-  return CRISPY_OK;
+                     h->d_tokens_all, h->d_best, batch, s, h->eot, h->d_finished, h->d_done_count, &f));
+  return decoder_step(h, batch, 0, true, true, s, true);
 }
 
 }  // namespace
@@ -1041,7 +1046,7 @@ int crispy_asr_decode_greedy_lang_device(crispy_asr* h, const float* d_enc, int 
   int pos = 0;
   rc = prefill(h, d_enc, batch, prompt, n_prompt, lang_tokens, s, &pos);
   if (rc != CRISPY_OK) return rc;
-  const int counters[2] = {pos, 0};
+  const int counters[4] = {pos - 1, 0, 0, 0};     // {position of the previous step, index of the next pick, ticket} (StepFuse)
   HIP_TRY(hipMemcpyAsync(h->d_counters, counters, sizeof(counters), hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemsetAsync(h->d_done_count, 0, sizeof(int), s));
   HIP_TRY(hipMemsetAsync(h->d_finished, 0, sizeof(int) * batch, s));

@@ -862,15 +862,31 @@ __global__ __launch_bounds__(256) void embed_kernel(const int* __restrict__ toke
 // greedy pick: argmax over the vocabulary with a suppression mask (mask[v] != 0 -> -inf); ties -> lowest id.
 // One 1024-thread block per clip; every thread walks the row in float4 / uchar4 steps with four loads in flight
 // (the 256-thread, one-float-per-iteration version ran at 0.1 TB/s: 118 us for 64 x 51865 logits).
+// the tail of a fused pick: embedding of the pick for the next step, then the counters by the last workgroup to finish
+__device__ __forceinline__ void step_fuse_tail(const StepFuse& f, int tok, int pos, int step, int b, int tid) {
+  for (int c = tid; c < f.D; c += 1024) f.x[(long)b * f.D + c] = f.tok_emb[(long)tok * f.D + c] + f.pos_emb[(long)pos * f.D + c];
+  if (tid == 0) {
+    __threadfence();
+    const unsigned t = atomicAdd(reinterpret_cast<unsigned*>(f.counters + 2), 1u);
+    if (t == gridDim.x - 1) {              // everyone else has finished, so everyone has read the old counters
+      f.counters[0] = pos;
+      f.counters[1] = step + 1;
+      f.counters[2] = 0;
+    }
+  }
+}
+
 __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, const unsigned char* __restrict__ mask,
                                                       const unsigned char* __restrict__ mask_first,
                                                       const int* __restrict__ step_dev, int V, int* __restrict__ tokens_out,
                                                       int* __restrict__ tokens_all, float* __restrict__ best_logit,
-                                                      int eot, int* __restrict__ finished, int* __restrict__ done_count) {
+                                                      int eot, int* __restrict__ finished, int* __restrict__ done_count, StepFuse fuse) {
   __shared__ float sv[16];
   __shared__ int si[16];
+  __shared__ int s_tok;
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int step = step_dev ? *step_dev : 0;
+  const int step = fuse.x ? fuse.counters[1] : step_dev ? *step_dev : 0;
+  const int pos = fuse.x ? fuse.counters[0] + 1 : 0;
   if (step == 0 && mask_first) mask = mask_first;
   const float* lg = logits + (long)b * V;
   float bv = -INFINITY;
@@ -912,6 +928,11 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
     if (best_logit) best_logit[(long)step * gridDim.x + b] = bv;
     // first EOT of this clip: the host polls done_count and stops replaying the step graph once every clip has one
     if (finished && bi == eot && !finished[b]) { finished[b] = 1; atomicAdd(done_count, 1); }
+    s_tok = bi;
+  }
+  if (fuse.x) {
+    __syncthreads();
+    step_fuse_tail(fuse, s_tok, pos, step, b, tid);
   }
 }
 
@@ -923,8 +944,10 @@ __global__ __launch_bounds__(1024) void ts_pick_kernel(TsPickArgs a) {
   __shared__ float s_v[2][16];
   __shared__ int s_i[2][16];
   __shared__ float s_sum[16];
+  __shared__ int s_tok;
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int step = a.step_dev ? *a.step_dev : 0;
+  const int step = a.fuse.x ? a.fuse.counters[1] : a.step_dev ? *a.step_dev : 0;
+  const int pos = a.fuse.x ? a.fuse.counters[0] + 1 : 0;
   TsState st = a.st[b];
   if (st.done) {   // finished window: keep feeding EOT so that the batch stays in lock step
     if (tid == 0) {
@@ -932,6 +955,7 @@ __global__ __launch_bounds__(1024) void ts_pick_kernel(TsPickArgs a) {
       a.tokens_all[(long)step * gridDim.x + b] = a.eot;
       a.tids_all[(long)step * gridDim.x + b] = a.beg;
     }
+    if (a.fuse.x) step_fuse_tail(a.fuse, a.eot, pos, step, b, tid);
     return;
   }
   const float* lg = a.logits + (long)b * a.V;
@@ -1024,12 +1048,12 @@ __global__ __launch_bounds__(1024) void ts_pick_kernel(TsPickArgs a) {
     if (a.rules == TS_RULES_WCPP && st.last_ts >= 0 && st.seek + 2 * (st.last_ts - a.beg) + 100 >= st.seek_end) done = true;
     if (done) { st.done = 1; atomicAdd(a.done_count, 1); }
     a.st[b] = st;
+    s_tok = pick;
   }
-}
-
-// end of a decode step: position and step counters advance on the device (graph-replay friendly)
-__global__ void advance_kernel(int* __restrict__ pos_dev, int* __restrict__ step_dev) {
-  if (threadIdx.x == 0) { *pos_dev += 1; *step_dev += 1; }
+  if (a.fuse.x) {
+    __syncthreads();
+    step_fuse_tail(a.fuse, s_tok, pos, step, b, tid);
+  }
 }
 
 }  // namespace
@@ -1130,17 +1154,13 @@ hipError_t embed_tokens_f32(const int* tokens, const float* tok_emb, const float
 }
 hipError_t argmax_f32(const float* logits, const unsigned char* mask, const unsigned char* mask_first,
                       const int* step_dev, int V, int* tokens_out, int* tokens_all, float* best, int B, hipStream_t s,
-                      int eot, int* finished, int* done_count) {
+                      int eot, int* finished, int* done_count, const StepFuse* fuse) {
   hipLaunchKernelGGL(argmax_kernel, dim3(B), dim3(1024), 0, s, logits, mask, mask_first, step_dev, V, tokens_out,
-                     tokens_all, best, eot, finished, done_count);
+                     tokens_all, best, eot, finished, done_count, fuse ? *fuse : StepFuse{});
   return hipGetLastError();
 }
 hipError_t ts_pick(const TsPickArgs& a, int B, hipStream_t s) {
   hipLaunchKernelGGL(ts_pick_kernel, dim3(B), dim3(1024), 0, s, a);
-  return hipGetLastError();
-}
-hipError_t advance_counters(int* pos_dev, int* step_dev, hipStream_t s) {
-  hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, s, pos_dev, step_dev);
   return hipGetLastError();
 }
 
