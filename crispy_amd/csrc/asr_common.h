@@ -58,6 +58,7 @@ struct GemmArgs {
   //    decoder self-attention block in one launch.
   const float* ln_s; const float* ln_c;
   float* C2; long ldc2; int n_split;
+  int c2_half;                                // skinny kernel: C2 is an f16 buffer (the decoder's self K|V cache in precision mode 1)
   // Tiled kernel only: head-major store for the cross K|V projection.  Row m = (clip b, frame t) with hm_rows frames
   // per clip, column n = (K or V, head, dim): element goes to C[((b * 2 + kv) * heads + head) * hm_rows * 64 + t * 64
   // + dim], so that one (clip, head) K or V block is a contiguous [hm_rows][64] run for the decode-step attention.
@@ -105,7 +106,7 @@ hipError_t attn_decoder_f32(const float* q, long ldq, const float* kv, long kv_b
 // the same kernel over an f16 K|V buffer (cross-attention in precision mode 1)
 hipError_t attn_decoder_kv16(const float* q, long ldq, const void* kv, long kv_batch_stride, long ldkv, long head_stride,
                              long koff, long voff, int n_keys_base, const int* pos_dev, float* out, long ldo, int B, int heads,
-                             hipStream_t s);
+                             hipStream_t s, int max_keys = 0);    // max_keys: upper bound of n_keys_base + *pos_dev (0: n_keys_base)
 hipError_t embed_tokens_f32(const int* tokens, const float* tok_emb, const float* pos_emb, int pos, const int* pos_dev,
                             float* x, int B, int D, hipStream_t s);
 // 48 -> 16 kHz resampler (rubato FftFixedIn(.., 1024, 1, 1) geometry)

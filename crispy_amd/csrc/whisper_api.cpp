@@ -78,6 +78,8 @@ struct crispy_asr {
   int* d_counters = nullptr;                 // [0] position, [1] generation step (device-side, advanced in-graph)
   hipGraphExec_t dec_graph = nullptr;        // one captured decode step, replayed per generated token
   int dec_graph_batch = 0;
+  int dec_max_keys = 0;                      // positions the current decode call can reach (prompt + new tokens): picks the
+  int dec_graph_keys = 0, ts_graph_keys = 0; //   self-attention kernel of mode 1, baked into the captured steps
   // timestamp-mode decoding (whisper.cpp no_timestamps = false)
   TsState* d_ts_state = nullptr;             // [dcap_batch]
   int* d_tids_all = nullptr;                 // [n_text_ctx][dcap_batch]
@@ -721,10 +723,15 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
     const float* xkv = h->d_xkv + l * (size_t)batch * Tn * 2 * dt;
     // causal self-attention against the cache; k | v of this position go straight into the cache row (b, pos)
     float* kv_dst = selfkv + (dev_pos ? 0 : (size_t)pos * 2 * dt);
+    // mode 1: the self K|V cache is f16, as whisper.cpp's kv_self is (it aliases the f32 cache: every decode call
+    // starts with its own prefill); the projection stores halves, the attention requests all its keys up front
+    const bool kv16 = fold && h->enc_precision == 1 && h->dec_max_keys > 0 && h->dec_max_keys <= 512;
+    _Float16* selfkv_h = reinterpret_cast<_Float16*>(h->d_selfkv) + l * (size_t)batch * C * 2 * dt;
     if (fold) {
       GemmArgs g = gemm(h->d_dx, dt, L.qkv_lw, dt, h->d_dq, dt, nullptr, batch, 3 * dt, dt);
       g.ln_s = L.qkv_ls; g.ln_c = L.qkv_lc;
       g.C2 = kv_dst; g.ldc2 = (long)C * 2 * dt; g.n_split = dt;
+      if (kv16) { g.C2 = reinterpret_cast<float*>(selfkv_h + (dev_pos ? 0 : (size_t)pos * 2 * dt)); g.c2_half = 1; }
       if (dev_pos) { g.c_off_dev = h->d_counters; g.c_off_scale = 2L * dt; }
       HIP_TRY(gemm_f32_nt(g, 1, s));
     } else {
@@ -734,8 +741,12 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
       if (dev_pos) { g.c_off_dev = h->d_counters; g.c_off_scale = 2L * dt; }
       HIP_TRY(gemm_f32_nt(g, 1, s));
     }
-    HIP_TRY(attn_decoder_f32(h->d_dq, dt, selfkv, (long)C * 2 * dt, 2L * dt, 64, 0, dt, dev_pos ? 1 : pos + 1, pos_dev,
-                             h->d_datt, dt, batch, H, s));
+    if (kv16)
+      HIP_TRY(attn_decoder_kv16(h->d_dq, dt, selfkv_h, (long)C * 2 * dt, 2L * dt, 64, 0, dt, dev_pos ? 1 : pos + 1, pos_dev,
+                                h->d_datt, dt, batch, H, s, h->dec_max_keys));
+    else
+      HIP_TRY(attn_decoder_f32(h->d_dq, dt, selfkv, (long)C * 2 * dt, 2L * dt, 64, 0, dt, dev_pos ? 1 : pos + 1, pos_dev,
+                               h->d_datt, dt, batch, H, s));
     {
       GemmArgs g = gemm(h->d_datt, dt, L.out_w, dt, h->d_dx, dt, L.out_b, batch, dt, dt);
       g.residual = h->d_dx; g.ldr = dt;
@@ -905,6 +916,7 @@ int decode_ts(crispy_asr* h, const float* d_enc, int batch, const int* prompt, i
   hipStream_t s = h->stream;
   int rc = reserve_dec(h, batch, n_prompt + max_new);
   if (rc != CRISPY_OK) return rc;
+  h->dec_max_keys = n_prompt + max_new;
   int pos = 0;
   rc = prefill(h, d_enc, batch, prompt, n_prompt, lang_tokens, s, &pos);
   if (rc != CRISPY_OK) return rc;
@@ -919,7 +931,9 @@ int decode_ts(crispy_asr* h, const float* d_enc, int batch, const int* prompt, i
   const TsPickArgs pa = ts_args(h, rules, mask, mask_first);
   int steps_run = 1;      // picks made = decoder steps replayed + the final pick
   if (max_new > 1) {
-    if (!h->ts_graph || h->ts_graph_batch != batch || h->ts_graph_rules != rules || h->ts_graph_mask != mask) {
+    const int key_class = h->dec_max_keys <= 128 ? 128 : h->dec_max_keys <= 256 ? 256 : 512;
+    if (!h->ts_graph || h->ts_graph_batch != batch || h->ts_graph_rules != rules || h->ts_graph_mask != mask ||
+        h->ts_graph_keys != key_class) {
       if (h->ts_graph) { (void)hipGraphExecDestroy(h->ts_graph); h->ts_graph = nullptr; }
       hipGraph_t graph = nullptr;
       HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -934,7 +948,7 @@ int decode_ts(crispy_asr* h, const float* d_enc, int batch, const int* prompt, i
       const hipError_t ie = hipGraphInstantiate(&h->ts_graph, graph, nullptr, nullptr, 0);
       (void)hipGraphDestroy(graph);
       HIP_TRY(ie);
-      h->ts_graph_batch = batch; h->ts_graph_rules = rules; h->ts_graph_mask = mask;
+      h->ts_graph_batch = batch; h->ts_graph_rules = rules; h->ts_graph_mask = mask; h->ts_graph_keys = key_class;
     }
     int done = 0;
     for (int i = 0; i + 1 < max_new; ++i) {
@@ -1042,6 +1056,7 @@ int crispy_asr_decode_greedy_lang_device(crispy_asr* h, const float* d_enc, int 
   hipStream_t s = h->stream;
   int rc = reserve_dec(h, batch, n_prompt + max_new);
   if (rc != CRISPY_OK) return rc;
+  h->dec_max_keys = n_prompt + max_new;
   const int V = h->hp.n_vocab;
   int pos = 0;
   rc = prefill(h, d_enc, batch, prompt, n_prompt, lang_tokens, s, &pos);
@@ -1053,7 +1068,8 @@ int crispy_asr_decode_greedy_lang_device(crispy_asr* h, const float* d_enc, int 
   HIP_TRY(hipStreamSynchronize(s));
   int steps_run = 1;      // picks made: replayed decoder steps + the final pick
   if (max_new > 1) {
-    if (!h->dec_graph || h->dec_graph_batch != batch) {
+    const int key_class = h->dec_max_keys <= 128 ? 128 : h->dec_max_keys <= 256 ? 256 : 512;
+    if (!h->dec_graph || h->dec_graph_batch != batch || h->dec_graph_keys != key_class) {
       if (h->dec_graph) { (void)hipGraphExecDestroy(h->dec_graph); h->dec_graph = nullptr; }
       hipGraph_t graph = nullptr;
       HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -1064,7 +1080,7 @@ int crispy_asr_decode_greedy_lang_device(crispy_asr* h, const float* d_enc, int 
       const hipError_t ie = hipGraphInstantiate(&h->dec_graph, graph, nullptr, nullptr, 0);
       (void)hipGraphDestroy(graph);
       HIP_TRY(ie);
-      h->dec_graph_batch = batch;
+      h->dec_graph_batch = batch; h->dec_graph_keys = key_class;
     }
     int done = 0;
     for (int i = 0; i + 1 < max_new; ++i) {

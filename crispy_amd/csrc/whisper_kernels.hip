@@ -297,7 +297,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_f32_kernel(GemmArgs g) {
     }
     if (GELU) v = gelu_erf(v);
     if (RES) v += e_res[q];
-    if (tid < ET && m < g.M && n0 + (tid & 31) < g.N) C[(long)m * ldc + enn] = v;   // only the stores are predicated
+    if (tid < ET && m < g.M && n0 + (tid & 31) < g.N) {                             // only the stores are predicated
+      if (second && g.c2_half) (reinterpret_cast<_Float16*>(g.C2) + coff - g.n_split)[(long)m * ldc + enn] = (_Float16)v;
+      else C[(long)m * ldc + enn] = v;
+    }
   }
 }
 
@@ -766,11 +769,15 @@ __global__ __launch_bounds__(64 * AD_WAVES) void attn_dec_kernel(const float* __
 // with 4 KB per wave in flight.  V does not wait for the scores; nothing goes through LDS but the 16 partial results.
 // Same partitioning and merge as attn_dec_kernel (per-wave max / sum / P.V merged by wave 0).
 // ---------------------------------------------------------------------------------------------
-constexpr int ADX_SLOTS = 12;                 // key slots of 8 keys per wave: 16 waves x 96 keys >= 1536
+// ADX_SLOTS = key slots of 8 keys per wave: 12 for the cross-attention (16 waves x 96 keys >= 1536); 1 / 2 / 4 for the
+// self-attention over the f16 K|V cache of mode 1 (<= 128 / 256 / 512 positions; the bound is known when the step is
+// captured, the key count itself comes from the device counter).
+template <int ADX_SLOTS>
 __global__ __launch_bounds__(64 * AD_WAVES) void attn_dec_x16_kernel(const float* __restrict__ q, long ldq,
                                                        const _Float16* __restrict__ kv, long kv_batch_stride,
-                                                       long ldkv, long head_stride, long koff, long voff, int n_keys,
-                                                       float* __restrict__ out, long ldo) {
+                                                       long ldkv, long head_stride, long koff, long voff, int n_keys_base,
+                                                       const int* __restrict__ pos_dev, float* __restrict__ out, long ldo) {
+  const int n_keys = n_keys_base + (pos_dev ? *pos_dev : 0);
   typedef _Float16 half8 __attribute__((ext_vector_type(8)));
   __shared__ __attribute__((aligned(16))) float part_o[AD_WAVES][64];
   __shared__ float part_m[AD_WAVES], part_l[AD_WAVES];
@@ -1137,10 +1144,17 @@ hipError_t attn_decoder_f32(const float* q, long ldq, const float* kv, long kv_b
 }
 hipError_t attn_decoder_kv16(const float* q, long ldq, const void* kv, long kv_batch_stride, long ldkv, long head_stride,
                              long koff, long voff, int n_keys_base, const int* pos_dev, float* out, long ldo, int B, int heads,
-                             hipStream_t s) {
-  if (!pos_dev && n_keys_base <= AD_WAVES * 8 * ADX_SLOTS && ldkv == 64 && AD_WAVES == 16) {   // cross-attention: all of K|V requested up front
-    hipLaunchKernelGGL(attn_dec_x16_kernel, dim3(heads, B), dim3(64 * AD_WAVES), 0, s, q, ldq,
-                       reinterpret_cast<const _Float16*>(kv), kv_batch_stride, ldkv, head_stride, koff, voff, n_keys_base, out, ldo);
+                             hipStream_t s, int max_keys) {
+  const int bound = max_keys > 0 ? max_keys : n_keys_base;
+  if ((max_keys > 0 || !pos_dev) && bound <= AD_WAVES * 8 * 12 && AD_WAVES == 16) {   // every byte of K|V requested up front
+    const _Float16* kvh = reinterpret_cast<const _Float16*>(kv);
+#define CRISPY_ADX(SL) hipLaunchKernelGGL(attn_dec_x16_kernel<SL>, dim3(heads, B), dim3(64 * AD_WAVES), 0, s, q, ldq, kvh, \
+                                          kv_batch_stride, ldkv, head_stride, koff, voff, n_keys_base, pos_dev, out, ldo)
+    if (bound <= AD_WAVES * 8) CRISPY_ADX(1);
+    else if (bound <= AD_WAVES * 16) CRISPY_ADX(2);
+    else if (bound <= AD_WAVES * 32) CRISPY_ADX(4);
+    else CRISPY_ADX(12);
+#undef CRISPY_ADX
     return hipGetLastError();
   }
   hipLaunchKernelGGL(attn_dec_kernel<_Float16>, dim3(heads, B), dim3(64 * AD_WAVES), 0, s, q, ldq,

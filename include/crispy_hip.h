@@ -253,7 +253,8 @@ int crispy_asr_synchronize(crispy_asr *h);
  * against the float64 oracle pin to 1e-4.  1: f16 operands with f32 accumulation (weights stored as f16, activations
  * rounded to f16 on the way into LDS) -- the numerics of whisper.cpp's ggml matrix products [UPSTREAM-RECALL], on
  * v_mfma_f32_32x32x16_f16, activations that only feed a matrix product kept in f16, the whole convolution stem and the
- * encoder attention on the f16 matrix cores.  Decoder in this mode: cross K|V projected and streamed in f16, logits =
+ * encoder attention on the f16 matrix cores.  Decoder in this mode: cross K|V and the self-attention K|V cache kept in
+ * f16 (as whisper.cpp's kv_self / kv_cross are), logits =
  * f16(LayerNorm(x)) . f16(token embedding)^T with f32 accumulation (whisper.cpp's f16 embedding under ggml's mul_mat);
  * the decoder's own projections, self-attention, LayerNorm and soft-max stay f32. */
 int crispy_asr_set_precision(crispy_asr *h, int mode);
