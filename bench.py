@@ -186,7 +186,7 @@ def asr_leg(local_rank: int, clips: int = 64, new_tokens: int = 32):
         return t
 
     def decode_n(n):
-        model.decode_greedy_device(enc.data_ptr(), clips, prompt, 2)       # graph for this mode is warm
+        model.decode_greedy_device(enc.data_ptr(), clips, prompt, n)       # the captured step for this mode and reach is warm
         t0 = time.perf_counter()
         model.decode_greedy_device(enc.data_ptr(), clips, prompt, n)
         return time.perf_counter() - t0
