@@ -653,6 +653,21 @@ def test_large_v3_turbo_dimensions_parity(oracle):
     toks, _ = m.transcribe_tokens([x], prompt, 3)
     rt, rb, rm = WO.greedy_decode(W, hp, ref, prompt, 3)
     assert_picks(toks[0], rt, rm, 1e-3, 3, "large-v3-turbo dims")
+    # precision mode 1 at these dimensions (256 x 128-tile GEMMs with N = 1280 / 2560 / 5120 and K = 384 / 1280 / 5120,
+    # the f16 self / cross K|V caches with 20 heads, the K-chunks-per-wave 20 logits kernel): the encoder against the
+    # f16-operand oracle with the bars of the Whisper-tiny test, the picks wherever the f32 margin resolves them
+    ref16 = WO.encoder_forward_f16(W, hp, oracle.oracle_logmel(x, whisper_mel_filters(128)))
+    try:
+        m.set_precision(1)
+        enc16 = m.encode([x])[0]
+        toks16, _ = m.transcribe_tokens([x], prompt, 3)
+    finally:
+        m.set_precision(0)
+    peak = np.abs(ref16).max()
+    rms16 = np.sqrt(np.mean((enc16 - ref16) ** 2)) / peak
+    rms64 = np.sqrt(np.mean((enc16 - ref) ** 2)) / peak
+    assert np.abs(enc16 - ref16).max() / peak <= 4e-4 and rms16 <= 8e-5 and rms16 < 0.7 * rms64, (rms16, rms64)
+    assert_picks(toks16[0], rt, rm, 0.05, 1, "large-v3-turbo dims, mode 1")
 
 
 def test_decode_batches_beyond_64_clips(model):
