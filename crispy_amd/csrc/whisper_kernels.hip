@@ -187,8 +187,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_f32_kernel(GemmArgs g) {
   float (*rstat)[32][2] = reinterpret_cast<float (*)[32][2]>(sk_smem + NW * SK_WAVE_LDS);
   constexpr int ET = NW >= 16 ? 1024 : NW >= 8 ? 512 : 256;    // threads that finish outputs (12 waves: the first 512)
   constexpr int RP = ET / 32, NQ = 32 / RP;    // epilogue: RP rows per pass, NQ passes
-  constexpr int PF = NW > 12 ? 2 : SK_PF;      // 16 waves: 128 registers per lane, two chunks in flight
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  constexpr int PF = NW > 12 ? 2 : SK_PF;      // 16 waves: 128 registers per lane, two chunks in flight (three spill 35 - 67 registers even with scalar bases)
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int li = lane & 31, lh = lane >> 5;
   const int n0 = blockIdx.x * 32;
   const int mb = blockIdx.y * 32;            // row block of 32 clips
@@ -205,12 +205,15 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_f32_kernel(GemmArgs g) {
   // row-per-lane 16-byte reads are conflict-free.  Operand registers, MFMA order and results are those of the
   // direct-load form.
   const int lr = lane >> 3, lc = (lane & 7) ^ lr;
-  const float* wsrc[4];
-  const float* asrc[4];
+  // wave-uniform bases (scalar registers) + 32-bit byte offsets per lane: eight address registers instead of sixteen,
+  // which is what lets the 16-wave form keep three chunks in flight inside its 128 registers
+  const char* __restrict__ Wb = reinterpret_cast<const char*>(W + kbeg);
+  const char* __restrict__ Ab = reinterpret_cast<const char*>(A + kbeg);
+  unsigned wsrc[4], asrc[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    wsrc[j] = W + (long)min(n0 + lr + 8 * j, g.N - 1) * g.ldw + kbeg + 4 * lc;
-    asrc[j] = A + (long)min(mb + lr + 8 * j, g.M - 1) * g.lda + kbeg + 4 * lc;   // rows >= M: clamped row, never stored
+    wsrc[j] = (unsigned)(((long)min(n0 + lr + 8 * j, g.N - 1) * g.ldw + 4 * lc) * 4);
+    asrc[j] = (unsigned)(((long)min(mb + lr + 8 * j, g.M - 1) * g.lda + 4 * lc) * 4);   // rows >= M: clamped row, never stored
   }
   f32x4* stw = reinterpret_cast<f32x4*>(sk_smem + wave * SK_WAVE_LDS);
   f32x4* sta = stw + 256;
@@ -226,8 +229,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_f32_kernel(GemmArgs g) {
   f32x4 w0[4], a0[4], w1[4], a1[4], w2[4], a2[4];
 #define SK_REQUEST(WR, AR, KO)                                            \
   _Pragma("unroll") for (int j = 0; j < 4; ++j) {                         \
-    WR[j] = *reinterpret_cast<const f32x4*>(wsrc[j] + (KO));             \
-    AR[j] = *reinterpret_cast<const f32x4*>(asrc[j] + (KO));             \
+    WR[j] = *reinterpret_cast<const f32x4*>(Wb + (size_t)wsrc[j] + 4 * (KO)); \
+    AR[j] = *reinterpret_cast<const f32x4*>(Ab + (size_t)asrc[j] + 4 * (KO)); \
   }
   SK_REQUEST(w0, a0, 0)
   if (PF > 1 && 32 < kper) { SK_REQUEST(w1, a1, 32) }
