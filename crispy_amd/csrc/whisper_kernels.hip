@@ -876,7 +876,10 @@ __global__ __launch_bounds__(256) void embed_kernel(const int* __restrict__ toke
 __device__ __forceinline__ void step_fuse_tail(const StepFuse& f, int tok, int pos, int step, int b, int tid) {
   for (int c = tid; c < f.D; c += 1024) f.x[(long)b * f.D + c] = f.tok_emb[(long)tok * f.D + c] + f.pos_emb[(long)pos * f.D + c];
   if (tid == 0) {
-    __threadfence();
+    // No fence: nothing of this kernel is read by another workgroup of it -- the ticket only elects the workgroup that
+    // stores the counters, every workgroup has consumed the old values long before its own increment, and the
+    // kernels behind read everything after the kernel boundary.  (A device-scope fence here writes back and
+    // invalidates the XCD's L2 once per workgroup and step.)
     const unsigned t = atomicAdd(reinterpret_cast<unsigned*>(f.counters + 2), 1u);
     if (t == gridDim.x - 1) {              // everyone else has finished, so everyone has read the old counters
       f.counters[0] = pos;
