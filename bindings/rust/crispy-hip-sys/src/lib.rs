@@ -339,7 +339,16 @@ impl GpuWhisperEngine {
         let c = path_cstring(model_path)?;
         let mut h = std::ptr::null_mut();
         check(unsafe { crispy_asr_load(c.as_ptr(), 0, &mut h) })?;
-        Ok(Self { h })
+        // whisper.cpp, the engine this one stands in for, multiplies f16 operands with f32 accumulation and keeps its
+        // K|V caches in f16: precision mode 1 is that arithmetic (and 2.3 x the f32 mode's speed).  The library's own
+        // default stays f32 -- the mode its 1e-4 parity against the float64 oracle is stated in.
+        let engine = Self { h };
+        check(unsafe { crispy_asr_set_precision(engine.h, 1) })?;
+        Ok(engine)
+    }
+    /// 0: exact f32 products (parity mode); 1: whisper.cpp's f16-operand arithmetic (the default of `load`).
+    pub fn set_precision(&mut self, mode: i32) -> Result<(), CrispyError> {
+        check(unsafe { crispy_asr_set_precision(self.h, mode as c_int) })
     }
     /// One chunk of at most 480 000 samples (16 kHz, f32 in +-1); `opts = None` is `TranscribeOptions::default()`:
     /// language auto-detected, transcribe task, timestamps on.  Empty audio gives an empty transcript
