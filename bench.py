@@ -191,10 +191,24 @@ def asr_leg(local_rank: int, clips: int = 64, new_tokens: int = 32):
         model.decode_greedy_device(enc.data_ptr(), clips, prompt, n)
         return time.perf_counter() - t0
 
+    def single_clip():
+        """The literal drop-in call: ONE 30 s chunk from host memory through the product path (PCM upload, log-mel,
+        encoder, cross K|V, prompt, 32 greedy tokens, ids back), as managers/transcription.rs:183-185 makes it."""
+        x1 = pcm[0].cpu().numpy()
+        model.transcribe_tokens([x1], prompt, new_tokens)
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            model.transcribe_tokens([x1], prompt, new_tokens)
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
+
     times = measure()                      # default precision: f32 operands, the mode the oracle parity is pinned in
+    one = single_clip()
     longer = {n: decode_n(n) for n in (64, 224)}      # SURVEY cfg 4 asks for 64 tokens; a full 30 s window can take 224
     model.set_precision(1)                 # the reference's precision: f16 operands / f32 accumulation (ggml numerics)
     times16 = measure()
+    one16 = single_clip()
     longer16 = {n: decode_n(n) for n in (64, 224)}
     model.set_precision(0)
     # CPU beside it: the float64 numpy oracle (BLAS on the host cores) on ONE 30 s clip, encoder + 2 greedy steps
@@ -246,6 +260,9 @@ def asr_leg(local_rank: int, clips: int = 64, new_tokens: int = 32):
                                                   "peak": 2500.0, "unit": "TFLOP/s",
                                                   "frac": enc_flops / times16["encoder"] / 1e12 / 2500.0,
                                                   "note": "peak = dense f16 MFMA (v_mfma_f32_32x32x16_f16)"}},
+        "single_clip": {"what": "ONE 30 s chunk, host PCM in, token ids out (crispy_asr_transcribe_tokens): the call the "
+                                "reference makes per chunk (managers/transcription.rs:183-185)",
+                        "ms": one * 1e3, "rtfx": 30.0 / one, "f16_operand_mode_ms": one16 * 1e3, "f16_operand_mode_rtfx": 30.0 / one16},
         "rtfx_logmel_encoder": audio_s / (times["logmel"] + times["encoder"]),
         "rtfx_end_to_end": audio_s / total,
         "logmel_roofline": {"bound": "hbm", "achieved": clips * 2.88e6 / times["logmel"] / 1e9, "peak": HBM_PEAK_GBS,
