@@ -458,7 +458,9 @@ def main():
     ap.add_argument("--frames", type=int, default=100, help="cfg2: frames per stream per step")
     ap.add_argument("--clips", type=int, default=256, help="cfg5: 30 s clips per step (sub-batch) per GPU")
     ap.add_argument("--new-tokens", type=int, default=32, help="cfg5: greedy tokens per clip")
-    ap.add_argument("--precision", type=int, default=0, help="cfg5: 0 = f32 operands, 1 = f16 operands (ggml numerics)")
+    ap.add_argument("--precision", type=int, default=1,
+                    help="cfg5: 1 = f16 operands / f32 accumulation, the arithmetic of the reference's whisper.cpp engine (default); "
+                         "0 = exact f32 products (the mode the oracle parity is stated in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-asr", action="store_true", help="skip the Whisper-tiny leg of the metric")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-stream process_frame latency leg")
