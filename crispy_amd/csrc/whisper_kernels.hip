@@ -872,6 +872,12 @@ __global__ __launch_bounds__(256) void embed_kernel(const int* __restrict__ toke
 // greedy pick: argmax over the vocabulary with a suppression mask (mask[v] != 0 -> -inf); ties -> lowest id.
 // One 1024-thread block per clip; every thread walks the row in float4 / uchar4 steps with four loads in flight
 // (the 256-thread, one-float-per-iteration version ran at 0.1 TB/s: 118 us for 64 x 51865 logits).
+constexpr int PICK_UNROLL = 13;                // float4 per thread of a 1024-thread pick: 53 248 logits in one round of requests
+__device__ __forceinline__ unsigned load_u32_unaligned(const unsigned char* p) {
+  unsigned v;
+  __builtin_memcpy(&v, p, 4);                  // global memory takes unaligned dword loads; the compiler emits one
+  return v;
+}
 // the tail of a fused pick: embedding of the pick for the next step, then the counters by the last workgroup to finish
 __device__ __forceinline__ void step_fuse_tail(const StepFuse& f, int tok, int pos, int step, int b, int tid) {
   for (int c = tid; c < f.D; c += 1024) f.x[(long)b * f.D + c] = f.tok_emb[(long)tok * f.D + c] + f.pos_emb[(long)pos * f.D + c];
@@ -912,8 +918,31 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
   if (tid < head && tid < V) consider((mask && mask[tid]) ? -INFINITY : lg[tid], tid);
   const int nvec = (V - head) >> 2;
   const float4* lg4 = reinterpret_cast<const float4*>(lg + head);
-#pragma unroll 4
-  for (int q = tid; q < nvec; q += 1024) {
+  // The whole row in flight at once: PICK_UNROLL x 1024 float4 cover 53 248 logits, requested from clamped addresses
+  // before any is looked at (with `unroll 4` the scan was four dependent round trips), and the four mask bytes of a
+  // float4 as ONE unaligned 32-bit load (rows and so v0 are only 4-byte aligned in the logits, 1-byte in the mask).
+  {
+    float4 xs[PICK_UNROLL];
+    unsigned ms[PICK_UNROLL];
+#pragma unroll
+    for (int u = 0; u < PICK_UNROLL; ++u) {
+      const int q = min(tid + 1024 * u, nvec - 1);
+      xs[u] = lg4[q];
+      ms[u] = mask ? load_u32_unaligned(mask + head + 4 * q) : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < PICK_UNROLL; ++u) {
+      const int q = tid + 1024 * u;
+      if (q < nvec) {
+        const int v0 = head + 4 * q;
+        consider((ms[u] & 0xffu) ? -INFINITY : xs[u].x, v0);
+        consider((ms[u] & 0xff00u) ? -INFINITY : xs[u].y, v0 + 1);
+        consider((ms[u] & 0xff0000u) ? -INFINITY : xs[u].z, v0 + 2);
+        consider((ms[u] & 0xff000000u) ? -INFINITY : xs[u].w, v0 + 3);
+      }
+    }
+  }
+  for (int q = tid + 1024 * PICK_UNROLL; q < nvec; q += 1024) {          // vocabularies beyond 53 248 entries
     const float4 x = lg4[q];
     const int v0 = head + 4 * q;
     unsigned char m0 = 0, m1 = 0, m2 = 0, m3 = 0;
@@ -997,8 +1026,28 @@ __global__ __launch_bounds__(1024) void ts_pick_kernel(TsPickArgs a) {
     if (tid < head) text((mask && mask[tid]) ? -INFINITY : lg[tid], tid);
     const int nvec = (a.eot - head) >> 2;
     const float4* lg4 = reinterpret_cast<const float4*>(lg + head);
-#pragma unroll 4
-    for (int q = tid; q < nvec; q += 1024) {
+    {                                          // the whole text range in flight at once (see argmax_kernel)
+      float4 xs[PICK_UNROLL];
+      unsigned ms[PICK_UNROLL];
+#pragma unroll
+      for (int u = 0; u < PICK_UNROLL; ++u) {
+        const int q = min(tid + 1024 * u, nvec - 1);
+        xs[u] = lg4[q];
+        ms[u] = mask ? load_u32_unaligned(mask + head + 4 * q) : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < PICK_UNROLL; ++u) {
+        const int q = tid + 1024 * u;
+        if (q < nvec) {
+          const int v0 = head + 4 * q;
+          text((ms[u] & 0xffu) ? -INFINITY : xs[u].x, v0);
+          text((ms[u] & 0xff00u) ? -INFINITY : xs[u].y, v0 + 1);
+          text((ms[u] & 0xff0000u) ? -INFINITY : xs[u].z, v0 + 2);
+          text((ms[u] & 0xff000000u) ? -INFINITY : xs[u].w, v0 + 3);
+        }
+      }
+    }
+    for (int q = tid + 1024 * PICK_UNROLL; q < nvec; q += 1024) {
       const float4 x = lg4[q];
       const int v0 = head + 4 * q;
       unsigned char m0 = 0, m1 = 0, m2 = 0, m3 = 0;
