@@ -58,6 +58,7 @@ struct GemmArgs {
   //    decoder self-attention block in one launch.
   const float* ln_s; const float* ln_c;
   float* C2; long ldc2; int n_split;
+  int w_half;                                 // skinny kernel: W points to an f16 matrix (ldw in halves), A is rounded to f16 (mode 1)
   int c2_half;                                // skinny kernel: C2 is an f16 buffer (the decoder's self K|V cache in precision mode 1)
   // Tiled kernel only: head-major store for the cross K|V projection.  Row m = (clip b, frame t) with hm_rows frames
   // per clip, column n = (K or V, head, dim): element goes to C[((b * 2 + kv) * heads + head) * hm_rows * 64 + t * 64

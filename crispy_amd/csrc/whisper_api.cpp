@@ -32,6 +32,7 @@ struct DecLayer {
   const float *ln1_w, *ln1_b, *qkv_w, *qkv_b, *out_w, *out_b;
   const float *lnx_w, *lnx_b, *xq_w, *xq_b, *xkv_w, *xkv_b, *xout_w, *xout_b;
   const void* xkv_wh = nullptr;              // f16 copy of the fused cross K|V projection (precision mode 1)
+  const void *out_wh = nullptr, *xout_wh = nullptr, *fc2_wh = nullptr;   // f16 copies of the plain (no LayerNorm in front) decode projections
   const float *ln2_w, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
   // LayerNorm folded into the consuming projection (decode steps with <= 64 clips): gamma-scaled weights, their row
   // sums and beta.W + bias (GemmArgs::ln_s / ln_c)
@@ -462,7 +463,13 @@ int crispy_asr_set_precision(crispy_asr* h, int mode) try {
       if (rc == CRISPY_OK) rc = half_copy(L.fc2_w, 4 * d * d, &L.fc2_wh);
     }
     for (DecLayer& L : h->dec)
-      if (rc == CRISPY_OK) rc = half_copy(L.xkv_w, 2 * (size_t)h->hp.n_text_state * h->hp.n_text_state, &L.xkv_wh);
+    {
+      const size_t dtt = h->hp.n_text_state;
+      if (rc == CRISPY_OK) rc = half_copy(L.xkv_w, 2 * dtt * dtt, &L.xkv_wh);
+      if (rc == CRISPY_OK) rc = half_copy(L.out_w, dtt * dtt, &L.out_wh);
+      if (rc == CRISPY_OK) rc = half_copy(L.xout_w, dtt * dtt, &L.xout_wh);
+      if (rc == CRISPY_OK) rc = half_copy(L.fc2_w, 4 * dtt * dtt, &L.fc2_wh);
+    }
     if (rc != CRISPY_OK) return rc;
     const int dt = h->hp.n_text_state;
     if (dt == 384 || dt == 512 || dt == 768 || dt == 1024 || dt == 1280) {    // the widths the f16 logits kernel is built for
@@ -747,9 +754,14 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
     else
       HIP_TRY(attn_decoder_f32(h->d_dq, dt, selfkv, (long)C * 2 * dt, 2L * dt, 64, 0, dt, dev_pos ? 1 : pos + 1, pos_dev,
                                h->d_datt, dt, batch, H, s));
+    // mode 1: the projections that have no LayerNorm in front (attention outputs, the MLP's second GEMM) in ggml's
+    // arithmetic -- f16 weights, the f32 activation rounded to f16 on the way into the matrix cores, f32 accumulation
+    const bool wh = fold && h->enc_precision == 1 && L.out_wh;
+    auto half_w = [&](GemmArgs& g, const void* w16) { if (wh) { g.W = reinterpret_cast<const float*>(w16); g.w_half = 1; } };
     {
       GemmArgs g = gemm(h->d_datt, dt, L.out_w, dt, h->d_dx, dt, L.out_b, batch, dt, dt);
       g.residual = h->d_dx; g.ldr = dt;
+      half_w(g, L.out_wh);
       HIP_TRY(gemm_f32_nt(g, 1, s));
     }
     // cross-attention over the encoder output (K | V precomputed once per clip)
@@ -770,6 +782,7 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
     {
       GemmArgs g = gemm(h->d_datt, dt, L.xout_w, dt, h->d_dx, dt, L.xout_b, batch, dt, dt);
       g.residual = h->d_dx; g.ldr = dt;
+      half_w(g, L.xout_wh);
       HIP_TRY(gemm_f32_nt(g, 1, s));
     }
     // MLP
@@ -787,6 +800,7 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
     {
       GemmArgs g = gemm(h->d_dh, 4L * dt, L.fc2_w, 4L * dt, h->d_dx, dt, L.fc2_b, batch, dt, 4 * dt);
       g.residual = h->d_dx; g.ldr = dt;
+      half_w(g, L.fc2_wh);
       HIP_TRY(gemm_f32_nt(g, 1, s));
     }
   }

@@ -165,6 +165,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
 // (24 for N = 384).  W is re-read per row block from L2.
 // ---------------------------------------------------------------------------------------------
 constexpr int SK_PF = 3;                       // K chunks (32 wide) in flight per wave
+typedef _Float16 sk_half8 __attribute__((ext_vector_type(8)));
 constexpr int SK_WAVE_LDS = 2048;              // floats of LDS per wave (two 4 KB operand chunks; later the 32 x 33 partial tile)
 __device__ __forceinline__ void sk_wave_sync() {     // LDS traffic of one wave: in order, so a fence for the compiler and a wait
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -178,8 +179,15 @@ __device__ __forceinline__ void sk_wave_sync() {     // LDS traffic of one wave:
 // NW = waves of a workgroup = ways K is split.  4 for the K = d projections; 16 for the MLP's second GEMM (K = 4 d):
 // with 4 waves that one ran four rounds of the memory latency on 24 workgroups (19.5 us at Whisper-tiny, three times
 // the other projections), with 16 it runs one like the rest.
-template <bool LN, bool GELU, bool RES, int NW>
+// WH: W is an f16 matrix (g.W reinterpreted, g.ldw in halves) and the products run on v_mfma_f32_32x32x16_f16 with
+// the A operand rounded to f16 on the way in -- ggml's arithmetic for a plain mul_mat (precision mode 1: the attention
+// output projections and the MLP's second GEMM, where no LayerNorm is folded in).  In f32 a 32 x 32 x 1536 tile is
+// 768 MFMAs of 64 cycles on ONE CU: 5 us of matrix-pipe time for the K = 4 d projection at Whisper-tiny, whatever the
+// number of clips; in f16 it is 96 MFMAs of 32 cycles.  Same loads for A, same epilogue; W arrives as two 16-byte
+// pieces per lane and chunk (4 lanes per 64-byte row piece, slot = piece ^ ((row >> 2) & 3): see gemm_hd_kernel).
+template <bool LN, bool GELU, bool RES, int NW, bool WH = false>
 __global__ __launch_bounds__(64 * NW) void gemm_skinny_f32_kernel(GemmArgs g) {
+  static_assert(!(WH && LN), "the f16-weight form has no LayerNorm fold");
   extern __shared__ __attribute__((aligned(16))) float sk_smem[];
   // per wave 8 KB: the transposition area of its operand chunks (W, then A: 32 rows x 8 sixteen-byte pieces each); the
   // wave's partial tile replaces it after the K loop
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_f32_kernel(GemmArgs g) {
   float (*rstat)[32][2] = reinterpret_cast<float (*)[32][2]>(sk_smem + NW * SK_WAVE_LDS);
   constexpr int ET = NW >= 16 ? 1024 : NW >= 8 ? 512 : 256;    // threads that finish outputs (12 waves: the first 512)
   constexpr int RP = ET / 32, NQ = 32 / RP;    // epilogue: RP rows per pass, NQ passes
-  constexpr int PF = NW > 12 ? 2 : SK_PF;      // 16 waves: 128 registers per lane, two chunks in flight (three spill 35 - 67 registers even with scalar bases)
+  constexpr int PF = NW > 12 ? 2 : SK_PF;            // 16 waves: 128 registers per lane, two chunks in flight (three spill 35 - 67 registers even with scalar bases)
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int li = lane & 31, lh = lane >> 5;
   const int n0 = blockIdx.x * 32;
@@ -207,12 +215,18 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_f32_kernel(GemmArgs g) {
   const int lr = lane >> 3, lc = (lane & 7) ^ lr;
   // wave-uniform bases (scalar registers) + 32-bit byte offsets per lane: eight address registers instead of sixteen,
   // which is what lets the 16-wave form keep three chunks in flight inside its 128 registers
-  const char* __restrict__ Wb = reinterpret_cast<const char*>(W + kbeg);
+  const char* __restrict__ Wb = WH ? reinterpret_cast<const char*>(reinterpret_cast<const _Float16*>(W) + kbeg)
+                                   : reinterpret_cast<const char*>(W + kbeg);
   const char* __restrict__ Ab = reinterpret_cast<const char*>(A + kbeg);
   unsigned wsrc[4], asrc[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    wsrc[j] = (unsigned)(((long)min(n0 + lr + 8 * j, g.N - 1) * g.ldw + 4 * lc) * 4);
+    if (WH) {                                // j < 2: row 16 j + (lane >> 2), the 16-byte piece that belongs into slot lane & 3
+      const int r = 16 * (j & 1) + (lane >> 2);
+      wsrc[j] = (unsigned)(((long)min(n0 + r, g.N - 1) * g.ldw + 8 * ((lane & 3) ^ ((r >> 2) & 3))) * 2);
+    } else {
+      wsrc[j] = (unsigned)(((long)min(n0 + lr + 8 * j, g.N - 1) * g.ldw + 4 * lc) * 4);
+    }
     asrc[j] = (unsigned)(((long)min(mb + lr + 8 * j, g.M - 1) * g.lda + 4 * lc) * 4);   // rows >= M: clamped row, never stored
   }
   f32x4* stw = reinterpret_cast<f32x4*>(sk_smem + wave * SK_WAVE_LDS);
@@ -229,7 +243,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_f32_kernel(GemmArgs g) {
   f32x4 w0[4], a0[4], w1[4], a1[4], w2[4], a2[4];
 #define SK_REQUEST(WR, AR, KO)                                            \
   _Pragma("unroll") for (int j = 0; j < 4; ++j) {                         \
-    WR[j] = *reinterpret_cast<const f32x4*>(Wb + (size_t)wsrc[j] + 4 * (KO)); \
+    if (!WH || j < 2) WR[j] = *reinterpret_cast<const f32x4*>(Wb + (size_t)wsrc[j] + (WH ? 2 : 4) * (KO)); \
     AR[j] = *reinterpret_cast<const f32x4*>(Ab + (size_t)asrc[j] + 4 * (KO)); \
   }
   SK_REQUEST(w0, a0, 0)
@@ -250,12 +264,20 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_f32_kernel(GemmArgs g) {
   // one chunk: registers -> LDS, request the chunk PF ahead into the same registers, LDS -> operand order, 16 MFMAs
 #define SK_CHUNK(WR, AR, KC)                                                                        \
   {                                                                                                 \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) { stw[64 * j + lane] = WR[j]; sta[64 * j + lane] = AR[j]; } \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) { if (!WH || j < 2) stw[64 * j + lane] = WR[j]; sta[64 * j + lane] = AR[j]; } \
     if ((KC) + 32 * PF < kper) { SK_REQUEST(WR, AR, (KC) + 32 * PF) }                               \
     sk_wave_sync();                                                                                 \
     f32x4 cw[4], ca[4];                                                                            \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) { cw[q] = stw[rslot[q]]; ca[q] = sta[rslot[q]]; } \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) { if (!WH) cw[q] = stw[rslot[q]]; ca[q] = sta[rslot[q]]; } \
+    if (WH) { cw[0] = stw[li * 4 + ((2 * lh) ^ ((li >> 2) & 3))]; cw[1] = stw[li * 4 + ((2 * lh + 1) ^ ((li >> 2) & 3))]; } \
     sk_wave_sync();                                                                                 \
+    if (WH) {                                                                                       \
+      _Pragma("unroll") for (int st = 0; st < 2; ++st) {        /* k = 16 lh + 8 st + e for both operands */ \
+        const sk_half8 av = {(_Float16)ca[2 * st].x, (_Float16)ca[2 * st].y, (_Float16)ca[2 * st].z, (_Float16)ca[2 * st].w, \
+                             (_Float16)ca[2 * st + 1].x, (_Float16)ca[2 * st + 1].y, (_Float16)ca[2 * st + 1].z, (_Float16)ca[2 * st + 1].w}; \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(sk_half8, cw[st]), acc, 0, 0, 0); \
+      }                                                                                             \
+    } else {                                                                                        \
     _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                 \
       const float wv[4] = {cw[q].x, cw[q].y, cw[q].z, cw[q].w};                                     \
       const float xv[4] = {ca[q].x, ca[q].y, ca[q].z, ca[q].w};                                     \
@@ -263,6 +285,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_f32_kernel(GemmArgs g) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[e], wv[e], acc, 0, 0, 0);                     \
         if (LN) { s0 += xv[e]; q0 = fmaf(xv[e], xv[e], q0); }                                       \
       }                                                                                             \
+    }                                                                                               \
     }                                                                                               \
   }
   for (int kc0 = 0; kc0 < kper; kc0 += 32 * PF) {
@@ -1120,15 +1143,15 @@ __global__ __launch_bounds__(1024) void ts_pick_kernel(TsPickArgs a) {
 
 }  // namespace
 
-template <bool LN, bool GELU, bool RES, int NW>
+template <bool LN, bool GELU, bool RES, int NW, bool WH = false>
 hipError_t sk_launch(dim3 grid, const GemmArgs& g, hipStream_t s) {
   constexpr size_t smem = NW * (SK_WAVE_LDS + 64) * sizeof(float);
   if (smem > 64 * 1024) {        // above the default dynamic-LDS limit (the CU has 160 KB); first called outside any capture
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_f32_kernel<LN, GELU, RES, NW>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_f32_kernel<LN, GELU, RES, NW, WH>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (attr != hipSuccess) return attr;
   }
-  hipLaunchKernelGGL((gemm_skinny_f32_kernel<LN, GELU, RES, NW>), grid, dim3(64 * NW), smem, s, g);
+  hipLaunchKernelGGL((gemm_skinny_f32_kernel<LN, GELU, RES, NW, WH>), grid, dim3(64 * NW), smem, s, g);
   return hipGetLastError();
 }
 template <int NW>
@@ -1162,6 +1185,15 @@ hipError_t gemm_f32_nt(const GemmArgs& g, int batch, hipStream_t s) {
     int nw = 4;
     if (g.M <= 64) nw = g.K % 512 == 0 ? 16 : g.K % 384 == 0 ? 12 : g.K % 256 == 0 ? 8 : 4;
     else if (kind == 1 && g.K >= 1024 && g.K % 512 == 0) nw = 16;
+    if (g.w_half) {                          // precision mode 1: f16 weight copy, residual projections only
+      if (kind != 1) return hipErrorInvalidValue;
+      switch (nw) {
+        case 16: return sk_launch<false, false, true, 16, true>(grid, g, s);
+        case 12: return sk_launch<false, false, true, 12, true>(grid, g, s);
+        case 8: return sk_launch<false, false, true, 8, true>(grid, g, s);
+        default: return sk_launch<false, false, true, 4, true>(grid, g, s);
+      }
+    }
     switch (nw) {
       case 16: return sk_dispatch<16>(kind, grid, g, s);
       case 12: return sk_dispatch<12>(kind, grid, g, s);
@@ -1169,6 +1201,7 @@ hipError_t gemm_f32_nt(const GemmArgs& g, int batch, hipStream_t s) {
       default: return sk_dispatch<4>(kind, grid, g, s);
     }
   }
+  if (g.w_half) return hipErrorInvalidValue;          // an f16 weight copy is only understood by the skinny kernel
   dim3 grid((g.N + GB_N - 1) / GB_N, (g.M + GB_M - 1) / GB_M, batch);
   hipLaunchKernelGGL(gemm_f32_nt_kernel, grid, dim3(256), 0, s, g);
   return hipGetLastError();
