@@ -199,15 +199,25 @@ class DecoderCache:
     """KV-cached incremental decoder (float64); `step(token)` returns the logits of the new position.
     Same arithmetic as `decoder_logits`, restated so that 200-token windows finish in seconds."""
 
-    def __init__(self, weights, hp, enc_out):
+    def __init__(self, weights, hp, enc_out, f16=False):
+        """f16=True: the decoder arithmetic of the library's precision mode 1, i.e. whisper.cpp's ggml graph
+        [UPSTREAM-RECALL] wherever a matrix product has no LayerNorm folded into it on the GPU -- cross K | V from the
+        f16-rounded encoder output and f16 weights, stored as f16 (kv_cross); the self-attention K | V cache stored
+        as f16 (kv_self); the attention outputs and the GELU'd hidden layer rounded to f16 against f16 weights
+        (attn.out, cross_attn.out, mlp.2); the final LayerNorm rounded to f16 against the f16 token embedding.  The
+        projections behind a LayerNorm (q | k | v, cross q, mlp.0) stay exact: the library folds the LayerNorm into
+        them and keeps them in f32."""
         self.W = _f64(weights)
         self.hp = hp
-        enc = enc_out.astype(np.float64)
+        self.f16 = f16
+        r = _h if f16 else (lambda a: a)
+        self.r = r
+        enc = r(enc_out.astype(np.float64))
         self.xk, self.xv, self.k, self.v = [], [], [], []
         for i in range(hp.n_text_layer):
             p = f"decoder.blocks.{i}.cross_attn"
-            self.xk.append(enc @ self.W[p + ".key.weight"].T)
-            self.xv.append(enc @ self.W[p + ".value.weight"].T + self.W[p + ".value.bias"])
+            self.xk.append(r(enc @ r(self.W[p + ".key.weight"]).T))
+            self.xv.append(r(enc @ r(self.W[p + ".value.weight"]).T + self.W[p + ".value.bias"]))
             self.k.append(np.zeros((0, hp.n_text_state)))
             self.v.append(np.zeros((0, hp.n_text_state)))
         self.pos = 0
@@ -224,23 +234,23 @@ class DecoderCache:
         return out
 
     def step(self, token):
-        W = self.W
+        W, r = self.W, self.r
         x = W["decoder.token_embedding.weight"][int(token)] + W["decoder.positional_embedding"][self.pos]
         for i in range(self.hp.n_text_layer):
             p = f"decoder.blocks.{i}"
             xn = _ln(x, W[p + ".attn_ln.weight"], W[p + ".attn_ln.bias"])
             q = xn @ W[p + ".attn.query.weight"].T + W[p + ".attn.query.bias"]
-            self.k[i] = np.vstack([self.k[i], xn @ W[p + ".attn.key.weight"].T])
-            self.v[i] = np.vstack([self.v[i], xn @ W[p + ".attn.value.weight"].T + W[p + ".attn.value.bias"]])
-            x = x + self._att(q, self.k[i], self.v[i]) @ W[p + ".attn.out.weight"].T + W[p + ".attn.out.bias"]
+            self.k[i] = np.vstack([self.k[i], r(xn @ W[p + ".attn.key.weight"].T)])
+            self.v[i] = np.vstack([self.v[i], r(xn @ W[p + ".attn.value.weight"].T + W[p + ".attn.value.bias"])])
+            x = x + r(self._att(q, self.k[i], self.v[i])) @ r(W[p + ".attn.out.weight"]).T + W[p + ".attn.out.bias"]
             xn = _ln(x, W[p + ".cross_attn_ln.weight"], W[p + ".cross_attn_ln.bias"])
             q = xn @ W[p + ".cross_attn.query.weight"].T + W[p + ".cross_attn.query.bias"]
-            x = x + self._att(q, self.xk[i], self.xv[i]) @ W[p + ".cross_attn.out.weight"].T + W[p + ".cross_attn.out.bias"]
+            x = x + r(self._att(q, self.xk[i], self.xv[i])) @ r(W[p + ".cross_attn.out.weight"]).T + W[p + ".cross_attn.out.bias"]
             xn = _ln(x, W[p + ".mlp_ln.weight"], W[p + ".mlp_ln.bias"])
-            x = x + _gelu(xn @ W[p + ".mlp.0.weight"].T + W[p + ".mlp.0.bias"]) @ W[p + ".mlp.2.weight"].T + W[p + ".mlp.2.bias"]
+            x = x + r(_gelu(xn @ W[p + ".mlp.0.weight"].T + W[p + ".mlp.0.bias"])) @ r(W[p + ".mlp.2.weight"]).T + W[p + ".mlp.2.bias"]
         self.pos += 1
         x = _ln(x, W["decoder.ln.weight"], W["decoder.ln.bias"])
-        return x @ W["decoder.token_embedding.weight"].T
+        return r(x) @ r(W["decoder.token_embedding.weight"]).T
 
 
 def special_tokens(n_vocab, eot=None):

@@ -591,6 +591,62 @@ def test_vocabulary_projection_both_precision_modes(tiny, model, batch):
     assert np.array_equal(got1.argmax(1)[clear], ref16.argmax(1)[clear])
 
 
+def test_mode_1_decoder_matches_the_f16_arithmetic_oracle(tiny, model):
+    """Precision mode 1 of the DECODER against an oracle of its own arithmetic (oracle DecoderCache(f16=True): f16 cross
+    and self K|V caches, f16 operands in the attention-output / MLP-second / vocabulary products; the LayerNorm-folded
+    projections exact), on encoder outputs handed over as they are: the logit of each greedy pick for 12 clips x 6
+    picks behind a 4-token prompt (72 logits; the oracle follows the GPU's picks, so the comparison is per step).
+    A picked logit moves by ~2e-4 of its size under these roundings, the same order as one f16 flip caused by f32
+    accumulation, so single values cannot tell the two oracles apart; over the 72 the GPU must be closer (rms) to the
+    f16 oracle than to the exact one (measured: 7.0e-5 against 9.9e-5, the two oracles 1.18e-4 apart -- the same
+    picture as the encoder's: what remains is f32 accumulation order moving values across f16 boundaries), within
+    1e-4 rms and 4e-4 at the worst value, and it must pick the f16 oracle's ids wherever that oracle's top-2 margin
+    exceeds 1e-3 of the scale."""
+    import torch
+    from oracle import whisper_oracle as WO
+    hp, W = tiny
+    rng = np.random.default_rng(11)
+    B, n_new = 12, 6
+    enc = (rng.standard_normal((B, 1500, hp.n_audio_state)) * 0.8).astype(np.float32)
+    prompt = [50258, 50259, 50359, 50363]
+    d_enc = torch.from_numpy(enc).to("cuda:0")
+    torch.cuda.synchronize()
+    try:
+        model.set_precision(1)
+        toks, n, lg = model.decode_greedy_device(d_enc.data_ptr(), B, prompt, n_new)
+    finally:
+        model.set_precision(0)
+    best = {True: np.zeros((B, n_new)), False: np.zeros((B, n_new))}
+    margin16 = np.zeros((B, n_new))
+    ids16 = np.zeros((B, n_new), np.int64)
+    for f16 in (True, False):
+        for b in range(B):
+            dc = WO.DecoderCache(W, hp, enc[b], f16=f16)
+            for t in prompt[:-1]:
+                dc.step(t)
+            tok = prompt[-1]
+            for i in range(n_new):
+                l = dc.step(tok)
+                tok = int(toks[b][i])
+                best[f16][b, i] = l.max()
+                if f16:
+                    top = np.partition(l, -2)[-2:]
+                    margin16[b, i] = top[1] - top[0]
+                    ids16[b, i] = int(np.argmax(l))
+    scale = np.abs(best[True]).max()
+    gap = np.sqrt(np.mean((best[True] - best[False]) ** 2)) / scale
+    e16 = (lg - best[True]) / scale
+    e64 = (lg - best[False]) / scale
+    rms16, rms64 = np.sqrt(np.mean(e16 ** 2)), np.sqrt(np.mean(e64 ** 2))
+    print(f"mode-1 decoder: rms to the f16 oracle {rms16:.2e}, to the exact one {rms64:.2e}, oracle gap {gap:.2e}, worst {np.abs(e16).max():.2e}")
+    assert gap > 5e-5, gap                                       # the roundings are visible
+    assert rms16 < 1e-4 and np.abs(e16).max() < 4e-4, (rms16, rms64, gap, np.abs(e16).max())
+    assert rms16 < 0.85 * rms64, (rms16, rms64, gap)             # its own oracle, not the exact one
+    resolved = margin16 > 1e-3 * scale
+    assert resolved.sum() >= B * n_new // 2, resolved.sum()
+    assert np.array_equal(toks[resolved], ids16[resolved])
+
+
 @pytest.mark.parametrize("d,vocab", [(512, 51865), (768, 51865), (1024, 51865), (1280, 51866)])
 def test_vocabulary_projection_at_the_other_catalog_widths(d, vocab):
     """The mode-1 logits kernel is built per model width (K-chunks per wave 8 / 12 / 16 / 20 for base / small / medium /

@@ -167,3 +167,19 @@ def test_final_logits_is_the_decoders_last_block_and_its_f16_form_rounds_both_op
     assert np.array_equal(ref16, xh @ Eh.T)
     gap = np.sqrt(np.mean((ref16 - ref) ** 2)) / np.abs(ref).max()
     assert 4e-5 < gap < 3e-4, gap
+
+
+def test_decoder_cache_f16_mode_only_rounds_where_it_says(tiny, enc_out):
+    """oracle DecoderCache(f16=True) = the exact cached decoder plus f16 roundings of the K|V caches and of the operands
+    of the plain products: (a) with f16=False it reproduces decoder_logits; (b) with f16=True the logits move by
+    1e-5 .. 1e-2 of their scale (rounding, not a different model) and the arg-max of a well-separated step is kept."""
+    from oracle import whisper_oracle as WO
+    hp, W = tiny
+    toks = [50258, 50259, 50359, 50363, 1000]
+    full = WO.decoder_logits(W, hp, enc_out, toks)
+    dc, dh = WO.DecoderCache(W, hp, enc_out), WO.DecoderCache(W, hp, enc_out, f16=True)
+    for i, t in enumerate(toks):
+        l, lh = dc.step(t), dh.step(t)
+        assert np.abs(l - full[i]).max() <= 1e-9 * np.abs(full[i]).max()
+        rel = np.abs(lh - l).max() / np.abs(l).max()
+        assert 1e-5 < rel < 1e-2, (i, rel)
