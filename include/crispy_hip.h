@@ -255,8 +255,10 @@ int crispy_asr_synchronize(crispy_asr *h);
  * v_mfma_f32_32x32x16_f16, activations that only feed a matrix product kept in f16, the whole convolution stem and the
  * encoder attention on the f16 matrix cores.  Decoder in this mode: cross K|V and the self-attention K|V cache kept in
  * f16 (as whisper.cpp's kv_self / kv_cross are), logits =
- * f16(LayerNorm(x)) . f16(token embedding)^T with f32 accumulation (whisper.cpp's f16 embedding under ggml's mul_mat);
- * the decoder's own projections, self-attention, LayerNorm and soft-max stay f32. */
+ * f16(LayerNorm(x)) . f16(token embedding)^T with f32 accumulation (whisper.cpp's f16 embedding under ggml's mul_mat),
+ * and the projections with no LayerNorm in front of them (attention outputs, the MLP's second product) with f16
+ * weights and the activation rounded to f16; the LayerNorm-folded projections (q | k | v, cross q, the MLP's first
+ * product), LayerNorm and soft-max stay f32.  oracle/whisper_oracle.py: encoder_forward_f16, DecoderCache(f16=True). */
 int crispy_asr_set_precision(crispy_asr *h, int mode);
 
 /* Stage entry point (parity tests): the last step of the decoder alone -- final LayerNorm and vocabulary projection
