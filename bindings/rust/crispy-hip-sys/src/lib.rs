@@ -222,6 +222,7 @@ pub const FRAME_SIZE: usize = CRISPY_RN_FRAME_SIZE;
 /// (audio.rs:270-273), first-frame drop (audio.rs:275-278).
 pub struct DenoiseState {
     h: *mut crispy_rn,
+    failed: Option<CrispyError>,
 }
 // SAFETY: the handle is owned exclusively and the library allows different threads to use a handle as long as calls
 // are serialised -- which `&mut self` guarantees; the reference moves the processor into the cpal closure
@@ -237,7 +238,7 @@ impl DenoiseState {
         let mut h = std::ptr::null_mut();
         // SAFETY: c outlives the call; h is a valid out-pointer.
         check(unsafe { crispy_rn_create_from_file(c.as_ptr(), 1, 0, &mut h) })?;
-        Ok(Box::new(Self { h }))
+        Ok(Box::new(Self { h, failed: None }))
     }
     /// ... or from the flat 87 503-byte int8 blob (layer order input_dense, vad_gru, vad_output, noise_gru,
     /// denoise_gru, denoise_output).
@@ -245,11 +246,14 @@ impl DenoiseState {
         let mut h = std::ptr::null_mut();
         // SAFETY: the slice is valid for weights.len() bytes; the library copies it before returning.
         check(unsafe { crispy_rn_create(weights.as_ptr(), weights.len(), 1, 0, &mut h) })?;
-        Ok(Box::new(Self { h }))
+        Ok(Box::new(Self { h, failed: None }))
     }
     /// `process_frame(&mut self, output, input) -> f32` (audio.rs:268): 480 samples each, f32 in int16 range;
-    /// returns the VAD probability.  Infallible like upstream: slice lengths are asserted (as upstream does), and a
-    /// device failure after construction -- which upstream cannot have -- yields silence and VAD 0.
+    /// returns the VAD probability.  The signature is infallible like upstream's (slice lengths are asserted, as upstream
+    /// does).  A device failure after construction -- which upstream cannot have -- must not turn into permanent
+    /// silence in the audio callback with nobody told: the frame is passed through UNDENOISED (the microphone keeps
+    /// working), VAD 0 is returned, and the error is latched for the host to poll with `take_error()` (e.g. once per
+    /// second from the thread that owns `NsState`, which can then fall back to `NoiseSuppressionMode::Off`).
     pub fn process_frame(&mut self, output: &mut [f32], input: &[f32]) -> f32 {
         assert_eq!(input.len(), FRAME_SIZE);
         assert_eq!(output.len(), FRAME_SIZE);
@@ -257,10 +261,21 @@ impl DenoiseState {
         // SAFETY: both slices hold exactly one frame; the call returns when `output` is complete.
         let rc = unsafe { crispy_rn_process(self.h, input.as_ptr(), output.as_mut_ptr(), &mut vad, 1, CRISPY_RN_LAYOUT_TBF) };
         if rc != CRISPY_OK {
-            output.fill(0.0);
+            if self.failed.is_none() {
+                self.failed = check(rc).err();       // the first failure, with the library's message for this thread
+            }
+            output.copy_from_slice(input);
             return 0.0;
         }
         vad
+    }
+    /// The first error `process_frame` met since the last call, if any (and clears it).
+    pub fn take_error(&mut self) -> Option<CrispyError> {
+        self.failed.take()
+    }
+    /// True once a `process_frame` call has failed and the error has not been taken yet.
+    pub fn has_failed(&self) -> bool {
+        self.failed.is_some()
     }
     /// What `set_monitoring_model` does by replacing the processor (audio.rs:955-965).
     pub fn reset(&mut self) -> Result<(), CrispyError> {

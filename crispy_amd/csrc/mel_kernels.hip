@@ -157,11 +157,8 @@ __global__ __launch_bounds__(256) void mel_finish_kernel(MelArgs a) {
 hipError_t mel_launch(const MelArgs& a, int batch, hipStream_t s) {
   hipError_t e = hipMemsetAsync(a.clip_max, 0x80, sizeof(int) * batch, s);  // 0x80808080: below any key
   if (e != hipSuccess) return e;
-  const size_t smem = 4 * MEL_NF * MEL_BS * (sizeof(float2) + sizeof(float));
-  if (smem > 64 * 1024) {      // 128 mel bins: above the default dynamic-LDS limit (the CU has 160 KB)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(mel_frames_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return e;
-  }
+  constexpr size_t smem = 4 * MEL_NF * MEL_BS * (sizeof(float2) + sizeof(float));     // 40 KB whatever the number of mel bins
+  static_assert(smem <= 64 * 1024, "above the default dynamic-LDS limit: the launch would need hipFuncSetAttribute per device");
   hipLaunchKernelGGL(mel_frames_kernel, dim3(MEL_TILES, batch), dim3(256), smem, s, a);
   e = hipGetLastError();
   if (e != hipSuccess) return e;

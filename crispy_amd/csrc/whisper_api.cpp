@@ -57,6 +57,7 @@ struct crispy_asr {
   const void* conv1_wh = nullptr;            // f16 conv1 kernel, rows zero-padded to conv1_kp columns
   int conv1_kp = 0;
   int enc_precision = 0;                     // 0: f32 operands (default), 1: f16 operands for the encoder GEMMs
+  bool half_ready = false;                   // every f16 weight copy of mode 1 exists (set after the last one and a stream sync)
   int xcd_swizzle = 1;                       // mode 1 GEMMs: column tiles of a row tile on one XCD (CRISPY_ASR_XCD=0 turns it off)
   std::vector<EncLayer> enc;
   const float *tok_emb = nullptr, *dec_pos = nullptr, *dec_ln_w = nullptr, *dec_ln_b = nullptr;
@@ -432,8 +433,10 @@ int crispy_asr_set_precision(crispy_asr* h, int mode) try {
   if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_set_precision: model not finalized");
   if (mode != 0 && mode != 1) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_set_precision: mode must be 0 (f32) or 1 (f16 encoder GEMM operands)");
   HIP_TRY(hipSetDevice(h->device));
-  if (mode == 1 && !h->conv2_wh) {
-    // f16 copies of the encoder GEMM weights, made on the device once
+  if (mode == 1 && !h->half_ready) {
+    // f16 copies of the encoder GEMM weights, made on the device once.  `half_ready` is only set after the last copy
+    // and a stream sync: a hipMalloc failing part-way (OOM on a large model) leaves the mode at 0 and a retry starts
+    // over (the partial copies stay owned by `derived` until the handle is freed) -- ADVICE r2.
     const size_t d = h->hp.n_audio_state;
     auto half_copy = [&](const float* w, size_t n, const void** out) -> int {
       void* p = nullptr;
@@ -481,6 +484,7 @@ int crispy_asr_set_precision(crispy_asr* h, int mode) try {
       h->tok_emb_hp = p;
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
+    h->half_ready = true;
   }
   if (h->enc_precision != mode) {   // the captured decode steps bake the cross-attention kernel in
     if (h->dec_graph) { (void)hipGraphExecDestroy(h->dec_graph); h->dec_graph = nullptr; h->dec_graph_batch = 0; }
@@ -1170,6 +1174,7 @@ int crispy_asr_detect_language_device(crispy_asr* h, const float* d_enc, int bat
   std::vector<int> tok(batch, sot);
   HIP_TRY(hipMemcpyAsync(h->d_tok, tok.data(), sizeof(int) * batch, hipMemcpyHostToDevice, s));
   HIP_TRY(hipStreamSynchronize(s));
+  h->dec_max_keys = 1;      // one position: the self K|V form (f16 in mode 1) must not depend on what the last decode call left here
   rc = decoder_step(h, batch, 0, false, true, s);
   if (rc != CRISPY_OK) return rc;
   if (!h->d_lang_mask) {

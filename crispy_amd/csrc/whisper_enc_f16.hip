@@ -589,8 +589,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void a
                                                          _Float16* __restrict__ out, int T, int D) {
   // K and V^T tiles of 32 keys are staged once per workgroup (the four waves work on the same clip and head) and
   // double buffered: the requests for tile i + 1 are in flight while tile i is computed, one barrier per tile.
-  __shared__ __attribute__((aligned(16))) _Float16 Ks[2][32 * AT_KLD];
-  __shared__ __attribute__((aligned(16))) _Float16 Vs[2][64 * AT_VLD];
+  // ONE LDS object: [K stage 0 | K stage 1 | V^T stage 0 | V^T stage 1] = 4 x 4608 bytes.  The epilogue reuses all of it as
+  // four per-wave [32][AT_KLD] output images, which is only defined behaviour inside a single object.
+  constexpr int AT_KST = 32 * AT_KLD, AT_VST = 64 * AT_VLD;          // halfs per K / V^T stage
+  __shared__ __attribute__((aligned(16))) _Float16 at_lds[2 * AT_KST + 2 * AT_VST];
+  static_assert(4 * 32 * AT_KLD <= 2 * AT_KST + 2 * AT_VST, "the four per-wave output images must fit the K | V^T stages");
+  _Float16 (*Ks)[AT_KST] = reinterpret_cast<_Float16 (*)[AT_KST]>(at_lds);
+  _Float16 (*Vs)[AT_VST] = reinterpret_cast<_Float16 (*)[AT_VST]>(at_lds + 2 * AT_KST);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, heads = gridDim.y;
@@ -714,9 +719,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void a
   const float inv = 1.f / l_run;
   // lane (li = query, lh) holds O[q][d] for d = acc_row(r) (+ 32 for o1).  Stored from here, every instruction would
   // touch 32 rows with 16 bytes each (16 instructions per wave, store-issue bound); through a [32][64 + 8] f16 image in
-  // the K stage that is free now, a wave writes whole 128-byte rows, 8 rows per 16-byte-per-lane instruction.
+  // the K | V^T stages that are free now, a wave writes whole 128-byte rows, 8 rows per 16-byte-per-lane instruction.
   __syncthreads();                                   // every wave has read its last K / V^T tile
-  _Float16* Timg = &Ks[0][0] + wave * (32 * AT_KLD);  // 4 x 4608 bytes = the two K stages
+  _Float16* Timg = at_lds + wave * (32 * AT_KLD);     // 4 x 4608 bytes = the two K stages and the two V^T stages
 #pragma unroll
   for (int g4 = 0; g4 < 4; ++g4) {
     const int d = 8 * g4 + 4 * lh;

@@ -16,6 +16,7 @@
 //   attn_enc_kernel        flash-style non-causal attention, one wave per 32 queries, S^T = K.Q^T so the
 //                          softmax statistics are per lane and P^T feeds the P.V MFMAs from registers.
 //   attn_dec_kernel        one wave per (clip, head): a single query against a KV cache / cross KV.
+#include <atomic>
 #include "asr_common.h"
 
 namespace crispy {
@@ -252,12 +253,20 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_f32_kernel(GemmArgs g) {
   // epilogue operands of this thread's outputs: column ec of rows (tid >> 5) + 8 q
   const int ec = min(tid & 31, g.N - 1 - n0), enn = n0 + ec;
   float e_s = 0.f, e_c = 0.f, e_res[NQ];
-  if (LN) { e_s = g.ln_s[enn]; e_c = g.ln_c[enn]; }
-  else if (g.bias) e_c = g.bias[enn];
-  if (RES) {
+  // The LayerNorm-fold forms with 12 / 16 waves (128 / 168 registers per lane) have no room to keep these three to six
+  // values across the K loop: the compiler parked them in scratch (a store behind a vmcnt wait in the prologue, a
+  // reload -- one more memory round trip -- after the loop).  Those forms request them AFTER the loop instead, under
+  // the LDS hand-off and the barrier: the same round trip, no scratch (tests/test_build_resources.py).
+  constexpr bool LATE_EPI = LN && (NW >= 16 || (NW >= 12 && RES));
+  auto request_epilogue = [&]() {
+    if (LN) { e_s = g.ln_s[enn]; e_c = g.ln_c[enn]; }
+    else if (g.bias) e_c = g.bias[enn];
+    if (RES) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) e_res[q] = g.residual[(long)min(mb + min((tid >> 5) + RP * q, 31), g.M - 1) * g.ldr + enn];
-  }
+      for (int q = 0; q < NQ; ++q) e_res[q] = g.residual[(long)min(mb + min((tid >> 5) + RP * q, 31), g.M - 1) * g.ldr + enn];
+    }
+  };
+  if (!LATE_EPI) request_epilogue();
   const long coff = g.c_off_dev ? (long)(*g.c_off_dev) * g.c_off_scale : 0L;
   float* __restrict__ C = second ? g.C2 + coff - g.n_split : g.C + (g.C2 ? 0L : coff);
   const long ldc = second ? g.ldc2 : g.ldc;
@@ -295,6 +304,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_f32_kernel(GemmArgs g) {
   }
 #undef SK_CHUNK
 #undef SK_REQUEST
+  if (LATE_EPI) request_epilogue();
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wave][acc_row(r, lane) * 33 + li] = acc[r];     // own area: after the wave's last reads
   if (LN) {
@@ -1147,9 +1157,18 @@ template <bool LN, bool GELU, bool RES, int NW, bool WH = false>
 hipError_t sk_launch(dim3 grid, const GemmArgs& g, hipStream_t s) {
   constexpr size_t smem = NW * (SK_WAVE_LDS + 64) * sizeof(float);
   if (smem > 64 * 1024) {        // above the default dynamic-LDS limit (the CU has 160 KB); first called outside any capture
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_f32_kernel<LN, GELU, RES, NW, WH>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (attr != hipSuccess) return attr;
+    // the attribute belongs to the CURRENT device's copy of the kernel: once per device, not once per process
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_f32_kernel<LN, GELU, RES, NW, WH>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) return e;
+      done.fetch_or(bit, std::memory_order_release);
+    }
   }
   hipLaunchKernelGGL((gemm_skinny_f32_kernel<LN, GELU, RES, NW, WH>), grid, dim3(64 * NW), smem, s, g);
   return hipGetLastError();

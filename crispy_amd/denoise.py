@@ -143,7 +143,7 @@ class DenoiseState:
 
     def debug_read(self, stream: int) -> np.ndarray:
         d = np.empty(N.RN_DBG_FLOATS, dtype=np.float32)
-        N.check(self._L.crispy_rn_debug_read(self._h, int(stream), d.ctypes.data_as(C.POINTER(C.c_float)), d.size))
+        N.check(self._L.crispy_rn_debug_read(self._h, int(stream), d.ctypes.data_as(C.POINTER(C.c_float)), d.size), self._L)
         return d
 
 

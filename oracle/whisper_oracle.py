@@ -388,9 +388,11 @@ def window_segments(win, seek, sp, token_text):
 
 
 def transcribe_timestamps(weights, hp, mel_window, n_samples, prompt, rules, token_text, n_max=None,
-                          suppress=None, suppress_first=None, eot=None, max_windows=1501):
+                          suppress=None, suppress_first=None, eot=None, max_windows=1501, f16=False):
     """whisper_full's seek loop over one clip (<= 30 s): `mel_window(seek)` returns the [n_mels, 3000] log-mel
-    window starting at mel frame `seek`.  Returns (segments, all kept tokens, windows)."""
+    window starting at mel frame `seek`.  Returns (segments, all kept tokens, windows).
+    f16=True chains the f16-operand arithmetic (the library's precision mode 1 = ggml's mul_mat numerics
+    [UPSTREAM-RECALL]): `encoder_forward_f16` -> `DecoderCache(f16=True)`."""
     sp = special_tokens(hp.n_vocab, eot)
     n_max = hp.n_text_ctx // 2 - 4 if n_max is None else n_max
     seek, seek_end = 0, n_samples // 160
@@ -398,8 +400,8 @@ def transcribe_timestamps(weights, hp, mel_window, n_samples, prompt, rules, tok
     if seek_end < 100:                         # whisper.cpp: "input is too short" -> nothing
         return segs, kept, wins
     while seek + 100 < seek_end and len(wins) < max_windows:
-        enc = encoder_forward(weights, hp, mel_window(seek))
-        dc = DecoderCache(weights, hp, enc)
+        enc = (encoder_forward_f16 if f16 else encoder_forward)(weights, hp, mel_window(seek))
+        dc = DecoderCache(weights, hp, enc, f16=f16)
         win = decode_window(dc.step, prompt, sp, rules, n_max, seek, seek_end, suppress, suppress_first)
         win["seek"] = seek
         wins.append(win)

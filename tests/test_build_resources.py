@@ -152,3 +152,41 @@ def test_f16_encoder_kernels_run_at_four_waves_per_simd_without_scratch(tmp_path
         seg = loop[:at]
         assert seg.count("ds_read_b128") == 12 and seg.count("global_load_lds_dwordx4") == 6, name
         assert "vmcnt(0)" not in seg, f"{name}: a compiler-inserted vmcnt(0) serialises the stages"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+@pytest.mark.parametrize("src_name", ["whisper_kernels.hip", "whisper_dec_f16.hip", "whisper_gemm_f16.hip", "mel_kernels.hip",
+                                      "resample_kernels.hip"])
+def test_asr_kernels_have_no_scratch_at_all(tmp_path, src_name):
+    """with this compiler a VGPR spill next to a divergent region is a correctness hazard (see the
+    module docstring), and the decode-step kernels -- gemm_skinny_f32_kernel (every LayerNorm / GELU / residual / K-split /
+    f16-weight form), attn_dec_kernel, attn_dec_x16_kernel, vocab_f16_kernel, gemm_vocab_f32_kernel, argmax_kernel,
+    ts_pick_kernel -- are full of predicated epilogues.  Six skinny forms used to park their epilogue operands in scratch;
+    they request them after the K loop now.  The rule for every ASR kernel file: ScratchSize == 0 and no spilled VGPR."""
+    src = os.path.join(ROOT, "crispy_amd", "csrc", src_name)
+    asm = tmp_path / "k.s"
+    out = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S",
+                          "-Rpass-analysis=kernel-resource-usage", src, "-o", str(asm)],
+                         capture_output=True, text=True, timeout=900, cwd=os.path.dirname(src))
+    assert out.returncode == 0, out.stderr[-2000:]
+    res, cur = {}, None
+    for line in out.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = m.group(1)
+            res[cur] = {}
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
+        if m and cur:
+            res[cur][m.group(1).strip()] = int(m.group(2))
+    assert res, out.stderr[-500:]
+    if src_name == "whisper_kernels.hip":
+        for must in ("gemm_skinny_f32_kernel", "ts_pick_kernel", "argmax_kernel", "attn_dec_kernel", "gemm_vocab_f32_kernel"):
+            assert any(must in k for k in res), (must, list(res))
+        assert sum("gemm_skinny_f32_kernel" in k for k in res) == 36      # 8 epilogue forms x 4 K splits + 4 f16-weight forms
+        assert sum("attn_dec_x16_kernel" in k for k in res) == 4           # 1 / 2 / 4 / 12 key slots per wave
+    if src_name == "whisper_dec_f16.hip":
+        assert sum("vocab_f16_kernel" in k for k in res) == 5              # tiny ... large widths
+    bad = {k: r for k, r in res.items() if r.get("ScratchSize", 0) != 0 or r.get("VGPRs Spill", 0) != 0}
+    assert not bad, bad
+    assert "scratch_store" not in asm.read_text() and "scratch_load" not in asm.read_text()

@@ -1,0 +1,215 @@
+"""End-to-end parity of PRECISION MODE 1 -- the precision that ships: the Rust binding's default
+(bindings/rust/crispy-hip-sys/src/lib.rs, `GpuWhisperEngine::load`), `bench.py --workload cfg5` and every headline ASR
+number run in it.  Reference call site: managers/transcription.rs:183-185.
+
+Every test here runs the library entry point a host would call (`crispy_asr_transcribe_tokens`, `crispy_asr_transcribe`,
+`crispy_asr_transcribe_batch`, `crispy_asr_detect_language_device`) with `crispy_asr_set_precision(h, 1)` and compares
+with the CHAINED f16-operand oracle: oracle log-mel -> `encoder_forward_f16` -> `DecoderCache(f16=True)` (oracle/
+whisper_oracle.py: both operands of every plain matrix product rounded to f16, exact accumulation; ggml's mul_mat
+arithmetic [UPSTREAM-RECALL]).
+
+Comparison rule (`forced_picks`).  The oracle is teacher-forced with the GPU's own tokens, so EVERY step is compared, not
+only the prefix up to the first close call.  Two assertions per step: (1) the GPU's pick is never further than `thr`
+below the oracle's best logit; (2) where the oracle's own top-2 margin exceeds `thr` the ids are equal -- and a minimum
+number of such resolvable steps is required (a margin-gated loop that compares nothing proves nothing).
+`thr` derives from the measured bar of the mode: a picked logit agrees with the f16 oracle to 4e-4 of the logit scale at
+the worst value (tests/test_gpu_whisper.py::test_mode_1_decoder_matches_the_f16_arithmetic_oracle), the chained encoder
+adds about as much again, so thr = MODE1_REL x scale with MODE1_REL = 4 x 4e-4.
+
+Weights: `synthetic_whisper_weights(..., sensitive=True)` -- sharpened cross-attention, so that the picks depend on the
+audio (the tests assert that different clips decode to different ids)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MODE1_REL = 4 * 4e-4
+
+
+def forced_picks(W, hp, enc, prompt, got, need, what, f16=True, suppress=None, rel=MODE1_REL):
+    """Teacher-forced comparison of greedy ids `got` (one clip) with the oracle decoder on encoder output `enc`."""
+    from oracle import whisper_oracle as WO
+    sp = WO.special_tokens(hp.n_vocab)
+    dc = WO.DecoderCache(W, hp, enc, f16=f16)
+    for t in prompt[:-1]:
+        dc.step(t)
+    tok, compared, worst = prompt[-1], 0, 0.0
+    for i, g in enumerate(got):
+        g = int(g)
+        lg = dc.step(tok)
+        if suppress is not None:
+            lg = lg.copy()
+            lg[np.asarray(suppress, dtype=np.int64)] = -np.inf
+        thr = rel * float(np.abs(lg[np.isfinite(lg)]).max())
+        best = int(np.argmax(lg))
+        top2 = np.partition(lg, -2)[-2:]
+        short = float(lg[best] - lg[g])
+        worst = max(worst, short)
+        assert short <= thr, (what, i, g, best, short, thr)
+        if top2[1] - top2[0] > thr:
+            assert g == best, (what, i, g, best, float(top2[1] - top2[0]), thr)
+            compared += 1
+        tok = g
+        if g == sp["eot"]:
+            break
+    assert compared >= need, (what, f"only {compared} picks had an oracle margin above the bar")
+    return compared, worst
+
+
+MODELS = {  # name: (weights seed, clips as (seed, samples), new tokens, resolvable picks required per clip)
+    "tiny": (0, ((300, 464000), (301, 130000), (302, 52000)), 8, 4),
+    "base": (1, ((310, 300000), (311, 90000)), 6, 4),
+    "small": (3, ((320, 160000),), 5, 4),          # one catalog model (managers/model.rs:74-93) at full depth
+}
+
+
+@pytest.mark.parametrize("name", list(MODELS))
+def test_mode1_transcribe_tokens_against_the_chained_f16_oracle(oracle, name):
+    """`crispy_asr_transcribe_tokens` in mode 1: host PCM -> log-mel -> f16 encoder -> cross K|V -> greedy decode, ids
+    against the chained f16 oracle; also closer to that oracle than the exact one would demand, and audio dependent."""
+    from crispy_amd import synth_audio
+    from crispy_amd.asr import WhisperModel
+    from crispy_amd.mel_filters import whisper_mel_filters
+    from crispy_amd.whisper_weights import HParams, synthetic_whisper_weights
+    from oracle import whisper_oracle as WO
+    wseed, clip_spec, n_new, need = MODELS[name]
+    hp = getattr(HParams, name)()
+    W = synthetic_whisper_weights(hp, wseed, sensitive=True)
+    m = WhisperModel(hp, W)
+    m.set_precision(1)
+    clips = [synth_audio.clip16k_np(s, n) for s, n in clip_spec]
+    prompt = WO.default_prompt(hp.n_vocab, no_timestamps=True)
+    toks, n = m.transcribe_tokens(clips, prompt, n_new)
+    again, _ = m.transcribe_tokens(clips, prompt, n_new)
+    assert np.array_equal(toks, again)                                   # deterministic
+    F = whisper_mel_filters(hp.n_mels)
+    total = 0
+    for b, c in enumerate(clips):
+        solo, _ = m.transcribe_tokens([c], prompt, n_new)
+        assert np.array_equal(solo[0], toks[b]), (name, b)              # batch == solo in mode 1
+        enc16 = WO.encoder_forward_f16(W, hp, oracle.oracle_logmel(c, F))
+        k, worst = forced_picks(W, hp, enc16, prompt, toks[b], need, f"{name} clip {b}")
+        print(f"mode 1 {name} clip {b}: {k} of {n_new} picks resolvable, worst shortfall {worst:.2e}, ids {toks[b].tolist()}")
+        total += k
+    if len(clips) > 1:
+        assert len({tuple(t.tolist()) for t in toks}) == len(clips), toks     # the ids depend on the audio
+    m.close()
+
+
+def _engine_file(tmp_path_factory, hp, W, tag):
+    from crispy_amd.ggml_io import synthetic_vocab, write_ggml
+    from crispy_amd.mel_filters import whisper_mel_filters
+    path = tmp_path_factory.mktemp("ggml_m1") / f"ggml-{tag}.bin"
+    write_ggml(str(path), hp, W, whisper_mel_filters(hp.n_mels), synthetic_vocab(hp.n_vocab), f16=False)
+    return str(path)
+
+
+def _wcpp_masks(hp):
+    from oracle import whisper_oracle as WO
+    sp = WO.special_tokens(hp.n_vocab)
+    sup = [sp["sot"], sp["nosp"], sp["translate"], sp["transcribe"], sp["prev"], sp["solm"]]
+    sup += list(range(sp["lang0"], sp["lang0"] + sp["n_lang"]))
+    return sp, sorted(sup), [220, sp["eot"]]
+
+
+def test_mode1_transcribe_segments_follow_the_f16_seek_loop(oracle, tmp_path_factory):
+    """`crispy_asr_transcribe` with whisper.cpp's default options (timestamps on, seek loop) in MODE 1 against
+    `transcribe_timestamps(f16=True)`: two windows, kept tokens, segment times and texts; `opts == NULL`; batch == single
+    calls in mode 1; a second, long clip on audio-sensitive weights compared up to its first unresolvable pick."""
+    import ctypes as C
+    from crispy_amd import _native as N, synth_audio
+    from crispy_amd.asr import WhisperEngine, transcribe_batch
+    from crispy_amd.mel_filters import whisper_mel_filters
+    from crispy_amd.whisper_weights import HParams, synthetic_whisper_weights
+    from oracle import whisper_oracle as WO
+    hp = HParams.tiny()
+    F = whisper_mel_filters(80)
+    sp, sup, sup_first = _wcpp_masks(hp)
+    prompt = [sp["sot"], sp["lang0"], sp["transcribe"]]
+    # (a) plain weights, 3.5 s clip: the oracle's windows all resolve (smallest margin 0.017 against a bar of ~0.007)
+    W = synthetic_whisper_weights(hp, 0)
+    eng = WhisperEngine(_engine_file(tmp_path_factory, hp, W, "tiny-s0"))
+    eng.set_precision(1)
+    x = synth_audio.clip16k_np(52, 56000)
+    text, segs, toks = eng.transcribe_segments(x, max_new_tokens=10, language_token=sp["lang0"])
+    rsegs, rkept, wins = WO.transcribe_timestamps(W, hp, lambda seek: oracle.oracle_logmel(x, F, seek), x.size, prompt,
+                                                  WO.RULES_WCPP, eng.token_text, n_max=10, suppress=sup,
+                                                  suppress_first=sup_first, max_windows=16, f16=True)
+    assert len(wins) >= 2
+    bar = MODE1_REL * 4.6                       # logit scale of this model: |logit| <= 4.6
+    assert min(min(w["margins"]) for w in wins) > bar, "test clip has a pick the mode cannot resolve; choose another seed"
+    assert toks == [t for t in rkept if t != sp["eot"]], (toks, rkept)
+    assert [(round(a * 100), round(b * 100), s) for a, b, s in segs] == [(a, b, s.decode()) for a, b, s in rsegs]
+    assert text == "".join(s for _, _, s in segs)
+    # opts == NULL = TranscribeOptions::default() (managers/transcription.rs:184): language detected, timestamps on
+    res = C.c_void_p()
+    N.check(N.lib().crispy_asr_transcribe(eng._h, x.ctypes.data, x.size, None, C.byref(res)))
+    r = C.cast(res, C.POINTER(N.AsrResult)).contents
+    lang_null, n_tok_null = int(r.language_token), int(r.n_tokens)
+    N.lib().crispy_asr_free_result(res)
+    _, segs_auto, toks_auto = eng.transcribe_segments(x, max_new_tokens=0)
+    assert lang_null == eng.last_language_token and n_tok_null == len(toks_auto) and lang_null >= sp["lang0"]
+    # batch == single calls, mode 1
+    clips = [x, synth_audio.clip16k_np(53, 90000), np.zeros(0, np.float32), synth_audio.clip16k_np(54, 15000)]
+    got = transcribe_batch(eng, clips, max_new_tokens=10, language_token=sp["lang0"], timestamps=True, with_segments=True)
+    assert got[0] == (text, toks, sp["lang0"], segs)
+    t1, s1, k1 = eng.transcribe_segments(clips[1], max_new_tokens=10, language_token=sp["lang0"])
+    assert got[1] == (t1, k1, sp["lang0"], s1) and got[2] == ("", [], 0, []) and got[3][:2] == ("", [])
+    eng.close()
+    # (b) audio-sensitive weights, 25 s clip: the kept tokens up to the oracle's first unresolvable pick
+    Ws = synthetic_whisper_weights(hp, 0, sensitive=True)
+    eng = WhisperEngine(_engine_file(tmp_path_factory, hp, Ws, "tiny-s0-sensitive"))
+    eng.set_precision(1)
+    y = synth_audio.clip16k_np(53, 400000)
+    _, _, ytoks = eng.transcribe_segments(y, max_new_tokens=10, language_token=sp["lang0"])
+    _, ykept, ywins = WO.transcribe_timestamps(Ws, hp, lambda seek: oracle.oracle_logmel(y, F, seek), y.size, prompt,
+                                               WO.RULES_WCPP, eng.token_text, n_max=10, suppress=sup,
+                                               suppress_first=sup_first, max_windows=2, f16=True)
+    ok = 0
+    for w in ywins:
+        kept_m = w["margins"][:w["result_len"]]
+        if min(w["margins"]) <= bar:
+            ok += int(np.argmax(np.array(kept_m) <= bar)) if (np.array(kept_m) <= bar).any() else len(kept_m)
+            break
+        ok += w["result_len"]
+    ref = [t for t in ykept[:ok]]
+    assert ok >= 5, (ok, [w["margins"] for w in ywins])
+    assert ytoks[:len([t for t in ref if t != sp["eot"]])] == [t for t in ref if t != sp["eot"]], (ytoks, ykept, ok)
+    eng.close()
+
+
+def test_mode1_language_detection_does_not_depend_on_call_history(oracle):
+    """`crispy_asr_detect_language_device` chose the f16 / f32 self K|V form by what the PREVIOUS decode call
+    had left in the handle.  A fresh handle, the same handle after a long decode, and the f16 oracle must agree."""
+    import torch
+    from crispy_amd import synth_audio
+    from crispy_amd.asr import WhisperModel
+    from crispy_amd.mel_filters import whisper_mel_filters
+    from crispy_amd.whisper_weights import HParams, synthetic_whisper_weights
+    from oracle import whisper_oracle as WO
+    hp = HParams.tiny()
+    W = synthetic_whisper_weights(hp, 0, sensitive=True)
+    sp = WO.special_tokens(hp.n_vocab)
+    clips = [synth_audio.clip16k_np(330 + i, 100000 + 60000 * i) for i in range(4)]
+    m = WhisperModel(hp, W)
+    m.set_precision(1)
+    d_enc = torch.from_numpy(m.encode(clips)).cuda()
+    torch.cuda.synchronize()
+    fresh = m.detect_language_device(d_enc.data_ptr(), 4)
+    m.decode_greedy_device(d_enc.data_ptr(), 4, [sp["sot"], sp["lang0"], sp["transcribe"], sp["not_"]], 300)   # 304 keys: the 512 class
+    after = m.detect_language_device(d_enc.data_ptr(), 4)
+    assert np.array_equal(fresh, after), (fresh, after)
+    F = whisper_mel_filters(80)
+    resolved = 0
+    for b, c in enumerate(clips):
+        enc16 = WO.encoder_forward_f16(W, hp, oracle.oracle_logmel(c, F))
+        lg = WO.DecoderCache(W, hp, enc16, f16=True).step(sp["sot"])
+        lang = lg[sp["lang0"]:sp["lang0"] + sp["n_lang"]]
+        top2 = np.sort(lang)[-2:]
+        if top2[1] - top2[0] > MODE1_REL * np.abs(lg).max():
+            assert fresh[b] == sp["lang0"] + int(np.argmax(lang)), (b, fresh[b])
+            resolved += 1
+    assert resolved >= 2, resolved
+    m.close()
