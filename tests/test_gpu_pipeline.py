@@ -202,16 +202,32 @@ def test_cfg4_full_size_1024_streams_x_30_s_end_to_end(oracle, precision):
         n = ref16.size - 400            # the oracle's last block saw zero padding where the GPU saw more audio
         assert np.abs(got[i, :n] - ref16[:n]).max() <= 2e-4, b
         assert np.mean(np.abs(got[i, :n] - ref16[:n]) > 1e-5) < 0.01
-    # (d) the whole chain for stream 333, all 30 s, from the oracles only
+    # (d) stream 333, all 30 s.  Three comparisons, because the audio-sensitive model AMPLIFIES encoder differences: measured
+    # on the oracle itself, encoder noise of the size mode 1 is allowed (5.5e-5 rms of the peak, what f32 accumulation in
+    # another order does to f16 roundings) moves single logits by up to 0.11 = 2.5 % of the logit scale over 64 steps
+    # (a plain fan-in model: 1e-3).  So: (d1) the GPU's encoder output against the oracle encoder of the mode on the
+    # GPU's own 16 kHz PCM, at the mode's bars; (d2) the decoder alone, teacher-forced on the GPU's encoder output, at
+    # the mode's strict bar -- every one of the 64 picks; (d3) the whole chain from the oracles only (denoise -> WAV ->
+    # resample -> log-mel -> encoder -> decoder) at the amplified bar in mode 1.
     b = 333
+    F = whisper_mel_filters(80)
+    enc_f = WO.encoder_forward_f16 if precision else WO.encoder_forward
+    enc_gpu = pipe._enc[b].cpu().numpy().astype(np.float64)          # chunk 0 (the 168-sample chunk 1 is never encoded)
+    ref_on_gpu_pcm = enc_f(W, hp, oracle.oracle_logmel(pcm16[b, :480000].cpu().numpy(), F))
+    peak = np.abs(ref_on_gpu_pcm).max()
+    e_max = np.abs(enc_gpu - ref_on_gpu_pcm).max() / peak
+    e_rms = np.sqrt(np.mean((enc_gpu - ref_on_gpu_pcm) ** 2)) / peak
+    assert e_max <= (4e-4 if precision else 1e-4) and e_rms <= (8e-5 if precision else 1e-5), (e_max, e_rms)
+    k2, w2 = forced_picks(W, hp, enc_gpu, prompt, toks[b, 0], 48, f"cfg 4 stream {b} mode {precision}, decoder on the GPU's encoder output",
+                          f16=bool(precision), rel=MODE1_REL if precision else 2.5e-4)
     den, _ = oracle.OracleDenoiseState(w).process(x[b].cpu().numpy())
     a = np.clip(den[1:].ravel() / np.float32(32768.0), -1, 1)
     ref16 = RO.resample_48k_to_16k(RO.wav_s16_roundtrip(a))[:480000]
-    mel = oracle.oracle_logmel(ref16, whisper_mel_filters(80))
-    enc = (WO.encoder_forward_f16 if precision else WO.encoder_forward)(W, hp, mel)
-    k, worst = forced_picks(W, hp, enc, prompt, toks[b, 0], 32, f"cfg 4 stream {b} mode {precision}", f16=bool(precision),
-                            rel=MODE1_REL if precision else 2.5e-4)
-    print(f"cfg 4 mode {precision}: stream {b}: {k} of {NEW} picks resolvable against the chained oracle, worst shortfall {worst:.2e}")
+    enc = enc_f(W, hp, oracle.oracle_logmel(ref16, F))
+    k3, w3 = forced_picks(W, hp, enc, prompt, toks[b, 0], 24, f"cfg 4 stream {b} mode {precision}, whole oracle chain", f16=bool(precision),
+                          rel=0.03 if precision else 2.5e-4)
+    print(f"cfg 4 mode {precision}: stream {b}: encoder {e_max:.1e} max / {e_rms:.1e} rms; decoder on the GPU's encoder output "
+          f"{k2} of {NEW} picks resolvable (worst shortfall {w2:.1e}); whole oracle chain {k3} of {NEW} (worst shortfall {w3:.1e})")
     wm.close()
 
 
@@ -289,10 +305,14 @@ def test_cfg5_one_shard_whisper_base_sub_batch_of_256_clips(oracle, precision):
     b = 100
     mel = oracle.oracle_logmel(pcm[b].cpu().numpy(), whisper_mel_filters(hp.n_mels))
     ref = (WO.encoder_forward_f16 if precision else WO.encoder_forward)(W, hp, mel)
-    got = enc[b].cpu().numpy()
+    got = enc[b].cpu().numpy().astype(np.float64)
     peak = np.abs(ref).max()
     assert np.abs(got - ref).max() / peak <= (4e-4 if precision else 1e-4)
-    k, worst = forced_picks(W, hp, ref, prompt, toks[b], 3, f"cfg 5 clip {b} mode {precision}", f16=bool(precision),
-                            rel=MODE1_REL if precision else 2.5e-4)
-    print(f"cfg 5 mode {precision}: clip {b}: {k} of {NEW} picks resolvable, worst shortfall {worst:.2e}, ids {toks[b].tolist()}")
+    # the decoder alone on the GPU's encoder output at the mode's strict bar, then the whole chain (the audio-sensitive
+    # model amplifies the allowed encoder difference: see the cfg 4 test)
+    k2, w2 = forced_picks(W, hp, got, prompt, toks[b], 4, f"cfg 5 clip {b} mode {precision}, decoder", f16=bool(precision),
+                          rel=MODE1_REL if precision else 2.5e-4)
+    k3, w3 = forced_picks(W, hp, ref, prompt, toks[b], 3, f"cfg 5 clip {b} mode {precision}, chain", f16=bool(precision),
+                          rel=0.03 if precision else 2.5e-4)
+    print(f"cfg 5 mode {precision}: clip {b}: decoder {k2} / chain {k3} of {NEW} picks resolvable, worst shortfalls {w2:.1e} / {w3:.1e}, ids {toks[b].tolist()}")
     m.close()
