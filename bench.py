@@ -32,8 +32,19 @@ BYTES_PER_STREAM_FRAME = 3840  # 480 f32 in + 480 f32 out
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(n_threads: int, frames_per_thread: int):
-    """Oracle (kind 'port') on host cores: independent streams, one per thread."""
+def _host_threads() -> int:
+    """Host threads this process may use (the GPU box hands a 1-GPU job a share of the host, not all of it)."""
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        return max(1, os.cpu_count() or 1)
+
+
+def cpu_baseline(frames_per_thread: int = 2500, reps: int = 12):
+    """Oracle (kind 'port') on host cores, BASELINE.md section 3: (a) ONE thread, one stream -- how the reference uses
+    nnnoiseless (one stream on the audio thread, audio.rs:751-787) -- and (b) every host thread this process may use,
+    one independent stream per thread.  `value` is (b); (a) rides along as `single_thread`.  Bounded: each leg is
+    `frames_per_thread x reps` frames per thread (~10 s)."""
     import numpy as np
     from concurrent.futures import ThreadPoolExecutor
 
@@ -62,30 +73,44 @@ def cpu_baseline(n_threads: int, frames_per_thread: int):
     else:
         L = O.lib()
     w = synthetic_weights(0)
-    xs = [np.ascontiguousarray(synth_audio.stream_np(b, frames_per_thread, silent=False) * np.float32(32768.0))
-          for b in range(n_threads)]
-    handles = [L.rno_create(w.ctypes.data, w.size) for _ in range(n_threads)]
-    outs = [np.empty_like(x) for x in xs]
+    build = "-O3 -march=native" if lib_path else "-O2"
 
-    REPS = 16       # the same buffer again and again (the state carries on): ~10 s of work on each thread
+    def leg(n_threads):
+        xs = [np.ascontiguousarray(synth_audio.stream_np(b, frames_per_thread, silent=False) * np.float32(32768.0))
+              for b in range(n_threads)]
+        handles = [L.rno_create(w.ctypes.data, w.size) for _ in range(n_threads)]
+        outs = [np.empty_like(x) for x in xs]
 
-    def run(i):
-        for _ in range(REPS):
-            L.rno_process_frames(handles[i], O.fp(outs[i]), O.fp(xs[i]), frames_per_thread, None)
+        def run(i):        # the same buffer again and again (the state carries on)
+            for _ in range(reps):
+                L.rno_process_frames(handles[i], O.fp(outs[i]), O.fp(xs[i]), frames_per_thread, None)
 
-    with ThreadPoolExecutor(n_threads) as ex:
-        list(ex.map(lambda i: L.rno_process_frames(handles[i], O.fp(outs[i]), O.fp(xs[i]), frames_per_thread, None),
-                    range(n_threads)))  # warm
-        t0 = time.perf_counter()
-        list(ex.map(run, range(n_threads)))
-        dt = time.perf_counter() - t0
-    for h in handles:
-        L.rno_destroy(h)
-    fps = n_threads * frames_per_thread * REPS / dt
-    return {"value": fps / 100.0, "unit": "concurrent real-time 48 kHz streams", "cores": n_threads,
-            "kind": "port",
-            "sample": f"{n_threads} streams x {frames_per_thread * REPS} frames (tone+noise), C oracle "
-                      f"{'-O3 -march=native' if lib_path else '-O2'}, one stream per thread, {dt:.1f} s"}
+        with ThreadPoolExecutor(n_threads) as ex:
+            list(ex.map(lambda i: L.rno_process_frames(handles[i], O.fp(outs[i]), O.fp(xs[i]), frames_per_thread, None),
+                        range(n_threads)))  # warm
+            t0 = time.perf_counter()
+            list(ex.map(run, range(n_threads)))
+            dt = time.perf_counter() - t0
+        for h in handles:
+            L.rno_destroy(h)
+        fps = n_threads * frames_per_thread * reps / dt
+        return {"value": fps / 100.0, "unit": "concurrent real-time 48 kHz streams", "cores": n_threads, "kind": "port",
+                "sample": f"{n_threads} stream(s) x {frames_per_thread * reps} frames (tone+noise), C oracle {build}, "
+                          f"one stream per thread, {dt:.1f} s"}
+
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    many = leg(_host_threads())
+    many["single_thread"] = leg(1)
+    many["host"] = {"cpu_model": cpu_model, "os_cpu_count": os.cpu_count(), "usable_threads": _host_threads()}
+    return many
 
 
 def measure_traffic(B: int, T: int):
@@ -142,18 +167,34 @@ def pmc_child(args):
     ds.synchronize()
 
 
-def asr_leg(local_rank: int, clips: int = 64, new_tokens: int = 32):
+def encoder_flops(hp) -> float:
+    """Encoder FLOPs per 30 s clip from the model's dimensions (SURVEY.md 8d's 36.9 GFLOP for tiny, 87.4 for base)."""
+    d, L, T = hp.n_audio_state, hp.n_audio_layer, hp.n_audio_ctx
+    conv = 2.0 * (2 * T) * d * 3 * hp.n_mels + 2.0 * T * d * 3 * d
+    block = 4 * 2.0 * T * d * d + 2 * 2.0 * T * T * d + 2 * 2.0 * T * d * 4 * d
+    return conv + L * block
+
+
+def asr_leg(local_rank: int, clips: int = 64, new_tokens: int = 32, ggml_path: str | None = None):
     """Second half of the headline metric: Whisper-tiny RTFx on one GPU (BASELINE configs[2]/[3]):
     `clips` x 30 s of 16 kHz audio resident in HBM -> log-mel -> encoder -> greedy decode of
-    `new_tokens` tokens (random-init weights never emit EOT, so the decode length is fixed)."""
+    `new_tokens` tokens (random-init weights never emit EOT, so the decode length is fixed).
+    `ggml_path`: a whisper.cpp model file supplied at run time (SURVEY.md 8d cfg 3: "if a ggml-tiny.bin is supplied at
+    run time use it") replaces the seeded random-init Whisper-tiny; the audio stays synthetic."""
     import numpy as np
     import torch
 
-    from crispy_amd.asr import LogMel, WhisperModel
+    from crispy_amd.asr import LogMel, WhisperEngine, WhisperModel
     from crispy_amd.whisper_weights import HParams, synthetic_whisper_weights
 
-    hp = HParams.tiny()
-    model = WhisperModel(hp, synthetic_whisper_weights(hp, 0), device=local_rank)
+    if ggml_path:
+        model = WhisperEngine(ggml_path, device=local_rank)
+        hp = model.hp
+        model_label = f"GGML model file {os.path.basename(ggml_path)} (d {hp.n_audio_state}, {hp.n_audio_layer}+{hp.n_text_layer} layers)"
+    else:
+        hp = HParams.tiny()
+        model = WhisperModel(hp, synthetic_whisper_weights(hp, 0), device=local_rank)
+        model_label = "whisper-tiny architecture, seeded random-init weights"
     lm = LogMel(hp.n_mels, device=local_rank)
     dev = torch.device("cuda", local_rank)
     g = torch.Generator(device=dev).manual_seed(0)
@@ -161,7 +202,9 @@ def asr_leg(local_rank: int, clips: int = 64, new_tokens: int = 32):
     melt = torch.zeros(clips, 3002, hp.n_mels, device=dev)
     enc = torch.empty(clips, 1500, hp.n_audio_state, device=dev)
     lens = np.full(clips, 480000)
-    prompt = [50258, 50259, 50359, 50363]
+    from crispy_amd import _native as N
+    sp = N.vocab_specials(hp.n_vocab)
+    prompt = ([sp.sot, sp.sot + 1, sp.transcribe, sp.notimestamps] if hp.n_vocab >= 51865 else [sp.sot, sp.notimestamps])
     torch.cuda.synchronize()
 
     def mel():
@@ -211,37 +254,48 @@ def asr_leg(local_rank: int, clips: int = 64, new_tokens: int = 32):
     one16 = single_clip()
     longer16 = {n: decode_n(n) for n in (64, 224)}
     model.set_precision(0)
-    # CPU beside it: the float64 numpy oracle (BLAS on the host cores) on ONE 30 s clip, encoder + 2 greedy steps
+    # CPU beside it (kind "port"): the numpy restatement in SINGLE precision (OpenBLAS sgemm on the host threads this
+    # process may use -- what a CPU engine's matrix products amount to) on ONE 30 s clip: C log-mel + encoder + greedy
+    # steps of the KV-cached decoder.  The float64 run of the same code is the parity oracle and is not what is timed.
     cpu = None
     try:
+        if ggml_path:
+            raise RuntimeError("no CPU restatement of a supplied model file (its tensors live in the library)")
         from crispy_amd import synth_audio
         from crispy_amd.mel_filters import whisper_mel_filters
         from oracle import whisper_oracle as WO
         from tests import oracle_lib as O
         W = synthetic_whisper_weights(hp, 0)
         x1 = synth_audio.clip16k_np(0, 480000)
+        WO.encoder_forward(W, hp, O.oracle_logmel(x1[:32000], whisper_mel_filters(hp.n_mels)), upto_layer=1, dtype=np.float32)  # warm BLAS
         t0 = time.perf_counter()
-        e1 = WO.encoder_forward(W, hp, O.oracle_logmel(x1, whisper_mel_filters(hp.n_mels)))
+        e1 = WO.encoder_forward(W, hp, O.oracle_logmel(x1, whisper_mel_filters(hp.n_mels)), dtype=np.float32)
         t_enc = time.perf_counter() - t0
-        dc = WO.DecoderCache(W, hp, e1)
+        t0 = time.perf_counter()
+        dc = WO.DecoderCache(W, hp, e1, dtype=np.float32)
         for t in prompt[:-1]:
             dc.step(t)
+        t_pre = time.perf_counter() - t0
         t0 = time.perf_counter()
         tok = prompt[-1]
-        for _ in range(4):
+        for _ in range(8):
             tok = int(np.argmax(dc.step(tok)))
-        t_tok = (time.perf_counter() - t0) / 4
-        cpu = {"value": 30.0 / (t_enc + new_tokens * t_tok), "unit": "x real time (end to end, same token count)",
-               "cores": os.cpu_count(), "kind": "port",
-               "sample": f"1 clip of 30 s: oracle log-mel + float64 numpy encoder {t_enc:.1f} s, KV-cached numpy decoder "
-                         f"{t_tok * 1e3:.0f} ms/token extrapolated to {new_tokens} tokens"}
+        t_tok = (time.perf_counter() - t0) / 8
+        cpu = {"value": 30.0 / (t_enc + t_pre + new_tokens * t_tok), "unit": "x real time (end to end, same token count)",
+               "cores": _host_threads(), "kind": "port",
+               "sample": f"1 clip of 30 s: C log-mel + float32 numpy/BLAS encoder {t_enc:.2f} s, cross K|V + prompt {t_pre:.2f} s, "
+                         f"KV-cached decoder {t_tok * 1e3:.1f} ms/token x {new_tokens} tokens; single stream, as the reference "
+                         f"runs one engine behind a mutex (managers/transcription.rs:27,178)"}
     except Exception as e:  # the baseline is a reported extra, never a reason to lose the GPU numbers
         cpu = {"error": str(e)}
     audio_s = clips * 30.0
-    enc_flops = clips * 36.9e9          # Whisper-tiny encoder per 30 s clip
+    enc_flops = clips * encoder_flops(hp)          # 36.9 GFLOP per 30 s clip for Whisper-tiny
     total = sum(times.values())
     return {
-        "model": "whisper-tiny architecture, seeded random-init weights, f32 on f32-input MFMA",
+        "model": model_label,
+        "modes": "top-level figures of this block: precision mode 0 (exact f32 products on the f32-input matrix cores, the "
+                 "mode the 1e-4 oracle parity is stated in); `f16_operand_mode`: precision mode 1 = the reference engine's "
+                 "arithmetic (f16 operands, f32 accumulation), the Rust binding's default",
         "clips": clips, "audio_seconds": audio_s, "new_tokens": new_tokens,
         "logmel_ms": times["logmel"] * 1e3, "encoder_ms": times["encoder"] * 1e3,
         "decode_ms": times["decode"] * 1e3, "decode_ms_per_token": times["decode"] * 1e3 / new_tokens,
@@ -354,6 +408,11 @@ def dry_run(args):
 
 
 def cfg5(args):
+    _numa = _bind_numa(_dist_env()[1], _dist_env()[2])      # before torch / HIP are touched
+    return _cfg5(args, _numa)
+
+
+def _cfg5(args, numa):
     """BASELINE configs[4]: Whisper-base full transcribe, 8192 streams sharded across 8 GPUs = 1024 x 30 s clips per
     GPU (static shard by stream id, no data-path collective).  One step = one sub-batch of `--clips` clips resident
     in HBM: log-mel -> encoder -> greedy decode of `--new-tokens` tokens (random-init weights never emit EOT, so the
@@ -366,7 +425,7 @@ def cfg5(args):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     from crispy_amd.asr import LogMel, WhisperModel
-    from crispy_amd.sharding import reduce_job_stats, shard_range
+    from crispy_amd.sharding import gather_token_ids, reduce_job_stats, shard_range
     from crispy_amd.whisper_weights import HParams, synthetic_whisper_weights
 
     hp = HParams.base()
@@ -420,6 +479,11 @@ def cfg5(args):
     dt = time.perf_counter() - t0
     per_rank = _gather_ms(dist, dt * 1e3, dev)
     dt, clips_total = reduce_job_stats(dt, SUB * args.steps, device=dev)
+    # the data product of the job: the fixed-width greedy ids of every rank's last sub-batch, gathered to
+    # all ranks in rank order with ONE RCCL all-gather ([SUB, NEW] int32 per rank, ~32 KB: latency-bound) -- outside the
+    # timed region, as transcript assembly is in the product; rank 0 prints a checksum of the assembled table
+    ids_dev = torch.from_numpy(np.ascontiguousarray(toks[0], dtype=np.int32)).to(dev)
+    all_ids = gather_token_ids(ids_dev)
     if rank == 0:
         enc_flops = 87.4e9 * SUB * args.steps                     # Whisper-base encoder per 30 s clip
         peak = 157.3 if args.precision == 0 else 2500.0
@@ -430,7 +494,10 @@ def cfg5(args):
             "n_gpus": world_reported, "steps": args.steps, "warmup": max(1, args.warmup),
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == 0 else "f16 operands / f32 accumulate", "data": "synthetic",
-            "per_rank_ms": per_rank,
+            "per_rank_ms": per_rank, "process_group": ("nccl (RCCL)" if dist else None), "numa_binding": numa,
+            "transcript_ids": {"shape": list(all_ids.shape), "gathered_with": "all_gather_into_tensor" if dist else "single rank",
+                               "checksum": int(all_ids.to(torch.int64).sum().item()),
+                               "rank0_first_clip": all_ids[0, :8].tolist()},
             "config": {"workload": f"Whisper-base full transcribe (BASELINE configs[4]): {SUB * args.steps} x 30 s clips per "
                                    f"GPU in sub-batches of {SUB}, {NEW} greedy tokens per clip, seeded random-init weights",
                        "clips_per_gpu": SUB * args.steps, "clips_per_step": SUB, "new_tokens": NEW,
@@ -446,18 +513,131 @@ def cfg5(args):
         dist.destroy_process_group()
 
 
+def cfg4(args):
+    """BASELINE configs[3]: end-to-end denoise -> adapter scaling / first-frame drop -> s16 WAV hand-off -> 48->16 kHz ->
+    30 s chunk -> log-mel -> Whisper-tiny encoder -> greedy decode of `--new-tokens` (64) tokens, `--pipe-streams` (1024)
+    streams x 30 s of 48 kHz audio resident in HBM per step, precision mode 1 (the reference engine's arithmetic) unless
+    --precision 0.  value = seconds of audio per wall second, whole job.
+
+    RNNoise is a strict 3000-frame recurrence per stream (~42 us per frame and wave whatever the stream count below 4096),
+    so inside ONE step it cannot overlap the ASR stages of the same streams; across steps it can: `--pipe-depth 2`
+    (default) drives two pipelines (own handles, own HIP streams, own workspaces) from two host threads, and the
+    denoise stage of step k + 1 runs under the encoder / decoder of step k.  `--pipe-depth 1` is the serial form whose
+    stage split is printed beside it."""
+    rank, local_rank, world = _dist_env()
+    numa = _bind_numa(local_rank, world)
+    import threading
+
+    import numpy as np
+    import torch
+
+    dist, world_reported = _init_dist("nccl", local_rank, world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    from crispy_amd import synth_audio
+    from crispy_amd.asr import WhisperModel
+    from crispy_amd.pipeline import DenoiseTranscribePipeline
+    from crispy_amd.sharding import reduce_job_stats, shard_range
+    from crispy_amd.whisper_weights import HParams, synthetic_whisper_weights
+
+    B, T, NEW, depth = args.pipe_streams, 3001, args.new_tokens, max(1, args.pipe_depth)
+    weights, weights_label = _rn_weights(args)
+    hp = HParams.tiny()
+    W = synthetic_whisper_weights(hp, 0)
+    lo, hi = shard_range(world * B, rank, world)
+    x = synth_audio.batch_torch(B, T, dev, first_stream=lo, seed=5).transpose(0, 1).contiguous()      # [B, T, 480]
+    prompt = [50258, 50259, 50359, 50363]
+    pipes = []
+    for _ in range(depth):
+        wm = WhisperModel(hp, W, device=local_rank)
+        wm.set_precision(args.precision)
+        pipes.append(DenoiseTranscribePipeline(weights, wm, B, device=local_rank))
+    torch.cuda.synchronize()
+    for p in pipes:                       # warm-up: workspaces, captured decode graphs, f16 weight copies
+        for _ in range(max(1, args.warmup)):
+            toks, _ = p.run(x, prompt, NEW)
+            p.ds.reset()
+    stage = dict(pipes[0].timings)        # serial stage split (the last warm-up run of pipeline 0, nothing beside it)
+    serial_ms = sum(stage.values()) * 1e3
+
+    def barrier():
+        if dist:
+            dist.barrier()
+
+    def worker(k):
+        for i in range(k, args.steps, depth):
+            pipes[k].run(x, prompt, NEW)
+            pipes[k].ds.reset()            # every step is a fresh batch of streams
+
+    torch.cuda.synchronize()
+    barrier()
+    if dist:
+        _flush_c_stdout()
+        barrier()
+    t0 = time.perf_counter()
+    if depth == 1:
+        worker(0)
+    else:
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(depth)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    per_rank = _gather_ms(dist, dt * 1e3, dev)
+    dt, streams_total = reduce_job_stats(dt, B * args.steps, device=dev)
+    if rank == 0:
+        audio_s = streams_total * 30.0
+        print(json.dumps({
+            "metric": "end-to-end denoise -> Whisper-tiny greedy decode RTFx (seconds of 48 kHz audio per wall second, whole job)",
+            "value": audio_s / dt, "unit": "x real time (whole job)", "n_gpus": world_reported, "steps": args.steps,
+            "warmup": max(1, args.warmup), "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 (RNNoise, resampler, log-mel) + " + ("f32" if args.precision == 0 else "f16 operands / f32 accumulate") + " (Whisper)",
+            "data": "synthetic", "per_rank_ms": per_rank, "process_group": ("nccl (RCCL)" if dist else None), "numa_binding": numa,
+            "config": {"workload": f"BASELINE configs[3]: {B} streams x 30 s @ 48 kHz per GPU and step -> RNNoise -> WAV s16 -> 48->16 kHz "
+                                   f"-> log-mel -> Whisper-tiny encoder -> {NEW} greedy tokens; {weights_label}; seeded random-init Whisper-tiny",
+                       "streams_per_gpu": B, "new_tokens": NEW, "precision_mode": args.precision, "pipe_depth": depth,
+                       "serial_step_ms": serial_ms, "serial_stage_ms": {k: v * 1e3 for k, v in stage.items()},
+                       "sharding": f"streams x{world_reported}, no collective",
+                       "tokens_checksum": int(np.asarray(toks, dtype=np.int64)[toks >= 0].sum())},
+            "roofline": {"bound": "mfma", "achieved": encoder_flops(hp) * streams_total / dt / 1e12,
+                         "peak": 157.3 if args.precision == 0 else 2500.0, "unit": "TFLOP/s",
+                         "frac": encoder_flops(hp) * streams_total / dt / 1e12 / (157.3 if args.precision == 0 else 2500.0),
+                         "traffic": None, "kernel": "Whisper encoder GEMMs + attention, priced against the WHOLE step "
+                                                    "(RNNoise, resampler, log-mel and the decoder included in the time)"},
+        }), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=("cfg2", "cfg5"), default="cfg2",
-                    help="cfg2 = batched RNNoise (BASELINE configs[1], the headline); cfg5 = Whisper-base full "
+    ap.add_argument("--workload", choices=("cfg2", "cfg4", "cfg5"), default="cfg2",
+                    help="cfg2 = batched RNNoise (BASELINE configs[1], the headline); cfg4 = end-to-end denoise -> WAV -> "
+                         "48->16 kHz -> Whisper-tiny greedy decode (BASELINE configs[3]); cfg5 = Whisper-base full "
                          "transcribe shards (BASELINE configs[4])")
+    ap.add_argument("--host-fed", action="store_true",
+                    help="cfg2: feed every step from page-locked HOST memory through crispy_rn_process (copy-in, kernels and "
+                         "copy-out pipelined per rank) -- the PCIe-inclusive rate, labelled as such; never the headline")
+    ap.add_argument("--rnnoise-model", default=None,
+                    help="cfg2 / cfg4: an rnnoise-nu text model file (what nnnoiseless::RnnModel::from_read parses) instead "
+                         "of the seeded synthetic int8 weights")
+    ap.add_argument("--ggml", default=None,
+                    help="ASR leg of cfg2: a whisper.cpp GGML model file (e.g. ggml-tiny.bin) instead of the seeded "
+                         "random-init Whisper-tiny (SURVEY.md 8d cfg 3)")
     ap.add_argument("--streams", type=int, default=4096, help="cfg2: streams per GPU")
     ap.add_argument("--frames", type=int, default=100, help="cfg2: frames per stream per step")
     ap.add_argument("--clips", type=int, default=256, help="cfg5: 30 s clips per step (sub-batch) per GPU")
-    ap.add_argument("--new-tokens", type=int, default=32, help="cfg5: greedy tokens per clip")
+    ap.add_argument("--new-tokens", type=int, default=None, help="greedy tokens per clip (default: cfg5 32, cfg4 64)")
+    ap.add_argument("--pipe-streams", type=int, default=1024, help="cfg4: 48 kHz streams per GPU (30 s each)")
+    ap.add_argument("--pipe-depth", type=int, default=2,
+                    help="cfg4: pipelines in flight (own handles and HIP streams, one host thread each): with 2, RNNoise of "
+                         "step k + 1 runs under the encoder / decoder of step k; 1 = serial")
     ap.add_argument("--precision", type=int, default=1,
                     help="cfg5: 1 = f16 operands / f32 accumulation, the arithmetic of the reference's whisper.cpp engine (default); "
                          "0 = exact f32 products (the mode the oracle parity is stated in)")
@@ -471,7 +651,9 @@ def main():
                     help="launcher self-test on CPU (gloo, no GPU work, no value); used by tests/test_sharding_gloo.py")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 4 if args.workload == "cfg5" else 10
+        args.steps = {"cfg5": 4, "cfg4": 2}.get(args.workload, 10)
+    if args.new_tokens is None:
+        args.new_tokens = 64 if args.workload == "cfg4" else 32
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
 
@@ -493,13 +675,30 @@ def main():
         return dry_run(args)
     if args.workload == "cfg5":
         return cfg5(args)
+    if args.workload == "cfg4":
+        return cfg4(args)
     return cfg2(args)
 
 
+def _rn_weights(args):
+    """Seeded synthetic int8 weights, or the path of an rnnoise-nu model file (parsed by crispy_rn_create_from_file)."""
+    if args.rnnoise_model:
+        return args.rnnoise_model, f"rnnoise-nu model file {os.path.basename(args.rnnoise_model)}"
+    from crispy_amd import synthetic_weights
+    return synthetic_weights(0), "seeded synthetic int8 weights"
+
+
+def _bind_numa(local_rank: int, world: int):
+    """Before torch or HIP are touched: pin this rank to the CPUs of its GPU's NUMA node (crispy_amd/launch.py)."""
+    from crispy_amd.launch import bind_rank_to_gpu_numa
+    return bind_rank_to_gpu_numa(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+
+
 def cfg2(args):
+    rank, local_rank, world = _dist_env()
+    numa = _bind_numa(local_rank, world)
     import torch
 
-    rank, local_rank, world = _dist_env()
     dist, world_reported = _init_dist("nccl", local_rank, world)
     use_dist = dist is not None
     torch.cuda.set_device(local_rank)
@@ -509,7 +708,7 @@ def cfg2(args):
     from crispy_amd.denoise import DenoiseState
 
     B, T = args.streams, args.frames
-    weights = synthetic_weights(0)
+    weights, weights_label = _rn_weights(args)
     ds = DenoiseState(weights, B, local_rank)   # fails loudly without libcrispy_hip.so / gfx950
     # streams shard by stream id (crispy_amd.sharding: block partition, no data-path collective):
     # weak scaling, rank r owns global stream ids [r*B, (r+1)*B)
@@ -519,9 +718,22 @@ def cfg2(args):
     d_in = synth_audio.batch_torch(B, T, dev, first_stream=lo, seed=0)
     d_out = torch.empty_like(d_in)
     torch.cuda.synchronize()
+    h_in = h_out = h_vad = None
+    if args.host_fed:
+        # the input lives in page-locked HOST memory of this rank (first-touched after the NUMA binding above) and every
+        # step crosses PCIe both ways: crispy_rn_process cuts the call into pieces and overlaps copy-in / kernels / copy-out
+        import numpy as np
+        h_in = d_in.cpu().numpy()
+        h_out = np.empty_like(h_in)
+        h_vad = np.empty((T, B), dtype=np.float32)
+        for arr in (h_in, h_out):
+            DenoiseState.register_host(arr)
 
     def step():
-        ds.process_device(d_in.data_ptr(), d_out.data_ptr(), T)
+        if args.host_fed:
+            ds.process_into(h_in, h_out, h_vad)
+        else:
+            ds.process_device(d_in.data_ptr(), d_out.data_ptr(), T)
 
     def barrier():
         if use_dist:
@@ -560,6 +772,8 @@ def cfg2(args):
     launches = N.lib().crispy_rn_n_launches(T)
     frame_ms = sum(k[0] for k in k_ms) / len(k_ms) / launches
     total_ms = sum(k[1] for k in k_ms) / len(k_ms)
+    if args.host_fed:
+        d_out.copy_(torch.from_numpy(h_out))
     finite = bool(torch.isfinite(d_out).all().item())
 
     fps = frames_total / dt
@@ -597,15 +811,19 @@ def cfg2(args):
             pass
         achieved = alg_bytes / (frame_ms * 1e-3) / 1e9
         line = {
-            "metric": "concurrent real-time 48 kHz streams/GPU (RNNoise)",
+            "metric": "concurrent real-time 48 kHz streams/GPU (RNNoise)"
+                      + (" -- HOST-FED flavour: PCIe copies inside the timed region, not the headline" if args.host_fed else ""),
             "value": fps / 100.0,
             "unit": "concurrent real-time 48 kHz streams (whole job)",
             "n_gpus": world_reported, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic", "per_rank_ms": per_rank_ms,
+            "dtype": "f32", "data": "synthetic" + (", host-resident (PCIe-inclusive)" if args.host_fed else ""),
+            "per_rank_ms": per_rank_ms,
+            "process_group": ("nccl (RCCL)" if use_dist else None), "numa_binding": numa,
             "config": {"workload": f"Batched RNNoise: {B} concurrent 48 kHz mono streams per GPU x {T} frames per step "
-                                   f"(BASELINE configs[1]), seeded synthetic int8 weights",
+                                   f"(BASELINE configs[1]), {weights_label}"
+                                   + (", fed from page-locked host memory through crispy_rn_process" if args.host_fed else ""),
                        "streams_per_gpu": B, "frames_per_step": T, "sharding": f"streams x{world_reported}, no collective",
                        "frames_per_s": fps, "output_finite": finite},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -615,22 +833,31 @@ def cfg2(args):
                          "alg_bytes_per_launch": alg_bytes, "valu": valu},
         }
         if world == 1 and not args.no_cpu_baseline:
-            ncores = os.cpu_count() or 1
-            nthreads = max(1, min(ncores, 32))
-            line["cpu_baseline"] = cpu_baseline(nthreads, 2500)
+            line["cpu_baseline"] = cpu_baseline()
         if world == 1 and not args.no_latency:
             # the literal drop-in: ONE stream, ONE frame per call, host slices (audio.rs:260-268), from a C program
             # compiled against include/crispy_hip.h; a child process, timed call by call
             try:
                 from tests import c_dropin
                 x1 = (synth_audio.stream_np(11, 20, silent=False) * 32768.0).astype("float32").reshape(20, 480)
-                line["latency_us"] = c_dropin.run(weights, x1, timed_calls=10000)[2]
+                lat_w = weights if not isinstance(weights, str) else synthetic_weights(0)
+                line["latency_us"] = c_dropin.run(lat_w, x1, timed_calls=10000)[2]
             except Exception as e:     # a reported extra, never a reason to lose the headline
                 line["latency_us"] = {"error": str(e)[:300]}
         if world == 1 and not args.no_asr:
             del d_in, d_out
             torch.cuda.empty_cache()
-            line["asr"] = asr_leg(local_rank)
+            line["asr"] = asr_leg(local_rank, ggml_path=args.ggml)
+            # the second half of BASELINE.json's metric at the top level, in the precision that ships (mode 1 = the
+            # reference engine's arithmetic; the Rust binding's default), with the mode-0 figure beside it
+            a = line["asr"]
+            line["asr_rtfx"] = {"metric": "Whisper-tiny RTFx at 1/8 GPU (one MI355X of the node)",
+                                "value": a["f16_operand_mode"]["rtfx_end_to_end"], "unit": "x real time",
+                                "precision_mode": 1, "arithmetic": "f16 operands, f32 accumulation (whisper.cpp / ggml mul_mat)",
+                                "clips": a["clips"], "new_tokens": a["new_tokens"],
+                                "value_precision_mode_0": a["rtfx_end_to_end"],
+                                "single_30s_chunk_from_host_ms": a["single_clip"]["f16_operand_mode_ms"],
+                                "model": a["model"]}
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()

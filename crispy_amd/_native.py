@@ -181,3 +181,15 @@ def load_library(path: str) -> C.CDLL:
 def check(rc: int, L: "C.CDLL | None" = None) -> None:
     if rc != 0:
         raise CrispyError(rc, (L or lib()).crispy_last_error().decode("utf-8", "replace"))
+
+
+class Specials(C.Structure):
+    """`crispy_asr_specials` (include/crispy_hip.h): special token ids of a whisper.cpp vocabulary of n_vocab entries."""
+    _fields_ = [(n, C.c_int) for n in ("eot", "sot", "lang0", "n_lang", "translate", "transcribe", "solm", "prev", "nosp",
+                                       "notimestamps", "beg", "multilingual")]
+
+
+def vocab_specials(n_vocab: int) -> Specials:
+    sp = Specials()
+    check(lib().crispy_asr_vocab_specials(int(n_vocab), C.byref(sp)))
+    return sp

@@ -103,3 +103,92 @@ def spawn_ranks(script: str, argv: Sequence[str], world: int, timeout_s: Optiona
     for t in pumps:
         t.join(5)
     return rc
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CPU / NUMA placement of a rank (the 6.5x target at 8 GPUs is about host input staging, not xGMI).
+# Everything below reads sysfs only: no HIP call, no torch import -- it runs BEFORE the rank touches its GPU.
+# ------------------------------------------------------------------------------------------------------------------
+def _parse_cpulist(text: str) -> List[int]:
+    cpus: List[int] = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        if "-" in part:
+            lo, hi = part.split("-")
+            cpus.extend(range(int(lo), int(hi) + 1))
+        else:
+            cpus.append(int(part))
+    return cpus
+
+
+def gpu_pci_addresses(kfd_root: str = "/sys/class/kfd/kfd/topology/nodes") -> List[str]:
+    """PCI addresses (dddd:bb:dd.f) of the GPU nodes KFD lists, in KFD order = HIP device order when no
+    *_VISIBLE_DEVICES variable re-orders them.  CPU nodes (simd_count 0) are skipped."""
+    out: List[str] = []
+    try:
+        nodes = sorted((int(n) for n in os.listdir(kfd_root) if n.isdigit()))
+    except OSError:
+        return out
+    for n in nodes:
+        props: Dict[str, int] = {}
+        try:
+            with open(os.path.join(kfd_root, str(n), "properties")) as f:
+                for line in f:
+                    k, _, v = line.strip().partition(" ")
+                    if v.strip().lstrip("-").isdigit():
+                        props[k] = int(v)
+        except OSError:
+            continue
+        if props.get("simd_count", 0) <= 0:
+            continue
+        loc, dom = props.get("location_id", 0), props.get("domain", 0)
+        out.append(f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7}")
+    return out
+
+
+def bind_rank_to_gpu_numa(local_rank: int, world_local: int = 1, pci_root: str = "/sys/bus/pci/devices",
+                          kfd_root: str = "/sys/class/kfd/kfd/topology/nodes") -> Optional[Dict[str, object]]:
+    """Restrict this process to the CPUs local to GPU `local_rank` (its PCI device's `local_cpulist`), and within them
+    to this rank's share when several ranks sit on one NUMA node -- so that a rank's host buffers are first-touched
+    on, and its copy threads run on, the socket its GPU hangs off.  Best effort: returns what it did, or None when the
+    topology cannot be read or the binding is refused (containers often pin the CPU set already); never raises.
+    Skipped when CRISPY_NO_NUMA_BIND=1 or when *_VISIBLE_DEVICES re-maps the devices (the KFD order is then not the HIP
+    order)."""
+    try:
+        if os.environ.get("CRISPY_NO_NUMA_BIND") == "1":
+            return None
+        if any(os.environ.get(v) for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")):
+            return None
+        gpus = gpu_pci_addresses(kfd_root)
+        if not (0 <= local_rank < len(gpus)):
+            return None
+        dev = os.path.join(pci_root, gpus[local_rank])
+        with open(os.path.join(dev, "local_cpulist")) as f:
+            local = _parse_cpulist(f.read())
+        node = -1
+        try:
+            with open(os.path.join(dev, "numa_node")) as f:
+                node = int(f.read().strip())
+        except (OSError, ValueError):
+            pass
+        allowed = sorted(set(local) & set(os.sched_getaffinity(0)))
+        if not allowed:
+            return None
+        # ranks whose GPUs share this CPU set split it evenly, in rank order
+        peers = []
+        for r in range(min(world_local, len(gpus))):
+            try:
+                with open(os.path.join(pci_root, gpus[r], "local_cpulist")) as f:
+                    if _parse_cpulist(f.read()) == local:
+                        peers.append(r)
+            except OSError:
+                pass
+        if local_rank in peers and len(peers) > 1 and len(allowed) >= len(peers):
+            share = len(allowed) // len(peers)
+            k = peers.index(local_rank)
+            allowed = allowed[k * share:(k + 1) * share]
+        os.sched_setaffinity(0, allowed)
+        return {"gpu_pci": gpus[local_rank], "numa_node": node, "cpus": len(allowed), "first_cpu": allowed[0]}
+    except Exception:
+        return None

@@ -64,17 +64,34 @@ class DenoiseTranscribePipeline:
 
     def run(self, d_in48, prompt, max_new: int):
         """d_in48: torch float32 [B, T, 480] on the device, int16-range samples (x32768 already applied).
-        Returns (tokens [B, n_chunks, max_new], pcm16k [B, n16] on the device)."""
+        Returns (tokens [B, n_chunks, max_new], pcm16k [B, n16] on the device -- a view of this pipeline's workspace,
+        valid until its next run)."""
         import time
         torch = self.torch
         B, T, _ = d_in48.shape
         assert B == self.B and d_in48.is_contiguous()
-        den = torch.empty_like(d_in48)
-        torch.cuda.synchronize()
+        n48 = (T - 1) * FRAME_SIZE                       # first frame dropped (audio.rs:275-278)
+        n16 = Resampler48to16.out_len(n48)
+        hp = self.whisper.hp
+        # Workspaces live with the pipeline (denoised audio, 16 kHz PCM, log-mel, encoder output: 5.9 + 2 + 1 + 2.4 GB at
+        # 1024 streams x 30 s): allocating them per call cost more than the log-mel kernel, and their fills run on torch's
+        # stream, which is not ordered against the handles' streams -- so they are made (and waited for) ONCE per shape.
+        # The hot path below issues no torch call and no device-wide synchronisation, only waits on its own handles'
+        # streams: two pipelines driven from two host threads overlap on the GPU (bench.py --workload cfg4).
+        key = (B, T, hp.n_mels, hp.n_audio_ctx, hp.n_audio_state)
+        if getattr(self, "_ws_key", None) != key:
+            self._den = torch.empty(B, T, FRAME_SIZE, device=self.dev)
+            self._pcm16 = torch.zeros(B, max(n16, 1), device=self.dev)
+            self._melt = torch.zeros(B, 3002, hp.n_mels, device=self.dev)
+            self._enc = torch.empty(B, hp.n_audio_ctx, hp.n_audio_state, device=self.dev)
+            self._ws_key = key
+            torch.cuda.synchronize()
+        den, pcm16, melt, enc = self._den, self._pcm16, self._melt, self._enc
+        torch.cuda.current_stream(self.dev).synchronize()     # the caller's fills of d_in48 (torch's stream only: idle in steady state)
         tm = self.timings = {"denoise": 0.0, "resample": 0.0, "logmel": 0.0, "encoder": 0.0, "decode": 0.0}
         t_prev = time.perf_counter()
 
-        def lap(stage):          # every stage below ends in a synchronize: wall-clock laps are stage times
+        def lap(stage):          # every stage below ends in a wait on its handle's stream: wall-clock laps are stage times
             nonlocal t_prev
             now = time.perf_counter()
             tm[stage] += now - t_prev
@@ -83,28 +100,13 @@ class DenoiseTranscribePipeline:
         self.ds.process_device(d_in48.data_ptr(), den.data_ptr(), T, layout="btf")
         self.ds.synchronize()
         lap("denoise")
-        n48 = (T - 1) * FRAME_SIZE                       # first frame dropped (audio.rs:275-278)
-        n16 = Resampler48to16.out_len(n48)
-        pcm16 = torch.zeros(B, max(n16, 1), device=self.dev)
-        torch.cuda.synchronize()          # torch's fill runs on torch's stream; the handles' streams are not ordered against it
         den_flat = den.view(B, T * FRAME_SIZE)
         self.rs.process_device(den_flat.data_ptr() + 4 * FRAME_SIZE, T * FRAME_SIZE, n48, B, pcm16.data_ptr(),
                                pcm16.shape[1], scale=1.0 / 32768.0, handoff=self.handoff)
         self.rs.synchronize()
         lap("resample")
         n_chunks = max(1, -(-n16 // CHUNK_SAMPLES))
-        hp = self.whisper.hp
         toks = np.full((B, n_chunks, max_new), -1, dtype=np.int32)      # -1: no token (chunk skipped, see below)
-        # log-mel and encoder-output workspaces (1 + 2.4 GB at 1024 clips) live with the pipeline: allocating them per
-        # call cost more than the log-mel kernel itself
-        key = (B, hp.n_mels, hp.n_audio_ctx, hp.n_audio_state)
-        if getattr(self, "_ws_key", None) != key:
-            self._melt = torch.zeros(B, 3002, hp.n_mels, device=self.dev)
-            self._enc = torch.empty(B, hp.n_audio_ctx, hp.n_audio_state, device=self.dev)
-            self._ws_key = key
-            torch.cuda.synchronize()
-            t_prev = time.perf_counter()
-        melt, enc = self._melt, self._enc
         for c in range(n_chunks):
             lo = c * CHUNK_SAMPLES
             n = min(CHUNK_SAMPLES, n16 - lo)

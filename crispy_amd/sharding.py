@@ -30,3 +30,18 @@ def reduce_job_stats(elapsed_s: float, frames_done: int, device=None):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(n, op=dist.ReduceOp.SUM)
     return float(t.item()), int(n.item())
+
+
+def gather_token_ids(ids):
+    """The one data-product exchange of the job: every rank's fixed-width greedy token ids
+    `[clips, new_tokens]` int32, concatenated in rank order on every rank -> `[world * clips, new_tokens]`.  One
+    `all_gather_into_tensor` (RCCL on the GPU box, gloo in the CPU tests); without a process group the tensor itself."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return ids
+    world = dist.get_world_size()
+    out = torch.empty((world * ids.shape[0],) + tuple(ids.shape[1:]), dtype=ids.dtype, device=ids.device)
+    dist.all_gather_into_tensor(out, ids.contiguous())
+    return out

@@ -22,7 +22,7 @@ from scipy.special import erf
 
 
 def _gelu(x):
-    return 0.5 * x * (1.0 + erf(x / np.sqrt(2.0)))
+    return 0.5 * x * (1.0 + erf(x / x.dtype.type(np.sqrt(2.0))))
 
 
 def _ln(x, w, b, eps=1e-5):
@@ -31,8 +31,8 @@ def _ln(x, w, b, eps=1e-5):
     return (x - mu) / np.sqrt(var + eps) * w + b
 
 
-def _f64(w):
-    return {k: v.astype(np.float64) for k, v in w.items()}
+def _f64(w, dtype=np.float64):
+    return {k: v.astype(dtype) for k, v in w.items()}
 
 
 def _mha(xq, xkv, W, prefix, n_head, causal=False):
@@ -44,9 +44,9 @@ def _mha(xq, xkv, W, prefix, n_head, causal=False):
     out = np.empty_like(q)
     for h in range(n_head):
         sl = slice(h * dh, (h + 1) * dh)
-        s = (q[:, sl] @ k[:, sl].T) / np.sqrt(dh)
+        s = (q[:, sl] @ k[:, sl].T) / q.dtype.type(np.sqrt(dh))
         if causal:
-            s = s + np.triu(np.full((Tq, k.shape[0]), -np.inf), k=1 + k.shape[0] - Tq)
+            s = s + np.triu(np.full((Tq, k.shape[0]), -np.inf, dtype=q.dtype), k=1 + k.shape[0] - Tq)
         s = s - s.max(-1, keepdims=True)
         p = np.exp(s)
         p /= p.sum(-1, keepdims=True)
@@ -54,10 +54,11 @@ def _mha(xq, xkv, W, prefix, n_head, causal=False):
     return out @ W[prefix + ".out.weight"].T + W[prefix + ".out.bias"]
 
 
-def encoder_forward(weights, hp, mel, upto_layer=None):
-    """mel: [n_mels, 3000] -> [1500, d] (float64)."""
-    W = _f64(weights)
-    x = mel.astype(np.float64)
+def encoder_forward(weights, hp, mel, upto_layer=None, dtype=np.float64):
+    """mel: [n_mels, 3000] -> [1500, d] (float64; dtype=np.float32 is the single-precision CPU run that bench.py times
+    as the ASR cpu_baseline -- BLAS sgemm on the host cores -- never the parity oracle)."""
+    W = _f64(weights, dtype)
+    x = mel.astype(dtype)
     xp = np.pad(x, ((0, 0), (1, 1)))
     w1 = W["encoder.conv1.weight"]
     h1 = sum(w1[:, :, k] @ xp[:, k:k + 3000] for k in range(3)) + W["encoder.conv1.bias"][:, None]
@@ -199,27 +200,28 @@ class DecoderCache:
     """KV-cached incremental decoder (float64); `step(token)` returns the logits of the new position.
     Same arithmetic as `decoder_logits`, restated so that 200-token windows finish in seconds."""
 
-    def __init__(self, weights, hp, enc_out, f16=False):
-        """f16=True: the decoder arithmetic of the library's precision mode 1, i.e. whisper.cpp's ggml graph
+    def __init__(self, weights, hp, enc_out, f16=False, dtype=np.float64):
+        """dtype=np.float32: single-precision CPU run for bench.py's cpu_baseline (not the parity oracle).
+        f16=True: the decoder arithmetic of the library's precision mode 1, i.e. whisper.cpp's ggml graph
         [UPSTREAM-RECALL] wherever a matrix product has no LayerNorm folded into it on the GPU -- cross K | V from the
         f16-rounded encoder output and f16 weights, stored as f16 (kv_cross); the self-attention K | V cache stored
         as f16 (kv_self); the attention outputs and the GELU'd hidden layer rounded to f16 against f16 weights
         (attn.out, cross_attn.out, mlp.2); the final LayerNorm rounded to f16 against the f16 token embedding.  The
         projections behind a LayerNorm (q | k | v, cross q, mlp.0) stay exact: the library folds the LayerNorm into
         them and keeps them in f32."""
-        self.W = _f64(weights)
+        self.W = _f64(weights, dtype)
         self.hp = hp
         self.f16 = f16
         r = _h if f16 else (lambda a: a)
         self.r = r
-        enc = r(enc_out.astype(np.float64))
+        enc = r(enc_out.astype(dtype))
         self.xk, self.xv, self.k, self.v = [], [], [], []
         for i in range(hp.n_text_layer):
             p = f"decoder.blocks.{i}.cross_attn"
             self.xk.append(r(enc @ r(self.W[p + ".key.weight"]).T))
             self.xv.append(r(enc @ r(self.W[p + ".value.weight"]).T + self.W[p + ".value.bias"]))
-            self.k.append(np.zeros((0, hp.n_text_state)))
-            self.v.append(np.zeros((0, hp.n_text_state)))
+            self.k.append(np.zeros((0, hp.n_text_state), dtype=dtype))
+            self.v.append(np.zeros((0, hp.n_text_state), dtype=dtype))
         self.pos = 0
 
     def _att(self, q, k, v):
@@ -228,7 +230,7 @@ class DecoderCache:
         out = np.empty_like(q)
         for h in range(H):
             sl = slice(h * dh, (h + 1) * dh)
-            s = (k[:, sl] @ q[sl]) / np.sqrt(dh)
+            s = (k[:, sl] @ q[sl]) / q.dtype.type(np.sqrt(dh))
             s = np.exp(s - s.max())
             out[sl] = (s / s.sum()) @ v[:, sl]
         return out

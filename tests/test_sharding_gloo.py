@@ -32,7 +32,11 @@ def _worker(rank, world, port, q):
     elapsed, frames = reduce_job_stats(0.5 + rank, (hi - lo) * 100)
     gathered = [None] * world
     dist.all_gather_object(gathered, mine.tolist())
-    q.put((rank, elapsed, frames, gathered))
+    # the job's data product: fixed-width token ids of every rank, one all_gather_into_tensor, rank order
+    from crispy_amd.sharding import gather_token_ids
+    ids = torch.arange(3 * 4, dtype=torch.int32).reshape(3, 4) + 1000 * rank
+    table = gather_token_ids(ids)
+    q.put((rank, elapsed, frames, gathered, table.tolist()))
     dist.destroy_process_group()
 
 
@@ -47,10 +51,52 @@ def test_two_rank_gloo_job_stats_and_assembly():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for rank, elapsed, frames, gathered in res:
+    want = np.concatenate([np.arange(12).reshape(3, 4) + 1000 * r for r in range(2)]).tolist()
+    for rank, elapsed, frames, gathered, table in res:
         assert elapsed == 1.5            # max over ranks
         assert frames == 1000            # all 10 streams x 100 frames
         assert sum(gathered, []) == [2.0 * i for i in range(10)]   # shards tile the stream ids in order
+        assert table == want             # [world * clips, new_tokens], rank order, on every rank
+
+
+def test_gather_token_ids_without_a_process_group_is_the_identity():
+    from crispy_amd.sharding import gather_token_ids
+    ids = torch.arange(6, dtype=torch.int32).reshape(2, 3)
+    assert gather_token_ids(ids) is ids
+
+
+def test_numa_binding_reads_the_kfd_and_pci_topology(tmp_path):
+    """crispy_amd.launch.bind_rank_to_gpu_numa against a fake sysfs: two CPU nodes, two GPUs on different NUMA nodes;
+    the rank is pinned to the CPUs its GPU's PCI device lists (intersected with what the process may use), nothing is
+    pinned when the topology is missing or a *_VISIBLE_DEVICES variable re-maps the devices, and nothing ever raises."""
+    from crispy_amd import launch
+    kfd, pci = tmp_path / "kfd", tmp_path / "pci"
+    for n, (simd, loc) in enumerate([(0, 0), (0, 0), (1024, 0x0500), (1024, 0x8508)]):      # bus 05 dev 0; bus 85 dev 1
+        d = kfd / str(n)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count {64 if simd == 0 else 0}\nsimd_count {simd}\nlocation_id {loc}\ndomain 0\n")
+    assert launch.gpu_pci_addresses(str(kfd)) == ["0000:05:00.0", "0000:85:01.0"]
+    mine = sorted(os.sched_getaffinity(0))
+    for addr, cpus, node in (("0000:05:00.0", f"{mine[0]}", 0), ("0000:85:01.0", f"{mine[-1]}", 1)):
+        d = pci / addr
+        d.mkdir(parents=True)
+        (d / "local_cpulist").write_text(cpus + "\n")
+        (d / "numa_node").write_text(f"{node}\n")
+    before = os.sched_getaffinity(0)
+    try:
+        got = launch.bind_rank_to_gpu_numa(1, 2, str(pci), str(kfd))
+        assert got == {"gpu_pci": "0000:85:01.0", "numa_node": 1, "cpus": 1, "first_cpu": mine[-1]}
+        assert os.sched_getaffinity(0) == {mine[-1]}
+    finally:
+        os.sched_setaffinity(0, before)
+    assert launch.bind_rank_to_gpu_numa(5, 8, str(pci), str(kfd)) is None          # no such GPU
+    assert launch.bind_rank_to_gpu_numa(0, 1, str(tmp_path / "nope"), str(tmp_path / "nope")) is None
+    os.environ["HIP_VISIBLE_DEVICES"] = "1"
+    try:
+        assert launch.bind_rank_to_gpu_numa(0, 2, str(pci), str(kfd)) is None
+    finally:
+        del os.environ["HIP_VISIBLE_DEVICES"]
+    assert launch._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
 
 
 # ---- bench.py's own launcher (crispy_amd/launch.py): `python bench.py --gpus 2` with no WORLD_SIZE starts 2 ranks ----
