@@ -17,7 +17,9 @@
 //
 // The analysis window [x_prev, x_cur] and the 1728-sample pitch buffer of the reference are both
 // windows of the same high-passed signal, so neither is stored as state: they are views of xhp.
+#include <type_traits>
 #include "rn_common.h"
+#include "rn_wave_sums.h"
 
 namespace crispy {
 namespace {
@@ -53,9 +55,12 @@ __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(
 __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
 
 // DPP lane permutations (gfx9 family): no LDS crossbar round trip, one VALU op per step.
+// (`old` = 0: passing the value itself -- legal for the quad / mirror permutations, whose every lane has a valid source --
+// ties the destination to the source register and cost 83 more copies than the zero-initialising moves it removed.)
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ float dpp_mov(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+  const int iv = __float_as_int(v);
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, iv, CTRL, ROW_MASK, 0xf, false));
 }
 // sum over the 64 lanes, result uniform (read from lane 63 into an SGPR)
 __device__ __forceinline__ float wave_sum(float v) {
@@ -340,44 +345,35 @@ struct BandEdges {
   int em1, e0, e1;
 };
 
-// Sum of one band's chunk partials (lane == band, lane < RN_NB): part[100 + c] for c in [em1, e0) -- the rising
-// half of the previous interval -- then part[c] for c in [e0, e1), doubled at the two edge bands.  The partials are
-// added in the reference's order but *read* RN_BAND_BATCH at a time: as plain `for (c = ...) sum += part[c]` loops
-// this compiled to one LDS round trip per chunk, up to 22 + 22 dependent trips per call (the widest bands), four
-// calls per frame.  Reads past a lane's range stay inside the workgroup's LDS and are replaced by 0.f, which leaves
-// the sum bit-identical.  Measured: 7.56 -> 7.43 ms per step although it adds ~700 VALU instructions per frame.
+// Sum of one band's chunk partials: part_hi[c] for c in [em1, e0) -- the rising half of the previous interval -- plus
+// part_lo[c] for c in [e0, e1), doubled at the two edge bands.  ALL 64 lanes call it; the result is valid in lanes
+// < RN_NB (lane == band).  Round 3 form: lanes 0..21 add up the rising halves, lanes 32..53 the falling halves of band
+// (lane - 32), one ds_bpermute joins them -- 24 select-and-add steps per call instead of 48 -- and the `k < n` tests
+// stay INLINE (`n` is laundered): they are invariant across frames, and hoisted out of the frame loop the compiler
+// turned them into 48 lane masks = 96 SGPRs, spilled into two VGPRs' lanes and fetched back with two v_readlane per
+// use: 416 of the kernel's 7 800 VALU instructions per frame were those v_readlane (ISA census).
+// The partials are *read* RN_BAND_BATCH at a time (as plain `for (c = ...) sum += part[c]` loops every chunk was its own
+// LDS round trip); reads past a lane's range stay inside the workgroup's LDS and are replaced by 0.f.
 #ifndef RN_BAND_BATCH
 #define RN_BAND_BATCH 8
 #endif
 __device__ __forceinline__ float band_sum(const float* part_lo, const float* part_hi, const BandEdges& be, int lane) {
+  const int band = lane & 31;               // (be holds the edges of band min(lane & 31, RN_NB - 1))
+  const bool falling = lane >= 32;
+  int n = falling ? (band < RN_NB - 1 ? be.e1 - be.e0 : 0) : (band > 0 ? be.e0 - be.em1 : 0);
+  if (band >= RN_NB) n = 0;
+  asm volatile("" : "+v"(n));
+  const float* p = falling ? part_lo + be.e0 : part_hi + be.em1;
   float sum = 0.f;
-#if RN_BAND_BATCH
-  const int n_hi = lane > 0 ? be.e0 - be.em1 : 0;
-  const int n_lo = lane < RN_NB - 1 ? be.e1 - be.e0 : 0;
-  const float* ph = part_hi + be.em1;
-  const float* pl = part_lo + be.e0;
 #pragma unroll
   for (int base = 0; base < 24; base += RN_BAND_BATCH) {
     float v[RN_BAND_BATCH];
 #pragma unroll
-    for (int k = 0; k < RN_BAND_BATCH; ++k) v[k] = ph[base + k];
+    for (int k = 0; k < RN_BAND_BATCH; ++k) v[k] = p[base + k];
 #pragma unroll
-    for (int k = 0; k < RN_BAND_BATCH; ++k) sum += base + k < n_hi ? v[k] : 0.f;
+    for (int k = 0; k < RN_BAND_BATCH; ++k) sum += base + k < n ? v[k] : 0.f;
   }
-#pragma unroll
-  for (int base = 0; base < 24; base += RN_BAND_BATCH) {
-    float v[RN_BAND_BATCH];
-#pragma unroll
-    for (int k = 0; k < RN_BAND_BATCH; ++k) v[k] = pl[base + k];
-#pragma unroll
-    for (int k = 0; k < RN_BAND_BATCH; ++k) sum += base + k < n_lo ? v[k] : 0.f;
-  }
-#else
-  if (lane > 0)
-    for (int c = be.em1; c < be.e0; ++c) sum += part_hi[c];
-  if (lane < RN_NB - 1)
-    for (int c = be.e0; c < be.e1; ++c) sum += part_lo[c];
-#endif
+  sum += __shfl(sum, (lane + 32) & 63, WAVE);       // rising + falling half (lanes >= 32 receive garbage: never used)
   if (lane == 0 || lane == RN_NB - 1) sum *= 2.f;
   return sum;
 }
@@ -429,7 +425,8 @@ __device__ __forceinline__ void band_pairs(const float2* S, const float2* Xc, fl
   }
   auto band_total = [&](float* out) {
     __syncthreads();
-    if (lane < RN_NB) out[lane] = band_sum(part, part + 100, be, lane);
+    const float bsum = band_sum(part, part + 100, be, lane);
+    if (lane < RN_NB) out[lane] = bsum;
     __syncthreads();
   };
   band_total(Eout);
@@ -733,17 +730,24 @@ __device__ __forceinline__ float dot_m(__amdgpu_buffer_rsrc_t rs, int w_off, int
 // so the accumulators are folded into the float result where the k loop crosses from one to the other.
 typedef int rn_i4 __attribute__((ext_vector_type(4)));
 constexpr int RN_IMG8_LD = 144;   // bytes per digit image (K <= 128), +16: the four 16-byte reads hit distinct banks
+// Wave maximum of NON-NEGATIVE floats (magnitudes), as a maximum of their bit patterns: for values >= 0 the unsigned
+// integer order IS the float order, v_max_u32 needs no canonicalisation of its operands (every fmaxf compiled to a
+// `v_max_f32 x, x, x` quieting step in front of the real v_max under the IEEE mode -- 170 of them per frame), and NaN
+// bit patterns simply compare as large numbers (scale_of clamps the exponent).
 __device__ __forceinline__ float wave_max(float v) {
-  v = fmaxf(v, dpp_mov<0xB1>(v));
-  v = fmaxf(v, dpp_mov<0x4E>(v));
-  v = fmaxf(v, dpp_mov<0x141>(v));
-  v = fmaxf(v, dpp_mov<0x140>(v));
-  v = fmaxf(v, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 15)));   // rows 0..3 hold their own max
-  float m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
-  m = fmaxf(m, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16)));
-  m = fmaxf(m, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)));
-  m = fmaxf(m, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48)));
-  return m;
+  unsigned u = __float_as_uint(v);
+  auto dm = [](unsigned x, auto ctrl) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, decltype(ctrl)::value, 0xf, 0xf, false);
+  };
+  u = max(u, dm(u, std::integral_constant<int, 0xB1>{}));
+  u = max(u, dm(u, std::integral_constant<int, 0x4E>{}));
+  u = max(u, dm(u, std::integral_constant<int, 0x141>{}));
+  u = max(u, dm(u, std::integral_constant<int, 0x140>{}));      // every lane of a 16-lane row holds the row maximum
+  unsigned m = (unsigned)__builtin_amdgcn_readlane((int)u, 0);
+  m = max(m, (unsigned)__builtin_amdgcn_readlane((int)u, 16));
+  m = max(m, (unsigned)__builtin_amdgcn_readlane((int)u, 32));
+  m = max(m, (unsigned)__builtin_amdgcn_readlane((int)u, 48));   // scalar maxima (s_max_u32): no VALU
+  return __uint_as_float(m);
 }
 // scale pair of a vector whose largest magnitude is m (wave-uniform): up = 2^s, dn = 2^-s
 struct RnScale { float up, dn; };
@@ -773,7 +777,7 @@ __device__ __forceinline__ RnScale image_i8(signed char* img, int lane, F f) {
   for (int j = 0; j < NT; ++j) {
     const int i = lane + WAVE * j;
     v[j] = i < NPAD ? f(min(i, NPAD - 1)) : 0.f;
-    m = fmaxf(m, fabsf(v[j]));
+    m = __uint_as_float(max(__float_as_uint(m), __float_as_uint(v[j]) & 0x7fffffffu));     // max |v| on the bit patterns
   }
   const RnScale sc = scale_of(wave_max(m));
 #pragma unroll
@@ -1142,11 +1146,20 @@ __device__ __forceinline__ void lag_dots(const float* xr, const float* const (&y
       if (SQ) syy[q] = fmaf(y, y, syy[q]);
     }
   }
+  // all NL (2 NL) totals reduced together: rn_wave_sums.h (four sums for ten VALU instructions instead of 4 x 12)
+#ifndef RN_BATCHED_SUMS
+#define RN_BATCHED_SUMS 1
+#endif
+#if RN_BATCHED_SUMS
+  wave_sums<NL>(sxy);
+  if (SQ) wave_sums<NL>(syy);
+#else
 #pragma unroll
   for (int q = 0; q < NL; ++q) {
     sxy[q] = wave_sum(sxy[q]);
     if (SQ) syy[q] = wave_sum(syy[q]);
   }
+#endif
 }
 
 // =============================================================================================
@@ -1220,7 +1233,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
   float lastg = lane < RN_NB ? a.lastg[(long)b * RN_NB + lane] : 0.f;
   BandEdges be;
   {
-    const int i = min(lane, RN_NB - 1);
+    const int i = min(lane & 31, RN_NB - 1);       // lanes 32..53 work on the falling halves of bands 0..21 (band_sum)
     be.e0 = tab->eband[i];
     be.e1 = tab->eband[i + 1];
     be.em1 = tab->eband[max(i - 1, 0)];
@@ -1318,8 +1331,12 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
 #pragma unroll
         for (int k = 0; k <= 4; ++k) ac[k] = fmaf(w[q + 5], w[q + 5 - k], ac[k]);
       }
+#if RN_BATCHED_SUMS
+      wave_sums<5>(ac);
+#else
 #pragma unroll
       for (int k = 0; k <= 4; ++k) ac[k] = wave_sum(ac[k]);
+#endif
       ac[0] *= 1.0001f;
 #pragma unroll
       for (int k = 1; k <= 4; ++k) ac[k] -= ac[k] * (.008f * k) * (.008f * k);
@@ -2097,10 +2114,13 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
         }
       }
       __syncthreads();
-      if (lane < RN_NB) {        // new band energies (Ep is dead), then the renormalisation and the smoothed gains
+      float sum;
+      {                          // new band energies (Ep is dead): every lane takes part (band_sum splits a band over two lanes)
         const float* part = P_LDS ? Xf + PL_A_FREE : Rb + (MODE == 2 ? 0 : RB_PART);
         const float* part_hi = P_LDS ? L.U + PL_U_FREE : part + 100;
-        const float sum = band_sum(part, part_hi, be, lane);
+        sum = band_sum(part, part_hi, be, lane);
+      }
+      if (lane < RN_NB) {        // the renormalisation and the smoothed gains
         L.U[U_R + lane] = sqrtf(L.Ex[lane] / (1e-8f + sum));  // norm
         float gg;
         if constexpr (MODE == 2) gg = a.g_smooth[((long)t * a.B + b) * RNN_GAIN_LD + lane];   // smoothing state lives in the gain-network kernel
