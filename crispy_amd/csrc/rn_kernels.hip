@@ -357,7 +357,36 @@ struct BandEdges {
 #ifndef RN_BAND_BATCH
 #define RN_BAND_BATCH 8
 #endif
+#ifndef RN_BAND_SPLIT
+#define RN_BAND_SPLIT 1
+#endif
 __device__ __forceinline__ float band_sum(const float* part_lo, const float* part_hi, const BandEdges& be, int lane) {
+#if !RN_BAND_SPLIT
+  // round-2 form (A/B builds): lane == band adds both halves, 48 select-and-add steps
+  float s_old = 0.f;
+  const int n_hi = lane > 0 && lane < RN_NB ? be.e0 - be.em1 : 0;
+  const int n_lo = lane < RN_NB - 1 ? be.e1 - be.e0 : 0;
+  const float* ph = part_hi + be.em1;
+  const float* pl = part_lo + be.e0;
+#pragma unroll
+  for (int base = 0; base < 24; base += RN_BAND_BATCH) {
+    float v[RN_BAND_BATCH];
+#pragma unroll
+    for (int k = 0; k < RN_BAND_BATCH; ++k) v[k] = ph[base + k];
+#pragma unroll
+    for (int k = 0; k < RN_BAND_BATCH; ++k) s_old += base + k < n_hi ? v[k] : 0.f;
+  }
+#pragma unroll
+  for (int base = 0; base < 24; base += RN_BAND_BATCH) {
+    float v[RN_BAND_BATCH];
+#pragma unroll
+    for (int k = 0; k < RN_BAND_BATCH; ++k) v[k] = pl[base + k];
+#pragma unroll
+    for (int k = 0; k < RN_BAND_BATCH; ++k) s_old += base + k < n_lo ? v[k] : 0.f;
+  }
+  if (lane == 0 || lane == RN_NB - 1) s_old *= 2.f;
+  return s_old;
+#endif
   const int band = lane & 31;               // (be holds the edges of band min(lane & 31, RN_NB - 1))
   const bool falling = lane >= 32;
   int n = falling ? (band < RN_NB - 1 ? be.e1 - be.e0 : 0) : (band > 0 ? be.e0 - be.em1 : 0);
