@@ -11,10 +11,12 @@ B, T = 6, 1000
 w = synthetic_weights(0)
 x = SA.batch_np(B, T, first_stream=40) * np.float32(32768.0)
 refs = [O.OracleDenoiseState(w).process(x[:, b])[0] for b in range(B)]
+REPS = int(os.environ.get("DIAG_REPS", "2"))
+MODES = (True,) if os.environ.get("DIAG_STAGED_ONLY") == "1" else (False, True)
 for path in sys.argv[1:]:
     L = N.lib() if path == "default" else N.load_library(os.path.abspath(path))
-    for staged in (False, True):
-        for rep in range(2):
+    for staged in MODES:
+        for rep in range(REPS):
             ds = DenoiseState(w, B, 0, lib=L)
             ds.set_pipeline(staged)
             out, vad = ds.process(x)
