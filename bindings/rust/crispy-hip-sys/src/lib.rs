@@ -165,6 +165,8 @@ extern "C" {
     pub fn crispy_asr_detect_language_device(h: *mut crispy_asr, d_enc: *const c_float, batch: c_int, lang_tokens_out: *mut c_int) -> c_int;
     pub fn crispy_asr_transcribe_tokens(h: *mut crispy_asr, pcm: *const c_float, pcm_stride: c_long, n_samples: *const c_int, batch: c_int, prompt: *const c_int, n_prompt: c_int, max_new: c_int, tokens_out: *mut c_int, n_out: *mut c_int) -> c_int;
     pub fn crispy_asr_load(model_path: *const c_char, device: c_int, out: *mut *mut crispy_asr) -> c_int;
+    pub fn crispy_asr_load_resident(model_path: *const c_char, device: c_int, out: *mut *mut crispy_asr) -> c_int;
+    pub fn crispy_asr_memory_info(h: *const crispy_asr, weight_bytes: *mut usize, quantised_bytes: *mut usize, scratch_bytes: *mut usize) -> c_int;
     pub fn crispy_asr_vocab_specials(n_vocab: c_int, out: *mut crispy_asr_specials) -> c_int;
     pub fn crispy_asr_token_text(h: *const crispy_asr, token: c_int, text: *mut *const c_char, len: *mut usize) -> c_int;
     pub fn crispy_asr_transcribe(h: *mut crispy_asr, pcm16k: *const c_float, n: usize, opts: *const crispy_asr_opts, out: *mut *mut crispy_asr_result) -> c_int;
@@ -353,7 +355,9 @@ impl GpuWhisperEngine {
     pub fn load(model_path: &Path) -> Result<Self, CrispyError> {
         let c = path_cstring(model_path)?;
         let mut h = std::ptr::null_mut();
-        check(unsafe { crispy_asr_load(c.as_ptr(), 0, &mut h) })?;
+        // resident load: a quantised catalog file (managers/model.rs:99,137) stays quantised in HBM (file-sized), f32 / f16
+        // files load as usual; either way the engine is in precision mode 1 afterwards
+        check(unsafe { crispy_asr_load_resident(c.as_ptr(), 0, &mut h) })?;
         // whisper.cpp, the engine this one stands in for, multiplies f16 operands with f32 accumulation and keeps its
         // K|V caches in f16: precision mode 1 is that arithmetic (and 2.3 x the f32 mode's speed).  The library's own
         // default stays f32 -- the mode its 1e-4 parity against the float64 oracle is stated in.

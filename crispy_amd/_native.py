@@ -36,7 +36,7 @@ MEL_SYMBOLS = ("crispy_mel_create", "crispy_mel_destroy", "crispy_mel_compute",
 ASR_SYMBOLS = ("crispy_asr_create", "crispy_asr_set_tensor", "crispy_asr_finalize", "crispy_asr_free",
                "crispy_asr_hparams_get", "crispy_asr_encode", "crispy_asr_encode_device", "crispy_asr_synchronize",
                "crispy_asr_set_suppress", "crispy_asr_decode_greedy_device", "crispy_asr_transcribe_tokens",
-               "crispy_asr_load", "crispy_asr_token_text", "crispy_asr_transcribe", "crispy_asr_free_result",
+               "crispy_asr_load", "crispy_asr_load_resident", "crispy_asr_memory_info", "crispy_asr_token_text", "crispy_asr_transcribe", "crispy_asr_free_result",
                "crispy_asr_decode_greedy_lang_device", "crispy_asr_detect_language_device",
                "crispy_asr_transcribe_batch", "crispy_asr_decode_timestamps_device", "crispy_asr_set_precision",
                "crispy_asr_vocab_specials", "crispy_asr_stage_logits_device")
@@ -151,6 +151,8 @@ def load_library(path: str) -> C.CDLL:
     L.crispy_asr_decode_greedy_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                                   C.c_void_p, C.c_void_p, C.c_void_p]
     L.crispy_asr_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.crispy_asr_load_resident.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.crispy_asr_memory_info.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.crispy_asr_token_text.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
     L.crispy_asr_transcribe.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]
     L.crispy_asr_transcribe_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]

@@ -130,6 +130,12 @@ class WhisperModel:
     def synchronize(self):
         N.check(N.lib().crispy_asr_synchronize(self._h))
 
+    def memory_info(self) -> dict:
+        """Device bytes held by the model itself: all weights / of which quantised blocks / de-quantisation scratch."""
+        w, q, sc = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        N.check(N.lib().crispy_asr_memory_info(self._h, C.byref(w), C.byref(q), C.byref(sc)))
+        return {"weight_bytes": w.value, "quantised_bytes": q.value, "scratch_bytes": sc.value}
+
     def set_precision(self, mode: int):
         """0: f32 operands (default, the mode the oracle parity is pinned in); 1: f16 operands / f32 accumulation for
         the encoder GEMMs (whisper.cpp's ggml numerics)."""
@@ -209,11 +215,14 @@ class WhisperEngine(WhisperModel):
     """`WhisperEngine::load(&model_path)` + `transcribe(&audio, &TranscribeOptions::default())`
     (managers/transcription.rs:138-141, 183-185) over a whisper.cpp GGML model file."""
 
-    def __init__(self, model_path: str, device: int = 0):  # noqa: super().__init__ is the tensor-by-tensor path
+    def __init__(self, model_path: str, device: int = 0, resident: bool = False):  # noqa: super().__init__ is the tensor-by-tensor path
+        """resident=True: `crispy_asr_load_resident` -- a quantised file (the catalog's q4_1 / q5_0 models,
+        managers/model.rs:99,137) keeps its matrices as ggml blocks in HBM and runs in precision mode 1 only."""
         from .whisper_weights import HParams
 
         self._h = C.c_void_p()
-        N.check(N.lib().crispy_asr_load(str(model_path).encode(), device, C.byref(self._h)))
+        load = N.lib().crispy_asr_load_resident if resident else N.lib().crispy_asr_load
+        N.check(load(str(model_path).encode(), device, C.byref(self._h)))
         hpa = (C.c_int * 10)()
         N.check(N.lib().crispy_asr_hparams_get(self._h, hpa))
         self.hp = HParams(*[int(v) for v in hpa])

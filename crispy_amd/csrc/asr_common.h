@@ -140,6 +140,8 @@ struct StepFuse {
   float* x;                            // [B][D] residual stream of the next step; nullptr: plain pick (step from step_dev)
   int D;
   int* counters;                       // {pos, step, ticket}
+  const unsigned char* tok_emb_q;      // resident quantised embedding (asr_quant.h) instead of tok_emb; nullptr: tok_emb
+  int tok_emb_ttype;
 };
 struct TsPickArgs {
   const float* logits;                 // [B][V]

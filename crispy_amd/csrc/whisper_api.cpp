@@ -13,6 +13,7 @@
 #include "../../include/crispy_hip.h"
 #include "api_util.h"
 #include "asr_common.h"
+#include "asr_quant.h"
 
 using namespace crispy;
 
@@ -24,11 +25,29 @@ struct Tensor {
   bool set = false;
 };
 
+// A 2-D tensor kept in HBM as the model file holds it (ggml blocks, asr_quant.h; ttype QT_F32: a dense f32 tensor of a
+// mixed file) and a row-wise concatenation of up to three of them (q | k | v, k | v): `crispy_asr_load_resident`.
+struct QTensor {
+  unsigned char* d = nullptr;
+  int ttype = 0;
+  size_t n = 0;          // elements
+  int cols = 0;          // innermost dimension (K)
+  size_t nbytes = 0;
+  bool owned = true;     // false: d aliases a dense Tensor of the handle
+};
+struct QRef {
+  const QTensor* t[3] = {nullptr, nullptr, nullptr};
+  int n = 0;
+  size_t elems() const { size_t e = 0; for (int i = 0; i < n; ++i) e += t[i]->n; return e; }
+};
+
 struct EncLayer {
+  QRef r_qkv, r_out, r_fc1, r_fc2;           // resident model: the weights as quantised blocks
   const void *qkv_wh = nullptr, *out_wh = nullptr, *fc1_wh = nullptr, *fc2_wh = nullptr;   // f16 copies (precision mode 1)
   const float *ln1_w, *ln1_b, *qkv_w, *qkv_b, *out_w, *out_b, *ln2_w, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
 };
 struct DecLayer {
+  QRef r_qkv, r_out, r_xq, r_xkv, r_xout, r_fc1, r_fc2;
   const float *ln1_w, *ln1_b, *qkv_w, *qkv_b, *out_w, *out_b;
   const float *lnx_w, *lnx_b, *xq_w, *xq_b, *xkv_w, *xkv_b, *xout_w, *xout_b;
   const void* xkv_wh = nullptr;              // f16 copy of the fused cross K|V projection (precision mode 1)
@@ -48,6 +67,14 @@ struct crispy_asr {
   crispy_mel* mel = nullptr;
   std::map<std::string, Tensor> tensors;   // as named by the model file
   std::vector<float*> derived;             // fused / reordered copies owned by the handle
+  size_t derived_bytes = 0;                // ... and their size (crispy_asr_memory_info)
+  // resident quantised model (crispy_asr_load_resident): 2-D tensors stay as ggml blocks, de-quantised into ONE scratch
+  // slot right in front of the kernel that consumes them (same stream: the consumer has finished before the next fill)
+  bool resident = false;
+  std::map<std::string, QTensor> qtensors;
+  void* q_scratch = nullptr;
+  size_t q_scratch_bytes = 0;
+  const QTensor* q_tok_emb = nullptr;
   bool finalized = false;
   // resolved pointers
   const float *conv1_w = nullptr, *conv1_b = nullptr, *conv2_w = nullptr, *conv2_b = nullptr, *enc_pos = nullptr;
@@ -148,6 +175,7 @@ int upload(crispy_asr* h, const std::vector<float>& host, const float** out) {
   float* d = nullptr;
   HIP_TRY(hipMalloc(&d, host.size() * sizeof(float)));
   h->derived.push_back(d);
+  h->derived_bytes += host.size() * sizeof(float);
   HIP_TRY(hipMemcpy(d, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
   *out = d;
   return CRISPY_OK;
@@ -217,6 +245,76 @@ int fold_ln(crispy_asr* h, const float* d_w, const float* d_bias, const float* d
   int rc = upload(h, W, lw);
   if (rc == CRISPY_OK) rc = upload(h, s, ls);
   if (rc == CRISPY_OK) rc = upload(h, c, lc);
+  return rc;
+}
+
+// ---- resident quantised tensors (asr_quant.h) -----------------------------------------------------------------
+// Dense copy of a (row-concatenated) resident tensor in the handle's scratch slot, enqueued on `s` right in front of
+// its consumer: f16 (the operands of precision mode 1), f32, or f32 x gamma[k] (the LayerNorm-folded decode projections).
+int dq(crispy_asr* h, const QRef& r, bool f16, const float* gamma, hipStream_t s, const void** out) {
+  const size_t esz = f16 ? 2 : 4;
+  if (r.n <= 0 || r.elems() * esz > h->q_scratch_bytes)
+    return fail(CRISPY_ERR_INVALID_ARG, "resident model: tensor of %zu elements does not fit the de-quantisation slot", r.elems());
+  char* dst = reinterpret_cast<char*>(h->q_scratch);
+  for (int i = 0; i < r.n; ++i) {
+    const QTensor& t = *r.t[i];
+    HIP_TRY(dequant_blocks(t.d, t.ttype, (long)(t.n / 32), t.cols, dst, f16 ? 1 : 0, gamma, s));
+    dst += t.n * esz;
+  }
+  *out = h->q_scratch;
+  return CRISPY_OK;
+}
+
+QRef qref(crispy_asr* h, std::initializer_list<std::string> names) {
+  QRef r;
+  for (const std::string& n : names) r.t[r.n++] = &h->qtensors[n];
+  return r;
+}
+
+// concatenated biases of row-fused weights (a missing bias is zeros)
+int fuse_bias(crispy_asr* h, const std::vector<std::string>& bnames, int d, const float** b_out) {
+  std::vector<float> Bv;
+  for (const std::string& b : bnames) {
+    if (!b.empty()) {
+      std::vector<float> t;
+      const int rc = download(h->tensors[b], t);
+      if (rc != CRISPY_OK) return rc;
+      Bv.insert(Bv.end(), t.begin(), t.end());
+    } else {
+      Bv.insert(Bv.end(), (size_t)d, 0.f);
+    }
+  }
+  return upload(h, Bv, b_out);
+}
+
+// ln_s / ln_c of fold_ln for a resident tensor: the dense weights exist only for the duration of the call
+int fold_ln_vectors(crispy_asr* h, const QRef& r, const float* d_bias, const float* d_gamma, const float* d_beta, size_t N,
+                    size_t K, const float** ls, const float** lc) {
+  const void* dense = nullptr;
+  int rc = dq(h, r, false, nullptr, h->stream, &dense);
+  if (rc != CRISPY_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const float *lw_unused = nullptr;
+  (void)lw_unused;
+  std::vector<float> W(N * K), b(N, 0.f), g(K), be(K);
+  HIP_TRY(hipMemcpy(W.data(), dense, W.size() * sizeof(float), hipMemcpyDeviceToHost));
+  if (d_bias) HIP_TRY(hipMemcpy(b.data(), d_bias, N * sizeof(float), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(g.data(), d_gamma, K * sizeof(float), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(be.data(), d_beta, K * sizeof(float), hipMemcpyDeviceToHost));
+  std::vector<float> sv(N), cv(N);
+  for (size_t n = 0; n < N; ++n) {          // the arithmetic of fold_ln, element for element
+    double ss = 0.0, cc = (double)b[n];
+    const float* row = W.data() + n * K;
+    for (size_t k = 0; k < K; ++k) {
+      cc += (double)be[k] * (double)row[k];
+      const float wg = row[k] * g[k];
+      ss += (double)wg;
+    }
+    sv[n] = (float)ss;
+    cv[n] = (float)cc;
+  }
+  rc = upload(h, sv, ls);
+  if (rc == CRISPY_OK) rc = upload(h, cv, lc);
   return rc;
 }
 
@@ -302,10 +400,9 @@ int crispy_asr_create(const crispy_asr_hparams* hp, const float* mel_filters, in
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     int r = crispy_mel_create(mel_filters, hp->n_mels, device, &h->mel);
     if (r != CRISPY_OK) return r;
-    for (const auto& kv : expected_tensors(*hp)) {
-      Tensor t;
+    for (const auto& kv : expected_tensors(*hp)) {     // device memory is taken when a tensor is set: a resident
+      Tensor t;                                         // quantised model never holds its matrices as f32
       t.n = kv.second;
-      HIP_TRY(hipMalloc(&t.d, t.n * sizeof(float)));
       h->tensors[kv.first] = t;
     }
     return CRISPY_OK;
@@ -327,6 +424,9 @@ void crispy_asr_free(crispy_asr* h) try {
   for (auto& kv : h->tensors)
     if (kv.second.d) (void)hipFree(kv.second.d);
   for (float* p : h->derived) (void)hipFree(p);
+  for (auto& kv : h->qtensors)
+    if (kv.second.d && kv.second.owned) (void)hipFree(kv.second.d);
+  if (h->q_scratch) (void)hipFree(h->q_scratch);
   if (h->d_suppress) (void)hipFree(h->d_suppress);
   if (h->d_suppress_first) (void)hipFree(h->d_suppress_first);
   if (h->d_ts_mask) (void)hipFree(h->d_ts_mask);
@@ -348,10 +448,157 @@ int crispy_asr_set_tensor(crispy_asr* h, const char* name, const float* data, si
     return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_set_tensor: '%s' has %zu elements, expected %zu", name, n_elems,
                 it->second.n);
   HIP_TRY(hipSetDevice(h->device));
+  if (!it->second.d) HIP_TRY(hipMalloc(&it->second.d, n_elems * sizeof(float)));
   HIP_TRY(hipMemcpy(it->second.d, data, n_elems * sizeof(float), hipMemcpyHostToDevice));
   it->second.set = true;
   return CRISPY_OK;
 } CRISPY_CATCH_RET("crispy_asr_set_tensor")
+
+namespace {
+
+int finalize_tail(crispy_asr* h) {
+  HIP_TRY(hipMalloc(&h->d_suppress, h->hp.n_vocab));
+  HIP_TRY(hipMalloc(&h->d_suppress_first, h->hp.n_vocab));
+  HIP_TRY(hipMemset(h->d_suppress, 0, h->hp.n_vocab));
+  HIP_TRY(hipMemset(h->d_suppress_first, 0, h->hp.n_vocab));
+  HIP_TRY(hipDeviceSynchronize());          // NULL-stream memsets vs the handle's non-blocking stream (see reserve_enc)
+  { const int mrc = build_ts_masks(h); if (mrc != CRISPY_OK) return mrc; }
+  h->finalized = true;
+  return CRISPY_OK;
+}
+
+// f16 copies of the two convolution kernels (precision mode 1; conv1's rows zero-padded to a multiple of 32 columns: the
+// padded operand columns of A read on into the next frames -- finite values -- and meet zeros here)
+int make_conv_halves(crispy_asr* h) {
+  const size_t d = h->hp.n_audio_state;
+  {
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, d * 3 * d * 2));
+    h->derived.push_back(reinterpret_cast<float*>(p));
+    h->derived_bytes += d * 3 * d * 2;
+    HIP_TRY(convert_f32_to_f16(h->conv2_w, p, (long)(d * 3 * d), h->stream));
+    h->conv2_wh = p;
+  }
+  const int k1 = 3 * h->hp.n_mels, k1p = (k1 + 31) / 32 * 32;
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, d * k1p * 2));
+  h->derived.push_back(reinterpret_cast<float*>(p));
+  h->derived_bytes += d * k1p * 2;
+  HIP_TRY(hipMemsetAsync(p, 0, d * k1p * 2, h->stream));
+  HIP_TRY(convert_rows_f32_to_f16(h->conv1_w, k1, p, k1p, k1, (long)d, h->stream));
+  h->conv1_wh = p;
+  h->conv1_kp = k1p;
+  return CRISPY_OK;
+}
+
+// crispy_asr_load_resident: the 2-D tensors stay as the file's ggml blocks (h->qtensors); what is made here is small --
+// fused biases, the LayerNorm-fold vectors of the decode projections, the two convolution kernels (f16 / f32 in every
+// ggml file) -- plus the token embedding packed in MFMA operand order for the logits (f16: the one matrix kept dense;
+// its quantised form stays resident too and serves the embedding look-ups).  Precision mode 1 only: the operands of
+// every matrix product are de-quantised to f16 (f32 x gamma for the folded projections) right in front of the product.
+int finalize_resident(crispy_asr* h) {
+  const int d = h->hp.n_audio_state, dt = h->hp.n_text_state, V = h->hp.n_vocab;
+  if (!(dt == 384 || dt == 512 || dt == 768 || dt == 1024 || dt == 1280))
+    return fail(CRISPY_ERR_UNSUPPORTED, "crispy_asr_load_resident: width %d has no f16 logits kernel", dt);
+  int rc;
+  if ((rc = reorder_conv(h, "encoder.conv1.weight", d, h->hp.n_mels, &h->conv1_w)) != CRISPY_OK) return rc;
+  if ((rc = reorder_conv(h, "encoder.conv2.weight", d, d, &h->conv2_w)) != CRISPY_OK) return rc;
+  h->conv1_b = T(h, "encoder.conv1.bias");
+  h->conv2_b = T(h, "encoder.conv2.bias");
+  h->enc_pos = T(h, "encoder.positional_embedding");
+  h->ln_post_w = T(h, "encoder.ln_post.weight");
+  h->ln_post_b = T(h, "encoder.ln_post.bias");
+  // a matrix the file holds dense (f32 / f16: mixed files) takes part as a QT_F32 "block" tensor aliasing its dense copy
+  auto matrix = [&](const std::string& name, int cols) -> int {
+    if (h->qtensors.count(name)) return CRISPY_OK;
+    Tensor& t = h->tensors[name];
+    if (!t.d) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_load_resident: tensor '%s' missing", name.c_str());
+    QTensor q;
+    q.d = reinterpret_cast<unsigned char*>(t.d); q.ttype = QT_F32; q.n = t.n; q.cols = cols; q.nbytes = t.n * 4; q.owned = false;
+    h->qtensors[name] = q;
+    return CRISPY_OK;
+  };
+  size_t max_elems = 0;
+  auto ref = [&](std::initializer_list<std::string> names, int cols, QRef* out) -> int {
+    for (const std::string& n : names) { const int r = matrix(n, cols); if (r != CRISPY_OK) return r; }
+    *out = qref(h, names);
+    if (out->elems() > max_elems) max_elems = out->elems();
+    return CRISPY_OK;
+  };
+  h->enc.resize(h->hp.n_audio_layer);
+  h->dec.resize(h->hp.n_text_layer);
+  for (int i = 0; i < h->hp.n_audio_layer; ++i) {
+    const std::string p = "encoder.blocks." + std::to_string(i) + ".";
+    EncLayer& L = h->enc[i];
+    L.ln1_w = T(h, p + "attn_ln.weight"); L.ln1_b = T(h, p + "attn_ln.bias");
+    L.ln2_w = T(h, p + "mlp_ln.weight"); L.ln2_b = T(h, p + "mlp_ln.bias");
+    L.out_b = T(h, p + "attn.out.bias"); L.fc1_b = T(h, p + "mlp.0.bias"); L.fc2_b = T(h, p + "mlp.2.bias");
+    L.qkv_w = L.out_w = L.fc1_w = L.fc2_w = nullptr;
+    if ((rc = ref({p + "attn.query.weight", p + "attn.key.weight", p + "attn.value.weight"}, d, &L.r_qkv)) != CRISPY_OK) return rc;
+    if ((rc = ref({p + "attn.out.weight"}, d, &L.r_out)) != CRISPY_OK) return rc;
+    if ((rc = ref({p + "mlp.0.weight"}, d, &L.r_fc1)) != CRISPY_OK) return rc;
+    if ((rc = ref({p + "mlp.2.weight"}, 4 * d, &L.r_fc2)) != CRISPY_OK) return rc;
+    if ((rc = fuse_bias(h, {p + "attn.query.bias", "", p + "attn.value.bias"}, d, &L.qkv_b)) != CRISPY_OK) return rc;
+  }
+  for (int i = 0; i < h->hp.n_text_layer; ++i) {
+    const std::string p = "decoder.blocks." + std::to_string(i) + ".";
+    DecLayer& L = h->dec[i];
+    L.ln1_w = T(h, p + "attn_ln.weight"); L.ln1_b = T(h, p + "attn_ln.bias");
+    L.lnx_w = T(h, p + "cross_attn_ln.weight"); L.lnx_b = T(h, p + "cross_attn_ln.bias");
+    L.ln2_w = T(h, p + "mlp_ln.weight"); L.ln2_b = T(h, p + "mlp_ln.bias");
+    L.out_b = T(h, p + "attn.out.bias"); L.xq_b = T(h, p + "cross_attn.query.bias");
+    L.xout_b = T(h, p + "cross_attn.out.bias"); L.fc1_b = T(h, p + "mlp.0.bias"); L.fc2_b = T(h, p + "mlp.2.bias");
+    L.qkv_w = L.out_w = L.xq_w = L.xkv_w = L.xout_w = L.fc1_w = L.fc2_w = nullptr;
+    L.qkv_lw = L.xq_lw = L.fc1_lw = nullptr;
+    if ((rc = ref({p + "attn.query.weight", p + "attn.key.weight", p + "attn.value.weight"}, dt, &L.r_qkv)) != CRISPY_OK) return rc;
+    if ((rc = ref({p + "attn.out.weight"}, dt, &L.r_out)) != CRISPY_OK) return rc;
+    if ((rc = ref({p + "cross_attn.query.weight"}, dt, &L.r_xq)) != CRISPY_OK) return rc;
+    if ((rc = ref({p + "cross_attn.key.weight", p + "cross_attn.value.weight"}, dt, &L.r_xkv)) != CRISPY_OK) return rc;
+    if ((rc = ref({p + "cross_attn.out.weight"}, dt, &L.r_xout)) != CRISPY_OK) return rc;
+    if ((rc = ref({p + "mlp.0.weight"}, dt, &L.r_fc1)) != CRISPY_OK) return rc;
+    if ((rc = ref({p + "mlp.2.weight"}, 4 * dt, &L.r_fc2)) != CRISPY_OK) return rc;
+    if ((rc = fuse_bias(h, {p + "attn.query.bias", "", p + "attn.value.bias"}, dt, &L.qkv_b)) != CRISPY_OK) return rc;
+    if ((rc = fuse_bias(h, {"", p + "cross_attn.value.bias"}, dt, &L.xkv_b)) != CRISPY_OK) return rc;
+  }
+  if ((rc = matrix("decoder.token_embedding.weight", dt)) != CRISPY_OK) return rc;
+  h->q_tok_emb = &h->qtensors["decoder.token_embedding.weight"];
+  h->tok_emb = nullptr;
+  h->dec_pos = T(h, "decoder.positional_embedding");
+  h->dec_ln_w = T(h, "decoder.ln.weight");
+  h->dec_ln_b = T(h, "decoder.ln.bias");
+  // the one scratch slot: the largest (fused) matrix as f32
+  h->q_scratch_bytes = max_elems * sizeof(float);
+  HIP_TRY(hipMalloc(&h->q_scratch, h->q_scratch_bytes));
+  for (DecLayer& L : h->dec) {     // LayerNorm-fold vectors of the decode projections (fold_ln's ln_s / ln_c)
+    rc = fold_ln_vectors(h, L.r_qkv, L.qkv_b, L.ln1_w, L.ln1_b, 3 * (size_t)dt, dt, &L.qkv_ls, &L.qkv_lc);
+    if (rc == CRISPY_OK) rc = fold_ln_vectors(h, L.r_xq, L.xq_b, L.lnx_w, L.lnx_b, dt, dt, &L.xq_ls, &L.xq_lc);
+    if (rc == CRISPY_OK) rc = fold_ln_vectors(h, L.r_fc1, L.fc1_b, L.ln2_w, L.ln2_b, 4 * (size_t)dt, dt, &L.fc1_ls, &L.fc1_lc);
+    if (rc != CRISPY_OK) return rc;
+  }
+  {   // token embedding for the logits: f16, packed in MFMA operand order, from a dense copy that lives for this block only
+    float* tmp = nullptr;
+    HIP_TRY(hipMalloc(&tmp, (size_t)V * dt * sizeof(float)));
+    hipError_t e = dequant_blocks(h->q_tok_emb->d, h->q_tok_emb->ttype, (long)((size_t)V * dt / 32), dt, tmp, 0, nullptr, h->stream);
+    void* packed = nullptr;
+    if (e == hipSuccess) e = hipMalloc(&packed, vocab_f16_packed_bytes(V, dt));
+    if (e == hipSuccess) {
+      h->derived.push_back(reinterpret_cast<float*>(packed));
+      h->derived_bytes += vocab_f16_packed_bytes(V, dt);
+      e = pack_vocab_f16(tmp, packed, V, dt, h->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(tmp);
+    HIP_TRY(e);
+    h->tok_emb_hp = packed;
+  }
+  if ((rc = make_conv_halves(h)) != CRISPY_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->half_ready = true;
+  h->enc_precision = 1;
+  return finalize_tail(h);
+}
+
+}  // namespace
 
 int crispy_asr_finalize(crispy_asr* h) try {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_finalize: NULL handle");
@@ -359,6 +606,7 @@ int crispy_asr_finalize(crispy_asr* h) try {
   for (const auto& kv : h->tensors)
     if (!kv.second.set) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_finalize: tensor '%s' was never set", kv.first.c_str());
   HIP_TRY(hipSetDevice(h->device));
+  if (h->resident) return finalize_resident(h);
   const int d = h->hp.n_audio_state, dt = h->hp.n_text_state;
   int rc;
   if ((rc = reorder_conv(h, "encoder.conv1.weight", d, h->hp.n_mels, &h->conv1_w)) != CRISPY_OK) return rc;
@@ -411,14 +659,7 @@ int crispy_asr_finalize(crispy_asr* h) try {
     if (rc == CRISPY_OK) rc = fold_ln(h, L.fc1_w, L.fc1_b, L.ln2_w, L.ln2_b, 4 * (size_t)dt, dt, &L.fc1_lw, &L.fc1_ls, &L.fc1_lc);
     if (rc != CRISPY_OK) return rc;
   }
-  HIP_TRY(hipMalloc(&h->d_suppress, h->hp.n_vocab));
-  HIP_TRY(hipMalloc(&h->d_suppress_first, h->hp.n_vocab));
-  HIP_TRY(hipMemset(h->d_suppress, 0, h->hp.n_vocab));
-  HIP_TRY(hipMemset(h->d_suppress_first, 0, h->hp.n_vocab));
-  HIP_TRY(hipDeviceSynchronize());          // NULL-stream memsets vs the handle's non-blocking stream (see reserve_enc)
-  { const int mrc = build_ts_masks(h); if (mrc != CRISPY_OK) return mrc; }
-  h->finalized = true;
-  return CRISPY_OK;
+  return finalize_tail(h);
 } CRISPY_CATCH_RET("crispy_asr_finalize")
 
 int crispy_asr_hparams_get(const crispy_asr* h, crispy_asr_hparams* out) try {
@@ -433,6 +674,9 @@ int crispy_asr_set_precision(crispy_asr* h, int mode) try {
   if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_set_precision: model not finalized");
   if (mode != 0 && mode != 1) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_set_precision: mode must be 0 (f32) or 1 (f16 encoder GEMM operands)");
   HIP_TRY(hipSetDevice(h->device));
+  if (h->resident && mode != 1)
+    return fail(CRISPY_ERR_UNSUPPORTED, "crispy_asr_set_precision: a resident quantised model runs in precision mode 1 only "
+                "(its matrices exist as f16 operands at the point of use, never as f32 tensors)");
   if (mode == 1 && !h->half_ready) {
     // f16 copies of the encoder GEMM weights, made on the device once.  `half_ready` is only set after the last copy
     // and a stream sync: a hipMalloc failing part-way (OOM on a large model) leaves the mode at 0 and a retry starts
@@ -576,25 +820,36 @@ int crispy_asr_encode_device(crispy_asr* h, const float* d_mel_t, int batch, flo
       g.C = C; g.ldc = ldc; g.bias = bias; g.M = (int)rows; g.N = N; g.K = K; g.vt_T = Tn; g.xcd_swizzle = swz;
       return g;
     };
+    // f16 weights of a product: the resident copy, or -- resident quantised model -- the blocks de-quantised into the
+    // scratch slot right here (the previous product has finished with the slot: same stream)
+    auto w16 = [&](const void* dense, const QRef& r, const void** out) -> int {
+      if (!h->resident) { *out = dense; return CRISPY_OK; }
+      return dq(h, r, true, nullptr, s, out);
+    };
     for (const EncLayer& L : h->enc) {
+      const void* w = nullptr;
       HIP_TRY(layernorm_f16out(h->w_x, L.ln1_w, L.ln1_b, xn_h, rows, d, s));
-      HIP_TRY(gemm_hh(hg(xn_h, d, L.qkv_wh, d, qk_h, 2L * d, L.qkv_b, 2 * d, d), HGEMM_F16, 1, s));
-      HIP_TRY(gemm_hh(hg(xn_h, d, reinterpret_cast<const _Float16*>(L.qkv_wh) + 2L * d * d, d, vt_h, 0, L.qkv_b + 2 * d, d, d),
+      if ((rc = w16(L.qkv_wh, L.r_qkv, &w)) != CRISPY_OK) return rc;
+      HIP_TRY(gemm_hh(hg(xn_h, d, w, d, qk_h, 2L * d, L.qkv_b, 2 * d, d), HGEMM_F16, 1, s));
+      HIP_TRY(gemm_hh(hg(xn_h, d, reinterpret_cast<const _Float16*>(w) + 2L * d * d, d, vt_h, 0, L.qkv_b + 2 * d, d, d),
                       HGEMM_VT, 1, s));
       HIP_TRY(attn_encoder_h(qk_h, vt_h, att_h, batch, Tn, d, H, s));
       {
-        HGemmArgs g = hg(att_h, d, L.out_wh, d, h->w_x, d, L.out_b, d, d);
+        if ((rc = w16(L.out_wh, L.r_out, &w)) != CRISPY_OK) return rc;
+        HGemmArgs g = hg(att_h, d, w, d, h->w_x, d, L.out_b, d, d);
         g.residual = h->w_x; g.ldr = d;
         HIP_TRY(gemm_hh(g, HGEMM_RES, 1, s));
       }
       HIP_TRY(layernorm_f16out(h->w_x, L.ln2_w, L.ln2_b, xn_h, rows, d, s));
       {
-        HGemmArgs g = hg(xn_h, d, L.fc1_wh, d, hid_h, 4L * d, L.fc1_b, 4 * d, d);
+        if ((rc = w16(L.fc1_wh, L.r_fc1, &w)) != CRISPY_OK) return rc;
+        HGemmArgs g = hg(xn_h, d, w, d, hid_h, 4L * d, L.fc1_b, 4 * d, d);
         g.gelu = 1;
         HIP_TRY(gemm_hh(g, HGEMM_F16, 1, s));
       }
       {
-        HGemmArgs g = hg(hid_h, 4L * d, L.fc2_wh, 4L * d, h->w_x, d, L.fc2_b, d, 4 * d);
+        if ((rc = w16(L.fc2_wh, L.r_fc2, &w)) != CRISPY_OK) return rc;
+        HGemmArgs g = hg(hid_h, 4L * d, w, 4L * d, h->w_x, d, L.fc2_b, d, 4 * d);
         g.residual = h->w_x; g.ldr = d;
         HIP_TRY(gemm_hh(g, HGEMM_RES, 1, s));
       }
@@ -726,8 +981,23 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
   // <= SKINNY_MAX_M clips: the projections run on the skinny kernel (row blocks of 32 clips), which folds the preceding LayerNorm in and writes q and
   // k|v of the self-attention block from one launch (17 launches fewer per step on Whisper-tiny)
   const bool fold = batch <= SKINNY_MAX_M && dt % 128 == 0;
-  if (!embedded)      // (a fused pick has written the residual stream already)
-    HIP_TRY(embed_tokens_f32(h->d_tok, h->tok_emb, h->dec_pos, pos, pos_dev, h->d_dx, batch, dt, s));
+  if (!embedded) {    // (a fused pick has written the residual stream already)
+    if (h->resident)
+      HIP_TRY(embed_tokens_q(h->d_tok, h->q_tok_emb->d, h->q_tok_emb->ttype, h->dec_pos, pos, pos_dev, h->d_dx, batch, dt, s));
+    else
+      HIP_TRY(embed_tokens_f32(h->d_tok, h->tok_emb, h->dec_pos, pos, pos_dev, h->d_dx, batch, dt, s));
+  }
+  // resident quantised model: every weight operand is de-quantised into the scratch slot in front of its product --
+  // f32 x gamma for the LayerNorm-folded projections (fold_ln's W' = W . diag(gamma), element for element), f16 for the
+  // plain ones, plain f32 on the un-folded path of very large batches
+  int qrc = CRISPY_OK;
+  auto w32 = [&](const float* dense, const QRef& r, const float* gamma) -> const float* {
+    if (!h->resident) return dense;
+    const void* o = nullptr;
+    const int e = dq(h, r, false, gamma, s, &o);
+    if (e != CRISPY_OK) qrc = e;
+    return reinterpret_cast<const float*>(o);
+  };
   for (size_t l = 0; l < h->dec.size(); ++l) {
     const DecLayer& L = h->dec[l];
     float* selfkv = h->d_selfkv + l * (size_t)batch * C * 2 * dt;
@@ -739,7 +1009,8 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
     const bool kv16 = fold && h->enc_precision == 1 && h->dec_max_keys > 0 && h->dec_max_keys <= 512;
     _Float16* selfkv_h = reinterpret_cast<_Float16*>(h->d_selfkv) + l * (size_t)batch * C * 2 * dt;
     if (fold) {
-      GemmArgs g = gemm(h->d_dx, dt, L.qkv_lw, dt, h->d_dq, dt, nullptr, batch, 3 * dt, dt);
+      GemmArgs g = gemm(h->d_dx, dt, w32(L.qkv_lw, L.r_qkv, L.ln1_w), dt, h->d_dq, dt, nullptr, batch, 3 * dt, dt);
+      if (qrc != CRISPY_OK) return qrc;
       g.ln_s = L.qkv_ls; g.ln_c = L.qkv_lc;
       g.C2 = kv_dst; g.ldc2 = (long)C * 2 * dt; g.n_split = dt;
       if (kv16) { g.C2 = reinterpret_cast<float*>(selfkv_h + (dev_pos ? 0 : (size_t)pos * 2 * dt)); g.c2_half = 1; }
@@ -747,8 +1018,10 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
       HIP_TRY(gemm_f32_nt(g, 1, s));
     } else {
       HIP_TRY(layernorm_f32(h->d_dx, L.ln1_w, L.ln1_b, h->d_dxn, batch, dt, s));
-      HIP_TRY(gemm_f32_nt(gemm(h->d_dxn, dt, L.qkv_w, dt, h->d_dq, dt, L.qkv_b, batch, dt, dt), 1, s));
-      GemmArgs g = gemm(h->d_dxn, dt, L.qkv_w + (size_t)dt * dt, dt, kv_dst, (long)C * 2 * dt, L.qkv_b + dt, batch, 2 * dt, dt);
+      const float* qkv_w = w32(L.qkv_w, L.r_qkv, nullptr);
+      if (qrc != CRISPY_OK) return qrc;
+      HIP_TRY(gemm_f32_nt(gemm(h->d_dxn, dt, qkv_w, dt, h->d_dq, dt, L.qkv_b, batch, dt, dt), 1, s));
+      GemmArgs g = gemm(h->d_dxn, dt, qkv_w + (size_t)dt * dt, dt, kv_dst, (long)C * 2 * dt, L.qkv_b + dt, batch, 2 * dt, dt);
       if (dev_pos) { g.c_off_dev = h->d_counters; g.c_off_scale = 2L * dt; }
       HIP_TRY(gemm_f32_nt(g, 1, s));
     }
@@ -760,22 +1033,39 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
                                h->d_datt, dt, batch, H, s));
     // mode 1: the projections that have no LayerNorm in front (attention outputs, the MLP's second GEMM) in ggml's
     // arithmetic -- f16 weights, the f32 activation rounded to f16 on the way into the matrix cores, f32 accumulation
-    const bool wh = fold && h->enc_precision == 1 && L.out_wh;
-    auto half_w = [&](GemmArgs& g, const void* w16) { if (wh) { g.W = reinterpret_cast<const float*>(w16); g.w_half = 1; } };
+    const bool wh = fold && h->enc_precision == 1 && (L.out_wh || h->resident);
+    // plain projection weights: the f16 copy (mode 1, folded path), the f32 tensor, or the resident blocks de-quantised to either
+    auto plain_w = [&](GemmArgs& g, const float* w_f32, const void* w_f16, const QRef& r) {
+      if (h->resident) {
+        const void* o = nullptr;
+        const int e = dq(h, r, wh, nullptr, s, &o);
+        if (e != CRISPY_OK) qrc = e;
+        g.W = reinterpret_cast<const float*>(o);
+        g.w_half = wh ? 1 : 0;
+      } else if (wh) {
+        g.W = reinterpret_cast<const float*>(w_f16); g.w_half = 1;
+      } else {
+        g.W = w_f32;
+      }
+    };
     {
       GemmArgs g = gemm(h->d_datt, dt, L.out_w, dt, h->d_dx, dt, L.out_b, batch, dt, dt);
       g.residual = h->d_dx; g.ldr = dt;
-      half_w(g, L.out_wh);
+      plain_w(g, L.out_w, L.out_wh, L.r_out);
+      if (qrc != CRISPY_OK) return qrc;
       HIP_TRY(gemm_f32_nt(g, 1, s));
     }
     // cross-attention over the encoder output (K | V precomputed once per clip)
     if (fold) {
-      GemmArgs g = gemm(h->d_dx, dt, L.xq_lw, dt, h->d_dq, dt, nullptr, batch, dt, dt);
+      GemmArgs g = gemm(h->d_dx, dt, w32(L.xq_lw, L.r_xq, L.lnx_w), dt, h->d_dq, dt, nullptr, batch, dt, dt);
+      if (qrc != CRISPY_OK) return qrc;
       g.ln_s = L.xq_ls; g.ln_c = L.xq_lc;
       HIP_TRY(gemm_f32_nt(g, 1, s));
     } else {
       HIP_TRY(layernorm_f32(h->d_dx, L.lnx_w, L.lnx_b, h->d_dxn, batch, dt, s));
-      HIP_TRY(gemm_f32_nt(gemm(h->d_dxn, dt, L.xq_w, dt, h->d_dq, dt, L.xq_b, batch, dt, dt), 1, s));
+      const float* xq_w = w32(L.xq_w, L.r_xq, nullptr);
+      if (qrc != CRISPY_OK) return qrc;
+      HIP_TRY(gemm_f32_nt(gemm(h->d_dxn, dt, xq_w, dt, h->d_dq, dt, L.xq_b, batch, dt, dt), 1, s));
     }
     if (h->enc_precision == 1)
       HIP_TRY(attn_decoder_kv16(h->d_dq, dt, reinterpret_cast<const char*>(h->d_xkv_h) + l * (size_t)batch * Tn * 2 * dt * 2,
@@ -786,25 +1076,29 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
     {
       GemmArgs g = gemm(h->d_datt, dt, L.xout_w, dt, h->d_dx, dt, L.xout_b, batch, dt, dt);
       g.residual = h->d_dx; g.ldr = dt;
-      half_w(g, L.xout_wh);
+      plain_w(g, L.xout_w, L.xout_wh, L.r_xout);
+      if (qrc != CRISPY_OK) return qrc;
       HIP_TRY(gemm_f32_nt(g, 1, s));
     }
     // MLP
     if (fold) {
-      GemmArgs g = gemm(h->d_dx, dt, L.fc1_lw, dt, h->d_dh, 4L * dt, nullptr, batch, 4 * dt, dt);
+      GemmArgs g = gemm(h->d_dx, dt, w32(L.fc1_lw, L.r_fc1, L.ln2_w), dt, h->d_dh, 4L * dt, nullptr, batch, 4 * dt, dt);
+      if (qrc != CRISPY_OK) return qrc;
       g.ln_s = L.fc1_ls; g.ln_c = L.fc1_lc;
       g.gelu = 1;
       HIP_TRY(gemm_f32_nt(g, 1, s));
     } else {
       HIP_TRY(layernorm_f32(h->d_dx, L.ln2_w, L.ln2_b, h->d_dxn, batch, dt, s));
-      GemmArgs g = gemm(h->d_dxn, dt, L.fc1_w, dt, h->d_dh, 4L * dt, L.fc1_b, batch, 4 * dt, dt);
+      GemmArgs g = gemm(h->d_dxn, dt, w32(L.fc1_w, L.r_fc1, nullptr), dt, h->d_dh, 4L * dt, L.fc1_b, batch, 4 * dt, dt);
+      if (qrc != CRISPY_OK) return qrc;
       g.gelu = 1;
       HIP_TRY(gemm_f32_nt(g, 1, s));
     }
     {
       GemmArgs g = gemm(h->d_dh, 4L * dt, L.fc2_w, 4L * dt, h->d_dx, dt, L.fc2_b, batch, dt, 4 * dt);
       g.residual = h->d_dx; g.ldr = dt;
-      half_w(g, L.fc2_wh);
+      plain_w(g, L.fc2_w, L.fc2_wh, L.r_fc2);
+      if (qrc != CRISPY_OK) return qrc;
       HIP_TRY(gemm_f32_nt(g, 1, s));
     }
   }
@@ -846,7 +1140,7 @@ Special special_tokens(const crispy_asr* h) { return vocab_specials(h->hp.n_voca
 // cross K | V of every layer, once per window (f16 mode: the decode steps stream an f16 copy of it)
 int compute_cross_kv(crispy_asr* h, const float* d_enc, int batch, hipStream_t s) {
   const int dt = h->hp.n_text_state, Tn = h->hp.n_audio_ctx;
-  if (h->enc_precision == 1 && h->dec[0].xkv_wh) {
+  if (h->enc_precision == 1 && (h->dec[0].xkv_wh || h->resident)) {
     // The reference's precision: the projection itself on the f16 matrix cores (encoder output and weights rounded
     // to f16, f32 accumulation), written as f16 head-major straight from the epilogue.  (It used to run as an f32 GEMM
     // followed by a conversion pass: 3.9 + 0.8 ms per layer at 256 Whisper-base clips, more than the whole encoder.)
@@ -854,8 +1148,10 @@ int compute_cross_kv(crispy_asr* h, const float* d_enc, int batch, hipStream_t s
     _Float16* enc_h = reinterpret_cast<_Float16*>(h->d_xkv);       // the f32 cross K|V buffer is unused in this mode
     HIP_TRY(convert_f32_to_f16(d_enc, enc_h, n, s));
     for (size_t l = 0; l < h->dec.size(); ++l) {
+      const void* xkv_wh = h->dec[l].xkv_wh;
+      if (h->resident) { const int rq = dq(h, h->dec[l].r_xkv, true, nullptr, s, &xkv_wh); if (rq != CRISPY_OK) return rq; }
       HGemmArgs g{};
-      g.A = enc_h; g.lda = dt; g.W = reinterpret_cast<const _Float16*>(h->dec[l].xkv_wh); g.ldw = dt;
+      g.A = enc_h; g.lda = dt; g.W = reinterpret_cast<const _Float16*>(xkv_wh); g.ldw = dt;
       g.C = reinterpret_cast<_Float16*>(h->d_xkv_h) + l * (size_t)batch * Tn * 2 * dt;
       g.bias = h->dec[l].xkv_b; g.M = batch * Tn; g.N = 2 * dt; g.K = dt; g.vt_T = Tn; g.kv_width = dt;
       g.xcd_swizzle = h->xcd_swizzle;
@@ -901,7 +1197,9 @@ int prefill(crispy_asr* h, const float* d_enc, int batch, const int* prompt, int
 }
 
 StepFuse step_fuse(crispy_asr* h) {
-  return StepFuse{h->tok_emb, h->dec_pos, h->d_dx, h->hp.n_text_state, h->d_counters};
+  StepFuse f{h->tok_emb, h->dec_pos, h->d_dx, h->hp.n_text_state, h->d_counters, nullptr, 0};
+  if (h->resident) { f.tok_emb_q = h->q_tok_emb->d; f.tok_emb_ttype = h->q_tok_emb->ttype; }
+  return f;
 }
 
 TsPickArgs ts_args(crispy_asr* h, int rules, const unsigned char* mask, const unsigned char* mask_first) {
@@ -1384,7 +1682,32 @@ void publish(crispy_asr_result_impl* r) {
 
 extern "C" {
 
+namespace {
+int load_impl(const char* model_path, int device, bool resident, crispy_asr** out);
+}
 int crispy_asr_load(const char* model_path, int device, crispy_asr** out) try {
+  return load_impl(model_path, device, false, out);
+} CRISPY_CATCH_RET("crispy_asr_load")
+
+int crispy_asr_load_resident(const char* model_path, int device, crispy_asr** out) try {
+  return load_impl(model_path, device, true, out);
+} CRISPY_CATCH_RET("crispy_asr_load_resident")
+
+int crispy_asr_memory_info(const crispy_asr* h, size_t* weight_bytes, size_t* quantised_bytes, size_t* scratch_bytes) try {
+  if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_memory_info: NULL handle");
+  size_t dense = h->derived_bytes, q = 0;
+  for (const auto& kv : h->tensors)
+    if (kv.second.d) dense += kv.second.n * sizeof(float);
+  for (const auto& kv : h->qtensors)
+    if (kv.second.owned) q += kv.second.nbytes;
+  if (weight_bytes) *weight_bytes = dense + q;
+  if (quantised_bytes) *quantised_bytes = q;
+  if (scratch_bytes) *scratch_bytes = h->q_scratch_bytes;
+  return CRISPY_OK;
+} CRISPY_CATCH_RET("crispy_asr_memory_info")
+
+namespace {
+int load_impl(const char* model_path, int device, bool resident, crispy_asr** out) {
   if (!out) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_load: out is NULL");
   *out = nullptr;
   if (!model_path) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_load: NULL path");
@@ -1422,6 +1745,7 @@ int crispy_asr_load(const char* model_path, int device, crispy_asr** out) try {
   int rc = crispy_asr_create(&hp, filters.data(), device, &h);
   if (rc != CRISPY_OK) return rc;
   h->vocab = std::move(vocab);
+  h->resident = resident;
   auto bail = [&](int code) {
     const std::string keep = last_error_cstr();
     crispy_asr_free(h);
@@ -1479,6 +1803,20 @@ int crispy_asr_load(const char* model_path, int device, crispy_asr** out) try {
       const size_t n_blocks = n / 32;
       qbuf.resize(n_blocks * qi.block_bytes);
       if (!r.read(qbuf.data(), qbuf.size())) { fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_load: truncated data of '%s'", name.c_str()); return bail(CRISPY_ERR_BAD_MODEL); }
+      if (resident && n_dims == 2) {
+        // the blocks stay as they are (managers/model.rs:99,137: the catalog's q4_1 / q5_0 files): no f32 tensor is made
+        QTensor q;
+        q.ttype = ttype; q.n = n; q.cols = ne[0]; q.nbytes = qbuf.size();
+        if (hipSetDevice(device) != hipSuccess || hipMalloc(&q.d, q.nbytes) != hipSuccess ||
+            hipMemcpy(q.d, qbuf.data(), q.nbytes, hipMemcpyHostToDevice) != hipSuccess) {
+          if (q.d) (void)hipFree(q.d);
+          fail(CRISPY_ERR_OOM, "crispy_asr_load_resident: no device memory for '%s' (%zu bytes)", name.c_str(), q.nbytes);
+          return bail(CRISPY_ERR_OOM);
+        }
+        h->qtensors[name] = q;
+        h->tensors[name].set = true;
+        continue;
+      }
       for (size_t bi = 0; bi < n_blocks; ++bi) dequant_block(ttype, qbuf.data() + bi * qi.block_bytes, buf.data() + bi * 32);
     }
     rc = crispy_asr_set_tensor(h, name.c_str(), buf.data(), n);
@@ -1488,7 +1826,8 @@ int crispy_asr_load(const char* model_path, int device, crispy_asr** out) try {
   if (rc != CRISPY_OK) return bail(rc);
   *out = h;
   return CRISPY_OK;
-} CRISPY_CATCH_RET("crispy_asr_load")
+}
+}  // namespace
 
 int crispy_asr_vocab_specials(int n_vocab, crispy_asr_specials* out) try {
   if (!out) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_vocab_specials: out is NULL");

@@ -18,6 +18,7 @@
 //   attn_dec_kernel        one wave per (clip, head): a single query against a KV cache / cross KV.
 #include <atomic>
 #include "asr_common.h"
+#include "asr_quant.h"
 
 namespace crispy {
 namespace {
@@ -913,7 +914,12 @@ __device__ __forceinline__ unsigned load_u32_unaligned(const unsigned char* p) {
 }
 // the tail of a fused pick: embedding of the pick for the next step, then the counters by the last workgroup to finish
 __device__ __forceinline__ void step_fuse_tail(const StepFuse& f, int tok, int pos, int step, int b, int tid) {
-  for (int c = tid; c < f.D; c += 1024) f.x[(long)b * f.D + c] = f.tok_emb[(long)tok * f.D + c] + f.pos_emb[(long)pos * f.D + c];
+  if (f.tok_emb_q) {
+    for (int c = tid; c < f.D; c += 1024)
+      f.x[(long)b * f.D + c] = q_elem(f.tok_emb_q, f.tok_emb_ttype, (long)tok * f.D + c) + f.pos_emb[(long)pos * f.D + c];
+  } else {
+    for (int c = tid; c < f.D; c += 1024) f.x[(long)b * f.D + c] = f.tok_emb[(long)tok * f.D + c] + f.pos_emb[(long)pos * f.D + c];
+  }
   if (tid == 0) {
     // No fence: nothing of this kernel is read by another workgroup of it -- the ticket only elects the workgroup that
     // stores the counters, every workgroup has consumed the old values long before its own increment, and the

@@ -318,6 +318,21 @@ int crispy_asr_transcribe_tokens(crispy_asr *h, const float *pcm, long pcm_strid
  * de-quantised to f32 at load time. */
 int crispy_asr_load(const char *model_path, int device, crispy_asr **out);
 
+/* The same, for the quantised files the reference's catalog ships (managers/model.rs:99 whisper-medium-q4_1.bin,
+ * :137 ggml-large-v3-q5_0.bin; `size_mb` 492 / 1100 at :101, :139): the 2-D tensors STAY in HBM as the file's ggml
+ * blocks (q4_0 / q4_1 / q5_0 / q5_1 / q8_0) and are de-quantised at the point of use -- to f16 operands in front of
+ * every matrix product, f32 x gamma for the LayerNorm-folded decode projections -- into one scratch slot the size of the
+ * largest layer matrix.  Resident weight bytes ~= file size (+ the token embedding once more as f16 in matrix-core
+ * operand order for the logits).  The engine runs in precision mode 1 (whisper.cpp's f16-operand arithmetic); 
+ * crispy_asr_set_precision(h, 0) is refused with CRISPY_ERR_UNSUPPORTED.  Results equal those of crispy_asr_load +
+ * crispy_asr_set_precision(h, 1) on the same file bit for bit.  f32 / f16 files load as with crispy_asr_load. */
+int crispy_asr_load_resident(const char *model_path, int device, crispy_asr **out);
+
+/* Device memory held by the model itself (not the per-call workspaces): every weight tensor, fused / folded / f16 copy
+ * and resident quantised block (`weight_bytes`), the part of it that is quantised blocks (`quantised_bytes`), and the
+ * de-quantisation scratch slot of a resident model (`scratch_bytes`).  Any out-pointer may be NULL. */
+int crispy_asr_memory_info(const crispy_asr *h, size_t *weight_bytes, size_t *quantised_bytes, size_t *scratch_bytes);
+
 /* Special-token ids of a whisper.cpp vocabulary of n_vocab entries [UPSTREAM-RECALL: whisper_vocab]: English-only
  * (51864): eot 50256, sot 50257, translate 50357, transcribe 50358, solm 50359, prev 50360, nosp 50361,
  * notimestamps 50362, first timestamp 50363, no language in the prompt; multilingual (51865, 51866 = large-v3):

@@ -1,0 +1,82 @@
+"""Quantised catalog models kept quantised in HBM (`crispy_asr_load_resident`; the reference ships whisper-medium-q4_1.bin
+and ggml-large-v3-q5_0.bin: managers/model.rs:99,137; VERDICT r2 missing #3).  A resident engine must equal the
+inflate-at-load engine in precision mode 1 on the same file BIT FOR BIT (same kernels, and every weight is de-quantised
+with the loader's operations in the loader's order), hold about the file's bytes, and refuse precision mode 0."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    from crispy_amd.whisper_weights import HParams, synthetic_whisper_weights
+    hp = HParams.tiny()
+    return hp, synthetic_whisper_weights(hp, 0, sensitive=True)
+
+
+@pytest.mark.parametrize("kind", ["q4_1", "q5_0", "q8_0", "q4_0", "q5_1"])
+def test_resident_model_equals_the_inflated_one(tiny, tmp_path, kind):
+    from crispy_amd import _native as N, synth_audio
+    from crispy_amd.asr import WhisperEngine, transcribe_batch
+    from crispy_amd.ggml_io import synthetic_vocab, write_ggml_quantized
+    from crispy_amd.mel_filters import whisper_mel_filters
+    hp, W = tiny
+    path = tmp_path / f"tiny-{kind}.bin"
+    write_ggml_quantized(str(path), hp, W, whisper_mel_filters(80), synthetic_vocab(hp.n_vocab), kind)
+    res = WhisperEngine(str(path), resident=True)
+    inf = WhisperEngine(str(path))
+    inf.set_precision(1)
+    # memory: the matrices are blocks, nothing of them exists as f32
+    n_mat = sum(int(np.prod(v.shape)) for k, v in W.items() if v.ndim == 2 and "positional" not in k)
+    bpw = {"q4_0": 18, "q4_1": 20, "q5_0": 22, "q5_1": 24, "q8_0": 34}[kind] / 32.0
+    mr, mi = res.memory_info(), inf.memory_info()
+    assert mr["quantised_bytes"] == int(n_mat * bpw) and mi["quantised_bytes"] == 0
+    assert mr["scratch_bytes"] == 4 * 4 * hp.n_text_state ** 2              # one slot: the largest matrix as f32
+    dense_f16_emb = 2 * hp.n_vocab * hp.n_text_state
+    assert mr["weight_bytes"] < mr["quantised_bytes"] + 1.3 * dense_f16_emb + 8e6, mr     # + packed f16 embedding + convs / vectors
+    assert mr["weight_bytes"] < 0.2 * mi["weight_bytes"], (mr, mi)
+    print(f"{kind}: file {os.path.getsize(path) / 1e6:.1f} MB, resident {mr['weight_bytes'] / 1e6:.1f} MB "
+          f"(blocks {mr['quantised_bytes'] / 1e6:.1f}), inflated + f16 copies {mi['weight_bytes'] / 1e6:.1f} MB")
+    with pytest.raises(N.CrispyError) as e:
+        res.set_precision(0)
+    assert e.value.code == -6
+    res.set_precision(1)
+    # encoder, bit for bit; ragged batch
+    clips = [synth_audio.clip16k_np(400 + i, n) for i, n in enumerate((480000, 96000, 31000))]
+    assert np.array_equal(res.encode(clips), inf.encode(clips))
+    # greedy ids through the product call, timestamps off and on (seek loop), language detection included
+    for c in clips[:2]:
+        assert res.transcribe(c, max_new_tokens=8) == inf.transcribe(c, max_new_tokens=8)
+        assert res.last_language_token == inf.last_language_token
+        assert res.transcribe_segments(c, max_new_tokens=10) == inf.transcribe_segments(c, max_new_tokens=10)
+    assert transcribe_batch(res, clips, max_new_tokens=6) == transcribe_batch(inf, clips, max_new_tokens=6)
+    # a step of 70 clips: second 32-row blocks of the skinny projections
+    many = [synth_audio.clip16k_np(500 + i, 48000) for i in range(70)]
+    prompt = [50258, 50259, 50359, 50363]
+    ta, _ = res.transcribe_tokens(many, prompt, 4)
+    tb, _ = inf.transcribe_tokens(many, prompt, 4)
+    assert np.array_equal(ta, tb)
+    assert len({tuple(t) for t in ta.tolist()}) > 20          # audio-sensitive weights: the clips decode differently
+    res.close(); inf.close()
+
+
+def test_resident_load_of_a_dense_file_is_the_ordinary_mode_1_engine(tiny, tmp_path):
+    """f32 / f16 files hold no blocks: `crispy_asr_load_resident` then keeps the matrices as the file has them (f32) and
+    still runs the same mode-1 arithmetic."""
+    from crispy_amd import synth_audio
+    from crispy_amd.asr import WhisperEngine
+    from crispy_amd.ggml_io import synthetic_vocab, write_ggml
+    from crispy_amd.mel_filters import whisper_mel_filters
+    hp, W = tiny
+    path = tmp_path / "tiny-f16.bin"
+    write_ggml(str(path), hp, W, whisper_mel_filters(80), synthetic_vocab(hp.n_vocab), f16=True)
+    res = WhisperEngine(str(path), resident=True)
+    inf = WhisperEngine(str(path))
+    inf.set_precision(1)
+    x = synth_audio.clip16k_np(7, 200000)
+    assert np.array_equal(res.encode([x]), inf.encode([x]))
+    assert res.transcribe(x, max_new_tokens=6) == inf.transcribe(x, max_new_tokens=6)
+    assert res.memory_info()["quantised_bytes"] == 0
