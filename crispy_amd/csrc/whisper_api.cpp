@@ -686,6 +686,7 @@ int crispy_asr_set_precision(crispy_asr* h, int mode) try {
       void* p = nullptr;
       HIP_TRY(hipMalloc(&p, n * 2));
       h->derived.push_back(reinterpret_cast<float*>(p));
+      h->derived_bytes += n * 2;
       HIP_TRY(convert_f32_to_f16(w, p, (long)n, h->stream));
       *out = p;
       return CRISPY_OK;
@@ -698,6 +699,7 @@ int crispy_asr_set_precision(crispy_asr* h, int mode) try {
       void* p = nullptr;
       HIP_TRY(hipMalloc(&p, d * k1p * 2));
       h->derived.push_back(reinterpret_cast<float*>(p));
+      h->derived_bytes += d * k1p * 2;
       HIP_TRY(hipMemsetAsync(p, 0, d * k1p * 2, h->stream));
       HIP_TRY(convert_rows_f32_to_f16(h->conv1_w, k1, p, k1p, k1, (long)d, h->stream));
       h->conv1_wh = p;
@@ -724,6 +726,7 @@ int crispy_asr_set_precision(crispy_asr* h, int mode) try {
       void* p = nullptr;
       HIP_TRY(hipMalloc(&p, vocab_f16_packed_bytes(h->hp.n_vocab, dt)));
       h->derived.push_back(reinterpret_cast<float*>(p));
+      h->derived_bytes += vocab_f16_packed_bytes(h->hp.n_vocab, dt);
       HIP_TRY(pack_vocab_f16(h->tok_emb, p, h->hp.n_vocab, dt, h->stream));
       h->tok_emb_hp = p;
     }

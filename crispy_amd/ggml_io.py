@@ -93,9 +93,11 @@ def _pack_nibbles(d, m, q, five: bool) -> np.ndarray:
     return np.concatenate(parts, axis=1)
 
 
-def write_ggml_quantized(path: str, hp, weights: dict, filters: np.ndarray, vocab: list, kind: str = "q5_0") -> dict:
+def write_ggml_quantized(path: str, hp, weights: dict, filters: np.ndarray, vocab: list, kind: str = "q5_0",
+                         keep: bool = True) -> dict:
     """Like the upstream `quantize` tool: 2-D `.weight` matrices whose rows are multiples of 32 become `kind`
-    blocks, the rest stays f16/f32.  Returns the weights as the loader will see them (de-quantised)."""
+    blocks, the rest stays f16/f32.  Returns the weights as the loader will see them (de-quantised; keep=False returns
+    an empty dict: catalog-size files).  `weights` needs `.items()` only (crispy_amd.whisper_weights.LazyWeights)."""
     import io
     seen = {}
     f32_always = {"encoder.conv1.bias", "encoder.conv2.bias", "encoder.positional_embedding",
@@ -124,7 +126,8 @@ def write_ggml_quantized(path: str, hp, weights: dict, filters: np.ndarray, voca
                 payload, deq, ttype = data.astype(np.float16).tobytes(), data.astype(np.float16).astype(np.float32), 1
             else:
                 payload, deq, ttype = data.tobytes(), data, 0
-            seen[name] = deq.reshape(np.asarray(w).shape)
+            if keep:
+                seen[name] = deq.reshape(np.asarray(w).shape)
             nb = name.encode("utf-8")
             f.write(struct.pack("<3i", data.ndim, len(nb), ttype))
             for i in range(data.ndim):

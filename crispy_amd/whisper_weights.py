@@ -121,6 +121,27 @@ def sinusoids(length: int, channels: int) -> np.ndarray:
     return np.concatenate([np.sin(t), np.cos(t)], axis=1).astype(np.float32)
 
 
+def synthetic_tensor(name: str, shape, seed: int = 0, sensitive: bool = False) -> np.ndarray:
+    """One tensor of the seeded random-init model (its own stream: seed, crc32(name)) -- see synthetic_whisper_weights."""
+    rng = np.random.default_rng([seed, zlib.crc32(name.encode())])
+    if name == "encoder.positional_embedding":
+        w = sinusoids(shape[0], shape[1])
+    elif name.endswith("_ln.weight") or name.endswith("ln_post.weight") or name == "decoder.ln.weight":
+        w = 1.0 + 0.1 * rng.standard_normal(shape)
+    elif name.endswith(".bias"):
+        w = 0.02 * rng.standard_normal(shape)
+    elif name == "decoder.token_embedding.weight":
+        w = 0.05 * rng.standard_normal(shape)
+    elif name == "decoder.positional_embedding":
+        w = 0.02 * rng.standard_normal(shape)
+    else:  # linear / conv: fan-in scaling keeps activations O(1) through the stack
+        fan_in = int(np.prod(shape[1:]))
+        w = rng.standard_normal(shape) / np.sqrt(fan_in)
+        if sensitive and ".cross_attn." in name:
+            w = w * (8.0 if (".query." in name or ".key." in name) else 4.0)
+    return np.ascontiguousarray(w, dtype=np.float32)
+
+
 def synthetic_whisper_weights(hp: HParams, seed: int = 0, sensitive: bool = False) -> "OrderedDict[str, np.ndarray]":
     """Seeded random-init model; every tensor has its own stream (seed, crc32(name)), so the result
     does not depend on generation order and is identical on every machine (numpy PCG64).
@@ -133,21 +154,17 @@ def synthetic_whisper_weights(hp: HParams, seed: int = 0, sensitive: bool = Fals
     them."""
     out: "OrderedDict[str, np.ndarray]" = OrderedDict()
     for name, shape in tensor_shapes(hp).items():
-        rng = np.random.default_rng([seed, zlib.crc32(name.encode())])
-        if name == "encoder.positional_embedding":
-            w = sinusoids(shape[0], shape[1])
-        elif name.endswith("_ln.weight") or name.endswith("ln_post.weight") or name == "decoder.ln.weight":
-            w = 1.0 + 0.1 * rng.standard_normal(shape)
-        elif name.endswith(".bias"):
-            w = 0.02 * rng.standard_normal(shape)
-        elif name == "decoder.token_embedding.weight":
-            w = 0.05 * rng.standard_normal(shape)
-        elif name == "decoder.positional_embedding":
-            w = 0.02 * rng.standard_normal(shape)
-        else:  # linear / conv: fan-in scaling keeps activations O(1) through the stack
-            fan_in = int(np.prod(shape[1:]))
-            w = rng.standard_normal(shape) / np.sqrt(fan_in)
-            if sensitive and ".cross_attn." in name:
-                w = w * (8.0 if (".query." in name or ".key." in name) else 4.0)
-        out[name] = np.ascontiguousarray(w, dtype=np.float32)
+        out[name] = synthetic_tensor(name, shape, seed, sensitive)
     return out
+
+
+class LazyWeights:
+    """`items()` of a seeded model, one tensor alive at a time: catalog-size files (medium 0.77 G, large-v3 1.55 G
+    parameters) are written without holding 3 - 6 GB of f32 on the host (tools/bench_resident.py)."""
+
+    def __init__(self, hp: HParams, seed: int = 0, sensitive: bool = False):
+        self.hp, self.seed, self.sensitive = hp, seed, sensitive
+
+    def items(self):
+        for name, shape in tensor_shapes(self.hp).items():
+            yield name, synthetic_tensor(name, shape, self.seed, self.sensitive)
