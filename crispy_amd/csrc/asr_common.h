@@ -65,9 +65,18 @@ struct GemmArgs {
   // + dim], so that one (clip, head) K or V block is a contiguous [hm_rows][64] run for the decode-step attention.
   int hm_rows, hm_width;                      // hm_rows = 0: plain row-major C;  hm_width = model width (N = 2 * width)
   int tiled;                                  // != 0: run the 128 x 128 tiled kernel even for a decode-step shape
+  // Skinny path, resident quantised weights (asr_quant.h): W is null; rows [p * wq_rows, (p + 1) * wq_rows) of the (row-fused)
+  // weight come from the ggml blocks of wq[p], K / 32 blocks per row, de-quantised in registers -- f32 (x wq_gamma[k]: the
+  // LayerNorm fold W' = W . diag(gamma)) for the f32 matrix cores, f16 when w_half is set.
+  const unsigned char* wq[3];
+  int wq_type, wq_rows;
+  const float* wq_gamma;
 };
 constexpr int SKINNY_MAX_M = 512;   // decode steps with up to this many clips use the skinny kernel (row blocks of 32)
 hipError_t gemm_f32_nt(const GemmArgs& g, int batch, hipStream_t s);
+// decode-step projection straight from resident ggml blocks (GemmArgs::wq): de-quantised in registers
+bool skinny_q_supported(const GemmArgs& g, int batch);
+hipError_t gemm_skinny_q(const GemmArgs& g, hipStream_t s);
 // f16-operand variant (whisper_gemm_f16.hip): A f32 rounded to f16 on the way into LDS, Wh an f16 copy of W [N][ldw]
 hipError_t gemm_f16_nt(const GemmArgs& g, const void* Wh, int batch, hipStream_t s);
 hipError_t convert_f32_to_f16(const float* src, void* dst, long n, hipStream_t s);

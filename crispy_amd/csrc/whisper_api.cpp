@@ -994,12 +994,40 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
   // f32 x gamma for the LayerNorm-folded projections (fold_ln's W' = W . diag(gamma), element for element), f16 for the
   // plain ones, plain f32 on the un-folded path of very large batches
   int qrc = CRISPY_OK;
-  auto w32 = [&](const float* dense, const QRef& r, const float* gamma) -> const float* {
+  auto w32 = [&](const float* dense, const QRef& r, const float* gamma) -> const float* {     // (un-folded path only)
     if (!h->resident) return dense;
     const void* o = nullptr;
     const int e = dq(h, r, false, gamma, s, &o);
     if (e != CRISPY_OK) qrc = e;
     return reinterpret_cast<const float*>(o);
+  };
+  // One projection of the folded path.  Dense model: W = the f32 (gamma-folded) tensor or its f16 copy.  Resident model:
+  // the skinny kernel reads the ggml blocks itself and de-quantises in registers (gemm_skinny_q); shapes it has no form
+  // for (and dense tensors of a mixed file) go through the scratch slot and the dense kernel.
+  auto proj = [&](GemmArgs g, const float* dense32, const void* dense16, const QRef& r, const float* gamma, bool half) -> int {
+    g.w_half = half ? 1 : 0;
+    if (!h->resident) {
+      g.W = half ? reinterpret_cast<const float*>(dense16) : dense32;
+      HIP_TRY(gemm_f32_nt(g, 1, s));
+      return CRISPY_OK;
+    }
+    bool blocks = r.n > 0 && r.t[0]->ttype != QT_F32;
+    for (int i = 1; i < r.n; ++i) blocks = blocks && r.t[i]->ttype == r.t[0]->ttype && r.t[i]->n == r.t[0]->n;
+    if (blocks && skinny_q_supported(g, 1)) {
+      g.W = nullptr;
+      for (int i = 0; i < 3; ++i) g.wq[i] = r.t[i < r.n ? i : 0]->d;
+      g.wq_type = r.t[0]->ttype;
+      g.wq_rows = (int)(r.t[0]->n / (size_t)r.t[0]->cols);
+      g.wq_gamma = gamma;
+      HIP_TRY(gemm_skinny_q(g, s));
+      return CRISPY_OK;
+    }
+    const void* o = nullptr;
+    const int e = dq(h, r, half, gamma, s, &o);
+    if (e != CRISPY_OK) return e;
+    g.W = reinterpret_cast<const float*>(o);
+    HIP_TRY(gemm_f32_nt(g, 1, s));
+    return CRISPY_OK;
   };
   for (size_t l = 0; l < h->dec.size(); ++l) {
     const DecLayer& L = h->dec[l];
@@ -1012,13 +1040,12 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
     const bool kv16 = fold && h->enc_precision == 1 && h->dec_max_keys > 0 && h->dec_max_keys <= 512;
     _Float16* selfkv_h = reinterpret_cast<_Float16*>(h->d_selfkv) + l * (size_t)batch * C * 2 * dt;
     if (fold) {
-      GemmArgs g = gemm(h->d_dx, dt, w32(L.qkv_lw, L.r_qkv, L.ln1_w), dt, h->d_dq, dt, nullptr, batch, 3 * dt, dt);
-      if (qrc != CRISPY_OK) return qrc;
+      GemmArgs g = gemm(h->d_dx, dt, nullptr, dt, h->d_dq, dt, nullptr, batch, 3 * dt, dt);
       g.ln_s = L.qkv_ls; g.ln_c = L.qkv_lc;
       g.C2 = kv_dst; g.ldc2 = (long)C * 2 * dt; g.n_split = dt;
       if (kv16) { g.C2 = reinterpret_cast<float*>(selfkv_h + (dev_pos ? 0 : (size_t)pos * 2 * dt)); g.c2_half = 1; }
       if (dev_pos) { g.c_off_dev = h->d_counters; g.c_off_scale = 2L * dt; }
-      HIP_TRY(gemm_f32_nt(g, 1, s));
+      if ((qrc = proj(g, L.qkv_lw, nullptr, L.r_qkv, L.ln1_w, false)) != CRISPY_OK) return qrc;
     } else {
       HIP_TRY(layernorm_f32(h->d_dx, L.ln1_w, L.ln1_b, h->d_dxn, batch, dt, s));
       const float* qkv_w = w32(L.qkv_w, L.r_qkv, nullptr);
@@ -1037,33 +1064,16 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
     // mode 1: the projections that have no LayerNorm in front (attention outputs, the MLP's second GEMM) in ggml's
     // arithmetic -- f16 weights, the f32 activation rounded to f16 on the way into the matrix cores, f32 accumulation
     const bool wh = fold && h->enc_precision == 1 && (L.out_wh || h->resident);
-    // plain projection weights: the f16 copy (mode 1, folded path), the f32 tensor, or the resident blocks de-quantised to either
-    auto plain_w = [&](GemmArgs& g, const float* w_f32, const void* w_f16, const QRef& r) {
-      if (h->resident) {
-        const void* o = nullptr;
-        const int e = dq(h, r, wh, nullptr, s, &o);
-        if (e != CRISPY_OK) qrc = e;
-        g.W = reinterpret_cast<const float*>(o);
-        g.w_half = wh ? 1 : 0;
-      } else if (wh) {
-        g.W = reinterpret_cast<const float*>(w_f16); g.w_half = 1;
-      } else {
-        g.W = w_f32;
-      }
-    };
     {
       GemmArgs g = gemm(h->d_datt, dt, L.out_w, dt, h->d_dx, dt, L.out_b, batch, dt, dt);
       g.residual = h->d_dx; g.ldr = dt;
-      plain_w(g, L.out_w, L.out_wh, L.r_out);
-      if (qrc != CRISPY_OK) return qrc;
-      HIP_TRY(gemm_f32_nt(g, 1, s));
+      if ((qrc = proj(g, L.out_w, L.out_wh, L.r_out, nullptr, wh)) != CRISPY_OK) return qrc;
     }
     // cross-attention over the encoder output (K | V precomputed once per clip)
     if (fold) {
-      GemmArgs g = gemm(h->d_dx, dt, w32(L.xq_lw, L.r_xq, L.lnx_w), dt, h->d_dq, dt, nullptr, batch, dt, dt);
-      if (qrc != CRISPY_OK) return qrc;
+      GemmArgs g = gemm(h->d_dx, dt, nullptr, dt, h->d_dq, dt, nullptr, batch, dt, dt);
       g.ln_s = L.xq_ls; g.ln_c = L.xq_lc;
-      HIP_TRY(gemm_f32_nt(g, 1, s));
+      if ((qrc = proj(g, L.xq_lw, nullptr, L.r_xq, L.lnx_w, false)) != CRISPY_OK) return qrc;
     } else {
       HIP_TRY(layernorm_f32(h->d_dx, L.lnx_w, L.lnx_b, h->d_dxn, batch, dt, s));
       const float* xq_w = w32(L.xq_w, L.r_xq, nullptr);
@@ -1079,17 +1089,14 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
     {
       GemmArgs g = gemm(h->d_datt, dt, L.xout_w, dt, h->d_dx, dt, L.xout_b, batch, dt, dt);
       g.residual = h->d_dx; g.ldr = dt;
-      plain_w(g, L.xout_w, L.xout_wh, L.r_xout);
-      if (qrc != CRISPY_OK) return qrc;
-      HIP_TRY(gemm_f32_nt(g, 1, s));
+      if ((qrc = proj(g, L.xout_w, L.xout_wh, L.r_xout, nullptr, wh)) != CRISPY_OK) return qrc;
     }
     // MLP
     if (fold) {
-      GemmArgs g = gemm(h->d_dx, dt, w32(L.fc1_lw, L.r_fc1, L.ln2_w), dt, h->d_dh, 4L * dt, nullptr, batch, 4 * dt, dt);
-      if (qrc != CRISPY_OK) return qrc;
+      GemmArgs g = gemm(h->d_dx, dt, nullptr, dt, h->d_dh, 4L * dt, nullptr, batch, 4 * dt, dt);
       g.ln_s = L.fc1_ls; g.ln_c = L.fc1_lc;
       g.gelu = 1;
-      HIP_TRY(gemm_f32_nt(g, 1, s));
+      if ((qrc = proj(g, L.fc1_lw, nullptr, L.r_fc1, L.ln2_w, false)) != CRISPY_OK) return qrc;
     } else {
       HIP_TRY(layernorm_f32(h->d_dx, L.ln2_w, L.ln2_b, h->d_dxn, batch, dt, s));
       GemmArgs g = gemm(h->d_dxn, dt, w32(L.fc1_w, L.r_fc1, nullptr), dt, h->d_dh, 4L * dt, L.fc1_b, batch, 4 * dt, dt);
@@ -1100,9 +1107,7 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
     {
       GemmArgs g = gemm(h->d_dh, 4L * dt, L.fc2_w, 4L * dt, h->d_dx, dt, L.fc2_b, batch, dt, 4 * dt);
       g.residual = h->d_dx; g.ldr = dt;
-      plain_w(g, L.fc2_w, L.fc2_wh, L.r_fc2);
-      if (qrc != CRISPY_OK) return qrc;
-      HIP_TRY(gemm_f32_nt(g, 1, s));
+      if ((qrc = proj(g, L.fc2_w, L.fc2_wh, L.r_fc2, nullptr, wh)) != CRISPY_OK) return qrc;
     }
   }
   if (want_logits) return decoder_logits(h, batch, s);
@@ -1810,7 +1815,7 @@ int load_impl(const char* model_path, int device, bool resident, crispy_asr** ou
         // the blocks stay as they are (managers/model.rs:99,137: the catalog's q4_1 / q5_0 files): no f32 tensor is made
         QTensor q;
         q.ttype = ttype; q.n = n; q.cols = ne[0]; q.nbytes = qbuf.size();
-        if (hipSetDevice(device) != hipSuccess || hipMalloc(&q.d, q.nbytes) != hipSuccess ||
+        if (hipSetDevice(device) != hipSuccess || hipMalloc(&q.d, q.nbytes + 16) != hipSuccess ||      // (+16: the in-register block fetch reads whole dwords)
             hipMemcpy(q.d, qbuf.data(), q.nbytes, hipMemcpyHostToDevice) != hipSuccess) {
           if (q.d) (void)hipFree(q.d);
           fail(CRISPY_ERR_OOM, "crispy_asr_load_resident: no device memory for '%s' (%zu bytes)", name.c_str(), q.nbytes);

@@ -342,6 +342,228 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_f32_kernel(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// The skinny kernel over RESIDENT QUANTISED weights (crispy_asr_load_resident; asr_quant.h).  Same decomposition, same
+// A path (row-coalesced loads, transposed through the wave's LDS area), same MFMA order, same epilogue -- the W operand
+// is different: a 32-wide K chunk of one output row is exactly ONE ggml block, and the 16 k values lane (row li, half
+// lh) contracts are the block's low (lh = 0) or high (lh = 1) nibbles, so every lane fetches its row's block (5 - 6
+// dwords, 18 - 24 bytes; two lanes share a block) straight into registers and de-quantises its 16 values there:
+// no LDS round trip for W, 0.56 - 1.06 bytes per weight from HBM instead of 2 or 4, and no separate de-quantisation
+// launch.  Values are computed with the loader's operations in the loader's order (int -> float, one multiply, one add,
+// times gamma[k] for the LayerNorm-folded form -- fold_ln's W' = W . diag(gamma) -- each rounded on its own; then
+// rounded to f16 for the WH form), so results equal those of the dense kernels on the de-quantised weights bit for bit.
+// ---------------------------------------------------------------------------------------------
+template <int TT> struct QFetch {
+  static constexpr int NWD = TT == QT_Q8_0 ? 5 : (quant_block_bytes(TT) + 3) / 4;
+  unsigned w[NWD];
+};
+template <int TT>
+__device__ __forceinline__ void q_fetch(QFetch<TT>& f, const unsigned char* b, int lh) {
+  if (TT == QT_Q8_0) {
+    unsigned short dv;
+    __builtin_memcpy(&dv, b, 2);
+    f.w[0] = dv;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f.w[1 + i] = q_u32(b + 2 + 16 * lh + 4 * i);
+  } else {
+#pragma unroll
+    for (int i = 0; i < QFetch<TT>::NWD; ++i) f.w[i] = q_u32(b + 4 * i);      // (the last dword may reach 2 bytes past the block)
+  }
+}
+__device__ __forceinline__ float q_half_bits(unsigned v) {
+  const unsigned short u = (unsigned short)(v & 0xffffu);
+  _Float16 h;
+  __builtin_memcpy(&h, &u, 2);
+  return (float)h;
+}
+// y[s] = weight 16 lh + s of the fetched block, s < 16
+template <int TT>
+__device__ __forceinline__ void q_half_block(const QFetch<TT>& f, int lh, float (&y)[16]) {
+#pragma clang fp contract(off)
+  const float d = q_half_bits(f.w[0]);
+  if (TT == QT_Q8_0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[4 * i + e] = (float)(int)(signed char)((f.w[1 + i] >> (8 * e)) & 0xff) * d;
+    return;
+  }
+  constexpr bool has_m = TT == QT_Q4_1 || TT == QT_Q5_1, has_h = TT == QT_Q5_0 || TT == QT_Q5_1;
+  const float m = has_m ? q_half_bits(f.w[0] >> 16) : 0.f;
+  unsigned qh = 0u, qs[4];
+  if (TT == QT_Q4_0) {          // {d}{qs 16} from byte 2
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qs[i] = (f.w[i] >> 16) | (f.w[i + 1] << 16);
+  } else if (TT == QT_Q4_1) {   // {d, m}{qs} from byte 4
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qs[i] = f.w[1 + i];
+  } else if (TT == QT_Q5_0) {   // {d}{qh 4}{qs} : qh at byte 2, qs at byte 6
+    qh = (f.w[0] >> 16) | (f.w[1] << 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qs[i] = (f.w[1 + i] >> 16) | (f.w[2 + i] << 16);
+  } else {                      // q5_1 {d, m}{qh}{qs}
+    qh = f.w[1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qs[i] = f.w[2 + i];
+  }
+  const int sh = 4 * lh;
+  const unsigned hb = has_h ? (qh >> (16 * lh)) : 0u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = 4 * i + e;
+      int x = (int)((qs[i] >> (8 * e + sh)) & 0x0fu);
+      if (has_h) x |= (int)((hb >> j) & 1u) << 4;
+      if (TT == QT_Q4_0) y[j] = (float)(x - 8) * d;
+      else if (TT == QT_Q5_0) y[j] = (float)(x - 16) * d;
+      else y[j] = (float)x * d + m;
+    }
+}
+
+template <int TT, bool LN, bool GELU, bool RES, int NW, bool WH>
+__global__ __launch_bounds__(64 * NW) void gemm_skinny_q_kernel(GemmArgs g) {
+  static_assert(!(WH && LN), "the f16 form has no LayerNorm fold");
+  extern __shared__ __attribute__((aligned(16))) float sk_smem[];
+  float (*red)[SK_WAVE_LDS] = reinterpret_cast<float (*)[SK_WAVE_LDS]>(sk_smem);
+  float (*rstat)[32][2] = reinterpret_cast<float (*)[32][2]>(sk_smem + NW * SK_WAVE_LDS);
+  constexpr int ET = NW >= 16 ? 1024 : NW >= 8 ? 512 : 256;
+  constexpr int RP = ET / 32, NQ = 32 / RP;
+  // chunks in flight: A 16 + block 6 (+ gamma 16) registers each; the LayerNorm-folded form with 16 waves has 128 registers
+  // per lane and keeps one (its K is 512 or 1024: one or two chunks per wave) -- two spilled 72 - 104 bytes
+  constexpr int PF = (LN && NW >= 16) ? 1 : 2;
+  constexpr int BB = quant_block_bytes(TT);
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.x * 32;
+  const int mb = blockIdx.y * 32;
+  const float* __restrict__ A = g.A;
+  const bool second = g.C2 && n0 >= g.n_split;
+  const int kper = g.K / NW;
+  const int kbeg = wave * kper;
+  const int lr = lane >> 3, lc = (lane & 7) ^ lr;
+  const char* __restrict__ Ab = reinterpret_cast<const char*>(A + kbeg);
+  unsigned asrc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) asrc[j] = (unsigned)(((long)min(mb + lr + 8 * j, g.M - 1) * g.lda + 4 * lc) * 4);
+  // this lane's weight row: part p of the row-fused matrix, local row r -> its blocks are contiguous
+  const unsigned char* __restrict__ wrow;
+  {
+    const int row = min(n0 + li, g.N - 1);
+    const int p = row / g.wq_rows;
+    const unsigned char* base = p == 0 ? g.wq[0] : (p == 1 ? g.wq[1] : g.wq[2]);
+    wrow = base + ((long)(row - p * g.wq_rows) * (g.K / 32) + kbeg / 32) * BB;
+  }
+  const float* __restrict__ gam = LN ? g.wq_gamma + kbeg + 16 * lh : nullptr;
+  f32x4* sta = reinterpret_cast<f32x4*>(sk_smem + wave * SK_WAVE_LDS) + 256;
+  int rslot[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) rslot[q] = li * 8 + ((4 * lh + q) ^ (li & 7));
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float s0 = 0.f, q0 = 0.f;
+  f32x4 a0[4], a1[4], g0[4], g1[4];
+  QFetch<TT> b0, b1;
+#define SKQ_REQUEST(BR, AR, GR, KO)                                                     \
+  {                                                                                     \
+    q_fetch<TT>(BR, wrow + (long)((KO) / 32) * BB, lh);                                \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                     \
+      AR[j] = *reinterpret_cast<const f32x4*>(Ab + (size_t)asrc[j] + 4 * (KO));         \
+      if (LN) GR[j] = *reinterpret_cast<const f32x4*>(gam + (KO) + 4 * j);              \
+    }                                                                                   \
+  }
+  SKQ_REQUEST(b0, a0, g0, 0)
+  if (PF > 1 && 32 < kper) SKQ_REQUEST(b1, a1, g1, 32)
+  const int ec = min(tid & 31, g.N - 1 - n0), enn = n0 + ec;
+  float e_s = 0.f, e_c = 0.f, e_res[NQ];
+  auto request_epilogue = [&]() {
+    if (LN) { e_s = g.ln_s[enn]; e_c = g.ln_c[enn]; }
+    else if (g.bias) e_c = g.bias[enn];
+    if (RES) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) e_res[q] = g.residual[(long)min(mb + min((tid >> 5) + RP * q, 31), g.M - 1) * g.ldr + enn];
+    }
+  };
+  const long coff = g.c_off_dev ? (long)(*g.c_off_dev) * g.c_off_scale : 0L;
+  float* __restrict__ C = second ? g.C2 + coff - g.n_split : g.C + (g.C2 ? 0L : coff);
+  const long ldc = second ? g.ldc2 : g.ldc;
+#define SKQ_CHUNK(BR, AR, GR, KC)                                                                   \
+  {                                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) sta[64 * j + lane] = AR[j];                       \
+    float wy[16];                                                                                   \
+    q_half_block<TT>(BR, lh, wy);                                                                   \
+    if (LN) {                                                                                       \
+      _Pragma("clang fp contract(off)")                                                             \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+        wy[4 * j] = wy[4 * j] * GR[j].x; wy[4 * j + 1] = wy[4 * j + 1] * GR[j].y;                   \
+        wy[4 * j + 2] = wy[4 * j + 2] * GR[j].z; wy[4 * j + 3] = wy[4 * j + 3] * GR[j].w;           \
+      }                                                                                             \
+    }                                                                                               \
+    if ((KC) + 32 * PF < kper) SKQ_REQUEST(BR, AR, GR, (KC) + 32 * PF)                              \
+    sk_wave_sync();                                                                                 \
+    f32x4 ca[4];                                                                                    \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) ca[q] = sta[rslot[q]];                            \
+    sk_wave_sync();                                                                                 \
+    if (WH) {                                                                                       \
+      _Pragma("unroll") for (int st = 0; st < 2; ++st) {                                            \
+        const sk_half8 av = {(_Float16)ca[2 * st].x, (_Float16)ca[2 * st].y, (_Float16)ca[2 * st].z, (_Float16)ca[2 * st].w, \
+                             (_Float16)ca[2 * st + 1].x, (_Float16)ca[2 * st + 1].y, (_Float16)ca[2 * st + 1].z, (_Float16)ca[2 * st + 1].w}; \
+        const sk_half8 wv = {(_Float16)wy[8 * st], (_Float16)wy[8 * st + 1], (_Float16)wy[8 * st + 2], (_Float16)wy[8 * st + 3], \
+                             (_Float16)wy[8 * st + 4], (_Float16)wy[8 * st + 5], (_Float16)wy[8 * st + 6], (_Float16)wy[8 * st + 7]}; \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, wv, acc, 0, 0, 0);                         \
+      }                                                                                             \
+    } else {                                                                                        \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                               \
+        const float xv[4] = {ca[q].x, ca[q].y, ca[q].z, ca[q].w};                                   \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                             \
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[e], wy[4 * q + e], acc, 0, 0, 0);           \
+          if (LN) { s0 += xv[e]; q0 = fmaf(xv[e], xv[e], q0); }                                     \
+        }                                                                                           \
+      }                                                                                             \
+    }                                                                                               \
+  }
+  for (int kc0 = 0; kc0 < kper; kc0 += 32 * PF) {
+    SKQ_CHUNK(b0, a0, g0, kc0)
+    if (PF > 1 && kc0 + 32 < kper) SKQ_CHUNK(b1, a1, g1, kc0 + 32)
+  }
+#undef SKQ_CHUNK
+#undef SKQ_REQUEST
+  request_epilogue();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][acc_row(r, lane) * 33 + li] = acc[r];
+  if (LN) {
+    s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);
+    if (lh == 0) { rstat[wave][li][0] = s0; rstat[wave][li][1] = q0; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int ml = min((tid >> 5) + RP * q, 31);
+    const int m = mb + ml;
+    float v = red[0][ml * 33 + ec];
+#pragma unroll
+    for (int w2 = 1; w2 < NW; ++w2) v += red[w2][ml * 33 + ec];
+    if (LN) {
+      float sum = rstat[0][ml][0], sq = rstat[0][ml][1];
+#pragma unroll
+      for (int w2 = 1; w2 < NW; ++w2) { sum += rstat[w2][ml][0]; sq += rstat[w2][ml][1]; }
+      const float mean = sum / (float)g.K;
+      const float var = fmaxf(sq / (float)g.K - mean * mean, 0.f);
+      const float rstd = 1.f / sqrtf(var + 1e-5f);
+      v = rstd * (v - mean * e_s) + e_c;
+    } else {
+      v += e_c;
+    }
+    if (GELU) v = gelu_erf(v);
+    if (RES) v += e_res[q];
+    if (tid < ET && m < g.M && n0 + (tid & 31) < g.N) {
+      if (second && g.c2_half) (reinterpret_cast<_Float16*>(g.C2) + coff - g.n_split)[(long)m * ldc + enn] = (_Float16)v;
+      else C[(long)m * ldc + enn] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Vocabulary projection of a decode step with <= 64 clips: logits[64][V] = x[64][K] . E[V][K]^T, V ~ 51 865, K = 128 KCH.
 // The skinny kernel above spends a workgroup's life on one 32-column tile (request, wait, 96 MFMAs, reduce): 1621
 // short-lived workgroups, 62 us for 80 MB.  Here 256 persistent workgroups (one per CU) keep their share of x in registers for
@@ -1190,6 +1412,65 @@ hipError_t sk_dispatch(int kind, dim3 grid, const GemmArgs& g, hipStream_t s) {
     case 5: return sk_launch<true, false, true, NW>(grid, g, s);
     case 6: return sk_launch<true, true, false, NW>(grid, g, s);
     default: return sk_launch<true, true, true, NW>(grid, g, s);
+  }
+}
+template <int TT, bool LN, bool GELU, bool RES, int NW, bool WH>
+hipError_t skq_launch(dim3 grid, const GemmArgs& g, hipStream_t s) {
+  constexpr size_t smem = NW * (SK_WAVE_LDS + 64) * sizeof(float);
+  if (smem > 64 * 1024) {
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_q_kernel<TT, LN, GELU, RES, NW, WH>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) return e;
+      done.fetch_or(bit, std::memory_order_release);
+    }
+  }
+  hipLaunchKernelGGL((gemm_skinny_q_kernel<TT, LN, GELU, RES, NW, WH>), grid, dim3(64 * NW), smem, s, g);
+  return hipGetLastError();
+}
+// the three forms a decode step uses: LayerNorm-folded (q | k | v, cross q), LayerNorm-folded + GELU (MLP first product),
+// plain f16 + residual (attention outputs, MLP second product)
+template <int TT, int NW>
+hipError_t skq_kind(int kind, bool wh, dim3 grid, const GemmArgs& g, hipStream_t s) {
+  if (wh) return kind == 1 ? skq_launch<TT, false, false, true, NW, true>(grid, g, s) : hipErrorInvalidValue;
+  if (kind == 4) return skq_launch<TT, true, false, false, NW, false>(grid, g, s);
+  if (kind == 6) return skq_launch<TT, true, true, false, NW, false>(grid, g, s);
+  return hipErrorInvalidValue;
+}
+template <int TT>
+hipError_t skq_nw(int nw, int kind, bool wh, dim3 grid, const GemmArgs& g, hipStream_t s) {
+  switch (nw) {
+    case 16: return skq_kind<TT, 16>(kind, wh, grid, g, s);
+    case 12: return skq_kind<TT, 12>(kind, wh, grid, g, s);
+    case 8: return skq_kind<TT, 8>(kind, wh, grid, g, s);
+    default: return skq_kind<TT, 4>(kind, wh, grid, g, s);
+  }
+}
+// true when the resident-weight skinny kernel has a form for this product (the caller de-quantises into its scratch
+// slot and takes the dense kernel otherwise)
+bool skinny_q_supported(const GemmArgs& g, int batch) {
+  if (!(batch == 1 && g.M <= SKINNY_MAX_M && g.K % 128 == 0 && !g.rowtab && !g.tiled)) return false;
+  const int kind = (g.ln_s ? 4 : 0) | (g.gelu ? 2 : 0) | (g.residual ? 1 : 0);
+  return g.w_half ? kind == 1 : (kind == 4 || kind == 6);
+}
+hipError_t gemm_skinny_q(const GemmArgs& g, hipStream_t s) {
+  const dim3 grid((g.N + 31) / 32, (g.M + 31) / 32);
+  const int kind = (g.ln_s ? 4 : 0) | (g.gelu ? 2 : 0) | (g.residual ? 1 : 0);
+  int nw = 4;
+  if (g.M <= 64) nw = g.K % 512 == 0 ? 16 : g.K % 384 == 0 ? 12 : g.K % 256 == 0 ? 8 : 4;
+  else if (kind == 1 && g.K >= 1024 && g.K % 512 == 0) nw = 16;
+  switch (g.wq_type) {
+    case QT_Q4_0: return skq_nw<QT_Q4_0>(nw, kind, g.w_half != 0, grid, g, s);
+    case QT_Q4_1: return skq_nw<QT_Q4_1>(nw, kind, g.w_half != 0, grid, g, s);
+    case QT_Q5_0: return skq_nw<QT_Q5_0>(nw, kind, g.w_half != 0, grid, g, s);
+    case QT_Q5_1: return skq_nw<QT_Q5_1>(nw, kind, g.w_half != 0, grid, g, s);
+    case QT_Q8_0: return skq_nw<QT_Q8_0>(nw, kind, g.w_half != 0, grid, g, s);
+    default: return hipErrorInvalidValue;
   }
 }
 hipError_t gemm_f32_nt(const GemmArgs& g, int batch, hipStream_t s) {
