@@ -415,7 +415,12 @@ def test_long_run_no_drift(oracle, weights0, staged):
         ro, rv = oracle.OracleDenoiseState(weights0).process(x[:, b])
         peak = max(np.abs(ro).max(), 1.0)
         tail_err = np.abs(out[900:, b] - ro[900:]).max() / peak
-        assert tail_err <= 1e-4, (b, tail_err)
+        if tail_err > 1e-4:      # where did it leave the oracle?  (one un-reproduced failure of the staged form in round 3)
+            e = np.abs(out[:, b] - ro).max(axis=1) / peak
+            bad = np.flatnonzero(e > 1e-4)
+            pytest.fail(f"stream {b} ({'staged' if staged else 'fused'}): tail error {tail_err:.3e}; first frame above 1e-4: "
+                        f"{bad[0] if bad.size else -1} of {T}, {bad.size} frames above it, worst {e.max():.3e} at frame {int(e.argmax())}; "
+                        f"vad error there {abs(float(vad[int(e.argmax()), b] - rv[int(e.argmax())])):.2e}")
         assert np.abs(vad[900:, b] - rv[900:]).max() < 1e-4
 
 
