@@ -1149,9 +1149,49 @@ __device__ __forceinline__ Cand wave_best(Cand c) {
 // offset, so every read is one ds_read_b32 with an immediate offset (64 m); the NL (or 2 NL) accumulation chains
 // and their DPP reductions are independent, which is what hides the LDS and cross-lane latencies -- the loops
 // these replace did one dependent wave reduction per lag.
+#ifndef RN_BATCHED_SUMS
+#define RN_BATCHED_SUMS 1
+#endif
+#ifndef RN_LAG_PAIRS
+#define RN_LAG_PAIRS 0   // measured, not kept: 88 fewer VALU instructions per frame (171 fewer copies) and 0.9 % SLOWER on the
+                         // same box (tools/ab_time.py, gpurun_out/r03l_ab.log): four dependent v_pk_fma_f32 per lag instead
+                         // of eight independent v_fmac -- after round 3's pass the kernel answers to its chains again
+#endif
+typedef float rn_f2 __attribute__((ext_vector_type(2)));
 template <int NL, bool SQ>
 __device__ __forceinline__ void lag_dots(const float* xr, const float* const (&yr)[NL], int lane, float (&sxy)[NL],
                                          float (&syy)[NL]) {
+#if RN_LAG_PAIRS
+  // Two consecutive 64-sample steps of ONE lag per packed instruction: the compiler fetches x[64 m], x[64 (m + 1)] and
+  // y_q[64 m], y_q[64 (m + 1)] with one ds_read2st64_b32 each, i.e. already as register pairs, so (x, x') * (y, y') +
+  // (acc, acc') is a v_pk_fma_f32 with no operand shuffling.  (Pairing two LAGS per instruction instead -- what the
+  // vectoriser made of the scalar loop -- needed one v_mov per product to re-pair the y registers: 186 of them per
+  // frame.)  The last step (j = 448 + lane) exists for lanes < 32 only: its y is zeroed elsewhere instead of a
+  // divergent tail block.  Even- and odd-step partial sums are added at the end.
+  rn_f2 xv[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) xv[m] = rn_f2{xr[WAVE * 2 * m], xr[WAVE * (2 * m + 1)]};
+  const bool tail_ok = lane < 32;
+  xv[3].y = tail_ok ? xv[3].y : 0.f;      // both factors: what lies behind the window is stale LDS, possibly NaN (0 x NaN)
+  rn_f2 axy[NL], ayy[NL];
+#pragma unroll
+  for (int q = 0; q < NL; ++q) { axy[q] = rn_f2{0.f, 0.f}; ayy[q] = rn_f2{0.f, 0.f}; }
+#pragma unroll
+  for (int q = 0; q < NL; ++q) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      rn_f2 y = rn_f2{yr[q][WAVE * 2 * m], yr[q][WAVE * (2 * m + 1)]};
+      if (m == 3) y.y = tail_ok ? y.y : 0.f;
+      axy[q] = __builtin_elementwise_fma(xv[m], y, axy[q]);
+      if (SQ) ayy[q] = __builtin_elementwise_fma(y, y, ayy[q]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NL; ++q) {
+    sxy[q] = axy[q].x + axy[q].y;
+    syy[q] = SQ ? ayy[q].x + ayy[q].y : 0.f;
+  }
+#else
   float xv[8];
 #pragma unroll
   for (int m = 0; m < 7; ++m) xv[m] = xr[WAVE * m];
@@ -1175,10 +1215,8 @@ __device__ __forceinline__ void lag_dots(const float* xr, const float* const (&y
       if (SQ) syy[q] = fmaf(y, y, syy[q]);
     }
   }
-  // all NL (2 NL) totals reduced together: rn_wave_sums.h (four sums for ten VALU instructions instead of 4 x 12)
-#ifndef RN_BATCHED_SUMS
-#define RN_BATCHED_SUMS 1
 #endif
+  // all NL (2 NL) totals reduced together: rn_wave_sums.h (four sums for ten VALU instructions instead of 4 x 12)
 #if RN_BATCHED_SUMS
   wave_sums<NL>(sxy);
   if (SQ) wave_sums<NL>(syy);
