@@ -208,7 +208,8 @@ struct crispy_rn {
   float* d_rnn_bias = nullptr;
   // state
   float* d_hp_mem = nullptr;
-  float* d_synth = nullptr;
+  float* d_synth = nullptr;       // overlap-add tails [B][480]: the current ones
+  float* d_synth_alt = nullptr;   // ... and where the synthesis kernel of the staged pipeline writes the next ones (swapped per launch)
   float* d_ceps = nullptr;
   float* d_lastg = nullptr;
   float* d_rnn = nullptr;
@@ -260,7 +261,7 @@ void free_all(crispy_rn* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  void* ptrs[] = {h->d_xspec, h->d_feat, h->d_silent, h->d_rec, h->d_graw, h->d_gsm, h->d_vadbuf, h->d_frags, h->d_rnn_bias, h->d_tab, h->d_wpack, h->d_hp_mem, h->d_synth, h->d_ceps, h->d_lastg, h->d_rnn,
+  void* ptrs[] = {h->d_xspec, h->d_feat, h->d_silent, h->d_rec, h->d_graw, h->d_gsm, h->d_vadbuf, h->d_frags, h->d_rnn_bias, h->d_tab, h->d_wpack, h->d_hp_mem, h->d_synth, h->d_synth_alt, h->d_ceps, h->d_lastg, h->d_rnn,
                   h->d_last_gain, h->d_last_period, h->d_memid, h->d_xhp, h->d_pspec, h->d_dbg, h->d_stage_in,
                   h->d_stage_out, h->d_stage_vad};
   for (void* p : ptrs)
@@ -461,6 +462,7 @@ int crispy_rn_create(const int8_t* weights, size_t nbytes, int n_streams, int de
     HIP_TRY(hipMalloc(&h->d_wpack, sizeof(uint32_t) * RnPack8::END));
     HIP_TRY(hipMalloc(&h->d_hp_mem, B * 2 * sizeof(float)));
     HIP_TRY(hipMalloc(&h->d_synth, B * 480 * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_synth_alt, B * 480 * sizeof(float)));
     HIP_TRY(hipMalloc(&h->d_ceps, B * 176 * sizeof(float)));
     HIP_TRY(hipMalloc(&h->d_lastg, B * RN_NB * sizeof(float)));
     HIP_TRY(hipMalloc(&h->d_rnn, B * 168 * sizeof(float)));
@@ -671,8 +673,17 @@ int process_device_impl(crispy_rn* h, const float* d_in, float* d_out, float* d_
         ra.frags = h->d_frags; ra.bias = h->d_rnn_bias;
         ra.tansig = reinterpret_cast<const float*>(reinterpret_cast<const char*>(h->d_tab) + offsetof(RnTables, tansig));
         HIP_TRY(rn_launch_rnn(ra, s));
+        // The first frame group of a stream reads the overlap-add tail the previous launch left, the last group writes
+        // the next one -- into the OTHER buffer: the groups of a launch are separate workgroups on different XCDs, and
+        // nothing orders the read of group 0 before the write of the last group (an XCD that is late dispatching its
+        // share of the grid -- the high-pass kernel of the helper stream is on another hardware queue -- let a 3-frame
+        // last group finish before group 0 had started: first frame of a sub-chunk wrong, in ~1 process out of 2).
+        sa.synth = h->d_synth;
+        sa.synth_out = h->d_synth_alt;
         HIP_TRY(rn_launch_synthesis(sa, s));
+        std::swap(h->d_synth, h->d_synth_alt);
       } else {
+        sa.synth = sa.synth_out = h->d_synth;
         HIP_TRY(rn_launch_frames(sa, s));
       }
       if (e) HIP_TRY(hipEventRecord(e[2 + 2 * i], s));

@@ -110,7 +110,8 @@ struct RnArgs {
   float* vadbuf;        // [T][B]
   // persistent per-stream state (HBM)
   float* hp_mem;        // [B][2]
-  float* synth;         // [B][480]
+  float* synth;         // [B][480] overlap-add tails, read at the start of a launch
+  float* synth_out;     // [B][480] ... written at its end (== synth except in the synthesis kernel: crispy_api.cpp)
   float* ceps;          // [B][8*22]
   float* lastg;         // [B][22]
   float* rnn;           // [B][168]

@@ -1239,6 +1239,14 @@ __device__ __forceinline__ void lag_dots(const float* xr, const float* const (&y
 // pitch: parity tests) are a separate instantiation: the six
 // `a.dbg && t == a.T - 1` tests kept two more kernel arguments live across the frame loop, where the scalar registers
 // are already spilled into VGPR lanes (v_writelane / v_readlane are VALU instructions).
+#ifndef RN_POISON_LDS
+#define RN_POISON_LDS 0
+#endif
+[[maybe_unused]] __device__ __forceinline__ void rn_poison_lds(uint32_t* p, int words) {
+  for (int i = threadIdx.x; i < words; i += WAVE) p[i] = 0x7fc0dead;
+  __syncthreads();
+}
+
 template <int MODE, bool DBG>
 __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VGPR_CAP void rn_frame_kernel(RnArgs a) {
   __shared__ RnLdsT<MODE> L;
@@ -1279,6 +1287,14 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
   }
 #endif
 
+#if RN_POISON_LDS
+  // Checker build (`make variants` -> libcrispy_hip_poison.so, tests/test_gpu_rnnoise.py): LDS is not cleared between
+  // workgroups, so a read of a word this workgroup has not written yet sees whatever the previous kernel on the CU left
+  // there -- right or wrong depending on the history of the process.  Filling the allocation with NaNs first turns
+  // every such read into a NaN in the output.
+  rn_poison_lds(reinterpret_cast<uint32_t*>(&L), sizeof(L) / 4);
+#endif
+
   // ---- load per-stream state ----
   if constexpr (MODE != 2) {
     for (int i = lane; i < 176; i += WAVE) L.ceps[i] = a.ceps[(long)b * 176 + i];
@@ -1289,7 +1305,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
   // are what pushed the kernel into scratch spills.  The synthesis kernel (low pressure) keeps it in registers.
   float2 synth[4];
   float* synth_g = a.synth + (long)b * 480;
-  constexpr bool TAIL_REGS = MODE == 2 || RN_TAIL_REGS;
+  // The analysis kernel (MODE 1) never touches the tail: no load here, no store at the end.
+  constexpr bool TAIL_REGS = MODE == 2 || (MODE == 0 && RN_TAIL_REGS);
   if constexpr (TAIL_REGS) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -1957,6 +1974,11 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
       continue;
     }
     if constexpr (MODE == 2) {
+#if RN_POISON_LDS
+      // the synthesis kernel carries nothing from frame to frame in LDS (its groups start at arbitrary frames)
+      __syncthreads();
+      rn_poison_lds(reinterpret_cast<uint32_t*>(&L), sizeof(L) / 4);
+#endif
       const long fr = (long)t * a.B + b;
       const float* rc = a.rec + fr * RN_REC_LD;
       for (int i = lane; i < RN_NFREQ; i += WAVE) L.A[i] = a.xspec[fr * 482 + i];
@@ -2250,7 +2272,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
     RN_LANE_RANGE(3);
     // ---- 10. frame_synthesis: inverse FFT, window, overlap-add ----
     real_inv_pre(L.A, w960, lane);
-    if constexpr (!TAIL_REGS) {
+    if constexpr (!TAIL_REGS && MODE != 1) {
       // issued ahead of the inverse FFT, consumed after it
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
@@ -2294,10 +2316,12 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
 
   // ---- store per-stream state (each kernel of the staged pipeline owns its part) ----
   if (TAIL_REGS && (MODE != 2 || t_last == a.T)) {
+    // the synthesis kernel writes the OTHER tail buffer: group 0 of this launch may not have read this one yet
+    float* tail_out = MODE == 2 ? a.synth_out + (long)b * 480 : synth_g;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int n = lane + WAVE * m;
-      if (n < 240) *reinterpret_cast<float2*>(synth_g + 2 * n) = synth[m];
+      if (n < 240) *reinterpret_cast<float2*>(tail_out + 2 * n) = synth[m];
     }
   }
   if constexpr (MODE != 2) {

@@ -113,6 +113,11 @@ __global__ __launch_bounds__(512) void rn_rnn_kernel(RnnArgs a) {
   load_frags<7>(w_dh, frags, RnnPack::F_DH, wave, 6, lane);
   load_frags<3>(w_out, frags, RnnPack::F_OUT, wave, 2, lane);
 
+#if defined(RN_POISON_LDS) && RN_POISON_LDS
+  // checker build (see rn_kernels.hip): NaNs in every word of LDS this workgroup has not written itself
+  for (int i = tid; i < (int)(sizeof(L) / 4); i += 512) reinterpret_cast<uint32_t*>(&L)[i] = 0x7fc0dead;
+  __syncthreads();
+#endif
   // ---- state in, LDS images zeroed ----
   {
     __bf16* z = &L.XD[0][0][0];
