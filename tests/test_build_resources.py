@@ -17,13 +17,28 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = "/opt/rocm/bin/hipcc"
 
 
+def _makefile_flags():
+    """The code-generation flags of the shipped build (crispy_amd/csrc/Makefile: CXXFLAGS), so that what is checked here
+    is the ISA that ships: -O3 -std=c++17 --offload-arch=gfx950 -fno-slp-vectorize ... (-fPIC / -W* dropped)."""
+    text = open(os.path.join(ROOT, "crispy_amd", "csrc", "Makefile")).read()
+    m = re.search(r"^CXXFLAGS \?= (.*)$", text, re.M)
+    assert m, "CXXFLAGS line not found in the Makefile"
+    flags = m.group(1).replace("$(ARCH)", "gfx950").split()
+    flags = [f for f in flags if f != "-fPIC" and not f.startswith("-W")]
+    assert "-O3" in flags and "--offload-arch=gfx950" in flags and "-fno-slp-vectorize" in flags, flags
+    return flags + ["-Wno-unused-function"]
+
+
+CGFLAGS = _makefile_flags()
+
+
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 @pytest.mark.parametrize("extra", [[], ["-DRN_PROFILE"]], ids=["product", "diagnostic"])
 def test_frame_kernel_resource_budget(tmp_path, extra):
     src = os.path.join(ROOT, "crispy_amd", "csrc", "rn_kernels.hip")
     asm = tmp_path / "rn.s"
     out = subprocess.run(
-        [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "--cuda-device-only", "-S",
+        [HIPCC, *CGFLAGS, "--cuda-device-only", "-S",
          "-Rpass-analysis=kernel-resource-usage", *extra, src, "-o", str(asm)],
         capture_output=True, text=True, timeout=600, cwd=os.path.dirname(src))
     assert out.returncode == 0, out.stderr[-2000:]
@@ -70,7 +85,7 @@ def test_mfma_gain_network_kernel_spills_only_in_the_prologue(tmp_path):
     applies: no spill store inside the frame loop."""
     src = os.path.join(ROOT, "crispy_amd", "csrc", "rn_rnn_kernel.hip")
     asm = tmp_path / "rnn.s"
-    out = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function",
+    out = subprocess.run([HIPCC, *CGFLAGS,
                           "--cuda-device-only", "-S", src, "-o", str(asm)],
                          capture_output=True, text=True, timeout=600, cwd=os.path.dirname(src))
     assert out.returncode == 0, out.stderr[-2000:]
@@ -91,7 +106,7 @@ def test_f16_encoder_kernels_run_at_four_waves_per_simd_without_scratch(tmp_path
     sunk below the MFMAs: both cost 2.4x)."""
     src = os.path.join(ROOT, "crispy_amd", "csrc", "whisper_enc_f16.hip")
     asm = tmp_path / "enc.s"
-    out = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S",
+    out = subprocess.run([HIPCC, *CGFLAGS, "--cuda-device-only", "-S",
                           "-Rpass-analysis=kernel-resource-usage", src, "-o", str(asm)],
                          capture_output=True, text=True, timeout=600, cwd=os.path.dirname(src))
     assert out.returncode == 0, out.stderr[-2000:]
@@ -165,7 +180,7 @@ def test_asr_kernels_have_no_scratch_at_all(tmp_path, src_name):
     they request them after the K loop now.  The rule for every ASR kernel file: ScratchSize == 0 and no spilled VGPR."""
     src = os.path.join(ROOT, "crispy_amd", "csrc", src_name)
     asm = tmp_path / "k.s"
-    out = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S",
+    out = subprocess.run([HIPCC, *CGFLAGS, "--cuda-device-only", "-S",
                           "-Rpass-analysis=kernel-resource-usage", src, "-o", str(asm)],
                          capture_output=True, text=True, timeout=900, cwd=os.path.dirname(src))
     assert out.returncode == 0, out.stderr[-2000:]
