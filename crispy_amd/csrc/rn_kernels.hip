@@ -62,6 +62,16 @@ __device__ __forceinline__ float dpp_mov(float v) {
   const int iv = __float_as_int(v);
   return __int_as_float(__builtin_amdgcn_update_dpp(0, iv, CTRL, ROW_MASK, 0xf, false));
 }
+// v + (v of the permuted lane) as ONE v_add_f32_dpp: the DPP combiner only folds a v_mov_b32_dpp into its user inside one
+// basic block, and the compiler likes to sink the add into a following `if (lane ...) store` -- then the move, its
+// zero-initialised destination and the add are three instructions.  Pinning the sum (an empty asm that "uses" it) keeps
+// the add where the move is.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  float r = v + dpp_mov<CTRL>(v);
+  asm volatile("" : "+v"(r));
+  return r;
+}
 // sum over the 64 lanes, result uniform (read from lane 63 into an SGPR)
 __device__ __forceinline__ float wave_sum(float v) {
   v += dpp_mov<0xB1>(v);        // quad_perm [1,0,3,2]
@@ -437,8 +447,8 @@ __device__ __forceinline__ void band_pairs(const float2* S, const float2* Xc, fl
       float e1 = sv.z * sv.z; e1 += sv.w * sv.w;
       float lo = (1.f - f.x) * e0 + (1.f - f.y) * e1;
       float hi = f.x * e0 + f.y * e1;
-      lo += dpp_mov<0xB1>(lo);
-      hi += dpp_mov<0xB1>(hi);
+      lo = dpp_add<0xB1>(lo);
+      hi = dpp_add<0xB1>(hi);
       if ((lane & 1) == 0) { part[pidx >> 1] = lo; part[100 + (pidx >> 1)] = hi; }
       if (CORR) {
         const float4 xv = *reinterpret_cast<const float4*>(Xc + 2 * pidx);
@@ -446,8 +456,8 @@ __device__ __forceinline__ void band_pairs(const float2* S, const float2* Xc, fl
         float c1 = xv.z * sv.z; c1 += xv.w * sv.w;
         float l2 = (1.f - f.x) * c0 + (1.f - f.y) * c1;
         float h2 = f.x * c0 + f.y * c1;
-        clo[m] = l2 + dpp_mov<0xB1>(l2);
-        chi[m] = h2 + dpp_mov<0xB1>(h2);
+        clo[m] = dpp_add<0xB1>(l2);
+        chi[m] = dpp_add<0xB1>(h2);
         if (park) *reinterpret_cast<float4*>(park + 2 * pidx) = sv;
       }
     }
@@ -757,6 +767,9 @@ __device__ __forceinline__ float dot_m(__amdgpu_buffer_rsrc_t rs, int w_off, int
 // sum_t 256^t 2^-s (float)D_t is the dot product to 2^-30 of the largest activation -- finer than the rounding of an
 // f32 accumulation of the same length.  The input part and the recurrent part of a GRU row have different scales,
 // so the accumulators are folded into the float result where the k loop crosses from one to the other.
+#ifndef RN_ACC_CONST0
+#define RN_ACC_CONST0 1
+#endif
 typedef int rn_i4 __attribute__((ext_vector_type(4)));
 constexpr int RN_IMG8_LD = 144;   // bytes per digit image (K <= 128), +16: the four 16-byte reads hit distinct banks
 // Wave maximum of NON-NEGATIVE floats (magnitudes), as a maximum of their bit patterns: for values >= 0 the unsigned
@@ -766,7 +779,9 @@ constexpr int RN_IMG8_LD = 144;   // bytes per digit image (K <= 128), +16: the 
 __device__ __forceinline__ float wave_max(float v) {
   unsigned u = __float_as_uint(v);
   auto dm = [](unsigned x, auto ctrl) {
-    return (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, decltype(ctrl)::value, 0xf, 0xf, false);
+    // old = 0 with all rows and banks enabled: the combiner folds move + maximum into one v_max_u32_dpp (with old = x
+    // it cannot -- x is not the identity of the operation -- and each step was a copy, a DPP move and the maximum)
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, decltype(ctrl)::value, 0xf, 0xf, false);
   };
   u = max(u, dm(u, std::integral_constant<int, 0xB1>{}));
   u = max(u, dm(u, std::integral_constant<int, 0x4E>{}));
@@ -882,10 +897,14 @@ __device__ __forceinline__ void dotn_i(__amdgpu_buffer_rsrc_t rs, int w_off, int
       if (k < K16) {
         if (k + 1 < K16) xn = k + 1 < MK16 ? xa4[k + 1] : xb4[k + 1 - MK16];
         if (MK16 > 0 && NK16 > 0 && k == MK16) fold(sa);
+        // (not in front of the first block of a chain: its accumulators are still the constant 0, which the MFMA takes
+        // as an inline operand -- laundering them there made the compiler zero 4 registers per accumulator first)
+        if (RN_ACC_CONST0 == 0 || !(k == 0 || (MK16 > 0 && NK16 > 0 && k == MK16))) {
 #pragma unroll
-        for (int r = 0; r < NR; ++r)
+          for (int r = 0; r < NR; ++r)
 #pragma unroll
-          for (int c = 0; c < NC; ++c) asm volatile("" : "+v"(a4[r][c]));
+            for (int c = 0; c < NC; ++c) asm volatile("" : "+v"(a4[r][c]));
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -2196,8 +2215,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
             float e1 = x.z * x.z; e1 += x.w * x.w;
             float lo = (1.f - fq[m].x) * e0 + (1.f - fq[m].y) * e1;
             float hi = fq[m].x * e0 + fq[m].y * e1;
-            lo += dpp_mov<0xB1>(lo);        // the other pair of this 4-bin chunk sits in the neighbouring lane
-            hi += dpp_mov<0xB1>(hi);
+            lo = dpp_add<0xB1>(lo);        // the other pair of this 4-bin chunk sits in the neighbouring lane
+            hi = dpp_add<0xB1>(hi);
             if ((lane & 1) == 0) { part[pidx >> 1] = lo; part_hi[pidx >> 1] = hi; }
           }
         }
