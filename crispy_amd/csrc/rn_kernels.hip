@@ -37,6 +37,11 @@ constexpr int RN_SYNTH_GROUP = 5;   // frames per synthesis workgroup (plus one 
 #define RN_PROF_DECL long long tprev_ = clock64(); \
   float* profp_ = (DBG && a.dbg) ? a.dbg + (long)blockIdx.x * RN_DBG_FLOATS + 3824 : nullptr;
 #define STAMP(k) { const long long tn_ = clock64(); if (profp_ && threadIdx.x == 0) profp_[k] += (float)(tn_ - tprev_); tprev_ = tn_; }
+#elif defined(RN_STOP_AFTER)
+// Diagnostic builds (tools/lds_by_stage.sh): the frame ends at stamp RN_STOP_AFTER, so that the difference of a hardware
+// counter between two such builds is what one stage contributes.  Results are meaningless; never shipped.
+#define RN_PROF_DECL
+#define STAMP(k) { if ((k) == RN_STOP_AFTER) { __syncthreads(); continue; } }
 #else
 #define RN_PROF_DECL
 #define STAMP(k)
