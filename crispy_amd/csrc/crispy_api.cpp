@@ -38,10 +38,31 @@ constexpr int kSubFrames = RN_SUB_FRAMES;
 // Frames of sub-chunk `index` of a segment with `remaining` frames left.  The high-pass recurrence of the first
 // sub-chunk cannot overlap anything (the previous call still reads xhp), so the segment starts with a short
 // sub-chunk and ramps up: the high-pass runs ~2.9x faster per frame than the frame kernel, so every next sub-chunk
-// (<= 2.7x the previous one) is filtered while the previous one is being processed.  3, 8, 12, 12, ...
+// (<= 2.7x the previous one) is filtered while the previous one is being processed.  3, 8, 12, 12, ... (rounds 1 - 2)
+// Round 3: beside the frame kernel the high-pass manages ~38 us per frame against the frame kernel's ~57, not the 2.9x it
+// has alone, so a sub-chunk may be at most ~1.5x its predecessor: behind 3, 8 the frame kernels of sub-chunks 1 and 2
+// waited 107 + 55 us for their input (tools/step_timeline.py).  CRISPY_RN_RAMP="3,4,6,9" overrides the ramp 3, 4, 5, 7, 10 (developer
+// knob; entries above the sub-chunk size are clipped).
+inline const std::vector<int>& ramp_frames() {
+  static const std::vector<int> ramp = [] {
+    std::vector<int> r;
+    if (const char* env = std::getenv("CRISPY_RN_RAMP")) {
+      for (const char* p = env; *p;) {
+        char* end = nullptr;
+        const long v = std::strtol(p, &end, 10);
+        if (end == p) break;
+        if (v > 0) r.push_back(v > kSubFrames ? kSubFrames : (int)v);
+        p = *end ? end + 1 : end;
+      }
+    }
+    if (r.empty()) r = {3, 4, 5, 7, 10};
+    return r;
+  }();
+  return ramp;
+}
 inline int sub_frames(int index, int remaining) {
-  static const int ramp[2] = {3, 8};
-  const int want = index < 2 ? ramp[index] : kSubFrames;
+  const std::vector<int>& ramp = ramp_frames();
+  const int want = index < (int)ramp.size() ? ramp[index] : kSubFrames;
   return remaining < want ? remaining : want;
 }
 inline int count_subs(int T) {
@@ -858,6 +879,7 @@ int crispy_rn_last_kernel_ms(crispy_rn* h, float* frame_kernel_ms, float* total_
   HIP_TRY(hipSetDevice(h->device));
   float fk = 0.f, tot = 0.f;
   size_t i = 0;
+  const bool timeline = std::getenv("CRISPY_RN_TIMELINE") != nullptr;   // developer aid: where a step's time goes (stderr)
   for (int n_sub : h->seg_subs) {
     const size_t last = i + 1 + 2 * (size_t)n_sub;
     HIP_TRY(hipEventSynchronize(h->ev[last]));
@@ -865,6 +887,12 @@ int crispy_rn_last_kernel_ms(crispy_rn* h, float* frame_kernel_ms, float* total_
     for (int k = 0; k < n_sub; ++k) {
       HIP_TRY(hipEventElapsedTime(&ms, h->ev[i + 1 + 2 * k], h->ev[i + 2 + 2 * k]));
       fk += ms;
+      if (timeline) {
+        float t0 = 0.f, gap = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t0, h->ev[i], h->ev[i + 1 + 2 * k]));
+        HIP_TRY(hipEventElapsedTime(&gap, h->ev[i + 2 * k], h->ev[i + 1 + 2 * k]));   // since the previous frame kernel ended (k = 0: since the segment began)
+        std::fprintf(stderr, "[rn timeline] sub-chunk %d: starts at %.3f ms (%.3f ms after the previous one ended), frame kernel %.3f ms\n", k, t0, gap, ms);
+      }
     }
     HIP_TRY(hipEventElapsedTime(&ms, h->ev[i], h->ev[last]));
     tot += ms;

@@ -413,7 +413,7 @@ def test_no_kernel_reads_lds_it_has_not_written(oracle, weights0, staged):
     from crispy_amd import synth_audio as SA
     from crispy_amd.denoise import DenoiseState
     L = N.load_variant("poison")
-    B, T = 9, 41                                       # sub-chunks of 3, 8, 12, 12, 6 frames: groups of 5 + ragged ends
+    B, T = 9, 41                                       # sub-chunks of 3, 4, 5, 7, 10, 12 frames: groups of 5 + ragged ends
     x = SA.batch_np(B, T, first_stream=300) * np.float32(32768.0)
     x[20:, 4] = 0.0                                    # one stream falls silent (the silence path skips most stages)
     ds = DenoiseState(weights0, B, 0, lib=L)

@@ -15,7 +15,7 @@ ks = raw["kernels"]
 fk = ks["rn_frame_kernel"]
 p = {k: round(v, 3) for k, v in fk["per_stream_frame"].items()}
 
-# bench launches 100 frames over 4096 streams as 3 + 8 + 7 x 12 + 5 (10 launches): the average duration of a frame-kernel
+# bench launches 100 frames over 4096 streams as 3 + 4 + 5 + 7 + 10 + 5 x 12 + 11 (11 launches; 3 + 8 + 7 x 12 + 5 = 10 up to r03b): the average duration of a frame-kernel
 # launch and the stream-frames it covers give the VALU issue fraction.
 avg_ns, calls = None, None
 stats = os.path.join(ROOT, "gpurun_out", f"{tag}_kernel_stats.csv")
