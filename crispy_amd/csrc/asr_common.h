@@ -71,6 +71,10 @@ struct GemmArgs {
   const unsigned char* wq[3];
   int wq_type, wq_rows;
   const float* wq_gamma;
+  // Skinny path: the number of rows the K split is chosen for (0: M).  The batched prompt step runs batch x P rows but
+  // must split K exactly as the one-row-per-clip steps of the same batch do, so that every row is bit-identical to the
+  // position-by-position prefill it replaces.
+  int m_hint;
 };
 constexpr int SKINNY_MAX_M = 512;   // decode steps with up to this many clips use the skinny kernel (row blocks of 32)
 hipError_t gemm_f32_nt(const GemmArgs& g, int batch, hipStream_t s);
@@ -110,15 +114,24 @@ hipError_t pack_vocab_f16(const float* E, void* dst, int V, int K, hipStream_t s
 hipError_t vocab_f16(const void* x, long ldx, const void* Ep, float* C, long ldc, int M, int N, int K, hipStream_t s);
 hipError_t layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, long rows, int D, hipStream_t s);
 hipError_t attn_encoder_f32(const float* qkv, float* out, int B, int T, int D, int heads, hipStream_t s);
+// Rows of a decode step: one query row per clip, or -- the batched prompt step -- G consecutive rows per clip (row =
+// clip * G + j, G = AttnRows::group): row b reads the K|V of clip b / G.  key_step = 1: row j sees n_keys_base + j keys
+// (causal self-attention over the positions the step itself writes).  One workgroup per (row, head) either way; the rows
+// of a clip are neighbours in the grid, so the repeats of a clip's cross K|V are served by the L2s / the Infinity Cache.
+// (A variant that walks a clip's rows over K|V registers loaded once needs 96 + ~40 registers at 4 waves per SIMD:
+// 468 bytes of scratch per lane -- not built.)
+struct AttnRows { int group = 1, key_step = 0; };
 hipError_t attn_decoder_f32(const float* q, long ldq, const float* kv, long kv_batch_stride, long ldkv, long head_stride,
                             long koff, long voff, int n_keys_base, const int* pos_dev, float* out, long ldo, int B, int heads,
-                            hipStream_t s);
+                            hipStream_t s, AttnRows rows = AttnRows());
 // the same kernel over an f16 K|V buffer (cross-attention in precision mode 1)
 hipError_t attn_decoder_kv16(const float* q, long ldq, const void* kv, long kv_batch_stride, long ldkv, long head_stride,
                              long koff, long voff, int n_keys_base, const int* pos_dev, float* out, long ldo, int B, int heads,
-                             hipStream_t s, int max_keys = 0);    // max_keys: upper bound of n_keys_base + *pos_dev (0: n_keys_base)
+                             hipStream_t s, int max_keys = 0,     // max_keys: upper bound of n_keys_base + *pos_dev (0: n_keys_base)
+                             AttnRows rows = AttnRows());
+// x[r][:] = tok_emb[tokens[r]] + pos_emb[pos + r % rows_per_clip] for B rows (rows_per_clip > 1: the batched prompt step)
 hipError_t embed_tokens_f32(const int* tokens, const float* tok_emb, const float* pos_emb, int pos, const int* pos_dev,
-                            float* x, int B, int D, hipStream_t s);
+                            float* x, int B, int D, hipStream_t s, int rows_per_clip = 1);
 // 48 -> 16 kHz resampler (rubato FftFixedIn(.., 1024, 1, 1) geometry)
 constexpr int RS_FFT_IN = 1026, RS_FFT_OUT = 342, RS_CHUNK = 1024;
 constexpr int RS_K = 1040;   // 1026 padded to the GEMM's k granularity

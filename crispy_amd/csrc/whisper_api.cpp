@@ -1,6 +1,7 @@
 // whisper_api.cpp -- extern "C" Whisper entry points (include/crispy_hip.h): model container,
 // encoder, greedy decoder.  Replaces transcribe_rs::whisper_cpp::WhisperEngine::{load, transcribe}
 // (reference: src-tauri/src/managers/transcription.rs:138-141, 183-185).
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -928,16 +929,18 @@ int reserve_dec(crispy_asr* h, int batch, int max_tokens) {
   const size_t B = batch, dt = h->hp.n_text_state, L = h->hp.n_text_layer, Tn = h->hp.n_audio_ctx,
                C = h->hp.n_text_ctx, V = h->hp.n_vocab;
   (void)max_tokens;
+  // activation rows: one per clip in a generation step, up to SKINNY_MAX_M in a batched prompt step (prefill)
+  const size_t R = B > (size_t)SKINNY_MAX_M ? B : (size_t)SKINNY_MAX_M;
   HIP_TRY(hipMalloc(&h->d_xkv, L * B * Tn * 2 * dt * sizeof(float)));
   HIP_TRY(hipMalloc(&h->d_selfkv, L * B * C * 2 * dt * sizeof(float)));
-  HIP_TRY(hipMalloc(&h->d_dx, B * dt * sizeof(float)));
-  HIP_TRY(hipMalloc(&h->d_dxn, B * dt * sizeof(float)));
-  HIP_TRY(hipMalloc(&h->d_dq, B * dt * sizeof(float)));
-  HIP_TRY(hipMalloc(&h->d_datt, B * dt * sizeof(float)));
-  HIP_TRY(hipMalloc(&h->d_dh, B * 4 * dt * sizeof(float)));
+  HIP_TRY(hipMalloc(&h->d_dx, R * dt * sizeof(float)));
+  HIP_TRY(hipMalloc(&h->d_dxn, R * dt * sizeof(float)));
+  HIP_TRY(hipMalloc(&h->d_dq, R * dt * sizeof(float)));
+  HIP_TRY(hipMalloc(&h->d_datt, R * dt * sizeof(float)));
+  HIP_TRY(hipMalloc(&h->d_dh, R * 4 * dt * sizeof(float)));
   HIP_TRY(hipMalloc(&h->d_logits, B * V * sizeof(float)));
   HIP_TRY(hipMalloc(&h->d_best, B * C * sizeof(float)));
-  HIP_TRY(hipMalloc(&h->d_tok, B * sizeof(int)));
+  HIP_TRY(hipMalloc(&h->d_tok, R * sizeof(int)));
   HIP_TRY(hipMalloc(&h->d_tokens_all, B * C * sizeof(int)));
   HIP_TRY(hipMalloc(&h->d_counters, 4 * sizeof(int)));      // position, pick index, ticket of the fused pick, spare
   HIP_TRY(hipMalloc(&h->d_ts_state, B * sizeof(TsState)));
@@ -950,22 +953,23 @@ int reserve_dec(crispy_asr* h, int batch, int max_tokens) {
 }
 
 // the last block of a decoder step: final LayerNorm and vocabulary projection of h->d_dx into h->d_logits
-int decoder_logits(crispy_asr* h, int batch, hipStream_t s) {
+int decoder_logits(crispy_asr* h, int batch, hipStream_t s, const float* x = nullptr) {
   const int dt = h->hp.n_text_state, V = h->hp.n_vocab;
+  if (!x) x = h->d_dx;
   const bool fold = batch <= SKINNY_MAX_M && dt % 128 == 0;
   if (h->enc_precision == 1 && h->tok_emb_hp) {
     // the reference's arithmetic: final LayerNorm in f32, rounded to f16, against the f16 embedding, f32 accumulation
-    HIP_TRY(layernorm_f16out(h->d_dx, h->dec_ln_w, h->dec_ln_b, h->d_dxn, batch, dt, s));
+    HIP_TRY(layernorm_f16out(x, h->dec_ln_w, h->dec_ln_b, h->d_dxn, batch, dt, s));
     HIP_TRY(vocab_f16(h->d_dxn, dt, h->tok_emb_hp, h->d_logits, V, batch, V, dt, s));
   } else {
     // vocabulary projection: above 64 clips the 128 x 128 tiled kernel (behind a LayerNorm launch) beats the skinny
     // kernel's 32-row blocks, which re-read the 80 MB embedding once per block (-3 % / -5 % per step at 128 / 512 clips)
     if (fold && batch <= 64) {
-      GemmArgs g = gemm(h->d_dx, dt, h->logit_lw, dt, h->d_logits, V, nullptr, batch, V, dt);
+      GemmArgs g = gemm(x, dt, h->logit_lw, dt, h->d_logits, V, nullptr, batch, V, dt);
       g.ln_s = h->logit_ls; g.ln_c = h->logit_lc;
       HIP_TRY(gemm_f32_nt(g, 1, s));
     } else {
-      HIP_TRY(layernorm_f32(h->d_dx, h->dec_ln_w, h->dec_ln_b, h->d_dxn, batch, dt, s));
+      HIP_TRY(layernorm_f32(x, h->dec_ln_w, h->dec_ln_b, h->d_dxn, batch, dt, s));
       GemmArgs g = gemm(h->d_dxn, dt, h->tok_emb, dt, h->d_logits, V, nullptr, batch, V, dt);
       g.tiled = fold ? 1 : 0;
       HIP_TRY(gemm_f32_nt(g, 1, s));
@@ -978,17 +982,31 @@ int decoder_logits(crispy_asr* h, int batch, hipStream_t s) {
 // dev_pos = false: the position is the host value `pos` (prompt tokens).
 // dev_pos = true : the position is read from h->d_counters[0] by the kernels, so the identical launch
 //                  sequence can be captured once in a hipGraph and replayed for every generated token.
-int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logits, hipStream_t s, bool embedded = false) {
+//
+// P > 1 (prefill only: host position, folded path): the step covers P consecutive positions pos .. pos + P - 1 of every
+// clip at once -- row = clip * P + j, token ids [batch][P] in h->d_tok.  Every row goes through exactly the arithmetic of
+// the one-position step it replaces (same K split: GemmArgs::m_hint; one attention workgroup per (row, head) with the row's
+// own key count), so the result is bit-identical to P steps -- at the cost of one.
+int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logits, hipStream_t s, bool embedded = false,
+                 int P = 1) {
   const int dt = h->hp.n_text_state, H = h->hp.n_text_head, Tn = h->hp.n_audio_ctx, C = h->hp.n_text_ctx;
   const int* pos_dev = dev_pos ? h->d_counters : nullptr;
+  const int clips = batch;
+  if (P < 1) P = 1;
+  batch = clips * P;                   // rows of this step
   // <= SKINNY_MAX_M clips: the projections run on the skinny kernel (row blocks of 32 clips), which folds the preceding LayerNorm in and writes q and
   // k|v of the self-attention block from one launch (17 launches fewer per step on Whisper-tiny)
   const bool fold = batch <= SKINNY_MAX_M && dt % 128 == 0;
+  if (P > 1 && (!fold || dev_pos || embedded))
+    return fail(CRISPY_ERR_INVALID_ARG, "decoder_step: a multi-position step needs the folded path and a host position");
+  AttnRows self_rows, cross_rows;
+  self_rows.group = P; self_rows.key_step = P > 1 ? 1 : 0;
+  cross_rows.group = P;
   if (!embedded) {    // (a fused pick has written the residual stream already)
     if (h->resident)
-      HIP_TRY(embed_tokens_q(h->d_tok, h->q_tok_emb->d, h->q_tok_emb->ttype, h->dec_pos, pos, pos_dev, h->d_dx, batch, dt, s));
+      HIP_TRY(embed_tokens_q(h->d_tok, h->q_tok_emb->d, h->q_tok_emb->ttype, h->dec_pos, pos, pos_dev, h->d_dx, batch, dt, s, P));
     else
-      HIP_TRY(embed_tokens_f32(h->d_tok, h->tok_emb, h->dec_pos, pos, pos_dev, h->d_dx, batch, dt, s));
+      HIP_TRY(embed_tokens_f32(h->d_tok, h->tok_emb, h->dec_pos, pos, pos_dev, h->d_dx, batch, dt, s, P));
   }
   // resident quantised model: every weight operand is de-quantised into the scratch slot in front of its product --
   // f32 x gamma for the LayerNorm-folded projections (fold_ln's W' = W . diag(gamma), element for element), f16 for the
@@ -1006,6 +1024,7 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
   // for (and dense tensors of a mixed file) go through the scratch slot and the dense kernel.
   auto proj = [&](GemmArgs g, const float* dense32, const void* dense16, const QRef& r, const float* gamma, bool half) -> int {
     g.w_half = half ? 1 : 0;
+    g.m_hint = clips;
     if (!h->resident) {
       g.W = half ? reinterpret_cast<const float*>(dense16) : dense32;
       HIP_TRY(gemm_f32_nt(g, 1, s));
@@ -1031,21 +1050,32 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
   };
   for (size_t l = 0; l < h->dec.size(); ++l) {
     const DecLayer& L = h->dec[l];
-    float* selfkv = h->d_selfkv + l * (size_t)batch * C * 2 * dt;
-    const float* xkv = h->d_xkv + l * (size_t)batch * Tn * 2 * dt;
+    float* selfkv = h->d_selfkv + l * (size_t)clips * C * 2 * dt;
+    const float* xkv = h->d_xkv + l * (size_t)clips * Tn * 2 * dt;
     // causal self-attention against the cache; k | v of this position go straight into the cache row (b, pos)
     float* kv_dst = selfkv + (dev_pos ? 0 : (size_t)pos * 2 * dt);
     // mode 1: the self K|V cache is f16, as whisper.cpp's kv_self is (it aliases the f32 cache: every decode call
     // starts with its own prefill); the projection stores halves, the attention requests all its keys up front
     const bool kv16 = fold && h->enc_precision == 1 && h->dec_max_keys > 0 && h->dec_max_keys <= 512;
-    _Float16* selfkv_h = reinterpret_cast<_Float16*>(h->d_selfkv) + l * (size_t)batch * C * 2 * dt;
+    _Float16* selfkv_h = reinterpret_cast<_Float16*>(h->d_selfkv) + l * (size_t)clips * C * 2 * dt;
     if (fold) {
       GemmArgs g = gemm(h->d_dx, dt, nullptr, dt, h->d_dq, dt, nullptr, batch, 3 * dt, dt);
       g.ln_s = L.qkv_ls; g.ln_c = L.qkv_lc;
       g.C2 = kv_dst; g.ldc2 = (long)C * 2 * dt; g.n_split = dt;
       if (kv16) { g.C2 = reinterpret_cast<float*>(selfkv_h + (dev_pos ? 0 : (size_t)pos * 2 * dt)); g.c2_half = 1; }
       if (dev_pos) { g.c_off_dev = h->d_counters; g.c_off_scale = 2L * dt; }
+      // P rows per clip: k | v of row (clip, j) belongs in cache row (clip, pos + j) -- one clip's P rows are adjacent there,
+      // but clips are C rows apart.  One clip: the rows land directly (row stride 2 dt).  Several: staged in the MLP's
+      // hidden buffer (free until fc1) and scattered by one strided copy.
+      const bool stage_kv = P > 1 && clips > 1;
+      if (P > 1) { g.ldc2 = 2L * dt; if (stage_kv) g.C2 = h->d_dh; }
       if ((qrc = proj(g, L.qkv_lw, nullptr, L.r_qkv, L.ln1_w, false)) != CRISPY_OK) return qrc;
+      if (stage_kv) {
+        const size_t esz = kv16 ? 2 : 4;
+        void* dst = kv16 ? static_cast<void*>(selfkv_h + (size_t)pos * 2 * dt) : static_cast<void*>(selfkv + (size_t)pos * 2 * dt);
+        HIP_TRY(hipMemcpy2DAsync(dst, (size_t)C * 2 * dt * esz, h->d_dh, (size_t)P * 2 * dt * esz, (size_t)P * 2 * dt * esz,
+                                 (size_t)clips, hipMemcpyDeviceToDevice, s));
+      }
     } else {
       HIP_TRY(layernorm_f32(h->d_dx, L.ln1_w, L.ln1_b, h->d_dxn, batch, dt, s));
       const float* qkv_w = w32(L.qkv_w, L.r_qkv, nullptr);
@@ -1057,10 +1087,10 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
     }
     if (kv16)
       HIP_TRY(attn_decoder_kv16(h->d_dq, dt, selfkv_h, (long)C * 2 * dt, 2L * dt, 64, 0, dt, dev_pos ? 1 : pos + 1, pos_dev,
-                                h->d_datt, dt, batch, H, s, h->dec_max_keys));
+                                h->d_datt, dt, batch, H, s, h->dec_max_keys, self_rows));
     else
       HIP_TRY(attn_decoder_f32(h->d_dq, dt, selfkv, (long)C * 2 * dt, 2L * dt, 64, 0, dt, dev_pos ? 1 : pos + 1, pos_dev,
-                               h->d_datt, dt, batch, H, s));
+                               h->d_datt, dt, batch, H, s, self_rows));
     // mode 1: the projections that have no LayerNorm in front (attention outputs, the MLP's second GEMM) in ggml's
     // arithmetic -- f16 weights, the f32 activation rounded to f16 on the way into the matrix cores, f32 accumulation
     const bool wh = fold && h->enc_precision == 1 && (L.out_wh || h->resident);
@@ -1081,11 +1111,12 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
       HIP_TRY(gemm_f32_nt(gemm(h->d_dxn, dt, xq_w, dt, h->d_dq, dt, L.xq_b, batch, dt, dt), 1, s));
     }
     if (h->enc_precision == 1)
-      HIP_TRY(attn_decoder_kv16(h->d_dq, dt, reinterpret_cast<const char*>(h->d_xkv_h) + l * (size_t)batch * Tn * 2 * dt * 2,
-                                (long)Tn * 2 * dt, 64, 64L * Tn, 0, (long)Tn * dt, Tn, nullptr, h->d_datt, dt, batch, H, s));
+      HIP_TRY(attn_decoder_kv16(h->d_dq, dt, reinterpret_cast<const char*>(h->d_xkv_h) + l * (size_t)clips * Tn * 2 * dt * 2,
+                                (long)Tn * 2 * dt, 64, 64L * Tn, 0, (long)Tn * dt, Tn, nullptr, h->d_datt, dt, batch, H, s, 0,
+                                cross_rows));
     else
       HIP_TRY(attn_decoder_f32(h->d_dq, dt, xkv, (long)Tn * 2 * dt, 64, 64L * Tn, 0, (long)Tn * dt, Tn, nullptr, h->d_datt, dt,
-                               batch, H, s));
+                               batch, H, s, cross_rows));
     {
       GemmArgs g = gemm(h->d_datt, dt, L.xout_w, dt, h->d_dx, dt, L.xout_b, batch, dt, dt);
       g.residual = h->d_dx; g.ldr = dt;
@@ -1110,7 +1141,13 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
       if ((qrc = proj(g, L.fc2_w, L.fc2_wh, L.r_fc2, nullptr, wh)) != CRISPY_OK) return qrc;
     }
   }
-  if (want_logits) return decoder_logits(h, batch, s);
+  if (want_logits) {
+    if (P == 1) return decoder_logits(h, clips, s);
+    // the logits of a prompt step are those of its LAST position: gather row (clip, P - 1) of every clip
+    HIP_TRY(hipMemcpy2DAsync(h->d_dq, (size_t)dt * 4, h->d_dx + (size_t)(P - 1) * dt, (size_t)P * dt * 4, (size_t)dt * 4,
+                             (size_t)clips, hipMemcpyDeviceToDevice, s));
+    return decoder_logits(h, clips, s, h->d_dq);
+  }
   return CRISPY_OK;
 }
 
@@ -1185,20 +1222,32 @@ int prefill(crispy_asr* h, const float* d_enc, int batch, const int* prompt, int
     const int rc = compute_cross_kv(h, d_enc, batch, s);
     if (rc != CRISPY_OK) return rc;
   }
-  std::vector<int> tok(batch);
+  if (lang_tokens && n_prompt > 1)
+    for (int b = 0; b < batch; ++b)
+      if (lang_tokens[b] < 0 || lang_tokens[b] >= h->hp.n_vocab)
+        return fail(CRISPY_ERR_INVALID_ARG, "decode: language token %d out of range", lang_tokens[b]);
+  // The prompt runs as multi-position steps: P positions of every clip per step (decoder_step, P > 1), as many as the
+  // skinny kernels' row range allows -- batch x P <= SKINNY_MAX_M, so a 4-token prompt of up to 128 clips is ONE step
+  // instead of four, and a long prompt (previous-text conditioning: up to 228 tokens of one clip) takes one step per
+  // 512 / batch positions.  Bit-identical to the position-by-position prefill (CRISPY_ASR_PREFILL=seq keeps that one
+  // available for the A/B test).
+  const char* pf_env = std::getenv("CRISPY_ASR_PREFILL");      // read per call: the A/B test flips it inside one process
+  const bool seq = pf_env && std::strcmp(pf_env, "seq") == 0;
+  const bool fold = batch <= SKINNY_MAX_M && h->hp.n_text_state % 128 == 0;
+  const int p_max = (!fold || seq) ? 1 : std::max(1, SKINNY_MAX_M / batch);
+  std::vector<int> tok;
   int pos = 0;
-  for (int i = 0; i < n_prompt; ++i, ++pos) {
-    std::fill(tok.begin(), tok.end(), prompt[i]);
-    if (i == 1 && lang_tokens)      // per-clip language token (auto-detected or caller supplied)
-      for (int b = 0; b < batch; ++b) {
-        if (lang_tokens[b] < 0 || lang_tokens[b] >= h->hp.n_vocab)
-          return fail(CRISPY_ERR_INVALID_ARG, "decode: language token %d out of range", lang_tokens[b]);
-        tok[b] = lang_tokens[b];
-      }
-    HIP_TRY(hipMemcpyAsync(h->d_tok, tok.data(), sizeof(int) * batch, hipMemcpyHostToDevice, s));
+  while (pos < n_prompt) {
+    const int P = std::min(p_max, n_prompt - pos);
+    tok.resize((size_t)batch * P);
+    for (int b = 0; b < batch; ++b)
+      for (int j = 0; j < P; ++j)
+        tok[(size_t)b * P + j] = (pos + j == 1 && lang_tokens) ? lang_tokens[b] : prompt[pos + j];   // per-clip language token
+    HIP_TRY(hipMemcpyAsync(h->d_tok, tok.data(), sizeof(int) * tok.size(), hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));  // tok is reused by the next iteration
-    const int rc = decoder_step(h, batch, pos, false, i == n_prompt - 1, s);
+    const int rc = decoder_step(h, batch, pos, false, pos + P == n_prompt, s, false, P);
     if (rc != CRISPY_OK) return rc;
+    pos += P;
   }
   *pos_out = pos;
   return CRISPY_OK;

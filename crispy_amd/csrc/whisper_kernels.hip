@@ -897,18 +897,21 @@ template <class KV>
 __global__ __launch_bounds__(64 * AD_WAVES) void attn_dec_kernel(const float* __restrict__ q, long ldq,
                                                        const KV* __restrict__ kv, long kv_batch_stride,
                                                        long ldkv, long head_stride, long koff, long voff, int n_keys_base,
-                                                       const int* __restrict__ pos_dev, float* __restrict__ out, long ldo) {
+                                                       const int* __restrict__ pos_dev, float* __restrict__ out, long ldo,
+                                                       AttnRows rows) {
   __shared__ float p_s[1536];
   __shared__ __attribute__((aligned(16))) float q_s[64];
   __shared__ __attribute__((aligned(16))) float part_o[AD_WAVES][64];
   __shared__ float part_m[AD_WAVES], part_l[AD_WAVES];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int h = blockIdx.x, b = blockIdx.y;
-  const int n_keys = n_keys_base + (pos_dev ? *pos_dev : 0);
+  // rows.group query rows per clip (asr_common.h: AttnRows): row b belongs to clip b / group and reads that clip's K|V
+  const int clip = b / rows.group;
+  const int n_keys = n_keys_base + (pos_dev ? *pos_dev : 0) + rows.key_step * (b % rows.group);
   if (tid < 64) q_s[tid] = q[(long)b * ldq + h * 64 + tid] * 0.125f;
   __syncthreads();
-  const KV* Kb = kv + (long)b * kv_batch_stride + koff + h * head_stride;
-  const KV* Vb = kv + (long)b * kv_batch_stride + voff + h * head_stride;
+  const KV* Kb = kv + (long)clip * kv_batch_stride + koff + h * head_stride;
+  const KV* Vb = kv + (long)clip * kv_batch_stride + voff + h * head_stride;
   const int per = (n_keys + AD_WAVES - 1) / AD_WAVES;
   const int k_lo = wave * per, k_hi = min(n_keys, k_lo + per);
   // scores: 16 lanes share one key row (coalesced 256-byte reads, 4 keys per wave instruction), the
@@ -1035,16 +1038,20 @@ template <int ADX_SLOTS>
 __global__ __launch_bounds__(64 * AD_WAVES) void attn_dec_x16_kernel(const float* __restrict__ q, long ldq,
                                                        const _Float16* __restrict__ kv, long kv_batch_stride,
                                                        long ldkv, long head_stride, long koff, long voff, int n_keys_base,
-                                                       const int* __restrict__ pos_dev, float* __restrict__ out, long ldo) {
-  const int n_keys = n_keys_base + (pos_dev ? *pos_dev : 0);
+                                                       const int* __restrict__ pos_dev, float* __restrict__ out, long ldo,
+                                                       AttnRows rows) {
+  // rows.group query rows per clip (asr_common.h: AttnRows): row b belongs to clip b / group and reads that clip's K|V
+  const int b = blockIdx.y;
+  const int clip = b / rows.group;
+  const int n_keys = n_keys_base + (pos_dev ? *pos_dev : 0) + rows.key_step * (b % rows.group);
   typedef _Float16 half8 __attribute__((ext_vector_type(8)));
   __shared__ __attribute__((aligned(16))) float part_o[AD_WAVES][64];
   __shared__ float part_m[AD_WAVES], part_l[AD_WAVES];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int h = blockIdx.x, b = blockIdx.y;
+  const int h = blockIdx.x;
   const int c = lane & 7, r = lane >> 3;
-  const _Float16* Kb = kv + (long)b * kv_batch_stride + koff + h * head_stride + 8 * c;
-  const _Float16* Vb = kv + (long)b * kv_batch_stride + voff + h * head_stride + 8 * c;
+  const _Float16* Kb = kv + (long)clip * kv_batch_stride + koff + h * head_stride + 8 * c;
+  const _Float16* Vb = kv + (long)clip * kv_batch_stride + voff + h * head_stride + 8 * c;
   const int per = (n_keys + AD_WAVES - 1) / AD_WAVES;
   const int k_lo = wave * per, k_hi = min(n_keys, k_lo + per);
   const int k_last = max(k_hi - 1, 0);          // clamp target of the slots past the partition (weight 0)
@@ -1118,10 +1125,11 @@ __global__ __launch_bounds__(64 * AD_WAVES) void attn_dec_x16_kernel(const float
 // token + positional embedding for one decode step: x[b][:] = tok_emb[token[b]] + pos_emb[pos]
 __global__ __launch_bounds__(256) void embed_kernel(const int* __restrict__ tokens, const float* __restrict__ tok_emb,
                                                     const float* __restrict__ pos_emb, int pos,
-                                                    const int* __restrict__ pos_dev, float* __restrict__ x, int D) {
+                                                    const int* __restrict__ pos_dev, float* __restrict__ x, int D, int rpc) {
   const int b = blockIdx.x;
   const int tok = tokens[b];
   if (pos_dev) pos = *pos_dev;
+  pos += b % rpc;                       // rpc rows per clip (the batched prompt step): consecutive positions
   for (int c = threadIdx.x; c < D; c += 256) x[(long)b * D + c] = tok_emb[(long)tok * D + c] + pos_emb[(long)pos * D + c];
 }
 
@@ -1462,7 +1470,8 @@ hipError_t gemm_skinny_q(const GemmArgs& g, hipStream_t s) {
   const dim3 grid((g.N + 31) / 32, (g.M + 31) / 32);
   const int kind = (g.ln_s ? 4 : 0) | (g.gelu ? 2 : 0) | (g.residual ? 1 : 0);
   int nw = 4;
-  if (g.M <= 64) nw = g.K % 512 == 0 ? 16 : g.K % 384 == 0 ? 12 : g.K % 256 == 0 ? 8 : 4;
+  const int m_nw = g.m_hint > 0 ? g.m_hint : g.M;
+  if (m_nw <= 64) nw = g.K % 512 == 0 ? 16 : g.K % 384 == 0 ? 12 : g.K % 256 == 0 ? 8 : 4;
   else if (kind == 1 && g.K >= 1024 && g.K % 512 == 0) nw = 16;
   switch (g.wq_type) {
     case QT_Q4_0: return skq_nw<QT_Q4_0>(nw, kind, g.w_half != 0, grid, g, s);
@@ -1489,7 +1498,8 @@ hipError_t gemm_f32_nt(const GemmArgs& g, int batch, hipStream_t s) {
     // 48 to 160).  Above that the chip is full and the extra partial tiles are only LDS traffic: 4 waves, except for
     // the MLP's second GEMM (K = 4 d).
     int nw = 4;
-    if (g.M <= 64) nw = g.K % 512 == 0 ? 16 : g.K % 384 == 0 ? 12 : g.K % 256 == 0 ? 8 : 4;
+    const int m_nw = g.m_hint > 0 ? g.m_hint : g.M;      // (the batched prompt step splits K as the one-row steps of its batch do)
+    if (m_nw <= 64) nw = g.K % 512 == 0 ? 16 : g.K % 384 == 0 ? 12 : g.K % 256 == 0 ? 8 : 4;
     else if (kind == 1 && g.K >= 1024 && g.K % 512 == 0) nw = 16;
     if (g.w_half) {                          // precision mode 1: f16 weight copy, residual projections only
       if (kind != 1) return hipErrorInvalidValue;
@@ -1531,19 +1541,21 @@ hipError_t attn_encoder_f32(const float* qkv, float* out, int B, int T, int D, i
 }
 hipError_t attn_decoder_f32(const float* q, long ldq, const float* kv, long kv_batch_stride, long ldkv, long head_stride,
                             long koff, long voff, int n_keys_base, const int* pos_dev, float* out, long ldo, int B, int heads,
-                            hipStream_t s) {
+                            hipStream_t s, AttnRows rows) {
+  if (rows.group < 1) return hipErrorInvalidValue;
   hipLaunchKernelGGL(attn_dec_kernel<float>, dim3(heads, B), dim3(64 * AD_WAVES), 0, s, q, ldq, kv, kv_batch_stride, ldkv, head_stride, koff, voff,
-                     n_keys_base, pos_dev, out, ldo);
+                     n_keys_base, pos_dev, out, ldo, rows);
   return hipGetLastError();
 }
 hipError_t attn_decoder_kv16(const float* q, long ldq, const void* kv, long kv_batch_stride, long ldkv, long head_stride,
                              long koff, long voff, int n_keys_base, const int* pos_dev, float* out, long ldo, int B, int heads,
-                             hipStream_t s, int max_keys) {
-  const int bound = max_keys > 0 ? max_keys : n_keys_base;
+                             hipStream_t s, int max_keys, AttnRows rows) {
+  if (rows.group < 1) return hipErrorInvalidValue;
+  const int bound = max_keys > 0 ? max_keys : n_keys_base + rows.key_step * (rows.group - 1);
   if ((max_keys > 0 || !pos_dev) && bound <= AD_WAVES * 8 * 12 && AD_WAVES == 16) {   // every byte of K|V requested up front
     const _Float16* kvh = reinterpret_cast<const _Float16*>(kv);
 #define CRISPY_ADX(SL) hipLaunchKernelGGL(attn_dec_x16_kernel<SL>, dim3(heads, B), dim3(64 * AD_WAVES), 0, s, q, ldq, kvh, \
-                                          kv_batch_stride, ldkv, head_stride, koff, voff, n_keys_base, pos_dev, out, ldo)
+                                          kv_batch_stride, ldkv, head_stride, koff, voff, n_keys_base, pos_dev, out, ldo, rows)
     if (bound <= AD_WAVES * 8) CRISPY_ADX(1);
     else if (bound <= AD_WAVES * 16) CRISPY_ADX(2);
     else if (bound <= AD_WAVES * 32) CRISPY_ADX(4);
@@ -1552,12 +1564,12 @@ hipError_t attn_decoder_kv16(const float* q, long ldq, const void* kv, long kv_b
     return hipGetLastError();
   }
   hipLaunchKernelGGL(attn_dec_kernel<_Float16>, dim3(heads, B), dim3(64 * AD_WAVES), 0, s, q, ldq,
-                     reinterpret_cast<const _Float16*>(kv), kv_batch_stride, ldkv, head_stride, koff, voff, n_keys_base, pos_dev, out, ldo);
+                     reinterpret_cast<const _Float16*>(kv), kv_batch_stride, ldkv, head_stride, koff, voff, n_keys_base, pos_dev, out, ldo, rows);
   return hipGetLastError();
 }
 hipError_t embed_tokens_f32(const int* tokens, const float* tok_emb, const float* pos_emb, int pos, const int* pos_dev,
-                            float* x, int B, int D, hipStream_t s) {
-  hipLaunchKernelGGL(embed_kernel, dim3(B), dim3(256), 0, s, tokens, tok_emb, pos_emb, pos, pos_dev, x, D);
+                            float* x, int B, int D, hipStream_t s, int rows_per_clip) {
+  hipLaunchKernelGGL(embed_kernel, dim3(B), dim3(256), 0, s, tokens, tok_emb, pos_emb, pos, pos_dev, x, D, rows_per_clip < 1 ? 1 : rows_per_clip);
   return hipGetLastError();
 }
 hipError_t argmax_f32(const float* logits, const unsigned char* mask, const unsigned char* mask_first,
