@@ -95,6 +95,7 @@ pub struct crispy_asr_opts {
     pub translate: c_int,
     pub max_new_tokens: c_int,
     pub no_timestamps: c_int,
+    pub no_prev_text: c_int,
 }
 
 #[repr(C)]

@@ -53,7 +53,7 @@ class AsrSpecials(C.Structure):
 class AsrOpts(C.Structure):
     """crispy_asr_opts"""
     _fields_ = [("language_token", C.c_int), ("translate", C.c_int), ("max_new_tokens", C.c_int),
-                ("no_timestamps", C.c_int)]
+                ("no_timestamps", C.c_int), ("no_prev_text", C.c_int)]
 
 
 class AsrSegment(C.Structure):

@@ -233,13 +233,14 @@ class WhisperEngine(WhisperModel):
         return C.string_at(p, n.value)
 
     def transcribe(self, audio: np.ndarray, max_new_tokens: int = 0, translate: bool = False, language_token: int = 0,
-                   timestamps: bool = False):
+                   timestamps: bool = False, prev_text: bool = True):
         """One chunk (<= 480000 samples at 16 kHz) -> (text, token ids); empty audio -> ("", []).
         language_token = 0 auto-detects, as `TranscribeOptions::default()` does.  timestamps = True is whisper.cpp's
         default decoding mode (timestamp tokens, seek loop); its segments are kept in `self.last_segments` as
-        (t0 seconds, t1 seconds, text)."""
+        (t0 seconds, t1 seconds, text).  prev_text = True: from the second window of the seek loop on, the decoder is
+        conditioned on the text so far (whisper.cpp's prompt_past)."""
         a = np.ascontiguousarray(audio, dtype=np.float32).ravel()
-        opts = N.AsrOpts(int(language_token), int(translate), int(max_new_tokens), 0 if timestamps else 1)
+        opts = N.AsrOpts(int(language_token), int(translate), int(max_new_tokens), 0 if timestamps else 1, 0 if prev_text else 1)
         res = C.c_void_p()
         N.check(N.lib().crispy_asr_transcribe(self._h, a.ctypes.data if a.size else None, a.size, C.byref(opts),
                                               C.byref(res)))
@@ -249,9 +250,9 @@ class WhisperEngine(WhisperModel):
             N.lib().crispy_asr_free_result(res)
         return text, tokens
 
-    def transcribe_segments(self, audio: np.ndarray, max_new_tokens: int = 0, language_token: int = 0):
+    def transcribe_segments(self, audio: np.ndarray, max_new_tokens: int = 0, language_token: int = 0, prev_text: bool = True):
         """`engine.transcribe(..)` with whisper.cpp's default options -> (text, [(t0, t1, text)], token ids)."""
-        text, tokens = self.transcribe(audio, max_new_tokens, False, language_token, timestamps=True)
+        text, tokens = self.transcribe(audio, max_new_tokens, False, language_token, timestamps=True, prev_text=prev_text)
         return text, self.last_segments, tokens
 
 
@@ -265,7 +266,7 @@ def _read_result(res) -> tuple:
 
 
 def transcribe_batch(engine: "WhisperEngine", clips, max_new_tokens: int = 0, language_token: int = 0,
-                     timestamps: bool = False, with_segments: bool = False):
+                     timestamps: bool = False, with_segments: bool = False, prev_text: bool = True):
     """`crispy_asr_transcribe_batch`: a list of chunks (each <= 30 s, empty allowed) -> [(text, tokens, language)]
     (+ segments with with_segments)."""
     arrs = [np.ascontiguousarray(c, dtype=np.float32).ravel() for c in clips]
@@ -273,7 +274,7 @@ def transcribe_batch(engine: "WhisperEngine", clips, max_new_tokens: int = 0, la
     ptrs = (C.c_void_p * max(nb, 1))(*[a.ctypes.data if a.size else None for a in arrs])
     lens = (C.c_size_t * max(nb, 1))(*[a.size for a in arrs])
     res = (C.c_void_p * max(nb, 1))()
-    opts = N.AsrOpts(int(language_token), 0, int(max_new_tokens), 0 if timestamps else 1)
+    opts = N.AsrOpts(int(language_token), 0, int(max_new_tokens), 0 if timestamps else 1, 0 if prev_text else 1)
     N.check(N.lib().crispy_asr_transcribe_batch(engine._h, ptrs, lens, nb, C.byref(opts), res))
     out = []
     for i in range(nb):

@@ -2008,6 +2008,14 @@ int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const si
       // ---- whisper_full's seek loop, all clips in lock step ----
       std::vector<int> seek(nb, 0), seek_end(nb);
       for (int k = 0; k < nb; ++k) seek_end[k] = lens[k] / 160;
+      // whisper.cpp's prompt_past [UPSTREAM-RECALL: whisper_full_with_state]: the kept tokens of the windows so far condition
+      // the next window -- prompt = <|startofprev|> + the last min(n_text_ctx / 2, |past|) of them + the usual prompt -- unless
+      // fewer than 5 s of audio are left ("a very short segment ... tends to confuse the decoder").  After a window: past =
+      // the past part of its prompt + its kept tokens.  (The temperature test `t_cur < 0.5` is always true here: greedy, no
+      // fallback.)
+      const bool use_past = !(opts && opts->no_prev_text);
+      std::vector<std::vector<int>> past(nb);
+      const int n_init = (int)prompt.size();
       // whisper.cpp loops until seek + 100 >= seek_end.  Every round advances every active clip by seek_delta >= 2
       // (a closed pair ends on a timestamp strictly above <|0.00|>, otherwise the delta is the whole window), so
       // 1500 rounds cover any 30 s clip; running out of them is reported, never a silently shorter transcript.
@@ -2030,10 +2038,41 @@ int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const si
         }
         std::vector<int> a_lang(na), a_seek(na), a_end(na), toks((size_t)na * max_new), tids((size_t)na * max_new), n_out(na, 0);
         for (int a = 0; a < na; ++a) { a_lang[a] = lang[act[a]]; a_seek[a] = seek[act[a]]; a_end[a] = seek_end[act[a]]; }
-        rc = decode_ts(h, h->w_enc, na, prompt.data(), (int)prompt.size(), sp.multilingual ? a_lang.data() : nullptr,
-                       TS_RULES_WCPP, a_seek.data(), a_end.data(), max_new, h->d_ts_mask, h->d_ts_mask_first, toks.data(),
-                       tids.data(), n_out.data());
-        if (rc != CRISPY_OK) return rc;
+        bool any_past = false;
+        for (int a = 0; a < na; ++a) {
+          const int k = act[a];
+          if (seek[k] > 0 && seek[k] + 500 >= seek_end[k]) past[k].clear();
+          any_past = any_past || (use_past && !past[k].empty());
+        }
+        std::vector<std::vector<int>> used((size_t)na);      // the prompt each clip's window ran with
+        if (!any_past) {
+          rc = decode_ts(h, h->w_enc, na, prompt.data(), n_init, sp.multilingual ? a_lang.data() : nullptr,
+                         TS_RULES_WCPP, a_seek.data(), a_end.data(), max_new, h->d_ts_mask, h->d_ts_mask_first, toks.data(),
+                         tids.data(), n_out.data());
+          if (rc != CRISPY_OK) return rc;
+        } else {
+          // prompts differ in length from clip to clip now: one decode call per clip (its prompt runs as one or two
+          // multi-position steps, see prefill), over its slice of the encoder output
+          const size_t enc_clip = (size_t)h->hp.n_audio_ctx * h->hp.n_audio_state;
+          for (int a = 0; a < na; ++a) {
+            const int k = act[a];
+            std::vector<int>& p = used[a];
+            if (use_past && !past[k].empty()) {
+              int n_take = std::min<int>(h->hp.n_text_ctx / 2, (int)past[k].size());
+              n_take = std::min(n_take, h->hp.n_text_ctx - max_new - n_init - 1);
+              if (n_take > 0) {
+                p.push_back(sp.prev);
+                p.insert(p.end(), past[k].end() - n_take, past[k].end());
+              }
+            }
+            p.insert(p.end(), prompt.begin(), prompt.end());
+            if (sp.multilingual) p[p.size() - n_init + 1] = a_lang[a];
+            rc = decode_ts(h, h->w_enc + (size_t)a * enc_clip, 1, p.data(), (int)p.size(), nullptr, TS_RULES_WCPP, &a_seek[a],
+                           &a_end[a], max_new, h->d_ts_mask, h->d_ts_mask_first, toks.data() + (size_t)a * max_new,
+                           tids.data() + (size_t)a * max_new, &n_out[a]);
+            if (rc != CRISPY_OK) return rc;
+          }
+        }
         for (int a = 0; a < na; ++a) {
           const int k = act[a];
           crispy_asr_result_impl* r = impl[live[k]];
@@ -2043,6 +2082,12 @@ int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const si
           window_segments(h, tk, tids.data() + (size_t)a * max_new, result_len, sp.beg, seek[k], seek_delta, r);
           for (int i = 0; i < result_len; ++i)
             if (tk[i] != h->eot) r->tokens.push_back(tk[i]);
+          {
+            std::vector<int> np;
+            if (!used[a].empty() && used[a].front() == sp.prev) np.assign(used[a].begin() + 1, used[a].end() - n_init);
+            np.insert(np.end(), tk, tk + result_len);
+            past[k].swap(np);
+          }
           seek[k] += seek_delta;
         }
       }

@@ -101,7 +101,7 @@ int crispy_rn_n_streams(const crispy_rn *h);
  * whose high-pass runs one launch ahead on a helper stream (bench.py's per-launch roofline uses it). */
 int crispy_rn_frames_per_launch(void);
 /* Number of rn_frame_kernel launches one call of n_frames makes: a segment (<= 250 frames) starts with short
- * sub-chunks (3, 8 frames) so that the sequential high-pass of the first one is the only exposed one, then 12
+ * sub-chunks (3, 4, 5, 7, 10 frames) so that the sequential high-pass of the first one is the only exposed one, then 12
  * (94 MB of high-passed signal at 4096 streams: still in the Infinity Cache when the frame kernel reads it). */
 int crispy_rn_n_launches(int n_frames);
 
@@ -354,6 +354,11 @@ typedef struct crispy_asr_opts {
   int no_timestamps;   /* 0 = whisper.cpp's default: timestamp tokens, 30 s windows advancing to the last closed
                           timestamp pair (whisper_full's seek loop), segments in the result.
                           1 = <|notimestamps|> prompt, one window, plain greedy arg-max, no segments. */
+  int no_prev_text;    /* 0 = whisper.cpp's behaviour inside one whisper_full call [UPSTREAM-RECALL]: from the second
+                          window on the decoder is conditioned on the text so far -- prompt <|startofprev|> + the last
+                          <= n_text_ctx / 2 tokens of the previous windows (their timestamp tokens included) + the
+                          usual <|startoftranscript|> ...; not when fewer than 5 s of audio are left.
+                          1 = every window starts from the bare prompt. */
 } crispy_asr_opts;
 
 /* One segment of the result (managers/transcription.rs:223-233: `seg.start`, `seg.end`, `seg.text`),

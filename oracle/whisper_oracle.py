@@ -390,24 +390,39 @@ def window_segments(win, seek, sp, token_text):
 
 
 def transcribe_timestamps(weights, hp, mel_window, n_samples, prompt, rules, token_text, n_max=None,
-                          suppress=None, suppress_first=None, eot=None, max_windows=1501, f16=False):
+                          suppress=None, suppress_first=None, eot=None, max_windows=1501, f16=False, prev_text=True):
     """whisper_full's seek loop over one clip (<= 30 s): `mel_window(seek)` returns the [n_mels, 3000] log-mel
     window starting at mel frame `seek`.  Returns (segments, all kept tokens, windows).
     f16=True chains the f16-operand arithmetic (the library's precision mode 1 = ggml's mul_mat numerics
-    [UPSTREAM-RECALL]): `encoder_forward_f16` -> `DecoderCache(f16=True)`."""
+    [UPSTREAM-RECALL]): `encoder_forward_f16` -> `DecoderCache(f16=True)`.
+    prev_text=True is whisper.cpp's `prompt_past` [UPSTREAM-RECALL: whisper_full_with_state]: from the second window on
+    the prompt is <|startofprev|> + the last min(n_text_ctx / 2, len(past)) tokens of the text so far + `prompt`; the past
+    is dropped when fewer than 5 s of audio are left (`seek > seek_start && seek + 500 >= seek_end`); after a window the
+    past becomes the past part of its prompt + its kept tokens (timestamp tokens and all)."""
     sp = special_tokens(hp.n_vocab, eot)
     n_max = hp.n_text_ctx // 2 - 4 if n_max is None else n_max
     seek, seek_end = 0, n_samples // 160
     segs, kept, wins = [], [], []
     if seek_end < 100:                         # whisper.cpp: "input is too short" -> nothing
         return segs, kept, wins
+    prompt = list(prompt)
+    past = []
     while seek + 100 < seek_end and len(wins) < max_windows:
+        if seek > 0 and seek + 500 >= seek_end:
+            past = []
+        p = list(prompt)
+        if prev_text and past:
+            n_take = min(hp.n_text_ctx // 2, len(past), hp.n_text_ctx - n_max - len(prompt) - 1)
+            if n_take > 0:
+                p = [sp["prev"]] + past[len(past) - n_take:] + p
         enc = (encoder_forward_f16 if f16 else encoder_forward)(weights, hp, mel_window(seek))
         dc = DecoderCache(weights, hp, enc, f16=f16)
-        win = decode_window(dc.step, prompt, sp, rules, n_max, seek, seek_end, suppress, suppress_first)
+        win = decode_window(dc.step, p, sp, rules, n_max, seek, seek_end, suppress, suppress_first)
         win["seek"] = seek
+        win["prompt"] = p
         wins.append(win)
         segs += window_segments(win, seek, sp, token_text)
         kept += win["tokens"][:win["result_len"]]
+        past = (p[1:len(p) - len(prompt)] if p[0] == sp["prev"] else []) + list(win["tokens"][:win["result_len"]])
         seek += win["seek_delta"]
     return segs, kept, wins

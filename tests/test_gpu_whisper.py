@@ -481,6 +481,58 @@ def test_transcribe_segments_follow_whisper_full_seek_loop(tiny, ggml_file, orac
     N.lib().crispy_asr_free_result(res)
 
 
+def test_seek_loop_conditions_later_windows_on_the_text_so_far(tiny, ggml_file, oracle):
+    """whisper.cpp's `prompt_past` [UPSTREAM-RECALL]: from the second window of a whisper_full call on, the prompt is
+    <|startofprev|> + the tokens kept so far + <|startoftranscript|> ...  12 s clips whose first window ends with more
+    than 5 s of audio left (under that the past is dropped): the product equals the oracle's seek loop window for window
+    -- kept tokens, segment times, texts -- with the conditioning and (no_prev_text = 1) without it, the two differ, and a
+    batch whose clips carry different pasts equals the single calls.  28 s: the past accumulates over three windows."""
+    from crispy_amd import synth_audio
+    from crispy_amd.asr import WhisperEngine, transcribe_batch
+    from crispy_amd.mel_filters import whisper_mel_filters
+    from oracle import whisper_oracle as WO
+    hp, W = tiny
+    eng = WhisperEngine(str(ggml_file))
+    sp, sup, sup_first = _wcpp_masks(hp)
+    F = whisper_mel_filters(80)
+    init = [sp["sot"], sp["lang0"], sp["transcribe"]]
+
+    def ref(x, prev_text):
+        return WO.transcribe_timestamps(W, hp, lambda seek: oracle.oracle_logmel(x, F, seek), x.size, init, WO.RULES_WCPP,
+                                        eng.token_text, n_max=10, suppress=sup, suppress_first=sup_first, max_windows=16,
+                                        prev_text=prev_text)
+
+    singles = {}
+    for seed, seconds in ((60, 12), (64, 12), (68, 28)):
+        x = synth_audio.clip16k_np(seed, 16000 * seconds)
+        text, segs, toks = eng.transcribe_segments(x, max_new_tokens=10, language_token=sp["lang0"])
+        rsegs, rkept, wins = ref(x, True)
+        assert min(min(w["margins"]) for w in wins) > 1e-3, "test clip has an f32-unresolvable pick; choose another seed"
+        lens = [len(w["prompt"]) for w in wins]
+        assert len(wins) >= 2 and lens[0] == 3 and max(lens) >= 3 + 1 + 5, lens        # a later window IS conditioned
+        assert all(w["prompt"][0] == sp["prev"] for w in wins if len(w["prompt"]) > 3)
+        assert toks == [t for t in rkept if t != sp["eot"]], (seed, toks, rkept)
+        assert [(round(a * 100), round(b * 100), s) for a, b, s in segs] == [(a, b, s.decode()) for a, b, s in rsegs]
+        singles[seed] = (x, text, toks, segs)
+        if seconds == 28:
+            assert len(wins) >= 3 and lens[2] > lens[1] > 3, lens                       # the past accumulates
+        # without the conditioning: every window on the bare prompt, a different transcript, still the oracle's
+        _, segs0, toks0 = eng.transcribe_segments(x, max_new_tokens=10, language_token=sp["lang0"], prev_text=False)
+        rsegs0, rkept0, wins0 = ref(x, False)
+        assert all(len(w["prompt"]) == 3 for w in wins0)
+        if min(min(w["margins"]) for w in wins0) > 1e-3:
+            assert toks0 == [t for t in rkept0 if t != sp["eot"]]
+        assert toks0 != toks
+    # a batch: round 0 runs batched on the bare prompt, later rounds clip by clip on their own prompts
+    clips = [singles[60][0], synth_audio.clip16k_np(52, 15000), singles[64][0], singles[68][0]]
+    got = transcribe_batch(eng, clips, max_new_tokens=10, language_token=sp["lang0"], timestamps=True, with_segments=True)
+    for i, seed in ((0, 60), (2, 64), (3, 68)):
+        _, text, toks, segs = singles[seed]
+        assert got[i] == (text, toks, sp["lang0"], segs), seed
+    assert got[1][:2] == ("", [])
+    eng.close()
+
+
 def test_f16_operand_encoder_mode(tiny, model):
     """crispy_asr_set_precision(1): encoder GEMMs with f16 operands / f32 accumulation (whisper.cpp's ggml numerics).
     Tolerance: 5e-3 of the peak against the f32 mode (f16 rounding of weights and activations, observed ~1e-3);
