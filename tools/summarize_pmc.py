@@ -23,7 +23,7 @@ if os.path.exists(stats):
     for r in csv.DictReader(open(stats)):
         if "rn_frame_kernel" in r["Name"]:
             avg_ns, calls = float(r["AverageNs"]), int(r["Calls"])
-frames_per_launch = 100.0 / 10.0
+frames_per_launch = 100.0 / (11.0 if tag >= "r03c" else 10.0)   # 3 + 4 + 5 + 7 + 10 + 5 x 12 + 11 from r03c on
 issue = None
 if avg_ns:
     issue = p["SQ_ACTIVE_INST_VALU"] * 4 * 4096 * frames_per_launch / (1024 * avg_ns * 1e-9 * 2.4e9)
@@ -47,11 +47,14 @@ out = {
                                    "lds": round(p["SQ_INSTS_LDS"]), "vmem_rd": round(p["SQ_INSTS_VMEM_RD"]),
                                    "vmem_wr": round(p["SQ_INSTS_VMEM_WR"], 1)},
         "wave_wait_fraction": round(p["SQ_WAIT_ANY"] / p["SQ_WAVE_CYCLES"], 3),
-        "lds_bank_conflict_fraction_of_lds_active": round(p["SQ_LDS_BANK_CONFLICT"] / p["SQ_ACTIVE_INST_LDS"], 3),
+        # SQ_LDS_BANK_CONFLICT counts cycles, SQ_ACTIVE_INST_LDS quad-cycles (MI355X_MICROARCH.md): summaries up to r03b
+        # divided one by the other without the factor 4 and overstated the conflicts four-fold
+        "lds_bank_conflict_fraction_of_lds_active": round(p["SQ_LDS_BANK_CONFLICT"] / (4.0 * p["SQ_ACTIVE_INST_LDS"]), 3),
+        "lds_pipe_busy_fraction": round(p["SQ_ACTIVE_INST_LDS"] * 4 * 16 / ((avg_ns or 1) * 1e-9 * 2.16e9 / frames_per_launch), 3) if avg_ns else None,
         "valu_issue_fraction": {
             "definition": "SQ_ACTIVE_INST_VALU * 4 cycles * stream-frames / (1024 SIMDs * kernel time * 2.4 GHz), "
                           f"kernel time from {tag}_bench_kernel_stats.csv "
-                          f"({(avg_ns or 0) / 1e6:.3f} ms avg per launch of 10 frames x 4096 streams)",
+                          f"({(avg_ns or 0) / 1e6:.3f} ms avg per launch of {frames_per_launch:.2f} frames x 4096 streams)",
             "value": None if issue is None else round(issue, 3)},
     },
 }
