@@ -169,6 +169,7 @@ extern "C" {
     pub fn crispy_asr_load_resident(model_path: *const c_char, device: c_int, out: *mut *mut crispy_asr) -> c_int;
     pub fn crispy_asr_memory_info(h: *const crispy_asr, weight_bytes: *mut usize, quantised_bytes: *mut usize, scratch_bytes: *mut usize) -> c_int;
     pub fn crispy_asr_vocab_specials(n_vocab: c_int, out: *mut crispy_asr_specials) -> c_int;
+    pub fn crispy_asr_language_token(n_vocab: c_int, code: *const c_char, token_out: *mut c_int) -> c_int;
     pub fn crispy_asr_token_text(h: *const crispy_asr, token: c_int, text: *mut *const c_char, len: *mut usize) -> c_int;
     pub fn crispy_asr_transcribe(h: *mut crispy_asr, pcm16k: *const c_float, n: usize, opts: *const crispy_asr_opts, out: *mut *mut crispy_asr_result) -> c_int;
     pub fn crispy_asr_transcribe_batch(h: *mut crispy_asr, pcm: *const *const c_float, n: *const usize, batch: c_int, opts: *const crispy_asr_opts, results: *mut *mut crispy_asr_result) -> c_int;
@@ -366,6 +367,11 @@ impl GpuWhisperEngine {
         check(unsafe { crispy_asr_set_precision(engine.h, 1) })?;
         Ok(engine)
     }
+    /// Vocabulary size of the loaded model (51864 English-only, 51865 multilingual, 51866 large-v3).
+    pub fn n_vocab(&self) -> c_int {
+        let mut hp = crispy_asr_hparams::default();
+        if unsafe { crispy_asr_hparams_get(self.h, &mut hp) } == CRISPY_OK { hp.n_vocab } else { 0 }
+    }
     /// 0: exact f32 products (parity mode); 1: whisper.cpp's f16-operand arithmetic (the default of `load`).
     pub fn set_precision(&mut self, mode: i32) -> Result<(), CrispyError> {
         check(unsafe { crispy_asr_set_precision(self.h, mode as c_int) })
@@ -416,8 +422,19 @@ mod speech_model {
     use transcribe_rs::{SpeechModel, TranscribeOptions, TranscriptionResult, TranscriptionSegment};
 
     impl SpeechModel for GpuWhisperEngine {
-        fn transcribe(&mut self, audio: &[f32], _options: &TranscribeOptions) -> Result<TranscriptionResult, Box<dyn std::error::Error + Send + Sync>> {
-            let t = self.transcribe_chunk(audio, None)?;
+        // `TranscribeOptions { language: Option<String>, translate: bool }` [UPSTREAM-RECALL: transcribe-rs 0.3.11; the
+        // reference only ever passes `TranscribeOptions::default()`, managers/transcription.rs:184,214 -- language unset,
+        // transcribe]: a set language becomes its token, an unset one is detected per chunk, as whisper.cpp does.
+        fn transcribe(&mut self, audio: &[f32], options: &TranscribeOptions) -> Result<TranscriptionResult, Box<dyn std::error::Error + Send + Sync>> {
+            let mut o = crispy_asr_opts::default();
+            if let Some(code) = options.language.as_deref() {
+                let c = std::ffi::CString::new(code)?;
+                let mut tok: c_int = 0;
+                check(unsafe { crispy_asr_language_token(self.n_vocab(), c.as_ptr(), &mut tok) })?;
+                o.language_token = tok;
+            }
+            o.translate = options.translate as c_int;
+            let t = self.transcribe_chunk(audio, Some(&o))?;
             Ok(TranscriptionResult {
                 text: t.text,
                 segments: t.segments.map(|v| v.into_iter().map(|s| TranscriptionSegment { start: s.start, end: s.end, text: s.text }).collect()),

@@ -39,7 +39,7 @@ ASR_SYMBOLS = ("crispy_asr_create", "crispy_asr_set_tensor", "crispy_asr_finaliz
                "crispy_asr_load", "crispy_asr_load_resident", "crispy_asr_memory_info", "crispy_asr_token_text", "crispy_asr_transcribe", "crispy_asr_free_result",
                "crispy_asr_decode_greedy_lang_device", "crispy_asr_detect_language_device",
                "crispy_asr_transcribe_batch", "crispy_asr_decode_timestamps_device", "crispy_asr_set_precision",
-               "crispy_asr_vocab_specials", "crispy_asr_stage_logits_device")
+               "crispy_asr_vocab_specials", "crispy_asr_stage_logits_device", "crispy_asr_language_token")
 RS_SYMBOLS = ("crispy_resampler_create", "crispy_resampler_destroy", "crispy_resampler_out_len",
               "crispy_resampler_process_device", "crispy_resampler_synchronize")
 ALL_SYMBOLS = RN_SYMBOLS + MEL_SYMBOLS + ASR_SYMBOLS + RS_SYMBOLS
@@ -115,6 +115,7 @@ def load_library(path: str) -> C.CDLL:
     L.crispy_rn_create_from_file.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.crispy_selftest_exception_guard.argtypes = [C.c_int]
     L.crispy_asr_vocab_specials.argtypes = [C.c_int, C.c_void_p]
+    L.crispy_asr_language_token.argtypes = [C.c_int, C.c_char_p, C.POINTER(C.c_int)]
     L.crispy_rn_destroy.restype = None
     L.crispy_rn_reset.argtypes = [C.c_void_p, C.c_int]
     L.crispy_rn_n_streams.argtypes = [C.c_void_p]

@@ -1896,6 +1896,33 @@ int crispy_asr_vocab_specials(int n_vocab, crispy_asr_specials* out) try {
   return CRISPY_OK;
 } CRISPY_CATCH_RET("crispy_asr_vocab_specials")
 
+int crispy_asr_language_token(int n_vocab, const char* code, int* token_out) try {
+  if (!code || !token_out) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_language_token: NULL argument");
+  if (n_vocab < 51864) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_language_token: %d is not a whisper vocabulary size", n_vocab);
+  // whisper.cpp g_lang / openai LANGUAGES order [UPSTREAM-RECALL]; index = whisper_lang_id
+  static const char* const kLang[] = {
+      "en", "zh", "de", "es", "ru", "ko", "fr", "ja", "pt", "tr", "pl", "ca", "nl", "ar", "sv", "it", "id", "hi", "fi", "vi",
+      "he", "uk", "el", "ms", "cs", "ro", "da", "hu", "ta", "no", "th", "ur", "hr", "bg", "lt", "la", "mi", "ml", "cy", "sk",
+      "te", "fa", "lv", "bn", "sr", "az", "sl", "kn", "et", "mk", "br", "eu", "is", "hy", "ne", "mn", "bs", "kk", "sq", "sw",
+      "gl", "mr", "pa", "si", "km", "sn", "yo", "so", "af", "oc", "ka", "be", "tg", "sd", "gu", "am", "yi", "lo", "uz", "fo",
+      "ht", "ps", "tk", "nn", "mt", "sa", "lb", "my", "bo", "tl", "mg", "as", "tt", "haw", "ln", "ha", "ba", "jw", "su", "yue"};
+  *token_out = 0;
+  if (!*code || std::strcmp(code, "auto") == 0) return CRISPY_OK;
+  const Special sp = vocab_specials(n_vocab);
+  int id = -1;
+  for (int i = 0; i < (int)(sizeof(kLang) / sizeof(kLang[0])); ++i)
+    if (std::strcmp(code, kLang[i]) == 0) { id = i; break; }
+  if (id < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_language_token: unknown language code '%s'", code);
+  if (!sp.multilingual) {
+    if (id == 0) return CRISPY_OK;                 // an English-only model transcribes English with no language token
+    return fail(CRISPY_ERR_UNSUPPORTED, "crispy_asr_language_token: an English-only vocabulary cannot take '%s'", code);
+  }
+  if (id >= sp.n_lang)
+    return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_language_token: this vocabulary has %d languages, '%s' is number %d", sp.n_lang, code, id + 1);
+  *token_out = sp.lang0 + id;
+  return CRISPY_OK;
+} CRISPY_CATCH_RET("crispy_asr_language_token")
+
 int crispy_asr_token_text(const crispy_asr* h, int token, const char** text, size_t* len) try {
   if (!h || !text || !len) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_token_text: NULL argument");
   if (token < 0 || token >= (int)h->vocab.size())

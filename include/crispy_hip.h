@@ -343,6 +343,14 @@ typedef struct crispy_asr_specials {
 } crispy_asr_specials;
 int crispy_asr_vocab_specials(int n_vocab, crispy_asr_specials *out);
 
+/* Language token of an ISO code as whisper.cpp's `whisper_lang_id` table orders them [UPSTREAM-RECALL: g_lang, the
+ * order of openai/whisper's LANGUAGES]: "en" -> lang0, "zh" -> lang0 + 1, ... "yue" -> lang0 + 99 (large-v3 only).
+ * For hosts that hold the language as a string (`TranscribeOptions.language`); the result goes into
+ * crispy_asr_opts::language_token.  English-only vocabularies have no language token: "en" gives 0 (= none),
+ * anything else CRISPY_ERR_UNSUPPORTED; an unknown code, or one the vocabulary has no token for, CRISPY_ERR_INVALID_ARG.
+ * "auto" and "" give 0 (auto-detect).  Pure function, no device needed. */
+int crispy_asr_language_token(int n_vocab, const char *code, int *token_out);
+
 /* Byte string of one vocabulary entry of a loaded model file (not NUL-terminated). */
 int crispy_asr_token_text(const crispy_asr *h, int token, const char **text, size_t *len);
 

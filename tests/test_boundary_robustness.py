@@ -132,6 +132,15 @@ def test_special_token_ids_for_en_multilingual_and_large_v3():
     assert WO.default_prompt(51865, no_timestamps=True) == [50258, 50259, 50359, 50363]
     assert WO.default_prompt(51866) == [50258, 50259, 50360]
     assert L.crispy_asr_vocab_specials(1000, C.byref(N.AsrSpecials())) == -1
+    # language codes -> tokens (whisper.cpp's whisper_lang_id order); pure function, no device
+    tok = C.c_int(-1)
+    for nv, code, want in ((51865, b"en", 50259), (51865, b"zh", 50260), (51865, b"de", 50261), (51865, b"su", 50259 + 98),
+                           (51866, b"yue", 50259 + 99), (51864, b"en", 0), (51865, b"auto", 0), (51865, b"", 0)):
+        assert L.crispy_asr_language_token(nv, code, C.byref(tok)) == 0 and tok.value == want, (nv, code, tok.value)
+    assert L.crispy_asr_language_token(51865, b"yue", C.byref(tok)) == -1        # 99 languages only
+    assert L.crispy_asr_language_token(51865, b"xx", C.byref(tok)) == -1
+    assert L.crispy_asr_language_token(51864, b"de", C.byref(tok)) == -6         # English-only vocabulary
+    assert L.crispy_asr_language_token(51865, None, C.byref(tok)) == -1
 
 
 # ---- GGML loader: nothing is sized from numbers a corrupt file supplies ---------------------------------------------
