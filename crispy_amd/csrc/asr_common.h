@@ -120,7 +120,9 @@ hipError_t attn_encoder_f32(const float* qkv, float* out, int B, int T, int D, i
 // of a clip are neighbours in the grid, so the repeats of a clip's cross K|V are served by the L2s / the Infinity Cache.
 // (A variant that walks a clip's rows over K|V registers loaded once needs 96 + ~40 registers at 4 waves per SIMD:
 // 468 bytes of scratch per lane -- not built.)
-struct AttnRows { int group = 1, key_step = 0; };
+// stream_kv = 1: the K|V of this launch will not be read again before it has left the caches (a decode step over many
+// clips): request it non-temporally, so that it does not evict the decoder's weights from the L2s.
+struct AttnRows { int group = 1, key_step = 0, stream_kv = 0; };
 hipError_t attn_decoder_f32(const float* q, long ldq, const float* kv, long kv_batch_stride, long ldkv, long head_stride,
                             long koff, long voff, int n_keys_base, const int* pos_dev, float* out, long ldo, int B, int heads,
                             hipStream_t s, AttnRows rows = AttnRows());

@@ -199,7 +199,7 @@ def test_asr_kernels_have_no_scratch_at_all(tmp_path, src_name):
         for must in ("gemm_skinny_f32_kernel", "ts_pick_kernel", "argmax_kernel", "attn_dec_kernel", "gemm_vocab_f32_kernel"):
             assert any(must in k for k in res), (must, list(res))
         assert sum("gemm_skinny_f32_kernel" in k for k in res) == 36      # 8 epilogue forms x 4 K splits + 4 f16-weight forms
-        assert sum("attn_dec_x16_kernel" in k for k in res) == 4           # 1 / 2 / 4 / 12 key slots per wave
+        assert sum("attn_dec_x16_kernel" in k for k in res) == 5           # 1 / 2 / 4 / 12 key slots per wave + the non-temporal 12 (K|V streams of many clips)
     if src_name == "whisper_dec_f16.hip":
         assert sum("vocab_f16_kernel" in k for k in res) == 5              # tiny ... large widths
     bad = {k: r for k, r in res.items() if r.get("ScratchSize", 0) != 0 or r.get("VGPRs Spill", 0) != 0}
