@@ -884,16 +884,27 @@ __global__ __launch_bounds__(256) void attn_enc_kernel(const float* __restrict__
 #define AD_WAVES_N 16
 #endif
 constexpr int AD_WAVES = AD_WAVES_N;   // key partitions per (clip, head): 1.2 GB of cross K|V per step want many loads in flight
-template <class KV> __device__ __forceinline__ float4 ld4(const KV* p);
-template <> __device__ __forceinline__ float4 ld4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
-template <> __device__ __forceinline__ float4 ld4<_Float16>(const _Float16* p) {
+// NT: non-temporal request (the K|V stream of a decode step over many clips, see attn_dec_x16_kernel)
+template <class KV, bool NT> __device__ __forceinline__ float4 ld4(const KV* p);
+template <> __device__ __forceinline__ float4 ld4<float, false>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ __forceinline__ float4 ld4<float, true>(const float* p) {
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ float4 ld4<_Float16, false>(const _Float16* p) {
   typedef _Float16 half4 __attribute__((ext_vector_type(4)));
   const half4 h = *reinterpret_cast<const half4*>(p);
   return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
 }
+template <> __device__ __forceinline__ float4 ld4<_Float16, true>(const _Float16* p) {
+  typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+  const half4 h = __builtin_nontemporal_load(reinterpret_cast<const half4*>(p));
+  return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+}
 // KV = float (self-attention cache, default cross K|V) or _Float16 (cross K|V in precision mode 1: half the bytes of
 // the stream that dominates a decode step; whisper.cpp keeps its KV caches in f16 as well)
-template <class KV>
+template <class KV, bool STREAM_KV = false>
 __global__ __launch_bounds__(64 * AD_WAVES) void attn_dec_kernel(const float* __restrict__ q, long ldq,
                                                        const KV* __restrict__ kv, long kv_batch_stride,
                                                        long ldkv, long head_stride, long koff, long voff, int n_keys_base,
@@ -928,7 +939,7 @@ __global__ __launch_bounds__(64 * AD_WAVES) void attn_dec_kernel(const float* __
         const int k = kb + 4 * u + sub;
         sacc[u] = 0.f;
         if (k < k_hi) {
-          const float4 t = ld4<KV>(Kb + (long)k * ldkv + 4 * c);
+          const float4 t = ld4<KV, STREAM_KV>(Kb + (long)k * ldkv + 4 * c);
           sacc[u] = t.x * qv.x;
           sacc[u] = fmaf(t.y, qv.y, sacc[u]);
           sacc[u] = fmaf(t.z, qv.z, sacc[u]);
@@ -984,7 +995,7 @@ __global__ __launch_bounds__(64 * AD_WAVES) void attn_dec_kernel(const float* __
         t[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         p[u] = 0.f;
         if (k < k_hi) {
-          t[u] = ld4<KV>(Vb + (long)k * ldkv + 4 * c);
+          t[u] = ld4<KV, STREAM_KV>(Vb + (long)k * ldkv + 4 * c);
           p[u] = p_s[k];
         }
       }
@@ -1555,8 +1566,12 @@ hipError_t attn_decoder_f32(const float* q, long ldq, const float* kv, long kv_b
                             long koff, long voff, int n_keys_base, const int* pos_dev, float* out, long ldo, int B, int heads,
                             hipStream_t s, AttnRows rows) {
   if (rows.group < 1) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(attn_dec_kernel<float>, dim3(heads, B), dim3(64 * AD_WAVES), 0, s, q, ldq, kv, kv_batch_stride, ldkv, head_stride, koff, voff,
-                     n_keys_base, pos_dev, out, ldo, rows);
+  if (rows.stream_kv)
+    hipLaunchKernelGGL((attn_dec_kernel<float, true>), dim3(heads, B), dim3(64 * AD_WAVES), 0, s, q, ldq, kv, kv_batch_stride, ldkv, head_stride, koff,
+                       voff, n_keys_base, pos_dev, out, ldo, rows);
+  else
+    hipLaunchKernelGGL((attn_dec_kernel<float, false>), dim3(heads, B), dim3(64 * AD_WAVES), 0, s, q, ldq, kv, kv_batch_stride, ldkv, head_stride, koff,
+                       voff, n_keys_base, pos_dev, out, ldo, rows);
   return hipGetLastError();
 }
 hipError_t attn_decoder_kv16(const float* q, long ldq, const void* kv, long kv_batch_stride, long ldkv, long head_stride,
@@ -1580,7 +1595,7 @@ hipError_t attn_decoder_kv16(const float* q, long ldq, const void* kv, long kv_b
 #undef CRISPY_ADX
     return hipGetLastError();
   }
-  hipLaunchKernelGGL(attn_dec_kernel<_Float16>, dim3(heads, B), dim3(64 * AD_WAVES), 0, s, q, ldq,
+  hipLaunchKernelGGL((attn_dec_kernel<_Float16, false>), dim3(heads, B), dim3(64 * AD_WAVES), 0, s, q, ldq,
                      reinterpret_cast<const _Float16*>(kv), kv_batch_stride, ldkv, head_stride, koff, voff, n_keys_base, pos_dev, out, ldo, rows);
   return hipGetLastError();
 }
