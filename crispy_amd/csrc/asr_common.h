@@ -5,6 +5,25 @@
 
 namespace crispy {
 
+// GELU as ggml's CPU backend computes it [UPSTREAM-RECALL: ggml_vec_gelu_f32 with GGML_GELU_FP16, ggml_gelu_f32] -- precision
+// mode 1.  ggml looks the value up in a table indexed by the f16 bit pattern of x, whose entries are
+//   f16( 0.5 x (1 + tanhf( sqrt(2 / pi) x (1 + 0.044715 x^2) )) )   evaluated in f32 at the f16 value x,
+// with x <= -10 -> 0 and x >= 10 -> x in front of the look-up.  The table is a memo of a pure function, so the same
+// thing evaluated on the fly -- round x to f16, the tanh formula in f32, round the result to f16 -- is the table entry,
+// except where this tanh (1 - 2 / (e^2u + 1): one v_exp_f32, one v_rcp_f32, ~1e-7 absolute) and libm's tanhf land on
+// different sides of an f16 rounding boundary (a 1e-3-relative step for about one value in a thousand).
+// 13 full-rate + 2 quarter-rate instructions per value; the exact-erf form of mode 0 (A&S 7.1.26) needs 22 + 2.
+__device__ __forceinline__ float gelu_ggml(float x) {
+  const float xh = (float)(_Float16)x;
+  const float u = (0.79788456080286535588f * xh) * fmaf(0.044715f * xh, xh, 1.0f);
+  const float t = __builtin_amdgcn_exp2f(u * 2.8853900817779268f);          // e^(2u); u <= 43 for |x| < 10: no overflow
+  const float r = __builtin_amdgcn_rcpf(t + 1.0f);
+  const float y = (0.5f * xh) * fmaf(-2.0f, r, 2.0f);                        // 1 + tanh u = 2 - 2 / (e^2u + 1)
+  float yh = (float)(_Float16)y;
+  yh = x <= -10.0f ? 0.0f : yh;
+  return x >= 10.0f ? x : yh;
+}
+
 constexpr int MEL_FRAMES = 3000;   // frames the encoder consumes (30 s)
 constexpr int MEL_TILE = 64;
 constexpr int MEL_TILES = 47;      // 3008 frames computed: the clip maximum also sees the tail frames
@@ -48,7 +67,7 @@ struct GemmArgs {
   const float* residual; long ldr; long strideR;
   const float* rowtab; int rowtab_period;
   int M, N, K;
-  int gelu;
+  int gelu;                                   // 1: exact erf form (precision mode 0); 2: ggml's form (gelu_ggml, mode 1)
   const int* c_off_dev; long c_off_scale;     // optional: C += (*c_off_dev) * c_off_scale (decoder KV-cache slot)
   // Skinny (decode-step) path only:
   //  * LayerNorm folded into the GEMM: W holds gamma-scaled rows, ln_s[n] = sum_k W[n][k], ln_c[n] = sum_k beta_k
@@ -71,10 +90,6 @@ struct GemmArgs {
   const unsigned char* wq[3];
   int wq_type, wq_rows;
   const float* wq_gamma;
-  // Skinny path: the number of rows the K split is chosen for (0: M).  The batched prompt step runs batch x P rows but
-  // must split K exactly as the one-row-per-clip steps of the same batch do, so that every row is bit-identical to the
-  // position-by-position prefill it replaces.
-  int m_hint;
 };
 constexpr int SKINNY_MAX_M = 512;   // decode steps with up to this many clips use the skinny kernel (row blocks of 32)
 hipError_t gemm_f32_nt(const GemmArgs& g, int batch, hipStream_t s);

@@ -89,7 +89,6 @@ struct crispy_asr {
   int xcd_swizzle = 1;                       // mode 1 GEMMs: column tiles of a row tile on one XCD (CRISPY_ASR_XCD=0 turns it off)
   std::vector<EncLayer> enc;
   const float *tok_emb = nullptr, *dec_pos = nullptr, *dec_ln_w = nullptr, *dec_ln_b = nullptr;
-  const float *logit_lw = nullptr, *logit_ls = nullptr, *logit_lc = nullptr;   // final LayerNorm folded into the logits GEMM
   std::vector<DecLayer> dec;
   unsigned char* d_suppress = nullptr;      // [n_vocab] tokens never emitted by the greedy decoder
   unsigned char* d_suppress_first = nullptr;  // additionally suppressed at the first sampled position
@@ -634,9 +633,6 @@ int crispy_asr_finalize(crispy_asr* h) try {
   h->dec_pos = T(h, "decoder.positional_embedding");
   h->dec_ln_w = T(h, "decoder.ln.weight");
   h->dec_ln_b = T(h, "decoder.ln.bias");
-  rc = fold_ln(h, h->tok_emb, nullptr, h->dec_ln_w, h->dec_ln_b, (size_t)h->hp.n_vocab, (size_t)h->hp.n_text_state,
-               &h->logit_lw, &h->logit_ls, &h->logit_lc);
-  if (rc != CRISPY_OK) return rc;
   h->dec.resize(h->hp.n_text_layer);
   for (int i = 0; i < h->hp.n_text_layer; ++i) {
     const std::string p = "decoder.blocks." + std::to_string(i) + ".";
@@ -962,18 +958,15 @@ int decoder_logits(crispy_asr* h, int batch, hipStream_t s, const float* x = nul
     HIP_TRY(layernorm_f16out(x, h->dec_ln_w, h->dec_ln_b, h->d_dxn, batch, dt, s));
     HIP_TRY(vocab_f16(h->d_dxn, dt, h->tok_emb_hp, h->d_logits, V, batch, V, dt, s));
   } else {
-    // vocabulary projection: above 64 clips the 128 x 128 tiled kernel (behind a LayerNorm launch) beats the skinny
-    // kernel's 32-row blocks, which re-read the 80 MB embedding once per block (-3 % / -5 % per step at 128 / 512 clips)
-    if (fold && batch <= 64) {
-      GemmArgs g = gemm(x, dt, h->logit_lw, dt, h->d_logits, V, nullptr, batch, V, dt);
-      g.ln_s = h->logit_ls; g.ln_c = h->logit_lc;
-      HIP_TRY(gemm_f32_nt(g, 1, s));
-    } else {
-      HIP_TRY(layernorm_f32(x, h->dec_ln_w, h->dec_ln_b, h->d_dxn, batch, dt, s));
-      GemmArgs g = gemm(h->d_dxn, dt, h->tok_emb, dt, h->d_logits, V, nullptr, batch, V, dt);
-      g.tiled = fold ? 1 : 0;
-      HIP_TRY(gemm_f32_nt(g, 1, s));
-    }
+    // Vocabulary projection in f32: LayerNorm launch + the 128 x 128 tiled kernel for every batch size.  (Up to 64 clips a
+    // persistent LayerNorm-folded kernel, gemm_vocab_f32_kernel, used to run instead -- ~7 us faster per step, but other
+    // arithmetic than the tiled path of larger batches: a clip's logits then depended, in the last bits, on the size of
+    // the batch it was decoded in.  Mode 0 is the mode the parity claims are made in; one path keeps "alone = in any
+    // batch" exact there too.)
+    HIP_TRY(layernorm_f32(x, h->dec_ln_w, h->dec_ln_b, h->d_dxn, batch, dt, s));
+    GemmArgs g = gemm(h->d_dxn, dt, h->tok_emb, dt, h->d_logits, V, nullptr, batch, V, dt);
+    g.tiled = fold ? 1 : 0;
+    HIP_TRY(gemm_f32_nt(g, 1, s));
   }
   return CRISPY_OK;
 }
@@ -985,7 +978,7 @@ int decoder_logits(crispy_asr* h, int batch, hipStream_t s, const float* x = nul
 //
 // P > 1 (prefill only: host position, folded path): the step covers P consecutive positions pos .. pos + P - 1 of every
 // clip at once -- row = clip * P + j, token ids [batch][P] in h->d_tok.  Every row goes through exactly the arithmetic of
-// the one-position step it replaces (same K split: GemmArgs::m_hint; one attention workgroup per (row, head) with the row's
+// the one-position step it replaces (the skinny GEMMs split K by K alone; one attention workgroup per (row, head) with the row's
 // own key count), so the result is bit-identical to P steps -- at the cost of one.
 int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logits, hipStream_t s, bool embedded = false,
                  int P = 1) {
@@ -1029,7 +1022,6 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
   // for (and dense tensors of a mixed file) go through the scratch slot and the dense kernel.
   auto proj = [&](GemmArgs g, const float* dense32, const void* dense16, const QRef& r, const float* gamma, bool half) -> int {
     g.w_half = half ? 1 : 0;
-    g.m_hint = clips;
     if (!h->resident) {
       g.W = half ? reinterpret_cast<const float*>(dense16) : dense32;
       HIP_TRY(gemm_f32_nt(g, 1, s));
@@ -1131,13 +1123,13 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
     if (fold) {
       GemmArgs g = gemm(h->d_dx, dt, nullptr, dt, h->d_dh, 4L * dt, nullptr, batch, 4 * dt, dt);
       g.ln_s = L.fc1_ls; g.ln_c = L.fc1_lc;
-      g.gelu = 1;
+      g.gelu = h->enc_precision == 1 ? 2 : 1;      // mode 1: ggml's GELU (asr_common.h: gelu_ggml)
       if ((qrc = proj(g, L.fc1_lw, nullptr, L.r_fc1, L.ln2_w, false)) != CRISPY_OK) return qrc;
     } else {
       HIP_TRY(layernorm_f32(h->d_dx, L.ln2_w, L.ln2_b, h->d_dxn, batch, dt, s));
       GemmArgs g = gemm(h->d_dxn, dt, w32(L.fc1_w, L.r_fc1, nullptr), dt, h->d_dh, 4L * dt, L.fc1_b, batch, 4 * dt, dt);
       if (qrc != CRISPY_OK) return qrc;
-      g.gelu = 1;
+      g.gelu = h->enc_precision == 1 ? 2 : 1;
       HIP_TRY(gemm_f32_nt(g, 1, s));
     }
     {

@@ -6,7 +6,7 @@
 // Reference path: transcribe_rs::SpeechModel::transcribe -> whisper.cpp decoder graph (called from
 // src-tauri/src/managers/transcription.rs:183-185, 213-215).
 //
-// In f32 the projection is bound by the f32 matrix pipe (45 us for 64 Whisper-tiny clips, see gemm_vocab_f32_kernel);
+// In f32 the projection is bound by the f32 matrix pipe (45 us for 64 Whisper-tiny clips);
 // with f16 operands the 32x32x16 MFMA is 16 x faster per k and the kernel is the 40 MB stream of E.  So E is stored
 // PACKED in MFMA operand order when the mode is switched on -- tile of 32 vocabulary rows, 16-wide K chunk, lane:
 // 16 bytes -- and a wave's load instruction is one contiguous KB.  256 (or 512) persistent workgroups walk over

@@ -153,7 +153,7 @@ __device__ __forceinline__ void hh_epilogue(const HGemmArgs& g, f32x16 (&acc)[2]
           const int n = n0 + wn + 32 * j + 8 * q + 4 * lh;
           float v0 = acc[i][j][4 * q] + bq[q].x, v1 = acc[i][j][4 * q + 1] + bq[q].y;
           float v2 = acc[i][j][4 * q + 2] + bq[q].z, v3 = acc[i][j][4 * q + 3] + bq[q].w;
-          if (g.gelu) { v0 = gelu_erf_e(v0); v1 = gelu_erf_e(v1); v2 = gelu_erf_e(v2); v3 = gelu_erf_e(v3); }
+          if (g.gelu) { v0 = gelu_ggml(v0); v1 = gelu_ggml(v1); v2 = gelu_ggml(v2); v3 = gelu_ggml(v3); }
           if (m < g.M && n < g.N) *reinterpret_cast<half4*>(C + (long)m * g.ldc + n) = to_half4(v0, v1, v2, v3);
         }
       }
@@ -209,7 +209,7 @@ __device__ __forceinline__ void hh_epilogue(const HGemmArgs& g, f32x16 (&acc)[2]
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int ml = 32 * i + acc_row_e(r0 + r, lane);
-            if (ml < mrem && nok) Ct[ml * ldc + nl] = gelu_erf_e(acc[i][j][r0 + r] + bias) + extra[r];
+            if (ml < mrem && nok) Ct[ml * ldc + nl] = gelu_ggml(acc[i][j][r0 + r] + bias) + extra[r];
           }
         }
       }
@@ -346,7 +346,7 @@ __device__ __forceinline__ void ep_write(const HGemmArgs& g, const f32x16 (&acc)
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         f32x2 v = {acc[j][r] + bias[j], acc[j][r + 1] + bias[j]};
-        if ((EPI == EPI_F16 && g.gelu) || EPI == EPI_TAB) v = gelu_erf_e2(v);
+        if ((EPI == EPI_F16 && g.gelu) || EPI == EPI_TAB) v = f32x2{gelu_ggml(v.x), gelu_ggml(v.y)};
         T[acc_row_e(r, lane) * EP_LD + 32 * j + li] = v.x;
         T[acc_row_e(r + 1, lane) * EP_LD + 32 * j + li] = v.y;
       }

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
         for (int r = 0; r < 8; ++r) {
           const int m = m0 + wm + 32 * i + acc_row_h(r0 + r, lane);
           float v = acc[i][j][r0 + r] + bias;
-          if (g.gelu) v = gelu_erf_h(v);
+          if (g.gelu) v = gelu_ggml(v);       // f16-operand GEMM: precision mode 1 only
           v += extra[r];
           if (m < g.M && n < g.N) C[(long)m * g.ldc + n] = v;
         }

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
           const int dm = wm + 32 * i + acc_row(r0 + r, lane);
           const int m = m0 + dm;
           float v = acc[i][j][r0 + r] + bias;
-          if (g.gelu) v = gelu_erf(v);
+          if (g.gelu) v = g.gelu == 2 ? gelu_ggml(v) : gelu_erf(v);
           v += extra[r];
           if (m >= g.M || n >= g.N) continue;
           if (hm) {
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_f32_kernel(GemmArgs g) {
     } else {
       v += e_c;
     }
-    if (GELU) v = gelu_erf(v);
+    if (GELU) v = g.gelu == 2 ? gelu_ggml(v) : gelu_erf(v);
     if (RES) v += e_res[q];
     if (tid < ET && m < g.M && n0 + (tid & 31) < g.N) {                             // only the stores are predicated
       if (second && g.c2_half) (reinterpret_cast<_Float16*>(g.C2) + coff - g.n_split)[(long)m * ldc + enn] = (_Float16)v;
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_q_kernel(GemmArgs g) {
     } else {
       v += e_c;
     }
-    if (GELU) v = gelu_erf(v);
+    if (GELU) v = g.gelu == 2 ? gelu_ggml(v) : gelu_erf(v);
     if (RES) v += e_res[q];
     if (tid < ET && m < g.M && n0 + (tid & 31) < g.N) {
       if (second && g.c2_half) (reinterpret_cast<_Float16*>(g.C2) + coff - g.n_split)[(long)m * ldc + enn] = (_Float16)v;
@@ -563,164 +563,6 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_q_kernel(GemmArgs g) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Vocabulary projection of a decode step with <= 64 clips: logits[64][V] = x[64][K] . E[V][K]^T, V ~ 51 865, K = 128 KCH.
-// The skinny kernel above spends a workgroup's life on one 32-column tile (request, wait, 96 MFMAs, reduce): 1621
-// short-lived workgroups, 62 us for 80 MB.  Here 256 persistent workgroups (one per CU) keep their share of x in registers for
-// the whole launch (it is the same for every tile), walk over the column tiles and request the next tile's rows of E
-// before the MFMAs of the current one; the cross-wave reduction is double-buffered, one barrier per tile.
-// Same operand order, LayerNorm fold and summation order as the skinny kernel, so the logits are bit-identical to it.
-// Measured 45 us (62 before).  Ablations on the GPU: without the stores 43.6, without the E loads 39.8, with neither
-// epilogue nor reduction 33 -- what is left is 7 tiles x 96 f32 MFMAs per wave at one wave per SIMD (2.6 us per
-// tile = 18 us) behind the launch and the prologue: the f32 matrix pipe, not memory, bounds this projection.
-// ---------------------------------------------------------------------------------------------
-template <int KCH>
-__global__ __launch_bounds__(256) void gemm_vocab_f32_kernel(GemmArgs g) {
-  __shared__ float red[2][4][64 * 33];
-  __shared__ float rstat[4][64][2];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int li = lane & 31, lh = lane >> 5;
-  const int kbeg = wave * 32 * KCH;
-  const float* __restrict__ W = g.W;
-  const float* a0row = g.A + (long)min(li, g.M - 1) * g.lda + kbeg + 16 * lh;
-  const float* a1row = g.A + (long)min(32 + li, g.M - 1) * g.lda + kbeg + 16 * lh;
-  const int ntiles = (g.N + 31) / 32;
-  int tile = blockIdx.x;
-  float4 w[KCH][4];
-  float ls = 0.f, lc = 0.f;                  // epilogue operands of this thread's column, fetched with the tile
-  auto request = [&](int t) {
-    const float* wrow = W + (long)min(t * 32 + li, g.N - 1) * g.ldw + kbeg + 16 * lh;
-#pragma unroll
-    for (int c = 0; c < KCH; ++c)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) w[c][q] = *reinterpret_cast<const float4*>(wrow + 32 * c + 4 * q);
-    const int nn = min(t * 32 + (tid & 31), g.N - 1);
-    ls = g.ln_s ? g.ln_s[nn] : 0.f;
-    lc = g.ln_s ? g.ln_c[nn] : g.bias ? g.bias[nn] : 0.f;
-  };
-  if (tile < ntiles) request(tile);
-  float4 a0[KCH][4], a1[KCH][4];
-  float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
-#pragma unroll
-  for (int c = 0; c < KCH; ++c)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      a0[c][q] = *reinterpret_cast<const float4*>(a0row + 32 * c + 4 * q);   // rows >= M: a clamped (valid) row, whose
-      a1[c][q] = *reinterpret_cast<const float4*>(a1row + 32 * c + 4 * q);   // outputs are never stored -- no branches
-    }
-  if (g.ln_s) {
-    // row statistics in the skinny kernel's order: chunk by chunk, element by element, then half-waves, then waves
-#pragma unroll
-    for (int c = 0; c < KCH; ++c)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float x0[4] = {a0[c][q].x, a0[c][q].y, a0[c][q].z, a0[c][q].w};
-        const float x1[4] = {a1[c][q].x, a1[c][q].y, a1[c][q].z, a1[c][q].w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          s0 += x0[e]; q0 = fmaf(x0[e], x0[e], q0);
-          s1 += x1[e]; q1 = fmaf(x1[e], x1[e], q1);
-        }
-      }
-    s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);
-    s1 += __shfl_xor(s1, 32, 64); q1 += __shfl_xor(q1, 32, 64);
-    if (lh == 0) {
-      rstat[wave][li][0] = s0; rstat[wave][li][1] = q0;
-      rstat[wave][32 + li][0] = s1; rstat[wave][32 + li][1] = q1;
-    }
-  }
-  __syncthreads();
-  float mean[8], rstd[8];                    // of the rows this thread finishes: ml = (tid >> 5) + 8 q, clamped
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int ml = min((tid >> 5) + 8 * q, g.M - 1);
-    mean[q] = 0.f; rstd[q] = 1.f;
-    if (g.ln_s) {
-      const float sum = rstat[0][ml][0] + rstat[1][ml][0] + rstat[2][ml][0] + rstat[3][ml][0];
-      const float sq = rstat[0][ml][1] + rstat[1][ml][1] + rstat[2][ml][1] + rstat[3][ml][1];
-      mean[q] = sum / (float)g.K;
-      const float var = fmaxf(sq / (float)g.K - mean[q] * mean[q], 0.f);
-      rstd[q] = 1.f / sqrtf(var + 1e-5f);
-    }
-  }
-  // Software pipeline over the tiles: the MFMAs of tile i and the epilogue of tile i - 1 (LDS reads of the other
-  // reduction buffer, LayerNorm fold, stores) sit in one basic block -- no branches: out-of-range rows / columns are
-  // clamped, so their threads recompute and re-store an in-range element with the identical value -- and are
-  // interleaved one epilogue row-step per six (KCH = 3) K steps, so the matrix pipe works in the shadow of the
-  // epilogue instead of after it.
-  const int cc = tid & 31;
-  auto epilogue_step = [&](int b, int t, float els, float elc, int q) {
-    const int ml = min((tid >> 5) + 8 * q, g.M - 1);
-    const int c = min(cc, g.N - 1 - t * 32);
-    float v = red[b][0][ml * 33 + c] + red[b][1][ml * 33 + c] + red[b][2][ml * 33 + c] + red[b][3][ml * 33 + c];
-    v = g.ln_s ? rstd[q] * (v - mean[q] * els) + elc : v + elc;
-    g.C[(long)ml * g.ldc + t * 32 + c] = v;
-  };
-  auto mfma_tile = [&](const float4 (&cw)[KCH][4], f32x16& acc0, f32x16& acc1, int eb, int et, float els, float elc, bool epi) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-#pragma unroll
-    for (int c = 0; c < KCH; ++c)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float wv[4] = {cw[c][q].x, cw[c][q].y, cw[c][q].z, cw[c][q].w};
-        const float x0[4] = {a0[c][q].x, a0[c][q].y, a0[c][q].z, a0[c][q].w};
-        const float x1[4] = {a1[c][q].x, a1[c][q].y, a1[c][q].z, a1[c][q].w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[e], wv[e], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[e], wv[e], acc1, 0, 0, 0);
-          const int step = (c * 4 + q) * 4 + e;                       // 0 .. 16 KCH - 1
-          if (epi && step % (2 * KCH) == 2 * KCH - 1) {
-            __builtin_amdgcn_sched_barrier(0);
-            epilogue_step(eb, et, els, elc, step / (2 * KCH));
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-      }
-  };
-  auto park = [&](int b, const f32x16& acc0, const f32x16& acc1) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = acc_row(r, lane);
-      red[b][wave][row * 33 + li] = acc0[r];
-      red[b][wave][(32 + row) * 33 + li] = acc1[r];
-    }
-  };
-  if (tile >= ntiles) return;                // (the grid never exceeds the tile count)
-  const int G = gridDim.x;
-  float pls = ls, plc = lc;
-  int prev_tile = tile;
-  {
-    float4 cw[KCH][4];
-#pragma unroll
-    for (int c = 0; c < KCH; ++c)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) cw[c][q] = w[c][q];
-    request(min(tile + G, ntiles - 1));
-    f32x16 acc0, acc1;
-    mfma_tile(cw, acc0, acc1, 0, 0, 0.f, 0.f, false);
-    park(0, acc0, acc1);
-    __syncthreads();
-  }
-  int buf = 1;
-  for (tile += G; tile < ntiles; tile += G, buf ^= 1) {
-    float4 cw[KCH][4];
-#pragma unroll
-    for (int c = 0; c < KCH; ++c)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) cw[c][q] = w[c][q];
-    const float cls = ls, clc = lc;
-    request(min(tile + G, ntiles - 1));
-    f32x16 acc0, acc1;
-    mfma_tile(cw, acc0, acc1, buf ^ 1, prev_tile, pls, plc, true);
-    park(buf, acc0, acc1);
-    __syncthreads();     // red[buf] complete; every reader of red[buf ^ 1] is behind this barrier too
-    prev_tile = tile; pls = cls; plc = clc;
-  }
-#pragma unroll
-  for (int q = 0; q < 8; ++q) epilogue_step(buf ^ 1, prev_tile, pls, plc, q);
-}
 
 // ---------------------------------------------------------------------------------------------
 // LayerNorm over the last dimension (eps 1e-5), one wave per row; D <= 1280, multiple of 64
@@ -1492,10 +1334,7 @@ bool skinny_q_supported(const GemmArgs& g, int batch) {
 hipError_t gemm_skinny_q(const GemmArgs& g, hipStream_t s) {
   const dim3 grid((g.N + 31) / 32, (g.M + 31) / 32);
   const int kind = (g.ln_s ? 4 : 0) | (g.gelu ? 2 : 0) | (g.residual ? 1 : 0);
-  int nw = 4;
-  const int m_nw = g.m_hint > 0 ? g.m_hint : g.M;
-  if (m_nw <= 64) nw = g.K % 512 == 0 ? 16 : g.K % 384 == 0 ? 12 : g.K % 256 == 0 ? 8 : 4;
-  else if (kind == 1 && g.K >= 1024 && g.K % 512 == 0) nw = 16;
+  const int nw = g.K % 512 == 0 ? 16 : g.K % 384 == 0 ? 12 : g.K % 256 == 0 ? 8 : 4;      // by K alone (see gemm_f32_nt)
   switch (g.wq_type) {
     case QT_Q4_0: return skq_nw<QT_Q4_0>(nw, kind, g.w_half != 0, grid, g, s);
     case QT_Q4_1: return skq_nw<QT_Q4_1>(nw, kind, g.w_half != 0, grid, g, s);
@@ -1506,24 +1345,16 @@ hipError_t gemm_skinny_q(const GemmArgs& g, hipStream_t s) {
   }
 }
 hipError_t gemm_f32_nt(const GemmArgs& g, int batch, hipStream_t s) {
-  if (batch == 1 && g.M <= 64 && g.N >= 8192 && (g.K == 384 || g.K == 512) && !g.rowtab && !g.tiled && !g.C2 && !g.gelu &&
-      !g.residual && !g.c_off_dev) {        // vocabulary projection of a decode step: persistent workgroups
-    const int wgs = min((g.N + 31) / 32, 256);      // 276 registers per lane: one workgroup per CU
-    if (g.K == 384) hipLaunchKernelGGL(gemm_vocab_f32_kernel<3>, dim3(wgs), dim3(256), 0, s, g);
-    else hipLaunchKernelGGL(gemm_vocab_f32_kernel<4>, dim3(wgs), dim3(256), 0, s, g);
-    return hipGetLastError();
-  }
   if (batch == 1 && g.M <= SKINNY_MAX_M && g.K % 128 == 0 && !g.rowtab && !g.tiled) {   // one decode step: latency-bound shape
     const dim3 grid((g.N + 31) / 32, (g.M + 31) / 32);
     const int kind = (g.ln_s ? 4 : 0) | (g.gelu ? 2 : 0) | (g.residual ? 1 : 0);
-    // Ways to split K.  Up to 64 clips the launch is a handful of workgroups and one workgroup's latency is the
-    // launch's: the widest split the width allows (a wave is left with 1 to 5 chunks: 16 to 80 f32 MFMAs instead of
-    // 48 to 160).  Above that the chip is full and the extra partial tiles are only LDS traffic: 4 waves, except for
-    // the MLP's second GEMM (K = 4 d).
-    int nw = 4;
-    const int m_nw = g.m_hint > 0 ? g.m_hint : g.M;      // (the batched prompt step splits K as the one-row steps of its batch do)
-    if (m_nw <= 64) nw = g.K % 512 == 0 ? 16 : g.K % 384 == 0 ? 12 : g.K % 256 == 0 ? 8 : 4;
-    else if (kind == 1 && g.K >= 1024 && g.K % 512 == 0) nw = 16;
+    // Ways to split K: the widest split the width allows (a wave is left with 1 to 5 chunks: 16 to 80 f32 MFMAs instead
+    // of 48 to 160) -- for EVERY row count.  A row's result depends on how K is split (the order its partial sums are
+    // added in), so a split chosen by the number of rows made the arithmetic of a clip depend on the size of the batch it
+    // was decoded in.  (Rounds 1 - 2 used 4 waves above 64 rows, "the chip is full": measured again in round 3 the wide
+    // split is 2 % faster at 128 tiny clips, equal at 256 base clips, 2 % slower at 512 tiny clips.)  With it a clip
+    // decodes to the same bits alone, in a batch of 512, and as a row of a multi-position prompt step.
+    const int nw = g.K % 512 == 0 ? 16 : g.K % 384 == 0 ? 12 : g.K % 256 == 0 ? 8 : 4;
     if (g.w_half) {                          // precision mode 1: f16 weight copy, residual projections only
       if (kind != 1) return hipErrorInvalidValue;
       switch (nw) {

@@ -25,6 +25,21 @@ def _gelu(x):
     return 0.5 * x * (1.0 + erf(x / x.dtype.type(np.sqrt(2.0))))
 
 
+def _gelu_ggml(x):
+    """GELU as ggml's CPU backend computes it [UPSTREAM-RECALL: ggml_vec_gelu_f32 under GGML_GELU_FP16]: a table indexed
+    by the f16 bit pattern of x whose entry is f16(ggml_gelu_f32(x)) = f16(0.5 x (1 + tanhf(sqrt(2 / pi) x (1 + 0.044715
+    x^2)))) evaluated in f32; x <= -10 -> 0 and x >= 10 -> x in front of the look-up.  The table memoises a pure function,
+    so it is evaluated directly here.  Used by the f16-operand (precision mode 1) chain; the exact oracle keeps erf."""
+    x = np.asarray(x)
+    xf = x.astype(np.float32)
+    xh = xf.astype(np.float16).astype(np.float32)
+    one, a, s2pi, half = np.float32(1.0), np.float32(0.044715), np.float32(0.79788456080286535587989211986876), np.float32(0.5)
+    with np.errstate(over="ignore"):
+        y = (half * xh * (one + np.tanh(s2pi * xh * (one + a * xh * xh)))).astype(np.float16).astype(np.float32)
+    y = np.where(xf <= -10.0, np.float32(0.0), np.where(xf >= 10.0, xf, y))
+    return y.astype(x.dtype)
+
+
 def _ln(x, w, b, eps=1e-5):
     mu = x.mean(-1, keepdims=True)
     var = ((x - mu) ** 2).mean(-1, keepdims=True)
@@ -88,8 +103,8 @@ def encoder_forward_f16(weights, hp, mel):
     """The encoder with the numerics of whisper.cpp's ggml matrix products [UPSTREAM-RECALL] -- what precision mode 1 of
     the library implements: every matrix product takes BOTH operands rounded to f16 (the 2-D weights, and the
     activation that enters the product) and accumulates exactly (float64 here, f32 on the matrix cores; the difference
-    is ~1e-6 of the result); everything else -- biases, GELU, LayerNorm statistics, soft-max, the residual stream -- is
-    f32 / exact.  Rounding points, in graph order:
+    is ~1e-6 of the result); GELU is ggml's (`_gelu_ggml`: the f16-indexed table of the tanh form); everything else --
+    biases, LayerNorm statistics, soft-max, the residual stream -- is f32 / exact.  Rounding points, in graph order:
       conv1   the log-mel frames and the conv1 kernel rounded (ggml: im2col in f16 x f16 kernel)
       conv2   GELU(conv1) and the conv2 kernel rounded
       block   LN(x) rounded -> q, k, v products; q, k, v rounded (+bias first); soft-max probabilities rounded as
@@ -103,11 +118,11 @@ def encoder_forward_f16(weights, hp, mel):
     xp = np.pad(x, ((0, 0), (1, 1)))
     w1 = _h(W["encoder.conv1.weight"])
     h1 = sum(w1[:, :, k] @ xp[:, k:k + 3000] for k in range(3)) + W["encoder.conv1.bias"][:, None]
-    h1 = _h(_gelu(h1))
+    h1 = _h(_gelu_ggml(h1))
     hp1 = np.pad(h1, ((0, 0), (1, 1)))
     w2 = _h(W["encoder.conv2.weight"])
     h2 = sum(w2[:, :, k] @ hp1[:, k:k + 3000:2][:, :1500] for k in range(3)) + W["encoder.conv2.bias"][:, None]
-    x = _gelu(h2).T + W["encoder.positional_embedding"]
+    x = _gelu_ggml(h2).T + W["encoder.positional_embedding"]
     H = hp.n_audio_head
     for i in range(hp.n_audio_layer):
         p = f"encoder.blocks.{i}"
@@ -124,7 +139,7 @@ def encoder_forward_f16(weights, hp, mel):
             att[:, sl] = (_h(pe) @ v[:, sl]) / pe.sum(-1, keepdims=True)
         x = x + _h(att) @ _h(W[p + ".attn.out.weight"]).T + W[p + ".attn.out.bias"]
         xn = _h(_ln(x, W[p + ".mlp_ln.weight"], W[p + ".mlp_ln.bias"]))
-        hid = _h(_gelu(xn @ _h(W[p + ".mlp.0.weight"]).T + W[p + ".mlp.0.bias"]))
+        hid = _h(_gelu_ggml(xn @ _h(W[p + ".mlp.0.weight"]).T + W[p + ".mlp.0.bias"]))
         x = x + hid @ _h(W[p + ".mlp.2.weight"]).T + W[p + ".mlp.2.bias"]
     return _ln(x, W["encoder.ln_post.weight"], W["encoder.ln_post.bias"])
 
@@ -249,7 +264,8 @@ class DecoderCache:
             q = xn @ W[p + ".cross_attn.query.weight"].T + W[p + ".cross_attn.query.bias"]
             x = x + r(self._att(q, self.xk[i], self.xv[i])) @ r(W[p + ".cross_attn.out.weight"]).T + W[p + ".cross_attn.out.bias"]
             xn = _ln(x, W[p + ".mlp_ln.weight"], W[p + ".mlp_ln.bias"])
-            x = x + r(_gelu(xn @ W[p + ".mlp.0.weight"].T + W[p + ".mlp.0.bias"])) @ r(W[p + ".mlp.2.weight"]).T + W[p + ".mlp.2.bias"]
+            g = (_gelu_ggml if self.f16 else _gelu)(xn @ W[p + ".mlp.0.weight"].T + W[p + ".mlp.0.bias"])
+            x = x + r(g) @ r(W[p + ".mlp.2.weight"]).T + W[p + ".mlp.2.bias"]
         self.pos += 1
         x = _ln(x, W["decoder.ln.weight"], W["decoder.ln.bias"])
         return r(x) @ r(W["decoder.token_embedding.weight"]).T

@@ -175,7 +175,7 @@ def test_f16_encoder_kernels_run_at_four_waves_per_simd_without_scratch(tmp_path
 def test_asr_kernels_have_no_scratch_at_all(tmp_path, src_name):
     """with this compiler a VGPR spill next to a divergent region is a correctness hazard (see the
     module docstring), and the decode-step kernels -- gemm_skinny_f32_kernel (every LayerNorm / GELU / residual / K-split /
-    f16-weight form), attn_dec_kernel, attn_dec_x16_kernel, vocab_f16_kernel, gemm_vocab_f32_kernel, argmax_kernel,
+    f16-weight form), attn_dec_kernel, attn_dec_x16_kernel, vocab_f16_kernel, argmax_kernel,
     ts_pick_kernel -- are full of predicated epilogues.  Six skinny forms used to park their epilogue operands in scratch;
     they request them after the K loop now.  The rule for every ASR kernel file: ScratchSize == 0 and no spilled VGPR."""
     src = os.path.join(ROOT, "crispy_amd", "csrc", src_name)
@@ -196,7 +196,7 @@ def test_asr_kernels_have_no_scratch_at_all(tmp_path, src_name):
             res[cur][m.group(1).strip()] = int(m.group(2))
     assert res, out.stderr[-500:]
     if src_name == "whisper_kernels.hip":
-        for must in ("gemm_skinny_f32_kernel", "ts_pick_kernel", "argmax_kernel", "attn_dec_kernel", "gemm_vocab_f32_kernel"):
+        for must in ("gemm_skinny_f32_kernel", "ts_pick_kernel", "argmax_kernel", "attn_dec_kernel"):
             assert any(must in k for k in res), (must, list(res))
         assert sum("gemm_skinny_f32_kernel" in k for k in res) == 36      # 8 epilogue forms x 4 K splits + 4 f16-weight forms
         assert sum("attn_dec_x16_kernel" in k for k in res) == 5           # 1 / 2 / 4 / 12 key slots per wave + the non-temporal 12 (K|V streams of many clips)

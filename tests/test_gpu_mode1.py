@@ -13,8 +13,10 @@ only the prefix up to the first close call.  Two assertions per step: (1) the GP
 below the oracle's best logit; (2) where the oracle's own top-2 margin exceeds `thr` the ids are equal -- and a minimum
 number of such resolvable steps is required (a margin-gated loop that compares nothing proves nothing).
 `thr` derives from the measured bar of the mode: a picked logit agrees with the f16 oracle to 4e-4 of the logit scale at
-the worst value (tests/test_gpu_whisper.py::test_mode_1_decoder_matches_the_f16_arithmetic_oracle), the chained encoder
-adds about as much again, so thr = MODE1_REL x scale with MODE1_REL = 4 x 4e-4.
+the worst value (tests/test_gpu_whisper.py::test_mode_1_decoder_matches_the_f16_arithmetic_oracle), so thr = MODE1_REL x
+scale with MODE1_REL = 4 x 4e-4 wherever the oracle decoder runs on the SAME encoder output as the product's.  The full
+chain (oracle encoder -> oracle decoder) is compared too, at rel = 0.03: the audio-sensitive weights amplify the encoder's
+3e-4 into logit-gap changes of ~1e-2 (see test_mode1_transcribe_tokens_against_the_chained_f16_oracle).
 
 Weights: `synthetic_whisper_weights(..., sensitive=True)` -- sharpened cross-attention, so that the picks depend on the
 audio (the tests assert that different clips decode to different ids)."""
@@ -90,8 +92,21 @@ def test_mode1_transcribe_tokens_against_the_chained_f16_oracle(oracle, name):
         solo, _ = m.transcribe_tokens([c], prompt, n_new)
         assert np.array_equal(solo[0], toks[b]), (name, b)              # batch == solo in mode 1
         enc16 = WO.encoder_forward_f16(W, hp, oracle.oracle_logmel(c, F))
-        k, worst = forced_picks(W, hp, enc16, prompt, toks[b], need, f"{name} clip {b}")
-        print(f"mode 1 {name} clip {b}: {k} of {n_new} picks resolvable, worst shortfall {worst:.2e}, ids {toks[b].tolist()}")
+        # (1) the encoder half of the chain: the product's own encoder output against the f16 oracle, at the encoder's bar
+        enc_gpu = m.encode([c])[0]
+        e_err = float(np.abs(enc_gpu - enc16).max() / np.abs(enc16).max())
+        e_bar = 4e-4 * float(np.sqrt(hp.n_audio_layer / 4.0))        # 4e-4 is the 4-layer figure; roundings add in quadrature
+        assert e_err <= e_bar, (name, b, e_err, e_bar)
+        # (2) the decoder half at the decoder's bar: teacher-forced oracle decoder ON THE PRODUCT'S encoder output
+        k, worst = forced_picks(W, hp, enc_gpu.astype(np.float64), prompt, toks[b], need, f"{name} clip {b} (decoder)")
+        # (3) the chain against the oracle's own encoder output.  These weights are audio-SENSITIVE on purpose (the ids must
+        # depend on the clip), and they amplify: an encoder difference of 3e-4 of the peak moves the gap between two logits
+        # by up to 0.014 here (tools/diag_mode1_long.py, clip 300: the oracle decoder itself picks 44116 on the product's
+        # encoder output and 47822 on the oracle's, margins 0.0075 and 0.0066).  So the chain is held to the bar the cfg 4
+        # test uses for the same reason (tests/test_gpu_pipeline.py): 0.03 of the logit scale, every step compared.
+        kc, worst_c = forced_picks(W, hp, enc16, prompt, toks[b], 1, f"{name} clip {b} (chain)", rel=0.03)
+        print(f"mode 1 {name} clip {b}: encoder {e_err:.2e} of the peak; decoder {k} of {n_new} picks resolvable, worst shortfall "
+              f"{worst:.2e}; chain worst shortfall {worst_c:.2e}; ids {toks[b].tolist()}")
         total += k
     if len(clips) > 1:
         assert len({tuple(t.tolist()) for t in toks}) == len(clips), toks     # the ids depend on the audio

@@ -38,7 +38,9 @@ def test_resident_model_equals_the_inflated_one(tiny, tmp_path, kind):
     dense_f16_emb = 2 * hp.n_vocab * hp.n_text_state
     assert mr["weight_bytes"] < mr["quantised_bytes"] + 1.3 * dense_f16_emb + 8e6, mr     # + packed f16 embedding + convs / vectors
     # (Whisper-tiny is the worst case: the 51 865 x 384 embedding is half of its matrices and stays once more as f16)
-    assert mr["weight_bytes"] < 0.3 * mi["weight_bytes"], (mr, mi)
+    # (0.36, not 0.3: the inflated engine no longer keeps a LayerNorm-folded f32 copy of the embedding for its logits,
+    # 80 MB of its former 335 MB at Whisper-tiny)
+    assert mr["weight_bytes"] < 0.36 * mi["weight_bytes"], (mr, mi)
     print(f"{kind}: file {os.path.getsize(path) / 1e6:.1f} MB, resident {mr['weight_bytes'] / 1e6:.1f} MB "
           f"(blocks {mr['quantised_bytes'] / 1e6:.1f}), inflated + f16 copies {mi['weight_bytes'] / 1e6:.1f} MB")
     with pytest.raises(N.CrispyError) as e:

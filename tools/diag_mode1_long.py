@@ -17,7 +17,7 @@ hp = HParams.tiny()
 W = synthetic_whisper_weights(hp, 0, sensitive=sens)
 m = WhisperModel(hp, W)
 m.set_precision(prec)
-x = synth_audio.clip16k_np(7, 300000)
+x = synth_audio.clip16k_np(int(os.environ.get("CLIP_SEED", 7)), int(os.environ.get("CLIP_N", 300000)))
 prompt = [50258, 50259, 50359, 50363]
 mel = O.oracle_logmel(x, whisper_mel_filters(80))
 enc_ref = (WO.encoder_forward_f16 if prec else WO.encoder_forward)(W, hp, mel)
