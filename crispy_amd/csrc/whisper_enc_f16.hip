@@ -32,40 +32,9 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 
 constexpr int HH_M = 128, HH_N = 128, HH_K = 32, HH_LD = 40;
 
-// erf-GELU with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, three orders of magnitude below the f16
-// rounding the result goes through): one v_rcp, one v_exp and ten full-rate operations.  The library erff costs ~40
-// VALU instructions per element, and with K = 384 the fc1 GEMM spent 70 % of its time in its epilogue.
-__device__ __forceinline__ float gelu_erf_e(float x) {
-  const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  p *= t;
-  const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);     // exp(-x^2 / 2)
-  const float erfa = fmaf(-p, e, 1.f);                                        // erf(|x| / sqrt 2)
-  return 0.5f * x * (1.f + __builtin_copysignf(erfa, x));
-}
-// The same for two values at once on the packed f32 instructions (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth of work
-// per issue slot): 22 instead of 37 instructions per pair, element for element the same operations and roundings.
-// GELU was 97 cycles per value and lane, 12.4 k of the 23.4 k cycles of an fc1 epilogue.
+// GELU: ggml's form (asr_common.h: gelu_ggml).  (Rounds 1 - 2 used the exact erf form here -- Abramowitz & Stegun 7.1.26,
+// on packed f32 instructions: 97 cycles per value and lane, 12.4 k of the 23.4 k cycles of an fc1 epilogue.)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 gelu_erf_e2(f32x2 x) {
-  const f32x2 z = __builtin_elementwise_abs(x) * 0.70710678118654752f;
-  const f32x2 d = __builtin_elementwise_fma((f32x2)(0.3275911f), z, (f32x2)(1.f));
-  const f32x2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-  f32x2 p = __builtin_elementwise_fma((f32x2)(1.061405429f), t, (f32x2)(-1.453152027f));
-  p = __builtin_elementwise_fma(p, t, (f32x2)(1.421413741f));
-  p = __builtin_elementwise_fma(p, t, (f32x2)(-0.284496736f));
-  p = __builtin_elementwise_fma(p, t, (f32x2)(0.254829592f));
-  p = p * t;
-  const f32x2 a = x * x * -0.72134752044448170f;
-  const f32x2 e = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
-  const f32x2 erfa = __builtin_elementwise_fma(-p, e, (f32x2)(1.f));
-  const f32x2 cs = {__builtin_copysignf(erfa.x, x.x), __builtin_copysignf(erfa.y, x.y)};
-  return 0.5f * x * (1.f + cs);
-}
 // row index of accumulator register r for this lane (32 x 32 MFMA C / D layout)
 __device__ __forceinline__ int acc_row_e(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 __device__ __forceinline__ half4 to_half4(float a, float b, float c, float d) {

@@ -20,7 +20,6 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 constexpr int HB_M = 128, HB_N = 128, HB_K = 32, HB_LD = 40;
 
-__device__ __forceinline__ float gelu_erf_h(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ int acc_row_h(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void gemm_f16_nt_kernel(GemmArgs g, const _Float16* __restrict__ Wh) {
