@@ -98,6 +98,34 @@ void build_tables(RnTables* t) {
       t->bin_frac[eband[i] * 4 + j] = (float)j / (float)bs;   // same f32 division as the reference
     }
   }
+  // band_piece (rn_common.h): lane 0 stays idle = the "zero" source of the two half-bands that do not exist (rising
+  // half of band 0, falling half of band 21)
+  {
+    int piece[64] = {0}, head[2][RN_NB];
+    for (int b = 0; b < RN_NB; ++b) head[0][b] = head[1][b] = 0;
+    int lane = 1;
+    for (int side = 0; side < 2; ++side)          // 0: rising halves (part_hi), 1: falling halves (part_lo)
+      for (int b = 0; b < RN_NB; ++b) {
+        const int c0 = side == 0 ? (b > 0 ? eband[b - 1] : 0) : eband[b];
+        const int c1 = side == 0 ? eband[b] : (b < RN_NB - 1 ? eband[b + 1] : eband[b]);
+        const int w = (side == 0 && b == 0) ? 0 : c1 - c0;
+        if (w <= 0) continue;
+        const int np = (w + 5) / 6;                                  // <= 4 pieces (w <= 22)
+        if ((lane & 15) + np > 16) lane = (lane + 15) & ~15;         // a half's pieces stay inside one DPP row
+        if (np > 4 || lane + np > 64) std::abort();                  // (cannot happen with the Opus band table)
+        head[side][b] = lane;
+        for (int p = 0, c = c0; p < np; ++p) {
+          const int n = (w - (c - c0) + (np - p) - 1) / (np - p);    // balanced: 22 -> 6, 6, 5, 5
+          piece[lane + p] = c | (n << 7) | (side << 10) | ((p + 1 < np ? 1 : 0) << 11) | ((p == 0 && np > 2 ? 1 : 0) << 12);
+          c += n;
+        }
+        lane += np;
+      }
+    for (int l = 0; l < 64; ++l) {
+      const int b = l < RN_NB ? l : 0;
+      t->band_piece[l] = piece[l] | (head[0][b] << 13) | (head[1][b] << 19);
+    }
+  }
 }
 
 // [K][rows] int8 (row stride `stride`) -> f16 [ceil(K/8)][rows][8]; dst in 16-byte units (4 dwords)

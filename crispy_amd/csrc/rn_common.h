@@ -27,6 +27,12 @@ struct RnTables {
   float bin_frac[400];        // position of bin inside its Opus band, j / band_size
   int bin_band[400];          // band index of every bin below 20 kHz
   int eband[24];              // band edges in 4-bin chunks (22 used)
+  // band_sum (rn_kernels.hip, round 3): the 42 non-empty half-bands -- rising half of band b = chunk partials
+  // part_hi[e(b-1) .. e(b)), falling half = part_lo[e(b) .. e(b+1)) -- cut into pieces of <= 6 chunks, one piece per lane,
+  // the pieces of a half on neighbouring lanes of one 16-lane row.  band_piece[lane] packs
+  //   bits 0-6 first chunk | 7-9 chunks (0: idle lane) | 10 part_lo (else part_hi) | 11 add lane + 1 | 12 then add lane + 2
+  //   | 13-18 lane holding the total of the rising half of band `lane` | 19-24 ... of the falling half (lanes < 22)
+  int band_piece[64];
 };
 
 // Flat blob offsets.

@@ -352,12 +352,19 @@ __device__ __forceinline__ void real_inv_pre(float2* buf, const float2* __restri
   __syncthreads();
 }
 
+#ifndef RN_BAND_SPLIT
+#define RN_BAND_SPLIT 2      // 0: round 2 (lane == band, 48 steps); 1: two lanes per band (24 steps); 2: pieces of <= 6 chunks
+#endif
 // ---------------------------------------------------------------------------------------------
 // Opus-band helpers (Appendix A.3 step 2).  `part` is 200 floats of scratch; e0/e1/em1 are this
 // lane's band edges (band = lane) in 4-bin chunks, loaded once per kernel.
 // ---------------------------------------------------------------------------------------------
 struct BandEdges {
+#if RN_BAND_SPLIT == 2
+  int piece;           // RnTables::band_piece[lane]
+#else
   int em1, e0, e1;
+#endif
 };
 
 // Sum of one band's chunk partials: part_hi[c] for c in [em1, e0) -- the rising half of the previous interval -- plus
@@ -372,11 +379,36 @@ struct BandEdges {
 #ifndef RN_BAND_BATCH
 #define RN_BAND_BATCH 8
 #endif
-#ifndef RN_BAND_SPLIT
-#define RN_BAND_SPLIT 1
-#endif
 __device__ __forceinline__ float band_sum(const float* part_lo, const float* part_hi, const BandEdges& be, int lane) {
-#if !RN_BAND_SPLIT
+#if RN_BAND_SPLIT == 2
+  // Round 3, second form.  A band is up to 22 + 22 chunk partials but most are 1 - 4: with one or two lanes per band the
+  // wave ran the longest band's 24 select-and-add steps (3 instructions and an LDS read each) for every band.  Here the 42
+  // half-bands are cut into 56 pieces of <= 6 chunks, one per lane (RnTables::band_piece, built on the host): 6 steps, then
+  // the <= 4 pieces of a half -- neighbouring lanes of one DPP row -- are joined by two shifted adds, and lane == band
+  // fetches its two halves with two ds_bpermute.  ~40 instructions and 8 LDS operations per call instead of ~84 and 25.
+  int bd = be.piece;
+  asm volatile("" : "+v"(bd));      // (laundered: the tests below are invariant across frames, and hoisted out of the frame
+                                    // loop they become lane masks in SGPRs that spill -- see the comment above)
+  const int n = (bd >> 7) & 7;
+  const float* p = ((bd >> 10) & 1 ? part_lo : part_hi) + (bd & 127);
+  float v[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) v[k] = p[k];          // (up to five floats past the piece: still this workgroup's LDS)
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) s += k < n ? v[k] : 0.f;
+  {
+    const float t1 = dpp_mov<0x101>(s);             // row_shl:1 -- the next lane's piece (0 past the row's end)
+    s += (bd >> 11) & 1 ? t1 : 0.f;
+    const float t2 = dpp_mov<0x102>(s);             // row_shl:2
+    s += (bd >> 12) & 1 ? t2 : 0.f;
+  }
+  const float rise = __int_as_float(__builtin_amdgcn_ds_bpermute(((bd >> 13) & 63) << 2, __float_as_int(s)));
+  const float fall = __int_as_float(__builtin_amdgcn_ds_bpermute(((bd >> 19) & 63) << 2, __float_as_int(s)));
+  float tot = rise + fall;                           // lanes >= RN_NB: band 0's value, never used
+  if (lane == 0 || lane == RN_NB - 1) tot *= 2.f;
+  return tot;
+#elif !RN_BAND_SPLIT
   // round-2 form (A/B builds): lane == band adds both halves, 48 select-and-add steps
   float s_old = 0.f;
   const int n_hi = lane > 0 && lane < RN_NB ? be.e0 - be.em1 : 0;
@@ -401,7 +433,7 @@ __device__ __forceinline__ float band_sum(const float* part_lo, const float* par
   }
   if (lane == 0 || lane == RN_NB - 1) s_old *= 2.f;
   return s_old;
-#endif
+#else
   const int band = lane & 31;               // (be holds the edges of band min(lane & 31, RN_NB - 1))
   const bool falling = lane >= 32;
   int n = falling ? (band < RN_NB - 1 ? be.e1 - be.e0 : 0) : (band > 0 ? be.e0 - be.em1 : 0);
@@ -420,6 +452,7 @@ __device__ __forceinline__ float band_sum(const float* part_lo, const float* par
   sum += __shfl(sum, (lane + 32) & 63, WAVE);       // rising + falling half (lanes >= 32 receive garbage: never used)
   if (lane == 0 || lane == RN_NB - 1) sum *= 2.f;
   return sum;
+#endif
 }
 
 // Band energies in the pair layout of the comb-filter stage: lane handles bins (2p, 2p+1), p = lane + 64 m, with
@@ -1341,10 +1374,14 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
   float lastg = lane < RN_NB ? a.lastg[(long)b * RN_NB + lane] : 0.f;
   BandEdges be;
   {
+#if RN_BAND_SPLIT == 2
+    be.piece = tab->band_piece[lane0];
+#else
     const int i = min(lane & 31, RN_NB - 1);       // lanes 32..53 work on the falling halves of bands 0..21 (band_sum)
     be.e0 = tab->eband[i];
     be.e1 = tab->eband[i + 1];
     be.em1 = tab->eband[max(i - 1, 0)];
+#endif
   }
   int memid = a.memid[b];
   int last_period = a.last_period[b];
