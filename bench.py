@@ -826,18 +826,18 @@ def cfg2(args):
             except Exception as e:
                 traffic_src = {"how": "committed profile (live measurement failed)", "error": str(e)[:200]}
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r03d_pmc.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r03e_pmc.json")))
             if pm["config"]["streams"] == B:
                 fk = pm["rn_frame_kernel"]
                 sf = B * T / launches                        # stream-frames per (average) launch
                 if traffic is None:
                     traffic = int(fk["hbm_bytes_per_stream_frame"] * sf)
-                    traffic_src = dict(traffic_src or {}, file="profiles/r03d_pmc.json")
+                    traffic_src = dict(traffic_src or {}, file="profiles/r03e_pmc.json")
                 # what actually bounds this kernel: VALU issue slots.  SQ_ACTIVE_INST_VALU counts 4-cycle issue
                 # slots; 1024 SIMDs; priced against the live kernel time at the 2.4 GHz peak clock.
                 valu = {"insts_per_stream_frame": fk["insts_per_stream_frame"]["valu"],
                         "issue_frac": fk["valu_active_quads_per_stream_frame"] * sf * 4 / (1024 * frame_ms * 1e-3 * 2.4e9),
-                        "source": "profiles/r03d_pmc.json (rocprofv3 --pmc SQ_ACTIVE_INST_VALU), live kernel time"}
+                        "source": "profiles/r03e_pmc.json (rocprofv3 --pmc SQ_ACTIVE_INST_VALU), live kernel time"}
         except Exception:
             pass
         achieved = alg_bytes / (frame_ms * 1e-3) / 1e9
