@@ -999,7 +999,10 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
   // step to step (plain loads: 16 tiny clips = 147 MB, 6.8 ms per call against 7.0 non-temporal); beyond that it is a
   // one-pass stream that only evicts the decoder's weights from the L2s, and is requested non-temporally
   // (AttnRows::stream_kv: 64 tiny clips 11.2 -> 10.3 ms, 256 base clips 46.7 -> 44.2 ms).
-  cross_rows.stream_kv = (size_t)clips * h->dec.size() * Tn * 2 * dt * (h->enc_precision == 1 ? 2 : 4) > ((size_t)256 << 20) ? 1 : 0;
+  // (not in a multi-position prompt step: the P rows of a clip read the same K|V one after the other, and the repeats are
+  // served by the Infinity Cache only if the first read allocates there: 2.06 vs 2.18 ms for the prompt of 128 clips)
+  static const bool prompt_nt = std::getenv("CRISPY_XKV_PROMPT_NT") != nullptr;      // developer A/B (tools/ab_prompt_nt.sh)
+  cross_rows.stream_kv = (P == 1 || prompt_nt) && (size_t)clips * h->dec.size() * Tn * 2 * dt * (h->enc_precision == 1 ? 2 : 4) > ((size_t)256 << 20) ? 1 : 0;
   if (!embedded) {    // (a fused pick has written the residual stream already)
     if (h->resident)
       HIP_TRY(embed_tokens_q(h->d_tok, h->q_tok_emb->d, h->q_tok_emb->ttype, h->dec_pos, pos, pos_dev, h->d_dx, batch, dt, s, P));
