@@ -3,7 +3,8 @@ positions of every clip in one pass through the decoder instead of P passes.  Th
 exactly the arithmetic of the one-position step it replaces -- so the test is too: token ids AND the picked logits of
 the following greedy decode are BIT-identical to the position-by-position prefill (CRISPY_ASR_PREFILL=seq), in both
 precision modes, for one clip, a few, a full row range (64 x 4 = 256 rows), a chunked prompt (200 clips: 2 + 2
-positions; a 37-token prompt of 20 clips: 25 + 12) and per-clip language tokens."""
+positions; a 37-token prompt of 20 clips: 25 + 12; the longest conditioned prompt, 228 tokens, of one clip in one step and
+of three clips in 170 + 58) and per-clip language tokens."""
 import os
 
 import numpy as np
@@ -36,7 +37,7 @@ def _both(fn):
 
 
 @pytest.mark.parametrize("precision", [0, 1])
-@pytest.mark.parametrize("clips,n_prompt", [(1, 4), (3, 4), (64, 4), (200, 4), (1, 37), (20, 37)])
+@pytest.mark.parametrize("clips,n_prompt", [(1, 4), (3, 4), (64, 4), (200, 4), (1, 37), (20, 37), (1, 228), (3, 228)])
 def test_prompt_steps_are_bit_identical_to_the_position_by_position_prefill(model, precision, clips, n_prompt):
     import torch
     model.set_precision(precision)
