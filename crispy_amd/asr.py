@@ -137,8 +137,9 @@ class WhisperModel:
         return {"weight_bytes": w.value, "quantised_bytes": q.value, "scratch_bytes": sc.value}
 
     def set_precision(self, mode: int):
-        """0: f32 operands (default, the mode the oracle parity is pinned in); 1: f16 operands / f32 accumulation for
-        the encoder GEMMs (whisper.cpp's ggml numerics)."""
+        """0: f32 operands (default, the mode the oracle parity is pinned in); 1: f16 operands / f32 accumulation
+        (whisper.cpp's ggml numerics); 2: mode 1 + the decoder's LayerNorm outputs rounded to f16 in front of q | k | v,
+        cross q and fc1 (ggml's rounding points for those products too; opt-in)."""
         N.check(N.lib().crispy_asr_set_precision(self._h, int(mode)))
 
     def stage_logits_device(self, d_x: int, batch: int, d_logits: int):

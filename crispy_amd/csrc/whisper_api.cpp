@@ -53,6 +53,7 @@ struct DecLayer {
   const float *lnx_w, *lnx_b, *xq_w, *xq_b, *xkv_w, *xkv_b, *xout_w, *xout_b;
   const void* xkv_wh = nullptr;              // f16 copy of the fused cross K|V projection (precision mode 1)
   const void *out_wh = nullptr, *xout_wh = nullptr, *fc2_wh = nullptr;   // f16 copies of the plain (no LayerNorm in front) decode projections
+  const void *qkv_wh = nullptr, *xq_wh = nullptr, *fc1_wh = nullptr;     // f16 copies of the un-folded q | k | v, cross-q, fc1 (precision mode 2)
   const float *ln2_w, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
   // LayerNorm folded into the consuming projection (decode steps with <= 64 clips): gamma-scaled weights, their row
   // sums and beta.W + bias (GemmArgs::ln_s / ln_c)
@@ -85,6 +86,9 @@ struct crispy_asr {
   const void* conv1_wh = nullptr;            // f16 conv1 kernel, rows zero-padded to conv1_kp columns
   int conv1_kp = 0;
   int enc_precision = 0;                     // 0: f32 operands (default), 1: f16 operands for the encoder GEMMs
+  bool dec_ln16 = false;                     // precision mode 2 = mode 1 + the decoder's LayerNorm output rounded to f16 in front of
+                                             // q | k | v, cross q and fc1 (f16 weights): ggml's rounding points, three launches more per layer
+  bool ln16_ready = false;
   bool half_ready = false;                   // every f16 weight copy of mode 1 exists (set after the last one and a stream sync)
   int xcd_swizzle = 1;                       // mode 1 GEMMs: column tiles of a row tile on one XCD (CRISPY_ASR_XCD=0 turns it off)
   std::vector<EncLayer> enc;
@@ -669,9 +673,12 @@ int crispy_asr_hparams_get(const crispy_asr* h, crispy_asr_hparams* out) try {
 int crispy_asr_set_precision(crispy_asr* h, int mode) try {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_set_precision: NULL handle");
   if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_set_precision: model not finalized");
-  if (mode != 0 && mode != 1) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_set_precision: mode must be 0 (f32) or 1 (f16 encoder GEMM operands)");
+  if (mode < 0 || mode > 2)
+    return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_set_precision: mode must be 0 (f32), 1 (f16 operands) or 2 (1 + f16 LayerNorm outputs in the decoder)");
   HIP_TRY(hipSetDevice(h->device));
-  if (h->resident && mode != 1)
+  const bool want_ln16 = mode == 2;
+  if (mode == 2) mode = 1;
+  if (h->resident && (mode != 1 || want_ln16))
     return fail(CRISPY_ERR_UNSUPPORTED, "crispy_asr_set_precision: a resident quantised model runs in precision mode 1 only "
                 "(its matrices exist as f16 operands at the point of use, never as f32 tensors)");
   if (mode == 1 && !h->half_ready) {
@@ -730,11 +737,34 @@ int crispy_asr_set_precision(crispy_asr* h, int mode) try {
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->half_ready = true;
   }
-  if (h->enc_precision != mode) {   // the captured decode steps bake the cross-attention kernel in
+  if (want_ln16 && !h->ln16_ready) {
+    // f16 copies of the decoder's q | k | v, cross-q and fc1 weights (un-folded: the LayerNorm runs as a launch of its own)
+    const size_t dtt = h->hp.n_text_state;
+    auto half_copy = [&](const float* w, size_t n, const void** out) -> int {
+      void* p = nullptr;
+      HIP_TRY(hipMalloc(&p, n * 2));
+      h->derived.push_back(reinterpret_cast<float*>(p));
+      h->derived_bytes += n * 2;
+      HIP_TRY(convert_f32_to_f16(w, p, (long)n, h->stream));
+      *out = p;
+      return CRISPY_OK;
+    };
+    int rc = CRISPY_OK;
+    for (DecLayer& L : h->dec) {
+      if (rc == CRISPY_OK) rc = half_copy(L.qkv_w, 3 * dtt * dtt, &L.qkv_wh);
+      if (rc == CRISPY_OK) rc = half_copy(L.xq_w, dtt * dtt, &L.xq_wh);
+      if (rc == CRISPY_OK) rc = half_copy(L.fc1_w, 4 * dtt * dtt, &L.fc1_wh);
+    }
+    if (rc != CRISPY_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->ln16_ready = true;
+  }
+  if (h->enc_precision != mode || h->dec_ln16 != want_ln16) {   // the captured decode steps bake the kernels in
     if (h->dec_graph) { (void)hipGraphExecDestroy(h->dec_graph); h->dec_graph = nullptr; h->dec_graph_batch = 0; }
     if (h->ts_graph) { (void)hipGraphExecDestroy(h->ts_graph); h->ts_graph = nullptr; h->ts_graph_batch = 0; }
   }
   h->enc_precision = mode;
+  h->dec_ln16 = want_ln16;
   return CRISPY_OK;
 } CRISPY_CATCH_RET("crispy_asr_set_precision")
 
@@ -1059,8 +1089,12 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
     const bool kv16 = fold && h->enc_precision == 1 && h->dec_max_keys > 0 && h->dec_max_keys <= 512;
     _Float16* selfkv_h = reinterpret_cast<_Float16*>(h->d_selfkv) + l * (size_t)clips * C * 2 * dt;
     if (fold) {
-      GemmArgs g = gemm(h->d_dx, dt, nullptr, dt, h->d_dq, dt, nullptr, batch, 3 * dt, dt);
-      g.ln_s = L.qkv_ls; g.ln_c = L.qkv_lc;
+      // precision mode 2: LayerNorm as a launch of its own, its output rounded to f16 on the way into the f16 matrix cores
+      // against f16 weights (ggml's mul_mat arithmetic for these products too); modes 0 / 1: LayerNorm folded in, f32 operands
+      const bool ln16 = h->dec_ln16;
+      if (ln16) HIP_TRY(layernorm_f32(h->d_dx, L.ln1_w, L.ln1_b, h->d_dxn, batch, dt, s));
+      GemmArgs g = gemm(ln16 ? h->d_dxn : h->d_dx, dt, nullptr, dt, h->d_dq, dt, ln16 ? L.qkv_b : nullptr, batch, 3 * dt, dt);
+      if (!ln16) { g.ln_s = L.qkv_ls; g.ln_c = L.qkv_lc; }
       g.C2 = kv_dst; g.ldc2 = (long)C * 2 * dt; g.n_split = dt;
       if (kv16) { g.C2 = reinterpret_cast<float*>(selfkv_h + (dev_pos ? 0 : (size_t)pos * 2 * dt)); g.c2_half = 1; }
       if (dev_pos) { g.c_off_dev = h->d_counters; g.c_off_scale = 2L * dt; }
@@ -1069,7 +1103,7 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
       // hidden buffer (free until fc1) and scattered by one strided copy.
       const bool stage_kv = P > 1 && clips > 1;
       if (P > 1) { g.ldc2 = 2L * dt; if (stage_kv) g.C2 = h->d_dh; }
-      if ((qrc = proj(g, L.qkv_lw, nullptr, L.r_qkv, L.ln1_w, false)) != CRISPY_OK) return qrc;
+      if ((qrc = proj(g, L.qkv_lw, L.qkv_wh, L.r_qkv, L.ln1_w, ln16)) != CRISPY_OK) return qrc;
       if (stage_kv) {
         const size_t esz = kv16 ? 2 : 4;
         void* dst = kv16 ? static_cast<void*>(selfkv_h + (size_t)pos * 2 * dt) : static_cast<void*>(selfkv + (size_t)pos * 2 * dt);
@@ -1101,9 +1135,11 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
     }
     // cross-attention over the encoder output (K | V precomputed once per clip)
     if (fold) {
-      GemmArgs g = gemm(h->d_dx, dt, nullptr, dt, h->d_dq, dt, nullptr, batch, dt, dt);
-      g.ln_s = L.xq_ls; g.ln_c = L.xq_lc;
-      if ((qrc = proj(g, L.xq_lw, nullptr, L.r_xq, L.lnx_w, false)) != CRISPY_OK) return qrc;
+      const bool ln16 = h->dec_ln16;
+      if (ln16) HIP_TRY(layernorm_f32(h->d_dx, L.lnx_w, L.lnx_b, h->d_dxn, batch, dt, s));
+      GemmArgs g = gemm(ln16 ? h->d_dxn : h->d_dx, dt, nullptr, dt, h->d_dq, dt, ln16 ? L.xq_b : nullptr, batch, dt, dt);
+      if (!ln16) { g.ln_s = L.xq_ls; g.ln_c = L.xq_lc; }
+      if ((qrc = proj(g, L.xq_lw, L.xq_wh, L.r_xq, L.lnx_w, ln16)) != CRISPY_OK) return qrc;
     } else {
       HIP_TRY(layernorm_f32(h->d_dx, L.lnx_w, L.lnx_b, h->d_dxn, batch, dt, s));
       const float* xq_w = w32(L.xq_w, L.r_xq, nullptr);
@@ -1124,10 +1160,12 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
     }
     // MLP
     if (fold) {
-      GemmArgs g = gemm(h->d_dx, dt, nullptr, dt, h->d_dh, 4L * dt, nullptr, batch, 4 * dt, dt);
-      g.ln_s = L.fc1_ls; g.ln_c = L.fc1_lc;
+      const bool ln16 = h->dec_ln16;
+      if (ln16) HIP_TRY(layernorm_f32(h->d_dx, L.ln2_w, L.ln2_b, h->d_dxn, batch, dt, s));
+      GemmArgs g = gemm(ln16 ? h->d_dxn : h->d_dx, dt, nullptr, dt, h->d_dh, 4L * dt, ln16 ? L.fc1_b : nullptr, batch, 4 * dt, dt);
+      if (!ln16) { g.ln_s = L.fc1_ls; g.ln_c = L.fc1_lc; }
       g.gelu = h->enc_precision == 1 ? 2 : 1;      // mode 1: ggml's GELU (asr_common.h: gelu_ggml)
-      if ((qrc = proj(g, L.fc1_lw, nullptr, L.r_fc1, L.ln2_w, false)) != CRISPY_OK) return qrc;
+      if ((qrc = proj(g, L.fc1_lw, L.fc1_wh, L.r_fc1, L.ln2_w, ln16)) != CRISPY_OK) return qrc;
     } else {
       HIP_TRY(layernorm_f32(h->d_dx, L.ln2_w, L.ln2_b, h->d_dxn, batch, dt, s));
       GemmArgs g = gemm(h->d_dxn, dt, w32(L.fc1_w, L.r_fc1, nullptr), dt, h->d_dh, 4L * dt, L.fc1_b, batch, 4 * dt, dt);

@@ -1355,14 +1355,20 @@ hipError_t gemm_f32_nt(const GemmArgs& g, int batch, hipStream_t s) {
     // split is 2 % faster at 128 tiny clips, equal at 256 base clips, 2 % slower at 512 tiny clips.)  With it a clip
     // decodes to the same bits alone, in a batch of 512, and as a row of a multi-position prompt step.
     const int nw = g.K % 512 == 0 ? 16 : g.K % 384 == 0 ? 12 : g.K % 256 == 0 ? 8 : 4;
-    if (g.w_half) {                          // precision mode 1: f16 weight copy, residual projections only
-      if (kind != 1) return hipErrorInvalidValue;
-      switch (nw) {
-        case 16: return sk_launch<false, false, true, 16, true>(grid, g, s);
-        case 12: return sk_launch<false, false, true, 12, true>(grid, g, s);
-        case 8: return sk_launch<false, false, true, 8, true>(grid, g, s);
-        default: return sk_launch<false, false, true, 4, true>(grid, g, s);
+    if (g.w_half) {                          // f16 weight copy: the residual projections (precision mode 1); bias-only and
+                                             // bias + GELU behind an explicit LayerNorm (precision mode 2)
+#define CRISPY_SK_WH(GL, RS)                                             \
+      switch (nw) {                                                      \
+        case 16: return sk_launch<false, GL, RS, 16, true>(grid, g, s);  \
+        case 12: return sk_launch<false, GL, RS, 12, true>(grid, g, s);  \
+        case 8: return sk_launch<false, GL, RS, 8, true>(grid, g, s);    \
+        default: return sk_launch<false, GL, RS, 4, true>(grid, g, s);   \
       }
+      if (kind == 1) { CRISPY_SK_WH(false, true) }
+      if (kind == 0) { CRISPY_SK_WH(false, false) }
+      if (kind == 2) { CRISPY_SK_WH(true, false) }
+#undef CRISPY_SK_WH
+      return hipErrorInvalidValue;
     }
     switch (nw) {
       case 16: return sk_dispatch<16>(kind, grid, g, s);

@@ -258,7 +258,12 @@ int crispy_asr_synchronize(crispy_asr *h);
  * f16(LayerNorm(x)) . f16(token embedding)^T with f32 accumulation (whisper.cpp's f16 embedding under ggml's mul_mat),
  * and the projections with no LayerNorm in front of them (attention outputs, the MLP's second product) with f16
  * weights and the activation rounded to f16; the LayerNorm-folded projections (q | k | v, cross q, the MLP's first
- * product), LayerNorm and soft-max stay f32.  oracle/whisper_oracle.py: encoder_forward_f16, DecoderCache(f16=True). */
+ * product), LayerNorm and soft-max stay f32; GELU is ggml's (the f16-indexed table of the tanh form, evaluated on the fly).
+ * oracle/whisper_oracle.py: encoder_forward_f16, DecoderCache(f16=True).
+ * 2 (opt-in): mode 1, and the decoder's LayerNorm output ALSO rounded to f16 in front of q | k | v, cross q and the MLP's
+ * first product, which then run against f16 weights -- ggml's rounding points for these products too [UPSTREAM-RECALL].
+ * The LayerNorm becomes a launch of its own (three more launches per layer and step: ~10 % slower decode steps at 64
+ * Whisper-tiny clips); not available for resident quantised models.  Oracle: DecoderCache(f16=True, ln16=True). */
 int crispy_asr_set_precision(crispy_asr *h, int mode);
 
 /* Stage entry point (parity tests): the last step of the decoder alone -- final LayerNorm and vocabulary projection

@@ -215,7 +215,7 @@ class DecoderCache:
     """KV-cached incremental decoder (float64); `step(token)` returns the logits of the new position.
     Same arithmetic as `decoder_logits`, restated so that 200-token windows finish in seconds."""
 
-    def __init__(self, weights, hp, enc_out, f16=False, dtype=np.float64):
+    def __init__(self, weights, hp, enc_out, f16=False, dtype=np.float64, ln16=False):
         """dtype=np.float32: single-precision CPU run for bench.py's cpu_baseline (not the parity oracle).
         f16=True: the decoder arithmetic of the library's precision mode 1, i.e. whisper.cpp's ggml graph
         [UPSTREAM-RECALL] wherever a matrix product has no LayerNorm folded into it on the GPU -- cross K | V from the
@@ -227,8 +227,13 @@ class DecoderCache:
         self.W = _f64(weights, dtype)
         self.hp = hp
         self.f16 = f16
+        # ln16 (the library's precision mode 2): the LayerNorm output is rounded to f16 -- and the weight too -- in front of
+        # the q | k | v, cross-q and fc1 products, as ggml's mul_mat does with an f32 activation against an f16 weight
+        # [UPSTREAM-RECALL]; mode 1 keeps those five products exact (LayerNorm folded into f32 GEMMs)
+        self.ln16 = bool(ln16 and f16)
         r = _h if f16 else (lambda a: a)
         self.r = r
+        self.rl = _h if self.ln16 else (lambda a: a)
         enc = r(enc_out.astype(dtype))
         self.xk, self.xv, self.k, self.v = [], [], [], []
         for i in range(hp.n_text_layer):
@@ -255,16 +260,17 @@ class DecoderCache:
         x = W["decoder.token_embedding.weight"][int(token)] + W["decoder.positional_embedding"][self.pos]
         for i in range(self.hp.n_text_layer):
             p = f"decoder.blocks.{i}"
-            xn = _ln(x, W[p + ".attn_ln.weight"], W[p + ".attn_ln.bias"])
-            q = xn @ W[p + ".attn.query.weight"].T + W[p + ".attn.query.bias"]
-            self.k[i] = np.vstack([self.k[i], r(xn @ W[p + ".attn.key.weight"].T)])
-            self.v[i] = np.vstack([self.v[i], r(xn @ W[p + ".attn.value.weight"].T + W[p + ".attn.value.bias"])])
+            rl = self.rl
+            xn = rl(_ln(x, W[p + ".attn_ln.weight"], W[p + ".attn_ln.bias"]))
+            q = xn @ rl(W[p + ".attn.query.weight"]).T + W[p + ".attn.query.bias"]
+            self.k[i] = np.vstack([self.k[i], r(xn @ rl(W[p + ".attn.key.weight"]).T)])
+            self.v[i] = np.vstack([self.v[i], r(xn @ rl(W[p + ".attn.value.weight"]).T + W[p + ".attn.value.bias"])])
             x = x + r(self._att(q, self.k[i], self.v[i])) @ r(W[p + ".attn.out.weight"]).T + W[p + ".attn.out.bias"]
-            xn = _ln(x, W[p + ".cross_attn_ln.weight"], W[p + ".cross_attn_ln.bias"])
-            q = xn @ W[p + ".cross_attn.query.weight"].T + W[p + ".cross_attn.query.bias"]
+            xn = rl(_ln(x, W[p + ".cross_attn_ln.weight"], W[p + ".cross_attn_ln.bias"]))
+            q = xn @ rl(W[p + ".cross_attn.query.weight"]).T + W[p + ".cross_attn.query.bias"]
             x = x + r(self._att(q, self.xk[i], self.xv[i])) @ r(W[p + ".cross_attn.out.weight"]).T + W[p + ".cross_attn.out.bias"]
-            xn = _ln(x, W[p + ".mlp_ln.weight"], W[p + ".mlp_ln.bias"])
-            g = (_gelu_ggml if self.f16 else _gelu)(xn @ W[p + ".mlp.0.weight"].T + W[p + ".mlp.0.bias"])
+            xn = rl(_ln(x, W[p + ".mlp_ln.weight"], W[p + ".mlp_ln.bias"]))
+            g = (_gelu_ggml if self.f16 else _gelu)(xn @ rl(W[p + ".mlp.0.weight"]).T + W[p + ".mlp.0.bias"])
             x = x + r(g) @ r(W[p + ".mlp.2.weight"]).T + W[p + ".mlp.2.bias"]
         self.pos += 1
         x = _ln(x, W["decoder.ln.weight"], W["decoder.ln.bias"])

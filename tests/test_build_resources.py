@@ -198,7 +198,7 @@ def test_asr_kernels_have_no_scratch_at_all(tmp_path, src_name):
     if src_name == "whisper_kernels.hip":
         for must in ("gemm_skinny_f32_kernel", "ts_pick_kernel", "argmax_kernel", "attn_dec_kernel"):
             assert any(must in k for k in res), (must, list(res))
-        assert sum("gemm_skinny_f32_kernel" in k for k in res) == 36      # 8 epilogue forms x 4 K splits + 4 f16-weight forms
+        assert sum("gemm_skinny_f32_kernel" in k for k in res) == 44      # 8 epilogue forms x 4 K splits + 3 x 4 f16-weight forms (residual; bias; bias + GELU)
         assert sum("attn_dec_x16_kernel" in k for k in res) == 5           # 1 / 2 / 4 / 12 key slots per wave + the non-temporal 12 (K|V streams of many clips)
     if src_name == "whisper_dec_f16.hip":
         assert sum("vocab_f16_kernel" in k for k in res) == 5              # tiny ... large widths

@@ -228,3 +228,50 @@ def test_mode1_language_detection_does_not_depend_on_call_history(oracle):
             resolved += 1
     assert resolved >= 2, resolved
     m.close()
+
+
+def test_mode2_transcribe_tokens_through_the_product_call(oracle):
+    """Precision mode 2 (mode 1 + f16 LayerNorm outputs in the decoder, opt-in) through `crispy_asr_transcribe_tokens`:
+    deterministic, batch == solo bit for bit, the decoder half against its own oracle (DecoderCache(f16=True, ln16=True))
+    on the product's encoder output, the chain at the amplified bar."""
+    from crispy_amd import synth_audio
+    from crispy_amd.asr import WhisperModel
+    from crispy_amd.mel_filters import whisper_mel_filters
+    from crispy_amd.whisper_weights import HParams, synthetic_whisper_weights
+    from oracle import whisper_oracle as WO
+    hp = HParams.tiny()
+    W = synthetic_whisper_weights(hp, 0, sensitive=True)
+    m = WhisperModel(hp, W)
+    m.set_precision(2)
+    clips = [synth_audio.clip16k_np(s, n) for s, n in ((300, 464000), (301, 130000))]
+    prompt = WO.default_prompt(hp.n_vocab, no_timestamps=True)
+    toks, _ = m.transcribe_tokens(clips, prompt, 8)
+    again, _ = m.transcribe_tokens(clips, prompt, 8)
+    assert np.array_equal(toks, again)
+    F = whisper_mel_filters(hp.n_mels)
+    sp = WO.special_tokens(hp.n_vocab)
+    for b, c in enumerate(clips):
+        solo, _ = m.transcribe_tokens([c], prompt, 8)
+        assert np.array_equal(solo[0], toks[b])
+        enc_gpu = m.encode([c])[0].astype(np.float64)
+        enc16 = WO.encoder_forward_f16(W, hp, oracle.oracle_logmel(c, F))
+        for enc, rel, need, what in ((enc_gpu, MODE1_REL, 4, "decoder"), (enc16, 0.03, 1, "chain")):
+            dc = WO.DecoderCache(W, hp, enc, f16=True, ln16=True)
+            for t in prompt[:-1]:
+                dc.step(t)
+            tok, compared = prompt[-1], 0
+            for i, g in enumerate(toks[b]):
+                g = int(g)
+                lg = dc.step(tok)
+                thr = rel * float(np.abs(lg).max())
+                best = int(np.argmax(lg))
+                top2 = np.partition(lg, -2)[-2:]
+                assert float(lg[best] - lg[g]) <= thr, (what, b, i, g, best)
+                if top2[1] - top2[0] > thr:
+                    assert g == best, (what, b, i)
+                    compared += 1
+                tok = g
+                if g == sp["eot"]:
+                    break
+            assert compared >= need, (what, b, compared)
+    m.close()

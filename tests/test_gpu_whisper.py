@@ -695,6 +695,64 @@ def test_mode_1_decoder_matches_the_f16_arithmetic_oracle(tiny, model):
     assert np.array_equal(toks[resolved], ids16[resolved])
 
 
+def test_mode_2_decoder_rounds_the_layernorm_outputs_as_ggml_does(tiny, model):
+    """Precision mode 2 (opt-in) = mode 1 + the decoder's LayerNorm output rounded to f16 in front of q | k | v, cross q
+    and fc1, against f16 weights -- ggml's mul_mat arithmetic for these products too.  Against its own oracle
+    (DecoderCache(f16=True, ln16=True)) on handed-over encoder outputs, 12 clips x 6 picks: within the decoder's bars
+    (rms < 1e-4, worst < 4e-4 of the scale), closer to the ln16 oracle than to the mode-1 oracle, ids equal wherever
+    the ln16 oracle's margin resolves them; and back in mode 1 the model decodes as before."""
+    import torch
+    from oracle import whisper_oracle as WO
+    hp, W = tiny
+    rng = np.random.default_rng(12)
+    B, n_new = 12, 6
+    enc = (rng.standard_normal((B, 1500, hp.n_audio_state)) * 0.8).astype(np.float32)
+    prompt = [50258, 50259, 50359, 50363]
+    d_enc = torch.from_numpy(enc).to("cuda:0")
+    torch.cuda.synchronize()
+    try:
+        model.set_precision(1)
+        toks1, _, lg1 = model.decode_greedy_device(d_enc.data_ptr(), B, prompt, n_new)
+        model.set_precision(2)
+        toks, n, lg = model.decode_greedy_device(d_enc.data_ptr(), B, prompt, n_new)
+        solo, _, lgs = model.decode_greedy_device(d_enc[5:6].contiguous().data_ptr(), 1, prompt, n_new)
+        model.set_precision(1)
+        again1, _, lg1b = model.decode_greedy_device(d_enc.data_ptr(), B, prompt, n_new)
+    finally:
+        model.set_precision(0)
+    assert np.array_equal(toks1, again1) and lg1.tobytes() == lg1b.tobytes()         # mode 1 untouched by the excursion
+    assert np.array_equal(solo[0], toks[5]) and lgs[0].tobytes() == lg[5].tobytes()   # alone = in the batch, bit for bit
+    best = {True: np.zeros((B, n_new)), False: np.zeros((B, n_new))}
+    margin = np.zeros((B, n_new))
+    ids = np.zeros((B, n_new), np.int64)
+    for ln16 in (True, False):
+        for b in range(B):
+            dc = WO.DecoderCache(W, hp, enc[b], f16=True, ln16=ln16)
+            for t in prompt[:-1]:
+                dc.step(t)
+            tok = prompt[-1]
+            for i in range(n_new):
+                l = dc.step(tok)
+                tok = int(toks[b][i])
+                best[ln16][b, i] = l.max()
+                if ln16:
+                    top = np.partition(l, -2)[-2:]
+                    margin[b, i] = top[1] - top[0]
+                    ids[b, i] = int(np.argmax(l))
+    scale = np.abs(best[True]).max()
+    gap = np.sqrt(np.mean((best[True] - best[False]) ** 2)) / scale
+    e2 = (lg - best[True]) / scale
+    e1 = (lg - best[False]) / scale
+    rms2, rms1 = np.sqrt(np.mean(e2 ** 2)), np.sqrt(np.mean(e1 ** 2))
+    print(f"mode-2 decoder: rms to the ln16 oracle {rms2:.2e}, to the mode-1 oracle {rms1:.2e}, oracle gap {gap:.2e}, worst {np.abs(e2).max():.2e}")
+    assert gap > 3e-5, gap                                       # the extra roundings are visible
+    assert rms2 < 1e-4 and np.abs(e2).max() < 4e-4, (rms2, rms1, gap, np.abs(e2).max())
+    assert rms2 < 0.85 * rms1, (rms2, rms1, gap)                 # its own oracle, not mode 1's
+    resolved = margin > 1e-3 * scale
+    assert resolved.sum() >= B * n_new // 2, resolved.sum()
+    assert np.array_equal(toks[resolved], ids[resolved])
+
+
 @pytest.mark.parametrize("d,vocab", [(512, 51865), (768, 51865), (1024, 51865), (1280, 51866)])
 def test_vocabulary_projection_at_the_other_catalog_widths(d, vocab):
     """The mode-1 logits kernel is built per model width (K-chunks per wave 8 / 12 / 16 / 20 for base / small / medium /
