@@ -553,7 +553,7 @@ def test_f16_operand_encoder_mode(tiny, model):
     again = model.encode([x])
     assert np.array_equal(again, ref)                # back in f32 mode: bit-identical to before
     with pytest.raises(Exception):
-        model.set_precision(2)
+        model.set_precision(3)                       # 0, 1 and (round 3) 2 are the modes
 
 
 def test_f16_operand_mode_matches_the_f16_operand_oracle(tiny, model, oracle):
