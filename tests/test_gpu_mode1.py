@@ -62,7 +62,7 @@ def forced_picks(W, hp, enc, prompt, got, need, what, f16=True, suppress=None, r
 
 MODELS = {  # name: (weights seed, clips as (seed, samples), new tokens, resolvable picks required per clip)
     "tiny": (0, ((300, 464000), (301, 130000), (302, 52000)), 8, 4),
-    "base": (1, ((310, 300000), (311, 90000)), 6, 4),
+    "base": (1, ((310, 300000),), 6, 4),
     "small": (3, ((320, 160000),), 5, 4),          # one catalog model (managers/model.rs:74-93) at full depth
 }
 
@@ -104,7 +104,9 @@ def test_mode1_transcribe_tokens_against_the_chained_f16_oracle(oracle, name):
         # by up to 0.014 here (tools/diag_mode1_long.py, clip 300: the oracle decoder itself picks 44116 on the product's
         # encoder output and 47822 on the oracle's, margins 0.0075 and 0.0066).  So the chain is held to the bar the cfg 4
         # test uses for the same reason (tests/test_gpu_pipeline.py): 0.03 of the logit scale, every step compared.
-        kc, worst_c = forced_picks(W, hp, enc16, prompt, toks[b], 1, f"{name} clip {b} (chain)", rel=0.03)
+        # (tiny and base only: at 12 + 12 layers the second teacher-forced oracle pass costs more than the rest of the case)
+        kc, worst_c = (forced_picks(W, hp, enc16, prompt, toks[b], 1, f"{name} clip {b} (chain)", rel=0.03)
+                       if hp.n_text_layer <= 6 else (0, float("nan")))
         print(f"mode 1 {name} clip {b}: encoder {e_err:.2e} of the peak; decoder {k} of {n_new} picks resolvable, worst shortfall "
               f"{worst:.2e}; chain worst shortfall {worst_c:.2e}; ids {toks[b].tolist()}")
         total += k
@@ -243,10 +245,10 @@ def test_mode2_transcribe_tokens_through_the_product_call(oracle):
     W = synthetic_whisper_weights(hp, 0, sensitive=True)
     m = WhisperModel(hp, W)
     m.set_precision(2)
-    clips = [synth_audio.clip16k_np(s, n) for s, n in ((300, 464000), (301, 130000))]
+    clips = [synth_audio.clip16k_np(s, n) for s, n in ((301, 130000),)]
     prompt = WO.default_prompt(hp.n_vocab, no_timestamps=True)
-    toks, _ = m.transcribe_tokens(clips, prompt, 8)
-    again, _ = m.transcribe_tokens(clips, prompt, 8)
+    toks, _ = m.transcribe_tokens(clips + [synth_audio.clip16k_np(302, 52000)], prompt, 8)      # decoded in a batch of two ...
+    again, _ = m.transcribe_tokens(clips + [synth_audio.clip16k_np(302, 52000)], prompt, 8)
     assert np.array_equal(toks, again)
     F = whisper_mel_filters(hp.n_mels)
     sp = WO.special_tokens(hp.n_vocab)

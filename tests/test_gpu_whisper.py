@@ -516,13 +516,15 @@ def test_seek_loop_conditions_later_windows_on_the_text_so_far(tiny, ggml_file, 
         singles[seed] = (x, text, toks, segs)
         if seconds == 28:
             assert len(wins) >= 3 and lens[2] > lens[1] > 3, lens                       # the past accumulates
-        # without the conditioning: every window on the bare prompt, a different transcript, still the oracle's
+        # without the conditioning: every window on the bare prompt, a different transcript, still the oracle's (the oracle
+        # side of this for the first clip only: it is the slow part of the test)
         _, segs0, toks0 = eng.transcribe_segments(x, max_new_tokens=10, language_token=sp["lang0"], prev_text=False)
-        rsegs0, rkept0, wins0 = ref(x, False)
-        assert all(len(w["prompt"]) == 3 for w in wins0)
-        if min(min(w["margins"]) for w in wins0) > 1e-3:
-            assert toks0 == [t for t in rkept0 if t != sp["eot"]]
         assert toks0 != toks
+        if seed == 60:
+            rsegs0, rkept0, wins0 = ref(x, False)
+            assert all(len(w["prompt"]) == 3 for w in wins0)
+            if min(min(w["margins"]) for w in wins0) > 1e-3:
+                assert toks0 == [t for t in rkept0 if t != sp["eot"]]
     # a batch: round 0 runs batched on the bare prompt, later rounds clip by clip on their own prompts
     clips = [singles[60][0], synth_audio.clip16k_np(52, 15000), singles[64][0], singles[68][0]]
     got = transcribe_batch(eng, clips, max_new_tokens=10, language_token=sp["lang0"], timestamps=True, with_segments=True)
@@ -642,10 +644,10 @@ def test_vocabulary_projection_both_precision_modes(tiny, model, batch):
 def test_mode_1_decoder_matches_the_f16_arithmetic_oracle(tiny, model):
     """Precision mode 1 of the DECODER against an oracle of its own arithmetic (oracle DecoderCache(f16=True): f16 cross
     and self K|V caches, f16 operands in the attention-output / MLP-second / vocabulary products; the LayerNorm-folded
-    projections exact), on encoder outputs handed over as they are: the logit of each greedy pick for 12 clips x 6
-    picks behind a 4-token prompt (72 logits; the oracle follows the GPU's picks, so the comparison is per step).
+    projections exact), on encoder outputs handed over as they are: the logit of each greedy pick for 8 clips x 6
+    picks behind a 4-token prompt (48 logits; the oracle follows the GPU's picks, so the comparison is per step).
     A picked logit moves by ~2e-4 of its size under these roundings, the same order as one f16 flip caused by f32
-    accumulation, so single values cannot tell the two oracles apart; over the 72 the GPU must be closer (rms) to the
+    accumulation, so single values cannot tell the two oracles apart; over the 48 the GPU must be closer (rms) to the
     f16 oracle than to the exact one (measured: 7.0e-5 against 9.9e-5, the two oracles 1.18e-4 apart -- the same
     picture as the encoder's: what remains is f32 accumulation order moving values across f16 boundaries), within
     1e-4 rms and 4e-4 at the worst value, and it must pick the f16 oracle's ids wherever that oracle's top-2 margin
@@ -654,7 +656,7 @@ def test_mode_1_decoder_matches_the_f16_arithmetic_oracle(tiny, model):
     from oracle import whisper_oracle as WO
     hp, W = tiny
     rng = np.random.default_rng(11)
-    B, n_new = 12, 6
+    B, n_new = 8, 6
     enc = (rng.standard_normal((B, 1500, hp.n_audio_state)) * 0.8).astype(np.float32)
     prompt = [50258, 50259, 50359, 50363]
     d_enc = torch.from_numpy(enc).to("cuda:0")
@@ -698,14 +700,14 @@ def test_mode_1_decoder_matches_the_f16_arithmetic_oracle(tiny, model):
 def test_mode_2_decoder_rounds_the_layernorm_outputs_as_ggml_does(tiny, model):
     """Precision mode 2 (opt-in) = mode 1 + the decoder's LayerNorm output rounded to f16 in front of q | k | v, cross q
     and fc1, against f16 weights -- ggml's mul_mat arithmetic for these products too.  Against its own oracle
-    (DecoderCache(f16=True, ln16=True)) on handed-over encoder outputs, 12 clips x 6 picks: within the decoder's bars
+    (DecoderCache(f16=True, ln16=True)) on handed-over encoder outputs, 4 clips x 6 picks: within the decoder's bars
     (rms < 1e-4, worst < 4e-4 of the scale), closer to the ln16 oracle than to the mode-1 oracle, ids equal wherever
     the ln16 oracle's margin resolves them; and back in mode 1 the model decodes as before."""
     import torch
     from oracle import whisper_oracle as WO
     hp, W = tiny
     rng = np.random.default_rng(12)
-    B, n_new = 12, 6
+    B, n_new = 4, 6
     enc = (rng.standard_normal((B, 1500, hp.n_audio_state)) * 0.8).astype(np.float32)
     prompt = [50258, 50259, 50359, 50363]
     d_enc = torch.from_numpy(enc).to("cuda:0")
@@ -715,13 +717,13 @@ def test_mode_2_decoder_rounds_the_layernorm_outputs_as_ggml_does(tiny, model):
         toks1, _, lg1 = model.decode_greedy_device(d_enc.data_ptr(), B, prompt, n_new)
         model.set_precision(2)
         toks, n, lg = model.decode_greedy_device(d_enc.data_ptr(), B, prompt, n_new)
-        solo, _, lgs = model.decode_greedy_device(d_enc[5:6].contiguous().data_ptr(), 1, prompt, n_new)
+        solo, _, lgs = model.decode_greedy_device(d_enc[3:4].contiguous().data_ptr(), 1, prompt, n_new)
         model.set_precision(1)
         again1, _, lg1b = model.decode_greedy_device(d_enc.data_ptr(), B, prompt, n_new)
     finally:
         model.set_precision(0)
     assert np.array_equal(toks1, again1) and lg1.tobytes() == lg1b.tobytes()         # mode 1 untouched by the excursion
-    assert np.array_equal(solo[0], toks[5]) and lgs[0].tobytes() == lg[5].tobytes()   # alone = in the batch, bit for bit
+    assert np.array_equal(solo[0], toks[3]) and lgs[0].tobytes() == lg[3].tobytes()   # alone = in the batch, bit for bit
     best = {True: np.zeros((B, n_new)), False: np.zeros((B, n_new))}
     margin = np.zeros((B, n_new))
     ids = np.zeros((B, n_new), np.int64)
