@@ -109,10 +109,13 @@ struct crispy_asr {
   int* d_tok = nullptr;
   int* d_tokens_all = nullptr;
   int* d_counters = nullptr;                 // [0] position, [1] generation step (device-side, advanced in-graph)
-  hipGraphExec_t dec_graph = nullptr;        // one captured decode step, replayed per generated token
-  int dec_graph_batch = 0;
-  int dec_max_keys = 0;                      // positions the current decode call can reach (prompt + new tokens): picks the
-  int dec_graph_keys = 0, ts_graph_keys = 0; //   self-attention kernel of mode 1, baked into the captured steps
+  // one captured decode step, replayed per generated token -- one per key class (<= 128 / 256 / 512 positions: the
+  // self-attention kernel of mode 1 is baked into the capture).  A transcribe call with previous-text conditioning
+  // alternates between classes from window to window (bare prompt, then prompt + past): with a single slot every window
+  // re-instantiated the graph (1 - 2 ms each).
+  hipGraphExec_t dec_graphs[3] = {nullptr, nullptr, nullptr};
+  int dec_graph_batch[3] = {0, 0, 0};
+  int dec_max_keys = 0;                      // positions the current decode call can reach (prompt + new tokens)
   // timestamp-mode decoding (whisper.cpp no_timestamps = false)
   TsState* d_ts_state = nullptr;             // [dcap_batch]
   int* d_tids_all = nullptr;                 // [n_text_ctx][dcap_batch]
@@ -121,9 +124,15 @@ struct crispy_asr {
   void* d_xkv_h = nullptr;                   // f16 copy of the cross K|V (precision mode 1)
   unsigned char* d_ts_mask = nullptr;        // [n_vocab] whisper.cpp's always-suppressed specials
   unsigned char* d_ts_mask_first = nullptr;  // ... plus suppress_blank (" " and EOT) at the first position
-  hipGraphExec_t ts_graph = nullptr;
-  int ts_graph_batch = 0, ts_graph_rules = -1;
-  const unsigned char *ts_graph_mask = nullptr;
+  hipGraphExec_t ts_graphs[3] = {nullptr, nullptr, nullptr};
+  int ts_graph_batch[3] = {0, 0, 0}, ts_graph_rules[3] = {-1, -1, -1};
+  const unsigned char* ts_graph_mask[3] = {nullptr, nullptr, nullptr};
+  void drop_graphs() {
+    for (int c = 0; c < 3; ++c) {
+      if (dec_graphs[c]) { (void)hipGraphExecDestroy(dec_graphs[c]); dec_graphs[c] = nullptr; dec_graph_batch[c] = 0; }
+      if (ts_graphs[c]) { (void)hipGraphExecDestroy(ts_graphs[c]); ts_graphs[c] = nullptr; ts_graph_batch[c] = 0; }
+    }
+  }
   int eot = 50257;
   std::vector<unsigned char> sup_all, sup_first;   // host copies of the two suppression lists
   std::vector<std::string> vocab;                  // token byte strings of a loaded model file
@@ -334,8 +343,7 @@ void free_dec_ws(crispy_asr* h) {
   if (h->d_tok) { (void)hipFree(h->d_tok); h->d_tok = nullptr; }
   if (h->d_tokens_all) { (void)hipFree(h->d_tokens_all); h->d_tokens_all = nullptr; }
   if (h->d_counters) { (void)hipFree(h->d_counters); h->d_counters = nullptr; }
-  if (h->dec_graph) { (void)hipGraphExecDestroy(h->dec_graph); h->dec_graph = nullptr; h->dec_graph_batch = 0; }
-  if (h->ts_graph) { (void)hipGraphExecDestroy(h->ts_graph); h->ts_graph = nullptr; h->ts_graph_batch = 0; }
+  h->drop_graphs();
   if (h->d_ts_state) { (void)hipFree(h->d_ts_state); h->d_ts_state = nullptr; }
   if (h->d_tids_all) { (void)hipFree(h->d_tids_all); h->d_tids_all = nullptr; }
   if (h->d_done_count) { (void)hipFree(h->d_done_count); h->d_done_count = nullptr; }
@@ -760,8 +768,7 @@ int crispy_asr_set_precision(crispy_asr* h, int mode) try {
     h->ln16_ready = true;
   }
   if (h->enc_precision != mode || h->dec_ln16 != want_ln16) {   // the captured decode steps bake the kernels in
-    if (h->dec_graph) { (void)hipGraphExecDestroy(h->dec_graph); h->dec_graph = nullptr; h->dec_graph_batch = 0; }
-    if (h->ts_graph) { (void)hipGraphExecDestroy(h->ts_graph); h->ts_graph = nullptr; h->ts_graph_batch = 0; }
+    h->drop_graphs();
   }
   h->enc_precision = mode;
   h->dec_ln16 = want_ln16;
@@ -1342,10 +1349,9 @@ int decode_ts(crispy_asr* h, const float* d_enc, int batch, const int* prompt, i
   const TsPickArgs pa = ts_args(h, rules, mask, mask_first);
   int steps_run = 1;      // picks made = decoder steps replayed + the final pick
   if (max_new > 1) {
-    const int key_class = h->dec_max_keys <= 128 ? 128 : h->dec_max_keys <= 256 ? 256 : 512;
-    if (!h->ts_graph || h->ts_graph_batch != batch || h->ts_graph_rules != rules || h->ts_graph_mask != mask ||
-        h->ts_graph_keys != key_class) {
-      if (h->ts_graph) { (void)hipGraphExecDestroy(h->ts_graph); h->ts_graph = nullptr; }
+    const int kc = h->dec_max_keys <= 128 ? 0 : h->dec_max_keys <= 256 ? 1 : 2;      // key class: its own graph slot
+    if (!h->ts_graphs[kc] || h->ts_graph_batch[kc] != batch || h->ts_graph_rules[kc] != rules || h->ts_graph_mask[kc] != mask) {
+      if (h->ts_graphs[kc]) { (void)hipGraphExecDestroy(h->ts_graphs[kc]); h->ts_graphs[kc] = nullptr; }
       hipGraph_t graph = nullptr;
       HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
       TsPickArgs pf = pa;                     // the pick of a replay also embeds its token and moves the counters on
@@ -1356,14 +1362,14 @@ int decode_ts(crispy_asr* h, const float* d_enc, int batch, const int* prompt, i
       if (rc != CRISPY_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
       HIP_TRY(pe);
       HIP_TRY(ce);
-      const hipError_t ie = hipGraphInstantiate(&h->ts_graph, graph, nullptr, nullptr, 0);
+      const hipError_t ie = hipGraphInstantiate(&h->ts_graphs[kc], graph, nullptr, nullptr, 0);
       (void)hipGraphDestroy(graph);
       HIP_TRY(ie);
-      h->ts_graph_batch = batch; h->ts_graph_rules = rules; h->ts_graph_mask = mask; h->ts_graph_keys = key_class;
+      h->ts_graph_batch[kc] = batch; h->ts_graph_rules[kc] = rules; h->ts_graph_mask[kc] = mask;
     }
     int done = 0;
     for (int i = 0; i + 1 < max_new; ++i) {
-      HIP_TRY(hipGraphLaunch(h->ts_graph, s));
+      HIP_TRY(hipGraphLaunch(h->ts_graphs[kc], s));
       ++steps_run;
       if ((i & 7) == 7) {   // every 8 tokens: have all windows ended?
         HIP_TRY(hipMemcpyAsync(&done, h->d_done_count, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1479,23 +1485,23 @@ int crispy_asr_decode_greedy_lang_device(crispy_asr* h, const float* d_enc, int 
   HIP_TRY(hipStreamSynchronize(s));
   int steps_run = 1;      // picks made: replayed decoder steps + the final pick
   if (max_new > 1) {
-    const int key_class = h->dec_max_keys <= 128 ? 128 : h->dec_max_keys <= 256 ? 256 : 512;
-    if (!h->dec_graph || h->dec_graph_batch != batch || h->dec_graph_keys != key_class) {
-      if (h->dec_graph) { (void)hipGraphExecDestroy(h->dec_graph); h->dec_graph = nullptr; }
+    const int kc = h->dec_max_keys <= 128 ? 0 : h->dec_max_keys <= 256 ? 1 : 2;      // key class: its own graph slot
+    if (!h->dec_graphs[kc] || h->dec_graph_batch[kc] != batch) {
+      if (h->dec_graphs[kc]) { (void)hipGraphExecDestroy(h->dec_graphs[kc]); h->dec_graphs[kc] = nullptr; }
       hipGraph_t graph = nullptr;
       HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
       rc = generation_body(h, batch, s);
       const hipError_t ce = hipStreamEndCapture(s, &graph);
       if (rc != CRISPY_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
       HIP_TRY(ce);
-      const hipError_t ie = hipGraphInstantiate(&h->dec_graph, graph, nullptr, nullptr, 0);
+      const hipError_t ie = hipGraphInstantiate(&h->dec_graphs[kc], graph, nullptr, nullptr, 0);
       (void)hipGraphDestroy(graph);
       HIP_TRY(ie);
-      h->dec_graph_batch = batch; h->dec_graph_keys = key_class;
+      h->dec_graph_batch[kc] = batch;
     }
     int done = 0;
     for (int i = 0; i + 1 < max_new; ++i) {
-      HIP_TRY(hipGraphLaunch(h->dec_graph, s));
+      HIP_TRY(hipGraphLaunch(h->dec_graphs[kc], s));
       ++steps_run;
       if ((i & 7) == 7) {   // every 8 tokens: has every clip produced its EOT?  (nothing after it is returned)
         HIP_TRY(hipMemcpyAsync(&done, h->d_done_count, sizeof(int), hipMemcpyDeviceToHost, s));
