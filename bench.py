@@ -277,6 +277,31 @@ def asr_leg(local_rank: int, clips: int = 64, new_tokens: int = 32, ggml_path: s
             ts.append(time.perf_counter() - t0)
         return float(np.median(ts))
 
+    def default_call():
+        """`engine.transcribe(&audio, &TranscribeOptions::default())` (managers/transcription.rs:183-185) as it is: opts =
+        NULL -- language detected, timestamp tokens, whisper_full's seek loop with previous-text conditioning -- on one 28 s
+        clip from host memory.  Random-init weights decide how many windows and tokens that is; both are reported."""
+        import ctypes as C
+        from crispy_amd import _native as N
+        x1 = np.ascontiguousarray(pcm[0].cpu().numpy()[:16000 * 28])
+        def call():
+            res = C.c_void_p()
+            N.check(N.lib().crispy_asr_transcribe(model._h, x1.ctypes.data, x1.size, None, C.byref(res)))
+            r = C.cast(res, C.POINTER(N.AsrResult)).contents
+            out = (int(r.n_tokens), int(r.n_segments))
+            N.lib().crispy_asr_free_result(res)
+            return out
+        n_tok, n_seg = call()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            call()
+            ts.append(time.perf_counter() - t0)
+        t = float(np.median(ts))
+        return {"what": "crispy_asr_transcribe(h, pcm, n, opts = NULL): language detection, timestamp rules, seek loop, previous-text "
+                        "conditioning; 28 s of audio from host memory", "ms": t * 1e3, "tokens": n_tok, "segments": n_seg,
+                "ms_per_token": t * 1e3 / max(n_tok, 1), "rtfx": 28.0 / t}
+
     times = measure()                      # default precision: f32 operands, the mode the oracle parity is pinned in
     one = single_clip()
     longer = {n: decode_n(n) for n in (64, 224)}      # SURVEY cfg 4 asks for 64 tokens; a full 30 s window can take 224
@@ -284,6 +309,10 @@ def asr_leg(local_rank: int, clips: int = 64, new_tokens: int = 32, ggml_path: s
     times16 = measure()
     one16 = single_clip()
     longer16 = {n: decode_n(n) for n in (64, 224)}
+    try:
+        default16 = default_call()
+    except Exception as e:                 # (a supplied model file without timestamp tokens, ...)
+        default16 = {"error": str(e)[:200]}
     model.set_precision(0)
     # CPU beside it (kind "port"): the numpy restatement in SINGLE precision (OpenBLAS sgemm on the host threads this
     # process may use -- what a CPU engine's matrix products amount to) on ONE 30 s clip: C log-mel + encoder + greedy
@@ -347,7 +376,8 @@ def asr_leg(local_rank: int, clips: int = 64, new_tokens: int = 32, ggml_path: s
                                                   "note": "peak = dense f16 MFMA (v_mfma_f32_32x32x16_f16)"}},
         "single_clip": {"what": "ONE 30 s chunk, host PCM in, token ids out (crispy_asr_transcribe_tokens): the call the "
                                 "reference makes per chunk (managers/transcription.rs:183-185)",
-                        "ms": one * 1e3, "rtfx": 30.0 / one, "f16_operand_mode_ms": one16 * 1e3, "f16_operand_mode_rtfx": 30.0 / one16},
+                        "ms": one * 1e3, "rtfx": 30.0 / one, "f16_operand_mode_ms": one16 * 1e3, "f16_operand_mode_rtfx": 30.0 / one16,
+                        "default_options_f16_operand_mode": default16},
         "rtfx_logmel_encoder": audio_s / (times["logmel"] + times["encoder"]),
         "rtfx_end_to_end": audio_s / total,
         "logmel_roofline": {"bound": "hbm", "achieved": clips * 2.88e6 / times["logmel"] / 1e9, "peak": HBM_PEAK_GBS,
