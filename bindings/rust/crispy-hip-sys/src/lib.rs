@@ -96,6 +96,14 @@ pub struct crispy_asr_opts {
     pub max_new_tokens: c_int,
     pub no_timestamps: c_int,
     pub no_prev_text: c_int,
+    /// whisper_full's decision logic; every field reads "0 = whisper.cpp's default" (include/crispy_hip.h), so
+    /// `crispy_asr_opts::default()` is `TranscribeOptions::default()`.
+    pub temperature: c_float,
+    pub temperature_inc: c_float,
+    pub entropy_thold: c_float,
+    pub logprob_thold: c_float,
+    pub no_speech_thold: c_float,
+    pub best_of: c_int,
 }
 
 #[repr(C)]
@@ -103,6 +111,22 @@ pub struct crispy_asr_segment {
     pub t0: c_float,
     pub t1: c_float,
     pub text: *const c_char,
+}
+
+/// What whisper_full decided about one window of the seek loop.
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default, PartialEq)]
+pub struct crispy_asr_window {
+    pub seek: c_int,
+    pub seek_advance: c_int,
+    pub n_tokens: c_int,
+    pub decoder: c_int,
+    pub failed: c_int,
+    pub no_speech: c_int,
+    pub temperature: c_float,
+    pub no_speech_prob: c_float,
+    pub avg_logprob: c_float,
+    pub entropy: c_float,
 }
 
 #[repr(C)]
@@ -113,6 +137,8 @@ pub struct crispy_asr_result {
     pub language_token: c_int,
     pub n_segments: c_int,
     pub segments: *const crispy_asr_segment,
+    pub n_windows: c_int,
+    pub windows: *const crispy_asr_window,
 }
 
 extern "C" {
@@ -171,6 +197,7 @@ extern "C" {
     pub fn crispy_asr_vocab_specials(n_vocab: c_int, out: *mut crispy_asr_specials) -> c_int;
     pub fn crispy_asr_language_token(n_vocab: c_int, code: *const c_char, token_out: *mut c_int) -> c_int;
     pub fn crispy_asr_token_text(h: *const crispy_asr, token: c_int, text: *mut *const c_char, len: *mut usize) -> c_int;
+    pub fn crispy_asr_decode_window_device(h: *mut crispy_asr, d_enc: *const c_float, rows: c_int, prompts: *const c_int, n_prompt: *const c_int, prompt_stride: c_int, rules: c_int, seek: *const c_int, seek_end: *const c_int, max_new: c_int, temperature: c_float, u: *const f64, tokens_out: *mut c_int, tids_out: *mut c_int, plog_out: *mut c_float, no_speech_prob_out: *mut c_float, n_out: *mut c_int) -> c_int;
     pub fn crispy_asr_transcribe(h: *mut crispy_asr, pcm16k: *const c_float, n: usize, opts: *const crispy_asr_opts, out: *mut *mut crispy_asr_result) -> c_int;
     pub fn crispy_asr_transcribe_batch(h: *mut crispy_asr, pcm: *const *const c_float, n: *const usize, batch: c_int, opts: *const crispy_asr_opts, results: *mut *mut crispy_asr_result) -> c_int;
     pub fn crispy_asr_free_result(r: *mut crispy_asr_result);
@@ -342,6 +369,8 @@ pub struct Transcript {
     pub segments: Option<Vec<Segment>>,
     pub tokens: Vec<i32>,
     pub language_token: i32,
+    /// Per window of whisper_full's seek loop: temperature accepted, no_speech_prob, avg_logprob, entropy, dropped / failed.
+    pub windows: Vec<crispy_asr_window>,
 }
 
 /// `transcribe_rs::whisper_cpp::WhisperEngine`: `load(&path)` + `transcribe(&audio, &TranscribeOptions::default())`.
@@ -398,7 +427,8 @@ impl GpuWhisperEngine {
             } else {
                 None
             };
-            Transcript { text, segments, tokens, language_token: res.language_token }
+            let windows = if res.n_windows > 0 { std::slice::from_raw_parts(res.windows, res.n_windows as usize).to_vec() } else { Vec::new() };
+            Transcript { text, segments, tokens, language_token: res.language_token, windows }
         };
         unsafe { crispy_asr_free_result(r) };
         Ok(out)

@@ -39,7 +39,8 @@ ASR_SYMBOLS = ("crispy_asr_create", "crispy_asr_set_tensor", "crispy_asr_finaliz
                "crispy_asr_load", "crispy_asr_load_resident", "crispy_asr_memory_info", "crispy_asr_token_text", "crispy_asr_transcribe", "crispy_asr_free_result",
                "crispy_asr_decode_greedy_lang_device", "crispy_asr_detect_language_device",
                "crispy_asr_transcribe_batch", "crispy_asr_decode_timestamps_device", "crispy_asr_set_precision",
-               "crispy_asr_vocab_specials", "crispy_asr_stage_logits_device", "crispy_asr_language_token")
+               "crispy_asr_vocab_specials", "crispy_asr_stage_logits_device", "crispy_asr_language_token",
+               "crispy_asr_decode_window_device")
 RS_SYMBOLS = ("crispy_resampler_create", "crispy_resampler_destroy", "crispy_resampler_out_len",
               "crispy_resampler_process_device", "crispy_resampler_synchronize")
 ALL_SYMBOLS = RN_SYMBOLS + MEL_SYMBOLS + ASR_SYMBOLS + RS_SYMBOLS
@@ -53,7 +54,9 @@ class AsrSpecials(C.Structure):
 class AsrOpts(C.Structure):
     """crispy_asr_opts"""
     _fields_ = [("language_token", C.c_int), ("translate", C.c_int), ("max_new_tokens", C.c_int),
-                ("no_timestamps", C.c_int), ("no_prev_text", C.c_int)]
+                ("no_timestamps", C.c_int), ("no_prev_text", C.c_int),
+                ("temperature", C.c_float), ("temperature_inc", C.c_float), ("entropy_thold", C.c_float),
+                ("logprob_thold", C.c_float), ("no_speech_thold", C.c_float), ("best_of", C.c_int)]
 
 
 class AsrSegment(C.Structure):
@@ -61,10 +64,18 @@ class AsrSegment(C.Structure):
     _fields_ = [("t0", C.c_float), ("t1", C.c_float), ("text", C.c_char_p)]
 
 
+class AsrWindow(C.Structure):
+    """crispy_asr_window"""
+    _fields_ = [("seek", C.c_int), ("seek_advance", C.c_int), ("n_tokens", C.c_int), ("decoder", C.c_int),
+                ("failed", C.c_int), ("no_speech", C.c_int), ("temperature", C.c_float), ("no_speech_prob", C.c_float),
+                ("avg_logprob", C.c_float), ("entropy", C.c_float)]
+
+
 class AsrResult(C.Structure):
     """crispy_asr_result"""
     _fields_ = [("text", C.c_char_p), ("tokens", C.POINTER(C.c_int)), ("n_tokens", C.c_int),
-                ("language_token", C.c_int), ("n_segments", C.c_int), ("segments", C.POINTER(AsrSegment))]
+                ("language_token", C.c_int), ("n_segments", C.c_int), ("segments", C.POINTER(AsrSegment)),
+                ("n_windows", C.c_int), ("windows", C.POINTER(AsrWindow))]
 
 
 class CrispyError(RuntimeError):
@@ -164,6 +175,9 @@ def load_library(path: str) -> C.CDLL:
     L.crispy_asr_decode_timestamps_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                                       C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                                       C.c_void_p]
+    L.crispy_asr_decode_window_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                                  C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.crispy_mel_window_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.crispy_asr_decode_greedy_lang_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                                        C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -198,6 +198,34 @@ class WhisperModel:
                                                             n.ctypes.data))
         return toks, tids, n
 
+    def decode_window_device(self, d_enc: int, prompts, max_new: int, rules: int = 0, seek=None, seek_end=None,
+                             temperature: float = 0.0, u=None):
+        """`crispy_asr_decode_window_device`: one pass of whisper_full's temperature ladder over one window per row; `prompts`
+        is a list of token lists (one per row, lengths may differ), `u` [max_new, rows] float64 switches to the sampling
+        pick at `temperature` -> (tokens, tids, plogs [rows, max_new], no_speech_prob [rows], picks per row)."""
+        rows = len(prompts)
+        stride = max(len(p) for p in prompts)
+        pm = np.zeros((rows, stride), dtype=np.int32)
+        for r, p in enumerate(prompts):
+            pm[r, :len(p)] = p
+        npr = np.asarray([len(p) for p in prompts], dtype=np.int32)
+        opt = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+        sk, se = opt(seek), opt(seek_end)
+        uu = None if u is None else np.ascontiguousarray(u, dtype=np.float64)
+        if uu is not None and uu.shape != (max_new, rows):
+            raise ValueError(f"u must be [max_new, rows] = {(max_new, rows)}, got {uu.shape}")
+        ptr = lambda a: None if a is None else a.ctypes.data
+        toks = np.empty((rows, max_new), dtype=np.int32)
+        tids = np.empty((rows, max_new), dtype=np.int32)
+        plog = np.empty((rows, max_new), dtype=np.float32)
+        nosp = np.empty(rows, dtype=np.float32)
+        n = np.empty(rows, dtype=np.int32)
+        N.check(N.lib().crispy_asr_decode_window_device(self._h, d_enc, rows, pm.ctypes.data, npr.ctypes.data, stride, int(rules),
+                                                        ptr(sk), ptr(se), max_new, float(temperature), ptr(uu),
+                                                        toks.ctypes.data, tids.ctypes.data, plog.ctypes.data, nosp.ctypes.data,
+                                                        n.ctypes.data))
+        return toks, tids, plog, nosp, n
+
     def transcribe_tokens(self, clips, prompt, max_new: int):
         """`SpeechModel::transcribe` up to token ids for a batch of <= 30 s clips."""
         if len(clips) == 0:
@@ -234,27 +262,42 @@ class WhisperEngine(WhisperModel):
         return C.string_at(p, n.value)
 
     def transcribe(self, audio: np.ndarray, max_new_tokens: int = 0, translate: bool = False, language_token: int = 0,
-                   timestamps: bool = False, prev_text: bool = True):
+                   timestamps: bool = False, prev_text: bool = True, **decision):
         """One chunk (<= 480000 samples at 16 kHz) -> (text, token ids); empty audio -> ("", []).
         language_token = 0 auto-detects, as `TranscribeOptions::default()` does.  timestamps = True is whisper.cpp's
         default decoding mode (timestamp tokens, seek loop); its segments are kept in `self.last_segments` as
-        (t0 seconds, t1 seconds, text).  prev_text = True: from the second window of the seek loop on, the decoder is
-        conditioned on the text so far (whisper.cpp's prompt_past)."""
+        (t0 seconds, t1 seconds, text), what whisper_full decided per window in `self.last_windows` (dicts of the
+        `crispy_asr_window` fields).  prev_text = True: from the second window of the seek loop on, the decoder is
+        conditioned on the text so far (whisper.cpp's prompt_past).  decision: temperature, temperature_inc,
+        entropy_thold, logprob_thold, no_speech_thold, best_of (0 / absent = whisper.cpp's default; fallback=False is
+        shorthand for temperature_inc = -1: one greedy pass per window)."""
         a = np.ascontiguousarray(audio, dtype=np.float32).ravel()
-        opts = N.AsrOpts(int(language_token), int(translate), int(max_new_tokens), 0 if timestamps else 1, 0 if prev_text else 1)
+        opts = make_opts(language_token, translate, max_new_tokens, timestamps, prev_text, **decision)
         res = C.c_void_p()
         N.check(N.lib().crispy_asr_transcribe(self._h, a.ctypes.data if a.size else None, a.size, C.byref(opts),
                                               C.byref(res)))
         try:
-            text, tokens, self.last_language_token, self.last_segments = _read_result(res)
+            text, tokens, self.last_language_token, self.last_segments, self.last_windows = _read_result(res)
         finally:
             N.lib().crispy_asr_free_result(res)
         return text, tokens
 
-    def transcribe_segments(self, audio: np.ndarray, max_new_tokens: int = 0, language_token: int = 0, prev_text: bool = True):
+    def transcribe_segments(self, audio: np.ndarray, max_new_tokens: int = 0, language_token: int = 0, prev_text: bool = True,
+                            **decision):
         """`engine.transcribe(..)` with whisper.cpp's default options -> (text, [(t0, t1, text)], token ids)."""
-        text, tokens = self.transcribe(audio, max_new_tokens, False, language_token, timestamps=True, prev_text=prev_text)
+        text, tokens = self.transcribe(audio, max_new_tokens, False, language_token, timestamps=True, prev_text=prev_text,
+                                       **decision)
         return text, self.last_segments, tokens
+
+
+def make_opts(language_token=0, translate=False, max_new_tokens=0, timestamps=False, prev_text=True, fallback=True,
+              temperature=0.0, temperature_inc=0.0, entropy_thold=0.0, logprob_thold=0.0, no_speech_thold=0.0, best_of=0):
+    """`crispy_asr_opts`; the decision fields read "0 = whisper.cpp's default" (include/crispy_hip.h)."""
+    if not fallback and temperature_inc == 0.0:
+        temperature_inc = -1.0
+    return N.AsrOpts(int(language_token), int(translate), int(max_new_tokens), 0 if timestamps else 1, 0 if prev_text else 1,
+                     float(temperature), float(temperature_inc), float(entropy_thold), float(logprob_thold),
+                     float(no_speech_thold), int(best_of))
 
 
 def _read_result(res) -> tuple:
@@ -263,19 +306,20 @@ def _read_result(res) -> tuple:
     tokens = [int(r.tokens[i]) for i in range(r.n_tokens)]
     segs = [(float(r.segments[i].t0), float(r.segments[i].t1), (r.segments[i].text or b"").decode("utf-8", "replace"))
             for i in range(r.n_segments)]
-    return text, tokens, int(r.language_token), segs
+    wins = [{k: getattr(r.windows[i], k) for k, _ in N.AsrWindow._fields_} for i in range(r.n_windows)]
+    return text, tokens, int(r.language_token), segs, wins
 
 
 def transcribe_batch(engine: "WhisperEngine", clips, max_new_tokens: int = 0, language_token: int = 0,
-                     timestamps: bool = False, with_segments: bool = False, prev_text: bool = True):
+                     timestamps: bool = False, with_segments: bool = False, prev_text: bool = True, **decision):
     """`crispy_asr_transcribe_batch`: a list of chunks (each <= 30 s, empty allowed) -> [(text, tokens, language)]
-    (+ segments with with_segments)."""
+    (+ segments and window decisions with with_segments)."""
     arrs = [np.ascontiguousarray(c, dtype=np.float32).ravel() for c in clips]
     nb = len(arrs)
     ptrs = (C.c_void_p * max(nb, 1))(*[a.ctypes.data if a.size else None for a in arrs])
     lens = (C.c_size_t * max(nb, 1))(*[a.size for a in arrs])
     res = (C.c_void_p * max(nb, 1))()
-    opts = N.AsrOpts(int(language_token), 0, int(max_new_tokens), 0 if timestamps else 1, 0 if prev_text else 1)
+    opts = make_opts(language_token, False, max_new_tokens, timestamps, prev_text, **decision)
     N.check(N.lib().crispy_asr_transcribe_batch(engine._h, ptrs, lens, nb, C.byref(opts), res))
     out = []
     for i in range(nb):

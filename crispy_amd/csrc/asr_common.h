@@ -137,7 +137,10 @@ hipError_t attn_encoder_f32(const float* qkv, float* out, int B, int T, int D, i
 // 468 bytes of scratch per lane -- not built.)
 // stream_kv = 1: the K|V of this launch will not be read again before it has left the caches (a decode step over many
 // clips): request it non-temporally, so that it does not evict the decoder's weights from the L2s.
-struct AttnRows { int group = 1, key_step = 0, stream_kv = 0; };
+// key_off (device, per clip, nullable): the clip's keys start at cache row key_off[clip] -- prompts of different lengths
+// are left-padded to a common length so that one batch decodes them in lock step (whisper_full's previous-text
+// conditioning); the key count shrinks by the same amount, a row with no key left writes zeros.
+struct AttnRows { int group = 1, key_step = 0, stream_kv = 0; const int* key_off = nullptr; };
 hipError_t attn_decoder_f32(const float* q, long ldq, const float* kv, long kv_batch_stride, long ldkv, long head_stride,
                             long koff, long voff, int n_keys_base, const int* pos_dev, float* out, long ldo, int B, int heads,
                             hipStream_t s, AttnRows rows = AttnRows());
@@ -148,7 +151,7 @@ hipError_t attn_decoder_kv16(const float* q, long ldq, const void* kv, long kv_b
                              AttnRows rows = AttnRows());
 // x[r][:] = tok_emb[tokens[r]] + pos_emb[pos + r % rows_per_clip] for B rows (rows_per_clip > 1: the batched prompt step)
 hipError_t embed_tokens_f32(const int* tokens, const float* tok_emb, const float* pos_emb, int pos, const int* pos_dev,
-                            float* x, int B, int D, hipStream_t s, int rows_per_clip = 1);
+                            float* x, int B, int D, hipStream_t s, int rows_per_clip = 1, const int* row_off = nullptr);
 // 48 -> 16 kHz resampler (rubato FftFixedIn(.., 1024, 1, 1) geometry)
 constexpr int RS_FFT_IN = 1026, RS_FFT_OUT = 342, RS_CHUNK = 1024;
 constexpr int RS_K = 1040;   // 1026 padded to the GEMM's k granularity
@@ -164,10 +167,13 @@ struct TsState {
   int last, prev;      // the two most recent picks of this window (-1: none)
   int n;               // picks so far
   int last_ts;         // most recent timestamp token that moves the monotonic bound (-1: none)
-  int done;            // EOT sampled, or (whisper.cpp) a timestamp within 1 s of the end of the audio
+  int done;            // EOT sampled, or (whisper.cpp) a timestamp within delta_min frames of the end of the audio
   int seek, seek_end;  // window start and audio length in mel frames
   int pad;
 };
+// whisper_full stops a window (and refuses a chunk) this many mel frames from the end of the audio [UPSTREAM-RECALL:
+// `delta_min = 10` = 100 ms in whisper.cpp >= 1.7.6; 1 s before]
+constexpr int TS_DELTA_MIN = 10;
 // A pick kernel that also starts the next decoder step (x != nullptr): counters = {position of the PREVIOUS step,
 // index of this pick, ticket}.  Every workgroup reads them when it starts; it embeds its clip's pick at position
 // counters[0] + 1 into x; the workgroup that finishes LAST (ticket) stores the new position and pick index -- all others
@@ -181,9 +187,11 @@ struct StepFuse {
   int* counters;                       // {pos, step, ticket}
   const unsigned char* tok_emb_q;      // resident quantised embedding (asr_quant.h) instead of tok_emb; nullptr: tok_emb
   int tok_emb_ttype;
+  const int* row_off;                  // [B] nullable: cache row r of clip b is position r - row_off[b] (left-padded prompts)
 };
 struct TsPickArgs {
-  const float* logits;                 // [B][V]
+  const float* logits;                 // [B][ld]: rows padded to a multiple of four floats, so that every row has the same
+  long ld;                             // 16-byte alignment and the same split over the threads (sums then do not depend on the row)
   const unsigned char* mask;           // [V] suppressed at every position (nullable)
   const unsigned char* mask_first;     // [V] suppressed at the first position (union with mask; nullable)
   TsState* st;                         // [B]
@@ -191,14 +199,24 @@ struct TsPickArgs {
   int* tokens_out;                     // [B] the pick (fed to the next decoder step)
   int* tokens_all;                     // [steps][B]
   int* tids_all;                       // [steps][B] most probable timestamp token at that step
+  float* plog_all;                     // [steps][B] log-probability of the pick (whisper_token_data::plog): log-softmax over
+                                       // everything allowed before the probability-mass rule (nullable)
   const int* step_dev;
   int* done_count;                     // number of clips that are done
+  int delta_min;
+  // sampling (whisper_sample_token(best = false), the temperature ladder of whisper_full): logits / *temperature, then
+  // std::discrete_distribution over the probabilities with the uniform variate u_all[step][b] drawn on the host
+  // (std::mt19937 + generate_canonical<double, 53>).  u_all == nullptr: greedy arg-max, temperature ignored.
+  const float* temperature;            // device scalar
+  const double* u_all;                 // [steps][B]
   StepFuse fuse;
 };
 hipError_t ts_pick(const TsPickArgs& a, int B, hipStream_t s);
+// p_out[b] = softmax(logits[b])[token] over the whole, unfiltered row (whisper_full's no_speech_prob)
+hipError_t softmax_prob_f32(const float* logits, int V, long ld, int token, float* p_out, int B, hipStream_t s);
 
 hipError_t argmax_f32(const float* logits, const unsigned char* mask, const unsigned char* mask_first,
-                      const int* step_dev, int V, int* tokens_out, int* tokens_all, float* best, int B, hipStream_t s,
+                      const int* step_dev, int V, long ld, int* tokens_out, int* tokens_all, float* best, int B, hipStream_t s,
                       int eot = -1, int* finished = nullptr, int* done_count = nullptr, const StepFuse* fuse = nullptr);
 
 }  // namespace crispy

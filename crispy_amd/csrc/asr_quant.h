@@ -95,6 +95,6 @@ hipError_t dequant_blocks(const void* q, int ttype, long n_blocks, int cols, voi
                           hipStream_t s);
 // x[b][:] = E[tokens[b]][:] + pos_emb[pos][:] with E a resident quantised tensor
 hipError_t embed_tokens_q(const int* tokens, const void* q_emb, int ttype, const float* pos_emb, int pos, const int* pos_dev,
-                          float* x, int B, int D, hipStream_t s, int rows_per_clip = 1);
+                          float* x, int B, int D, hipStream_t s, int rows_per_clip = 1, const int* row_off = nullptr);
 
 }  // namespace crispy

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <map>
 #include <new>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -124,14 +125,21 @@ struct crispy_asr {
   void* d_xkv_h = nullptr;                   // f16 copy of the cross K|V (precision mode 1)
   unsigned char* d_ts_mask = nullptr;        // [n_vocab] whisper.cpp's always-suppressed specials
   unsigned char* d_ts_mask_first = nullptr;  // ... plus suppress_blank (" " and EOT) at the first position
-  hipGraphExec_t ts_graphs[3] = {nullptr, nullptr, nullptr};
-  int ts_graph_batch[3] = {0, 0, 0}, ts_graph_rules[3] = {-1, -1, -1};
-  const unsigned char* ts_graph_mask[3] = {nullptr, nullptr, nullptr};
+  // [key class + 3 x sampling]: the greedy pick and the sampling pick (temperature fallback) are different kernels
+  hipGraphExec_t ts_graphs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int ts_graph_batch[6] = {0, 0, 0, 0, 0, 0}, ts_graph_rules[6] = {-1, -1, -1, -1, -1, -1};
+  const unsigned char* ts_graph_mask[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  float* d_plog_all = nullptr;               // [n_text_ctx][dcap_batch] log-probability of every pick
+  float* d_nosp = nullptr;                   // [dcap_batch] no_speech_prob of the window
+  double* d_u_all = nullptr;                 // [n_text_ctx][dcap_batch] uniform variates of a sampling pass (drawn on the host)
+  float* d_temperature = nullptr;            // device scalar
+  int* d_row_off = nullptr;                  // [dcap_batch] left padding of every clip's prompt (cache rows)
+  const int* cur_row_off = nullptr;          // d_row_off while a window decode is running, else nullptr (decoder_step reads it)
   void drop_graphs() {
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < 3; ++c)
       if (dec_graphs[c]) { (void)hipGraphExecDestroy(dec_graphs[c]); dec_graphs[c] = nullptr; dec_graph_batch[c] = 0; }
+    for (int c = 0; c < 6; ++c)
       if (ts_graphs[c]) { (void)hipGraphExecDestroy(ts_graphs[c]); ts_graphs[c] = nullptr; ts_graph_batch[c] = 0; }
-    }
   }
   int eot = 50257;
   std::vector<unsigned char> sup_all, sup_first;   // host copies of the two suppression lists
@@ -349,6 +357,12 @@ void free_dec_ws(crispy_asr* h) {
   if (h->d_done_count) { (void)hipFree(h->d_done_count); h->d_done_count = nullptr; }
   if (h->d_finished) { (void)hipFree(h->d_finished); h->d_finished = nullptr; }
   if (h->d_xkv_h) { (void)hipFree(h->d_xkv_h); h->d_xkv_h = nullptr; }
+  if (h->d_plog_all) { (void)hipFree(h->d_plog_all); h->d_plog_all = nullptr; }
+  if (h->d_nosp) { (void)hipFree(h->d_nosp); h->d_nosp = nullptr; }
+  if (h->d_u_all) { (void)hipFree(h->d_u_all); h->d_u_all = nullptr; }
+  if (h->d_temperature) { (void)hipFree(h->d_temperature); h->d_temperature = nullptr; }
+  if (h->d_row_off) { (void)hipFree(h->d_row_off); h->d_row_off = nullptr; }
+  h->cur_row_off = nullptr;
   h->dcap_batch = 0;
 }
 
@@ -956,11 +970,17 @@ int crispy_asr_synchronize(crispy_asr* h) try {
 
 namespace {
 
+// Row stride of h->d_logits: the vocabulary padded to a multiple of four floats.  n_vocab is odd (51865): with rows V
+// apart every clip's row has another 16-byte alignment, the pick kernels split it over their threads differently, and a
+// sum over the row (the log-probability of a pick) comes out with other last bits for the same logits -- enough to
+// reorder two best-of decoders that sampled the same tokens.
+long logits_ld(const crispy_asr* h) { return ((long)h->hp.n_vocab + 3) & ~3L; }
+
 int reserve_dec(crispy_asr* h, int batch, int max_tokens) {
   if (batch <= h->dcap_batch) return CRISPY_OK;
   free_dec_ws(h);
   const size_t B = batch, dt = h->hp.n_text_state, L = h->hp.n_text_layer, Tn = h->hp.n_audio_ctx,
-               C = h->hp.n_text_ctx, V = h->hp.n_vocab;
+               C = h->hp.n_text_ctx;
   (void)max_tokens;
   // activation rows: one per clip in a generation step, up to SKINNY_MAX_M in a batched prompt step (prefill)
   const size_t R = B > (size_t)SKINNY_MAX_M ? B : (size_t)SKINNY_MAX_M;
@@ -971,7 +991,7 @@ int reserve_dec(crispy_asr* h, int batch, int max_tokens) {
   HIP_TRY(hipMalloc(&h->d_dq, R * dt * sizeof(float)));
   HIP_TRY(hipMalloc(&h->d_datt, R * dt * sizeof(float)));
   HIP_TRY(hipMalloc(&h->d_dh, R * 4 * dt * sizeof(float)));
-  HIP_TRY(hipMalloc(&h->d_logits, B * V * sizeof(float)));
+  HIP_TRY(hipMalloc(&h->d_logits, B * (size_t)logits_ld(h) * sizeof(float)));
   HIP_TRY(hipMalloc(&h->d_best, B * C * sizeof(float)));
   HIP_TRY(hipMalloc(&h->d_tok, R * sizeof(int)));
   HIP_TRY(hipMalloc(&h->d_tokens_all, B * C * sizeof(int)));
@@ -981,6 +1001,11 @@ int reserve_dec(crispy_asr* h, int batch, int max_tokens) {
   HIP_TRY(hipMalloc(&h->d_done_count, sizeof(int)));
   HIP_TRY(hipMalloc(&h->d_finished, B * sizeof(int)));
   HIP_TRY(hipMalloc(&h->d_xkv_h, L * B * Tn * 2 * dt * 2));
+  HIP_TRY(hipMalloc(&h->d_plog_all, B * C * sizeof(float)));
+  HIP_TRY(hipMalloc(&h->d_nosp, B * sizeof(float)));
+  HIP_TRY(hipMalloc(&h->d_u_all, B * C * sizeof(double)));
+  HIP_TRY(hipMalloc(&h->d_temperature, sizeof(float)));
+  HIP_TRY(hipMalloc(&h->d_row_off, B * sizeof(int)));
   h->dcap_batch = batch;
   return CRISPY_OK;
 }
@@ -993,7 +1018,7 @@ int decoder_logits(crispy_asr* h, int batch, hipStream_t s, const float* x = nul
   if (h->enc_precision == 1 && h->tok_emb_hp) {
     // the reference's arithmetic: final LayerNorm in f32, rounded to f16, against the f16 embedding, f32 accumulation
     HIP_TRY(layernorm_f16out(x, h->dec_ln_w, h->dec_ln_b, h->d_dxn, batch, dt, s));
-    HIP_TRY(vocab_f16(h->d_dxn, dt, h->tok_emb_hp, h->d_logits, V, batch, V, dt, s));
+    HIP_TRY(vocab_f16(h->d_dxn, dt, h->tok_emb_hp, h->d_logits, logits_ld(h), batch, V, dt, s));
   } else {
     // Vocabulary projection in f32: LayerNorm launch + the 128 x 128 tiled kernel for every batch size.  (Up to 64 clips a
     // persistent LayerNorm-folded kernel, gemm_vocab_f32_kernel, used to run instead -- ~7 us faster per step, but other
@@ -1001,7 +1026,7 @@ int decoder_logits(crispy_asr* h, int batch, hipStream_t s, const float* x = nul
     // the batch it was decoded in.  Mode 0 is the mode the parity claims are made in; one path keeps "alone = in any
     // batch" exact there too.)
     HIP_TRY(layernorm_f32(x, h->dec_ln_w, h->dec_ln_b, h->d_dxn, batch, dt, s));
-    GemmArgs g = gemm(h->d_dxn, dt, h->tok_emb, dt, h->d_logits, V, nullptr, batch, V, dt);
+    GemmArgs g = gemm(h->d_dxn, dt, h->tok_emb, dt, h->d_logits, logits_ld(h), nullptr, batch, V, dt);
     g.tiled = fold ? 1 : 0;
     HIP_TRY(gemm_f32_nt(g, 1, s));
   }
@@ -1031,6 +1056,7 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
     return fail(CRISPY_ERR_INVALID_ARG, "decoder_step: a multi-position step needs the folded path and a host position");
   AttnRows self_rows, cross_rows;
   self_rows.group = P; self_rows.key_step = P > 1 ? 1 : 0;
+  self_rows.key_off = h->cur_row_off;        // left-padded prompts (decode_ts): every clip's keys start at its own cache row
   cross_rows.group = P;
   // The cross K|V of all layers and clips against the 256 MB Infinity Cache: while it fits, it is what stays cached from
   // step to step (plain loads: 16 tiny clips = 147 MB, 6.8 ms per call against 7.0 non-temporal); beyond that it is a
@@ -1042,9 +1068,10 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
   cross_rows.stream_kv = (P == 1 || prompt_nt) && (size_t)clips * h->dec.size() * Tn * 2 * dt * (h->enc_precision == 1 ? 2 : 4) > ((size_t)256 << 20) ? 1 : 0;
   if (!embedded) {    // (a fused pick has written the residual stream already)
     if (h->resident)
-      HIP_TRY(embed_tokens_q(h->d_tok, h->q_tok_emb->d, h->q_tok_emb->ttype, h->dec_pos, pos, pos_dev, h->d_dx, batch, dt, s, P));
+      HIP_TRY(embed_tokens_q(h->d_tok, h->q_tok_emb->d, h->q_tok_emb->ttype, h->dec_pos, pos, pos_dev, h->d_dx, batch, dt, s, P,
+                             h->cur_row_off));
     else
-      HIP_TRY(embed_tokens_f32(h->d_tok, h->tok_emb, h->dec_pos, pos, pos_dev, h->d_dx, batch, dt, s, P));
+      HIP_TRY(embed_tokens_f32(h->d_tok, h->tok_emb, h->dec_pos, pos, pos_dev, h->d_dx, batch, dt, s, P, h->cur_row_off));
   }
   // resident quantised model: every weight operand is de-quantised into the scratch slot in front of its product --
   // f32 x gamma for the LayerNorm-folded projections (fold_ln's W' = W . diag(gamma), element for element), f16 for the
@@ -1261,19 +1288,17 @@ int compute_cross_kv(crispy_asr* h, const float* d_enc, int batch, hipStream_t s
   return CRISPY_OK;
 }
 
-int prefill(crispy_asr* h, const float* d_enc, int batch, const int* prompt, int n_prompt, const int* lang_tokens,
-            hipStream_t s, int* pos_out) {
+// cross K | V of every layer once per window, then the prompts: tok_mat [batch][n_rows] (host) holds every clip's prompt
+// RIGHT-aligned -- a clip whose prompt is shorter than n_rows is padded on the left (token 0) with rows it never attends
+// to (h->cur_row_off: the padding per clip; nullptr = none).  Leaves the logits of the last prompt position in h->d_logits.
+int prefill(crispy_asr* h, const float* d_enc, int batch, const int* tok_mat, int n_rows, hipStream_t s, int* pos_out) {
   {
     const int rc = compute_cross_kv(h, d_enc, batch, s);
     if (rc != CRISPY_OK) return rc;
   }
-  if (lang_tokens && n_prompt > 1)
-    for (int b = 0; b < batch; ++b)
-      if (lang_tokens[b] < 0 || lang_tokens[b] >= h->hp.n_vocab)
-        return fail(CRISPY_ERR_INVALID_ARG, "decode: language token %d out of range", lang_tokens[b]);
   // The prompt runs as multi-position steps: P positions of every clip per step (decoder_step, P > 1), as many as the
   // skinny kernels' row range allows -- batch x P <= SKINNY_MAX_M, so a 4-token prompt of up to 128 clips is ONE step
-  // instead of four, and a long prompt (previous-text conditioning: up to 228 tokens of one clip) takes one step per
+  // instead of four, and a long prompt (previous-text conditioning: up to 228 tokens per clip) takes one step per
   // 512 / batch positions.  Bit-identical to the position-by-position prefill (CRISPY_ASR_PREFILL=seq keeps that one
   // available for the A/B test).
   const char* pf_env = std::getenv("CRISPY_ASR_PREFILL");      // read per call: the A/B test flips it inside one process
@@ -1282,15 +1307,14 @@ int prefill(crispy_asr* h, const float* d_enc, int batch, const int* prompt, int
   const int p_max = (!fold || seq) ? 1 : std::max(1, SKINNY_MAX_M / batch);
   std::vector<int> tok;
   int pos = 0;
-  while (pos < n_prompt) {
-    const int P = std::min(p_max, n_prompt - pos);
+  while (pos < n_rows) {
+    const int P = std::min(p_max, n_rows - pos);
     tok.resize((size_t)batch * P);
     for (int b = 0; b < batch; ++b)
-      for (int j = 0; j < P; ++j)
-        tok[(size_t)b * P + j] = (pos + j == 1 && lang_tokens) ? lang_tokens[b] : prompt[pos + j];   // per-clip language token
+      for (int j = 0; j < P; ++j) tok[(size_t)b * P + j] = tok_mat[(size_t)b * n_rows + pos + j];
     HIP_TRY(hipMemcpyAsync(h->d_tok, tok.data(), sizeof(int) * tok.size(), hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));  // tok is reused by the next iteration
-    const int rc = decoder_step(h, batch, pos, false, pos + P == n_prompt, s, false, P);
+    const int rc = decoder_step(h, batch, pos, false, pos + P == n_rows, s, false, P);
     if (rc != CRISPY_OK) return rc;
     pos += P;
   }
@@ -1299,7 +1323,7 @@ int prefill(crispy_asr* h, const float* d_enc, int batch, const int* prompt, int
 }
 
 StepFuse step_fuse(crispy_asr* h) {
-  StepFuse f{h->tok_emb, h->dec_pos, h->d_dx, h->hp.n_text_state, h->d_counters, nullptr, 0};
+  StepFuse f{h->tok_emb, h->dec_pos, h->d_dx, h->hp.n_text_state, h->d_counters, nullptr, 0, h->cur_row_off};
   if (h->resident) { f.tok_emb_q = h->q_tok_emb->d; f.tok_emb_ttype = h->q_tok_emb->ttype; }
   return f;
 }
@@ -1308,6 +1332,7 @@ TsPickArgs ts_args(crispy_asr* h, int rules, const unsigned char* mask, const un
   const Special sp = special_tokens(h);
   TsPickArgs a{};
   a.logits = h->d_logits;
+  a.ld = logits_ld(h);
   a.mask = mask;
   a.mask_first = mask_first;
   a.st = h->d_ts_state;
@@ -1320,24 +1345,56 @@ TsPickArgs ts_args(crispy_asr* h, int rules, const unsigned char* mask, const un
   a.tokens_out = h->d_tok;
   a.tokens_all = h->d_tokens_all;
   a.tids_all = h->d_tids_all;
+  a.plog_all = h->d_plog_all;
   a.step_dev = h->d_counters + 1;
   a.done_count = h->d_done_count;
+  a.delta_min = TS_DELTA_MIN;
+  a.temperature = h->d_temperature;
+  a.u_all = nullptr;
   return a;
 }
 
-// One decoding window per clip under the timestamp rules (oracle/whisper_oracle.py: decode_window).
-// tokens_out / tids_out: [batch][max_new]; n_out[b] = picks up to and including the one that ended the window.
-int decode_ts(crispy_asr* h, const float* d_enc, int batch, const int* prompt, int n_prompt, const int* lang_tokens,
-              int rules, const int* seek, const int* seek_end, int max_new, const unsigned char* mask,
-              const unsigned char* mask_first, int* tokens_out, int* tids_out, int* n_out) {
+// One decoding pass over one window per row under the timestamp rules (oracle/whisper_oracle.py: decode_window /
+// decode_temperature).  Every row has its own prompt (previous-text conditioning makes them differ in length: they are
+// left-padded to the longest and decoded in lock step, each row attending from its own first cache row on -- the
+// arithmetic of the row decoded alone, bit for bit).  u == nullptr: greedy arg-max.  u [max_new][rows] (host): the
+// sampling pass of the temperature ladder at `temperature` > 0, one uniform variate per (step, row).
+// tokens_out / tids_out / plog_out: [rows][max_new]; n_out[b] = picks up to and including the one that ended the window;
+// nosp_out[b] = softmax of the last prompt position's unfiltered logits at <|nospeech|>.
+int decode_ts(crispy_asr* h, const float* d_enc, int batch, const std::vector<std::vector<int>>& prompts, int rules,
+              const int* seek, const int* seek_end, int max_new, const unsigned char* mask, const unsigned char* mask_first,
+              float temperature, const double* u, int* tokens_out, int* tids_out, float* plog_out, float* nosp_out,
+              int* n_out) {
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = h->stream;
-  int rc = reserve_dec(h, batch, n_prompt + max_new);
+  if ((int)prompts.size() != batch) return fail(CRISPY_ERR_INVALID_ARG, "decode: %zu prompts for %d rows", prompts.size(), batch);
+  int n_rows = 0;
+  for (const auto& p : prompts) {
+    if (p.empty()) return fail(CRISPY_ERR_INVALID_ARG, "decode: empty prompt");
+    for (int t : p)
+      if (t < 0 || t >= h->hp.n_vocab) return fail(CRISPY_ERR_INVALID_ARG, "decode: prompt token %d out of range", t);
+    n_rows = std::max(n_rows, (int)p.size());
+  }
+  if (n_rows + max_new > h->hp.n_text_ctx)
+    return fail(CRISPY_ERR_INVALID_ARG, "decode: %d prompt + %d new tokens exceed n_text_ctx %d", n_rows, max_new, h->hp.n_text_ctx);
+  if (u && !(temperature > 0.f)) return fail(CRISPY_ERR_INVALID_ARG, "decode: sampling needs a temperature > 0");
+  int rc = reserve_dec(h, batch, n_rows + max_new);
   if (rc != CRISPY_OK) return rc;
-  h->dec_max_keys = n_prompt + max_new;
+  h->dec_max_keys = n_rows + max_new;
+  std::vector<int> off(batch), tok_mat((size_t)batch * n_rows, 0);
+  for (int b = 0; b < batch; ++b) {
+    off[b] = n_rows - (int)prompts[b].size();
+    std::copy(prompts[b].begin(), prompts[b].end(), tok_mat.begin() + (size_t)b * n_rows + off[b]);
+  }
+  HIP_TRY(hipMemcpyAsync(h->d_row_off, off.data(), sizeof(int) * batch, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  struct OffGuard { crispy_asr* h; ~OffGuard() { h->cur_row_off = nullptr; } } guard{h};
+  h->cur_row_off = h->d_row_off;
   int pos = 0;
-  rc = prefill(h, d_enc, batch, prompt, n_prompt, lang_tokens, s, &pos);
+  rc = prefill(h, d_enc, batch, tok_mat.data(), n_rows, s, &pos);
   if (rc != CRISPY_OK) return rc;
+  const Special sp = special_tokens(h);
+  HIP_TRY(softmax_prob_f32(h->d_logits, h->hp.n_vocab, logits_ld(h), sp.nosp, h->d_nosp, batch, s));
   std::vector<TsState> st(batch);
   for (int b = 0; b < batch; ++b) st[b] = TsState{-1, -1, 0, -1, 0, seek ? seek[b] : 0, seek_end ? seek_end[b] : (1 << 30), 0};
   // {position of the previous step, index of the next pick, ticket}: the fused pick of a replay embeds at counters[0] + 1
@@ -1345,11 +1402,15 @@ int decode_ts(crispy_asr* h, const float* d_enc, int batch, const int* prompt, i
   HIP_TRY(hipMemcpyAsync(h->d_counters, counters, sizeof(counters), hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(h->d_ts_state, st.data(), sizeof(TsState) * batch, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemsetAsync(h->d_done_count, 0, sizeof(int), s));
+  HIP_TRY(hipMemcpyAsync(h->d_temperature, &temperature, sizeof(float), hipMemcpyHostToDevice, s));
+  if (u) HIP_TRY(hipMemcpyAsync(h->d_u_all, u, sizeof(double) * (size_t)max_new * batch, hipMemcpyHostToDevice, s));
   HIP_TRY(hipStreamSynchronize(s));
-  const TsPickArgs pa = ts_args(h, rules, mask, mask_first);
+  TsPickArgs pa = ts_args(h, rules, mask, mask_first);
+  pa.u_all = u ? h->d_u_all : nullptr;
   int steps_run = 1;      // picks made = decoder steps replayed + the final pick
   if (max_new > 1) {
-    const int kc = h->dec_max_keys <= 128 ? 0 : h->dec_max_keys <= 256 ? 1 : 2;      // key class: its own graph slot
+    // its own graph slot per key class and kind of pick
+    const int kc = (h->dec_max_keys <= 128 ? 0 : h->dec_max_keys <= 256 ? 1 : 2) + (u ? 3 : 0);
     if (!h->ts_graphs[kc] || h->ts_graph_batch[kc] != batch || h->ts_graph_rules[kc] != rules || h->ts_graph_mask[kc] != mask) {
       if (h->ts_graphs[kc]) { (void)hipGraphExecDestroy(h->ts_graphs[kc]); h->ts_graphs[kc] = nullptr; }
       hipGraph_t graph = nullptr;
@@ -1380,8 +1441,11 @@ int decode_ts(crispy_asr* h, const float* d_enc, int batch, const int* prompt, i
   }
   HIP_TRY(ts_pick(pa, batch, s));   // the last pick needs no further decoder step
   std::vector<int> all((size_t)steps_run * batch), tids((size_t)steps_run * batch);
+  std::vector<float> plog((size_t)steps_run * batch), nosp(batch);
   HIP_TRY(hipMemcpyAsync(all.data(), h->d_tokens_all, all.size() * sizeof(int), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(tids.data(), h->d_tids_all, tids.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(plog.data(), h->d_plog_all, plog.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(nosp.data(), h->d_nosp, nosp.size() * sizeof(float), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(st.data(), h->d_ts_state, sizeof(TsState) * batch, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   for (int b = 0; b < batch; ++b) {
@@ -1389,7 +1453,9 @@ int decode_ts(crispy_asr* h, const float* d_enc, int batch, const int* prompt, i
     for (int i = 0; i < max_new; ++i) {
       tokens_out[(size_t)b * max_new + i] = i < n ? all[(size_t)i * batch + b] : h->eot;
       if (tids_out) tids_out[(size_t)b * max_new + i] = i < n ? tids[(size_t)i * batch + b] : pa.beg;
+      if (plog_out) plog_out[(size_t)b * max_new + i] = i < n ? plog[(size_t)i * batch + b] : 0.f;
     }
+    if (nosp_out) nosp_out[b] = nosp[b];
     if (n_out) n_out[b] = n;
   }
   return CRISPY_OK;
@@ -1399,7 +1465,7 @@ int decode_ts(crispy_asr* h, const float* d_enc, int batch, const int* prompt, i
 // advance the device counters: the body of one generated token
 int generation_body(crispy_asr* h, int batch, hipStream_t s) {
   const StepFuse f = step_fuse(h);         // pick + embedding of the pick + counters in one launch
-  HIP_TRY(argmax_f32(h->d_logits, h->d_suppress, h->d_suppress_first, h->d_counters + 1, h->hp.n_vocab, h->d_tok,
+  HIP_TRY(argmax_f32(h->d_logits, h->d_suppress, h->d_suppress_first, h->d_counters + 1, h->hp.n_vocab, logits_ld(h), h->d_tok,
                      h->d_tokens_all, h->d_best, batch, s, h->eot, h->d_finished, h->d_done_count, &f));
   return decoder_step(h, batch, 0, true, true, s, true);
 }
@@ -1443,7 +1509,8 @@ int crispy_asr_stage_logits_device(crispy_asr* h, const float* d_x, int batch, f
   HIP_TRY(hipMemcpyAsync(h->d_dx, d_x, sizeof(float) * batch * dt, hipMemcpyDeviceToDevice, s));
   rc = decoder_logits(h, batch, s);
   if (rc != CRISPY_OK) return rc;
-  HIP_TRY(hipMemcpyAsync(d_logits, h->d_logits, sizeof(float) * (size_t)batch * V, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpy2DAsync(d_logits, sizeof(float) * (size_t)V, h->d_logits, sizeof(float) * (size_t)logits_ld(h), sizeof(float) * (size_t)V,
+                           (size_t)batch, hipMemcpyDeviceToDevice, s));
   HIP_TRY(hipStreamSynchronize(s));
   return CRISPY_OK;
 } CRISPY_CATCH_RET("crispy_asr_stage_logits_device")
@@ -1476,7 +1543,16 @@ int crispy_asr_decode_greedy_lang_device(crispy_asr* h, const float* d_enc, int 
   h->dec_max_keys = n_prompt + max_new;
   const int V = h->hp.n_vocab;
   int pos = 0;
-  rc = prefill(h, d_enc, batch, prompt, n_prompt, lang_tokens, s, &pos);
+  {
+    std::vector<int> tok_mat((size_t)batch * n_prompt);
+    for (int b = 0; b < batch; ++b)
+      for (int j = 0; j < n_prompt; ++j) {
+        const int t = (j == 1 && lang_tokens) ? lang_tokens[b] : prompt[j];        // per-clip language token
+        if (t < 0 || t >= h->hp.n_vocab) return fail(CRISPY_ERR_INVALID_ARG, "decode: language token %d out of range", t);
+        tok_mat[(size_t)b * n_prompt + j] = t;
+      }
+    rc = prefill(h, d_enc, batch, tok_mat.data(), n_prompt, s, &pos);
+  }
   if (rc != CRISPY_OK) return rc;
   const int counters[4] = {pos - 1, 0, 0, 0};     // {position of the previous step, index of the next pick, ticket} (StepFuse)
   HIP_TRY(hipMemcpyAsync(h->d_counters, counters, sizeof(counters), hipMemcpyHostToDevice, s));
@@ -1511,7 +1587,7 @@ int crispy_asr_decode_greedy_lang_device(crispy_asr* h, const float* d_enc, int 
     }
   }
   // the last pick needs no further decoder step
-  HIP_TRY(argmax_f32(h->d_logits, h->d_suppress, h->d_suppress_first, h->d_counters + 1, V, h->d_tok, h->d_tokens_all,
+  HIP_TRY(argmax_f32(h->d_logits, h->d_suppress, h->d_suppress_first, h->d_counters + 1, V, logits_ld(h), h->d_tok, h->d_tokens_all,
                      h->d_best, batch, s, h->eot, h->d_finished, h->d_done_count));
   std::vector<int> all((size_t)max_new * batch, h->eot);
   std::vector<float> best((size_t)max_new * batch, 0.f);
@@ -1549,9 +1625,39 @@ int crispy_asr_decode_timestamps_device(crispy_asr* h, const float* d_enc, int b
   for (int i = 0; i < n_prompt; ++i)
     if (prompt[i] < 0 || prompt[i] >= h->hp.n_vocab)
       return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_decode_timestamps_device: prompt token %d out of range", prompt[i]);
-  return decode_ts(h, d_enc, batch, prompt, n_prompt, lang_tokens, rules, seek, seek_end, max_new, h->d_suppress,
-                   h->d_suppress_first, tokens_out, tids_out, n_out);
+  std::vector<std::vector<int>> prompts((size_t)batch, std::vector<int>(prompt, prompt + n_prompt));
+  if (lang_tokens && n_prompt > 1)
+    for (int b = 0; b < batch; ++b) prompts[b][1] = lang_tokens[b];
+  return decode_ts(h, d_enc, batch, prompts, rules, seek, seek_end, max_new, h->d_suppress, h->d_suppress_first, 0.f, nullptr,
+                   tokens_out, tids_out, nullptr, nullptr, n_out);
 } CRISPY_CATCH_RET("crispy_asr_decode_timestamps_device")
+
+int crispy_asr_decode_window_device(crispy_asr* h, const float* d_enc, int rows, const int* prompts, const int* n_prompt,
+                                    int prompt_stride, int rules, const int* seek, const int* seek_end, int max_new,
+                                    float temperature, const double* u, int* tokens_out, int* tids_out, float* plog_out,
+                                    float* no_speech_prob_out, int* n_out) try {
+  if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_decode_window_device: NULL handle");
+  if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_decode_window_device: model not finalized");
+  if (rows < 0 || max_new < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_decode_window_device: negative size");
+  if (rows == 0 || max_new == 0) return CRISPY_OK;
+  if (!d_enc || !prompts || !n_prompt || !tokens_out || prompt_stride <= 0)
+    return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_decode_window_device: NULL argument");
+  if (rules != TS_RULES_WCPP && rules != TS_RULES_OPENAI)
+    return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_decode_window_device: rules must be 0 (whisper.cpp) or 1 (openai)");
+  if (special_tokens(h).beg + 1501 > h->hp.n_vocab)
+    return fail(CRISPY_ERR_UNSUPPORTED, "crispy_asr_decode_window_device: vocabulary of %d has no timestamp tokens", h->hp.n_vocab);
+  if (u && !(temperature > 0.f))
+    return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_decode_window_device: sampling (u != NULL) needs a temperature > 0");
+  std::vector<std::vector<int>> pr((size_t)rows);
+  for (int b = 0; b < rows; ++b) {
+    if (n_prompt[b] <= 0 || n_prompt[b] > prompt_stride)
+      return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_decode_window_device: row %d has a prompt of %d tokens (stride %d)", b, n_prompt[b], prompt_stride);
+    pr[b].assign(prompts + (size_t)b * prompt_stride, prompts + (size_t)b * prompt_stride + n_prompt[b]);
+  }
+  if (!h->d_ts_mask) { const int rc = build_ts_masks(h); if (rc != CRISPY_OK) return rc; }
+  return decode_ts(h, d_enc, rows, pr, rules, seek, seek_end, max_new, h->d_ts_mask, h->d_ts_mask_first, temperature, u,
+                   tokens_out, tids_out, plog_out, no_speech_prob_out, n_out);
+} CRISPY_CATCH_RET("crispy_asr_decode_window_device")
 
 // whisper.cpp `whisper_lang_auto_detect`: feed <|startoftranscript|> alone and take the most probable
 // language token [UPSTREAM-RECALL].  English-only vocabularies have nothing to detect.
@@ -1582,7 +1688,7 @@ int crispy_asr_detect_language_device(crispy_asr* h, const float* d_enc, int bat
     HIP_TRY(hipMalloc(&h->d_lang_mask, V));
     HIP_TRY(hipMemcpy(h->d_lang_mask, m.data(), V, hipMemcpyHostToDevice));
   }
-  HIP_TRY(argmax_f32(h->d_logits, h->d_lang_mask, nullptr, nullptr, V, h->d_tok, nullptr, nullptr, batch, s));
+  HIP_TRY(argmax_f32(h->d_logits, h->d_lang_mask, nullptr, nullptr, V, logits_ld(h), h->d_tok, nullptr, nullptr, batch, s));
   HIP_TRY(hipMemcpyAsync(lang_tokens_out, h->d_tok, sizeof(int) * batch, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   return CRISPY_OK;
@@ -1702,6 +1808,7 @@ struct crispy_asr_result_impl {
   std::vector<std::string> seg_text;
   std::vector<float> seg_t0, seg_t1;
   std::vector<crispy_asr_segment> segs;
+  std::vector<crispy_asr_window> wins;
 };
 
 // whisper.cpp's always-suppressed specials (whisper_process_logits [UPSTREAM-RECALL]): sot, nosp, translate,
@@ -1726,25 +1833,64 @@ int build_ts_masks(crispy_asr* h) {
   return CRISPY_OK;
 }
 
-// whisper_full's bookkeeping over the picks of one window (oracle/whisper_oracle.py: decode_window):
-// how many tokens are kept and how far the window advances
-void window_bookkeeping(const int* toks, int n, int max_new, int beg, int eot, int seek, int seek_end, int* result_len,
-                        int* seek_delta) {
-  bool has_ts = false, ended = false;
-  int sd = 3000, rl = 0;
-  for (int i = 0; i < n; ++i) {
-    const int t = toks[i];
-    if (t > beg) { sd = 2 * (t - beg); rl = i + 1; has_ts = true; }
-    if (t == eot || (has_ts && seek + sd + 100 >= seek_end)) {
-      if (t == eot && rl == 0) rl = i + 1;          // no temperature fallback: keep what was decoded
-      ended = true;
-      break;
+// One decoder of one pass over a window: the picks the device made, and whisper_full's bookkeeping replayed over them
+// (oracle/whisper_oracle.py: decode_temperature) [UPSTREAM-RECALL: whisper_full_with_state, "update the decoder state"].
+struct DecoderPass {
+  const int* toks = nullptr;
+  const int* tids = nullptr;
+  const float* plog = nullptr;
+  int n = 0;                         // picks made (the device stops a row at EOT or at a timestamp delta_min from the end)
+  bool has_ts = false, failed = false, completed = false, scored = false;
+  int seek_delta = 3000, result_len = 0;
+  double sum_logprobs = 0, avg_logprobs = -INFINITY, score = -INFINITY, entropy = 0;
+};
+
+void replay_decoder(DecoderPass& d, int n_max, int beg, int eot, int seek, int seek_end, int delta_min) {
+  for (int i = 0; i < d.n; ++i) {
+    const int t = d.toks[i];
+    if (t > beg) {
+      const int sd = 2 * (t - beg);
+      if (d.has_ts && d.seek_delta > sd && d.result_len < i) { d.failed = true; return; }   // "do not allow to go back in time"
+      d.seek_delta = sd; d.result_len = i + 1; d.has_ts = true;
     }
+    if (t == eot || (d.has_ts && seek + d.seek_delta + delta_min >= seek_end)) {
+      if (d.result_len == 0) {
+        if (seek + d.seek_delta + delta_min >= seek_end) d.result_len = i + 1;
+        else { d.failed = true; return; }                   // end of text before any timestamp: nothing to keep
+      }
+      d.completed = true;
+      return;
+    }
+    if (i == n_max - 1 && (d.result_len == 0 || d.seek_delta < 1500)) { d.failed = true; return; }   // repetition loop
   }
-  if (!ended && rl == 0) rl = n;
-  (void)max_new;
-  *result_len = rl;
-  *seek_delta = sd;
+}
+
+// whisper_sequence_score over the kept tokens: sum / mean log-probability, the ranking score (length_penalty -1: the
+// mean), entropy of the token histogram of the last 32
+void score_decoder(DecoderPass& d) {
+  if (d.result_len == 0) return;
+  double sum = 0;
+  for (int i = 0; i < d.result_len; ++i) sum += d.plog[i];
+  d.sum_logprobs = sum;
+  d.avg_logprobs = sum / d.result_len;
+  d.score = sum / d.result_len;
+  std::map<int, int> cnt;
+  int c = 0;
+  for (int i = std::max(0, d.result_len - 32); i < d.result_len; ++i) { cnt[d.toks[i]]++; ++c; }
+  double ent = 0;
+  for (const auto& kv : cnt) {
+    const double p = kv.second / (double)c;
+    ent -= p * std::log(p);
+  }
+  d.entropy = ent;
+  d.scored = true;
+}
+
+// std::generate_canonical<double, 53>(std::mt19937) as libstdc++ and libc++ compute it: two draws, (x0 + x1 2^32) / 2^64
+double canonical(std::mt19937& g) {
+  const double x0 = (double)g(), x1 = (double)g();
+  const double u = (x0 + x1 * 4294967296.0) / 18446744073709551616.0;
+  return u < 1.0 ? u : std::nextafter(1.0, 0.0);
 }
 
 // segments of one window as whisper_full builds them (oracle: window_segments); times in seconds
@@ -1777,6 +1923,8 @@ void publish(crispy_asr_result_impl* r) {
   r->pub.language_token = r->language_token;
   r->pub.n_segments = (int)r->segs.size();
   r->pub.segments = r->segs.empty() ? nullptr : r->segs.data();
+  r->pub.n_windows = (int)r->wins.size();
+  r->pub.windows = r->wins.empty() ? nullptr : r->wins.data();
 }
 
 }  // namespace
@@ -2010,7 +2158,7 @@ int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const si
                   "(commands/transcription.rs:249-302)", i, n[i]);
     if (n[i] > 0) {
       if (!pcm[i]) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: clip %d is NULL", i);
-      if (n[i] / 160 < 100) continue;
+      if (1 + ((long)n[i] + 200 - 400) / 160 < TS_DELTA_MIN) continue;
       live.push_back(i);
       if (n[i] > stride) stride = n[i];
     }
@@ -2077,17 +2225,55 @@ int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const si
         return CRISPY_OK;
       }
       // ---- whisper_full's seek loop, all clips in lock step ----
+      // [UPSTREAM-RECALL: whisper_full_with_state].  Per round every clip that has audio left decodes one window:
+      //   * prompt = (<|startofprev|> + the last min(n_text_ctx / 2, |past|) tokens of the text so far) + the usual prompt;
+      //     the past is dropped when fewer than 5 s of audio are left ("a very short segment ... tends to confuse the
+      //     decoder") and for a re-decode at a temperature >= 0.5; after a window: past = the past part of its prompt + its
+      //     kept tokens (nothing from a window dropped as silence);
+      //   * the temperature ladder: greedy at `temperature`, all clips of the round as ONE batch (their prompts differ in
+      //     length: decode_ts left-pads); a clip whose window fails is decoded again at the next temperature with
+      //     best_of sampling decoders (rows of one batch over copies of its encoder output), until one passes or the
+      //     ladder ends;
+      //   * no-speech rule, segments, and how far the window advances (the last closed timestamp pair, the whole
+      //     window after a single closing timestamp).
+      const int delta_min = TS_DELTA_MIN;
       std::vector<int> seek(nb, 0), seek_end(nb);
-      for (int k = 0; k < nb; ++k) seek_end[k] = lens[k] / 160;
-      // whisper.cpp's prompt_past [UPSTREAM-RECALL: whisper_full_with_state]: the kept tokens of the windows so far condition
-      // the next window -- prompt = <|startofprev|> + the last min(n_text_ctx / 2, |past|) of them + the usual prompt -- unless
-      // fewer than 5 s of audio are left ("a very short segment ... tends to confuse the decoder").  After a window: past =
-      // the past part of its prompt + its kept tokens.  (The temperature test `t_cur < 0.5` is always true here: greedy, no
-      // fallback.)
+      for (int k = 0; k < nb; ++k) seek_end[k] = 1 + (lens[k] + 200 - 400) / 160;      // whisper.cpp's mel.n_len_org
+      const float t0 = opts ? opts->temperature : 0.f;
+      const float t_inc = !opts || opts->temperature_inc == 0.f ? 0.2f : opts->temperature_inc;
+      const float entropy_thold = !opts || opts->entropy_thold == 0.f ? 2.4f : opts->entropy_thold;
+      const float logprob_thold = !opts || opts->logprob_thold == 0.f ? -1.0f : opts->logprob_thold;
+      const float no_speech_thold = !opts || opts->no_speech_thold == 0.f ? 0.6f : opts->no_speech_thold;
+      const int best_of = std::max(1, !opts || opts->best_of == 0 ? 5 : opts->best_of);
+      if (best_of > 8) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: best_of %d > 8 (WHISPER_MAX_DECODERS)", best_of);
+      std::vector<float> temps;
+      if (t_inc > 0.f) for (float t = t0; t < 1.0f + 1e-6f; t += t_inc) temps.push_back(t);
+      else temps.push_back(t0);
+      if (temps.empty()) temps.push_back(t0);
       const bool use_past = !(opts && opts->no_prev_text);
       std::vector<std::vector<int>> past(nb);
+      std::vector<std::vector<std::mt19937>> rngs(nb);
+      for (int k = 0; k < nb; ++k)
+        for (int j = 0; j < best_of; ++j) rngs[k].emplace_back((unsigned)j);
       const int n_init = (int)prompt.size();
-      // whisper.cpp loops until seek + 100 >= seek_end.  Every round advances every active clip by seek_delta >= 2
+      const size_t enc_clip = (size_t)h->hp.n_audio_ctx * h->hp.n_audio_state;
+      float* d_enc_rep = nullptr;                         // best_of copies of one clip's encoder output (fallback passes)
+      struct RepGuard { float** p; ~RepGuard() { if (*p) (void)hipFree(*p); } } rep_guard{&d_enc_rep};
+      auto build_prompt = [&](int k, int lang_tok, float t_cur) {
+        std::vector<int> p;
+        if (use_past && !past[k].empty() && t_cur < 0.5f) {
+          int n_take = std::min<int>(h->hp.n_text_ctx / 2, (int)past[k].size());
+          n_take = std::min(n_take, h->hp.n_text_ctx - max_new - n_init - 1);
+          if (n_take > 0) {
+            p.push_back(sp.prev);
+            p.insert(p.end(), past[k].end() - n_take, past[k].end());
+          }
+        }
+        p.insert(p.end(), prompt.begin(), prompt.end());
+        if (sp.multilingual) p[p.size() - n_init + 1] = lang_tok;
+        return p;
+      };
+      // whisper.cpp loops until seek + delta_min >= seek_end.  Every round advances every active clip by seek_delta >= 2
       // (a closed pair ends on a timestamp strictly above <|0.00|>, otherwise the delta is the whole window), so
       // 1500 rounds cover any 30 s clip; running out of them is reported, never a silently shorter transcript.
       const int kMaxRounds = 1501;
@@ -2096,7 +2282,7 @@ int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const si
           return fail(CRISPY_ERR_HIP, "crispy_asr_transcribe_batch: seek loop did not terminate after %d windows", kMaxRounds);
         std::vector<int> act;
         for (int k = 0; k < nb; ++k)
-          if (seek_end[k] >= 100 && seek[k] + 100 < seek_end[k]) act.push_back(k);   // < 1 s left: whisper.cpp stops
+          if (seek_end[k] >= delta_min && seek[k] + delta_min < seek_end[k]) act.push_back(k);   // < 100 ms left: whisper.cpp stops
         if (act.empty()) break;
         const int na = (int)act.size();
         if (!(round == 0 && na == nb)) {     // round 0 with every clip active: the encoder output is already there
@@ -2107,58 +2293,142 @@ int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const si
           rc = crispy_asr_encode_device(h, h->w_melt, na, h->w_enc, h->stream);
           if (rc != CRISPY_OK) return rc;
         }
-        std::vector<int> a_lang(na), a_seek(na), a_end(na), toks((size_t)na * max_new), tids((size_t)na * max_new), n_out(na, 0);
-        for (int a = 0; a < na; ++a) { a_lang[a] = lang[act[a]]; a_seek[a] = seek[act[a]]; a_end[a] = seek_end[act[a]]; }
-        bool any_past = false;
         for (int a = 0; a < na; ++a) {
           const int k = act[a];
           if (seek[k] > 0 && seek[k] + 500 >= seek_end[k]) past[k].clear();
-          any_past = any_past || (use_past && !past[k].empty());
         }
-        std::vector<std::vector<int>> used((size_t)na);      // the prompt each clip's window ran with
-        if (!any_past) {
-          rc = decode_ts(h, h->w_enc, na, prompt.data(), n_init, sp.multilingual ? a_lang.data() : nullptr,
-                         TS_RULES_WCPP, a_seek.data(), a_end.data(), max_new, h->d_ts_mask, h->d_ts_mask_first, toks.data(),
-                         tids.data(), n_out.data());
-          if (rc != CRISPY_OK) return rc;
-        } else {
-          // prompts differ in length from clip to clip now: one decode call per clip (its prompt runs as one or two
-          // multi-position steps, see prefill), over its slice of the encoder output
-          const size_t enc_clip = (size_t)h->hp.n_audio_ctx * h->hp.n_audio_state;
-          for (int a = 0; a < na; ++a) {
-            const int k = act[a];
-            std::vector<int>& p = used[a];
-            if (use_past && !past[k].empty()) {
-              int n_take = std::min<int>(h->hp.n_text_ctx / 2, (int)past[k].size());
-              n_take = std::min(n_take, h->hp.n_text_ctx - max_new - n_init - 1);
-              if (n_take > 0) {
-                p.push_back(sp.prev);
-                p.insert(p.end(), past[k].end() - n_take, past[k].end());
+        // per active clip: the pass whisper_full ends up accepting
+        struct Accepted {
+          std::vector<int> toks, tids, prompt;
+          std::vector<float> plog;
+          DecoderPass d;
+          float nosp = 0.f, temperature = 0.f;
+          int decoder = 0;
+          bool have = false;
+        };
+        std::vector<Accepted> acc((size_t)na);
+        std::vector<int> pending((size_t)na);
+        for (int a = 0; a < na; ++a) pending[a] = a;
+        for (size_t it = 0; it < temps.size() && !pending.empty(); ++it) {
+          const float t_cur = temps[it];
+          const bool last_temp = it + 1 == temps.size();
+          const int n_dec = t_cur > 0.f ? best_of : 1;
+          std::vector<int> still;
+          // groups of rows decoded together: at temperature 0 all pending clips (one row each, straight off h->w_enc when
+          // nothing has dropped out yet); above it one clip at a time, n_dec rows over copies of its encoder output
+          std::vector<std::vector<int>> groups;
+          if (n_dec == 1) groups.push_back(pending);
+          else for (int a : pending) groups.push_back({a});
+          for (const std::vector<int>& grp : groups) {
+            const int rows = n_dec == 1 ? (int)grp.size() : n_dec;
+            const float* d_enc = h->w_enc;
+            const bool contiguous = n_dec == 1 && (int)grp.size() == na;
+            if (!contiguous) {
+              if (!d_enc_rep) HIP_TRY(hipMalloc(&d_enc_rep, (size_t)std::max(na, best_of) * enc_clip * sizeof(float)));
+              for (int r = 0; r < rows; ++r) {
+                const int a = n_dec == 1 ? grp[r] : grp[0];
+                HIP_TRY(hipMemcpyAsync(d_enc_rep + (size_t)r * enc_clip, h->w_enc + (size_t)a * enc_clip, enc_clip * sizeof(float),
+                                       hipMemcpyDeviceToDevice, h->stream));
+              }
+              d_enc = d_enc_rep;
+            }
+            std::vector<std::vector<int>> prompts((size_t)rows);
+            std::vector<int> r_seek(rows), r_end(rows);
+            for (int r = 0; r < rows; ++r) {
+              const int a = n_dec == 1 ? grp[r] : grp[0], k = act[a];
+              prompts[r] = build_prompt(k, lang[k], t_cur);
+              r_seek[r] = seek[k]; r_end[r] = seek_end[k];
+            }
+            std::vector<double> u;
+            if (t_cur > 0.f) {            // the variates decoder j would draw, from a copy of its generator
+              const int k = act[grp[0]];
+              u.resize((size_t)max_new * rows);
+              for (int j = 0; j < rows; ++j) {
+                std::mt19937 g = rngs[k][j];
+                for (int i = 0; i < max_new; ++i) u[(size_t)i * rows + j] = canonical(g);
               }
             }
-            p.insert(p.end(), prompt.begin(), prompt.end());
-            if (sp.multilingual) p[p.size() - n_init + 1] = a_lang[a];
-            rc = decode_ts(h, h->w_enc + (size_t)a * enc_clip, 1, p.data(), (int)p.size(), nullptr, TS_RULES_WCPP, &a_seek[a],
-                           &a_end[a], max_new, h->d_ts_mask, h->d_ts_mask_first, toks.data() + (size_t)a * max_new,
-                           tids.data() + (size_t)a * max_new, &n_out[a]);
+            std::vector<int> toks((size_t)rows * max_new), tids((size_t)rows * max_new), n_out(rows, 0);
+            std::vector<float> plog((size_t)rows * max_new), nosp(rows, 0.f);
+            rc = decode_ts(h, d_enc, rows, prompts, TS_RULES_WCPP, r_seek.data(), r_end.data(), max_new, h->d_ts_mask,
+                           h->d_ts_mask_first, t_cur, t_cur > 0.f ? u.data() : nullptr, toks.data(), tids.data(), plog.data(),
+                           nosp.data(), n_out.data());
             if (rc != CRISPY_OK) return rc;
+            // evaluate: per clip of the group, its n_dec decoders
+            const int n_clips = n_dec == 1 ? (int)grp.size() : 1;
+            for (int c = 0; c < n_clips; ++c) {
+              const int a = grp[c], k = act[a];
+              std::vector<DecoderPass> decs((size_t)n_dec);
+              for (int j = 0; j < n_dec; ++j) {
+                const int r = n_dec == 1 ? c : j;
+                DecoderPass& d = decs[j];
+                d.toks = toks.data() + (size_t)r * max_new;
+                d.tids = tids.data() + (size_t)r * max_new;
+                d.plog = plog.data() + (size_t)r * max_new;
+                d.n = n_out[r];
+                replay_decoder(d, max_new, sp.beg, h->eot, seek[k], seek_end[k], delta_min);
+                if (t_cur > 0.f) rngs[k][j].discard(2ull * (unsigned long long)d.n);      // what it drew: two per pick
+              }
+              // rank the sequences that did not fail (whisper.cpp: "rank the resulting sequences and select the best one")
+              int best = acc[a].have ? acc[a].decoder : 0;      // best_decoder_id survives a pass in which every decoder failed
+              if (best >= n_dec) best = 0;
+              double best_score = -INFINITY;
+              for (int j = 0; j < n_dec; ++j) {
+                DecoderPass& d = decs[j];
+                if (d.failed) continue;
+                score_decoder(d);
+                if (d.result_len > 32 && d.entropy < entropy_thold) { d.failed = true; continue; }
+                if (best_score < d.score) { best_score = d.score; best = j; }
+              }
+              const DecoderPass& bd = decs[best];
+              bool success = true;
+              if (!last_temp && (bd.failed || (bd.avg_logprobs < logprob_thold && nosp[n_dec == 1 ? c : 0] < no_speech_thold)))
+                success = false;
+              Accepted& A = acc[a];
+              const int r = n_dec == 1 ? c : best;
+              A.toks.assign(toks.begin() + (size_t)r * max_new, toks.begin() + (size_t)r * max_new + bd.n);
+              A.tids.assign(tids.begin() + (size_t)r * max_new, tids.begin() + (size_t)r * max_new + bd.n);
+              A.plog.assign(plog.begin() + (size_t)r * max_new, plog.begin() + (size_t)r * max_new + bd.n);
+              A.d = bd;
+              A.d.toks = A.toks.data(); A.d.tids = A.tids.data(); A.d.plog = A.plog.data();
+              A.prompt = prompts[r];
+              A.nosp = nosp[n_dec == 1 ? c : 0];
+              A.temperature = t_cur;
+              A.decoder = best;
+              A.have = true;
+              if (!success) still.push_back(a);
+            }
           }
+          pending.swap(still);
         }
         for (int a = 0; a < na; ++a) {
           const int k = act[a];
           crispy_asr_result_impl* r = impl[live[k]];
-          const int* tk = toks.data() + (size_t)a * max_new;
-          int result_len = 0, seek_delta = 3000;
-          window_bookkeeping(tk, n_out[a], max_new, sp.beg, h->eot, seek[k], seek_end[k], &result_len, &seek_delta);
-          window_segments(h, tk, tids.data() + (size_t)a * max_new, result_len, sp.beg, seek[k], seek_delta, r);
-          for (int i = 0; i < result_len; ++i)
-            if (tk[i] != h->eot) r->tokens.push_back(tk[i]);
+          const Accepted& A = acc[a];
+          const DecoderPass& d = A.d;
+          // a decoder that failed before the ranking keeps all its tokens (only ranked sequences are cut to result_len)
+          const int n_cur = d.scored ? d.result_len : d.n;
+          const bool is_no_speech = A.nosp > no_speech_thold && d.avg_logprobs < logprob_thold;
           {
             std::vector<int> np;
-            if (!used[a].empty() && used[a].front() == sp.prev) np.assign(used[a].begin() + 1, used[a].end() - n_init);
-            np.insert(np.end(), tk, tk + result_len);
+            if (A.prompt.front() == sp.prev) np.assign(A.prompt.begin() + 1, A.prompt.end() - n_init);
+            if (!is_no_speech) np.insert(np.end(), A.toks.begin(), A.toks.begin() + d.result_len);
             past[k].swap(np);
           }
+          int seek_delta = d.seek_delta;
+          if (n_cur > 0 && !is_no_speech) {
+            window_segments(h, A.toks.data(), A.tids.data(), n_cur, sp.beg, seek[k], seek_delta, r);
+            for (int i = 0; i < n_cur; ++i)
+              if (A.toks[i] != h->eot) r->tokens.push_back(A.toks[i]);
+          }
+          // a single closing timestamp: nothing is left to say in this chunk [UPSTREAM-RECALL: whisper.cpp PR 2629]
+          if (n_cur > 1 && A.toks[n_cur - 2] < sp.beg && A.toks[n_cur - 1] > sp.beg)
+            seek_delta = std::min(seek_end[k] - seek[k], 3000);
+          crispy_asr_window w{};
+          w.seek = seek[k]; w.seek_advance = seek_delta; w.n_tokens = is_no_speech ? 0 : n_cur; w.decoder = A.decoder;
+          w.failed = d.failed ? 1 : 0; w.no_speech = is_no_speech ? 1 : 0; w.temperature = A.temperature;
+          w.no_speech_prob = A.nosp; w.avg_logprob = (float)d.avg_logprobs; w.entropy = (float)d.entropy;
+          r->wins.push_back(w);
           seek[k] += seek_delta;
         }
       }

@@ -760,11 +760,18 @@ __global__ __launch_bounds__(64 * AD_WAVES) void attn_dec_kernel(const float* __
   const int h = blockIdx.x, b = blockIdx.y;
   // rows.group query rows per clip (asr_common.h: AttnRows): row b belongs to clip b / group and reads that clip's K|V
   const int clip = b / rows.group;
-  const int n_keys = n_keys_base + (pos_dev ? *pos_dev : 0) + rows.key_step * (b % rows.group);
+  // rows.key_off: the clip's keys start at cache row key_off[clip] (left-padded prompts); the partition below then runs
+  // over the same key COUNT from a shifted base -- the arithmetic of the un-padded clip, bit for bit
+  const int k_off = rows.key_off ? rows.key_off[clip] : 0;
+  const int n_keys = n_keys_base + (pos_dev ? *pos_dev : 0) + rows.key_step * (b % rows.group) - k_off;
+  if (n_keys <= 0) {                    // a padding row in front of the clip's prompt: nothing to attend to, never read
+    if (tid < 64) out[(long)b * ldo + h * 64 + tid] = 0.f;
+    return;
+  }
   if (tid < 64) q_s[tid] = q[(long)b * ldq + h * 64 + tid] * 0.125f;
   __syncthreads();
-  const KV* Kb = kv + (long)clip * kv_batch_stride + koff + h * head_stride;
-  const KV* Vb = kv + (long)clip * kv_batch_stride + voff + h * head_stride;
+  const KV* Kb = kv + (long)clip * kv_batch_stride + koff + h * head_stride + (long)k_off * ldkv;
+  const KV* Vb = kv + (long)clip * kv_batch_stride + voff + h * head_stride + (long)k_off * ldkv;
   const int per = (n_keys + AD_WAVES - 1) / AD_WAVES;
   const int k_lo = wave * per, k_hi = min(n_keys, k_lo + per);
   // scores: 16 lanes share one key row (coalesced 256-byte reads, 4 keys per wave instruction), the
@@ -896,15 +903,20 @@ __global__ __launch_bounds__(64 * AD_WAVES) void attn_dec_x16_kernel(const float
   // rows.group query rows per clip (asr_common.h: AttnRows): row b belongs to clip b / group and reads that clip's K|V
   const int b = blockIdx.y;
   const int clip = b / rows.group;
-  const int n_keys = n_keys_base + (pos_dev ? *pos_dev : 0) + rows.key_step * (b % rows.group);
+  const int k_off = rows.key_off ? rows.key_off[clip] : 0;       // see attn_dec_kernel
+  const int n_keys = n_keys_base + (pos_dev ? *pos_dev : 0) + rows.key_step * (b % rows.group) - k_off;
   typedef _Float16 half8 __attribute__((ext_vector_type(8)));
   __shared__ __attribute__((aligned(16))) float part_o[AD_WAVES][64];
   __shared__ float part_m[AD_WAVES], part_l[AD_WAVES];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int h = blockIdx.x;
+  if (n_keys <= 0) {
+    if (tid < 64) out[(long)b * ldo + h * 64 + tid] = 0.f;
+    return;
+  }
   const int c = lane & 7, r = lane >> 3;
-  const _Float16* Kb = kv + (long)clip * kv_batch_stride + koff + h * head_stride + 8 * c;
-  const _Float16* Vb = kv + (long)clip * kv_batch_stride + voff + h * head_stride + 8 * c;
+  const _Float16* Kb = kv + (long)clip * kv_batch_stride + koff + h * head_stride + 8 * c + (long)k_off * ldkv;
+  const _Float16* Vb = kv + (long)clip * kv_batch_stride + voff + h * head_stride + 8 * c + (long)k_off * ldkv;
   const int per = (n_keys + AD_WAVES - 1) / AD_WAVES;
   const int k_lo = wave * per, k_hi = min(n_keys, k_lo + per);
   const int k_last = max(k_hi - 1, 0);          // clamp target of the slots past the partition (weight 0)
@@ -990,11 +1002,13 @@ __global__ __launch_bounds__(64 * AD_WAVES) void attn_dec_x16_kernel(const float
 // token + positional embedding for one decode step: x[b][:] = tok_emb[token[b]] + pos_emb[pos]
 __global__ __launch_bounds__(256) void embed_kernel(const int* __restrict__ tokens, const float* __restrict__ tok_emb,
                                                     const float* __restrict__ pos_emb, int pos,
-                                                    const int* __restrict__ pos_dev, float* __restrict__ x, int D, int rpc) {
+                                                    const int* __restrict__ pos_dev, float* __restrict__ x, int D, int rpc,
+                                                    const int* __restrict__ row_off) {
   const int b = blockIdx.x;
   const int tok = tokens[b];
   if (pos_dev) pos = *pos_dev;
   pos += b % rpc;                       // rpc rows per clip (the batched prompt step): consecutive positions
+  if (row_off) pos = max(pos - row_off[b / rpc], 0);      // left-padded prompts: cache row -> position of this clip
   for (int c = threadIdx.x; c < D; c += 256) x[(long)b * D + c] = tok_emb[(long)tok * D + c] + pos_emb[(long)pos * D + c];
 }
 
@@ -1009,11 +1023,12 @@ __device__ __forceinline__ unsigned load_u32_unaligned(const unsigned char* p) {
 }
 // the tail of a fused pick: embedding of the pick for the next step, then the counters by the last workgroup to finish
 __device__ __forceinline__ void step_fuse_tail(const StepFuse& f, int tok, int pos, int step, int b, int tid) {
+  const int pe = f.row_off ? pos - f.row_off[b] : pos;    // cache row `pos` is position pos - row_off[b] of a left-padded clip
   if (f.tok_emb_q) {
     for (int c = tid; c < f.D; c += 1024)
-      f.x[(long)b * f.D + c] = q_elem(f.tok_emb_q, f.tok_emb_ttype, (long)tok * f.D + c) + f.pos_emb[(long)pos * f.D + c];
+      f.x[(long)b * f.D + c] = q_elem(f.tok_emb_q, f.tok_emb_ttype, (long)tok * f.D + c) + f.pos_emb[(long)pe * f.D + c];
   } else {
-    for (int c = tid; c < f.D; c += 1024) f.x[(long)b * f.D + c] = f.tok_emb[(long)tok * f.D + c] + f.pos_emb[(long)pos * f.D + c];
+    for (int c = tid; c < f.D; c += 1024) f.x[(long)b * f.D + c] = f.tok_emb[(long)tok * f.D + c] + f.pos_emb[(long)pe * f.D + c];
   }
   if (tid == 0) {
     // No fence: nothing of this kernel is read by another workgroup of it -- the ticket only elects the workgroup that
@@ -1031,7 +1046,7 @@ __device__ __forceinline__ void step_fuse_tail(const StepFuse& f, int tok, int p
 
 __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, const unsigned char* __restrict__ mask,
                                                       const unsigned char* __restrict__ mask_first,
-                                                      const int* __restrict__ step_dev, int V, int* __restrict__ tokens_out,
+                                                      const int* __restrict__ step_dev, int V, long ld, int* __restrict__ tokens_out,
                                                       int* __restrict__ tokens_all, float* __restrict__ best_logit,
                                                       int eot, int* __restrict__ finished, int* __restrict__ done_count, StepFuse fuse) {
   __shared__ float sv[16];
@@ -1041,7 +1056,7 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
   const int step = fuse.x ? fuse.counters[1] : step_dev ? *step_dev : 0;
   const int pos = fuse.x ? fuse.counters[0] + 1 : 0;
   if (step == 0 && mask_first) mask = mask_first;
-  const float* lg = logits + (long)b * V;
+  const float* lg = logits + (long)b * ld;
   float bv = -INFINITY;
   int bi = 0x7fffffff;
   auto consider = [&](float x, int v) {
@@ -1112,14 +1127,64 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
   }
 }
 
+// What may be picked next in a window under the timestamp rules (oracle/whisper_oracle.py: _apply_rules), from the
+// window's state; uniform per clip and step.
+struct TsRule {
+  const unsigned char* mask;
+  int beg, not_tok, ts_lo, ts_hi;     // timestamps below ts_lo and above ts_hi are not allowed
+  bool no_ts, forced_ts, text_allowed;
+  __device__ __forceinline__ TsRule(const TsPickArgs& a, const TsState& st) {
+    mask = (st.n == 0 && a.mask_first) ? a.mask_first : a.mask;
+    beg = a.beg; not_tok = a.not_tok;
+    const bool last_ts = st.n >= 1 && st.last >= a.beg;
+    const bool pen_ts = st.n < 2 || st.prev >= a.beg;
+    ts_lo = a.beg; ts_hi = a.V - 1;
+    if (st.last_ts >= 0) ts_lo = (a.rules == TS_RULES_OPENAI && !(last_ts && !pen_ts)) ? st.last_ts + 1 : st.last_ts;
+    const bool initial = st.n == 0;
+    if (initial && a.max_initial_ts > 0) ts_hi = a.beg + a.max_initial_ts;
+    no_ts = last_ts && pen_ts;
+    forced_ts = initial && a.rules == TS_RULES_OPENAI;      // the first pick is a timestamp
+    text_allowed = !(last_ts && !pen_ts) && !forced_ts;     // ids < eot
+  }
+  // ids >= eot (EOT, specials, timestamps)
+  __device__ __forceinline__ bool masked_hi(int v) const {
+    if (mask && mask[v]) return true;
+    if (v == not_tok) return true;
+    if (v >= beg) return no_ts || v < ts_lo || v > ts_hi;
+    return forced_ts;
+  }
+  __device__ __forceinline__ bool allowed(int v, int eot) const {
+    if (v < eot) return text_allowed && !(mask && mask[v]);
+    return !masked_hi(v);
+  }
+};
+
+// record a pick and move the window's state on (thread 0 of the clip's workgroup)
+__device__ __forceinline__ void ts_commit(const TsPickArgs& a, TsState& st, int b, int step, int pick, int tsid, float plog) {
+  a.tokens_out[b] = pick;
+  a.tokens_all[(long)step * gridDim.x + b] = pick;
+  a.tids_all[(long)step * gridDim.x + b] = tsid;
+  if (a.plog_all) a.plog_all[(long)step * gridDim.x + b] = plog;
+  st.prev = st.last;
+  st.last = pick;
+  st.n += 1;
+  if (a.rules == TS_RULES_OPENAI ? pick >= a.beg : pick > a.beg) st.last_ts = pick;
+  bool done = pick == a.eot;
+  if (a.rules == TS_RULES_WCPP && st.last_ts >= 0 && st.seek + 2 * (st.last_ts - a.beg) + a.delta_min >= st.seek_end) done = true;
+  if (done) { st.done = 1; atomicAdd(a.done_count, 1); }
+  a.st[b] = st;
+}
+
 // greedy pick under the timestamp rules: one 1024-thread block per clip.  Plain text tokens [0, eot) are either all
 // subject to the suppression mask only or not allowed at all (uniform per clip and step), so they are scanned in
-// float4 steps or skipped; the ~1600 special and timestamp ids take the per-id rule path; the log-sum-exp of the
-// allowed timestamps is a second pass over 1501 values.
+// float4 steps or skipped; the ~1600 special and timestamp ids take the per-id rule path.  The row stays in registers
+// between the two passes: maxima (the pick, the reference point of the exponentials), then the two sums -- over
+// everything allowed (the pick's log-probability, whisper_token_data::plog) and over the allowed timestamps (the
+// probability-mass rule).
 __global__ __launch_bounds__(1024) void ts_pick_kernel(TsPickArgs a) {
   __shared__ float s_v[2][16];
   __shared__ int s_i[2][16];
-  __shared__ float s_sum[16];
+  __shared__ float s_sum[2][16];
   __shared__ int s_tok;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int step = a.fuse.x ? a.fuse.counters[1] : a.step_dev ? *a.step_dev : 0;
@@ -1130,75 +1195,73 @@ __global__ __launch_bounds__(1024) void ts_pick_kernel(TsPickArgs a) {
       a.tokens_out[b] = a.eot;
       a.tokens_all[(long)step * gridDim.x + b] = a.eot;
       a.tids_all[(long)step * gridDim.x + b] = a.beg;
+      if (a.plog_all) a.plog_all[(long)step * gridDim.x + b] = 0.f;
     }
     if (a.fuse.x) step_fuse_tail(a.fuse, a.eot, pos, step, b, tid);
     return;
   }
-  const float* lg = a.logits + (long)b * a.V;
-  const unsigned char* mask = (st.n == 0 && a.mask_first) ? a.mask_first : a.mask;
-  const bool last_ts = st.n >= 1 && st.last >= a.beg;
-  const bool pen_ts = st.n < 2 || st.prev >= a.beg;
-  // timestamps below `ts_lo` and above `ts_hi` are not allowed
-  int ts_lo = a.beg, ts_hi = a.V - 1;
-  if (st.last_ts >= 0) ts_lo = (a.rules == TS_RULES_OPENAI && !(last_ts && !pen_ts)) ? st.last_ts + 1 : st.last_ts;
-  const bool initial = st.n == 0;
-  if (initial && a.max_initial_ts > 0) ts_hi = a.beg + a.max_initial_ts;
-  const bool no_ts = last_ts && pen_ts;
-  const bool forced_ts = initial && a.rules == TS_RULES_OPENAI;      // the first pick is a timestamp
-  const bool text_allowed = !(last_ts && !pen_ts) && !forced_ts;     // ids < eot
-  auto masked = [&](int v) -> bool {                                 // ids >= eot (EOT, specials, timestamps)
-    if (mask && mask[v]) return true;
-    if (v == a.not_tok) return true;
-    if (v >= a.beg) return no_ts || v < ts_lo || v > ts_hi;
-    return forced_ts;
-  };
+  const float* lg = a.logits + (long)b * a.ld;
+  const TsRule rule(a, st);
+  const unsigned char* mask = rule.mask;
+  const bool text_allowed = rule.text_allowed;
+  // the text range [0, eot): scalar head up to the first 16-byte boundary, float4 body in registers, scalar tail
+  const int head = min((int)(((16 - ((size_t)lg & 15)) & 15) >> 2), a.eot);
+  const int nvec = (a.eot - head) >> 2;
+  const float4* lg4 = reinterpret_cast<const float4*>(lg + head);
+  float4 xs[PICK_UNROLL];
+  if (text_allowed) {                          // the whole text range in flight at once (see argmax_kernel)
+    unsigned ms[PICK_UNROLL];
+#pragma unroll
+    for (int u = 0; u < PICK_UNROLL; ++u) {
+      const int q = min(tid + 1024 * u, nvec - 1);
+      xs[u] = lg4[q];
+      ms[u] = mask ? load_u32_unaligned(mask + head + 4 * q) : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < PICK_UNROLL; ++u) {
+      if (ms[u] & 0xffu) xs[u].x = -INFINITY;
+      if (ms[u] & 0xff00u) xs[u].y = -INFINITY;
+      if (ms[u] & 0xff0000u) xs[u].z = -INFINITY;
+      if (ms[u] & 0xff000000u) xs[u].w = -INFINITY;
+    }
+  }
+  // every allowed (value, id) of this thread's share of the row: the plain text ids through FT(x, v), the ids from EOT up
+  // through FH(x, v).  (A macro, not a lambda: closures that capture the running maxima by reference ended up in scratch.)
+#define TS_SCAN(FT, FH)                                                                                              \
+  do {                                                                                                               \
+    if (text_allowed) {                                                                                              \
+      if (tid < head) { const float x_ = (mask && mask[tid]) ? -INFINITY : lg[tid]; FT(x_, tid); }                   \
+      _Pragma("unroll") for (int u = 0; u < PICK_UNROLL; ++u) {                                                      \
+        const int q = tid + 1024 * u;                                                                                \
+        if (q < nvec) {                                                                                              \
+          const int v0 = head + 4 * q;                                                                               \
+          FT(xs[u].x, v0); FT(xs[u].y, (v0 + 1)); FT(xs[u].z, (v0 + 2)); FT(xs[u].w, (v0 + 3));                      \
+        }                                                                                                            \
+      }                                                                                                              \
+      for (int q = tid + 1024 * PICK_UNROLL; q < nvec; q += 1024) { /* vocabularies beyond 53 248 entries */         \
+        float4 x = lg4[q];                                                                                           \
+        const int v0 = head + 4 * q;                                                                                 \
+        if (mask) {                                                                                                  \
+          if (mask[v0]) x.x = -INFINITY;                                                                             \
+          if (mask[v0 + 1]) x.y = -INFINITY;                                                                         \
+          if (mask[v0 + 2]) x.z = -INFINITY;                                                                         \
+          if (mask[v0 + 3]) x.w = -INFINITY;                                                                         \
+        }                                                                                                            \
+        FT(x.x, v0); FT(x.y, (v0 + 1)); FT(x.z, (v0 + 2)); FT(x.w, (v0 + 3));                                        \
+      }                                                                                                              \
+      for (int v = head + 4 * nvec + tid; v < a.eot; v += 1024) {                                                    \
+        const float x_ = (mask && mask[v]) ? -INFINITY : lg[v];                                                      \
+        FT(x_, v);                                                                                                   \
+      }                                                                                                              \
+    }                                                                                                                \
+    for (int v = a.eot + tid; v < a.V; v += 1024)                                                                    \
+      if (!rule.masked_hi(v)) { const float x_ = lg[v]; FH(x_, v); }                                                 \
+  } while (0)
   float tv = -INFINITY, xv = -INFINITY;   // best text (v < beg) and best timestamp
   int ti = 0x7fffffff, xi = 0x7fffffff;
-  auto text = [&](float x, int v) { if (x > tv || (x == tv && v < ti)) { tv = x; ti = v; } };
-  if (text_allowed) {
-    const int head = min((int)(((16 - ((size_t)lg & 15)) & 15) >> 2), a.eot);
-    if (tid < head) text((mask && mask[tid]) ? -INFINITY : lg[tid], tid);
-    const int nvec = (a.eot - head) >> 2;
-    const float4* lg4 = reinterpret_cast<const float4*>(lg + head);
-    {                                          // the whole text range in flight at once (see argmax_kernel)
-      float4 xs[PICK_UNROLL];
-      unsigned ms[PICK_UNROLL];
-#pragma unroll
-      for (int u = 0; u < PICK_UNROLL; ++u) {
-        const int q = min(tid + 1024 * u, nvec - 1);
-        xs[u] = lg4[q];
-        ms[u] = mask ? load_u32_unaligned(mask + head + 4 * q) : 0u;
-      }
-#pragma unroll
-      for (int u = 0; u < PICK_UNROLL; ++u) {
-        const int q = tid + 1024 * u;
-        if (q < nvec) {
-          const int v0 = head + 4 * q;
-          text((ms[u] & 0xffu) ? -INFINITY : xs[u].x, v0);
-          text((ms[u] & 0xff00u) ? -INFINITY : xs[u].y, v0 + 1);
-          text((ms[u] & 0xff0000u) ? -INFINITY : xs[u].z, v0 + 2);
-          text((ms[u] & 0xff000000u) ? -INFINITY : xs[u].w, v0 + 3);
-        }
-      }
-    }
-    for (int q = tid + 1024 * PICK_UNROLL; q < nvec; q += 1024) {
-      const float4 x = lg4[q];
-      const int v0 = head + 4 * q;
-      unsigned char m0 = 0, m1 = 0, m2 = 0, m3 = 0;
-      if (mask) { m0 = mask[v0]; m1 = mask[v0 + 1]; m2 = mask[v0 + 2]; m3 = mask[v0 + 3]; }
-      text(m0 ? -INFINITY : x.x, v0);
-      text(m1 ? -INFINITY : x.y, v0 + 1);
-      text(m2 ? -INFINITY : x.z, v0 + 2);
-      text(m3 ? -INFINITY : x.w, v0 + 3);
-    }
-    for (int v = head + 4 * nvec + tid; v < a.eot; v += 1024) text((mask && mask[v]) ? -INFINITY : lg[v], v);
-  }
-  for (int v = a.eot + tid; v < a.V; v += 1024) {
-    if (masked(v)) continue;
-    const float x = lg[v];
-    if (v < a.beg) text(x, v);
-    else if (x > xv || (x == xv && v < xi)) { xv = x; xi = v; }
-  }
+#define TS_MAX_T(x, v) do { if ((x) > tv || ((x) == tv && (v) < ti)) { tv = (x); ti = (v); } } while (0)
+#define TS_MAX_H(x, v) do { if ((v) < a.beg) TS_MAX_T(x, v); else if ((x) > xv || ((x) == xv && (v) < xi)) { xv = (x); xi = (v); } } while (0)
+  TS_SCAN(TS_MAX_T, TS_MAX_H);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     float ov = __shfl_xor(tv, off, 64); int oi = __shfl_xor(ti, off, 64);
@@ -1215,40 +1278,201 @@ __global__ __launch_bounds__(1024) void ts_pick_kernel(TsPickArgs a) {
     if (s_v[0][w] > max_text || (s_v[0][w] == max_text && s_i[0][w] < arg_text)) { max_text = s_v[0][w]; arg_text = s_i[0][w]; }
     if (s_v[1][w] > max_ts || (s_v[1][w] == max_ts && s_i[1][w] < arg_ts)) { max_ts = s_v[1][w]; arg_ts = s_i[1][w]; }
   }
-  // log-sum-exp of the allowed timestamp logits
-  float sum = 0.f;
-  if (max_ts > -INFINITY)
-    for (int v = a.beg + tid; v < a.V; v += 1024)
-      if (!masked(v)) sum += expf(lg[v] - max_ts);
+  // sums of exponentials: everything allowed against the overall maximum, the allowed timestamps against theirs
+  const float max_all = fmaxf(max_text, max_ts);
+  float sum_all = 0.f, sum = 0.f;
+#define TS_SUM_T(x, v) do { (void)(v); sum_all += __expf((x) - max_all); } while (0)      /* (a masked value is -inf: adds 0) */
+#define TS_SUM_H(x, v) do { sum_all += __expf((x) - max_all); if ((v) >= a.beg) sum += expf((x) - max_ts); } while (0)
+  if (max_all > -INFINITY) TS_SCAN(TS_SUM_T, TS_SUM_H);
+#undef TS_SUM_T
+#undef TS_SUM_H
+#undef TS_MAX_T
+#undef TS_MAX_H
+#undef TS_SCAN
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
-  if ((tid & 63) == 0) s_sum[tid >> 6] = sum;
+  for (int off = 32; off > 0; off >>= 1) { sum += __shfl_xor(sum, off, 64); sum_all += __shfl_xor(sum_all, off, 64); }
+  if ((tid & 63) == 0) { s_sum[0][tid >> 6] = sum; s_sum[1][tid >> 6] = sum_all; }
   __syncthreads();
   if (tid == 0) {
-    float tot = 0.f;
-    for (int w = 0; w < 16; ++w) tot += s_sum[w];
+    float tot = 0.f, tot_all = 0.f;
+    for (int w = 0; w < 16; ++w) { tot += s_sum[0][w]; tot_all += s_sum[1][w]; }
     const float lse_ts = max_ts > -INFINITY ? max_ts + logf(tot) : -INFINITY;
     int pick;
     if (lse_ts > max_text) pick = arg_ts;                       // timestamps carry more mass than any text token
     else pick = (max_ts > max_text) ? arg_ts : arg_text;        // plain arg-max, ties -> lowest id (text ids are lower)
     if (pick == 0x7fffffff) pick = a.eot;                       // everything masked: cannot happen with sane masks
     const int tsid = pick >= a.beg ? pick : (max_ts > -INFINITY ? arg_ts : a.beg);
-    a.tokens_out[b] = pick;
-    a.tokens_all[(long)step * gridDim.x + b] = pick;
-    a.tids_all[(long)step * gridDim.x + b] = tsid;
-    st.prev = st.last;
-    st.last = pick;
-    st.n += 1;
-    if (a.rules == TS_RULES_OPENAI ? pick >= a.beg : pick > a.beg) st.last_ts = pick;
-    bool done = pick == a.eot;
-    if (a.rules == TS_RULES_WCPP && st.last_ts >= 0 && st.seek + 2 * (st.last_ts - a.beg) + 100 >= st.seek_end) done = true;
-    if (done) { st.done = 1; atomicAdd(a.done_count, 1); }
-    a.st[b] = st;
+    const float plog = (pick >= a.beg ? max_ts : max_text) - (max_all + logf(tot_all));
+    ts_commit(a, st, b, step, pick, tsid, plog);
     s_tok = pick;
   }
   if (a.fuse.x) {
     __syncthreads();
     step_fuse_tail(a.fuse, s_tok, pos, step, b, tid);
+  }
+}
+
+// The sampling form of the pick (whisper_sample_token(best = false) at a temperature > 0 [UPSTREAM-RECALL]): logits /
+// temperature, the same rules, probabilities = exp(log-softmax) with the text tokens removed when the probability-mass
+// rule fires, then std::discrete_distribution -- the first id whose cumulative share of the (re-normalised) probability
+// reaches the uniform variate u the host drew for this (step, row).  Only the fallback path of whisper_full comes here
+// (a window the greedy pass failed on), so the kernel is plain: thread t owns the ids [t * chunk, (t + 1) * chunk),
+// three passes over them (maxima, sums, probabilities), cumulative sums in double.
+__global__ __launch_bounds__(1024) void ts_sample_kernel(TsPickArgs a) {
+  __shared__ float s_v[2][16];
+  __shared__ int s_i[16];
+  __shared__ float s_sum[2][16];
+  __shared__ double s_cum[1024];
+  __shared__ double s_wave[16];
+  __shared__ int s_tok, s_last;
+  __shared__ float s_px;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int step = a.fuse.x ? a.fuse.counters[1] : a.step_dev ? *a.step_dev : 0;
+  const int pos = a.fuse.x ? a.fuse.counters[0] + 1 : 0;
+  TsState st = a.st[b];
+  if (st.done) {
+    if (tid == 0) {
+      a.tokens_out[b] = a.eot;
+      a.tokens_all[(long)step * gridDim.x + b] = a.eot;
+      a.tids_all[(long)step * gridDim.x + b] = a.beg;
+      if (a.plog_all) a.plog_all[(long)step * gridDim.x + b] = 0.f;
+    }
+    if (a.fuse.x) step_fuse_tail(a.fuse, a.eot, pos, step, b, tid);
+    return;
+  }
+  const float* lg = a.logits + (long)b * a.ld;
+  const TsRule rule(a, st);
+  const float T = *a.temperature;
+  const double u = a.u_all[(long)step * gridDim.x + b];
+  const int chunk = (a.V + 1023) / 1024;
+  const int v0 = tid * chunk, v1 = min(a.V, v0 + chunk);
+  if (tid == 0) { s_tok = -1; s_last = -1; }
+  float tv = -INFINITY, xv = -INFINITY;
+  int xi = 0x7fffffff;
+  for (int v = v0; v < v1; ++v) {
+    if (!rule.allowed(v, a.eot)) continue;
+    const float x = lg[v] / T;
+    if (v < a.beg) tv = fmaxf(tv, x);
+    else if (x > xv) { xv = x; xi = v; }                      // ascending ids: the first maximum stays
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    tv = fmaxf(tv, __shfl_xor(tv, off, 64));
+    const float ov = __shfl_xor(xv, off, 64); const int oi = __shfl_xor(xi, off, 64);
+    if (ov > xv || (ov == xv && oi < xi)) { xv = ov; xi = oi; }
+  }
+  if ((tid & 63) == 0) { s_v[0][tid >> 6] = tv; s_v[1][tid >> 6] = xv; s_i[tid >> 6] = xi; }
+  __syncthreads();
+  float max_text = s_v[0][0], max_ts = s_v[1][0];
+  int arg_ts = s_i[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) {
+    max_text = fmaxf(max_text, s_v[0][w]);
+    if (s_v[1][w] > max_ts || (s_v[1][w] == max_ts && s_i[w] < arg_ts)) { max_ts = s_v[1][w]; arg_ts = s_i[w]; }
+  }
+  const float max_all = fmaxf(max_text, max_ts);
+  float sum_all = 0.f, sum_ts = 0.f;
+  for (int v = v0; v < v1; ++v) {
+    if (!rule.allowed(v, a.eot)) continue;
+    const float x = lg[v] / T;
+    sum_all += expf(x - max_all);
+    if (v >= a.beg) sum_ts += expf(x - max_ts);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { sum_all += __shfl_xor(sum_all, off, 64); sum_ts += __shfl_xor(sum_ts, off, 64); }
+  if ((tid & 63) == 0) { s_sum[0][tid >> 6] = sum_all; s_sum[1][tid >> 6] = sum_ts; }
+  __syncthreads();
+  float tot_all = 0.f, tot_ts = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) { tot_all += s_sum[0][w]; tot_ts += s_sum[1][w]; }
+  const float lse_all = max_all + logf(tot_all);
+  const float lse_ts = max_ts > -INFINITY ? max_ts + logf(tot_ts) : -INFINITY;
+  const bool ts_only = lse_ts > max_text;                      // the probability-mass rule
+  // probabilities of this thread's ids, then an inclusive scan of the 1024 partial sums
+  double loc = 0.0;
+  int last_pos = -1;
+  for (int v = v0; v < v1; ++v) {
+    if ((ts_only && v < a.beg) || !rule.allowed(v, a.eot)) continue;
+    const float p = expf(lg[v] / T - lse_all);
+    if (p > 0.f) { loc += (double)p; last_pos = v; }
+  }
+  double inc = loc;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double o = __shfl_up(inc, off, 64);
+    if ((tid & 63) >= off) inc += o;
+  }
+  if ((tid & 63) == 63) s_wave[tid >> 6] = inc;
+  if (last_pos >= 0) atomicMax(&s_last, last_pos);
+  __syncthreads();
+  double base = 0.0, total = 0.0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) { if (w < (tid >> 6)) base += s_wave[w]; total += s_wave[w]; }
+  inc += base;
+  s_cum[tid] = inc;
+  __syncthreads();
+  // the thread whose interval (cum[t - 1], cum[t]] / total contains u walks its ids; the last id with any probability closes at 1.0
+  const double lo = (tid ? s_cum[tid - 1] : 0.0) / total;
+  const bool owns_last = last_pos >= 0 && last_pos == s_last;
+  const double hi = owns_last ? 1.0 : inc / total;
+  if (loc > 0.0 && ((lo < u && u <= hi) || (tid == 0 && u <= 0.0 && false))) {
+    double c = tid ? s_cum[tid - 1] : 0.0;
+    int pick = last_pos;
+    float px = 0.f;
+    for (int v = v0; v < v1; ++v) {
+      if ((ts_only && v < a.beg) || !rule.allowed(v, a.eot)) continue;
+      const float x = lg[v] / T;
+      const float p = expf(x - lse_all);
+      if (p <= 0.f) continue;
+      c += (double)p;
+      if (c / total >= u || v == last_pos) { pick = v; px = x; break; }
+    }
+    s_tok = pick;
+    s_px = px;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int pick = s_tok;
+    float px = s_px;
+    if (pick < 0) {                     // u fell between two threads' rounded interval ends: the id the lower one ends on
+      pick = s_last >= 0 ? s_last : a.eot;
+      px = lg[pick] / T;
+    }
+    const int tsid = pick >= a.beg ? pick : (max_ts > -INFINITY ? arg_ts : a.beg);
+    ts_commit(a, st, b, step, pick, tsid, px - lse_all);
+    s_tok = pick;
+  }
+  if (a.fuse.x) {
+    __syncthreads();
+    step_fuse_tail(a.fuse, s_tok, pos, step, b, tid);
+  }
+}
+
+// p_out[b] = softmax(row b)[token]: one 1024-thread block per row, two passes (maximum, sum of exponentials)
+__global__ __launch_bounds__(1024) void softmax_prob_kernel(const float* __restrict__ logits, int V, long ld, int token, float* __restrict__ p_out) {
+  __shared__ float s_r[16];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* lg = logits + (long)b * ld;
+  float m = -INFINITY;
+  for (int v = tid; v < V; v += 1024) m = fmaxf(m, lg[v]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((tid & 63) == 0) s_r[tid >> 6] = m;
+  __syncthreads();
+  m = s_r[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) m = fmaxf(m, s_r[w]);
+  __syncthreads();
+  float sum = 0.f;
+  for (int v = tid; v < V; v += 1024) sum += expf(lg[v] - m);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  if ((tid & 63) == 0) s_r[tid >> 6] = sum;
+  __syncthreads();
+  if (tid == 0) {
+    float tot = 0.f;
+    for (int w = 0; w < 16; ++w) tot += s_r[w];
+    p_out[b] = expf(lg[token] - m - logf(tot));
   }
 }
 
@@ -1437,18 +1661,29 @@ hipError_t attn_decoder_kv16(const float* q, long ldq, const void* kv, long kv_b
   return hipGetLastError();
 }
 hipError_t embed_tokens_f32(const int* tokens, const float* tok_emb, const float* pos_emb, int pos, const int* pos_dev,
-                            float* x, int B, int D, hipStream_t s, int rows_per_clip) {
-  hipLaunchKernelGGL(embed_kernel, dim3(B), dim3(256), 0, s, tokens, tok_emb, pos_emb, pos, pos_dev, x, D, rows_per_clip < 1 ? 1 : rows_per_clip);
+                            float* x, int B, int D, hipStream_t s, int rows_per_clip, const int* row_off) {
+  hipLaunchKernelGGL(embed_kernel, dim3(B), dim3(256), 0, s, tokens, tok_emb, pos_emb, pos, pos_dev, x, D, rows_per_clip < 1 ? 1 : rows_per_clip, row_off);
   return hipGetLastError();
 }
 hipError_t argmax_f32(const float* logits, const unsigned char* mask, const unsigned char* mask_first,
-                      const int* step_dev, int V, int* tokens_out, int* tokens_all, float* best, int B, hipStream_t s,
+                      const int* step_dev, int V, long ld, int* tokens_out, int* tokens_all, float* best, int B, hipStream_t s,
                       int eot, int* finished, int* done_count, const StepFuse* fuse) {
-  hipLaunchKernelGGL(argmax_kernel, dim3(B), dim3(1024), 0, s, logits, mask, mask_first, step_dev, V, tokens_out,
+  hipLaunchKernelGGL(argmax_kernel, dim3(B), dim3(1024), 0, s, logits, mask, mask_first, step_dev, V, ld, tokens_out,
                      tokens_all, best, eot, finished, done_count, fuse ? *fuse : StepFuse{});
   return hipGetLastError();
 }
+hipError_t softmax_prob_f32(const float* logits, int V, long ld, int token, float* p_out, int B, hipStream_t s) {
+  if (token < 0 || token >= V) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(softmax_prob_kernel, dim3(B), dim3(1024), 0, s, logits, V, ld, token, p_out);
+  return hipGetLastError();
+}
+
 hipError_t ts_pick(const TsPickArgs& a, int B, hipStream_t s) {
+  if (a.u_all) {
+    if (!a.temperature) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ts_sample_kernel, dim3(B), dim3(1024), 0, s, a);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(ts_pick_kernel, dim3(B), dim3(1024), 0, s, a);
   return hipGetLastError();
 }

@@ -40,11 +40,13 @@ __global__ __launch_bounds__(256) void dequant_kernel(const unsigned char* __res
 
 __global__ __launch_bounds__(256) void embed_q_kernel(const int* __restrict__ tokens, const unsigned char* __restrict__ q_emb,
                                                       int ttype, const float* __restrict__ pos_emb, int pos,
-                                                      const int* __restrict__ pos_dev, float* __restrict__ x, int D, int rpc) {
+                                                      const int* __restrict__ pos_dev, float* __restrict__ x, int D, int rpc,
+                                                      const int* __restrict__ row_off) {
   const int b = blockIdx.x;
   const int tok = tokens[b];
   if (pos_dev) pos = *pos_dev;
   pos += b % rpc;
+  if (row_off) pos = max(pos - row_off[b / rpc], 0);
   for (int c = threadIdx.x; c < D; c += 256) x[(long)b * D + c] = q_elem(q_emb, ttype, (long)tok * D + c) + pos_emb[(long)pos * D + c];
 }
 
@@ -82,9 +84,9 @@ hipError_t dequant_blocks(const void* q, int ttype, long n_blocks, int cols, voi
 }
 
 hipError_t embed_tokens_q(const int* tokens, const void* q_emb, int ttype, const float* pos_emb, int pos, const int* pos_dev,
-                          float* x, int B, int D, hipStream_t s, int rows_per_clip) {
+                          float* x, int B, int D, hipStream_t s, int rows_per_clip, const int* row_off) {
   hipLaunchKernelGGL(embed_q_kernel, dim3(B), dim3(256), 0, s, tokens, reinterpret_cast<const unsigned char*>(q_emb), ttype,
-                     pos_emb, pos, pos_dev, x, D, rows_per_clip < 1 ? 1 : rows_per_clip);
+                     pos_emb, pos, pos_dev, x, D, rows_per_clip < 1 ? 1 : rows_per_clip, row_off);
   return hipGetLastError();
 }
 

@@ -299,7 +299,7 @@ int crispy_asr_decode_greedy_lang_device(crispy_asr *h, const float *d_enc, int 
  * openai-whisper's ApplyTimestampRules): <|notimestamps|> suppressed, timestamps in pairs except before EOT,
  * non-decreasing, first one <= 1.00 s, and a timestamp is forced once the probability mass of all timestamps
  * exceeds the most probable text token.  rules: 0 = whisper.cpp flavour [UPSTREAM-RECALL] (the window also
- * ends at a timestamp within 1 s of seek_end), 1 = openai / HuggingFace flavour (forced first timestamp,
+ * ends at a timestamp within 100 ms of seek_end), 1 = openai / HuggingFace flavour (forced first timestamp,
  * strictly later after a closed pair; pinned by tests/golden/whisper_tiny_ts_golden.npz).  prompt without
  * <|notimestamps|>; seek / seek_end [batch] (host, nullable): window start and audio length in mel frames.
  * tokens_out / tids_out [batch][max_new] (tids: the most probable timestamp token at every step, nullable),
@@ -308,6 +308,20 @@ int crispy_asr_decode_timestamps_device(crispy_asr *h, const float *d_enc, int b
                                         int n_prompt, const int *lang_tokens, int rules, const int *seek,
                                         const int *seek_end, int max_new, int *tokens_out, int *tids_out,
                                         int *n_out);
+
+/* Stage entry point (parity tests): one pass of whisper_full's temperature ladder over one window per row -- what the
+ * transcribe calls run per window and temperature.  Every row has its own prompt (prompts [rows][prompt_stride],
+ * n_prompt[rows]; rows of different length decode in lock step, each bit-identical to the row decoded alone), the
+ * suppression masks are whisper.cpp's own (specials never, " " and EOT not first).  u == NULL: greedy at temperature 0.
+ * u [max_new][rows] (host doubles in [0, 1)): the sampling pick of whisper_sample_token at `temperature` > 0 -- logits /
+ * temperature, std::discrete_distribution with u as its uniform variate.  Outputs [rows][max_new]: tokens, the most
+ * probable timestamp token of every step (nullable), the log-probability of every pick (nullable; log-softmax over
+ * everything allowed before the probability-mass rule); no_speech_prob_out [rows] (nullable); n_out as above. */
+int crispy_asr_decode_window_device(crispy_asr *h, const float *d_enc, int rows, const int *prompts,
+                                    const int *n_prompt, int prompt_stride, int rules, const int *seek,
+                                    const int *seek_end, int max_new, float temperature, const double *u,
+                                    int *tokens_out, int *tids_out, float *plog_out, float *no_speech_prob_out,
+                                    int *n_out);
 
 /* whisper.cpp language auto-detection: <|startoftranscript|> alone, arg-max over the language tokens.
  * lang_tokens_out[batch] (host).  English-only vocabularies -> CRISPY_ERR_UNSUPPORTED. */
@@ -359,19 +373,36 @@ int crispy_asr_language_token(int n_vocab, const char *code, int *token_out);
 /* Byte string of one vocabulary entry of a loaded model file (not NUL-terminated). */
 int crispy_asr_token_text(const crispy_asr *h, int token, const char **text, size_t *len);
 
-/* TranscribeOptions::default() (managers/transcription.rs:184): language unset, transcribe task. */
+/* TranscribeOptions::default() (managers/transcription.rs:184): language unset, transcribe task, and whisper.cpp's
+ * whisper_full_default_params(GREEDY) for everything else.  A zeroed struct IS that default: every field reads
+ * "0 = whisper.cpp's default". */
 typedef struct crispy_asr_opts {
   int language_token;  /* 0 = auto-detect (what TranscribeOptions::default() leaves to whisper.cpp); else the token id */
   int translate;       /* 0 = transcribe */
   int max_new_tokens;  /* 0 = whisper.cpp's per-window limit (n_text_ctx / 2 - 4; n_text_ctx / 2 without timestamps) */
   int no_timestamps;   /* 0 = whisper.cpp's default: timestamp tokens, 30 s windows advancing to the last closed
                           timestamp pair (whisper_full's seek loop), segments in the result.
-                          1 = <|notimestamps|> prompt, one window, plain greedy arg-max, no segments. */
+                          1 = <|notimestamps|> prompt, one window, plain greedy arg-max, no segments, none of the
+                          decision logic below. */
   int no_prev_text;    /* 0 = whisper.cpp's behaviour inside one whisper_full call [UPSTREAM-RECALL]: from the second
                           window on the decoder is conditioned on the text so far -- prompt <|startofprev|> + the last
                           <= n_text_ctx / 2 tokens of the previous windows (their timestamp tokens included) + the
-                          usual <|startoftranscript|> ...; not when fewer than 5 s of audio are left.
-                          1 = every window starts from the bare prompt. */
+                          usual <|startoftranscript|> ...; not when fewer than 5 s of audio are left, and not in a
+                          re-decode at a temperature >= 0.5.  1 = every window starts from the bare prompt. */
+  /* whisper_full's decision logic [UPSTREAM-RECALL: whisper_full_with_state, whisper_sequence_score].  A window is
+   * decoded greedily at `temperature`; if its decoder failed (end of text before any timestamp away from the end of the
+   * audio, no end within the token limit while less than half the window was covered, entropy of the last 32 tokens
+   * below entropy_thold), or its average log-probability is below logprob_thold while no_speech_prob <
+   * no_speech_thold, it is decoded again at temperature + temperature_inc, ... up to 1.0 -- above 0 with `best_of`
+   * sampling decoders (std::mt19937(j) + std::discrete_distribution, decoder j seeded j at the start of every call),
+   * the best-scoring one that did not fail wins; the last temperature is accepted as it is.  A window whose
+   * no_speech_prob > no_speech_thold and whose average log-probability < logprob_thold yields no text. */
+  float temperature;     /* first temperature of the ladder (0) */
+  float temperature_inc; /* 0 = 0.2; < 0: no fallback (one pass at `temperature`, accepted as it is) */
+  float entropy_thold;   /* 0 = 2.4; < 0: never fails on entropy */
+  float logprob_thold;   /* 0 = -1.0 */
+  float no_speech_thold; /* 0 = 0.6; >= 1: no window is ever dropped as silence */
+  int best_of;           /* 0 = 5 */
 } crispy_asr_opts;
 
 /* One segment of the result (managers/transcription.rs:223-233: `seg.start`, `seg.end`, `seg.text`),
@@ -381,6 +412,21 @@ typedef struct crispy_asr_segment {
   const char *text;    /* UTF-8, NUL-terminated, untrimmed */
 } crispy_asr_segment;
 
+/* What whisper_full decided about one window of the seek loop (timestamp mode only). */
+typedef struct crispy_asr_window {
+  int seek;              /* window start, mel frames (10 ms) from the start of the chunk */
+  int seek_advance;      /* frames the loop moved on by */
+  int n_tokens;          /* tokens of this window that went into the result (0 when dropped) */
+  int decoder;           /* which of the best_of decoders won (0 at temperature 0) */
+  int failed;            /* 1 = the decoder failed and was accepted all the same (last temperature of the ladder) */
+  int no_speech;         /* 1 = dropped by the no-speech rule */
+  float temperature;     /* the temperature the accepted pass ran at */
+  float no_speech_prob;  /* softmax of the last prompt position's unfiltered logits at <|nospeech|> (whisper.cpp takes it
+                            there: the prompt pass yields the logits of its last position only) */
+  float avg_logprob;     /* mean log-probability of the kept tokens (-inf for a decoder that failed before scoring) */
+  float entropy;         /* entropy of the token histogram of the last 32 kept tokens */
+} crispy_asr_window;
+
 /* Library-owned result of one transcribe call; release with crispy_asr_free_result. */
 typedef struct crispy_asr_result {
   const char *text;    /* UTF-8, NUL-terminated, untrimmed (the caller trims: transcription.rs:187) */
@@ -389,11 +435,14 @@ typedef struct crispy_asr_result {
   int language_token;  /* the language token used (detected or given); 0 for English-only vocabularies */
   int n_segments;      /* 0 with no_timestamps (the reference then falls back to one segment, transcription.rs:236-249) */
   const crispy_asr_segment *segments;
+  int n_windows;       /* windows of the seek loop, in order (0 with no_timestamps) */
+  const crispy_asr_window *windows;
 } crispy_asr_result;
 
 /* engine.transcribe(&audio, &TranscribeOptions::default()) for ONE chunk of <= 480000 samples
- * (16 kHz f32, host).  n == 0 returns an empty result (transcription.rs:175-177), and so does a chunk shorter than
- * 1 s = 100 mel frames (n / 160 < 100): whisper.cpp's whisper_full refuses it and yields no segments.  Needs a model
+ * (16 kHz f32, host).  n == 0 returns an empty result (transcription.rs:175-177), and so does a chunk of fewer than
+ * 10 mel frames (100 ms; the frame count is 1 + (n - 200) / 160, i.e. 2999 for a full chunk): whisper.cpp's whisper_full
+ * refuses it and yields no segments [UPSTREAM-RECALL: delta_min, n_len_org].  Needs a model
  * loaded from a file (vocabulary) for text; tokens are always returned.  opts == NULL is
  * TranscribeOptions::default(): language auto-detected, transcribe, timestamps on. */
 int crispy_asr_transcribe(crispy_asr *h, const float *pcm16k, size_t n, const crispy_asr_opts *opts,

@@ -236,6 +236,16 @@ class DecoderCache:
         self.rl = _h if self.ln16 else (lambda a: a)
         enc = r(enc_out.astype(dtype))
         self.xk, self.xv, self.k, self.v = [], [], [], []
+        # the weights as the products see them, rounded once (r: the plain products of the f16 chain; rl: the
+        # LayerNorm-fed ones of mode 2) -- the same values step() used to round anew at every position
+        self.Wr, self.Wl = {}, {}
+        for i in range(hp.n_text_layer):
+            p = f"decoder.blocks.{i}"
+            for k in (".attn.out.weight", ".cross_attn.out.weight", ".mlp.2.weight"):
+                self.Wr[p + k] = r(self.W[p + k])
+            for k in (".attn.query.weight", ".attn.key.weight", ".attn.value.weight", ".cross_attn.query.weight", ".mlp.0.weight"):
+                self.Wl[p + k] = self.rl(self.W[p + k])
+        self.Wr["decoder.token_embedding.weight"] = r(self.W["decoder.token_embedding.weight"])
         for i in range(hp.n_text_layer):
             p = f"decoder.blocks.{i}.cross_attn"
             self.xk.append(r(enc @ r(self.W[p + ".key.weight"]).T))
@@ -255,26 +265,33 @@ class DecoderCache:
             out[sl] = (s / s.sum()) @ v[:, sl]
         return out
 
+    def fork(self):
+        """A decoder that continues from this one's state on its own (whisper_kv_cache_seq_cp for a further best-of decoder)."""
+        import copy
+        o = copy.copy(self)
+        o.k, o.v = list(self.k), list(self.v)      # step() replaces the per-layer arrays, it never writes into them
+        return o
+
     def step(self, token):
-        W, r = self.W, self.r
+        W, r, Wr, Wl = self.W, self.r, self.Wr, self.Wl
         x = W["decoder.token_embedding.weight"][int(token)] + W["decoder.positional_embedding"][self.pos]
         for i in range(self.hp.n_text_layer):
             p = f"decoder.blocks.{i}"
             rl = self.rl
             xn = rl(_ln(x, W[p + ".attn_ln.weight"], W[p + ".attn_ln.bias"]))
-            q = xn @ rl(W[p + ".attn.query.weight"]).T + W[p + ".attn.query.bias"]
-            self.k[i] = np.vstack([self.k[i], r(xn @ rl(W[p + ".attn.key.weight"]).T)])
-            self.v[i] = np.vstack([self.v[i], r(xn @ rl(W[p + ".attn.value.weight"]).T + W[p + ".attn.value.bias"])])
-            x = x + r(self._att(q, self.k[i], self.v[i])) @ r(W[p + ".attn.out.weight"]).T + W[p + ".attn.out.bias"]
+            q = xn @ Wl[p + ".attn.query.weight"].T + W[p + ".attn.query.bias"]
+            self.k[i] = np.vstack([self.k[i], r(xn @ Wl[p + ".attn.key.weight"].T)])
+            self.v[i] = np.vstack([self.v[i], r(xn @ Wl[p + ".attn.value.weight"].T + W[p + ".attn.value.bias"])])
+            x = x + r(self._att(q, self.k[i], self.v[i])) @ Wr[p + ".attn.out.weight"].T + W[p + ".attn.out.bias"]
             xn = rl(_ln(x, W[p + ".cross_attn_ln.weight"], W[p + ".cross_attn_ln.bias"]))
-            q = xn @ rl(W[p + ".cross_attn.query.weight"]).T + W[p + ".cross_attn.query.bias"]
-            x = x + r(self._att(q, self.xk[i], self.xv[i])) @ r(W[p + ".cross_attn.out.weight"]).T + W[p + ".cross_attn.out.bias"]
+            q = xn @ Wl[p + ".cross_attn.query.weight"].T + W[p + ".cross_attn.query.bias"]
+            x = x + r(self._att(q, self.xk[i], self.xv[i])) @ Wr[p + ".cross_attn.out.weight"].T + W[p + ".cross_attn.out.bias"]
             xn = rl(_ln(x, W[p + ".mlp_ln.weight"], W[p + ".mlp_ln.bias"]))
-            g = (_gelu_ggml if self.f16 else _gelu)(xn @ rl(W[p + ".mlp.0.weight"]).T + W[p + ".mlp.0.bias"])
-            x = x + r(g) @ r(W[p + ".mlp.2.weight"]).T + W[p + ".mlp.2.bias"]
+            g = (_gelu_ggml if self.f16 else _gelu)(xn @ Wl[p + ".mlp.0.weight"].T + W[p + ".mlp.0.bias"])
+            x = x + r(g) @ Wr[p + ".mlp.2.weight"].T + W[p + ".mlp.2.bias"]
         self.pos += 1
         x = _ln(x, W["decoder.ln.weight"], W["decoder.ln.bias"])
-        return r(x) @ r(W["decoder.token_embedding.weight"]).T
+        return r(x) @ Wr["decoder.token_embedding.weight"].T
 
 
 def special_tokens(n_vocab, eot=None):
@@ -307,10 +324,27 @@ def default_prompt(n_vocab, lang_token=None, translate=False, no_timestamps=Fals
     return p
 
 
-def timestamp_rules(lg, seq, sp, rules, suppress=None, suppress_first=None, max_initial_ts=50):
-    """Masked copy of the logits `lg` for the next pick, given the tokens `seq` sampled so far in this window.
-    Returns (masked logits, index of the most probable timestamp token)."""
+def n_len_org(n_samples):
+    """Mel frames whisper_full may decode from [UPSTREAM-RECALL: log_mel_spectrogram, `mel.n_len_org = 1 + (n_samples +
+    stage_2_pad - frame_size) / frame_step` with stage_2_pad = 200, frame 400, step 160; C integer division]: 2999 for a
+    full 30 s chunk, not 3000."""
+    q = n_samples + 200 - 400
+    return 1 + (q // 160 if q >= 0 else -((-q) // 160))
+
+
+# whisper_full_default_params(WHISPER_SAMPLING_GREEDY) [UPSTREAM-RECALL] -- what TranscribeOptions::default()
+# (managers/transcription.rs:184) leaves in force -- plus the two constants of whisper_full_with_state this file needs.
+WCPP_PARAMS = dict(temperature=0.0, temperature_inc=0.2, entropy_thold=2.4, logprob_thold=-1.0, no_speech_thold=0.6,
+                   best_of=5, length_penalty=-1.0, max_initial_ts=50, n_max_text_ctx=16384,
+                   delta_min=10)          # 100 ms: whisper.cpp >= 1.7.6 stops / refuses below it (1 s before)
+
+
+def _apply_rules(lg, seq, sp, rules, suppress=None, suppress_first=None, max_initial_ts=50, temperature=0.0):
+    """whisper_process_logits up to (not including) the probability-mass rule: a float64 copy of `lg`, divided by the
+    temperature when it is > 0, with everything that may not be sampled next at -inf."""
     lg = np.array(lg, dtype=np.float64)
+    if temperature > 0.0:
+        lg = lg / temperature
     beg, eot = sp["beg"], sp["eot"]
     if suppress is not None and len(suppress):
         lg[np.asarray(suppress, dtype=np.int64)] = -np.inf
@@ -339,46 +373,327 @@ def timestamp_rules(lg, seq, sp, rules, suppress=None, suppress_first=None, max_
         ts = [t for t in seq if t > beg]          # whisper.cpp: has_ts / seek_delta only move on tokens > <|0.00|>
         if ts:
             lg[beg:ts[-1]] = -np.inf
-    tsl = lg[beg:]
+    return lg
+
+
+def _log_softmax(lg):
+    """whisper_compute_logprobs: log-softmax over the entries that are not -inf."""
+    m = lg.max()
+    if not np.isfinite(m):
+        return np.full_like(lg, -np.inf)
+    return lg - (m + np.log(np.exp(lg - m).sum()))
+
+
+def process_logits(lg, seq, sp, rules, suppress=None, suppress_first=None, max_initial_ts=50, temperature=0.0):
+    """whisper_process_logits [UPSTREAM-RECALL]: (masked logits, log-probabilities, most probable timestamp token).
+    The log-probabilities are normalised over everything allowed BEFORE the probability-mass rule; when that rule
+    fires, the text tokens are removed from both arrays afterwards (so the remaining probabilities no longer sum to
+    one: whisper_sample_token's discrete_distribution renormalises, a token's `plog` does not)."""
+    beg = sp["beg"]
+    lg = _apply_rules(lg, seq, sp, rules, suppress, suppress_first, max_initial_ts, temperature)
+    lp = _log_softmax(lg)
+    tsl = lp[beg:]
     tid = beg + int(np.argmax(tsl)) if np.isfinite(tsl.max()) else beg
     m = tsl.max()
     lse_ts = m + np.log(np.exp(tsl - m).sum()) if np.isfinite(m) else -np.inf
-    if lse_ts > lg[:beg].max():
+    if lse_ts > lp[:beg].max():
         lg[:beg] = -np.inf
-    return lg, tid
+        lp[:beg] = -np.inf
+    return lg, lp, tid
+
+
+def timestamp_rules(lg, seq, sp, rules, suppress=None, suppress_first=None, max_initial_ts=50):
+    """Masked copy of the logits `lg` for the next pick, given the tokens `seq` sampled so far in this window.
+    Returns (masked logits, index of the most probable timestamp token)."""
+    ml, _, tid = process_logits(lg, seq, sp, rules, suppress, suppress_first, max_initial_ts)
+    return ml, tid
 
 
 def decode_window(step_logits, prompt, sp, rules, n_max, seek, seek_end, suppress=None, suppress_first=None,
-                  max_initial_ts=50):
-    """One whisper_full window [UPSTREAM-RECALL]: greedy picks under the timestamp rules until EOT, n_max tokens
-    or a timestamp within 1 s of the end of the audio.  `step_logits(token)` feeds one token and returns the next
-    logits.  Returns dict(tokens, tids, result_len, seek_delta, margins)."""
+                  max_initial_ts=50, delta_min=10):
+    """One greedy pass over one window, as the library's stage entry point `crispy_asr_decode_timestamps_device` runs it:
+    picks under the timestamp rules until EOT, n_max tokens or a timestamp within `delta_min` frames of the end of the
+    audio.  `step_logits(token)` feeds one token and returns the next logits.  Returns dict(tokens, tids, plogs,
+    result_len, seek_delta, margins).  (whisper_full's own bookkeeping -- failure flags, scores, the temperature ladder
+    -- is `decode_temperature` / `whisper_full` below; result_len here is the plain "last timestamp, else everything".)"""
     lg = None
     for t in prompt:
         lg = step_logits(t)
     beg, eot = sp["beg"], sp["eot"]
-    toks, tids, margins = [], [], []
+    toks, tids, margins, plogs = [], [], [], []
     has_ts, seek_delta, result_len = False, 3000, 0
     for i in range(n_max):
-        ml, tid = timestamp_rules(lg, toks, sp, rules, suppress, suppress_first, max_initial_ts)
+        ml, lp, tid = process_logits(lg, toks, sp, rules, suppress, suppress_first, max_initial_ts)
         t = int(np.argmax(ml))
         top2 = np.partition(ml, -2)[-2:]
         margins.append(float(top2[1] - top2[0]))
         toks.append(t)
+        plogs.append(float(lp[t]))
         tids.append(tid if t < beg else t)
         if t > beg:
             seek_delta = 2 * (t - beg)
             result_len = i + 1
             has_ts = True
-        if t == eot or (has_ts and seek + seek_delta + 100 >= seek_end):
+        if t == eot or (has_ts and seek + seek_delta + delta_min >= seek_end):
             if t == eot and result_len == 0:
-                result_len = i + 1            # no temperature fallback here: keep what was decoded
+                result_len = i + 1
             break
         lg = step_logits(t)
     else:
         if result_len == 0:
             result_len = len(toks)
-    return dict(tokens=toks, tids=tids, result_len=result_len, seek_delta=seek_delta, margins=margins)
+    return dict(tokens=toks, tids=tids, plogs=plogs, result_len=result_len, seek_delta=seek_delta, margins=margins)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# whisper_full's decision logic [UPSTREAM-RECALL: whisper.cpp whisper_full_with_state, whisper_sequence_score,
+# whisper_sample_token; source not vendored] -- what decides, on a real recording, whether a window's greedy text is
+# kept, re-decoded at a higher temperature, or dropped as silence.
+# ---------------------------------------------------------------------------------------------------------
+class MT19937:
+    """std::mt19937 (32-bit Mersenne twister, `init_genrand` seeding) -- whisper.cpp seeds decoder j with
+    std::mt19937(j).  Known answer (the C++ standard's own check): the 10000th output of the default seed 5489 is
+    4123659995 (tests/test_oracle_whisper.py)."""
+
+    def __init__(self, seed=5489):
+        mt = [0] * 624
+        mt[0] = seed & 0xFFFFFFFF
+        for i in range(1, 624):
+            mt[i] = (1812433253 * (mt[i - 1] ^ (mt[i - 1] >> 30)) + i) & 0xFFFFFFFF
+        self.mt, self.idx = mt, 624
+
+    def _twist(self):
+        mt = self.mt
+        for i in range(624):
+            y = (mt[i] & 0x80000000) | (mt[(i + 1) % 624] & 0x7FFFFFFF)
+            mt[i] = mt[(i + 397) % 624] ^ (y >> 1) ^ (0x9908B0DF if y & 1 else 0)
+        self.idx = 0
+
+    def next_u32(self):
+        if self.idx >= 624:
+            self._twist()
+        y = self.mt[self.idx]
+        self.idx += 1
+        y ^= y >> 11
+        y ^= (y << 7) & 0x9D2C5680
+        y ^= (y << 15) & 0xEFC60000
+        y ^= y >> 18
+        return y & 0xFFFFFFFF
+
+    def canonical(self):
+        """std::generate_canonical<double, 53>(mt19937) as libstdc++ and libc++ both compute it: two draws,
+        (x0 + x1 * 2^32) / 2^64 in double arithmetic, a result of 1.0 replaced by the largest double below it."""
+        x0, x1 = self.next_u32(), self.next_u32()
+        u = (float(x0) + float(x1) * 4294967296.0) / 18446744073709551616.0
+        return u if u < 1.0 else float(np.nextafter(1.0, 0.0))
+
+
+def sample_index(probs, u):
+    """std::discrete_distribution<>(probs)(rng) with the uniform variate `u` already drawn [UPSTREAM-RECALL: libstdc++
+    -- probabilities divided by their sum, partial sums in double, last one forced to 1.0, std::lower_bound].  Returns
+    (index, distance of u to the nearer edge of that index's interval of the cumulative distribution)."""
+    p = np.asarray(probs, dtype=np.float64)
+    cp = np.cumsum(p / np.cumsum(p)[-1])
+    cp[-1] = 1.0
+    i = int(np.searchsorted(cp, u, side="left"))
+    lo = cp[i - 1] if i > 0 else 0.0
+    return i, float(min(u - lo, cp[i] - u))
+
+
+def sequence_score(toks, plogs, result_len, length_penalty=-1.0):
+    """whisper_sequence_score: sum / average of the picks' log-probabilities over the kept tokens, the score the
+    best-of decoders are ranked by, and the entropy of the token histogram of the last 32 kept tokens."""
+    if result_len == 0:
+        return None
+    s = float(sum(plogs[:result_len]))
+    penalty = float(result_len)
+    if length_penalty > 0.0:
+        penalty = ((5.0 + penalty) / 6.0) ** length_penalty
+    last = toks[max(0, result_len - 32):result_len]
+    cnt = {}
+    for t in last:
+        cnt[t] = cnt.get(t, 0) + 1
+    ent = 0.0
+    for t in sorted(cnt):                                  # std::map order
+        p = cnt[t] / float(len(last))
+        ent -= p * np.log(p)
+    return dict(sum_logprobs=s, avg_logprobs=s / result_len, score=s / penalty, entropy=float(ent))
+
+
+def decode_temperature(dc, prompt, sp, rules, n_max, seek, seek_end, t_cur, n_dec, rngs, params, suppress=None,
+                       suppress_first=None, no_timestamps=False):
+    """One iteration of whisper_full's temperature ladder over one window: the prompt, then `n_dec` decoders that share
+    it (1 at temperature 0, best_of above) sampling in lock step, each with whisper.cpp's completion / failure
+    bookkeeping; afterwards the sequences are scored and the best one that did not fail is chosen.
+    `dc`: a fresh DecoderCache (fork() gives every further decoder its own copy after the prompt).
+    Returns dict(decoders=[...], best=index or None, no_speech_prob)."""
+    beg, eot = sp["beg"], sp["eot"]
+    delta_min = params["delta_min"]
+    lg0 = None
+    for t in prompt:
+        lg0 = dc.step(t)
+    # before any filtering, at the last prompt position (the only one whose logits the prompt pass produces)
+    no_speech_prob = float(np.exp(_log_softmax(np.asarray(lg0, dtype=np.float64))[sp["nosp"]]))
+    decs = []
+    for j in range(n_dec):
+        decs.append(dict(dc=dc if j == 0 else None, toks=[], tids=[], plogs=[], margins=[], has_ts=False,
+                         seek_delta=3000, result_len=0, failed=False, completed=False, lg=lg0, score=None))
+    for j in range(1, n_dec):
+        decs[j]["dc"] = dc.fork()
+    for i in range(n_max):
+        for j, d in enumerate(decs):
+            if d["completed"] or d["failed"]:
+                continue
+            ml, lp, tid = process_logits(d["lg"], d["toks"], sp, rules, suppress, suppress_first,
+                                         params["max_initial_ts"], t_cur)
+            if t_cur < 1e-6:
+                t = int(np.argmax(ml))                        # whisper_sample_token(best): first index of the maximum
+                top2 = np.partition(ml, -2)[-2:]
+                d["margins"].append(float(top2[1] - top2[0]))
+            else:
+                pr = np.where(np.isfinite(lp), np.exp(lp), 0.0)
+                t, gap = sample_index(pr, rngs[j].canonical())
+                d["margins"].append(gap)
+            d["toks"].append(t)
+            d["plogs"].append(float(lp[t]))
+            d["tids"].append(tid if t < beg else t)
+        for j, d in enumerate(decs):
+            if d["completed"] or d["failed"]:
+                continue
+            t = d["toks"][-1]
+            if t > beg:
+                sd_new = 2 * (t - beg)
+                if d["has_ts"] and d["seek_delta"] > sd_new and d["result_len"] < i:
+                    d["failed"] = True                        # "do not allow to go back in time"
+                    continue
+                d["seek_delta"], d["result_len"], d["has_ts"] = sd_new, i + 1, True
+            if t == eot or (d["has_ts"] and seek + d["seek_delta"] + delta_min >= seek_end):
+                if d["result_len"] == 0 and not no_timestamps:
+                    if seek + d["seek_delta"] + delta_min >= seek_end:
+                        d["result_len"] = i + 1
+                    else:
+                        d["failed"] = True                    # EOT before any timestamp: nothing to keep
+                        continue
+                if no_timestamps:
+                    d["result_len"], d["seek_delta"] = i + 1, 3000
+                d["completed"] = True
+                continue
+            if i == n_max - 1 and (d["result_len"] == 0 or d["seek_delta"] < 1500):
+                d["failed"] = True                            # repetition loop
+        if all(d["completed"] or d["failed"] for d in decs):
+            break
+        for d in decs:
+            if not (d["completed"] or d["failed"]):
+                d["lg"] = d["dc"].step(d["toks"][-1])
+    best, best_score = None, -np.inf
+    for j, d in enumerate(decs):
+        if d["failed"]:
+            continue
+        d["kept"] = d["toks"][:d["result_len"]]
+        sc = sequence_score(d["toks"], d["plogs"], d["result_len"], params["length_penalty"])
+        d["score"] = sc
+        if sc is None:
+            continue          # whisper_sequence_score returns early: the -inf of the decoder's initialisation stays
+        if d["result_len"] > 32 and sc["entropy"] < params["entropy_thold"]:
+            d["failed"] = True
+            continue
+        if best_score < sc["score"]:
+            best_score, best = sc["score"], j
+    return dict(decoders=decs, best=best, no_speech_prob=no_speech_prob)
+
+
+def whisper_full(weights, hp, mel_window, n_samples, prompt, rules, token_text, params=None, n_max=None, suppress=None,
+                 suppress_first=None, eot=None, max_windows=1501, f16=False, prev_text=True, decoder_kw=None, encoder=None):
+    """whisper_full_with_state over one chunk [UPSTREAM-RECALL], greedy strategy: the seek loop, and per window the
+    temperature ladder `temperature, + temperature_inc, .. <= 1.0` -- one greedy decoder at 0, `best_of` sampling
+    decoders above; a window's result is accepted unless its best decoder failed (EOT before a timestamp away from the
+    end of the audio, repetition to the token limit, entropy of the last 32 tokens below `entropy_thold`) or its average
+    log-probability is below `logprob_thold` while `no_speech_prob < no_speech_thold`; at the last temperature it is
+    accepted regardless.  A window with `no_speech_prob > no_speech_thold` and an average log-probability below
+    `logprob_thold` yields no segment and adds nothing to the conditioning text.  Decoder j draws from MT19937(j),
+    seeded anew for every call (whisper.cpp re-seeds decoders >= 1 per call and keeps decoder 0's generator in the state).
+    `encoder(mel)` replaces the encoder pass (tests on weight sets whose decoder ignores the audio).
+    Returns (segments, kept tokens, windows); a window carries everything the decision used."""
+    P = dict(WCPP_PARAMS)
+    P.update(params or {})
+    sp = special_tokens(hp.n_vocab, eot)
+    n_max = hp.n_text_ctx // 2 - 4 if n_max is None else n_max
+    delta_min = P["delta_min"]
+    seek, seek_end = 0, n_len_org(n_samples)
+    segs, kept, wins = [], [], []
+    if seek_end < delta_min:                       # "input is too short"
+        return segs, kept, wins
+    temps = [P["temperature"]]
+    if P["temperature_inc"] > 0.0:
+        temps = []
+        t = np.float32(P["temperature"])
+        while t < np.float32(1.0 + 1e-6):
+            temps.append(float(t))
+            t = np.float32(t + np.float32(P["temperature_inc"]))
+    n_best = max(1, int(P["best_of"]))
+    rngs = [MT19937(j) for j in range(n_best)]
+    prompt = list(prompt)
+    past = []
+    no_ts = sp["not_"] in prompt
+    while len(wins) < max_windows:
+        if seek + delta_min >= seek_end:
+            break
+        if seek > 0 and seek + 500 >= seek_end:
+            past = []
+        mel = mel_window(seek)
+        enc = encoder(mel) if encoder is not None else (encoder_forward_f16 if f16 else encoder_forward)(weights, hp, mel)
+        best_id, its, last = 0, [], None
+        for it, t_cur in enumerate(temps):
+            n_dec = n_best if t_cur > 0.0 else 1
+            p = list(prompt)
+            if prev_text and past and t_cur < 0.5 and P["n_max_text_ctx"] > 0:
+                n_take = min(P["n_max_text_ctx"], hp.n_text_ctx // 2, len(past), hp.n_text_ctx - n_max - len(prompt) - 1)
+                if n_take > 0:
+                    p = [sp["prev"]] + past[len(past) - n_take:] + p
+            dc = DecoderCache(weights, hp, enc, f16=f16, **(decoder_kw or {}))
+            r = decode_temperature(dc, p, sp, rules, n_max, seek, seek_end, t_cur, n_dec, rngs, P, suppress,
+                                   suppress_first, no_ts)
+            r["temperature"], r["prompt"] = t_cur, p
+            its.append(r)
+            if r["best"] is not None:
+                best_id = r["best"]                          # (best_decoder_id survives an iteration in which every decoder failed)
+            last = r
+            success = True
+            if it != len(temps) - 1:
+                d = r["decoders"][best_id] if best_id < len(r["decoders"]) else r["decoders"][0]
+                avg = d["score"]["avg_logprobs"] if (d["score"] and not d["failed"]) else -np.inf
+                if d["failed"] or (avg < P["logprob_thold"] and r["no_speech_prob"] < P["no_speech_thold"]):
+                    success = False
+            if success:
+                break
+        if best_id >= len(last["decoders"]):
+            best_id = 0
+        d = last["decoders"][best_id]
+        toks_cur = d["kept"] if "kept" in d else list(d["toks"])        # a failed decoder's tokens are not cut
+        tids_cur = d["tids"][:len(toks_cur)]
+        sc = d["score"] if "kept" in d else None
+        avg = sc["avg_logprobs"] if sc else -np.inf
+        is_no_speech = last["no_speech_prob"] > P["no_speech_thold"] and avg < P["logprob_thold"]
+        p = last["prompt"]
+        past = list(p[1:len(p) - len(prompt)]) if p[0] == sp["prev"] else []
+        if not is_no_speech:
+            past += list(d["toks"][:d["result_len"]])
+        seek_delta = d["seek_delta"]
+        win = dict(seek=seek, prompt=p, tokens=list(toks_cur), tids=list(tids_cur), result_len=len(toks_cur),
+                   n_past=d["result_len"],                    # what of it conditions the next window (0 for an early failure)
+                   plogs=list(d["plogs"][:len(toks_cur)]), margins=list(d["margins"][:len(toks_cur)]),
+                   seek_delta=seek_delta, no_speech_prob=last["no_speech_prob"], avg_logprob=avg,
+                   entropy=sc["entropy"] if sc else 0.0, temperature=last["temperature"], decoder=best_id,
+                   failed=bool(d["failed"]), is_no_speech=bool(is_no_speech), iterations=its)
+        if toks_cur and not is_no_speech:
+            segs += window_segments(win, seek, sp, token_text)
+            kept += list(toks_cur)
+        if len(toks_cur) > 1 and toks_cur[-2] < sp["beg"] and toks_cur[-1] > sp["beg"]:
+            seek_delta = min(seek_end - seek, 3000)          # single timestamp ending: nothing after it in this chunk
+        win["seek_advance"] = seek_delta
+        wins.append(win)
+        seek += seek_delta
+    return segs, kept, wins
 
 
 def window_segments(win, seek, sp, token_text):
@@ -412,39 +727,13 @@ def window_segments(win, seek, sp, token_text):
 
 
 def transcribe_timestamps(weights, hp, mel_window, n_samples, prompt, rules, token_text, n_max=None,
-                          suppress=None, suppress_first=None, eot=None, max_windows=1501, f16=False, prev_text=True):
-    """whisper_full's seek loop over one clip (<= 30 s): `mel_window(seek)` returns the [n_mels, 3000] log-mel
-    window starting at mel frame `seek`.  Returns (segments, all kept tokens, windows).
-    f16=True chains the f16-operand arithmetic (the library's precision mode 1 = ggml's mul_mat numerics
-    [UPSTREAM-RECALL]): `encoder_forward_f16` -> `DecoderCache(f16=True)`.
-    prev_text=True is whisper.cpp's `prompt_past` [UPSTREAM-RECALL: whisper_full_with_state]: from the second window on
-    the prompt is <|startofprev|> + the last min(n_text_ctx / 2, len(past)) tokens of the text so far + `prompt`; the past
-    is dropped when fewer than 5 s of audio are left (`seek > seek_start && seek + 500 >= seek_end`); after a window the
-    past becomes the past part of its prompt + its kept tokens (timestamp tokens and all)."""
-    sp = special_tokens(hp.n_vocab, eot)
-    n_max = hp.n_text_ctx // 2 - 4 if n_max is None else n_max
-    seek, seek_end = 0, n_samples // 160
-    segs, kept, wins = [], [], []
-    if seek_end < 100:                         # whisper.cpp: "input is too short" -> nothing
-        return segs, kept, wins
-    prompt = list(prompt)
-    past = []
-    while seek + 100 < seek_end and len(wins) < max_windows:
-        if seek > 0 and seek + 500 >= seek_end:
-            past = []
-        p = list(prompt)
-        if prev_text and past:
-            n_take = min(hp.n_text_ctx // 2, len(past), hp.n_text_ctx - n_max - len(prompt) - 1)
-            if n_take > 0:
-                p = [sp["prev"]] + past[len(past) - n_take:] + p
-        enc = (encoder_forward_f16 if f16 else encoder_forward)(weights, hp, mel_window(seek))
-        dc = DecoderCache(weights, hp, enc, f16=f16)
-        win = decode_window(dc.step, p, sp, rules, n_max, seek, seek_end, suppress, suppress_first)
-        win["seek"] = seek
-        win["prompt"] = p
-        wins.append(win)
-        segs += window_segments(win, seek, sp, token_text)
-        kept += win["tokens"][:win["result_len"]]
-        past = (p[1:len(p) - len(prompt)] if p[0] == sp["prev"] else []) + list(win["tokens"][:win["result_len"]])
-        seek += win["seek_delta"]
-    return segs, kept, wins
+                          suppress=None, suppress_first=None, eot=None, max_windows=1501, f16=False, prev_text=True,
+                          fallback=False, params=None, decoder_kw=None, encoder=None):
+    """`whisper_full` with (fallback=True) or without (temperature_inc = 0: one greedy pass per window, accepted as it
+    is) the temperature ladder; everything else -- no-speech rule, failure flags, single-timestamp ending -- applies in
+    both.  Returns (segments, all kept tokens, windows)."""
+    P = dict(params or {})
+    if not fallback:
+        P.setdefault("temperature_inc", 0.0)
+    return whisper_full(weights, hp, mel_window, n_samples, prompt, rules, token_text, P, n_max, suppress, suppress_first,
+                        eot, max_windows, f16, prev_text, decoder_kw, encoder)

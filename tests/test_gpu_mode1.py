@@ -150,7 +150,7 @@ def test_mode1_transcribe_segments_follow_the_f16_seek_loop(oracle, tmp_path_fac
     eng = WhisperEngine(_engine_file(tmp_path_factory, hp, W, "tiny-s0"))
     eng.set_precision(1)
     x = synth_audio.clip16k_np(52, 56000)
-    text, segs, toks = eng.transcribe_segments(x, max_new_tokens=10, language_token=sp["lang0"])
+    text, segs, toks = eng.transcribe_segments(x, max_new_tokens=10, language_token=sp["lang0"], fallback=False)
     rsegs, rkept, wins = WO.transcribe_timestamps(W, hp, lambda seek: oracle.oracle_logmel(x, F, seek), x.size, prompt,
                                                   WO.RULES_WCPP, eng.token_text, n_max=10, suppress=sup,
                                                   suppress_first=sup_first, max_windows=16, f16=True)
@@ -169,18 +169,18 @@ def test_mode1_transcribe_segments_follow_the_f16_seek_loop(oracle, tmp_path_fac
     _, segs_auto, toks_auto = eng.transcribe_segments(x, max_new_tokens=0)
     assert lang_null == eng.last_language_token and n_tok_null == len(toks_auto) and lang_null >= sp["lang0"]
     # batch == single calls, mode 1
-    clips = [x, synth_audio.clip16k_np(53, 90000), np.zeros(0, np.float32), synth_audio.clip16k_np(54, 15000)]
-    got = transcribe_batch(eng, clips, max_new_tokens=10, language_token=sp["lang0"], timestamps=True, with_segments=True)
-    assert got[0] == (text, toks, sp["lang0"], segs)
-    t1, s1, k1 = eng.transcribe_segments(clips[1], max_new_tokens=10, language_token=sp["lang0"])
-    assert got[1] == (t1, k1, sp["lang0"], s1) and got[2] == ("", [], 0, []) and got[3][:2] == ("", [])
+    clips = [x, synth_audio.clip16k_np(53, 90000), np.zeros(0, np.float32), synth_audio.clip16k_np(54, 1500)]
+    got = transcribe_batch(eng, clips, max_new_tokens=10, language_token=sp["lang0"], timestamps=True, with_segments=True, fallback=False)
+    assert got[0][:4] == (text, toks, sp["lang0"], segs)
+    t1, s1, k1 = eng.transcribe_segments(clips[1], max_new_tokens=10, language_token=sp["lang0"], fallback=False)
+    assert got[1][:4] == (t1, k1, sp["lang0"], s1) and got[2] == ("", [], 0, [], []) and got[3][:2] == ("", [])
     eng.close()
     # (b) audio-sensitive weights, 25 s clip: the kept tokens up to the oracle's first unresolvable pick
     Ws = synthetic_whisper_weights(hp, 0, sensitive=True)
     eng = WhisperEngine(_engine_file(tmp_path_factory, hp, Ws, "tiny-s0-sensitive"))
     eng.set_precision(1)
     y = synth_audio.clip16k_np(53, 400000)
-    _, _, ytoks = eng.transcribe_segments(y, max_new_tokens=10, language_token=sp["lang0"])
+    _, _, ytoks = eng.transcribe_segments(y, max_new_tokens=10, language_token=sp["lang0"], fallback=False)
     _, ykept, ywins = WO.transcribe_timestamps(Ws, hp, lambda seek: oracle.oracle_logmel(y, F, seek), y.size, prompt,
                                                WO.RULES_WCPP, eng.token_text, n_max=10, suppress=sup,
                                                suppress_first=sup_first, max_windows=2, f16=True)

@@ -193,53 +193,3 @@ def test_decoder_cache_f16_mode_only_rounds_where_it_says(tiny, enc_out):
         assert np.array_equal(l0, l)
         rel = np.abs(l2 - lh).max() / np.abs(lh).max()
         assert 1e-5 < rel < 1e-2, (i, rel)
-
-
-def test_seek_loop_conditions_on_the_text_so_far(tiny, monkeypatch):
-    """whisper.cpp's prompt_past in the oracle's seek loop [UPSTREAM-RECALL], with a scripted decoder in place of the
-    network: the second window's prompt is <|startofprev|> + what the first window kept + the bare prompt; the third
-    carries the second's past part + its kept tokens; the past is cut to n_text_ctx / 2 and dropped for a window that
-    starts with less than 5 s of audio left; prev_text=False leaves every window on the bare prompt."""
-    from oracle import whisper_oracle as WO
-    hp, W = tiny
-    sp = WO.special_tokens(hp.n_vocab)
-    init = [sp["sot"], sp["lang0"], sp["transcribe"]]
-    seen = []
-
-    def fake_window(step, prompt, sp_, rules, n_max, seek, seek_end, *a, **k):
-        seen.append(list(prompt))
-        n = len(seen)
-        toks = [sp["beg"], 1000 + n, 2000 + n, sp["beg"] + 350]        # <|0.00|> text text <|7.00|>
-        return dict(tokens=toks, tids=toks, result_len=4, seek_delta=700, margins=[1.0] * 4)
-
-    monkeypatch.setattr(WO, "decode_window", fake_window)
-    monkeypatch.setattr(WO, "encoder_forward", lambda *a, **k: None)
-    monkeypatch.setattr(WO, "DecoderCache", lambda *a, **k: type("D", (), {"step": None})())
-    mel = lambda seek: None
-    n = 16000 * 24                                                     # 2400 frames: windows at 0, 700, 1400, (2100: < 5 s left)
-    _, kept, wins = WO.transcribe_timestamps(W, hp, mel, n, init, WO.RULES_WCPP, lambda t: b"", n_max=10)
-    assert [w["seek"] for w in wins] == [0, 700, 1400, 2100]
-    w0 = [sp["beg"], 1001, 2001, sp["beg"] + 350]
-    w1 = [sp["beg"], 1002, 2002, sp["beg"] + 350]
-    assert seen[0] == init
-    assert seen[1] == [sp["prev"]] + w0 + init
-    assert seen[2] == [sp["prev"]] + w0 + w1 + init
-    assert seen[3] == init                                             # 2100 + 500 >= 2400: the past is dropped
-    assert kept[:8] == w0 + w1
-    seen.clear()
-    WO.transcribe_timestamps(W, hp, mel, n, init, WO.RULES_WCPP, lambda t: b"", n_max=10, prev_text=False)
-    assert all(p == init for p in seen) and len(seen) == 4
-    # the cut: a past longer than n_text_ctx / 2 keeps its tail, and prompt + n_max never exceeds n_text_ctx
-    seen.clear()
-
-    def long_window(step, prompt, sp_, rules, n_max, seek, seek_end, *a, **k):
-        seen.append(list(prompt))
-        toks = [sp["beg"]] + list(range(3000, 3000 + 150)) + [sp["beg"] + 300]
-        return dict(tokens=toks, tids=toks, result_len=len(toks), seek_delta=600, margins=[1.0] * len(toks))
-
-    monkeypatch.setattr(WO, "decode_window", long_window)
-    WO.transcribe_timestamps(W, hp, mel, 16000 * 30, init, WO.RULES_WCPP, lambda t: b"", n_max=None)
-    n_max = hp.n_text_ctx // 2 - 4
-    assert len(seen[1]) == 1 + 152 + 3
-    assert len(seen[2]) == 1 + min(hp.n_text_ctx // 2, hp.n_text_ctx - n_max - 3 - 1) + 3 and len(seen[2]) + n_max <= hp.n_text_ctx
-    assert seen[2][-3:] == init and seen[2][0] == sp["prev"] and seen[2][-4] == sp["beg"] + 300

@@ -92,7 +92,7 @@ def test_hip_transcribe_matches_whisper_cpp():
     res = C.c_void_p()
     N.check(N.lib().crispy_asr_transcribe(eng._h, x.ctypes.data, x.size, None, C.byref(res)))
     try:
-        text, tokens, lang, segs = _read_result(res)
+        text, tokens, lang, segs, _wins = _read_result(res)
     finally:
         N.lib().crispy_asr_free_result(res)
     sp = N.vocab_specials(eng.hp.n_vocab)

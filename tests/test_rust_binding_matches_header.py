@@ -10,10 +10,11 @@ HDR = os.path.join(ROOT, "include", "crispy_hip.h")
 RS = os.path.join(ROOT, "bindings", "rust", "crispy-hip-sys", "src", "lib.rs")
 
 OPAQUE = {"crispy_rn", "crispy_mel", "crispy_asr", "crispy_resampler"}
-STRUCTS = {"crispy_asr_hparams", "crispy_asr_specials", "crispy_asr_opts", "crispy_asr_segment", "crispy_asr_result"}
-SCALARS_C = {"int": "i32", "long": "i64", "float": "f32", "size_t": "usize", "char": "c_char", "void": "c_void",
+STRUCTS = {"crispy_asr_hparams", "crispy_asr_specials", "crispy_asr_opts", "crispy_asr_segment", "crispy_asr_window",
+           "crispy_asr_result"}
+SCALARS_C = {"int": "i32", "long": "i64", "float": "f32", "double": "f64", "size_t": "usize", "char": "c_char", "void": "c_void",
              "int8_t": "i8", "unsigned char": "u8", "crispy_rn_layout": "i32"}
-SCALARS_RS = {"c_int": "i32", "c_long": "i64", "c_float": "f32", "f32": "f32", "usize": "usize", "c_char": "c_char",
+SCALARS_RS = {"c_int": "i32", "c_long": "i64", "c_float": "f32", "f32": "f32", "f64": "f64", "c_double": "f64", "usize": "usize", "c_char": "c_char",
               "c_void": "c_void", "i8": "i8", "c_uchar": "u8", "u8": "u8", "crispy_rn_layout": "i32", "i32": "i32"}
 
 
