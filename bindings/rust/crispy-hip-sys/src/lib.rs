@@ -386,8 +386,9 @@ impl GpuWhisperEngine {
     pub fn load(model_path: &Path) -> Result<Self, CrispyError> {
         let c = path_cstring(model_path)?;
         let mut h = std::ptr::null_mut();
-        // resident load: a quantised catalog file (managers/model.rs:99,137) stays quantised in HBM (file-sized), f32 / f16
-        // files load as usual; either way the engine is in precision mode 1 afterwards
+        // resident load: a quantised catalog file (managers/model.rs:99,137) stays quantised in HBM (file-sized) and runs in
+        // precision mode 1 only; an f32 / f16 file (ggml-small.bin, large-v3-turbo) loads exactly as crispy_asr_load loads it
+        // -- dense, every precision mode available.  Either way the engine is in precision mode 1 afterwards
         check(unsafe { crispy_asr_load_resident(c.as_ptr(), 0, &mut h) })?;
         // whisper.cpp, the engine this one stands in for, multiplies f16 operands with f32 accumulation and keeps its
         // K|V caches in f16: precision mode 1 is that arithmetic (and 2.3 x the f32 mode's speed).  The library's own
@@ -401,7 +402,8 @@ impl GpuWhisperEngine {
         let mut hp = crispy_asr_hparams::default();
         if unsafe { crispy_asr_hparams_get(self.h, &mut hp) } == CRISPY_OK { hp.n_vocab } else { 0 }
     }
-    /// 0: exact f32 products (parity mode); 1: whisper.cpp's f16-operand arithmetic (the default of `load`).
+    /// 0: exact f32 products (parity mode; refused with CRISPY_ERR_UNSUPPORTED for a quantised file, which `load` keeps
+    /// resident as ggml blocks); 1: whisper.cpp's f16-operand arithmetic (the default of `load`).
     pub fn set_precision(&mut self, mode: i32) -> Result<(), CrispyError> {
         check(unsafe { crispy_asr_set_precision(self.h, mode as c_int) })
     }

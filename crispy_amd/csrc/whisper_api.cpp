@@ -77,6 +77,7 @@ struct crispy_asr {
   std::map<std::string, QTensor> qtensors;
   void* q_scratch = nullptr;
   size_t q_scratch_bytes = 0;
+  hipEvent_t ev_scratch = nullptr;           // orders a caller's stream against the handle's around the scratch slot
   const QTensor* q_tok_emb = nullptr;
   bool finalized = false;
   // resolved pointers
@@ -453,6 +454,7 @@ void crispy_asr_free(crispy_asr* h) try {
   for (auto& kv : h->qtensors)
     if (kv.second.d && kv.second.owned) (void)hipFree(kv.second.d);
   if (h->q_scratch) (void)hipFree(h->q_scratch);
+  if (h->ev_scratch) (void)hipEventDestroy(h->ev_scratch);
   if (h->d_suppress) (void)hipFree(h->d_suppress);
   if (h->d_suppress_first) (void)hipFree(h->d_suppress_first);
   if (h->d_ts_mask) (void)hipFree(h->d_ts_mask);
@@ -799,6 +801,23 @@ int crispy_asr_encode_device(crispy_asr* h, const float* d_mel_t, int batch, flo
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
   int rc = reserve_enc(h, batch);
   if (rc != CRISPY_OK) return rc;
+  // A resident quantised model de-quantises every weight into ONE scratch slot in front of its product; decode, cross K|V
+  // and the LayerNorm folding fill it on the handle's own stream.  A caller's stream is not ordered against that one, so
+  // an encode enqueued here while a decode of the same handle is still in flight would overwrite weights in use
+  // (ADVICE r3): order the two explicitly -- this encode starts after everything enqueued on the handle's stream so far,
+  // and the handle's stream continues after it.
+  struct ScratchOrder {
+    crispy_asr* h; hipStream_t s; bool on;
+    ~ScratchOrder() {
+      if (on && hipEventRecord(h->ev_scratch, s) == hipSuccess) (void)hipStreamWaitEvent(h->stream, h->ev_scratch, 0);
+    }
+  } scratch_order{h, s, false};
+  if (h->resident && s != h->stream) {
+    if (!h->ev_scratch) HIP_TRY(hipEventCreateWithFlags(&h->ev_scratch, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(h->ev_scratch, h->stream));
+    HIP_TRY(hipStreamWaitEvent(s, h->ev_scratch, 0));
+    scratch_order.on = true;
+  }
   const int d = h->hp.n_audio_state, Tn = h->hp.n_audio_ctx, nm = h->hp.n_mels, H = h->hp.n_audio_head;
   const long rows = (long)batch * Tn;
   // encoder GEMM: f16 operands when the mode is on and an f16 copy of the weight exists (K multiple of 32)
@@ -1956,6 +1975,21 @@ int crispy_asr_memory_info(const crispy_asr* h, size_t* weight_bytes, size_t* qu
 } CRISPY_CATCH_RET("crispy_asr_memory_info")
 
 namespace {
+// the matrices finalize_resident consumes as ggml blocks (QRef): attention and MLP weights, the token embedding.  Any
+// other 2-D tensor a file may hold quantised (whisper.cpp's own tool leaves them alone, the format does not forbid it:
+// positional embeddings, the [d, 1] convolution biases) is read through T() as dense f32 and is inflated at load.
+bool resident_block_name(const std::string& name) {
+  if (name == "decoder.token_embedding.weight") return true;
+  static const char* const tails[] = {".attn.query.weight", ".attn.key.weight", ".attn.value.weight", ".attn.out.weight",
+                                      ".cross_attn.query.weight", ".cross_attn.key.weight", ".cross_attn.value.weight",
+                                      ".cross_attn.out.weight", ".mlp.0.weight", ".mlp.2.weight"};
+  for (const char* t : tails) {
+    const size_t n = std::strlen(t);
+    if (name.size() >= n && name.compare(name.size() - n, n, t) == 0) return true;
+  }
+  return false;
+}
+
 int load_impl(const char* model_path, int device, bool resident, crispy_asr** out) {
   if (!out) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_load: out is NULL");
   *out = nullptr;
@@ -1994,7 +2028,7 @@ int load_impl(const char* model_path, int device, bool resident, crispy_asr** ou
   int rc = crispy_asr_create(&hp, filters.data(), device, &h);
   if (rc != CRISPY_OK) return rc;
   h->vocab = std::move(vocab);
-  h->resident = resident;
+  // (h->resident is decided after the tensor loop: only a file that HAS quantised matrices takes the resident path)
   auto bail = [&](int code) {
     const std::string keep = last_error_cstr();
     crispy_asr_free(h);
@@ -2052,7 +2086,7 @@ int load_impl(const char* model_path, int device, bool resident, crispy_asr** ou
       const size_t n_blocks = n / 32;
       qbuf.resize(n_blocks * qi.block_bytes);
       if (!r.read(qbuf.data(), qbuf.size())) { fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_load: truncated data of '%s'", name.c_str()); return bail(CRISPY_ERR_BAD_MODEL); }
-      if (resident && n_dims == 2) {
+      if (resident && n_dims == 2 && resident_block_name(name)) {
         // the blocks stay as they are (managers/model.rs:99,137: the catalog's q4_1 / q5_0 files): no f32 tensor is made
         QTensor q;
         q.ttype = ttype; q.n = n; q.cols = ne[0]; q.nbytes = qbuf.size();
@@ -2071,8 +2105,17 @@ int load_impl(const char* model_path, int device, bool resident, crispy_asr** ou
     rc = crispy_asr_set_tensor(h, name.c_str(), buf.data(), n);
     if (rc != CRISPY_OK) return bail(rc);
   }
+  // A file without a single quantised matrix (f32 / f16: the catalog's ggml-small.bin and large-v3-turbo,
+  // managers/model.rs:80,118) loads exactly as crispy_asr_load does: dense tensors, the ordinary finalize, the f16 copies
+  // of precision mode 1 -- not the resident path, where every matrix would be copied into the scratch slot in front of
+  // every product.
+  h->resident = resident && !h->qtensors.empty();
   rc = crispy_asr_finalize(h);
   if (rc != CRISPY_OK) return bail(rc);
+  if (resident && !h->resident) {              // what crispy_asr_load_resident promises: whisper.cpp's arithmetic
+    rc = crispy_asr_set_precision(h, 1);
+    if (rc != CRISPY_OK) return bail(rc);
+  }
   *out = h;
   return CRISPY_OK;
 }

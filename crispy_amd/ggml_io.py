@@ -94,14 +94,18 @@ def _pack_nibbles(d, m, q, five: bool) -> np.ndarray:
 
 
 def write_ggml_quantized(path: str, hp, weights: dict, filters: np.ndarray, vocab: list, kind: str = "q5_0",
-                         keep: bool = True) -> dict:
+                         keep: bool = True, also_positional: bool = False) -> dict:
     """Like the upstream `quantize` tool: 2-D `.weight` matrices whose rows are multiples of 32 become `kind`
     blocks, the rest stays f16/f32.  Returns the weights as the loader will see them (de-quantised; keep=False returns
-    an empty dict: catalog-size files).  `weights` needs `.items()` only (crispy_amd.whisper_weights.LazyWeights)."""
+    an empty dict: catalog-size files).  `weights` needs `.items()` only (crispy_amd.whisper_weights.LazyWeights).
+    also_positional: quantise the two positional embeddings too -- the upstream tool never does, the file format allows
+    it (the loaders must cope: tests/test_gpu_resident.py)."""
     import io
     seen = {}
     f32_always = {"encoder.conv1.bias", "encoder.conv2.bias", "encoder.positional_embedding",
                   "decoder.positional_embedding"}
+    if also_positional:
+        f32_always -= {"encoder.positional_embedding", "decoder.positional_embedding"}
     with open(path, "wb") as f:
         f.write(struct.pack("<I", GGML_MAGIC))
         f.write(struct.pack("<11i", *hp.as_ints(), GGML_TYPES[kind]))
@@ -117,7 +121,8 @@ def write_ggml_quantized(path: str, hp, weights: dict, filters: np.ndarray, voca
             data = np.ascontiguousarray(w, dtype=np.float32)
             if name in ("encoder.conv1.bias", "encoder.conv2.bias"):
                 data = data.reshape(-1, 1)
-            quant = data.ndim == 2 and name.endswith(".weight") and data.shape[1] % 32 == 0 and name not in f32_always
+            quant = (data.ndim == 2 and (name.endswith(".weight") or (also_positional and name.endswith("positional_embedding")))
+                     and data.shape[1] % 32 == 0 and name not in f32_always)
             as_f16 = (not quant) and data.ndim >= 2 and name not in f32_always
             if quant:
                 payload, deq = quantize_blocks(data, kind)

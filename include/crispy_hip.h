@@ -344,7 +344,12 @@ int crispy_asr_load(const char *model_path, int device, crispy_asr **out);
  * largest layer matrix.  Resident weight bytes ~= file size (+ the token embedding once more as f16 in matrix-core
  * operand order for the logits).  The engine runs in precision mode 1 (whisper.cpp's f16-operand arithmetic); 
  * crispy_asr_set_precision(h, 0) is refused with CRISPY_ERR_UNSUPPORTED.  Results equal those of crispy_asr_load +
- * crispy_asr_set_precision(h, 1) on the same file bit for bit.  f32 / f16 files load as with crispy_asr_load. */
+ * crispy_asr_set_precision(h, 1) on the same file bit for bit.  Only the matrices the engine consumes as blocks stay
+ * quantised (attention and MLP weights, the token embedding); any other quantised tensor is inflated.  A file with no
+ * quantised matrix at all (f32 / f16: ggml-small.bin, ggml-large-v3-turbo.bin, managers/model.rs:80,118) loads exactly
+ * as crispy_asr_load does -- dense tensors, every precision mode available, crispy_asr_memory_info reports no quantised
+ * bytes and no scratch slot.  crispy_asr_encode_device on a caller's stream is ordered against the handle's own stream
+ * around the scratch slot (the encode starts after the work enqueued on the handle so far; the handle continues after it). */
 int crispy_asr_load_resident(const char *model_path, int device, crispy_asr **out);
 
 /* Device memory held by the model itself (not the per-call workspaces): every weight tensor, fused / folded / f16 copy

@@ -67,9 +67,10 @@ def test_resident_model_equals_the_inflated_one(tiny, tmp_path, kind):
     res.close(); inf.close()
 
 
-def test_resident_load_of_a_dense_file_is_the_ordinary_mode_1_engine(tiny, tmp_path):
-    """f32 / f16 files hold no blocks: `crispy_asr_load_resident` then keeps the matrices as the file has them (f32) and
-    still runs the same mode-1 arithmetic."""
+def test_resident_load_of_a_dense_file_is_the_ordinary_engine(tiny, tmp_path):
+    """f32 / f16 files hold no blocks (the catalog's ggml-small.bin and ggml-large-v3-turbo.bin, managers/model.rs:80,118):
+    `crispy_asr_load_resident` then IS `crispy_asr_load` + mode 1 -- dense tensors and their f16 copies, no scratch slot
+    (nothing is copied in front of a product), every precision mode available, the same bytes held."""
     from crispy_amd import synth_audio
     from crispy_amd.asr import WhisperEngine
     from crispy_amd.ggml_io import synthetic_vocab, write_ggml
@@ -81,6 +82,70 @@ def test_resident_load_of_a_dense_file_is_the_ordinary_mode_1_engine(tiny, tmp_p
     inf = WhisperEngine(str(path))
     inf.set_precision(1)
     x = synth_audio.clip16k_np(7, 200000)
-    assert np.array_equal(res.encode([x]), inf.encode([x]))
+    assert np.array_equal(res.encode([x]), inf.encode([x]))                 # mode 1 without being asked: what load_resident promises
     assert res.transcribe(x, max_new_tokens=6) == inf.transcribe(x, max_new_tokens=6)
-    assert res.memory_info()["quantised_bytes"] == 0
+    mr, mi = res.memory_info(), inf.memory_info()
+    assert mr["quantised_bytes"] == 0 and mr["scratch_bytes"] == 0 and mr == mi, (mr, mi)
+    for mode in (0, 2, 1):                                                  # not refused
+        res.set_precision(mode); inf.set_precision(mode)
+        assert np.array_equal(res.encode([x]), inf.encode([x]))
+    res.close(); inf.close()
+
+
+def test_a_file_that_quantises_its_positional_embeddings_loads_both_ways(tiny, tmp_path):
+    """The format lets any 2-D tensor be quantised; whisper.cpp's tool leaves the positional embeddings alone.  The resident
+    loader keeps blocks only for the matrices it consumes as blocks and inflates the rest (it used to mark these tensors as
+    set with no device copy: the first embed kernel would have read a null pointer)."""
+    from crispy_amd import synth_audio
+    from crispy_amd.asr import WhisperEngine
+    from crispy_amd.ggml_io import synthetic_vocab, write_ggml_quantized
+    from crispy_amd.mel_filters import whisper_mel_filters
+    hp, W = tiny
+    path = tmp_path / "tiny-q8-pos.bin"
+    write_ggml_quantized(str(path), hp, W, whisper_mel_filters(80), synthetic_vocab(hp.n_vocab), "q8_0", also_positional=True)
+    res = WhisperEngine(str(path), resident=True)
+    inf = WhisperEngine(str(path))
+    inf.set_precision(1)
+    x = synth_audio.clip16k_np(8, 150000)
+    e = res.encode([x])
+    assert np.isfinite(e).all() and np.array_equal(e, inf.encode([x]))
+    assert res.transcribe(x, max_new_tokens=6) == inf.transcribe(x, max_new_tokens=6)
+    res.close(); inf.close()
+
+
+def test_resident_encode_on_a_callers_stream_is_ordered_against_the_handles_stream(tiny, tmp_path):
+    """One scratch slot per resident model: an encode on the caller's stream must not start filling it while a decode of the
+    same handle is still in flight on the handle's stream, and the decode that follows must see the encoder's output
+    (ADVICE r3).  Back to back without a host synchronisation in between: a long decode (enqueue only ends with its own
+    sync, so a second encode is issued first on a side stream while the first call's tail is still running), encodes on a
+    torch side stream, results equal to the same calls made one at a time."""
+    import torch
+    from crispy_amd import synth_audio
+    from crispy_amd.asr import LogMel, WhisperEngine
+    from crispy_amd.ggml_io import synthetic_vocab, write_ggml_quantized
+    from crispy_amd.mel_filters import whisper_mel_filters
+    hp, W = tiny
+    path = tmp_path / "tiny-q5-stream.bin"
+    write_ggml_quantized(str(path), hp, W, whisper_mel_filters(80), synthetic_vocab(hp.n_vocab), "q5_0")
+    res = WhisperEngine(str(path), resident=True)
+    clips = [synth_audio.clip16k_np(600 + i, 480000) for i in range(8)]
+    ref = res.encode(clips)                                      # everything on the handle's stream
+    mel = LogMel(80)
+    pcm = torch.from_numpy(np.stack(clips)).cuda()
+    d_melt = torch.zeros((8, 3002, 80), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    mel.compute_device(pcm.data_ptr(), 480000, [480000] * 8, d_out_t=d_melt.data_ptr())
+    mel.synchronize()
+    side = torch.cuda.Stream()
+    outs = [torch.empty((8, 1500, hp.n_audio_state), dtype=torch.float32, device="cuda") for _ in range(3)]
+    prompt = [50258, 50259, 50359, 50363]
+    for k in range(3):
+        # a decode on the handle's own stream (fills the scratch slot for every projection) ...
+        res.decode_greedy_device(torch.from_numpy(ref).cuda().data_ptr(), 8, prompt, 6)
+        # ... and straight after it an encode on the side stream
+        res.encode_device(d_melt.data_ptr(), 8, outs[k].data_ptr(), side.cuda_stream)
+    side.synchronize()
+    res.synchronize()
+    for k in range(3):
+        assert np.array_equal(outs[k].cpu().numpy(), ref), k
+    res.close()
