@@ -283,24 +283,40 @@ def asr_leg(local_rank: int, clips: int = 64, new_tokens: int = 32, ggml_path: s
         clip from host memory.  Random-init weights decide how many windows and tokens that is; both are reported."""
         import ctypes as C
         from crispy_amd import _native as N
+        from crispy_amd.asr import make_opts
         x1 = np.ascontiguousarray(pcm[0].cpu().numpy()[:16000 * 28])
-        def call():
+
+        def call(opts):
             res = C.c_void_p()
-            N.check(N.lib().crispy_asr_transcribe(model._h, x1.ctypes.data, x1.size, None, C.byref(res)))
+            N.check(N.lib().crispy_asr_transcribe(model._h, x1.ctypes.data, x1.size, C.byref(opts) if opts is not None else None,
+                                                  C.byref(res)))
             r = C.cast(res, C.POINTER(N.AsrResult)).contents
-            out = (int(r.n_tokens), int(r.n_segments))
+            temps = [float(r.windows[i].temperature) for i in range(r.n_windows)]
+            out = (int(r.n_tokens), int(r.n_segments), int(r.n_windows), sum(t > 0 for t in temps),
+                   sum(int(r.windows[i].no_speech) for i in range(r.n_windows)))
             N.lib().crispy_asr_free_result(res)
             return out
-        n_tok, n_seg = call()
-        ts = []
-        for _ in range(3):
-            t0 = time.perf_counter()
-            call()
-            ts.append(time.perf_counter() - t0)
-        t = float(np.median(ts))
-        return {"what": "crispy_asr_transcribe(h, pcm, n, opts = NULL): language detection, timestamp rules, seek loop, previous-text "
-                        "conditioning; 28 s of audio from host memory", "ms": t * 1e3, "tokens": n_tok, "segments": n_seg,
-                "ms_per_token": t * 1e3 / max(n_tok, 1), "rtfx": 28.0 / t}
+
+        def timed(opts):
+            n_tok, n_seg, n_win, n_fb, n_ns = call(opts)
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                call(opts)
+                ts.append(time.perf_counter() - t0)
+            t = float(np.median(ts))
+            return {"ms": t * 1e3, "tokens": n_tok, "segments": n_seg, "windows": n_win, "windows_re_decoded": n_fb,
+                    "windows_dropped_as_silence": n_ns, "ms_per_token": t * 1e3 / max(n_tok, 1), "rtfx": 28.0 / t}
+
+        # opts = NULL walks whisper_full's temperature ladder wherever a window fails its thresholds -- on random-init
+        # weights (log-probability ~ -10 per token, no end of text) that is every window, all the way to 1.0 with five
+        # sampling decoders per pass, exactly as whisper.cpp would on such logits; the single greedy pass per window
+        # (temperature_inc < 0) is timed beside it: what a window that decodes well costs
+        out = timed(None)
+        out["what"] = ("crispy_asr_transcribe(h, pcm, n, opts = NULL): language detection, timestamp rules, seek loop, previous-text "
+                       "conditioning, no-speech rule, temperature fallback; 28 s of audio from host memory")
+        out["one_greedy_pass_per_window"] = timed(make_opts(timestamps=True, fallback=False))
+        return out
 
     times = measure()                      # default precision: f32 operands, the mode the oracle parity is pinned in
     one = single_clip()

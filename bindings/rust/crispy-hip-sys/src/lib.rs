@@ -155,7 +155,6 @@ extern "C" {
     pub fn crispy_rn_n_streams(h: *const crispy_rn) -> c_int;
     pub fn crispy_rn_frames_per_launch() -> c_int;
     pub fn crispy_rn_n_launches(n_frames: c_int) -> c_int;
-    pub fn crispy_rn_set_pipeline(h: *mut crispy_rn, staged: c_int) -> c_int;
     pub fn crispy_rn_process(h: *mut crispy_rn, input: *const c_float, output: *mut c_float, vad: *mut c_float, n_frames: c_int, layout: crispy_rn_layout) -> c_int;
     pub fn crispy_host_register(p: *mut c_void, bytes: usize) -> c_int;
     pub fn crispy_host_unregister(p: *mut c_void) -> c_int;
@@ -163,7 +162,6 @@ extern "C" {
     pub fn crispy_rn_synchronize(h: *mut crispy_rn) -> c_int;
     pub fn crispy_rn_set_timing(h: *mut crispy_rn, enable: c_int) -> c_int;
     pub fn crispy_rn_last_kernel_ms(h: *mut crispy_rn, frame_kernel_ms: *mut c_float, total_ms: *mut c_float) -> c_int;
-    pub fn crispy_rn_stage_rnn_device(h: *mut crispy_rn, d_feat: *const c_float, d_silent: *const c_uchar, d_g_raw: *mut c_float, d_g_smooth: *mut c_float, d_vad: *mut c_float, n_frames: c_int, hip_stream: *mut c_void) -> c_int;
     pub fn crispy_rn_stage_tansig_device(h: *mut crispy_rn, d_x: *const c_float, d_y: *mut c_float, n: usize, sigmoid: c_int, hip_stream: *mut c_void) -> c_int;
     pub fn crispy_rn_debug_capture(h: *mut crispy_rn, enable: c_int) -> c_int;
     pub fn crispy_rn_debug_read(h: *mut crispy_rn, stream: c_int, dst: *mut c_float, n_floats: usize) -> c_int;

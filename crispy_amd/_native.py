@@ -22,10 +22,10 @@ LAYOUT_BTF = 1
 RN_SYMBOLS = (
     "crispy_last_error", "crispy_version", "crispy_device_count",
     "crispy_rn_create", "crispy_rn_destroy", "crispy_rn_reset", "crispy_rn_n_streams",
-    "crispy_rn_frames_per_launch", "crispy_rn_n_launches", "crispy_rn_set_pipeline",
+    "crispy_rn_frames_per_launch", "crispy_rn_n_launches",
     "crispy_rn_process", "crispy_rn_process_device", "crispy_rn_synchronize",
     "crispy_rn_set_timing", "crispy_rn_last_kernel_ms",
-    "crispy_rn_debug_capture", "crispy_rn_debug_read", "crispy_rn_stage_rnn_device", "crispy_rn_stage_tansig_device",
+    "crispy_rn_debug_capture", "crispy_rn_debug_read", "crispy_rn_stage_tansig_device",
     "crispy_host_register", "crispy_host_unregister",
     "crispy_rn_weights_from_file", "crispy_rn_create_from_file", "crispy_selftest_exception_guard",
 )
@@ -96,9 +96,8 @@ def lib() -> C.CDLL:
 
 
 def load_variant(name: str) -> C.CDLL:
-    """Another build of the same library next to the default one: libcrispy_hip_<name>.so (`make variants`:
-    gru0 / gru1 = the gain network of the frame kernel on v_fma_mix_f32 / f16 MFMA instead of int8 MFMA).  A separate
-    handle with its own state; parity tests run the same cases through every form."""
+    """Another build of the same library next to the default one: libcrispy_hip_<name>.so (`make variants`: poison = the
+    checker build whose RNNoise kernels fill their LDS with NaNs first).  A separate handle with its own state."""
     return load_library(os.path.join(_HERE, f"libcrispy_hip_{name}.so"))
 
 
@@ -138,9 +137,7 @@ def load_library(path: str) -> C.CDLL:
     L.crispy_host_unregister.argtypes = [C.c_void_p]
     L.crispy_rn_set_timing.argtypes = [C.c_void_p, C.c_int]
     L.crispy_rn_last_kernel_ms.argtypes = [C.c_void_p, f32p, f32p]
-    L.crispy_rn_stage_rnn_device.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_void_p]
     L.crispy_rn_stage_tansig_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
-    L.crispy_rn_set_pipeline.argtypes = [C.c_void_p, C.c_int]
     L.crispy_rn_debug_capture.argtypes = [C.c_void_p, C.c_int]
     L.crispy_rn_debug_read.argtypes = [C.c_void_p, C.c_int, f32p, C.c_size_t]
     L.crispy_mel_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]

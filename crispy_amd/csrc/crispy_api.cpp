@@ -191,56 +191,6 @@ void pack_weights(std::vector<uint32_t>& out, const int8_t* w) {
 }
 
 
-// bf16 B fragments of the batched MFMA gain network (rn_rnn_kernel.hip).  Lane l of fragment (tile n, k step
-// ks) holds W[k = 32 ks + 8 (l >> 4) + j][column 16 n + (l & 15)], j = 0..7; int8 values are exact in bf16.
-void pack_rnn_fragments(std::vector<uint16_t>& frags, std::vector<float>& bias, const int8_t* w) {
-  frags.assign((size_t)RnnPack::F_END * 64 * 8, 0);
-  bias.assign(RnnPack::B_END, 0.f);
-  auto bf16_bits = [](int v) {
-    const float f = (float)v;
-    uint32_t u;
-    std::memcpy(&u, &f, 4);
-    return (uint16_t)(u >> 16);   // |v| <= 128 needs at most 8 significant bits: truncation is exact
-  };
-  struct Phase {
-    int first, tiles, ksteps, n_cols, col0;
-    // weight of input row kk for (absolute) gate column c, or 0 beyond the real K
-    const int8_t* Win; int m_in, stride;
-    const int8_t* Wrec; int n_rec;
-  };
-  const Phase ph[9] = {
-      {RnnPack::F_DENSE, 2, 2, 24, 0, w + RnBlob::ID_W, 42, 24, nullptr, 0},
-      {RnnPack::F_VZR, 3, 2, 48, 0, w + RnBlob::VG_W, 24, 72, w + RnBlob::VG_R, 24},
-      {RnnPack::F_VH, 2, 2, 24, 48, w + RnBlob::VG_W, 24, 72, w + RnBlob::VG_R, 24},
-      {RnnPack::F_VO, 1, 1, 1, 0, w + RnBlob::VO_W, 24, 1, nullptr, 0},
-      {RnnPack::F_NZR, 6, 5, 96, 0, w + RnBlob::NG_W, 90, 144, w + RnBlob::NG_R, 48},
-      {RnnPack::F_NH, 3, 5, 48, 96, w + RnBlob::NG_W, 90, 144, w + RnBlob::NG_R, 48},
-      {RnnPack::F_DZR, 12, 7, 192, 0, w + RnBlob::DG_W, 114, 288, w + RnBlob::DG_R, 96},
-      {RnnPack::F_DH, 6, 7, 96, 192, w + RnBlob::DG_W, 114, 288, w + RnBlob::DG_R, 96},
-      {RnnPack::F_OUT, 2, 3, 22, 0, w + RnBlob::DO_W, 96, 22, nullptr, 0},
-  };
-  for (const Phase& p : ph)
-    for (int tile = 0; tile < p.tiles; ++tile)
-      for (int ks = 0; ks < p.ksteps; ++ks)
-        for (int l = 0; l < 64; ++l)
-          for (int j = 0; j < 8; ++j) {
-            const int col = tile * 16 + (l & 15), kk = ks * 32 + 8 * (l >> 4) + j;
-            int v = 0;
-            if (col < p.n_cols) {
-              const int c = p.col0 + col;
-              if (kk < p.m_in) v = p.Win[(size_t)kk * p.stride + c];
-              else if (kk < p.m_in + p.n_rec) v = p.Wrec[(size_t)(kk - p.m_in) * p.stride + c];
-            }
-            frags[(((size_t)p.first + tile * p.ksteps + ks) * 64 + l) * 8 + j] = bf16_bits(v);
-          }
-  for (int i = 0; i < 24; ++i) bias[RnnPack::B_DENSE + i] = w[RnBlob::ID_B + i];
-  for (int i = 0; i < 72; ++i) bias[RnnPack::B_VG + i] = w[RnBlob::VG_B + i];
-  bias[RnnPack::B_VO] = w[RnBlob::VO_B];
-  for (int i = 0; i < 144; ++i) bias[RnnPack::B_NG + i] = w[RnBlob::NG_B + i];
-  for (int i = 0; i < 288; ++i) bias[RnnPack::B_DG + i] = w[RnBlob::DG_B + i];
-  for (int i = 0; i < 22; ++i) bias[RnnPack::B_OUT + i] = w[RnBlob::DO_B + i];
-}
-
 }  // namespace
 
 struct crispy_rn {
@@ -253,12 +203,9 @@ struct crispy_rn {
   // constants
   RnTables* d_tab = nullptr;
   uint32_t* d_wpack = nullptr;
-  uint16_t* d_frags = nullptr;   // bf16 MFMA fragments of the batched gain network
-  float* d_rnn_bias = nullptr;
   // state
   float* d_hp_mem = nullptr;
-  float* d_synth = nullptr;       // overlap-add tails [B][480]: the current ones
-  float* d_synth_alt = nullptr;   // ... and where the synthesis kernel of the staged pipeline writes the next ones (swapped per launch)
+  float* d_synth = nullptr;       // overlap-add tails [B][480]
   float* d_ceps = nullptr;
   float* d_lastg = nullptr;
   float* d_rnn = nullptr;
@@ -268,9 +215,6 @@ struct crispy_rn {
   // workspace
   float* d_xhp = nullptr;
   long xhp_stride = 0;
-  float2* d_pspec = nullptr;
-  // staged pipeline workspaces, one sub-chunk deep
-  bool staged = false;
   // Frames per high-pass launch.  A high-pass wave keeps the VALU of its SIMD ~35 % busy (nine dependent f64
   // operations per sample) and a frame-kernel launch lasts as long as its slowest wave, so a sub-chunk's high-pass as
   // one 0.3 ms kernel delays the four frame waves that share its SIMD by ~0.08 ms per launch (0.8 ms per 100-frame
@@ -280,13 +224,6 @@ struct crispy_rn {
   int hp_ahead = 0;          // > 0: the high-pass runs at most this many sub-chunks in front of the frame kernels
   std::vector<hipEvent_t> ev_fr;   // one per sub-chunk: frame kernel done (only used with hp_ahead)
   bool hp_upfront = false;   // diagnostic (CRISPY_RN_HP=upfront): every high-pass of a call segment first, on the main stream
-  float2* d_xspec = nullptr;
-  float* d_feat = nullptr;
-  unsigned char* d_silent = nullptr;
-  float* d_rec = nullptr;
-  float* d_graw = nullptr;
-  float* d_gsm = nullptr;
-  float* d_vadbuf = nullptr;
   float* d_dbg = nullptr;
   // host-pointer staging
   float* d_stage_in = nullptr;
@@ -310,8 +247,8 @@ void free_all(crispy_rn* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  void* ptrs[] = {h->d_xspec, h->d_feat, h->d_silent, h->d_rec, h->d_graw, h->d_gsm, h->d_vadbuf, h->d_frags, h->d_rnn_bias, h->d_tab, h->d_wpack, h->d_hp_mem, h->d_synth, h->d_synth_alt, h->d_ceps, h->d_lastg, h->d_rnn,
-                  h->d_last_gain, h->d_last_period, h->d_memid, h->d_xhp, h->d_pspec, h->d_dbg, h->d_stage_in,
+  void* ptrs[] = {h->d_tab, h->d_wpack, h->d_hp_mem, h->d_synth, h->d_ceps, h->d_lastg, h->d_rnn,
+                  h->d_last_gain, h->d_last_period, h->d_memid, h->d_xhp, h->d_dbg, h->d_stage_in,
                   h->d_stage_out, h->d_stage_vad};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -511,7 +448,6 @@ int crispy_rn_create(const int8_t* weights, size_t nbytes, int n_streams, int de
     HIP_TRY(hipMalloc(&h->d_wpack, sizeof(uint32_t) * RnPack8::END));
     HIP_TRY(hipMalloc(&h->d_hp_mem, B * 2 * sizeof(float)));
     HIP_TRY(hipMalloc(&h->d_synth, B * 480 * sizeof(float)));
-    HIP_TRY(hipMalloc(&h->d_synth_alt, B * 480 * sizeof(float)));
     HIP_TRY(hipMalloc(&h->d_ceps, B * 176 * sizeof(float)));
     HIP_TRY(hipMalloc(&h->d_lastg, B * RN_NB * sizeof(float)));
     HIP_TRY(hipMalloc(&h->d_rnn, B * 168 * sizeof(float)));
@@ -519,18 +455,7 @@ int crispy_rn_create(const int8_t* weights, size_t nbytes, int n_streams, int de
     HIP_TRY(hipMalloc(&h->d_last_period, B * sizeof(int)));
     HIP_TRY(hipMalloc(&h->d_memid, B * sizeof(int)));
     HIP_TRY(hipMalloc(&h->d_xhp, B * h->xhp_stride * sizeof(float)));
-    // the staged pipeline parks one sub-chunk of spectra; the fused kernel needs one frame of P only
-    HIP_TRY(hipMalloc(&h->d_pspec, B * 482 * sizeof(float2) * kSubFrames));
-    HIP_TRY(hipMalloc(&h->d_xspec, B * 482 * sizeof(float2) * kSubFrames));
-    HIP_TRY(hipMalloc(&h->d_feat, B * RNN_FEAT_LD * sizeof(float) * kSubFrames));
-    HIP_TRY(hipMalloc(&h->d_silent, B * kSubFrames));
-    HIP_TRY(hipMalloc(&h->d_rec, B * RN_REC_LD * sizeof(float) * kSubFrames));
-    HIP_TRY(hipMalloc(&h->d_graw, B * RNN_GAIN_LD * sizeof(float) * kSubFrames));
-    HIP_TRY(hipMalloc(&h->d_gsm, B * RNN_GAIN_LD * sizeof(float) * kSubFrames));
-    HIP_TRY(hipMalloc(&h->d_vadbuf, B * sizeof(float) * kSubFrames));
     {
-      const char* env = std::getenv("CRISPY_RN_PIPELINE");
-      h->staged = env && std::strcmp(env, "staged") == 0;   // default: the single fused frame kernel
       const char* hp = std::getenv("CRISPY_RN_HP");
       h->hp_upfront = hp && std::strcmp(hp, "upfront") == 0;
       const char* sp = std::getenv("CRISPY_RN_HP_SPLIT");
@@ -546,13 +471,6 @@ int crispy_rn_create(const int8_t* weights, size_t nbytes, int n_streams, int de
     std::vector<uint32_t> pack;
     pack_weights(pack, weights);
     HIP_TRY(hipMemcpy(h->d_wpack, pack.data(), sizeof(uint32_t) * pack.size(), hipMemcpyHostToDevice));
-    std::vector<uint16_t> frags;
-    std::vector<float> rbias;
-    pack_rnn_fragments(frags, rbias, weights);
-    HIP_TRY(hipMalloc(&h->d_frags, frags.size() * sizeof(uint16_t)));
-    HIP_TRY(hipMalloc(&h->d_rnn_bias, rbias.size() * sizeof(float)));
-    HIP_TRY(hipMemcpy(h->d_frags, frags.data(), frags.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->d_rnn_bias, rbias.data(), rbias.size() * sizeof(float), hipMemcpyHostToDevice));
     int z = zero_state(h, -1);
     if (z != CRISPY_OK) return z;
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -578,12 +496,6 @@ int crispy_rn_n_launches(int n_frames) try {
   for (int t0 = 0; t0 < n_frames; t0 += kChunkFrames) n += count_subs(n_frames - t0 < kChunkFrames ? n_frames - t0 : kChunkFrames);
   return n;
 } CRISPY_CATCH_RET("crispy_rn_n_launches")
-
-int crispy_rn_set_pipeline(crispy_rn* h, int staged) try {
-  if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_set_pipeline: NULL handle");
-  h->staged = staged != 0;
-  return CRISPY_OK;
-} CRISPY_CATCH_RET("crispy_rn_set_pipeline")
 
 int crispy_rn_reset(crispy_rn* h, int stream) try {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_reset: NULL handle");
@@ -626,14 +538,6 @@ int process_device_impl(crispy_rn* h, const float* d_in, float* d_out, float* d_
   a.stride_b = stride_b;
   a.xhp = h->d_xhp;
   a.xhp_stride = h->xhp_stride;
-  a.pspec = h->d_pspec;
-  a.xspec = h->d_xspec;
-  a.feat = h->d_feat;
-  a.silent = h->d_silent;
-  a.rec = h->d_rec;
-  a.g_raw = h->d_graw;
-  a.g_smooth = h->d_gsm;
-  a.vadbuf = h->d_vadbuf;
   a.hp_mem = h->d_hp_mem;
   a.synth = h->d_synth;
   a.ceps = h->d_ceps;
@@ -712,29 +616,7 @@ int process_device_impl(crispy_rn* h, const float* d_in, float* d_out, float* d_
       if (h->hp_ahead > 0) { const int rc_hp = enqueue_hp_until(i + h->hp_ahead - 1); if (rc_hp != CRISPY_OK) return rc_hp; }
       HIP_TRY(hipStreamWaitEvent(s, h->ev_hp[i], 0));
       if (e) HIP_TRY(hipEventRecord(e[1 + 2 * i], s));
-      if (h->staged && !sa.dbg) {
-        // analysis (per stream, up to the 42 features) -> gain network batched over streams on the matrix
-        // cores -> synthesis (per stream); spectra and band energies travel through L2/HBM
-        HIP_TRY(rn_launch_analysis(sa, s));
-        RnnArgs ra{};
-        ra.feat = h->d_feat; ra.silent = h->d_silent; ra.g_raw = h->d_graw; ra.g_smooth = h->d_gsm; ra.vad = h->d_vadbuf;
-        ra.T = sa.T; ra.B = h->B; ra.rnn = h->d_rnn; ra.lastg = h->d_lastg;
-        ra.frags = h->d_frags; ra.bias = h->d_rnn_bias;
-        ra.tansig = reinterpret_cast<const float*>(reinterpret_cast<const char*>(h->d_tab) + offsetof(RnTables, tansig));
-        HIP_TRY(rn_launch_rnn(ra, s));
-        // The first frame group of a stream reads the overlap-add tail the previous launch left, the last group writes
-        // the next one -- into the OTHER buffer: the groups of a launch are separate workgroups on different XCDs, and
-        // nothing orders the read of group 0 before the write of the last group (an XCD that is late dispatching its
-        // share of the grid -- the high-pass kernel of the helper stream is on another hardware queue -- let a 3-frame
-        // last group finish before group 0 had started: first frame of a sub-chunk wrong, in ~1 process out of 2).
-        sa.synth = h->d_synth;
-        sa.synth_out = h->d_synth_alt;
-        HIP_TRY(rn_launch_synthesis(sa, s));
-        std::swap(h->d_synth, h->d_synth_alt);
-      } else {
-        sa.synth = sa.synth_out = h->d_synth;
-        HIP_TRY(rn_launch_frames(sa, s));
-      }
+      HIP_TRY(rn_launch_frames(sa, s));
       if (e) HIP_TRY(hipEventRecord(e[2 + 2 * i], s));
       if (h->hp_ahead > 0) HIP_TRY(hipEventRecord(h->ev_fr[i], s));
       ts += sa.T;
@@ -940,24 +822,6 @@ int crispy_rn_stage_tansig_device(crispy_rn* h, const float* d_x, float* d_y, si
   HIP_TRY(rn_launch_tansig(h->d_tab, d_x, d_y, (long)n, sigmoid != 0, hip_stream ? (hipStream_t)hip_stream : h->stream));
   return CRISPY_OK;
 } CRISPY_CATCH_RET("crispy_rn_stage_tansig_device")
-
-int crispy_rn_stage_rnn_device(crispy_rn* h, const float* d_feat, const unsigned char* d_silent, float* d_g_raw,
-                               float* d_g_smooth, float* d_vad, int n_frames, void* hip_stream) try {
-  if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_stage_rnn_device: NULL handle");
-  if (n_frames < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_stage_rnn_device: n_frames < 0");
-  if (n_frames == 0) return CRISPY_OK;
-  if (!d_feat || !d_silent || !d_g_raw || !d_g_smooth)
-    return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_stage_rnn_device: NULL argument");
-  HIP_TRY(hipSetDevice(h->device));
-  RnnArgs a{};
-  a.feat = d_feat; a.silent = d_silent; a.g_raw = d_g_raw; a.g_smooth = d_g_smooth; a.vad = d_vad;
-  a.T = n_frames; a.B = h->B;
-  a.rnn = h->d_rnn; a.lastg = h->d_lastg;
-  a.frags = h->d_frags; a.bias = h->d_rnn_bias;
-  a.tansig = reinterpret_cast<const float*>(reinterpret_cast<const char*>(h->d_tab) + offsetof(RnTables, tansig));
-  HIP_TRY(rn_launch_rnn(a, hip_stream ? (hipStream_t)hip_stream : h->stream));
-  return CRISPY_OK;
-} CRISPY_CATCH_RET("crispy_rn_stage_rnn_device")
 
 int crispy_rn_debug_capture(crispy_rn* h, int enable) try {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_debug_capture: NULL handle");

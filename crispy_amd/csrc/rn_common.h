@@ -16,7 +16,6 @@ constexpr int RN_HIST_FRAMES = 4;
 constexpr int RN_TAPS = 72;
 constexpr int RN_WEIGHT_BYTES = 87503;
 constexpr int RN_DBG_FLOATS = 4304;    // mirrors oracle RNO_DBG_*
-constexpr int RN_REC_LD = 72;          // per (frame, stream) record handed from the analysis to the synthesis kernel
 
 // Device tables (built on the host in double precision, one copy per handle).
 struct RnTables {
@@ -104,20 +103,9 @@ struct RnArgs {
   // workspace: high-passed signal, per stream contiguous: [B][xhp_stride], first RN_HIST = history
   float* xhp;
   long xhp_stride;
-  float2* pspec;        // pitch-frame spectrum parked in L2/HBM between its FFT and the comb filter:
-                        // fused kernel [B][482]; staged pipeline [T][B][482]
-  // staged pipeline (analysis kernel -> batched MFMA gain network -> synthesis kernel), per sub-chunk
-  float2* xspec;        // [T][B][482] analysis spectrum
-  float* feat;          // [T][B][RNN_FEAT_LD]
-  unsigned char* silent;  // [T][B]
-  float* rec;           // [T][B][RN_REC_LD]: Ex(22) Ep(22) Exp(22) pitch_index pitch_gain
-  float* g_raw;         // [T][B][RNN_GAIN_LD]
-  float* g_smooth;      // [T][B][RNN_GAIN_LD]
-  float* vadbuf;        // [T][B]
   // persistent per-stream state (HBM)
   float* hp_mem;        // [B][2]
-  float* synth;         // [B][480] overlap-add tails, read at the start of a launch
-  float* synth_out;     // [B][480] ... written at its end (== synth except in the synthesis kernel: crispy_api.cpp)
+  float* synth;         // [B][480] overlap-add tails, read at the start of a launch and written at its end
   float* ceps;          // [B][8*22]
   float* lastg;         // [B][22]
   float* rnn;           // [B][168]
@@ -129,42 +117,8 @@ struct RnArgs {
   const uint32_t* wpack;
 };
 
-// ---- stream-batched MFMA gain network (rn_rnn_kernel.hip) ----
-constexpr int RNN_FEAT_LD = 48;   // features per (frame, stream), 42 used
-constexpr int RNN_GAIN_LD = 24;   // gains per (frame, stream), 22 used
-// B fragments (64 lanes x 8 bf16 = 1 KB each), ordered [phase][16-column tile][32-deep k step]
-struct RnnPack {
-  static constexpr int F_DENSE = 0;             //  2 tiles x 2 k steps   K = feat(42)
-  static constexpr int F_VZR = F_DENSE + 4;     //  3 x 2                 K = dense(24) | vad_state(24)
-  static constexpr int F_VH = F_VZR + 6;        //  2 x 2                 K = dense | h*r
-  static constexpr int F_VO = F_VH + 4;         //  1 x 1                 K = vad_state
-  static constexpr int F_NZR = F_VO + 1;        //  6 x 5                 K = dense | vad_state | feat | noise_state
-  static constexpr int F_NH = F_NZR + 30;       //  3 x 5
-  static constexpr int F_DZR = F_NH + 15;       // 12 x 7                 K = vad_state | noise_state | feat | den_state
-  static constexpr int F_DH = F_DZR + 84;       //  6 x 7
-  static constexpr int F_OUT = F_DH + 42;       //  2 x 3                 K = den_state
-  static constexpr int F_END = F_OUT + 6;       // 192 fragments
-  static constexpr int B_DENSE = 0, B_VG = 24, B_VO = 96, B_NG = 97, B_DG = 241, B_OUT = 529, B_END = 551;
-};
-struct RnnArgs {
-  const float* feat;            // [T][B][RNN_FEAT_LD]
-  const unsigned char* silent;  // [T][B] 1 = the frame took the E < 0.04 branch: state untouched, gains 0
-  float* g_raw;                 // [T][B][RNN_GAIN_LD] sigmoid outputs (what the comb filter uses)
-  float* g_smooth;              // [T][B][RNN_GAIN_LD] after g = max(g, 0.6 lastg)
-  float* vad;                   // [T][B] or null
-  int T, B;
-  float* rnn;                   // [B][168] GRU state (in/out)
-  float* lastg;                 // [B][22] (in/out)
-  const void* frags;            // RnnPack::F_END KB of bf16 fragments
-  const float* bias;            // RnnPack::B_END floats
-  const float* tansig;          // 208 floats
-};
-hipError_t rn_launch_rnn(const RnnArgs& a, hipStream_t s);
-
 hipError_t rn_launch_highpass(const RnArgs& a, hipStream_t s);
 hipError_t rn_launch_frames(const RnArgs& a, hipStream_t s);            // fused: analysis + gain network + synthesis
-hipError_t rn_launch_analysis(const RnArgs& a, hipStream_t s);          // staged: up to the 42 features
-hipError_t rn_launch_synthesis(const RnArgs& a, hipStream_t s);         // staged: comb filter, gains, inverse FFT, OLA
 hipError_t rn_launch_roll_history(const RnArgs& a, hipStream_t s);
 hipError_t rn_launch_tansig(const RnTables* tab, const float* x, float* y, long n, int sigmoid, hipStream_t s);
 

@@ -25,10 +25,6 @@ namespace crispy {
 namespace {
 
 constexpr int WAVE = 64;
-#ifndef RN_TAIL_REGS
-#define RN_TAIL_REGS 1   // 1: the fused kernel keeps the overlap-add tail in registers across frames
-#endif
-constexpr int RN_SYNTH_GROUP = 5;   // frames per synthesis workgroup (plus one warm-up frame)
 
 // In-kernel stage stamps (diagnostic build only: make PROFILE=1 -> libcrispy_hip_prof.so).
 #ifdef RN_PROFILE
@@ -153,7 +149,7 @@ __device__ __forceinline__ void butterfly<8>(const float2 (&v)[8], float2 (&o)[8
 // passes collide: a store is serviced in groups of 16 lanes over 32 banks, and `buf[4 j + r]` (radix 4, stride 1) puts
 // lanes j and j + 4, `buf[32 (j / 4) + (j % 4) + 4 r]` (radix 8, stride 4) all lanes with equal j % 4, on one bank
 // -- 4-way, 16 LDS cycles per store instead of 4.  Both hand-offs are private to two passes, so they use layouts
-// in which the store *and* the matching load are conflict-free (RN_FFT_SWIZZLE=0: natural order):
+// in which the store *and* the matching load are conflict-free:
 //   pass 1 -> 2: element i at (i % 4) * 120 + i / 4  (the store becomes r * 120 + j: consecutive lanes; the load of
 //                butterfly j reads (j % 4) * 120 + j / 4 + 15 r: four 16-bank windows 0 / 48 / 32 / 16 apart)
 //   pass 2 -> 3: element i = 32 a + 4 r + m at i ^ ((a & 3) << 2): the four a of a 16-lane group spread over the
@@ -163,32 +159,14 @@ __device__ __forceinline__ void butterfly<8>(const float2 (&v)[8], float2 (&o)[8
 // high-pass kernel at 32 (two float4 blocks of input in flight instead of eight; 12 B of prologue scratch).
 // amdgpu_num_vgpr counts the unified VGPR + AGPR file on gfx950, so the attribute wants half the number (120 / 32
 // given directly are silently ignored).  Measured: 7.71 -> 7.585 ms per 100-frame step.
-#ifndef RN_VGPR_CAP
 #define RN_VGPR_CAP __attribute__((amdgpu_num_vgpr(60)))
-#endif
-#ifndef RN_HP_BLK
-#define RN_HP_BLK 2
-#endif
-#ifndef RN_HP_VGPR_CAP
 #define RN_HP_VGPR_CAP __attribute__((amdgpu_num_vgpr(16)))
-#endif
-#ifndef RN_PRIO_SPREAD
-#define RN_PRIO_SPREAD 1
-#endif
-#ifndef RN_STAGGER_TICKS
-#define RN_STAGGER_TICKS 0
-#endif
-#ifndef RN_RD_PARALLEL
-#define RN_RD_PARALLEL 1
-#endif
-#ifndef RN_FFT_SWIZZLE
-#define RN_FFT_SWIZZLE 1
-#endif
+constexpr int RN_HP_BLK = 2;
 template <int R, int NS>
 __device__ __forceinline__ int fft_rd(int j, int r) {
   constexpr int M = 480 / R;
-  if (RN_FFT_SWIZZLE && R == 8 && NS == 4) return (j & 3) * 120 + (j >> 2) + 15 * r;
-  if (RN_FFT_SWIZZLE && R == 3 && NS == 32) {
+  if (R == 8 && NS == 4) return (j & 3) * 120 + (j >> 2) + 15 * r;
+  if (R == 3 && NS == 32) {
     const int i = j + r * M;
     return i ^ (((i >> 5) & 3) << 2);
   }
@@ -196,8 +174,8 @@ __device__ __forceinline__ int fft_rd(int j, int r) {
 }
 template <int R, int NS>
 __device__ __forceinline__ int fft_wr(int j, int r) {
-  if (RN_FFT_SWIZZLE && R == 4 && NS == 1) return r * 120 + j;
-  if (RN_FFT_SWIZZLE && R == 8 && NS == 4) {
+  if (R == 4 && NS == 1) return r * 120 + j;
+  if (R == 8 && NS == 4) {
     const int a = j >> 2, m = j & 3;
     return 32 * a + m + 4 * (r ^ (a & 3));
   }
@@ -352,19 +330,12 @@ __device__ __forceinline__ void real_inv_pre(float2* buf, const float2* __restri
   __syncthreads();
 }
 
-#ifndef RN_BAND_SPLIT
-#define RN_BAND_SPLIT 2      // 0: round 2 (lane == band, 48 steps); 1: two lanes per band (24 steps); 2: pieces of <= 6 chunks
-#endif
 // ---------------------------------------------------------------------------------------------
 // Opus-band helpers (Appendix A.3 step 2).  `part` is 200 floats of scratch; e0/e1/em1 are this
 // lane's band edges (band = lane) in 4-bin chunks, loaded once per kernel.
 // ---------------------------------------------------------------------------------------------
 struct BandEdges {
-#if RN_BAND_SPLIT == 2
   int piece;           // RnTables::band_piece[lane]
-#else
-  int em1, e0, e1;
-#endif
 };
 
 // Sum of one band's chunk partials: part_hi[c] for c in [em1, e0) -- the rising half of the previous interval -- plus
@@ -374,13 +345,9 @@ struct BandEdges {
 // stay INLINE (`n` is laundered): they are invariant across frames, and hoisted out of the frame loop the compiler
 // turned them into 48 lane masks = 96 SGPRs, spilled into two VGPRs' lanes and fetched back with two v_readlane per
 // use: 416 of the kernel's 7 800 VALU instructions per frame were those v_readlane (ISA census).
-// The partials are *read* RN_BAND_BATCH at a time (as plain `for (c = ...) sum += part[c]` loops every chunk was its own
+// The partials are *read* eight at a time (as plain `for (c = ...) sum += part[c]` loops every chunk was its own
 // LDS round trip); reads past a lane's range stay inside the workgroup's LDS and are replaced by 0.f.
-#ifndef RN_BAND_BATCH
-#define RN_BAND_BATCH 8
-#endif
 __device__ __forceinline__ float band_sum(const float* part_lo, const float* part_hi, const BandEdges& be, int lane) {
-#if RN_BAND_SPLIT == 2
   // Round 3, second form.  A band is up to 22 + 22 chunk partials but most are 1 - 4: with one or two lanes per band the
   // wave ran the longest band's 24 select-and-add steps (3 instructions and an LDS read each) for every band.  Here the 42
   // half-bands are cut into 56 pieces of <= 6 chunks, one per lane (RnTables::band_piece, built on the host): 6 steps, then
@@ -408,51 +375,6 @@ __device__ __forceinline__ float band_sum(const float* part_lo, const float* par
   float tot = rise + fall;                           // lanes >= RN_NB: band 0's value, never used
   if (lane == 0 || lane == RN_NB - 1) tot *= 2.f;
   return tot;
-#elif !RN_BAND_SPLIT
-  // round-2 form (A/B builds): lane == band adds both halves, 48 select-and-add steps
-  float s_old = 0.f;
-  const int n_hi = lane > 0 && lane < RN_NB ? be.e0 - be.em1 : 0;
-  const int n_lo = lane < RN_NB - 1 ? be.e1 - be.e0 : 0;
-  const float* ph = part_hi + be.em1;
-  const float* pl = part_lo + be.e0;
-#pragma unroll
-  for (int base = 0; base < 24; base += RN_BAND_BATCH) {
-    float v[RN_BAND_BATCH];
-#pragma unroll
-    for (int k = 0; k < RN_BAND_BATCH; ++k) v[k] = ph[base + k];
-#pragma unroll
-    for (int k = 0; k < RN_BAND_BATCH; ++k) s_old += base + k < n_hi ? v[k] : 0.f;
-  }
-#pragma unroll
-  for (int base = 0; base < 24; base += RN_BAND_BATCH) {
-    float v[RN_BAND_BATCH];
-#pragma unroll
-    for (int k = 0; k < RN_BAND_BATCH; ++k) v[k] = pl[base + k];
-#pragma unroll
-    for (int k = 0; k < RN_BAND_BATCH; ++k) s_old += base + k < n_lo ? v[k] : 0.f;
-  }
-  if (lane == 0 || lane == RN_NB - 1) s_old *= 2.f;
-  return s_old;
-#else
-  const int band = lane & 31;               // (be holds the edges of band min(lane & 31, RN_NB - 1))
-  const bool falling = lane >= 32;
-  int n = falling ? (band < RN_NB - 1 ? be.e1 - be.e0 : 0) : (band > 0 ? be.e0 - be.em1 : 0);
-  if (band >= RN_NB) n = 0;
-  asm volatile("" : "+v"(n));
-  const float* p = falling ? part_lo + be.e0 : part_hi + be.em1;
-  float sum = 0.f;
-#pragma unroll
-  for (int base = 0; base < 24; base += RN_BAND_BATCH) {
-    float v[RN_BAND_BATCH];
-#pragma unroll
-    for (int k = 0; k < RN_BAND_BATCH; ++k) v[k] = p[base + k];
-#pragma unroll
-    for (int k = 0; k < RN_BAND_BATCH; ++k) sum += base + k < n ? v[k] : 0.f;
-  }
-  sum += __shfl(sum, (lane + 32) & 63, WAVE);       // rising + falling half (lanes >= 32 receive garbage: never used)
-  if (lane == 0 || lane == RN_NB - 1) sum *= 2.f;
-  return sum;
-#endif
 }
 
 // Band energies in the pair layout of the comb-filter stage: lane handles bins (2p, 2p+1), p = lane + 64 m, with
@@ -568,235 +490,32 @@ __device__ __forceinline__ float sigmoid_approx(float x, const TansigTab& table)
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 // After the lane id has been laundered its range is unknown, every `table[lane + 64 k]` index is sign-extended and
 // the load takes a 64-bit VGPR address (ashr + 64-bit shift-add per load).  Stating the range lets the sign extension
-// fold away: SGPR base + 32-bit lane offset + immediate.  RN_LANE_RANGE_MASK selects the laundering sites it is
-// stated at (register allocation differs per site; the frame loop must stay free of spill stores).
-#ifndef RN_LANE_RANGE_MASK
-#define RN_LANE_RANGE_MASK 255
-#endif
-#define RN_LANE_RANGE(site) do { if ((RN_LANE_RANGE_MASK >> (site)) & 1) __builtin_assume((unsigned)lane < (unsigned)WAVE); } while (0)
-#ifndef RN_GRU_MFMA
-#define RN_GRU_MFMA 2   // 1: the gain network's matrix-vector products on v_mfma_f32_4x4x4_16B_f16; 2: on
-                        // v_mfma_i32_4x4x4_16B_i8 with int8 weights in memory (both below); 0: v_fma_mix_f32
-#endif
+// fold away: SGPR base + 32-bit lane offset + immediate.
+#define RN_LANE_RANGE(site) __builtin_assume((unsigned)lane < (unsigned)WAVE)
 // 16-byte weight loads per row in flight ahead of their use, for 3 / 2 / 1 rows per lane: the largest that keep
 // the frame loop free of spill stores (tests/test_build_resources.py)
-#ifndef RN_BLK3
-#define RN_BLK3 1
-#define RN_BLK2 (RN_GRU_MFMA == 2 ? 1 : 2)
-#define RN_BLK1 4
-#endif
+constexpr int RN_BLK3 = 1, RN_BLK2 = 1, RN_BLK1 = 4;
 
-// acc[r] += sum_k W[k][row[r]] * xa[k] + sum_k U[k][row[r]] * xb[k].  Weights: f16 [K8][rows][8] (16 bytes per lane
-// per 8 MACs, each MAC one v_fma_mix_f32); xa / xb live in LDS, 16-byte aligned, zero padded to 8*K8.
-//  * The weight stream comes from L2 (~0.6 us per dependent round trip at this occupancy), so the k-loop is fully
-//    unrolled over the concatenated [W | U] rows in blocks of 16-byte loads, with the next block issued before
-//    the current one is consumed (8 KB per wave in flight; 16 KB measured slower: spills).
-//  * Buffer loads: one resource descriptor for the whole pack (4 SGPRs), voffset = row*16 (one VGPR), the matrix /
-//    k-row offset as a scalar -- no per-load 64-bit vector address arithmetic.
-//  * sched_barrier pins the issue order (prefetch, then for every k-step: LDS reads of step k+1, FMAs of step k);
-//    left alone the scheduler hoists every load of a block to its top and spills.
-//  * Two accumulators: dependent v_fma_mix_f32 need a wait state in between.
 typedef unsigned int rn_u4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ h8 wload(__amdgpu_buffer_rsrc_t rs, int row16, int off_h8) {
-  return __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rs, row16, off_h8 * 16, 0));
-}
-// NR rows per lane (row[r], r < NR) share every activation read: the broadcast ds_read_b128 moves 1 KB through the
-// LDS return path for 16 bytes of information, so rows are batched against it.
-// Block sizes (RN_BLKn for n rows per lane) are the largest that keep the kernel out of scratch inside the frame
-// loop.  That is a correctness matter, not only speed: this compiler places VGPR spill stores of a join block
-// *before* the block's exec restore, so a value spilled right after a divergent region (e.g. `if (lane == 0)`) is
-// saved for the active lanes only and reloaded as garbage in the others.  tests/test_build_resources.py pins the
-// scratch size.
-template <int MK8, int NK8, int ROWS, int NR>
-__device__ __forceinline__ void dotn_h(__amdgpu_buffer_rsrc_t rs, int w_off, int u_off, const int (&row)[NR],
-                                       const float* xa, const float* xb, float (&acc)[NR]) {
-  constexpr int K8 = MK8 + NK8;
-  constexpr int BLK = NR >= 3 ? RN_BLK3 : (NR == 2 ? RN_BLK2 : RN_BLK1);
-  constexpr int NBLK = (K8 + BLK - 1) / BLK;
-  int row16[NR];
+// The one product that stays on the vector ALU: vad_output, 24 -> 1, on lane 0.  Its row of the f16 weight pack is
+// three 16-byte buffer loads (one resource descriptor for the whole pack, the k-row offset as an immediate); even k
+// into one accumulator, odd k into a second one (dependent v_fma_mix_f32 need a wait state in between).
+__device__ __forceinline__ float dot_vad(__amdgpu_buffer_rsrc_t rs, int w_off, const float* x, float acc0) {
+  float acc = acc0, acc1 = 0.f;
 #pragma unroll
-  for (int r = 0; r < NR; ++r) row16[r] = row[r] * 16;
-  // opaque per call: the activation reads are invariant across calls with the same vectors, and keeping them
-  // (up to 54 float4) in registers spills.  (An integer, so that the pointers stay LDS pointers.)
-  int xo = 0;
-  asm volatile("" : "+v"(xo));
-  const float4* xa4 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(xa) + xo);
-  const float4* xb4 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(xb) + xo);
-  h8 w[2][BLK][NR];
-  float4 xc0 = MK8 > 0 ? xa4[0] : xb4[0], xc1 = MK8 > 0 ? xa4[1] : xb4[1], xn0 = xc0, xn1 = xc1;
+  for (int k = 0; k < 3; ++k) {
+    const h8 w = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rs, 0, (w_off + k) * 16, 0));
 #pragma unroll
-  for (int q = 0; q < BLK; ++q)
-    if (q < K8) {
-#pragma unroll
-      for (int r = 0; r < NR; ++r)
-        w[0][q][r] = wload(rs, row16[r], q < MK8 ? w_off + q * ROWS : u_off + (q - MK8) * ROWS);
-    }
-  float acc1[NR];
-#pragma unroll
-  for (int r = 0; r < NR; ++r) acc1[r] = 0.f;
-#pragma unroll
-  for (int blk = 0; blk < NBLK; ++blk) {
-    if (blk + 1 < NBLK) {
-#pragma unroll
-      for (int q = 0; q < BLK; ++q) {
-        const int k = (blk + 1) * BLK + q;
-        if (k < K8) {
-#pragma unroll
-          for (int r = 0; r < NR; ++r)
-            w[(blk + 1) & 1][q][r] = wload(rs, row16[r], k < MK8 ? w_off + k * ROWS : u_off + (k - MK8) * ROWS);
-        }
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < BLK; ++q) {
-      const int k = blk * BLK + q;
-      if (k < K8) {
-        if (k + 1 < K8) {
-          xn0 = k + 1 < MK8 ? xa4[2 * (k + 1)] : xb4[2 * (k + 1 - MK8)];
-          xn1 = k + 1 < MK8 ? xa4[2 * (k + 1) + 1] : xb4[2 * (k + 1 - MK8) + 1];
-        }
-        // a side-effecting node the accumulators flow through: sched_barrier alone orders only the memory
-        // operations, the FMAs would all sink below the last load of the row
-#pragma unroll
-        for (int r = 0; r < NR; ++r) asm volatile("" : "+v"(acc[r]), "+v"(acc1[r]));
-        __builtin_amdgcn_sched_barrier(0);
-        const float xs[8] = {xc0.x, xc0.y, xc0.z, xc0.w, xc1.x, xc1.y, xc1.z, xc1.w};
-#pragma unroll
-        for (int e = 0; e < 8; e += 2) {
-#pragma unroll
-          for (int r = 0; r < NR; ++r) {
-            acc[r] = fmaf((float)w[blk & 1][q][r][e], xs[e], acc[r]);
-            acc1[r] = fmaf((float)w[blk & 1][q][r][e + 1], xs[e + 1], acc1[r]);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        xc0 = xn0;
-        xc1 = xn1;
-      }
+    for (int e = 0; e < 8; e += 2) {
+      acc = fmaf((float)w[e], x[8 * k + e], acc);
+      acc1 = fmaf((float)w[e + 1], x[8 * k + e + 1], acc1);
     }
   }
-#pragma unroll
-  for (int r = 0; r < NR; ++r) acc[r] += acc1[r];
-}
-template <int K8, int ROWS>
-__device__ __forceinline__ float dot_h(__amdgpu_buffer_rsrc_t rs, int w_off, int row, const float* x, float acc0) {
-  const int rows[1] = {row};
-  float acc[1] = {acc0};
-  dotn_h<K8, 0, ROWS, 1>(rs, w_off, w_off, rows, x, x, acc);
-  return acc[0];
-}
-
-// ---- the same products on the matrix pipe, still one wave per stream and lane = output row ----
-// v_mfma_f32_4x4x4_16B_f16 is 16 independent 4x4x4 blocks; block b lives in lanes 4b..4b+3.  Its "A" rows carry the
-// activation vector split into three f16 terms (x = hi + lo + lo2 exactly: 3 x 11 significand bits), the same in every
-// block; its "B" columns carry four consecutive-k f16 weights of row = lane -- the 16-byte weight loads of the VALU
-// form feed two MFMAs unchanged.  D[i][j] of block b lands in lane 4b+j, register i: the lane of row r ends up with
-// the three term sums of *its* row in its own registers (register 3 = whatever the clamped fourth A row produced,
-// ignored).  int8 x f16-term products are exact in f32, so only the summation order differs from the VALU form.
-// 256 MACs per 8-cycle MFMA against 64 per 4-cycle v_fma_mix_f32, and the VALU issue slots go to the other three
-// waves of the SIMD (tools/micro/mfma4x4_matvec.hip checks the layout and the rates).
-// Activation images: f16 [3 terms][RN_IMG_LD], a term stride of 272 bytes keeps the three 16-byte broadcast reads
-// of a wave on different banks.
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-typedef float rn_f4 __attribute__((ext_vector_type(4)));
-constexpr int RN_IMG_LD = 136;
-__device__ __forceinline__ void split_store(_Float16* img, int i, float v) {
-  const _Float16 hi = (_Float16)v;
-  const float r1 = v - (float)hi;
-  const _Float16 lo = (_Float16)r1;
-  const _Float16 lo2 = (_Float16)(r1 - (float)lo);
-  img[i] = hi;
-  img[RN_IMG_LD + i] = lo;
-  img[2 * RN_IMG_LD + i] = lo2;
-}
-// toff: this lane's term offset in bytes (min(lane & 3, 2) * RN_IMG_LD * 2), opaque to the optimiser
-template <int MK8, int NK8, int ROWS, int NR>
-__device__ __forceinline__ void dotn_m(__amdgpu_buffer_rsrc_t rs, int w_off, int u_off, const int (&row)[NR],
-                                       const _Float16* xa, const _Float16* xb, int toff, float (&acc)[NR]) {
-  constexpr int K8 = MK8 + NK8;
-  constexpr int BLK = NR >= 3 ? RN_BLK3 : (NR == 2 ? RN_BLK2 : RN_BLK1);
-  constexpr int NBLK = (K8 + BLK - 1) / BLK;
-  constexpr int NC = NR >= 3 ? 1 : 2;   // accumulator chains per row: a dependent MFMA waits two more cycles
-  int row16[NR];
-#pragma unroll
-  for (int r = 0; r < NR; ++r) row16[r] = row[r] * 16;
-  asm volatile("" : "+v"(toff));
-  const h8* xa8 = reinterpret_cast<const h8*>(reinterpret_cast<const char*>(xa) + toff);
-  const h8* xb8 = reinterpret_cast<const h8*>(reinterpret_cast<const char*>(xb) + toff);
-  h8 w[2][BLK][NR];
-  h8 xc = MK8 > 0 ? xa8[0] : xb8[0], xn = xc;
-#pragma unroll
-  for (int q = 0; q < BLK; ++q)
-    if (q < K8) {
-#pragma unroll
-      for (int r = 0; r < NR; ++r)
-        w[0][q][r] = wload(rs, row16[r], q < MK8 ? w_off + q * ROWS : u_off + (q - MK8) * ROWS);
-    }
-  rn_f4 a4[NR][NC];
-#pragma unroll
-  for (int r = 0; r < NR; ++r)
-#pragma unroll
-    for (int c = 0; c < NC; ++c) a4[r][c] = rn_f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int blk = 0; blk < NBLK; ++blk) {
-    if (blk + 1 < NBLK) {
-#pragma unroll
-      for (int q = 0; q < BLK; ++q) {
-        const int k = (blk + 1) * BLK + q;
-        if (k < K8) {
-#pragma unroll
-          for (int r = 0; r < NR; ++r)
-            w[(blk + 1) & 1][q][r] = wload(rs, row16[r], k < MK8 ? w_off + k * ROWS : u_off + (k - MK8) * ROWS);
-        }
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < BLK; ++q) {
-      const int k = blk * BLK + q;
-      if (k < K8) {
-        if (k + 1 < K8) xn = k + 1 < MK8 ? xa8[k + 1] : xb8[k + 1 - MK8];
-#pragma unroll
-        for (int r = 0; r < NR; ++r)
-#pragma unroll
-          for (int c = 0; c < NC; ++c) asm volatile("" : "+v"(a4[r][c]));
-        __builtin_amdgcn_sched_barrier(0);
-        const h4 x0 = {xc[0], xc[1], xc[2], xc[3]}, x1 = {xc[4], xc[5], xc[6], xc[7]};
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-          const h8 wv = w[blk & 1][q][r];
-          a4[r][0] = __builtin_amdgcn_mfma_f32_4x4x4f16(x0, h4{wv[0], wv[1], wv[2], wv[3]}, a4[r][0], 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-          const h8 wv = w[blk & 1][q][r];
-          a4[r][NC - 1] = __builtin_amdgcn_mfma_f32_4x4x4f16(x1, h4{wv[4], wv[5], wv[6], wv[7]}, a4[r][NC - 1], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        xc = xn;
-      }
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    float s = a4[r][0][0] + a4[r][0][1] + a4[r][0][2];
-    if (NC == 2) s += a4[r][1][0] + a4[r][1][1] + a4[r][1][2];
-    acc[r] += s;
-  }
-}
-template <int K8, int ROWS>
-__device__ __forceinline__ float dot_m(__amdgpu_buffer_rsrc_t rs, int w_off, int row, const _Float16* x, int toff,
-                                       float acc0) {
-  const int rows[1] = {row};
-  float acc[1] = {acc0};
-  dotn_m<K8, 0, ROWS, 1>(rs, w_off, w_off, rows, x, x, toff, acc);
-  return acc[0];
+  return acc + acc1;
 }
 
 // One GRU layer (ReLU candidate).  in_vec[M] and state[N] in LDS, zero padded to multiples of 8;
 // zbuf / hr: N floats of scratch each.  w_off / u_off: 16-byte offsets of the two matrices in the weight pack.
-// ---- int8 form (RN_GRU_MFMA == 2) ----
 // The stage is bound by the weight stream through the CU's vector L1 (16 waves x 176 KB of f16 per frame = 71 B per
 // clock against 64), not by arithmetic, so the weights stay int8 in memory (RnPack8: 16 MACs per 16-byte load) and
 // the activations become *fixed point*: per vector one power-of-two scale 2^s with max|x| 2^s <= 2^30, q = rint(x 2^s),
@@ -805,9 +524,6 @@ __device__ __forceinline__ float dot_m(__amdgpu_buffer_rsrc_t rs, int w_off, int
 // sum_t 256^t 2^-s (float)D_t is the dot product to 2^-30 of the largest activation -- finer than the rounding of an
 // f32 accumulation of the same length.  The input part and the recurrent part of a GRU row have different scales,
 // so the accumulators are folded into the float result where the k loop crosses from one to the other.
-#ifndef RN_ACC_CONST0
-#define RN_ACC_CONST0 1
-#endif
 typedef int rn_i4 __attribute__((ext_vector_type(4)));
 constexpr int RN_IMG8_LD = 144;   // bytes per digit image (K <= 128), +16: the four 16-byte reads hit distinct banks
 // Wave maximum of NON-NEGATIVE floats (magnitudes), as a maximum of their bit patterns: for values >= 0 the unsigned
@@ -937,7 +653,7 @@ __device__ __forceinline__ void dotn_i(__amdgpu_buffer_rsrc_t rs, int w_off, int
         if (MK16 > 0 && NK16 > 0 && k == MK16) fold(sa);
         // (not in front of the first block of a chain: its accumulators are still the constant 0, which the MFMA takes
         // as an inline operand -- laundering them there made the compiler zero 4 registers per accumulator first)
-        if (RN_ACC_CONST0 == 0 || !(k == 0 || (MK16 > 0 && NK16 > 0 && k == MK16))) {
+        if (!(k == 0 || (MK16 > 0 && NK16 > 0 && k == MK16))) {
 #pragma unroll
           for (int r = 0; r < NR; ++r)
 #pragma unroll
@@ -1021,117 +737,6 @@ __device__ __forceinline__ void gru_layer_i(__amdgpu_buffer_rsrc_t rs, int w_off
   __syncthreads();
 }
 
-// MFMA form: in_img holds the split image of the layer input (caller), st_img receives the split image of the
-// state (gates pass) and then of h*r (candidate pass); zbuf as in the VALU form.  Every lane runs every MFMA (the
-// matrix pipe ignores nothing a predicate could express: rows are clamped, results are predicated).
-template <int M, int N>
-__device__ __forceinline__ void gru_layer_m(__amdgpu_buffer_rsrc_t rs, int w_off, int u_off,
-                                            const float* __restrict__ bias, const _Float16* in_img,
-                                            float* state, float* zbuf, _Float16* st_img, int toff,
-                                            const TansigTab& tansig, int lane) {
-  constexpr int ROWS = 3 * N;
-  constexpr int MK8 = (M + 7) / 8, NK8 = (N + 7) / 8;
-  constexpr int NRZ = (2 * N + WAVE - 1) / WAVE, NRC = (N + WAVE - 1) / WAVE;
-  const float S = 1.f / 256.f;
-  for (int i = lane; i < NK8 * 8; i += WAVE) split_store(st_img, i, i < N ? state[i] : 0.f);
-  __syncthreads();
-  {
-    int rows[NRZ];
-    float acc[NRZ];
-#pragma unroll
-    for (int r = 0; r < NRZ; ++r) {
-      rows[r] = min(lane + WAVE * r, 2 * N - 1);
-      acc[r] = bias[rows[r]];
-    }
-    dotn_m<MK8, NK8, ROWS, NRZ>(rs, w_off, u_off, rows, in_img, st_img, toff, acc);
-#pragma unroll
-    for (int r = 0; r < NRZ; ++r) {
-      const int row = lane + WAVE * r;
-      const float s = sigmoid_approx(S * acc[r], tansig);
-      if (row < 2 * N) {
-        if (row < N) zbuf[row] = s;
-        else split_store(st_img, row - N, state[row - N] * s);
-      }
-    }
-  }
-  __syncthreads();
-  {
-    int rows[NRC];
-    float acc[NRC];
-#pragma unroll
-    for (int r = 0; r < NRC; ++r) {
-      rows[r] = 2 * N + min(lane + WAVE * r, N - 1);
-      acc[r] = bias[rows[r]];
-    }
-    dotn_m<MK8, NK8, ROWS, NRC>(rs, w_off, u_off, rows, in_img, st_img, toff, acc);
-#pragma unroll
-    for (int r = 0; r < NRC; ++r) {
-      const int i = lane + WAVE * r;
-      if (i < N) {
-        float c = S * acc[r];
-        c = c < 0.f ? 0.f : c;
-        const float z = zbuf[i];
-        state[i] = z * state[i] + (1.f - z) * c;
-      }
-    }
-  }
-  __syncthreads();
-}
-
-template <int M, int N>
-__device__ __forceinline__ void gru_layer(__amdgpu_buffer_rsrc_t rs, int w_off, int u_off,
-                                          const float* __restrict__ bias, const float* in_vec,
-                                          float* state, float* zbuf, float* hr,
-                                          const TansigTab& tansig, int lane) {
-  constexpr int ROWS = 3 * N;
-  constexpr int MK8 = (M + 7) / 8, NK8 = (N + 7) / 8;
-  constexpr int NRZ = (2 * N + WAVE - 1) / WAVE, NRC = (N + WAVE - 1) / WAVE;
-  const float S = 1.f / 256.f;
-  // update (z) and reset (r) gates: rows [0, 2N), all of them in one pass over the activations
-  {
-    int rows[NRZ];
-    float acc[NRZ];
-#pragma unroll
-    for (int r = 0; r < NRZ; ++r) {
-      rows[r] = min(lane + WAVE * r, 2 * N - 1);
-      acc[r] = bias[rows[r]];
-    }
-    dotn_h<MK8, NK8, ROWS, NRZ>(rs, w_off, u_off, rows, in_vec, state, acc);
-#pragma unroll
-    for (int r = 0; r < NRZ; ++r) {
-      const int row = lane + WAVE * r;
-      const float s = sigmoid_approx(S * acc[r], tansig);     // all lanes (table lookup by bpermute)
-      if (row < 2 * N) {
-        if (row < N) zbuf[row] = s;
-        else hr[row - N] = state[row - N] * s;
-      }
-    }
-  }
-  __syncthreads();
-  // candidate rows [2N, 3N): recurrent part sees h*r
-  {
-    int rows[NRC];
-    float acc[NRC];
-#pragma unroll
-    for (int r = 0; r < NRC; ++r) {
-      rows[r] = 2 * N + min(lane + WAVE * r, N - 1);
-      acc[r] = bias[rows[r]];
-    }
-    dotn_h<MK8, NK8, ROWS, NRC>(rs, w_off, u_off, rows, in_vec, hr, acc);
-#pragma unroll
-    for (int r = 0; r < NRC; ++r) {
-      const int i = lane + WAVE * r;
-      if (i < N) {
-        float c = S * acc[r];
-        c = c < 0.f ? 0.f : c;
-        const float z = zbuf[i];
-        state[i] = z * state[i] + (1.f - z) * c;
-      }
-    }
-  }
-  __syncthreads();
-}
-
 // ---------------------------------------------------------------------------------------------
 // LDS of one wave: 10 176 bytes, so that 16 waves (= 16 streams) are resident per CU.
 //   A   pitch phase: scratch (x4|y4, fine xcorr, yy_lookup)      then: analysis spectrum X / synthesis
@@ -1139,27 +744,16 @@ __device__ __forceinline__ void gru_layer(__amdgpu_buffer_rsrc_t rs, int w_off, 
 //       after its band sums), RNN vectors, band partial sums
 //   U   band partial sums while A and Bb both hold spectra | Ly, tmp22, g, r
 // ---------------------------------------------------------------------------------------------
-// The synthesis kernel (MODE 2) needs one spectrum buffer and 800 B of band scratch only: 5.7 KB, so up to
-// 28 of its (stream, frame-group) workgroups are resident per CU.
-template <int MODE>
-struct alignas(16) RnLdsT {
+struct alignas(16) RnLds {
   float2 A[482];
-  float2 Bb[MODE == 2 ? 100 : 482];
+  float2 Bb[482];
   float U[200];
-  float ceps[MODE == 2 ? 4 : 8 * 22];
-  float rnn_state[MODE == 2 ? 4 : 168];  // vad 24 | noise 48 | denoise 96
+  float ceps[8 * 22];
+  float rnn_state[168];  // vad 24 | noise 48 | denoise 96
   float Ex[24], Ep[24], Exp[24];
 };
-static_assert(sizeof(RnLdsT<0>) <= 10240, "16 workgroups per CU need <= 10 KB of LDS each");
+static_assert(sizeof(RnLds) <= 10240, "16 workgroups per CU need <= 10 KB of LDS each");
 
-// offsets (floats) inside Bb while it serves the RNN -- the staged kernels and the non-default forms of the in-wave
-// gain network (RN_GRU_MFMA 0 / 1), which park the pitch spectrum in global memory.  The default fused kernel keeps
-// P in Bb[0, 800) through the gain network and up to the comb filter instead (RN_P_LDS below).
-constexpr int RB_FEAT = 0, RB_DENSE = 48, RB_IN = 72, RB_Z = 192, RB_PART = 384;
-[[maybe_unused]] constexpr int RB_HR = 288;
-// RB_IMG: two split f16 activation images (3 terms x RN_IMG_LD halves each = 2 x 204 floats) of the MFMA gain
-// network; shares the floats of RB_PART, which is only used after the network
-constexpr int RB_IMG = 384;
 // offsets inside U outside band_sums (Ly is dead once the features exist: U[48, 192) is free for the gain network)
 constexpr int U_G = 0, U_R = 24, U_VAD = 46, U_LY = 48;
 // ---- pitch spectrum kept in LDS (fused kernel, int8 gain network) ----
@@ -1172,9 +766,6 @@ constexpr int U_G = 0, U_R = 24, U_VAD = 46, U_LY = 48;
 //   Bb[800, 842) features   Bb[842, 938) z gates   Bb[938, 962) dense layer
 //   A [800, 944) digit image of the recurrent operand (4 x 144 B), then the rising-half band partials of the comb filter
 //   U [ 48, 192) digit image of the layer input (4 x 144 B; Ly before it), then the falling-half band partials
-#ifndef RN_P_LDS
-#define RN_P_LDS 1
-#endif
 constexpr int PL_FEAT = 800, PL_Z = 842, PL_DENSE = 938, PL_A_FREE = 800, PL_U_FREE = 48;
 
 // top-2 bookkeeping of find_best_pitch as an ordering on (num, den, idx)
@@ -1206,49 +797,10 @@ __device__ __forceinline__ Cand wave_best(Cand c) {
 // offset, so every read is one ds_read_b32 with an immediate offset (64 m); the NL (or 2 NL) accumulation chains
 // and their DPP reductions are independent, which is what hides the LDS and cross-lane latencies -- the loops
 // these replace did one dependent wave reduction per lag.
-#ifndef RN_BATCHED_SUMS
-#define RN_BATCHED_SUMS 1
-#endif
-#ifndef RN_LAG_PAIRS
-#define RN_LAG_PAIRS 0   // measured, not kept: 88 fewer VALU instructions per frame (171 fewer copies) and 0.9 % SLOWER on the
-                         // same box (tools/ab_time.py, gpurun_out/r03l_ab.log): four dependent v_pk_fma_f32 per lag instead
-                         // of eight independent v_fmac -- after round 3's pass the kernel answers to its chains again
-#endif
 typedef float rn_f2 __attribute__((ext_vector_type(2)));
 template <int NL, bool SQ>
 __device__ __forceinline__ void lag_dots(const float* xr, const float* const (&yr)[NL], int lane, float (&sxy)[NL],
                                          float (&syy)[NL]) {
-#if RN_LAG_PAIRS
-  // Two consecutive 64-sample steps of ONE lag per packed instruction: the compiler fetches x[64 m], x[64 (m + 1)] and
-  // y_q[64 m], y_q[64 (m + 1)] with one ds_read2st64_b32 each, i.e. already as register pairs, so (x, x') * (y, y') +
-  // (acc, acc') is a v_pk_fma_f32 with no operand shuffling.  (Pairing two LAGS per instruction instead -- what the
-  // vectoriser made of the scalar loop -- needed one v_mov per product to re-pair the y registers: 186 of them per
-  // frame.)  The last step (j = 448 + lane) exists for lanes < 32 only: its y is zeroed elsewhere instead of a
-  // divergent tail block.  Even- and odd-step partial sums are added at the end.
-  rn_f2 xv[4];
-#pragma unroll
-  for (int m = 0; m < 4; ++m) xv[m] = rn_f2{xr[WAVE * 2 * m], xr[WAVE * (2 * m + 1)]};
-  const bool tail_ok = lane < 32;
-  xv[3].y = tail_ok ? xv[3].y : 0.f;      // both factors: what lies behind the window is stale LDS, possibly NaN (0 x NaN)
-  rn_f2 axy[NL], ayy[NL];
-#pragma unroll
-  for (int q = 0; q < NL; ++q) { axy[q] = rn_f2{0.f, 0.f}; ayy[q] = rn_f2{0.f, 0.f}; }
-#pragma unroll
-  for (int q = 0; q < NL; ++q) {
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      rn_f2 y = rn_f2{yr[q][WAVE * 2 * m], yr[q][WAVE * (2 * m + 1)]};
-      if (m == 3) y.y = tail_ok ? y.y : 0.f;
-      axy[q] = __builtin_elementwise_fma(xv[m], y, axy[q]);
-      if (SQ) ayy[q] = __builtin_elementwise_fma(y, y, ayy[q]);
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < NL; ++q) {
-    sxy[q] = axy[q].x + axy[q].y;
-    syy[q] = SQ ? ayy[q].x + ayy[q].y : 0.f;
-  }
-#else
   float xv[8];
 #pragma unroll
   for (int m = 0; m < 7; ++m) xv[m] = xr[WAVE * m];
@@ -1272,26 +824,15 @@ __device__ __forceinline__ void lag_dots(const float* xr, const float* const (&y
       if (SQ) syy[q] = fmaf(y, y, syy[q]);
     }
   }
-#endif
   // all NL (2 NL) totals reduced together: rn_wave_sums.h (four sums for ten VALU instructions instead of 4 x 12)
-#if RN_BATCHED_SUMS
   wave_sums<NL>(sxy);
   if (SQ) wave_sums<NL>(syy);
-#else
-#pragma unroll
-  for (int q = 0; q < NL; ++q) {
-    sxy[q] = wave_sum(sxy[q]);
-    if (SQ) syy[q] = wave_sum(syy[q]);
-  }
-#endif
 }
 
 // =============================================================================================
 // frame kernel: one wave per stream, loops over the T frames of the call
 // =============================================================================================
-// MODE 0: fused frame (analysis, in-wave gain network, synthesis).
-// MODE 1: analysis only -- stops after the 42 features and parks X, P, band energies for the synthesis kernel.
-// MODE 2: synthesis only -- gains come from the stream-batched MFMA gain network (rn_rnn_kernel.hip).
+// The fused frame: analysis, in-wave gain network, synthesis.
 // DBG: the per-stage debug capture of the last frame (crispy_rn_debug_capture) and the per-frame taps (features, gains,
 // pitch: parity tests) are a separate instantiation: the six
 // `a.dbg && t == a.T - 1` tests kept two more kernel arguments live across the frame loop, where the scalar registers
@@ -1304,45 +845,24 @@ __device__ __forceinline__ void lag_dots(const float* xr, const float* const (&y
   __syncthreads();
 }
 
-template <int MODE, bool DBG>
+template <bool DBG>
 __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VGPR_CAP void rn_frame_kernel(RnArgs a) {
-  __shared__ RnLdsT<MODE> L;
+  __shared__ RnLds L;
   const int lane0 = threadIdx.x;
   const int b = blockIdx.x;
   if (b >= a.B) return;
   int lane = lane0;
   const RnTables* tab = a.tab;
   const float* xs = a.xhp + (long)b * a.xhp_stride;
-#if RN_PRIO_SPREAD
   // Different issue priorities per wave slot, so that the four waves of a SIMD drift out of phase without anyone
-  // sleeping (0: off, 1: by wave slot, 2: by SIMD, 3: by slot + SIMD parity).  Measured over three alternating 30-step
-  // runs each: 1 -> 8.175 ms per step against 8.238 (-0.8 %), 2 and 3 -> no change.
-  if constexpr (MODE == 0) {
-    unsigned hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    const unsigned slot = hw & 3u, simd = (hw >> 4) & 3u;
-    const unsigned pr = RN_PRIO_SPREAD == 1 ? slot : (RN_PRIO_SPREAD == 2 ? simd : ((slot + simd) & 3u));
-    if (pr == 0) __builtin_amdgcn_s_setprio(0);
-    else if (pr == 1) __builtin_amdgcn_s_setprio(1);
-    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
-    else __builtin_amdgcn_s_setprio(3);
-  }
-#endif
-#if RN_STAGGER_TICKS > 0
-  // Experiment (off): the 16 waves of a CU run the same stages at the same time (they start together and execute the
-  // same instruction stream), so they want the vector L1 together in the gain network and the LDS together in the
-  // transforms.  A start offset per wave slot / SIMD de-phases them.  RN_STAGGER_TICKS: s_memtime ticks (10 ns)
-  // per step; the offset is (wave slot * 4 + SIMD) steps.  Measured: offsets up to 15 / 37 / 75 us cost +0.09 / +0.19 /
-  // +0.27 ms per 100-frame step where the idle tails of ten launches alone would cost 0.15 / 0.37 / 0.75 ms -- so
-  // de-phased waves do run ~6 % faster in steady state, but a launch of 12 frames is too short to pay for its tail.
-  if constexpr (MODE == 0) {
-    unsigned hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    const unsigned slot = hw & 15u, simd = (hw >> 4) & 3u;
-    const long long until = (long long)wall_clock64() + (long long)((slot & 3u) * 4u + simd) * RN_STAGGER_TICKS;
-    while ((long long)wall_clock64() < until) __builtin_amdgcn_s_sleep(32);
-  }
-#endif
+  // sleeping: -0.8 % per step over three alternating 30-step runs (by SIMD, or by slot + SIMD parity: no change).
+  unsigned hw;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  const unsigned pr = hw & 3u;
+  if (pr == 0) __builtin_amdgcn_s_setprio(0);
+  else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+  else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+  else __builtin_amdgcn_s_setprio(3);
 
 #if RN_POISON_LDS
   // Checker build (`make variants` -> libcrispy_hip_poison.so, tests/test_gpu_rnnoise.py): LDS is not cleared between
@@ -1353,35 +873,22 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
 #endif
 
   // ---- load per-stream state ----
-  if constexpr (MODE != 2) {
-    for (int i = lane; i < 176; i += WAVE) L.ceps[i] = a.ceps[(long)b * 176 + i];
-    for (int i = lane; i < 168; i += WAVE) L.rnn_state[i] = a.rnn[(long)b * 168 + i];
-  }
+  for (int i = lane; i < 176; i += WAVE) L.ceps[i] = a.ceps[(long)b * 176 + i];
+  for (int i = lane; i < 168; i += WAVE) L.rnn_state[i] = a.rnn[(long)b * 168 + i];
   // Overlap-add tail, samples (2n, 2n+1) for n = lane + 64 m.  The fused kernel keeps it in the state buffer
   // (L2) and touches it once per frame: eight VGPRs that would otherwise be live across the whole frame loop
   // are what pushed the kernel into scratch spills.  The synthesis kernel (low pressure) keeps it in registers.
   float2 synth[4];
   float* synth_g = a.synth + (long)b * 480;
-  // The analysis kernel (MODE 1) never touches the tail: no load here, no store at the end.
-  constexpr bool TAIL_REGS = MODE == 2 || (MODE == 0 && RN_TAIL_REGS);
-  if constexpr (TAIL_REGS) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int n = lane + WAVE * m;
-      synth[m] = (n < 240 && (MODE != 2 || blockIdx.y == 0)) ? *reinterpret_cast<const float2*>(synth_g + 2 * n) : make_float2(0.f, 0.f);
+      synth[m] = n < 240 ? *reinterpret_cast<const float2*>(synth_g + 2 * n) : make_float2(0.f, 0.f);
     }
-  }
   float lastg = lane < RN_NB ? a.lastg[(long)b * RN_NB + lane] : 0.f;
   BandEdges be;
   {
-#if RN_BAND_SPLIT == 2
     be.piece = tab->band_piece[lane0];
-#else
-    const int i = min(lane & 31, RN_NB - 1);       // lanes 32..53 work on the falling halves of bands 0..21 (band_sum)
-    be.e0 = tab->eband[i];
-    be.e1 = tab->eband[i + 1];
-    be.em1 = tab->eband[max(i - 1, 0)];
-#endif
   }
   int memid = a.memid[b];
   int last_period = a.last_period[b];
@@ -1391,22 +898,11 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
   float* lp = reinterpret_cast<float*>(L.Bb);  // 864 floats during the pitch phase
   float* Sa = reinterpret_cast<float*>(L.A);   // pitch-phase scratch
   float* Rb = reinterpret_cast<float*>(L.Bb);  // RNN vectors after the pitch spectrum is parked
-  constexpr bool P_LDS = MODE == 0 && RN_GRU_MFMA == 2 && RN_P_LDS;
-  constexpr int KB_FEAT = P_LDS ? PL_FEAT : RB_FEAT;
+  constexpr int KB_FEAT = PL_FEAT;
   float* Xf = reinterpret_cast<float*>(L.A);
 
-  // MODE 2 runs over (stream, group of RN_SYNTH_GROUP frames): synthesis has no cross-frame dependency except
-  // the overlap-add tail, which a group obtains by re-synthesising the frame before its first one (warm-up,
-  // nothing written).  5x more independent waves than streams hide the per-wave latency.
-  int t_first = 0, t_out = 0, t_last = a.T;
-  if constexpr (MODE == 2) {
-    t_out = blockIdx.y * RN_SYNTH_GROUP;
-    t_first = t_out > 0 ? t_out - 1 : 0;
-    t_last = min(a.T, t_out + RN_SYNTH_GROUP);
-    if (t_out >= a.T) return;
-  }
   RN_PROF_DECL
-  for (int t = t_first; t < t_last; ++t) {
+  for (int t = 0; t < a.T; ++t) {
     // Launder the lane id and the table / weight base pointers once per frame: every per-lane table
     // address is loop-invariant, and without this the compiler hoists ~250 of them out of the frame
     // loop into registers (429 VGPR+AGPR, one wave per SIMD).  Opaque values keep them per-frame.
@@ -1429,7 +925,6 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
     const float2* __restrict__ w960 = tab->w960;
     const float* __restrict__ hw = tab->half_window;
     const float* __restrict__ wpf = reinterpret_cast<const float*>(wpraw);
-    float2* pg = a.pspec + (MODE == 0 ? (long)b : (long)t * a.B + b) * 482;
     const float* xw = xs + (long)(t + 3) * RN_FRAME;  // [x_prev, x_cur]
     const float* pb = xs + (long)t * RN_FRAME + 672;  // 1728-sample pitch buffer ending at x_cur
 
@@ -1437,7 +932,6 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
     float pitch_gain = 0.f;
     bool silence = false;
     float vad_prob = 0.f;
-    if constexpr (MODE != 2) {
     // ---- 1. pitch: half-rate, LPC whitening (lp in Bb) ----
     {
       // all 14 x 2 window loads of a lane are requested before the first one is used (a `for (i = lane; ...)` loop
@@ -1476,12 +970,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
 #pragma unroll
         for (int k = 0; k <= 4; ++k) ac[k] = fmaf(w[q + 5], w[q + 5 - k], ac[k]);
       }
-#if RN_BATCHED_SUMS
       wave_sums<5>(ac);
-#else
-#pragma unroll
-      for (int k = 0; k <= 4; ++k) ac[k] = wave_sum(ac[k]);
-#endif
       ac[0] *= 1.0001f;
 #pragma unroll
       for (int k = 1; k <= 4; ++k) ac[k] -= ac[k] * (.008f * k) * (.008f * k);
@@ -1794,7 +1283,6 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
             if (k0 + q <= 15) { T1_[k0 + q - 2] = 0; xyk_[k0 + q - 2] = 0.f; yyk_[k0 + q - 2] = 0.f; }
         }
       }
-#if RN_RD_PARALLEL
       // The threshold test of candidate k depends on k, T0, g0 and the previous frame only, never on the running best,
       // and the reference's loop keeps the *last* k that passes: so lane k - 2 evaluates candidate k (one square root
       // and one division per lane instead of fourteen of each in every lane, one after the other) and the highest
@@ -1827,24 +1315,6 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
           g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g1), w));
         }
       }
-#else
-#pragma unroll
-      for (int k = 2; k <= 15; ++k) {
-        const int T1 = T1_[k - 2];
-        if (T1 >= 30) {       // (zero marks k past the reference's break)
-          const float xyk = xyk_[k - 2], yyk = yyk_[k - 2];
-          const float g1 = xyk / sqrtf(1.f + xx * yyk);
-          float cont;
-          if (abs(T1 - prev_period) <= 1) cont = last_gain;
-          else if (abs(T1 - prev_period) <= 2 && 5 * k * k < T0) cont = .5f * last_gain;
-          else cont = 0.f;
-          float thresh = fmaxf(.3f, .7f * g0 - cont);
-          if (T1 < 90) thresh = fmaxf(.4f, .85f * g0 - cont);
-          else if (T1 < 60) thresh = fmaxf(.5f, .9f * g0 - cont);
-          if (g1 > thresh) { best_xy = xyk; best_yy = yyk; T = T1; g = g1; }
-        }
-      }
-#endif
       best_xy = fmaxf(0.f, best_xy);
       float pgv = (best_yy <= best_xy) ? 1.f : best_xy / (best_yy + 1.f);
       float xc3[3];
@@ -1905,7 +1375,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
     STAMP(7)
     // band energy of P, band correlation with X, and P parked in L2 from the same registers (read back by the comb
     // filter, which needs bins < 400 only); Bb becomes the RNN workspace
-    band_pairs<true>(L.Bb, L.A, L.U, L.Ep, L.Exp, P_LDS ? nullptr : pg, tab, be, lane);
+    band_pairs<true>(L.Bb, L.A, L.U, L.Ep, L.Exp, nullptr, tab, be, lane);
     if (DBG && a.dbg && t == a.T - 1) {
       float* D = a.dbg + (long)b * RN_DBG_FLOATS;
       const float* Pf = reinterpret_cast<const float*>(L.Bb);
@@ -1930,7 +1400,6 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
       L.Exp[lane] = L.Exp[lane] / sqrtf(.001f + L.Ex[lane] * L.Ep[lane]);
       L.U[U_LY + lane] = log10f(1e-2f + L.Ex[lane]);
     }
-    if (!P_LDS && lane < 6) { Rb[RB_FEAT + 42 + lane] = 0.f; }
     __syncthreads();
     if (DBG && a.dbg && t == a.T - 1 && lane < RN_NB) {
       float* D = a.dbg + (long)b * RN_DBG_FLOATS;
@@ -2017,45 +1486,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
       __syncthreads();
       STAMP(9)
     }
-    }  // MODE != 2
 
-    if constexpr (MODE == 1) {
-      // ---- hand-off to the batched gain network and the synthesis kernel ----
-      const long fr = (long)t * a.B + b;
-      for (int i = lane; i < RN_NFREQ; i += WAVE) a.xspec[fr * 482 + i] = L.A[i];
-      if (lane < RNN_FEAT_LD) a.feat[fr * RNN_FEAT_LD + lane] = lane < RN_NFEAT ? Rb[KB_FEAT + lane] : 0.f;
-      float* rc = a.rec + fr * RN_REC_LD;
-      if (lane < RN_NB) { rc[lane] = L.Ex[lane]; rc[22 + lane] = L.Ep[lane]; rc[44 + lane] = L.Exp[lane]; }
-      if (lane == 0) {
-        rc[66] = (float)pitch_index;
-        rc[67] = pitch_gain;
-        a.silent[fr] = silence ? 1 : 0;
-      }
-      __syncthreads();
-      continue;
-    }
-    if constexpr (MODE == 2) {
-#if RN_POISON_LDS
-      // the synthesis kernel carries nothing from frame to frame in LDS (its groups start at arbitrary frames)
-      __syncthreads();
-      rn_poison_lds(reinterpret_cast<uint32_t*>(&L), sizeof(L) / 4);
-#endif
-      const long fr = (long)t * a.B + b;
-      const float* rc = a.rec + fr * RN_REC_LD;
-      for (int i = lane; i < RN_NFREQ; i += WAVE) L.A[i] = a.xspec[fr * 482 + i];
-      if (lane < RN_NB) {
-        L.Ex[lane] = rc[lane]; L.Ep[lane] = rc[22 + lane]; L.Exp[lane] = rc[44 + lane];
-        L.U[U_G + lane] = a.g_raw[fr * RNN_GAIN_LD + lane];
-      }
-      pitch_index = (int)rc[66];
-      pitch_gain = rc[67];
-      silence = a.silent[fr] != 0;
-      vad_prob = a.vadbuf[fr];
-      __syncthreads();
-    }
 
     if (!silence) {
-      if constexpr (MODE == 0) {
       lane = lane0;
       asm volatile("" : "+v"(lane));   // (lane re-laundered: per-lane addresses of later stages are otherwise computed early / shared with earlier
       RN_LANE_RANGE(1);
@@ -2063,15 +1496,13 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
       // ---- 8. RNN (vectors in Bb) ----
       const float S = 1.f / 256.f;
       float* feat = Rb + KB_FEAT;
-      float* dense = Rb + (P_LDS ? PL_DENSE : RB_DENSE);
-      [[maybe_unused]] float* zbuf = Rb + (P_LDS ? PL_Z : RB_Z);
-      [[maybe_unused]] float* gin = Rb + RB_IN;     // the f16 / VALU forms of the network (RN_GRU_MFMA 0, 1)
+      float* dense = Rb + PL_DENSE;
+      float* zbuf = Rb + PL_Z;
       TansigTab tansig;
       tansig.load(tab->tansig, lane);
-#if RN_GRU_MFMA == 2
       // signed-digit int8 images of the layer inputs (in_img) and of the recurrent operand (st_img)
-      signed char* in_img = reinterpret_cast<signed char*>(P_LDS ? L.U + PL_U_FREE : Rb + RB_IMG);
-      signed char* st_img = P_LDS ? reinterpret_cast<signed char*>(Xf + PL_A_FREE) : in_img + 4 * RN_IMG8_LD;
+      signed char* in_img = reinterpret_cast<signed char*>(L.U + PL_U_FREE);
+      signed char* st_img = reinterpret_cast<signed char*>(Xf + PL_A_FREE);
       const int toff = (lane & 3) * RN_IMG8_LD;
       RnScale sc = image_i8<48>(in_img, lane, [&](int i) { return i < RN_NFEAT ? feat[i] : 0.f; });
       __syncthreads();
@@ -2089,7 +1520,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
         float acc = 0.f;
         if (lane == 0) {
           acc = wpf[RnPack::VO_B];
-          acc = dot_h<rn_k8(24), 1>(wrs, RnPack::VO_W, 0, L.rnn_state, acc);
+          acc = dot_vad(wrs, RnPack::VO_W, L.rnn_state, acc);
         }
         const float v = sigmoid_approx(S * acc, tansig);
         if (lane == 0) L.U[U_VAD] = v;
@@ -2114,100 +1545,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
         const float gv = sigmoid_approx(S * acc, tansig);
         if (lane < RN_NB) L.U[U_G + lane] = gv;
       }
-#elif RN_GRU_MFMA == 1
-      // split f16 images of the layer inputs (in_img) and of the recurrent operand (st_img) behind the f32 vectors
-      _Float16* in_img = reinterpret_cast<_Float16*>(Rb + RB_IMG);
-      _Float16* st_img = in_img + 3 * RN_IMG_LD;
-      const int toff = min(lane & 3, 2) * (RN_IMG_LD * 2);
-      if (lane < 48) split_store(in_img, lane, feat[lane]);          // feat[42..47] = 0
-      __syncthreads();
-      {
-        const int row = min(lane, 23);
-        const float acc = dot_m<rn_k8(42), 24>(wrs, RnPack::ID_W, row, in_img, toff, wpf[RnPack::ID_B + row]);
-        const float d = tansig_approx(S * acc, tansig);
-        if (lane < 24) { dense[lane] = d; split_store(in_img, lane, d); }
-      }
-      __syncthreads();
-      gru_layer_m<24, 24>(wrs, RnPack::VG_W, RnPack::VG_R, wpf + RnPack::VG_B, in_img,
-                          L.rnn_state, Rb + RB_Z, st_img, toff, tansig, lane);
-      {
-        float acc = 0.f;
-        if (lane == 0) {
-          acc = wpf[RnPack::VO_B];
-          acc = dot_h<rn_k8(24), 1>(wrs, RnPack::VO_W, 0, L.rnn_state, acc);
-        }
-        const float v = sigmoid_approx(S * acc, tansig);
-        if (lane == 0) L.U[U_VAD] = v;
-      }
-      for (int i = lane; i < 96; i += WAVE)
-        split_store(in_img, i, i < 24 ? dense[i] : (i < 48 ? L.rnn_state[i - 24] : (i < 90 ? feat[i - 48] : 0.f)));
-      __syncthreads();
-      vad_prob = L.U[U_VAD];
-      STAMP(10)
-      gru_layer_m<90, 48>(wrs, RnPack::NG_W, RnPack::NG_R, wpf + RnPack::NG_B, in_img,
-                          L.rnn_state + 24, Rb + RB_Z, st_img, toff, tansig, lane);
-      STAMP(11)
-      for (int i = lane; i < 120; i += WAVE)
-        split_store(in_img, i, i < 72 ? L.rnn_state[i] : (i < 114 ? feat[i - 72] : 0.f));
-      __syncthreads();
-      gru_layer_m<114, 96>(wrs, RnPack::DG_W, RnPack::DG_R, wpf + RnPack::DG_B, in_img,
-                           L.rnn_state + 72, Rb + RB_Z, st_img, toff, tansig, lane);
-      for (int i = lane; i < 96; i += WAVE) split_store(st_img, i, L.rnn_state[72 + i]);
-      __syncthreads();
-      {
-        const int row = min(lane, RN_NB - 1);
-        const float acc = dot_m<rn_k8(96), RN_NB>(wrs, RnPack::DO_W, row, st_img, toff, wpf[RnPack::DO_B + row]);
-        const float gv = sigmoid_approx(S * acc, tansig);
-        if (lane < RN_NB) L.U[U_G + lane] = gv;
-      }
-#else
-      {
-        float acc = 0.f;
-        if (lane < 24) {
-          acc = wpf[RnPack::ID_B + lane];
-          acc = dot_h<rn_k8(42), 24>(wrs, RnPack::ID_W, lane, feat, acc);
-        }
-        const float d = tansig_approx(S * acc, tansig);
-        if (lane < 24) dense[lane] = d;
-      }
-      __syncthreads();
-      gru_layer<24, 24>(wrs, RnPack::VG_W, RnPack::VG_R, wpf + RnPack::VG_B, dense,
-                        L.rnn_state, Rb + RB_Z, Rb + RB_HR, tansig, lane);
-      {
-        float acc = 0.f;
-        if (lane == 0) {
-          acc = wpf[RnPack::VO_B];
-          acc = dot_h<rn_k8(24), 1>(wrs, RnPack::VO_W, 0, L.rnn_state, acc);
-        }
-        const float v = sigmoid_approx(S * acc, tansig);
-        if (lane == 0) L.U[U_VAD] = v;
-      }
-      for (int i = lane; i < 96; i += WAVE)
-        gin[i] = i < 24 ? dense[i] : (i < 48 ? L.rnn_state[i - 24] : (i < 90 ? feat[i - 48] : 0.f));
-      __syncthreads();
-      vad_prob = L.U[U_VAD];
-      STAMP(10)
-      gru_layer<90, 48>(wrs, RnPack::NG_W, RnPack::NG_R, wpf + RnPack::NG_B, gin,
-                        L.rnn_state + 24, Rb + RB_Z, Rb + RB_HR, tansig, lane);
-      STAMP(11)
-      for (int i = lane; i < 120; i += WAVE)
-        gin[i] = i < 72 ? L.rnn_state[i] : (i < 114 ? feat[i - 72] : 0.f);
-      __syncthreads();
-      gru_layer<114, 96>(wrs, RnPack::DG_W, RnPack::DG_R, wpf + RnPack::DG_B, gin,
-                         L.rnn_state + 72, Rb + RB_Z, Rb + RB_HR, tansig, lane);
-      {
-        float acc = 0.f;
-        if (lane < RN_NB) {
-          acc = wpf[RnPack::DO_B + lane];
-          acc = dot_h<rn_k8(96), RN_NB>(wrs, RnPack::DO_W, lane, L.rnn_state + 72, acc);
-        }
-        const float gv = sigmoid_approx(S * acc, tansig);
-        if (lane < RN_NB) L.U[U_G + lane] = gv;
-      }
-#endif
       __syncthreads();
       STAMP(12)
-      }  // MODE == 0
 
       lane = lane0;
       asm volatile("" : "+v"(lane));
@@ -2224,7 +1563,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
 #pragma unroll
         for (int m = 0; m < 4; ++m) {       // parked pitch spectrum and the per-bin tables: issued before r is ready
           const int pidx = min(lane + WAVE * m, 199);
-          pq[m] = P_LDS ? *reinterpret_cast<const float4*>(L.Bb + 2 * pidx) : *reinterpret_cast<const float4*>(pg + 2 * pidx);
+          pq[m] = *reinterpret_cast<const float4*>(L.Bb + 2 * pidx);
           fq[m] = *reinterpret_cast<const float2*>(tab->bin_frac + 2 * pidx);
           bq[m] = tab->bin_band[2 * pidx];
         }
@@ -2238,8 +1577,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
           L.U[U_R + lane] = r;
         }
         __syncthreads();
-        float* part = P_LDS ? Xf + PL_A_FREE : Rb + (MODE == 2 ? 0 : RB_PART);
-        float* part_hi = P_LDS ? L.U + PL_U_FREE : part + 100;
+        float* part = Xf + PL_A_FREE;
+        float* part_hi = L.U + PL_U_FREE;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           const int pidx = lane + WAVE * m;
@@ -2266,15 +1605,13 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
       __syncthreads();
       float sum;
       {                          // new band energies (Ep is dead): every lane takes part (band_sum splits a band over two lanes)
-        const float* part = P_LDS ? Xf + PL_A_FREE : Rb + (MODE == 2 ? 0 : RB_PART);
-        const float* part_hi = P_LDS ? L.U + PL_U_FREE : part + 100;
+        const float* part = Xf + PL_A_FREE;
+        const float* part_hi = L.U + PL_U_FREE;
         sum = band_sum(part, part_hi, be, lane);
       }
       if (lane < RN_NB) {        // the renormalisation and the smoothed gains
         L.U[U_R + lane] = sqrtf(L.Ex[lane] / (1e-8f + sum));  // norm
-        float gg;
-        if constexpr (MODE == 2) gg = a.g_smooth[((long)t * a.B + b) * RNN_GAIN_LD + lane];   // smoothing state lives in the gain-network kernel
-        else gg = fmaxf(L.U[U_G + lane], .6f * lastg);
+        const float gg = fmaxf(L.U[U_G + lane], .6f * lastg);
         L.U[U_G + lane] = gg;
         lastg = gg;
       }
@@ -2309,9 +1646,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
     STAMP(13)
 
     // ---- taps / debug ----
-    if (DBG && a.taps && t >= t_out) {
+    if (DBG && a.taps) {
       float* tp = a.taps + ((long)t * a.B + b) * RN_TAPS;
-      if (lane < RN_NFEAT) tp[lane] = MODE == 2 ? a.feat[((long)t * a.B + b) * RNN_FEAT_LD + lane] : Rb[MODE == 2 ? 0 : KB_FEAT + lane];
+      if (lane < RN_NFEAT) tp[lane] = Rb[KB_FEAT + lane];
       if (lane < RN_NB) tp[42 + lane] = L.U[U_G + lane];
       if (lane == 0) {
         tp[64] = (float)pitch_index;
@@ -2321,7 +1658,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
         tp[68] = tp[69] = tp[70] = tp[71] = 0.f;
       }
     }
-    if (a.vad && lane == 0 && t >= t_out) a.vad[(long)t * a.B + b] = vad_prob;
+    if (a.vad && lane == 0) a.vad[(long)t * a.B + b] = vad_prob;
     if (DBG && a.dbg && t == a.T - 1) {
       float* D = a.dbg + (long)b * RN_DBG_FLOATS;
       for (int i = lane; i < 962; i += WAVE) D[2862 + i] = Xf[i];
@@ -2333,14 +1670,6 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
     RN_LANE_RANGE(3);
     // ---- 10. frame_synthesis: inverse FFT, window, overlap-add ----
     real_inv_pre(L.A, w960, lane);
-    if constexpr (!TAIL_REGS && MODE != 1) {
-      // issued ahead of the inverse FFT, consumed after it
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int n = lane + WAVE * m;
-        synth[m] = n < 240 ? *reinterpret_cast<const float2*>(synth_g + 2 * n) : make_float2(0.f, 0.f);
-      }
-    }
     fft480(L.A, w960, lane);
     STAMP(14)
     {
@@ -2364,10 +1693,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
           ov.y = fmaf(-z.y, hwa[m].y, synth[m].y);
           // the output is never read back here: non-temporal stores keep it from allocating in L2 next to the history
           // window and the parked spectrum (-1.1 KB of fetches per stream-frame, time unchanged)
-          if (t >= t_out) { __builtin_nontemporal_store(ov.x, o + i0); __builtin_nontemporal_store(ov.y, o + i0 + 1); }
+          __builtin_nontemporal_store(ov.x, o + i0); __builtin_nontemporal_store(ov.y, o + i0 + 1);
           synth[m].x = z2.x * hwb[m].y;
           synth[m].y = -z2.y * hwb[m].x;
-          if constexpr (!TAIL_REGS) *reinterpret_cast<float2*>(synth_g + i0) = synth[m];
         }
       }
     }
@@ -2376,27 +1704,23 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
   }
 
   // ---- store per-stream state (each kernel of the staged pipeline owns its part) ----
-  if (TAIL_REGS && (MODE != 2 || t_last == a.T)) {
+  {
     // the synthesis kernel writes the OTHER tail buffer: group 0 of this launch may not have read this one yet
-    float* tail_out = MODE == 2 ? a.synth_out + (long)b * 480 : synth_g;
+    float* tail_out = synth_g;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int n = lane + WAVE * m;
       if (n < 240) *reinterpret_cast<float2*>(tail_out + 2 * n) = synth[m];
     }
   }
-  if constexpr (MODE != 2) {
-    for (int i = lane; i < 176; i += WAVE) a.ceps[(long)b * 176 + i] = L.ceps[i];
-    if (lane == 0) {
-      a.memid[b] = memid;
-      a.last_period[b] = last_period;
-      a.last_gain[b] = last_gain;
-    }
+  for (int i = lane; i < 176; i += WAVE) a.ceps[(long)b * 176 + i] = L.ceps[i];
+  if (lane == 0) {
+    a.memid[b] = memid;
+    a.last_period[b] = last_period;
+    a.last_gain[b] = last_gain;
   }
-  if constexpr (MODE == 0) {
-    for (int i = lane; i < 168; i += WAVE) a.rnn[(long)b * 168 + i] = L.rnn_state[i];
-    if (lane < RN_NB) a.lastg[(long)b * RN_NB + lane] = lastg;
-  }
+  for (int i = lane; i < 168; i += WAVE) a.rnn[(long)b * 168 + i] = L.rnn_state[i];
+  if (lane < RN_NB) a.lastg[(long)b * RN_NB + lane] = lastg;
 }
 
 // =============================================================================================
@@ -2497,18 +1821,8 @@ hipError_t rn_launch_highpass(const RnArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 hipError_t rn_launch_frames(const RnArgs& a, hipStream_t s) {
-  if (a.dbg || a.taps) hipLaunchKernelGGL((rn_frame_kernel<0, true>), dim3(a.B), dim3(WAVE), 0, s, a);
-  else hipLaunchKernelGGL((rn_frame_kernel<0, false>), dim3(a.B), dim3(WAVE), 0, s, a);
-  return hipGetLastError();
-}
-hipError_t rn_launch_analysis(const RnArgs& a, hipStream_t s) {
-  if (a.dbg || a.taps) hipLaunchKernelGGL((rn_frame_kernel<1, true>), dim3(a.B), dim3(WAVE), 0, s, a);
-  else hipLaunchKernelGGL((rn_frame_kernel<1, false>), dim3(a.B), dim3(WAVE), 0, s, a);
-  return hipGetLastError();
-}
-hipError_t rn_launch_synthesis(const RnArgs& a, hipStream_t s) {
-  if (a.dbg || a.taps) hipLaunchKernelGGL((rn_frame_kernel<2, true>), dim3(a.B, (a.T + RN_SYNTH_GROUP - 1) / RN_SYNTH_GROUP), dim3(WAVE), 0, s, a);
-  else hipLaunchKernelGGL((rn_frame_kernel<2, false>), dim3(a.B, (a.T + RN_SYNTH_GROUP - 1) / RN_SYNTH_GROUP), dim3(WAVE), 0, s, a);
+  if (a.dbg || a.taps) hipLaunchKernelGGL((rn_frame_kernel<true>), dim3(a.B), dim3(WAVE), 0, s, a);
+  else hipLaunchKernelGGL((rn_frame_kernel<false>), dim3(a.B), dim3(WAVE), 0, s, a);
   return hipGetLastError();
 }
 hipError_t rn_launch_tansig(const RnTables* tab, const float* x, float* y, long n, int sigmoid, hipStream_t s) {

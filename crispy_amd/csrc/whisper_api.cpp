@@ -2180,8 +2180,9 @@ int crispy_asr_transcribe(crispy_asr* h, const float* pcm16k, size_t n, const cr
 //   no_timestamps = 1: prompt [sot, lang, task, <|notimestamps|>], one window, plain greedy arg-max.
 //   no_timestamps = 0 (whisper.cpp's default, what TranscribeOptions::default() runs): whisper_full's seek loop
 //     [UPSTREAM-RECALL] -- windows of 30 s starting at `seek`, greedy picks under the timestamp rules, the window
-//     advances to the last closed timestamp pair, segments are cut at timestamp tokens.  Not reproduced: the
-//     temperature fallback (sampled re-decoding when the entropy / log-probability thresholds reject a window).
+//     advances to the last closed timestamp pair, segments are cut at timestamp tokens; per window the no-speech rule and
+//     the temperature ladder (best_of sampling decoders above temperature 0) decide what is kept.  Not reproduced: beam
+//     search at temperature 0.
 int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const size_t* n, int batch,
                                 const crispy_asr_opts* opts, crispy_asr_result** results) try {
   if (!h || !results) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: NULL argument");

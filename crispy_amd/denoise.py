@@ -111,18 +111,9 @@ class DenoiseState:
         N.check(self._L.crispy_rn_process_device(self._h, d_in, d_out, d_vad or None, d_taps or None,
                                                  int(n_frames), lay, stream or None), self._L)
 
-    def stage_rnn_device(self, d_feat: int, d_silent: int, d_g_raw: int, d_g_smooth: int, n_frames: int, d_vad: int = 0):
-        """The gain network alone on the matrix cores (stage entry point for parity tests)."""
-        N.check(self._L.crispy_rn_stage_rnn_device(self._h, d_feat, d_silent, d_g_raw, d_g_smooth, d_vad or None,
-                                                   int(n_frames), None), self._L)
-
     def stage_tansig_device(self, d_x: int, d_y: int, n: int, sigmoid: bool = False):
         """tansig_approx / sigmoid_approx as the frame kernel evaluates them (stage entry point for parity tests)."""
         N.check(self._L.crispy_rn_stage_tansig_device(self._h, d_x, d_y, int(n), int(sigmoid), None), self._L)
-
-    def set_pipeline(self, staged: bool):
-        """True: analysis -> batched MFMA gain network -> synthesis; False (default): single fused kernel."""
-        N.check(self._L.crispy_rn_set_pipeline(self._h, int(staged)), self._L)
 
     def synchronize(self):
         N.check(self._L.crispy_rn_synchronize(self._h), self._L)

@@ -105,13 +105,6 @@ int crispy_rn_frames_per_launch(void);
  * (94 MB of high-passed signal at 4096 streams: still in the Infinity Cache when the frame kernel reads it). */
 int crispy_rn_n_launches(int n_frames);
 
-/* Pipeline selection: 0 (default) runs the single fused frame kernel; staged != 0 (or the environment
- * variable CRISPY_RN_PIPELINE=staged at create time) runs every launch as analysis kernel -> gain network
- * batched over streams on the matrix cores (bf16 hi/lo/lo2 split, f32-exact) -> synthesis kernel over
- * (stream, frame group).  Same algorithm; outputs agree to f32 rounding, state is shared, so the mode may
- * be switched between calls. */
-int crispy_rn_set_pipeline(crispy_rn *h, int staged);
-
 /*
  * process_frame for every stream, n_frames consecutive frames each (audio.rs:268).
  * in/out are HOST pointers to n_frames*n_streams*480 floats in `layout`; samples are f32 in
@@ -156,15 +149,6 @@ int crispy_rn_synchronize(crispy_rn *h);
  */
 int crispy_rn_set_timing(crispy_rn *h, int enable);
 int crispy_rn_last_kernel_ms(crispy_rn *h, float *frame_kernel_ms, float *total_ms);
-
-/* Stage entry point (parity tests): the gain network alone -- dense + 3 GRUs + output layers of
- * process_frame, batched over the handle's streams on the matrix cores, for n_frames consecutive frames.
- * d_feat [n_frames][n_streams][48] (42 used), d_silent [n_frames][n_streams] (1 = frame took the
- * silence branch), outputs d_g_raw / d_g_smooth [n_frames][n_streams][24] (22 used), d_vad nullable.
- * Advances the handle's GRU state and gain-smoothing state. */
-int crispy_rn_stage_rnn_device(crispy_rn *h, const float *d_feat, const unsigned char *d_silent,
-                               float *d_g_raw, float *d_g_smooth, float *d_vad, int n_frames,
-                               void *hip_stream);
 
 /* Stage entry point (parity tests): the activation functions of the gain network exactly as the frame kernel
  * evaluates them (201-entry tanh table + interpolation, |x| >= 8 clamps; sigmoid != 0: 0.5 + 0.5 tansig(0.5 x)) on n

@@ -334,80 +334,12 @@ def test_sampled_oracle_parity_at_full_size(oracle, weights0):
     assert bad == 0, f"{bad}/{len(pick)} sampled streams out of tolerance"
 
 
-def test_batched_mfma_gain_network_matches_oracle(oracle, weights0):
-    """Stage entry point crispy_rn_stage_rnn_device (bf16 hi/lo/lo2 split on the matrix cores, 16 streams per
-    workgroup) against oracle rno_compute_rnn over 30 frames, incl. silent frames (state untouched, gains 0),
-    a stream count that is not a multiple of 16, and the g = max(g, 0.6 lastg) smoothing."""
-    import torch
-    B, T = 37, 30
-    rng = np.random.default_rng(5)
-    feat = (rng.standard_normal((T, B, 48)) * 2.0).astype(np.float32)
-    feat[:, :, 42:] = 0
-    silent = (rng.uniform(size=(T, B)) < 0.15).astype(np.uint8)
-    silent[:, 3] = 1                         # a stream that is silent throughout
-    ds = _mk(weights0, B)
-    dev = torch.device("cuda:0")
-    d_feat = torch.from_numpy(feat).to(dev)
-    d_sil = torch.from_numpy(silent).to(dev)
-    d_graw = torch.zeros(T, B, 24, device=dev)
-    d_gsm = torch.zeros(T, B, 24, device=dev)
-    d_vad = torch.zeros(T, B, device=dev)
-    torch.cuda.synchronize()
-    # two calls: the state carries over
-    ds.stage_rnn_device(d_feat.data_ptr(), d_sil.data_ptr(), d_graw.data_ptr(), d_gsm.data_ptr(), 11, d_vad.data_ptr())
-    ds.stage_rnn_device(d_feat[11:].contiguous().data_ptr(), d_sil[11:].contiguous().data_ptr(),
-                        d_graw[11:].data_ptr(), d_gsm[11:].data_ptr(), T - 11, d_vad[11:].data_ptr())
-    ds.synchronize()
-    graw, gsm, vad = d_graw.cpu().numpy(), d_gsm.cpu().numpy(), d_vad.cpu().numpy()
-    for b in range(B):
-        state = np.zeros(168, np.float32)
-        lastg = np.zeros(22, np.float32)
-        for t in range(T):
-            if silent[t, b]:
-                assert np.all(graw[t, b] == 0) and np.all(gsm[t, b] == 0) and vad[t, b] == 0
-                continue
-            g = np.empty(22, np.float32)
-            v = np.empty(1, np.float32)
-            f = np.ascontiguousarray(feat[t, b, :42])
-            oracle.lib().rno_compute_rnn(weights0.ctypes.data, oracle.fp(state), oracle.fp(g), oracle.fp(v), oracle.fp(f))
-            gs = np.maximum(g, np.float32(0.6) * lastg)
-            lastg = gs
-            assert np.abs(graw[t, b, :22] - g).max() < 2e-5, (b, t)
-            assert np.abs(gsm[t, b, :22] - gs).max() < 2e-5
-            assert abs(vad[t, b] - v[0]) < 2e-5
-
-
-def test_staged_and_fused_pipelines_agree(oracle, weights0):
-    """The staged pipeline (analysis -> MFMA gain network -> synthesis) and the single fused kernel are the same
-    algorithm: both within tolerance of the oracle, within 1e-5 of each other, and switchable mid-stream."""
-    from crispy_amd import synth_audio as SA
-    B, T = 20, 60
-    x = SA.batch_np(B, T) * np.float32(32768.0)
-    a = _mk(weights0, B); a.set_pipeline(True)
-    f = _mk(weights0, B); f.set_pipeline(False)
-    oa, va = a.process(x)
-    of, vf = f.process(x)
-    peak = np.abs(of).max()
-    assert np.abs(oa - of).max() <= 1e-5 * peak and np.abs(va - vf).max() < 1e-5
-    for b in (0, 7, 9, 19):
-        ro, rv = oracle.OracleDenoiseState(weights0).process(x[:, b])
-        _assert_pcm_close(oa[:, b], ro, f"staged {b}")
-        _assert_pcm_close(of[:, b], ro, f"fused {b}")
-    m = _mk(weights0, B)
-    parts = []
-    for i, (t0, t1) in enumerate(((0, 13), (13, 40), (40, 60))):
-        m.set_pipeline(i % 2 == 0)
-        parts.append(m.process(np.ascontiguousarray(x[t0:t1]))[0])
-    assert np.abs(np.concatenate(parts) - of).max() <= 1e-5 * peak
-
-
-@pytest.mark.parametrize("staged", [False, True])
-def test_no_kernel_reads_lds_it_has_not_written(oracle, weights0, staged):
+def test_no_kernel_reads_lds_it_has_not_written(oracle, weights0):
     """LDS is not cleared between workgroups: a kernel that reads a word before writing it sees what the previous kernel
-    on that CU left behind, and is right or wrong depending on the history of the process (round 3: the staged pipeline
-    failed in one pytest process out of three, never alone).  libcrispy_hip_poison.so (`make variants`, RN_POISON_LDS) is
-    the same code with every RNNoise kernel filling its LDS allocation with NaNs first -- and the synthesis kernel again
-    before every frame: both pipelines must still match the oracle, with taps (the DBG instantiations) and without."""
+    on that CU left behind, and is right or wrong depending on the history of the process (round 3: a since-retired
+    pipeline failed in one pytest process out of three, never alone).  libcrispy_hip_poison.so (`make variants`,
+    RN_POISON_LDS) is the same code with every RNNoise kernel filling its LDS allocation with NaNs first: it must still
+    match the oracle, with taps (the DBG instantiation) and without."""
     import torch
     from crispy_amd import _native as N
     from crispy_amd import synth_audio as SA
@@ -417,7 +349,6 @@ def test_no_kernel_reads_lds_it_has_not_written(oracle, weights0, staged):
     x = SA.batch_np(B, T, first_stream=300) * np.float32(32768.0)
     x[20:, 4] = 0.0                                    # one stream falls silent (the silence path skips most stages)
     ds = DenoiseState(weights0, B, 0, lib=L)
-    ds.set_pipeline(staged)
     o1, v1 = ds.process(x)
     assert np.isfinite(o1).all() and np.isfinite(v1).all(), "NaN: some kernel read LDS it had not written"
     dev = torch.device("cuda:0")
@@ -427,38 +358,35 @@ def test_no_kernel_reads_lds_it_has_not_written(oracle, weights0, staged):
     d_taps = torch.zeros(T, B, 72, device=dev)
     torch.cuda.synchronize()
     dt = DenoiseState(weights0, B, 0, lib=L)
-    dt.set_pipeline(staged)
     dt.process_device(d_in.data_ptr(), d_out.data_ptr(), T, d_vad.data_ptr(), d_taps.data_ptr())
     dt.synchronize()
     o2, taps = d_out.cpu().numpy(), d_taps.cpu().numpy()
     assert np.isfinite(o2).all() and np.isfinite(taps).all(), "NaN with taps: some kernel read LDS it had not written"
     for b in range(B):
         ro, rv = oracle.OracleDenoiseState(weights0).process(x[:, b])
-        _assert_pcm_close(o1[:, b], ro, f"poisoned LDS, staged={staged}, stream {b}")
-        _assert_pcm_close(o2[:, b], ro, f"poisoned LDS with taps, staged={staged}, stream {b}")
+        _assert_pcm_close(o1[:, b], ro, f"poisoned LDS, stream {b}")
+        _assert_pcm_close(o2[:, b], ro, f"poisoned LDS with taps, stream {b}")
         assert np.abs(v1[:, b] - rv).max() < 1e-4
 
 
-@pytest.mark.parametrize("staged", [False, True])
-def test_long_run_no_drift(oracle, weights0, staged):
+def test_long_run_no_drift(oracle, weights0):
     """10 s of audio (1000 frames, 40 launches, 4 internal 250-frame segments): recurrent state (GRUs, pitch
     continuity, cepstral ring, OLA) must not drift away from the oracle; checked on the LAST second."""
     from crispy_amd import synth_audio as SA
     B, T = 6, 1000
     x = SA.batch_np(B, T, first_stream=40) * np.float32(32768.0)
     ds = _mk(weights0, B)
-    ds.set_pipeline(staged)
     out, vad = ds.process(x)
     for b in range(B):
         ro, rv = oracle.OracleDenoiseState(weights0).process(x[:, b])
         peak = max(np.abs(ro).max(), 1.0)
         tail_err = np.abs(out[900:, b] - ro[900:]).max() / peak
-        if tail_err > 1e-4:      # where did it leave the oracle?  (one un-reproduced failure of the staged form in round 3)
+        if tail_err > 1e-4:      # where did it leave the oracle?
             e = np.abs(out[:, b] - ro).max(axis=1) / peak
             bad = np.flatnonzero(e > 1e-4)
             w = int(e.argmax())
             es = np.flatnonzero(np.abs(out[w, b] - ro[w]) / peak > 1e-4)
-            pytest.fail(f"stream {b} ({'staged' if staged else 'fused'}): tail error {tail_err:.3e}; frames above 1e-4: "
+            pytest.fail(f"stream {b}: tail error {tail_err:.3e}; frames above 1e-4: "
                         f"{bad[:24].tolist()} ({bad.size} of {T}), worst {e.max():.3e} at frame {w}, samples {es.min()}..{es.max()} ({es.size}) of it; "
                         f"vad error there {abs(float(vad[int(e.argmax()), b] - rv[int(e.argmax())])):.2e}")
         assert np.abs(vad[900:, b] - rv[900:]).max() < 1e-4
@@ -518,49 +446,28 @@ def test_capture_callback_glue_with_the_denoiser(oracle, weights0):
     assert abs(cb.rms() - float(np.sqrt(np.mean(x.astype(np.float64) ** 2)))) < 1e-5
 
 
-# ---- parity hardening: weight extremes through every form of the gain network ----------------------
+# ---- parity hardening: weight extremes through the gain network -------------------------------------
 XGOLD = os.path.join(os.path.dirname(__file__), "golden", "rnnoise_extreme_golden.npz")
-_VARIANTS = {}
 
 
-def _variant(name):
-    """None = the shipped library (int8 MFMA gain network); 'gru0' / 'gru1' = the v_fma_mix_f32 / f16-MFMA builds of the
-    same sources (`make variants`, built by __graft_entry__.build()); 'staged' = shipped library, staged pipeline
-    (bf16 3-way-split MFMA gain network batched over streams)."""
-    from crispy_amd import _native as N
-    if name in (None, "staged"):
-        return None
-    if name not in _VARIANTS:
-        _VARIANTS[name] = N.load_variant(name)
-    return _VARIANTS[name]
-
-
-@pytest.mark.parametrize("form", ["fused_i8", "staged", "gru0", "gru1"])
 @pytest.mark.parametrize("kind", ["pos127", "neg127", "alt127", "zero", "bias_pos127", "bias_neg127", "heavy_tail",
                                   "row_saturating"])
-def test_weight_extremes_every_gain_network_form(oracle, kind, form):
+def test_weight_extremes_through_the_gain_network(oracle, kind):
     """All-+127, all--127, alternating +-127, zero, saturated biases, a heavy-tailed trained-like draw and rows that
-    pin gates at the +-8 clamp: PCM, gains and VAD of every form of the gain network (int8-MFMA fixed point, f16
-    MFMA, v_fma_mix_f32, stream-batched bf16 MFMA) against the oracle -- 40 frames live, and the committed 12-frame
-    golden vectors."""
+    pin gates at the +-8 clamp: PCM, gains and VAD of the gain network (int8 weights on v_mfma_i32_4x4x4_16B_i8, the
+    activations as per-vector power-of-two fixed point) against the oracle -- 40 frames live, and the committed 12-frame
+    golden vectors.  (Rounds 1 - 3 kept three more forms of the network alive beside this one -- v_fma_mix_f32, f16 MFMA,
+    a stream-batched bf16 MFMA kernel -- and ran them through these cases too; the f16 form overflowed on
+    `row_saturating`, which is why the shipped form scales every vector.  They were retired in round 4.)"""
     from crispy_amd import rnn_weights as RW
     from crispy_amd.denoise import DenoiseState
-    from tests.golden.make_rnnoise_extreme_golden import inputs
     import torch
-    if (kind, form) == ("row_saturating", "gru1"):
-        # A finding of this very test: the f16-MFMA form (RN_GRU_MFMA=1, a non-default build kept for A/B timing) splits
-        # activations into three f16 terms, and f16 overflows above 65504 -- with these weights the ReLU GRU state passes
-        # 1.3e5 in frame 11.  The shipped int8 fixed-point form scales every vector by a power of two and the
-        # stream-batched form splits into bf16 (f32's exponent range); both pass this case.
-        pytest.xfail("RN_GRU_MFMA=1 (f16 split) overflows for |activation| > 65504; non-default build")
     w = RW.extreme_weights(kind)
-    L = _variant(None if form == "fused_i8" else form)
     G = np.load(XGOLD)
     # (1) golden vectors, one stream per input
     names = ("tone", "loud")
     xg = np.stack([G[f"x/{n}"] for n in names], axis=1)                  # [12, 2, 480]
-    ds = DenoiseState(w, 2, 0, lib=L)
-    ds.set_pipeline(form == "staged")
+    ds = DenoiseState(w, 2, 0)
     dev = torch.device("cuda:0")
     d_in = torch.from_numpy(xg).to(dev)
     d_out = torch.empty_like(d_in)
@@ -571,7 +478,7 @@ def test_weight_extremes_every_gain_network_form(oracle, kind, form):
     ds.synchronize()
     out, vad, taps = d_out.cpu().numpy(), d_vad.cpu().numpy(), d_taps.cpu().numpy()
     for i, n in enumerate(names):
-        _assert_pcm_close(out[:, i], G[f"{kind}/{n}/out"], f"{kind}/{form}/{n} golden")
+        _assert_pcm_close(out[:, i], G[f"{kind}/{n}/out"], f"{kind}/{n} golden")
         assert np.abs(vad[:, i] - G[f"{kind}/{n}/vad"]).max() < 1e-4
         assert np.abs(taps[:, i, 42:64] - G[f"{kind}/{n}/gains"]).max() < 1e-4
     # (2) 40 frames live against the oracle, 5 different streams (incl. one that goes silent half way)
@@ -579,14 +486,13 @@ def test_weight_extremes_every_gain_network_form(oracle, kind, form):
     T, B = 40, 5
     x = SA.batch_np(B, T, first_stream=200) * np.float32(32768.0)
     x[T // 2:, 3] = 0.0
-    ds = DenoiseState(w, B, 0, lib=L)
-    ds.set_pipeline(form == "staged")
+    ds = DenoiseState(w, B, 0)
     o2, v2 = ds.process(x)
     assert np.isfinite(o2).all()
     for b in range(B):
         ro, rv = oracle.OracleDenoiseState(w).process(x[:, b])
-        _assert_pcm_close(o2[:, b], ro, f"{kind}/{form} stream {b}")
-        assert np.abs(v2[:, b] - rv).max() < 1e-4, (kind, form, b)
+        _assert_pcm_close(o2[:, b], ro, f"{kind} stream {b}")
+        assert np.abs(v2[:, b] - rv).max() < 1e-4, (kind, b)
 
 
 def test_tansig_and_sigmoid_every_table_cell_and_both_clamps(oracle, weights0):
