@@ -29,7 +29,56 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BYTES_PER_STREAM_FRAME = 3840  # 480 f32 in + 480 f32 out
+FLOPS_PER_STREAM_FRAME = 0.45e6  # gain network 175 k + three 960-point transforms 75 k + pitch 120 k + bands / DCT / filters 80 k
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: fp32 vector, 256 CUs x 256 flop / clock x 2.4 GHz
+
+
+class _ClockSampler:
+    """Shader clock of the GPU while a loop runs, read from sysfs by a side thread every 0.2 s (never from inside the
+    loop): /sys/class/drm/card*/device/pp_dpm_sclk marks the current level with '*'.  None where the file is missing."""
+
+    def __init__(self, local_rank: int = 0):
+        import glob
+        self.paths = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        self.path = self.paths[min(local_rank, len(self.paths) - 1)] if self.paths else None
+        self.samples = []
+        self._stop = False
+        self._th = None
+
+    def _read(self):
+        import re
+        try:
+            with open(self.path) as f:
+                for ln in f:
+                    if "*" in ln:
+                        m = re.search(r"(\d+)\s*[Mm][Hh]z", ln)
+                        if m:
+                            return int(m.group(1))
+        except OSError:
+            pass
+        return None
+
+    def __enter__(self):
+        import threading
+        if self.path:
+            def loop():
+                while not self._stop:
+                    v = self._read()
+                    if v:
+                        self.samples.append(v)
+                    time.sleep(0.2)
+            self._th = threading.Thread(target=loop, daemon=True)
+            self._th.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop = True
+        if self._th:
+            self._th.join()
+
+    def mean(self):
+        return sum(self.samples) / len(self.samples) if self.samples else None
 
 
 def _host_threads() -> int:
@@ -486,10 +535,12 @@ def dry_run(args):
 
 def cfg5(args):
     _numa = _bind_numa(_dist_env()[1], _dist_env()[2])      # before torch / HIP are touched
-    return _cfg5(args, _numa)
+    line = _cfg5(args, _numa)
+    if line is not None:
+        print(json.dumps(line), flush=True)
 
 
-def _cfg5(args, numa):
+def _cfg5(args, numa, in_process=False):
     """BASELINE configs[4]: Whisper-base full transcribe, 8192 streams sharded across 8 GPUs = 1024 x 30 s clips per
     GPU (static shard by stream id, no data-path collective).  One step = one sub-batch of `--clips` clips resident
     in HBM: log-mel -> encoder -> greedy decode of `--new-tokens` tokens (random-init weights never emit EOT, so the
@@ -498,7 +549,8 @@ def _cfg5(args, numa):
     import torch
 
     rank, local_rank, world = _dist_env()
-    dist, world_reported = _init_dist("nccl", local_rank, world)
+    # in_process: a leg of the headline run (cfg2) -- one rank, no process group of its own
+    dist, world_reported = (None, 1) if in_process else _init_dist("nccl", local_rank, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     from crispy_amd.asr import LogMel, WhisperModel
@@ -565,7 +617,7 @@ def _cfg5(args, numa):
         enc_flops = 87.4e9 * SUB * args.steps                     # Whisper-base encoder per 30 s clip
         peak = 157.3 if args.precision == 0 else 2500.0
         ach = enc_flops / stage["encoder"] / 1e12
-        print(json.dumps({
+        line = {
             "metric": "Whisper-base full transcribe RTFx (seconds of audio per wall second, whole job)",
             "value": clips_total * 30.0 / dt, "unit": "x real time (whole job)",
             "n_gpus": world_reported, "steps": args.steps, "warmup": max(1, args.warmup),
@@ -585,9 +637,14 @@ def _cfg5(args, numa):
                          "traffic": None, "kernel": "encoder GEMMs + attention (87.4 GFLOP per clip)",
                          "note": "encoder wall time of rank 0 incl. launch gaps; peak = dense "
                                  + ("f32-input MFMA" if args.precision == 0 else "f16 MFMA")},
-        }), flush=True)
+        }
+    else:
+        line = None
+    model.close()
+    lm.close()
     if dist:
         dist.destroy_process_group()
+    return line
 
 
 def cfg4(args):
@@ -603,12 +660,19 @@ def cfg4(args):
     stage split is printed beside it."""
     rank, local_rank, world = _dist_env()
     numa = _bind_numa(local_rank, world)
+    line = _cfg4(args, numa)
+    if line is not None:
+        print(json.dumps(line), flush=True)
+
+
+def _cfg4(args, numa, in_process=False):
+    rank, local_rank, world = _dist_env()
     import threading
 
     import numpy as np
     import torch
 
-    dist, world_reported = _init_dist("nccl", local_rank, world)
+    dist, world_reported = (None, 1) if in_process else _init_dist("nccl", local_rank, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     from crispy_amd import synth_audio
@@ -667,7 +731,7 @@ def cfg4(args):
     dt, streams_total = reduce_job_stats(dt, B * args.steps, device=dev)
     if rank == 0:
         audio_s = streams_total * 30.0
-        print(json.dumps({
+        line = {
             "metric": "end-to-end denoise -> Whisper-tiny greedy decode RTFx (seconds of 48 kHz audio per wall second, whole job)",
             "value": audio_s / dt, "unit": "x real time (whole job)", "n_gpus": world_reported, "steps": args.steps,
             "warmup": max(1, args.warmup), "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -684,9 +748,15 @@ def cfg4(args):
                          "frac": encoder_flops(hp) * streams_total / dt / 1e12 / (157.3 if args.precision == 0 else 2500.0),
                          "traffic": None, "kernel": "Whisper encoder GEMMs + attention, priced against the WHOLE step "
                                                     "(RNNoise, resampler, log-mel and the decoder included in the time)"},
-        }), flush=True)
+        }
+    else:
+        line = None
+    for p in pipes:
+        p.close()
+        p.whisper.close()
     if dist:
         dist.destroy_process_group()
+    return line
 
 
 def main():
@@ -721,6 +791,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-asr", action="store_true", help="skip the Whisper-tiny leg of the metric")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-stream process_frame latency leg")
+    ap.add_argument("--no-cfg45", action="store_true", help="cfg2: skip the in-process cfg4 / cfg5 legs")
+    ap.add_argument("--sustain-seconds", type=float, default=5.0,
+                    help="cfg2: length of the sustained-rate loop behind the timed steps (0 = off)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not run the two rocprofv3 --pmc passes; roofline.traffic then comes from profiles/")
@@ -843,6 +916,23 @@ def cfg2(args):
         ds.synchronize()
         k_ms.append(ds.last_kernel_ms())
     ds.set_timing(False)
+    # A sustained figure beside the driver-timed burst (20 steps = 0.12 s): the same step for `--sustain-seconds` of wall
+    # time (default 5), clock sampled by a side thread.  Synchronised every 50 steps so that the host cannot run ahead.
+    sustained = None
+    if args.sustain_seconds > 0 and not args.host_fed:
+        with _ClockSampler(local_rank) as clk:
+            n_sus = 0
+            t0s = time.perf_counter()
+            while time.perf_counter() - t0s < args.sustain_seconds:
+                for _ in range(50):
+                    step()
+                ds.synchronize()
+                n_sus += 50
+            dts = time.perf_counter() - t0s
+        sustained = {"seconds": dts, "steps": n_sus, "ms_per_step": dts / n_sus * 1e3,
+                     "value": B * T * n_sus / dts / 100.0, "unit": "concurrent real-time 48 kHz streams (this rank)",
+                     "sclk_mhz_mean": clk.mean(), "sclk_samples": len(clk.samples),
+                     "sclk_source": clk.path or "no pp_dpm_sclk in sysfs"}
     from crispy_amd import _native as N
     # rn_frame_kernel launches per step (a call starts with short launches of 3 and 8 frames, then 12 per launch);
     # per-launch figures below are averages over them: algorithmic bytes of a step / launches, kernel time / launches
@@ -887,6 +977,7 @@ def cfg2(args):
         except Exception:
             pass
         achieved = alg_bytes / (frame_ms * 1e-3) / 1e9
+        flops = FLOPS_PER_STREAM_FRAME * B * T / launches / (frame_ms * 1e-3) / 1e12
         line = {
             "metric": "concurrent real-time 48 kHz streams/GPU (RNNoise)"
                       + (" -- HOST-FED flavour: PCIe copies inside the timed region, not the headline" if args.host_fed else ""),
@@ -903,11 +994,19 @@ def cfg2(args):
                                    + (", fed from page-locked host memory through crispy_rn_process" if args.host_fed else ""),
                        "streams_per_gpu": B, "frames_per_step": T, "sharding": f"streams x{world_reported}, no collective",
                        "frames_per_s": fps, "output_finite": finite},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            # with the per-stream state on chip this kernel is bound by the fp32 vector pipe (117 flop per
+            # algorithmic byte against a machine balance of 20), so that is the roof `frac` is taken against; the HBM
+            # figures (algorithmic bytes per launch against 8 TB/s, counter traffic) ride beside it.
+            "roofline": {"bound": "valu", "achieved": flops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flops / VALU_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "rn_frame_kernel", "kernel_ms": frame_ms, "launches_per_step": launches,
                          "enqueue_ms": total_ms,
-                         "alg_bytes_per_launch": alg_bytes, "valu": valu},
+                         "alg_flops_per_launch": FLOPS_PER_STREAM_FRAME * B * T / launches,
+                         "alg_bytes_per_launch": alg_bytes, "valu": valu,
+                         "hbm": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                                 "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None}},
+            "sustained": sustained,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
@@ -935,6 +1034,29 @@ def cfg2(args):
                                 "value_precision_mode_0": a["rtfx_end_to_end"],
                                 "single_30s_chunk_from_host_ms": a["single_clip"]["f16_operand_mode_ms"],
                                 "model": a["model"]}
+        if world == 1 and not args.no_cfg45:
+            # BASELINE configs[3] and configs[4] inside the same run (and so inside the driver's clock around it): one
+            # 1024-stream end-to-end step pair and 256-clip Whisper-base steps, each through its own workload function
+            import copy
+            ds.close()
+            torch.cuda.empty_cache()
+            for key, fn, over in (("cfg4", _cfg4, dict(steps=2, warmup=1, new_tokens=64)),
+                                  ("cfg5", _cfg5, dict(steps=2, warmup=1, new_tokens=32))):
+                a2 = copy.copy(args)
+                for k2, v2 in over.items():
+                    setattr(a2, k2, v2)
+                try:
+                    t0c = time.perf_counter()
+                    r = fn(a2, numa, in_process=True)
+                    c = r["config"]
+                    line[key] = {"workload": c["workload"], "ms_per_step": r["ms_per_step"], "rtfx": r["value"], "steps": r["steps"],
+                                 "stage_ms": c.get("serial_stage_ms") or c.get("stage_ms_per_step"),
+                                 "serial_step_ms": c.get("serial_step_ms"), "pipe_depth": c.get("pipe_depth"),
+                                 "precision_mode": a2.precision, "tokens_checksum": c.get("tokens_checksum")
+                                 or (r.get("transcript_ids") or {}).get("checksum"), "leg_wall_s": time.perf_counter() - t0c}
+                except Exception as e:     # a reported extra, never a reason to lose the headline
+                    line[key] = {"error": str(e)[:300]}
+                torch.cuda.empty_cache()
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()

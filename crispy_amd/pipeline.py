@@ -62,6 +62,13 @@ class DenoiseTranscribePipeline:
         self.lm = LogMel(whisper.hp.n_mels, device=device)
         self.handoff = 2 if wav_handoff else 1
 
+    def close(self):
+        """Release the handles and workspaces this pipeline owns (not the Whisper model: the caller's)."""
+        for h in (self.ds, self.rs, self.lm):
+            h.close()
+        self._den = self._pcm16 = self._melt = self._enc = None
+        self._ws_key = None
+
     def run(self, d_in48, prompt, max_new: int):
         """d_in48: torch float32 [B, T, 480] on the device, int16-range samples (x32768 already applied).
         Returns (tokens [B, n_chunks, max_new], pcm16k [B, n16] on the device -- a view of this pipeline's workspace,
@@ -110,9 +117,10 @@ class DenoiseTranscribePipeline:
         for c in range(n_chunks):
             lo = c * CHUNK_SAMPLES
             n = min(CHUNK_SAMPLES, n16 - lo)
-            if n // 160 < 100:
-                # whisper.cpp refuses input shorter than 1 s (100 mel frames) and returns no segments: the few samples
-                # the resampler leaves past the last full 30 s chunk transcribe to nothing, as they do in the app
+            if 1 + max(n - 200, 0) // 160 < 10:
+                # whisper.cpp refuses input shorter than 100 ms (10 mel frames of 1 + (n - 200) / 160) and returns no
+                # segments: the 168 samples the resampler leaves past the last full 30 s chunk transcribe to nothing, as
+                # they do in the app
                 continue
             self.lm.compute_device(pcm16.data_ptr() + 4 * lo, pcm16.shape[1], np.full(B, n), 0, melt.data_ptr())
             self.lm.synchronize()

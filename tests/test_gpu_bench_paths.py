@@ -26,7 +26,7 @@ def _bench(args, env_extra=None, timeout=600):
     return json.loads(last)
 
 
-QUICK = ["--no-asr", "--no-latency", "--no-live-traffic", "--no-cpu-baseline"]
+QUICK = ["--no-asr", "--no-latency", "--no-live-traffic", "--no-cpu-baseline", "--no-cfg45", "--sustain-seconds", "0"]
 
 
 def test_cfg2_through_rccl_with_one_rank():
