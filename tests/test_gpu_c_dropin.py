@@ -39,3 +39,54 @@ def test_c_dropin_matches_oracle_and_reports_latency(oracle, weights0):
     assert np.abs(vad - rv).max() < 1e-4
     assert lat["calls"] == 300 and 0 < lat["p50"] <= lat["p99"] <= lat["max"]
     assert lat["p99"] < 10000, f"a process_frame call must fit the 10 ms audio callback budget: {lat}"
+
+
+def _build_multi_gpu(out_dir):
+    exe = os.path.join(out_dir, "multi_gpu")
+    lib_dir = os.path.join(ROOT, "crispy_amd")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-O2", "-D_POSIX_C_SOURCE=199309L", "-pthread",
+                    "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "multi_gpu.c"), "-o", exe,
+                    "-L", lib_dir, "-lcrispy_hip", f"-Wl,-rpath,{lib_dir}"], check=True, capture_output=True, text=True)
+    return exe
+
+
+def test_multi_gpu_c_program_compiles_as_c99(tmp_path):
+    """CPU: tests/c/multi_gpu.c builds against the header with -std=c99 -pedantic -Werror and, without a device, says so."""
+    exe = _build_multi_gpu(str(tmp_path))
+    from crispy_amd import _native as N
+    if N.lib().crispy_device_count() > 0:
+        pytest.skip("a GPU is present: covered by the gpu test below")
+    r = subprocess.run([exe, "m", "i", "o", "4", "2", "2"], capture_output=True, text=True)
+    assert r.returncode == 3 and "no gfx950 device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_multi_gpu_c_program_shards_by_stream_id_without_changing_a_sample(oracle, weights0, tmp_path):
+    """The stream-sharded split from the C ABI alone (no Python, no torch.distributed): one process, one handle and one
+    host thread per shard, block partition by stream id, shard r on device r % crispy_device_count().  The shards are
+    independent, so 1, 3 and 8 shards give the same bytes and the same checksum, equal to the oracle's per stream.  On
+    a box with several GPUs the shards really sit on different devices; on a 1-GPU box they share the one there is
+    (same code path: per-shard handles, threads, partition)."""
+    import json
+    from crispy_amd import rnn_weights as RW, synth_audio as SA
+    exe = _build_multi_gpu(str(tmp_path))
+    B, T = 24, 12
+    x = SA.batch_np(B, T, first_stream=700) * np.float32(32768.0)                  # [T, B, 480]
+    model = tmp_path / "m.txt"
+    RW.save_rnnoise_nu_text(str(model), weights0)
+    (tmp_path / "in.f32").write_bytes(np.ascontiguousarray(x).tobytes())
+    outs, sums = {}, {}
+    for shards in (1, 3, 8):
+        fo = tmp_path / f"out{shards}.f32"
+        r = subprocess.run([exe, str(model), str(tmp_path / "in.f32"), str(fo), str(B), str(T), str(shards)],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        info = json.loads(r.stdout.strip().splitlines()[-1])
+        assert info["shards"] == shards and info["devices"] >= 1
+        outs[shards] = np.fromfile(fo, dtype=np.float32).reshape(T, B, 480)
+        sums[shards] = info["checksum"]
+    assert np.array_equal(outs[1], outs[3]) and np.array_equal(outs[1], outs[8])
+    assert sums[1] == sums[3] == sums[8]
+    for b in (0, 7, 23):
+        ro, _ = oracle.OracleDenoiseState(weights0).process(np.ascontiguousarray(x[:, b]))
+        assert np.abs(outs[8][:, b] - ro).max() <= 1e-4 * np.abs(ro).max() + 1e-3
