@@ -277,3 +277,57 @@ def test_mode2_transcribe_tokens_through_the_product_call(oracle):
                     break
             assert compared >= need, (what, b, compared)
     m.close()
+
+
+def test_mode1_product_call_equals_the_chained_oracle_on_plain_weights_at_the_strict_bar(oracle, tmp_path_factory):
+    """The whole product call against the whole oracle chain at the STRICT bar.  The audio-sensitive
+    weights of the tests above amplify the encoder's 3e-4 into logit-gap changes of 1e-2, so there the chain is only held
+    to 0.03 of the logit scale; plain fan-in-scaled weights do not amplify, and `crispy_asr_transcribe_batch` (mode 1,
+    whisper.cpp's default options apart from the temperature ladder: timestamp tokens, seek loop, previous-text
+    conditioning, 24 tokens per window) must then return the ids of oracle log-mel -> `encoder_forward_f16` ->
+    `DecoderCache(f16=True)` -> `whisper_full` EXACTLY, window for window -- four clips, >= 5 windows, >= 96 tokens,
+    every pick's oracle margin above MODE1_REL x the logit scale (asserted: a margin-gated comparison that compares
+    nothing proves nothing) -- with the segment times and the per-window statistics."""
+    from crispy_amd import synth_audio
+    from crispy_amd.asr import WhisperEngine, transcribe_batch
+    from crispy_amd.mel_filters import whisper_mel_filters
+    from crispy_amd.whisper_weights import HParams, synthetic_whisper_weights
+    from oracle import whisper_oracle as WO
+    hp = HParams.tiny()
+    W = synthetic_whisper_weights(hp, 1)                           # plain: no sharpened cross-attention
+    eng = WhisperEngine(_engine_file(tmp_path_factory, hp, W, "tiny-s1-plain"))
+    eng.set_precision(1)
+    sp, sup, sup_first = _wcpp_masks(hp)
+    F = whisper_mel_filters(hp.n_mels)
+    prompt = [sp["sot"], sp["lang0"], sp["transcribe"]]
+    clips = [synth_audio.clip16k_np(s, 16000 * 28) for s in (95, 97, 91, 93)]
+    got = transcribe_batch(eng, clips, max_new_tokens=24, language_token=sp["lang0"], timestamps=True, with_segments=True,
+                           fallback=False)
+    n_win = n_tok = 0
+    for c, x in enumerate(clips):
+        rsegs, rkept, wins = WO.transcribe_timestamps(W, hp, lambda seek: oracle.oracle_logmel(x, F, seek), x.size, prompt,
+                                                      WO.RULES_WCPP, eng.token_text, n_max=24, suppress=sup,
+                                                      suppress_first=sup_first, f16=True)
+        # the bar: MODE1_REL of the logit scale of this model (the largest |logit| the oracle saw at a pick)
+        dc = WO.DecoderCache(W, hp, WO.encoder_forward_f16(W, hp, oracle.oracle_logmel(x, F, 0)), f16=True)
+        lg = None
+        for t in prompt:
+            lg = dc.step(t)
+        thr = MODE1_REL * float(np.abs(lg).max())
+        worst = min(min(w["margins"]) for w in wins)
+        assert worst > thr, (c, worst, thr, "choose another clip: an oracle pick of this one is not resolvable at the strict bar")
+        text, toks, lang, segs, gw = got[c]
+        assert toks == [t for t in rkept if t != sp["eot"]], (c, toks, rkept)
+        assert [(round(a * 100), round(b * 100), s) for a, b, s in segs] == [(a, b, s.decode()) for a, b, s in rsegs], c
+        assert len(gw) == len(wins)
+        for g, w in zip(gw, wins):
+            assert (g["seek"], g["seek_advance"], g["failed"], g["no_speech"]) == (w["seek"], w["seek_advance"], int(w["failed"]), int(w["is_no_speech"]))
+            assert abs(g["no_speech_prob"] - w["no_speech_prob"]) <= 2e-2 * w["no_speech_prob"] + 1e-9
+            if np.isfinite(w["avg_logprob"]):
+                assert abs(g["avg_logprob"] - w["avg_logprob"]) <= 2 * thr, (c, g, w["avg_logprob"])
+        n_win += len(wins)
+        n_tok += sum(len(w["tokens"]) for w in wins)
+        print(f"plain weights clip {c}: {len(wins)} windows, {sum(len(w['tokens']) for w in wins)} picks, smallest oracle margin "
+              f"{worst:.4f} against a bar of {thr:.4f}")
+    assert n_win >= 5 and n_tok >= 96, (n_win, n_tok)
+    eng.close()
