@@ -41,15 +41,26 @@ class _ClockSampler:
     def __init__(self, local_rank: int = 0):
         import glob
         self.paths = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-        self.path = self.paths[min(local_rank, len(self.paths) - 1)] if self.paths else None
+        self.path = None
+        # the DRM card of THIS HIP device, by PCI address (a box shows every GPU of its host in sysfs, the job owns one)
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(local_rank)
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}."
+            for q in self.paths:
+                if want in os.path.realpath(os.path.dirname(q)):
+                    self.path = q
+        except Exception:
+            pass
+        self.by_pci = self.path is not None
         self.samples = []
         self._stop = False
         self._th = None
 
-    def _read(self):
+    def _read_one(self, path):
         import re
         try:
-            with open(self.path) as f:
+            with open(path) as f:
                 for ln in f:
                     if "*" in ln:
                         m = re.search(r"(\d+)\s*[Mm][Hh]z", ln)
@@ -59,9 +70,16 @@ class _ClockSampler:
             pass
         return None
 
+    def _read(self):
+        if self.path:
+            return self._read_one(self.path)
+        # no PCI match: the card under load is the one with the highest clock
+        vals = [v for v in (self._read_one(q) for q in self.paths) if v]
+        return max(vals) if vals else None
+
     def __enter__(self):
         import threading
-        if self.path:
+        if self.paths:
             def loop():
                 while not self._stop:
                     v = self._read()
@@ -559,53 +577,81 @@ def _cfg5(args, numa, in_process=False):
 
     hp = HParams.base()
     SUB, NEW = args.clips, args.new_tokens
-    model = WhisperModel(hp, synthetic_whisper_weights(hp, 0), device=local_rank)
-    model.set_precision(args.precision)
-    lm = LogMel(hp.n_mels, device=local_rank)
+    depth = max(1, args.cfg5_depth)
+    # `depth` sub-batches in flight, each with its own engine handle, HIP stream, workspaces and host thread: the encoder
+    # of one sub-batch (matrix cores) runs beside the decode steps of another (cross K|V stream + latency-bound
+    # projections).  depth 1 is the serial form whose stage split is printed.
+    W = synthetic_whisper_weights(hp, 0)
     lo, hi = shard_range(world * SUB * args.steps, rank, world)      # global clip ids this rank owns
     g = torch.Generator(device=dev).manual_seed(1000 + lo)
     pcm = torch.randn(SUB, 480000, generator=g, device=dev) * 0.1    # every sub-batch reuses one resident buffer
-    melt = torch.zeros(SUB, 3002, hp.n_mels, device=dev)
-    enc = torch.empty(SUB, 1500, hp.n_audio_state, device=dev)
     lens = np.full(SUB, 480000)
     prompt = [50258, 50259, 50359, 50363]
     stage = {"logmel": 0.0, "encoder": 0.0, "decode": 0.0}
-    torch.cuda.synchronize()             # the fills above ran on torch's stream; the handles use their own
 
-    def step():
-        t0 = time.perf_counter()
-        lm.compute_device(pcm.data_ptr(), 480000, lens, 0, melt.data_ptr(), stream=0)
-        lm.synchronize()
-        t1 = time.perf_counter()
-        model.encode_device(melt.data_ptr(), SUB, enc.data_ptr())
-        model.synchronize()
-        t2 = time.perf_counter()
-        toks = model.decode_greedy_device(enc.data_ptr(), SUB, prompt, NEW)
-        t3 = time.perf_counter()
-        stage["logmel"] += t1 - t0
-        stage["encoder"] += t2 - t1
-        stage["decode"] += t3 - t2
-        return toks
+    class Lane:
+        def __init__(self):
+            self.model = WhisperModel(hp, W, device=local_rank)
+            self.model.set_precision(args.precision)
+            self.lm = LogMel(hp.n_mels, device=local_rank)
+            self.melt = torch.zeros(SUB, 3002, hp.n_mels, device=dev)
+            self.enc = torch.empty(SUB, 1500, hp.n_audio_state, device=dev)
+            self.toks = None
+
+        def step(self, timed):
+            t0 = time.perf_counter()
+            self.lm.compute_device(pcm.data_ptr(), 480000, lens, 0, self.melt.data_ptr(), stream=0)
+            self.lm.synchronize()
+            t1 = time.perf_counter()
+            self.model.encode_device(self.melt.data_ptr(), SUB, self.enc.data_ptr())
+            self.model.synchronize()
+            t2 = time.perf_counter()
+            self.toks = self.model.decode_greedy_device(self.enc.data_ptr(), SUB, prompt, NEW)
+            t3 = time.perf_counter()
+            if timed:
+                stage["logmel"] += t1 - t0
+                stage["encoder"] += t2 - t1
+                stage["decode"] += t3 - t2
+
+    lanes = [Lane() for _ in range(depth)]
+    torch.cuda.synchronize()             # the fills above ran on torch's stream; the handles use their own
 
     def barrier():
         if dist:
             dist.barrier()
 
-    for _ in range(max(1, args.warmup)):
-        step()
+    for ln in lanes:
+        for _ in range(max(1, args.warmup)):
+            ln.step(False)
+    # the serial stage split: lane 0 alone, nothing beside it
+    n_serial = 2
+    for _ in range(n_serial):
+        lanes[0].step(True)
+    stage = {k: v / n_serial for k, v in stage.items()}
     torch.cuda.synchronize()
     barrier()
     if dist:
         _flush_c_stdout()
         barrier()
-    for k in stage:
-        stage[k] = 0.0
+
+    def worker(k):
+        for _ in range(k, args.steps, depth):
+            lanes[k].step(False)
+
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        toks = step()
+    if depth == 1:
+        worker(0)
+    else:
+        import threading
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(depth)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    toks = lanes[0].toks
     per_rank = _gather_ms(dist, dt * 1e3, dev)
     dt, clips_total = reduce_job_stats(dt, SUB * args.steps, device=dev)
     # the data product of the job: the fixed-width greedy ids of every rank's last sub-batch, gathered to
@@ -614,7 +660,7 @@ def _cfg5(args, numa, in_process=False):
     ids_dev = torch.from_numpy(np.ascontiguousarray(toks[0], dtype=np.int32)).to(dev)
     all_ids = gather_token_ids(ids_dev)
     if rank == 0:
-        enc_flops = 87.4e9 * SUB * args.steps                     # Whisper-base encoder per 30 s clip
+        enc_flops = 87.4e9 * SUB                                  # Whisper-base encoder per 30 s clip
         peak = 157.3 if args.precision == 0 else 2500.0
         ach = enc_flops / stage["encoder"] / 1e12
         line = {
@@ -631,7 +677,9 @@ def _cfg5(args, numa, in_process=False):
                                    f"GPU in sub-batches of {SUB}, {NEW} greedy tokens per clip, seeded random-init weights",
                        "clips_per_gpu": SUB * args.steps, "clips_per_step": SUB, "new_tokens": NEW,
                        "sharding": f"clips x{world_reported}, no collective", "clips_per_s": clips_total / dt,
-                       "stage_ms_per_step": {k: v / args.steps * 1e3 for k, v in stage.items()},
+                       "sub_batches_in_flight": depth,
+                       "stage_ms_per_step": {k: v * 1e3 for k, v in stage.items()},
+                       "serial_step_ms": sum(stage.values()) * 1e3,
                        "tokens_shape": list(np.asarray(toks[0]).shape)},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                          "traffic": None, "kernel": "encoder GEMMs + attention (87.4 GFLOP per clip)",
@@ -640,8 +688,9 @@ def _cfg5(args, numa, in_process=False):
         }
     else:
         line = None
-    model.close()
-    lm.close()
+    for ln in lanes:
+        ln.model.close()
+        ln.lm.close()
     if dist:
         dist.destroy_process_group()
     return line
@@ -654,10 +703,11 @@ def cfg4(args):
     --precision 0.  value = seconds of audio per wall second, whole job.
 
     RNNoise is a strict 3000-frame recurrence per stream (~42 us per frame and wave whatever the stream count below 4096),
-    so inside ONE step it cannot overlap the ASR stages of the same streams; across steps it can: `--pipe-depth 2`
-    (default) drives two pipelines (own handles, own HIP streams, own workspaces) from two host threads, and the
-    denoise stage of step k + 1 runs under the encoder / decoder of step k.  `--pipe-depth 1` is the serial form whose
-    stage split is printed beside it."""
+    so inside ONE step it cannot overlap the ASR stages of the same streams; across steps it can: `--pipe-depth 4`
+    (default) drives four pipelines (own handles, own HIP streams, own workspaces) from four host threads, and the
+    denoise stages of later steps run under the encoder / decoder of earlier ones (depth 1 / 2 / 3 / 4: 401 / 338 / 337 /
+    302 ms per step; a fifth pipeline no longer fits the decode workspaces of four).  `--pipe-depth 1` is the serial form
+    whose stage split is printed beside it."""
     rank, local_rank, world = _dist_env()
     numa = _bind_numa(local_rank, world)
     line = _cfg4(args, numa)
@@ -782,7 +832,10 @@ def main():
     ap.add_argument("--clips", type=int, default=256, help="cfg5: 30 s clips per step (sub-batch) per GPU")
     ap.add_argument("--new-tokens", type=int, default=None, help="greedy tokens per clip (default: cfg5 32, cfg4 64)")
     ap.add_argument("--pipe-streams", type=int, default=1024, help="cfg4: 48 kHz streams per GPU (30 s each)")
-    ap.add_argument("--pipe-depth", type=int, default=2,
+    ap.add_argument("--cfg5-depth", type=int, default=2,
+                    help="cfg5: sub-batches in flight (own engine handle, HIP stream and host thread each): the encoder of one "
+                         "runs beside the decode steps of another; 1 = serial")
+    ap.add_argument("--pipe-depth", type=int, default=4,
                     help="cfg4: pipelines in flight (own handles and HIP streams, one host thread each): with 2, RNNoise of "
                          "step k + 1 runs under the encoder / decoder of step k; 1 = serial")
     ap.add_argument("--precision", type=int, default=1,
@@ -932,7 +985,8 @@ def cfg2(args):
         sustained = {"seconds": dts, "steps": n_sus, "ms_per_step": dts / n_sus * 1e3,
                      "value": B * T * n_sus / dts / 100.0, "unit": "concurrent real-time 48 kHz streams (this rank)",
                      "sclk_mhz_mean": clk.mean(), "sclk_samples": len(clk.samples),
-                     "sclk_source": clk.path or "no pp_dpm_sclk in sysfs"}
+                     "sclk_source": (clk.path + " (matched by PCI address)") if clk.by_pci else
+                                    ("highest of " + str(len(clk.paths)) + " pp_dpm_sclk files" if clk.paths else "no pp_dpm_sclk in sysfs")}
     from crispy_amd import _native as N
     # rn_frame_kernel launches per step (a call starts with short launches of 3 and 8 frames, then 12 per launch);
     # per-launch figures below are averages over them: algorithmic bytes of a step / launches, kernel time / launches
@@ -1040,7 +1094,7 @@ def cfg2(args):
             import copy
             ds.close()
             torch.cuda.empty_cache()
-            for key, fn, over in (("cfg4", _cfg4, dict(steps=2, warmup=1, new_tokens=64)),
+            for key, fn, over in (("cfg4", _cfg4, dict(steps=4, warmup=1, new_tokens=64)),
                                   ("cfg5", _cfg5, dict(steps=2, warmup=1, new_tokens=32))):
                 a2 = copy.copy(args)
                 for k2, v2 in over.items():

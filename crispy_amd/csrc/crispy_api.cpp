@@ -34,6 +34,12 @@ constexpr int kChunkFrames = 250;   // workspace bound: frames of high-passed si
 #define RN_SUB_FRAMES 12
 #endif
 constexpr int kSubFrames = RN_SUB_FRAMES;
+// Up to this many streams a handle runs the stage-pipelined frame kernel (three waves per stream, 26.7 KB of LDS and 128
+// VGPRs: five such workgroups per CU = 1280 streams on 256 CUs); above it one wave per stream.  Measured
+// (tools/rn_small_batch.py, 300 frames per call): frame kernels alone 20.6 against 34.7 us per frame at 1024 streams,
+// 17.4 against 31.6 at 256; whole calls 9.4 against 11.0 ms and 7.9 against 10.0 ms -- the sequential high-pass chain of a
+// stream (~26 us per frame: ten f64-path instructions per sample on one lane) is what bounds a call from there on.
+constexpr int kStagedMaxStreams = 1280;
 
 // Frames of sub-chunk `index` of a segment with `remaining` frames left.  The high-pass recurrence of the first
 // sub-chunk cannot overlap anything (the previous call still reads xhp), so the segment starts with a short
@@ -221,6 +227,11 @@ struct crispy_rn {
   // step, measured with CRISPY_RN_HP=upfront).  As kernels of two frames the 64 waves land on other SIMDs every
   // ~50 us and the delay spreads: 8.17 -> 7.68 ms per step (1 frame: 7.83, 3: 8.07, 4: 8.15, 6: 8.0, whole: 8.17).
   int hp_split = 2;
+  // Waves per stream of the frame kernel: 1 = one wave runs the whole frame (every pipe of the chip is busy from ~4 waves per
+  // SIMD = 4096 streams up); 3 = the frame's three stages on three waves, a frame apart (rn_frame3_kernel: a stream
+  // advances a frame per ~10 k quad-cycles instead of ~26 k -- what counts while there are fewer waves than SIMD slots).
+  // Chosen at create time from the stream count; CRISPY_RN_WAVES=1|3 overrides (tests run both forms).
+  int waves = 1;
   int hp_ahead = 0;          // > 0: the high-pass runs at most this many sub-chunks in front of the frame kernels
   std::vector<hipEvent_t> ev_fr;   // one per sub-chunk: frame kernel done (only used with hp_ahead)
   bool hp_upfront = false;   // diagnostic (CRISPY_RN_HP=upfront): every high-pass of a call segment first, on the main stream
@@ -458,6 +469,8 @@ int crispy_rn_create(const int8_t* weights, size_t nbytes, int n_streams, int de
     {
       const char* hp = std::getenv("CRISPY_RN_HP");
       h->hp_upfront = hp && std::strcmp(hp, "upfront") == 0;
+      const char* wv = std::getenv("CRISPY_RN_WAVES");
+      h->waves = wv ? (std::atoi(wv) == 3 ? 3 : 1) : (n_streams <= kStagedMaxStreams ? 3 : 1);
       const char* sp = std::getenv("CRISPY_RN_HP_SPLIT");
       if (sp) h->hp_split = std::atoi(sp);   // 0: one kernel per sub-chunk
       const char* ah = std::getenv("CRISPY_RN_HP_AHEAD");
@@ -616,7 +629,7 @@ int process_device_impl(crispy_rn* h, const float* d_in, float* d_out, float* d_
       if (h->hp_ahead > 0) { const int rc_hp = enqueue_hp_until(i + h->hp_ahead - 1); if (rc_hp != CRISPY_OK) return rc_hp; }
       HIP_TRY(hipStreamWaitEvent(s, h->ev_hp[i], 0));
       if (e) HIP_TRY(hipEventRecord(e[1 + 2 * i], s));
-      HIP_TRY(rn_launch_frames(sa, s));
+      HIP_TRY(rn_launch_frames(sa, s, h->waves));
       if (e) HIP_TRY(hipEventRecord(e[2 + 2 * i], s));
       if (h->hp_ahead > 0) HIP_TRY(hipEventRecord(h->ev_fr[i], s));
       ts += sa.T;

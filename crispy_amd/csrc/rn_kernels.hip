@@ -88,6 +88,22 @@ __device__ __forceinline__ float wave_sum(float v) {
 // 480-point complex FFT, in place in LDS, one wave.  Stockham passes with register staging:
 // every lane reads the inputs of its butterflies, the wave synchronises, every lane writes.
 // ---------------------------------------------------------------------------------------------
+// Synchronisation of the lanes that work on one stream.  NW = 1 (the default kernel): the workgroup IS the wave, and
+// rn_sync<NW>() is the cheapest statement of "this wave's LDS traffic has landed".  NW = 3 (the stage-pipelined kernel
+// for small stream counts): the workgroup holds three waves that are at DIFFERENT points of different frames between
+// two ticks, so inside a stage only the wave itself may be waited for; the workgroup barrier stands at the tick.
+template <int NW>
+__device__ __forceinline__ void rn_sync() {
+  if constexpr (NW == 1) {
+    __syncthreads();
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
 template <int R>
 __device__ __forceinline__ void butterfly(const float2 (&v)[R], float2 (&o)[R]);
 
@@ -182,7 +198,7 @@ __device__ __forceinline__ int fft_wr(int j, int r) {
   const int k = j % NS;
   return (j / NS) * NS * R + k + r * NS;
 }
-template <int R, int NS>
+template <int NW, int R, int NS>
 __device__ __forceinline__ void fft_pass(float2* buf, const float2* __restrict__ w960, int lane) {
   constexpr int M = 480 / R;
   constexpr int NBF = (M + WAVE - 1) / WAVE;
@@ -211,7 +227,7 @@ __device__ __forceinline__ void fft_pass(float2* buf, const float2* __restrict__
       butterfly<R>(v, o[nb]);
     }
   }
-  __syncthreads();
+  rn_sync<NW>();
 #pragma unroll
   for (int nb = 0; nb < NBF; ++nb) {
     const int j = lane + WAVE * nb;
@@ -220,21 +236,22 @@ __device__ __forceinline__ void fft_pass(float2* buf, const float2* __restrict__
       for (int r = 0; r < R; ++r) buf[fft_wr<R, NS>(j, r)] = o[nb][r];
     }
   }
-  __syncthreads();
+  rn_sync<NW>();
 }
 
 // forward DFT of the 480 complex points in buf (unscaled, natural order); caller synchronised
+template <int NW>
 __device__ __forceinline__ void fft480(float2* buf, const float2* __restrict__ w960, int lane) {
-  fft_pass<4, 1>(buf, w960, lane);
-  fft_pass<8, 4>(buf, w960, lane);      // 480 = 4 . 8 . 3 . 5: four LDS round trips instead of five (4 . 4 . 2 . 3 . 5)
-  fft_pass<3, 32>(buf, w960, lane);
-  fft_pass<5, 96>(buf, w960, lane);
+  fft_pass<NW, 4, 1>(buf, w960, lane);
+  fft_pass<NW, 8, 4>(buf, w960, lane);      // 480 = 4 . 8 . 3 . 5: four LDS round trips instead of five (4 . 4 . 2 . 3 . 5)
+  fft_pass<NW, 3, 32>(buf, w960, lane);
+  fft_pass<NW, 5, 96>(buf, w960, lane);
 }
 
 // The same transform with the first pass (radix 4, stride 1) fed by a loader instead of LDS: in(j, r) returns point
 // j + 120 r.  The analysis transforms window their input straight from global memory this way, which saves the
 // separate "window -> LDS -> barrier -> read back" phase.  buf must be free (caller synchronised).
-template <class In>
+template <int NW, class In>
 __device__ __forceinline__ void fft480_from(float2* buf, In in, const float2* __restrict__ w960, int lane) {
   {
     float2 o[2][4];
@@ -256,14 +273,15 @@ __device__ __forceinline__ void fft480_from(float2* buf, In in, const float2* __
         for (int r = 0; r < 4; ++r) buf[fft_wr<4, 1>(j, r)] = o[nb][r];
       }
     }
-    __syncthreads();
+    rn_sync<NW>();
   }
-  fft_pass<8, 4>(buf, w960, lane);
-  fft_pass<3, 32>(buf, w960, lane);
-  fft_pass<5, 96>(buf, w960, lane);
+  fft_pass<NW, 8, 4>(buf, w960, lane);
+  fft_pass<NW, 3, 32>(buf, w960, lane);
+  fft_pass<NW, 5, 96>(buf, w960, lane);
 }
 
 // buf holds Z = FFT480(x[2n] + i x[2n+1]); turn it into X[0..480] = DFT960(x)/960 in place.
+template <int NW>
 __device__ __forceinline__ void real_fwd_post(float2* buf, const float2* __restrict__ w960, int lane) {
   const float scale = 1.0f / 960.0f;
   // table loads of all four trips first (clamped index): inside the `k <= 240` bodies each of them was a load - wait
@@ -296,11 +314,12 @@ __device__ __forceinline__ void real_fwd_post(float2* buf, const float2* __restr
       buf[480 - k] = xn;
     }
   }
-  __syncthreads();
+  rn_sync<NW>();
 }
 
 // buf holds X[0..480]; replace it by conj(Z) with Z[k] = (X[k]+conj X[480-k]) + i w^-k (X[k]-conj X[480-k])
 // so that a forward FFT yields conj of the interleaved time signal.
+template <int NW>
 __device__ __forceinline__ void real_inv_pre(float2* buf, const float2* __restrict__ w960, int lane) {
   float2 wk[4], wn[4];
 #pragma unroll
@@ -327,7 +346,7 @@ __device__ __forceinline__ void real_inv_pre(float2* buf, const float2* __restri
       if (k > 0) buf[480 - k] = zn;
     }
   }
-  __syncthreads();
+  rn_sync<NW>();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -383,7 +402,7 @@ __device__ __forceinline__ float band_sum(const float* part_lo, const float* par
 // the band correlation Re(X P*) against a second spectrum and parks S in global memory from the registers.
 //   E[band]  of S            -> Eout
 //   C[band]  of (Xc, S)      -> Cout   (CORR)
-template <bool CORR>
+template <int NW, bool CORR>
 __device__ __forceinline__ void band_pairs(const float2* S, const float2* Xc, float* part, float* Eout, float* Cout,
                                            float2* park, const RnTables* __restrict__ tab, const BandEdges& be,
                                            int lane) {
@@ -423,10 +442,10 @@ __device__ __forceinline__ void band_pairs(const float2* S, const float2* Xc, fl
     }
   }
   auto band_total = [&](float* out) {
-    __syncthreads();
+    rn_sync<NW>();
     const float bsum = band_sum(part, part + 100, be, lane);
     if (lane < RN_NB) out[lane] = bsum;
-    __syncthreads();
+    rn_sync<NW>();
   };
   band_total(Eout);
   if (CORR) {
@@ -683,7 +702,7 @@ __device__ __forceinline__ float dot_i(__amdgpu_buffer_rsrc_t rs, int w_off, int
 }
 // in_img / sin: digit image and 2^-s of the layer input (caller); st_img: the state's image, then h*r's at the same
 // scale (|h r| <= |h|).
-template <int M, int N>
+template <int NW, int M, int N>
 __device__ __forceinline__ void gru_layer_i(__amdgpu_buffer_rsrc_t rs, int w_off, int u_off,
                                             const float* __restrict__ bias, const signed char* in_img, float sin,
                                             float* state, float* zbuf, signed char* st_img, int toff,
@@ -693,7 +712,7 @@ __device__ __forceinline__ void gru_layer_i(__amdgpu_buffer_rsrc_t rs, int w_off
   constexpr int NRZ = (2 * N + WAVE - 1) / WAVE, NRC = (N + WAVE - 1) / WAVE;
   const float S = 1.f / 256.f;
   const RnScale sst = image_i8<NK16 * 16>(st_img, lane, [&](int i) { return i < N ? state[min(i, N - 1)] : 0.f; });
-  __syncthreads();
+  rn_sync<NW>();
   {
     int rows[NRZ];
     float acc[NRZ];
@@ -713,7 +732,7 @@ __device__ __forceinline__ void gru_layer_i(__amdgpu_buffer_rsrc_t rs, int w_off
       }
     }
   }
-  __syncthreads();
+  rn_sync<NW>();
   {
     int rows[NRC];
     float acc[NRC];
@@ -734,25 +753,45 @@ __device__ __forceinline__ void gru_layer_i(__amdgpu_buffer_rsrc_t rs, int w_off
       }
     }
   }
-  __syncthreads();
+  rn_sync<NW>();
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS of one wave: 10 176 bytes, so that 16 waves (= 16 streams) are resident per CU.
-//   A   pitch phase: scratch (x4|y4, fine xcorr, yy_lookup)      then: analysis spectrum X / synthesis
-//   Bb  pitch phase: lp[864] whitened half-rate buffer            then: pitch spectrum P (parked in L2
-//       after its band sums), RNN vectors, band partial sums
+// LDS of one stream.  RnSlot is what one frame occupies from its spectra onwards:
+//   A   analysis spectrum X / synthesis                (NW = 1 also: pitch-phase scratch -- x4|y4, fine xcorr, yy_lookup)
+//   Bb  pitch spectrum P, RNN vectors, band partials   (NW = 1 also: lp[864], the whitened half-rate buffer)
 //   U   band partial sums while A and Bb both hold spectra | Ly, tmp22, g, r
+// NW = 1 (one wave per stream): one slot + the cepstral ring + the GRU state = 10 192 bytes, 16 streams per CU.
+// NW = 3 (stage pipeline, small stream counts): TWO slots (the spectra wave fills one while the synthesis wave empties
+// the other), the pitch wave's own scratch, and the pitch results of two frames in flight: 26.7 KB, 6 streams per CU.
 // ---------------------------------------------------------------------------------------------
-struct alignas(16) RnLds {
+struct alignas(16) RnSlot {
   float2 A[482];
   float2 Bb[482];
   float U[200];
+  float Ex[24], Ep[24], Exp[24];
+  int pitch_index;       // NW = 3: handed from the spectra stage to the synthesis stage with the frame
+  float pitch_gain;
+  int silence;
+  int pad;
+};
+template <int NW> struct RnLdsT;
+template <> struct alignas(16) RnLdsT<1> {
+  RnSlot s[1];
   float ceps[8 * 22];
   float rnn_state[168];  // vad 24 | noise 48 | denoise 96
-  float Ex[24], Ep[24], Exp[24];
 };
-static_assert(sizeof(RnLds) <= 10240, "16 workgroups per CU need <= 10 KB of LDS each");
+template <> struct alignas(16) RnLdsT<3> {
+  RnSlot s[2];           // by frame parity
+  float2 pa[482];        // pitch stage: scratch
+  float2 pb[482];        // pitch stage: lp[864]
+  float ceps[8 * 22];
+  float rnn_state[168];
+  int pitch_index[2];    // pitch stage -> spectra stage, by frame parity
+  float pitch_gain[2];
+};
+static_assert(sizeof(RnLdsT<1>) <= 10240, "16 workgroups per CU need <= 10 KB of LDS each");
+static_assert(6 * sizeof(RnLdsT<3>) <= 160 * 1024, "six stage-pipelined streams per CU");
 
 // offsets inside U outside band_sums (Ly is dead once the features exist: U[48, 192) is free for the gain network)
 constexpr int U_G = 0, U_R = 24, U_VAD = 46, U_LY = 48;
@@ -845,24 +884,38 @@ __device__ __forceinline__ void lag_dots(const float* xr, const float* const (&y
   __syncthreads();
 }
 
-template <bool DBG>
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VGPR_CAP void rn_frame_kernel(RnArgs a) {
-  __shared__ RnLds L;
-  const int lane0 = threadIdx.x;
+// NW = 1: one wave per stream, the whole frame in sequence (4096 streams = 16 waves per CU: every pipe is busy).
+// NW = 3: three waves per stream, one per STAGE, each a frame behind the one before it -- wave 0 the pitch analysis of
+// frame k, wave 1 the spectra and features of frame k - 1, wave 2 gain network + synthesis of frame k - 2 -- with one
+// workgroup barrier per tick.  A frame is a chain of ~26 k dependent quad-cycles whatever the stream count; with 1024
+// streams there is one wave per SIMD and nothing to hide that chain behind, so the chain is cut in three (9.8 k / 6.5 k /
+// 10.2 k quad-cycles) and the stream advances a frame per ~10 k instead.  Same code per stage, same arithmetic.
+__device__ __forceinline__ float2* rn_lds_lp(RnLdsT<1>& L) { return L.s[0].Bb; }
+__device__ __forceinline__ float2* rn_lds_sa(RnLdsT<1>& L) { return L.s[0].A; }
+__device__ __forceinline__ float2* rn_lds_lp(RnLdsT<3>& L) { return L.pb; }
+__device__ __forceinline__ float2* rn_lds_sa(RnLdsT<3>& L) { return L.pa; }
+
+template <bool DBG, int NW>
+__device__ __forceinline__ void rn_frame_body(const RnArgs& a) {
+  __shared__ RnLdsT<NW> L;
+  const int wave = NW == 1 ? 0 : (int)(threadIdx.x >> 6);
+  const int lane0 = threadIdx.x & (WAVE - 1);
   const int b = blockIdx.x;
   if (b >= a.B) return;
   int lane = lane0;
   const RnTables* tab = a.tab;
   const float* xs = a.xhp + (long)b * a.xhp_stride;
-  // Different issue priorities per wave slot, so that the four waves of a SIMD drift out of phase without anyone
-  // sleeping: -0.8 % per step over three alternating 30-step runs (by SIMD, or by slot + SIMD parity: no change).
-  unsigned hw;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-  const unsigned pr = hw & 3u;
-  if (pr == 0) __builtin_amdgcn_s_setprio(0);
-  else if (pr == 1) __builtin_amdgcn_s_setprio(1);
-  else if (pr == 2) __builtin_amdgcn_s_setprio(2);
-  else __builtin_amdgcn_s_setprio(3);
+  if constexpr (NW == 1) {
+    // Different issue priorities per wave slot, so that the four waves of a SIMD drift out of phase without anyone
+    // sleeping: -0.8 % per step over three alternating 30-step runs (by SIMD, or by slot + SIMD parity: no change).
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    const unsigned pr = hw & 3u;
+    if (pr == 0) __builtin_amdgcn_s_setprio(0);
+    else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+  }
 
 #if RN_POISON_LDS
   // Checker build (`make variants` -> libcrispy_hip_poison.so, tests/test_gpu_rnnoise.py): LDS is not cleared between
@@ -872,19 +925,20 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
   rn_poison_lds(reinterpret_cast<uint32_t*>(&L), sizeof(L) / 4);
 #endif
 
-  // ---- load per-stream state ----
-  for (int i = lane; i < 176; i += WAVE) L.ceps[i] = a.ceps[(long)b * 176 + i];
-  for (int i = lane; i < 168; i += WAVE) L.rnn_state[i] = a.rnn[(long)b * 168 + i];
-  // Overlap-add tail, samples (2n, 2n+1) for n = lane + 64 m.  The fused kernel keeps it in the state buffer
-  // (L2) and touches it once per frame: eight VGPRs that would otherwise be live across the whole frame loop
-  // are what pushed the kernel into scratch spills.  The synthesis kernel (low pressure) keeps it in registers.
+  // ---- load per-stream state (NW = 3: each stage's wave owns its part) ----
+  const bool own_a = NW == 1 || wave == 0, own_b = NW == 1 || wave == 1, own_c = NW == 1 || wave == 2;
+  if (own_b)
+    for (int i = lane; i < 176; i += WAVE) L.ceps[i] = a.ceps[(long)b * 176 + i];
+  if (own_c)
+    for (int i = lane; i < 168; i += WAVE) L.rnn_state[i] = a.rnn[(long)b * 168 + i];
+  // Overlap-add tail, samples (2n, 2n+1) for n = lane + 64 m, in registers across the frames of the launch
   float2 synth[4];
   float* synth_g = a.synth + (long)b * 480;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int n = lane + WAVE * m;
-      synth[m] = n < 240 ? *reinterpret_cast<const float2*>(synth_g + 2 * n) : make_float2(0.f, 0.f);
-    }
+  for (int m = 0; m < 4; ++m) {
+    const int n = lane + WAVE * m;
+    synth[m] = n < 240 ? *reinterpret_cast<const float2*>(synth_g + 2 * n) : make_float2(0.f, 0.f);
+  }
   float lastg = lane < RN_NB ? a.lastg[(long)b * RN_NB + lane] : 0.f;
   BandEdges be;
   {
@@ -895,14 +949,18 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
   float last_gain = a.last_gain[b];
   __syncthreads();
 
-  float* lp = reinterpret_cast<float*>(L.Bb);  // 864 floats during the pitch phase
-  float* Sa = reinterpret_cast<float*>(L.A);   // pitch-phase scratch
-  float* Rb = reinterpret_cast<float*>(L.Bb);  // RNN vectors after the pitch spectrum is parked
   constexpr int KB_FEAT = PL_FEAT;
-  float* Xf = reinterpret_cast<float*>(L.A);
 
   RN_PROF_DECL
-  for (int t = 0; t < a.T; ++t) {
+  // NW = 3: tick k runs frame k on wave 0, frame k - 1 on wave 1, frame k - 2 on wave 2, then the workgroup barrier
+  for (int tick = 0; tick < a.T + (NW - 1); ++tick) {
+    const int t = tick - wave;
+    if (NW == 1 || (t >= 0 && t < a.T)) {
+    RnSlot& SL = L.s[NW == 1 ? 0 : (t & 1)];
+    float* lp = reinterpret_cast<float*>(rn_lds_lp(L));   // 864 floats during the pitch phase
+    float* Sa = reinterpret_cast<float*>(rn_lds_sa(L));   // pitch-phase scratch
+    float* Rb = reinterpret_cast<float*>(SL.Bb);           // RNN vectors, band partials
+    float* Xf = reinterpret_cast<float*>(SL.A);
     // Launder the lane id and the table / weight base pointers once per frame: every per-lane table
     // address is loop-invariant, and without this the compiler hoists ~250 of them out of the frame
     // loop into registers (429 VGPR+AGPR, one wave per SIMD).  Opaque values keep them per-frame.
@@ -932,795 +990,827 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
     float pitch_gain = 0.f;
     bool silence = false;
     float vad_prob = 0.f;
-    // ---- 1. pitch: half-rate, LPC whitening (lp in Bb) ----
-    {
-      // all 14 x 2 window loads of a lane are requested before the first one is used (a `for (i = lane; ...)` loop
-      // with the bound test in it compiled to load - wait - load - wait per trip: 27 exposed round trips per frame)
-      float2 v[14];
-      float x0[14];
-#pragma unroll
-      for (int k = 0; k < 14; ++k) {
-        const int i = min(lane + WAVE * k, 863);
-        v[k] = *reinterpret_cast<const float2*>(pb + 2 * i);
-        x0[k] = pb[2 * i - 1];                      // i = 0 reads the (valid) sample before the buffer, zeroed below
-      }
-#pragma unroll
-      for (int k = 0; k < 14; ++k) {
-        const int i = lane + WAVE * k;
-        const float xm = i > 0 ? x0[k] : 0.f;
-        if (i < 864) lp[i] = .5f * (.5f * (xm + v[k].y) + v[k].x);
-      }
-    }
-    __syncthreads();
-    // Each lane owns 14 consecutive half-rate samples (plus a 5-sample halo) in registers: the same window feeds
-    // the autocorrelation partial sums (lags 0..4) and, once the LPC is known, the 5-tap FIR -- no second pass of
-    // LDS reads.  Samples outside [0, 864) are zero, which is also what the reference's `i >= k` guard amounts to.
-    float lpc2[5];
-    const int base = lane * 14;
-    float w[19];
-#pragma unroll
-    for (int q = 0; q < 19; ++q) {
-      const int idx = base - 5 + q;
-      w[q] = (idx >= 0 && idx < 864) ? lp[idx] : 0.f;
-    }
-    {
-      float ac[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int q = 0; q < 14; ++q) {
-#pragma unroll
-        for (int k = 0; k <= 4; ++k) ac[k] = fmaf(w[q + 5], w[q + 5 - k], ac[k]);
-      }
-      wave_sums<5>(ac);
-      ac[0] *= 1.0001f;
-#pragma unroll
-      for (int k = 1; k <= 4; ++k) ac[k] -= ac[k] * (.008f * k) * (.008f * k);
-      float lpc[4] = {0.f, 0.f, 0.f, 0.f};
-      float error = ac[0];
-      if (ac[0] != 0.f) {
-        bool done = false;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (!done) {
-            float rr = 0.f;
-#pragma unroll
-            for (int j = 0; j < i; ++j) rr += lpc[j] * ac[i - j];
-            rr += ac[i + 1];
-            const float r = -rr / error;
-            lpc[i] = r;
-#pragma unroll
-            for (int j = 0; j < (i + 1) >> 1; ++j) {
-              const float t1 = lpc[j], t2 = lpc[i - 1 - j];
-              lpc[j] = t1 + r * t2;
-              lpc[i - 1 - j] = t2 + r * t1;
-            }
-            error = error - r * r * error;
-            if (error < .001f * ac[0]) done = true;
-          }
-        }
-      }
-      float tmp = 1.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        tmp = .9f * tmp;
-        lpc[i] = lpc[i] * tmp;
-      }
-      lpc2[0] = lpc[0] + .8f;
-      lpc2[1] = lpc[1] + .8f * lpc[0];
-      lpc2[2] = lpc[2] + .8f * lpc[1];
-      lpc2[3] = lpc[3] + .8f * lpc[2];
-      lpc2[4] = .8f * lpc[3];
-    }
-    {
-      // 5-tap FIR in place from the register window
-      float y[14];
-#pragma unroll
-      for (int q = 0; q < 14; ++q) {
-        float sum = w[q + 5];
-        sum = fmaf(lpc2[0], w[q + 4], sum);
-        sum = fmaf(lpc2[1], w[q + 3], sum);
-        sum = fmaf(lpc2[2], w[q + 2], sum);
-        sum = fmaf(lpc2[3], w[q + 1], sum);
-        sum = fmaf(lpc2[4], w[q], sum);
-        y[q] = sum;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < 14; ++q)
-        if (base + q < 864) lp[base + q] = y[q];
-      __syncthreads();
-    }
-    STAMP(0)
-    lane = lane0;
-    asm volatile("" : "+v"(lane));
-    RN_LANE_RANGE(4);
-
-    // ---- 2. pitch_search: 4x-decimated coarse search over 147 lags (scratch in A) ----
-    float* x4 = Sa;        // 240
-    float* y4 = Sa + 240;  // 387 (+ guard to 392)
-    float* pre = Sa;       // 392: exclusive prefix sums of y4^2, written after x4/y4 are dead (aliases them)
-    {
-      // reads of all trips first (clamped indices): as `for (j = lane; ...) x4[j] = lp[...]` loops every trip was an
-      // LDS read - wait - write round trip, eleven in a row
-      float vx[4], vy[7];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) vx[m] = lp[384 + 2 * min(lane + WAVE * m, 239)];
-#pragma unroll
-      for (int m = 0; m < 7; ++m) vy[m] = lp[2 * min(lane + WAVE * m, 386)];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int j = lane + WAVE * m;
-        if (j < 240) x4[j] = vx[m];
-      }
-#pragma unroll
-      for (int m = 0; m < 7; ++m) {
-        const int j = lane + WAVE * m;
-        if (j < 392) y4[j] = j < 387 ? vy[m] : 0.f;
-      }
-    }
-    __syncthreads();
-    int best0, best1;
-    {
-      // lane owns the three consecutive lags 3*lane + {0,1,2} (lanes 0..48): the y window slides through registers,
-      // one new LDS read per step instead of three (lane stride 3 floats: conflict-free), x broadcast as float4
-      float xc[3] = {0.f, 0.f, 0.f};
+    if (own_a) {      // ======== stage 1: pitch analysis ========
+      // ---- 1. pitch: half-rate, LPC whitening (lp in Bb) ----
       {
-        const float4* xv4 = reinterpret_cast<const float4*>(x4);
-        const float* yp = y4 + 3 * min(lane, 48);      // reads reach y4[3*48 + 2 + 239] = y4[385] < 387
-        float y0 = yp[0], y1 = yp[1];
-#pragma unroll 4
-        for (int j4 = 0; j4 < 60; ++j4) {
-          const float4 xv = xv4[j4];
-          const int j = 4 * j4;
-          const float y2 = yp[j + 2], y3 = yp[j + 3], y4v = yp[j + 4], y5 = yp[j + 5];
-          xc[0] = fmaf(xv.x, y0, xc[0]);
-          xc[1] = fmaf(xv.x, y1, xc[1]);
-          xc[2] = fmaf(xv.x, y2, xc[2]);
-          xc[0] = fmaf(xv.y, y1, xc[0]);
-          xc[1] = fmaf(xv.y, y2, xc[1]);
-          xc[2] = fmaf(xv.y, y3, xc[2]);
-          xc[0] = fmaf(xv.z, y2, xc[0]);
-          xc[1] = fmaf(xv.z, y3, xc[1]);
-          xc[2] = fmaf(xv.z, y4v, xc[2]);
-          xc[0] = fmaf(xv.w, y3, xc[0]);
-          xc[1] = fmaf(xv.w, y4v, xc[1]);
-          xc[2] = fmaf(xv.w, y5, xc[2]);
-          y0 = y4v;
-          y1 = y5;
+        // all 14 x 2 window loads of a lane are requested before the first one is used (a `for (i = lane; ...)` loop
+        // with the bound test in it compiled to load - wait - load - wait per trip: 27 exposed round trips per frame)
+        float2 v[14];
+        float x0[14];
+  #pragma unroll
+        for (int k = 0; k < 14; ++k) {
+          const int i = min(lane + WAVE * k, 863);
+          v[k] = *reinterpret_cast<const float2*>(pb + 2 * i);
+          x0[k] = pb[2 * i - 1];                      // i = 0 reads the (valid) sample before the buffer, zeroed below
+        }
+  #pragma unroll
+        for (int k = 0; k < 14; ++k) {
+          const int i = lane + WAVE * k;
+          const float xm = i > 0 ? x0[k] : 0.f;
+          if (i < 864) lp[i] = .5f * (.5f * (xm + v[k].y) + v[k].x);
         }
       }
-      STAMP(1)
-      // Syy of find_best_pitch: Syy(lag) = 1 + sum_{j=lag}^{lag+239} y4[j]^2 from a wave prefix sum.
-      // (the reference's running update is the same quantity; its max(1, .) clamp only guards rounding)
+      rn_sync<NW>();
+      // Each lane owns 14 consecutive half-rate samples (plus a 5-sample halo) in registers: the same window feeds
+      // the autocorrelation partial sums (lags 0..4) and, once the LPC is known, the 5-tap FIR -- no second pass of
+      // LDS reads.  Samples outside [0, 864) are zero, which is also what the reference's `i >= k` guard amounts to.
+      float lpc2[5];
+      const int base = lane * 14;
+      float w[19];
+  #pragma unroll
+      for (int q = 0; q < 19; ++q) {
+        const int idx = base - 5 + q;
+        w[q] = (idx >= 0 && idx < 864) ? lp[idx] : 0.f;
+      }
       {
-        float loc[7];
-        float run = 0.f;
-#pragma unroll
-        for (int q = 0; q < 7; ++q) {
-          const int j = 7 * lane + q;
-          const float v = j < 392 ? y4[j] : 0.f;
-          loc[q] = run;          // exclusive
-          run = fmaf(v, v, run);
+        float ac[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  #pragma unroll
+        for (int q = 0; q < 14; ++q) {
+  #pragma unroll
+          for (int k = 0; k <= 4; ++k) ac[k] = fmaf(w[q + 5], w[q + 5 - k], ac[k]);
         }
-        float incl = run;
-#pragma unroll
-        for (int off = 1; off < WAVE; off <<= 1) {
-          const float o = __shfl_up(incl, off, WAVE);
-          if (lane >= off) incl += o;
-        }
-        const float excl = incl - run;
-        __syncthreads();  // every lane has read its y4 values before pre overwrites the region
-#pragma unroll
-        for (int q = 0; q < 7; ++q)
-          if (7 * lane + q < 392) pre[7 * lane + q] = excl + loc[q];
-      }
-      __syncthreads();
-      // this lane's best two candidates, in lag order
-      Cand c0 = {-1.f, 0.f, 1 << 20}, c1 = {-1.f, 0.f, 1 << 20};
-      int nvalid = 0;
-#pragma unroll
-      for (int rr = 0; rr < 3; ++rr) {
-        const int lag = 3 * lane + rr;
-        if (lag < 147 && xc[rr] > 0.f) {
-          const float syy = fmaxf(1.f, 1.f + (pre[lag + 240] - pre[lag]));
-          const float x16 = xc[rr] * 1e-12f;
-          const Cand c = {x16 * x16, syy, lag};
-          ++nvalid;
-          if (cand_better(c, c0)) { c1 = c0; c0 = c; }
-          else if (cand_better(c, c1)) c1 = c;
-        }
-      }
-      const int total_valid = __popcll(__ballot(nvalid > 0)) == 0 ? 0 : (int)wave_sum((float)nvalid);
-      const Cand w0 = wave_best(c0);
-      const Cand mine = (c0.idx == w0.idx) ? c1 : c0;   // the winner's lane offers its runner-up
-      const Cand w1 = wave_best(mine);
-      if (total_valid == 0) { best0 = 0; best1 = 1; }
-      else if (total_valid == 1) { best0 = w0.idx; best1 = 0; }
-      else { best0 = w0.idx; best1 = w1.idx; }
-    }
-    __syncthreads();
-    STAMP(2)
-
-    // ---- 3. fine search at half rate around the two coarse candidates ----
-    float* fine = Sa;  // 294 (+2 guard) correlation values, zero where not evaluated
-    for (int i = lane; i < 296; i += WAVE) fine[i] = 0.f;
-    __syncthreads();
-    {
-      const int ca = 2 * min(best0, best1), cb = 2 * max(best0, best1);
-      Cand bestc = {-1.f, 0.f, 0};
-      bool any = false;
-      // all (up to) ten lags ca-2..ca+2, cb-2..cb+2 in one pass; skipped ones are computed at lag 0 and ignored
-      int lagi[10];
-      bool use[10];
-      const float* yr[10];
-#pragma unroll
-      for (int q = 0; q < 10; ++q) {
-        const int pass = q / 5, d = q % 5 - 2;
-        const int i = (pass == 0 ? ca : cb) + d;
-        use[q] = !(i < 0 || i >= 294) && !(pass == 1 && abs(i - ca) <= 2);
-        lagi[q] = use[q] ? i : 0;
-        yr[q] = lp + lagi[q] + lane;
-      }
-      float sxy[10], syy[10];
-      lag_dots<10, true>(lp + 384 + lane, yr, lane, sxy, syy);
-#pragma unroll
-      for (int q = 0; q < 10; ++q) {
-        if (use[q]) {
-          const float syq = fmaxf(1.f, 1.f + syy[q]);
-          const float xv = fmaxf(-1.f, sxy[q]);
-          if (lane == 0) fine[lagi[q]] = xv;
-          if (xv > 0.f) {
-            const float x16 = xv * 1e-12f;
-            const Cand c = {x16 * x16, syq, lagi[q]};
-            if (!any || cand_better(c, bestc)) { bestc = c; any = true; }
-          }
-        }
-      }
-      __syncthreads();
-      const int bp = any ? bestc.idx : 0;
-      int offset = 0;
-      if (bp > 0 && bp < 293) {
-        const float fa = fine[bp - 1], fb = fine[bp], fc = fine[bp + 1];
-        if ((fc - fa) > .7f * (fb - fa)) offset = 1;
-        else if ((fa - fc) > .7f * (fb - fc)) offset = -1;
-      }
-      pitch_index = 768 - (2 * bp - offset);
-    }
-    __syncthreads();
-    STAMP(3)
-    if (DBG && a.dbg && t == a.T - 1) {
-      float* D = a.dbg + (long)b * RN_DBG_FLOATS;
-      for (int i = lane; i < 864; i += WAVE) D[984 + i] = lp[i];
-      if (lane == 0) D[1848] = (float)pitch_index;
-#ifndef RN_PROFILE
-      for (int i = lane; i < 480; i += WAVE) D[3824 + i] = xw[480 + i];
-#endif
-    }
-
-    // ---- 4. remove_doubling at half rate (maxperiod 384, minperiod 30, N 480) ----
-    {
-      const float* x = lp + 384;
-      int T0 = pitch_index / 2;
-      const int prev_period = last_period / 2;
-      if (T0 >= 384) T0 = 383;
-      int T = T0;
-      float xx, xy;
-      {
-        const float* yr[2] = {x + lane, x - T0 + lane};
-        float sa[2], sb[2];
-        lag_dots<2, false>(x + lane, yr, lane, sa, sb);
-        xx = sa[0];
-        xy = sa[1];
-      }
-      // yy_lookup[m] = max(0, xx + sum_{q<=m} (x[-q]^2 - x[480-q]^2)) via a wave prefix sum
-      float* yyl = Sa + 296;  // 385 entries
-      {
-        float loc[6];
-        float run = 0.f;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-          const int m = 6 * lane + 1 + q;
-          const float u = x[-m], v = x[480 - m];
-          run += u * u - v * v;
-          loc[q] = run;
-        }
-        float incl = run;
-#pragma unroll
-        for (int off = 1; off < WAVE; off <<= 1) {
-          const float o = __shfl_up(incl, off, WAVE);
-          if (lane >= off) incl += o;
-        }
-        const float excl = incl - run;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) yyl[6 * lane + 1 + q] = fmaxf(0.f, xx + (excl + loc[q]));
-        if (lane == 0) yyl[0] = xx;
-      }
-      __syncthreads();
-      float yy = yyl[T0];
-      float best_xy = xy, best_yy = yy;
-      const float g0 = xy / sqrtf(1.f + xx * yy);
-      float g = g0;
-      // The candidate lags depend on T0 only, so the (up to) 28 inner products are taken in chunks of four k
-      // (eight lags) with independent accumulation chains and reductions; T1 falls with k, so the reference's
-      // `break` at T1 < 30 is a prefix: a chunk is skipped when its first k is already out, and the sequential
-      // threshold logic below runs on the stored sums.
-      float xyk_[14], yyk_[14];
-      int T1_[14];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int k0 = 2 + 4 * c;
-        if ((2 * T0 + k0) / (2 * k0) >= 30) {
-          constexpr int NKC = 4;
-          const float* yr[2 * NKC];
-          int t1[NKC], t1b[NKC];
-#pragma unroll
-          for (int q = 0; q < NKC; ++q) {
-            const int k = k0 + q;
-            t1[q] = 0; t1b[q] = 0;
-            if (k <= 15) {
-              const int T1 = (2 * T0 + k) / (2 * k);
-              if (T1 >= 30) {
-                t1[q] = T1;
-                if (k == 2) t1b[q] = (T1 + T0 > 384) ? T0 : T0 + T1;
-                else t1b[q] = (2 * c_second_check[k] * T0 + k) / (2 * k);
+        wave_sums<5>(ac);
+        ac[0] *= 1.0001f;
+  #pragma unroll
+        for (int k = 1; k <= 4; ++k) ac[k] -= ac[k] * (.008f * k) * (.008f * k);
+        float lpc[4] = {0.f, 0.f, 0.f, 0.f};
+        float error = ac[0];
+        if (ac[0] != 0.f) {
+          bool done = false;
+  #pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (!done) {
+              float rr = 0.f;
+  #pragma unroll
+              for (int j = 0; j < i; ++j) rr += lpc[j] * ac[i - j];
+              rr += ac[i + 1];
+              const float r = -rr / error;
+              lpc[i] = r;
+  #pragma unroll
+              for (int j = 0; j < (i + 1) >> 1; ++j) {
+                const float t1 = lpc[j], t2 = lpc[i - 1 - j];
+                lpc[j] = t1 + r * t2;
+                lpc[i - 1 - j] = t2 + r * t1;
               }
-            }
-            yr[2 * q] = x - t1[q] + lane;
-            yr[2 * q + 1] = x - t1b[q] + lane;
-          }
-          float sa[2 * NKC], sb[2 * NKC];
-          lag_dots<2 * NKC, false>(x + lane, yr, lane, sa, sb);
-#pragma unroll
-          for (int q = 0; q < NKC; ++q) {
-            if (k0 + q <= 15) {
-              T1_[k0 + q - 2] = t1[q];
-              xyk_[k0 + q - 2] = .5f * (sa[2 * q] + sa[2 * q + 1]);
-              yyk_[k0 + q - 2] = .5f * (yyl[t1[q]] + yyl[t1b[q]]);
+              error = error - r * r * error;
+              if (error < .001f * ac[0]) done = true;
             }
           }
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (k0 + q <= 15) { T1_[k0 + q - 2] = 0; xyk_[k0 + q - 2] = 0.f; yyk_[k0 + q - 2] = 0.f; }
         }
-      }
-      // The threshold test of candidate k depends on k, T0, g0 and the previous frame only, never on the running best,
-      // and the reference's loop keeps the *last* k that passes: so lane k - 2 evaluates candidate k (one square root
-      // and one division per lane instead of fourteen of each in every lane, one after the other) and the highest
-      // passing lane wins.  Same operations per candidate, bit-identical decisions.
-      {
-        int T1 = 0;
-        float xyk = 0.f, yyk = 0.f;
-#pragma unroll
-        for (int k = 2; k <= 15; ++k) {
-          const bool mine = lane == k - 2;
-          T1 = mine ? T1_[k - 2] : T1;
-          xyk = mine ? xyk_[k - 2] : xyk;
-          yyk = mine ? yyk_[k - 2] : yyk;
+        float tmp = 1.f;
+  #pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          tmp = .9f * tmp;
+          lpc[i] = lpc[i] * tmp;
         }
-        const int k = lane + 2;
-        const float g1 = xyk / sqrtf(1.f + xx * yyk);
-        float cont;
-        if (abs(T1 - prev_period) <= 1) cont = last_gain;
-        else if (abs(T1 - prev_period) <= 2 && 5 * k * k < T0) cont = .5f * last_gain;
-        else cont = 0.f;
-        float thresh = fmaxf(.3f, .7f * g0 - cont);
-        if (T1 < 90) thresh = fmaxf(.4f, .85f * g0 - cont);
-        else if (T1 < 60) thresh = fmaxf(.5f, .9f * g0 - cont);
-        const unsigned long long pass = __ballot(lane < 14 && T1 >= 30 && g1 > thresh);
-        if (pass != 0ull) {
-          const int w = 63 - __builtin_clzll(pass);   // wave-uniform: the largest k that passes
-          best_xy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xyk), w));
-          best_yy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(yyk), w));
-          T = __builtin_amdgcn_readlane(T1, w);
-          g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g1), w));
-        }
-      }
-      best_xy = fmaxf(0.f, best_xy);
-      float pgv = (best_yy <= best_xy) ? 1.f : best_xy / (best_yy + 1.f);
-      float xc3[3];
-      {
-        const float* yr[3] = {x - (T - 1) + lane, x - T + lane, x - (T + 1) + lane};
-        float sb[3];
-        lag_dots<3, false>(x + lane, yr, lane, xc3, sb);
-      }
-      int offset = 0;
-      if ((xc3[2] - xc3[0]) > .7f * (xc3[1] - xc3[0])) offset = 1;
-      else if ((xc3[0] - xc3[2]) > .7f * (xc3[1] - xc3[2])) offset = -1;
-      if (pgv > g) pgv = g;
-      pitch_index = 2 * T + offset;
-      if (pitch_index < 60) pitch_index = 60;
-      pitch_gain = pgv;
-      last_period = pitch_index;
-      last_gain = pgv;
-    }
-    __syncthreads();
-    STAMP(4)
-    lane = lane0;
-    asm volatile("" : "+v"(lane));
-    RN_LANE_RANGE(5);
-
-    // ---- 5. frame_analysis: window, 960-point real FFT (in A), band energies (partials in Bb) ----
-    // complex point n = (x[2n], x[2n+1]) times the window; points >= 240 sit in the mirrored half of the window
-    fft480_from(L.A, [&](int j, int r) {
-      const int n = j + 120 * r;
-      const float2 v = *reinterpret_cast<const float2*>(xw + 2 * n);
-      const float w0 = r < 2 ? hw[2 * n] : hw[959 - 2 * n];
-      const float w1 = r < 2 ? hw[2 * n + 1] : hw[958 - 2 * n];
-      return make_float2(v.x * w0, v.y * w1);
-    }, w960, lane);
-    real_fwd_post(L.A, w960, lane);
-    STAMP(5)
-    band_pairs<false>(L.A, nullptr, Rb, L.Ex, nullptr, nullptr, tab, be, lane);
-    STAMP(6)
-    lane = lane0;
-    asm volatile("" : "+v"(lane));
-    RN_LANE_RANGE(6);
-    if (DBG && a.dbg && t == a.T - 1) {
-      float* D = a.dbg + (long)b * RN_DBG_FLOATS;
-      for (int i = lane; i < 962; i += WAVE) D[0 + i] = Xf[i];
-      if (lane < RN_NB) D[962 + lane] = L.Ex[lane];
-    }
-
-    // ---- 6. pitch frame: window, FFT (in Bb), band energy / correlation (partials in U) ----
-    {
-      const float* pp = pb + (768 - pitch_index);
-      fft480_from(L.Bb, [&](int j, int r) {
-        const int n = j + 120 * r;
-        const float w0 = r < 2 ? hw[2 * n] : hw[959 - 2 * n];
-        const float w1 = r < 2 ? hw[2 * n + 1] : hw[958 - 2 * n];
-        return make_float2(pp[2 * n] * w0, pp[2 * n + 1] * w1);
-      }, w960, lane);
-    }
-    real_fwd_post(L.Bb, w960, lane);
-    STAMP(7)
-    // band energy of P, band correlation with X, and P parked in L2 from the same registers (read back by the comb
-    // filter, which needs bins < 400 only); Bb becomes the RNN workspace
-    band_pairs<true>(L.Bb, L.A, L.U, L.Ep, L.Exp, nullptr, tab, be, lane);
-    if (DBG && a.dbg && t == a.T - 1) {
-      float* D = a.dbg + (long)b * RN_DBG_FLOATS;
-      const float* Pf = reinterpret_cast<const float*>(L.Bb);
-      for (int i = lane; i < 962; i += WAVE) D[1856 + i] = Pf[i];
-    }
-    __syncthreads();
-    STAMP(8)
-    lane = lane0;
-    asm volatile("" : "+v"(lane));
-    RN_LANE_RANGE(7);
-
-    // ---- 7. features (Appendix A.3 step 5) ----
-    // this lane's column of the DCT table serves both transforms; issued first so that the L2 round trip
-    // overlaps the band normalisation below
-    float dctc[RN_NB];
-    {
-      const float* __restrict__ dcol = tab->dct + min(lane, RN_NB - 1);
-#pragma unroll
-      for (int j = 0; j < RN_NB; ++j) dctc[j] = dcol[j * RN_NB];
-    }
-    if (lane < RN_NB) {
-      L.Exp[lane] = L.Exp[lane] / sqrtf(.001f + L.Ex[lane] * L.Ep[lane]);
-      L.U[U_LY + lane] = log10f(1e-2f + L.Ex[lane]);
-    }
-    __syncthreads();
-    if (DBG && a.dbg && t == a.T - 1 && lane < RN_NB) {
-      float* D = a.dbg + (long)b * RN_DBG_FLOATS;
-      D[2818 + lane] = L.Ep[lane];
-      D[2840 + lane] = L.Exp[lane];
-    }
-    const float dct_norm = 0.30151134457776363f;  // sqrt(2/22)
-    float E = 0.f;
-    float se = 0.f, sl = 0.f;
-    {
-      // The band follower is a 22-step recurrence: every lane runs it on broadcast reads and feeds its own DCT
-      // sums on the way -- of the followed log energies (22 coefficients) and of the band correlation (6), which
-      // share this lane's table column.
-      float logMax = -2.f, follow = -2.f;
-#pragma unroll
-      for (int i = 0; i < RN_NB; ++i) {
-        float ly = L.U[U_LY + i];
-        ly = fmaxf(logMax - 7.f, fmaxf(follow - 1.5f, ly));
-        logMax = fmaxf(logMax, ly);
-        follow = fmaxf(follow - 1.5f, ly);
-        E += L.Ex[i];
-        sl = fmaf(ly, dctc[i], sl);
-        se = fmaf(L.Exp[i], dctc[i], se);
-        if (i % 4 == 3) {   // bound the live ranges: all 66 broadcast reads hoisted to the top would spill
-          asm volatile("" : "+v"(sl), "+v"(se), "+v"(E), "+v"(logMax), "+v"(follow));
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    }
-    {
-      if (lane < 6) {
-        float v = se * dct_norm;
-        if (lane == 0) v -= 1.3f;
-        if (lane == 1) v -= 0.9f;
-        Rb[KB_FEAT + 34 + lane] = v;
-      }
-      if (lane == 6) Rb[KB_FEAT + 40] = .01f * (float)(pitch_index - 300);
-      silence = E < 0.04f;
-      if (!silence && lane < RN_NB) {
-        float v = sl * dct_norm;
-        if (lane == 0) v -= 12.f;
-        if (lane == 1) v -= 4.f;
-        Rb[KB_FEAT + lane] = v;
-        L.ceps[memid * RN_NB + lane] = v;
-      }
-    }
-    __syncthreads();
-    if (silence) {
-      if (lane < RN_NFEAT) Rb[KB_FEAT + lane] = 0.f;
-      if (lane < RN_NB) L.U[U_G + lane] = 0.f;
-      __syncthreads();
-    } else {
-      {
-        const int m1 = (memid < 1) ? 8 + memid - 1 : memid - 1;
-        const int m2 = (memid < 2) ? 8 + memid - 2 : memid - 2;
-        if (lane < 6) {
-          const float c0 = L.ceps[memid * RN_NB + lane];
-          const float c1 = L.ceps[m1 * RN_NB + lane];
-          const float c2 = L.ceps[m2 * RN_NB + lane];
-          Rb[KB_FEAT + lane] = c0 + c1 + c2;
-          Rb[KB_FEAT + RN_NB + lane] = c0 - c2;
-          Rb[KB_FEAT + RN_NB + 6 + lane] = c0 - 2.f * c1 + c2;
-        }
-        memid = (memid + 1 == 8) ? 0 : memid + 1;
+        lpc2[0] = lpc[0] + .8f;
+        lpc2[1] = lpc[1] + .8f * lpc[0];
+        lpc2[2] = lpc[2] + .8f * lpc[1];
+        lpc2[3] = lpc[3] + .8f * lpc[2];
+        lpc2[4] = .8f * lpc[3];
       }
       {
-        // spectral variability: lane = 8*i + j holds ||ceps_i - ceps_j||^2; min over j within each group of 8
-        // lanes and the sum over the 8 groups by DPP (every lane of a group ends up with the group minimum, so
-        // the wave sum counts each minimum eight times)
-        const int ci = lane >> 3, cj = lane & 7;
-        float dist = 0.f;
-#pragma unroll
-        for (int k = 0; k < RN_NB; ++k) {
-          const float d = L.ceps[ci * RN_NB + k] - L.ceps[cj * RN_NB + k];
-          dist = fmaf(d, d, dist);
+        // 5-tap FIR in place from the register window
+        float y[14];
+  #pragma unroll
+        for (int q = 0; q < 14; ++q) {
+          float sum = w[q + 5];
+          sum = fmaf(lpc2[0], w[q + 4], sum);
+          sum = fmaf(lpc2[1], w[q + 3], sum);
+          sum = fmaf(lpc2[2], w[q + 2], sum);
+          sum = fmaf(lpc2[3], w[q + 1], sum);
+          sum = fmaf(lpc2[4], w[q], sum);
+          y[q] = sum;
         }
-        float md = (ci == cj) ? 1e15f : dist;
-        md = fminf(md, dpp_mov<0xB1>(md));     // quad_perm [1,0,3,2]
-        md = fminf(md, dpp_mov<0x4E>(md));     // quad_perm [2,3,0,1]
-        md = fminf(md, dpp_mov<0x141>(md));    // row_half_mirror: the other quad of the group of 8
-        const float sv = wave_sum(md) * .125f;
-        if (lane == 0) Rb[KB_FEAT + 41] = sv / 8.f - 2.1f;
+        rn_sync<NW>();
+  #pragma unroll
+        for (int q = 0; q < 14; ++q)
+          if (base + q < 864) lp[base + q] = y[q];
+        rn_sync<NW>();
       }
-      __syncthreads();
-      STAMP(9)
-    }
-
-
-    if (!silence) {
-      lane = lane0;
-      asm volatile("" : "+v"(lane));   // (lane re-laundered: per-lane addresses of later stages are otherwise computed early / shared with earlier
-      RN_LANE_RANGE(1);
-      // stages and stay live across the gain network, which is where registers are scarcest)
-      // ---- 8. RNN (vectors in Bb) ----
-      const float S = 1.f / 256.f;
-      float* feat = Rb + KB_FEAT;
-      float* dense = Rb + PL_DENSE;
-      float* zbuf = Rb + PL_Z;
-      TansigTab tansig;
-      tansig.load(tab->tansig, lane);
-      // signed-digit int8 images of the layer inputs (in_img) and of the recurrent operand (st_img)
-      signed char* in_img = reinterpret_cast<signed char*>(L.U + PL_U_FREE);
-      signed char* st_img = reinterpret_cast<signed char*>(Xf + PL_A_FREE);
-      const int toff = (lane & 3) * RN_IMG8_LD;
-      RnScale sc = image_i8<48>(in_img, lane, [&](int i) { return i < RN_NFEAT ? feat[i] : 0.f; });
-      __syncthreads();
-      {
-        const int row = min(lane, 23);
-        const float acc = dot_i<rn_k16(42), 24>(wrs, RnPack8::ID_W, row, in_img, toff, sc.dn, wpf[RnPack::ID_B + row]);
-        const float d = tansig_approx(S * acc, tansig);
-        if (lane < 24) dense[lane] = d;
-      }
-      __syncthreads();
-      sc = image_i8<32>(in_img, lane, [&](int i) { return i < 24 ? dense[i] : 0.f; });
-      gru_layer_i<24, 24>(wrs, RnPack8::VG_W, RnPack8::VG_R, wpf + RnPack::VG_B, in_img, sc.dn,
-                          L.rnn_state, zbuf, st_img, toff, tansig, lane);
-      {
-        float acc = 0.f;
-        if (lane == 0) {
-          acc = wpf[RnPack::VO_B];
-          acc = dot_vad(wrs, RnPack::VO_W, L.rnn_state, acc);
-        }
-        const float v = sigmoid_approx(S * acc, tansig);
-        if (lane == 0) L.U[U_VAD] = v;
-      }
-      sc = image_i8<96>(in_img, lane, [&](int i) {
-        return i < 24 ? dense[i] : (i < 48 ? L.rnn_state[i - 24] : (i < 90 ? feat[i - 48] : 0.f)); });
-      __syncthreads();
-      vad_prob = L.U[U_VAD];
-      STAMP(10)
-      gru_layer_i<90, 48>(wrs, RnPack8::NG_W, RnPack8::NG_R, wpf + RnPack::NG_B, in_img, sc.dn,
-                          L.rnn_state + 24, zbuf, st_img, toff, tansig, lane);
-      STAMP(11)
-      sc = image_i8<128>(in_img, lane, [&](int i) { return i < 72 ? L.rnn_state[i] : (i < 114 ? feat[i - 72] : 0.f); });
-      __syncthreads();
-      gru_layer_i<114, 96>(wrs, RnPack8::DG_W, RnPack8::DG_R, wpf + RnPack::DG_B, in_img, sc.dn,
-                           L.rnn_state + 72, zbuf, st_img, toff, tansig, lane);
-      sc = image_i8<96>(st_img, lane, [&](int i) { return L.rnn_state[72 + i]; });
-      __syncthreads();
-      {
-        const int row = min(lane, RN_NB - 1);
-        const float acc = dot_i<rn_k16(96), RN_NB>(wrs, RnPack8::DO_W, row, st_img, toff, sc.dn, wpf[RnPack::DO_B + row]);
-        const float gv = sigmoid_approx(S * acc, tansig);
-        if (lane < RN_NB) L.U[U_G + lane] = gv;
-      }
-      __syncthreads();
-      STAMP(12)
-
+      STAMP(0)
       lane = lane0;
       asm volatile("" : "+v"(lane));
-      RN_LANE_RANGE(2);
-      // ---- 9. pitch_filter + gain application (Appendix A.3 step 7) ----
-      // Pair layout: lane handles bins (2p, 2p+1), p = lane + 64 m -- one ds_read_b128 / one 16-byte global load
-      // per pair at a 16-byte lane stride (conflict-free, coalesced), and a pair never straddles a band (edges are
-      // multiples of 4 bins).  The new band energies are summed from the registers of the comb-filter pass.
-      // (Keeping X in registers up to the final gains as well costs 16 VGPRs across two barriers and spills.)
-      float2 fq[4];
-      int bq[4];
+      RN_LANE_RANGE(4);
+
+      // ---- 2. pitch_search: 4x-decimated coarse search over 147 lags (scratch in A) ----
+      float* x4 = Sa;        // 240
+      float* y4 = Sa + 240;  // 387 (+ guard to 392)
+      float* pre = Sa;       // 392: exclusive prefix sums of y4^2, written after x4/y4 are dead (aliases them)
       {
-        float4 pq[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {       // parked pitch spectrum and the per-bin tables: issued before r is ready
-          const int pidx = min(lane + WAVE * m, 199);
-          pq[m] = *reinterpret_cast<const float4*>(L.Bb + 2 * pidx);
-          fq[m] = *reinterpret_cast<const float2*>(tab->bin_frac + 2 * pidx);
-          bq[m] = tab->bin_band[2 * pidx];
+        // reads of all trips first (clamped indices): as `for (j = lane; ...) x4[j] = lp[...]` loops every trip was an
+        // LDS read - wait - write round trip, eleven in a row
+        float vx[4], vy[7];
+  #pragma unroll
+        for (int m = 0; m < 4; ++m) vx[m] = lp[384 + 2 * min(lane + WAVE * m, 239)];
+  #pragma unroll
+        for (int m = 0; m < 7; ++m) vy[m] = lp[2 * min(lane + WAVE * m, 386)];
+  #pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int j = lane + WAVE * m;
+          if (j < 240) x4[j] = vx[m];
         }
-        if (lane < RN_NB) {
-          const float ex = L.Exp[lane], gg = L.U[U_G + lane];
-          float r;
-          if (ex > gg) r = 1.f;
-          else r = (ex * ex) * (1.f - gg * gg) / (.001f + (gg * gg) * (1.f - ex * ex));
-          r = sqrtf(fminf(1.f, fmaxf(0.f, r)));
-          r *= sqrtf(L.Ex[lane] / (1e-8f + L.Ep[lane]));
-          L.U[U_R + lane] = r;
+  #pragma unroll
+        for (int m = 0; m < 7; ++m) {
+          const int j = lane + WAVE * m;
+          if (j < 392) y4[j] = j < 387 ? vy[m] : 0.f;
         }
-        __syncthreads();
-        float* part = Xf + PL_A_FREE;
-        float* part_hi = L.U + PL_U_FREE;
-#pragma unroll
+      }
+      rn_sync<NW>();
+      int best0, best1;
+      {
+        // lane owns the three consecutive lags 3*lane + {0,1,2} (lanes 0..48): the y window slides through registers,
+        // one new LDS read per step instead of three (lane stride 3 floats: conflict-free), x broadcast as float4
+        float xc[3] = {0.f, 0.f, 0.f};
+        {
+          const float4* xv4 = reinterpret_cast<const float4*>(x4);
+          const float* yp = y4 + 3 * min(lane, 48);      // reads reach y4[3*48 + 2 + 239] = y4[385] < 387
+          float y0 = yp[0], y1 = yp[1];
+  #pragma unroll 4
+          for (int j4 = 0; j4 < 60; ++j4) {
+            const float4 xv = xv4[j4];
+            const int j = 4 * j4;
+            const float y2 = yp[j + 2], y3 = yp[j + 3], y4v = yp[j + 4], y5 = yp[j + 5];
+            xc[0] = fmaf(xv.x, y0, xc[0]);
+            xc[1] = fmaf(xv.x, y1, xc[1]);
+            xc[2] = fmaf(xv.x, y2, xc[2]);
+            xc[0] = fmaf(xv.y, y1, xc[0]);
+            xc[1] = fmaf(xv.y, y2, xc[1]);
+            xc[2] = fmaf(xv.y, y3, xc[2]);
+            xc[0] = fmaf(xv.z, y2, xc[0]);
+            xc[1] = fmaf(xv.z, y3, xc[1]);
+            xc[2] = fmaf(xv.z, y4v, xc[2]);
+            xc[0] = fmaf(xv.w, y3, xc[0]);
+            xc[1] = fmaf(xv.w, y4v, xc[1]);
+            xc[2] = fmaf(xv.w, y5, xc[2]);
+            y0 = y4v;
+            y1 = y5;
+          }
+        }
+        STAMP(1)
+        // Syy of find_best_pitch: Syy(lag) = 1 + sum_{j=lag}^{lag+239} y4[j]^2 from a wave prefix sum.
+        // (the reference's running update is the same quantity; its max(1, .) clamp only guards rounding)
+        {
+          float loc[7];
+          float run = 0.f;
+  #pragma unroll
+          for (int q = 0; q < 7; ++q) {
+            const int j = 7 * lane + q;
+            const float v = j < 392 ? y4[j] : 0.f;
+            loc[q] = run;          // exclusive
+            run = fmaf(v, v, run);
+          }
+          float incl = run;
+  #pragma unroll
+          for (int off = 1; off < WAVE; off <<= 1) {
+            const float o = __shfl_up(incl, off, WAVE);
+            if (lane >= off) incl += o;
+          }
+          const float excl = incl - run;
+          rn_sync<NW>();  // every lane has read its y4 values before pre overwrites the region
+  #pragma unroll
+          for (int q = 0; q < 7; ++q)
+            if (7 * lane + q < 392) pre[7 * lane + q] = excl + loc[q];
+        }
+        rn_sync<NW>();
+        // this lane's best two candidates, in lag order
+        Cand c0 = {-1.f, 0.f, 1 << 20}, c1 = {-1.f, 0.f, 1 << 20};
+        int nvalid = 0;
+  #pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+          const int lag = 3 * lane + rr;
+          if (lag < 147 && xc[rr] > 0.f) {
+            const float syy = fmaxf(1.f, 1.f + (pre[lag + 240] - pre[lag]));
+            const float x16 = xc[rr] * 1e-12f;
+            const Cand c = {x16 * x16, syy, lag};
+            ++nvalid;
+            if (cand_better(c, c0)) { c1 = c0; c0 = c; }
+            else if (cand_better(c, c1)) c1 = c;
+          }
+        }
+        const int total_valid = __popcll(__ballot(nvalid > 0)) == 0 ? 0 : (int)wave_sum((float)nvalid);
+        const Cand w0 = wave_best(c0);
+        const Cand mine = (c0.idx == w0.idx) ? c1 : c0;   // the winner's lane offers its runner-up
+        const Cand w1 = wave_best(mine);
+        if (total_valid == 0) { best0 = 0; best1 = 1; }
+        else if (total_valid == 1) { best0 = w0.idx; best1 = 0; }
+        else { best0 = w0.idx; best1 = w1.idx; }
+      }
+      rn_sync<NW>();
+      STAMP(2)
+
+      // ---- 3. fine search at half rate around the two coarse candidates ----
+      float* fine = Sa;  // 294 (+2 guard) correlation values, zero where not evaluated
+      for (int i = lane; i < 296; i += WAVE) fine[i] = 0.f;
+      rn_sync<NW>();
+      {
+        const int ca = 2 * min(best0, best1), cb = 2 * max(best0, best1);
+        Cand bestc = {-1.f, 0.f, 0};
+        bool any = false;
+        // all (up to) ten lags ca-2..ca+2, cb-2..cb+2 in one pass; skipped ones are computed at lag 0 and ignored
+        int lagi[10];
+        bool use[10];
+        const float* yr[10];
+  #pragma unroll
+        for (int q = 0; q < 10; ++q) {
+          const int pass = q / 5, d = q % 5 - 2;
+          const int i = (pass == 0 ? ca : cb) + d;
+          use[q] = !(i < 0 || i >= 294) && !(pass == 1 && abs(i - ca) <= 2);
+          lagi[q] = use[q] ? i : 0;
+          yr[q] = lp + lagi[q] + lane;
+        }
+        float sxy[10], syy[10];
+        lag_dots<10, true>(lp + 384 + lane, yr, lane, sxy, syy);
+  #pragma unroll
+        for (int q = 0; q < 10; ++q) {
+          if (use[q]) {
+            const float syq = fmaxf(1.f, 1.f + syy[q]);
+            const float xv = fmaxf(-1.f, sxy[q]);
+            if (lane == 0) fine[lagi[q]] = xv;
+            if (xv > 0.f) {
+              const float x16 = xv * 1e-12f;
+              const Cand c = {x16 * x16, syq, lagi[q]};
+              if (!any || cand_better(c, bestc)) { bestc = c; any = true; }
+            }
+          }
+        }
+        rn_sync<NW>();
+        const int bp = any ? bestc.idx : 0;
+        int offset = 0;
+        if (bp > 0 && bp < 293) {
+          const float fa = fine[bp - 1], fb = fine[bp], fc = fine[bp + 1];
+          if ((fc - fa) > .7f * (fb - fa)) offset = 1;
+          else if ((fa - fc) > .7f * (fb - fc)) offset = -1;
+        }
+        pitch_index = 768 - (2 * bp - offset);
+      }
+      rn_sync<NW>();
+      STAMP(3)
+      if (DBG && a.dbg && t == a.T - 1) {
+        float* D = a.dbg + (long)b * RN_DBG_FLOATS;
+        for (int i = lane; i < 864; i += WAVE) D[984 + i] = lp[i];
+        if (lane == 0) D[1848] = (float)pitch_index;
+  #ifndef RN_PROFILE
+        for (int i = lane; i < 480; i += WAVE) D[3824 + i] = xw[480 + i];
+  #endif
+      }
+
+      // ---- 4. remove_doubling at half rate (maxperiod 384, minperiod 30, N 480) ----
+      {
+        const float* x = lp + 384;
+        int T0 = pitch_index / 2;
+        const int prev_period = last_period / 2;
+        if (T0 >= 384) T0 = 383;
+        int T = T0;
+        float xx, xy;
+        {
+          const float* yr[2] = {x + lane, x - T0 + lane};
+          float sa[2], sb[2];
+          lag_dots<2, false>(x + lane, yr, lane, sa, sb);
+          xx = sa[0];
+          xy = sa[1];
+        }
+        // yy_lookup[m] = max(0, xx + sum_{q<=m} (x[-q]^2 - x[480-q]^2)) via a wave prefix sum
+        float* yyl = Sa + 296;  // 385 entries
+        {
+          float loc[6];
+          float run = 0.f;
+  #pragma unroll
+          for (int q = 0; q < 6; ++q) {
+            const int m = 6 * lane + 1 + q;
+            const float u = x[-m], v = x[480 - m];
+            run += u * u - v * v;
+            loc[q] = run;
+          }
+          float incl = run;
+  #pragma unroll
+          for (int off = 1; off < WAVE; off <<= 1) {
+            const float o = __shfl_up(incl, off, WAVE);
+            if (lane >= off) incl += o;
+          }
+          const float excl = incl - run;
+  #pragma unroll
+          for (int q = 0; q < 6; ++q) yyl[6 * lane + 1 + q] = fmaxf(0.f, xx + (excl + loc[q]));
+          if (lane == 0) yyl[0] = xx;
+        }
+        rn_sync<NW>();
+        float yy = yyl[T0];
+        float best_xy = xy, best_yy = yy;
+        const float g0 = xy / sqrtf(1.f + xx * yy);
+        float g = g0;
+        // The candidate lags depend on T0 only, so the (up to) 28 inner products are taken in chunks of four k
+        // (eight lags) with independent accumulation chains and reductions; T1 falls with k, so the reference's
+        // `break` at T1 < 30 is a prefix: a chunk is skipped when its first k is already out, and the sequential
+        // threshold logic below runs on the stored sums.
+        float xyk_[14], yyk_[14];
+        int T1_[14];
+  #pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int k0 = 2 + 4 * c;
+          if ((2 * T0 + k0) / (2 * k0) >= 30) {
+            constexpr int NKC = 4;
+            const float* yr[2 * NKC];
+            int t1[NKC], t1b[NKC];
+  #pragma unroll
+            for (int q = 0; q < NKC; ++q) {
+              const int k = k0 + q;
+              t1[q] = 0; t1b[q] = 0;
+              if (k <= 15) {
+                const int T1 = (2 * T0 + k) / (2 * k);
+                if (T1 >= 30) {
+                  t1[q] = T1;
+                  if (k == 2) t1b[q] = (T1 + T0 > 384) ? T0 : T0 + T1;
+                  else t1b[q] = (2 * c_second_check[k] * T0 + k) / (2 * k);
+                }
+              }
+              yr[2 * q] = x - t1[q] + lane;
+              yr[2 * q + 1] = x - t1b[q] + lane;
+            }
+            float sa[2 * NKC], sb[2 * NKC];
+            lag_dots<2 * NKC, false>(x + lane, yr, lane, sa, sb);
+  #pragma unroll
+            for (int q = 0; q < NKC; ++q) {
+              if (k0 + q <= 15) {
+                T1_[k0 + q - 2] = t1[q];
+                xyk_[k0 + q - 2] = .5f * (sa[2 * q] + sa[2 * q + 1]);
+                yyk_[k0 + q - 2] = .5f * (yyl[t1[q]] + yyl[t1b[q]]);
+              }
+            }
+          } else {
+  #pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (k0 + q <= 15) { T1_[k0 + q - 2] = 0; xyk_[k0 + q - 2] = 0.f; yyk_[k0 + q - 2] = 0.f; }
+          }
+        }
+        // The threshold test of candidate k depends on k, T0, g0 and the previous frame only, never on the running best,
+        // and the reference's loop keeps the *last* k that passes: so lane k - 2 evaluates candidate k (one square root
+        // and one division per lane instead of fourteen of each in every lane, one after the other) and the highest
+        // passing lane wins.  Same operations per candidate, bit-identical decisions.
+        {
+          int T1 = 0;
+          float xyk = 0.f, yyk = 0.f;
+  #pragma unroll
+          for (int k = 2; k <= 15; ++k) {
+            const bool mine = lane == k - 2;
+            T1 = mine ? T1_[k - 2] : T1;
+            xyk = mine ? xyk_[k - 2] : xyk;
+            yyk = mine ? yyk_[k - 2] : yyk;
+          }
+          const int k = lane + 2;
+          const float g1 = xyk / sqrtf(1.f + xx * yyk);
+          float cont;
+          if (abs(T1 - prev_period) <= 1) cont = last_gain;
+          else if (abs(T1 - prev_period) <= 2 && 5 * k * k < T0) cont = .5f * last_gain;
+          else cont = 0.f;
+          float thresh = fmaxf(.3f, .7f * g0 - cont);
+          if (T1 < 90) thresh = fmaxf(.4f, .85f * g0 - cont);
+          else if (T1 < 60) thresh = fmaxf(.5f, .9f * g0 - cont);
+          const unsigned long long pass = __ballot(lane < 14 && T1 >= 30 && g1 > thresh);
+          if (pass != 0ull) {
+            const int w = 63 - __builtin_clzll(pass);   // wave-uniform: the largest k that passes
+            best_xy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xyk), w));
+            best_yy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(yyk), w));
+            T = __builtin_amdgcn_readlane(T1, w);
+            g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g1), w));
+          }
+        }
+        best_xy = fmaxf(0.f, best_xy);
+        float pgv = (best_yy <= best_xy) ? 1.f : best_xy / (best_yy + 1.f);
+        float xc3[3];
+        {
+          const float* yr[3] = {x - (T - 1) + lane, x - T + lane, x - (T + 1) + lane};
+          float sb[3];
+          lag_dots<3, false>(x + lane, yr, lane, xc3, sb);
+        }
+        int offset = 0;
+        if ((xc3[2] - xc3[0]) > .7f * (xc3[1] - xc3[0])) offset = 1;
+        else if ((xc3[0] - xc3[2]) > .7f * (xc3[1] - xc3[2])) offset = -1;
+        if (pgv > g) pgv = g;
+        pitch_index = 2 * T + offset;
+        if (pitch_index < 60) pitch_index = 60;
+        pitch_gain = pgv;
+        last_period = pitch_index;
+        last_gain = pgv;
+      }
+      rn_sync<NW>();
+      STAMP(4)
+      if constexpr (NW > 1) {
+        if (lane == 0) { L.pitch_index[t & 1] = pitch_index; L.pitch_gain[t & 1] = pitch_gain; }
+      }
+    }
+    if (own_b) {      // ======== stage 2: spectra, band energies, features ========
+      if constexpr (NW > 1) {
+        pitch_index = __builtin_amdgcn_readfirstlane(L.pitch_index[t & 1]);
+        pitch_gain = L.pitch_gain[t & 1];
+      }
+      lane = lane0;
+      asm volatile("" : "+v"(lane));
+      RN_LANE_RANGE(5);
+
+      // ---- 5. frame_analysis: window, 960-point real FFT (in A), band energies (partials in Bb) ----
+      // complex point n = (x[2n], x[2n+1]) times the window; points >= 240 sit in the mirrored half of the window
+      fft480_from<NW>(SL.A, [&](int j, int r) {
+        const int n = j + 120 * r;
+        const float2 v = *reinterpret_cast<const float2*>(xw + 2 * n);
+        const float w0 = r < 2 ? hw[2 * n] : hw[959 - 2 * n];
+        const float w1 = r < 2 ? hw[2 * n + 1] : hw[958 - 2 * n];
+        return make_float2(v.x * w0, v.y * w1);
+      }, w960, lane);
+      real_fwd_post<NW>(SL.A, w960, lane);
+      STAMP(5)
+      band_pairs<NW, false>(SL.A, nullptr, Rb, SL.Ex, nullptr, nullptr, tab, be, lane);
+      STAMP(6)
+      lane = lane0;
+      asm volatile("" : "+v"(lane));
+      RN_LANE_RANGE(6);
+      if (DBG && a.dbg && t == a.T - 1) {
+        float* D = a.dbg + (long)b * RN_DBG_FLOATS;
+        for (int i = lane; i < 962; i += WAVE) D[0 + i] = Xf[i];
+        if (lane < RN_NB) D[962 + lane] = SL.Ex[lane];
+      }
+
+      // ---- 6. pitch frame: window, FFT (in Bb), band energy / correlation (partials in U) ----
+      {
+        const float* pp = pb + (768 - pitch_index);
+        fft480_from<NW>(SL.Bb, [&](int j, int r) {
+          const int n = j + 120 * r;
+          const float w0 = r < 2 ? hw[2 * n] : hw[959 - 2 * n];
+          const float w1 = r < 2 ? hw[2 * n + 1] : hw[958 - 2 * n];
+          return make_float2(pp[2 * n] * w0, pp[2 * n + 1] * w1);
+        }, w960, lane);
+      }
+      real_fwd_post<NW>(SL.Bb, w960, lane);
+      STAMP(7)
+      // band energy of P, band correlation with X, and P parked in L2 from the same registers (read back by the comb
+      // filter, which needs bins < 400 only); Bb becomes the RNN workspace
+      band_pairs<NW, true>(SL.Bb, SL.A, SL.U, SL.Ep, SL.Exp, nullptr, tab, be, lane);
+      if (DBG && a.dbg && t == a.T - 1) {
+        float* D = a.dbg + (long)b * RN_DBG_FLOATS;
+        const float* Pf = reinterpret_cast<const float*>(SL.Bb);
+        for (int i = lane; i < 962; i += WAVE) D[1856 + i] = Pf[i];
+      }
+      rn_sync<NW>();
+      STAMP(8)
+      lane = lane0;
+      asm volatile("" : "+v"(lane));
+      RN_LANE_RANGE(7);
+
+      // ---- 7. features (Appendix A.3 step 5) ----
+      // this lane's column of the DCT table serves both transforms; issued first so that the L2 round trip
+      // overlaps the band normalisation below
+      float dctc[RN_NB];
+      {
+        const float* __restrict__ dcol = tab->dct + min(lane, RN_NB - 1);
+  #pragma unroll
+        for (int j = 0; j < RN_NB; ++j) dctc[j] = dcol[j * RN_NB];
+      }
+      if (lane < RN_NB) {
+        SL.Exp[lane] = SL.Exp[lane] / sqrtf(.001f + SL.Ex[lane] * SL.Ep[lane]);
+        SL.U[U_LY + lane] = log10f(1e-2f + SL.Ex[lane]);
+      }
+      rn_sync<NW>();
+      if (DBG && a.dbg && t == a.T - 1 && lane < RN_NB) {
+        float* D = a.dbg + (long)b * RN_DBG_FLOATS;
+        D[2818 + lane] = SL.Ep[lane];
+        D[2840 + lane] = SL.Exp[lane];
+      }
+      const float dct_norm = 0.30151134457776363f;  // sqrt(2/22)
+      float E = 0.f;
+      float se = 0.f, sl = 0.f;
+      {
+        // The band follower is a 22-step recurrence: every lane runs it on broadcast reads and feeds its own DCT
+        // sums on the way -- of the followed log energies (22 coefficients) and of the band correlation (6), which
+        // share this lane's table column.
+        float logMax = -2.f, follow = -2.f;
+  #pragma unroll
+        for (int i = 0; i < RN_NB; ++i) {
+          float ly = SL.U[U_LY + i];
+          ly = fmaxf(logMax - 7.f, fmaxf(follow - 1.5f, ly));
+          logMax = fmaxf(logMax, ly);
+          follow = fmaxf(follow - 1.5f, ly);
+          E += SL.Ex[i];
+          sl = fmaf(ly, dctc[i], sl);
+          se = fmaf(SL.Exp[i], dctc[i], se);
+          if (i % 4 == 3) {   // bound the live ranges: all 66 broadcast reads hoisted to the top would spill
+            asm volatile("" : "+v"(sl), "+v"(se), "+v"(E), "+v"(logMax), "+v"(follow));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      {
+        if (lane < 6) {
+          float v = se * dct_norm;
+          if (lane == 0) v -= 1.3f;
+          if (lane == 1) v -= 0.9f;
+          Rb[KB_FEAT + 34 + lane] = v;
+        }
+        if (lane == 6) Rb[KB_FEAT + 40] = .01f * (float)(pitch_index - 300);
+        silence = E < 0.04f;
+        if (!silence && lane < RN_NB) {
+          float v = sl * dct_norm;
+          if (lane == 0) v -= 12.f;
+          if (lane == 1) v -= 4.f;
+          Rb[KB_FEAT + lane] = v;
+          L.ceps[memid * RN_NB + lane] = v;
+        }
+      }
+      rn_sync<NW>();
+      if (silence) {
+        if (lane < RN_NFEAT) Rb[KB_FEAT + lane] = 0.f;
+        if (lane < RN_NB) SL.U[U_G + lane] = 0.f;
+        rn_sync<NW>();
+      } else {
+        {
+          const int m1 = (memid < 1) ? 8 + memid - 1 : memid - 1;
+          const int m2 = (memid < 2) ? 8 + memid - 2 : memid - 2;
+          if (lane < 6) {
+            const float c0 = L.ceps[memid * RN_NB + lane];
+            const float c1 = L.ceps[m1 * RN_NB + lane];
+            const float c2 = L.ceps[m2 * RN_NB + lane];
+            Rb[KB_FEAT + lane] = c0 + c1 + c2;
+            Rb[KB_FEAT + RN_NB + lane] = c0 - c2;
+            Rb[KB_FEAT + RN_NB + 6 + lane] = c0 - 2.f * c1 + c2;
+          }
+          memid = (memid + 1 == 8) ? 0 : memid + 1;
+        }
+        {
+          // spectral variability: lane = 8*i + j holds ||ceps_i - ceps_j||^2; min over j within each group of 8
+          // lanes and the sum over the 8 groups by DPP (every lane of a group ends up with the group minimum, so
+          // the wave sum counts each minimum eight times)
+          const int ci = lane >> 3, cj = lane & 7;
+          float dist = 0.f;
+  #pragma unroll
+          for (int k = 0; k < RN_NB; ++k) {
+            const float d = L.ceps[ci * RN_NB + k] - L.ceps[cj * RN_NB + k];
+            dist = fmaf(d, d, dist);
+          }
+          float md = (ci == cj) ? 1e15f : dist;
+          md = fminf(md, dpp_mov<0xB1>(md));     // quad_perm [1,0,3,2]
+          md = fminf(md, dpp_mov<0x4E>(md));     // quad_perm [2,3,0,1]
+          md = fminf(md, dpp_mov<0x141>(md));    // row_half_mirror: the other quad of the group of 8
+          const float sv = wave_sum(md) * .125f;
+          if (lane == 0) Rb[KB_FEAT + 41] = sv / 8.f - 2.1f;
+        }
+        rn_sync<NW>();
+        STAMP(9)
+      }
+      if constexpr (NW > 1) {
+        if (lane == 0) { SL.pitch_index = pitch_index; SL.pitch_gain = pitch_gain; SL.silence = silence ? 1 : 0; }
+      }
+    }
+    if (own_c) {      // ======== stage 3: gain network, pitch filter, synthesis ========
+      if constexpr (NW > 1) {
+        pitch_index = __builtin_amdgcn_readfirstlane(SL.pitch_index);
+        pitch_gain = SL.pitch_gain;
+        silence = __builtin_amdgcn_readfirstlane(SL.silence) != 0;
+      }
+      if (!silence) {
+        lane = lane0;
+        asm volatile("" : "+v"(lane));   // (lane re-laundered: per-lane addresses of later stages are otherwise computed early / shared with earlier
+        RN_LANE_RANGE(1);
+        // stages and stay live across the gain network, which is where registers are scarcest)
+        // ---- 8. RNN (vectors in Bb) ----
+        const float S = 1.f / 256.f;
+        float* feat = Rb + KB_FEAT;
+        float* dense = Rb + PL_DENSE;
+        float* zbuf = Rb + PL_Z;
+        TansigTab tansig;
+        tansig.load(tab->tansig, lane);
+        // signed-digit int8 images of the layer inputs (in_img) and of the recurrent operand (st_img)
+        signed char* in_img = reinterpret_cast<signed char*>(SL.U + PL_U_FREE);
+        signed char* st_img = reinterpret_cast<signed char*>(Xf + PL_A_FREE);
+        const int toff = (lane & 3) * RN_IMG8_LD;
+        RnScale sc = image_i8<48>(in_img, lane, [&](int i) { return i < RN_NFEAT ? feat[i] : 0.f; });
+        rn_sync<NW>();
+        {
+          const int row = min(lane, 23);
+          const float acc = dot_i<rn_k16(42), 24>(wrs, RnPack8::ID_W, row, in_img, toff, sc.dn, wpf[RnPack::ID_B + row]);
+          const float d = tansig_approx(S * acc, tansig);
+          if (lane < 24) dense[lane] = d;
+        }
+        rn_sync<NW>();
+        sc = image_i8<32>(in_img, lane, [&](int i) { return i < 24 ? dense[i] : 0.f; });
+        gru_layer_i<NW, 24, 24>(wrs, RnPack8::VG_W, RnPack8::VG_R, wpf + RnPack::VG_B, in_img, sc.dn,
+                            L.rnn_state, zbuf, st_img, toff, tansig, lane);
+        {
+          float acc = 0.f;
+          if (lane == 0) {
+            acc = wpf[RnPack::VO_B];
+            acc = dot_vad(wrs, RnPack::VO_W, L.rnn_state, acc);
+          }
+          const float v = sigmoid_approx(S * acc, tansig);
+          if (lane == 0) SL.U[U_VAD] = v;
+        }
+        sc = image_i8<96>(in_img, lane, [&](int i) {
+          return i < 24 ? dense[i] : (i < 48 ? L.rnn_state[i - 24] : (i < 90 ? feat[i - 48] : 0.f)); });
+        rn_sync<NW>();
+        vad_prob = SL.U[U_VAD];
+        STAMP(10)
+        gru_layer_i<NW, 90, 48>(wrs, RnPack8::NG_W, RnPack8::NG_R, wpf + RnPack::NG_B, in_img, sc.dn,
+                            L.rnn_state + 24, zbuf, st_img, toff, tansig, lane);
+        STAMP(11)
+        sc = image_i8<128>(in_img, lane, [&](int i) { return i < 72 ? L.rnn_state[i] : (i < 114 ? feat[i - 72] : 0.f); });
+        rn_sync<NW>();
+        gru_layer_i<NW, 114, 96>(wrs, RnPack8::DG_W, RnPack8::DG_R, wpf + RnPack::DG_B, in_img, sc.dn,
+                             L.rnn_state + 72, zbuf, st_img, toff, tansig, lane);
+        sc = image_i8<96>(st_img, lane, [&](int i) { return L.rnn_state[72 + i]; });
+        rn_sync<NW>();
+        {
+          const int row = min(lane, RN_NB - 1);
+          const float acc = dot_i<rn_k16(96), RN_NB>(wrs, RnPack8::DO_W, row, st_img, toff, sc.dn, wpf[RnPack::DO_B + row]);
+          const float gv = sigmoid_approx(S * acc, tansig);
+          if (lane < RN_NB) SL.U[U_G + lane] = gv;
+        }
+        rn_sync<NW>();
+        STAMP(12)
+
+        lane = lane0;
+        asm volatile("" : "+v"(lane));
+        RN_LANE_RANGE(2);
+        // ---- 9. pitch_filter + gain application (Appendix A.3 step 7) ----
+        // Pair layout: lane handles bins (2p, 2p+1), p = lane + 64 m -- one ds_read_b128 / one 16-byte global load
+        // per pair at a 16-byte lane stride (conflict-free, coalesced), and a pair never straddles a band (edges are
+        // multiples of 4 bins).  The new band energies are summed from the registers of the comb-filter pass.
+        // (Keeping X in registers up to the final gains as well costs 16 VGPRs across two barriers and spills.)
+        float2 fq[4];
+        int bq[4];
+        {
+          float4 pq[4];
+  #pragma unroll
+          for (int m = 0; m < 4; ++m) {       // parked pitch spectrum and the per-bin tables: issued before r is ready
+            const int pidx = min(lane + WAVE * m, 199);
+            pq[m] = *reinterpret_cast<const float4*>(SL.Bb + 2 * pidx);
+            fq[m] = *reinterpret_cast<const float2*>(tab->bin_frac + 2 * pidx);
+            bq[m] = tab->bin_band[2 * pidx];
+          }
+          if (lane < RN_NB) {
+            const float ex = SL.Exp[lane], gg = SL.U[U_G + lane];
+            float r;
+            if (ex > gg) r = 1.f;
+            else r = (ex * ex) * (1.f - gg * gg) / (.001f + (gg * gg) * (1.f - ex * ex));
+            r = sqrtf(fminf(1.f, fmaxf(0.f, r)));
+            r *= sqrtf(SL.Ex[lane] / (1e-8f + SL.Ep[lane]));
+            SL.U[U_R + lane] = r;
+          }
+          rn_sync<NW>();
+          float* part = Xf + PL_A_FREE;
+          float* part_hi = SL.U + PL_U_FREE;
+  #pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const int pidx = lane + WAVE * m;
+            if (pidx < 200) {
+              const float r0 = SL.U[U_R + bq[m]], r1 = SL.U[U_R + bq[m] + 1];
+              const float rf0 = (1.f - fq[m].x) * r0 + fq[m].x * r1;
+              const float rf1 = (1.f - fq[m].y) * r0 + fq[m].y * r1;
+              float4 x = *reinterpret_cast<const float4*>(SL.A + 2 * pidx);
+              x.x = fmaf(rf0, pq[m].x, x.x);
+              x.y = fmaf(rf0, pq[m].y, x.y);
+              x.z = fmaf(rf1, pq[m].z, x.z);
+              x.w = fmaf(rf1, pq[m].w, x.w);
+              *reinterpret_cast<float4*>(SL.A + 2 * pidx) = x;
+              float e0 = x.x * x.x; e0 += x.y * x.y;
+              float e1 = x.z * x.z; e1 += x.w * x.w;
+              float lo = (1.f - fq[m].x) * e0 + (1.f - fq[m].y) * e1;
+              float hi = fq[m].x * e0 + fq[m].y * e1;
+              lo = dpp_add<0xB1>(lo);        // the other pair of this 4-bin chunk sits in the neighbouring lane
+              hi = dpp_add<0xB1>(hi);
+              if ((lane & 1) == 0) { part[pidx >> 1] = lo; part_hi[pidx >> 1] = hi; }
+            }
+          }
+        }
+        rn_sync<NW>();
+        float sum;
+        {                          // new band energies (Ep is dead): every lane takes part (band_sum splits a band over two lanes)
+          const float* part = Xf + PL_A_FREE;
+          const float* part_hi = SL.U + PL_U_FREE;
+          sum = band_sum(part, part_hi, be, lane);
+        }
+        if (lane < RN_NB) {        // the renormalisation and the smoothed gains
+          SL.U[U_R + lane] = sqrtf(SL.Ex[lane] / (1e-8f + sum));  // norm
+          const float gg = fmaxf(SL.U[U_G + lane], .6f * lastg);
+          SL.U[U_G + lane] = gg;
+          lastg = gg;
+        }
+        rn_sync<NW>();
+        // band values and spectrum pairs of all four trips first (bq / indices are always valid: clamped where they
+        // were made), so that the trips do not each wait for their own LDS reads
+        float nq[4][2], gq[4][2];
+        float4 xq[4];
+  #pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          nq[m][0] = SL.U[U_R + bq[m]]; nq[m][1] = SL.U[U_R + bq[m] + 1];
+          gq[m][0] = SL.U[U_G + bq[m]]; gq[m][1] = SL.U[U_G + bq[m] + 1];
+          xq[m] = *reinterpret_cast<const float4*>(SL.A + 2 * min(lane + WAVE * m, 199));
+        }
+  #pragma unroll
         for (int m = 0; m < 4; ++m) {
           const int pidx = lane + WAVE * m;
           if (pidx < 200) {
-            const float r0 = L.U[U_R + bq[m]], r1 = L.U[U_R + bq[m] + 1];
-            const float rf0 = (1.f - fq[m].x) * r0 + fq[m].x * r1;
-            const float rf1 = (1.f - fq[m].y) * r0 + fq[m].y * r1;
-            float4 x = *reinterpret_cast<const float4*>(L.A + 2 * pidx);
-            x.x = fmaf(rf0, pq[m].x, x.x);
-            x.y = fmaf(rf0, pq[m].y, x.y);
-            x.z = fmaf(rf1, pq[m].z, x.z);
-            x.w = fmaf(rf1, pq[m].w, x.w);
-            *reinterpret_cast<float4*>(L.A + 2 * pidx) = x;
-            float e0 = x.x * x.x; e0 += x.y * x.y;
-            float e1 = x.z * x.z; e1 += x.w * x.w;
-            float lo = (1.f - fq[m].x) * e0 + (1.f - fq[m].y) * e1;
-            float hi = fq[m].x * e0 + fq[m].y * e1;
-            lo = dpp_add<0xB1>(lo);        // the other pair of this 4-bin chunk sits in the neighbouring lane
-            hi = dpp_add<0xB1>(hi);
-            if ((lane & 1) == 0) { part[pidx >> 1] = lo; part_hi[pidx >> 1] = hi; }
+            const float n0 = nq[m][0], n1 = nq[m][1];
+            const float g0 = gq[m][0], g1 = gq[m][1];
+            const float nf0 = (1.f - fq[m].x) * n0 + fq[m].x * n1, nf1 = (1.f - fq[m].y) * n0 + fq[m].y * n1;
+            const float gf0 = (1.f - fq[m].x) * g0 + fq[m].x * g1, gf1 = (1.f - fq[m].y) * g0 + fq[m].y * g1;
+            float4 x = xq[m];
+            x.x *= nf0; x.y *= nf0; x.z *= nf1; x.w *= nf1;
+            x.x *= gf0; x.y *= gf0; x.z *= gf1; x.w *= gf1;
+            *reinterpret_cast<float4*>(SL.A + 2 * pidx) = x;
+          }
+        }
+        for (int i = 400 + lane; i < RN_NFREQ; i += WAVE) SL.A[i] = make_float2(0.f, 0.f);   // above 20 kHz
+        rn_sync<NW>();
+      }
+      STAMP(13)
+
+      // ---- taps / debug ----
+      if (DBG && a.taps) {
+        float* tp = a.taps + ((long)t * a.B + b) * RN_TAPS;
+        if (lane < RN_NFEAT) tp[lane] = Rb[KB_FEAT + lane];
+        if (lane < RN_NB) tp[42 + lane] = SL.U[U_G + lane];
+        if (lane == 0) {
+          tp[64] = (float)pitch_index;
+          tp[65] = pitch_gain;
+          tp[66] = vad_prob;
+          tp[67] = silence ? 1.f : 0.f;
+          tp[68] = tp[69] = tp[70] = tp[71] = 0.f;
+        }
+      }
+      if (a.vad && lane == 0) a.vad[(long)t * a.B + b] = vad_prob;
+      if (DBG && a.dbg && t == a.T - 1) {
+        float* D = a.dbg + (long)b * RN_DBG_FLOATS;
+        for (int i = lane; i < 962; i += WAVE) D[2862 + i] = Xf[i];
+      }
+      rn_sync<NW>();
+
+      lane = lane0;
+      asm volatile("" : "+v"(lane));
+      RN_LANE_RANGE(3);
+      // ---- 10. frame_synthesis: inverse FFT, window, overlap-add ----
+      real_inv_pre<NW>(SL.A, w960, lane);
+      fft480<NW>(SL.A, w960, lane);
+      STAMP(14)
+      {
+        float* o = a.out + (long)t * a.stride_t + (long)b * a.stride_b;
+        float2 hwa[4], hwb[4];                  // window values of all four trips, requested together
+  #pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int n = min(lane + WAVE * m, 239);
+          hwa[m] = *reinterpret_cast<const float2*>(hw + 2 * n);          // hw[i0], hw[i1]
+          hwb[m] = *reinterpret_cast<const float2*>(hw + 478 - 2 * n);    // hw[479 - i1], hw[479 - i0]
+        }
+  #pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int n = lane + WAVE * m;
+          if (n < 240) {
+            const float2 z = SL.A[n];
+            const float2 z2 = SL.A[240 + n];
+            const int i0 = 2 * n;
+            float2 ov;
+            ov.x = fmaf(z.x, hwa[m].x, synth[m].x);
+            ov.y = fmaf(-z.y, hwa[m].y, synth[m].y);
+            // the output is never read back here: non-temporal stores keep it from allocating in L2 next to the history
+            // window and the parked spectrum (-1.1 KB of fetches per stream-frame, time unchanged)
+            __builtin_nontemporal_store(ov.x, o + i0); __builtin_nontemporal_store(ov.y, o + i0 + 1);
+            synth[m].x = z2.x * hwb[m].y;
+            synth[m].y = -z2.y * hwb[m].x;
           }
         }
       }
-      __syncthreads();
-      float sum;
-      {                          // new band energies (Ep is dead): every lane takes part (band_sum splits a band over two lanes)
-        const float* part = Xf + PL_A_FREE;
-        const float* part_hi = L.U + PL_U_FREE;
-        sum = band_sum(part, part_hi, be, lane);
-      }
-      if (lane < RN_NB) {        // the renormalisation and the smoothed gains
-        L.U[U_R + lane] = sqrtf(L.Ex[lane] / (1e-8f + sum));  // norm
-        const float gg = fmaxf(L.U[U_G + lane], .6f * lastg);
-        L.U[U_G + lane] = gg;
-        lastg = gg;
-      }
-      __syncthreads();
-      // band values and spectrum pairs of all four trips first (bq / indices are always valid: clamped where they
-      // were made), so that the trips do not each wait for their own LDS reads
-      float nq[4][2], gq[4][2];
-      float4 xq[4];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        nq[m][0] = L.U[U_R + bq[m]]; nq[m][1] = L.U[U_R + bq[m] + 1];
-        gq[m][0] = L.U[U_G + bq[m]]; gq[m][1] = L.U[U_G + bq[m] + 1];
-        xq[m] = *reinterpret_cast<const float4*>(L.A + 2 * min(lane + WAVE * m, 199));
-      }
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int pidx = lane + WAVE * m;
-        if (pidx < 200) {
-          const float n0 = nq[m][0], n1 = nq[m][1];
-          const float g0 = gq[m][0], g1 = gq[m][1];
-          const float nf0 = (1.f - fq[m].x) * n0 + fq[m].x * n1, nf1 = (1.f - fq[m].y) * n0 + fq[m].y * n1;
-          const float gf0 = (1.f - fq[m].x) * g0 + fq[m].x * g1, gf1 = (1.f - fq[m].y) * g0 + fq[m].y * g1;
-          float4 x = xq[m];
-          x.x *= nf0; x.y *= nf0; x.z *= nf1; x.w *= nf1;
-          x.x *= gf0; x.y *= gf0; x.z *= gf1; x.w *= gf1;
-          *reinterpret_cast<float4*>(L.A + 2 * pidx) = x;
-        }
-      }
-      for (int i = 400 + lane; i < RN_NFREQ; i += WAVE) L.A[i] = make_float2(0.f, 0.f);   // above 20 kHz
-      __syncthreads();
+      rn_sync<NW>();
+      STAMP(15)
     }
-    STAMP(13)
-
-    // ---- taps / debug ----
-    if (DBG && a.taps) {
-      float* tp = a.taps + ((long)t * a.B + b) * RN_TAPS;
-      if (lane < RN_NFEAT) tp[lane] = Rb[KB_FEAT + lane];
-      if (lane < RN_NB) tp[42 + lane] = L.U[U_G + lane];
-      if (lane == 0) {
-        tp[64] = (float)pitch_index;
-        tp[65] = pitch_gain;
-        tp[66] = vad_prob;
-        tp[67] = silence ? 1.f : 0.f;
-        tp[68] = tp[69] = tp[70] = tp[71] = 0.f;
-      }
-    }
-    if (a.vad && lane == 0) a.vad[(long)t * a.B + b] = vad_prob;
-    if (DBG && a.dbg && t == a.T - 1) {
-      float* D = a.dbg + (long)b * RN_DBG_FLOATS;
-      for (int i = lane; i < 962; i += WAVE) D[2862 + i] = Xf[i];
-    }
-    __syncthreads();
-
-    lane = lane0;
-    asm volatile("" : "+v"(lane));
-    RN_LANE_RANGE(3);
-    // ---- 10. frame_synthesis: inverse FFT, window, overlap-add ----
-    real_inv_pre(L.A, w960, lane);
-    fft480(L.A, w960, lane);
-    STAMP(14)
-    {
-      float* o = a.out + (long)t * a.stride_t + (long)b * a.stride_b;
-      float2 hwa[4], hwb[4];                  // window values of all four trips, requested together
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int n = min(lane + WAVE * m, 239);
-        hwa[m] = *reinterpret_cast<const float2*>(hw + 2 * n);          // hw[i0], hw[i1]
-        hwb[m] = *reinterpret_cast<const float2*>(hw + 478 - 2 * n);    // hw[479 - i1], hw[479 - i0]
-      }
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int n = lane + WAVE * m;
-        if (n < 240) {
-          const float2 z = L.A[n];
-          const float2 z2 = L.A[240 + n];
-          const int i0 = 2 * n;
-          float2 ov;
-          ov.x = fmaf(z.x, hwa[m].x, synth[m].x);
-          ov.y = fmaf(-z.y, hwa[m].y, synth[m].y);
-          // the output is never read back here: non-temporal stores keep it from allocating in L2 next to the history
-          // window and the parked spectrum (-1.1 KB of fetches per stream-frame, time unchanged)
-          __builtin_nontemporal_store(ov.x, o + i0); __builtin_nontemporal_store(ov.y, o + i0 + 1);
-          synth[m].x = z2.x * hwb[m].y;
-          synth[m].y = -z2.y * hwb[m].x;
-        }
-      }
-    }
-    __syncthreads();
-    STAMP(15)
+    }      // this wave has a frame in this tick
+    if constexpr (NW > 1) __syncthreads();
   }
 
-  // ---- store per-stream state (each kernel of the staged pipeline owns its part) ----
-  {
-    // the synthesis kernel writes the OTHER tail buffer: group 0 of this launch may not have read this one yet
-    float* tail_out = synth_g;
+  // ---- store per-stream state (NW = 3: by the wave that owns it) ----
+  if (own_c) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int n = lane + WAVE * m;
-      if (n < 240) *reinterpret_cast<float2*>(tail_out + 2 * n) = synth[m];
+      if (n < 240) *reinterpret_cast<float2*>(synth_g + 2 * n) = synth[m];
     }
+    for (int i = lane; i < 168; i += WAVE) a.rnn[(long)b * 168 + i] = L.rnn_state[i];
+    if (lane < RN_NB) a.lastg[(long)b * RN_NB + lane] = lastg;
   }
-  for (int i = lane; i < 176; i += WAVE) a.ceps[(long)b * 176 + i] = L.ceps[i];
-  if (lane == 0) {
-    a.memid[b] = memid;
+  if (own_b) {
+    for (int i = lane; i < 176; i += WAVE) a.ceps[(long)b * 176 + i] = L.ceps[i];
+    if (lane == 0) a.memid[b] = memid;
+  }
+  if (own_a && lane == 0) {
     a.last_period[b] = last_period;
     a.last_gain[b] = last_gain;
   }
-  for (int i = lane; i < 168; i += WAVE) a.rnn[(long)b * 168 + i] = L.rnn_state[i];
-  if (lane < RN_NB) a.lastg[(long)b * RN_NB + lane] = lastg;
+}
+
+template <bool DBG>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VGPR_CAP void rn_frame_kernel(RnArgs a) {
+  rn_frame_body<DBG, 1>(a);
+}
+// Four waves per SIMD (<= 128 registers, what the one-wave form lives in too): five of these workgroups per CU, so that
+// 1024 streams are resident at once on 256 CUs with room to spare (six fit by their LDS).
+template <bool DBG>
+__global__ __launch_bounds__(3 * WAVE) __attribute__((amdgpu_waves_per_eu(4))) void rn_frame3_kernel(RnArgs a) {
+  rn_frame_body<DBG, 3>(a);
 }
 
 // =============================================================================================
@@ -1729,6 +1819,10 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4))) RN_VG
 __global__ __launch_bounds__(WAVE) RN_HP_VGPR_CAP void rn_highpass_kernel(RnArgs a) {
   const int b = blockIdx.x * WAVE + threadIdx.x;
   if (b >= a.B) return;
+  // One lane per stream, a chain of ten f64-path instructions per sample that nothing inside the wave can overlap: the
+  // frame kernels wait for it (with few streams it IS the critical path of a call), so this wave issues ahead of the
+  // frame waves that share its SIMD.
+  __builtin_amdgcn_s_setprio(3);
   const double a0h = 0.5 * (double)-1.99599f, a1 = (double)0.99600f;   // b = (-2, 1) is folded into the two fmas
   float m0 = a.hp_mem[2 * b], m1 = a.hp_mem[2 * b + 1];
   float* dst = a.xhp + (long)b * a.xhp_stride + RN_HIST;
@@ -1820,7 +1914,12 @@ hipError_t rn_launch_highpass(const RnArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(rn_highpass_kernel, dim3((a.B + WAVE - 1) / WAVE), dim3(WAVE), 0, s, a);
   return hipGetLastError();
 }
-hipError_t rn_launch_frames(const RnArgs& a, hipStream_t s) {
+hipError_t rn_launch_frames(const RnArgs& a, hipStream_t s, int waves_per_stream) {
+  if (waves_per_stream == 3) {
+    if (a.dbg || a.taps) hipLaunchKernelGGL((rn_frame3_kernel<true>), dim3(a.B), dim3(3 * WAVE), 0, s, a);
+    else hipLaunchKernelGGL((rn_frame3_kernel<false>), dim3(a.B), dim3(3 * WAVE), 0, s, a);
+    return hipGetLastError();
+  }
   if (a.dbg || a.taps) hipLaunchKernelGGL((rn_frame_kernel<true>), dim3(a.B), dim3(WAVE), 0, s, a);
   else hipLaunchKernelGGL((rn_frame_kernel<false>), dim3(a.B), dim3(WAVE), 0, s, a);
   return hipGetLastError();

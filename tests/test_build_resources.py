@@ -68,6 +68,13 @@ def test_frame_kernel_resource_budget(tmp_path, extra):
             loop = body.find("Loop Header: Depth=1")
         assert loop > 0, name
         assert "scratch_store" not in body[loop:], f"{name}: VGPR spill store inside the frame loop"
+    # the three-wave stage pipeline (<= 1280 streams): five workgroups per CU need <= 128 registers and <= 32 KB of LDS each
+    frame3 = {k: v for k, v in res.items() if "rn_frame3_kernel" in k}
+    assert len(frame3) == 2, list(res)
+    for name, r in frame3.items():
+        assert r["VGPRs"] + r.get("AGPRs", 0) <= 128, (name, r)
+        assert r["LDS Size"] <= 32 * 1024, (name, r)
+        assert r["ScratchSize"] == 0, (name, r)
     hp = {k: v for k, v in res.items() if "rn_highpass_kernel" in k}
     assert len(hp) == 1, list(res)
     for name, r in hp.items():

@@ -10,6 +10,15 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=["1", "3"], ids=["one_wave_per_stream", "three_wave_stage_pipeline"])
+def rn_waves(request, monkeypatch):
+    """Every test of this file runs against both forms of the frame kernel: one wave per stream (what a handle picks above
+    1280 streams) and the three-wave stage pipeline (what it picks up to there); CRISPY_RN_WAVES is read at create time."""
+    monkeypatch.setenv("CRISPY_RN_WAVES", request.param)
+    return request.param
+
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "rnnoise_golden.npz")
 REL = 1e-4
 
