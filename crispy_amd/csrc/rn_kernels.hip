@@ -363,7 +363,7 @@ struct BandEdges {
 // (lane - 32), one ds_bpermute joins them -- 24 select-and-add steps per call instead of 48 -- and the `k < n` tests
 // stay INLINE (`n` is laundered): they are invariant across frames, and hoisted out of the frame loop the compiler
 // turned them into 48 lane masks = 96 SGPRs, spilled into two VGPRs' lanes and fetched back with two v_readlane per
-// use: 416 of the kernel's 7 800 VALU instructions per frame were those v_readlane (ISA census).
+// use: 416 of the kernel's 7 800 VALU instructions per frame were those v_readlane (ISA census, NOTEBOOK.md section 4 v8).
 // The partials are *read* eight at a time (as plain `for (c = ...) sum += part[c]` loops every chunk was its own
 // LDS round trip); reads past a lane's range stay inside the workgroup's LDS and are replaced by 0.f.
 __device__ __forceinline__ float band_sum(const float* part_lo, const float* part_hi, const BandEdges& be, int lane) {

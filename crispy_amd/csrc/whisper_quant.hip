@@ -56,7 +56,7 @@ hipError_t dq_launch(const void* q, long n_blocks, int cols, void* dst, int dst_
   const unsigned char* qb = reinterpret_cast<const unsigned char*>(q);
   const int bpr = cols / 32;
   if (dst_f16) {
-    if (gamma) return hipErrorInvalidValue;      // the folded projections stay f32
+    if (gamma) return hipErrorInvalidValue;      // the folded projections stay f32 (NOTEBOOK.md section 4)
     hipLaunchKernelGGL((dequant_kernel<TT, true, false>), grid, block, 0, s, qb, n_blocks, bpr, dst, gamma);
   } else if (gamma) {
     hipLaunchKernelGGL((dequant_kernel<TT, false, true>), grid, block, 0, s, qb, n_blocks, bpr, dst, gamma);

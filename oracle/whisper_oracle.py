@@ -223,7 +223,7 @@ class DecoderCache:
         as f16 (kv_self); the attention outputs and the GELU'd hidden layer rounded to f16 against f16 weights
         (attn.out, cross_attn.out, mlp.2); the final LayerNorm rounded to f16 against the f16 token embedding.  The
         projections behind a LayerNorm (q | k | v, cross q, mlp.0) stay exact: the library folds the LayerNorm into
-        them and keeps them in f32."""
+        them and keeps them in f32 (NOTEBOOK.md section 4)."""
         self.W = _f64(weights, dtype)
         self.hp = hp
         self.f16 = f16

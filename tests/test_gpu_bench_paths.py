@@ -38,7 +38,7 @@ def test_cfg2_through_rccl_with_one_rank():
     assert line["n_gpus"] == 1 and len(line["per_rank_ms"]) == 1           # as RCCL's process group reports it
     assert line["config"]["output_finite"] and line["value"] > 8000       # the north-star floor, by a wide margin
     assert line["roofline"]["kernel"] == "rn_frame_kernel" and 0 < line["roofline"]["frac"] < 1
-    # RCCL initialised must not cost the step its stream concurrency (hardware queues)
+    # RCCL initialised must not cost the step its stream concurrency (NOTEBOOK.md section 5: hardware queues)
     assert line["ms_per_step"] < 1.25 * plain["ms_per_step"], (line["ms_per_step"], plain["ms_per_step"])
 
 

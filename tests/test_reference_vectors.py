@@ -62,7 +62,7 @@ def test_hip_process_frame_matches_nnnoiseless(case):
 
 def test_oracle_resampler_matches_rubato():
     """oracle/resample_oracle.py against rubato::FftFixedIn(48000, 16000, 1024, 1, 1) fed in 1024-sample calls
-    (commands/transcription.rs:198-208, 314-357) -- settles the buffering question DESIGN.md section 2 leaves open."""
+    (commands/transcription.rs:198-208, 314-357) -- settles the buffering question NOTEBOOK.md section 2 leaves open."""
     from oracle import resample_oracle as RO
     r = _man()["resampler"]
     if not os.path.exists(os.path.join(DIR, r["ref_out"])):
