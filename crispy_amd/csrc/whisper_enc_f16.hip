@@ -414,15 +414,15 @@ __device__ __forceinline__ void hd_epilogue(const HGemmArgs& g, f32x16 (&acc)[2]
 // LDS round trip instead of two (measured on the one-image form: 1 750 cycles from the first image write to the
 // hand-off and 1 790 from there to the last store -- each mostly queueing behind the other workgroup's k loop), and
 // the residual / positional operands of a pass are requested a whole pass ahead.
-template <int EPI>
-__device__ __forceinline__ void hd2_epilogue(const HGemmArgs& g, f32x16 (&acc)[4][2], float* T0, float* T1, int m0, int n0, int wm,
+template <int EPI, int MI>
+__device__ __forceinline__ void hd2_epilogue(const HGemmArgs& g, f32x16 (&acc)[MI][2], float* T0, float* T1, int m0, int n0, int wm,
                                              int wn, int lane, int bz, const float (&bias)[2]) {
   float4 ex[2][8];
   ep_prefetch<EPI>(g, ex[0], m0, n0, wm, wn, 0, lane, bz);
   ep_write<EPI>(g, acc[0], T0, lane, bias);
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    if (p + 1 < 4) {
+  for (int p = 0; p < MI; ++p) {
+    if (p + 1 < MI) {
       ep_prefetch<EPI>(g, ex[(p + 1) & 1], m0, n0, wm, wn, 32 * (p + 1), lane, bz);
       ep_write<EPI>(g, acc[p + 1], (p & 1) ? T0 : T1, lane, bias);     // its previous reader (pass p - 1) has issued its stores
     }
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
 constexpr int AT_KLD = 72;    // halfs per K row in LDS (64 + 8): 16-lane b128 reads spread over all banks
 constexpr int AT_VLD = 36;    // halfs per V^T row in LDS (32 + 4): b64 reads of 16 rows hit 16 distinct bank pairs
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void attn_enc_h_kernel(const _Float16* __restrict__ qk, const _Float16* __restrict__ vt,
-                                                         _Float16* __restrict__ out, int T, int D) {
+                                                         _Float16* __restrict__ out, int T, int D, int heads, int n_clips) {
   // K and V^T tiles of 32 keys are staged once per workgroup (the four waves work on the same clip and head) and
   // double buffered: the requests for tile i + 1 are in flight while tile i is computed, one barrier per tile.
   // ONE LDS object: [K stage 0 | K stage 1 | V^T stage 0 | V^T stage 1] = 4 x 4608 bytes.  The epilogue reuses all of it as
@@ -567,8 +567,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void a
   _Float16 (*Vs)[AT_VST] = reinterpret_cast<_Float16 (*)[AT_VST]>(at_lds + 2 * AT_KST);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y, heads = gridDim.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  // Workgroups go to the eight XCDs round-robin by linear id, and every XCD has its own L2: as a (query block, head, clip)
+  // grid the twelve query blocks of one (clip, head) landed on eight different L2s and its K | V^T -- 384 KB that all
+  // twelve read -- came from HBM up to eight times (rocprofv3 FETCH_SIZE, tiny, 64 clips: 1.28 GB per launch against
+  // 221 MB of q | k | V^T).  So: linear id L -> XCD L % 8, and the query blocks of a group are consecutive slots of ONE
+  // XCD: group = 8 (slot / nq) + xcd, query block = slot % nq (grid padded to whole groups of eight).
+  const int nq = (T + 127) / 128;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int grp = 8 * (slot / nq) + xcd;
+  if (grp >= heads * n_clips) return;
+  const int b = grp / heads, h = grp - b * heads;
+  const int q0 = (slot % nq) * 128 + wave * 32;
   const long ld = 2L * D;
   const _Float16* Qp = qk + (long)b * T * ld + h * 64;
   const _Float16* Kp = Qp + D;
@@ -727,10 +736,26 @@ __global__ void f32_to_f16_rows_kernel(const float* __restrict__ src, long lds, 
 // 72 KB of LDS (three stages of 16 + 8 KB), 2 workgroups per CU.  Same operand layout, swizzle and epilogue (the
 // wave's 128 rows go through the 32-row epilogue image as two 64-row halves).
 // ---------------------------------------------------------------------------------------------
-constexpr int HD2_M = 256, HD2_A_BYTES = HD2_M * HH_K * 2, HD2_STAGE_BYTES = HD2_A_BYTES + HD_TILE_BYTES;   // 16 + 8 KB
-template <int EPI>
+// MI = 32-row blocks per wave: 4 -> 256 x 128 tiles, 3 -> 192 x 128.  The shorter tile exists for the tail: 96 000 rows x
+// 384 columns are 1 125 tiles of 256 rows on 512 workgroup slots = 2.2 rounds, i.e. three rounds with the last one a
+// fifth full (out-projection, fc2, V^T); as 1 500 tiles of 192 rows they are 2.93 rounds of 3/4 the length (gemm_hh picks
+// the height that minimises rounds x height).
+constexpr int HD2_M = 256;      // the taller of the two
+// One LDS-DMA request of 16 bytes per lane.  A plain (non-template) function on purpose: inside anything that depends on
+// a template parameter -- a loop bound, a lambda of a kernel template -- the builtin fails to instantiate in hipcc's
+// HOST pass, where it does not exist, and takes the enclosing kernel's stub with it without a diagnostic.
+__device__ __forceinline__ void lds_dma16(const _Float16* src, unsigned char* dst) {
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  __builtin_amdgcn_global_load_lds(src, (lds_ptr)dst, 16, 0, 0);
+}
+template <int EM>      // EM = epilogue + 8 * MI (one parameter: hipcc's host pass leaves the stub of a two-parameter kernel template undefined)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_hd2_kernel(HGemmArgs g) {
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[HD_STAGES * HD2_STAGE_BYTES];   // [stage][A 256 rows | W 128 rows]
+  constexpr int EPI = EM & 7, MI = EM >> 3;
+  constexpr int TM = 64 * MI, A_BYTES = TM * HH_K * 2, STAGE_BYTES = A_BYTES + HD_TILE_BYTES;     // 16 | 12 KB + 8 KB
+  constexpr int NRD = 2 * MI + 4;                                                                   // operand reads per trip
+  constexpr int RING_BYTES = HD_STAGES * STAGE_BYTES, IMG_BYTES = 4 * 2 * EP_IMAGE_BYTES;
+  static_assert(MI == 3 || MI == 4, "192- or 256-row tiles");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[RING_BYTES > IMG_BYTES ? RING_BYTES : IMG_BYTES];   // [stage][A TM rows | W 128 rows]; then two epilogue images per wave
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   int bx = blockIdx.x, by = blockIdx.y;
   if (g.xcd_swizzle) {
@@ -739,21 +764,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     const int xcd = lin & 7, slot = lin >> 3;
     by = 8 * (slot / nt) + xcd;
     bx = slot % nt;
-    if (by * HD2_M >= g.M) return;
+    if (by * TM >= g.M) return;
   }
   const int bz = blockIdx.z;
   const _Float16* __restrict__ A = g.A + (long)bz * g.strideA;
   const _Float16* __restrict__ W = g.W;
-  const int m0 = by * HD2_M, n0 = bx * HH_N;
-  const int wm = (wave >> 1) * 128, wn = (wave & 1) * 64;
+  const int m0 = by * TM, n0 = bx * HH_N;
+  const int wm = (wave >> 1) * (32 * MI), wn = (wave & 1) * 64;
   const int li = lane & 31, lh = lane >> 5;
 
-  // ---- requests: wave w fills rows [64 w, 64 w + 64) of A (four 1 KB wave-requests) and [32 w, 32 w + 32) of W (two) ----
-  const _Float16* ga[4];
+  // ---- requests: wave w fills rows [16 MI w, 16 MI (w + 1)) of A (MI 1 KB wave-requests) and [32 w, 32 w + 32) of W (two) ----
+  const _Float16* ga[MI];
   const _Float16* gw[2];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int r = 64 * wave + 16 * u + (lane >> 2);
+  for (int u = 0; u < MI; ++u) {
+    const int r = 16 * MI * wave + 16 * u + (lane >> 2);
     ga[u] = A + (long)min(m0 + r, g.M - 1) * g.lda + 8 * ((lane & 3) ^ ((r >> 2) & 3));   // clamped rows: results not stored
   }
 #pragma unroll
@@ -763,24 +788,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
   }
   typedef __attribute__((address_space(3))) void* lds_ptr;
   auto request = [&](int stage, int k0) {
-    unsigned char* base = smem + stage * HD2_STAGE_BYTES;
+    unsigned char* base = smem + stage * STAGE_BYTES;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) __builtin_amdgcn_global_load_lds(ga[u] + k0, (lds_ptr)(base + wave * 4096 + 1024 * u), 16, 0, 0);
+    for (int u = 0; u < MI; ++u) lds_dma16(ga[u] + k0, base + (wave * MI + u) * 1024);
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
-      __builtin_amdgcn_global_load_lds(gw[u] + k0, (lds_ptr)(base + HD2_A_BYTES + wave * 2048 + 1024 * u), 16, 0, 0);
+    for (int u = 0; u < 2; ++u) lds_dma16(gw[u] + k0, base + A_BYTES + wave * 2048 + 1024 * u);
   };
 
   const int swz = (li >> 2) & 3;
   const unsigned lds0 = (unsigned)(size_t)(lds_ptr)smem;
   const unsigned a_ks0 = lds0 + (wm + li) * 64 + ((lh ^ swz) << 4);
   const unsigned a_ks1 = lds0 + (wm + li) * 64 + (((2 + lh) ^ swz) << 4);
-  const unsigned w_ks0 = lds0 + HD2_A_BYTES + (wn + li) * 64 + ((lh ^ swz) << 4);
-  const unsigned w_ks1 = lds0 + HD2_A_BYTES + (wn + li) * 64 + (((2 + lh) ^ swz) << 4);
+  const unsigned w_ks0 = lds0 + A_BYTES + (wn + li) * 64 + ((lh ^ swz) << 4);
+  const unsigned w_ks1 = lds0 + A_BYTES + (wn + li) * 64 + (((2 + lh) ^ swz) << 4);
 
-  f32x16 acc[4][2];
+  f32x16 acc[MI][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -794,43 +818,56 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
   for (int j = 0; j < 2; ++j) bias[j] = g.bias ? g.bias[min(n0 + wn + 32 * j + li, g.N - 1)] : 0.f;
   int stage = 0;
   for (int kb = 0; kb < nk; ++kb) {
-    if (kb + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0F76);      // vmcnt(6): the six requests of stage kb + 1 may be pending
-    else __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
+    if (kb + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0F70 | (MI + 2));      // vmcnt(MI + 2): the requests of stage kb + 1 may be pending
+    else __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0)
     __builtin_amdgcn_s_barrier();
     if (kb + 2 < nk) {
       const int s2 = stage + 2 >= HD_STAGES ? stage + 2 - HD_STAGES : stage + 2;
       request(s2, (kb + 2) * HH_K);
     }
-    const unsigned so = (unsigned)stage * HD2_STAGE_BYTES;
-    half8 a0[4], a1[4], w0[2], w1[2];          // a0 / w0: k sub-step 0, a1 / w1: sub-step 1; index = 32-row block
+    const unsigned so = (unsigned)stage * STAGE_BYTES;
+    half8 a0[4], a1[4], w0[2], w1[2];          // a0 / w0: k sub-step 0, a1 / w1: sub-step 1; index = 32-row block (a?[3]: MI = 4 only)
     asm volatile("ds_read_b128 %0, %1" : "=v"(a0[0]) : "v"(a_ks0 + so));
     asm volatile("ds_read_b128 %0, %1" : "=v"(w0[0]) : "v"(w_ks0 + so));
     asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(w0[1]) : "v"(w_ks0 + so));
     asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(a0[1]) : "v"(a_ks0 + so));
     asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(a0[2]) : "v"(a_ks0 + so));
-    asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(a0[3]) : "v"(a_ks0 + so));
+    if constexpr (MI == 4) asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(a0[3]) : "v"(a_ks0 + so));
     asm volatile("ds_read_b128 %0, %1" : "=v"(a1[0]) : "v"(a_ks1 + so));
     asm volatile("ds_read_b128 %0, %1" : "=v"(w1[0]) : "v"(w_ks1 + so));
     asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(w1[1]) : "v"(w_ks1 + so));
     asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(a1[1]) : "v"(a_ks1 + so));
     asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(a1[2]) : "v"(a_ks1 + so));
-    asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(a1[3]) : "v"(a_ks1 + so));
+    if constexpr (MI == 4) asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(a1[3]) : "v"(a_ks1 + so));
 #define HD2_MFMA(i_, j_, av, wv) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, wv, acc[i_][j_], 0, 0, 0);
-    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a0[0]), "+v"(w0[0]), "+v"(w0[1]), "+v"(a0[1]));
+    // NRD reads in flight; the waits name how many may still be: after the first four, after the rest of sub-step 0, ...
+    if constexpr (MI == 4) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a0[0]), "+v"(w0[0]), "+v"(w0[1]), "+v"(a0[1]));
+    else asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a0[0]), "+v"(w0[0]), "+v"(w0[1]), "+v"(a0[1]));
     HD2_MFMA(0, 0, a0[0], w0[0]) HD2_MFMA(0, 1, a0[0], w0[1]) HD2_MFMA(1, 0, a0[1], w0[0]) HD2_MFMA(1, 1, a0[1], w0[1])
-    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a0[2]), "+v"(a0[3]));
-    HD2_MFMA(2, 0, a0[2], w0[0]) HD2_MFMA(2, 1, a0[2], w0[1]) HD2_MFMA(3, 0, a0[3], w0[0]) HD2_MFMA(3, 1, a0[3], w0[1])
-    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a1[0]), "+v"(w1[0]), "+v"(w1[1]), "+v"(a1[1]));
+    if constexpr (MI == 4) {
+      asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a0[2]), "+v"(a0[3]));
+      HD2_MFMA(2, 0, a0[2], w0[0]) HD2_MFMA(2, 1, a0[2], w0[1]) HD2_MFMA(3, 0, a0[3], w0[0]) HD2_MFMA(3, 1, a0[3], w0[1])
+      asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a1[0]), "+v"(w1[0]), "+v"(w1[1]), "+v"(a1[1]));
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(a0[2]));
+      HD2_MFMA(2, 0, a0[2], w0[0]) HD2_MFMA(2, 1, a0[2], w0[1])
+      asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a1[0]), "+v"(w1[0]), "+v"(w1[1]), "+v"(a1[1]));
+    }
     HD2_MFMA(0, 0, a1[0], w1[0]) HD2_MFMA(0, 1, a1[0], w1[1]) HD2_MFMA(1, 0, a1[1], w1[0]) HD2_MFMA(1, 1, a1[1], w1[1])
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a1[2]), "+v"(a1[3]));
-    HD2_MFMA(2, 0, a1[2], w1[0]) HD2_MFMA(2, 1, a1[2], w1[1]) HD2_MFMA(3, 0, a1[3], w1[0]) HD2_MFMA(3, 1, a1[3], w1[1])
+    if constexpr (MI == 4) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a1[2]), "+v"(a1[3]));
+      HD2_MFMA(2, 0, a1[2], w1[0]) HD2_MFMA(2, 1, a1[2], w1[1]) HD2_MFMA(3, 0, a1[3], w1[0]) HD2_MFMA(3, 1, a1[3], w1[1])
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a1[2]));
+      HD2_MFMA(2, 0, a1[2], w1[0]) HD2_MFMA(2, 1, a1[2], w1[1])
+    }
 #undef HD2_MFMA
+    static_assert(NRD == 2 * MI + 4, "the lgkmcnt waits above count NRD reads");
     stage = stage + 1 == HD_STAGES ? 0 : stage + 1;
   }
   __builtin_amdgcn_s_barrier();          // every wave has read its last operands: the stages become epilogue images
-  static_assert(4 * 2 * EP_IMAGE_BYTES <= HD_STAGES * HD2_STAGE_BYTES, "two epilogue images per wave");
   float* T0 = reinterpret_cast<float*>(smem + wave * (2 * EP_IMAGE_BYTES));
-  hd2_epilogue<EPI>(g, acc, T0, T0 + EP_IMAGE_BYTES / 4, m0, n0, wm, wn, lane, bz, bias);
+  hd2_epilogue<EPI, MI>(g, acc, T0, T0 + EP_IMAGE_BYTES / 4, m0, n0, wm, wn, lane, bz, bias);
 }
 
 }  // namespace
@@ -858,17 +895,28 @@ hipError_t gemm_hh(const HGemmArgs& g, int epi, int batch, hipStream_t s) {
   if (a.xcd_swizzle) grid.y = (unsigned)(((mt + 7) / 8) * 8);      // whole groups of eight row tiles
   static const bool direct = [] { const char* e = std::getenv("CRISPY_ASR_GEMM"); return !(e && e[0] == 'r'); }();   // "regs": the register-staged loop
   static const bool tall = [] { const char* e = std::getenv("CRISPY_ASR_GEMM"); return !(e && e[0] == 's'); }();     // "square": 128 x 128 tiles only
-  if ((direct || epi == EPI_KVH) && tall && g.M >= 4 * HD2_M) {      // 256 x 128 tiles
-    const int mt2 = (g.M + HD2_M - 1) / HD2_M;
+  if ((direct || epi == EPI_KVH) && tall && g.M >= 4 * HD2_M) {      // 256 x 128 or 192 x 128 tiles
+    // two workgroups per CU: rounds x tile height is what the launch costs; ties go to the taller tile
+    static const int slots = [] {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+      return 2 * n;
+    }();
+    static const int force_mi = [] { const char* e = std::getenv("CRISPY_ASR_TILE_ROWS"); return e ? std::atoi(e) / 64 : 0; }();   // 192 | 256
+    auto cost = [&](int mi) { const long tiles = (long)((g.M + 64 * mi - 1) / (64 * mi)) * nt * batch; return ((tiles + slots - 1) / slots) * mi; };
+    const int mi = (force_mi == 3 || force_mi == 4) ? force_mi : (cost(3) < cost(4) ? 3 : 4);
+    const int mt2 = (g.M + 64 * mi - 1) / (64 * mi);
     dim3 grid2(nt, a.xcd_swizzle ? (unsigned)(((mt2 + 7) / 8) * 8) : (unsigned)mt2, batch);
+#define HD2_LAUNCH(E) { if (mi == 3) hipLaunchKernelGGL(gemm_hd2_kernel<E + 8 * 3>, grid2, dim3(256), 0, s, a); else hipLaunchKernelGGL(gemm_hd2_kernel<E + 8 * 4>, grid2, dim3(256), 0, s, a); }
     switch (epi) {
-      case EPI_F16: hipLaunchKernelGGL(gemm_hd2_kernel<EPI_F16>, grid2, dim3(256), 0, s, a); break;
-      case EPI_RES: hipLaunchKernelGGL(gemm_hd2_kernel<EPI_RES>, grid2, dim3(256), 0, s, a); break;
-      case EPI_VT: hipLaunchKernelGGL(gemm_hd2_kernel<EPI_VT>, grid2, dim3(256), 0, s, a); break;
-      case EPI_TAB: hipLaunchKernelGGL(gemm_hd2_kernel<EPI_TAB>, grid2, dim3(256), 0, s, a); break;
-      case EPI_KVH: hipLaunchKernelGGL(gemm_hd2_kernel<EPI_KVH>, grid2, dim3(256), 0, s, a); break;
+      case EPI_F16: HD2_LAUNCH(EPI_F16) break;
+      case EPI_RES: HD2_LAUNCH(EPI_RES) break;
+      case EPI_VT: HD2_LAUNCH(EPI_VT) break;
+      case EPI_TAB: HD2_LAUNCH(EPI_TAB) break;
+      case EPI_KVH: HD2_LAUNCH(EPI_KVH) break;
       default: return hipErrorInvalidValue;
     }
+#undef HD2_LAUNCH
     return hipGetLastError();
   }
   if (direct || epi == EPI_KVH) {
@@ -893,9 +941,10 @@ hipError_t gemm_hh(const HGemmArgs& g, int epi, int batch, hipStream_t s) {
 }
 
 hipError_t attn_encoder_h(const void* qk, const void* vt, void* out, int B, int T, int D, int heads, hipStream_t s) {
-  hipLaunchKernelGGL(attn_enc_h_kernel, dim3((T + 127) / 128, heads, B), dim3(256), 0, s,
+  const int nq = (T + 127) / 128, groups8 = (heads * B + 7) / 8;
+  hipLaunchKernelGGL(attn_enc_h_kernel, dim3((unsigned)(8 * groups8 * nq)), dim3(256), 0, s,
                      reinterpret_cast<const _Float16*>(qk), reinterpret_cast<const _Float16*>(vt),
-                     reinterpret_cast<_Float16*>(out), T, D);
+                     reinterpret_cast<_Float16*>(out), T, D, heads, B);
   return hipGetLastError();
 }
 

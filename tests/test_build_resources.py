@@ -140,21 +140,24 @@ def test_f16_encoder_kernels_run_at_four_waves_per_simd_without_scratch(tmp_path
         seg = loop[:pos[-1]]
         assert seg.count("ds_read_b128") == 8 and seg.count("global_load_lds_dwordx4") == 4, name
         assert "vmcnt(0)" not in seg, f"{name}: a compiler-inserted vmcnt(0) serialises the stages"
-    # the 256 x 128 tile form (M >= 1024 rows): three stages of 24 KB, two workgroups per CU, six LDS-DMA requests,
-    # twelve ds_read_b128 and sixteen MFMAs per trip, again without a compiler-inserted vmcnt(0)
+    # the 256 x 128 and 192 x 128 tile forms (M >= 1024 rows; template argument = epilogue + 8 x row blocks per wave):
+    # 72 KB of LDS (the ring or the epilogue images, whichever is larger), two workgroups per CU, MI + 2 LDS-DMA
+    # requests, 2 MI + 4 ds_read_b128 and 4 MI MFMAs per trip, again without a compiler-inserted vmcnt(0)
     hd2 = {k: v for k, v in res.items() if "gemm_hd2_kernel" in k}
-    assert len(hd2) == 5, list(res)
+    assert len(hd2) == 10, list(res)
     for name, r in hd2.items():
+        mi = int(re.search(r"gemm_hd2_kernelILi(\d+)E", name).group(1)) >> 3
+        assert mi in (3, 4), name
         assert r["ScratchSize"] == 0 and r["LDS Size"] == 3 * 24576 and r["VGPRs"] + r.get("AGPRs", 0) <= 256, (name, r)
         body = text[text.index(name + ":"):]
         body = body[:body.index(".Lfunc_end")]
         loop = body[body.index("Loop Header: Depth=1"):]
         loop = loop[loop.index("s_barrier"):]
         at = 0
-        for _ in range(16):
+        for _ in range(4 * mi):
             at = loop.index("v_mfma_f32_32x32x16_f16", at) + 1
         seg = loop[:at]
-        assert seg.count("ds_read_b128") == 12 and seg.count("global_load_lds_dwordx4") == 6, name
+        assert seg.count("ds_read_b128") == 2 * mi + 4 and seg.count("global_load_lds_dwordx4") == mi + 2, name
         assert "vmcnt(0)" not in seg, f"{name}: a compiler-inserted vmcnt(0) serialises the stages"
 
 
