@@ -331,3 +331,24 @@ def test_mode1_product_call_equals_the_chained_oracle_on_plain_weights_at_the_st
               f"{worst:.4f} against a bar of {thr:.4f}")
     assert n_win >= 5 and n_tok >= 96, (n_win, n_tok)
     eng.close()
+
+
+@pytest.mark.gpu
+def test_mode1_encoder_does_not_depend_on_the_gemm_tile_height():
+    """The f16 GEMMs of >= 1024 rows run on 256 x 128 or 192 x 128 tiles, chosen per launch by rounds x height
+    (whisper_enc_f16.hip: gemm_hh).  The choice is read once per process, so each height gets a process of its own: the
+    encoder output of 8 clips (12 000 rows: every tile form with ragged last row tiles) must be the same bytes."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    crcs = {}
+    for rows in ("192", "256", ""):
+        env = dict(os.environ, B="8", PREC="1", MODEL="tiny")
+        env.pop("CRISPY_ASR_TILE_ROWS", None)
+        if rows:
+            env["CRISPY_ASR_TILE_ROWS"] = rows
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "enc_time.py")], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if " crc " in ln][-1]
+        crcs[rows or "auto"] = line.rsplit(" all ", 1)[1].strip()
+    assert len(set(crcs.values())) == 1, crcs
