@@ -401,7 +401,9 @@ impl GpuWhisperEngine {
         if unsafe { crispy_asr_hparams_get(self.h, &mut hp) } == CRISPY_OK { hp.n_vocab } else { 0 }
     }
     /// 0: exact f32 products (parity mode; refused with CRISPY_ERR_UNSUPPORTED for a quantised file, which `load` keeps
-    /// resident as ggml blocks); 1: whisper.cpp's f16-operand arithmetic (the default of `load`).
+    /// resident as ggml blocks); 1: whisper.cpp's f16-operand arithmetic (the default of `load`); 2: mode 1 plus ggml's
+    /// remaining rounding points (LayerNorm outputs of the decode step, queries and normalised probabilities inside every
+    /// attention), opt-in and slower.
     pub fn set_precision(&mut self, mode: i32) -> Result<(), CrispyError> {
         check(unsafe { crispy_asr_set_precision(self.h, mode as c_int) })
     }

@@ -120,7 +120,8 @@ struct HGemmArgs {
 constexpr int HGEMM_F16 = 0, HGEMM_RES = 1, HGEMM_VT = 2, HGEMM_TAB = 3, HGEMM_KVH = 4;
 hipError_t gemm_hh(const HGemmArgs& g, int epi, int batch, hipStream_t s);
 hipError_t layernorm_f16out(const float* x, const float* gamma, const float* beta, void* y, long rows, int D, hipStream_t s);
-hipError_t attn_encoder_h(const void* qk, const void* vt, void* out, int B, int T, int D, int heads, hipStream_t s);
+hipError_t attn_encoder_h(const void* qk, const void* vt, void* out, int B, int T, int D, int heads, hipStream_t s,
+                          int norm16 = 0);      // norm16: normalised probabilities rounded to f16 (precision mode 2)
 hipError_t convert_rows_f32_to_f16(const float* src, long lds, void* dst, long ldd, int cols, long rows, hipStream_t s);
 // ---- precision mode 1, decode step (whisper_dec_f16.hip): vocabulary projection over a packed f16 embedding ----
 size_t vocab_f16_packed_bytes(int V, int K);
@@ -140,7 +141,11 @@ hipError_t attn_encoder_f32(const float* qkv, float* out, int B, int T, int D, i
 // key_off (device, per clip, nullable): the clip's keys start at cache row key_off[clip] -- prompts of different lengths
 // are left-padded to a common length so that one batch decodes them in lock step (whisper_full's previous-text
 // conditioning); the key count shrinks by the same amount, a row with no key left writes zeros.
-struct AttnRows { int group = 1, key_step = 0, stream_kv = 0; const int* key_off = nullptr; };
+// attn16 (precision mode 2, f16 K|V only): ggml's rounding points inside the attention -- the query rounded to f16 in front
+// of K.q, and the soft-max taken in full, normalised, and THEN rounded to f16 in front of P.V (mul_mat converts its f32
+// operand to the type of the f16 cache it multiplies) [UPSTREAM-RECALL]; costs two more hand-offs between the waves of a
+// (row, head), since the rounding needs the sum over all keys first.
+struct AttnRows { int group = 1, key_step = 0, stream_kv = 0; const int* key_off = nullptr; int attn16 = 0; };
 hipError_t attn_decoder_f32(const float* q, long ldq, const float* kv, long kv_batch_stride, long ldkv, long head_stride,
                             long koff, long voff, int n_keys_base, const int* pos_dev, float* out, long ldo, int B, int heads,
                             hipStream_t s, AttnRows rows = AttnRows());

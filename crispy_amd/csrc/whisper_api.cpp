@@ -903,7 +903,7 @@ int crispy_asr_encode_device(crispy_asr* h, const float* d_mel_t, int batch, flo
       HIP_TRY(gemm_hh(hg(xn_h, d, w, d, qk_h, 2L * d, L.qkv_b, 2 * d, d), HGEMM_F16, 1, s));
       HIP_TRY(gemm_hh(hg(xn_h, d, reinterpret_cast<const _Float16*>(w) + 2L * d * d, d, vt_h, 0, L.qkv_b + 2 * d, d, d),
                       HGEMM_VT, 1, s));
-      HIP_TRY(attn_encoder_h(qk_h, vt_h, att_h, batch, Tn, d, H, s));
+      HIP_TRY(attn_encoder_h(qk_h, vt_h, att_h, batch, Tn, d, H, s, h->dec_ln16 ? 1 : 0));     // mode 2: ggml's rounding points inside the attention
       {
         if ((rc = w16(L.out_wh, L.r_out, &w)) != CRISPY_OK) return rc;
         HGemmArgs g = hg(att_h, d, w, d, h->w_x, d, L.out_b, d, d);
@@ -1077,6 +1077,8 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
   self_rows.group = P; self_rows.key_step = P > 1 ? 1 : 0;
   self_rows.key_off = h->cur_row_off;        // left-padded prompts (decode_ts): every clip's keys start at its own cache row
   cross_rows.group = P;
+  // precision mode 2: q and the normalised probabilities rounded to f16 inside the attentions over the f16 caches
+  cross_rows.attn16 = h->dec_ln16 && h->enc_precision == 1 ? 1 : 0;
   // The cross K|V of all layers and clips against the 256 MB Infinity Cache: while it fits, it is what stays cached from
   // step to step (plain loads: 16 tiny clips = 147 MB, 6.8 ms per call against 7.0 non-temporal); beyond that it is a
   // one-pass stream that only evicts the decoder's weights from the L2s, and is requested non-temporally
@@ -1141,6 +1143,7 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
     // starts with its own prefill); the projection stores halves, the attention requests all its keys up front
     const bool kv16 = fold && h->enc_precision == 1 && h->dec_max_keys > 0 && h->dec_max_keys <= 512;
     _Float16* selfkv_h = reinterpret_cast<_Float16*>(h->d_selfkv) + l * (size_t)clips * C * 2 * dt;
+    self_rows.attn16 = kv16 && h->dec_ln16 ? 1 : 0;
     if (fold) {
       // precision mode 2: LayerNorm as a launch of its own, its output rounded to f16 on the way into the f16 matrix cores
       // against f16 weights (ggml's mul_mat arithmetic for these products too); modes 0 / 1: LayerNorm folded in, f32 operands

@@ -554,6 +554,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
 // ---------------------------------------------------------------------------------------------
 constexpr int AT_KLD = 72;    // halfs per K row in LDS (64 + 8): 16-lane b128 reads spread over all banks
 constexpr int AT_VLD = 36;    // halfs per V^T row in LDS (32 + 4): b64 reads of 16 rows hit 16 distinct bank pairs
+// NORM16 (precision mode 2): ggml's order inside the attention -- soft-max in full, normalised, THEN rounded to f16 in
+// front of P.V [UPSTREAM-RECALL] -- which needs the row's maximum and sum before the first probability is rounded: a
+// statistics pass over K (scores, running maximum, running sum) in front of the pass that multiplies.
+template <bool NORM16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void attn_enc_h_kernel(const _Float16* __restrict__ qk, const _Float16* __restrict__ vt,
                                                          _Float16* __restrict__ out, int T, int D, int heads, int n_clips) {
   // K and V^T tiles of 32 keys are staged once per workgroup (the four waves work on the same clip and head) and
@@ -610,6 +614,56 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void a
   __syncthreads();
 
   const int n_tiles = (T + 31) / 32;
+  float m_fix = 0.f, inv_l = 0.f;         // NORM16: the row's maximum (log2 units) and 1 / sum over all keys
+  if constexpr (NORM16) {
+    float mr = -1e30f, lr = 0.f;
+    for (int it = 0; it < n_tiles; ++it) {
+      const int k0 = it * 32, buf = it & 1;
+      rk = *reinterpret_cast<const uint4*>(kaddr(min(it + 1, n_tiles - 1) * 32));
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const half8 kh = *reinterpret_cast<const half8*>(&Ks[buf][li * AT_KLD + 16 * ks + 8 * lh]);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s, 0, 0, 0);
+      }
+      if (k0 + 32 > T) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (k0 + acc_row_e(r, lane) >= T) s[r] = -3e38f;
+      }
+      float mloc = fmaxf(fmaxf(s[0], s[1]), s[2]);
+#pragma unroll
+      for (int r = 3; r < 15; r += 2) mloc = fmaxf(fmaxf(mloc, s[r]), s[r + 1]);
+      mloc = fmaxf(mloc, s[15]) * sc;
+      {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mloc), __float_as_uint(mloc), false, false);
+        mloc = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      }
+      const float m_new = fmaxf(mr, mloc);
+      lr *= __builtin_amdgcn_exp2f(mr - m_new);
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) psum += __builtin_amdgcn_exp2f(fmaf(s[r], sc, -m_new));
+      lr += psum;
+      mr = m_new;
+      __builtin_amdgcn_sched_barrier(0);
+      *reinterpret_cast<uint4*>(&Ks[buf ^ 1][kso]) = rk;
+      __syncthreads();
+    }
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lr), __float_as_uint(lr), false, false);
+      lr = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    m_fix = mr;
+    inv_l = 1.f / lr;
+    // K tile 0 again (V^T tile 0 is still where the prologue put it); everyone is behind the loop's last barrier
+    rk = *reinterpret_cast<const uint4*>(kaddr(0));
+    *reinterpret_cast<uint4*>(&Ks[0][kso]) = rk;
+    __syncthreads();
+  }
   for (int it = 0; it < n_tiles; ++it) {
     const int k0 = it * 32, buf = it & 1;
     {
@@ -644,7 +698,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void a
     // Raise the reference exponent only when it is exceeded by more than 2^6 (p <= 128 fits f16 with room to spare),
     // and keep it an INTEGER: 2^(t - m) with integer m has the mantissa of 2^t, so the f16 rounding of a probability
     // does not depend on which tile last raised the reference -- the oracle rounds 2^(t - ceil(row max)) the same way.
-    if (__builtin_amdgcn_ballot_w64(mloc > m_run + 6.f) != 0ull) {
+    if (!NORM16 && __builtin_amdgcn_ballot_w64(mloc > m_run + 6.f) != 0ull) {
       const float m_new = ceilf(fmaxf(m_run, mloc));
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       l_run *= alpha;
@@ -656,7 +710,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void a
     half8 ph[2];
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
-      const float p0 = __builtin_amdgcn_exp2f(fmaf(s[r], sc, -m_run)), p1 = __builtin_amdgcn_exp2f(fmaf(s[r + 1], sc, -m_run));
+      float p0, p1;
+      if constexpr (NORM16) {
+        p0 = __builtin_amdgcn_exp2f(fmaf(s[r], sc, -m_fix)) * inv_l;
+        p1 = __builtin_amdgcn_exp2f(fmaf(s[r + 1], sc, -m_fix)) * inv_l;
+      } else {
+        p0 = __builtin_amdgcn_exp2f(fmaf(s[r], sc, -m_run));
+        p1 = __builtin_amdgcn_exp2f(fmaf(s[r + 1], sc, -m_run));
+      }
       psum += p0 + p1;
       const half2v pp = __builtin_convertvector(float2v{p0, p1}, half2v);
       ph[r >> 3][r & 7] = pp[0];
@@ -694,7 +755,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void a
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
     l_run = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
   }
-  const float inv = 1.f / l_run;
+  const float inv = NORM16 ? 1.f : 1.f / l_run;       // NORM16: the probabilities were normalised before they were rounded
   // lane (li = query, lh) holds O[q][d] for d = acc_row(r) (+ 32 for o1).  Stored from here, every instruction would
   // touch 32 rows with 16 bytes each (16 instructions per wave, store-issue bound); through a [32][64 + 8] f16 image in
   // the K | V^T stages that are free now, a wave writes whole 128-byte rows, 8 rows per 16-byte-per-lane instruction.
@@ -940,11 +1001,15 @@ hipError_t gemm_hh(const HGemmArgs& g, int epi, int batch, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t attn_encoder_h(const void* qk, const void* vt, void* out, int B, int T, int D, int heads, hipStream_t s) {
+hipError_t attn_encoder_h(const void* qk, const void* vt, void* out, int B, int T, int D, int heads, hipStream_t s, int norm16) {
   const int nq = (T + 127) / 128, groups8 = (heads * B + 7) / 8;
-  hipLaunchKernelGGL(attn_enc_h_kernel, dim3((unsigned)(8 * groups8 * nq)), dim3(256), 0, s,
-                     reinterpret_cast<const _Float16*>(qk), reinterpret_cast<const _Float16*>(vt),
-                     reinterpret_cast<_Float16*>(out), T, D, heads, B);
+  const dim3 grid((unsigned)(8 * groups8 * nq));
+  if (norm16)
+    hipLaunchKernelGGL(attn_enc_h_kernel<true>, grid, dim3(256), 0, s, reinterpret_cast<const _Float16*>(qk),
+                       reinterpret_cast<const _Float16*>(vt), reinterpret_cast<_Float16*>(out), T, D, heads, B);
+  else
+    hipLaunchKernelGGL(attn_enc_h_kernel<false>, grid, dim3(256), 0, s, reinterpret_cast<const _Float16*>(qk),
+                       reinterpret_cast<const _Float16*>(vt), reinterpret_cast<_Float16*>(out), T, D, heads, B);
   return hipGetLastError();
 }
 

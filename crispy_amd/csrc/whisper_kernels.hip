@@ -942,8 +942,14 @@ __global__ __launch_bounds__(64 * AD_WAVES) void attn_dec_x16_kernel(const float
   {
     const float4 q0 = *reinterpret_cast<const float4*>(q + (long)b * ldq + h * 64 + 8 * c);
     const float4 q1 = *reinterpret_cast<const float4*>(q + (long)b * ldq + h * 64 + 8 * c + 4);
-    qv[0] = q0.x * 0.125f; qv[1] = q0.y * 0.125f; qv[2] = q0.z * 0.125f; qv[3] = q0.w * 0.125f;
-    qv[4] = q1.x * 0.125f; qv[5] = q1.y * 0.125f; qv[6] = q1.z * 0.125f; qv[7] = q1.w * 0.125f;
+    qv[0] = q0.x; qv[1] = q0.y; qv[2] = q0.z; qv[3] = q0.w;
+    qv[4] = q1.x; qv[5] = q1.y; qv[6] = q1.z; qv[7] = q1.w;
+    if (rows.attn16) {       // the query as ggml's K.q sees it: rounded BEFORE the scaling (q / 8 may be an f16 subnormal where q is not)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qv[e] = (float)(_Float16)qv[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qv[e] *= 0.125f;
   }
   float sc[ADX_SLOTS];
   float mloc = -1e30f;
@@ -965,9 +971,31 @@ __global__ __launch_bounds__(64 * AD_WAVES) void attn_dec_x16_kernel(const float
   float acc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  float inv16 = 0.f;           // attn16: 1 / (sum over ALL keys); the maximum is the row's, not the wave's
+  if (rows.attn16) {
+    if (lane == 0) part_m[wave] = mloc;
+    __syncthreads();
+    float m = part_m[0];
+#pragma unroll
+    for (int w = 1; w < AD_WAVES; ++w) m = fmaxf(m, part_m[w]);
+    mloc = m;
+    float ls = 0.f;
+#pragma unroll
+    for (int i = 0; i < ADX_SLOTS; ++i) ls += k_lo + 8 * i + r < k_hi ? __expf(sc[i] - mloc) : 0.f;
+#pragma unroll
+    for (int off = 8; off <= 32; off <<= 1) ls += __shfl_xor(ls, off, 64);     // the eight lanes of a key hold the same score
+    if (lane == 0) part_l[wave] = ls;
+    __syncthreads();
+    float l = 0.f;
+#pragma unroll
+    for (int w = 0; w < AD_WAVES; ++w) l += part_l[w];
+    inv16 = 1.f / l;
+    __syncthreads();           // part_m / part_l are written again below
+  }
 #pragma unroll
   for (int i = 0; i < ADX_SLOTS; ++i) {
-    const float pw = k_lo + 8 * i + r < k_hi ? __expf(sc[i] - mloc) : 0.f;
+    float pw = k_lo + 8 * i + r < k_hi ? __expf(sc[i] - mloc) : 0.f;
+    if (rows.attn16) pw = (float)(_Float16)(pw * inv16);      // the normalised probability as ggml's P.V sees it
     lsum += pw;
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = fmaf(pw, (float)vr[i][e], acc[e]);
@@ -995,7 +1023,8 @@ __global__ __launch_bounds__(64 * AD_WAVES) void attn_dec_x16_kernel(const float
       o = fmaf(part_o[w][lane], scl, o);
       l = fmaf(part_l[w], scl, l);
     }
-    out[(long)b * ldo + h * 64 + lane] = o / l;
+    // attn16: the probabilities were normalised before they were rounded (every wave's maximum is the row's: scl = 1)
+    out[(long)b * ldo + h * 64 + lane] = rows.attn16 ? o : o / l;
   }
 }
 
@@ -1656,6 +1685,7 @@ hipError_t attn_decoder_kv16(const float* q, long ldq, const void* kv, long kv_b
 #undef CRISPY_ADX
     return hipGetLastError();
   }
+  if (rows.attn16) return hipErrorInvalidValue;      // only the all-keys-up-front kernel above rounds inside the attention
   hipLaunchKernelGGL((attn_dec_kernel<_Float16, false>), dim3(heads, B), dim3(64 * AD_WAVES), 0, s, q, ldq,
                      reinterpret_cast<const _Float16*>(kv), kv_batch_stride, ldkv, head_stride, koff, voff, n_keys_base, pos_dev, out, ldo, rows);
   return hipGetLastError();

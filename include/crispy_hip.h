@@ -244,10 +244,13 @@ int crispy_asr_synchronize(crispy_asr *h);
  * weights and the activation rounded to f16; the LayerNorm-folded projections (q | k | v, cross q, the MLP's first
  * product), LayerNorm and soft-max stay f32; GELU is ggml's (the f16-indexed table of the tanh form, evaluated on the fly).
  * oracle/whisper_oracle.py: encoder_forward_f16, DecoderCache(f16=True).
- * 2 (opt-in): mode 1, and the decoder's LayerNorm output ALSO rounded to f16 in front of q | k | v, cross q and the MLP's
- * first product, which then run against f16 weights -- ggml's rounding points for these products too [UPSTREAM-RECALL].
- * The LayerNorm becomes a launch of its own (three more launches per layer and step: ~10 % slower decode steps at 64
- * Whisper-tiny clips); not available for resident quantised models.  Oracle: DecoderCache(f16=True, ln16=True). */
+ * 2 (opt-in): mode 1 plus ggml's remaining rounding points [UPSTREAM-RECALL]: the decoder's LayerNorm output rounded to
+ * f16 in front of q | k | v, cross q and the MLP's first product, which then run against f16 weights (the LayerNorm
+ * becomes a launch of its own: three more launches per layer and step); and inside every attention -- encoder, decoder
+ * self and cross -- the query rounded to f16 in front of K.q and the soft-max taken in full, normalised, and only then
+ * rounded to f16 in front of P.V (the encoder runs a statistics pass over K first; a decode step two more hand-offs
+ * between the waves of a row).  Not available for resident quantised models.
+ * Oracle: encoder_forward_f16(attn16=True), DecoderCache(f16=True, ln16=True, attn16=True). */
 int crispy_asr_set_precision(crispy_asr *h, int mode);
 
 /* Stage entry point (parity tests): the last step of the decoder alone -- final LayerNorm and vocabulary projection

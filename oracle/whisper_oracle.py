@@ -99,7 +99,7 @@ def _h(a):
     return np.asarray(a, dtype=np.float32).astype(np.float16).astype(np.float64)
 
 
-def encoder_forward_f16(weights, hp, mel):
+def encoder_forward_f16(weights, hp, mel, attn16=False):
     """The encoder with the numerics of whisper.cpp's ggml matrix products [UPSTREAM-RECALL] -- what precision mode 1 of
     the library implements: every matrix product takes BOTH operands rounded to f16 (the 2-D weights, and the
     activation that enters the product) and accumulates exactly (float64 here, f32 on the matrix cores; the difference
@@ -112,7 +112,10 @@ def encoder_forward_f16(weights, hp, mel):
               depend on m, which is what lets a tiled kernel reproduce it; the sum uses the unrounded values),
               P.V on rounded operands, the normalised result rounded -> out projection; LN(x) rounded -> fc1;
               GELU(fc1) rounded -> fc2
-      ln_post exact."""
+      ln_post exact.
+    attn16 (the library's precision mode 2): the soft-max is taken in full, NORMALISED, and the normalised probabilities
+    are what is rounded to f16 in front of P.V -- ggml's order (soft_max_ext writes f32 probabilities, mul_mat against
+    the f16 V converts them) [UPSTREAM-RECALL] -- instead of mode 1's 2^(t - m) mantissas divided afterwards."""
     W = _f64(weights)
     x = _h(mel)
     xp = np.pad(x, ((0, 0), (1, 1)))
@@ -135,6 +138,10 @@ def encoder_forward_f16(weights, hp, mel):
         for hh in range(H):
             sl = slice(hh * dh, (hh + 1) * dh)
             t = (q[:, sl] @ k[:, sl].T) / np.sqrt(dh) * np.log2(np.e)
+            if attn16:
+                pe = np.exp2(t - t.max(-1, keepdims=True))
+                att[:, sl] = _h(pe / pe.sum(-1, keepdims=True)) @ v[:, sl]
+                continue
             pe = np.exp2(t - np.ceil(t.max(-1, keepdims=True)))      # integer reference exponent: the mantissa of 2^t
             att[:, sl] = (_h(pe) @ v[:, sl]) / pe.sum(-1, keepdims=True)
         x = x + _h(att) @ _h(W[p + ".attn.out.weight"]).T + W[p + ".attn.out.bias"]
@@ -215,7 +222,7 @@ class DecoderCache:
     """KV-cached incremental decoder (float64); `step(token)` returns the logits of the new position.
     Same arithmetic as `decoder_logits`, restated so that 200-token windows finish in seconds."""
 
-    def __init__(self, weights, hp, enc_out, f16=False, dtype=np.float64, ln16=False):
+    def __init__(self, weights, hp, enc_out, f16=False, dtype=np.float64, ln16=False, attn16=False):
         """dtype=np.float32: single-precision CPU run for bench.py's cpu_baseline (not the parity oracle).
         f16=True: the decoder arithmetic of the library's precision mode 1, i.e. whisper.cpp's ggml graph
         [UPSTREAM-RECALL] wherever a matrix product has no LayerNorm folded into it on the GPU -- cross K | V from the
@@ -231,6 +238,10 @@ class DecoderCache:
         # the q | k | v, cross-q and fc1 products, as ggml's mul_mat does with an f32 activation against an f16 weight
         # [UPSTREAM-RECALL]; mode 1 keeps those five products exact (LayerNorm folded into f32 GEMMs)
         self.ln16 = bool(ln16 and f16)
+        # attn16 (mode 2 as well): the query is rounded to f16 in front of K.q and the NORMALISED soft-max probabilities in
+        # front of P.V -- ggml's mul_mat converts its f32 operand to the f16 of the K / V cache it multiplies
+        # [UPSTREAM-RECALL]; mode 1 keeps q and the probabilities in f32 against the f16 caches
+        self.attn16 = bool(attn16 and f16)
         r = _h if f16 else (lambda a: a)
         self.r = r
         self.rl = _h if self.ln16 else (lambda a: a)
@@ -260,9 +271,11 @@ class DecoderCache:
         out = np.empty_like(q)
         for h in range(H):
             sl = slice(h * dh, (h + 1) * dh)
-            s = (k[:, sl] @ q[sl]) / q.dtype.type(np.sqrt(dh))
+            qh = _h(q[sl]).astype(q.dtype) if self.attn16 else q[sl]
+            s = (k[:, sl] @ qh) / q.dtype.type(np.sqrt(dh))
             s = np.exp(s - s.max())
-            out[sl] = (s / s.sum()) @ v[:, sl]
+            pr = s / s.sum()
+            out[sl] = (_h(pr).astype(q.dtype) if self.attn16 else pr) @ v[:, sl]
         return out
 
     def fork(self):

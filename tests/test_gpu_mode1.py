@@ -233,9 +233,10 @@ def test_mode1_language_detection_does_not_depend_on_call_history(oracle):
 
 
 def test_mode2_transcribe_tokens_through_the_product_call(oracle):
-    """Precision mode 2 (mode 1 + f16 LayerNorm outputs in the decoder, opt-in) through `crispy_asr_transcribe_tokens`:
-    deterministic, batch == solo bit for bit, the decoder half against its own oracle (DecoderCache(f16=True, ln16=True))
-    on the product's encoder output, the chain at the amplified bar."""
+    """Precision mode 2 (mode 1 + ggml's remaining rounding points: f16 LayerNorm outputs in the decoder, q and the
+    normalised probabilities rounded inside every attention; opt-in) through `crispy_asr_transcribe_tokens`:
+    deterministic, batch == solo bit for bit, the decoder half against its own oracle (DecoderCache(f16=True, ln16=True,
+    attn16=True)) on the product's encoder output, the chain (encoder_forward_f16(attn16=True)) at the amplified bar."""
     from crispy_amd import synth_audio
     from crispy_amd.asr import WhisperModel
     from crispy_amd.mel_filters import whisper_mel_filters
@@ -256,9 +257,9 @@ def test_mode2_transcribe_tokens_through_the_product_call(oracle):
         solo, _ = m.transcribe_tokens([c], prompt, 8)
         assert np.array_equal(solo[0], toks[b])
         enc_gpu = m.encode([c])[0].astype(np.float64)
-        enc16 = WO.encoder_forward_f16(W, hp, oracle.oracle_logmel(c, F))
+        enc16 = WO.encoder_forward_f16(W, hp, oracle.oracle_logmel(c, F), attn16=True)
         for enc, rel, need, what in ((enc_gpu, MODE1_REL, 4, "decoder"), (enc16, 0.03, 1, "chain")):
-            dc = WO.DecoderCache(W, hp, enc, f16=True, ln16=True)
+            dc = WO.DecoderCache(W, hp, enc, f16=True, ln16=True, attn16=True)
             for t in prompt[:-1]:
                 dc.step(t)
             tok, compared = prompt[-1], 0

@@ -596,6 +596,39 @@ def test_f16_operand_mode_matches_the_f16_operand_oracle(tiny, model, oracle):
         assert rms16 < 0.7 * rms64, (seed, rms16, rms64)             # its own oracle, not the exact one
 
 
+def test_mode_2_encoder_rounds_the_normalised_probabilities(tiny, model, oracle):
+    """Precision mode 2 in the encoder: the soft-max taken in full, normalised, then rounded to f16 in front of P.V (ggml's
+    order; a statistics pass over K in front of the multiplying pass) instead of mode 1's 2^(t - m) mantissas.  Against
+    encoder_forward_f16(attn16=True) at the mode-1 bars, closer to it than to the mode-1 oracle is NOT asked for (the two
+    oracles differ by less than the accumulation-order noise); what is asked: within the bars of its own oracle, and the
+    output differs from mode 1's (the other kernel ran), and mode 1 is untouched afterwards."""
+    from crispy_amd import synth_audio
+    from crispy_amd.mel_filters import whisper_mel_filters
+    from oracle import whisper_oracle as WO
+    hp, W = tiny
+    x = synth_audio.clip16k_np(5, 130000)
+    mel = oracle.oracle_logmel(x, whisper_mel_filters(80))
+    ref = WO.encoder_forward_f16(W, hp, mel, attn16=True)
+    peak = np.abs(ref).max()
+    try:
+        model.set_precision(1)
+        got1 = model.encode([x])[0]
+        model.set_precision(2)
+        got2 = model.encode([x, x])                      # two clips: batch == solo below
+        solo = model.encode([x])[0]
+        model.set_precision(1)
+        again1 = model.encode([x])[0]
+    finally:
+        model.set_precision(0)
+    assert got1.tobytes() == again1.tobytes()
+    assert got2[0].tobytes() == solo.tobytes() and got2[1].tobytes() == solo.tobytes()
+    assert got2[0].tobytes() != got1.tobytes()
+    err = np.abs(got2[0] - ref).max() / peak
+    rms = np.sqrt(np.mean((got2[0] - ref) ** 2)) / peak
+    print(f"mode-2 encoder: max {err:.2e} rms {rms:.2e} of the peak")
+    assert err <= 4e-4 and rms <= 8e-5, (err, rms)
+
+
 @pytest.mark.parametrize("batch", [1, 64, 100])
 def test_vocabulary_projection_both_precision_modes(tiny, model, batch):
     """crispy_asr_stage_logits_device = the last block of a decoder step (final LayerNorm + vocabulary projection),
@@ -698,11 +731,16 @@ def test_mode_1_decoder_matches_the_f16_arithmetic_oracle(tiny, model):
 
 
 def test_mode_2_decoder_rounds_the_layernorm_outputs_as_ggml_does(tiny, model):
-    """Precision mode 2 (opt-in) = mode 1 + the decoder's LayerNorm output rounded to f16 in front of q | k | v, cross q
-    and fc1, against f16 weights -- ggml's mul_mat arithmetic for these products too.  Against its own oracle
-    (DecoderCache(f16=True, ln16=True)) on handed-over encoder outputs, 4 clips x 6 picks: within the decoder's bars
-    (rms < 1e-4, worst < 4e-4 of the scale), closer to the ln16 oracle than to the mode-1 oracle, ids equal wherever
-    the ln16 oracle's margin resolves them; and back in mode 1 the model decodes as before."""
+    """Precision mode 2 (opt-in) = mode 1 + ggml's remaining rounding points in the decoder: the LayerNorm output rounded
+    to f16 in front of q | k | v, cross q and fc1, against f16 weights; inside both attentions the query rounded to f16
+    in front of K.q and the NORMALISED soft-max probabilities in front of P.V (round 4).  Against its own oracle
+    (DecoderCache(f16=True, ln16=True, attn16=True)) on handed-over encoder outputs, 4 clips x 6 picks: closer to that
+    oracle than to the mode-1 oracle, ids equal wherever the oracle's margin resolves them; and back in mode 1 the model
+    decodes as before.  The bar: every f16 rounding point turns a 3e-7 difference in accumulation order into a full
+    2^-11 step for one value in a few thousand; simulated on the oracle itself (3e-7 noise in front of every activation
+    rounding, these 24 picks) that alone is 1.02e-4 of the scale rms in mode 1, 0.90e-4 with the LayerNorm roundings and
+    1.12e-4 with the attention's as well -- measured here 1.25e-4 (9.2e-5 before the attention's roundings existed).  So:
+    rms < 1.6e-4, worst < 5e-4, and distinctly nearer to this oracle than to mode 1's (2.1e-4)."""
     import torch
     from oracle import whisper_oracle as WO
     hp, W = tiny
@@ -729,7 +767,7 @@ def test_mode_2_decoder_rounds_the_layernorm_outputs_as_ggml_does(tiny, model):
     ids = np.zeros((B, n_new), np.int64)
     for ln16 in (True, False):
         for b in range(B):
-            dc = WO.DecoderCache(W, hp, enc[b], f16=True, ln16=ln16)
+            dc = WO.DecoderCache(W, hp, enc[b], f16=True, ln16=ln16, attn16=ln16)
             for t in prompt[:-1]:
                 dc.step(t)
             tok = prompt[-1]
@@ -748,7 +786,7 @@ def test_mode_2_decoder_rounds_the_layernorm_outputs_as_ggml_does(tiny, model):
     rms2, rms1 = np.sqrt(np.mean(e2 ** 2)), np.sqrt(np.mean(e1 ** 2))
     print(f"mode-2 decoder: rms to the ln16 oracle {rms2:.2e}, to the mode-1 oracle {rms1:.2e}, oracle gap {gap:.2e}, worst {np.abs(e2).max():.2e}")
     assert gap > 3e-5, gap                                       # the extra roundings are visible
-    assert rms2 < 1e-4 and np.abs(e2).max() < 4e-4, (rms2, rms1, gap, np.abs(e2).max())
+    assert rms2 < 1.6e-4 and np.abs(e2).max() < 5e-4, (rms2, rms1, gap, np.abs(e2).max())
     assert rms2 < 0.85 * rms1, (rms2, rms1, gap)                 # its own oracle, not mode 1's
     resolved = margin > 1e-3 * scale
     assert resolved.sum() >= B * n_new // 2, resolved.sum()

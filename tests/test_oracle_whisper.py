@@ -143,6 +143,11 @@ def test_f16_operand_encoder_oracle_is_a_small_perturbation_of_the_exact_one(ora
     b = WO.encoder_forward_f16(W, hp, mel)
     rel = np.abs(a - b).max() / np.abs(a).max()
     assert 1e-4 < rel < 5e-3, rel
+    # attn16 (precision mode 2): normalised probabilities rounded instead of the 2^(t - m) mantissas -- another rounding
+    # of the same size at another point: different from mode 1's, as far from the exact graph
+    c = WO.encoder_forward_f16(W, hp, mel, attn16=True)
+    assert 1e-6 < np.abs(c - b).max() / np.abs(a).max() < 5e-3
+    assert 1e-4 < np.abs(a - c).max() / np.abs(a).max() < 5e-3
     assert WO._h(1.0 + 2.0 ** -11) == 1.0 and WO._h(1.0 + 3 * 2.0 ** -11) == 1.0 + 2.0 ** -9    # round to nearest even
     assert WO._h(70000.0) == np.inf                                                                # f16 range
 
@@ -193,3 +198,12 @@ def test_decoder_cache_f16_mode_only_rounds_where_it_says(tiny, enc_out):
         assert np.array_equal(l0, l)
         rel = np.abs(l2 - lh).max() / np.abs(lh).max()
         assert 1e-5 < rel < 1e-2, (i, rel)
+    # (d) attn16=True (mode 2 as well): q and the normalised probabilities rounded to f16 inside the attentions -- a further
+    # small move; without f16 the flag does nothing
+    d3, d2 = WO.DecoderCache(W, hp, enc_out, f16=True, ln16=True, attn16=True), WO.DecoderCache(W, hp, enc_out, f16=True, ln16=True)
+    d0, dc = WO.DecoderCache(W, hp, enc_out, attn16=True), WO.DecoderCache(W, hp, enc_out)
+    for i, t in enumerate(toks):
+        l3, l2, l0, l = d3.step(t), d2.step(t), d0.step(t), dc.step(t)
+        assert np.array_equal(l0, l)
+        rel = np.abs(l3 - l2).max() / np.abs(l2).max()
+        assert 1e-6 < rel < 1e-2, (i, rel)
