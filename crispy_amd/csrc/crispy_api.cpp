@@ -609,7 +609,7 @@ int process_device_impl(crispy_rn* h, const float* d_in, float* d_out, float* d_
           pa.T = (sa.T - f0) < per ? (sa.T - f0) : per;
           pa.in = sa.in + (long)f0 * a.stride_t;
           pa.xhp = sa.xhp + (long)f0 * RN_FRAME;
-          HIP_TRY(rn_launch_highpass(pa, hs));
+          HIP_TRY(rn_launch_highpass(pa, hs, h->waves == 3));
         }
         HIP_TRY(hipEventRecord(h->ev_hp[i], hs));
         hp_ts += sa.T;

@@ -117,7 +117,7 @@ struct RnArgs {
   const uint32_t* wpack;
 };
 
-hipError_t rn_launch_highpass(const RnArgs& a, hipStream_t s);
+hipError_t rn_launch_highpass(const RnArgs& a, hipStream_t s, bool deep = false);   // deep: 32 samples requested ahead (few streams)
 hipError_t rn_launch_frames(const RnArgs& a, hipStream_t s, int waves_per_stream = 1);   // the frame: analysis + gain network + synthesis
 hipError_t rn_launch_roll_history(const RnArgs& a, hipStream_t s);
 hipError_t rn_launch_tansig(const RnTables* tab, const float* x, float* y, long n, int sigmoid, hipStream_t s);

@@ -1816,7 +1816,13 @@ __global__ __launch_bounds__(3 * WAVE) __attribute__((amdgpu_waves_per_eu(4))) v
 // =============================================================================================
 // high-pass: one lane per stream, strictly sequential (Appendix A.3 step 1, double products)
 // =============================================================================================
-__global__ __launch_bounds__(WAVE) RN_HP_VGPR_CAP void rn_highpass_kernel(RnArgs a) {
+// BLK = float4 blocks per request group.  2 (8 samples, 32 registers): the form that fits beside four frame waves of a
+// SIMD at thousands of streams.  8 (32 samples ahead, no register cap): few streams, where this chain is what a call
+// waits for and nothing competes for registers -- in the stream-major layout every lane reads from its own 5.8 MB
+// region (a TLB entry each), and one block of eight samples ahead (~0.4 us of chain) does not cover a miss:
+// 1024 streams x 3001 frames 127 ms per call in that layout against 89 ms frame-major, same frame kernels.
+template <int BLK>
+__device__ __forceinline__ void rn_highpass_body(const RnArgs& a) {
   const int b = blockIdx.x * WAVE + threadIdx.x;
   if (b >= a.B) return;
   // One lane per stream, a chain of ten f64-path instructions per sample that nothing inside the wave can overlap: the
@@ -1829,7 +1835,8 @@ __global__ __launch_bounds__(WAVE) RN_HP_VGPR_CAP void rn_highpass_kernel(RnArgs
   // The recurrence is a dependent chain of five operations per sample; what the lane must not also wait for is its
   // input.  Blocks of 4 RN_HP_BLK samples are requested one block ahead, across frame boundaries: with the load
   // issued right in front of its use the kernel spent most of its time on one L1/L2 round trip per four samples.
-  constexpr int BLK = RN_HP_BLK, NBLK = RN_FRAME / 4 / BLK;   // blocks per frame
+  constexpr int NBLK = RN_FRAME / 4 / BLK;   // blocks per frame
+  static_assert(RN_FRAME % (4 * BLK) == 0, "whole blocks per frame");
   const long total = (long)a.T * NBLK;
   auto block_ptr = [&](long k) {
     const long t = k / NBLK, blk = k - t * NBLK;
@@ -1872,6 +1879,8 @@ __global__ __launch_bounds__(WAVE) RN_HP_VGPR_CAP void rn_highpass_kernel(RnArgs
   a.hp_mem[2 * b] = m0;
   a.hp_mem[2 * b + 1] = m1;
 }
+__global__ __launch_bounds__(WAVE) RN_HP_VGPR_CAP void rn_highpass_kernel(RnArgs a) { rn_highpass_body<RN_HP_BLK>(a); }
+__global__ __launch_bounds__(WAVE) void rn_highpass_deep_kernel(RnArgs a) { rn_highpass_body<8>(a); }
 
 // Stage entry point for parity tests: the frame kernel's own activation code (TansigTab in four registers per lane,
 // ds_bpermute lookups, the +-8 clamps) applied to n arbitrary arguments, so that every table cell and both clamps can
@@ -1910,8 +1919,9 @@ __global__ __launch_bounds__(256) void rn_roll_history_kernel(RnArgs a) {
 
 }  // namespace
 
-hipError_t rn_launch_highpass(const RnArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(rn_highpass_kernel, dim3((a.B + WAVE - 1) / WAVE), dim3(WAVE), 0, s, a);
+hipError_t rn_launch_highpass(const RnArgs& a, hipStream_t s, bool deep) {
+  if (deep) hipLaunchKernelGGL(rn_highpass_deep_kernel, dim3((a.B + WAVE - 1) / WAVE), dim3(WAVE), 0, s, a);
+  else hipLaunchKernelGGL(rn_highpass_kernel, dim3((a.B + WAVE - 1) / WAVE), dim3(WAVE), 0, s, a);
   return hipGetLastError();
 }
 hipError_t rn_launch_frames(const RnArgs& a, hipStream_t s, int waves_per_stream) {
