@@ -175,9 +175,9 @@ __device__ __forceinline__ void butterfly<8>(const float2 (&v)[8], float2 (&o)[8
 // high-pass kernel at 32 (two float4 blocks of input in flight instead of eight; 12 B of prologue scratch).
 // amdgpu_num_vgpr counts the unified VGPR + AGPR file on gfx950, so the attribute wants half the number (120 / 32
 // given directly are silently ignored).  Measured: 7.71 -> 7.585 ms per 100-frame step.
-#define RN_VGPR_CAP __attribute__((amdgpu_num_vgpr(56)))
-#define RN_HP_VGPR_CAP __attribute__((amdgpu_num_vgpr(32)))
-constexpr int RN_HP_BLK = 4;
+#define RN_VGPR_CAP __attribute__((amdgpu_num_vgpr(60)))
+#define RN_HP_VGPR_CAP __attribute__((amdgpu_num_vgpr(16)))
+constexpr int RN_HP_BLK = 2;
 template <int R, int NS>
 __device__ __forceinline__ int fft_rd(int j, int r) {
   constexpr int M = 480 / R;
