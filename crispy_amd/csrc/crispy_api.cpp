@@ -234,6 +234,7 @@ struct crispy_rn {
   int waves = 1;
   int hp_ahead = 0;          // > 0: the high-pass runs at most this many sub-chunks in front of the frame kernels
   std::vector<hipEvent_t> ev_fr;   // one per sub-chunk: frame kernel done (only used with hp_ahead)
+  bool hp_deep = false;      // the high-pass requests 32 samples ahead (80 registers): set where a wave of it fits beside the frame waves
   bool hp_upfront = false;   // diagnostic (CRISPY_RN_HP=upfront): every high-pass of a call segment first, on the main stream
   float* d_dbg = nullptr;
   // host-pointer staging
@@ -471,6 +472,10 @@ int crispy_rn_create(const int8_t* weights, size_t nbytes, int n_streams, int de
       h->hp_upfront = hp && std::strcmp(hp, "upfront") == 0;
       const char* wv = std::getenv("CRISPY_RN_WAVES");
       h->waves = wv ? (std::atoi(wv) == 3 ? 3 : 1) : (n_streams <= kStagedMaxStreams ? 3 : 1);
+      // with the stage-pipelined form, i.e. <= 1280 streams: from 1536 streams on a call is as long as its frame kernels
+      // with either request depth (sweep in NOTEBOOK 8.6)
+      const char* hd = std::getenv("CRISPY_RN_HP_DEEP");
+      h->hp_deep = hd ? std::atoi(hd) != 0 : h->waves == 3;
       const char* sp = std::getenv("CRISPY_RN_HP_SPLIT");
       if (sp) h->hp_split = std::atoi(sp);   // 0: one kernel per sub-chunk
       const char* ah = std::getenv("CRISPY_RN_HP_AHEAD");
@@ -609,7 +614,7 @@ int process_device_impl(crispy_rn* h, const float* d_in, float* d_out, float* d_
           pa.T = (sa.T - f0) < per ? (sa.T - f0) : per;
           pa.in = sa.in + (long)f0 * a.stride_t;
           pa.xhp = sa.xhp + (long)f0 * RN_FRAME;
-          HIP_TRY(rn_launch_highpass(pa, hs, h->waves == 3));
+          HIP_TRY(rn_launch_highpass(pa, hs, h->hp_deep));
         }
         HIP_TRY(hipEventRecord(h->ev_hp[i], hs));
         hp_ts += sa.T;

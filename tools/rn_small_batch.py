@@ -14,7 +14,7 @@ from crispy_amd.denoise import DenoiseState
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 w = synthetic_weights(0)
 dev = torch.device("cuda", 0)
-for B in (256, 1024, 1280):
+for B in [int(v) for v in os.environ.get("STREAMS", "256,1024,1280").split(",")]:
     x = synth_audio.batch_torch(B, T, dev, first_stream=0, seed=0)
     y = torch.empty_like(x)
     torch.cuda.synchronize()
