@@ -1054,10 +1054,10 @@ __device__ __forceinline__ unsigned load_u32_unaligned(const unsigned char* p) {
 __device__ __forceinline__ void step_fuse_tail(const StepFuse& f, int tok, int pos, int step, int b, int tid) {
   const int pe = f.row_off ? pos - f.row_off[b] : pos;    // cache row `pos` is position pos - row_off[b] of a left-padded clip
   if (f.tok_emb_q) {
-    for (int c = tid; c < f.D; c += 1024)
+    for (int c = tid; c < f.D; c += (int)blockDim.x)
       f.x[(long)b * f.D + c] = q_elem(f.tok_emb_q, f.tok_emb_ttype, (long)tok * f.D + c) + f.pos_emb[(long)pe * f.D + c];
   } else {
-    for (int c = tid; c < f.D; c += 1024) f.x[(long)b * f.D + c] = f.tok_emb[(long)tok * f.D + c] + f.pos_emb[(long)pe * f.D + c];
+    for (int c = tid; c < f.D; c += (int)blockDim.x) f.x[(long)b * f.D + c] = f.tok_emb[(long)tok * f.D + c] + f.pos_emb[(long)pe * f.D + c];
   }
   if (tid == 0) {
     // No fence: nothing of this kernel is read by another workgroup of it -- the ticket only elects the workgroup that
@@ -1347,12 +1347,15 @@ __global__ __launch_bounds__(1024) void ts_pick_kernel(TsPickArgs a) {
 // reaches the uniform variate u the host drew for this (step, row).  Only the fallback path of whisper_full comes here
 // (a window the greedy pass failed on), so the kernel is plain: thread t owns the ids [t * chunk, (t + 1) * chunk),
 // three passes over them (maxima, sums, probabilities), cumulative sums in double.
-__global__ __launch_bounds__(1024) void ts_sample_kernel(TsPickArgs a) {
-  __shared__ float s_v[2][16];
-  __shared__ int s_i[16];
-  __shared__ float s_sum[2][16];
-  __shared__ double s_cum[1024];
-  __shared__ double s_wave[16];
+// 512 threads per row, a thread's ids in registers: TS_CHUNK = 104 of them, n_vocab <= 512 x 104 = 53 248 (1024 threads x 52
+// ids would have to live in 128 registers: 124 bytes of scratch per lane)
+constexpr int TS_THREADS = 512, TS_WAVES = TS_THREADS / 64, TS_CHUNK = 104;
+__global__ __launch_bounds__(TS_THREADS) void ts_sample_kernel(TsPickArgs a) {
+  __shared__ float s_v[2][TS_WAVES];
+  __shared__ int s_i[TS_WAVES];
+  __shared__ float s_sum[2][TS_WAVES];
+  __shared__ double s_cum[TS_THREADS];
+  __shared__ double s_wave[TS_WAVES];
   __shared__ int s_tok, s_last;
   __shared__ float s_px;
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -1373,16 +1376,27 @@ __global__ __launch_bounds__(1024) void ts_sample_kernel(TsPickArgs a) {
   const TsRule rule(a, st);
   const float T = *a.temperature;
   const double u = a.u_all[(long)step * gridDim.x + b];
-  const int chunk = (a.V + 1023) / 1024;
+  const int chunk = (a.V + TS_THREADS - 1) / TS_THREADS;
   const int v0 = tid * chunk, v1 = min(a.V, v0 + chunk);
   if (tid == 0) { s_tok = -1; s_last = -1; }
+  // This thread's ids live in registers for the whole kernel: x = logit / T where the rules allow the id, -inf where
+  // they do not (one load, one division and one rule test per id instead of three of each; the first version walked
+  // lg[] three times, 51 strided loads per thread and pass: 148 us per pick, a sixth of the time of a call that falls
+  // back through the temperature ladder).  TS_CHUNK bounds the vocabulary at 512 x 104 ids (the launcher checks).
+  float xr[TS_CHUNK];
+#pragma unroll
+  for (int k = 0; k < TS_CHUNK; ++k) {
+    const int v = v0 + k;
+    xr[k] = (v < v1 && rule.allowed(v, a.eot)) ? lg[v] / T : -INFINITY;
+  }
+  const int nb = a.beg - v0;        // ids k < nb are text / special ids, k >= nb timestamps
   float tv = -INFINITY, xv = -INFINITY;
   int xi = 0x7fffffff;
-  for (int v = v0; v < v1; ++v) {
-    if (!rule.allowed(v, a.eot)) continue;
-    const float x = lg[v] / T;
-    if (v < a.beg) tv = fmaxf(tv, x);
-    else if (x > xv) { xv = x; xi = v; }                      // ascending ids: the first maximum stays
+#pragma unroll
+  for (int k = 0; k < TS_CHUNK; ++k) {
+    const float x = xr[k];
+    if (k < nb) tv = fmaxf(tv, x);
+    else if (x > xv) { xv = x; xi = v0 + k; }                  // ascending ids: the first maximum stays
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -1395,17 +1409,18 @@ __global__ __launch_bounds__(1024) void ts_sample_kernel(TsPickArgs a) {
   float max_text = s_v[0][0], max_ts = s_v[1][0];
   int arg_ts = s_i[0];
 #pragma unroll
-  for (int w = 1; w < 16; ++w) {
+  for (int w = 1; w < TS_WAVES; ++w) {
     max_text = fmaxf(max_text, s_v[0][w]);
     if (s_v[1][w] > max_ts || (s_v[1][w] == max_ts && s_i[w] < arg_ts)) { max_ts = s_v[1][w]; arg_ts = s_i[w]; }
   }
   const float max_all = fmaxf(max_text, max_ts);
   float sum_all = 0.f, sum_ts = 0.f;
-  for (int v = v0; v < v1; ++v) {
-    if (!rule.allowed(v, a.eot)) continue;
-    const float x = lg[v] / T;
+#pragma unroll
+  for (int k = 0; k < TS_CHUNK; ++k) {
+    const float x = xr[k];
+    if (x == -INFINITY) continue;                              // not allowed (or past the row): contributed nothing before either
     sum_all += expf(x - max_all);
-    if (v >= a.beg) sum_ts += expf(x - max_ts);
+    if (k >= nb) sum_ts += expf(x - max_ts);
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { sum_all += __shfl_xor(sum_all, off, 64); sum_ts += __shfl_xor(sum_ts, off, 64); }
@@ -1413,17 +1428,19 @@ __global__ __launch_bounds__(1024) void ts_sample_kernel(TsPickArgs a) {
   __syncthreads();
   float tot_all = 0.f, tot_ts = 0.f;
 #pragma unroll
-  for (int w = 0; w < 16; ++w) { tot_all += s_sum[0][w]; tot_ts += s_sum[1][w]; }
+  for (int w = 0; w < TS_WAVES; ++w) { tot_all += s_sum[0][w]; tot_ts += s_sum[1][w]; }
   const float lse_all = max_all + logf(tot_all);
   const float lse_ts = max_ts > -INFINITY ? max_ts + logf(tot_ts) : -INFINITY;
   const bool ts_only = lse_ts > max_text;                      // the probability-mass rule
-  // probabilities of this thread's ids, then an inclusive scan of the 1024 partial sums
+  // probabilities of this thread's ids (kept: the owner of u walks them again), then an inclusive scan of the 512 partial sums
   double loc = 0.0;
   int last_pos = -1;
-  for (int v = v0; v < v1; ++v) {
-    if ((ts_only && v < a.beg) || !rule.allowed(v, a.eot)) continue;
-    const float p = expf(lg[v] / T - lse_all);
-    if (p > 0.f) { loc += (double)p; last_pos = v; }
+#pragma unroll
+  for (int k = 0; k < TS_CHUNK; ++k) {
+    float p = 0.f;
+    if (xr[k] != -INFINITY && !(ts_only && k < nb)) p = expf(xr[k] - lse_all);
+    if (p > 0.f) { loc += (double)p; last_pos = v0 + k; }
+    else xr[k] = -INFINITY;                                    // from here on: -inf = contributes nothing
   }
   double inc = loc;
 #pragma unroll
@@ -1436,7 +1453,7 @@ __global__ __launch_bounds__(1024) void ts_sample_kernel(TsPickArgs a) {
   __syncthreads();
   double base = 0.0, total = 0.0;
 #pragma unroll
-  for (int w = 0; w < 16; ++w) { if (w < (tid >> 6)) base += s_wave[w]; total += s_wave[w]; }
+  for (int w = 0; w < TS_WAVES; ++w) { if (w < (tid >> 6)) base += s_wave[w]; total += s_wave[w]; }
   inc += base;
   s_cum[tid] = inc;
   __syncthreads();
@@ -1444,17 +1461,17 @@ __global__ __launch_bounds__(1024) void ts_sample_kernel(TsPickArgs a) {
   const double lo = (tid ? s_cum[tid - 1] : 0.0) / total;
   const bool owns_last = last_pos >= 0 && last_pos == s_last;
   const double hi = owns_last ? 1.0 : inc / total;
-  if (loc > 0.0 && ((lo < u && u <= hi) || (tid == 0 && u <= 0.0 && false))) {
+  if (loc > 0.0 && lo < u && u <= hi) {
     double c = tid ? s_cum[tid - 1] : 0.0;
     int pick = last_pos;
     float px = 0.f;
-    for (int v = v0; v < v1; ++v) {
-      if ((ts_only && v < a.beg) || !rule.allowed(v, a.eot)) continue;
-      const float x = lg[v] / T;
-      const float p = expf(x - lse_all);
-      if (p <= 0.f) continue;
-      c += (double)p;
-      if (c / total >= u || v == last_pos) { pick = v; px = x; break; }
+    bool found = false;
+#pragma unroll
+    for (int k = 0; k < TS_CHUNK; ++k) {
+      const float x = xr[k];
+      if (found || x == -INFINITY) continue;
+      c += (double)expf(x - lse_all);
+      if (c / total >= u || v0 + k == last_pos) { pick = v0 + k; px = x; found = true; }
     }
     s_tok = pick;
     s_px = px;
@@ -1710,8 +1727,8 @@ hipError_t softmax_prob_f32(const float* logits, int V, long ld, int token, floa
 
 hipError_t ts_pick(const TsPickArgs& a, int B, hipStream_t s) {
   if (a.u_all) {
-    if (!a.temperature) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ts_sample_kernel, dim3(B), dim3(1024), 0, s, a);
+    if (!a.temperature || a.V > TS_THREADS * TS_CHUNK) return hipErrorInvalidValue;      // a thread's ids live in TS_CHUNK registers
+    hipLaunchKernelGGL(ts_sample_kernel, dim3(B), dim3(TS_THREADS), 0, s, a);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(ts_pick_kernel, dim3(B), dim3(1024), 0, s, a);
