@@ -748,7 +748,9 @@ def _cfg4(args, numa, in_process=False):
         for _ in range(max(1, args.warmup)):
             toks, _ = p.run(x, prompt, NEW)
             p.ds.reset()
-    stage = dict(pipes[0].timings)        # serial stage split (the last warm-up run of pipeline 0, nothing beside it)
+    toks, _ = pipes[0].run(x, prompt, NEW)   # one more run of pipeline 0 alone, everything warm: the serial stage split
+    pipes[0].ds.reset()
+    stage = dict(pipes[0].timings)
     serial_ms = sum(stage.values()) * 1e3
 
     def barrier():
