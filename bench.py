@@ -703,11 +703,12 @@ def cfg4(args):
     --precision 0.  value = seconds of audio per wall second, whole job.
 
     RNNoise is a strict 3000-frame recurrence per stream (~42 us per frame and wave whatever the stream count below 4096),
-    so inside ONE step it cannot overlap the ASR stages of the same streams; across steps it can: `--pipe-depth 4`
-    (default) drives four pipelines (own handles, own HIP streams, own workspaces) from four host threads, and the
-    denoise stages of later steps run under the encoder / decoder of earlier ones (depth 1 / 2 / 3 / 4: 401 / 338 / 337 /
-    302 ms per step; a fifth pipeline no longer fits the decode workspaces of four).  `--pipe-depth 1` is the serial form
-    whose stage split is printed beside it."""
+    so inside ONE step it cannot overlap the ASR stages of the same streams; across steps it can: `--pipe-depth 3`
+    (default) drives three pipelines (own handles, own HIP streams, own workspaces) from three host threads, and the
+    denoise stages of later steps run under the encoder / decoder of earlier ones.  End of round 4, depth 1 / 2 / 3 / 4:
+    328 / 321 / 307 / 309 ms per step as a process of its own (8 steps), 324 / 310 / 309 / 323 as a leg of the headline
+    process -- which hardware queue a HIP stream lands on is the runtime's choice, and streams that share one take turns
+    (NOTEBOOK 8.7).  `--pipe-depth 1` is the serial form whose stage split is printed beside it."""
     rank, local_rank, world = _dist_env()
     numa = _bind_numa(local_rank, world)
     line = _cfg4(args, numa)
@@ -837,7 +838,7 @@ def main():
     ap.add_argument("--cfg5-depth", type=int, default=2,
                     help="cfg5: sub-batches in flight (own engine handle, HIP stream and host thread each): the encoder of one "
                          "runs beside the decode steps of another; 1 = serial")
-    ap.add_argument("--pipe-depth", type=int, default=4,
+    ap.add_argument("--pipe-depth", type=int, default=3,
                     help="cfg4: pipelines in flight (own handles and HIP streams, one host thread each): with 2, RNNoise of "
                          "step k + 1 runs under the encoder / decoder of step k; 1 = serial")
     ap.add_argument("--precision", type=int, default=1,
@@ -1096,7 +1097,7 @@ def cfg2(args):
             import copy
             ds.close()
             torch.cuda.empty_cache()
-            for key, fn, over in (("cfg4", _cfg4, dict(steps=4, warmup=1, new_tokens=64)),
+            for key, fn, over in (("cfg4", _cfg4, dict(steps=6, warmup=1, new_tokens=64)),
                                   ("cfg5", _cfg5, dict(steps=2, warmup=1, new_tokens=32))):
                 a2 = copy.copy(args)
                 for k2, v2 in over.items():
