@@ -433,6 +433,13 @@ def asr_leg(local_rank: int, clips: int = 64, new_tokens: int = 32, ggml_path: s
         cpu = {"error": str(e)}
     audio_s = clips * 30.0
     enc_flops = clips * encoder_flops(hp)          # 36.9 GFLOP per 30 s clip for Whisper-tiny
+    # mode-1 bytes (NOTEBOOK 8.1): per layer LayerNorm x 2 (f32 in, f16 out), q|k|v, attention, out-projection and fc2
+    # (f16 A, f32 residual in and out), fc1 (f16 in, 4 d f16 out) = 64 M d bytes with M = 1500 rows per clip; stem: the f16
+    # log-mel, conv1's f16 output written and read, conv2's f32 output
+    m_rows, d_enc = clips * hp.n_audio_ctx, hp.n_audio_state
+    enc_bytes16 = hp.n_audio_layer * 64.0 * m_rows * d_enc + clips * 3000 * hp.n_mels * 2 + 2 * (2 * m_rows) * d_enc * 2 + m_rows * d_enc * 4
+    steps16 = new_tokens + 4                       # positions of the decode call: the 4-token prompt + the new tokens
+    dec_bytes16 = steps16 * (hp.n_text_layer * clips * hp.n_audio_ctx * 2 * hp.n_text_state * 2 + hp.n_vocab * hp.n_text_state * 2)
     total = sum(times.values())
     return {
         "model": model_label,
@@ -456,7 +463,21 @@ def asr_leg(local_rank: int, clips: int = 64, new_tokens: int = 32, ggml_path: s
                              "encoder_roofline": {"bound": "mfma", "achieved": enc_flops / times16["encoder"] / 1e12,
                                                   "peak": 2500.0, "unit": "TFLOP/s",
                                                   "frac": enc_flops / times16["encoder"] / 1e12 / 2500.0,
-                                                  "note": "peak = dense f16 MFMA (v_mfma_f32_32x32x16_f16)"}},
+                                                  "note": "peak = dense f16 MFMA (v_mfma_f32_32x32x16_f16)"},
+                             # the same pass against the OTHER roof: with K = d and an f32 residual stream every GEMM of
+                             # this encoder sits left of the 312 flop / byte ridge (NOTEBOOK 8.1), so bytes are the price
+                             "encoder_hbm_roofline": {"bound": "hbm", "achieved": enc_bytes16 / times16["encoder"] / 1e9,
+                                                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                      "frac": enc_bytes16 / times16["encoder"] / 1e9 / HBM_PEAK_GBS,
+                                                      "bytes_per_pass": enc_bytes16,
+                                                      "note": "algorithmic bytes of the tensors each kernel reads and writes "
+                                                              "once (64 M d per layer + the convolution stem); L2 / "
+                                                              "Infinity-Cache hits between producer and consumer not deducted"},
+                             "decode_hbm_roofline": {"bound": "hbm", "achieved": dec_bytes16 / times16["decode"] / 1e9,
+                                                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                     "frac": dec_bytes16 / times16["decode"] / 1e9 / HBM_PEAK_GBS,
+                                                     "note": "f16 cross K|V of all layers + the f16 token embedding, once per "
+                                                             "decoded position"}},
         "single_clip": {"what": "ONE 30 s chunk, host PCM in, token ids out (crispy_asr_transcribe_tokens): the call the "
                                 "reference makes per chunk (managers/transcription.rs:183-185)",
                         "ms": one * 1e3, "rtfx": 30.0 / one, "f16_operand_mode_ms": one16 * 1e3, "f16_operand_mode_rtfx": 30.0 / one16,
