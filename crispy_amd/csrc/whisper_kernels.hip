@@ -1186,6 +1186,14 @@ struct TsRule {
     if (v < eot) return text_allowed && !(mask && mask[v]);
     return !masked_hi(v);
   }
+  // the same with the id's suppression byte already loaded (the sampling pick reads eight at a time)
+  __device__ __forceinline__ bool allowed_m(int v, int eot, bool masked) const {
+    if (masked) return false;
+    if (v < eot) return text_allowed;
+    if (v == not_tok) return false;
+    if (v >= beg) return !(no_ts || v < ts_lo || v > ts_hi);
+    return !forced_ts;
+  }
 };
 
 // record a pick and move the window's state on (thread 0 of the clip's workgroup)
@@ -1347,18 +1355,50 @@ __global__ __launch_bounds__(1024) void ts_pick_kernel(TsPickArgs a) {
 // reaches the uniform variate u the host drew for this (step, row).  Only the fallback path of whisper_full comes here
 // (a window the greedy pass failed on), so the kernel is plain: thread t owns the ids [t * chunk, (t + 1) * chunk),
 // three passes over them (maxima, sums, probabilities), cumulative sums in double.
-// 512 threads per row, a thread's ids in registers: TS_CHUNK = 104 of them, n_vocab <= 512 x 104 = 53 248 (1024 threads x 52
-// ids would have to live in 128 registers: 124 bytes of scratch per lane)
-constexpr int TS_THREADS = 512, TS_WAVES = TS_THREADS / 64, TS_CHUNK = 104;
+// The sampling pick: 1024 threads per row.  Ids are dealt out in blocks of 8192: thread t owns the eight consecutive ids
+// 8192 j + 8 t .. + 7 of every block j (7 blocks cover n_vocab <= 57 344: the launcher checks), so a wave's loads are two
+// contiguous float4 runs per block -- and one 8-byte run of the suppression mask -- instead of 64 scattered lines per id
+// (the first form, one contiguous range of ids per thread: 148 us per pick, most of a call that falls back through the
+// temperature ladder).  Three passes over the row (maximum; sums; probabilities), each re-reading it from the L2 it was
+// just written to: keeping the row in registers across the passes was tried in three shapes and spilled in all of them
+// (56 - 104 values per lane beside three inlined expf per value).  The cumulative distribution runs in id order =
+// (block, thread, element): per block an inclusive scan of the threads' eight-id sums in double, block bases from a
+// 7 x 16 table of wave totals; the thread whose run contains u walks its eight ids.
+constexpr int TS_THREADS = 1024, TS_WAVES = TS_THREADS / 64, TS_E = 8, TS_BLK = TS_THREADS * TS_E, TS_NB = 7;
+// x[e] = logit / T where the rules allow id v0 + e, -inf where they do not or past the row
+__device__ __forceinline__ void ts_load_run(const TsRule& rule, const float* __restrict__ lg, int V, int eot, float T, int v0, float (&x)[TS_E]) {
+  float raw[TS_E];
+  unsigned char mk[TS_E];
+  if (v0 + TS_E <= V) {                 // whole run inside the row: rows are 16-byte aligned (ld % 4 == 0), so is v0
+    const float4 q0 = *reinterpret_cast<const float4*>(lg + v0), q1 = *reinterpret_cast<const float4*>(lg + v0 + 4);
+    raw[0] = q0.x; raw[1] = q0.y; raw[2] = q0.z; raw[3] = q0.w; raw[4] = q1.x; raw[5] = q1.y; raw[6] = q1.z; raw[7] = q1.w;
+    uint2 m8 = make_uint2(0u, 0u);
+    if (rule.mask) m8 = *reinterpret_cast<const uint2*>(rule.mask + v0);
+#pragma unroll
+    for (int e = 0; e < TS_E; ++e) mk[e] = (unsigned char)((e < 4 ? m8.x >> (8 * e) : m8.y >> (8 * (e - 4))) & 0xffu);
+  } else {
+#pragma unroll
+    for (int e = 0; e < TS_E; ++e) {
+      const int v = v0 + e;
+      raw[e] = v < V ? lg[v] : 0.f;
+      mk[e] = (v < V && rule.mask) ? rule.mask[v] : 0;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < TS_E; ++e) {
+    const int v = v0 + e;
+    x[e] = (v < V && rule.allowed_m(v, eot, mk[e] != 0)) ? raw[e] / T : -INFINITY;
+  }
+}
 __global__ __launch_bounds__(TS_THREADS) void ts_sample_kernel(TsPickArgs a) {
   __shared__ float s_v[2][TS_WAVES];
   __shared__ int s_i[TS_WAVES];
   __shared__ float s_sum[2][TS_WAVES];
-  __shared__ double s_cum[TS_THREADS];
-  __shared__ double s_wave[TS_WAVES];
+  __shared__ double s_wtot[TS_NB][TS_WAVES];
+  __shared__ double s_own[TS_NB][TS_THREADS], s_pre[TS_NB][TS_THREADS];     // a run's sum / what its wave holds in front of it (2 x 56 KB)
   __shared__ int s_tok, s_last;
   __shared__ float s_px;
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int step = a.fuse.x ? a.fuse.counters[1] : a.step_dev ? *a.step_dev : 0;
   const int pos = a.fuse.x ? a.fuse.counters[0] + 1 : 0;
   TsState st = a.st[b];
@@ -1376,27 +1416,20 @@ __global__ __launch_bounds__(TS_THREADS) void ts_sample_kernel(TsPickArgs a) {
   const TsRule rule(a, st);
   const float T = *a.temperature;
   const double u = a.u_all[(long)step * gridDim.x + b];
-  const int chunk = (a.V + TS_THREADS - 1) / TS_THREADS;
-  const int v0 = tid * chunk, v1 = min(a.V, v0 + chunk);
   if (tid == 0) { s_tok = -1; s_last = -1; }
-  // This thread's ids live in registers for the whole kernel: x = logit / T where the rules allow the id, -inf where
-  // they do not (one load, one division and one rule test per id instead of three of each; the first version walked
-  // lg[] three times, 51 strided loads per thread and pass: 148 us per pick, a sixth of the time of a call that falls
-  // back through the temperature ladder).  TS_CHUNK bounds the vocabulary at 512 x 104 ids (the launcher checks).
-  float xr[TS_CHUNK];
-#pragma unroll
-  for (int k = 0; k < TS_CHUNK; ++k) {
-    const int v = v0 + k;
-    xr[k] = (v < v1 && rule.allowed(v, a.eot)) ? lg[v] / T : -INFINITY;
-  }
-  const int nb = a.beg - v0;        // ids k < nb are text / special ids, k >= nb timestamps
+  // ---- pass 1: maxima of the text / special ids and of the timestamps ----
   float tv = -INFINITY, xv = -INFINITY;
   int xi = 0x7fffffff;
+#pragma unroll 1
+  for (int jb = 0; jb < TS_NB; ++jb) {
+    const int v0 = TS_BLK * jb + TS_E * tid;
+    float x[TS_E];
+    ts_load_run(rule, lg, a.V, a.eot, T, v0, x);
 #pragma unroll
-  for (int k = 0; k < TS_CHUNK; ++k) {
-    const float x = xr[k];
-    if (k < nb) tv = fmaxf(tv, x);
-    else if (x > xv) { xv = x; xi = v0 + k; }                  // ascending ids: the first maximum stays
+    for (int e = 0; e < TS_E; ++e) {
+      if (v0 + e < a.beg) tv = fmaxf(tv, x[e]);
+      else if (x[e] > xv) { xv = x[e]; xi = v0 + e; }          // a thread's ids ascend: its first maximum stays
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -1404,7 +1437,7 @@ __global__ __launch_bounds__(TS_THREADS) void ts_sample_kernel(TsPickArgs a) {
     const float ov = __shfl_xor(xv, off, 64); const int oi = __shfl_xor(xi, off, 64);
     if (ov > xv || (ov == xv && oi < xi)) { xv = ov; xi = oi; }
   }
-  if ((tid & 63) == 0) { s_v[0][tid >> 6] = tv; s_v[1][tid >> 6] = xv; s_i[tid >> 6] = xi; }
+  if (lane == 0) { s_v[0][wave] = tv; s_v[1][wave] = xv; s_i[wave] = xi; }
   __syncthreads();
   float max_text = s_v[0][0], max_ts = s_v[1][0];
   int arg_ts = s_i[0];
@@ -1414,17 +1447,23 @@ __global__ __launch_bounds__(TS_THREADS) void ts_sample_kernel(TsPickArgs a) {
     if (s_v[1][w] > max_ts || (s_v[1][w] == max_ts && s_i[w] < arg_ts)) { max_ts = s_v[1][w]; arg_ts = s_i[w]; }
   }
   const float max_all = fmaxf(max_text, max_ts);
+  // ---- pass 2: sums of exponentials ----
   float sum_all = 0.f, sum_ts = 0.f;
+#pragma unroll 1
+  for (int jb = 0; jb < TS_NB; ++jb) {
+    const int v0 = TS_BLK * jb + TS_E * tid;
+    float x[TS_E];
+    ts_load_run(rule, lg, a.V, a.eot, T, v0, x);
 #pragma unroll
-  for (int k = 0; k < TS_CHUNK; ++k) {
-    const float x = xr[k];
-    if (x == -INFINITY) continue;                              // not allowed (or past the row): contributed nothing before either
-    sum_all += expf(x - max_all);
-    if (k >= nb) sum_ts += expf(x - max_ts);
+    for (int e = 0; e < TS_E; ++e) {
+      if (x[e] == -INFINITY) continue;                         // not allowed, or past the row
+      sum_all += expf(x[e] - max_all);
+      if (v0 + e >= a.beg) sum_ts += expf(x[e] - max_ts);
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { sum_all += __shfl_xor(sum_all, off, 64); sum_ts += __shfl_xor(sum_ts, off, 64); }
-  if ((tid & 63) == 0) { s_sum[0][tid >> 6] = sum_all; s_sum[1][tid >> 6] = sum_ts; }
+  if (lane == 0) { s_sum[0][wave] = sum_all; s_sum[1][wave] = sum_ts; }
   __syncthreads();
   float tot_all = 0.f, tot_ts = 0.f;
 #pragma unroll
@@ -1432,55 +1471,78 @@ __global__ __launch_bounds__(TS_THREADS) void ts_sample_kernel(TsPickArgs a) {
   const float lse_all = max_all + logf(tot_all);
   const float lse_ts = max_ts > -INFINITY ? max_ts + logf(tot_ts) : -INFINITY;
   const bool ts_only = lse_ts > max_text;                      // the probability-mass rule
-  // probabilities of this thread's ids (kept: the owner of u walks them again), then an inclusive scan of the 512 partial sums
-  double loc = 0.0;
+  // ---- pass 3: probabilities, eight-id sums per block, and per block an inclusive scan over the wave ----
   int last_pos = -1;
+#pragma unroll 1
+  for (int jb = 0; jb < TS_NB; ++jb) {
+    const int v0 = TS_BLK * jb + TS_E * tid;
+    float x[TS_E];
+    ts_load_run(rule, lg, a.V, a.eot, T, v0, x);
+    double sj = 0.0;
 #pragma unroll
-  for (int k = 0; k < TS_CHUNK; ++k) {
-    float p = 0.f;
-    if (xr[k] != -INFINITY && !(ts_only && k < nb)) p = expf(xr[k] - lse_all);
-    if (p > 0.f) { loc += (double)p; last_pos = v0 + k; }
-    else xr[k] = -INFINITY;                                    // from here on: -inf = contributes nothing
-  }
-  double inc = loc;
+    for (int e = 0; e < TS_E; ++e) {
+      float p = 0.f;
+      if (x[e] != -INFINITY && !(ts_only && v0 + e < a.beg)) p = expf(x[e] - lse_all);
+      if (p > 0.f) { sj += (double)p; last_pos = v0 + e; }
+    }
+    double in = sj;
 #pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const double o = __shfl_up(inc, off, 64);
-    if ((tid & 63) >= off) inc += o;
+    for (int off = 1; off < 64; off <<= 1) {
+      const double o = __shfl_up(in, off, 64);
+      if (lane >= off) in += o;
+    }
+    s_own[jb][tid] = sj;
+    s_pre[jb][tid] = in - sj;
+    if (lane == 63) s_wtot[jb][wave] = in;
   }
-  if ((tid & 63) == 63) s_wave[tid >> 6] = inc;
   if (last_pos >= 0) atomicMax(&s_last, last_pos);
   __syncthreads();
-  double base = 0.0, total = 0.0;
+  double total = 0.0;
 #pragma unroll
-  for (int w = 0; w < TS_WAVES; ++w) { if (w < (tid >> 6)) base += s_wave[w]; total += s_wave[w]; }
-  inc += base;
-  s_cum[tid] = inc;
-  __syncthreads();
-  // the thread whose interval (cum[t - 1], cum[t]] / total contains u walks its ids; the last id with any probability closes at 1.0
-  const double lo = (tid ? s_cum[tid - 1] : 0.0) / total;
-  const bool owns_last = last_pos >= 0 && last_pos == s_last;
-  const double hi = owns_last ? 1.0 : inc / total;
-  if (loc > 0.0 && lo < u && u <= hi) {
-    double c = tid ? s_cum[tid - 1] : 0.0;
-    int pick = last_pos;
-    float px = 0.f;
-    bool found = false;
+  for (int jb = 0; jb < TS_NB; ++jb)
 #pragma unroll
-    for (int k = 0; k < TS_CHUNK; ++k) {
-      const float x = xr[k];
-      if (found || x == -INFINITY) continue;
-      c += (double)expf(x - lse_all);
-      if (c / total >= u || v0 + k == last_pos) { pick = v0 + k; px = x; found = true; }
+    for (int w = 0; w < TS_WAVES; ++w) total += s_wtot[jb][w];
+  // the run whose interval (cum before, cum after] / total contains u is walked by its thread; the last id with any
+  // probability closes at 1.0.  id order = (block, wave, lane, element).
+  const int glast = s_last;
+  double run = 0.0;                  // everything of the blocks before jb
+#pragma unroll 1
+  for (int jb = 0; jb < TS_NB; ++jb) {
+    double front = run;              // + the waves of this block before mine
+#pragma unroll
+    for (int w = 0; w < TS_WAVES; ++w) {
+      if (w < wave) front += s_wtot[jb][w];
+      run += s_wtot[jb][w];
     }
-    s_tok = pick;
-    s_px = px;
+    const double own = s_own[jb][tid];
+    if (!(own > 0.0)) continue;
+    const double before = front + s_pre[jb][tid], after = before + own;
+    const int v0 = TS_BLK * jb + TS_E * tid;
+    const bool owns_last = glast >= v0 && glast < v0 + TS_E;
+    const double lo = before / total, hi = owns_last ? 1.0 : after / total;
+    if (lo < u && u <= hi) {
+      double c = before;
+      int pick = -1;
+      float px = 0.f;
+      for (int e = 0; e < TS_E; ++e) {
+        const int v = v0 + e;
+        if (pick >= 0 || v >= a.V || (ts_only && v < a.beg) || !rule.allowed(v, a.eot)) continue;
+        const float x = lg[v] / T;
+        const float p = expf(x - lse_all);
+        if (!(p > 0.f)) continue;
+        c += (double)p;
+        if (c / total >= u || v == glast) { pick = v; px = x; }
+      }
+      if (pick < 0) { pick = glast; px = lg[glast] / T; }      // (rounding: the run's last id)
+      s_tok = pick;
+      s_px = px;
+    }
   }
   __syncthreads();
   if (tid == 0) {
     int pick = s_tok;
     float px = s_px;
-    if (pick < 0) {                     // u fell between two threads' rounded interval ends: the id the lower one ends on
+    if (pick < 0) {                     // u fell between two runs' rounded interval ends: the last id with any probability
       pick = s_last >= 0 ? s_last : a.eot;
       px = lg[pick] / T;
     }
@@ -1727,7 +1789,7 @@ hipError_t softmax_prob_f32(const float* logits, int V, long ld, int token, floa
 
 hipError_t ts_pick(const TsPickArgs& a, int B, hipStream_t s) {
   if (a.u_all) {
-    if (!a.temperature || a.V > TS_THREADS * TS_CHUNK) return hipErrorInvalidValue;      // a thread's ids live in TS_CHUNK registers
+    if (!a.temperature || a.V > TS_BLK * TS_NB) return hipErrorInvalidValue;      // a thread's ids live in TS_NB x TS_E registers
     hipLaunchKernelGGL(ts_sample_kernel, dim3(B), dim3(TS_THREADS), 0, s, a);
     return hipGetLastError();
   }
