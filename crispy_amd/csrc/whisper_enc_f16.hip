@@ -664,12 +664,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void a
     *reinterpret_cast<uint4*>(&Ks[0][kso]) = rk;
     __syncthreads();
   }
+  // this thread's row of the NEXT K tile: a pointer stepped by 32 rows per trip (the clamp to the last row only matters
+  // in the last tile; recomputing min(k0 + krow, T - 1) * ld per trip was nine vector instructions of 64-bit arithmetic
+  // in a loop whose vector pipe is the bottleneck)
+  const _Float16* knext = kaddr(n_tiles > 1 ? 32 : 0);
+  const long kstep = 32 * ld;
   for (int it = 0; it < n_tiles; ++it) {
     const int k0 = it * 32, buf = it & 1;
     {
       const int kn = min(it + 1, n_tiles - 1) * 32;      // the last trip re-requests its own tile (never used)
-      rk = *reinterpret_cast<const uint4*>(kaddr(kn));
+      rk = *reinterpret_cast<const uint4*>(knext);
       rv = *reinterpret_cast<const uint4*>(vg + kn);
+      // rows of tile it + 2: unclamped while that tile is not the last one (all its rows < T), else through kaddr
+      if (it + 2 < n_tiles - 1) knext += kstep;
+      else knext = kaddr(min(it + 2, n_tiles - 1) * 32);
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- S^T tile: rows = keys (li), columns = queries ----
