@@ -1,5 +1,5 @@
-"""Decode-step timing: python tools/dec_time.py  (env: MODEL=tiny|base B=64 NEW=32 PREC=0|1 CRISPY_ASR_DEC_BRANCHES=n).
-Prints ms per decode call, ms per generated token and a checksum of the tokens (must not depend on the branch count)."""
+"""Decode-step timing: python tools/dec_time.py  (env: MODEL=tiny|base B=64 NEW=32 PREC=0|1|2).
+Prints ms per decode call, ms per position and a checksum of the tokens (A/B of decode-step changes: must not move)."""
 import sys, os, time, zlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -20,5 +20,5 @@ for _ in range(5):
     toks = m.decode_greedy_device(enc.data_ptr(), B, prompt, NEW)
     torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
 t = float(np.median(ts))
-print(f"MODEL={hp.n_audio_state} B={B} NEW={NEW} PREC={os.environ.get('PREC', 0)} branches={os.environ.get('CRISPY_ASR_DEC_BRANCHES', 'auto')}"
+print(f"MODEL={hp.n_audio_state} B={B} NEW={NEW} PREC={os.environ.get('PREC', 0)}"
       f" decode {t:.2f} ms  {t / (NEW + len(prompt)):.3f} ms/position  crc {zlib.crc32(np.ascontiguousarray(toks[0]).tobytes()):08x}")
