@@ -75,8 +75,29 @@ def test_frame_kernel_resource_budget(tmp_path, extra):
         assert r["VGPRs"] + r.get("AGPRs", 0) <= 128, (name, r)
         assert r["LDS Size"] <= 32 * 1024, (name, r)
         assert r["ScratchSize"] == 0, (name, r)
+    # the high-pass kernels live in their own file (same flags): the 32-register form that fits beside four frame waves
+    src_hp = os.path.join(ROOT, "crispy_amd", "csrc", "rn_highpass.hip")
+    asm_hp = tmp_path / "rn_hp.s"
+    out = subprocess.run(
+        [HIPCC, *CGFLAGS, "--cuda-device-only", "-S",
+         "-Rpass-analysis=kernel-resource-usage", *extra, src_hp, "-o", str(asm_hp)],
+        capture_output=True, text=True, timeout=600, cwd=os.path.dirname(src_hp))
+    assert out.returncode == 0, out.stderr[-2000:]
+    res, cur = {}, None
+    for line in out.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = m.group(1)
+            res[cur] = {}
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
+        if m and cur:
+            res[cur][m.group(1).strip()] = int(m.group(2))
+    text = asm_hp.read_text()
     hp = {k: v for k, v in res.items() if "rn_highpass_kernel" in k}
     assert len(hp) == 1, list(res)
+    deep = {k: v for k, v in res.items() if "rn_highpass_deep_kernel" in k}
+    assert len(deep) == 1 and all(r["ScratchSize"] == 0 for r in deep.values()), deep
     for name, r in hp.items():
         assert r["VGPRs"] + r.get("AGPRs", 0) <= 32, (name, r)
         body = text[text.index(name + ":"):]
