@@ -211,6 +211,25 @@ def cpu_baseline(frames_per_thread: int = 2500, reps: int = 12):
     return many
 
 
+def committed_pmc():
+    """The newest committed counter summary of rn_frame_kernel: (file, streams, per-stream-frame counters).  One reader
+    for both layouts under profiles/: what tools/collect_profiles.sh writes (`kernels.<name>.per_stream_frame`) and what
+    tools/summarize_pmc.py makes of it (`rn_frame_kernel.per_stream_frame` + `config`)."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_pmc.json")), reverse=True):
+        try:
+            pm = json.load(open(f))
+            if "kernels" in pm:
+                psf, streams = pm["kernels"]["rn_frame_kernel"]["per_stream_frame"], pm["streams"]
+            else:
+                psf, streams = pm["rn_frame_kernel"]["per_stream_frame"], pm["config"]["streams"]
+            if all(k in psf for k in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU")):
+                return os.path.relpath(f, ROOT), int(streams), psf
+        except Exception:
+            continue
+    raise FileNotFoundError("no counter summary under profiles/")
+
+
 def measure_traffic(B: int, T: int):
     """HBM-side traffic of rn_frame_kernel measured on THIS box for THIS build: two separate `rocprofv3 --pmc` passes
     (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950; no trace domains beside them) over a child process that
@@ -1040,18 +1059,17 @@ def cfg2(args):
             except Exception as e:
                 traffic_src = {"how": "committed profile (live measurement failed)", "error": str(e)[:200]}
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r03e_pmc.json")))
-            if pm["config"]["streams"] == B:
-                fk = pm["rn_frame_kernel"]
+            pm_file, streams, psf = committed_pmc()
+            if streams == B:
                 sf = B * T / launches                        # stream-frames per (average) launch
                 if traffic is None:
-                    traffic = int(fk["hbm_bytes_per_stream_frame"] * sf)
-                    traffic_src = dict(traffic_src or {}, file="profiles/r03e_pmc.json")
+                    traffic = int((2 * psf["FETCH_SIZE"] + psf["WRITE_SIZE"]) * 1024 * sf)
+                    traffic_src = dict(traffic_src or {}, file=pm_file)
                 # what actually bounds this kernel: VALU issue slots.  SQ_ACTIVE_INST_VALU counts 4-cycle issue
                 # slots; 1024 SIMDs; priced against the live kernel time at the 2.4 GHz peak clock.
-                valu = {"insts_per_stream_frame": fk["insts_per_stream_frame"]["valu"],
-                        "issue_frac": fk["valu_active_quads_per_stream_frame"] * sf * 4 / (1024 * frame_ms * 1e-3 * 2.4e9),
-                        "source": "profiles/r03e_pmc.json (rocprofv3 --pmc SQ_ACTIVE_INST_VALU), live kernel time"}
+                valu = {"insts_per_stream_frame": round(psf["SQ_INSTS_VALU"]),
+                        "issue_frac": psf["SQ_ACTIVE_INST_VALU"] * sf * 4 / (1024 * frame_ms * 1e-3 * 2.4e9),
+                        "source": f"{pm_file} (rocprofv3 --pmc SQ_ACTIVE_INST_VALU), live kernel time"}
         except Exception:
             pass
         achieved = alg_bytes / (frame_ms * 1e-3) / 1e9

@@ -31,6 +31,8 @@ pub const CRISPY_ERR_UNSUPPORTED: c_int = -6;
 pub const CRISPY_RN_FRAME_SIZE: usize = 480;
 pub const CRISPY_RN_WEIGHT_BYTES: usize = 87503;
 pub const CRISPY_RN_TAPS: usize = 72;
+/// The ABI this file was written against (crispy_hip.h: CRISPY_ABI_VERSION); every constructor checks it.
+pub const CRISPY_ABI_VERSION: c_int = 3;
 pub const CRISPY_MEL_FRAMES: usize = 3000;
 pub const CRISPY_MEL_BINS: usize = 201;
 
@@ -144,6 +146,7 @@ pub struct crispy_asr_result {
 extern "C" {
     pub fn crispy_last_error() -> *const c_char;
     pub fn crispy_version() -> *const c_char;
+    pub fn crispy_abi_version() -> c_int;
     pub fn crispy_device_count() -> c_int;
     pub fn crispy_selftest_exception_guard(kind: c_int) -> c_int;
 
@@ -232,6 +235,16 @@ fn check(rc: c_int) -> Result<(), CrispyError> {
     Err(CrispyError { code: rc, message })
 }
 
+/// Refuses a library built from another header: a `crispy_asr_opts` of another size would be read past its end.
+fn check_abi() -> Result<(), CrispyError> {
+    // SAFETY: no arguments, no state.
+    let got = unsafe { crispy_abi_version() };
+    if got != CRISPY_ABI_VERSION {
+        return Err(CrispyError { code: CRISPY_ERR_UNSUPPORTED, message: format!("libcrispy_hip ABI {got}, binding written for {CRISPY_ABI_VERSION}") });
+    }
+    Ok(())
+}
+
 fn path_cstring(p: &Path) -> Result<CString, CrispyError> {
     CString::new(p.to_string_lossy().as_bytes()).map_err(|_| CrispyError {
         code: CRISPY_ERR_INVALID_ARG,
@@ -263,6 +276,7 @@ impl DenoiseState {
     /// cannot be redistributed with this library, so the model comes from an rnnoise-nu text file (the format
     /// `nnnoiseless::RnnModel::from_read` parses) ...
     pub fn from_model_file(path: &Path) -> Result<Box<Self>, CrispyError> {
+        check_abi()?;
         let c = path_cstring(path)?;
         let mut h = std::ptr::null_mut();
         // SAFETY: c outlives the call; h is a valid out-pointer.
@@ -272,6 +286,7 @@ impl DenoiseState {
     /// ... or from the flat 87 503-byte int8 blob (layer order input_dense, vad_gru, vad_output, noise_gru,
     /// denoise_gru, denoise_output).
     pub fn from_weights(weights: &[i8]) -> Result<Box<Self>, CrispyError> {
+        check_abi()?;
         let mut h = std::ptr::null_mut();
         // SAFETY: the slice is valid for weights.len() bytes; the library copies it before returning.
         check(unsafe { crispy_rn_create(weights.as_ptr(), weights.len(), 1, 0, &mut h) })?;
@@ -382,6 +397,7 @@ unsafe impl Send for GpuWhisperEngine {}
 impl GpuWhisperEngine {
     /// `WhisperEngine::load(&model_path)` (managers/transcription.rs:138-141): a whisper.cpp GGML model file.
     pub fn load(model_path: &Path) -> Result<Self, CrispyError> {
+        check_abi()?;
         let c = path_cstring(model_path)?;
         let mut h = std::ptr::null_mut();
         // resident load: a quantised catalog file (managers/model.rs:99,137) stays quantised in HBM (file-sized) and runs in

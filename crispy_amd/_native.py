@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CRISPY_HIP_LIB") or os.path.join(_HERE, "libcrispy_hip.so")
 
 RN_FRAME = 480
+ABI_VERSION = 3
 RN_WEIGHT_BYTES = 87503
 RN_TAPS = 72
 RN_DBG_FLOATS = 4304
@@ -20,7 +21,7 @@ LAYOUT_BTF = 1
 
 # every symbol include/crispy_hip.h declares (checked by tests/test_abi.py)
 RN_SYMBOLS = (
-    "crispy_last_error", "crispy_version", "crispy_device_count",
+    "crispy_last_error", "crispy_version", "crispy_abi_version", "crispy_device_count",
     "crispy_rn_create", "crispy_rn_destroy", "crispy_rn_reset", "crispy_rn_n_streams",
     "crispy_rn_frames_per_launch", "crispy_rn_n_launches",
     "crispy_rn_process", "crispy_rn_process_device", "crispy_rn_synchronize",
@@ -119,6 +120,9 @@ def load_library(path: str) -> C.CDLL:
     L.crispy_last_error.restype = C.c_char_p
     L.crispy_version.restype = C.c_char_p
     L.crispy_device_count.restype = C.c_int
+    L.crispy_abi_version.restype = C.c_int
+    if L.crispy_abi_version() != ABI_VERSION:      # include/crispy_hip.h: CRISPY_ABI_VERSION
+        raise RuntimeError(f"{path}: ABI version {L.crispy_abi_version()}, this binding was written for {ABI_VERSION}")
     L.crispy_rn_create.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.crispy_rn_destroy.argtypes = [C.c_void_p]
     L.crispy_rn_weights_from_file.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t]

@@ -1,5 +1,7 @@
 // api_util.h -- error plumbing shared by the extern "C" translation units.
 #pragma once
+#include <cstdlib>
+
 #include <hip/hip_runtime.h>
 
 #include "../../include/crispy_hip.h"
@@ -16,6 +18,19 @@ bool device_is_gfx950(int dev);
 // (std::bad_alloc / std::length_error -> CRISPY_ERR_OOM, anything else -> CRISPY_ERR_HIP), records a message and
 // returns the status.  Never throws (the message buffer is a fixed thread-local array).
 int fail_exception(const char* where) noexcept;
+
+// Environment variables the library reads -- two kinds, nothing else calls getenv:
+//  * test hooks (test_env): read in every build and listed under "Environment" in include/crispy_hip.h.  They select
+//    between forms that give bit-identical results (the tests that use them assert exactly that), never a result;
+//  * developer knobs (dev_env): A/B switches for tools/ (ramps, request depths, timelines, tile walkers).  Compiled OUT of
+//    the release library -- a host's environment must not steer which kernel form the product runs -- and in with
+//    `make dev` (-DCRISPY_DEV_KNOBS, ../libcrispy_hip_dev.so; tools pick it through CRISPY_HIP_LIB).
+inline const char* test_env(const char* name) { return std::getenv(name); }
+#ifdef CRISPY_DEV_KNOBS
+inline const char* dev_env(const char* name) { return std::getenv(name); }
+#else
+inline const char* dev_env(const char*) { return nullptr; }
+#endif
 
 }  // namespace crispy
 

@@ -96,10 +96,7 @@ hipError_t gemm_f32_nt(const GemmArgs& g, int batch, hipStream_t s);
 // decode-step projection straight from resident ggml blocks (GemmArgs::wq): de-quantised in registers
 bool skinny_q_supported(const GemmArgs& g, int batch);
 hipError_t gemm_skinny_q(const GemmArgs& g, hipStream_t s);
-// f16-operand variant (whisper_gemm_f16.hip): A f32 rounded to f16 on the way into LDS, Wh an f16 copy of W [N][ldw]
-hipError_t gemm_f16_nt(const GemmArgs& g, const void* Wh, int batch, hipStream_t s);
-hipError_t convert_f32_to_f16(const float* src, void* dst, long n, hipStream_t s);
-hipError_t attn_encoder_f16(const float* qkv, float* out, int B, int T, int D, int heads, hipStream_t s);
+hipError_t convert_f32_to_f16(const float* src, void* dst, long n, hipStream_t s);      // whisper_enc_f16.hip
 // ---- precision mode 1, activations in f16 between the encoder kernels (whisper_enc_f16.hip) ----
 constexpr int ENC_TP = 1504;   // keys per V^T row: 1500 padded to whole 32-key tiles
 struct HGemmArgs {

@@ -52,7 +52,7 @@ constexpr int kStagedMaxStreams = 1280;
 inline const std::vector<int>& ramp_frames() {
   static const std::vector<int> ramp = [] {
     std::vector<int> r;
-    if (const char* env = std::getenv("CRISPY_RN_RAMP")) {
+    if (const char* env = dev_env("CRISPY_RN_RAMP")) {
       for (const char* p = env; *p;) {
         char* end = nullptr;
         const long v = std::strtol(p, &end, 10);
@@ -306,7 +306,8 @@ extern "C" {
 
 const char* crispy_last_error(void) { return last_error_cstr(); }
 
-const char* crispy_version(void) { return "crispy_hip 0.1.0 gfx950"; }
+const char* crispy_version(void) { return "crispy_hip 0.3.0 gfx950"; }
+int crispy_abi_version(void) { return CRISPY_ABI_VERSION; }
 
 int crispy_device_count(void) try {
   int n = 0;
@@ -468,17 +469,17 @@ int crispy_rn_create(const int8_t* weights, size_t nbytes, int n_streams, int de
     HIP_TRY(hipMalloc(&h->d_memid, B * sizeof(int)));
     HIP_TRY(hipMalloc(&h->d_xhp, B * h->xhp_stride * sizeof(float)));
     {
-      const char* hp = std::getenv("CRISPY_RN_HP");
+      const char* hp = dev_env("CRISPY_RN_HP");
       h->hp_upfront = hp && std::strcmp(hp, "upfront") == 0;
-      const char* wv = std::getenv("CRISPY_RN_WAVES");
+      const char* wv = test_env("CRISPY_RN_WAVES");
       h->waves = wv ? (std::atoi(wv) == 3 ? 3 : 1) : (n_streams <= kStagedMaxStreams ? 3 : 1);
       // with the stage-pipelined form, i.e. <= 1280 streams: from 1536 streams on a call is as long as its frame kernels
       // with either request depth (sweep in NOTEBOOK 8.6)
-      const char* hd = std::getenv("CRISPY_RN_HP_DEEP");
+      const char* hd = dev_env("CRISPY_RN_HP_DEEP");
       h->hp_deep = hd ? std::atoi(hd) != 0 : h->waves == 3;
-      const char* sp = std::getenv("CRISPY_RN_HP_SPLIT");
+      const char* sp = dev_env("CRISPY_RN_HP_SPLIT");
       if (sp) h->hp_split = std::atoi(sp);   // 0: one kernel per sub-chunk
-      const char* ah = std::getenv("CRISPY_RN_HP_AHEAD");
+      const char* ah = dev_env("CRISPY_RN_HP_AHEAD");
       h->hp_ahead = ah ? std::atoi(ah) : 0;
     }
     RnTables* tab = new RnTables();
@@ -807,7 +808,7 @@ int crispy_rn_last_kernel_ms(crispy_rn* h, float* frame_kernel_ms, float* total_
   HIP_TRY(hipSetDevice(h->device));
   float fk = 0.f, tot = 0.f;
   size_t i = 0;
-  const bool timeline = std::getenv("CRISPY_RN_TIMELINE") != nullptr;   // developer aid: where a step's time goes (stderr)
+  const bool timeline = dev_env("CRISPY_RN_TIMELINE") != nullptr;   // developer aid: where a step's time goes (stderr)
   for (int n_sub : h->seg_subs) {
     const size_t last = i + 1 + 2 * (size_t)n_sub;
     HIP_TRY(hipEventSynchronize(h->ev[last]));

@@ -421,7 +421,7 @@ int crispy_asr_create(const crispy_asr_hparams* hp, const float* mel_filters, in
   h->device = device;
   h->hp = *hp;
   h->eot = hp->n_vocab >= 51865 ? 50257 : 50256;   // multilingual vocabularies shift the specials by one
-  if (const char* e = std::getenv("CRISPY_ASR_XCD")) h->xcd_swizzle = std::atoi(e) != 0;
+  if (const char* e = dev_env("CRISPY_ASR_XCD")) h->xcd_swizzle = std::atoi(e) != 0;
   auto body = [&]() -> int {
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -820,11 +820,6 @@ int crispy_asr_encode_device(crispy_asr* h, const float* d_mel_t, int batch, flo
   }
   const int d = h->hp.n_audio_state, Tn = h->hp.n_audio_ctx, nm = h->hp.n_mels, H = h->hp.n_audio_head;
   const long rows = (long)batch * Tn;
-  // encoder GEMM: f16 operands when the mode is on and an f16 copy of the weight exists (K multiple of 32)
-  auto egemm = [&](const GemmArgs& g, const void* wh, int nb) -> hipError_t {
-    if (h->enc_precision == 1 && wh && g.K % 32 == 0) return gemm_f16_nt(g, wh, nb, s);
-    return gemm_f32_nt(g, nb, s);
-  };
   if (h->enc_precision == 1) {
     // The convolution stem on the f16 matrix cores too (ggml runs a convolution as im2col in f16 x f16 kernel): the
     // frame-major mel is rounded to f16 once, conv1 writes GELU(h1) as f16 (it only feeds conv2), conv2 reads it as
@@ -871,7 +866,7 @@ int crispy_asr_encode_device(crispy_asr* h, const float* d_mel_t, int batch, flo
       g.gelu = 1;
       g.rowtab = h->enc_pos;
       g.rowtab_period = Tn;
-      HIP_TRY(egemm(g, h->conv2_wh, batch));
+      HIP_TRY(gemm_f32_nt(g, batch, s));
     }
   }
   if (h->enc_precision == 1) {
@@ -927,24 +922,23 @@ int crispy_asr_encode_device(crispy_asr* h, const float* d_mel_t, int batch, flo
   } else
   for (const EncLayer& L : h->enc) {
     HIP_TRY(layernorm_f32(h->w_x, L.ln1_w, L.ln1_b, h->w_xn, rows, d, s));
-    HIP_TRY(egemm(gemm(h->w_xn, d, L.qkv_w, d, h->w_qkv, 3L * d, L.qkv_b, (int)rows, 3 * d, d), L.qkv_wh, 1));
-    if (h->enc_precision == 1) HIP_TRY(attn_encoder_f16(h->w_qkv, h->w_att, batch, Tn, d, H, s));
-    else HIP_TRY(attn_encoder_f32(h->w_qkv, h->w_att, batch, Tn, d, H, s));
+    HIP_TRY(gemm_f32_nt(gemm(h->w_xn, d, L.qkv_w, d, h->w_qkv, 3L * d, L.qkv_b, (int)rows, 3 * d, d), 1, s));
+    HIP_TRY(attn_encoder_f32(h->w_qkv, h->w_att, batch, Tn, d, H, s));
     {
       GemmArgs g = gemm(h->w_att, d, L.out_w, d, h->w_x, d, L.out_b, (int)rows, d, d);
       g.residual = h->w_x; g.ldr = d;
-      HIP_TRY(egemm(g, L.out_wh, 1));
+      HIP_TRY(gemm_f32_nt(g, 1, s));
     }
     HIP_TRY(layernorm_f32(h->w_x, L.ln2_w, L.ln2_b, h->w_xn, rows, d, s));
     {
       GemmArgs g = gemm(h->w_xn, d, L.fc1_w, d, h->w_h, 4L * d, L.fc1_b, (int)rows, 4 * d, d);
       g.gelu = 1;
-      HIP_TRY(egemm(g, L.fc1_wh, 1));
+      HIP_TRY(gemm_f32_nt(g, 1, s));
     }
     {
       GemmArgs g = gemm(h->w_h, 4L * d, L.fc2_w, 4L * d, h->w_x, d, L.fc2_b, (int)rows, d, 4 * d);
       g.residual = h->w_x; g.ldr = d;
-      HIP_TRY(egemm(g, L.fc2_wh, 1));
+      HIP_TRY(gemm_f32_nt(g, 1, s));
     }
   }
   HIP_TRY(layernorm_f32(h->w_x, h->ln_post_w, h->ln_post_b, d_out, rows, d, s));
@@ -1085,7 +1079,7 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
   // (AttnRows::stream_kv: 64 tiny clips 11.2 -> 10.3 ms, 256 base clips 46.7 -> 44.2 ms).
   // (not in a multi-position prompt step: the P rows of a clip read the same K|V one after the other, and the repeats are
   // served by the Infinity Cache only if the first read allocates there: 2.06 vs 2.18 ms for the prompt of 128 clips)
-  static const bool prompt_nt = std::getenv("CRISPY_XKV_PROMPT_NT") != nullptr;      // developer A/B (tools/ab_prompt_nt.sh)
+  static const bool prompt_nt = dev_env("CRISPY_XKV_PROMPT_NT") != nullptr;      // developer A/B (tools/ab_prompt_nt.sh)
   cross_rows.stream_kv = (P == 1 || prompt_nt) && (size_t)clips * h->dec.size() * Tn * 2 * dt * (h->enc_precision == 1 ? 2 : 4) > ((size_t)256 << 20) ? 1 : 0;
   if (!embedded) {    // (a fused pick has written the residual stream already)
     if (h->resident)
@@ -1323,7 +1317,7 @@ int prefill(crispy_asr* h, const float* d_enc, int batch, const int* tok_mat, in
   // instead of four, and a long prompt (previous-text conditioning: up to 228 tokens per clip) takes one step per
   // 512 / batch positions.  Bit-identical to the position-by-position prefill (CRISPY_ASR_PREFILL=seq keeps that one
   // available for the A/B test).
-  const char* pf_env = std::getenv("CRISPY_ASR_PREFILL");      // read per call: the A/B test flips it inside one process
+  const char* pf_env = test_env("CRISPY_ASR_PREFILL");      // read per call: the A/B test flips it inside one process
   const bool seq = pf_env && std::strcmp(pf_env, "seq") == 0;
   const bool fold = batch <= SKINNY_MAX_M && h->hp.n_text_state % 128 == 0;
   const int p_max = (!fold || seq) ? 1 : std::max(1, SKINNY_MAX_M / batch);

@@ -17,6 +17,7 @@
 //                          O^T += V^T.P^T; the running maximum is only raised when a score exceeds it by 2^6 (a stale
 //                          maximum scales every probability of a row by the same power of two, which f16 rounding does
 //                          not see), so the 32 accumulator rescales per tile are rare.
+#include "api_util.h"
 #include "asr_common.h"
 
 #include <cstdlib>
@@ -787,6 +788,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void a
   }
 }
 
+__global__ void f32_to_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = (_Float16)src[i];
+}
+
 __global__ void f32_to_f16_rows_kernel(const float* __restrict__ src, long lds, _Float16* __restrict__ dst, long ldd,
                                        int cols, long rows) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -962,16 +968,23 @@ hipError_t gemm_hh(const HGemmArgs& g, int epi, int batch, hipStream_t s) {
   HGemmArgs a = g;
   dim3 grid(nt, mt, batch);
   if (a.xcd_swizzle) grid.y = (unsigned)(((mt + 7) / 8) * 8);      // whole groups of eight row tiles
-  static const bool direct = [] { const char* e = std::getenv("CRISPY_ASR_GEMM"); return !(e && e[0] == 'r'); }();   // "regs": the register-staged loop
-  static const bool tall = [] { const char* e = std::getenv("CRISPY_ASR_GEMM"); return !(e && e[0] == 's'); }();     // "square": 128 x 128 tiles only
+  static const bool direct = [] { const char* e = dev_env("CRISPY_ASR_GEMM"); return !(e && e[0] == 'r'); }();   // "regs": the register-staged loop
+  static const bool tall = [] { const char* e = dev_env("CRISPY_ASR_GEMM"); return !(e && e[0] == 's'); }();     // "square": 128 x 128 tiles only
   if ((direct || epi == EPI_KVH) && tall && g.M >= 4 * HD2_M) {      // 256 x 128 or 192 x 128 tiles
     // two workgroups per CU: rounds x tile height is what the launch costs; ties go to the taller tile
-    static const int slots = [] {
+    // (per device: a process may hold handles on several devices -- ADVICE r4; both tile heights give the same bits,
+    // tests/test_gpu_mode1.py::test_mode1_encoder_does_not_depend_on_the_gemm_tile_height)
+    const int slots = [] {
+      static int cu_of[64] = {};                 // 0 = not asked yet; races write the same value
       int dev = 0, n = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-      return 2 * n;
+      if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 512;
+      if (cu_of[dev] == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cu_of[dev] = n;
+      }
+      return 2 * cu_of[dev];
     }();
-    static const int force_mi = [] { const char* e = std::getenv("CRISPY_ASR_TILE_ROWS"); return e ? std::atoi(e) / 64 : 0; }();   // 192 | 256
+    static const int force_mi = [] { const char* e = test_env("CRISPY_ASR_TILE_ROWS"); return e ? std::atoi(e) / 64 : 0; }();   // 192 | 256
     auto cost = [&](int mi) { const long tiles = (long)((g.M + 64 * mi - 1) / (64 * mi)) * nt * batch; return ((tiles + slots - 1) / slots) * mi; };
     const int mi = (force_mi == 3 || force_mi == 4) ? force_mi : (cost(3) < cost(4) ? 3 : 4);
     const int mt2 = (g.M + 64 * mi - 1) / (64 * mi);
@@ -1025,6 +1038,12 @@ hipError_t convert_rows_f32_to_f16(const float* src, long lds, void* dst, long l
   const long n = rows * cols;
   hipLaunchKernelGGL(f32_to_f16_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, lds,
                      reinterpret_cast<_Float16*>(dst), ldd, cols, rows);
+  return hipGetLastError();
+}
+
+hipError_t convert_f32_to_f16(const float* src, void* dst, long n, hipStream_t s) {
+  hipLaunchKernelGGL(f32_to_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src,
+                     reinterpret_cast<_Float16*>(dst), n);
   return hipGetLastError();
 }
 

@@ -21,6 +21,21 @@
  *     (managers/transcription.rs:27).  Different handles may be used from different threads.
  *   - there is NO CPU fallback: without a gfx950 device every create/load call fails with
  *     CRISPY_ERR_NO_DEVICE.
+ *   - ABI version: CRISPY_ABI_VERSION below is bumped whenever a struct grows, an entry point goes away or an argument
+ *     changes meaning; a binding compares it with crispy_abi_version() when it loads the library and refuses a
+ *     mismatch (a caller built against an older crispy_asr_opts would have the library read past its struct).
+ *
+ * Environment.  The release library reads exactly these variables -- test hooks that choose between forms whose results
+ * are bit-identical (the test that uses one asserts that); nothing else in a host's environment changes what runs.
+ * Developer A/B knobs exist only in the `make dev` build (crispy_amd/csrc/api_util.h: dev_env).
+ *     CRISPY_RN_WAVES=1|3        frame-kernel form of a crispy_rn handle (default: 3 up to 1280 streams, 1 above);
+ *                                read by crispy_rn_create*            (tests/test_gpu_rnnoise.py)
+ *     CRISPY_ASR_PREFILL=seq     prompt one position per step instead of multi-position steps; read per decode call
+ *                                                                     (tests/test_gpu_prefill.py)
+ *     CRISPY_ASR_TILE_ROWS=192|256  tile height of the mode-1 encoder GEMMs; read once per process
+ *                                                                     (tests/test_gpu_mode1.py)
+ *     CRISPY_ASR_DECODE=stages   decode steps as one launch per stage instead of the fused step kernels; read per decode
+ *                                call                                 (tests/test_gpu_fused_decode.py)
  */
 #ifndef CRISPY_HIP_H
 #define CRISPY_HIP_H
@@ -58,6 +73,11 @@ typedef struct crispy_rn crispy_rn;
 const char *crispy_last_error(void);
 /* "crispy_hip <version> gfx950" */
 const char *crispy_version(void);
+/* The ABI this header describes; crispy_abi_version() returns the one the library was built with.
+ *   1: rounds 1 - 3.   2: round 4 (crispy_asr_opts 20 -> 44 bytes, crispy_asr_result gained windows, the staged RNNoise
+ *   pipeline entry points removed).   3: round 5 (this header). */
+#define CRISPY_ABI_VERSION 3
+int crispy_abi_version(void);
 /* Number of usable gfx950 devices (0 when there is none; never fails). */
 int crispy_device_count(void);
 /* Self-test of the boundary's exception guard: every entry point is a function-try-block, so a C++ exception

@@ -184,7 +184,7 @@ def test_f16_encoder_kernels_run_at_four_waves_per_simd_without_scratch(tmp_path
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-@pytest.mark.parametrize("src_name", ["whisper_kernels.hip", "whisper_dec_f16.hip", "whisper_gemm_f16.hip", "mel_kernels.hip",
+@pytest.mark.parametrize("src_name", ["whisper_kernels.hip", "whisper_dec_f16.hip", "mel_kernels.hip",
                                       "resample_kernels.hip"])
 def test_asr_kernels_have_no_scratch_at_all(tmp_path, src_name):
     """with this compiler a VGPR spill next to a divergent region is a correctness hazard (see the

@@ -10,7 +10,7 @@ if [ "$mode" = build ]; then
   for spec in "$@"; do
     name=${spec%%:*}; flags=${spec#*:}
     (cd crispy_amd/csrc && /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -fno-slp-vectorize $flags -x hip -shared \
-       -o build/variants/lib_$name.so api_util.cpp crispy_api.cpp rn_kernels.hip asr_api.cpp mel_kernels.hip resample_kernels.hip whisper_kernels.hip whisper_gemm_f16.hip whisper_enc_f16.hip whisper_dec_f16.hip whisper_quant.hip whisper_api.cpp) &
+       -o build/variants/lib_$name.so api_util.cpp crispy_api.cpp rn_kernels.hip asr_api.cpp mel_kernels.hip resample_kernels.hip whisper_kernels.hip whisper_enc_f16.hip whisper_dec_f16.hip whisper_quant.hip whisper_api.cpp) &
   done
   wait
 else
