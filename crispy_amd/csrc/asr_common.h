@@ -151,6 +151,50 @@ hipError_t attn_decoder_kv16(const float* q, long ldq, const void* kv, long kv_b
                              long koff, long voff, int n_keys_base, const int* pos_dev, float* out, long ldo, int B, int heads,
                              hipStream_t s, int max_keys = 0,     // max_keys: upper bound of n_keys_base + *pos_dev (0: n_keys_base)
                              AttnRows rows = AttnRows());
+// ---- fused decode step (whisper_dec_fused.hip): a generated token's layer in three launches -------------------------
+// The residual stream entering a block: x = x_in + bias + part[0] + ... + part[n - 1] (n fixed per kernel: heads or 4 D / 128),
+// written to x_out by the row's first workgroup; LayerNorm (ln_g, ln_b) of it feeds the block's first product as f16.
+struct FusedIn {
+  const float* x_in;                 // [rows][D]
+  const float* bias;                 // [D] bias of the projection whose partials are added (unused by a layer's first block of step 0)
+  const float* part;                 // [n][rows][D]
+  float* x_out;                      // [rows][D]
+  const float* ln_g; const float* ln_b;
+};
+struct FusedSelfArgs {
+  FusedIn in;
+  const _Float16* wqkv; const float* bqkv;     // [3 D][D] f16 (q | k | v rows), [3 D]
+  const _Float16* wo;                          // [D][D] f16
+  _Float16* kv; long kv_row_stride;            // self K | V cache of this layer: [rows][n_text_ctx][2 D] f16
+  const int* pos_dev;                          // device: cache row of this step's token
+  const int* key_off;                          // [rows] nullable: first cache row of the row's clip (left-padded prompts)
+  int attn16, max_keys;                        // max_keys: bound of pos + 1 for this call (slot count of the attention)
+  float* part_out;                             // [heads][rows][D]
+  int rows, D;
+};
+struct FusedCrossArgs {
+  FusedIn in;
+  const _Float16* wq; const float* bq;         // [D][D] f16, [D]
+  const _Float16* wo;
+  const _Float16* xkv; long clip_stride;       // cross K | V of this layer: per clip [K | V][head][n_keys][64] f16
+  int n_keys, group;                           // encoder positions; rows per clip (rows of a clip share its K | V)
+  int attn16, stream_kv;
+  float* part_out;                             // [heads][rows][D]
+  int rows, D;
+};
+struct FusedMlpArgs {
+  FusedIn in;
+  const _Float16* w1; const float* b1;         // [4 D][D] f16, [4 D]
+  const _Float16* w2;                          // [D][4 D] f16
+  float* part_out;                             // [4 D / 128][rows][D]
+  int rows, D;
+};
+struct FusedFinishArgs { FusedIn in; _Float16* y; int rows, D; };     // in.part: the last layer's MLP partials
+bool fused_decode_supported(int D, int max_keys, int n_audio_ctx);
+hipError_t fused_self(const FusedSelfArgs& a, bool first_layer, hipStream_t s);   // first_layer: x_in is complete (no partials)
+hipError_t fused_cross(const FusedCrossArgs& a, hipStream_t s);
+hipError_t fused_mlp(const FusedMlpArgs& a, hipStream_t s);
+hipError_t fused_finish(const FusedFinishArgs& a, hipStream_t s);
 // x[r][:] = tok_emb[tokens[r]] + pos_emb[pos + r % rows_per_clip] for B rows (rows_per_clip > 1: the batched prompt step)
 hipError_t embed_tokens_f32(const int* tokens, const float* tok_emb, const float* pos_emb, int pos, const int* pos_dev,
                             float* x, int B, int D, hipStream_t s, int rows_per_clip = 1, const int* row_off = nullptr);

@@ -88,9 +88,17 @@ struct crispy_asr {
   const void* conv1_wh = nullptr;            // f16 conv1 kernel, rows zero-padded to conv1_kp columns
   int conv1_kp = 0;
   int enc_precision = 0;                     // 0: f32 operands (default), 1: f16 operands for the encoder GEMMs
-  bool dec_ln16 = false;                     // precision mode 2 = mode 1 + the decoder's LayerNorm output rounded to f16 in front of
-                                             // q | k | v, cross q and fc1 (f16 weights): ggml's rounding points, three launches more per layer
+  // precision modes 1 and 2: the decoder's LayerNorm output rounded to f16 in front of q | k | v, cross q and fc1 (f16 weights) --
+  // ggml's mul_mat arithmetic for these products too [UPSTREAM-RECALL].  (Rounds 2 - 4 kept them in f32 in mode 1, with the
+  // LayerNorm folded into an f32 GEMM; since round 5 a generated token runs through the fused step kernels of
+  // whisper_dec_fused.hip, which multiply f16 LayerNorm outputs, and the staged path follows so that a position's
+  // arithmetic does not depend on which path computed it.)
+  bool dec_ln16 = false;
+  bool dec_attn16 = false;                   // precision mode 2: + the query and the normalised probabilities rounded to f16 inside every attention
   bool ln16_ready = false;
+  bool fused_path = true;                    // generated tokens through the fused step kernels when the model allows (CRISPY_ASR_DECODE=stages: never)
+  float* d_fx[3] = {nullptr, nullptr, nullptr};      // fused step: residual stream after the self / cross / MLP input sums [rows][dt]
+  float* d_fpart[3] = {nullptr, nullptr, nullptr};   // fused step: partial rows of the self / cross out-projection [heads][rows][dt], MLP [dt / 32][rows][dt]
   bool half_ready = false;                   // every f16 weight copy of mode 1 exists (set after the last one and a stream sync)
   int xcd_swizzle = 1;                       // mode 1 GEMMs: column tiles of a row tile on one XCD (CRISPY_ASR_XCD=0 turns it off)
   std::vector<EncLayer> enc;
@@ -105,7 +113,7 @@ struct crispy_asr {
         *w_att = nullptr, *w_h = nullptr, *w_enc = nullptr;
   long cap_pcm_stride = 0;
   // decoder workspace
-  int dcap_batch = 0;
+  int dcap_batch = 0, dcap_xclips = 0;       // rows / audio clips the decoder workspace holds
   float *d_xkv = nullptr, *d_selfkv = nullptr, *d_dx = nullptr, *d_dxn = nullptr, *d_dq = nullptr, *d_datt = nullptr,
         *d_dh = nullptr, *d_logits = nullptr, *d_best = nullptr;
   int* d_tok = nullptr;
@@ -126,21 +134,37 @@ struct crispy_asr {
   void* d_xkv_h = nullptr;                   // f16 copy of the cross K|V (precision mode 1)
   unsigned char* d_ts_mask = nullptr;        // [n_vocab] whisper.cpp's always-suppressed specials
   unsigned char* d_ts_mask_first = nullptr;  // ... plus suppress_blank (" " and EOT) at the first position
-  // [key class + 3 x sampling]: the greedy pick and the sampling pick (temperature fallback) are different kernels
-  hipGraphExec_t ts_graphs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  int ts_graph_batch[6] = {0, 0, 0, 0, 0, 0}, ts_graph_rules[6] = {-1, -1, -1, -1, -1, -1};
-  const unsigned char* ts_graph_mask[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // captured window-decode steps by what is baked into them: key class, kind of pick (greedy / sampling: different kernels),
+  // rows, rows per clip, rules and mask.  A transcribe call alternates between several of them -- the greedy pass over all
+  // clips, sampling passes over the failed ones x best_of, windows with and without the text so far -- and with one
+  // slot per class every switch re-captured the step (1 - 2 ms each).
+  struct TsKey {
+    int kc, sampling, rows, xgroup, rules;
+    const unsigned char* mask;
+    bool operator<(const TsKey& o) const {
+      if (kc != o.kc) return kc < o.kc;
+      if (sampling != o.sampling) return sampling < o.sampling;
+      if (rows != o.rows) return rows < o.rows;
+      if (xgroup != o.xgroup) return xgroup < o.xgroup;
+      if (rules != o.rules) return rules < o.rules;
+      return mask < o.mask;
+    }
+  };
+  std::map<TsKey, hipGraphExec_t> ts_graphs;
   float* d_plog_all = nullptr;               // [n_text_ctx][dcap_batch] log-probability of every pick
   float* d_nosp = nullptr;                   // [dcap_batch] no_speech_prob of the window
   double* d_u_all = nullptr;                 // [n_text_ctx][dcap_batch] uniform variates of a sampling pass (drawn on the host)
   float* d_temperature = nullptr;            // device scalar
   int* d_row_off = nullptr;                  // [dcap_batch] left padding of every clip's prompt (cache rows)
   const int* cur_row_off = nullptr;          // d_row_off while a window decode is running, else nullptr (decoder_step reads it)
+  int cur_xgroup = 1;                        // rows per audio clip while a window decode is running: the best-of decoders of a clip are
+                                             // rows of their own (own self K|V cache) over ONE cross K|V (decode_ts)
   void drop_graphs() {
     for (int c = 0; c < 3; ++c)
       if (dec_graphs[c]) { (void)hipGraphExecDestroy(dec_graphs[c]); dec_graphs[c] = nullptr; dec_graph_batch[c] = 0; }
-    for (int c = 0; c < 6; ++c)
-      if (ts_graphs[c]) { (void)hipGraphExecDestroy(ts_graphs[c]); ts_graphs[c] = nullptr; ts_graph_batch[c] = 0; }
+    for (auto& kv : ts_graphs)
+      if (kv.second) (void)hipGraphExecDestroy(kv.second);
+    ts_graphs.clear();
   }
   int eot = 50257;
   std::vector<unsigned char> sup_all, sup_first;   // host copies of the two suppression lists
@@ -309,37 +333,6 @@ int fuse_bias(crispy_asr* h, const std::vector<std::string>& bnames, int d, cons
   return upload(h, Bv, b_out);
 }
 
-// ln_s / ln_c of fold_ln for a resident tensor: the dense weights exist only for the duration of the call
-int fold_ln_vectors(crispy_asr* h, const QRef& r, const float* d_bias, const float* d_gamma, const float* d_beta, size_t N,
-                    size_t K, const float** ls, const float** lc) {
-  const void* dense = nullptr;
-  int rc = dq(h, r, false, nullptr, h->stream, &dense);
-  if (rc != CRISPY_OK) return rc;
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  const float *lw_unused = nullptr;
-  (void)lw_unused;
-  std::vector<float> W(N * K), b(N, 0.f), g(K), be(K);
-  HIP_TRY(hipMemcpy(W.data(), dense, W.size() * sizeof(float), hipMemcpyDeviceToHost));
-  if (d_bias) HIP_TRY(hipMemcpy(b.data(), d_bias, N * sizeof(float), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(g.data(), d_gamma, K * sizeof(float), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(be.data(), d_beta, K * sizeof(float), hipMemcpyDeviceToHost));
-  std::vector<float> sv(N), cv(N);
-  for (size_t n = 0; n < N; ++n) {          // the arithmetic of fold_ln, element for element
-    double ss = 0.0, cc = (double)b[n];
-    const float* row = W.data() + n * K;
-    for (size_t k = 0; k < K; ++k) {
-      cc += (double)be[k] * (double)row[k];
-      const float wg = row[k] * g[k];
-      ss += (double)wg;
-    }
-    sv[n] = (float)ss;
-    cv[n] = (float)cc;
-  }
-  rc = upload(h, sv, ls);
-  if (rc == CRISPY_OK) rc = upload(h, cv, lc);
-  return rc;
-}
-
 void free_ws(crispy_asr* h) {
   for (float** p : {&h->w_melt, &h->w_pcm, &h->w_h1, &h->w_x, &h->w_xn, &h->w_qkv, &h->w_att, &h->w_h, &h->w_enc})
     if (*p) { (void)hipFree(*p); *p = nullptr; }
@@ -363,8 +356,13 @@ void free_dec_ws(crispy_asr* h) {
   if (h->d_u_all) { (void)hipFree(h->d_u_all); h->d_u_all = nullptr; }
   if (h->d_temperature) { (void)hipFree(h->d_temperature); h->d_temperature = nullptr; }
   if (h->d_row_off) { (void)hipFree(h->d_row_off); h->d_row_off = nullptr; }
+  for (int i = 0; i < 3; ++i) {
+    if (h->d_fx[i]) { (void)hipFree(h->d_fx[i]); h->d_fx[i] = nullptr; }
+    if (h->d_fpart[i]) { (void)hipFree(h->d_fpart[i]); h->d_fpart[i] = nullptr; }
+  }
   h->cur_row_off = nullptr;
   h->dcap_batch = 0;
+  h->dcap_xclips = 0;
 }
 
 int reserve_enc(crispy_asr* h, int batch) {
@@ -597,12 +595,6 @@ int finalize_resident(crispy_asr* h) {
   // the one scratch slot: the largest (fused) matrix as f32
   h->q_scratch_bytes = max_elems * sizeof(float);
   HIP_TRY(hipMalloc(&h->q_scratch, h->q_scratch_bytes));
-  for (DecLayer& L : h->dec) {     // LayerNorm-fold vectors of the decode projections (fold_ln's ln_s / ln_c)
-    rc = fold_ln_vectors(h, L.r_qkv, L.qkv_b, L.ln1_w, L.ln1_b, 3 * (size_t)dt, dt, &L.qkv_ls, &L.qkv_lc);
-    if (rc == CRISPY_OK) rc = fold_ln_vectors(h, L.r_xq, L.xq_b, L.lnx_w, L.lnx_b, dt, dt, &L.xq_ls, &L.xq_lc);
-    if (rc == CRISPY_OK) rc = fold_ln_vectors(h, L.r_fc1, L.fc1_b, L.ln2_w, L.ln2_b, 4 * (size_t)dt, dt, &L.fc1_ls, &L.fc1_lc);
-    if (rc != CRISPY_OK) return rc;
-  }
   {   // token embedding for the logits: f16, packed in MFMA operand order, from a dense copy that lives for this block only
     float* tmp = nullptr;
     HIP_TRY(hipMalloc(&tmp, (size_t)V * dt * sizeof(float)));
@@ -623,6 +615,7 @@ int finalize_resident(crispy_asr* h) {
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->half_ready = true;
   h->enc_precision = 1;
+  h->dec_ln16 = true;                        // mode 1: f16 LayerNorm outputs against the blocks de-quantised to f16 (gemm_skinny_q, WH forms)
   return finalize_tail(h);
 }
 
@@ -700,9 +693,10 @@ int crispy_asr_set_precision(crispy_asr* h, int mode) try {
   if (mode < 0 || mode > 2)
     return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_set_precision: mode must be 0 (f32), 1 (f16 operands) or 2 (1 + f16 LayerNorm outputs in the decoder)");
   HIP_TRY(hipSetDevice(h->device));
-  const bool want_ln16 = mode == 2;
+  const bool want_attn16 = mode == 2;
   if (mode == 2) mode = 1;
-  if (h->resident && (mode != 1 || want_ln16))
+  const bool want_ln16 = mode == 1;
+  if (h->resident && (mode != 1 || want_attn16))
     return fail(CRISPY_ERR_UNSUPPORTED, "crispy_asr_set_precision: a resident quantised model runs in precision mode 1 only "
                 "(its matrices exist as f16 operands at the point of use, never as f32 tensors)");
   if (mode == 1 && !h->half_ready) {
@@ -761,7 +755,7 @@ int crispy_asr_set_precision(crispy_asr* h, int mode) try {
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->half_ready = true;
   }
-  if (want_ln16 && !h->ln16_ready) {
+  if (want_ln16 && !h->resident && !h->ln16_ready) {
     // f16 copies of the decoder's q | k | v, cross-q and fc1 weights (un-folded: the LayerNorm runs as a launch of its own)
     const size_t dtt = h->hp.n_text_state;
     auto half_copy = [&](const float* w, size_t n, const void** out) -> int {
@@ -783,11 +777,12 @@ int crispy_asr_set_precision(crispy_asr* h, int mode) try {
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->ln16_ready = true;
   }
-  if (h->enc_precision != mode || h->dec_ln16 != want_ln16) {   // the captured decode steps bake the kernels in
+  if (h->enc_precision != mode || h->dec_ln16 != want_ln16 || h->dec_attn16 != want_attn16) {   // the captured decode steps bake the kernels in
     h->drop_graphs();
   }
   h->enc_precision = mode;
   h->dec_ln16 = want_ln16;
+  h->dec_attn16 = want_attn16;
   return CRISPY_OK;
 } CRISPY_CATCH_RET("crispy_asr_set_precision")
 
@@ -898,7 +893,7 @@ int crispy_asr_encode_device(crispy_asr* h, const float* d_mel_t, int batch, flo
       HIP_TRY(gemm_hh(hg(xn_h, d, w, d, qk_h, 2L * d, L.qkv_b, 2 * d, d), HGEMM_F16, 1, s));
       HIP_TRY(gemm_hh(hg(xn_h, d, reinterpret_cast<const _Float16*>(w) + 2L * d * d, d, vt_h, 0, L.qkv_b + 2 * d, d, d),
                       HGEMM_VT, 1, s));
-      HIP_TRY(attn_encoder_h(qk_h, vt_h, att_h, batch, Tn, d, H, s, h->dec_ln16 ? 1 : 0));     // mode 2: ggml's rounding points inside the attention
+      HIP_TRY(attn_encoder_h(qk_h, vt_h, att_h, batch, Tn, d, H, s, h->dec_attn16 ? 1 : 0));     // mode 2: ggml's rounding points inside the attention
       {
         if ((rc = w16(L.out_wh, L.r_out, &w)) != CRISPY_OK) return rc;
         HGemmArgs g = hg(att_h, d, w, d, h->w_x, d, L.out_b, d, d);
@@ -989,15 +984,19 @@ namespace {
 // reorder two best-of decoders that sampled the same tokens.
 long logits_ld(const crispy_asr* h) { return ((long)h->hp.n_vocab + 3) & ~3L; }
 
-int reserve_dec(crispy_asr* h, int batch, int max_tokens) {
-  if (batch <= h->dcap_batch) return CRISPY_OK;
+// Decoder workspace for `batch` rows (sequences with a self K|V cache of their own) over `xclips` audio clips (cross K|V;
+// 0: one clip per row).  Grows only; growing frees everything and drops the captured steps.
+int reserve_dec(crispy_asr* h, int batch, int xclips = 0) {
+  if (xclips <= 0) xclips = batch;
+  if (batch <= h->dcap_batch && xclips <= h->dcap_xclips) return CRISPY_OK;
+  batch = std::max(batch, h->dcap_batch);
+  xclips = std::max(xclips, h->dcap_xclips);
   free_dec_ws(h);
-  const size_t B = batch, dt = h->hp.n_text_state, L = h->hp.n_text_layer, Tn = h->hp.n_audio_ctx,
+  const size_t B = batch, X = xclips, dt = h->hp.n_text_state, L = h->hp.n_text_layer, Tn = h->hp.n_audio_ctx,
                C = h->hp.n_text_ctx;
-  (void)max_tokens;
   // activation rows: one per clip in a generation step, up to SKINNY_MAX_M in a batched prompt step (prefill)
   const size_t R = B > (size_t)SKINNY_MAX_M ? B : (size_t)SKINNY_MAX_M;
-  HIP_TRY(hipMalloc(&h->d_xkv, L * B * Tn * 2 * dt * sizeof(float)));
+  HIP_TRY(hipMalloc(&h->d_xkv, L * X * Tn * 2 * dt * sizeof(float)));
   HIP_TRY(hipMalloc(&h->d_selfkv, L * B * C * 2 * dt * sizeof(float)));
   HIP_TRY(hipMalloc(&h->d_dx, R * dt * sizeof(float)));
   HIP_TRY(hipMalloc(&h->d_dxn, R * dt * sizeof(float)));
@@ -1013,13 +1012,20 @@ int reserve_dec(crispy_asr* h, int batch, int max_tokens) {
   HIP_TRY(hipMalloc(&h->d_tids_all, B * C * sizeof(int)));
   HIP_TRY(hipMalloc(&h->d_done_count, sizeof(int)));
   HIP_TRY(hipMalloc(&h->d_finished, B * sizeof(int)));
-  HIP_TRY(hipMalloc(&h->d_xkv_h, L * B * Tn * 2 * dt * 2));
+  HIP_TRY(hipMalloc(&h->d_xkv_h, L * X * Tn * 2 * dt * 2));
   HIP_TRY(hipMalloc(&h->d_plog_all, B * C * sizeof(float)));
   HIP_TRY(hipMalloc(&h->d_nosp, B * sizeof(float)));
   HIP_TRY(hipMalloc(&h->d_u_all, B * C * sizeof(double)));
   HIP_TRY(hipMalloc(&h->d_temperature, sizeof(float)));
   HIP_TRY(hipMalloc(&h->d_row_off, B * sizeof(int)));
+  if (fused_decode_supported((int)dt, 1, (int)Tn)) {
+    for (int i = 0; i < 3; ++i) {
+      HIP_TRY(hipMalloc(&h->d_fx[i], B * dt * sizeof(float)));
+      HIP_TRY(hipMalloc(&h->d_fpart[i], (i == 2 ? dt / 32 : dt / 64) * B * dt * sizeof(float)));
+    }
+  }
   h->dcap_batch = batch;
+  h->dcap_xclips = xclips;
   return CRISPY_OK;
 }
 
@@ -1046,6 +1052,72 @@ int decoder_logits(crispy_asr* h, int batch, hipStream_t s, const float* x = nul
   return CRISPY_OK;
 }
 
+// Rows of the biggest decode step the fused kernels take: the row range of the staged path's skinny projections, so that
+// ONE threshold separates "a row decodes to the same bits alone and in any batch" from the tiled path of larger batches
+// (crispy_amd/pipeline.py decodes in groups of <= 512 for that reason).
+constexpr int FUSED_MAX_ROWS = SKINNY_MAX_M;
+
+// CRISPY_ASR_DECODE=stages (test hook, include/crispy_hip.h): every decode step as one launch per stage.  Read at the start
+// of a decode call; a change drops the captured steps.
+void choose_decode_path(crispy_asr* h) {
+  const char* e = test_env("CRISPY_ASR_DECODE");
+  const bool fused = !(e && std::strcmp(e, "stages") == 0);
+  if (fused != h->fused_path) { h->drop_graphs(); h->fused_path = fused; }
+}
+
+bool fused_step_ok(const crispy_asr* h, int rows) {
+  return h->fused_path && h->enc_precision == 1 && !h->resident && h->ln16_ready && h->tok_emb_hp && h->d_fx[0] &&
+         rows <= FUSED_MAX_ROWS && fused_decode_supported(h->hp.n_text_state, h->dec_max_keys, h->hp.n_audio_ctx);
+}
+
+// A generated token's decoder step through the fused kernels (whisper_dec_fused.hip): 3 launches per layer + the final
+// LayerNorm + the vocabulary projection.  The token's embedding is in h->d_dx (written by the pick that chose it), its
+// position in h->d_counters[0]; one row per decoder, `rows / xgroup` clips (rows of a clip share its cross K | V).
+int decoder_step_fused(crispy_asr* h, int rows, hipStream_t s) {
+  const int dt = h->hp.n_text_state, Tn = h->hp.n_audio_ctx, C = h->hp.n_text_ctx;
+  const size_t clips = (size_t)rows, xclips = (size_t)(rows / h->cur_xgroup);
+  const int attn16 = h->dec_attn16 ? 1 : 0;
+  const int stream_kv = xclips * h->dec.size() * Tn * 2 * dt * 2 > ((size_t)256 << 20) ? 1 : 0;      // see decoder_step
+  float *xa = h->d_fx[0], *xb = h->d_fx[1], *xc = h->d_fx[2];
+  float *pa = h->d_fpart[0], *pb = h->d_fpart[1], *pc = h->d_fpart[2];
+  const float* x_in = h->d_dx;
+  const float* prev_bias = nullptr;
+  for (size_t l = 0; l < h->dec.size(); ++l) {
+    const DecLayer& L = h->dec[l];
+    FusedSelfArgs a{};
+    a.in = FusedIn{x_in, prev_bias, pc, xa, L.ln1_w, L.ln1_b};
+    a.wqkv = reinterpret_cast<const _Float16*>(L.qkv_wh); a.bqkv = L.qkv_b;
+    a.wo = reinterpret_cast<const _Float16*>(L.out_wh);
+    a.kv = reinterpret_cast<_Float16*>(h->d_selfkv) + l * clips * C * 2 * dt; a.kv_row_stride = (long)C * 2 * dt;
+    a.pos_dev = h->d_counters; a.key_off = h->cur_row_off;
+    a.attn16 = attn16; a.max_keys = h->dec_max_keys;
+    a.part_out = pa; a.rows = rows; a.D = dt;
+    HIP_TRY(fused_self(a, l == 0, s));
+    FusedCrossArgs b{};
+    b.in = FusedIn{xa, L.out_b, pa, xb, L.lnx_w, L.lnx_b};
+    b.wq = reinterpret_cast<const _Float16*>(L.xq_wh); b.bq = L.xq_b;
+    b.wo = reinterpret_cast<const _Float16*>(L.xout_wh);
+    b.xkv = reinterpret_cast<const _Float16*>(h->d_xkv_h) + l * xclips * Tn * 2 * dt; b.clip_stride = (long)Tn * 2 * dt;
+    b.n_keys = Tn; b.group = h->cur_xgroup; b.attn16 = attn16; b.stream_kv = stream_kv;
+    b.part_out = pb; b.rows = rows; b.D = dt;
+    HIP_TRY(fused_cross(b, s));
+    FusedMlpArgs m{};
+    m.in = FusedIn{xb, L.xout_b, pb, xc, L.ln2_w, L.ln2_b};
+    m.w1 = reinterpret_cast<const _Float16*>(L.fc1_wh); m.b1 = L.fc1_b;
+    m.w2 = reinterpret_cast<const _Float16*>(L.fc2_wh);
+    m.part_out = pc; m.rows = rows; m.D = dt;
+    HIP_TRY(fused_mlp(m, s));
+    x_in = xc;
+    prev_bias = L.fc2_b;
+  }
+  FusedFinishArgs f{};
+  f.in = FusedIn{xc, prev_bias, pc, xa, h->dec_ln_w, h->dec_ln_b};
+  f.y = reinterpret_cast<_Float16*>(h->d_dxn); f.rows = rows; f.D = dt;
+  HIP_TRY(fused_finish(f, s));
+  HIP_TRY(vocab_f16(h->d_dxn, dt, h->tok_emb_hp, h->d_logits, logits_ld(h), rows, h->hp.n_vocab, dt, s));
+  return CRISPY_OK;
+}
+
 // one decoder step for all clips: token ids in h->d_tok; leaves logits in h->d_logits.
 // dev_pos = false: the position is the host value `pos` (prompt tokens).
 // dev_pos = true : the position is read from h->d_counters[0] by the kernels, so the identical launch
@@ -1061,6 +1133,8 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
   const int* pos_dev = dev_pos ? h->d_counters : nullptr;
   const int clips = batch;
   if (P < 1) P = 1;
+  // a generated token (its embedding written by the pick, its position on the device): the fused step kernels
+  if (P == 1 && dev_pos && embedded && want_logits && fused_step_ok(h, clips)) return decoder_step_fused(h, clips, s);
   batch = clips * P;                   // rows of this step
   // <= SKINNY_MAX_M clips: the projections run on the skinny kernel (row blocks of 32 clips), which folds the preceding LayerNorm in and writes q and
   // k|v of the self-attention block from one launch (17 launches fewer per step on Whisper-tiny)
@@ -1070,9 +1144,11 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
   AttnRows self_rows, cross_rows;
   self_rows.group = P; self_rows.key_step = P > 1 ? 1 : 0;
   self_rows.key_off = h->cur_row_off;        // left-padded prompts (decode_ts): every clip's keys start at its own cache row
-  cross_rows.group = P;
+  const int xg = h->cur_xgroup;              // sequences (rows with a self K|V cache of their own) per audio clip
+  const size_t xclips = (size_t)(clips / xg);
+  cross_rows.group = P * xg;
   // precision mode 2: q and the normalised probabilities rounded to f16 inside the attentions over the f16 caches
-  cross_rows.attn16 = h->dec_ln16 && h->enc_precision == 1 ? 1 : 0;
+  cross_rows.attn16 = h->dec_attn16 && h->enc_precision == 1 ? 1 : 0;
   // The cross K|V of all layers and clips against the 256 MB Infinity Cache: while it fits, it is what stays cached from
   // step to step (plain loads: 16 tiny clips = 147 MB, 6.8 ms per call against 7.0 non-temporal); beyond that it is a
   // one-pass stream that only evicts the decoder's weights from the L2s, and is requested non-temporally
@@ -1080,7 +1156,7 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
   // (not in a multi-position prompt step: the P rows of a clip read the same K|V one after the other, and the repeats are
   // served by the Infinity Cache only if the first read allocates there: 2.06 vs 2.18 ms for the prompt of 128 clips)
   static const bool prompt_nt = dev_env("CRISPY_XKV_PROMPT_NT") != nullptr;      // developer A/B (tools/ab_prompt_nt.sh)
-  cross_rows.stream_kv = (P == 1 || prompt_nt) && (size_t)clips * h->dec.size() * Tn * 2 * dt * (h->enc_precision == 1 ? 2 : 4) > ((size_t)256 << 20) ? 1 : 0;
+  cross_rows.stream_kv = (P == 1 || prompt_nt) && xclips * h->dec.size() * Tn * 2 * dt * (h->enc_precision == 1 ? 2 : 4) > ((size_t)256 << 20) ? 1 : 0;
   if (!embedded) {    // (a fused pick has written the residual stream already)
     if (h->resident)
       HIP_TRY(embed_tokens_q(h->d_tok, h->q_tok_emb->d, h->q_tok_emb->ttype, h->dec_pos, pos, pos_dev, h->d_dx, batch, dt, s, P,
@@ -1130,14 +1206,14 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
   for (size_t l = 0; l < h->dec.size(); ++l) {
     const DecLayer& L = h->dec[l];
     float* selfkv = h->d_selfkv + l * (size_t)clips * C * 2 * dt;
-    const float* xkv = h->d_xkv + l * (size_t)clips * Tn * 2 * dt;
+    const float* xkv = h->d_xkv + l * xclips * Tn * 2 * dt;
     // causal self-attention against the cache; k | v of this position go straight into the cache row (b, pos)
     float* kv_dst = selfkv + (dev_pos ? 0 : (size_t)pos * 2 * dt);
     // mode 1: the self K|V cache is f16, as whisper.cpp's kv_self is (it aliases the f32 cache: every decode call
     // starts with its own prefill); the projection stores halves, the attention requests all its keys up front
     const bool kv16 = fold && h->enc_precision == 1 && h->dec_max_keys > 0 && h->dec_max_keys <= 512;
     _Float16* selfkv_h = reinterpret_cast<_Float16*>(h->d_selfkv) + l * (size_t)clips * C * 2 * dt;
-    self_rows.attn16 = kv16 && h->dec_ln16 ? 1 : 0;
+    self_rows.attn16 = kv16 && h->dec_attn16 ? 1 : 0;
     if (fold) {
       // precision mode 2: LayerNorm as a launch of its own, its output rounded to f16 on the way into the f16 matrix cores
       // against f16 weights (ggml's mul_mat arithmetic for these products too); modes 0 / 1: LayerNorm folded in, f32 operands
@@ -1153,7 +1229,7 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
       // hidden buffer (free until fc1) and scattered by one strided copy.
       const bool stage_kv = P > 1 && clips > 1;
       if (P > 1) { g.ldc2 = 2L * dt; if (stage_kv) g.C2 = h->d_dh; }
-      if ((qrc = proj(g, L.qkv_lw, L.qkv_wh, L.r_qkv, L.ln1_w, ln16)) != CRISPY_OK) return qrc;
+      if ((qrc = proj(g, L.qkv_lw, L.qkv_wh, L.r_qkv, ln16 ? nullptr : L.ln1_w, ln16)) != CRISPY_OK) return qrc;
       if (stage_kv) {
         const size_t esz = kv16 ? 2 : 4;
         void* dst = kv16 ? static_cast<void*>(selfkv_h + (size_t)pos * 2 * dt) : static_cast<void*>(selfkv + (size_t)pos * 2 * dt);
@@ -1189,7 +1265,7 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
       if (ln16) HIP_TRY(layernorm_f32(h->d_dx, L.lnx_w, L.lnx_b, h->d_dxn, batch, dt, s));
       GemmArgs g = gemm(ln16 ? h->d_dxn : h->d_dx, dt, nullptr, dt, h->d_dq, dt, ln16 ? L.xq_b : nullptr, batch, dt, dt);
       if (!ln16) { g.ln_s = L.xq_ls; g.ln_c = L.xq_lc; }
-      if ((qrc = proj(g, L.xq_lw, L.xq_wh, L.r_xq, L.lnx_w, ln16)) != CRISPY_OK) return qrc;
+      if ((qrc = proj(g, L.xq_lw, L.xq_wh, L.r_xq, ln16 ? nullptr : L.lnx_w, ln16)) != CRISPY_OK) return qrc;
     } else {
       HIP_TRY(layernorm_f32(h->d_dx, L.lnx_w, L.lnx_b, h->d_dxn, batch, dt, s));
       const float* xq_w = w32(L.xq_w, L.r_xq, nullptr);
@@ -1197,7 +1273,7 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
       HIP_TRY(gemm_f32_nt(gemm(h->d_dxn, dt, xq_w, dt, h->d_dq, dt, L.xq_b, batch, dt, dt), 1, s));
     }
     if (h->enc_precision == 1)
-      HIP_TRY(attn_decoder_kv16(h->d_dq, dt, reinterpret_cast<const char*>(h->d_xkv_h) + l * (size_t)clips * Tn * 2 * dt * 2,
+      HIP_TRY(attn_decoder_kv16(h->d_dq, dt, reinterpret_cast<const char*>(h->d_xkv_h) + l * xclips * Tn * 2 * dt * 2,
                                 (long)Tn * 2 * dt, 64, 64L * Tn, 0, (long)Tn * dt, Tn, nullptr, h->d_datt, dt, batch, H, s, 0,
                                 cross_rows));
     else
@@ -1215,7 +1291,7 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
       GemmArgs g = gemm(ln16 ? h->d_dxn : h->d_dx, dt, nullptr, dt, h->d_dh, 4L * dt, ln16 ? L.fc1_b : nullptr, batch, 4 * dt, dt);
       if (!ln16) { g.ln_s = L.fc1_ls; g.ln_c = L.fc1_lc; }
       g.gelu = h->enc_precision == 1 ? 2 : 1;      // mode 1: ggml's GELU (asr_common.h: gelu_ggml)
-      if ((qrc = proj(g, L.fc1_lw, L.fc1_wh, L.r_fc1, L.ln2_w, ln16)) != CRISPY_OK) return qrc;
+      if ((qrc = proj(g, L.fc1_lw, L.fc1_wh, L.r_fc1, ln16 ? nullptr : L.ln2_w, ln16)) != CRISPY_OK) return qrc;
     } else {
       HIP_TRY(layernorm_f32(h->d_dx, L.ln2_w, L.ln2_b, h->d_dxn, batch, dt, s));
       GemmArgs g = gemm(h->d_dxn, dt, w32(L.fc1_w, L.r_fc1, nullptr), dt, h->d_dh, 4L * dt, L.fc1_b, batch, 4 * dt, dt);
@@ -1309,7 +1385,7 @@ int compute_cross_kv(crispy_asr* h, const float* d_enc, int batch, hipStream_t s
 // to (h->cur_row_off: the padding per clip; nullptr = none).  Leaves the logits of the last prompt position in h->d_logits.
 int prefill(crispy_asr* h, const float* d_enc, int batch, const int* tok_mat, int n_rows, hipStream_t s, int* pos_out) {
   {
-    const int rc = compute_cross_kv(h, d_enc, batch, s);
+    const int rc = compute_cross_kv(h, d_enc, batch / h->cur_xgroup, s);
     if (rc != CRISPY_OK) return rc;
   }
   // The prompt runs as multi-position steps: P positions of every clip per step (decoder_step, P > 1), as many as the
@@ -1377,13 +1453,16 @@ TsPickArgs ts_args(crispy_asr* h, int rules, const unsigned char* mask, const un
 // sampling pass of the temperature ladder at `temperature` > 0, one uniform variate per (step, row).
 // tokens_out / tids_out / plog_out: [rows][max_new]; n_out[b] = picks up to and including the one that ended the window;
 // nosp_out[b] = softmax of the last prompt position's unfiltered logits at <|nospeech|>.
+// xgroup: rows per audio clip -- d_enc holds batch / xgroup encoder outputs, rows [c * xgroup, (c + 1) * xgroup) decode
+// clip c (the best-of decoders of a fallback pass: own prompt, own self K|V cache, own variates, ONE cross K|V).
 int decode_ts(crispy_asr* h, const float* d_enc, int batch, const std::vector<std::vector<int>>& prompts, int rules,
               const int* seek, const int* seek_end, int max_new, const unsigned char* mask, const unsigned char* mask_first,
               float temperature, const double* u, int* tokens_out, int* tids_out, float* plog_out, float* nosp_out,
-              int* n_out) {
+              int* n_out, int xgroup = 1) {
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = h->stream;
   if ((int)prompts.size() != batch) return fail(CRISPY_ERR_INVALID_ARG, "decode: %zu prompts for %d rows", prompts.size(), batch);
+  if (xgroup < 1 || batch % xgroup != 0) return fail(CRISPY_ERR_INVALID_ARG, "decode: %d rows are not whole groups of %d", batch, xgroup);
   int n_rows = 0;
   for (const auto& p : prompts) {
     if (p.empty()) return fail(CRISPY_ERR_INVALID_ARG, "decode: empty prompt");
@@ -1394,8 +1473,9 @@ int decode_ts(crispy_asr* h, const float* d_enc, int batch, const std::vector<st
   if (n_rows + max_new > h->hp.n_text_ctx)
     return fail(CRISPY_ERR_INVALID_ARG, "decode: %d prompt + %d new tokens exceed n_text_ctx %d", n_rows, max_new, h->hp.n_text_ctx);
   if (u && !(temperature > 0.f)) return fail(CRISPY_ERR_INVALID_ARG, "decode: sampling needs a temperature > 0");
-  int rc = reserve_dec(h, batch, n_rows + max_new);
+  int rc = reserve_dec(h, batch, batch / xgroup);
   if (rc != CRISPY_OK) return rc;
+  choose_decode_path(h);
   h->dec_max_keys = n_rows + max_new;
   std::vector<int> off(batch), tok_mat((size_t)batch * n_rows, 0);
   for (int b = 0; b < batch; ++b) {
@@ -1404,8 +1484,9 @@ int decode_ts(crispy_asr* h, const float* d_enc, int batch, const std::vector<st
   }
   HIP_TRY(hipMemcpyAsync(h->d_row_off, off.data(), sizeof(int) * batch, hipMemcpyHostToDevice, s));
   HIP_TRY(hipStreamSynchronize(s));
-  struct OffGuard { crispy_asr* h; ~OffGuard() { h->cur_row_off = nullptr; } } guard{h};
+  struct OffGuard { crispy_asr* h; ~OffGuard() { h->cur_row_off = nullptr; h->cur_xgroup = 1; } } guard{h};
   h->cur_row_off = h->d_row_off;
+  h->cur_xgroup = xgroup;
   int pos = 0;
   rc = prefill(h, d_enc, batch, tok_mat.data(), n_rows, s, &pos);
   if (rc != CRISPY_OK) return rc;
@@ -1425,10 +1506,14 @@ int decode_ts(crispy_asr* h, const float* d_enc, int batch, const std::vector<st
   pa.u_all = u ? h->d_u_all : nullptr;
   int steps_run = 1;      // picks made = decoder steps replayed + the final pick
   if (max_new > 1) {
-    // its own graph slot per key class and kind of pick
-    const int kc = (h->dec_max_keys <= 128 ? 0 : h->dec_max_keys <= 256 ? 1 : 2) + (u ? 3 : 0);
-    if (!h->ts_graphs[kc] || h->ts_graph_batch[kc] != batch || h->ts_graph_rules[kc] != rules || h->ts_graph_mask[kc] != mask) {
-      if (h->ts_graphs[kc]) { (void)hipGraphExecDestroy(h->ts_graphs[kc]); h->ts_graphs[kc] = nullptr; }
+    const crispy_asr::TsKey key{h->dec_max_keys <= 128 ? 0 : h->dec_max_keys <= 256 ? 1 : 2, u ? 1 : 0, batch, xgroup, rules, mask};
+    auto slot = h->ts_graphs.find(key);
+    if (slot == h->ts_graphs.end()) {
+      if (h->ts_graphs.size() >= 32) {          // a bound, not a policy: nothing real alternates between this many shapes
+        for (auto& kv : h->ts_graphs) (void)hipGraphExecDestroy(kv.second);
+        h->ts_graphs.clear();
+      }
+      hipGraphExec_t exec = nullptr;
       hipGraph_t graph = nullptr;
       HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
       TsPickArgs pf = pa;                     // the pick of a replay also embeds its token and moves the counters on
@@ -1439,14 +1524,14 @@ int decode_ts(crispy_asr* h, const float* d_enc, int batch, const std::vector<st
       if (rc != CRISPY_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
       HIP_TRY(pe);
       HIP_TRY(ce);
-      const hipError_t ie = hipGraphInstantiate(&h->ts_graphs[kc], graph, nullptr, nullptr, 0);
+      const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
       (void)hipGraphDestroy(graph);
       HIP_TRY(ie);
-      h->ts_graph_batch[kc] = batch; h->ts_graph_rules[kc] = rules; h->ts_graph_mask[kc] = mask;
+      slot = h->ts_graphs.emplace(key, exec).first;
     }
     int done = 0;
     for (int i = 0; i + 1 < max_new; ++i) {
-      HIP_TRY(hipGraphLaunch(h->ts_graphs[kc], s));
+      HIP_TRY(hipGraphLaunch(slot->second, s));
       ++steps_run;
       if ((i & 7) == 7) {   // every 8 tokens: have all windows ended?
         HIP_TRY(hipMemcpyAsync(&done, h->d_done_count, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1518,7 +1603,7 @@ int crispy_asr_stage_logits_device(crispy_asr* h, const float* d_x, int batch, f
   if (!d_x || !d_logits) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_stage_logits_device: NULL argument");
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = h->stream;
-  int rc = reserve_dec(h, batch, 1);
+  int rc = reserve_dec(h, batch);
   if (rc != CRISPY_OK) return rc;
   const int dt = h->hp.n_text_state, V = h->hp.n_vocab;
   // through the decode step's own buffers, so that the code under test is decoder_step's last block
@@ -1554,8 +1639,9 @@ int crispy_asr_decode_greedy_lang_device(crispy_asr* h, const float* d_enc, int 
       return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_decode_greedy_device: prompt token %d out of range", prompt[i]);
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = h->stream;
-  int rc = reserve_dec(h, batch, n_prompt + max_new);
+  int rc = reserve_dec(h, batch);
   if (rc != CRISPY_OK) return rc;
+  choose_decode_path(h);
   h->dec_max_keys = n_prompt + max_new;
   const int V = h->hp.n_vocab;
   int pos = 0;
@@ -1686,7 +1772,7 @@ int crispy_asr_detect_language_device(crispy_asr* h, const float* d_enc, int bat
   if (h->hp.n_vocab < 51865) return fail(CRISPY_ERR_UNSUPPORTED, "crispy_asr_detect_language_device: English-only vocabulary");
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = h->stream;
-  int rc = reserve_dec(h, batch, 1);
+  int rc = reserve_dec(h, batch);
   if (rc != CRISPY_OK) return rc;
   const int V = h->hp.n_vocab;
   rc = compute_cross_kv(h, d_enc, batch, s);
@@ -2298,7 +2384,15 @@ int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const si
         for (int j = 0; j < best_of; ++j) rngs[k].emplace_back((unsigned)j);
       const int n_init = (int)prompt.size();
       const size_t enc_clip = (size_t)h->hp.n_audio_ctx * h->hp.n_audio_state;
-      float* d_enc_rep = nullptr;                         // best_of copies of one clip's encoder output (fallback passes)
+      // rows of one fallback decode: whole clips x best_of
+      const int kLadderRows = 256;
+      // the decoder workspace for the widest pass of this call, taken once: growing it between the greedy pass and the
+      // first fallback pass freed every buffer and dropped the captured steps
+      if (temps.size() > 1 && best_of > 1) {
+        rc = reserve_dec(h, std::max(nb, std::min(nb * best_of, (kLadderRows / best_of) * best_of)), nb);
+        if (rc != CRISPY_OK) return rc;
+      }
+      float* d_enc_rep = nullptr;                         // the encoder outputs of a group of fallback clips, gathered (one per clip)
       struct RepGuard { float** p; ~RepGuard() { if (*p) (void)hipFree(*p); } } rep_guard{&d_enc_rep};
       auto build_prompt = [&](int k, int lang_tok, float t_cur) {
         std::vector<int> p;
@@ -2355,53 +2449,54 @@ int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const si
           const bool last_temp = it + 1 == temps.size();
           const int n_dec = t_cur > 0.f ? best_of : 1;
           std::vector<int> still;
-          // groups of rows decoded together: at temperature 0 all pending clips (one row each, straight off h->w_enc when
-          // nothing has dropped out yet); above it one clip at a time, n_dec rows over copies of its encoder output
+          // Groups of clips decoded together, n_dec rows each (rows [c n_dec, (c + 1) n_dec) of a group are the decoders of its
+          // clip c: one cross K|V per clip, decode_ts's xgroup).  At temperature 0 that is every pending clip in one group, one
+          // row each, straight off h->w_enc while nothing has dropped out; above it the pending clips x best_of, in groups of
+          // at most kLadderRows rows -- ALL of them side by side, not one clip after the other (a batch in
+          // which a third of the windows fall back used to decode them one by one, five rows at a time).
+          const int per_group = n_dec == 1 ? (int)pending.size() : std::max(1, kLadderRows / n_dec);
           std::vector<std::vector<int>> groups;
-          if (n_dec == 1) groups.push_back(pending);
-          else for (int a : pending) groups.push_back({a});
+          for (size_t g0 = 0; g0 < pending.size(); g0 += (size_t)per_group)
+            groups.emplace_back(pending.begin() + g0, pending.begin() + std::min(pending.size(), g0 + (size_t)per_group));
           for (const std::vector<int>& grp : groups) {
-            const int rows = n_dec == 1 ? (int)grp.size() : n_dec;
+            const int n_clips = (int)grp.size(), rows = n_clips * n_dec;
             const float* d_enc = h->w_enc;
-            const bool contiguous = n_dec == 1 && (int)grp.size() == na;
-            if (!contiguous) {
-              if (!d_enc_rep) HIP_TRY(hipMalloc(&d_enc_rep, (size_t)std::max(na, best_of) * enc_clip * sizeof(float)));
-              for (int r = 0; r < rows; ++r) {
-                const int a = n_dec == 1 ? grp[r] : grp[0];
-                HIP_TRY(hipMemcpyAsync(d_enc_rep + (size_t)r * enc_clip, h->w_enc + (size_t)a * enc_clip, enc_clip * sizeof(float),
+            bool contiguous = true;               // the group's clips are w_enc's first n_clips, in order
+            for (int c = 0; c < n_clips; ++c) contiguous = contiguous && grp[c] == c;
+            if (!contiguous) {                    // one copy per CLIP (its decoders share it)
+              if (!d_enc_rep) HIP_TRY(hipMalloc(&d_enc_rep, (size_t)std::min(na, std::max(per_group, 1)) * enc_clip * sizeof(float)));
+              for (int c = 0; c < n_clips; ++c)
+                HIP_TRY(hipMemcpyAsync(d_enc_rep + (size_t)c * enc_clip, h->w_enc + (size_t)grp[c] * enc_clip, enc_clip * sizeof(float),
                                        hipMemcpyDeviceToDevice, h->stream));
-              }
               d_enc = d_enc_rep;
             }
             std::vector<std::vector<int>> prompts((size_t)rows);
             std::vector<int> r_seek(rows), r_end(rows);
             for (int r = 0; r < rows; ++r) {
-              const int a = n_dec == 1 ? grp[r] : grp[0], k = act[a];
+              const int k = act[grp[r / n_dec]];
               prompts[r] = build_prompt(k, lang[k], t_cur);
               r_seek[r] = seek[k]; r_end[r] = seek_end[k];
             }
             std::vector<double> u;
-            if (t_cur > 0.f) {            // the variates decoder j would draw, from a copy of its generator
-              const int k = act[grp[0]];
+            if (t_cur > 0.f) {            // the variates decoder j of clip k would draw, from a copy of ITS generator
               u.resize((size_t)max_new * rows);
-              for (int j = 0; j < rows; ++j) {
-                std::mt19937 g = rngs[k][j];
-                for (int i = 0; i < max_new; ++i) u[(size_t)i * rows + j] = canonical(g);
+              for (int r = 0; r < rows; ++r) {
+                std::mt19937 g = rngs[act[grp[r / n_dec]]][r % n_dec];
+                for (int i = 0; i < max_new; ++i) u[(size_t)i * rows + r] = canonical(g);
               }
             }
             std::vector<int> toks((size_t)rows * max_new), tids((size_t)rows * max_new), n_out(rows, 0);
             std::vector<float> plog((size_t)rows * max_new), nosp(rows, 0.f);
             rc = decode_ts(h, d_enc, rows, prompts, TS_RULES_WCPP, r_seek.data(), r_end.data(), max_new, h->d_ts_mask,
                            h->d_ts_mask_first, t_cur, t_cur > 0.f ? u.data() : nullptr, toks.data(), tids.data(), plog.data(),
-                           nosp.data(), n_out.data());
+                           nosp.data(), n_out.data(), n_dec);
             if (rc != CRISPY_OK) return rc;
             // evaluate: per clip of the group, its n_dec decoders
-            const int n_clips = n_dec == 1 ? (int)grp.size() : 1;
             for (int c = 0; c < n_clips; ++c) {
               const int a = grp[c], k = act[a];
               std::vector<DecoderPass> decs((size_t)n_dec);
               for (int j = 0; j < n_dec; ++j) {
-                const int r = n_dec == 1 ? c : j;
+                const int r = c * n_dec + j;
                 DecoderPass& d = decs[j];
                 d.toks = toks.data() + (size_t)r * max_new;
                 d.tids = tids.data() + (size_t)r * max_new;
@@ -2422,18 +2517,19 @@ int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const si
                 if (best_score < d.score) { best_score = d.score; best = j; }
               }
               const DecoderPass& bd = decs[best];
+              const float clip_nosp = nosp[c * n_dec];          // every decoder of a clip saw the same prompt logits
               bool success = true;
-              if (!last_temp && (bd.failed || (bd.avg_logprobs < logprob_thold && nosp[n_dec == 1 ? c : 0] < no_speech_thold)))
+              if (!last_temp && (bd.failed || (bd.avg_logprobs < logprob_thold && clip_nosp < no_speech_thold)))
                 success = false;
               Accepted& A = acc[a];
-              const int r = n_dec == 1 ? c : best;
+              const int r = c * n_dec + best;
               A.toks.assign(toks.begin() + (size_t)r * max_new, toks.begin() + (size_t)r * max_new + bd.n);
               A.tids.assign(tids.begin() + (size_t)r * max_new, tids.begin() + (size_t)r * max_new + bd.n);
               A.plog.assign(plog.begin() + (size_t)r * max_new, plog.begin() + (size_t)r * max_new + bd.n);
               A.d = bd;
               A.d.toks = A.toks.data(); A.d.tids = A.tids.data(); A.d.plog = A.plog.data();
               A.prompt = prompts[r];
-              A.nosp = nosp[n_dec == 1 ? c : 0];
+              A.nosp = clip_nosp;
               A.temperature = t_cur;
               A.decoder = best;
               A.have = true;

@@ -1642,7 +1642,12 @@ hipError_t skq_launch(dim3 grid, const GemmArgs& g, hipStream_t s) {
 // plain f16 + residual (attention outputs, MLP second product)
 template <int TT, int NW>
 hipError_t skq_kind(int kind, bool wh, dim3 grid, const GemmArgs& g, hipStream_t s) {
-  if (wh) return kind == 1 ? skq_launch<TT, false, false, true, NW, true>(grid, g, s) : hipErrorInvalidValue;
+  if (wh) {      // f16 operands: the residual projections; behind an explicit LayerNorm (f16 LayerNorm outputs) bias only and bias + GELU
+    if (kind == 1) return skq_launch<TT, false, false, true, NW, true>(grid, g, s);
+    if (kind == 0) return skq_launch<TT, false, false, false, NW, true>(grid, g, s);
+    if (kind == 2) return skq_launch<TT, false, true, false, NW, true>(grid, g, s);
+    return hipErrorInvalidValue;
+  }
   if (kind == 4) return skq_launch<TT, true, false, false, NW, false>(grid, g, s);
   if (kind == 6) return skq_launch<TT, true, true, false, NW, false>(grid, g, s);
   return hipErrorInvalidValue;
@@ -1661,7 +1666,7 @@ hipError_t skq_nw(int nw, int kind, bool wh, dim3 grid, const GemmArgs& g, hipSt
 bool skinny_q_supported(const GemmArgs& g, int batch) {
   if (!(batch == 1 && g.M <= SKINNY_MAX_M && g.K % 128 == 0 && !g.rowtab && !g.tiled)) return false;
   const int kind = (g.ln_s ? 4 : 0) | (g.gelu ? 2 : 0) | (g.residual ? 1 : 0);
-  return g.w_half ? kind == 1 : (kind == 4 || kind == 6);
+  return g.w_half ? (kind == 1 || kind == 0 || kind == 2) : (kind == 4 || kind == 6);
 }
 hipError_t gemm_skinny_q(const GemmArgs& g, hipStream_t s) {
   const dim3 grid((g.N + 31) / 32, (g.M + 31) / 32);

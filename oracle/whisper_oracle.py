@@ -222,21 +222,24 @@ class DecoderCache:
     """KV-cached incremental decoder (float64); `step(token)` returns the logits of the new position.
     Same arithmetic as `decoder_logits`, restated so that 200-token windows finish in seconds."""
 
-    def __init__(self, weights, hp, enc_out, f16=False, dtype=np.float64, ln16=False, attn16=False):
+    def __init__(self, weights, hp, enc_out, f16=False, dtype=np.float64, ln16=None, attn16=False):
         """dtype=np.float32: single-precision CPU run for bench.py's cpu_baseline (not the parity oracle).
         f16=True: the decoder arithmetic of the library's precision mode 1, i.e. whisper.cpp's ggml graph
         [UPSTREAM-RECALL] wherever a matrix product has no LayerNorm folded into it on the GPU -- cross K | V from the
         f16-rounded encoder output and f16 weights, stored as f16 (kv_cross); the self-attention K | V cache stored
         as f16 (kv_self); the attention outputs and the GELU'd hidden layer rounded to f16 against f16 weights
-        (attn.out, cross_attn.out, mlp.2); the final LayerNorm rounded to f16 against the f16 token embedding.  The
-        projections behind a LayerNorm (q | k | v, cross q, mlp.0) stay exact: the library folds the LayerNorm into
-        them and keeps them in f32 (NOTEBOOK.md section 4)."""
+        (attn.out, cross_attn.out, mlp.2); the final LayerNorm rounded to f16 against the f16 token embedding; and
+        (ln16, on with f16 unless switched off) the LayerNorm outputs rounded to f16 against f16 weights in front of
+        q | k | v, cross q and mlp.0."""
         self.W = _f64(weights, dtype)
         self.hp = hp
         self.f16 = f16
-        # ln16 (the library's precision mode 2): the LayerNorm output is rounded to f16 -- and the weight too -- in front of
-        # the q | k | v, cross-q and fc1 products, as ggml's mul_mat does with an f32 activation against an f16 weight
-        # [UPSTREAM-RECALL]; mode 1 keeps those five products exact (LayerNorm folded into f32 GEMMs)
+        # ln16: the LayerNorm output is rounded to f16 -- and the weight too -- in front of the q | k | v, cross-q and fc1
+        # products, as ggml's mul_mat does with an f32 activation against an f16 weight [UPSTREAM-RECALL].  Part of the
+        # library's precision modes 1 and 2 since round 5 (default: follows f16); ln16=False is the arithmetic of rounds
+        # 2 - 4, where mode 1 kept those five products exact (LayerNorm folded into f32 GEMMs).
+        if ln16 is None:
+            ln16 = f16
         self.ln16 = bool(ln16 and f16)
         # attn16 (mode 2 as well): the query is rounded to f16 in front of K.q and the NORMALISED soft-max probabilities in
         # front of P.V -- ggml's mul_mat converts its f32 operand to the f16 of the K / V cache it multiplies

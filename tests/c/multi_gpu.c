@@ -7,7 +7,7 @@
  *   multi_gpu <model.txt> <in.f32> <out.f32> <n_streams> <n_frames> <n_shards>
  *
  * in.f32: [n_frames][n_streams][480] raw floats (int16 range, CRISPY_RN_LAYOUT_TBF); out.f32 receives the denoised
- * audio in the same layout.  Shard r owns streams [r B / R, (r + 1) B / R): it copies its columns into a contiguous
+ * audio in the same layout.  Shard r owns a contiguous block of streams (shard_range): it copies its columns into a contiguous
  * [n_frames][own][480] block, runs crispy_rn_process on its own handle and thread, and scatters the result back.
  * One JSON line on stdout: devices, shards, streams per shard, a checksum of the output (sum of every sample as a
  * double) and the wall time.  tests/test_gpu_c_dropin.py runs it with 1 shard and with several and compares both the
@@ -85,7 +85,8 @@ int main(int argc, char **argv) {
   for (int r = 0; r < R; ++r) {
     memset(&sh[r], 0, sizeof(sh[r]));
     sh[r].model = argv[1]; sh[r].in = in; sh[r].out = out; sh[r].n_streams = B; sh[r].n_frames = T;
-    sh[r].lo = (int)((long)r * B / R); sh[r].hi = (int)((long)(r + 1) * B / R);     /* crispy_amd/sharding.py: shard_range */
+    sh[r].lo = r * (B / R) + (r < B % R ? r : B % R);     /* crispy_amd/sharding.py: shard_range (the first B % R shards get one more) */
+    sh[r].hi = sh[r].lo + B / R + (r < B % R ? 1 : 0);
     sh[r].device = r % n_dev;
     if (pthread_create(&th[r], NULL, run_shard, &sh[r]) != 0) return 5;
   }

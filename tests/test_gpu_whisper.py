@@ -676,15 +676,17 @@ def test_vocabulary_projection_both_precision_modes(tiny, model, batch):
 
 def test_mode_1_decoder_matches_the_f16_arithmetic_oracle(tiny, model):
     """Precision mode 1 of the DECODER against an oracle of its own arithmetic (oracle DecoderCache(f16=True): f16 cross
-    and self K|V caches, f16 operands in the attention-output / MLP-second / vocabulary products; the LayerNorm-folded
-    projections exact), on encoder outputs handed over as they are: the logit of each greedy pick for 8 clips x 6
-    picks behind a 4-token prompt (48 logits; the oracle follows the GPU's picks, so the comparison is per step).
-    A picked logit moves by ~2e-4 of its size under these roundings, the same order as one f16 flip caused by f32
-    accumulation, so single values cannot tell the two oracles apart; over the 48 the GPU must be closer (rms) to the
-    f16 oracle than to the exact one (measured: 7.0e-5 against 9.9e-5, the two oracles 1.18e-4 apart -- the same
-    picture as the encoder's: what remains is f32 accumulation order moving values across f16 boundaries), within
-    1e-4 rms and 4e-4 at the worst value, and it must pick the f16 oracle's ids wherever that oracle's top-2 margin
-    exceeds 1e-3 of the scale."""
+    and self K|V caches, f16 operands in every product -- since round 5 the LayerNorm outputs in front of q | k | v,
+    cross q and fc1 included, as ggml rounds them), on encoder outputs handed over as they are: the logit of each greedy
+    pick for 8 clips x 6 picks behind a 4-token prompt (48 logits; the oracle follows the GPU's picks, so the comparison
+    is per step).  The generated tokens run through the fused step kernels (whisper_dec_fused.hip), the prompt through
+    the staged ones.  A picked logit moves by ~2e-4 of its size under these roundings, the same order as one f16 flip
+    caused by f32 accumulation, so single values cannot tell the two oracles apart; over the 48 the GPU must be closer
+    (rms) to the f16 oracle than to the exact one (measured: 1.21e-4 against 1.87e-4, the two oracles 1.78e-4 apart;
+    with the f32 LayerNorm-folded products of rounds 2 - 4: 7.0e-5 / 9.9e-5 / 1.18e-4 -- every rounding point turns a
+    3e-7 difference in accumulation order into a full 2^-11 step for one value in a few thousand, and there are three
+    more of them per layer now), within 1.6e-4 rms (the bar mode 2 has had for the same rounding points) and 5e-4 at the
+    worst value, and it must pick the f16 oracle's ids wherever that oracle's top-2 margin exceeds 1e-3 of the scale."""
     import torch
     from oracle import whisper_oracle as WO
     hp, W = tiny
@@ -723,7 +725,7 @@ def test_mode_1_decoder_matches_the_f16_arithmetic_oracle(tiny, model):
     rms16, rms64 = np.sqrt(np.mean(e16 ** 2)), np.sqrt(np.mean(e64 ** 2))
     print(f"mode-1 decoder: rms to the f16 oracle {rms16:.2e}, to the exact one {rms64:.2e}, oracle gap {gap:.2e}, worst {np.abs(e16).max():.2e}")
     assert gap > 5e-5, gap                                       # the roundings are visible
-    assert rms16 < 1e-4 and np.abs(e16).max() < 4e-4, (rms16, rms64, gap, np.abs(e16).max())
+    assert rms16 < 1.6e-4 and np.abs(e16).max() < 5e-4, (rms16, rms64, gap, np.abs(e16).max())
     assert rms16 < 0.85 * rms64, (rms16, rms64, gap)             # its own oracle, not the exact one
     resolved = margin16 > 1e-3 * scale
     assert resolved.sum() >= B * n_new // 2, resolved.sum()
@@ -765,9 +767,9 @@ def test_mode_2_decoder_rounds_the_layernorm_outputs_as_ggml_does(tiny, model):
     best = {True: np.zeros((B, n_new)), False: np.zeros((B, n_new))}
     margin = np.zeros((B, n_new))
     ids = np.zeros((B, n_new), np.int64)
-    for ln16 in (True, False):
+    for ln16 in (True, False):          # True: mode 2's oracle; False: mode 1's (f16 LayerNorm outputs too, since round 5: only the attentions differ)
         for b in range(B):
-            dc = WO.DecoderCache(W, hp, enc[b], f16=True, ln16=ln16, attn16=ln16)
+            dc = WO.DecoderCache(W, hp, enc[b], f16=True, ln16=True, attn16=ln16)
             for t in prompt[:-1]:
                 dc.step(t)
             tok = prompt[-1]
@@ -787,7 +789,11 @@ def test_mode_2_decoder_rounds_the_layernorm_outputs_as_ggml_does(tiny, model):
     print(f"mode-2 decoder: rms to the ln16 oracle {rms2:.2e}, to the mode-1 oracle {rms1:.2e}, oracle gap {gap:.2e}, worst {np.abs(e2).max():.2e}")
     assert gap > 3e-5, gap                                       # the extra roundings are visible
     assert rms2 < 1.6e-4 and np.abs(e2).max() < 5e-4, (rms2, rms1, gap, np.abs(e2).max())
-    assert rms2 < 0.85 * rms1, (rms2, rms1, gap)                 # its own oracle, not mode 1's
+    # (rounds 3 - 4 also asked for "distinctly nearer to this oracle than to mode 1's": then the two oracles differed by the
+    # LayerNorm roundings too, 2.1e-4 apart.  Since round 5 mode 1 rounds its LayerNorm outputs as well, the oracles are
+    # 1.07e-4 apart -- the attentions' roundings alone, below the 1.2 - 1.4e-4 either mode sits from its own oracle -- and
+    # the picked logits cannot tell them apart: measured 1.38e-4 to this oracle, 1.40e-4 to mode 1's.)
+    assert rms2 < 1.05 * rms1, (rms2, rms1, gap)
     resolved = margin > 1e-3 * scale
     assert resolved.sum() >= B * n_new // 2, resolved.sum()
     assert np.array_equal(toks[resolved], ids[resolved])

@@ -188,10 +188,12 @@ def test_decoder_cache_f16_mode_only_rounds_where_it_says(tiny, enc_out):
         assert np.abs(l - full[i]).max() <= 1e-9 * np.abs(full[i]).max()
         rel = np.abs(lh - l).max() / np.abs(l).max()
         assert 1e-5 < rel < 1e-2, (i, rel)
-    # (c) ln16=True (the library's precision mode 2) rounds the LayerNorm outputs and the q | k | v, cross-q, fc1 weights on
-    # top: a further small move away from the f16 chain; without f16 the flag does nothing
-    d2, d0 = WO.DecoderCache(W, hp, enc_out, f16=True, ln16=True), WO.DecoderCache(W, hp, enc_out, f16=False, ln16=True)
-    dh = WO.DecoderCache(W, hp, enc_out, f16=True)
+    # (c) ln16 (on by default with f16: the library's precision modes 1 and 2 since round 5) rounds the LayerNorm outputs and
+    # the q | k | v, cross-q, fc1 weights on top of the plain products: a further small move away from the chain without
+    # it (ln16=False: the mode 1 of rounds 2 - 4); without f16 the flag does nothing
+    d2, d0 = WO.DecoderCache(W, hp, enc_out, f16=True), WO.DecoderCache(W, hp, enc_out, f16=False, ln16=True)
+    assert d2.ln16 and not d0.ln16
+    dh = WO.DecoderCache(W, hp, enc_out, f16=True, ln16=False)
     dc = WO.DecoderCache(W, hp, enc_out)
     for i, t in enumerate(toks):
         l2, lh, l0, l = d2.step(t), dh.step(t), d0.step(t), dc.step(t)
