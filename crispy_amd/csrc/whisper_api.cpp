@@ -123,8 +123,7 @@ struct crispy_asr {
   // self-attention kernel of mode 1 is baked into the capture).  A transcribe call with previous-text conditioning
   // alternates between classes from window to window (bare prompt, then prompt + past): with a single slot every window
   // re-instantiated the graph (1 - 2 ms each).
-  hipGraphExec_t dec_graphs[3] = {nullptr, nullptr, nullptr};
-  int dec_graph_batch[3] = {0, 0, 0};
+
   int dec_max_keys = 0;                      // positions the current decode call can reach (prompt + new tokens)
   // timestamp-mode decoding (whisper.cpp no_timestamps = false)
   TsState* d_ts_state = nullptr;             // [dcap_batch]
@@ -139,9 +138,11 @@ struct crispy_asr {
   // clips, sampling passes over the failed ones x best_of, windows with and without the text so far -- and with one
   // slot per class every switch re-captured the step (1 - 2 ms each).
   struct TsKey {
-    int kc, sampling, rows, xgroup, rules;
+    int kc, sampling, rows, xgroup, rules;     // sampling: 0 greedy pick under the timestamp rules, 1 sampling pick, 2 plain arg-max (no timestamps)
     const unsigned char* mask;
+    int steps;                                 // generated tokens per replay
     bool operator<(const TsKey& o) const {
+      if (steps != o.steps) return steps < o.steps;
       if (kc != o.kc) return kc < o.kc;
       if (sampling != o.sampling) return sampling < o.sampling;
       if (rows != o.rows) return rows < o.rows;
@@ -160,8 +161,6 @@ struct crispy_asr {
   int cur_xgroup = 1;                        // rows per audio clip while a window decode is running: the best-of decoders of a clip are
                                              // rows of their own (own self K|V cache) over ONE cross K|V (decode_ts)
   void drop_graphs() {
-    for (int c = 0; c < 3; ++c)
-      if (dec_graphs[c]) { (void)hipGraphExecDestroy(dec_graphs[c]); dec_graphs[c] = nullptr; dec_graph_batch[c] = 0; }
     for (auto& kv : ts_graphs)
       if (kv.second) (void)hipGraphExecDestroy(kv.second);
     ts_graphs.clear();
@@ -1446,6 +1445,60 @@ TsPickArgs ts_args(crispy_asr* h, int rules, const unsigned char* mask, const un
   return a;
 }
 
+// Tokens per graph replay: a replay costs 8 - 16 us of host / dispatch time whatever it holds (MI355X_MICROARCH.md,
+// graph-replay-floor; measured here 7.8 us between the last kernel of a step and the first of the next), so a decode
+// loop replays FOUR captured steps at a time and the odd ones singly.  The device counters carry the position from step
+// to step inside a replay exactly as between replays.
+constexpr int kStepsPerReplay = 4;
+
+// The captured step(s) for `key`: `body()` enqueues ONE generated token on h->stream (pick + decoder step).
+template <class Body>
+int step_graph(crispy_asr* h, crispy_asr::TsKey key, Body body, hipGraphExec_t* out) {
+  auto slot = h->ts_graphs.find(key);
+  if (slot == h->ts_graphs.end()) {
+    if (h->ts_graphs.size() >= 48) h->drop_graphs();      // a bound, not a policy: nothing real alternates between this many shapes
+    hipStream_t s = h->stream;
+    hipGraphExec_t exec = nullptr;
+    hipGraph_t graph = nullptr;
+    HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    int rc = CRISPY_OK;
+    for (int i = 0; i < key.steps && rc == CRISPY_OK; ++i) rc = body();
+    const hipError_t ce = hipStreamEndCapture(s, &graph);
+    if (rc != CRISPY_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    HIP_TRY(ce);
+    const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    HIP_TRY(ie);
+    slot = h->ts_graphs.emplace(key, exec).first;
+  }
+  *out = slot->second;
+  return CRISPY_OK;
+}
+
+// Replays `n_steps` generated tokens (kStepsPerReplay at a time, then singly); every 8 tokens it asks whether every row
+// is done (h->d_done_count >= rows) and stops early.  Returns the steps run in *steps_run.
+template <class Body>
+int run_steps(crispy_asr* h, crispy_asr::TsKey key, int rows, int n_steps, Body body, int* steps_run) {
+  hipStream_t s = h->stream;
+  int done = 0, ran = 0;
+  while (ran < n_steps) {
+    key.steps = n_steps - ran >= kStepsPerReplay ? kStepsPerReplay : 1;
+    hipGraphExec_t g = nullptr;
+    const int rc = step_graph(h, key, body, &g);
+    if (rc != CRISPY_OK) return rc;
+    HIP_TRY(hipGraphLaunch(g, s));
+    const int before = ran;
+    ran += key.steps;
+    if (ran / 8 != before / 8) {       // every 8 tokens: has every row ended?  (nothing behind its end is returned)
+      HIP_TRY(hipMemcpyAsync(&done, h->d_done_count, sizeof(int), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      if (done >= rows) break;
+    }
+  }
+  *steps_run = ran;
+  return CRISPY_OK;
+}
+
 // One decoding pass over one window per row under the timestamp rules (oracle/whisper_oracle.py: decode_window /
 // decode_temperature).  Every row has its own prompt (previous-text conditioning makes them differ in length: they are
 // left-padded to the longest and decoded in lock step, each row attending from its own first cache row on -- the
@@ -1506,39 +1559,16 @@ int decode_ts(crispy_asr* h, const float* d_enc, int batch, const std::vector<st
   pa.u_all = u ? h->d_u_all : nullptr;
   int steps_run = 1;      // picks made = decoder steps replayed + the final pick
   if (max_new > 1) {
-    const crispy_asr::TsKey key{h->dec_max_keys <= 128 ? 0 : h->dec_max_keys <= 256 ? 1 : 2, u ? 1 : 0, batch, xgroup, rules, mask};
-    auto slot = h->ts_graphs.find(key);
-    if (slot == h->ts_graphs.end()) {
-      if (h->ts_graphs.size() >= 32) {          // a bound, not a policy: nothing real alternates between this many shapes
-        for (auto& kv : h->ts_graphs) (void)hipGraphExecDestroy(kv.second);
-        h->ts_graphs.clear();
-      }
-      hipGraphExec_t exec = nullptr;
-      hipGraph_t graph = nullptr;
-      HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-      TsPickArgs pf = pa;                     // the pick of a replay also embeds its token and moves the counters on
-      pf.fuse = step_fuse(h);
-      hipError_t pe = ts_pick(pf, batch, s);
-      rc = pe == hipSuccess ? decoder_step(h, batch, 0, true, true, s, true) : CRISPY_OK;
-      const hipError_t ce = hipStreamEndCapture(s, &graph);
-      if (rc != CRISPY_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-      HIP_TRY(pe);
-      HIP_TRY(ce);
-      const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-      (void)hipGraphDestroy(graph);
-      HIP_TRY(ie);
-      slot = h->ts_graphs.emplace(key, exec).first;
-    }
-    int done = 0;
-    for (int i = 0; i + 1 < max_new; ++i) {
-      HIP_TRY(hipGraphLaunch(slot->second, s));
-      ++steps_run;
-      if ((i & 7) == 7) {   // every 8 tokens: have all windows ended?
-        HIP_TRY(hipMemcpyAsync(&done, h->d_done_count, sizeof(int), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        if (done >= batch) break;
-      }
-    }
+    const crispy_asr::TsKey key{h->dec_max_keys <= 128 ? 0 : h->dec_max_keys <= 256 ? 1 : 2, u ? 1 : 0, batch, xgroup, rules, mask, 1};
+    TsPickArgs pf = pa;                     // the pick of a replay also embeds its token and moves the counters on
+    pf.fuse = step_fuse(h);
+    int ran = 0;
+    rc = run_steps(h, key, batch, max_new - 1, [&]() -> int {
+      HIP_TRY(ts_pick(pf, batch, s));
+      return decoder_step(h, batch, 0, true, true, s, true);
+    }, &ran);
+    if (rc != CRISPY_OK) return rc;
+    steps_run += ran;
   }
   HIP_TRY(ts_pick(pa, batch, s));   // the last pick needs no further decoder step
   std::vector<int> all((size_t)steps_run * batch), tids((size_t)steps_run * batch);
@@ -1663,30 +1693,11 @@ int crispy_asr_decode_greedy_lang_device(crispy_asr* h, const float* d_enc, int 
   HIP_TRY(hipStreamSynchronize(s));
   int steps_run = 1;      // picks made: replayed decoder steps + the final pick
   if (max_new > 1) {
-    const int kc = h->dec_max_keys <= 128 ? 0 : h->dec_max_keys <= 256 ? 1 : 2;      // key class: its own graph slot
-    if (!h->dec_graphs[kc] || h->dec_graph_batch[kc] != batch) {
-      if (h->dec_graphs[kc]) { (void)hipGraphExecDestroy(h->dec_graphs[kc]); h->dec_graphs[kc] = nullptr; }
-      hipGraph_t graph = nullptr;
-      HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-      rc = generation_body(h, batch, s);
-      const hipError_t ce = hipStreamEndCapture(s, &graph);
-      if (rc != CRISPY_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-      HIP_TRY(ce);
-      const hipError_t ie = hipGraphInstantiate(&h->dec_graphs[kc], graph, nullptr, nullptr, 0);
-      (void)hipGraphDestroy(graph);
-      HIP_TRY(ie);
-      h->dec_graph_batch[kc] = batch;
-    }
-    int done = 0;
-    for (int i = 0; i + 1 < max_new; ++i) {
-      HIP_TRY(hipGraphLaunch(h->dec_graphs[kc], s));
-      ++steps_run;
-      if ((i & 7) == 7) {   // every 8 tokens: has every clip produced its EOT?  (nothing after it is returned)
-        HIP_TRY(hipMemcpyAsync(&done, h->d_done_count, sizeof(int), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        if (done >= batch) break;
-      }
-    }
+    const crispy_asr::TsKey key{h->dec_max_keys <= 128 ? 0 : h->dec_max_keys <= 256 ? 1 : 2, 2, batch, 1, 0, nullptr, 1};
+    int ran = 0;
+    rc = run_steps(h, key, batch, max_new - 1, [&]() -> int { return generation_body(h, batch, s); }, &ran);
+    if (rc != CRISPY_OK) return rc;
+    steps_run += ran;
   }
   // the last pick needs no further decoder step
   HIP_TRY(argmax_f32(h->d_logits, h->d_suppress, h->d_suppress_first, h->d_counters + 1, V, logits_ld(h), h->d_tok, h->d_tokens_all,

@@ -56,6 +56,16 @@ template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
 __device__ __forceinline__ float sum8(float v) { return dpp_add<0x141>(dpp_add<0x4E>(dpp_add<0xB1>(v))); }
 __device__ __forceinline__ float sum16(float v) { return dpp_add<0x140>(sum8(v)); }
 
+// Workgroup barrier for LDS traffic ONLY: __syncthreads() waits for every outstanding vector-memory operation first
+// (s_waitcnt vmcnt(0)), i.e. the first barrier of a kernel would wait for all the weights and keys requested at its top
+// and serialise exactly the overlap these kernels are built on (measured: a row's pass through the MLP block cost ~3 us
+// with the next row's residual stream "in flight").  Nothing in these kernels hands GLOBAL data from wave to wave.
+__device__ __forceinline__ void fd_bar() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // a load from a workgroup-uniform base (scalar registers) + a 32-bit byte offset per lane: one address register instead of
 // two per request -- these kernels keep up to 60 requests per lane in flight
 template <class T> __device__ __forceinline__ T ldu(const void* base, unsigned byte_off) {
@@ -65,45 +75,69 @@ template <class T> __device__ __forceinline__ T ldu(const void* base, unsigned b
 // The residual stream entering a block, and its LayerNorm as the f16 vector the products read:
 //   xs = x_in + bias + part[0] + part[1] + ... (this order), written to x_out by the row's first workgroup;
 //   xn = f16(LayerNorm(xs)) -- one wave, a lane holds columns lane + 64 q, two passes (layernorm_h_kernel's arithmetic).
+// RB rows per workgroup: thread tid holds column tid % D of rows tid / D, tid / D + S, ... (S = 1024 / D = 2 rows per pass).
 template <int D, int NP>
-struct FdInput {
-  float v, gm, bt, b, pv[NP > 0 ? NP : 1];
-  // the loads, issued FIRST in a kernel: they return first, and the LayerNorm runs while the weights are still arriving
-  __device__ __forceinline__ void request(const FusedIn& in, int rows, int row) {
+struct FdParams {          // what does not depend on the row: LayerNorm gamma | beta (staged in LDS), the bias
+  float gm, bt, b;
+  __device__ __forceinline__ void request(const FusedIn& in) {
+    const int col = threadIdx.x % D;
+    gm = in.ln_g[col];
+    bt = in.ln_b[col];
+    b = NP > 0 ? in.bias[col] : 0.f;
+  }
+  __device__ __forceinline__ void stage(float* gb) const {      // visible to the LayerNorm waves behind the first finish()'s barrier
     const int tid = threadIdx.x;
-    if (tid < D) {
-      v = ldu<float>(in.x_in + (long)row * D, 4u * tid);
-      gm = in.ln_g[tid];
-      bt = in.ln_b[tid];
-      if (NP > 0) {
-        b = in.bias[tid];
-        const float* prow = in.part + (long)row * D;
+    if (tid < D) { gb[tid] = gm; gb[D + tid] = bt; }
+  }
+};
+template <int D, int NP, int RB>
+struct FdInput {
+  static constexpr int S = FD_THREADS / D;
+  static constexpr int PASSES = (RB + S - 1) / S;
+  float v[PASSES], pv[PASSES][NP > 0 ? NP : 1];
+  // the loads, issued FIRST in a kernel: they return first, and the LayerNorm runs while the weights are still arriving
+  __device__ __forceinline__ void request(const FusedIn& in, int rows, int row0) {
+    const int tid = threadIdx.x, slot = tid / D, col = tid % D;
 #pragma unroll
-        for (int p = 0; p < NP; ++p) pv[p] = ldu<float>(prow, 4u * (unsigned)(p * rows * D + tid));
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int r = ps * S + slot;
+      if (slot < S && r < RB) {
+        const int row = min(row0 + r, rows - 1);                 // past the last row: a valid row again, never stored
+        v[ps] = ldu<float>(in.x_in + (long)row * D, 4u * col);
+        if (NP > 0) {
+          const float* prow = in.part + (long)row * D;
+#pragma unroll
+          for (int p = 0; p < NP; ++p) pv[ps][p] = ldu<float>(prow, 4u * (unsigned)(p * rows * D + col));
+        }
       }
     }
   }
-  __device__ __forceinline__ void finish(const FusedIn& in, int row, bool writer, float* xs, _Float16* xn) {
-    const int tid = threadIdx.x;
+  // xs [RB][D] f32, gb [2][D] (FdParams::stage), xn [RB][D] f16.  Row r's LayerNorm is wave r's.
+  __device__ __forceinline__ void finish(const FusedIn& in, float bias, int rows, int row0, bool writer, float* xs, const float* gb,
+                                         _Float16* xn) {
+    const int tid = threadIdx.x, slot = tid / D, col = tid % D;
     constexpr int PER = D / 64;
-    float* gb = xs + D;                      // gamma | beta, staged by the threads that hold a column (2 registers, not 2 PER)
-    if (tid < D) {
-      float x = v;
-      if (NP > 0) {
-        x += b;
 #pragma unroll
-        for (int p = 0; p < NP; ++p) x += pv[p];
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int r = ps * S + slot;
+      if (slot < S && r < RB) {
+        float x = v[ps];
+        if (NP > 0) {
+          x += bias;
+#pragma unroll
+          for (int p = 0; p < NP; ++p) x += pv[ps][p];
+        }
+        xs[r * D + col] = x;
+        if (writer && row0 + r < rows) in.x_out[(long)(row0 + r) * D + col] = x;
       }
-      xs[tid] = x;
-      gb[tid] = gm;
-      gb[D + tid] = bt;
-      if (writer) in.x_out[(long)row * D + tid] = x;
     }
-    __syncthreads();
-    if (tid < 64) {
+    fd_bar();
+    const int wave = tid >> 6, lane = tid & 63;
+    if (wave < RB) {
+      const float* xr = xs + wave * D;
       float e[PER], s = 0.f;
 #pragma unroll
-      for (int q = 0; q < PER; ++q) { e[q] = xs[tid + 64 * q]; s += e[q]; }
+      for (int q = 0; q < PER; ++q) { e[q] = xr[lane + 64 * q]; s += e[q]; }
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
       const float mean = s / (float)D;
@@ -114,9 +148,9 @@ struct FdInput {
       for (int off = 32; off > 0; off >>= 1) s2 += __shfl_xor(s2, off, 64);
       const float rstd = 1.f / sqrtf(s2 / (float)D + 1e-5f);
 #pragma unroll
-      for (int q = 0; q < PER; ++q) xn[tid + 64 * q] = (_Float16)((e[q] - mean) * rstd * gb[tid + 64 * q] + gb[D + tid + 64 * q]);
+      for (int q = 0; q < PER; ++q) xn[wave * D + lane + 64 * q] = (_Float16)((e[q] - mean) * rstd * gb[lane + 64 * q] + gb[D + lane + 64 * q]);
     }
-    __syncthreads();
+    fd_bar();
   }
 };
 
@@ -132,7 +166,7 @@ struct HeadOut {
     for (int p = 0; p < NPASS; ++p)
       w[p] = ldu<half8>(W + col0, 2u * (unsigned)((128 * p + 8 * wave + (lane >> 3)) * D + 8 * (lane & 7)));
   }
-  __device__ __forceinline__ void finish(const _Float16* att_h, float* po) const {
+  __device__ __forceinline__ void finish(const _Float16* att_h, float* po) const {      // att_h [64], po [D]: one row
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const half8 a = *reinterpret_cast<const half8*>(att_h + 8 * (lane & 7));
 #pragma unroll
@@ -193,7 +227,7 @@ __device__ __forceinline__ void fd_attend(const half8 (&kr)[SLOTS], half8 (&vr)[
   float inv16 = 0.f;
   if (attn16) {                 // the soft-max in full, normalised, THEN rounded (ggml's P.V operand): needs the row's maximum and sum first
     if (lane == 0) part_m[wave] = mloc;
-    __syncthreads();
+    fd_bar();
     float m = part_m[0];
 #pragma unroll
     for (int w = 1; w < FD_WAVES; ++w) m = fmaxf(m, part_m[w]);
@@ -204,12 +238,12 @@ __device__ __forceinline__ void fd_attend(const half8 (&kr)[SLOTS], half8 (&vr)[
 #pragma unroll
     for (int off = 8; off <= 32; off <<= 1) ls += __shfl_xor(ls, off, 64);
     if (lane == 0) part_l[wave] = ls;
-    __syncthreads();
+    fd_bar();
     float l = 0.f;
 #pragma unroll
     for (int w = 0; w < FD_WAVES; ++w) l += part_l[w];
     inv16 = 1.f / l;
-    __syncthreads();
+    fd_bar();
   }
 #pragma unroll
   for (int i = 0; i < SLOTS; ++i) {
@@ -231,7 +265,7 @@ __device__ __forceinline__ void fd_attend(const half8 (&kr)[SLOTS], half8 (&vr)[
     *reinterpret_cast<float4*>(&part_o[wave][8 * c + 4]) = make_float4(acc[4], acc[5], acc[6], acc[7]);
   }
   if (lane == 0) { part_m[wave] = mloc; part_l[wave] = lsum; }
-  __syncthreads();
+  fd_bar();
   if (wave == 0) {
     float m = part_m[0];
 #pragma unroll
@@ -245,53 +279,65 @@ __device__ __forceinline__ void fd_attend(const half8 (&kr)[SLOTS], half8 (&vr)[
     }
     att_h[lane] = (_Float16)(attn16 ? o : o / l);
   }
-  __syncthreads();
+  fd_bar();
 }
 
-template <int D>
-__device__ __forceinline__ void fd_store_partial(const float* po, float* part_out, int rows, int row, int slice) {
-  const int tid = threadIdx.x;
-  if (tid < D / 4)
-    *reinterpret_cast<float4*>(part_out + ((long)slice * rows + row) * D + 4 * tid) = *reinterpret_cast<const float4*>(po + 4 * tid);
+// po [RB][D] -> part_out[slice][row0 + r][:]
+template <int D, int RB>
+__device__ __forceinline__ void fd_store_partial(const float* po, float* part_out, int rows, int row0, int slice) {
+  const int tid = threadIdx.x, r = tid / (D / 4), q = tid % (D / 4);
+  if (r < RB && row0 + r < rows)
+    *reinterpret_cast<float4*>(part_out + ((long)slice * rows + row0 + r) * D + 4 * q) = *reinterpret_cast<const float4*>(po + r * D + 4 * q);
 }
 
-// ---- self-attention block of one (row, head) ---------------------------------------------------------------------
-template <int D, int NP, int SLOTS>
+// ---- self-attention block: one head of RB rows -------------------------------------------------------------------------
+// RB rows per workgroup share the head's weights in registers and go through the block TOGETHER: one residual-stream
+// assembly, RB LayerNorms on RB waves, the q | k | v products of all rows off the same weight registers, then the
+// attentions one after the other and the out-projections together.  (A decode step of many rows would otherwise run
+// more workgroups than the chip holds at once -- ~100 registers x 1024 threads is a whole CU -- each re-reading the
+// weights.)  Every row's arithmetic is that of the RB = 1 form, operation for operation.
+template <int D, int NP, int SLOTS, int RB>
 __global__ __launch_bounds__(FD_THREADS) void fused_self_kernel(FusedSelfArgs a) {
   constexpr int PPL = D / 128;              // 16-byte pieces per lane of a K = D weight row (16 lanes per row)
-  __shared__ __attribute__((aligned(16))) float xs[3 * D];      // residual stream | gamma | beta
-  __shared__ __attribute__((aligned(16))) _Float16 xn[D];
-  __shared__ __attribute__((aligned(16))) float q_s[64];
-  __shared__ __attribute__((aligned(16))) _Float16 kv_new[128];       // k | v of this position, as the cache holds them
+  __shared__ __attribute__((aligned(16))) float xs[RB * D];
+  __shared__ __attribute__((aligned(16))) float gb[2 * D];      // LayerNorm gamma | beta
+  __shared__ __attribute__((aligned(16))) _Float16 xn[RB * D];
+  __shared__ __attribute__((aligned(16))) float q_s[RB][64];
+  __shared__ __attribute__((aligned(16))) _Float16 kv_new[RB][128];       // k | v of this position, as the cache holds them
   __shared__ __attribute__((aligned(16))) float part_o[FD_WAVES][64];
   __shared__ float part_m[FD_WAVES], part_l[FD_WAVES];
-  __shared__ __attribute__((aligned(16))) _Float16 att_h[64];
-  __shared__ __attribute__((aligned(16))) float po[D];
+  __shared__ __attribute__((aligned(16))) _Float16 att_h[RB][64];
+  __shared__ __attribute__((aligned(16))) float po[RB * D];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int h = blockIdx.x, row = blockIdx.y;
+  const int h = blockIdx.x, row0 = blockIdx.y * RB;
   const int pos = *a.pos_dev;                                          // cache row of this step's token
-  const int k_off = a.key_off ? a.key_off[row] : 0;                    // left-padded prompts: the clip's first cache row
-  const int n_keys = pos + 1 - k_off;                                  // keys the row attends to, its own included (>= 1 in a generated step)
+  const int c8 = lane & 7, r8 = lane >> 3;
   // (1) everything this workgroup will read, requested before anything is waited for.  The cache: keys k_off .. pos - 1;
   // slots past them (and the new key, which no cache row holds yet) take the new k | v from LDS below.
-  FdInput<D, NP> fin;
-  fin.request(a.in, a.rows, row);
-  _Float16* cache = a.kv + (long)row * a.kv_row_stride;
-  const int c8 = lane & 7, r8 = lane >> 3;
-  const int per = (max(n_keys, 1) + FD_WAVES - 1) / FD_WAVES;
-  const int k_lo = wave * per, k_hi = min(n_keys, k_lo + per);
-  const int k_cached = max(n_keys - 2, 0);                             // last key that is in the cache (clamp target)
-  half8 kr[SLOTS], vr[SLOTS];
-  {
+  FdParams<D, NP> par;
+  par.request(a.in);
+  FdInput<D, NP, RB> fin;
+  fin.request(a.in, a.rows, row0);
+  int n_keys[RB], k_lo[RB], k_hi[RB];
+  half8 kr[RB][SLOTS], vr[RB][SLOTS];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int row = min(row0 + rb, a.rows - 1);
+    const int k_off = a.key_off ? a.key_off[row] : 0;                  // left-padded prompts: the clip's first cache row
+    n_keys[rb] = pos + 1 - k_off;                                      // keys the row attends to, its own included (>= 1 in a generated step)
+    const int per = (max(n_keys[rb], 1) + FD_WAVES - 1) / FD_WAVES;
+    k_lo[rb] = wave * per;
+    k_hi[rb] = min(n_keys[rb], k_lo[rb] + per);
+    const int k_cached = max(n_keys[rb] - 2, 0);                       // last key that is in the cache (clamp target)
     // a uniform base (scalar registers) + one 32-bit byte offset per lane and slot, shared by the key and its value
-    const char* Kb = reinterpret_cast<const char*>(cache + (long)k_off * (2 * D) + h * 64);
+    const char* Kb = reinterpret_cast<const char*>(a.kv + (long)row * a.kv_row_stride + (long)k_off * (2 * D) + h * 64);
     unsigned off[SLOTS];
 #pragma unroll
-    for (int i = 0; i < SLOTS; ++i) off[i] = (unsigned)((min(k_lo + 8 * i + r8, k_cached) * (2 * D) + 8 * c8) * 2);
+    for (int i = 0; i < SLOTS; ++i) off[i] = (unsigned)((min(k_lo[rb] + 8 * i + r8, k_cached) * (2 * D) + 8 * c8) * 2);
 #pragma unroll
-    for (int i = 0; i < SLOTS; ++i) kr[i] = *reinterpret_cast<const half8*>(Kb + off[i]);
+    for (int i = 0; i < SLOTS; ++i) kr[rb][i] = *reinterpret_cast<const half8*>(Kb + off[i]);
 #pragma unroll
-    for (int i = 0; i < SLOTS; ++i) vr[i] = *reinterpret_cast<const half8*>(Kb + 2 * D + off[i]);
+    for (int i = 0; i < SLOTS; ++i) vr[rb][i] = *reinterpret_cast<const half8*>(Kb + 2 * D + off[i]);
   }
   // q | k | v rows of this head: pass p = q, k, v; 4 rows per wave and pass, 16 lanes per row
   const int g = lane >> 4, c = lane & 15;
@@ -307,13 +353,15 @@ __global__ __launch_bounds__(FD_THREADS) void fused_self_kernel(FusedSelfArgs a)
 #pragma unroll
   for (int p = 0; p < 3; ++p) b3[p] = a.bqkv[p * D + h * 64 + jrow];
   __builtin_amdgcn_sched_barrier(0);
-  // (2) residual stream + LayerNorm
-  fin.finish(a.in, row, h == 0, xs, xn);
-  // (3) q | k | v of the head
-  {
+  // (2) residual stream + LayerNorm of every row
+  par.stage(gb);
+  fin.finish(a.in, par.b, a.rows, row0, h == 0, xs, gb, xn);
+  // (3) q | k | v of the head, every row
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
     half8 xp[PPL];
 #pragma unroll
-    for (int j = 0; j < PPL; ++j) xp[j] = *reinterpret_cast<const half8*>(xn + 8 * c + 128 * j);
+    for (int j = 0; j < PPL; ++j) xp[j] = *reinterpret_cast<const half8*>(xn + rb * D + 8 * c + 128 * j);
     float acc[3];
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
@@ -323,34 +371,39 @@ __global__ __launch_bounds__(FD_THREADS) void fused_self_kernel(FusedSelfArgs a)
       acc[p] = sum16(v) + b3[p];
     }
     if (c == 0) {
-      q_s[jrow] = acc[0];
-      kv_new[jrow] = (_Float16)acc[1];
-      kv_new[64 + jrow] = (_Float16)acc[2];
+      q_s[rb][jrow] = acc[0];
+      kv_new[rb][jrow] = (_Float16)acc[1];
+      kv_new[rb][64 + jrow] = (_Float16)acc[2];
     }
   }
   HeadOut<D> ho;
-  ho.request(a.wo, h * 64);                                            // in flight during the attention
-  __syncthreads();
-  // the cache row of this position: 8 + 8 sixteen-byte pieces
-  if (tid < 16) {
-    const half8 v = *reinterpret_cast<const half8*>(kv_new + 8 * tid);
-    *reinterpret_cast<half8*>(cache + (long)pos * (2 * D) + (tid < 8 ? 0 : D - 64) + h * 64 + 8 * tid) = v;
-  }
-  // (4) attention: slots at or past the new key read it from LDS (finite values; past the last key the weight is zero)
-  {
-    const half8 kn = *reinterpret_cast<const half8*>(kv_new + 8 * c8), vn = *reinterpret_cast<const half8*>(kv_new + 64 + 8 * c8);
-#pragma unroll
-    for (int i = 0; i < SLOTS; ++i) {
-      const bool from_cache = k_lo + 8 * i + r8 < n_keys - 1;
-      kr[i] = from_cache ? kr[i] : kn;
-      vr[i] = from_cache ? vr[i] : vn;
+  ho.request(a.wo, h * 64);                                            // in flight during the attention, in the registers the q | k | v weights leave
+  fd_bar();
+  // the cache rows of this position: 8 + 8 sixteen-byte pieces per row
+  if (tid < 16 * RB) {
+    const int rb = tid >> 4, t = tid & 15;
+    if (row0 + rb < a.rows) {
+      const half8 v = *reinterpret_cast<const half8*>(&kv_new[rb][8 * t]);
+      *reinterpret_cast<half8*>(a.kv + (long)(row0 + rb) * a.kv_row_stride + (long)pos * (2 * D) + (t < 8 ? 0 : D - 64) + h * 64 + 8 * t) = v;
     }
   }
-  fd_attend<SLOTS>(kr, vr, q_s, k_lo, k_hi, a.attn16, part_o, part_m, part_l, att_h, [] {}, [] {});
-  // (5) this head's share of the output projection
-  ho.finish(att_h, po);
-  __syncthreads();
-  fd_store_partial<D>(po, a.part_out, a.rows, row, h);
+  // (4) attention, row after row: slots at or past the new key read it from LDS (finite values; past the last key the weight is zero)
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const half8 kn = *reinterpret_cast<const half8*>(&kv_new[rb][8 * c8]), vn = *reinterpret_cast<const half8*>(&kv_new[rb][64 + 8 * c8]);
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+      const bool from_cache = k_lo[rb] + 8 * i + r8 < n_keys[rb] - 1;
+      kr[rb][i] = from_cache ? kr[rb][i] : kn;
+      vr[rb][i] = from_cache ? vr[rb][i] : vn;
+    }
+    fd_attend<SLOTS>(kr[rb], vr[rb], q_s[rb], k_lo[rb], k_hi[rb], a.attn16, part_o, part_m, part_l, att_h[rb], [] {}, [] {});
+  }
+  // (5) this head's share of the output projection, every row
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) ho.finish(att_h[rb], po + rb * D);
+  fd_bar();
+  fd_store_partial<D, RB>(po, a.part_out, a.rows, row0, h);
 }
 
 // ---- cross-attention block of one (row, head) ----------------------------------------------------------------------
@@ -358,7 +411,8 @@ constexpr int FX_SLOTS = 12;                // 16 waves x 12 slots x 8 keys >= 1
 template <int D, int NP, bool STREAM_KV>
 __global__ __launch_bounds__(FD_THREADS) void fused_cross_kernel(FusedCrossArgs a) {
   constexpr int PPL = D / 128;
-  __shared__ __attribute__((aligned(16))) float xs[3 * D];      // residual stream | gamma | beta
+  __shared__ __attribute__((aligned(16))) float xs[D];
+  __shared__ __attribute__((aligned(16))) float gb[2 * D];      // LayerNorm gamma | beta
   __shared__ __attribute__((aligned(16))) _Float16 xn[D];
   __shared__ __attribute__((aligned(16))) float q_s[64];
   __shared__ __attribute__((aligned(16))) float part_o[FD_WAVES][64];
@@ -367,7 +421,9 @@ __global__ __launch_bounds__(FD_THREADS) void fused_cross_kernel(FusedCrossArgs 
   __shared__ __attribute__((aligned(16))) float po[D];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int h = blockIdx.x, row = blockIdx.y;
-  FdInput<D, NP> fin;
+  FdParams<D, NP> par;
+  par.request(a.in);
+  FdInput<D, NP, 1> fin;
   fin.request(a.in, a.rows, row);
   const int clip = row / a.group;                                      // rows of one clip (best-of decoders) share its K | V
   const int Tn = a.n_keys;
@@ -399,7 +455,8 @@ __global__ __launch_bounds__(FD_THREADS) void fused_cross_kernel(FusedCrossArgs 
   }
   const float bq = a.bq[h * 64 + jrow];
   __builtin_amdgcn_sched_barrier(0);
-  fin.finish(a.in, row, h == 0, xs, xn);
+  par.stage(gb);
+  fin.finish(a.in, par.b, a.rows, row, h == 0, xs, gb, xn);
   {
     float v = 0.f;
 #pragma unroll
@@ -407,7 +464,7 @@ __global__ __launch_bounds__(FD_THREADS) void fused_cross_kernel(FusedCrossArgs 
     v = sum16(v) + bq;
     if (c == 0) q_s[jrow] = v;
   }
-  __syncthreads();
+  fd_bar();
   HeadOut<D> ho;
   fd_attend<FX_SLOTS>(kr, vr, q_s, k_lo, k_hi, a.attn16, part_o, part_m, part_l, att_h,
                       [&] {
@@ -421,23 +478,27 @@ __global__ __launch_bounds__(FD_THREADS) void fused_cross_kernel(FusedCrossArgs 
                       },
                       [&] { ho.request(a.wo, h * 64); });
   ho.finish(att_h, po);
-  __syncthreads();
-  fd_store_partial<D>(po, a.part_out, a.rows, row, h);
+  fd_bar();
+  fd_store_partial<D, 1>(po, a.part_out, a.rows, row, h);
 }
 
-// ---- MLP block: 128 hidden units of one row ------------------------------------------------------------------------
-template <int D, int NP>
+// ---- MLP block: 128 hidden units of RB rows ---------------------------------------------------------------------------
+// RB rows share the chunk's weights in registers and go through the block together (see fused_self_kernel).
+template <int D, int NP, int RB>
 __global__ __launch_bounds__(FD_THREADS) void fused_mlp_kernel(FusedMlpArgs a) {
   constexpr int PPL = D / 128;
   constexpr int NP2 = D / 64;               // passes of 64 output rows over fc2's D rows
-  __shared__ __attribute__((aligned(16))) float xs[3 * D];      // residual stream | gamma | beta
-  __shared__ __attribute__((aligned(16))) _Float16 xn[D];
-  __shared__ __attribute__((aligned(16))) _Float16 hh[128];
-  __shared__ __attribute__((aligned(16))) float po[D];
+  __shared__ __attribute__((aligned(16))) float xs[RB * D];
+  __shared__ __attribute__((aligned(16))) float gb[2 * D];      // LayerNorm gamma | beta
+  __shared__ __attribute__((aligned(16))) _Float16 xn[RB * D];
+  __shared__ __attribute__((aligned(16))) _Float16 hh[RB][128];
+  __shared__ __attribute__((aligned(16))) float po[RB * D];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int ch = blockIdx.x, row = blockIdx.y;
-  FdInput<D, NP> fin;
-  fin.request(a.in, a.rows, row);
+  const int ch = blockIdx.x, row0 = blockIdx.y * RB;
+  FdParams<D, NP> par;
+  par.request(a.in);
+  FdInput<D, NP, RB> fin;
+  fin.request(a.in, a.rows, row0);
   const int g = lane >> 4, c = lane & 15;
   const int jrow = 4 * wave + g;
   half8 w1[2][PPL], w2[NP2];
@@ -453,54 +514,78 @@ __global__ __launch_bounds__(FD_THREADS) void fused_mlp_kernel(FusedMlpArgs a) {
   for (int p = 0; p < NP2; ++p)
     w2[p] = ldu<half8>(a.w2 + 128 * ch, 2u * (unsigned)((64 * p + jrow) * (4 * D) + 8 * c));
   __builtin_amdgcn_sched_barrier(0);
-  fin.finish(a.in, row, ch == 0, xs, xn);
-  {
+  par.stage(gb);
+  fin.finish(a.in, par.b, a.rows, row0, ch == 0, xs, gb, xn);
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
     half8 xp[PPL];
 #pragma unroll
-    for (int j = 0; j < PPL; ++j) xp[j] = *reinterpret_cast<const half8*>(xn + 8 * c + 128 * j);
+    for (int j = 0; j < PPL; ++j) xp[j] = *reinterpret_cast<const half8*>(xn + rb * D + 8 * c + 128 * j);
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       float v = 0.f;
 #pragma unroll
       for (int j = 0; j < PPL; ++j) v = dot8(w1[p][j], xp[j], v);
       v = sum16(v) + b1[p];
-      if (c == 0) hh[64 * p + jrow] = (_Float16)gelu_ggml(v);
+      if (c == 0) hh[rb][64 * p + jrow] = (_Float16)gelu_ggml(v);
     }
   }
-  __syncthreads();
-  {
-    const half8 hp = *reinterpret_cast<const half8*>(hh + 8 * c);
+  fd_bar();
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const half8 hp = *reinterpret_cast<const half8*>(&hh[rb][8 * c]);
 #pragma unroll
     for (int p = 0; p < NP2; ++p) {
       const float v = sum16(dot8(w2[p], hp, 0.f));
-      if (c == 0) po[64 * p + jrow] = v;
+      if (c == 0) po[rb * D + 64 * p + jrow] = v;
     }
   }
-  __syncthreads();
-  fd_store_partial<D>(po, a.part_out, a.rows, row, ch);
+  fd_bar();
+  fd_store_partial<D, RB>(po, a.part_out, a.rows, row0, ch);
 }
 
 // ---- the step's last block: residual stream complete, final LayerNorm as the f16 row the vocabulary projection reads ----
 template <int D, int NP>
-__global__ __launch_bounds__(512) void fused_finish_kernel(FusedFinishArgs a) {
-  __shared__ __attribute__((aligned(16))) float xs[3 * D];      // residual stream | gamma | beta
+__global__ __launch_bounds__(FD_THREADS) void fused_finish_kernel(FusedFinishArgs a) {
+  __shared__ __attribute__((aligned(16))) float xs[D];
+  __shared__ __attribute__((aligned(16))) float gb[2 * D];
   __shared__ __attribute__((aligned(16))) _Float16 xn[D];
   const int row = blockIdx.x;
-  FdInput<D, NP> fin;
+  FdParams<D, NP> par;
+  par.request(a.in);
+  FdInput<D, NP, 1> fin;
   fin.request(a.in, a.rows, row);
-  fin.finish(a.in, row, true, xs, xn);
+  par.stage(gb);
+  fin.finish(a.in, par.b, a.rows, row, true, xs, gb, xn);
   if (threadIdx.x < D / 8)
     *reinterpret_cast<half8*>(a.y + (long)row * D + 8 * threadIdx.x) = *reinterpret_cast<const half8*>(xn + 8 * threadIdx.x);
 }
 
-template <int D>
-hipError_t self_launch(const FusedSelfArgs& a, bool first, hipStream_t s) {
-  const dim3 grid(D / 64, a.rows), block(FD_THREADS);
+// Rows per workgroup: one while the launch stays near one workgroup per CU (256 of them), else two (self block; with
+// four key slots per wave and row there are no registers for a second row) or two / four / eight (MLP block).
+template <int D, int NP>
+hipError_t self_launch(const FusedSelfArgs& a, hipStream_t s) {
   const int slots = a.max_keys <= 128 ? 1 : a.max_keys <= 256 ? 2 : 4;
-#define FD_SELF(NP, SL) hipLaunchKernelGGL((fused_self_kernel<D, NP, SL>), grid, block, 0, s, a)
-  if (first) { if (slots == 1) FD_SELF(0, 1); else if (slots == 2) FD_SELF(0, 2); else FD_SELF(0, 4); }
-  else { if (slots == 1) FD_SELF(D / 32, 1); else if (slots == 2) FD_SELF(D / 32, 2); else FD_SELF(D / 32, 4); }
+  const bool two = slots <= 2 && (D / 64) * a.rows > 256 + 64;
+  const dim3 block(FD_THREADS), grid(D / 64, two ? (a.rows + 1) / 2 : a.rows);
+#define FD_SELF(SL, RB) hipLaunchKernelGGL((fused_self_kernel<D, NP, SL, RB>), grid, block, 0, s, a)
+  if (two) { if (slots == 1) FD_SELF(1, 2); else FD_SELF(2, 2); }
+  else { if (slots == 1) FD_SELF(1, 1); else if (slots == 2) FD_SELF(2, 1); else FD_SELF(4, 1); }
 #undef FD_SELF
+  return hipGetLastError();
+}
+template <int D>
+hipError_t mlp_launch(const FusedMlpArgs& a, hipStream_t s) {
+  const int per_row = D / 32;
+  int rb = 1;
+  while (rb < 8 && per_row * ((a.rows + rb - 1) / rb) > 256 + 64) rb *= 2;
+  const dim3 block(FD_THREADS), grid(per_row, (a.rows + rb - 1) / rb);
+  switch (rb) {
+    case 1: hipLaunchKernelGGL((fused_mlp_kernel<D, D / 64, 1>), grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((fused_mlp_kernel<D, D / 64, 2>), grid, block, 0, s, a); break;
+    case 4: hipLaunchKernelGGL((fused_mlp_kernel<D, D / 64, 4>), grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL((fused_mlp_kernel<D, D / 64, 8>), grid, block, 0, s, a); break;
+  }
   return hipGetLastError();
 }
 
@@ -513,8 +598,8 @@ bool fused_decode_supported(int D, int max_keys, int n_audio_ctx) {
 hipError_t fused_self(const FusedSelfArgs& a, bool first, hipStream_t s) {
   if (a.rows <= 0) return hipSuccess;
   switch (a.D) {
-    case 384: return self_launch<384>(a, first, s);
-    case 512: return self_launch<512>(a, first, s);
+    case 384: return first ? self_launch<384, 0>(a, s) : self_launch<384, 12>(a, s);
+    case 512: return first ? self_launch<512, 0>(a, s) : self_launch<512, 16>(a, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -536,16 +621,14 @@ hipError_t fused_cross(const FusedCrossArgs& a, hipStream_t s) {
 
 hipError_t fused_mlp(const FusedMlpArgs& a, hipStream_t s) {
   if (a.rows <= 0) return hipSuccess;
-  const dim3 grid(a.D / 32, a.rows), block(FD_THREADS);
-  if (a.D == 384) hipLaunchKernelGGL((fused_mlp_kernel<384, 6>), grid, block, 0, s, a);
-  else if (a.D == 512) hipLaunchKernelGGL((fused_mlp_kernel<512, 8>), grid, block, 0, s, a);
-  else return hipErrorInvalidValue;
-  return hipGetLastError();
+  if (a.D == 384) return mlp_launch<384>(a, s);
+  if (a.D == 512) return mlp_launch<512>(a, s);
+  return hipErrorInvalidValue;
 }
 
 hipError_t fused_finish(const FusedFinishArgs& a, hipStream_t s) {
   if (a.rows <= 0) return hipSuccess;
-  const dim3 grid(a.rows), block(512);
+  const dim3 grid(a.rows), block(FD_THREADS);
   if (a.D == 384) hipLaunchKernelGGL((fused_finish_kernel<384, 12>), grid, block, 0, s, a);
   else if (a.D == 512) hipLaunchKernelGGL((fused_finish_kernel<512, 16>), grid, block, 0, s, a);
   else return hipErrorInvalidValue;

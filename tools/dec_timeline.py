@@ -1,6 +1,6 @@
 """Developer tool: the kernels of the LAST decode step of a rocprofv3 kernel-trace CSV, in order, with start offsets and gaps."""
 import csv, glob, sys
-f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
+f = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[-1]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "vocab" in r["Kernel_Name"]]
