@@ -406,8 +406,10 @@ int crispy_asr_create(const crispy_asr_hparams* hp, const float* mel_filters, in
   if (!hp || !mel_filters) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_create: NULL argument");
   auto width_ok = [](int d) { return d == 384 || d == 512 || d == 768 || d == 1024 || d == 1280; };   // tiny ... large
   if (hp->n_audio_ctx != 1500 || !width_ok(hp->n_audio_state) || !width_ok(hp->n_text_state) ||
-      hp->n_audio_head * 64 != hp->n_audio_state || hp->n_text_head * 64 != hp->n_text_state ||
-      hp->n_audio_layer <= 0 || hp->n_text_layer <= 0 ||
+      // (divisions, not products: a hostile head count from a model file must not overflow -- found by the sanitizer
+      // harness, tests/test_host_sanitizers.py)
+      hp->n_audio_state % 64 != 0 || hp->n_audio_head != hp->n_audio_state / 64 || hp->n_text_head != hp->n_text_state / 64 ||
+      hp->n_audio_layer <= 0 || hp->n_audio_layer > 64 || hp->n_text_layer <= 0 || hp->n_text_layer > 64 ||
       hp->n_text_ctx <= 0 || hp->n_text_ctx > 448 || hp->n_vocab <= 0 || (hp->n_mels != 80 && hp->n_mels != 128) ||
       (hp->n_mels * 3) % 16)
     return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_create: unsupported hyper-parameters (widths 384/512/768/1024/1280, head dim 64, ctx 1500/<=448)");

@@ -71,7 +71,9 @@ def _mha(xq, xkv, W, prefix, n_head, causal=False):
 
 def encoder_forward(weights, hp, mel, upto_layer=None, dtype=np.float64):
     """mel: [n_mels, 3000] -> [1500, d] (float64; dtype=np.float32 is the single-precision CPU run that bench.py times
-    as the ASR cpu_baseline -- BLAS sgemm on the host cores -- never the parity oracle)."""
+    as the ASR cpu_baseline -- BLAS sgemm on the host cores -- and the oracle of the two largest catalog models in
+    tests/test_gpu_whisper.py::test_catalog_models_at_full_depth, where float64 costs 100 s of the GPU suite's time
+    limit and the single-precision rounding is two orders below the bar)."""
     W = _f64(weights, dtype)
     x = mel.astype(dtype)
     xp = np.pad(x, ((0, 0), (1, 1)))

@@ -235,6 +235,9 @@ def test_temperature_ladder_on_a_scripted_model(oracle, tmp_path_factory, mode):
     got = transcribe_batch(eng, [x[:16000 * 7], x, x[:16000 * 3]], language_token=sp["lang0"], timestamps=True, with_segments=True)
     assert got[1][:4] == (text, toks, sp["lang0"], segs) and got[1][4] == wins
     eng.close()
+    if mode == 1:
+        return        # the rest is decision logic that does not depend on the arithmetic: mode 0 runs it (the oracle's 1 300
+                      # float64 decoder steps of it are 25 s of a GPU suite with a time limit)
     # ... and a model that repeats itself whatever the prompt
     rows = script_rows(2, [BEG] + [REP] * 40 + [BEG + 100, BEG + 100, EOT])
     rows.update(script_rows(46, [BEG] + [REP] * 40 + [BEG + 100, BEG + 100, EOT]))      # window 2: 1 + 43 + 3 tokens of prompt

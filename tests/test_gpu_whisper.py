@@ -952,7 +952,10 @@ def test_catalog_models_at_full_depth(oracle, name):
     m = WhisperModel(hp, W)
     x = synth_audio.clip16k_np(77, 160000)
     enc = m.encode([x])[0]
-    ref = WO.encoder_forward(W, hp, oracle.oracle_logmel(x, whisper_mel_filters(hp.n_mels)))
+    # medium / large-v3: the oracle in single precision (its own rounding is ~1e-6 of the peak against a bar of 1e-4; in
+    # float64 these two encoders are 100 s of numpy on the GPU box's host cores, a sixth of the suite's time limit)
+    ref = WO.encoder_forward(W, hp, oracle.oracle_logmel(x, whisper_mel_filters(hp.n_mels)),
+                             dtype=np.float64 if name == "small" else np.float32).astype(np.float64)
     assert enc.shape == (1500, hp.n_audio_state)
     err = np.abs(enc - ref).max() / np.abs(ref).max()
     assert err <= 1e-4, (name, err)
