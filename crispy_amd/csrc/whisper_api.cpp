@@ -1053,10 +1053,15 @@ int decoder_logits(crispy_asr* h, int batch, hipStream_t s, const float* x = nul
   return CRISPY_OK;
 }
 
-// Rows of the biggest decode step the fused kernels take: the row range of the staged path's skinny projections, so that
-// ONE threshold separates "a row decodes to the same bits alone and in any batch" from the tiled path of larger batches
-// (crispy_amd/pipeline.py decodes in groups of <= 512 for that reason).
-constexpr int FUSED_MAX_ROWS = SKINNY_MAX_M;
+// Rows of the biggest decode step the fused kernels take.  One workgroup per (row pair, head) holds a head's weights in
+// its registers -- the right shape while the step is a chain of latencies (1 row: 0.105 vs 0.173 ms per token; 64 rows:
+// 0.236 vs 0.291), the wrong one once there are enough rows to feed the matrix cores: measured per position, fused /
+// staged, Whisper-tiny 128 rows 0.389 / 0.405 ms, 256 rows 0.708 / 0.664, 512 rows 1.330 / 1.175; Whisper-base 64 rows
+// 0.398 / 0.474, 128 rows 0.721 / 0.705, 512 rows 2.78 / 2.22.  So: up to 128 rows fused, above staged.  Consequence: a row
+// decodes to the same bits alone and in any batch of up to 128 rows, and to the same bits in any batch of 129 .. 512
+// rows; across the two ranges the bits may differ (the forms add a row's partial sums in different orders) while both
+// sit at the mode's bar from the oracle (tests/test_gpu_fused_decode.py).
+constexpr int FUSED_MAX_ROWS = 128;
 
 // CRISPY_ASR_DECODE=stages (test hook, include/crispy_hip.h): every decode step as one launch per stage.  Read at the start
 // of a decode call; a change drops the captured steps.
@@ -2397,8 +2402,8 @@ int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const si
         for (int j = 0; j < best_of; ++j) rngs[k].emplace_back((unsigned)j);
       const int n_init = (int)prompt.size();
       const size_t enc_clip = (size_t)h->hp.n_audio_ctx * h->hp.n_audio_state;
-      // rows of one fallback decode: whole clips x best_of
-      const int kLadderRows = 256;
+      // rows of one fallback decode: whole clips x best_of, within what the fused step kernels take
+      const int kLadderRows = FUSED_MAX_ROWS;
       // the decoder workspace for the widest pass of this call, taken once: growing it between the greedy pass and the
       // first fallback pass freed every buffer and dropped the captured steps
       if (temps.size() > 1 && best_of > 1) {
