@@ -402,6 +402,23 @@ def asr_leg(local_rank: int, clips: int = 64, new_tokens: int = 32, ggml_path: s
         out["what"] = ("crispy_asr_transcribe(h, pcm, n, opts = NULL): language detection, timestamp rules, seek loop, previous-text "
                        "conditioning, no-speech rule, temperature fallback; 28 s of audio from host memory")
         out["one_greedy_pass_per_window"] = timed(make_opts(timestamps=True, fallback=False))
+        # the same call for 64 clips at once, every window walking the whole ladder (random-init logits): since round 5 the
+        # fallback passes of ALL failed clips decode side by side, best_of rows per clip over one cross K|V (they used to run
+        # clip after clip: ~64 x the single-clip time by construction)
+        from crispy_amd.asr import transcribe_batch
+        clips = [np.ascontiguousarray(pcm[i % pcm.shape[0]].cpu().numpy()[:16000 * 28]) for i in range(64)]
+        eng = type("E", (), {"_h": model._h})()
+        transcribe_batch(eng, clips, timestamps=True)
+        ts = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            res = transcribe_batch(eng, clips, timestamps=True, with_segments=True)
+            ts.append(time.perf_counter() - t0)
+        out["batch_ladder"] = {"clips": 64, "ms": float(np.median(ts)) * 1e3, "single_clip_ms": out["ms"],
+                               "ratio_to_single_clip": float(np.median(ts)) * 1e3 / out["ms"],
+                               "windows": int(sum(len(r[4]) for r in res)),
+                               "windows_re_decoded": int(sum(sum(w["temperature"] > 0 for w in r[4]) for r in res)),
+                               "rtfx": 64 * 28.0 / float(np.median(ts))}
         return out
 
     times = measure()                      # default precision: f32 operands, the mode the oracle parity is pinned in

@@ -420,12 +420,20 @@ __global__ __launch_bounds__(FD_THREADS) void fused_cross_kernel(FusedCrossArgs 
   __shared__ __attribute__((aligned(16))) _Float16 att_h[64];
   __shared__ __attribute__((aligned(16))) float po[D];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int h = blockIdx.x, row = blockIdx.y;
+  // Workgroup -> (row, head).  The `group` rows of a clip (the best-of decoders of a fallback pass) read the SAME keys and
+  // values: they are placed on one XCD, one after the other in its dispatch order (workgroups are dealt round-robin over
+  // the 8 XCDs: MI355X_MICROARCH.md, observed -- for speed only), so that the clip's K | V of this head comes from HBM once
+  // and from that XCD's L2 for the other rows.  group == 1: the plain order (clip-major, head fastest).
+  constexpr int H = D / 64;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int gi = (slot / a.group) * 8 + xcd;                           // which (clip, head)
+  if (gi >= (a.rows / a.group) * H) return;                            // the padding of the last round of eight
+  const int clip = gi / H, h = gi % H;
+  const int row = clip * a.group + slot % a.group;
   FdParams<D, NP> par;
   par.request(a.in);
   FdInput<D, NP, 1> fin;
   fin.request(a.in, a.rows, row);
-  const int clip = row / a.group;                                      // rows of one clip (best-of decoders) share its K | V
   const int Tn = a.n_keys;
   const int c8 = lane & 7, r8 = lane >> 3;
   const int per = (Tn + FD_WAVES - 1) / FD_WAVES;
@@ -606,7 +614,9 @@ hipError_t fused_self(const FusedSelfArgs& a, bool first, hipStream_t s) {
 
 hipError_t fused_cross(const FusedCrossArgs& a, hipStream_t s) {
   if (a.rows <= 0) return hipSuccess;
-  const dim3 grid(a.D / 64, a.rows), block(FD_THREADS);
+  if (a.group < 1 || a.rows % a.group != 0) return hipErrorInvalidValue;
+  const int n_groups = (a.rows / a.group) * (a.D / 64);               // (clip, head) pairs; eight of them per round of the XCDs
+  const dim3 grid((unsigned)(8 * a.group * ((n_groups + 7) / 8))), block(FD_THREADS);
   if (a.D == 384) {
     if (a.stream_kv) hipLaunchKernelGGL((fused_cross_kernel<384, 6, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((fused_cross_kernel<384, 6, false>), grid, block, 0, s, a);
