@@ -91,7 +91,7 @@ pub struct crispy_asr_specials {
 }
 
 #[repr(C)]
-#[derive(Clone, Copy, Debug, Default)]
+#[derive(Clone, Copy, Debug)]
 pub struct crispy_asr_opts {
     pub language_token: c_int,
     pub translate: c_int,
@@ -106,6 +106,20 @@ pub struct crispy_asr_opts {
     pub logprob_thold: c_float,
     pub no_speech_thold: c_float,
     pub best_of: c_int,
+    /// ABI 3: whisper_full_params.suppress_nst, prompt_tokens / prompt_n_tokens, !no_context, and the beam width this
+    /// library does not implement (0 or 1).
+    pub suppress_nst: c_int,
+    pub initial_prompt: *const c_int,
+    pub n_initial_prompt: c_int,
+    pub carry_context: c_int,
+    pub beam_size: c_int,
+}
+impl Default for crispy_asr_opts {
+    /// All zero / NULL = `TranscribeOptions::default()` (a raw pointer has no derived Default).
+    fn default() -> Self {
+        // SAFETY: every field is an integer, a float or a raw pointer: the all-zero bit pattern is a valid value of each.
+        unsafe { std::mem::zeroed() }
+    }
 }
 
 #[repr(C)]
@@ -473,6 +487,9 @@ mod speech_model {
         // `TranscribeOptions { language: Option<String>, translate: bool }` [UPSTREAM-RECALL: transcribe-rs 0.3.11; the
         // reference only ever passes `TranscribeOptions::default()`, managers/transcription.rs:184,214 -- language unset,
         // transcribe]: a set language becomes its token, an unset one is detected per chunk, as whisper.cpp does.
+        // (What transcribe-rs may set on whisper.cpp beyond these two -- suppress_nst, an initial prompt, no_context = false --
+        // has a field in `crispy_asr_opts` since ABI 3; a host that knows the engine's settings passes them through
+        // `transcribe_chunk(audio, Some(&opts))`.  Beam search is not built: `beam_size` > 1 is refused.)
         fn transcribe(&mut self, audio: &[f32], options: &TranscribeOptions) -> Result<TranscriptionResult, Box<dyn std::error::Error + Send + Sync>> {
             let mut o = crispy_asr_opts::default();
             if let Some(code) = options.language.as_deref() {

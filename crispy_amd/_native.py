@@ -57,7 +57,9 @@ class AsrOpts(C.Structure):
     _fields_ = [("language_token", C.c_int), ("translate", C.c_int), ("max_new_tokens", C.c_int),
                 ("no_timestamps", C.c_int), ("no_prev_text", C.c_int),
                 ("temperature", C.c_float), ("temperature_inc", C.c_float), ("entropy_thold", C.c_float),
-                ("logprob_thold", C.c_float), ("no_speech_thold", C.c_float), ("best_of", C.c_int)]
+                ("logprob_thold", C.c_float), ("no_speech_thold", C.c_float), ("best_of", C.c_int),
+                ("suppress_nst", C.c_int), ("initial_prompt", C.POINTER(C.c_int)), ("n_initial_prompt", C.c_int),
+                ("carry_context", C.c_int), ("beam_size", C.c_int)]
 
 
 class AsrSegment(C.Structure):

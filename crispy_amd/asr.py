@@ -291,13 +291,24 @@ class WhisperEngine(WhisperModel):
 
 
 def make_opts(language_token=0, translate=False, max_new_tokens=0, timestamps=False, prev_text=True, fallback=True,
-              temperature=0.0, temperature_inc=0.0, entropy_thold=0.0, logprob_thold=0.0, no_speech_thold=0.0, best_of=0):
-    """`crispy_asr_opts`; the decision fields read "0 = whisper.cpp's default" (include/crispy_hip.h)."""
+              temperature=0.0, temperature_inc=0.0, entropy_thold=0.0, logprob_thold=0.0, no_speech_thold=0.0, best_of=0,
+              suppress_nst=False, initial_prompt=None, carry_context=False, beam_size=0):
+    """`crispy_asr_opts`; the decision fields read "0 = whisper.cpp's default" (include/crispy_hip.h).  The struct keeps a
+    reference to the initial-prompt array (`_keep`) for as long as it lives."""
     if not fallback and temperature_inc == 0.0:
         temperature_inc = -1.0
-    return N.AsrOpts(int(language_token), int(translate), int(max_new_tokens), 0 if timestamps else 1, 0 if prev_text else 1,
-                     float(temperature), float(temperature_inc), float(entropy_thold), float(logprob_thold),
-                     float(no_speech_thold), int(best_of))
+    o = N.AsrOpts(int(language_token), int(translate), int(max_new_tokens), 0 if timestamps else 1, 0 if prev_text else 1,
+                  float(temperature), float(temperature_inc), float(entropy_thold), float(logprob_thold),
+                  float(no_speech_thold), int(best_of))
+    o.suppress_nst = 1 if suppress_nst else 0
+    if initial_prompt is not None and len(initial_prompt):
+        arr = (C.c_int * len(initial_prompt))(*[int(t) for t in initial_prompt])
+        o._keep = arr
+        o.initial_prompt = C.cast(arr, C.POINTER(C.c_int))
+        o.n_initial_prompt = len(initial_prompt)
+    o.carry_context = 1 if carry_context else 0
+    o.beam_size = int(beam_size)
+    return o
 
 
 def _read_result(res) -> tuple:

@@ -133,6 +133,9 @@ struct crispy_asr {
   void* d_xkv_h = nullptr;                   // f16 copy of the cross K|V (precision mode 1)
   unsigned char* d_ts_mask = nullptr;        // [n_vocab] whisper.cpp's always-suppressed specials
   unsigned char* d_ts_mask_first = nullptr;  // ... plus suppress_blank (" " and EOT) at the first position
+  unsigned char* d_ts_mask_nst = nullptr;    // the two masks with whisper.cpp's non-speech tokens added (opts.suppress_nst; built on first use)
+  unsigned char* d_ts_mask_first_nst = nullptr;
+  std::vector<int> prompt_past;              // conditioning text the last single-chunk call ended with (opts.carry_context)
   // captured window-decode steps by what is baked into them: key class, kind of pick (greedy / sampling: different kernels),
   // rows, rows per clip, rules and mask.  A transcribe call alternates between several of them -- the greedy pass over all
   // clips, sampling passes over the failed ones x best_of, windows with and without the text so far -- and with one
@@ -458,6 +461,8 @@ void crispy_asr_free(crispy_asr* h) try {
   if (h->d_suppress_first) (void)hipFree(h->d_suppress_first);
   if (h->d_ts_mask) (void)hipFree(h->d_ts_mask);
   if (h->d_ts_mask_first) (void)hipFree(h->d_ts_mask_first);
+  if (h->d_ts_mask_nst) (void)hipFree(h->d_ts_mask_nst);
+  if (h->d_ts_mask_first_nst) (void)hipFree(h->d_ts_mask_first_nst);
   if (h->d_lang_mask) (void)hipFree(h->d_lang_mask);
   free_ws(h);
   free_dec_ws(h);
@@ -1954,6 +1959,45 @@ int build_ts_masks(crispy_asr* h) {
   return CRISPY_OK;
 }
 
+// whisper_full_params.suppress_nst [UPSTREAM-RECALL: whisper.cpp `non_speech_tokens` + whisper_process_logits]: every
+// string of the list, as it stands and with a leading space, that the vocabulary holds as ONE token; then " -" and " '"
+// ("allow hyphens and single quotes between words, but not at the beginning of a word").  Oracle: whisper_oracle.py
+// non_speech_token_ids.
+std::vector<int> non_speech_token_ids(const std::vector<std::string>& vocab) {
+  static const char* const kList[] = {
+      "\"", "#", "(", ")", "*", "+", "/", ":", ";", "<", "=", ">", "@", "[", "\\", "]", "^", "_", "`", "{", "|", "}", "~",
+      "\xe3\x80\x8c", "\xe3\x80\x8d", "\xe3\x80\x8e", "\xe3\x80\x8f",          // the four CJK corner brackets
+      "<<", ">>", "<<<", ">>>", "--", "---", "-(", "-[", "('", "(\"", "((", "))", "(((", ")))", "[[", "]]", "{{", "}}",
+      "\xe2\x99\xaa\xe2\x99\xaa", "\xe2\x99\xaa\xe2\x99\xaa\xe2\x99\xaa",      // two / three eighth notes
+      "\xe2\x99\xa9", "\xe2\x99\xaa", "\xe2\x99\xab", "\xe2\x99\xac", "\xe2\x99\xad", "\xe2\x99\xae", "\xe2\x99\xaf"};
+  std::map<std::string, int> id;
+  for (size_t t = 0; t < vocab.size(); ++t) id.emplace(vocab[t], (int)t);      // first id of a string, as token_to_id would hold one
+  std::vector<int> out;
+  auto add = [&](const std::string& s) { auto it = id.find(s); if (it != id.end()) out.push_back(it->second); };
+  for (const char* t : kList) { add(t); add(std::string(" ") + t); }
+  add(" -");
+  add(" '");
+  std::sort(out.begin(), out.end());
+  out.erase(std::unique(out.begin(), out.end()), out.end());
+  return out;
+}
+
+int build_nst_masks(crispy_asr* h) {
+  if (h->d_ts_mask_nst) return CRISPY_OK;
+  if (!h->d_ts_mask) { const int rc = build_ts_masks(h); if (rc != CRISPY_OK) return rc; }
+  const int V = h->hp.n_vocab;
+  std::vector<unsigned char> m(V), f(V);
+  HIP_TRY(hipMemcpy(m.data(), h->d_ts_mask, V, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(f.data(), h->d_ts_mask_first, V, hipMemcpyDeviceToHost));
+  for (int t : non_speech_token_ids(h->vocab))
+    if (t < V) { m[t] = 1; f[t] = 1; }
+  HIP_TRY(hipMalloc(&h->d_ts_mask_nst, V));
+  HIP_TRY(hipMalloc(&h->d_ts_mask_first_nst, V));
+  HIP_TRY(hipMemcpy(h->d_ts_mask_nst, m.data(), V, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->d_ts_mask_first_nst, f.data(), V, hipMemcpyHostToDevice));
+  return CRISPY_OK;
+}
+
 // One decoder of one pass over a window: the picks the device made, and whisper_full's bookkeeping replayed over them
 // (oracle/whisper_oracle.py: decode_temperature) [UPSTREAM-RECALL: whisper_full_with_state, "update the decoder state"].
 struct DecoderPass {
@@ -2319,6 +2363,24 @@ int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const si
   if (nb > 0) {
     const Special sp = special_tokens(h);
     const bool timestamps = !(opts && opts->no_timestamps) && sp.beg + 1501 <= h->hp.n_vocab;
+    if (opts && opts->beam_size > 1) {
+      cleanup();
+      return fail(CRISPY_ERR_UNSUPPORTED, "crispy_asr_transcribe_batch: beam search (beam_size %d) is not built; 0 or 1", opts->beam_size);
+    }
+    if (opts && (opts->n_initial_prompt < 0 || (opts->n_initial_prompt > 0 && !opts->initial_prompt))) {
+      cleanup();
+      return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: initial_prompt is NULL or its count negative");
+    }
+    if (opts && opts->carry_context && batch != 1) {
+      cleanup();
+      return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: carry_context needs a single-chunk call (batch %d)", batch);
+    }
+    if (opts)
+      for (int i = 0; i < opts->n_initial_prompt; ++i)
+        if (opts->initial_prompt[i] < 0 || opts->initial_prompt[i] >= h->hp.n_vocab) {
+          cleanup();
+          return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: initial prompt token %d out of range", opts->initial_prompt[i]);
+        }
     std::vector<int> prompt = {sp.sot};
     if (sp.multilingual) {
       prompt.push_back(opts && opts->language_token > 0 ? opts->language_token : sp.lang0);   // <|en|>
@@ -2397,7 +2459,22 @@ int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const si
       else temps.push_back(t0);
       if (temps.empty()) temps.push_back(t0);
       const bool use_past = !(opts && opts->no_prev_text);
+      // The conditioning text a chunk starts with [UPSTREAM-RECALL: whisper_full_with_state, prompt_past]: nothing
+      // (no_context = true, whisper.cpp's default); with carry_context what the previous call on this handle ended with;
+      // the caller's initial prompt rotated in front of that.
       std::vector<std::vector<int>> past(nb);
+      {
+        std::vector<int> start;
+        if (opts && opts->n_initial_prompt > 0) start.assign(opts->initial_prompt, opts->initial_prompt + opts->n_initial_prompt);
+        if (opts && opts->carry_context) start.insert(start.end(), h->prompt_past.begin(), h->prompt_past.end());
+        for (int k = 0; k < nb; ++k) past[k] = start;
+      }
+      const unsigned char *ts_mask = h->d_ts_mask, *ts_mask_first = h->d_ts_mask_first;
+      if (opts && opts->suppress_nst) {
+        rc = build_nst_masks(h);
+        if (rc != CRISPY_OK) return rc;
+        ts_mask = h->d_ts_mask_nst; ts_mask_first = h->d_ts_mask_first_nst;
+      }
       std::vector<std::vector<std::mt19937>> rngs(nb);
       for (int k = 0; k < nb; ++k)
         for (int j = 0; j < best_of; ++j) rngs[k].emplace_back((unsigned)j);
@@ -2506,8 +2583,8 @@ int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const si
             }
             std::vector<int> toks((size_t)rows * max_new), tids((size_t)rows * max_new), n_out(rows, 0);
             std::vector<float> plog((size_t)rows * max_new), nosp(rows, 0.f);
-            rc = decode_ts(h, d_enc, rows, prompts, TS_RULES_WCPP, r_seek.data(), r_end.data(), max_new, h->d_ts_mask,
-                           h->d_ts_mask_first, t_cur, t_cur > 0.f ? u.data() : nullptr, toks.data(), tids.data(), plog.data(),
+            rc = decode_ts(h, d_enc, rows, prompts, TS_RULES_WCPP, r_seek.data(), r_end.data(), max_new, ts_mask,
+                           ts_mask_first, t_cur, t_cur > 0.f ? u.data() : nullptr, toks.data(), tids.data(), plog.data(),
                            nosp.data(), n_out.data(), n_dec);
             if (rc != CRISPY_OK) return rc;
             // evaluate: per clip of the group, its n_dec decoders
@@ -2592,6 +2669,7 @@ int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const si
         crispy_asr_result_impl* r = impl[live[k]];
         for (const std::string& t : r->seg_text) r->text += t;
       }
+      if (batch == 1) h->prompt_past = past[0];      // whisper.cpp keeps prompt_past in the state; the next call uses it only with carry_context
       return CRISPY_OK;
     };
     const int rc = run();

@@ -415,6 +415,22 @@ typedef struct crispy_asr_opts {
   float logprob_thold;   /* 0 = -1.0 */
   float no_speech_thold; /* 0 = 0.6; >= 1: no window is ever dropped as silence */
   int best_of;           /* 0 = 5 */
+  /* ---- appended with ABI 3 (zero / NULL = the behaviour before): the other whisper_full parameters a host may set ---- */
+  int suppress_nst;      /* whisper_full_params.suppress_nst [UPSTREAM-RECALL]: 1 = the non-speech tokens -- whisper.cpp's list
+                            of punctuation runs, brackets and music notes, each looked up in the MODEL'S vocabulary as it
+                            stands and with a leading space, plus " -" and " '" -- are never picked.  Needs a model loaded
+                            from a file (the vocabulary's text); a model without one has nothing to look up. */
+  const int *initial_prompt;   /* whisper_full_params.prompt_tokens: token ids placed in FRONT of the conditioning text of every
+                                  chunk of the call (whisper.cpp rotates them in front of prompt_past); the first window's prompt is
+                                  then <|startofprev|> + the last <= n_text_ctx / 2 of them + the usual prompt.  The host
+                                  tokenises (the reference's engine does: transcribe-rs hands whisper.cpp text).  NULL: none. */
+  int n_initial_prompt;
+  int carry_context;     /* 1 = whisper_full_params.no_context = false: the conditioning text the previous call on this handle
+                            ended with is where this call's first window starts (a recording transcribed chunk by chunk
+                            through one engine).  Single-chunk calls only (batch == 1); 0 = whisper.cpp's default
+                            (no_context = true: every call starts clean). */
+  int beam_size;         /* whisper.cpp's BEAM_SEARCH strategy at temperature 0 is NOT built: must be 0 or 1
+                            (CRISPY_ERR_UNSUPPORTED otherwise) -- INTEGRATION.md, "Behavioural differences". */
 } crispy_asr_opts;
 
 /* One segment of the result (managers/transcription.rs:223-233: `seg.start`, `seg.end`, `seg.text`),

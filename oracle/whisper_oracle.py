@@ -620,8 +620,34 @@ def decode_temperature(dc, prompt, sp, rules, n_max, seek, seek_end, t_cur, n_de
     return dict(decoders=decs, best=best, no_speech_prob=no_speech_prob)
 
 
+# whisper.cpp's `non_speech_tokens` [UPSTREAM-RECALL], suppressed with whisper_full_params.suppress_nst
+NON_SPEECH_TOKENS = ['"', "#", "(", ")", "*", "+", "/", ":", ";", "<", "=", ">", "@", "[", "\\", "]", "^", "_", "`", "{", "|", "}", "~",
+                     "\u300c", "\u300d", "\u300e", "\u300f", "<<", ">>", "<<<", ">>>", "--", "---", "-(", "-[", "('", '("', "((", "))",
+                     "(((", ")))", "[[", "]]", "{{", "}}", "\u266a\u266a", "\u266a\u266a\u266a", "\u2669", "\u266a", "\u266b", "\u266c",
+                     "\u266d", "\u266e", "\u266f"]
+
+
+def non_speech_token_ids(vocab):
+    """Token ids whisper_process_logits sets to -inf under suppress_nst [UPSTREAM-RECALL]: every string of the list as it
+    stands and with a leading space, where the vocabulary (a list of byte strings, index = id) holds it as one token;
+    then " -" and " '" (hyphens and quotes are allowed between words, not at the start of one)."""
+    first = {}
+    for i, t in enumerate(vocab):
+        first.setdefault(bytes(t), i)
+    out = set()
+    for t in NON_SPEECH_TOKENS:
+        for cand in (t.encode("utf-8"), (" " + t).encode("utf-8")):
+            if cand in first:
+                out.add(first[cand])
+    for cand in (b" -", b" '"):
+        if cand in first:
+            out.add(first[cand])
+    return sorted(out)
+
+
 def whisper_full(weights, hp, mel_window, n_samples, prompt, rules, token_text, params=None, n_max=None, suppress=None,
-                 suppress_first=None, eot=None, max_windows=1501, f16=False, prev_text=True, decoder_kw=None, encoder=None):
+                 suppress_first=None, eot=None, max_windows=1501, f16=False, prev_text=True, decoder_kw=None, encoder=None,
+                 initial_prompt=None, past0=None, state=None):
     """whisper_full_with_state over one chunk [UPSTREAM-RECALL], greedy strategy: the seek loop, and per window the
     temperature ladder `temperature, + temperature_inc, .. <= 1.0` -- one greedy decoder at 0, `best_of` sampling
     decoders above; a window's result is accepted unless its best decoder failed (EOT before a timestamp away from the
@@ -631,6 +657,9 @@ def whisper_full(weights, hp, mel_window, n_samples, prompt, rules, token_text, 
     `logprob_thold` yields no segment and adds nothing to the conditioning text.  Decoder j draws from MT19937(j),
     seeded anew for every call (whisper.cpp re-seeds decoders >= 1 per call and keeps decoder 0's generator in the state).
     `encoder(mel)` replaces the encoder pass (tests on weight sets whose decoder ignores the audio).
+    initial_prompt (whisper_full_params.prompt_tokens): token ids rotated in FRONT of the conditioning text the chunk starts
+    with; past0: that text (prompt_past of the state when no_context = false; empty by default: no_context = true).  `state`
+    (a dict) receives "prompt_past": the conditioning text the call ends with.
     Returns (segments, kept tokens, windows); a window carries everything the decision used."""
     P = dict(WCPP_PARAMS)
     P.update(params or {})
@@ -651,7 +680,7 @@ def whisper_full(weights, hp, mel_window, n_samples, prompt, rules, token_text, 
     n_best = max(1, int(P["best_of"]))
     rngs = [MT19937(j) for j in range(n_best)]
     prompt = list(prompt)
-    past = []
+    past = list(initial_prompt or []) + list(past0 or [])
     no_ts = sp["not_"] in prompt
     while len(wins) < max_windows:
         if seek + delta_min >= seek_end:
@@ -711,6 +740,8 @@ def whisper_full(weights, hp, mel_window, n_samples, prompt, rules, token_text, 
         win["seek_advance"] = seek_delta
         wins.append(win)
         seek += seek_delta
+    if state is not None:
+        state["prompt_past"] = list(past)
     return segs, kept, wins
 
 
@@ -746,7 +777,7 @@ def window_segments(win, seek, sp, token_text):
 
 def transcribe_timestamps(weights, hp, mel_window, n_samples, prompt, rules, token_text, n_max=None,
                           suppress=None, suppress_first=None, eot=None, max_windows=1501, f16=False, prev_text=True,
-                          fallback=False, params=None, decoder_kw=None, encoder=None):
+                          fallback=False, params=None, decoder_kw=None, encoder=None, **full_kw):
     """`whisper_full` with (fallback=True) or without (temperature_inc = 0: one greedy pass per window, accepted as it
     is) the temperature ladder; everything else -- no-speech rule, failure flags, single-timestamp ending -- applies in
     both.  Returns (segments, all kept tokens, windows)."""
@@ -754,4 +785,4 @@ def transcribe_timestamps(weights, hp, mel_window, n_samples, prompt, rules, tok
     if not fallback:
         P.setdefault("temperature_inc", 0.0)
     return whisper_full(weights, hp, mel_window, n_samples, prompt, rules, token_text, P, n_max, suppress, suppress_first,
-                        eot, max_windows, f16, prev_text, decoder_kw, encoder)
+                        eot, max_windows, f16, prev_text, decoder_kw, encoder, **full_kw)

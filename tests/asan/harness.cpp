@@ -207,6 +207,7 @@ int fuzz_rnnoise(const char* path, int n, unsigned seed) {
 // decide: one case per line
 //   P <n_max> <beg> <eot> <seek> <seek_end> <delta_min> <n> tok*n tid*n plog*n      -> replay + score + segments of a pass
 //   U <seed> <count>                                                                   -> the first <count> variates of std::mt19937(seed)
+//   N <file>                                                                           -> non_speech_token_ids of a vocabulary (one hex string per line)
 int decide() {
   crispy_asr h;                           // no device state is touched: vocabulary and eot only
   char line[1 << 16];
@@ -217,6 +218,29 @@ int decide() {
       std::mt19937 g(seed);
       printf("[");
       for (int i = 0; i < count; ++i) printf("%s%.17g", i ? ", " : "", canonical(g));
+      printf("]\n");
+      continue;
+    }
+    if (line[0] == 'N') {             // N <file>: one vocabulary entry per line (hex) -> the ids suppress_nst masks
+      char path[4096];
+      if (sscanf(line + 1, "%4095s", path) != 1) return 2;
+      std::vector<std::string> vocab;
+      FILE* f = fopen(path, "r");
+      if (!f) return 2;
+      char hex[4096];
+      while (fgets(hex, sizeof(hex), f)) {
+        std::string t;
+        for (size_t i = 0; hex[i] && hex[i + 1] && hex[i] != '\n'; i += 2) {
+          unsigned v = 0;
+          sscanf(hex + i, "%2x", &v);
+          t.push_back((char)v);
+        }
+        vocab.push_back(t);
+      }
+      fclose(f);
+      printf("[");
+      bool first = true;
+      for (int id : non_speech_token_ids(vocab)) { printf("%s%d", first ? "" : ", ", id); first = false; }
       printf("]\n");
       continue;
     }

@@ -339,3 +339,86 @@ def test_fallback_passes_of_a_batch_run_side_by_side_and_equal_the_single_calls(
     sub = transcribe_batch(eng, [clips[4], clips[1], clips[7]], **kw)
     assert sub == [got[4], got[1], got[7]]
     eng.close()
+
+
+def test_non_speech_suppression_initial_prompt_and_carried_context(oracle, tmp_path_factory):
+    """The whisper_full parameters a host may set beyond the defaults (crispy_asr_opts, ABI 3), product
+    against oracle in precision mode 1:
+    (a) suppress_nst on a scripted model whose vocabulary holds "(" and " -": the script's favourites at two positions are
+        those tokens -- picked without the option, the runners-up with it; the mask is exactly the oracle's id set;
+    (b) an initial prompt and, from the second call on, the context carried over from the call before (no_context = false),
+        on plain weights: three consecutive single-chunk calls equal the oracle's whisper_full chain, token for token;
+    (c) what is not built says so: beam_size > 1 is CRISPY_ERR_UNSUPPORTED, carry_context in a batch call invalid."""
+    from crispy_amd import _native as N, synth_audio
+    from crispy_amd.asr import WhisperEngine, transcribe_batch
+    from crispy_amd.ggml_io import synthetic_vocab, write_ggml
+    from crispy_amd.mel_filters import whisper_mel_filters
+    from crispy_amd.whisper_weights import HParams, synthetic_whisper_weights
+    from oracle import whisper_oracle as WO
+    from tests.scripted_model import script_rows, scripted_whisper_weights
+    hp = HParams.tiny()
+    sp, BEG, EOT = _scripts(hp)
+    _, sup, sup_first = _wcpp_masks(hp)
+    F = whisper_mel_filters(80)
+    # ---- (a)
+    PAREN, DASH, A, B = 1001, 1003, 2345, 3456
+    beta = 1.0 - 1.0 * np.sqrt(2.0) / hp.n_text_state            # the favourite leads the runner-up by one logit at gain 100
+    rows = script_rows(2, [BEG, [(PAREN, 1.0), (A, beta)], [(DASH, 1.0), (B, beta)], BEG + 300, BEG + 300, EOT])
+    W = scripted_whisper_weights(hp, rows, gain=100.0)
+    vocab = synthetic_vocab(hp.n_vocab)
+    vocab[PAREN], vocab[DASH], vocab[4000], vocab[4001] = b"(", b" -", b"-", "♪".encode()
+    path = str(tmp_path_factory.mktemp("ggml_nst") / "nst.bin")
+    write_ggml(path, hp, W, F, vocab, f16=False)
+    eng = WhisperEngine(path)
+    eng.set_precision(1)
+    x = synth_audio.clip16k_np(80, 16000 * 7)
+    nst = WO.non_speech_token_ids(vocab)
+    assert nst == [PAREN, DASH, 4001]
+    _, _, plain = eng.transcribe_segments(x, language_token=sp["lang0"], fallback=False)
+    _, _, masked = eng.transcribe_segments(x, language_token=sp["lang0"], fallback=False, suppress_nst=True)
+    assert plain[:5] == [BEG, PAREN, DASH, BEG + 300, BEG + 300] and masked[:5] == [BEG, A, B, BEG + 300, BEG + 300]
+    enc0 = np.zeros((hp.n_audio_ctx, hp.n_audio_state))
+    for got, extra in ((plain, []), (masked, nst)):
+        _, rk, _ = WO.transcribe_timestamps(W, hp, lambda seek: None, x.size, [sp["sot"], sp["lang0"], sp["transcribe"]], WO.RULES_WCPP,
+                                            eng.token_text, suppress=sorted(sup + extra), suppress_first=sup_first, f16=True,
+                                            encoder=lambda mel: enc0)
+        assert got == [t for t in rk if t != EOT], (got, rk)
+    # ---- (c)
+    for bad, code in ((dict(beam_size=2), -6), (dict(beam_size=5), -6)):
+        with pytest.raises(N.CrispyError) as e:
+            eng.transcribe_segments(x, language_token=sp["lang0"], **bad)
+        assert e.value.code == code
+    with pytest.raises(N.CrispyError) as e:
+        transcribe_batch(eng, [x, x], language_token=sp["lang0"], timestamps=True, carry_context=True)
+    assert e.value.code == -1
+    eng.transcribe_segments(x, language_token=sp["lang0"], beam_size=1, fallback=False)       # 0 and 1 are the greedy strategy
+    eng.close()
+    # ---- (b)
+    Wp = synthetic_whisper_weights(hp, 1)                          # plain fan-in-scaled weights: the strict bar holds (test_gpu_mode1)
+    eng = WhisperEngine(_engine_file(tmp_path_factory, hp, Wp, "tiny-s1-ctx"))
+    eng.set_precision(1)
+    init = [1000, 2000, 3000, 4000, 5000]
+    prompt = [sp["sot"], sp["lang0"], sp["transcribe"]]
+    chunks = [synth_audio.clip16k_np(s, 16000 * 9) for s in (95, 97, 91)]
+    past, thr_seen = [], []
+    for i, c in enumerate(chunks):
+        _, _, toks = eng.transcribe_segments(c, max_new_tokens=12, language_token=sp["lang0"], fallback=False, initial_prompt=init,
+                                             carry_context=(i > 0))
+        st = {}
+        _, rk, wins = WO.transcribe_timestamps(Wp, hp, lambda seek: oracle.oracle_logmel(c, F, seek), c.size, prompt, WO.RULES_WCPP,
+                                               eng.token_text, n_max=12, suppress=sup, suppress_first=sup_first, f16=True,
+                                               initial_prompt=init, past0=past, state=st)
+        assert wins[0]["prompt"][:1 + len(init)] == [sp["prev"]] + init
+        if i > 0:
+            assert len(wins[0]["prompt"]) > 1 + len(init) + 3          # the call before left text behind
+        thr_seen.append(min(min(w["margins"]) for w in wins))
+        assert toks == [t for t in rk if t != EOT], (i, toks, rk, thr_seen)
+        past = st["prompt_past"]
+    print(f"carried context: smallest oracle margins per call {thr_seen}")
+    # without carry_context the second chunk starts clean again: another transcript than with it
+    _, _, clean = eng.transcribe_segments(chunks[1], max_new_tokens=12, language_token=sp["lang0"], fallback=False, initial_prompt=init)
+    _, rk, wins = WO.transcribe_timestamps(Wp, hp, lambda seek: oracle.oracle_logmel(chunks[1], F, seek), chunks[1].size, prompt,
+                                           WO.RULES_WCPP, eng.token_text, n_max=12, suppress=sup, suppress_first=sup_first, f16=True,
+                                           initial_prompt=init)
+    assert clean == [t for t in rk if t != EOT] and len(wins[0]["prompt"]) == 1 + len(init) + 3
+    eng.close()

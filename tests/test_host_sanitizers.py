@@ -213,9 +213,25 @@ def test_decision_logic_of_the_library_equals_the_oracles_on_scripted_decoders(h
                                                              " ".join(map(str, d["tids"])), " ".join(repr(float(np.float32(p))) for p in d["plogs"])))
             refs.append((d, seek))
     lines += ["U %d 6" % s for s in (0, 1, 4, 12345)]
+    # the ids suppress_nst masks, on a vocabulary that holds some of whisper.cpp's non-speech strings (and near misses)
+    vocab = [b" w%d" % i for i in range(300)]
+    rs = np.random.default_rng(3)
+    cands = [t.encode("utf-8") for t in WO.NON_SPEECH_TOKENS] + [(" " + t).encode("utf-8") for t in WO.NON_SPEECH_TOKENS] + \
+            [b" -", b" '", b"-", b"'", b" (x", b"((((", b"", b" "]
+    for i, c in zip(rs.permutation(300)[:len(cands)], cands):
+        vocab[int(i)] = c
+    vocab[299] = b"("                                          # a duplicate string: the first id counts
+    import tempfile
+    vf = tempfile.NamedTemporaryFile("w", suffix=".hex", delete=False)
+    vf.write("".join(t.hex() + "\n" for t in vocab))
+    vf.close()
+    lines.append("N " + vf.name)
     r = _run(harness, ["decide"], stdin="\n".join(lines) + "\n")
+    os.unlink(vf.name)
     assert r.returncode == 0, r.stderr[-2000:]
     got = [json.loads(ln) for ln in r.stdout.strip().splitlines()]
+    nst = got.pop()
+    assert nst == WO.non_speech_token_ids(vocab) and len(nst) >= 2 * len(WO.NON_SPEECH_TOKENS) - 2, (nst, WO.non_speech_token_ids(vocab))
     assert len(got) == len(refs) + 4
     seen = dict(failed=0, completed=0, limit=0, segs=0)
     for g, (d, seek) in zip(got, refs):

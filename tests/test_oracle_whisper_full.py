@@ -298,3 +298,41 @@ def test_past_is_not_used_at_half_temperature_and_above(scripted):
     assert len(prompts) == 1 + 6
     past = [SP["prev"], BEG, 11, BEG + 300, BEG + 300] + INIT
     assert prompts[1:4] == [past] * 3 and prompts[4:] == [INIT] * 3      # 0, 0.2, 0.4 | 0.6, 0.8, 1.0
+
+
+def test_non_speech_tokens_are_looked_up_as_they_stand_and_with_a_leading_space():
+    """whisper_full_params.suppress_nst [UPSTREAM-RECALL]: the list's strings that the vocabulary holds as ONE token, bare and
+    behind a space; " -" and " '" on top ("-" and "'" themselves stay: hyphens and quotes inside words)."""
+    vocab = [b" w%d" % i for i in range(40)]
+    put = {3: b"(", 4: b" (", 7: b"-", 8: b" -", 9: b"'", 10: b" '", 12: "♪".encode(), 13: " ♪♪".encode(), 15: b"((",
+           16: b" hello(", 20: b"\\", 21: b' "', 22: b"(", 30: b"--"}
+    for i, t in put.items():
+        vocab[i] = t
+    ids = WO.non_speech_token_ids(vocab)
+    assert ids == [3, 4, 8, 10, 12, 13, 15, 20, 21, 30]        # 22 is a second "(": token_to_id holds one id per string; 7, 9, 16 stay
+
+
+def test_initial_prompt_and_carried_context_are_where_the_first_window_starts(scripted):
+    """prompt_tokens are rotated in FRONT of the state's prompt_past [UPSTREAM-RECALL]; the first window is conditioned on
+    both, later windows on what the loop made of them; `state` hands the text on to the next call (no_context = false)."""
+    seen = []
+
+    def script(gen, prompt):
+        if not gen:
+            seen.append(list(prompt))
+        seq = [BEG, 700, 701, BEG + 100, BEG + 100, EOT]
+        return peaky(seq[len(gen)] if len(gen) < len(seq) else EOT)
+
+    scripted(lambda k: script)
+    st = {}
+    segs, kept, wins = run(16000 * 20, initial_prompt=[11, 12], past0=[21, 22, 23], state=st, max_windows=2)
+    assert seen[0] == [SP["prev"], 11, 12, 21, 22, 23] + INIT
+    assert wins[0]["prompt"] == seen[0] and kept[:4] == [BEG, 700, 701, BEG + 100]
+    # the second window (2 s in, 18 s left) is conditioned on all of it plus what the first one kept
+    first_kept = wins[0]["tokens"][:wins[0]["n_past"]]
+    assert wins[1]["prompt"] == [SP["prev"], 11, 12, 21, 22, 23] + first_kept + INIT
+    # the text the call ends with: what conditioned its last window + what that window kept
+    assert st["prompt_past"] == [11, 12, 21, 22, 23] + first_kept + wins[1]["tokens"][:wins[1]["n_past"]]
+    seen.clear()
+    run(16000 * 4)
+    assert seen[0] == INIT                                    # no_context = true, no prompt: the bare prompt
