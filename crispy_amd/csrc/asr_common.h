@@ -163,8 +163,8 @@ struct FusedIn {
 };
 struct FusedSelfArgs {
   FusedIn in;
-  const _Float16* wqkv; const float* bqkv;     // [3 D][D] f16 (q | k | v rows), [3 D]
-  const _Float16* wo;                          // [D][D] f16
+  const _Float16* wqkv; const float* bqkv;     // q | k | v weights PACKED by fused_pack_weights(kind 0); bias [3 D]
+  const _Float16* wo;                          // out-projection PACKED (kind 1)
   _Float16* kv; long kv_row_stride;            // self K | V cache of this layer: [rows][n_text_ctx][2 D] f16
   const int* pos_dev;                          // device: cache row of this step's token
   const int* key_off;                          // [rows] nullable: first cache row of the row's clip (left-padded prompts)
@@ -184,13 +184,16 @@ struct FusedCrossArgs {
 };
 struct FusedMlpArgs {
   FusedIn in;
-  const _Float16* w1; const float* b1;         // [4 D][D] f16, [4 D]
-  const _Float16* w2;                          // [D][4 D] f16
+  const _Float16* w1; const float* b1;         // fc1 PACKED (kind 2), bias [4 D]
+  const _Float16* w2;                          // fc2 PACKED (kind 3)
   float* part_out;                             // [4 D / 128][rows][D]
   int rows, D;
 };
 struct FusedFinishArgs { FusedIn in; _Float16* y; int rows, D; };     // in.part: the last layer's MLP partials
 bool fused_decode_supported(int D, int max_keys, int n_audio_ctx);
+// f16 weights [rows][ld] -> the tile order the fused kernels' matrix-core operands are requested in (same byte count);
+// kind 0: fused q | k | v [3 D][D]; 1: attention out-projection [D][D]; 2: fc1 [4 D][D]; 3: fc2 [D][4 D]
+hipError_t fused_pack_weights(const void* W, void* dst, int D, int kind, hipStream_t s);
 hipError_t fused_self(const FusedSelfArgs& a, bool first_layer, hipStream_t s);   // first_layer: x_in is complete (no partials)
 hipError_t fused_cross(const FusedCrossArgs& a, hipStream_t s);
 hipError_t fused_mlp(const FusedMlpArgs& a, hipStream_t s);

@@ -54,7 +54,8 @@ struct DecLayer {
   const float *lnx_w, *lnx_b, *xq_w, *xq_b, *xkv_w, *xkv_b, *xout_w, *xout_b;
   const void* xkv_wh = nullptr;              // f16 copy of the fused cross K|V projection (precision mode 1)
   const void *out_wh = nullptr, *xout_wh = nullptr, *fc2_wh = nullptr;   // f16 copies of the plain (no LayerNorm in front) decode projections
-  const void *qkv_wh = nullptr, *xq_wh = nullptr, *fc1_wh = nullptr;     // f16 copies of the un-folded q | k | v, cross-q, fc1 (precision mode 2)
+  const void *qkv_wh = nullptr, *xq_wh = nullptr, *fc1_wh = nullptr;     // f16 copies of the un-folded q | k | v, cross-q, fc1 (precision modes 1 / 2)
+  const void *qkv_p = nullptr, *out_p = nullptr, *fc1_p = nullptr, *fc2_p = nullptr;   // ... packed for the fused step kernels (fused_pack_weights)
   const float *ln2_w, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
   // LayerNorm folded into the consuming projection (decode steps with <= 64 clips): gamma-scaled weights, their row
   // sums and beta.W + bias (GemmArgs::ln_s / ln_c)
@@ -778,6 +779,21 @@ int crispy_asr_set_precision(crispy_asr* h, int mode) try {
       if (rc == CRISPY_OK) rc = half_copy(L.qkv_w, 3 * dtt * dtt, &L.qkv_wh);
       if (rc == CRISPY_OK) rc = half_copy(L.xq_w, dtt * dtt, &L.xq_wh);
       if (rc == CRISPY_OK) rc = half_copy(L.fc1_w, 4 * dtt * dtt, &L.fc1_wh);
+      if (fused_decode_supported((int)dtt, 1, h->hp.n_audio_ctx)) {      // the fused step kernels' operand order (same bytes once more)
+        auto packed = [&](const void* src, size_t n, int kind, const void** out) -> int {
+          void* p = nullptr;
+          HIP_TRY(hipMalloc(&p, n * 2));
+          h->derived.push_back(reinterpret_cast<float*>(p));
+          h->derived_bytes += n * 2;
+          HIP_TRY(fused_pack_weights(src, p, (int)dtt, kind, h->stream));
+          *out = p;
+          return CRISPY_OK;
+        };
+        if (rc == CRISPY_OK) rc = packed(L.qkv_wh, 3 * dtt * dtt, 0, &L.qkv_p);
+        if (rc == CRISPY_OK) rc = packed(L.out_wh, dtt * dtt, 1, &L.out_p);
+        if (rc == CRISPY_OK) rc = packed(L.fc1_wh, 4 * dtt * dtt, 2, &L.fc1_p);
+        if (rc == CRISPY_OK) rc = packed(L.fc2_wh, 4 * dtt * dtt, 3, &L.fc2_p);
+      }
     }
     if (rc != CRISPY_OK) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1077,7 +1093,7 @@ void choose_decode_path(crispy_asr* h) {
 }
 
 bool fused_step_ok(const crispy_asr* h, int rows) {
-  return h->fused_path && h->enc_precision == 1 && !h->resident && h->ln16_ready && h->tok_emb_hp && h->d_fx[0] &&
+  return h->fused_path && h->enc_precision == 1 && !h->resident && h->ln16_ready && h->dec[0].qkv_p && h->tok_emb_hp && h->d_fx[0] &&
          rows <= FUSED_MAX_ROWS && fused_decode_supported(h->hp.n_text_state, h->dec_max_keys, h->hp.n_audio_ctx);
 }
 
@@ -1097,8 +1113,8 @@ int decoder_step_fused(crispy_asr* h, int rows, hipStream_t s) {
     const DecLayer& L = h->dec[l];
     FusedSelfArgs a{};
     a.in = FusedIn{x_in, prev_bias, pc, xa, L.ln1_w, L.ln1_b};
-    a.wqkv = reinterpret_cast<const _Float16*>(L.qkv_wh); a.bqkv = L.qkv_b;
-    a.wo = reinterpret_cast<const _Float16*>(L.out_wh);
+    a.wqkv = reinterpret_cast<const _Float16*>(L.qkv_p); a.bqkv = L.qkv_b;
+    a.wo = reinterpret_cast<const _Float16*>(L.out_p);
     a.kv = reinterpret_cast<_Float16*>(h->d_selfkv) + l * clips * C * 2 * dt; a.kv_row_stride = (long)C * 2 * dt;
     a.pos_dev = h->d_counters; a.key_off = h->cur_row_off;
     a.attn16 = attn16; a.max_keys = h->dec_max_keys;
@@ -1115,8 +1131,8 @@ int decoder_step_fused(crispy_asr* h, int rows, hipStream_t s) {
     HIP_TRY(fused_cross(b, s));
     FusedMlpArgs m{};
     m.in = FusedIn{xb, L.xout_b, pb, xc, L.ln2_w, L.ln2_b};
-    m.w1 = reinterpret_cast<const _Float16*>(L.fc1_wh); m.b1 = L.fc1_b;
-    m.w2 = reinterpret_cast<const _Float16*>(L.fc2_wh);
+    m.w1 = reinterpret_cast<const _Float16*>(L.fc1_p); m.b1 = L.fc1_b;
+    m.w2 = reinterpret_cast<const _Float16*>(L.fc2_p);
     m.part_out = pc; m.rows = rows; m.D = dt;
     HIP_TRY(fused_mlp(m, s));
     x_in = xc;

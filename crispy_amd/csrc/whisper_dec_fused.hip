@@ -22,11 +22,16 @@
 //                           fc2                                                                   grid (4 D / 128, rows)
 //       fused_finish_kernel x = x2 + b + sum(MLP partials);  final LayerNorm -> f16 row for the vocabulary projection
 //
-//   * one workgroup = one ROW (clip), 16 waves; every weight byte the workgroup needs (196 KB at D = 384) is requested in
-//     its first instructions, together with the residual stream and the self K | V cache, so the chain LayerNorm ->
-//     product -> attention -> product inside a launch waits for memory ONCE.  Everything is a matrix-VECTOR product: lanes
-//     share a weight row 16 (K = D) or 8 (K = 64) ways, v_dot2c_f32_f16 on the f16 pairs, f32 sums inside the DPP row.
-//     No matrix cores: one row has nothing to tile, and a row's arithmetic is trivially the same in every batch.
+//   * one workgroup = one head (or 128 hidden units) of 1 - 8 rows, 16 waves; every weight byte the workgroup needs
+//     (196 KB at D = 384) is requested in its first instructions, together with the residual stream and the self K | V
+//     cache, so the chain LayerNorm -> product -> attention -> product inside a launch waits for memory ONCE.  The
+//     products of the self and MLP blocks run on v_mfma_f32_16x16x32_f16 with the WEIGHTS as the A operand, straight from
+//     the registers they were requested into (tile = 16 weight rows, lane = row l & 15, k = 8 (l >> 4) .. + 7), and the
+//     rows of the step as the 16 columns of B (from LDS): a column's result depends on that column alone, so a row
+//     decodes to the same bits whatever else is in the workgroup or the batch, and 1 .. 16 rows cost the same.  (The first
+//     form multiplied on v_dot2c_f32_f16 with DPP row sums: with 4 rows per workgroup its 16 waves spent 5 us in the
+//     vector pipe.)  The cross block is one row per workgroup by construction (its K | V fills the registers) and keeps
+//     the matrix-VECTOR form.
 //
 // Arithmetic = ggml's for these products [UPSTREAM-RECALL: mul_mat converts its f32 operand to the f16 of the weight]:
 // LayerNorm in f32, its output rounded to f16 against f16 weights, f32 accumulation; q . k with the f32 query against the f16
@@ -38,7 +43,11 @@ namespace crispy {
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int FD_NB = 16;          // columns of an MFMA tile = rows of the step a workgroup can take
 
 constexpr int FD_WAVES = 16;
 constexpr int FD_THREADS = 64 * FD_WAVES;
@@ -113,6 +122,9 @@ struct FdInput {
     }
   }
   // xs [RB][D] f32, gb [2][D] (FdParams::stage), xn [RB][D] f16.  Row r's LayerNorm is wave r's.
+  // XLD: halves between two rows of xn (D for the matrix-vector readers; D + 8 where xn is an MFMA operand: 16 rows read
+  // side by side then fall on different banks)
+  template <int XLD = D>
   __device__ __forceinline__ void finish(const FusedIn& in, float bias, int rows, int row0, bool writer, float* xs, const float* gb,
                                          _Float16* xn) {
     const int tid = threadIdx.x, slot = tid / D, col = tid % D;
@@ -148,7 +160,7 @@ struct FdInput {
       for (int off = 32; off > 0; off >>= 1) s2 += __shfl_xor(s2, off, 64);
       const float rstd = 1.f / sqrtf(s2 / (float)D + 1e-5f);
 #pragma unroll
-      for (int q = 0; q < PER; ++q) xn[wave * D + lane + 64 * q] = (_Float16)((e[q] - mean) * rstd * gb[lane + 64 * q] + gb[D + lane + 64 * q]);
+      for (int q = 0; q < PER; ++q) xn[wave * XLD + lane + 64 * q] = (_Float16)((e[q] - mean) * rstd * gb[lane + 64 * q] + gb[D + lane + 64 * q]);
     }
     fd_bar();
   }
@@ -186,7 +198,23 @@ struct HeadOut {
 // to request what comes after the attention.
 // after_scores(): called when every key has been consumed -- the cross-attention requests its values there, into the
 // registers the keys leave (both at once do not fit beside the projections: 48 + 48 of 128 registers).
-template <int SLOTS, class AfterScores, class Mid>
+// MERGE = false: stops once the wave's partial (max, sum, P.V) is in part_o / part_m / part_l -- the caller runs the
+// partials of several rows, ONE barrier, and fd_merge of row r on wave r (the self block with RB rows).
+__device__ __forceinline__ void fd_merge(const float (*part_o)[64], const float* part_m, const float* part_l, int attn16, _Float16* att_h) {
+  const int lane = threadIdx.x & 63;
+  float m = part_m[0];
+#pragma unroll
+  for (int w = 1; w < FD_WAVES; ++w) m = fmaxf(m, part_m[w]);
+  float o = 0.f, l = 0.f;
+#pragma unroll
+  for (int w = 0; w < FD_WAVES; ++w) {
+    const float scl = __expf(part_m[w] - m);
+    o = fmaf(part_o[w][lane], scl, o);
+    l = fmaf(part_l[w], scl, l);
+  }
+  att_h[lane] = (_Float16)(attn16 ? o : o / l);
+}
+template <int SLOTS, bool MERGE = true, class AfterScores, class Mid>
 __device__ __forceinline__ void fd_attend(const half8 (&kr)[SLOTS], half8 (&vr)[SLOTS], const float* q_s, int k_lo, int k_hi,
                                           int attn16, float (*part_o)[64], float* part_m, float* part_l, _Float16* att_h,
                                           AfterScores after_scores, Mid mid) {
@@ -265,21 +293,11 @@ __device__ __forceinline__ void fd_attend(const half8 (&kr)[SLOTS], half8 (&vr)[
     *reinterpret_cast<float4*>(&part_o[wave][8 * c + 4]) = make_float4(acc[4], acc[5], acc[6], acc[7]);
   }
   if (lane == 0) { part_m[wave] = mloc; part_l[wave] = lsum; }
-  fd_bar();
-  if (wave == 0) {
-    float m = part_m[0];
-#pragma unroll
-    for (int w = 1; w < FD_WAVES; ++w) m = fmaxf(m, part_m[w]);
-    float o = 0.f, l = 0.f;
-#pragma unroll
-    for (int w = 0; w < FD_WAVES; ++w) {
-      const float scl = __expf(part_m[w] - m);
-      o = fmaf(part_o[w][lane], scl, o);
-      l = fmaf(part_l[w], scl, l);
-    }
-    att_h[lane] = (_Float16)(attn16 ? o : o / l);
+  if (MERGE) {
+    fd_bar();
+    if (wave == 0) fd_merge(part_o, part_m, part_l, attn16, att_h);
+    fd_bar();
   }
-  fd_bar();
 }
 
 // po [RB][D] -> part_out[slice][row0 + r][:]
@@ -292,92 +310,102 @@ __device__ __forceinline__ void fd_store_partial(const float* po, float* part_ou
 
 // ---- self-attention block: one head of RB rows -------------------------------------------------------------------------
 // RB rows per workgroup share the head's weights in registers and go through the block TOGETHER: one residual-stream
-// assembly, RB LayerNorms on RB waves, the q | k | v products of all rows off the same weight registers, then the
-// attentions one after the other and the out-projections together.  (A decode step of many rows would otherwise run
-// more workgroups than the chip holds at once -- ~100 registers x 1024 threads is a whole CU -- each re-reading the
-// weights.)  Every row's arithmetic is that of the RB = 1 form, operation for operation.
+// assembly, RB LayerNorms on RB waves, the q | k | v products of all rows in one pass of the matrix cores (waves 0 - 11: one
+// 16-row weight tile each over all of K; waves 12 - 15 hold the out-projection's tiles), then the attentions' partial passes
+// one after the other (a row's keys fill the 16 waves), their merges side by side, and the out-projections together.
 template <int D, int NP, int SLOTS, int RB>
 __global__ __launch_bounds__(FD_THREADS) void fused_self_kernel(FusedSelfArgs a) {
-  constexpr int PPL = D / 128;              // 16-byte pieces per lane of a K = D weight row (16 lanes per row)
+  constexpr int KS = D / 32;                // k-steps of a K = D product = weight registers (half8) per wave
+  constexpr int XLD = D + 8;
+  constexpr int OT = D / 64;                // out-projection tiles per wave (waves 12 - 15), two k-steps each
+  static_assert(2 * OT == KS, "both roles hold the same number of weight registers");
   __shared__ __attribute__((aligned(16))) float xs[RB * D];
   __shared__ __attribute__((aligned(16))) float gb[2 * D];      // LayerNorm gamma | beta
-  __shared__ __attribute__((aligned(16))) _Float16 xn[RB * D];
-  __shared__ __attribute__((aligned(16))) float q_s[RB][64];
-  __shared__ __attribute__((aligned(16))) _Float16 kv_new[RB][128];       // k | v of this position, as the cache holds them
-  __shared__ __attribute__((aligned(16))) float part_o[FD_WAVES][64];
-  __shared__ float part_m[FD_WAVES], part_l[FD_WAVES];
-  __shared__ __attribute__((aligned(16))) _Float16 att_h[RB][64];
+  __shared__ __attribute__((aligned(16))) _Float16 xn[FD_NB * XLD];
+  __shared__ __attribute__((aligned(16))) float q_s[FD_NB][64];
+  __shared__ __attribute__((aligned(16))) _Float16 kv_new[FD_NB][128];    // k | v of this position, as the cache holds them
+  __shared__ __attribute__((aligned(16))) float part_o[RB][FD_WAVES][64];
+  __shared__ float part_m[RB][FD_WAVES], part_l[RB][FD_WAVES];
+  __shared__ __attribute__((aligned(16))) _Float16 att_h[FD_NB][72];
   __shared__ __attribute__((aligned(16))) float po[RB * D];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = blockIdx.x, row0 = blockIdx.y * RB;
   const int pos = *a.pos_dev;                                          // cache row of this step's token
   const int c8 = lane & 7, r8 = lane >> 3;
+  const int n16 = lane & 15, kq = lane >> 4;                           // MFMA roles: row / column l & 15, k-group l >> 4
   // (1) everything this workgroup will read, requested before anything is waited for.  The cache: keys k_off .. pos - 1;
   // slots past them (and the new key, which no cache row holds yet) take the new k | v from LDS below.
   FdParams<D, NP> par;
   par.request(a.in);
   FdInput<D, NP, RB> fin;
   fin.request(a.in, a.rows, row0);
+  // LATE: weights + keys + values do not fit the registers together (D = 512 with four key slots: 64 + 32 of 128) -- the
+  // cache is then requested behind the q | k | v product and the out-projection's weights behind the attention: two
+  // exposed round trips to the L2 for Whisper-base at contexts beyond 256 positions, instead of spills.
+  constexpr bool LATE = KS * 4 + RB * SLOTS * 8 >= 96;
   int n_keys[RB], k_lo[RB], k_hi[RB];
   half8 kr[RB][SLOTS], vr[RB][SLOTS];
+  auto request_kv = [&] {
 #pragma unroll
-  for (int rb = 0; rb < RB; ++rb) {
-    const int row = min(row0 + rb, a.rows - 1);
-    const int k_off = a.key_off ? a.key_off[row] : 0;                  // left-padded prompts: the clip's first cache row
-    n_keys[rb] = pos + 1 - k_off;                                      // keys the row attends to, its own included (>= 1 in a generated step)
-    const int per = (max(n_keys[rb], 1) + FD_WAVES - 1) / FD_WAVES;
-    k_lo[rb] = wave * per;
-    k_hi[rb] = min(n_keys[rb], k_lo[rb] + per);
-    const int k_cached = max(n_keys[rb] - 2, 0);                       // last key that is in the cache (clamp target)
-    // a uniform base (scalar registers) + one 32-bit byte offset per lane and slot, shared by the key and its value
-    const char* Kb = reinterpret_cast<const char*>(a.kv + (long)row * a.kv_row_stride + (long)k_off * (2 * D) + h * 64);
-    unsigned off[SLOTS];
+    for (int rb = 0; rb < RB; ++rb) {
+      const int row = min(row0 + rb, a.rows - 1);
+      const int k_off = a.key_off ? a.key_off[row] : 0;                // left-padded prompts: the clip's first cache row
+      n_keys[rb] = pos + 1 - k_off;                                    // keys the row attends to, its own included (>= 1 in a generated step)
+      const int per = (max(n_keys[rb], 1) + FD_WAVES - 1) / FD_WAVES;
+      k_lo[rb] = wave * per;
+      k_hi[rb] = min(n_keys[rb], k_lo[rb] + per);
+      const int k_cached = max(n_keys[rb] - 2, 0);                     // last key that is in the cache (clamp target)
+      // a uniform base (scalar registers) + one 32-bit byte offset per lane and slot, shared by the key and its value
+      const char* Kb = reinterpret_cast<const char*>(a.kv + (long)row * a.kv_row_stride + (long)k_off * (2 * D) + h * 64);
+      unsigned off[SLOTS];
 #pragma unroll
-    for (int i = 0; i < SLOTS; ++i) off[i] = (unsigned)((min(k_lo[rb] + 8 * i + r8, k_cached) * (2 * D) + 8 * c8) * 2);
+      for (int i = 0; i < SLOTS; ++i) off[i] = (unsigned)((min(k_lo[rb] + 8 * i + r8, k_cached) * (2 * D) + 8 * c8) * 2);
 #pragma unroll
-    for (int i = 0; i < SLOTS; ++i) kr[rb][i] = *reinterpret_cast<const half8*>(Kb + off[i]);
+      for (int i = 0; i < SLOTS; ++i) kr[rb][i] = *reinterpret_cast<const half8*>(Kb + off[i]);
 #pragma unroll
-    for (int i = 0; i < SLOTS; ++i) vr[rb][i] = *reinterpret_cast<const half8*>(Kb + 2 * D + off[i]);
+      for (int i = 0; i < SLOTS; ++i) vr[rb][i] = *reinterpret_cast<const half8*>(Kb + 2 * D + off[i]);
+    }
+  };
+  if (!LATE) request_kv();
+  // the weights, in MFMA operand order straight from memory (lane: row n16 of the tile, 16 bytes at k = 32 s + 8 kq)
+  half8 wa[KS];
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (wave < 12) {                          // q | k | v tile `wave`: projection wave / 4, rows 16 (wave % 4) .. + 15 of the head
+    const int p = wave >> 2, j0 = 16 * (wave & 3);
+    const _Float16* wt = a.wqkv + (long)(h * 12 + wave) * KS * 512;     // packed: fused_pack_kernel, kind 0
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) wa[s2] = ldu<half8>(wt, 2u * (unsigned)(512 * s2 + 8 * lane));
+    bias4 = *reinterpret_cast<const f32x4*>(a.bqkv + p * D + h * 64 + j0 + 4 * kq);
   }
-  // q | k | v rows of this head: pass p = q, k, v; 4 rows per wave and pass, 16 lanes per row
-  const int g = lane >> 4, c = lane & 15;
-  const int jrow = 4 * wave + g;                                       // 0 .. 63 inside the head
-  half8 w3[3][PPL];
+  // out-projection (waves 12 - 15): tiles OT (wave - 12) .. + OT - 1 of D / 16, K = the head's 64 columns.  Requested here
+  // with everything else (LATE: behind the attention).
+  constexpr bool LATE_WO = LATE;
+  auto request_wo = [&] {
+    const _Float16* wt = a.wo + (long)(h * (D / 16) + OT * (wave - 12)) * 2 * 512;      // packed, kind 1: this wave's tiles are adjacent
 #pragma unroll
-  for (int p = 0; p < 3; ++p) {
-    const _Float16* wh = a.wqkv + (long)(p * D + h * 64) * D;          // uniform
-#pragma unroll
-    for (int j = 0; j < PPL; ++j) w3[p][j] = ldu<half8>(wh, 2u * (unsigned)(jrow * D + 8 * c + 128 * j));
-  }
-  float b3[3];
-#pragma unroll
-  for (int p = 0; p < 3; ++p) b3[p] = a.bqkv[p * D + h * 64 + jrow];
+    for (int u = 0; u < 2 * OT; ++u) wa[u] = ldu<half8>(wt, 2u * (unsigned)(512 * u + 8 * lane));
+  };
+  if (!LATE_WO && wave >= 12) request_wo();
   __builtin_amdgcn_sched_barrier(0);
   // (2) residual stream + LayerNorm of every row
   par.stage(gb);
-  fin.finish(a.in, par.b, a.rows, row0, h == 0, xs, gb, xn);
-  // (3) q | k | v of the head, every row
+  fin.template finish<XLD>(a.in, par.b, a.rows, row0, h == 0, xs, gb, xn);
+  // (3) q | k | v of the head: D[weight row][step row] on the matrix cores, every row of the step at once
+  if (wave < 12) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int rb = 0; rb < RB; ++rb) {
-    half8 xp[PPL];
-#pragma unroll
-    for (int j = 0; j < PPL; ++j) xp[j] = *reinterpret_cast<const half8*>(xn + rb * D + 8 * c + 128 * j);
-    float acc[3];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      float v = 0.f;
-#pragma unroll
-      for (int j = 0; j < PPL; ++j) v = dot8(w3[p][j], xp[j], v);
-      acc[p] = sum16(v) + b3[p];
-    }
-    if (c == 0) {
-      q_s[rb][jrow] = acc[0];
-      kv_new[rb][jrow] = (_Float16)acc[1];
-      kv_new[rb][64 + jrow] = (_Float16)acc[2];
+    for (int s2 = 0; s2 < KS; ++s2)
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[s2], *reinterpret_cast<const half8*>(xn + n16 * XLD + 32 * s2 + 8 * kq), acc, 0, 0, 0);
+    const int p = wave >> 2, j0 = 16 * (wave & 3) + 4 * kq;          // this lane: row n16 of the step, outputs j0 .. j0 + 3 of projection p
+    if (p == 0) {
+      *reinterpret_cast<f32x4*>(&q_s[n16][j0]) = acc + bias4;
+    } else {
+      const f32x4 v = acc + bias4;
+      *reinterpret_cast<half4v*>(&kv_new[n16][64 * (p - 1) + j0]) = half4v{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
     }
   }
-  HeadOut<D> ho;
-  ho.request(a.wo, h * 64);                                            // in flight during the attention, in the registers the q | k | v weights leave
+  if (LATE) { __builtin_amdgcn_sched_barrier(0); request_kv(); }
   fd_bar();
   // the cache rows of this position: 8 + 8 sixteen-byte pieces per row
   if (tid < 16 * RB) {
@@ -397,11 +425,23 @@ __global__ __launch_bounds__(FD_THREADS) void fused_self_kernel(FusedSelfArgs a)
       kr[rb][i] = from_cache ? kr[rb][i] : kn;
       vr[rb][i] = from_cache ? vr[rb][i] : vn;
     }
-    fd_attend<SLOTS>(kr[rb], vr[rb], q_s[rb], k_lo[rb], k_hi[rb], a.attn16, part_o, part_m, part_l, att_h[rb], [] {}, [] {});
+    fd_attend<SLOTS, false>(kr[rb], vr[rb], q_s[rb], k_lo[rb], k_hi[rb], a.attn16, part_o[rb], part_m[rb], part_l[rb], att_h[rb], [] {}, [] {});
   }
-  // (5) this head's share of the output projection, every row
+  fd_bar();                                                            // the partials of every row: one barrier, then row r's merge on wave r
+  if (wave < RB) fd_merge(part_o[wave], part_m[wave], part_l[wave], a.attn16, att_h[wave]);
+  fd_bar();
+  // (5) this head's share of the output projection, every row: waves 12 - 15
+  if (wave >= 12) {
+    if (LATE_WO) request_wo();
 #pragma unroll
-  for (int rb = 0; rb < RB; ++rb) ho.finish(att_h[rb], po + rb * D);
+    for (int j = 0; j < OT; ++j) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[2 * j + s2], *reinterpret_cast<const half8*>(&att_h[n16][32 * s2 + 8 * kq]), acc, 0, 0, 0);
+      if (n16 < RB) *reinterpret_cast<f32x4*>(po + n16 * D + 16 * (OT * (wave - 12) + j) + 4 * kq) = acc;
+    }
+  }
   fd_bar();
   fd_store_partial<D, RB>(po, a.part_out, a.rows, row0, h);
 }
@@ -491,61 +531,60 @@ __global__ __launch_bounds__(FD_THREADS) void fused_cross_kernel(FusedCrossArgs 
 }
 
 // ---- MLP block: 128 hidden units of RB rows ---------------------------------------------------------------------------
-// RB rows share the chunk's weights in registers and go through the block together (see fused_self_kernel).
+// RB rows share the chunk's weights in registers and go through the block together (see fused_self_kernel): waves 0 - 7
+// hold one 16-row tile of fc1 each over all of K, waves 8 - 15 the D / 16 tiles of fc2 over the chunk's 128 columns.
 template <int D, int NP, int RB>
 __global__ __launch_bounds__(FD_THREADS) void fused_mlp_kernel(FusedMlpArgs a) {
-  constexpr int PPL = D / 128;
-  constexpr int NP2 = D / 64;               // passes of 64 output rows over fc2's D rows
+  constexpr int KS = D / 32;                // k-steps of fc1 = weight registers (half8) per wave
+  constexpr int XLD = D + 8;
+  constexpr int T2 = D / 128;               // fc2 tiles per wave (waves 8 - 15), four k-steps each
+  static_assert(4 * T2 == KS, "both roles hold the same number of weight registers");
   __shared__ __attribute__((aligned(16))) float xs[RB * D];
   __shared__ __attribute__((aligned(16))) float gb[2 * D];      // LayerNorm gamma | beta
-  __shared__ __attribute__((aligned(16))) _Float16 xn[RB * D];
-  __shared__ __attribute__((aligned(16))) _Float16 hh[RB][128];
+  __shared__ __attribute__((aligned(16))) _Float16 xn[FD_NB * XLD];
+  __shared__ __attribute__((aligned(16))) _Float16 hh[FD_NB][136];
   __shared__ __attribute__((aligned(16))) float po[RB * D];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ch = blockIdx.x, row0 = blockIdx.y * RB;
+  const int n16 = lane & 15, kq = lane >> 4;
   FdParams<D, NP> par;
   par.request(a.in);
   FdInput<D, NP, RB> fin;
   fin.request(a.in, a.rows, row0);
-  const int g = lane >> 4, c = lane & 15;
-  const int jrow = 4 * wave + g;
-  half8 w1[2][PPL], w2[NP2];
-  float b1[2];
+  half8 wa[KS];
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (wave < 8) {                           // fc1: hidden units 128 ch + 16 wave .. + 15
+    const _Float16* wt = a.w1 + (long)(ch * 8 + wave) * KS * 512;       // packed, kind 2
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const _Float16* wh = a.w1 + (long)(128 * ch + 64 * p) * D;          // uniform
+    for (int s2 = 0; s2 < KS; ++s2) wa[s2] = ldu<half8>(wt, 2u * (unsigned)(512 * s2 + 8 * lane));
+    bias4 = *reinterpret_cast<const f32x4*>(a.b1 + 128 * ch + 16 * wave + 4 * kq);
+  } else {                                  // fc2: output rows 16 (T2 (wave - 8) + j) .. + 15, the chunk's 128 columns
+    const _Float16* wt = a.w2 + (long)(ch * (D / 16) + T2 * (wave - 8)) * 4 * 512;      // packed, kind 3
 #pragma unroll
-    for (int j = 0; j < PPL; ++j) w1[p][j] = ldu<half8>(wh, 2u * (unsigned)(jrow * D + 8 * c + 128 * j));
-    b1[p] = a.b1[128 * ch + 64 * p + jrow];
+    for (int u = 0; u < 4 * T2; ++u) wa[u] = ldu<half8>(wt, 2u * (unsigned)(512 * u + 8 * lane));
   }
-#pragma unroll
-  for (int p = 0; p < NP2; ++p)
-    w2[p] = ldu<half8>(a.w2 + 128 * ch, 2u * (unsigned)((64 * p + jrow) * (4 * D) + 8 * c));
   __builtin_amdgcn_sched_barrier(0);
   par.stage(gb);
-  fin.finish(a.in, par.b, a.rows, row0, ch == 0, xs, gb, xn);
+  fin.template finish<XLD>(a.in, par.b, a.rows, row0, ch == 0, xs, gb, xn);
+  if (wave < 8) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int rb = 0; rb < RB; ++rb) {
-    half8 xp[PPL];
-#pragma unroll
-    for (int j = 0; j < PPL; ++j) xp[j] = *reinterpret_cast<const half8*>(xn + rb * D + 8 * c + 128 * j);
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      float v = 0.f;
-#pragma unroll
-      for (int j = 0; j < PPL; ++j) v = dot8(w1[p][j], xp[j], v);
-      v = sum16(v) + b1[p];
-      if (c == 0) hh[rb][64 * p + jrow] = (_Float16)gelu_ggml(v);
-    }
+    for (int s2 = 0; s2 < KS; ++s2)
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[s2], *reinterpret_cast<const half8*>(xn + n16 * XLD + 32 * s2 + 8 * kq), acc, 0, 0, 0);
+    const f32x4 v = acc + bias4;
+    *reinterpret_cast<half4v*>(&hh[n16][16 * wave + 4 * kq]) =
+        half4v{(_Float16)gelu_ggml(v[0]), (_Float16)gelu_ggml(v[1]), (_Float16)gelu_ggml(v[2]), (_Float16)gelu_ggml(v[3])};
   }
   fd_bar();
+  if (wave >= 8) {
 #pragma unroll
-  for (int rb = 0; rb < RB; ++rb) {
-    const half8 hp = *reinterpret_cast<const half8*>(&hh[rb][8 * c]);
+    for (int j = 0; j < T2; ++j) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int p = 0; p < NP2; ++p) {
-      const float v = sum16(dot8(w2[p], hp, 0.f));
-      if (c == 0) po[rb * D + 64 * p + jrow] = v;
+      for (int s2 = 0; s2 < 4; ++s2)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[4 * j + s2], *reinterpret_cast<const half8*>(&hh[n16][32 * s2 + 8 * kq]), acc, 0, 0, 0);
+      if (n16 < RB) *reinterpret_cast<f32x4*>(po + n16 * D + 16 * (T2 * (wave - 8) + j) + 4 * kq) = acc;
     }
   }
   fd_bar();
@@ -569,15 +608,53 @@ __global__ __launch_bounds__(FD_THREADS) void fused_finish_kernel(FusedFinishArg
     *reinterpret_cast<half8*>(a.y + (long)row * D + 8 * threadIdx.x) = *reinterpret_cast<const half8*>(xn + 8 * threadIdx.x);
 }
 
+// dst[((g * tiles + t) * ksteps + s) * 512 + lane * 8 + e] = W[row0(g, t) + (lane & 15)][col0(g, s) + 8 (lane >> 4) + e]:
+// the weights in the order the MFMA A operand wants them -- one wave request = one contiguous KB (the same bytes read row
+// by row are sixteen 64-byte segments per request, and a one-row step waited 1.8 us longer per launch for them).
+// kind 0: q | k | v of a head (g = head; tile t = projection t / 4, head rows 16 (t % 4) ..; all of K)
+// kind 1: out-projection slice of a head (g = head; tile = 16 output rows; K = the head's 64 columns)
+// kind 2: fc1 chunk (g = chunk of 128 hidden units; tile = 16 of them; all of K)
+// kind 3: fc2 chunk (g = chunk; tile = 16 output rows; K = the chunk's 128 columns)
+__global__ __launch_bounds__(256) void fused_pack_kernel(const _Float16* __restrict__ W, _Float16* __restrict__ dst, int D, int kind,
+                                                         long pieces) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= pieces) return;
+  const int lane = (int)(idx & 63);
+  long u = idx >> 6;
+  int tiles, ksteps;
+  switch (kind) {
+    case 0: tiles = 12; ksteps = D / 32; break;
+    case 1: tiles = D / 16; ksteps = 2; break;
+    case 2: tiles = 8; ksteps = D / 32; break;
+    default: tiles = D / 16; ksteps = 4; break;
+  }
+  const int s2 = (int)(u % ksteps); u /= ksteps;
+  const int t = (int)(u % tiles);
+  const int g = (int)(u / tiles);
+  long row, col, ld;
+  switch (kind) {
+    case 0: row = (long)(t >> 2) * D + g * 64 + 16 * (t & 3); col = 32 * s2; ld = D; break;
+    case 1: row = 16 * t; col = g * 64 + 32 * s2; ld = D; break;
+    case 2: row = 128 * g + 16 * t; col = 32 * s2; ld = D; break;
+    default: row = 16 * t; col = 128 * g + 32 * s2; ld = 4L * D; break;
+  }
+  const half8 v = *reinterpret_cast<const half8*>(W + (row + (lane & 15)) * ld + col + 8 * (lane >> 4));
+  *reinterpret_cast<half8*>(dst + idx * 8) = v;
+}
+
 // Rows per workgroup: one while the launch stays near one workgroup per CU (256 of them), else two (self block; with
 // four key slots per wave and row there are no registers for a second row) or two / four / eight (MLP block).
 template <int D, int NP>
 hipError_t self_launch(const FusedSelfArgs& a, hipStream_t s) {
   const int slots = a.max_keys <= 128 ? 1 : a.max_keys <= 256 ? 2 : 4;
-  const bool two = slots <= 2 && (D / 64) * a.rows > 256 + 64;
-  const dim3 block(FD_THREADS), grid(D / 64, two ? (a.rows + 1) / 2 : a.rows);
+  // rows per workgroup: registers hold RB x slots x 8 of keys and values beside the weights
+  const int rb_max = slots == 1 ? (D > 384 ? 2 : 4) : (slots == 2 && D <= 384 ? 2 : 1);
+  int rb = 1;
+  while (rb < rb_max && (D / 64) * ((a.rows + rb - 1) / rb) > 256 + 64) rb *= 2;
+  const dim3 block(FD_THREADS), grid(D / 64, (a.rows + rb - 1) / rb);
 #define FD_SELF(SL, RB) hipLaunchKernelGGL((fused_self_kernel<D, NP, SL, RB>), grid, block, 0, s, a)
-  if (two) { if (slots == 1) FD_SELF(1, 2); else FD_SELF(2, 2); }
+  if (rb == 4) { if constexpr (D <= 384) FD_SELF(1, 4); }
+  else if (rb == 2) { if (slots == 1) FD_SELF(1, 2); else if constexpr (D <= 384) FD_SELF(2, 2); }
   else { if (slots == 1) FD_SELF(1, 1); else if (slots == 2) FD_SELF(2, 1); else FD_SELF(4, 1); }
 #undef FD_SELF
   return hipGetLastError();
@@ -598,6 +675,14 @@ hipError_t mlp_launch(const FusedMlpArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+hipError_t fused_pack_weights(const void* W, void* dst, int D, int kind, hipStream_t s) {
+  const long elems = kind <= 0 ? 3L * D * D : kind == 1 ? (long)D * D : 4L * D * D;
+  const long pieces = elems / 8;
+  hipLaunchKernelGGL(fused_pack_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const _Float16*>(W),
+                     reinterpret_cast<_Float16*>(dst), D, kind, pieces);
+  return hipGetLastError();
+}
 
 bool fused_decode_supported(int D, int max_keys, int n_audio_ctx) {
   return (D == 384 || D == 512) && max_keys > 0 && max_keys <= 512 && n_audio_ctx <= FD_WAVES * FX_SLOTS * 8;

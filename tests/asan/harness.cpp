@@ -41,6 +41,7 @@ hipError_t dequant_blocks(const void*, int, long, int, void* dst, int f16, const
 hipError_t embed_tokens_f32(const int*, const float*, const float*, int, const int*, float*, int, int, hipStream_t, int, const int*) { return hipSuccess; }
 hipError_t embed_tokens_q(const int*, const void*, int, const float*, int, const int*, float*, int, int, hipStream_t, int, const int*) { return hipSuccess; }
 bool fused_decode_supported(int, int, int) { return false; }
+hipError_t fused_pack_weights(const void*, void*, int, int, hipStream_t) { return hipSuccess; }
 hipError_t fused_self(const FusedSelfArgs&, bool, hipStream_t) { return hipSuccess; }
 hipError_t fused_cross(const FusedCrossArgs&, hipStream_t) { return hipSuccess; }
 hipError_t fused_mlp(const FusedMlpArgs&, hipStream_t) { return hipSuccess; }
