@@ -106,8 +106,8 @@ pub struct crispy_asr_opts {
     pub logprob_thold: c_float,
     pub no_speech_thold: c_float,
     pub best_of: c_int,
-    /// ABI 3: whisper_full_params.suppress_nst, prompt_tokens / prompt_n_tokens, !no_context, and the beam width this
-    /// library does not implement (0 or 1).
+    /// ABI 3: whisper_full_params.suppress_nst, prompt_tokens / prompt_n_tokens, !no_context, and beam_search.beam_size
+    /// (> 1: the BEAM_SEARCH strategy, at most 8 decoders).
     pub suppress_nst: c_int,
     pub initial_prompt: *const c_int,
     pub n_initial_prompt: c_int,
@@ -489,7 +489,7 @@ mod speech_model {
         // transcribe]: a set language becomes its token, an unset one is detected per chunk, as whisper.cpp does.
         // (What transcribe-rs may set on whisper.cpp beyond these two -- suppress_nst, an initial prompt, no_context = false --
         // has a field in `crispy_asr_opts` since ABI 3; a host that knows the engine's settings passes them through
-        // `transcribe_chunk(audio, Some(&opts))`.  Beam search is not built: `beam_size` > 1 is refused.)
+        // `transcribe_chunk(audio, Some(&opts))`; so does `beam_size` for an engine configured for BeamSearch.)
         fn transcribe(&mut self, audio: &[f32], options: &TranscribeOptions) -> Result<TranscriptionResult, Box<dyn std::error::Error + Send + Sync>> {
             let mut o = crispy_asr_opts::default();
             if let Some(code) = options.language.as_deref() {

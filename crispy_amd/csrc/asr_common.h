@@ -259,8 +259,20 @@ struct TsPickArgs {
   const float* temperature;            // device scalar
   const double* u_all;                 // [steps][B]
   StepFuse fuse;
+  // beam search (whisper_sample_token_topk [UPSTREAM-RECALL]): n_cand > 0 -- every row that is not done draws n_cand ids
+  // from ITS distribution with the variates u_all[b][0 .. n_cand) and records them (id, log-probability, most probable
+  // timestamp) in cand_*[b][n_cand]; nothing is committed: which candidate a decoder continues with is the host's
+  // decision (whisper_api.cpp: decode_beam), which writes the rows' states back before the next step.
+  int n_cand;
+  int* cand_tok; float* cand_plog; int* cand_tid;
 };
+constexpr int TS_MAX_CAND = 8;          // = WHISPER_MAX_DECODERS
 hipError_t ts_pick(const TsPickArgs& a, int B, hipStream_t s);
+// Beam search: row r of a self K | V cache [layers][rows][row_bytes] continues the sequence of row parent[r] -- the bytes
+// [off, off + len) of every layer's row parent[r] become row r's (rows with parent[r] == r are left alone).  Two launches
+// through `scratch` [layers][rows][len] (a row may be somebody's parent and somebody else's child).  len % 16 == 0.
+hipError_t beam_kv_reorder(void* kv, void* scratch, const int* parent_dev, int layers, int rows, long row_bytes, long off, long len,
+                           hipStream_t s);
 // p_out[b] = softmax(logits[b])[token] over the whole, unfiltered row (whisper_full's no_speech_prob)
 hipError_t softmax_prob_f32(const float* logits, int V, long ld, int token, float* p_out, int B, hipStream_t s);
 

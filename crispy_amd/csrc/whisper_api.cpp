@@ -162,6 +162,8 @@ struct crispy_asr {
   float* d_temperature = nullptr;            // device scalar
   int* d_row_off = nullptr;                  // [dcap_batch] left padding of every clip's prompt (cache rows)
   const int* cur_row_off = nullptr;          // d_row_off while a window decode is running, else nullptr (decoder_step reads it)
+  void* d_beam_kv = nullptr; size_t beam_kv_bytes = 0;      // beam search: the rows' cache bytes in flight between parents and children
+  int* d_beam_parent = nullptr;              // [dcap_batch]
   int cur_xgroup = 1;                        // rows per audio clip while a window decode is running: the best-of decoders of a clip are
                                              // rows of their own (own self K|V cache) over ONE cross K|V (decode_ts)
   void drop_graphs() {
@@ -357,6 +359,8 @@ void free_dec_ws(crispy_asr* h) {
   if (h->d_plog_all) { (void)hipFree(h->d_plog_all); h->d_plog_all = nullptr; }
   if (h->d_nosp) { (void)hipFree(h->d_nosp); h->d_nosp = nullptr; }
   if (h->d_u_all) { (void)hipFree(h->d_u_all); h->d_u_all = nullptr; }
+  if (h->d_beam_kv) { (void)hipFree(h->d_beam_kv); h->d_beam_kv = nullptr; h->beam_kv_bytes = 0; }
+  if (h->d_beam_parent) { (void)hipFree(h->d_beam_parent); h->d_beam_parent = nullptr; }
   if (h->d_temperature) { (void)hipFree(h->d_temperature); h->d_temperature = nullptr; }
   if (h->d_row_off) { (void)hipFree(h->d_row_off); h->d_row_off = nullptr; }
   for (int i = 0; i < 3; ++i) {
@@ -1040,6 +1044,7 @@ int reserve_dec(crispy_asr* h, int batch, int xclips = 0) {
   HIP_TRY(hipMalloc(&h->d_u_all, B * C * sizeof(double)));
   HIP_TRY(hipMalloc(&h->d_temperature, sizeof(float)));
   HIP_TRY(hipMalloc(&h->d_row_off, B * sizeof(int)));
+  HIP_TRY(hipMalloc(&h->d_beam_parent, B * sizeof(int)));
   if (fused_decode_supported((int)dt, 1, (int)Tn)) {
     for (int i = 0; i < 3; ++i) {
       HIP_TRY(hipMalloc(&h->d_fx[i], B * dt * sizeof(float)));
@@ -1146,6 +1151,11 @@ int decoder_step_fused(crispy_asr* h, int rows, hipStream_t s) {
   return CRISPY_OK;
 }
 
+// the self K | V cache of a decode call over `rows` rows holds halves (mode 1, folded path) or floats
+bool self_kv_half(const crispy_asr* h, int rows) {
+  return rows <= SKINNY_MAX_M && h->hp.n_text_state % 128 == 0 && h->enc_precision == 1 && h->dec_max_keys > 0 && h->dec_max_keys <= 512;
+}
+
 // one decoder step for all clips: token ids in h->d_tok; leaves logits in h->d_logits.
 // dev_pos = false: the position is the host value `pos` (prompt tokens).
 // dev_pos = true : the position is read from h->d_counters[0] by the kernels, so the identical launch
@@ -1239,7 +1249,7 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
     float* kv_dst = selfkv + (dev_pos ? 0 : (size_t)pos * 2 * dt);
     // mode 1: the self K|V cache is f16, as whisper.cpp's kv_self is (it aliases the f32 cache: every decode call
     // starts with its own prefill); the projection stores halves, the attention requests all its keys up front
-    const bool kv16 = fold && h->enc_precision == 1 && h->dec_max_keys > 0 && h->dec_max_keys <= 512;
+    const bool kv16 = self_kv_half(h, batch);
     _Float16* selfkv_h = reinterpret_cast<_Float16*>(h->d_selfkv) + l * (size_t)clips * C * 2 * dt;
     self_rows.attn16 = kv16 && h->dec_attn16 ? 1 : 0;
     if (fold) {
@@ -1617,6 +1627,208 @@ int decode_ts(crispy_asr* h, const float* d_enc, int batch, const std::vector<st
     }
     if (nosp_out) nosp_out[b] = nosp[b];
     if (n_out) n_out[b] = n;
+  }
+  return CRISPY_OK;
+}
+
+// std::generate_canonical<double, 53>(std::mt19937) as libstdc++ and libc++ compute it: two draws, (x0 + x1 2^32) / 2^64
+double canonical(std::mt19937& g) {
+  const double x0 = (double)g(), x1 = (double)g();
+  const double u = (x0 + x1 * 4294967296.0) / 18446744073709551616.0;
+  return u < 1.0 ? u : std::nextafter(1.0, 0.0);
+}
+
+// One pass of whisper_full's BEAM_SEARCH strategy over one window per clip [UPSTREAM-RECALL: whisper_full_with_state,
+// whisper_sample_token_topk; restated in oracle/whisper_oracle.py: decode_temperature(beam_size=)].  Every clip has n_dec
+// decoders (rows [c n_dec, (c + 1) n_dec): beam_size of them at temperature 0, best_of above) over ONE cross K | V.  Per step:
+//   * every decoder that is neither completed nor failed DRAWS n_cand ids from its distribution (std::discrete_distribution
+//     over the probabilities the rules leave at this temperature, n_cand variates from the decoder's own generator -- the
+//     device pick kernel in its candidate form) -> candidates (decoder, sequence + id, sum of ALL log-probabilities);
+//   * the clip's candidates are sorted by that sum (descending; ties: decoder index) and dealt to the live decoders in
+//     order, skipping candidates whose token sequence equals the one just dealt (not at the first step); a decoder takes
+//     the candidate's sequence, window state and -- on the device -- the self K | V rows of the decoder it came from;
+//   * completion / failure bookkeeping as in the sampling pass; the next decoder step feeds every live row its last id.
+// The host decides between steps (one round trip per token: this is the strategy's structure, not a captured loop).
+// rng[r]: the generator of row r's decoder; it advances by n_cand variates per step the decoder is live.
+// Outputs as decode_ts: the sequence every decoder ENDS with.
+int decode_beam(crispy_asr* h, const float* d_enc, int n_clips, int n_dec, int n_cand, const std::vector<std::vector<int>>& clip_prompts,
+                int rules, const int* seek, const int* seek_end, int max_new, const unsigned char* mask, const unsigned char* mask_first,
+                float temperature, const std::vector<std::mt19937*>& rng, int* tokens_out, int* tids_out, float* plog_out,
+                float* nosp_out, int* n_out) {
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  const int rows = n_clips * n_dec;
+  if (n_clips < 1 || n_dec < 1 || n_dec > TS_MAX_CAND || n_cand < 1 || n_cand > TS_MAX_CAND || (int)clip_prompts.size() != n_clips ||
+      (int)rng.size() != rows)
+    return fail(CRISPY_ERR_INVALID_ARG, "beam decode: %d clips x %d decoders, %d candidates", n_clips, n_dec, n_cand);
+  int n_rows = 0;
+  for (const auto& p : clip_prompts) {
+    if (p.empty()) return fail(CRISPY_ERR_INVALID_ARG, "beam decode: empty prompt");
+    for (int t : p)
+      if (t < 0 || t >= h->hp.n_vocab) return fail(CRISPY_ERR_INVALID_ARG, "beam decode: prompt token %d out of range", t);
+    n_rows = std::max(n_rows, (int)p.size());
+  }
+  if (n_rows + max_new > h->hp.n_text_ctx)
+    return fail(CRISPY_ERR_INVALID_ARG, "beam decode: %d prompt + %d new tokens exceed n_text_ctx %d", n_rows, max_new, h->hp.n_text_ctx);
+  int rc = reserve_dec(h, rows, n_clips);
+  if (rc != CRISPY_OK) return rc;
+  choose_decode_path(h);
+  h->dec_max_keys = n_rows + max_new;
+  const int dt = h->hp.n_text_state, C = h->hp.n_text_ctx, L = (int)h->dec.size();
+  std::vector<int> off(rows), tok_mat((size_t)rows * n_rows, 0);
+  for (int r = 0; r < rows; ++r) {
+    const std::vector<int>& p = clip_prompts[r / n_dec];
+    off[r] = n_rows - (int)p.size();
+    std::copy(p.begin(), p.end(), tok_mat.begin() + (size_t)r * n_rows + off[r]);
+  }
+  HIP_TRY(hipMemcpyAsync(h->d_row_off, off.data(), sizeof(int) * rows, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  struct OffGuard { crispy_asr* h; ~OffGuard() { h->cur_row_off = nullptr; h->cur_xgroup = 1; } } guard{h};
+  h->cur_row_off = h->d_row_off;
+  h->cur_xgroup = n_dec;
+  int pos = 0;
+  rc = prefill(h, d_enc, rows, tok_mat.data(), n_rows, s, &pos);
+  if (rc != CRISPY_OK) return rc;
+  const Special sp = special_tokens(h);
+  HIP_TRY(softmax_prob_f32(h->d_logits, h->hp.n_vocab, logits_ld(h), sp.nosp, h->d_nosp, rows, s));
+  const float t_eff = temperature > 0.f ? temperature : 1.0f;       // temperature 0: the logits as they are (x / 1)
+  HIP_TRY(hipMemcpyAsync(h->d_temperature, &t_eff, sizeof(float), hipMemcpyHostToDevice, s));
+  // the bytes of a row's cache the decoders of a clip can differ in: the generated positions
+  const size_t esz = self_kv_half(h, rows) ? 2 : 4;
+  const size_t row_bytes = (size_t)C * 2 * dt * esz, pos_bytes = (size_t)2 * dt * esz;
+  const size_t need = (size_t)L * rows * (size_t)max_new * pos_bytes;
+  if (need > h->beam_kv_bytes) {
+    if (h->d_beam_kv) (void)hipFree(h->d_beam_kv);
+    h->d_beam_kv = nullptr; h->beam_kv_bytes = 0;
+    HIP_TRY(hipMalloc(&h->d_beam_kv, need));
+    h->beam_kv_bytes = need;
+  }
+  struct Seq {
+    std::vector<int> toks, tids;
+    std::vector<float> plog;
+    double sum_all = 0.0;
+    bool has_ts = false, failed = false, completed = false;
+    int seek_delta = 3000, result_len = 0;
+    TsState st;
+  };
+  std::vector<Seq> seq((size_t)rows);
+  for (int r = 0; r < rows; ++r) {
+    const int c = r / n_dec;
+    seq[r].st = TsState{-1, -1, 0, -1, 0, seek ? seek[c] : 0, seek_end ? seek_end[c] : (1 << 30), 0};
+  }
+  TsPickArgs pa = ts_args(h, rules, mask, mask_first);
+  pa.u_all = h->d_u_all;
+  pa.n_cand = n_cand;
+  pa.cand_tok = h->d_tokens_all; pa.cand_plog = h->d_plog_all; pa.cand_tid = h->d_tids_all;
+  const int delta_min = TS_DELTA_MIN;
+  std::vector<double> u((size_t)rows * n_cand);
+  std::vector<TsState> st((size_t)rows);
+  std::vector<int> c_tok((size_t)rows * n_cand), c_tid((size_t)rows * n_cand), parent((size_t)rows), feed((size_t)rows);
+  std::vector<float> c_plog((size_t)rows * n_cand);
+  struct Cand { int j, k; double sum; };
+  for (int i = 0; i < max_new; ++i) {
+    for (int r = 0; r < rows; ++r) {
+      const bool live = !(seq[r].completed || seq[r].failed);
+      for (int k = 0; k < n_cand; ++k) u[(size_t)r * n_cand + k] = live ? canonical(*rng[r]) : 0.5;
+      st[r] = seq[r].st;
+      st[r].done = live ? 0 : 1;
+    }
+    HIP_TRY(hipMemcpyAsync(h->d_u_all, u.data(), u.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(h->d_ts_state, st.data(), st.size() * sizeof(TsState), hipMemcpyHostToDevice, s));
+    HIP_TRY(ts_pick(pa, rows, s));
+    HIP_TRY(hipMemcpyAsync(c_tok.data(), h->d_tokens_all, c_tok.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(c_tid.data(), h->d_tids_all, c_tid.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(c_plog.data(), h->d_plog_all, c_plog.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    bool moved = false, any_live = false;
+    for (int r = 0; r < rows; ++r) parent[r] = r;
+    for (int c = 0; c < n_clips; ++c) {
+      const int r0 = c * n_dec;
+      std::vector<Cand> cands;
+      for (int j = 0; j < n_dec; ++j) {
+        const Seq& q = seq[r0 + j];
+        if (q.completed || q.failed) continue;
+        for (int k = 0; k < n_cand; ++k) {
+          const size_t x = (size_t)(r0 + j) * n_cand + k;
+          if (c_tok[x] < 0 || c_tok[x] >= h->hp.n_vocab) return fail(CRISPY_ERR_HIP, "beam decode: candidate id %d", c_tok[x]);
+          cands.push_back(Cand{j, k, q.sum_all + (double)c_plog[x]});
+        }
+      }
+      if (cands.empty()) continue;
+      std::stable_sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) {
+        if (a.sum != b.sum) return a.sum > b.sum;
+        return a.j < b.j;
+      });
+      auto tok_of = [&](const Cand& x) { return c_tok[(size_t)(r0 + x.j) * n_cand + x.k]; };
+      auto same = [&](const Cand& a, const Cand& b) {      // whisper_sequence_tokens_equal of the two candidates' sequences
+        return tok_of(a) == tok_of(b) && (a.j == b.j || seq[r0 + a.j].toks == seq[r0 + b.j].toks);
+      };
+      std::vector<Seq> next(seq.begin() + r0, seq.begin() + r0 + n_dec);
+      size_t cur_c = 0;
+      for (int j = 0; j < n_dec; ++j) {
+        if (seq[r0 + j].completed || seq[r0 + j].failed) continue;
+        if (cur_c >= cands.size()) cur_c = 0;
+        const Cand cur = cands[cur_c++];
+        while (cands.size() > cur_c && i > 0 && same(cands[cur_c], cur)) ++cur_c;
+        const size_t x = (size_t)(r0 + cur.j) * n_cand + cur.k;
+        Seq q = seq[r0 + cur.j];
+        q.toks.push_back(c_tok[x]); q.tids.push_back(c_tid[x]); q.plog.push_back(c_plog[x]);
+        q.sum_all = cur.sum;
+        // the rules' view of the sequence (the pick kernel's ts_commit)
+        q.st.prev = q.st.last; q.st.last = c_tok[x]; q.st.n += 1;
+        if (rules == TS_RULES_OPENAI ? c_tok[x] >= sp.beg : c_tok[x] > sp.beg) q.st.last_ts = c_tok[x];
+        next[j] = std::move(q);
+        parent[r0 + j] = r0 + cur.j;
+        moved = moved || cur.j != j;
+      }
+      std::move(next.begin(), next.end(), seq.begin() + r0);
+      // completion / failure of every live decoder on its new last token
+      for (int j = 0; j < n_dec; ++j) {
+        Seq& d = seq[r0 + j];
+        if (d.completed || d.failed) continue;
+        const int t = d.toks.back();
+        const int sk = d.st.seek, se = d.st.seek_end;
+        if (t > sp.beg) {
+          const int sd = 2 * (t - sp.beg);
+          if (d.has_ts && d.seek_delta > sd && d.result_len < i) { d.failed = true; continue; }      // "do not allow to go back in time"
+          d.seek_delta = sd; d.result_len = i + 1; d.has_ts = true;
+        }
+        if (t == h->eot || (d.has_ts && sk + d.seek_delta + delta_min >= se)) {
+          if (d.result_len == 0) {
+            if (sk + d.seek_delta + delta_min >= se) d.result_len = i + 1;
+            else { d.failed = true; continue; }
+          }
+          d.completed = true;
+          continue;
+        }
+        if (i == max_new - 1 && (d.result_len == 0 || d.seek_delta < 1500)) { d.failed = true; continue; }
+        any_live = true;
+      }
+    }
+    if (!any_live || i == max_new - 1) break;
+    if (moved && i > 0) {
+      HIP_TRY(hipMemcpyAsync(h->d_beam_parent, parent.data(), sizeof(int) * rows, hipMemcpyHostToDevice, s));
+      HIP_TRY(beam_kv_reorder(h->d_selfkv, h->d_beam_kv, h->d_beam_parent, L, rows, (long)row_bytes, (long)((size_t)pos * pos_bytes),
+                              (long)((size_t)i * pos_bytes), s));
+    }
+    for (int r = 0; r < rows; ++r) feed[r] = (seq[r].completed || seq[r].failed || seq[r].toks.empty()) ? h->eot : seq[r].toks.back();
+    HIP_TRY(hipMemcpyAsync(h->d_tok, feed.data(), sizeof(int) * rows, hipMemcpyHostToDevice, s));
+    rc = decoder_step(h, rows, pos + i, false, true, s);
+    if (rc != CRISPY_OK) return rc;
+  }
+  std::vector<float> nosp(rows);
+  HIP_TRY(hipMemcpyAsync(nosp.data(), h->d_nosp, nosp.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  for (int r = 0; r < rows; ++r) {
+    const Seq& q = seq[r];
+    const int n = std::min<int>((int)q.toks.size(), max_new);
+    for (int i = 0; i < max_new; ++i) {
+      tokens_out[(size_t)r * max_new + i] = i < n ? q.toks[i] : h->eot;
+      if (tids_out) tids_out[(size_t)r * max_new + i] = i < n ? q.tids[i] : sp.beg;
+      if (plog_out) plog_out[(size_t)r * max_new + i] = i < n ? q.plog[i] : 0.f;
+    }
+    if (nosp_out) nosp_out[r] = nosp[r];
+    if (n_out) n_out[r] = n;
   }
   return CRISPY_OK;
 }
@@ -2067,13 +2279,6 @@ void score_decoder(DecoderPass& d) {
   d.scored = true;
 }
 
-// std::generate_canonical<double, 53>(std::mt19937) as libstdc++ and libc++ compute it: two draws, (x0 + x1 2^32) / 2^64
-double canonical(std::mt19937& g) {
-  const double x0 = (double)g(), x1 = (double)g();
-  const double u = (x0 + x1 * 4294967296.0) / 18446744073709551616.0;
-  return u < 1.0 ? u : std::nextafter(1.0, 0.0);
-}
-
 // segments of one window as whisper_full builds them (oracle: window_segments); times in seconds
 void window_segments(const crispy_asr* h, const int* toks, const int* tids, int n, int beg, int seek, int seek_delta,
                      crispy_asr_result_impl* r) {
@@ -2379,9 +2584,13 @@ int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const si
   if (nb > 0) {
     const Special sp = special_tokens(h);
     const bool timestamps = !(opts && opts->no_timestamps) && sp.beg + 1501 <= h->hp.n_vocab;
-    if (opts && opts->beam_size > 1) {
+    if (opts && (opts->beam_size < 0 || opts->beam_size > TS_MAX_CAND)) {
       cleanup();
-      return fail(CRISPY_ERR_UNSUPPORTED, "crispy_asr_transcribe_batch: beam search (beam_size %d) is not built; 0 or 1", opts->beam_size);
+      return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: beam_size %d; 0 .. %d (WHISPER_MAX_DECODERS)", opts->beam_size, TS_MAX_CAND);
+    }
+    if (opts && opts->beam_size > 1 && !timestamps) {
+      cleanup();
+      return fail(CRISPY_ERR_UNSUPPORTED, "crispy_asr_transcribe_batch: beam search runs inside whisper_full's window loop (timestamps on)");
     }
     if (opts && (opts->n_initial_prompt < 0 || (opts->n_initial_prompt > 0 && !opts->initial_prompt))) {
       cleanup();
@@ -2491,18 +2700,24 @@ int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const si
         if (rc != CRISPY_OK) return rc;
         ts_mask = h->d_ts_mask_nst; ts_mask_first = h->d_ts_mask_first_nst;
       }
+      // whisper.cpp's BEAM_SEARCH strategy (beam_size > 1): beam_size decoders at temperature 0, best_of above, every pass through
+      // decode_beam (candidates drawn per decoder, sorted, dealt; see there); 0 / 1: the GREEDY strategy
+      const int beam = opts && opts->beam_size > 1 ? opts->beam_size : 0;
       std::vector<std::vector<std::mt19937>> rngs(nb);
       for (int k = 0; k < nb; ++k)
-        for (int j = 0; j < best_of; ++j) rngs[k].emplace_back((unsigned)j);
+        for (int j = 0; j < std::max(best_of, beam); ++j) rngs[k].emplace_back((unsigned)j);
       const int n_init = (int)prompt.size();
       const size_t enc_clip = (size_t)h->hp.n_audio_ctx * h->hp.n_audio_state;
       // rows of one fallback decode: whole clips x best_of, within what the fused step kernels take
       const int kLadderRows = FUSED_MAX_ROWS;
       // the decoder workspace for the widest pass of this call, taken once: growing it between the greedy pass and the
       // first fallback pass freed every buffer and dropped the captured steps
-      if (temps.size() > 1 && best_of > 1) {
-        rc = reserve_dec(h, std::max(nb, std::min(nb * best_of, (kLadderRows / best_of) * best_of)), nb);
-        if (rc != CRISPY_OK) return rc;
+      {
+        const int n_wide = std::max(temps.size() > 1 ? best_of : 1, std::max(beam, 1));
+        if (n_wide > 1) {
+          rc = reserve_dec(h, std::max(nb, std::min(nb * n_wide, (kLadderRows / n_wide) * n_wide)), nb);
+          if (rc != CRISPY_OK) return rc;
+        }
       }
       float* d_enc_rep = nullptr;                         // the encoder outputs of a group of fallback clips, gathered (one per clip)
       struct RepGuard { float** p; ~RepGuard() { if (*p) (void)hipFree(*p); } } rep_guard{&d_enc_rep};
@@ -2559,14 +2774,14 @@ int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const si
         for (size_t it = 0; it < temps.size() && !pending.empty(); ++it) {
           const float t_cur = temps[it];
           const bool last_temp = it + 1 == temps.size();
-          const int n_dec = t_cur > 0.f ? best_of : 1;
+          const int n_dec = t_cur > 0.f ? best_of : (beam ? beam : 1);
           std::vector<int> still;
           // Groups of clips decoded together, n_dec rows each (rows [c n_dec, (c + 1) n_dec) of a group are the decoders of its
           // clip c: one cross K|V per clip, decode_ts's xgroup).  At temperature 0 that is every pending clip in one group, one
           // row each, straight off h->w_enc while nothing has dropped out; above it the pending clips x best_of, in groups of
           // at most kLadderRows rows -- ALL of them side by side, not one clip after the other (a batch in
           // which a third of the windows fall back used to decode them one by one, five rows at a time).
-          const int per_group = n_dec == 1 ? (int)pending.size() : std::max(1, kLadderRows / n_dec);
+          const int per_group = n_dec == 1 && !beam ? (int)pending.size() : std::max(1, kLadderRows / n_dec);
           std::vector<std::vector<int>> groups;
           for (size_t g0 = 0; g0 < pending.size(); g0 += (size_t)per_group)
             groups.emplace_back(pending.begin() + g0, pending.begin() + std::min(pending.size(), g0 + (size_t)per_group));
@@ -2590,7 +2805,7 @@ int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const si
               r_seek[r] = seek[k]; r_end[r] = seek_end[k];
             }
             std::vector<double> u;
-            if (t_cur > 0.f) {            // the variates decoder j of clip k would draw, from a copy of ITS generator
+            if (t_cur > 0.f && !beam) {   // the variates decoder j of clip k would draw, from a copy of ITS generator
               u.resize((size_t)max_new * rows);
               for (int r = 0; r < rows; ++r) {
                 std::mt19937 g = rngs[act[grp[r / n_dec]]][r % n_dec];
@@ -2599,9 +2814,23 @@ int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const si
             }
             std::vector<int> toks((size_t)rows * max_new), tids((size_t)rows * max_new), n_out(rows, 0);
             std::vector<float> plog((size_t)rows * max_new), nosp(rows, 0.f);
-            rc = decode_ts(h, d_enc, rows, prompts, TS_RULES_WCPP, r_seek.data(), r_end.data(), max_new, ts_mask,
-                           ts_mask_first, t_cur, t_cur > 0.f ? u.data() : nullptr, toks.data(), tids.data(), plog.data(),
-                           nosp.data(), n_out.data(), n_dec);
+            if (beam) {
+              std::vector<std::vector<int>> clip_prompts((size_t)n_clips);
+              std::vector<int> c_seek(n_clips), c_end(n_clips);
+              std::vector<std::mt19937*> row_rng((size_t)rows);
+              for (int c = 0; c < n_clips; ++c) {
+                const int k = act[grp[c]];
+                clip_prompts[c] = prompts[(size_t)c * n_dec];
+                c_seek[c] = seek[k]; c_end[c] = seek_end[k];
+                for (int j = 0; j < n_dec; ++j) row_rng[(size_t)c * n_dec + j] = &rngs[k][j];
+              }
+              rc = decode_beam(h, d_enc, n_clips, n_dec, beam, clip_prompts, TS_RULES_WCPP, c_seek.data(), c_end.data(), max_new, ts_mask,
+                               ts_mask_first, t_cur, row_rng, toks.data(), tids.data(), plog.data(), nosp.data(), n_out.data());
+            } else {
+              rc = decode_ts(h, d_enc, rows, prompts, TS_RULES_WCPP, r_seek.data(), r_end.data(), max_new, ts_mask,
+                             ts_mask_first, t_cur, t_cur > 0.f ? u.data() : nullptr, toks.data(), tids.data(), plog.data(),
+                             nosp.data(), n_out.data(), n_dec);
+            }
             if (rc != CRISPY_OK) return rc;
             // evaluate: per clip of the group, its n_dec decoders
             for (int c = 0; c < n_clips; ++c) {
@@ -2615,7 +2844,7 @@ int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const si
                 d.plog = plog.data() + (size_t)r * max_new;
                 d.n = n_out[r];
                 replay_decoder(d, max_new, sp.beg, h->eot, seek[k], seek_end[k], delta_min);
-                if (t_cur > 0.f) rngs[k][j].discard(2ull * (unsigned long long)d.n);      // what it drew: two per pick
+                if (t_cur > 0.f && !beam) rngs[k][j].discard(2ull * (unsigned long long)d.n);      // what it drew: two per pick (a beam pass drew from the generators themselves)
               }
               // rank the sequences that did not fail (whisper.cpp: "rank the resulting sequences and select the best one")
               int best = acc[a].have ? acc[a].decoder : 0;      // best_decoder_id survives a pass in which every decoder failed

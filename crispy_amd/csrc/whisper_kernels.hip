@@ -16,6 +16,7 @@
 //   attn_enc_kernel        flash-style non-causal attention, one wave per 32 queries, S^T = K.Q^T so the
 //                          softmax statistics are per lane and P^T feeds the P.V MFMAs from registers.
 //   attn_dec_kernel        one wave per (clip, head): a single query against a KV cache / cross KV.
+#include <algorithm>
 #include <atomic>
 #include "asr_common.h"
 #include "asr_quant.h"
@@ -1398,11 +1399,16 @@ __global__ __launch_bounds__(TS_THREADS) void ts_sample_kernel(TsPickArgs a) {
   __shared__ double s_own[TS_NB][TS_THREADS], s_pre[TS_NB][TS_THREADS];     // a run's sum / what its wave holds in front of it (2 x 56 KB)
   __shared__ int s_tok, s_last;
   __shared__ float s_px;
+  __shared__ int s_ctok[TS_MAX_CAND];
+  __shared__ float s_cpx[TS_MAX_CAND];
+  __shared__ double s_cu[TS_MAX_CAND];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int step = a.fuse.x ? a.fuse.counters[1] : a.step_dev ? *a.step_dev : 0;
   const int pos = a.fuse.x ? a.fuse.counters[0] + 1 : 0;
   TsState st = a.st[b];
+  const int n_cand = a.n_cand;
   if (st.done) {
+    if (n_cand > 0) return;             // beam search: a finished decoder draws nothing
     if (tid == 0) {
       a.tokens_out[b] = a.eot;
       a.tokens_all[(long)step * gridDim.x + b] = a.eot;
@@ -1415,8 +1421,9 @@ __global__ __launch_bounds__(TS_THREADS) void ts_sample_kernel(TsPickArgs a) {
   const float* lg = a.logits + (long)b * a.ld;
   const TsRule rule(a, st);
   const float T = *a.temperature;
-  const double u = a.u_all[(long)step * gridDim.x + b];
+  const double u = n_cand > 0 ? 0.0 : a.u_all[(long)step * gridDim.x + b];
   if (tid == 0) { s_tok = -1; s_last = -1; }
+  if (tid < n_cand) { s_ctok[tid] = -1; s_cu[tid] = a.u_all[(long)b * n_cand + tid]; }
   // ---- pass 1: maxima of the text / special ids and of the timestamps ----
   float tv = -INFINITY, xv = -INFINITY;
   int xi = 0x7fffffff;
@@ -1520,7 +1527,8 @@ __global__ __launch_bounds__(TS_THREADS) void ts_sample_kernel(TsPickArgs a) {
     const int v0 = TS_BLK * jb + TS_E * tid;
     const bool owns_last = glast >= v0 && glast < v0 + TS_E;
     const double lo = before / total, hi = owns_last ? 1.0 : after / total;
-    if (lo < u && u <= hi) {
+    // the walk of this run for one variate
+    auto walk = [&](double uu, int* tok_out, float* px_out) {
       double c = before;
       int pick = -1;
       float px = 0.f;
@@ -1531,14 +1539,36 @@ __global__ __launch_bounds__(TS_THREADS) void ts_sample_kernel(TsPickArgs a) {
         const float p = expf(x - lse_all);
         if (!(p > 0.f)) continue;
         c += (double)p;
-        if (c / total >= u || v == glast) { pick = v; px = x; }
+        if (c / total >= uu || v == glast) { pick = v; px = x; }
       }
       if (pick < 0) { pick = glast; px = lg[glast] / T; }      // (rounding: the run's last id)
-      s_tok = pick;
-      s_px = px;
+      *tok_out = pick;
+      *px_out = px;
+    };
+    if (n_cand > 0) {
+      for (int k = 0; k < n_cand; ++k) {
+        const double uk = s_cu[k];
+        if (lo < uk && uk <= hi) walk(uk, &s_ctok[k], &s_cpx[k]);
+      }
+    } else if (lo < u && u <= hi) {
+      walk(u, &s_tok, &s_px);
     }
   }
   __syncthreads();
+  if (n_cand > 0) {
+    if (tid < n_cand) {
+      int pick = s_ctok[tid];
+      float px = s_cpx[tid];
+      if (pick < 0) {                   // the variate fell between two runs' rounded interval ends: the last id with any probability
+        pick = s_last >= 0 ? s_last : a.eot;
+        px = lg[pick] / T;
+      }
+      a.cand_tok[(long)b * n_cand + tid] = pick;
+      a.cand_plog[(long)b * n_cand + tid] = px - lse_all;
+      a.cand_tid[(long)b * n_cand + tid] = pick >= a.beg ? pick : (max_ts > -INFINITY ? arg_ts : a.beg);
+    }
+    return;
+  }
   if (tid == 0) {
     int pick = s_tok;
     float px = s_px;
@@ -1553,6 +1583,20 @@ __global__ __launch_bounds__(TS_THREADS) void ts_sample_kernel(TsPickArgs a) {
   if (a.fuse.x) {
     __syncthreads();
     step_fuse_tail(a.fuse, s_tok, pos, step, b, tid);
+  }
+}
+
+// beam_kv_reorder: phase 0 gathers the parents' bytes into scratch, phase 1 scatters them into the rows
+__global__ __launch_bounds__(256) void beam_kv_copy_kernel(char* __restrict__ kv, char* __restrict__ scratch, const int* __restrict__ parent,
+                                                           int rows, long row_bytes, long off, long len, int phase) {
+  const int r = blockIdx.x, l = blockIdx.y;
+  const int p = parent[r];
+  if (p == r) return;
+  char* row = kv + ((long)l * rows + (phase == 0 ? p : r)) * row_bytes + off;
+  char* tmp = scratch + ((long)l * rows + r) * len;
+  for (long x = 16L * (blockIdx.z * 256 + threadIdx.x); x < len; x += 16L * 256 * gridDim.z) {
+    if (phase == 0) *reinterpret_cast<uint4*>(tmp + x) = *reinterpret_cast<const uint4*>(row + x);
+    else *reinterpret_cast<uint4*>(row + x) = *reinterpret_cast<const uint4*>(tmp + x);
   }
 }
 
@@ -1792,7 +1836,19 @@ hipError_t softmax_prob_f32(const float* logits, int V, long ld, int token, floa
   return hipGetLastError();
 }
 
+hipError_t beam_kv_reorder(void* kv, void* scratch, const int* parent_dev, int layers, int rows, long row_bytes, long off, long len,
+                           hipStream_t s) {
+  if (len <= 0) return hipSuccess;
+  if (len % 16 != 0 || off % 16 != 0 || row_bytes % 16 != 0 || off + len > row_bytes) return hipErrorInvalidValue;
+  const unsigned z = (unsigned)std::min<long>(16, (len + 16 * 256 - 1) / (16 * 256));
+  for (int phase = 0; phase < 2; ++phase)
+    hipLaunchKernelGGL(beam_kv_copy_kernel, dim3(rows, layers, z), dim3(256), 0, s, reinterpret_cast<char*>(kv),
+                       reinterpret_cast<char*>(scratch), parent_dev, rows, row_bytes, off, len, phase);
+  return hipGetLastError();
+}
+
 hipError_t ts_pick(const TsPickArgs& a, int B, hipStream_t s) {
+  if (a.n_cand < 0 || a.n_cand > TS_MAX_CAND || (a.n_cand > 0 && !(a.u_all && a.cand_tok && a.cand_plog && a.cand_tid))) return hipErrorInvalidValue;
   if (a.u_all) {
     if (!a.temperature || a.V > TS_BLK * TS_NB) return hipErrorInvalidValue;      // a thread's ids live in TS_NB x TS_E registers
     hipLaunchKernelGGL(ts_sample_kernel, dim3(B), dim3(TS_THREADS), 0, s, a);

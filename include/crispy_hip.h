@@ -429,8 +429,12 @@ typedef struct crispy_asr_opts {
                             ended with is where this call's first window starts (a recording transcribed chunk by chunk
                             through one engine).  Single-chunk calls only (batch == 1); 0 = whisper.cpp's default
                             (no_context = true: every call starts clean). */
-  int beam_size;         /* whisper.cpp's BEAM_SEARCH strategy at temperature 0 is NOT built: must be 0 or 1
-                            (CRISPY_ERR_UNSUPPORTED otherwise) -- INTEGRATION.md, "Behavioural differences". */
+  int beam_size;         /* > 1: whisper.cpp's BEAM_SEARCH strategy [UPSTREAM-RECALL: whisper_full_with_state,
+                            whisper_sample_token_topk] -- beam_size decoders per window at temperature 0 (best_of above), every
+                            live decoder drawing beam_size candidate ids per step from its distribution, candidates sorted by
+                            the sum of their log-probabilities and dealt to the decoders without repeating a sequence.  One
+                            host round trip per token.  0 | 1: the GREEDY strategy.  At most 8 (WHISPER_MAX_DECODERS); needs
+                            timestamps (no_timestamps = 1 with beam_size > 1: CRISPY_ERR_UNSUPPORTED). */
 } crispy_asr_opts;
 
 /* One segment of the result (managers/transcription.rs:223-233: `seg.start`, `seg.end`, `seg.text`),

@@ -539,11 +539,17 @@ def sequence_score(toks, plogs, result_len, length_penalty=-1.0):
 
 
 def decode_temperature(dc, prompt, sp, rules, n_max, seek, seek_end, t_cur, n_dec, rngs, params, suppress=None,
-                       suppress_first=None, no_timestamps=False):
+                       suppress_first=None, no_timestamps=False, beam_size=0):
     """One iteration of whisper_full's temperature ladder over one window: the prompt, then `n_dec` decoders that share
     it (1 at temperature 0, best_of above) sampling in lock step, each with whisper.cpp's completion / failure
     bookkeeping; afterwards the sequences are scored and the best one that did not fail is chosen.
     `dc`: a fresh DecoderCache (fork() gives every further decoder its own copy after the prompt).
+    beam_size > 1: the BEAM_SEARCH strategy [UPSTREAM-RECALL: whisper_full_with_state + whisper_sample_token_topk] -- every
+    live decoder DRAWS beam_size ids from its distribution (std::discrete_distribution over the probabilities, its own
+    generator: in whisper.cpp >= 1.5 the "top-k" are samples, the partial sort's result is unused); the candidates
+    (decoder, sequence + id) are sorted by the sum of ALL their log-probabilities (descending; ties: decoder index) and
+    dealt to the live decoders in order, a candidate whose token sequence equals the one just dealt being skipped except at
+    the first step; the decoder continues from the KV cache of the decoder its candidate came from.
     Returns dict(decoders=[...], best=index or None, no_speech_prob)."""
     beg, eot = sp["beg"], sp["eot"]
     delta_min = params["delta_min"]
@@ -555,11 +561,42 @@ def decode_temperature(dc, prompt, sp, rules, n_max, seek, seek_end, t_cur, n_de
     decs = []
     for j in range(n_dec):
         decs.append(dict(dc=dc if j == 0 else None, toks=[], tids=[], plogs=[], margins=[], has_ts=False,
-                         seek_delta=3000, result_len=0, failed=False, completed=False, lg=lg0, score=None))
+                         seek_delta=3000, result_len=0, failed=False, completed=False, lg=lg0, score=None, sum_all=0.0))
     for j in range(1, n_dec):
         decs[j]["dc"] = dc.fork()
     for i in range(n_max):
-        for j, d in enumerate(decs):
+        if beam_size > 1:
+            cands = []
+            for j, d in enumerate(decs):
+                if d["completed"] or d["failed"]:
+                    continue
+                ml, lp, tid = process_logits(d["lg"], d["toks"], sp, rules, suppress, suppress_first,
+                                             params["max_initial_ts"], t_cur)
+                pr = np.where(np.isfinite(lp), np.exp(lp), 0.0)
+                for _ in range(beam_size):
+                    t, gap = sample_index(pr, rngs[j].canonical())
+                    # whisper_token_data::plog is a float; sum_logprobs_all a double
+                    cands.append(dict(j=j, t=t, plog=float(np.float32(lp[t])), tid=tid if t < beg else t, gap=gap,
+                                      sum_all=d["sum_all"] + float(np.float32(lp[t]))))
+            cands.sort(key=lambda c: (-c["sum_all"], c["j"]))          # (stable: candidates that tie in both keep their draw order)
+            live = [j for j, d in enumerate(decs) if not (d["completed"] or d["failed"])]
+            new, cur_c = {}, 0
+            for j in live:
+                if cur_c >= len(cands):
+                    cur_c = 0
+                cur = cands[cur_c]
+                cur_c += 1
+                cur_toks = decs[cur["j"]]["toks"] + [cur["t"]]
+                while len(cands) > cur_c and i > 0 and decs[cands[cur_c]["j"]]["toks"] + [cands[cur_c]["t"]] == cur_toks:
+                    cur_c += 1
+                src = decs[cur["j"]]
+                new[j] = dict(dc=src["dc"].fork(), toks=cur_toks, tids=src["tids"] + [cur["tid"]],
+                              plogs=src["plogs"] + [cur["plog"]], margins=src["margins"] + [cur["gap"]],
+                              has_ts=src["has_ts"], seek_delta=src["seek_delta"], result_len=src["result_len"], failed=False,
+                              completed=False, lg=None, score=None, sum_all=cur["sum_all"], parent=cur["j"])
+            for j in live:
+                decs[j] = new[j]
+        for j, d in enumerate(decs if beam_size <= 1 else []):       # GREEDY strategy: one pick per live decoder
             if d["completed"] or d["failed"]:
                 continue
             ml, lp, tid = process_logits(d["lg"], d["toks"], sp, rules, suppress, suppress_first,
@@ -574,6 +611,7 @@ def decode_temperature(dc, prompt, sp, rules, n_max, seek, seek_end, t_cur, n_de
                 d["margins"].append(gap)
             d["toks"].append(t)
             d["plogs"].append(float(lp[t]))
+            d["sum_all"] += float(lp[t])
             d["tids"].append(tid if t < beg else t)
         for j, d in enumerate(decs):
             if d["completed"] or d["failed"]:
@@ -648,7 +686,8 @@ def non_speech_token_ids(vocab):
 def whisper_full(weights, hp, mel_window, n_samples, prompt, rules, token_text, params=None, n_max=None, suppress=None,
                  suppress_first=None, eot=None, max_windows=1501, f16=False, prev_text=True, decoder_kw=None, encoder=None,
                  initial_prompt=None, past0=None, state=None):
-    """whisper_full_with_state over one chunk [UPSTREAM-RECALL], greedy strategy: the seek loop, and per window the
+    """whisper_full_with_state over one chunk [UPSTREAM-RECALL], greedy strategy (params["beam_size"] > 1: BEAM_SEARCH, see
+    decode_temperature): the seek loop, and per window the
     temperature ladder `temperature, + temperature_inc, .. <= 1.0` -- one greedy decoder at 0, `best_of` sampling
     decoders above; a window's result is accepted unless its best decoder failed (EOT before a timestamp away from the
     end of the audio, repetition to the token limit, entropy of the last 32 tokens below `entropy_thold`) or its average
@@ -678,7 +717,9 @@ def whisper_full(weights, hp, mel_window, n_samples, prompt, rules, token_text, 
             temps.append(float(t))
             t = np.float32(t + np.float32(P["temperature_inc"]))
     n_best = max(1, int(P["best_of"]))
-    rngs = [MT19937(j) for j in range(n_best)]
+    beam = int(P.get("beam_size", 0))
+    beam = beam if beam > 1 else 0                 # BEAM_SEARCH strategy: beam decoders at temperature 0, best_of above
+    rngs = [MT19937(j) for j in range(max(n_best, beam))]
     prompt = list(prompt)
     past = list(initial_prompt or []) + list(past0 or [])
     no_ts = sp["not_"] in prompt
@@ -691,7 +732,7 @@ def whisper_full(weights, hp, mel_window, n_samples, prompt, rules, token_text, 
         enc = encoder(mel) if encoder is not None else (encoder_forward_f16 if f16 else encoder_forward)(weights, hp, mel)
         best_id, its, last = 0, [], None
         for it, t_cur in enumerate(temps):
-            n_dec = n_best if t_cur > 0.0 else 1
+            n_dec = n_best if t_cur > 0.0 else (beam or 1)
             p = list(prompt)
             if prev_text and past and t_cur < 0.5 and P["n_max_text_ctx"] > 0:
                 n_take = min(P["n_max_text_ctx"], hp.n_text_ctx // 2, len(past), hp.n_text_ctx - n_max - len(prompt) - 1)
@@ -699,7 +740,7 @@ def whisper_full(weights, hp, mel_window, n_samples, prompt, rules, token_text, 
                     p = [sp["prev"]] + past[len(past) - n_take:] + p
             dc = DecoderCache(weights, hp, enc, f16=f16, **(decoder_kw or {}))
             r = decode_temperature(dc, p, sp, rules, n_max, seek, seek_end, t_cur, n_dec, rngs, P, suppress,
-                                   suppress_first, no_ts)
+                                   suppress_first, no_ts, beam_size=beam)
             r["temperature"], r["prompt"] = t_cur, p
             its.append(r)
             if r["best"] is not None:

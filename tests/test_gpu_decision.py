@@ -422,3 +422,56 @@ def test_non_speech_suppression_initial_prompt_and_carried_context(oracle, tmp_p
                                            initial_prompt=init)
     assert clean == [t for t in rk if t != EOT] and len(wins[0]["prompt"]) == 1 + len(init) + 3
     eng.close()
+
+
+def test_beam_search_on_a_scripted_model(oracle, tmp_path_factory):
+    """whisper.cpp's BEAM_SEARCH strategy (crispy_asr_opts.beam_size = 3) through `crispy_asr_transcribe`
+    on the ladder model: per step every live decoder draws three ids from its distribution (the device pick kernel in its
+    candidate form, variates from the decoder's own MT19937), the host sorts the clip's candidates by the sum of all their
+    log-probabilities and deals them out without repeating a sequence, and the self K|V rows follow the sequences on the
+    device.  Window 1 (bare prompt): the three beams hold the X and the Y reading of the near tie, the X reading wins on its
+    score; window 2 (conditioned on the text so far: one token 40 times) fails the entropy check at temperatures 0 .. 0.4
+    -- beam passes with best_of = 5 decoders above 0 -- and passes at 0.6 without the past; the last window is short.
+    Product == oracle: tokens, segments, per window the temperature, the winning decoder and the statistics -- which also
+    pins how many variates every generator has drawn by then.  Then the same clip inside a batch, and mode 1 == itself
+    across batch compositions."""
+    from crispy_amd import synth_audio
+    from crispy_amd.asr import WhisperEngine, transcribe_batch
+    from crispy_amd.whisper_weights import HParams
+    from tests.scripted_model import script_rows, scripted_whisper_weights
+    hp = HParams.tiny()
+    sp, BEG, EOT = _scripts(hp)
+    X, Y, REP = 1234, 2345, 777
+    beta = 1.0 - 1.0 * np.sqrt(2.0) / hp.n_text_state
+    rows = script_rows(2, [BEG, 1001, [(X, 1.0), (Y, beta)], 1003, BEG + 300, BEG + 300, EOT])
+    rows.update(script_rows(9, [BEG] + [REP] * 40 + [BEG + 100, BEG + 100, EOT]))
+    W = scripted_whisper_weights(hp, rows, gain=100.0)
+    eng = WhisperEngine(_engine_file(tmp_path_factory, hp, W, "beam"))
+    x = synth_audio.clip16k_np(80, 16000 * 13)
+    text, segs, toks = eng.transcribe_segments(x, language_token=sp["lang0"], beam_size=3)
+    wins = eng.last_windows
+    rsegs, rkept, rwins = _ref(W, hp, x.size, eng, 0, params=dict(beam_size=3))
+    first = rwins[0]["iterations"][0]["decoders"]
+    assert len(first) == 3 and {tuple(d["toks"][:3]) for d in first} == {(BEG, 1001, X), (BEG, 1001, Y)}      # both readings are held
+    assert min(min(d["margins"]) for w in rwins for it in w["iterations"] for d in it["decoders"]) > 1e-4       # the draws are resolvable
+    assert any(it["temperature"] > 0 and len(it["decoders"]) == 5 for w in rwins for it in w["iterations"])
+    assert toks == [t for t in rkept if t != EOT], (toks, rkept)
+    assert [(round(a * 100), round(b * 100), s) for a, b, s in segs] == [(a, b, s.decode()) for a, b, s in rsegs]
+    _same_windows(wins, rwins, 1e-4, "beam")
+    kw = dict(language_token=sp["lang0"], timestamps=True, with_segments=True, beam_size=3)
+    got = transcribe_batch(eng, [x[:16000 * 7], x, x[:16000 * 3]], **kw)
+    assert got[1][:4] == (text, toks, sp["lang0"], segs) and got[1][4] == wins
+    # greedy on the same clip takes another road through the ladder but ends with the same text (the X reading)
+    _, _, toks_g = eng.transcribe_segments(x, language_token=sp["lang0"])
+    assert toks_g == toks
+    eng.set_precision(1)
+    solo = transcribe_batch(eng, [x], **kw)[0]
+    both = transcribe_batch(eng, [x[:16000 * 5], x], **kw)
+    assert both[1] == solo and any(w["temperature"] > 0 for w in solo[4])
+    eng.close()
+    with pytest.raises(Exception):
+        eng2 = WhisperEngine(_engine_file(tmp_path_factory, hp, W, "beam"))
+        try:
+            eng2.transcribe_segments(x, language_token=sp["lang0"], beam_size=9)      # > WHISPER_MAX_DECODERS
+        finally:
+            eng2.close()

@@ -336,3 +336,88 @@ def test_initial_prompt_and_carried_context_are_where_the_first_window_starts(sc
     seen.clear()
     run(16000 * 4)
     assert seen[0] == INIT                                    # no_context = true, no prompt: the bare prompt
+
+
+def test_beam_search_keeps_the_branch_the_greedy_pass_loses(scripted):
+    """whisper.cpp's BEAM_SEARCH strategy [UPSTREAM-RECALL] on the X / Y model of the sampled-pass test: X (logit 10) leads
+    into near-uniform text, Y (9) into a confident sentence.  Greedy takes X and fails the log-probability bar at
+    temperature 0; with beam_size = 3 every live decoder draws three ids per step from its distribution, the candidates are
+    sorted by the sum of all their log-probabilities and dealt to the decoders without repeating a sequence -- so as soon
+    as one draw of nine is Y a decoder holds [<|0.00|>, Y], and from the next step on that branch sorts first.  The window
+    is accepted at temperature 0 with the Y sentence; the decoders that held X-branches run on and are out-scored."""
+    X, Y = 1234, 2345
+    good = [BEG, Y] + list(range(700, 707)) + [BEG + 200, BEG + 200]
+    bad = [BEG, X] + list(range(800, 806)) + [BEG + 200, BEG + 200]
+
+    def script(gen, prompt):
+        if len(gen) == 0:
+            return peaky(BEG)
+        if len(gen) == 1:
+            lg = np.full(V, -30.0)
+            lg[X], lg[Y] = 10.0, 9.0
+            return lg
+        if gen[1] == Y:
+            return peaky(good[len(gen)] if len(gen) < len(good) else EOT)
+        return flat(bad[len(gen)]) if len(gen) < len(bad) else peaky(EOT)
+
+    scripted(lambda i: script)
+    g = run(16000 * 30, fallback=False, max_windows=1, n_max=24)
+    assert g[2][0]["tokens"][:2] == [BEG, X] and g[2][0]["avg_logprob"] < -1.0            # what greedy does with it
+    scripted(lambda i: script)
+    a = run(16000 * 30, fallback=True, max_windows=1, n_max=24, params=dict(beam_size=3))
+    scripted(lambda i: script)
+    b = run(16000 * 30, fallback=True, max_windows=1, n_max=24, params=dict(beam_size=3))
+    w = a[2][0]
+    assert w["tokens"] == b[2][0]["tokens"] and w["decoder"] == b[2][0]["decoder"]         # deterministic: MT19937(j) per decoder
+    assert w["temperature"] == 0.0 and not w["failed"] and w["avg_logprob"] > -1.0
+    assert w["tokens"] == good and a[1] == good
+    it0 = w["iterations"][0]
+    assert len(w["iterations"]) == 1 and len(it0["decoders"]) == 3
+    win = it0["decoders"][w["decoder"]]
+    assert win["completed"] and win["toks"][:len(good)] == good
+    # the sum the candidates are sorted by is the sum of ALL plogs of the sequence
+    for d in it0["decoders"]:
+        assert abs(d["sum_all"] - sum(float(np.float32(p)) for p in d["plogs"])) < 1e-9
+    # the second pick: log-softmax of (10, 9) at Y, no temperature scaling at temperature 0
+    assert abs(win["plogs"][1] - (-math.log(1.0 + math.exp(1.0)))) < 1e-6
+    # the draws: at step 1 every decoder draws three variates from MT19937(j); X iff u < p(X) -- at least one of the nine is Y
+    p_x = 1.0 / (1.0 + math.exp(-1.0))
+    ys = 0
+    for j in range(3):
+        r = WO.MT19937(j)
+        [r.canonical() for _ in range(3)]                    # step 0: three draws, all <|0.00|>
+        ys += sum(r.canonical() >= p_x for _ in range(3))
+    assert ys >= 1
+
+
+def test_beam_candidates_are_dealt_in_order_of_their_summed_log_probability(scripted):
+    """The dealing rule on a model with three comparable continuations: after <|0.00|> the ids A, B, C carry 50 / 30 / 20 %.
+    Whatever the nine draws of the step are, the live decoders end up with the DISTINCT drawn sequences in descending
+    probability order, decoder 0 first, wrapping around to the best one when fewer distinct sequences were drawn than
+    there are decoders (whisper.cpp: `if (cur_c >= beam_candidates.size()) cur_c = 0`)."""
+    A, B, C_ = 1111, 2222, 3333
+
+    def script(gen, prompt):
+        if len(gen) == 0:
+            return peaky(BEG)
+        if len(gen) == 1:
+            lg = np.full(V, -40.0)
+            lg[A], lg[B], lg[C_] = math.log(0.5), math.log(0.3), math.log(0.2)
+            return lg
+        return peaky([BEG + 100, BEG + 100][len(gen) - 2] if len(gen) < 4 else EOT)
+
+    scripted(lambda i: script)
+    dc = WO.DecoderCache(None, HP, None)
+    rngs = [WO.MT19937(j) for j in range(3)]
+    r = WO.decode_temperature(dc, INIT, SP, WO.RULES_WCPP, 2, 0, 3000, 0.0, 3, rngs, WO.WCPP_PARAMS, SUP, SUP_FIRST, beam_size=3)
+    drawn = []
+    for j in range(3):
+        g = WO.MT19937(j)
+        [g.canonical() for _ in range(3)]
+        for _ in range(3):
+            u = g.canonical()
+            drawn.append(A if u <= 0.5 else B if u <= 0.8 else C_)
+    order = [t for t in (A, B, C_) if t in drawn]
+    want = [order[j % len(order)] if j < len(order) else order[(j - len(order)) % len(order)] for j in range(3)]
+    assert [d["toks"] for d in r["decoders"]] == [[BEG, t] for t in want]
+    assert all(d["parent"] in (0, 1, 2) for d in r["decoders"])
