@@ -225,7 +225,35 @@ struct crispy_resampler {
   float* d_a = nullptr;     // [rows][1040]
   float* d_y = nullptr;     // [rows][684]
   long cap_rows = 0;
+  // the f16-pair form (asr_common.h: rs_prep_split): W' [342][3 x 2 x RS_PITCH] f16 = W_hi | W_hi | W_lo over the window
+  // [previous block | block]; planes [2][streams][(n_blk + 1) x RS_PITCH] f16
+  void* d_w16 = nullptr;
+  void* d_planes = nullptr;
+  long cap_plane_blocks = 0;
 };
+
+// f32 -> f16 bits, round to nearest even (host: this file is also built by g++ without _Float16)
+uint16_t f16_bits(float f) {
+  uint32_t x;
+  std::memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  x &= 0x7fffffffu;
+  if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0u));
+  if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                 // >= 65520: rounds to infinity
+  if (x < 0x38800000u) {                                                   // below 2^-14: a subnormal half, spacing 2^-24
+    const float a = std::fabs(f) * 16777216.0f;
+    return (uint16_t)(sign | (uint32_t)std::nearbyint(a));
+  }
+  uint32_t h = (((x >> 23) - 112u) << 10) | ((x & 0x7fffffu) >> 13);
+  const uint32_t rem = x & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;
+  return (uint16_t)(sign | h);
+}
+double f16_value(uint16_t h) {
+  const int e = (h >> 10) & 31, m = h & 1023;
+  const double v = e == 0 ? std::ldexp((double)m, -24) : std::ldexp((double)(1024 + m), e - 25);
+  return (h & 0x8000) ? -v : v;
+}
 
 extern "C" {
 
@@ -280,6 +308,21 @@ int crispy_resampler_create(int device, crispy_resampler** out) try {
   std::vector<float> W((size_t)RS_N * RS_K, 0.f);
   for (int n = 0; n < RS_N; ++n)
     for (int j = 0; j < NI; ++j) W[(size_t)n * RS_K + j] = (float)g[((3 * n - j) % N2 + N2) % N2];
+  // the f16-pair operator over the window [previous block | block]: output n of a block = row n of the block's own
+  // product + row 342 + n of the previous block's (the overlap-add, folded into the operator)
+  const int KW = 2 * RS_PITCH;
+  std::vector<uint16_t> W16((size_t)NO * 3 * KW, 0);
+  for (int n = 0; n < NO; ++n)
+    for (int half = 0; half < 2; ++half)
+      for (int j = 0; j < NI; ++j) {
+        const int m = half == 0 ? NO + n : n;
+        const double w = g[((3 * m - j) % N2 + N2) % N2];
+        const uint16_t hi = f16_bits((float)w);
+        const uint16_t lo = f16_bits((float)(w - f16_value(hi)));
+        uint16_t* row = W16.data() + (size_t)n * 3 * KW;
+        const int k = half * RS_PITCH + j;
+        row[k] = hi; row[KW + k] = hi; row[2 * KW + k] = lo;
+      }
   crispy_resampler* h = new (std::nothrow) crispy_resampler();
   if (!h) return fail(CRISPY_ERR_OOM, "crispy_resampler_create: host allocation failed");
   h->device = device;
@@ -288,6 +331,8 @@ int crispy_resampler_create(int device, crispy_resampler** out) try {
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIP_TRY(hipMalloc(&h->d_w, W.size() * sizeof(float)));
     HIP_TRY(hipMemcpy(h->d_w, W.data(), W.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&h->d_w16, W16.size() * sizeof(uint16_t)));
+    HIP_TRY(hipMemcpy(h->d_w16, W16.data(), W16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     return CRISPY_OK;
   };
   rc = body();
@@ -300,7 +345,7 @@ void crispy_resampler_destroy(crispy_resampler* h) try {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (void* p : {(void*)h->d_w, (void*)h->d_a, (void*)h->d_y})
+  for (void* p : {(void*)h->d_w, (void*)h->d_a, (void*)h->d_y, h->d_w16, h->d_planes})
     if (p) (void)hipFree(p);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -317,6 +362,37 @@ int crispy_resampler_process_device(crispy_resampler* h, const float* d_in, long
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
   const int n_blk = (int)(n_out / RS_FFT_OUT);
+  // The f16-pair form on the f16 matrix cores (rows of the output must take 8-byte stores); CRISPY_RS_GEMM=f32 (developer
+  // build) keeps the f32 form below for A/B.
+  static const bool pair_form = [] { const char* e = dev_env("CRISPY_RS_GEMM"); return !(e && e[0] == 'f'); }();
+  if (pair_form && out_stride % 2 == 0 && ((size_t)d_out & 7) == 0) {
+    const long max_blocks = 1L << 18;   // 262144 block slots: 1.1 GB of planes
+    int group = (int)(max_blocks / (n_blk + 1));
+    if (group < 1) group = 1;
+    if (group > batch) group = batch;
+    const long need = (long)group * (n_blk + 1);
+    if (need > h->cap_plane_blocks) {
+      if (h->d_planes) (void)hipFree(h->d_planes);
+      h->d_planes = nullptr;
+      h->cap_plane_blocks = 0;
+      HIP_TRY(hipMalloc(&h->d_planes, (size_t)need * RS_PITCH * 2 * sizeof(uint16_t)));
+      h->cap_plane_blocks = need;
+    }
+    for (int b0 = 0; b0 < batch; b0 += group) {
+      const int nb = (batch - b0) < group ? (batch - b0) : group;
+      HIP_TRY(rs_prep_split(d_in + (long)b0 * in_stride, in_stride, n_in, scale, wav_s16, h->d_planes, nb, n_blk, s));
+      HGemmArgs g{};
+      g.A = reinterpret_cast<const _Float16*>(h->d_planes); g.lda = RS_PITCH; g.strideA = (long)(n_blk + 1) * RS_PITCH;
+      g.W = reinterpret_cast<const _Float16*>(h->d_w16); g.ldw = 3L * 2 * RS_PITCH;
+      g.C = d_out + (long)b0 * out_stride; g.ldc = RS_FFT_OUT; g.strideC = out_stride;
+      g.M = n_blk; g.N = RS_FFT_OUT; g.K = 3 * 2 * RS_PITCH;
+      g.k_seg = 2 * RS_PITCH;
+      g.a_seg_off[0] = 0; g.a_seg_off[1] = (long)nb * (n_blk + 1) * RS_PITCH; g.a_seg_off[2] = 0;      // x_hi | x_lo | x_hi
+      g.xcd_swizzle = 1;
+      HIP_TRY(gemm_hh(g, HGEMM_F32, nb, s));
+    }
+    return CRISPY_OK;
+  }
   // bounded workspace: process the streams in groups
   const long max_rows = 1L << 17;   // 131072 rows: 545 MB of A + 359 MB of Y
   int group = (int)(max_rows / n_blk);

@@ -113,8 +113,13 @@ struct HGemmArgs {
   int kv_width;                     // EPI_KVH: model width dt (N = 2 dt); element (clip b, frame t; K|V, head, dim) goes to
                                     //   C[((b * 2 + kv) * heads + head) * vt_T * 64 + t * 64 + dim] as f16
   int xcd_swizzle;                  // all column tiles of a row tile on one XCD
+  // K in segments (k_seg > 0, a multiple of 32; K = n * k_seg, n <= 3): segment i of a row of A starts a_seg_off[i] elements
+  // from the row's start (W stays [N][K] contiguous) -- the resampler's x_hi | x_lo | x_hi against W_hi | W_hi | W_lo.
+  int k_seg;
+  long a_seg_off[3];
 };
-constexpr int HGEMM_F16 = 0, HGEMM_RES = 1, HGEMM_VT = 2, HGEMM_TAB = 3, HGEMM_KVH = 4;
+// HGEMM_F32: C = acc as f32 [M][ldc], ldc even (rows 8-byte aligned); no bias
+constexpr int HGEMM_F16 = 0, HGEMM_RES = 1, HGEMM_VT = 2, HGEMM_TAB = 3, HGEMM_KVH = 4, HGEMM_F32 = 5;
 hipError_t gemm_hh(const HGemmArgs& g, int epi, int batch, hipStream_t s);
 hipError_t layernorm_f16out(const float* x, const float* gamma, const float* beta, void* y, long rows, int D, hipStream_t s);
 hipError_t attn_encoder_h(const void* qk, const void* vt, void* out, int B, int T, int D, int heads, hipStream_t s,
@@ -208,6 +213,14 @@ constexpr int RS_N = 684;    // 342 outputs + 342 of overlap per block
 hipError_t rs_prep(const float* in, long in_stride, long n_in, float scale, int wav_s16, float* A, int batch,
                    int n_blk, hipStream_t s);
 hipError_t rs_ola(const float* Y, float* out, long out_stride, int batch, int n_blk, hipStream_t s);
+// The same map on the f16 matrix cores: x = x_hi + x_lo and W = W_hi + W_lo as f16 pairs (24 bits of each between them),
+// y = x_hi W_hi + x_lo W_hi + x_hi W_lo with f32 accumulation -- 3 x the products at 16 x the rate.  A row of the GEMM is
+// the window [block - 1 | block] of a stream (2 x RS_PITCH halves, rows overlap: lda = RS_PITCH), its 342 outputs are the
+// block's output samples with the overlap of the previous block already added.
+constexpr int RS_PITCH = 1056;          // a block's 1026 samples padded to whole 32-wide k-blocks
+// planes[2][batch][(n_blk + 1) * RS_PITCH] f16: hi | lo, block 0 of every stream zero (the block before the first)
+hipError_t rs_prep_split(const float* in, long in_stride, long n_in, float scale, int wav_s16, void* planes, int batch, int n_blk,
+                         hipStream_t s);
 
 // Greedy pick under the timestamp rules (whisper.cpp whisper_process_logits / openai ApplyTimestampRules; the
 // semantics are restated in oracle/whisper_oracle.py: timestamp_rules).  One decoding window per clip.

@@ -47,7 +47,51 @@ __global__ __launch_bounds__(256) void rs_ola_kernel(const float* __restrict__ Y
   }
 }
 
+// hi | lo planes of the scaled input (rs_prep_kernel's value, split): plane p, stream b, block blk + 1 (block 0 stays zero),
+// RS_PITCH halves per block with the 30 behind the 1026 samples zero.  x_lo = f16(x - f32(x_hi)): exact difference, rounded
+// once (absolute error <= 2^-25 where it is a subnormal) -- the pair carries x to ~3e-8 of full scale.
+__global__ __launch_bounds__(256) void rs_prep_split_kernel(const float* __restrict__ in, long in_stride, long n_in, float scale,
+                                                            int wav_s16, _Float16* __restrict__ planes, long plane_stride, int n_blk,
+                                                            long n_slots) {
+  // a thread: two consecutive samples of one block slot -> one 4-byte store per plane (consecutive lanes, consecutive
+  // addresses on both sides; eight samples per thread made every load a 32-byte-strided gather and was no faster than
+  // one sample per thread)
+  typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+  constexpr int PER = RS_PITCH / 2;       // 528 threads' worth per slot
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long row = idx / PER;             // b * (n_blk + 1) + block slot
+  if (row >= n_slots) return;
+  const int j0 = (int)(idx % PER) * 2;
+  const int b = (int)(row / (n_blk + 1)), blk = (int)(row % (n_blk + 1)) - 1;
+  const float* x = in + (long)b * in_stride + (long)blk * RS_FFT_IN;
+  half2v hi, lo;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int j = j0 + e;
+    float v = 0.f;
+    if (blk >= 0 && j < RS_FFT_IN && (long)blk * RS_FFT_IN + j < n_in) {
+      v = x[j] * scale;
+      if (wav_s16 >= 1) v = fminf(1.f, fmaxf(-1.f, v));
+      if (wav_s16 >= 2) v = truncf(v * 32767.f) / 32768.f;
+    }
+    const _Float16 h = (_Float16)v;
+    hi[e] = h;
+    lo[e] = (_Float16)(v - (float)h);
+  }
+  *reinterpret_cast<half2v*>(planes + row * RS_PITCH + j0) = hi;
+  *reinterpret_cast<half2v*>(planes + plane_stride + row * RS_PITCH + j0) = lo;
+}
+
 }  // namespace
+
+hipError_t rs_prep_split(const float* in, long in_stride, long n_in, float scale, int wav_s16, void* planes, int batch, int n_blk,
+                         hipStream_t s) {
+  const long plane_stride = (long)batch * (n_blk + 1) * RS_PITCH;
+  const long n_slots = (long)batch * (n_blk + 1), n_thr = n_slots * (RS_PITCH / 2);
+  hipLaunchKernelGGL(rs_prep_split_kernel, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, s, in, in_stride, n_in, scale,
+                     wav_s16, reinterpret_cast<_Float16*>(planes), plane_stride, n_blk, n_slots);
+  return hipGetLastError();
+}
 
 hipError_t rs_prep(const float* in, long in_stride, long n_in, float scale, int wav_s16, float* A, int batch,
                    int n_blk, hipStream_t s) {

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void layernorm_h_kernel(const float* __restric
   for (int q = 0; q < PER; ++q) yr[lane + 64 * q] = (_Float16)((v[q] - mean) * rstd * gm[q] + bt[q]);
 }
 
-enum { EPI_F16 = 0, EPI_RES = 1, EPI_VT = 2, EPI_TAB = 3, EPI_KVH = 4 };
+enum { EPI_F16 = 0, EPI_RES = 1, EPI_VT = 2, EPI_TAB = 3, EPI_KVH = 4, EPI_F32 = 5 };
 
 // one k-block (32) of a wave's 64 x 64 output tile from the staged operand tiles
 template <int EPI>
@@ -373,6 +373,15 @@ __device__ __forceinline__ void ep_store(const HGemmArgs& g, const float* T, con
       const half8 hv = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
       if (rb + row < mrem && c8 < nrem) *reinterpret_cast<half8*>(C + (long)row * g.ldc + c8) = hv;
     }
+  } else if (EPI == EPI_F32) {
+    float* __restrict__ C = reinterpret_cast<float*>(g.C) + (long)bz * g.strideC + (long)(m0 + wm + rb) * g.ldc + (n0 + wn);
+    const int c2 = (lane & 31) * 2;                           // 32 lanes per row, 2 columns each: rows are 8-byte aligned only
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      const int row = (lane >> 5) + 2 * p;
+      const float2 x = *reinterpret_cast<const float2*>(T + row * EP_LD + c2);
+      if (rb + row < mrem && c2 < nrem) *reinterpret_cast<float2*>(C + (long)row * g.ldc + c2) = x;
+    }
   } else if (EPI == EPI_RES || EPI == EPI_TAB) {
     float* __restrict__ C = reinterpret_cast<float*>(g.C) + (long)bz * g.strideC + (long)(m0 + wm + rb) * g.ldc + (n0 + wn);
     const int c4 = (lane & 15) * 4;                           // 16 lanes per row, 4 columns (16 bytes of f32) each
@@ -456,6 +465,12 @@ __device__ __forceinline__ void hd2_epilogue(const HGemmArgs& g, f32x16 (&acc)[M
 // LDS-DMA request (`s_waitcnt vmcnt(0)`), which would serialise the stages; the counters are kept by hand instead.
 // ---------------------------------------------------------------------------------------------
 constexpr int HD_STAGES = 3, HD_TILE_BYTES = HH_M * HH_K * 2;     // 8 KB per operand tile
+// where k-block k0 of A starts inside a row (HGemmArgs::k_seg: K in segments that live at their own offsets)
+__device__ __forceinline__ long a_seg_k(const HGemmArgs& g, int k0) {
+  if (g.k_seg <= 0) return k0;
+  const int seg = k0 / g.k_seg;
+  return g.a_seg_off[seg] + (k0 - seg * g.k_seg);
+}
 template <int EPI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void gemm_hd_kernel(HGemmArgs g) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[HD_STAGES * 2 * HD_TILE_BYTES];   // [stage][A | W]
@@ -489,9 +504,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
   typedef __attribute__((address_space(3))) void* lds_ptr;
   auto request = [&](int stage, int k0) {
     unsigned char* base = smem + stage * (2 * HD_TILE_BYTES) + wave * 2048;
+    const long ka = a_seg_k(g, k0);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      __builtin_amdgcn_global_load_lds(ga[u] + k0, (lds_ptr)(base + 1024 * u), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(ga[u] + ka, (lds_ptr)(base + 1024 * u), 16, 0, 0);
       __builtin_amdgcn_global_load_lds(gw[u] + k0, (lds_ptr)(base + HD_TILE_BYTES + 1024 * u), 16, 0, 0);
     }
   };
@@ -864,8 +880,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
   typedef __attribute__((address_space(3))) void* lds_ptr;
   auto request = [&](int stage, int k0) {
     unsigned char* base = smem + stage * STAGE_BYTES;
+    const long ka = a_seg_k(g, k0);
 #pragma unroll
-    for (int u = 0; u < MI; ++u) lds_dma16(ga[u] + k0, base + (wave * MI + u) * 1024);
+    for (int u = 0; u < MI; ++u) lds_dma16(ga[u] + ka, base + (wave * MI + u) * 1024);
 #pragma unroll
     for (int u = 0; u < 2; ++u) lds_dma16(gw[u] + k0, base + A_BYTES + wave * 2048 + 1024 * u);
   };
@@ -970,7 +987,7 @@ hipError_t gemm_hh(const HGemmArgs& g, int epi, int batch, hipStream_t s) {
   if (a.xcd_swizzle) grid.y = (unsigned)(((mt + 7) / 8) * 8);      // whole groups of eight row tiles
   static const bool direct = [] { const char* e = dev_env("CRISPY_ASR_GEMM"); return !(e && e[0] == 'r'); }();   // "regs": the register-staged loop
   static const bool tall = [] { const char* e = dev_env("CRISPY_ASR_GEMM"); return !(e && e[0] == 's'); }();     // "square": 128 x 128 tiles only
-  if ((direct || epi == EPI_KVH) && tall && g.M >= 4 * HD2_M) {      // 256 x 128 or 192 x 128 tiles
+  if ((direct || epi == EPI_KVH || epi == EPI_F32) && tall && g.M >= 4 * HD2_M) {      // 256 x 128 or 192 x 128 tiles
     // two workgroups per CU: rounds x tile height is what the launch costs; ties go to the taller tile
     // (per device: a process may hold handles on several devices -- ADVICE r4; both tile heights give the same bits,
     // tests/test_gpu_mode1.py::test_mode1_encoder_does_not_depend_on_the_gemm_tile_height)
@@ -996,18 +1013,20 @@ hipError_t gemm_hh(const HGemmArgs& g, int epi, int batch, hipStream_t s) {
       case EPI_VT: HD2_LAUNCH(EPI_VT) break;
       case EPI_TAB: HD2_LAUNCH(EPI_TAB) break;
       case EPI_KVH: HD2_LAUNCH(EPI_KVH) break;
+      case EPI_F32: HD2_LAUNCH(EPI_F32) break;
       default: return hipErrorInvalidValue;
     }
 #undef HD2_LAUNCH
     return hipGetLastError();
   }
-  if (direct || epi == EPI_KVH) {
+  if (direct || epi == EPI_KVH || epi == EPI_F32) {
     switch (epi) {
       case EPI_F16: hipLaunchKernelGGL(gemm_hd_kernel<EPI_F16>, grid, dim3(256), 0, s, a); break;
       case EPI_RES: hipLaunchKernelGGL(gemm_hd_kernel<EPI_RES>, grid, dim3(256), 0, s, a); break;
       case EPI_VT: hipLaunchKernelGGL(gemm_hd_kernel<EPI_VT>, grid, dim3(256), 0, s, a); break;
       case EPI_TAB: hipLaunchKernelGGL(gemm_hd_kernel<EPI_TAB>, grid, dim3(256), 0, s, a); break;
       case EPI_KVH: hipLaunchKernelGGL(gemm_hd_kernel<EPI_KVH>, grid, dim3(256), 0, s, a); break;
+      case EPI_F32: hipLaunchKernelGGL(gemm_hd_kernel<EPI_F32>, grid, dim3(256), 0, s, a); break;
       default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -1586,6 +1586,153 @@ __global__ __launch_bounds__(TS_THREADS) void ts_sample_kernel(TsPickArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same cross-attention for the query rows of ONE clip together (rows.group > 1, every row over the same keys:
+// the positions of a batched prompt step, the decoders of a fallback pass): one workgroup per (head, clip, chunk of
+// ADG_ROWS rows) holds the clip's K and V of the head in registers once and takes its rows one after the other -- with
+// a workgroup per row the clip's K | V reaches the CUs once per row (from the XCD's L2 after the first), and a prompt
+// step over 64 clips x 4 positions was 85 us per layer against 30 for the bytes from HBM.  Per row exactly
+// attn_dec_x16_kernel's arithmetic (partition, per-wave triples, merge), so a row's bits do not depend on the form.
+// The row loop is kept rolled and the f16 -> f32 conversions pinned inside it (hoisted, they are 96 more registers).
+// ---------------------------------------------------------------------------------------------
+constexpr int ADG_ROWS = 8;
+template <bool STREAM_KV>
+__global__ __launch_bounds__(64 * AD_WAVES) void attn_dec_x16g_kernel(const float* __restrict__ q, long ldq, const _Float16* __restrict__ kv,
+                                                                      long kv_batch_stride, long ldkv, long head_stride, long koff, long voff,
+                                                                      int n_keys, float* __restrict__ out, long ldo, AttnRows rows) {
+  constexpr int SL = 12;
+  typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+  __shared__ __attribute__((aligned(16))) float part_o[ADG_ROWS][AD_WAVES][64];
+  __shared__ float part_m[ADG_ROWS][AD_WAVES], part_l[ADG_ROWS][AD_WAVES];
+  __shared__ float wave_m[ADG_ROWS][AD_WAVES], wave_l[ADG_ROWS][AD_WAVES];
+  __shared__ float sc_s[ADG_ROWS][AD_WAVES][SL][8];          // the scores: 6 KB per row (in registers they do not fit beside the keys)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int h = blockIdx.x, clip = blockIdx.y;
+  const int r_lo = blockIdx.z * ADG_ROWS, n_r = min(ADG_ROWS, rows.group - r_lo);
+  const int c = lane & 7, r = lane >> 3;
+  const _Float16* Kb = kv + (long)clip * kv_batch_stride + koff + h * head_stride + 8 * c;
+  const _Float16* Vb = kv + (long)clip * kv_batch_stride + voff + h * head_stride + 8 * c;
+  const int per = (n_keys + AD_WAVES - 1) / AD_WAVES;
+  const int k_lo = wave * per, k_hi = min(n_keys, k_lo + per);
+  const int k_last = max(k_hi - 1, 0);
+  half8 kr[SL];
+#pragma unroll
+  for (int i = 0; i < SL; ++i) {
+    const half8* p = reinterpret_cast<const half8*>(Kb + (long)min(k_lo + 8 * i + r, k_last) * ldkv);
+    kr[i] = STREAM_KV ? __builtin_nontemporal_load(p) : *p;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // scores of every row of the chunk from the keys in registers
+#pragma unroll 1
+  for (int j = 0; j < n_r; ++j) {
+    const long b = (long)clip * rows.group + r_lo + j;
+    float qv[8];
+    const float4 q0 = *reinterpret_cast<const float4*>(q + b * ldq + h * 64 + 8 * c);
+    const float4 q1 = *reinterpret_cast<const float4*>(q + b * ldq + h * 64 + 8 * c + 4);
+    qv[0] = q0.x; qv[1] = q0.y; qv[2] = q0.z; qv[3] = q0.w;
+    qv[4] = q1.x; qv[5] = q1.y; qv[6] = q1.z; qv[7] = q1.w;
+    if (rows.attn16) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qv[e] = (float)(_Float16)qv[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qv[e] *= 0.125f;
+    float mloc = -1e30f;
+#pragma unroll
+    for (int i = 0; i < SL; ++i) {
+      asm volatile("" : "+v"(kr[i]));
+      float v = (float)kr[i][0] * qv[0];
+#pragma unroll
+      for (int e = 1; e < 8; ++e) v = fmaf((float)kr[i][e], qv[e], v);
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));
+      const float sc = k_lo + 8 * i + r < k_hi ? v : -1e30f;
+      if (c == 0) sc_s[j][wave][i][r] = sc;
+      mloc = fmaxf(mloc, sc);
+    }
+#pragma unroll
+    for (int off = 8; off <= 32; off <<= 1) mloc = fmaxf(mloc, __shfl_xor(mloc, off, 64));
+    if (lane == 0) wave_m[j][wave] = mloc;
+  }
+  // the values, into the registers the keys leave
+  __builtin_amdgcn_sched_barrier(0);
+  half8 vr[SL];
+#pragma unroll
+  for (int i = 0; i < SL; ++i) {
+    const half8* p = reinterpret_cast<const half8*>(Vb + (long)min(k_lo + 8 * i + r, k_last) * ldkv);
+    vr[i] = STREAM_KV ? __builtin_nontemporal_load(p) : *p;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();
+  if (rows.attn16) {             // mode 2: every row's maximum and sum over ALL keys before a probability is rounded
+#pragma unroll 1
+    for (int j = 0; j < n_r; ++j) {
+      float m = wave_m[j][0];
+#pragma unroll
+      for (int w = 1; w < AD_WAVES; ++w) m = fmaxf(m, wave_m[j][w]);
+      float ls = 0.f;
+#pragma unroll
+      for (int i = 0; i < SL; ++i) ls += k_lo + 8 * i + r < k_hi ? __expf(sc_s[j][wave][i][r] - m) : 0.f;
+#pragma unroll
+      for (int off = 8; off <= 32; off <<= 1) ls += __shfl_xor(ls, off, 64);
+      if (lane == 0) wave_l[j][wave] = ls;
+    }
+    __syncthreads();
+  }
+#pragma unroll 1
+  for (int j = 0; j < n_r; ++j) {
+    float mloc = wave_m[j][wave], inv16 = 0.f;
+    if (rows.attn16) {
+      float l = 0.f;
+      mloc = wave_m[j][0];
+#pragma unroll
+      for (int w = 1; w < AD_WAVES; ++w) mloc = fmaxf(mloc, wave_m[j][w]);
+#pragma unroll
+      for (int w = 0; w < AD_WAVES; ++w) l += wave_l[j][w];
+      inv16 = 1.f / l;
+    }
+    float lsum = 0.f;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < SL; ++i) {
+      float pw = k_lo + 8 * i + r < k_hi ? __expf(sc_s[j][wave][i][r] - mloc) : 0.f;
+      if (rows.attn16) pw = (float)(_Float16)(pw * inv16);
+      lsum += pw;
+      asm volatile("" : "+v"(vr[i]));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(pw, (float)vr[i][e], acc[e]);
+    }
+#pragma unroll
+    for (int off = 8; off <= 32; off <<= 1) {
+      lsum += __shfl_xor(lsum, off, 64);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += __shfl_xor(acc[e], off, 64);
+    }
+    if (r == 0) {
+      *reinterpret_cast<float4*>(&part_o[j][wave][8 * c]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      *reinterpret_cast<float4*>(&part_o[j][wave][8 * c + 4]) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+    if (lane == 0) { part_m[j][wave] = mloc; part_l[j][wave] = lsum; }
+  }
+  __syncthreads();
+  if (wave < n_r) {              // row `wave` of the chunk: the merge of its 16 triples
+    float m = part_m[wave][0];
+#pragma unroll
+    for (int w = 1; w < AD_WAVES; ++w) m = fmaxf(m, part_m[wave][w]);
+    float o = 0.f, l = 0.f;
+#pragma unroll
+    for (int w = 0; w < AD_WAVES; ++w) {
+      const float scl = __expf(part_m[wave][w] - m);
+      o = fmaf(part_o[wave][w][lane], scl, o);
+      l = fmaf(part_l[wave][w], scl, l);
+    }
+    out[((long)clip * rows.group + r_lo + wave) * ldo + h * 64 + lane] = rows.attn16 ? o : o / l;
+  }
+}
+
 // beam_kv_reorder: phase 0 gathers the parents' bytes into scratch, phase 1 scatters them into the rows
 __global__ __launch_bounds__(256) void beam_kv_copy_kernel(char* __restrict__ kv, char* __restrict__ scratch, const int* __restrict__ parent,
                                                            int rows, long row_bytes, long off, long len, int phase) {
@@ -1801,6 +1948,19 @@ hipError_t attn_decoder_kv16(const float* q, long ldq, const void* kv, long kv_b
     const _Float16* kvh = reinterpret_cast<const _Float16*>(kv);
 #define CRISPY_ADX(SL) hipLaunchKernelGGL((attn_dec_x16_kernel<SL, false>), dim3(heads, B), dim3(64 * AD_WAVES), 0, s, q, ldq, kvh, \
                                           kv_batch_stride, ldkv, head_stride, koff, voff, n_keys_base, pos_dev, out, ldo, rows)
+    // several rows per clip over the same keys (a prompt step's positions, a pass's decoders): the clip's K | V once per chunk of rows
+    // (worth it once the one-workgroup-per-row grid is several rounds of the CUs: a row's pass is a latency chain of its own)
+    if (rows.group > 1 && rows.key_step == 0 && !rows.key_off && !pos_dev && B % rows.group == 0 && bound > AD_WAVES * 32 && n_keys_base > 0 &&
+        (long)heads * B > 512) {
+      const dim3 grid(heads, B / rows.group, (rows.group + ADG_ROWS - 1) / ADG_ROWS);
+      if (rows.stream_kv)
+        hipLaunchKernelGGL((attn_dec_x16g_kernel<true>), grid, dim3(64 * AD_WAVES), 0, s, q, ldq, kvh, kv_batch_stride, ldkv, head_stride, koff,
+                           voff, n_keys_base, out, ldo, rows);
+      else
+        hipLaunchKernelGGL((attn_dec_x16g_kernel<false>), grid, dim3(64 * AD_WAVES), 0, s, q, ldq, kvh, kv_batch_stride, ldkv, head_stride, koff,
+                           voff, n_keys_base, out, ldo, rows);
+      return hipGetLastError();
+    }
     if (rows.stream_kv && bound > AD_WAVES * 32) {     // the cross-attention of a step over many clips
       hipLaunchKernelGGL((attn_dec_x16_kernel<12, true>), dim3(heads, B), dim3(64 * AD_WAVES), 0, s, q, ldq, kvh, kv_batch_stride,
                          ldkv, head_stride, koff, voff, n_keys_base, pos_dev, out, ldo, rows);

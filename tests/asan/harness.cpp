@@ -59,6 +59,7 @@ size_t vocab_f16_packed_bytes(int V, int K) { return (size_t)((V + 31) / 32) * 3
 hipError_t vocab_f16(const void*, long, const void*, float*, long, int, int, int, hipStream_t) { return hipSuccess; }
 hipError_t rs_ola(const float*, float*, long, int, int, hipStream_t) { return hipSuccess; }
 hipError_t rs_prep(const float*, long, long, float, int, float*, int, int, hipStream_t) { return hipSuccess; }
+hipError_t rs_prep_split(const float*, long, long, float, int, void*, int, int, hipStream_t) { return hipSuccess; }
 hipError_t softmax_prob_f32(const float*, int, long, int, float*, int, hipStream_t) { return hipSuccess; }
 hipError_t ts_pick(const TsPickArgs&, int, hipStream_t) { return hipSuccess; }
 hipError_t beam_kv_reorder(void*, void*, const int*, int, int, long, long, long, hipStream_t) { return hipSuccess; }
