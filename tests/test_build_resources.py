@@ -148,7 +148,7 @@ def test_f16_encoder_kernels_run_at_four_waves_per_simd_without_scratch(tmp_path
     # the LDS-direct main loop (default): three stages of 16 KB, no scratch, and between the barrier and the MFMAs of
     # a k-block nothing but the hand-kept counters: four LDS-DMA requests, eight ds_read_b128, no vmcnt(0)
     hd = {k: v for k, v in res.items() if "gemm_hd_kernel" in k}
-    assert len(hd) == 5, list(res)      # + the cross K|V projection (f16 head-major)
+    assert len(hd) == 6, list(res)      # + the cross K|V projection (f16 head-major) + the resampler's plain f32 rows
     for name, r in hd.items():
         assert r["ScratchSize"] == 0 and r["LDS Size"] == 3 * 16384 and r["VGPRs"] + r.get("AGPRs", 0) <= 128, (name, r)
         body = text[text.index(name + ":"):]
@@ -166,7 +166,7 @@ def test_f16_encoder_kernels_run_at_four_waves_per_simd_without_scratch(tmp_path
     # 72 KB of LDS (the ring or the epilogue images, whichever is larger), two workgroups per CU, MI + 2 LDS-DMA
     # requests, 2 MI + 4 ds_read_b128 and 4 MI MFMAs per trip, again without a compiler-inserted vmcnt(0)
     hd2 = {k: v for k, v in res.items() if "gemm_hd2_kernel" in k}
-    assert len(hd2) == 10, list(res)
+    assert len(hd2) == 12, list(res)
     for name, r in hd2.items():
         mi = int(re.search(r"gemm_hd2_kernelILi(\d+)E", name).group(1)) >> 3
         assert mi in (3, 4), name
@@ -184,7 +184,7 @@ def test_f16_encoder_kernels_run_at_four_waves_per_simd_without_scratch(tmp_path
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-@pytest.mark.parametrize("src_name", ["whisper_kernels.hip", "whisper_dec_f16.hip", "mel_kernels.hip",
+@pytest.mark.parametrize("src_name", ["whisper_kernels.hip", "whisper_dec_f16.hip", "whisper_dec_fused.hip", "mel_kernels.hip",
                                       "resample_kernels.hip"])
 def test_asr_kernels_have_no_scratch_at_all(tmp_path, src_name):
     """with this compiler a VGPR spill next to a divergent region is a correctness hazard (see the
@@ -214,6 +214,10 @@ def test_asr_kernels_have_no_scratch_at_all(tmp_path, src_name):
             assert any(must in k for k in res), (must, list(res))
         assert sum("gemm_skinny_f32_kernel" in k for k in res) == 44      # 8 epilogue forms x 4 K splits + 3 x 4 f16-weight forms (residual; bias; bias + GELU)
         assert sum("attn_dec_x16_kernel" in k for k in res) == 5           # 1 / 2 / 4 / 12 key slots per wave + the non-temporal 12 (K|V streams of many clips)
+    if src_name == "whisper_dec_fused.hip":       # the fused decode step: every (width, key slots, rows per workgroup) form at <= 128 registers
+        for must, n in (("fused_self_kernel", 20), ("fused_cross_kernel", 4), ("fused_mlp_kernel", 8), ("fused_finish_kernel", 2)):
+            assert sum(must in k for k in res) == n, (must, [k for k in res if must in k])
+        assert all(r["VGPRs"] + r.get("AGPRs", 0) <= 128 for k, r in res.items() if "fused_" in k and "pack" not in k)
     if src_name == "whisper_dec_f16.hip":
         assert sum("vocab_f16_kernel" in k for k in res) == 5              # tiny ... large widths
     bad = {k: r for k, r in res.items() if r.get("ScratchSize", 0) != 0 or r.get("VGPRs Spill", 0) != 0}

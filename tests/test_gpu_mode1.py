@@ -306,11 +306,21 @@ def test_mode1_product_call_equals_the_chained_oracle_on_plain_weights_at_the_st
                            fallback=False)
     n_win = n_tok = 0
     for c, x in enumerate(clips):
-        rsegs, rkept, wins = WO.transcribe_timestamps(W, hp, lambda seek: oracle.oracle_logmel(x, F, seek), x.size, prompt,
-                                                      WO.RULES_WCPP, eng.token_text, n_max=24, suppress=sup,
-                                                      suppress_first=sup_first, f16=True)
+        encs = {}                                                   # the oracle's encoder output per window start (window 0 is used twice)
+
+        def mel_window(seek):
+            encs["cur"] = seek
+            return oracle.oracle_logmel(x, F, seek)
+
+        def encoder(mel):
+            if encs["cur"] not in encs:
+                encs[encs["cur"]] = WO.encoder_forward_f16(W, hp, mel)
+            return encs[encs["cur"]]
+
+        rsegs, rkept, wins = WO.transcribe_timestamps(W, hp, mel_window, x.size, prompt, WO.RULES_WCPP, eng.token_text, n_max=24,
+                                                      suppress=sup, suppress_first=sup_first, f16=True, encoder=encoder)
         # the bar: MODE1_REL of the logit scale of this model (the largest |logit| the oracle saw at a pick)
-        dc = WO.DecoderCache(W, hp, WO.encoder_forward_f16(W, hp, oracle.oracle_logmel(x, F, 0)), f16=True)
+        dc = WO.DecoderCache(W, hp, encs[0], f16=True)
         lg = None
         for t in prompt:
             lg = dc.step(t)
