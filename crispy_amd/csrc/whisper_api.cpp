@@ -1079,11 +1079,12 @@ int decoder_logits(crispy_asr* h, int batch, hipStream_t s, const float* x = nul
   return CRISPY_OK;
 }
 
-// Rows of the biggest decode step the fused kernels take.  One workgroup per (row pair, head) holds a head's weights in
-// its registers -- the right shape while the step is a chain of latencies (1 row: 0.105 vs 0.173 ms per token; 64 rows:
-// 0.236 vs 0.291), the wrong one once there are enough rows to feed the matrix cores: measured per position, fused /
-// staged, Whisper-tiny 128 rows 0.389 / 0.405 ms, 256 rows 0.708 / 0.664, 512 rows 1.330 / 1.175; Whisper-base 64 rows
-// 0.398 / 0.474, 128 rows 0.721 / 0.705, 512 rows 2.78 / 2.22.  So: up to 128 rows fused, above staged.  Consequence: a row
+// Rows of the biggest decode step the fused kernels take.  One workgroup per (row group, head) holds a head's weights in
+// its registers -- the right shape while the step is a chain of latencies (1 row: 0.108 vs 0.173 ms per token; 64 rows:
+// 0.222 vs 0.291), no better than 32-row matrix-core tiles once the rows fill them: measured per position, fused / staged
+// (the blocks' products on the matrix cores), Whisper-tiny 128 rows 0.337 / 0.397 ms, 256 rows 0.631 / 0.652, 512 rows 1.186 /
+// 1.174; Whisper-base 128 rows 0.657 / 0.702, 256 rows 1.309 / 1.200, 512 rows 2.60 / 2.23.  So: up to 128 rows fused, above
+// staged (one limit for both widths).  Consequence: a row
 // decodes to the same bits alone and in any batch of up to 128 rows, and to the same bits in any batch of 129 .. 512
 // rows; across the two ranges the bits may differ (the forms add a row's partial sums in different orders) while both
 // sit at the mode's bar from the oracle (tests/test_gpu_fused_decode.py).
