@@ -271,6 +271,7 @@ struct TsPickArgs {
   // (std::mt19937 + generate_canonical<double, 53>).  u_all == nullptr: greedy arg-max, temperature ignored.
   const float* temperature;            // device scalar
   const double* u_all;                 // [steps][B]
+  float* x_scratch;                    // sampling: [B][TS_SCRATCH_ROW] floats, the rule-filtered row between the kernel's passes
   StepFuse fuse;
   // beam search (whisper_sample_token_topk [UPSTREAM-RECALL]): n_cand > 0 -- every row that is not done draws n_cand ids
   // from ITS distribution with the variates u_all[b][0 .. n_cand) and records them (id, log-probability, most probable
@@ -280,6 +281,7 @@ struct TsPickArgs {
   int* cand_tok; float* cand_plog; int* cand_tid;
 };
 constexpr int TS_MAX_CAND = 8;          // = WHISPER_MAX_DECODERS
+constexpr int TS_SCRATCH_ROW = 7 * 8192;  // ts_sample_kernel: TS_NB blocks of TS_BLK ids per row
 hipError_t ts_pick(const TsPickArgs& a, int B, hipStream_t s);
 // Beam search: row r of a self K | V cache [layers][rows][row_bytes] continues the sequence of row parent[r] -- the bytes
 // [off, off + len) of every layer's row parent[r] become row r's (rows with parent[r] == r are left alone).  Two launches

@@ -158,6 +158,7 @@ struct crispy_asr {
   std::map<TsKey, hipGraphExec_t> ts_graphs;
   float* d_plog_all = nullptr;               // [n_text_ctx][dcap_batch] log-probability of every pick
   float* d_nosp = nullptr;                   // [dcap_batch] no_speech_prob of the window
+  float* d_ts_x = nullptr;                   // [dcap_batch][TS_SCRATCH_ROW] the sampling pick's filtered rows
   double* d_u_all = nullptr;                 // [n_text_ctx][dcap_batch] uniform variates of a sampling pass (drawn on the host)
   float* d_temperature = nullptr;            // device scalar
   int* d_row_off = nullptr;                  // [dcap_batch] left padding of every clip's prompt (cache rows)
@@ -359,6 +360,7 @@ void free_dec_ws(crispy_asr* h) {
   if (h->d_plog_all) { (void)hipFree(h->d_plog_all); h->d_plog_all = nullptr; }
   if (h->d_nosp) { (void)hipFree(h->d_nosp); h->d_nosp = nullptr; }
   if (h->d_u_all) { (void)hipFree(h->d_u_all); h->d_u_all = nullptr; }
+  if (h->d_ts_x) { (void)hipFree(h->d_ts_x); h->d_ts_x = nullptr; }
   if (h->d_beam_kv) { (void)hipFree(h->d_beam_kv); h->d_beam_kv = nullptr; h->beam_kv_bytes = 0; }
   if (h->d_beam_parent) { (void)hipFree(h->d_beam_parent); h->d_beam_parent = nullptr; }
   if (h->d_temperature) { (void)hipFree(h->d_temperature); h->d_temperature = nullptr; }
@@ -1042,6 +1044,7 @@ int reserve_dec(crispy_asr* h, int batch, int xclips = 0) {
   HIP_TRY(hipMalloc(&h->d_plog_all, B * C * sizeof(float)));
   HIP_TRY(hipMalloc(&h->d_nosp, B * sizeof(float)));
   HIP_TRY(hipMalloc(&h->d_u_all, B * C * sizeof(double)));
+  HIP_TRY(hipMalloc(&h->d_ts_x, B * (size_t)TS_SCRATCH_ROW * sizeof(float)));
   HIP_TRY(hipMalloc(&h->d_temperature, sizeof(float)));
   HIP_TRY(hipMalloc(&h->d_row_off, B * sizeof(int)));
   HIP_TRY(hipMalloc(&h->d_beam_parent, B * sizeof(int)));
@@ -1482,6 +1485,7 @@ TsPickArgs ts_args(crispy_asr* h, int rules, const unsigned char* mask, const un
   a.delta_min = TS_DELTA_MIN;
   a.temperature = h->d_temperature;
   a.u_all = nullptr;
+  a.x_scratch = h->d_ts_x;
   return a;
 }
 

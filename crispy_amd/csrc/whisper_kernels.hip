@@ -1366,6 +1366,7 @@ __global__ __launch_bounds__(1024) void ts_pick_kernel(TsPickArgs a) {
 // (block, thread, element): per block an inclusive scan of the threads' eight-id sums in double, block bases from a
 // 7 x 16 table of wave totals; the thread whose run contains u walks its eight ids.
 constexpr int TS_THREADS = 1024, TS_WAVES = TS_THREADS / 64, TS_E = 8, TS_BLK = TS_THREADS * TS_E, TS_NB = 7;
+static_assert(TS_SCRATCH_ROW == TS_NB * TS_BLK, "asr_common.h sizes the sampling pick's row scratch");
 // x[e] = logit / T where the rules allow id v0 + e, -inf where they do not or past the row
 __device__ __forceinline__ void ts_load_run(const TsRule& rule, const float* __restrict__ lg, int V, int eot, float T, int v0, float (&x)[TS_E]) {
   float raw[TS_E];
@@ -1390,6 +1391,10 @@ __device__ __forceinline__ void ts_load_run(const TsRule& rule, const float* __r
     const int v = v0 + e;
     x[e] = (v < V && rule.allowed_m(v, eot, mk[e] != 0)) ? raw[e] / T : -INFINITY;
   }
+}
+__device__ __forceinline__ void ts_read_run(const float* __restrict__ xrow, int v0, float (&x)[TS_E]) {     // the thread's own stores
+  const float4 q0 = *reinterpret_cast<const float4*>(xrow + v0), q1 = *reinterpret_cast<const float4*>(xrow + v0 + 4);
+  x[0] = q0.x; x[1] = q0.y; x[2] = q0.z; x[3] = q0.w; x[4] = q1.x; x[5] = q1.y; x[6] = q1.z; x[7] = q1.w;
 }
 __global__ __launch_bounds__(TS_THREADS) void ts_sample_kernel(TsPickArgs a) {
   __shared__ float s_v[2][TS_WAVES];
@@ -1427,11 +1432,17 @@ __global__ __launch_bounds__(TS_THREADS) void ts_sample_kernel(TsPickArgs a) {
   // ---- pass 1: maxima of the text / special ids and of the timestamps ----
   float tv = -INFINITY, xv = -INFINITY;
   int xi = 0x7fffffff;
+  // The row as the passes see it (logit / T where the rules allow the id, -inf elsewhere) is evaluated ONCE and parked in
+  // xrow (global, this row's TS_NB x TS_BLK floats): passes 2 and 3 read a thread's own eight-id runs back instead of
+  // re-deriving them -- the rules and the IEEE division were 44 of the ~126 instructions per id of the three passes.
+  float* __restrict__ xrow = a.x_scratch + (long)b * (TS_NB * TS_BLK);
 #pragma unroll 1
   for (int jb = 0; jb < TS_NB; ++jb) {
     const int v0 = TS_BLK * jb + TS_E * tid;
     float x[TS_E];
     ts_load_run(rule, lg, a.V, a.eot, T, v0, x);
+    *reinterpret_cast<float4*>(xrow + v0) = make_float4(x[0], x[1], x[2], x[3]);
+    *reinterpret_cast<float4*>(xrow + v0 + 4) = make_float4(x[4], x[5], x[6], x[7]);
 #pragma unroll
     for (int e = 0; e < TS_E; ++e) {
       if (v0 + e < a.beg) tv = fmaxf(tv, x[e]);
@@ -1460,7 +1471,7 @@ __global__ __launch_bounds__(TS_THREADS) void ts_sample_kernel(TsPickArgs a) {
   for (int jb = 0; jb < TS_NB; ++jb) {
     const int v0 = TS_BLK * jb + TS_E * tid;
     float x[TS_E];
-    ts_load_run(rule, lg, a.V, a.eot, T, v0, x);
+    ts_read_run(xrow, v0, x);
 #pragma unroll
     for (int e = 0; e < TS_E; ++e) {
       if (x[e] == -INFINITY) continue;                         // not allowed, or past the row
@@ -1484,7 +1495,7 @@ __global__ __launch_bounds__(TS_THREADS) void ts_sample_kernel(TsPickArgs a) {
   for (int jb = 0; jb < TS_NB; ++jb) {
     const int v0 = TS_BLK * jb + TS_E * tid;
     float x[TS_E];
-    ts_load_run(rule, lg, a.V, a.eot, T, v0, x);
+    ts_read_run(xrow, v0, x);
     double sj = 0.0;
 #pragma unroll
     for (int e = 0; e < TS_E; ++e) {
@@ -2010,7 +2021,7 @@ hipError_t beam_kv_reorder(void* kv, void* scratch, const int* parent_dev, int l
 hipError_t ts_pick(const TsPickArgs& a, int B, hipStream_t s) {
   if (a.n_cand < 0 || a.n_cand > TS_MAX_CAND || (a.n_cand > 0 && !(a.u_all && a.cand_tok && a.cand_plog && a.cand_tid))) return hipErrorInvalidValue;
   if (a.u_all) {
-    if (!a.temperature || a.V > TS_BLK * TS_NB) return hipErrorInvalidValue;      // a thread's ids live in TS_NB x TS_E registers
+    if (!a.temperature || !a.x_scratch || a.V > TS_BLK * TS_NB) return hipErrorInvalidValue;      // a thread's ids: TS_NB runs of TS_E
     hipLaunchKernelGGL(ts_sample_kernel, dim3(B), dim3(TS_THREADS), 0, s, a);
     return hipGetLastError();
   }
