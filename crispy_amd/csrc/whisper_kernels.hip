@@ -1263,6 +1263,16 @@ __global__ __launch_bounds__(1024) void ts_pick_kernel(TsPickArgs a) {
       if (ms[u] & 0xff000000u) xs[u].w = -INFINITY;
     }
   }
+  // the ids from EOT up (EOT, specials, timestamps: 1 608 of them, two per thread): value and rule evaluated once, kept in
+  // registers for both passes (re-loading them in the second pass was another exposed round trip to the logits)
+  float hx[2];
+  bool hok[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int v = a.eot + tid + 1024 * k;
+    hok[k] = v < a.V && !rule.masked_hi(min(v, a.V - 1));
+    hx[k] = lg[min(v, a.V - 1)];
+  }
   // every allowed (value, id) of this thread's share of the row: the plain text ids through FT(x, v), the ids from EOT up
   // through FH(x, v).  (A macro, not a lambda: closures that capture the running maxima by reference ended up in scratch.)
 #define TS_SCAN(FT, FH)                                                                                              \
@@ -1292,7 +1302,9 @@ __global__ __launch_bounds__(1024) void ts_pick_kernel(TsPickArgs a) {
         FT(x_, v);                                                                                                   \
       }                                                                                                              \
     }                                                                                                                \
-    for (int v = a.eot + tid; v < a.V; v += 1024)                                                                    \
+    _Pragma("unroll") for (int k = 0; k < 2; ++k)                                                                    \
+      if (hok[k]) FH(hx[k], (a.eot + tid + 1024 * k));                                                               \
+    for (int v = a.eot + tid + 2048; v < a.V; v += 1024)      /* more than 2 048 ids from EOT up: no such vocabulary */ \
       if (!rule.masked_hi(v)) { const float x_ = lg[v]; FH(x_, v); }                                                 \
   } while (0)
   float tv = -INFINITY, xv = -INFINITY;   // best text (v < beg) and best timestamp
