@@ -130,6 +130,11 @@ size_t vocab_f16_packed_bytes(int V, int K);
 hipError_t pack_vocab_f16(const float* E, void* dst, int V, int K, hipStream_t s);
 // logits[M][ldc] (f32) = x[M][ldx] (f16) . E^T, E packed by pack_vocab_f16; K in {384, 512, 768, 1024, 1280}
 hipError_t vocab_f16(const void* x, long ldx, const void* Ep, float* C, long ldc, int M, int N, int K, hipStream_t s);
+// the same with the step's final LayerNorm taken in (fused decode path, M <= VOCAB_FUSE_ROWS rows, K = 384 | 512): the rows
+// are assembled from the last MLP block's partials (FusedIn, asr_common.h below) and normalised by every workgroup itself
+struct FusedIn;
+constexpr int VOCAB_FUSE_ROWS = 4;
+hipError_t vocab_f16_fused(const FusedIn& in, const void* Ep, float* C, long ldc, int M, int N, int K, hipStream_t s);
 hipError_t layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, long rows, int D, hipStream_t s);
 hipError_t attn_encoder_f32(const float* qkv, float* out, int B, int T, int D, int heads, hipStream_t s);
 // Rows of a decode step: one query row per clip, or -- the batched prompt step -- G consecutive rows per clip (row =

@@ -1149,6 +1149,10 @@ int decoder_step_fused(crispy_asr* h, int rows, hipStream_t s) {
   }
   FusedFinishArgs f{};
   f.in = FusedIn{xc, prev_bias, pc, xa, h->dec_ln_w, h->dec_ln_b};
+  if (rows <= VOCAB_FUSE_ROWS) {       // a few rows: the vocabulary projection normalises them itself (one launch fewer in the chain)
+    HIP_TRY(vocab_f16_fused(f.in, h->tok_emb_hp, h->d_logits, logits_ld(h), rows, h->hp.n_vocab, dt, s));
+    return CRISPY_OK;
+  }
   f.y = reinterpret_cast<_Float16*>(h->d_dxn); f.rows = rows; f.D = dt;
   HIP_TRY(fused_finish(f, s));
   HIP_TRY(vocab_f16(h->d_dxn, dt, h->tok_emb_hp, h->d_logits, logits_ld(h), rows, h->hp.n_vocab, dt, s));

@@ -14,6 +14,7 @@
 // requested before the current tile's MFMAs, the four partial tiles meet in a double-buffered LDS image: one barrier
 // per tile.
 #include "asr_common.h"
+#include "fd_ln.h"
 
 namespace crispy {
 namespace {
@@ -41,28 +42,72 @@ __global__ __launch_bounds__(256) void pack_vocab_kernel(const float* __restrict
   *reinterpret_cast<half8*>(dst + idx * 8) = o;
 }
 
-template <int KCH>     // 16-wide K chunks per wave: K = 64 KCH
+// FUSE (steps of <= VOCAB_FUSE_ROWS rows on the fused decode path): x is not read -- every workgroup assembles the step's
+// final residual stream from the last MLP block's partial rows and normalises it itself (fd_ln.h: the instructions of
+// fused_finish_kernel, row r on wave r), which takes the final-LayerNorm launch out of a step that is a chain of launches.
+template <int KCH, bool FUSE>     // 16-wide K chunks per wave: K = 64 KCH
 __global__ __launch_bounds__(256) void vocab_f16_kernel(const _Float16* __restrict__ x, long ldx, const _Float16* __restrict__ Ep,
-                                                        float* __restrict__ C, long ldc, int M, int N, int ntiles) {
+                                                        float* __restrict__ C, long ldc, int M, int N, int ntiles, FusedIn in) {
   __shared__ float red[2][4][64 * 33];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, g = lane >> 5;
   const int mb = blockIdx.y * 64;
   constexpr int KC = 4 * KCH;
-  // this wave's K slice of the 64 rows of x, in operand order (rows >= M: a clamped row, never stored)
-  half8 xa[2][KCH];
-#pragma unroll
-  for (int rb = 0; rb < 2; ++rb) {
-    const _Float16* xr = x + (long)min(mb + 32 * rb + li, M - 1) * ldx + 16 * (wave * KCH) + 8 * g;
-#pragma unroll
-    for (int c = 0; c < KCH; ++c) xa[rb][c] = *reinterpret_cast<const half8*>(xr + 16 * c);
-  }
   const half8* ep = reinterpret_cast<const half8*>(Ep) + (long)wave * KCH * 64 + lane;
   int t = blockIdx.x;
   half8 w[KCH], wn[KCH];
-  if (t < ntiles) {
+  if (t < ntiles) {        // (requested first: in flight while the rows are normalised)
 #pragma unroll
     for (int c = 0; c < KCH; ++c) w[c] = ep[((long)t * KC + c) * 64];
+  }
+  // this wave's K slice of the 64 rows of x, in operand order (rows >= M: a clamped row, never stored)
+  half8 xa[2][KCH];
+  if constexpr (FUSE) {
+    constexpr int D = 64 * KCH, NP = D / 32;
+    float* xs = &red[0][0][0];                                   // [VOCAB_FUSE_ROWS][D] f32, then gamma | beta [2 D]
+    float* gb = xs + VOCAB_FUSE_ROWS * D;
+    _Float16* xn = reinterpret_cast<_Float16*>(&red[1][0][0]);   // [VOCAB_FUSE_ROWS][D] f16
+    // a thread's two columns (tid, tid + 256; the second clamped where D ends), everything of a row requested at once:
+    // one round trip per row, like the final-LayerNorm kernel this replaces
+    constexpr int CPT = (D + 255) / 256;
+    int col[CPT];
+    float bias[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+      col[k] = min(tid + 256 * k, D - 1);
+      gb[col[k]] = in.ln_g[col[k]];
+      gb[D + col[k]] = in.ln_b[col[k]];
+      bias[k] = in.bias[col[k]];
+    }
+#pragma unroll 1
+    for (int r = 0; r < M; ++r) {
+      float v[CPT], pv[CPT][NP];
+#pragma unroll
+      for (int k = 0; k < CPT; ++k) {
+        v[k] = in.x_in[(long)r * D + col[k]];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) pv[k][p] = in.part[((long)p * M + r) * D + col[k]];
+      }
+#pragma unroll
+      for (int k = 0; k < CPT; ++k) xs[r * D + col[k]] = fd_assemble<NP>(v[k], bias[k], pv[k]);      // (a clamped duplicate writes the same value)
+    }
+    __syncthreads();
+    if (wave < M) fd_layernorm_wave<D>(xs + wave * D, gb, xn + wave * D, lane);
+    __syncthreads();
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const _Float16* xr = xn + min(32 * rb + li, M - 1) * D + 16 * (wave * KCH) + 8 * g;
+#pragma unroll
+      for (int c = 0; c < KCH; ++c) xa[rb][c] = *reinterpret_cast<const half8*>(xr + 16 * c);
+    }
+    __syncthreads();                                             // red[] is the tiles' from here on
+  } else {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const _Float16* xr = x + (long)min(mb + 32 * rb + li, M - 1) * ldx + 16 * (wave * KCH) + 8 * g;
+#pragma unroll
+      for (int c = 0; c < KCH; ++c) xa[rb][c] = *reinterpret_cast<const half8*>(xr + 16 * c);
+    }
   }
   int buf = 0;
   for (; t < ntiles; t += gridDim.x) {
@@ -109,6 +154,17 @@ hipError_t pack_vocab_f16(const float* E, void* dst, int V, int K, hipStream_t s
   return hipGetLastError();
 }
 
+hipError_t vocab_f16_fused(const FusedIn& in, const void* Ep, float* C, long ldc, int M, int N, int K, hipStream_t s) {
+  if (M < 1 || M > VOCAB_FUSE_ROWS || !in.x_in || !in.bias || !in.part || !in.ln_g || !in.ln_b) return hipErrorInvalidValue;
+  const int ntiles = (N + 31) / 32;
+  const _Float16* eh = reinterpret_cast<const _Float16*>(Ep);
+  const dim3 grid((unsigned)min(ntiles, 512), 1), block(256);
+  if (K == 384) hipLaunchKernelGGL((vocab_f16_kernel<6, true>), grid, block, 0, s, nullptr, 0L, eh, C, ldc, M, N, ntiles, in);
+  else if (K == 512) hipLaunchKernelGGL((vocab_f16_kernel<8, true>), grid, block, 0, s, nullptr, 0L, eh, C, ldc, M, N, ntiles, in);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
 hipError_t vocab_f16(const void* x, long ldx, const void* Ep, float* C, long ldc, int M, int N, int K, hipStream_t s) {
   const int ntiles = (N + 31) / 32;
   const _Float16* xh = reinterpret_cast<const _Float16*>(x);
@@ -116,7 +172,7 @@ hipError_t vocab_f16(const void* x, long ldx, const void* Ep, float* C, long ldc
   const dim3 block(256);
   const unsigned my = (unsigned)((M + 63) / 64);
 #define CRISPY_VOCAB(KCH, WGS)                                                                              \
-  hipLaunchKernelGGL(vocab_f16_kernel<KCH>, dim3((unsigned)min(ntiles, WGS), my), block, 0, s, xh, ldx, eh, C, ldc, M, N, ntiles)
+  hipLaunchKernelGGL((vocab_f16_kernel<KCH, false>), dim3((unsigned)min(ntiles, WGS), my), block, 0, s, xh, ldx, eh, C, ldc, M, N, ntiles, FusedIn{})
   switch (K) {      // the widths of the Whisper family
     case 384: CRISPY_VOCAB(6, 512); break;
     case 512: CRISPY_VOCAB(8, 512); break;

@@ -38,6 +38,7 @@
 // cache (mode 2: the query and the normalised probabilities rounded to f16, AttnRows::attn16); attention output and GELU'd
 // hidden units rounded to f16 against f16 weights.  Oracle: oracle/whisper_oracle.py DecoderCache(f16=True, ln16=True).
 #include "asr_common.h"
+#include "fd_ln.h"
 
 namespace crispy {
 namespace {
@@ -128,40 +129,18 @@ struct FdInput {
   __device__ __forceinline__ void finish(const FusedIn& in, float bias, int rows, int row0, bool writer, float* xs, const float* gb,
                                          _Float16* xn) {
     const int tid = threadIdx.x, slot = tid / D, col = tid % D;
-    constexpr int PER = D / 64;
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
       const int r = ps * S + slot;
       if (slot < S && r < RB) {
-        float x = v[ps];
-        if (NP > 0) {
-          x += bias;
-#pragma unroll
-          for (int p = 0; p < NP; ++p) x += pv[ps][p];
-        }
+        const float x = fd_assemble<NP>(v[ps], bias, pv[ps]);
         xs[r * D + col] = x;
         if (writer && row0 + r < rows) in.x_out[(long)(row0 + r) * D + col] = x;
       }
     }
     fd_bar();
     const int wave = tid >> 6, lane = tid & 63;
-    if (wave < RB) {
-      const float* xr = xs + wave * D;
-      float e[PER], s = 0.f;
-#pragma unroll
-      for (int q = 0; q < PER; ++q) { e[q] = xr[lane + 64 * q]; s += e[q]; }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-      const float mean = s / (float)D;
-      float s2 = 0.f;
-#pragma unroll
-      for (int q = 0; q < PER; ++q) { const float d = e[q] - mean; s2 = fmaf(d, d, s2); }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) s2 += __shfl_xor(s2, off, 64);
-      const float rstd = 1.f / sqrtf(s2 / (float)D + 1e-5f);
-#pragma unroll
-      for (int q = 0; q < PER; ++q) xn[wave * XLD + lane + 64 * q] = (_Float16)((e[q] - mean) * rstd * gb[lane + 64 * q] + gb[D + lane + 64 * q]);
-    }
+    if (wave < RB) fd_layernorm_wave<D>(xs + wave * D, gb, xn + wave * XLD, lane);
     fd_bar();
   }
 };

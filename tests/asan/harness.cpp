@@ -57,6 +57,7 @@ hipError_t mel_window_launch(const MelArgs&, int, hipStream_t) { return hipSucce
 hipError_t pack_vocab_f16(const float*, void*, int, int, hipStream_t) { return hipSuccess; }
 size_t vocab_f16_packed_bytes(int V, int K) { return (size_t)((V + 31) / 32) * 32 * K * sizeof(_Float16); }
 hipError_t vocab_f16(const void*, long, const void*, float*, long, int, int, int, hipStream_t) { return hipSuccess; }
+hipError_t vocab_f16_fused(const FusedIn&, const void*, float*, long, int, int, int, hipStream_t) { return hipSuccess; }
 hipError_t rs_ola(const float*, float*, long, int, int, hipStream_t) { return hipSuccess; }
 hipError_t rs_prep(const float*, long, long, float, int, float*, int, int, hipStream_t) { return hipSuccess; }
 hipError_t rs_prep_split(const float*, long, long, float, int, void*, int, int, hipStream_t) { return hipSuccess; }

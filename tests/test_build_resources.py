@@ -219,7 +219,7 @@ def test_asr_kernels_have_no_scratch_at_all(tmp_path, src_name):
             assert sum(must in k for k in res) == n, (must, [k for k in res if must in k])
         assert all(r["VGPRs"] + r.get("AGPRs", 0) <= 128 for k, r in res.items() if "fused_" in k and "pack" not in k)
     if src_name == "whisper_dec_f16.hip":
-        assert sum("vocab_f16_kernel" in k for k in res) == 5              # tiny ... large widths
+        assert sum("vocab_f16_kernel" in k for k in res) == 7              # tiny ... large widths + the two forms that take the final LayerNorm in
     bad = {k: r for k, r in res.items() if r.get("ScratchSize", 0) != 0 or r.get("VGPRs Spill", 0) != 0}
     assert not bad, bad
     assert "scratch_store" not in asm.read_text() and "scratch_load" not in asm.read_text()
