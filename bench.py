@@ -1167,6 +1167,18 @@ def cfg2(args):
                                  "serial_step_ms": c.get("serial_step_ms"), "pipe_depth": c.get("pipe_depth"),
                                  "precision_mode": a2.precision, "tokens_checksum": c.get("tokens_checksum")
                                  or (r.get("transcript_ids") or {}).get("checksum"), "leg_wall_s": time.perf_counter() - t0c}
+                    st = line[key]["stage_ms"] or {}
+                    if key == "cfg4" and st.get("resample"):
+                        # the 48 -> 16 kHz stage against its two roofs: the bytes it must move (f32 in at 48 kHz, f32 out at 16 kHz)
+                        # and the f16 matrix-core flops of the pair form it runs as (3 products of 1404 x 342 x 2112 per 30 s stream)
+                        n_str = c.get("streams_per_gpu") or 1024
+                        by = n_str * (1440000 + 480168) * 4.0
+                        fl = n_str * 3 * 2.0 * 1404 * 342 * 2112
+                        ms = st["resample"]
+                        line[key]["resample_roofline"] = {
+                            "hbm": {"achieved": by / ms / 1e6, "peak": 8000.0, "unit": "GB/s", "frac": by / ms / 1e6 / 8000.0},
+                            "mfma": {"achieved": fl / ms / 1e9, "peak": 2500.0, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / 2500.0},
+                            "note": "rubato's FftFixedIn as a fixed linear map on the f16 matrix cores with f16 (hi, lo) operand pairs (DESIGN section 4)"}
                 except Exception as e:     # a reported extra, never a reason to lose the headline
                     line[key] = {"error": str(e)[:300]}
                 torch.cuda.empty_cache()
