@@ -21,6 +21,7 @@
 //       fused_mlp_kernel    x2 = x1 + b + sum(head partials);  LayerNorm;  128 hidden units: fc1 + ggml GELU;  their partial
 //                           fc2                                                                   grid (4 D / 128, rows)
 //       fused_finish_kernel x = x2 + b + sum(MLP partials);  final LayerNorm -> f16 row for the vocabulary projection
+//                           (steps of <= 4 rows: the vocabulary kernel does this itself, whisper_dec_f16.hip / fd_ln.h)
 //
 //   * one workgroup = one head (or 128 hidden units) of 1 - 8 rows, 16 waves; every weight byte the workgroup needs
 //     (196 KB at D = 384) is requested in its first instructions, together with the residual stream and the self K | V
