@@ -58,6 +58,39 @@ def test_resampler_matches_oracle(handoff):
         assert np.abs(out[b] - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), b
 
 
+def test_resampler_forms_agree_and_an_odd_output_stride_is_served():
+    """The resampler has two forms of the same linear map: f16 (hi, lo) operand pairs on the f16 matrix cores (the default;
+    its rows are stored eight bytes at a time, so it needs an even output stride and an 8-byte aligned base) and the f32
+    matrix-core form with an overlap-add pass, which serves every other layout.  Both against the oracle at the same bar,
+    and against each other -- an output buffer with an odd row stride, and one whose base is only 4-byte aligned."""
+    import torch
+    from crispy_amd import synth_audio
+    from crispy_amd.pipeline import Resampler48to16
+    from oracle import resample_oracle as RO
+    B, n = 3, 48000 + 123
+    x = np.stack([synth_audio.stream_np(210 + b, (n + 479) // 480, silent=False)[:n] for b in range(B)]).astype(np.float32)
+    rs = Resampler48to16()
+    n16 = rs.out_len(n)
+    d_in = torch.from_numpy(x).cuda()
+    even = torch.zeros(B, n16, device="cuda")
+    odd = torch.full((B, n16 + 1), 7.0, device="cuda")                 # row stride n16 + 1: odd
+    off = torch.full((B * n16 + 1,), 7.0, device="cuda")               # base + 4 bytes
+    torch.cuda.synchronize()
+    rs.process_device(d_in.data_ptr(), n, n, B, even.data_ptr(), n16)
+    rs.process_device(d_in.data_ptr(), n, n, B, odd.data_ptr(), n16 + 1)
+    rs.process_device(d_in.data_ptr(), n, n, B, off.data_ptr() + 4, n16)
+    rs.synchronize()
+    a, b, c = even.cpu().numpy(), odd.cpu().numpy(), off.cpu().numpy()
+    assert n16 % 2 == 0 and np.all(b[:, n16] == 7.0) and c[0] == 7.0  # nothing written outside the rows
+    for k in range(B):
+        ref = RO.resample_48k_to_16k(x[k])
+        bar = 1e-5 * max(1.0, np.abs(ref).max())
+        assert np.abs(a[k] - ref).max() <= bar and np.abs(b[k, :n16] - ref).max() <= bar
+        assert np.abs(c[1 + k * n16:1 + (k + 1) * n16] - ref).max() <= bar
+        assert np.abs(a[k] - b[k, :n16]).max() <= 5e-6                 # the two forms: a few f32 roundings of a sum of 1026 terms apart
+    rs.close() if hasattr(rs, "close") else None
+
+
 def test_resampler_is_a_unity_gain_lowpass():
     """Size-independent property at 30 s: a 1 kHz tone passes with unit gain, a 10 kHz tone (above the 8 kHz
     Nyquist) is rejected."""
