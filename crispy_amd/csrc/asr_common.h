@@ -12,7 +12,7 @@ namespace crispy {
 // thing evaluated on the fly -- round x to f16, the tanh formula in f32, round the result to f16 -- is the table entry,
 // except where this tanh (1 - 2 / (e^2u + 1): one v_exp_f32, one v_rcp_f32, ~1e-7 absolute) and libm's tanhf land on
 // different sides of an f16 rounding boundary (a 1e-3-relative step for about one value in a thousand).
-// 13 full-rate + 2 quarter-rate instructions per value; the exact-erf form of mode 0 (A&S 7.1.26) needs 22 + 2.
+// 13 plain + 2 transcendental (8-cycle) instructions per value; the exact-erf form of mode 0 (A&S 7.1.26) needs 22 + 2.
 __device__ __forceinline__ float gelu_ggml(float x) {
   const float xh = (float)(_Float16)x;
   const float u = (0.79788456080286535588f * xh) * fmaf(0.044715f * xh, xh, 1.0f);
