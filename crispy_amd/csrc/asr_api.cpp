@@ -381,15 +381,19 @@ int crispy_resampler_process_device(crispy_resampler* h, const float* d_in, long
     for (int b0 = 0; b0 < batch; b0 += group) {
       const int nb = (batch - b0) < group ? (batch - b0) : group;
       HIP_TRY(rs_prep_split(d_in + (long)b0 * in_stride, in_stride, n_in, scale, wav_s16, h->d_planes, nb, n_blk, s));
+      // the streams of the group as ONE row dimension (their block slots are contiguous in the planes): row m is window
+      // m % (n_blk + 1) of stream m / (n_blk + 1); the last window of a stream [last block | the next stream's zero slot] is
+      // not an output block and is dropped by the epilogue (as separate matrices of 1404 rows a tenth of the tiles was padding)
       HGemmArgs g{};
-      g.A = reinterpret_cast<const _Float16*>(h->d_planes); g.lda = RS_PITCH; g.strideA = (long)(n_blk + 1) * RS_PITCH;
+      g.A = reinterpret_cast<const _Float16*>(h->d_planes); g.lda = RS_PITCH;
       g.W = reinterpret_cast<const _Float16*>(h->d_w16); g.ldw = 3L * 2 * RS_PITCH;
-      g.C = d_out + (long)b0 * out_stride; g.ldc = RS_FFT_OUT; g.strideC = out_stride;
-      g.M = n_blk; g.N = RS_FFT_OUT; g.K = 3 * 2 * RS_PITCH;
+      g.C = d_out + (long)b0 * out_stride; g.ldc = RS_FFT_OUT;
+      g.M = nb * (n_blk + 1) - 1; g.N = RS_FFT_OUT; g.K = 3 * 2 * RS_PITCH;      // (- 1: the very last window would read past the planes)
+      g.c_group_rows = n_blk + 1; g.c_group_valid = n_blk; g.c_group_stride = out_stride;
       g.k_seg = 2 * RS_PITCH;
       g.a_seg_off[0] = 0; g.a_seg_off[1] = (long)nb * (n_blk + 1) * RS_PITCH; g.a_seg_off[2] = 0;      // x_hi | x_lo | x_hi
       g.xcd_swizzle = 1;
-      HIP_TRY(gemm_hh(g, HGEMM_F32, nb, s));
+      HIP_TRY(gemm_hh(g, HGEMM_F32, 1, s));
     }
     return CRISPY_OK;
   }

@@ -117,6 +117,11 @@ struct HGemmArgs {
   // from the row's start (W stays [N][K] contiguous) -- the resampler's x_hi | x_lo | x_hi against W_hi | W_hi | W_lo.
   int k_seg;
   long a_seg_off[3];
+  // HGEMM_F32 with the rows of C in groups (c_group_rows > 0): row m of the product is row m % c_group_rows of group
+  // m / c_group_rows, stored at C + group * c_group_stride + row * ldc if row < c_group_valid, dropped otherwise -- the
+  // resampler's streams as ONE row dimension (their last window each is not an output block).
+  int c_group_rows, c_group_valid;
+  long c_group_stride;
 };
 // HGEMM_F32: C = acc as f32 [M][ldc], ldc even (rows 8-byte aligned); no bias
 constexpr int HGEMM_F16 = 0, HGEMM_RES = 1, HGEMM_VT = 2, HGEMM_TAB = 3, HGEMM_KVH = 4, HGEMM_F32 = 5;

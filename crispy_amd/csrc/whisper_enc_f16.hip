@@ -380,7 +380,14 @@ __device__ __forceinline__ void ep_store(const HGemmArgs& g, const float* T, con
     for (int p = 0; p < 16; ++p) {
       const int row = (lane >> 5) + 2 * p;
       const float2 x = *reinterpret_cast<const float2*>(T + row * EP_LD + c2);
-      if (rb + row < mrem && c2 < nrem) *reinterpret_cast<float2*>(C + (long)row * g.ldc + c2) = x;
+      if (g.c_group_rows > 0) {                               // rows in groups: (group, row in group) from the global row
+        const int m = m0 + wm + rb + row;
+        const int grp = m / g.c_group_rows, r = m - grp * g.c_group_rows;
+        if (rb + row < mrem && c2 < nrem && r < g.c_group_valid)
+          *reinterpret_cast<float2*>(reinterpret_cast<float*>(g.C) + (long)grp * g.c_group_stride + (long)r * g.ldc + (n0 + wn) + c2) = x;
+      } else if (rb + row < mrem && c2 < nrem) {
+        *reinterpret_cast<float2*>(C + (long)row * g.ldc + c2) = x;
+      }
     }
   } else if (EPI == EPI_RES || EPI == EPI_TAB) {
     float* __restrict__ C = reinterpret_cast<float*>(g.C) + (long)bz * g.strideC + (long)(m0 + wm + rb) * g.ldc + (n0 + wn);
