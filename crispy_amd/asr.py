@@ -25,11 +25,15 @@ class LogMel:
             raise ValueError("filters must be [n_mel, 201]")
         self.n_mel = n_mel
         self._h = C.c_void_p()
-        N.check(N.lib().crispy_mel_create(f.ctypes.data, n_mel, device, C.byref(self._h)))
+        self._L = N.lib()        # the library this handle belongs to (a test may run another build side by side)
+        self._ck(self._L.crispy_mel_create(f.ctypes.data, n_mel, device, C.byref(self._h)))
+
+    def _ck(self, rc: int) -> None:
+        N.check(rc, self._L)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
-            N.lib().crispy_mel_destroy(self._h)
+            self._L.crispy_mel_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -52,25 +56,25 @@ class LogMel:
             for i, c in enumerate(clips):
                 pcm[i, :c.size] = c
         out = np.empty((pcm.shape[0], self.n_mel, N_FRAMES), dtype=np.float32)
-        N.check(N.lib().crispy_mel_compute(self._h, pcm.ctypes.data, pcm.shape[1], lens.ctypes.data,
+        self._ck(self._L.crispy_mel_compute(self._h, pcm.ctypes.data, pcm.shape[1], lens.ctypes.data,
                                            pcm.shape[0], out.ctypes.data))
         return out
 
     def compute_device(self, d_pcm: int, pcm_stride: int, n_samples: np.ndarray, d_out: int = 0, d_out_t: int = 0,
                        stream: int = 0):
         lens = np.ascontiguousarray(n_samples, dtype=np.int32)
-        N.check(N.lib().crispy_mel_compute_device(self._h, d_pcm, pcm_stride, lens.ctypes.data, lens.size,
+        self._ck(self._L.crispy_mel_compute_device(self._h, d_pcm, pcm_stride, lens.ctypes.data, lens.size,
                                                   d_out or None, d_out_t or None, stream or None))
 
     def window_device(self, clip_idx, seek, d_out: int = 0, d_out_t: int = 0, stream: int = 0):
         """Later 30 s windows (whisper_full's seek loop) of the clips of the last compute_device call."""
         ci = np.ascontiguousarray(clip_idx, dtype=np.int32)
         sk = np.ascontiguousarray(seek, dtype=np.int32)
-        N.check(N.lib().crispy_mel_window_device(self._h, ci.ctypes.data, sk.ctypes.data, ci.size, d_out or None,
+        self._ck(self._L.crispy_mel_window_device(self._h, ci.ctypes.data, sk.ctypes.data, ci.size, d_out or None,
                                                  d_out_t or None, stream or None))
 
     def synchronize(self):
-        N.check(N.lib().crispy_mel_synchronize(self._h))
+        self._ck(self._L.crispy_mel_synchronize(self._h))
 
 
 class WhisperModel:
@@ -83,20 +87,24 @@ class WhisperModel:
         f = whisper_mel_filters(hp.n_mels) if filters is None else np.ascontiguousarray(filters, dtype=np.float32)
         self.hp = hp
         self._h = C.c_void_p()
+        self._L = N.lib()        # the library this handle belongs to
         hpa = (C.c_int * 10)(*hp.as_ints())
-        N.check(N.lib().crispy_asr_create(hpa, f.ctypes.data, device, C.byref(self._h)))
+        self._ck(self._L.crispy_asr_create(hpa, f.ctypes.data, device, C.byref(self._h)))
         for name, shape in tensor_shapes(hp).items():
             if name not in weights:
                 raise KeyError(f"missing tensor {name}")
             w = np.ascontiguousarray(weights[name], dtype=np.float32)
             if w.shape != tuple(shape):
                 raise ValueError(f"{name}: shape {w.shape}, expected {tuple(shape)}")
-            N.check(N.lib().crispy_asr_set_tensor(self._h, name.encode(), w.ctypes.data, w.size))
-        N.check(N.lib().crispy_asr_finalize(self._h))
+            self._ck(self._L.crispy_asr_set_tensor(self._h, name.encode(), w.ctypes.data, w.size))
+        self._ck(self._L.crispy_asr_finalize(self._h))
+
+    def _ck(self, rc: int) -> None:
+        N.check(rc, self._L)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
-            N.lib().crispy_asr_free(self._h)
+            self._L.crispy_asr_free(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -120,36 +128,36 @@ class WhisperModel:
         """PCM clips (16 kHz, <= 30 s each) -> encoder output [B, 1500, d]."""
         pcm, lens = self._pack(clips)
         out = np.empty((pcm.shape[0], self.hp.n_audio_ctx, self.hp.n_audio_state), dtype=np.float32)
-        N.check(N.lib().crispy_asr_encode(self._h, pcm.ctypes.data, pcm.shape[1], lens.ctypes.data, pcm.shape[0],
+        self._ck(self._L.crispy_asr_encode(self._h, pcm.ctypes.data, pcm.shape[1], lens.ctypes.data, pcm.shape[0],
                                           out.ctypes.data))
         return out
 
     def encode_device(self, d_mel_t: int, batch: int, d_out: int, stream: int = 0):
-        N.check(N.lib().crispy_asr_encode_device(self._h, d_mel_t, batch, d_out, stream or None))
+        self._ck(self._L.crispy_asr_encode_device(self._h, d_mel_t, batch, d_out, stream or None))
 
     def synchronize(self):
-        N.check(N.lib().crispy_asr_synchronize(self._h))
+        self._ck(self._L.crispy_asr_synchronize(self._h))
 
     def memory_info(self) -> dict:
         """Device bytes held by the model itself: all weights / of which quantised blocks / de-quantisation scratch."""
         w, q, sc = C.c_size_t(), C.c_size_t(), C.c_size_t()
-        N.check(N.lib().crispy_asr_memory_info(self._h, C.byref(w), C.byref(q), C.byref(sc)))
+        self._ck(self._L.crispy_asr_memory_info(self._h, C.byref(w), C.byref(q), C.byref(sc)))
         return {"weight_bytes": w.value, "quantised_bytes": q.value, "scratch_bytes": sc.value}
 
     def set_precision(self, mode: int):
         """0: f32 operands (default, the mode the oracle parity is pinned in); 1: f16 operands / f32 accumulation
         (whisper.cpp's ggml numerics); 2: mode 1 + the decoder's LayerNorm outputs rounded to f16 in front of q | k | v,
         cross q and fc1 (ggml's rounding points for those products too; opt-in)."""
-        N.check(N.lib().crispy_asr_set_precision(self._h, int(mode)))
+        self._ck(self._L.crispy_asr_set_precision(self._h, int(mode)))
 
     def stage_logits_device(self, d_x: int, batch: int, d_logits: int):
         """Final LayerNorm + vocabulary projection of d_x [batch][n_text_state] into d_logits [batch][n_vocab] (device
         pointers), in the current precision mode: the last block of a decoder step, for parity tests."""
-        N.check(N.lib().crispy_asr_stage_logits_device(self._h, d_x, batch, d_logits))
+        self._ck(self._L.crispy_asr_stage_logits_device(self._h, d_x, batch, d_logits))
 
     def set_suppress(self, ids, first_only: bool = False):
         a = np.ascontiguousarray(ids, dtype=np.int32)
-        N.check(N.lib().crispy_asr_set_suppress(self._h, a.ctypes.data, a.size, int(first_only)))
+        self._ck(self._L.crispy_asr_set_suppress(self._h, a.ctypes.data, a.size, int(first_only)))
 
     def set_default_suppression(self):
         """whisper.cpp's no-timestamps greedy masks: every id above <|endoftext|> is never emitted;
@@ -163,14 +171,14 @@ class WhisperModel:
         toks = np.empty((batch, max_new), dtype=np.int32)
         n = np.empty(batch, dtype=np.int32)
         lg = np.empty((batch, max_new), dtype=np.float32)
-        N.check(N.lib().crispy_asr_decode_greedy_device(self._h, d_enc, batch, p.ctypes.data, p.size, max_new,
+        self._ck(self._L.crispy_asr_decode_greedy_device(self._h, d_enc, batch, p.ctypes.data, p.size, max_new,
                                                         toks.ctypes.data, n.ctypes.data, lg.ctypes.data))
         return toks, n, lg
 
     def detect_language_device(self, d_enc: int, batch: int) -> np.ndarray:
         """Language token per clip (whisper.cpp auto-detection)."""
         out = np.empty(batch, dtype=np.int32)
-        N.check(N.lib().crispy_asr_detect_language_device(self._h, d_enc, batch, out.ctypes.data))
+        self._ck(self._L.crispy_asr_detect_language_device(self._h, d_enc, batch, out.ctypes.data))
         return out
 
     def decode_greedy_lang_device(self, d_enc: int, batch: int, prompt, lang_tokens, max_new: int):
@@ -178,7 +186,7 @@ class WhisperModel:
         lt = np.ascontiguousarray(lang_tokens, dtype=np.int32)
         toks = np.empty((batch, max_new), dtype=np.int32)
         n = np.empty(batch, dtype=np.int32)
-        N.check(N.lib().crispy_asr_decode_greedy_lang_device(self._h, d_enc, batch, p.ctypes.data, p.size,
+        self._ck(self._L.crispy_asr_decode_greedy_lang_device(self._h, d_enc, batch, p.ctypes.data, p.size,
                                                              lt.ctypes.data, max_new, toks.ctypes.data, n.ctypes.data, None))
         return toks, n
 
@@ -193,7 +201,7 @@ class WhisperModel:
         toks = np.empty((batch, max_new), dtype=np.int32)
         tids = np.empty((batch, max_new), dtype=np.int32)
         n = np.empty(batch, dtype=np.int32)
-        N.check(N.lib().crispy_asr_decode_timestamps_device(self._h, d_enc, batch, p.ctypes.data, p.size, ptr(lt), int(rules),
+        self._ck(self._L.crispy_asr_decode_timestamps_device(self._h, d_enc, batch, p.ctypes.data, p.size, ptr(lt), int(rules),
                                                             ptr(sk), ptr(se), max_new, toks.ctypes.data, tids.ctypes.data,
                                                             n.ctypes.data))
         return toks, tids, n
@@ -220,7 +228,7 @@ class WhisperModel:
         plog = np.empty((rows, max_new), dtype=np.float32)
         nosp = np.empty(rows, dtype=np.float32)
         n = np.empty(rows, dtype=np.int32)
-        N.check(N.lib().crispy_asr_decode_window_device(self._h, d_enc, rows, pm.ctypes.data, npr.ctypes.data, stride, int(rules),
+        self._ck(self._L.crispy_asr_decode_window_device(self._h, d_enc, rows, pm.ctypes.data, npr.ctypes.data, stride, int(rules),
                                                         ptr(sk), ptr(se), max_new, float(temperature), ptr(uu),
                                                         toks.ctypes.data, tids.ctypes.data, plog.ctypes.data, nosp.ctypes.data,
                                                         n.ctypes.data))
@@ -234,7 +242,7 @@ class WhisperModel:
         p = np.ascontiguousarray(prompt, dtype=np.int32)
         toks = np.empty((pcm.shape[0], max_new), dtype=np.int32)
         n = np.empty(pcm.shape[0], dtype=np.int32)
-        N.check(N.lib().crispy_asr_transcribe_tokens(self._h, pcm.ctypes.data, pcm.shape[1], lens.ctypes.data,
+        self._ck(self._L.crispy_asr_transcribe_tokens(self._h, pcm.ctypes.data, pcm.shape[1], lens.ctypes.data,
                                                      pcm.shape[0], p.ctypes.data, p.size, max_new,
                                                      toks.ctypes.data, n.ctypes.data))
         return toks, n
@@ -250,15 +258,16 @@ class WhisperEngine(WhisperModel):
         from .whisper_weights import HParams
 
         self._h = C.c_void_p()
-        load = N.lib().crispy_asr_load_resident if resident else N.lib().crispy_asr_load
-        N.check(load(str(model_path).encode(), device, C.byref(self._h)))
+        self._L = N.lib()
+        load = self._L.crispy_asr_load_resident if resident else self._L.crispy_asr_load
+        self._ck(load(str(model_path).encode(), device, C.byref(self._h)))
         hpa = (C.c_int * 10)()
-        N.check(N.lib().crispy_asr_hparams_get(self._h, hpa))
+        self._ck(self._L.crispy_asr_hparams_get(self._h, hpa))
         self.hp = HParams(*[int(v) for v in hpa])
 
     def token_text(self, token: int) -> bytes:
         p, n = C.c_char_p(), C.c_size_t()
-        N.check(N.lib().crispy_asr_token_text(self._h, int(token), C.byref(p), C.byref(n)))
+        self._ck(self._L.crispy_asr_token_text(self._h, int(token), C.byref(p), C.byref(n)))
         return C.string_at(p, n.value)
 
     def transcribe(self, audio: np.ndarray, max_new_tokens: int = 0, translate: bool = False, language_token: int = 0,
@@ -274,12 +283,12 @@ class WhisperEngine(WhisperModel):
         a = np.ascontiguousarray(audio, dtype=np.float32).ravel()
         opts = make_opts(language_token, translate, max_new_tokens, timestamps, prev_text, **decision)
         res = C.c_void_p()
-        N.check(N.lib().crispy_asr_transcribe(self._h, a.ctypes.data if a.size else None, a.size, C.byref(opts),
+        self._ck(self._L.crispy_asr_transcribe(self._h, a.ctypes.data if a.size else None, a.size, C.byref(opts),
                                               C.byref(res)))
         try:
             text, tokens, self.last_language_token, self.last_segments, self.last_windows = _read_result(res)
         finally:
-            N.lib().crispy_asr_free_result(res)
+            self._L.crispy_asr_free_result(res)
         return text, tokens
 
     def transcribe_segments(self, audio: np.ndarray, max_new_tokens: int = 0, language_token: int = 0, prev_text: bool = True,
@@ -331,7 +340,7 @@ def transcribe_batch(engine: "WhisperEngine", clips, max_new_tokens: int = 0, la
     lens = (C.c_size_t * max(nb, 1))(*[a.size for a in arrs])
     res = (C.c_void_p * max(nb, 1))()
     opts = make_opts(language_token, False, max_new_tokens, timestamps, prev_text, **decision)
-    N.check(N.lib().crispy_asr_transcribe_batch(engine._h, ptrs, lens, nb, C.byref(opts), res))
+    engine._ck(engine._L.crispy_asr_transcribe_batch(engine._h, ptrs, lens, nb, C.byref(opts), res))
     out = []
     for i in range(nb):
         r = C.c_void_p(res[i])
@@ -339,7 +348,7 @@ def transcribe_batch(engine: "WhisperEngine", clips, max_new_tokens: int = 0, la
             full = _read_result(r)
             out.append(full if with_segments else full[:3])
         finally:
-            N.lib().crispy_asr_free_result(r)
+            engine._L.crispy_asr_free_result(r)
     return out
 
 

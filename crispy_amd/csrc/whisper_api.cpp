@@ -704,7 +704,8 @@ int crispy_asr_set_precision(crispy_asr* h, int mode) try {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_set_precision: NULL handle");
   if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_set_precision: model not finalized");
   if (mode < 0 || mode > 2)
-    return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_set_precision: mode must be 0 (f32), 1 (f16 operands) or 2 (1 + f16 LayerNorm outputs in the decoder)");
+    return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_set_precision: mode must be 0 (f32 operands), 1 (whisper.cpp's arithmetic: f16 operands of every product, f16 LayerNorm outputs and caches) "
+                "or 2 (1 + the query and the normalised probabilities rounded to f16 inside the attentions)");
   HIP_TRY(hipSetDevice(h->device));
   const bool want_attn16 = mode == 2;
   if (mode == 2) mode = 1;
@@ -1082,23 +1083,32 @@ int decoder_logits(crispy_asr* h, int batch, hipStream_t s, const float* x = nul
   return CRISPY_OK;
 }
 
-// Rows of the biggest decode step the fused kernels take.  One workgroup per (row group, head) holds a head's weights in
-// its registers -- the right shape while the step is a chain of latencies (1 row: 0.108 vs 0.173 ms per token; 64 rows:
-// 0.222 vs 0.291), no better than 32-row matrix-core tiles once the rows fill them: measured per position, fused / staged
-// (the blocks' products on the matrix cores), Whisper-tiny 128 rows 0.337 / 0.397 ms, 256 rows 0.631 / 0.652, 512 rows 1.186 /
-// 1.174; Whisper-base 128 rows 0.657 / 0.702, 256 rows 1.309 / 1.200, 512 rows 2.60 / 2.23.  So: up to 128 rows fused, above
-// staged (one limit for both widths).  Consequence: a row
-// decodes to the same bits alone and in any batch of up to 128 rows, and to the same bits in any batch of 129 .. 512
-// rows; across the two ranges the bits may differ (the forms add a row's partial sums in different orders) while both
-// sit at the mode's bar from the oracle (tests/test_gpu_fused_decode.py).
-constexpr int FUSED_MAX_ROWS = 128;
+// Rows of the biggest decode step the fused kernels take: every step the folded path can hold (SKINNY_MAX_M).  One
+// workgroup per (row group, head) holds a head's weights in its registers -- the right shape while the step is a chain of
+// latencies (1 row: 0.108 vs 0.173 ms per token staged; 64 rows: 0.222 vs 0.291) and within a few per cent of 32-row
+// matrix-core tiles once the rows fill them (Whisper-tiny 512 rows 1.19 vs 1.17 ms).  Rounds 5 switched to the staged
+// kernels above 128 rows; the two forms add a row's partial sums in different orders, so a clip's bits -- at a near tie
+// its tokens -- depended on whether its batch had more than 128 rows.  Now ONE form decodes every
+// generated token of a dense tiny / base model in modes 1 / 2, whatever the batch: a row decodes to the same bits alone
+// and in any batch of up to 512 rows (tests/test_gpu_fused_decode.py, tests/test_gpu_pipeline.py cfg 4 / cfg 5 without
+// any path override).
+constexpr int FUSED_MAX_ROWS = SKINNY_MAX_M;
+// rows of one group of fallback passes (whole clips x best_of); a grouping choice only -- every row's bits are those of
+// its clip decoded alone
+constexpr int kLadderRowsMax = 128;
 
-// CRISPY_ASR_DECODE=stages (test hook, include/crispy_hip.h): every decode step as one launch per stage.  Read at the start
-// of a decode call; a change drops the captured steps.
+// CRISPY_ASR_DECODE=stages (developer knob: `make dev` build only, api_util.h): every decode step as one launch per stage --
+// the second implementation of the same arithmetic the fused kernels are tested against (tests/test_gpu_fused_decode.py
+// loads libcrispy_hip_dev.so for it).  The forms are NOT bit-identical, so the release library does not read it: nothing in
+// a host's environment changes a transcript.  Read at the start of a decode call; a change drops the captured steps.
 void choose_decode_path(crispy_asr* h) {
-  const char* e = test_env("CRISPY_ASR_DECODE");
+  const char* e = dev_env("CRISPY_ASR_DECODE");
   const bool fused = !(e && std::strcmp(e, "stages") == 0);
-  if (fused != h->fused_path) { h->drop_graphs(); h->fused_path = fused; }
+  if (fused != h->fused_path) {
+    (void)hipStreamSynchronize(h->stream);
+    h->drop_graphs();
+    h->fused_path = fused;
+  }
 }
 
 bool fused_step_ok(const crispy_asr* h, int rows) {
@@ -1504,7 +1514,11 @@ template <class Body>
 int step_graph(crispy_asr* h, crispy_asr::TsKey key, Body body, hipGraphExec_t* out) {
   auto slot = h->ts_graphs.find(key);
   if (slot == h->ts_graphs.end()) {
-    if (h->ts_graphs.size() >= 48) h->drop_graphs();      // a bound, not a policy: nothing real alternates between this many shapes
+    if (h->ts_graphs.size() >= 48) {     // a bound, not a policy: nothing real alternates between this many shapes
+      // run_steps launches without waiting (it polls every 8 tokens): an exec replayed a moment ago may still be in flight
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      h->drop_graphs();
+    }
     hipStream_t s = h->stream;
     hipGraphExec_t exec = nullptr;
     hipGraph_t graph = nullptr;
@@ -2717,19 +2731,40 @@ int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const si
         for (int j = 0; j < std::max(best_of, beam); ++j) rngs[k].emplace_back((unsigned)j);
       const int n_init = (int)prompt.size();
       const size_t enc_clip = (size_t)h->hp.n_audio_ctx * h->hp.n_audio_state;
-      // rows of one fallback decode: whole clips x best_of, within what the fused step kernels take
-      const int kLadderRows = FUSED_MAX_ROWS;
+      // rows of one fallback decode: whole clips x best_of
+      const int kLadderRows = kLadderRowsMax;
       // the decoder workspace for the widest pass of this call, taken once: growing it between the greedy pass and the
-      // first fallback pass freed every buffer and dropped the captured steps
+      // first fallback pass freed every buffer and dropped the captured steps.  Widest = the most rows any pass
+      // of the ladder can have: the beam pass at temperature 0 (groups of kLadderRows / beam clips x beam rows) and the
+      // best_of passes above it (kLadderRows / best_of clips x best_of rows) -- ADVICE r5: with beam < best_of the beam
+      // pass is the wider one.
       {
-        const int n_wide = std::max(temps.size() > 1 ? best_of : 1, std::max(beam, 1));
-        if (n_wide > 1) {
-          rc = reserve_dec(h, std::max(nb, std::min(nb * n_wide, (kLadderRows / n_wide) * n_wide)), nb);
+        auto pass_rows = [&](int n_dec) { return std::min(nb * n_dec, std::max(1, kLadderRows / n_dec) * n_dec); };
+        int rows_max = nb;
+        if (temps.size() > 1 && best_of > 1) rows_max = std::max(rows_max, pass_rows(best_of));
+        if (beam > 1) rows_max = std::max(rows_max, pass_rows(beam));
+        if (rows_max > nb) {
+          rc = reserve_dec(h, rows_max, nb);
           if (rc != CRISPY_OK) return rc;
         }
       }
-      float* d_enc_rep = nullptr;                         // the encoder outputs of a group of fallback clips, gathered (one per clip)
+      // the encoder outputs of a group of fallback clips, gathered (one per clip).  The group size changes from pass to pass
+      // (every pending clip in one group at n_dec == 1, kLadderRows / n_dec otherwise): the buffer is kept by capacity and
+      // regrown -- round 5 sized it from the first group that needed it, and a later, larger group overflowed it
+      float* d_enc_rep = nullptr;
+      int enc_rep_clips = 0;
       struct RepGuard { float** p; ~RepGuard() { if (*p) (void)hipFree(*p); } } rep_guard{&d_enc_rep};
+      auto reserve_enc_rep = [&](int n_clips) -> int {
+        if (n_clips <= enc_rep_clips) return CRISPY_OK;
+        if (d_enc_rep) {                                    // copies into / decodes from the old buffer may be in flight
+          HIP_TRY(hipStreamSynchronize(h->stream));
+          (void)hipFree(d_enc_rep);
+          d_enc_rep = nullptr; enc_rep_clips = 0;
+        }
+        HIP_TRY(hipMalloc(&d_enc_rep, (size_t)n_clips * enc_clip * sizeof(float)));
+        enc_rep_clips = n_clips;
+        return CRISPY_OK;
+      };
       auto build_prompt = [&](int k, int lang_tok, float t_cur) {
         std::vector<int> p;
         if (use_past && !past[k].empty() && t_cur < 0.5f) {
@@ -2800,7 +2835,8 @@ int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const si
             bool contiguous = true;               // the group's clips are w_enc's first n_clips, in order
             for (int c = 0; c < n_clips; ++c) contiguous = contiguous && grp[c] == c;
             if (!contiguous) {                    // one copy per CLIP (its decoders share it)
-              if (!d_enc_rep) HIP_TRY(hipMalloc(&d_enc_rep, (size_t)std::min(na, std::max(per_group, 1)) * enc_clip * sizeof(float)));
+              rc = reserve_enc_rep(n_clips);
+              if (rc != CRISPY_OK) return rc;
               for (int c = 0; c < n_clips; ++c)
                 HIP_TRY(hipMemcpyAsync(d_enc_rep + (size_t)c * enc_clip, h->w_enc + (size_t)grp[c] * enc_clip, enc_clip * sizeof(float),
                                        hipMemcpyDeviceToDevice, h->stream));

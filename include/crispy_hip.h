@@ -25,17 +25,17 @@
  *     changes meaning; a binding compares it with crispy_abi_version() when it loads the library and refuses a
  *     mismatch (a caller built against an older crispy_asr_opts would have the library read past its struct).
  *
- * Environment.  The release library reads exactly these variables -- test hooks that choose between forms whose results
- * are bit-identical (the test that uses one asserts that); nothing else in a host's environment changes what runs.
- * Developer A/B knobs exist only in the `make dev` build (crispy_amd/csrc/api_util.h: dev_env).
+ * Environment.  The release library reads exactly these three variables -- test hooks that choose between forms whose
+ * results are bit-identical (the test that uses one asserts that); nothing else in a host's environment changes what runs,
+ * and nothing in it changes a result.  Developer A/B knobs exist only in the `make dev` build, libcrispy_hip_dev.so
+ * (crispy_amd/csrc/api_util.h: dev_env) -- among them CRISPY_ASR_DECODE=stages, the decode step as one launch per stage,
+ * whose results are NOT bit-identical to the fused step kernels' (tests/test_gpu_fused_decode.py compares the two builds).
  *     CRISPY_RN_WAVES=1|3        frame-kernel form of a crispy_rn handle (default: 3 up to 1280 streams, 1 above);
  *                                read by crispy_rn_create*            (tests/test_gpu_rnnoise.py)
  *     CRISPY_ASR_PREFILL=seq     prompt one position per step instead of multi-position steps; read per decode call
  *                                                                     (tests/test_gpu_prefill.py)
  *     CRISPY_ASR_TILE_ROWS=192|256  tile height of the mode-1 encoder GEMMs; read once per process
  *                                                                     (tests/test_gpu_mode1.py)
- *     CRISPY_ASR_DECODE=stages   decode steps as one launch per stage instead of the fused step kernels; read per decode
- *                                call                                 (tests/test_gpu_fused_decode.py)
  */
 #ifndef CRISPY_HIP_H
 #define CRISPY_HIP_H

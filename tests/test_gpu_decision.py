@@ -344,6 +344,43 @@ def test_fallback_passes_of_a_batch_run_side_by_side_and_equal_the_single_calls(
     eng.close()
 
 
+def test_fallback_groups_that_grow_between_passes_stay_inside_their_buffers(tmp_path_factory):
+    """the gathered encoder outputs of a group of fallback clips were allocated once per call, sized by the
+    FIRST group that needed them -- and the group size changes from pass to pass: 128 / beam clips at temperature 0, 128 /
+    best_of above.  21 clips of the ladder model, beam 8: clip 0 (7 s) passes its second window, clips 1 .. 20 (13 s) fail
+    theirs at temperature 0 in groups of 16 + 4 (not a prefix of the active clips: gathered copies, buffer of 16 clips), then
+    decode again at 0.2 .. 0.6 with best_of = 5 as ONE group of 20 clips -- 4 clips past the end of the round-5 buffer (9 MB
+    over whatever lay behind it).  Every clip must equal its single call, as in the test above."""
+    from crispy_amd import synth_audio
+    from crispy_amd.asr import WhisperEngine, transcribe_batch
+    from crispy_amd.whisper_weights import HParams
+    from tests.scripted_model import script_rows, scripted_whisper_weights
+    hp = HParams.tiny()
+    sp, BEG, EOT = _scripts(hp)
+    X, Y, REP = 1234, 2345, 777
+    beta = 1.0 - 1.0 * np.sqrt(2.0) / hp.n_text_state
+    rows = script_rows(2, [BEG, 1001, [(X, 1.0), (Y, beta)], 1003, BEG + 300, BEG + 300, EOT])
+    rows.update(script_rows(9, [BEG] + [REP] * 40 + [BEG + 100, BEG + 100, EOT]))
+    W = scripted_whisper_weights(hp, rows, gain=100.0)
+    eng = WhisperEngine(_engine_file(tmp_path_factory, hp, W, "ladder-grow"))
+    eng.set_precision(1)
+    base = synth_audio.clip16k_np(80, 16000 * 13)
+    clips = [base[:16000 * 7]] + [base[:16000 * 13 - 160 * i] for i in range(20)]
+    kw = dict(language_token=sp["lang0"], timestamps=True, with_segments=True, beam_size=8)
+    got = transcribe_batch(eng, clips, **kw)
+    temps = {round(w["temperature"], 1) for r in got for w in r[4]}
+    assert 0.0 in temps and max(temps) >= 0.2, temps             # windows accepted at temperature 0 and in the ladder
+    for c in (0, 1, 17, 20):
+        solo = transcribe_batch(eng, [clips[c]], **kw)[0]
+        assert got[c] == solo, (c, got[c][4], solo[4])
+    # the same with one sampling decoder and a log-probability bar nothing passes: groups of ALL pending clips
+    kw1 = dict(language_token=sp["lang0"], timestamps=True, with_segments=True, best_of=1)
+    got1 = transcribe_batch(eng, clips, **kw1)
+    for c in (0, 2, 20):
+        assert got1[c] == transcribe_batch(eng, [clips[c]], **kw1)[0], c
+    eng.close()
+
+
 def test_non_speech_suppression_initial_prompt_and_carried_context(oracle, tmp_path_factory):
     """The whisper_full parameters a host may set beyond the defaults (crispy_asr_opts, ABI 3), product
     against oracle in precision mode 1:

@@ -1,30 +1,34 @@
 """The fused decode step (crispy_amd/csrc/whisper_dec_fused.hip): a generated token's decoder layer in three launches --
 self-attention block, cross-attention block, MLP block, each with the preceding projection's all-to-all turned into
-partial rows the next launch adds up -- against the same step as one launch per stage (CRISPY_ASR_DECODE=stages, a test
-hook of the library) and against the oracle of the mode (oracle/whisper_oracle.py DecoderCache(f16=True): f16 LayerNorm
-outputs, f16 K | V caches, f16 operands of every product, f32 accumulation -- ggml's arithmetic [UPSTREAM-RECALL]).
-Reference call shape: engine.transcribe per token, src-tauri/src/managers/transcription.rs:183-185.
+partial rows the next launch adds up.  It is the ONE form the product decodes a generated token of a dense Whisper-tiny /
+-base model with in precision modes 1 / 2, whatever the batch (1 .. 512 rows): asserted here as "a row decodes to the same
+ids and the same picked-logit bytes alone and in batches of 70, 129 and 512 rows" (the reference has
+one engine and one answer per chunk: src-tauri/src/managers/transcription.rs:27,178).
 
-The two launch forms add a row's partial sums in different orders, so they are NOT bit-identical to each other; each is
-deterministic and independent of the batch (asserted), and both sit at the mode's bar from the oracle (asserted)."""
-import os
-
+Second implementation of the same arithmetic: the step as one launch per stage (`CRISPY_ASR_DECODE=stages`, a developer
+knob that only libcrispy_hip_dev.so reads -- tests/native_variant.py).  The two forms add a row's partial sums in different
+orders, so they are NOT bit-identical to each other; each is deterministic, and both sit at the mode's bar from the oracle
+(oracle/whisper_oracle.py DecoderCache(f16=True): f16 LayerNorm outputs, f16 K | V caches, f16 operands of every product,
+f32 accumulation -- ggml's arithmetic [UPSTREAM-RECALL]).
+Reference call shape: engine.transcribe per token, src-tauri/src/managers/transcription.rs:183-185."""
 import numpy as np
 import pytest
+
+from tests.native_variant import staged_decoder
 
 pytestmark = pytest.mark.gpu
 
 
-def _path(stages, fn):
-    old = os.environ.pop("CRISPY_ASR_DECODE", None)
-    try:
-        if stages:
-            os.environ["CRISPY_ASR_DECODE"] = "stages"
-        return fn()
-    finally:
-        os.environ.pop("CRISPY_ASR_DECODE", None)
-        if old is not None:
-            os.environ["CRISPY_ASR_DECODE"] = old
+def _staged(hp, W, mode, d_enc_ptr, rows, prompt, n_new):
+    """The same decode call through the developer build's one-launch-per-stage step."""
+    from crispy_amd.asr import WhisperModel
+    with staged_decoder():
+        m = WhisperModel(hp, W)
+        try:
+            m.set_precision(mode)
+            return m.decode_greedy_device(d_enc_ptr, rows, prompt, n_new)
+        finally:
+            m.close()
 
 
 @pytest.fixture(scope="module", params=["tiny", "base"])
@@ -53,12 +57,12 @@ def test_fused_step_against_the_staged_step_and_the_oracle(model, mode):
     torch.cuda.synchronize()
     try:
         m.set_precision(mode)
-        tf, _, lf = _path(False, lambda: m.decode_greedy_device(d_enc.data_ptr(), B, prompt, n_new))
-        tf2, _, lf2 = _path(False, lambda: m.decode_greedy_device(d_enc.data_ptr(), B, prompt, n_new))
-        ts, _, ls = _path(True, lambda: m.decode_greedy_device(d_enc.data_ptr(), B, prompt, n_new))
-        solo, _, lsolo = _path(False, lambda: m.decode_greedy_device(d_enc[2:3].contiguous().data_ptr(), 1, prompt, n_new))
+        tf, _, lf = m.decode_greedy_device(d_enc.data_ptr(), B, prompt, n_new)
+        tf2, _, lf2 = m.decode_greedy_device(d_enc.data_ptr(), B, prompt, n_new)
+        solo, _, lsolo = m.decode_greedy_device(d_enc[2:3].contiguous().data_ptr(), 1, prompt, n_new)
     finally:
         m.set_precision(0)
+    ts, _, ls = _staged(hp, W, mode, d_enc.data_ptr(), B, prompt, n_new)
     assert np.array_equal(tf, tf2) and lf.tobytes() == lf2.tobytes()                 # deterministic
     assert np.array_equal(solo[0], tf[2]) and lsolo[0].tobytes() == lf[2].tobytes()   # alone = in the batch, bit for bit
     best = np.zeros((B, n_new)); margin = np.zeros((B, n_new)); ids = np.zeros((B, n_new), np.int64)
@@ -105,12 +109,12 @@ def test_fused_step_over_every_key_class_and_many_rows(model, n_new, rows):
     torch.cuda.synchronize()
     try:
         m.set_precision(1)
-        tf, nf, lf = _path(False, lambda: m.decode_greedy_device(d_enc.data_ptr(), rows, prompt, n_new))
-        ts, ns, ls = _path(True, lambda: m.decode_greedy_device(d_enc.data_ptr(), rows, prompt, n_new))
+        tf, nf, lf = m.decode_greedy_device(d_enc.data_ptr(), rows, prompt, n_new)
         r = rows - 1
-        solo, _, lsolo = _path(False, lambda: m.decode_greedy_device(d_enc[r:r + 1].contiguous().data_ptr(), 1, prompt, n_new))
+        solo, _, lsolo = m.decode_greedy_device(d_enc[r:r + 1].contiguous().data_ptr(), 1, prompt, n_new)
     finally:
         m.set_precision(0)
+    ts, ns, ls = _staged(hp, W, 1, d_enc.data_ptr(), rows, prompt, n_new)
     assert np.array_equal(solo[0], tf[r]) and lsolo[0].tobytes() == lf[r].tobytes()
     agree = []
     for b in range(rows):
@@ -125,3 +129,35 @@ def test_fused_step_over_every_key_class_and_many_rows(model, n_new, rows):
     # (a row whose top two logits sit closer than the forms' difference in accumulation order parts ways there -- one of
     # 70 rows did at its 6th pick -- and everything behind that pick is another sequence)
     assert np.median(agree) >= min(n_new, 30) and np.mean(np.asarray(agree) >= 12) >= 0.9, agree
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_a_row_decodes_to_the_same_bits_in_batches_of_1_70_129_and_512(model, mode):
+    """The product's own path selection, no override: the first 1 / 70 / 129 / 512 of 512 clips decode as ONE step batch each
+    (the kernels pick other rows-per-workgroup shapes, grids of 6 to 8192 workgroups, plain and non-temporal K | V loads);
+    every clip of a smaller batch must come out of every larger one with the same ids and the same picked-logit BYTES.
+    512 rows is the step size BASELINE cfg 4 decodes with, 129 the first size that took the staged kernels in round 5."""
+    import torch
+    m, hp, W = model
+    n_new = 12
+    g = torch.Generator(device="cuda:0").manual_seed(77)
+    d_enc = torch.randn(512, 1500, hp.n_audio_state, generator=g, device="cuda:0") * 0.8
+    prompt = [50258, 50259, 50359, 50363]
+    torch.cuda.synchronize()
+    out = {}
+    try:
+        m.set_precision(mode)
+        for rows in (1, 70, 129, 512):
+            t, _, l = m.decode_greedy_device(d_enc.data_ptr(), rows, prompt, n_new)
+            out[rows] = (t.copy(), l.copy())
+        # and from the middle of the big batch: clip 300 alone
+        t300, _, l300 = m.decode_greedy_device(d_enc[300:301].contiguous().data_ptr(), 1, prompt, n_new)
+    finally:
+        m.set_precision(0)
+    t512, l512 = out[512]
+    for rows in (1, 70, 129):
+        t, l = out[rows]
+        assert np.array_equal(t, t512[:rows]), (rows, np.nonzero((t != t512[:rows]).any(axis=1))[0][:8])
+        assert l.tobytes() == l512[:rows].tobytes(), rows
+    assert np.array_equal(t300[0], t512[300]) and l300[0].tobytes() == l512[300].tobytes()
+    assert len({tuple(r) for r in t512.tolist()}) > 256          # the rows are different sequences, not one repeated

@@ -7,24 +7,6 @@ pytestmark = pytest.mark.gpu
 
 
 
-import contextlib
-import os
-
-
-@contextlib.contextmanager
-def _decode_path(value):
-    """CRISPY_ASR_DECODE for the calls inside (read by the library at the start of every decode call)."""
-    old = os.environ.get("CRISPY_ASR_DECODE")
-    os.environ["CRISPY_ASR_DECODE"] = value
-    try:
-        yield
-    finally:
-        if old is None:
-            os.environ.pop("CRISPY_ASR_DECODE", None)
-        else:
-            os.environ["CRISPY_ASR_DECODE"] = old
-
-
 def test_resampler_out_len_follows_the_chunk_loop():
     from crispy_amd.pipeline import Resampler48to16
     for n in (0, 1, 1023, 1024, 1025, 1026, 2048, 2052, 48000, 1440000, 1439520):
@@ -240,16 +222,14 @@ def test_cfg4_full_size_1024_streams_x_30_s_end_to_end(oracle, precision):
     assert distinct > 200, distinct                                      # the transcript depends on the audio
     pick = [0, 333, 1023]
     solo = DenoiseTranscribePipeline(w, wm, 1)
-    # The batch decodes in groups of 512 rows: one launch per stage.  A step of up to 128 rows takes the fused step
-    # kernels in modes 1 / 2 (whisper_api.cpp: FUSED_MAX_ROWS), which add a row's partial sums in another order -- so the
-    # solo run is held to the staged form too (the library's test hook), and "alone = in the batch, bit for bit" is the
-    # statement it has always been: same kernels, any batch.  Fused against staged: tests/test_gpu_fused_decode.py.
-    with _decode_path("stages"):
-        for b in pick:
-            t1, p1 = solo.run(x[b:b + 1].contiguous(), prompt, NEW)
-            assert torch.equal(p1[0], pcm16[b]), b
-            assert np.array_equal(t1[0], toks[b]), (b, t1[0], toks[b])
-            solo.ds.reset()
+    # The batch decodes in groups of 512 rows, the solo run one row at a time -- both through the product's own path
+    # selection (the fused step kernels at every batch size since round 6: whisper_api.cpp FUSED_MAX_ROWS): "alone = in a
+    # BASELINE batch, bit for bit" with no override.
+    for b in pick:
+        t1, p1 = solo.run(x[b:b + 1].contiguous(), prompt, NEW)
+        assert torch.equal(p1[0], pcm16[b]), b
+        assert np.array_equal(t1[0], toks[b]), (b, t1[0], toks[b])
+        solo.ds.reset()
     xs = x[pick, :301].cpu().numpy()
     got = pcm16[pick].cpu().numpy()
     for i, b in enumerate(pick):
@@ -357,8 +337,7 @@ def test_cfg5_one_shard_whisper_base_sub_batch_of_256_clips(oracle, precision):
         e1 = m.encode([pcm[b].cpu().numpy()])[0]
         if not np.array_equal(e1, enc[b].cpu().numpy()):
             pytest.fail(_cfg5_mismatch_report(m, lm, hp, pcm, melt, enc, b, e1))
-        with _decode_path("stages"):           # 256 rows decode one launch per stage; so does the solo run here (see cfg 4)
-            t1, _ = m.transcribe_tokens([pcm[b].cpu().numpy()], prompt, NEW)
+        t1, _ = m.transcribe_tokens([pcm[b].cpu().numpy()], prompt, NEW)      # alone, no path override (see cfg 4)
         assert np.array_equal(t1[0], toks[b]), (b, t1[0], toks[b])
     b = 100
     mel = oracle.oracle_logmel(pcm[b].cpu().numpy(), whisper_mel_filters(hp.n_mels))

@@ -18,11 +18,11 @@ def tiny():
 
 
 @pytest.mark.parametrize("kind", ["q4_1", "q5_0", "q8_0", "q4_0", "q5_1"])
-def test_resident_model_equals_the_inflated_one(tiny, tmp_path, kind, monkeypatch):
+def test_resident_model_equals_the_inflated_one(tiny, tmp_path, kind):
     # "same kernels": a resident model's generated tokens run one launch per stage (the projections de-quantise their blocks
     # in registers); an inflated Whisper-tiny would take the fused step kernels, which add a row's partial sums in another
-    # order -- so the inflated engine is held to the staged path for this comparison (the library's test hook)
-    monkeypatch.setenv("CRISPY_ASR_DECODE", "stages")
+    # order -- so the inflated engine is held to the staged path for this comparison: it lives in the developer build of the
+    # library, which reads CRISPY_ASR_DECODE=stages (tests/native_variant.py; the release library no longer does)
     from crispy_amd import _native as N, synth_audio
     from crispy_amd.asr import WhisperEngine, transcribe_batch
     from crispy_amd.ggml_io import synthetic_vocab, write_ggml_quantized
@@ -31,8 +31,18 @@ def test_resident_model_equals_the_inflated_one(tiny, tmp_path, kind, monkeypatc
     path = tmp_path / f"tiny-{kind}.bin"
     write_ggml_quantized(str(path), hp, W, whisper_mel_filters(80), synthetic_vocab(hp.n_vocab), kind)
     res = WhisperEngine(str(path), resident=True)
-    inf = WhisperEngine(str(path))
-    inf.set_precision(1)
+    from tests.native_variant import staged_decoder
+    with staged_decoder():                   # (the knob is read per decode call: the comparisons below stay inside the block)
+        inf = WhisperEngine(str(path))
+        inf.set_precision(1)
+        _compare_resident_with_inflated(res, inf, hp, W, kind, path)
+        inf.close()
+    res.close()
+
+
+def _compare_resident_with_inflated(res, inf, hp, W, kind, path):
+    from crispy_amd import _native as N, synth_audio
+    from crispy_amd.asr import transcribe_batch
     # memory: the matrices are blocks, nothing of them exists as f32
     n_mat = sum(int(np.prod(v.shape)) for k, v in W.items() if v.ndim == 2 and "positional" not in k)
     bpw = {"q4_0": 18, "q4_1": 20, "q5_0": 22, "q5_1": 24, "q8_0": 34}[kind] / 32.0
@@ -68,7 +78,6 @@ def test_resident_model_equals_the_inflated_one(tiny, tmp_path, kind, monkeypatc
     tb, _ = inf.transcribe_tokens(many, prompt, 4)
     assert np.array_equal(ta, tb)
     assert len({tuple(t) for t in ta.tolist()}) > 10          # audio-sensitive weights: the clips decode differently
-    res.close(); inf.close()
 
 
 def test_resident_load_of_a_dense_file_is_the_ordinary_engine(tiny, tmp_path):
