@@ -902,6 +902,7 @@ def main():
                     help="cfg5: 1 = f16 operands / f32 accumulation, the arithmetic of the reference's whisper.cpp engine (default); "
                          "0 = exact f32 products (the mode the oracle parity is stated in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-fed", action="store_true", help="cfg2: skip the PCIe-inclusive leg (f32 and int16 transport) of the default run")
     ap.add_argument("--no-asr", action="store_true", help="skip the Whisper-tiny leg of the metric")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-stream process_frame latency leg")
     ap.add_argument("--no-cfg45", action="store_true", help="cfg2: skip the in-process cfg4 / cfg5 legs")
@@ -955,6 +956,42 @@ def _bind_numa(local_rank: int, world: int):
     """Before torch or HIP are touched: pin this rank to the CPUs of its GPU's NUMA node (crispy_amd/launch.py)."""
     from crispy_amd.launch import bind_rank_to_gpu_numa
     return bind_rank_to_gpu_numa(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+
+
+def host_fed_leg(ds, d_in, B, T, steps=20, warmup=2):
+    """The PCIe-inclusive flavour of the headline, inside the default run: the same step fed from
+    page-locked HOST memory through crispy_rn_process (f32 samples) and crispy_rn_process_s16 (int16 samples: the formats the
+    reference's capture / recording paths hold, audio.rs:794-855) -- copy-in, kernels and copy-out pipelined in pieces of
+    frames.  717 k "streams" of the HBM-resident headline are 275 GB/s of f32 PCM each way: no host link feeds that; this is
+    what one does."""
+    import numpy as np
+    from crispy_amd.denoise import DenoiseState
+    out = {}
+    h_f = d_in.cpu().numpy()
+    legs = (("f32", h_f, lambda x, o, v: ds.process_into(x, o, v)),
+            ("s16", np.clip(np.rint(h_f), -32768, 32767).astype(np.int16), lambda x, o, v: ds.process_s16(x, out=o, vad=v)))
+    for name, h_in, call in legs:
+        h_out = np.empty_like(h_in)
+        h_vad = np.empty((T, B), dtype=np.float32)
+        for arr in (h_in, h_out):
+            DenoiseState.register_host(arr)
+        try:
+            for _ in range(warmup):
+                call(h_in, h_out, h_vad)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                call(h_in, h_out, h_vad)          # (returns when `out` is complete: nothing left in flight)
+            dt = time.perf_counter() - t0
+        finally:
+            for arr in (h_in, h_out):
+                DenoiseState.unregister_host(arr)
+        out[name] = {"value": B * T * steps / dt / 100.0, "ms_per_step": dt / steps * 1e3, "steps": steps,
+                     "pcie_gbps_each_way": h_in.nbytes * steps / dt / 1e9, "bytes_per_sample": int(h_in.itemsize)}
+    return {"unit": "concurrent real-time 48 kHz streams (this GPU), input and output in page-locked host memory",
+            "value": out["f32"]["value"], "ms_per_step": out["f32"]["ms_per_step"],
+            "pcie_gbps_each_way": out["f32"]["pcie_gbps_each_way"], "f32": out["f32"], "s16": out["s16"],
+            "s16_over_f32": out["s16"]["value"] / out["f32"]["value"],
+            "entry_points": "crispy_rn_process / crispy_rn_process_s16 (pieces of frames on three streams; DESIGN section 6)"}
 
 
 def cfg2(args):
@@ -1123,6 +1160,11 @@ def cfg2(args):
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not args.host_fed and not args.no_host_fed:
+            try:
+                line["host_fed"] = host_fed_leg(ds, d_in, B, T)
+            except Exception as e:     # a reported extra, never a reason to lose the headline
+                line["host_fed"] = {"error": str(e)[:300]}
         if world == 1 and not args.no_latency:
             # the literal drop-in: ONE stream, ONE frame per call, host slices (audio.rs:260-268), from a C program
             # compiled against include/crispy_hip.h; a child process, timed call by call

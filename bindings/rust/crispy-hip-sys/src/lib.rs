@@ -27,12 +27,13 @@ pub const CRISPY_ERR_HIP: c_int = -3;
 pub const CRISPY_ERR_OOM: c_int = -4;
 pub const CRISPY_ERR_BAD_MODEL: c_int = -5;
 pub const CRISPY_ERR_UNSUPPORTED: c_int = -6;
+pub const CRISPY_ERR_CANCELLED: c_int = -7;
 
 pub const CRISPY_RN_FRAME_SIZE: usize = 480;
 pub const CRISPY_RN_WEIGHT_BYTES: usize = 87503;
 pub const CRISPY_RN_TAPS: usize = 72;
 /// The ABI this file was written against (crispy_hip.h: CRISPY_ABI_VERSION); every constructor checks it.
-pub const CRISPY_ABI_VERSION: c_int = 3;
+pub const CRISPY_ABI_VERSION: c_int = 4;
 pub const CRISPY_MEL_FRAMES: usize = 3000;
 pub const CRISPY_MEL_BINS: usize = 201;
 
@@ -157,6 +158,9 @@ pub struct crispy_asr_result {
     pub windows: *const crispy_asr_window,
 }
 
+/// `crispy_asr_progress_fn`: called after every group of chunks with (samples done, samples total, user).
+pub type crispy_asr_progress_fn = Option<unsafe extern "C" fn(samples_done: usize, samples_total: usize, user: *mut c_void)>;
+
 extern "C" {
     pub fn crispy_last_error() -> *const c_char;
     pub fn crispy_version() -> *const c_char;
@@ -176,6 +180,8 @@ extern "C" {
     pub fn crispy_host_register(p: *mut c_void, bytes: usize) -> c_int;
     pub fn crispy_host_unregister(p: *mut c_void) -> c_int;
     pub fn crispy_rn_process_device(h: *mut crispy_rn, d_in: *const c_float, d_out: *mut c_float, d_vad: *mut c_float, d_taps: *mut c_float, n_frames: c_int, layout: crispy_rn_layout, hip_stream: *mut c_void) -> c_int;
+    pub fn crispy_rn_process_s16(h: *mut crispy_rn, input: *const i16, out: *mut i16, vad: *mut c_float, n_frames: c_int, layout: crispy_rn_layout) -> c_int;
+    pub fn crispy_rn_process_s16_device(h: *mut crispy_rn, d_in: *const i16, d_out: *mut i16, d_vad: *mut c_float, n_frames: c_int, layout: crispy_rn_layout, hip_stream: *mut c_void) -> c_int;
     pub fn crispy_rn_synchronize(h: *mut crispy_rn) -> c_int;
     pub fn crispy_rn_set_timing(h: *mut crispy_rn, enable: c_int) -> c_int;
     pub fn crispy_rn_last_kernel_ms(h: *mut crispy_rn, frame_kernel_ms: *mut c_float, total_ms: *mut c_float) -> c_int;
@@ -216,6 +222,7 @@ extern "C" {
     pub fn crispy_asr_transcribe(h: *mut crispy_asr, pcm16k: *const c_float, n: usize, opts: *const crispy_asr_opts, out: *mut *mut crispy_asr_result) -> c_int;
     pub fn crispy_asr_transcribe_batch(h: *mut crispy_asr, pcm: *const *const c_float, n: *const usize, batch: c_int, opts: *const crispy_asr_opts, results: *mut *mut crispy_asr_result) -> c_int;
     pub fn crispy_asr_free_result(r: *mut crispy_asr_result);
+    pub fn crispy_asr_transcribe_recording(h: *mut crispy_asr, pcm16k: *const c_float, n: usize, opts: *const crispy_asr_opts, max_batch: c_int, cancel_flag: *const c_int, progress: crispy_asr_progress_fn, progress_user: *mut c_void, out: *mut *mut crispy_asr_result) -> c_int;
 
     pub fn crispy_resampler_create(device: c_int, out: *mut *mut crispy_resampler) -> c_int;
     pub fn crispy_resampler_destroy(h: *mut crispy_resampler);
@@ -445,26 +452,72 @@ impl GpuWhisperEngine {
         let o = opts.map_or(std::ptr::null(), |o| o as *const crispy_asr_opts);
         let p = if audio.is_empty() { std::ptr::null() } else { audio.as_ptr() };
         check(unsafe { crispy_asr_transcribe(self.h, p, audio.len(), o, &mut r) })?;
-        // SAFETY: on success r points to a library-owned result that stays valid until crispy_asr_free_result.
-        let out = unsafe {
-            let res = &*r;
-            let text = if res.text.is_null() { String::new() } else { CStr::from_ptr(res.text).to_string_lossy().into_owned() };
-            let tokens = if res.n_tokens > 0 { std::slice::from_raw_parts(res.tokens, res.n_tokens as usize).to_vec() } else { Vec::new() };
-            let segments = if res.n_segments > 0 {
-                Some(std::slice::from_raw_parts(res.segments, res.n_segments as usize).iter().map(|s| Segment {
-                    start: s.t0,
-                    end: s.t1,
-                    text: if s.text.is_null() { String::new() } else { CStr::from_ptr(s.text).to_string_lossy().into_owned() },
-                }).collect())
-            } else {
-                None
-            };
-            let windows = if res.n_windows > 0 { std::slice::from_raw_parts(res.windows, res.n_windows as usize).to_vec() } else { Vec::new() };
-            Transcript { text, segments, tokens, language_token: res.language_token, windows }
-        };
-        unsafe { crispy_asr_free_result(r) };
-        Ok(out)
+        Ok(unsafe { take_result(r) })
     }
+    /// `run_transcription`'s chunk loop (commands/transcription.rs:249-302, 363-400, 468) over a whole 16 kHz recording in
+    /// ONE call: 30 s chunks decoded `max_batch` at a time (0 = 128), chunk texts trimmed and joined with a space.
+    /// `cancel`: the reference's `Arc<AtomicBool>` (polled before every group and between windows; a set flag gives
+    /// `Err` with `code == CRISPY_ERR_CANCELLED`, where the reference returns without saving).  `progress(done, total)` in
+    /// samples after every group -- what the reference emits as "transcription-progress" (:285-299).
+    pub fn transcribe_recording(&mut self, audio: &[f32], opts: Option<&crispy_asr_opts>, max_batch: usize,
+                                cancel: Option<&std::sync::atomic::AtomicBool>, mut progress: Option<&mut dyn FnMut(usize, usize)>)
+                                -> Result<Transcript, CrispyError> {
+        unsafe extern "C" fn tramp(done: usize, total: usize, user: *mut c_void) {
+            // SAFETY: `user` is the `&mut Option<&mut dyn FnMut>` of the enclosing call, alive for its whole duration.
+            let f = &mut *(user as *mut Option<&mut dyn FnMut(usize, usize)>);
+            if let Some(f) = f.as_mut() { f(done, total) }
+        }
+        // AtomicBool has the layout of a u8; the library reads an int.  A relay thread-free way: mirror the flag into an
+        // AtomicI32 the callback refreshes would miss cancels between groups, so the flag the library polls is an i32 the
+        // host sets directly when it can (`cancel_i32`); for an AtomicBool the mirror is refreshed by a watcher thread.
+        let mirror = std::sync::Arc::new(std::sync::atomic::AtomicI32::new(0));
+        let stop = std::sync::Arc::new(std::sync::atomic::AtomicBool::new(false));
+        let watcher = cancel.map(|c| {
+            let (m, st) = (mirror.clone(), stop.clone());
+            let c_ptr = c as *const std::sync::atomic::AtomicBool as usize;
+            std::thread::spawn(move || {
+                // SAFETY: the AtomicBool outlives this call (borrowed for it); the thread is joined before it returns.
+                let c = unsafe { &*(c_ptr as *const std::sync::atomic::AtomicBool) };
+                while !st.load(std::sync::atomic::Ordering::Relaxed) {
+                    if c.load(std::sync::atomic::Ordering::Relaxed) { m.store(1, std::sync::atomic::Ordering::Relaxed); break; }
+                    std::thread::sleep(std::time::Duration::from_millis(2));
+                }
+            })
+        });
+        let mut r: *mut crispy_asr_result = std::ptr::null_mut();
+        let o = opts.map_or(std::ptr::null(), |o| o as *const crispy_asr_opts);
+        let p = if audio.is_empty() { std::ptr::null() } else { audio.as_ptr() };
+        let cb: crispy_asr_progress_fn = if progress.is_some() { Some(tramp) } else { None };
+        let rc = unsafe {
+            crispy_asr_transcribe_recording(self.h, p, audio.len(), o, max_batch as c_int, mirror.as_ptr() as *const c_int, cb,
+                                            &mut progress as *mut Option<&mut dyn FnMut(usize, usize)> as *mut c_void, &mut r)
+        };
+        stop.store(true, std::sync::atomic::Ordering::Relaxed);
+        if let Some(w) = watcher { let _ = w.join(); }
+        check(rc)?;
+        Ok(unsafe { take_result(r) })
+    }
+}
+
+/// Copies a library-owned result out and frees it.
+/// SAFETY: `r` is a result a successful transcribe call returned and nobody has freed.
+unsafe fn take_result(r: *mut crispy_asr_result) -> Transcript {
+    let res = &*r;
+    let text = if res.text.is_null() { String::new() } else { CStr::from_ptr(res.text).to_string_lossy().into_owned() };
+    let tokens = if res.n_tokens > 0 { std::slice::from_raw_parts(res.tokens, res.n_tokens as usize).to_vec() } else { Vec::new() };
+    let segments = if res.n_segments > 0 {
+        Some(std::slice::from_raw_parts(res.segments, res.n_segments as usize).iter().map(|s| Segment {
+            start: s.t0,
+            end: s.t1,
+            text: if s.text.is_null() { String::new() } else { CStr::from_ptr(s.text).to_string_lossy().into_owned() },
+        }).collect())
+    } else {
+        None
+    };
+    let windows = if res.n_windows > 0 { std::slice::from_raw_parts(res.windows, res.n_windows as usize).to_vec() } else { Vec::new() };
+    let out = Transcript { text, segments, tokens, language_token: res.language_token, windows };
+    crispy_asr_free_result(r);
+    out
 }
 impl Drop for GpuWhisperEngine {
     fn drop(&mut self) {

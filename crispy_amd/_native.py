@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CRISPY_HIP_LIB") or os.path.join(_HERE, "libcrispy_hip.so")
 
 RN_FRAME = 480
-ABI_VERSION = 3
+ABI_VERSION = 4
 RN_WEIGHT_BYTES = 87503
 RN_TAPS = 72
 RN_DBG_FLOATS = 4304
@@ -24,7 +24,7 @@ RN_SYMBOLS = (
     "crispy_last_error", "crispy_version", "crispy_abi_version", "crispy_device_count",
     "crispy_rn_create", "crispy_rn_destroy", "crispy_rn_reset", "crispy_rn_n_streams",
     "crispy_rn_frames_per_launch", "crispy_rn_n_launches",
-    "crispy_rn_process", "crispy_rn_process_device", "crispy_rn_synchronize",
+    "crispy_rn_process", "crispy_rn_process_device", "crispy_rn_process_s16", "crispy_rn_process_s16_device", "crispy_rn_synchronize",
     "crispy_rn_set_timing", "crispy_rn_last_kernel_ms",
     "crispy_rn_debug_capture", "crispy_rn_debug_read", "crispy_rn_stage_tansig_device",
     "crispy_host_register", "crispy_host_unregister",
@@ -41,7 +41,7 @@ ASR_SYMBOLS = ("crispy_asr_create", "crispy_asr_set_tensor", "crispy_asr_finaliz
                "crispy_asr_decode_greedy_lang_device", "crispy_asr_detect_language_device",
                "crispy_asr_transcribe_batch", "crispy_asr_decode_timestamps_device", "crispy_asr_set_precision",
                "crispy_asr_vocab_specials", "crispy_asr_stage_logits_device", "crispy_asr_language_token",
-               "crispy_asr_decode_window_device")
+               "crispy_asr_decode_window_device", "crispy_asr_transcribe_recording")
 RS_SYMBOLS = ("crispy_resampler_create", "crispy_resampler_destroy", "crispy_resampler_out_len",
               "crispy_resampler_process_device", "crispy_resampler_synchronize")
 ALL_SYMBOLS = RN_SYMBOLS + MEL_SYMBOLS + ASR_SYMBOLS + RS_SYMBOLS
@@ -79,6 +79,11 @@ class AsrResult(C.Structure):
     _fields_ = [("text", C.c_char_p), ("tokens", C.POINTER(C.c_int)), ("n_tokens", C.c_int),
                 ("language_token", C.c_int), ("n_segments", C.c_int), ("segments", C.POINTER(AsrSegment)),
                 ("n_windows", C.c_int), ("windows", C.POINTER(AsrWindow))]
+
+
+ERR_CANCELLED = -7
+# crispy_asr_progress_fn: void (*)(size_t samples_done, size_t samples_total, void *user)
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_size_t, C.c_size_t, C.c_void_p)
 
 
 class CrispyError(RuntimeError):
@@ -138,6 +143,8 @@ def load_library(path: str) -> C.CDLL:
     L.crispy_rn_process.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     L.crispy_rn_process_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_int, C.c_int, C.c_void_p]
+    L.crispy_rn_process_s16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.crispy_rn_process_s16_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.crispy_rn_synchronize.argtypes = [C.c_void_p]
     L.crispy_host_register.argtypes = [C.c_void_p, C.c_size_t]
     L.crispy_host_unregister.argtypes = [C.c_void_p]
@@ -172,6 +179,8 @@ def load_library(path: str) -> C.CDLL:
     L.crispy_asr_transcribe.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]
     L.crispy_asr_transcribe_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.crispy_asr_free_result.argtypes = [C.c_void_p]
+    L.crispy_asr_transcribe_recording.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p,
+                                                  PROGRESS_FN, C.c_void_p, C.POINTER(C.c_void_p)]
     L.crispy_asr_free_result.restype = None
     L.crispy_asr_set_precision.argtypes = [C.c_void_p, C.c_int]
     L.crispy_asr_stage_logits_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]

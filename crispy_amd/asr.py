@@ -352,17 +352,46 @@ def transcribe_batch(engine: "WhisperEngine", clips, max_new_tokens: int = 0, la
     return out
 
 
-def transcribe_recording(engine: "WhisperEngine", pcm16k: np.ndarray, max_new_tokens: int = 0) -> str:
-    """The chunker of `run_transcription` (commands/transcription.rs:249-302, 363-400, 468): hard 30 s cuts,
-    the final partial chunk passed as is, chunk texts trimmed and joined with a single space."""
+def transcribe_recording_serial(engine: "WhisperEngine", pcm16k: np.ndarray, max_new_tokens: int = 0, timestamps: bool = False,
+                                **decision) -> str:
+    """The chunker of `run_transcription` as the reference runs it (commands/transcription.rs:249-302, 363-400, 468): hard
+    30 s cuts, ONE engine call per chunk, the final partial chunk passed as is, chunk texts trimmed and joined with a single
+    space.  Kept as the statement `transcribe_recording` is tested against."""
     parts = []
     x = np.ascontiguousarray(pcm16k, dtype=np.float32).ravel()
     for t0 in range(0, x.size, CHUNK_SAMPLES):
-        text, _ = engine.transcribe(x[t0:t0 + CHUNK_SAMPLES], max_new_tokens)
+        text, _ = engine.transcribe(x[t0:t0 + CHUNK_SAMPLES], max_new_tokens, timestamps=timestamps, **decision)
         text = text.strip()
         if text:
             parts.append(text)
     return " ".join(parts)
+
+
+class Cancelled(Exception):
+    """`transcribe_recording` saw its cancel flag set (the reference returns without saving: transcription.rs:251,359,402)."""
+
+
+def transcribe_recording(engine: "WhisperEngine", pcm16k: np.ndarray, max_new_tokens: int = 0, timestamps: bool = False,
+                         max_batch: int = 0, cancel=None, progress=None, with_result: bool = False, **decision):
+    """`crispy_asr_transcribe_recording`: the same chunk loop with the chunks decoded side by side, `max_batch` (0 = 128) per
+    engine call -- an hour of audio is one call instead of 120 -- and the reference's two hooks:
+    cancel: a `ctypes.c_int` another thread (or the progress callback) sets non-zero -> raises `Cancelled`;
+    progress: callable (samples_done, samples_total), called after every group of chunks (transcription.rs:285-299).
+    Returns the text; with_result also (text, tokens, language, segments, windows) of the whole recording."""
+    x = np.ascontiguousarray(pcm16k, dtype=np.float32).ravel()
+    opts = make_opts(0, False, max_new_tokens, timestamps, True, **decision)
+    res = C.c_void_p()
+    cb = N.PROGRESS_FN(lambda done, total, _user: progress(int(done), int(total))) if progress else N.PROGRESS_FN()
+    rc = engine._L.crispy_asr_transcribe_recording(engine._h, x.ctypes.data if x.size else None, x.size, C.byref(opts), int(max_batch),
+                                                   C.byref(cancel) if cancel is not None else None, cb, None, C.byref(res))
+    if rc == N.ERR_CANCELLED:
+        raise Cancelled()
+    engine._ck(rc)
+    try:
+        full = _read_result(res)
+    finally:
+        engine._L.crispy_asr_free_result(res)
+    return full if with_result else full[0]
 
 
 def transcribe_with_timestamps(engine: "WhisperEngine", audio: np.ndarray, chunk_offset_seconds: float,

@@ -297,8 +297,9 @@ int zero_state(crispy_rn* h, int stream) {
   return CRISPY_OK;
 }
 
-int process_device_impl(crispy_rn* h, const float* d_in, float* d_out, float* d_vad, float* d_taps, int n_frames,
-                        long stride_t, long stride_b, hipStream_t s);
+int process_device_impl(crispy_rn* h, const void* d_in, void* d_out, float* d_vad, float* d_taps, int n_frames,
+                        long stride_t, long stride_b, hipStream_t s, bool s16 = false);
+int process_host_impl(crispy_rn* h, const void* in, void* out, float* vad, int n_frames, crispy_rn_layout layout, bool s16);
 
 }  // namespace
 
@@ -544,14 +545,36 @@ int crispy_rn_process_device(crispy_rn* h, const float* d_in, float* d_out, floa
   return process_device_impl(h, d_in, d_out, d_vad, d_taps, n_frames, stride_t, stride_b, s);
 } CRISPY_CATCH_RET("crispy_rn_process_device")
 
+int crispy_rn_process_s16_device(crispy_rn* h, const int16_t* d_in, int16_t* d_out, float* d_vad, int n_frames,
+                                 crispy_rn_layout layout, void* hip_stream) try {
+  if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_process_s16_device: NULL handle");
+  if (n_frames < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_process_s16_device: n_frames < 0");
+  if (n_frames == 0) return CRISPY_OK;
+  if (!d_in || !d_out) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_process_s16_device: NULL audio pointer");
+  if (layout != CRISPY_RN_LAYOUT_TBF && layout != CRISPY_RN_LAYOUT_BTF)
+    return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_process_s16_device: unknown layout %d", (int)layout);
+  if (((uintptr_t)d_in | (uintptr_t)d_out) & 15)
+    return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_process_s16_device: audio pointers must be 16-byte aligned");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
+  const long stride_t = layout == CRISPY_RN_LAYOUT_TBF ? (long)h->B * RN_FRAME : (long)RN_FRAME;
+  const long stride_b = layout == CRISPY_RN_LAYOUT_TBF ? (long)RN_FRAME : (long)n_frames * RN_FRAME;
+  return process_device_impl(h, d_in, d_out, d_vad, nullptr, n_frames, stride_t, stride_b, s, true);
+} CRISPY_CATCH_RET("crispy_rn_process_s16_device")
+
 }  // extern "C"
 
 namespace {
 // n_frames frames of every stream with explicit element strides of (frame, stream): what the public entry point
 // derives from its layout argument, and what the pipelined host path calls per piece of a larger BTF tensor
-int process_device_impl(crispy_rn* h, const float* d_in, float* d_out, float* d_vad, float* d_taps, int n_frames,
-                        long stride_t, long stride_b, hipStream_t s) {
+int process_device_impl(crispy_rn* h, const void* d_in_v, void* d_out_v, float* d_vad, float* d_taps, int n_frames,
+                        long stride_t, long stride_b, hipStream_t s, bool s16) {
+  // int16 transport (crispy_rn_process_s16*): the same element strides over 2-byte samples; the kernels cast back
+  const long esz = s16 ? 2 : 4;
+  auto in_at = [&](long elems) { return reinterpret_cast<const float*>(static_cast<const char*>(d_in_v) + elems * esz); };
+  auto out_at = [&](long elems) { return reinterpret_cast<float*>(static_cast<char*>(d_out_v) + elems * esz); };
   RnArgs a{};
+  a.in_s16 = a.out_s16 = s16 ? 1 : 0;
   a.B = h->B;
   a.stride_t = stride_t;
   a.stride_b = stride_b;
@@ -605,7 +628,7 @@ int process_device_impl(crispy_rn* h, const float* d_in, float* d_out, float* d_
         const int i = hp_next, ts = hp_ts;
         RnArgs sa = a;
         sa.T = sub_frames(i, T - ts);
-        sa.in = d_in + (long)(t0 + ts) * a.stride_t;
+        sa.in = in_at((long)(t0 + ts) * a.stride_t);
         sa.xhp = h->d_xhp + (long)ts * RN_FRAME;   // row pointer shifted by the frames already filtered
         hipStream_t hs = h->hp_upfront ? s : h->hp_stream;
         if (h->hp_ahead > 0 && i >= h->hp_ahead) HIP_TRY(hipStreamWaitEvent(hs, h->ev_fr[i - h->hp_ahead], 0));
@@ -613,7 +636,7 @@ int process_device_impl(crispy_rn* h, const float* d_in, float* d_out, float* d_
         for (int f0 = 0; f0 < sa.T; f0 += per) {
           RnArgs pa = sa;
           pa.T = (sa.T - f0) < per ? (sa.T - f0) : per;
-          pa.in = sa.in + (long)f0 * a.stride_t;
+          pa.in = in_at((long)(t0 + ts + f0) * a.stride_t);
           pa.xhp = sa.xhp + (long)f0 * RN_FRAME;
           HIP_TRY(rn_launch_highpass(pa, hs, h->hp_deep));
         }
@@ -627,7 +650,7 @@ int process_device_impl(crispy_rn* h, const float* d_in, float* d_out, float* d_
     for (int i = 0, ts = 0; i < n_sub; ++i) {
       RnArgs sa = a;
       sa.T = sub_frames(i, T - ts);
-      sa.out = d_out + (long)(t0 + ts) * a.stride_t;
+      sa.out = out_at((long)(t0 + ts) * a.stride_t);
       sa.vad = d_vad ? d_vad + (long)(t0 + ts) * h->B : nullptr;
       sa.taps = d_taps ? d_taps + (long)(t0 + ts) * h->B * RN_TAPS : nullptr;
       sa.dbg = (t0 + ts + sa.T == n_frames) ? h->d_dbg : nullptr;
@@ -665,10 +688,29 @@ int crispy_host_unregister(void* p) try {
 
 int crispy_rn_process(crispy_rn* h, const float* in, float* out, float* vad, int n_frames,
                       crispy_rn_layout layout) try {
+  return process_host_impl(h, in, out, vad, n_frames, layout, false);
+} CRISPY_CATCH_RET("crispy_rn_process")
+
+int crispy_rn_process_s16(crispy_rn* h, const int16_t* in, int16_t* out, float* vad, int n_frames,
+                          crispy_rn_layout layout) try {
+  return process_host_impl(h, in, out, vad, n_frames, layout, true);
+} CRISPY_CATCH_RET("crispy_rn_process_s16")
+
+}  // extern "C"
+
+namespace {
+// crispy_rn_process / crispy_rn_process_s16: host tensors of f32 or int16 samples (esz bytes each) through the staging
+// buffers -- sized for f32, an int16 call uses half of them
+int process_host_impl(crispy_rn* h, const void* in_v, void* out_v, float* vad, int n_frames, crispy_rn_layout layout, bool s16) {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_process: NULL handle");
   if (n_frames < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_process: n_frames < 0");
   if (n_frames == 0) return CRISPY_OK;
-  if (!in || !out) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_process: NULL audio pointer");
+  if (!in_v || !out_v) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_process: NULL audio pointer");
+  if (layout != CRISPY_RN_LAYOUT_TBF && layout != CRISPY_RN_LAYOUT_BTF)
+    return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_process: unknown layout %d", (int)layout);
+  const size_t esz = s16 ? sizeof(int16_t) : sizeof(float);
+  const char* in = static_cast<const char*>(in_v);
+  char* out = static_cast<char*>(out_v);
   HIP_TRY(hipSetDevice(h->device));
   const size_t n = (size_t)n_frames * h->B * RN_FRAME;
   if (h->stage_frames < (size_t)n_frames) {
@@ -683,14 +725,15 @@ int crispy_rn_process(crispy_rn* h, const float* in, float* out, float* vad, int
     h->stage_frames = (size_t)n_frames;
   }
   const size_t B = (size_t)h->B;
-  const size_t frame_bytes = B * RN_FRAME * sizeof(float);          // one frame of every stream
-  if (n * sizeof(float) < (size_t)(8u << 20)) {
+  const size_t frame_bytes = B * RN_FRAME * esz;          // one frame of every stream
+  if (n * esz < (size_t)(8u << 20)) {
     // small calls (the single-stream process_frame drop-in): one copy in, one call, one copy out
-    HIP_TRY(hipMemcpyAsync(h->d_stage_in, in, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    int rc = crispy_rn_process_device(h, h->d_stage_in, h->d_stage_out, vad ? h->d_stage_vad : nullptr,
-                                      nullptr, n_frames, layout, nullptr);
+    HIP_TRY(hipMemcpyAsync(h->d_stage_in, in, n * esz, hipMemcpyHostToDevice, h->stream));
+    int rc = process_device_impl(h, h->d_stage_in, h->d_stage_out, vad ? h->d_stage_vad : nullptr, nullptr, n_frames,
+                                 layout == CRISPY_RN_LAYOUT_TBF ? (long)h->B * RN_FRAME : (long)RN_FRAME,
+                                 layout == CRISPY_RN_LAYOUT_TBF ? (long)RN_FRAME : (long)n_frames * RN_FRAME, h->stream, s16);
     if (rc != CRISPY_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(out, h->d_stage_out, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(out, h->d_stage_out, n * esz, hipMemcpyDeviceToHost, h->stream));
     if (vad)
       HIP_TRY(hipMemcpyAsync(vad, h->d_stage_vad, (size_t)n_frames * h->B * sizeof(float),
                              hipMemcpyDeviceToHost, h->stream));
@@ -724,12 +767,14 @@ int crispy_rn_process(crispy_rn* h, const float* in, float* out, float* vad, int
   const long stride_t = tbf ? (long)B * RN_FRAME : (long)RN_FRAME;
   const long stride_b = tbf ? (long)RN_FRAME : (long)n_frames * RN_FRAME;
   // piece [t0, t0 + T): contiguous in TBF, B rows of T * 480 floats at a pitch of n_frames * 480 in BTF
-  auto copy_piece = [&](float* dst, const float* src, int t0, int T, hipMemcpyKind kind, hipStream_t st) -> hipError_t {
+  auto copy_piece = [&](void* dst_v, const void* src_v, int t0, int T, hipMemcpyKind kind, hipStream_t st) -> hipError_t {
+    char* dst = static_cast<char*>(dst_v);
+    const char* src = static_cast<const char*>(src_v);
     if (tbf)
-      return hipMemcpyAsync(dst + (size_t)t0 * stride_t, src + (size_t)t0 * stride_t, (size_t)T * frame_bytes, kind, st);
-    const size_t pitch = (size_t)n_frames * RN_FRAME * sizeof(float);
-    return hipMemcpy2DAsync(dst + (size_t)t0 * RN_FRAME, pitch, src + (size_t)t0 * RN_FRAME, pitch,
-                            (size_t)T * RN_FRAME * sizeof(float), B, kind, st);
+      return hipMemcpyAsync(dst + (size_t)t0 * stride_t * esz, src + (size_t)t0 * stride_t * esz, (size_t)T * frame_bytes, kind, st);
+    const size_t pitch = (size_t)n_frames * RN_FRAME * esz;
+    return hipMemcpy2DAsync(dst + (size_t)t0 * RN_FRAME * esz, pitch, src + (size_t)t0 * RN_FRAME * esz, pitch,
+                            (size_t)T * RN_FRAME * esz, B, kind, st);
   };
   std::atomic<int> recorded{0};          // pieces whose "frame kernels done" event has been recorded by this call
   std::atomic<bool> abort_flag{false};
@@ -768,8 +813,9 @@ int crispy_rn_process(crispy_rn* h, const float* in, float* out, float* vad, int
     if (feed_err == hipSuccess) feed_err = hipEventRecord(h->ev_in[i], h->h2d_stream);
     if (feed_err == hipSuccess) feed_err = hipStreamWaitEvent(h->stream, h->ev_in[i], 0);
     if (feed_err != hipSuccess) break;
-    rc = process_device_impl(h, h->d_stage_in + (size_t)t0 * stride_t, h->d_stage_out + (size_t)t0 * stride_t,
-                             vad ? h->d_stage_vad + (size_t)t0 * B : nullptr, nullptr, T, stride_t, stride_b, h->stream);
+    rc = process_device_impl(h, reinterpret_cast<const char*>(h->d_stage_in) + (size_t)t0 * stride_t * esz,
+                             reinterpret_cast<char*>(h->d_stage_out) + (size_t)t0 * stride_t * esz,
+                             vad ? h->d_stage_vad + (size_t)t0 * B : nullptr, nullptr, T, stride_t, stride_b, h->stream, s16);
     if (rc != CRISPY_OK) break;
     feed_err = hipEventRecord(h->ev_done[i], h->stream);
     if (feed_err == hipSuccess) recorded.store(i + 1, std::memory_order_release);
@@ -784,7 +830,10 @@ int crispy_rn_process(crispy_rn* h, const float* in, float* out, float* vad, int
   if (drain_err != hipSuccess)
     return fail(CRISPY_ERR_HIP, "crispy_rn_process: copy-out failed: %s", hipGetErrorString(drain_err));
   return CRISPY_OK;
-} CRISPY_CATCH_RET("crispy_rn_process")
+}
+}  // namespace
+
+extern "C" {
 
 int crispy_rn_synchronize(crispy_rn* h) try {
   if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_rn_synchronize: NULL handle");

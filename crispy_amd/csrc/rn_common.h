@@ -96,6 +96,11 @@ struct RnArgs {
   const float* in;      // caller layout
   float* out;           // caller layout
   long stride_t, stride_b;  // element strides of (frame, stream) in `in`/`out`
+  // int16 sample transport (crispy_rn_process_s16*): `in` / `out` point at int16_t samples (same ELEMENT strides).
+  // in_s16: the high-pass reads (float)s -- what the reference's i16 capture path feeds process_frame: s / 32768 (audio.rs:814)
+  // x 32768 (audio.rs:264), both exact.  out_s16: the frame kernel stores trunc(clamp(y / 32768, -1, 1) x 32767) -- the
+  // adapter's / 32768 + clamp (audio.rs:270-273) and the WAV writer's quantisation (recording.rs:109-110).
+  int in_s16, out_s16;
   float* vad;           // [T][B] or null
   float* taps;          // [T][B][72] or null
   float* dbg;           // [B][RN_DBG_FLOATS] or null (last frame of the call)

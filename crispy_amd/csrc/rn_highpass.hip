@@ -3,6 +3,7 @@
 //   rn_roll_history_kernel                         keeps the last 4 high-passed frames of every stream for the next call
 // Reference: nnnoiseless::DenoiseState::process_frame's first step (audio.rs:268 call site; xiph/rnnoise denoise.c biquad).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "rn_common.h"
 
 namespace crispy {
@@ -22,7 +23,9 @@ constexpr int RN_HP_BLK = 2;
 // waits for and nothing competes for registers -- in the stream-major layout every lane reads from its own 5.8 MB
 // region (a TLB entry each), and one block of eight samples ahead (~0.4 us of chain) does not cover a miss:
 // 1024 streams x 3001 frames 127 ms per call in that layout against 89 ms frame-major, same frame kernels.
-template <int BLK>
+// S16: the input is int16 PCM (RnArgs::in_s16) -- a block of four samples is 8 bytes, converted as it moves from the
+// request registers to the chain (int16 -> f32 is exact); everything behind the conversion is the same instructions.
+template <int BLK, bool S16>
 __device__ __forceinline__ void rn_highpass_body(const RnArgs& a) {
   const int b = blockIdx.x * WAVE + threadIdx.x;
   if (b >= a.B) return;
@@ -39,19 +42,24 @@ __device__ __forceinline__ void rn_highpass_body(const RnArgs& a) {
   constexpr int NBLK = RN_FRAME / 4 / BLK;   // blocks per frame
   static_assert(RN_FRAME % (4 * BLK) == 0, "whole blocks per frame");
   const long total = (long)a.T * NBLK;
+  typedef typename std::conditional<S16, short4, float4>::type Raw;      // four samples as the caller holds them
   auto block_ptr = [&](long k) {
     const long t = k / NBLK, blk = k - t * NBLK;
-    return reinterpret_cast<const float4*>(a.in + t * a.stride_t + (long)b * a.stride_b) + blk * BLK;
+    const long at = t * a.stride_t + (long)b * a.stride_b;
+    const Raw* p = S16 ? reinterpret_cast<const Raw*>(reinterpret_cast<const int16_t*>(a.in) + at) : reinterpret_cast<const Raw*>(a.in + at);
+    return p + blk * BLK;
   };
-  float4 cur[BLK], nxt[BLK];
+  auto widen = [](const Raw& r) { return make_float4((float)r.x, (float)r.y, (float)r.z, (float)r.w); };
+  float4 cur[BLK];
+  Raw nxt[BLK];
   {
-    const float4* p = block_ptr(0);
+    const Raw* p = block_ptr(0);
 #pragma unroll
-    for (int q = 0; q < BLK; ++q) cur[q] = p[q];
+    for (int q = 0; q < BLK; ++q) cur[q] = widen(p[q]);
   }
   for (long k = 0; k < total; ++k) {
     {
-      const float4* p = block_ptr(k + 1 < total ? k + 1 : k);     // last block: a harmless re-read
+      const Raw* p = block_ptr(k + 1 < total ? k + 1 : k);     // last block: a harmless re-read
 #pragma unroll
       for (int q = 0; q < BLK; ++q) nxt[q] = p[q];
     }
@@ -75,13 +83,15 @@ __device__ __forceinline__ void rn_highpass_body(const RnArgs& a) {
       d4[q] = make_float4(yo[0], yo[1], yo[2], yo[3]);
     }
 #pragma unroll
-    for (int q = 0; q < BLK; ++q) cur[q] = nxt[q];
+    for (int q = 0; q < BLK; ++q) cur[q] = widen(nxt[q]);
   }
   a.hp_mem[2 * b] = m0;
   a.hp_mem[2 * b + 1] = m1;
 }
-__global__ __launch_bounds__(WAVE) RN_HP_VGPR_CAP void rn_highpass_kernel(RnArgs a) { rn_highpass_body<RN_HP_BLK>(a); }
-__global__ __launch_bounds__(WAVE) void rn_highpass_deep_kernel(RnArgs a) { rn_highpass_body<8>(a); }
+template <bool S16>
+__global__ __launch_bounds__(WAVE) RN_HP_VGPR_CAP void rn_highpass_kernel(RnArgs a) { rn_highpass_body<RN_HP_BLK, S16>(a); }
+template <bool S16>
+__global__ __launch_bounds__(WAVE) void rn_highpass_deep_kernel(RnArgs a) { rn_highpass_body<8, S16>(a); }
 
 // keep the last RN_HIST high-passed samples of every stream at the front of its xhp row
 __global__ __launch_bounds__(256) void rn_roll_history_kernel(RnArgs a) {
@@ -105,8 +115,14 @@ __global__ __launch_bounds__(256) void rn_roll_history_kernel(RnArgs a) {
 }  // namespace
 
 hipError_t rn_launch_highpass(const RnArgs& a, hipStream_t s, bool deep) {
-  if (deep) hipLaunchKernelGGL(rn_highpass_deep_kernel, dim3((a.B + WAVE - 1) / WAVE), dim3(WAVE), 0, s, a);
-  else hipLaunchKernelGGL(rn_highpass_kernel, dim3((a.B + WAVE - 1) / WAVE), dim3(WAVE), 0, s, a);
+  const dim3 grid((a.B + WAVE - 1) / WAVE), block(WAVE);
+  if (a.in_s16) {
+    if (deep) hipLaunchKernelGGL(rn_highpass_deep_kernel<true>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(rn_highpass_kernel<true>, grid, block, 0, s, a);
+  } else {
+    if (deep) hipLaunchKernelGGL(rn_highpass_deep_kernel<false>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(rn_highpass_kernel<false>, grid, block, 0, s, a);
+  }
   return hipGetLastError();
 }
 hipError_t rn_launch_roll_history(const RnArgs& a, hipStream_t s) {

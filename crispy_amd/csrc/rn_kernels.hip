@@ -1767,7 +1767,16 @@ __device__ __forceinline__ void rn_frame_body(const RnArgs& a) {
             ov.y = fmaf(-z.y, hwa[m].y, synth[m].y);
             // the output is never read back here: non-temporal stores keep it from allocating in L2 next to the history
             // window and the parked spectrum (-1.1 KB of fetches per stream-frame, time unchanged)
-            __builtin_nontemporal_store(ov.x, o + i0); __builtin_nontemporal_store(ov.y, o + i0 + 1);
+            if (a.out_s16) {
+              // int16 transport (RnArgs::out_s16): the adapter's / 32768 and clamp (audio.rs:270-273), the WAV writer's
+              // x 32767 truncated toward zero (recording.rs:109-110); two samples = one dword of the caller's int16 frame
+              const float q0 = truncf(fminf(fmaxf(ov.x * (1.f / 32768.f), -1.f), 1.f) * 32767.f);
+              const float q1 = truncf(fminf(fmaxf(ov.y * (1.f / 32768.f), -1.f), 1.f) * 32767.f);
+              const unsigned pk = ((unsigned)(int)q0 & 0xffffu) | ((unsigned)(int)q1 << 16);
+              __builtin_nontemporal_store(pk, reinterpret_cast<unsigned*>(reinterpret_cast<int16_t*>(a.out) + (long)t * a.stride_t + (long)b * a.stride_b + i0));
+            } else {
+              __builtin_nontemporal_store(ov.x, o + i0); __builtin_nontemporal_store(ov.y, o + i0 + 1);
+            }
             synth[m].x = z2.x * hwb[m].y;
             synth[m].y = -z2.y * hwb[m].x;
           }

@@ -180,6 +180,8 @@ struct crispy_asr {
 namespace {
 
 int build_ts_masks(crispy_asr* h);   // defined with the timestamp-mode code below
+int transcribe_batch_impl(crispy_asr* h, const float* const* pcm, const size_t* n, int batch, const crispy_asr_opts* opts,
+                          crispy_asr_result** results, const volatile int* cancel);
 
 void add_spec(std::map<std::string, size_t>& spec, const std::string& name, size_t n) { spec[name] = n; }
 
@@ -2575,6 +2577,17 @@ int crispy_asr_transcribe(crispy_asr* h, const float* pcm16k, size_t n, const cr
 //     search at temperature 0.
 int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const size_t* n, int batch,
                                 const crispy_asr_opts* opts, crispy_asr_result** results) try {
+  return transcribe_batch_impl(h, pcm, n, batch, opts, results, nullptr);
+} CRISPY_CATCH_RET("crispy_asr_transcribe_batch")
+
+}  // extern "C"
+
+namespace {
+
+// cancel (nullable): polled at the top of every round of the seek loop -- a set flag ends the call with
+// CRISPY_ERR_CANCELLED and no results (crispy_asr_transcribe_recording: commands/transcription.rs:251,359,402)
+int transcribe_batch_impl(crispy_asr* h, const float* const* pcm, const size_t* n, int batch, const crispy_asr_opts* opts,
+                          crispy_asr_result** results, const volatile int* cancel) {
   if (!h || !results) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: NULL argument");
   if (batch < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: batch < 0");
   for (int i = 0; i < batch; ++i) results[i] = nullptr;
@@ -2786,6 +2799,7 @@ int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const si
       for (int round = 0;; ++round) {
         if (round >= kMaxRounds)
           return fail(CRISPY_ERR_HIP, "crispy_asr_transcribe_batch: seek loop did not terminate after %d windows", kMaxRounds);
+        if (cancel && *cancel) return fail(CRISPY_ERR_CANCELLED, "transcription cancelled by the caller");
         std::vector<int> act;
         for (int k = 0; k < nb; ++k)
           if (seek_end[k] >= delta_min && seek[k] + delta_min < seek_end[k]) act.push_back(k);   // < 100 ms left: whisper.cpp stops
@@ -2970,7 +2984,115 @@ int crispy_asr_transcribe_batch(crispy_asr* h, const float* const* pcm, const si
     results[i] = &impl[i]->pub;
   }
   return CRISPY_OK;
-} CRISPY_CATCH_RET("crispy_asr_transcribe_batch")
+}
+
+// Rust's str::trim(): the code points with the White_Space property, off both ends of a UTF-8 string
+// (managers/transcription.rs:187 trims every chunk's text; commands/transcription.rs:276 tests `trim().is_empty()`)
+bool unicode_space(unsigned cp) {
+  return (cp >= 9 && cp <= 13) || cp == 0x20 || cp == 0x85 || cp == 0xA0 || cp == 0x1680 || (cp >= 0x2000 && cp <= 0x200A) ||
+         cp == 0x2028 || cp == 0x2029 || cp == 0x202F || cp == 0x205F || cp == 0x3000;
+}
+std::string trim_unicode(const std::string& s) {
+  auto decode = [&](size_t i, size_t* len) -> unsigned {      // one code point at byte i (malformed bytes stand for themselves)
+    const unsigned char c = (unsigned char)s[i];
+    auto cont = [&](size_t k) { return i + k < s.size() && ((unsigned char)s[i + k] & 0xC0) == 0x80; };
+    if (c < 0x80) { *len = 1; return c; }
+    if ((c & 0xE0) == 0xC0 && cont(1)) { *len = 2; return ((c & 0x1Fu) << 6) | ((unsigned char)s[i + 1] & 0x3Fu); }
+    if ((c & 0xF0) == 0xE0 && cont(1) && cont(2)) {
+      *len = 3;
+      return ((c & 0x0Fu) << 12) | (((unsigned char)s[i + 1] & 0x3Fu) << 6) | ((unsigned char)s[i + 2] & 0x3Fu);
+    }
+    *len = 1;
+    return 0xFFFFFFFFu;
+  };
+  size_t a = 0, b = s.size();
+  while (a < b) {
+    size_t len = 1;
+    if (!unicode_space(decode(a, &len))) break;
+    a += len;
+  }
+  while (b > a) {
+    size_t k = b - 1;
+    while (k > a && ((unsigned char)s[k] & 0xC0) == 0x80 && b - k < 3) --k;      // back to the lead byte of the last code point
+    size_t len = 1;
+    const unsigned cp = decode(k, &len);
+    if (k + len != b || !unicode_space(cp)) break;
+    b = k;
+  }
+  return s.substr(a, b - a);
+}
+
+}  // namespace
+
+extern "C" {
+
+// `run_transcription`'s chunk loop (commands/transcription.rs:249-302, 363-400, 468) over a whole 16 kHz recording, with
+// the chunks decoded TOGETHER: the reference's loop is serial because its engine is (one chunk per call under a mutex,
+// managers/transcription.rs:27,178), yet the chunks are independent -- TranscribeOptions::default() carries no context
+// from chunk to chunk (:184) -- so a group of them is one batch call and an hour of audio is one or two calls, not 120.
+int crispy_asr_transcribe_recording(crispy_asr* h, const float* pcm16k, size_t n, const crispy_asr_opts* opts, int max_batch,
+                                    const volatile int* cancel_flag, crispy_asr_progress_fn progress, void* progress_user,
+                                    crispy_asr_result** out) try {
+  if (!out) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_recording: out is NULL");
+  *out = nullptr;
+  if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_recording: NULL handle");
+  if (n > 0 && !pcm16k) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_recording: NULL audio");
+  if (max_batch < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_recording: max_batch < 0");
+  if (opts && opts->carry_context)
+    return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_recording: carry_context is a single-chunk option (the chunks of a "
+                "recording are decoded side by side, each from a clean context, as the reference does)");
+  if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_transcribe_recording: model not finalized");
+  constexpr size_t kChunk = 480000;                        // 30 s at 16 kHz (commands/transcription.rs:175-176)
+  const size_t n_chunks = (n + kChunk - 1) / kChunk;       // the last partial chunk is passed as it is (the engine pads)
+  const size_t group = max_batch > 0 ? (size_t)max_batch : 128;
+  crispy_asr_result_impl* R = new (std::nothrow) crispy_asr_result_impl();
+  if (!R) return fail(CRISPY_ERR_OOM, "crispy_asr_transcribe_recording: host allocation failed");
+  struct Own { crispy_asr_result_impl* r; ~Own() { delete r; } } own{R};
+  bool first_text = true;
+  for (size_t g0 = 0; g0 < n_chunks; g0 += group) {
+    if (cancel_flag && *cancel_flag) return fail(CRISPY_ERR_CANCELLED, "transcription cancelled by the caller");
+    const int nb = (int)std::min(group, n_chunks - g0);
+    std::vector<const float*> ptrs((size_t)nb);
+    std::vector<size_t> lens((size_t)nb);
+    std::vector<crispy_asr_result*> res((size_t)nb, nullptr);
+    for (int i = 0; i < nb; ++i) {
+      const size_t at = (g0 + (size_t)i) * kChunk;
+      ptrs[i] = pcm16k + at;
+      lens[i] = std::min(kChunk, n - at);
+    }
+    const int rc = transcribe_batch_impl(h, ptrs.data(), lens.data(), nb, opts, res.data(), cancel_flag);
+    if (rc != CRISPY_OK) return rc;
+    for (int i = 0; i < nb; ++i) {
+      const crispy_asr_result& r = *res[i];
+      const size_t ci = g0 + (size_t)i;
+      const std::string t = trim_unicode(r.text ? r.text : "");
+      if (!t.empty()) {                                    // parts.push(..) only for non-blank chunk texts; joined with " "
+        if (!first_text) R->text += ' ';
+        R->text += t;
+        first_text = false;
+      }
+      R->tokens.insert(R->tokens.end(), r.tokens, r.tokens + r.n_tokens);
+      if (ci == 0) R->language_token = r.language_token;
+      const float t_off = (float)(ci * 30.0);              // chunk_start_seconds (transcription.rs:262)
+      for (int k = 0; k < r.n_segments; ++k) {
+        R->seg_t0.push_back(t_off + r.segments[k].t0);
+        R->seg_t1.push_back(t_off + r.segments[k].t1);
+        R->seg_text.emplace_back(r.segments[k].text ? r.segments[k].text : "");
+      }
+      for (int k = 0; k < r.n_windows; ++k) {
+        crispy_asr_window w = r.windows[k];
+        w.seek += (int)(ci * 3000);
+        R->wins.push_back(w);
+      }
+      crispy_asr_free_result(res[i]);
+    }
+    if (progress) progress(std::min(n, (g0 + (size_t)nb) * kChunk), n, progress_user);
+  }
+  publish(R);
+  own.r = nullptr;
+  *out = &R->pub;
+  return CRISPY_OK;
+} CRISPY_CATCH_RET("crispy_asr_transcribe_recording")
 
 void crispy_asr_free_result(crispy_asr_result* r) try {
   if (!r) return;

@@ -83,6 +83,30 @@ class DenoiseState:
         N.check(self._L.crispy_rn_process(self._h, x.ctypes.data, out.ctypes.data, vad.ctypes.data, T, lay), self._L)
         return out, vad
 
+    def process_s16(self, x: np.ndarray, layout: str = "tbf", out: np.ndarray | None = None, vad: np.ndarray | None = None):
+        """`crispy_rn_process_s16`: int16 PCM [T, B, 480] / [B, T, 480] in -> (int16 out like x, vad [T, B]).  A sample s
+        enters process_frame as float(s); the output is trunc(clamp(y / 32768, -1, 1) * 32767) -- the adapter's scaling and
+        clamp (audio.rs:270-273) and the WAV writer's quantisation (recording.rs:109-110).  Half the PCIe bytes of `process`."""
+        if x.dtype != np.int16 or not x.flags.c_contiguous:
+            raise ValueError("process_s16: a C-contiguous int16 array is required")
+        lay = N.LAYOUT_TBF if layout == "tbf" else N.LAYOUT_BTF
+        if x.ndim != 3 or x.shape[2] != FRAME_SIZE:
+            raise ValueError("process_s16: x must be [T,B,480] or [B,T,480]")
+        T = x.shape[0] if layout == "tbf" else x.shape[1]
+        Bn = x.shape[1] if layout == "tbf" else x.shape[0]
+        if Bn != self.n_streams:
+            raise ValueError(f"process_s16: {Bn} streams given, handle has {self.n_streams}")
+        out = np.empty_like(x) if out is None else out
+        vad = np.empty((T, Bn), dtype=np.float32) if vad is None else vad
+        if out.dtype != np.int16 or out.shape != x.shape or not out.flags.c_contiguous or vad.shape != (T, Bn):
+            raise ValueError("process_s16: out / vad shape or type mismatch")
+        N.check(self._L.crispy_rn_process_s16(self._h, x.ctypes.data, out.ctypes.data, vad.ctypes.data, T, lay), self._L)
+        return out, vad
+
+    def process_s16_device(self, d_in: int, d_out: int, n_frames: int, d_vad: int = 0, layout: str = "tbf", stream: int = 0):
+        lay = N.LAYOUT_TBF if layout == "tbf" else N.LAYOUT_BTF
+        N.check(self._L.crispy_rn_process_s16_device(self._h, d_in, d_out, d_vad or None, int(n_frames), lay, stream or None), self._L)
+
     @staticmethod
     def register_host(arr: np.ndarray):
         """Page-lock a host array the caller reuses across `process` calls (crispy_host_register): copies become DMA."""

@@ -54,7 +54,8 @@ typedef enum crispy_status {
   CRISPY_ERR_HIP = -3,
   CRISPY_ERR_OOM = -4,
   CRISPY_ERR_BAD_MODEL = -5,
-  CRISPY_ERR_UNSUPPORTED = -6
+  CRISPY_ERR_UNSUPPORTED = -6,
+  CRISPY_ERR_CANCELLED = -7 /* crispy_asr_transcribe_recording: the caller's cancel flag was set; no result */
 } crispy_status;
 
 #define CRISPY_RN_FRAME_SIZE 480      /* nnnoiseless::FRAME_SIZE (audio.rs:4) */
@@ -75,8 +76,9 @@ const char *crispy_last_error(void);
 const char *crispy_version(void);
 /* The ABI this header describes; crispy_abi_version() returns the one the library was built with.
  *   1: rounds 1 - 3.   2: round 4 (crispy_asr_opts 20 -> 44 bytes, crispy_asr_result gained windows, the staged RNNoise
- *   pipeline entry points removed).   3: round 5 (this header). */
-#define CRISPY_ABI_VERSION 3
+ *   pipeline entry points removed).   3: round 5.   4: round 6 (this header: crispy_asr_transcribe_recording and its
+ *   CRISPY_ERR_CANCELLED, the int16 sample transport crispy_rn_process_s16*). */
+#define CRISPY_ABI_VERSION 4
 int crispy_abi_version(void);
 /* Number of usable gfx950 devices (0 when there is none; never fails). */
 int crispy_device_count(void);
@@ -157,6 +159,24 @@ int crispy_host_unregister(void *p);
 int crispy_rn_process_device(crispy_rn *h, const float *d_in, float *d_out, float *d_vad,
                              float *d_taps, int n_frames, crispy_rn_layout layout,
                              void *hip_stream);
+
+/*
+ * Integer sample transport: the same call with int16 PCM in and out -- half the bytes of the f32 form across PCIe, and the
+ * formats the reference's capture and recording paths actually hold (cpal i16 / u16 input streams, audio.rs:794-855; the
+ * s16 WAV the transcriber reads back, commands/transcription.rs:306-313).
+ *   in : sample s enters process_frame as (float)s -- the reference's s as f32 / 32768.0 (audio.rs:814) x 32768.0
+ *        (audio.rs:264), both exact;  a u16 stream is the host's (s - 32768) first, as audio.rs:872 does.
+ *   out: trunc(clamp(y / 32768, -1, 1) x 32767) for process_frame's output y -- the adapter's / 32768 and clamp
+ *        (audio.rs:270-273, volume 1) followed by the WAV writer's quantisation, `(s.clamp(-1.0, 1.0) * 32767.0) as i16`
+ *        (recording.rs:109-110), fused into the frame kernel's store.  Bit-exact with crispy_rn_process followed by that
+ *        arithmetic on the host (tests/test_gpu_rnnoise.py).
+ * State, layouts, vad, the first-frame drop (caller side) and the pipelining of large host calls are those of the f32
+ * entry points; one handle may mix f32 and int16 calls.  Device pointers 16-byte aligned.
+ */
+int crispy_rn_process_s16(crispy_rn *h, const int16_t *in, int16_t *out, float *vad, int n_frames,
+                          crispy_rn_layout layout);
+int crispy_rn_process_s16_device(crispy_rn *h, const int16_t *d_in, int16_t *d_out, float *d_vad, int n_frames,
+                                 crispy_rn_layout layout, void *hip_stream);
 
 /* Block until everything enqueued on the handle's own stream has finished. */
 int crispy_rn_synchronize(crispy_rn *h);
@@ -485,6 +505,26 @@ int crispy_asr_transcribe(crispy_asr *h, const float *pcm16k, size_t n, const cr
 int crispy_asr_transcribe_batch(crispy_asr *h, const float *const *pcm, const size_t *n, int batch,
                                 const crispy_asr_opts *opts, crispy_asr_result **results);
 void crispy_asr_free_result(crispy_asr_result *r);
+
+/* `run_transcription`'s chunk loop (commands/transcription.rs:249-302, 363-400, 468) for a whole recording already at
+ * 16 kHz: n samples are cut into 480 000-sample chunks (the last, partial one passed as it is), every chunk goes through
+ * engine.transcribe(&chunk, opts), the chunk texts are trimmed (Rust's str::trim: Unicode white space), the non-blank ones
+ * joined with ONE space -> result.text.  Where the reference's loop is serial (one chunk per engine call), the chunks here
+ * are decoded in groups of `max_batch` (0 = 128) by one crispy_asr_transcribe_batch each -- they are independent:
+ * TranscribeOptions::default() carries no context between chunks -- and the text is byte for byte what the chunk-by-chunk
+ * loop gives (tests/test_gpu_recording.py).  Also in the result: the tokens of all chunks, the segments with their times
+ * shifted by the chunk's start (chunk index x 30 s: `chunk_start_seconds`), the windows with `seek` shifted by 3000
+ * frames per chunk; language_token = the first chunk's.
+ *   cancel_flag (nullable): polled before every group and between the windows of the seek loop, as the reference polls its
+ *     AtomicBool before every chunk (:251, :359, :402); once it reads non-zero the call returns CRISPY_ERR_CANCELLED and no
+ *     result (the reference returns without saving anything).  The host sets it from another thread.
+ *   progress (nullable): called on the calling thread after every group with (samples done, n, progress_user) -- what the
+ *     reference turns into its "transcription-progress" event (:285-299).  It must not call into this handle.
+ * n == 0: an empty result (:190-194).  opts->carry_context is refused (a single-chunk option). */
+typedef void (*crispy_asr_progress_fn)(size_t samples_done, size_t samples_total, void *user);
+int crispy_asr_transcribe_recording(crispy_asr *h, const float *pcm16k, size_t n, const crispy_asr_opts *opts,
+                                    int max_batch, const volatile int *cancel_flag, crispy_asr_progress_fn progress,
+                                    void *progress_user, crispy_asr_result **out);
 
 /* ------------------------------------------------------------------------------------------
  * 48 kHz -> 16 kHz resampler between the denoiser and the ASR front end:

@@ -26,7 +26,7 @@ def _bench(args, env_extra=None, timeout=600):
     return json.loads(last)
 
 
-QUICK = ["--no-asr", "--no-latency", "--no-live-traffic", "--no-cpu-baseline", "--no-cfg45", "--sustain-seconds", "0"]
+QUICK = ["--no-asr", "--no-latency", "--no-live-traffic", "--no-cpu-baseline", "--no-cfg45", "--no-host-fed", "--sustain-seconds", "0"]
 
 
 def test_cfg2_through_rccl_with_one_rank():
@@ -57,6 +57,16 @@ def test_cfg2_host_fed_flavour():
     line = _bench(["--steps", "2", "--warmup", "1", "--host-fed", "--streams", "1024", "--frames", "50", *QUICK])
     assert "HOST-FED" in line["metric"] and "host-resident" in line["data"]
     assert line["config"]["output_finite"] and line["value"] > 8000
+    # ... and as a leg of the default line: f32 and int16 sample transport beside the HBM-resident value
+    quick = [a for a in QUICK if a != "--no-host-fed"]
+    line = _bench(["--steps", "2", "--warmup", "1", *quick])
+    hf = line["host_fed"]
+    assert "error" not in hf, hf
+    assert hf["f32"]["bytes_per_sample"] == 4 and hf["s16"]["bytes_per_sample"] == 2
+    assert 8000 < hf["value"] < line["value"] and hf["pcie_gbps_each_way"] > 5
+    print(f"host-fed: f32 {hf['f32']['value']:.0f} streams at {hf['f32']['pcie_gbps_each_way']:.1f} GB/s each way, "
+          f"s16 {hf['s16']['value']:.0f} at {hf['s16']['pcie_gbps_each_way']:.1f} = {hf['s16_over_f32']:.2f} x")
+    assert hf["s16_over_f32"] > 1.3, hf
 
 
 def test_cfg4_two_pipelines_in_flight_equal_the_serial_form():

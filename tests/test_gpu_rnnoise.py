@@ -242,6 +242,50 @@ def test_pipelined_host_path_equals_device_path(weights0):
             DenoiseState.unregister_host(arr)
 
 
+def test_int16_transport_equals_the_f32_entry_point_then_the_wav_quantisation(weights0):
+    """`crispy_rn_process_s16*`: int16 PCM in and out -- the formats the reference's capture and
+    recording paths hold (audio.rs:794-855, commands/transcription.rs:306-313).  Integer work, so the bar is equality:
+    s16 entry point == f32 entry point on float(s), then the oracle's `wav_s16_roundtrip` (/ 32768, clamp, x 32767
+    truncated: audio.rs:270-273, recording.rs:109-110) -- at 4096 streams, both layouts, host (small call, pipelined
+    call) and device entry points, chunked calls continuing the streams, VAD identical."""
+    import torch
+    from crispy_amd import synth_audio as SA
+    from oracle import resample_oracle as RO
+    B, T = 4096, 24
+    xf = SA.batch_np(B, T) * np.float32(32768.0)
+    xf[:, 7] *= 3.0                                                   # a stream that clips at the int16 rails
+    xi = np.clip(np.rint(xf), -32768, 32767).astype(np.int16)         # [T, B, 480]
+    ref_ds = _mk(weights0, B)
+    ref, rvad = ref_ds.process(xi.astype(np.float32))
+    want = (RO.wav_s16_roundtrip(ref / np.float32(32768.0)) * np.float32(32768.0)).astype(np.int16)
+    assert np.abs(want).max() > 20000 and len(np.unique(want)) > 10000
+    # host entry point: 94 MB in -> the pipelined path; then two chunked calls on a fresh handle
+    out, vad = _mk(weights0, B).process_s16(xi)
+    assert out.dtype == np.int16 and np.array_equal(out, want) and np.array_equal(vad, rvad)
+    ds = _mk(weights0, B)
+    o1, v1 = ds.process_s16(xi[:10])
+    o2, v2 = ds.process_s16(xi[10:])
+    assert np.array_equal(np.concatenate([o1, o2]), want) and np.array_equal(np.concatenate([v1, v2]), rvad)
+    # stream-major layout through the device entry point
+    ds = _mk(weights0, B)
+    d_in = torch.from_numpy(np.ascontiguousarray(xi.transpose(1, 0, 2))).cuda()
+    d_out = torch.empty_like(d_in)
+    d_vad = torch.empty(T, B, device="cuda")
+    torch.cuda.synchronize()
+    ds.process_s16_device(d_in.data_ptr(), d_out.data_ptr(), T, d_vad=d_vad.data_ptr(), layout="btf")
+    ds.synchronize()
+    assert np.array_equal(d_out.cpu().numpy().transpose(1, 0, 2), want) and np.array_equal(d_vad.cpu().numpy(), rvad)
+    # a handle may mix the transports: f32 call, then int16 call, continue one another's streams
+    ds = _mk(weights0, B)
+    a, _ = ds.process(xi[:10].astype(np.float32))
+    b, _ = ds.process_s16(xi[10:])
+    assert np.array_equal(a, ref[:10]) and np.array_equal(b, want[10:])
+    # the single-stream drop-in shape (a small call: one copy in, one out)
+    one = _mk(weights0, 1)
+    o, _ = one.process_s16(np.ascontiguousarray(xi[:, 5:6]))
+    assert np.array_equal(o[:, 0], want[:, 5])
+
+
 def test_streams_are_independent_and_reset_is_per_stream(weights0):
     from crispy_amd import synth_audio as SA
     T = 20

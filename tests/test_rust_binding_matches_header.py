@@ -13,9 +13,11 @@ OPAQUE = {"crispy_rn", "crispy_mel", "crispy_asr", "crispy_resampler"}
 STRUCTS = {"crispy_asr_hparams", "crispy_asr_specials", "crispy_asr_opts", "crispy_asr_segment", "crispy_asr_window",
            "crispy_asr_result"}
 SCALARS_C = {"int": "i32", "long": "i64", "float": "f32", "double": "f64", "size_t": "usize", "char": "c_char", "void": "c_void",
-             "int8_t": "i8", "unsigned char": "u8", "crispy_rn_layout": "i32"}
+             "int8_t": "i8", "int16_t": "i16", "unsigned char": "u8", "crispy_rn_layout": "i32",
+             "crispy_asr_progress_fn": "crispy_asr_progress_fn"}
 SCALARS_RS = {"c_int": "i32", "c_long": "i64", "c_float": "f32", "f32": "f32", "f64": "f64", "c_double": "f64", "usize": "usize", "c_char": "c_char",
-              "c_void": "c_void", "i8": "i8", "c_uchar": "u8", "u8": "u8", "crispy_rn_layout": "i32", "i32": "i32"}
+              "c_void": "c_void", "i8": "i8", "c_uchar": "u8", "u8": "u8", "crispy_rn_layout": "i32", "i32": "i32", "i16": "i16",
+              "crispy_asr_progress_fn": "crispy_asr_progress_fn"}
 
 
 def _strip_c_comments(s):
@@ -25,7 +27,7 @@ def _strip_c_comments(s):
 def canon_c(t: str) -> str:
     """'const float *const *' -> '*const *const f32'; 'crispy_rn **' -> '*mut *mut crispy_rn'; 'int' -> 'i32'."""
     t = " ".join(t.replace("*", " * ").split())
-    toks = t.split()
+    toks = [x for x in t.split() if x != "volatile"]      # Rust has no volatile types: the binding reads through a raw pointer
     # base type = everything before the first '*', minus a leading/trailing const
     first = toks.index("*") if "*" in toks else len(toks)
     base_toks = [x for x in toks[:first] if x != "const"]
