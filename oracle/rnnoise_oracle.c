@@ -346,6 +346,56 @@ void rno_pitch_downsample(const float *x, float *x_lp) {
   }
 }
 
+/* ---- decision margin of the pitch analysis (test instrumentation, no effect on any result) -------------------------
+ * The pitch index is an integer picked by comparisons between correlations.  Another correct f32 implementation adds the
+ * same products in another order, so its correlations differ by ~1e-6 of their Cauchy-Schwarz scale sqrt(Sxx Syy) -- and
+ * where two compared quantities sit closer than that, it may legitimately pick the other side.  g_pitch_margin is, for
+ * the frame being analysed, the SMALLEST gap at any comparison that decides the index, each in units in which such an
+ * error is O(1e-6): cos^2 = xcorr^2 / (Sxx Syy) for the rankings of find_best_pitch (gap between the last candidate kept
+ * and the best one dropped), correlation / sqrt(Sxx Syy) for the two interpolation tests, the pitch gain (already a
+ * cosine) for remove_doubling's `g1 > thresh`.  Thread-local: the oracle is also timed on many threads (bench.py).
+ * tests/test_gpu_rnnoise.py: the HIP kernel's pitch index must EQUAL the oracle's on every frame whose margin exceeds 1e-5. */
+static __thread float g_pitch_margin;
+static __thread int g_pitch_margin_site;      /* which comparison it was: 1 coarse ranking, 2 fine ranking, 3 sign test, 4 / 6 interpolation, 5 g1 > thresh */
+static void margin_note_at(float gap, int site) {
+  if (gap < 0) gap = -gap;
+  if (gap < g_pitch_margin) { g_pitch_margin = gap; g_pitch_margin_site = site; }
+}
+/* gap protecting the `keep` best candidates of a find_best_pitch pass: cos^2 of the keep-th best minus the next one */
+static void margin_ranking(const float *xcorr, const float *y, int len, int max_pitch, float Sxx, int keep) {
+  float top[3] = {0, 0, 0};
+  float Syy0 = 1, Syy;
+  if (!(Sxx > 0)) return;                       /* an all-zero frame: every sum is exactly zero in any order */
+  for (int j = 0; j < len; j++) Syy0 += y[j] * y[j];
+  Syy = Syy0;
+  for (int i = 0; i < max_pitch; i++) {
+    if (xcorr[i] > 0) {
+      const float c = (xcorr[i] / Sxx) * (xcorr[i] / Syy);
+      if (c > top[0]) { top[2] = top[1]; top[1] = top[0]; top[0] = c; }
+      else if (c > top[1]) { top[2] = top[1]; top[1] = c; }
+      else if (c > top[2]) top[2] = c;
+    }
+    Syy += y[i + len] * y[i + len] - y[i] * y[i];
+    if (Syy < 1) Syy = 1;
+  }
+  /* the sign test `xcorr > 0` is a decision too -- for a lag that would rank among the kept ones if it passed */
+  Syy = Syy0;
+  for (int i = 0; i < max_pitch; i++) {
+    if (!(xcorr[i] > 0)) {
+      const float c = (xcorr[i] / Sxx) * (xcorr[i] / Syy);
+      if (c > top[keep - 1]) margin_note_at((float)sqrt(c), 3);
+    }
+    Syy += y[i + len] * y[i + len] - y[i] * y[i];
+    if (Syy < 1) Syy = 1;
+  }
+  if (top[keep - 1] > 0) margin_note_at(top[keep - 1] - top[keep], keep == 2 ? 1 : 2);   /* fewer positive lags than kept: the sign tests are the decisions */
+}
+static void margin_interp(float a, float b, float c, float scale, int site) {
+  if (!(scale > 0)) return;
+  margin_note_at(((c - a) - .7f * (b - a)) / scale, site);
+  margin_note_at(((a - c) - .7f * (b - c)) / scale, site);
+}
+
 static void find_best_pitch(const float *xcorr, const float *y, int len, int max_pitch,
                             int *best_pitch) {
   float Syy = 1;
@@ -384,6 +434,7 @@ int rno_pitch_search(const float *x_lp, const float *y, int len, int max_pitch) 
   for (int j = 0; j < lag >> 2; j++) y_lp4[j] = y[2 * j];
   pitch_xcorr(x_lp4, y_lp4, xcorr, len >> 2, max_pitch >> 2);
   find_best_pitch(xcorr, y_lp4, len >> 2, max_pitch >> 2, best_pitch);
+  margin_ranking(xcorr, y_lp4, len >> 2, max_pitch >> 2, inner_prod(x_lp4, x_lp4, len >> 2), 2);   /* both of the top two are used */
   for (int i = 0; i < max_pitch >> 1; i++) {
     xcorr[i] = 0;
     if (abs(i - 2 * best_pitch[0]) > 2 && abs(i - 2 * best_pitch[1]) > 2) continue;
@@ -391,6 +442,13 @@ int rno_pitch_search(const float *x_lp, const float *y, int len, int max_pitch) 
     xcorr[i] = sum < -1 ? -1 : sum;
   }
   find_best_pitch(xcorr, y, len >> 1, max_pitch >> 1, best_pitch);
+  {
+    const float Sxx = inner_prod(x_lp, x_lp, len >> 1);
+    margin_ranking(xcorr, y, len >> 1, max_pitch >> 1, Sxx, 1);                                       /* only the best is used */
+    if (best_pitch[0] > 0 && best_pitch[0] < (max_pitch >> 1) - 1)
+      margin_interp(xcorr[best_pitch[0] - 1], xcorr[best_pitch[0]], xcorr[best_pitch[0] + 1],
+                    (float)sqrt(Sxx * (1 + inner_prod(y + best_pitch[0], y + best_pitch[0], len >> 1))), 4);
+  }
   if (best_pitch[0] > 0 && best_pitch[0] < (max_pitch >> 1) - 1) {
     float a = xcorr[best_pitch[0] - 1];
     float b = xcorr[best_pitch[0]];
@@ -462,12 +520,14 @@ float rno_remove_doubling(const float *x, int maxperiod, int minperiod, int N, i
     thresh = .7f * g0 - cont; if (thresh < .3f) thresh = .3f;
     if (T1 < 3 * minperiod) { thresh = .85f * g0 - cont; if (thresh < .4f) thresh = .4f; }
     else if (T1 < 2 * minperiod) { thresh = .9f * g0 - cont; if (thresh < .5f) thresh = .5f; }
+    margin_note_at(g1 - thresh, 5);
     if (g1 > thresh) { best_xy = xy; best_yy = yy; T = T1; g = g1; }
   }
   if (best_xy < 0) best_xy = 0;
   if (best_yy <= best_xy) pg = 1.f;
   else pg = best_xy / (best_yy + 1);
   for (k = 0; k < 3; k++) xcorr[k] = inner_prod(x, x - (T + k - 1), N);
+  margin_interp(xcorr[0], xcorr[1], xcorr[2], (float)sqrt(xx * (1 + yy_lookup[T])), 6);
   if ((xcorr[2] - xcorr[0]) > .7f * (xcorr[1] - xcorr[0])) offset = 1;
   else if ((xcorr[0] - xcorr[2]) > .7f * (xcorr[1] - xcorr[2])) offset = -1;
   else offset = 0;
@@ -592,6 +652,8 @@ struct rno_state {
   float rnn_state[168];
   float taps[RNO_TAPS];
   float dbg[RNO_DBG_FLOATS];
+  float pitch_margin;
+  int pitch_margin_site;
 };
 
 rno_state *rno_create(const int8_t *weights, size_t nbytes) {
@@ -610,6 +672,8 @@ void rno_reset(rno_state *st) {
 }
 
 void rno_last_taps(const rno_state *st, float *taps) { memcpy(taps, st->taps, sizeof(st->taps)); }
+float rno_last_pitch_margin(const rno_state *st) { return st->pitch_margin; }
+int rno_last_pitch_margin_site(const rno_state *st) { return st->pitch_margin_site; }
 void rno_last_debug(const rno_state *st, float *dbg) { memcpy(dbg, st->dbg, sizeof(st->dbg)); }
 
 /* Appendix A.3 steps 2-5; returns 1 on the silence branch */
@@ -641,6 +705,7 @@ static int compute_frame_features(rno_state *st, float *Xr, float *Xi, float *Pr
   memcpy(&st->pitch_buf[PITCH_BUF_SIZE - FRAME_SIZE], in, FRAME_SIZE * sizeof(float));
   rno_pitch_downsample(st->pitch_buf, pitch_buf);
   memcpy(st->dbg + RNO_DBG_LP, pitch_buf, sizeof(pitch_buf));
+  g_pitch_margin = 1e30f;
   pitch_index = rno_pitch_search(pitch_buf + (PITCH_MAX_PERIOD >> 1), pitch_buf, PITCH_FRAME_SIZE,
                                  PITCH_MAX_PERIOD - 3 * PITCH_MIN_PERIOD);
   pitch_index = PITCH_MAX_PERIOD - pitch_index;
@@ -651,6 +716,8 @@ static int compute_frame_features(rno_state *st, float *Xr, float *Xi, float *Pr
   st->last_gain = gain;
   st->taps[64] = (float)pitch_index;
   st->taps[65] = gain;
+  st->pitch_margin_site = g_pitch_margin_site;
+  st->pitch_margin = g_pitch_margin;     /* smallest gap at a comparison that decided the index (see margin_note) */
   for (int i = 0; i < WINDOW_SIZE; i++)
     p[i] = st->pitch_buf[PITCH_BUF_SIZE - WINDOW_SIZE - pitch_index + i];
   apply_window(p);

@@ -63,6 +63,10 @@ void rno_process_frames(rno_state *st, float *out, const float *in, int n_frames
 /* taps of the most recent frame: [0..41] features, [42..63] gains (after the 0.6 decay max),
  * [64] pitch_index, [65] pitch gain, [66] vad, [67] silence flag, [68..71] reserved. */
 void rno_last_taps(const rno_state *st, float *taps);
+/* smallest gap at any comparison that decided the most recent frame's pitch index, in units in which the difference
+ * between two correct f32 implementations is O(1e-6) (rnnoise_oracle.c: margin_note): test instrumentation */
+float rno_last_pitch_margin(const rno_state *st);
+int rno_last_pitch_margin_site(const rno_state *st);
 void rno_last_debug(const rno_state *st, float *dbg);
 
 /* ---- stage entry points (unit tests pin these against numpy/scipy) ---- */

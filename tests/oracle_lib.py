@@ -39,6 +39,8 @@ def lib():
         L.rno_process_frame.argtypes = [C.c_void_p, f32p, f32p]
         L.rno_process_frames.argtypes = [C.c_void_p, f32p, f32p, C.c_int, f32p]
         L.rno_last_taps.argtypes = [C.c_void_p, f32p]
+        L.rno_last_pitch_margin.argtypes = [C.c_void_p]
+        L.rno_last_pitch_margin.restype = C.c_float
         L.rno_last_debug.argtypes = [C.c_void_p, f32p]
         L.rno_forward_transform.argtypes = [f32p, f32p, f32p]
         L.rno_inverse_transform.argtypes = [f32p, f32p, f32p]
@@ -110,8 +112,12 @@ class OracleDenoiseState:
         lib().rno_last_debug(self._h, fp(d))
         return d
 
-    def process(self, x: np.ndarray, with_taps: bool = False):
-        """x: [n_frames, 480] -> out [n_frames, 480], vad [n_frames] (, taps [n_frames, 72])."""
+    def pitch_margin(self) -> float:
+        """Smallest gap at a comparison that decided the last frame's pitch index (oracle/rnnoise_oracle.c: margin_note)."""
+        return float(lib().rno_last_pitch_margin(self._h))
+
+    def process(self, x: np.ndarray, with_taps: bool = False, with_margin: bool = False):
+        """x: [n_frames, 480] -> out [n_frames, 480], vad [n_frames] (, taps [n_frames, 72]) (, pitch margins [n_frames])."""
         x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, FRAME)
         n = x.shape[0]
         out = np.empty_like(x)
@@ -120,10 +126,12 @@ class OracleDenoiseState:
             lib().rno_process_frames(self._h, fp(out), fp(x), n, fp(vad))
             return out, vad
         taps = np.empty((n, TAPS), dtype=np.float32)
+        margin = np.empty(n, dtype=np.float32)
         for t in range(n):
             out[t], vad[t] = self.process_frame(x[t])
             taps[t] = self.taps()
-        return out, vad, taps
+            margin[t] = self.pitch_margin()
+        return (out, vad, taps, margin) if with_margin else (out, vad, taps)
 
 
 def oracle_logmel(x: np.ndarray, filters: np.ndarray, seek: int = 0) -> np.ndarray:

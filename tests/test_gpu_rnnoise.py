@@ -34,6 +34,25 @@ def _assert_pcm_close(out, ref, what=""):
     assert err <= REL * peak + 1e-3, f"{what}: err {err} vs peak {peak}"
 
 
+PITCH_TOL = 1e-5      # a decision whose gap exceeds this (units: oracle/rnnoise_oracle.c, margin_note) must come out the same
+
+
+def _account_for_pitch(got, ref, margin, what):
+    """Pitch index, an integer: EQUAL to the oracle's on every frame whose decision margin exceeds PITCH_TOL -- the smallest gap
+    at any comparison that decides the index (top-two ranking of find_best_pitch, the interpolation tests, remove_doubling's
+    g1 - thresh), in units in which two correct f32 implementations differ by ~1e-6 -- or whose PREVIOUS frame already
+    differed (remove_doubling's continuity bonus reads last_period: a frame inherits its predecessor's near tie).  Returns
+    (mismatches, frames with a margin inside the tolerance); the callers bound the rate (VERDICT r5 next #7)."""
+    got, ref = np.asarray(got), np.asarray(ref)
+    diff = got != ref
+    inherited = np.zeros_like(diff)
+    inherited[1:] = diff[:-1]
+    unexplained = diff & (margin > PITCH_TOL) & ~inherited
+    assert not unexplained.any(), (what, "frames", np.nonzero(unexplained)[0].tolist(), "kernel", got[unexplained].tolist(),
+                                   "oracle", ref[unexplained].tolist(), "margins", margin[unexplained].tolist())
+    return int(diff.sum()), int((margin <= PITCH_TOL).sum())
+
+
 def test_native_library_is_the_one_running():
     from crispy_amd import _native as N
     assert os.path.exists(N.LIB_PATH)
@@ -97,16 +116,22 @@ def test_parity_mixed_batch_with_taps(oracle, weights0):
     ds.process_device(d_in.data_ptr(), d_out.data_ptr(), T, d_vad.data_ptr(), d_taps.data_ptr())
     ds.synchronize()
     out, taps, vad = d_out.cpu().numpy(), d_taps.cpu().numpy(), d_vad.cpu().numpy()
-    n_pitch_ok = 0
+    n_diff = n_close = 0
+    per_stream = []
     for b in range(B):
-        ro, rv, rt = oracle.OracleDenoiseState(weights0).process(x[:, b], with_taps=True)
+        ro, rv, rt, margin = oracle.OracleDenoiseState(weights0).process(x[:, b], with_taps=True, with_margin=True)
         _assert_pcm_close(out[:, b], ro, f"stream {b}")
         assert np.abs(vad[:, b] - rv).max() < 1e-4
         assert np.abs(taps[:, b, 42:64] - rt[:, 42:64]).max() < 1e-4          # gains
         assert np.abs(taps[:, b, :42] - rt[:, :42]).max() <= 1e-4 * max(1.0, np.abs(rt[:, :42]).max())
         assert np.array_equal(taps[:, b, 67], rt[:, 67])                      # silence flags
-        n_pitch_ok += int((taps[:, b, 64] == rt[:, 64]).sum())
-    assert n_pitch_ok >= 0.99 * B * T
+        d, c = _account_for_pitch(taps[:, b, 64], rt[:, 64], margin, f"stream {b}")
+        per_stream.append(d)
+        n_diff += d
+        n_close += c
+    print(f"pitch index: {n_diff} of {B * T} frames differ from the oracle (per stream {per_stream}), every one inside the decision "
+          f"margin {PITCH_TOL:g} or behind a frame that was; {n_close} frames have a margin that small")
+    assert n_diff <= 0.002 * B * T + 1, (n_diff, per_stream)
 
 
 def test_highpass_stage_is_bit_exact(oracle, weights0):
@@ -364,27 +389,38 @@ def test_full_size_properties_4096_streams(weights0):
 
 
 def test_sampled_oracle_parity_at_full_size(oracle, weights0):
-    """4096-stream batch, 40 frames: 24 sampled streams against the oracle."""
+    """4096-stream batch, 40 frames: 24 sampled streams against the oracle -- PCM, and the pitch index held to equality
+    outside the oracle's decision margin (the taps form of the frame kernel: same arithmetic, captures on)."""
     import torch
     from crispy_amd import synth_audio as SA
     B, T = 4096, 40
     dev = torch.device("cuda:0")
     d_in = SA.batch_torch(B, T, dev, seed=11)
     d_out = torch.empty_like(d_in)
+    d_taps = torch.zeros(T, B, 72, device=dev)
     ds = _mk(weights0, B)
     torch.cuda.synchronize()
-    ds.process_device(d_in.data_ptr(), d_out.data_ptr(), T)
+    ds.process_device(d_in.data_ptr(), d_out.data_ptr(), T, d_taps=d_taps.data_ptr())
     ds.synchronize()
     pick = list(range(0, B, 171))
     x = d_in[:, pick].cpu().numpy()
     out = d_out[:, pick].cpu().numpy()
-    bad = 0
+    tp = d_taps[:, pick, 64].cpu().numpy()
+    bad = n_diff = n_close = 0
+    per_stream = []
     for i, b in enumerate(pick):
-        ro, _ = oracle.OracleDenoiseState(weights0).process(np.ascontiguousarray(x[:, i]))
+        ro, _, rt, margin = oracle.OracleDenoiseState(weights0).process(np.ascontiguousarray(x[:, i]), with_taps=True, with_margin=True)
         err = np.abs(out[:, i] - ro).max()
         if err > REL * np.abs(ro).max() + 1e-3:
             bad += 1
+        d, c = _account_for_pitch(tp[:, i], rt[:, 64], margin, f"stream {b}")
+        per_stream.append(d)
+        n_diff += d
+        n_close += c
     assert bad == 0, f"{bad}/{len(pick)} sampled streams out of tolerance"
+    n = len(pick) * T
+    print(f"pitch index at 4096 streams: {n_diff} of {n} sampled frames differ (per stream {per_stream}); {n_close} frames inside the margin")
+    assert n_diff <= 0.002 * n + 1, (n_diff, per_stream)
 
 
 def test_no_kernel_reads_lds_it_has_not_written(oracle, weights0):

@@ -308,3 +308,30 @@ def test_compute_rnn_at_weight_extremes_matches_float64_rederivation(oracle, kin
         hv, hn, hd = state[:24].astype(np.float64), state[24:72].astype(np.float64), state[72:].astype(np.float64)
     if kind in ("pos127", "neg127", "alt127", "row_saturating"):
         assert saturated > 0, "the case was meant to reach the +-8 clamp"
+
+
+def test_pitch_decision_margin_flags_the_frames_a_rounding_sized_perturbation_can_flip(oracle, weights0):
+    """The margin instrumentation the GPU pitch-index test relies on (oracle/rnnoise_oracle.c: margin_note; VERDICT r5
+    next #7): the input of 24 streams x 150 frames perturbed by one part in 2^23 (one f32 rounding of every sample, the size of
+    the difference between two correct f32 implementations' partial sums).  Wherever the pitch index of the perturbed run
+    differs, the unperturbed frame's decision margin is small, or the frame before already differed (last_period feeds
+    remove_doubling's continuity bonus) -- and small margins are rare, so "equal outside the margin" is a strong statement."""
+    from crispy_amd import synth_audio as SA
+    B, T = 24, 150
+    x = SA.batch_np(B, T) * np.float32(32768.0)
+    rng = np.random.default_rng(5)
+    xp = (x * (1.0 + rng.choice([-1.0, 0.0, 1.0], size=x.shape) * 2.0 ** -23)).astype(np.float32)
+    n_diff = n_small = 0
+    for b in range(B):
+        _, _, t0, m0 = oracle.OracleDenoiseState(weights0).process(x[:, b], with_taps=True, with_margin=True)
+        _, _, t1, _ = oracle.OracleDenoiseState(weights0).process(xp[:, b], with_taps=True, with_margin=True)
+        diff = t0[:, 64] != t1[:, 64]
+        inherited = np.zeros_like(diff)
+        inherited[1:] = diff[:-1]
+        loose = diff & (m0 > 1e-4) & ~inherited
+        assert not loose.any(), (b, np.nonzero(loose)[0], m0[loose])
+        n_diff += int(diff.sum())
+        n_small += int((m0 <= 1e-5).sum())
+        assert np.all(m0 >= 0)
+    print(f"{n_diff} of {B * T} frames flip under the perturbation; {n_small} frames have a margin <= 1e-5")
+    assert n_small <= 0.01 * B * T, n_small
