@@ -2651,12 +2651,8 @@ int transcribe_batch_impl(crispy_asr* h, const float* const* pcm, const size_t* 
     int max_new = opts && opts->max_new_tokens > 0 ? opts->max_new_tokens
                                                    : (timestamps ? h->hp.n_text_ctx / 2 - 4 : h->hp.n_text_ctx / 2);
     if ((int)prompt.size() + max_new > h->hp.n_text_ctx) max_new = h->hp.n_text_ctx - (int)prompt.size();
-    std::vector<float> packed((size_t)nb * stride, 0.f);
     std::vector<int> lens(nb), lang(nb, 0);
-    for (int k = 0; k < nb; ++k) {
-      std::memcpy(packed.data() + (size_t)k * stride, pcm[live[k]], n[live[k]] * sizeof(float));
-      lens[k] = (int)n[live[k]];
-    }
+    for (int k = 0; k < nb; ++k) lens[k] = (int)n[live[k]];
     const bool detect = sp.multilingual && !(opts && opts->language_token > 0);
     auto run = [&]() -> int {
       HIP_TRY(hipSetDevice(h->device));
@@ -2668,7 +2664,11 @@ int transcribe_batch_impl(crispy_asr* h, const float* const* pcm, const size_t* 
         HIP_TRY(hipMalloc(&h->w_pcm, (size_t)h->cap_batch * stride * sizeof(float)));
         h->cap_pcm_stride = (long)stride;
       }
-      HIP_TRY(hipMemcpyAsync(h->w_pcm, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+      // every clip straight from the caller's memory into its row (no packed host copy: for the 21 chunks of a ten-minute
+      // recording that was 40 MB zero-filled, copied and then copied again); what lies behind a clip's end in its row is
+      // never read -- the log-mel takes n_samples per clip
+      for (int k = 0; k < nb; ++k)
+        HIP_TRY(hipMemcpyAsync(h->w_pcm + (size_t)k * stride, pcm[live[k]], (size_t)lens[k] * sizeof(float), hipMemcpyHostToDevice, h->stream));
       rc = crispy_mel_compute_device(h->mel, h->w_pcm, (long)stride, lens.data(), nb, nullptr, h->w_melt, h->stream);
       if (rc != CRISPY_OK) return rc;
       rc = crispy_asr_encode_device(h, h->w_melt, nb, h->w_enc, h->stream);
