@@ -427,10 +427,19 @@ __global__ __launch_bounds__(FD_THREADS) void fused_self_kernel(FusedSelfArgs a)
 }
 
 // ---- cross-attention block of one (row, head) ----------------------------------------------------------------------
+// Round 6: the clip's keys AND values are requested in the kernel's first instructions (96 registers of them; round 5
+// requested the values behind the scores, "both at once do not fit beside the projections" -- and a workgroup's 384 KB
+// came in two bursts with the CU's memory pipe idle between them: 4.9 TB/s where attn_dec_x16_kernel, which requests
+// both, streams at 6.05).  What made room: the cross-q weights of the head (64 x D f16) no longer pass through registers --
+// they are the FIRST request of the kernel, an LDS DMA (global_load_lds), and the projection reads them from LDS.  Same
+// products in the same order: a row's bits are those of round 5.
 constexpr int FX_SLOTS = 12;                // 16 waves x 12 slots x 8 keys >= 1536 encoder positions
 template <int D, int NP, bool STREAM_KV>
 __global__ __launch_bounds__(FD_THREADS) void fused_cross_kernel(FusedCrossArgs a) {
   constexpr int PPL = D / 128;
+  constexpr int WQ_BYTES = 64 * D * 2, WQ_ROUND = FD_THREADS * 16;      // one DMA instruction per thread moves 16 KB per workgroup
+  static_assert(WQ_BYTES % WQ_ROUND == 0, "whole DMA rounds");
+  __shared__ __attribute__((aligned(16))) _Float16 wq_s[64 * D];        // cross-q weights of this head, as memory holds them
   __shared__ __attribute__((aligned(16))) float xs[D];
   __shared__ __attribute__((aligned(16))) float gb[2 * D];      // LayerNorm gamma | beta
   __shared__ __attribute__((aligned(16))) _Float16 xn[D];
@@ -439,7 +448,8 @@ __global__ __launch_bounds__(FD_THREADS) void fused_cross_kernel(FusedCrossArgs 
   __shared__ float part_m[FD_WAVES], part_l[FD_WAVES];
   __shared__ __attribute__((aligned(16))) _Float16 att_h[64];
   __shared__ __attribute__((aligned(16))) float po[D];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // Workgroup -> (row, head).  The `group` rows of a clip (the best-of decoders of a fallback pass) read the SAME keys and
   // values: they are placed on one XCD, one after the other in its dispatch order (workgroups are dealt round-robin over
   // the 8 XCDs: MI355X_MICROARCH.md, observed -- for speed only), so that the clip's K | V of this head comes from HBM once
@@ -450,61 +460,70 @@ __global__ __launch_bounds__(FD_THREADS) void fused_cross_kernel(FusedCrossArgs 
   if (gi >= (a.rows / a.group) * H) return;                            // the padding of the last round of eight
   const int clip = gi / H, h = gi % H;
   const int row = clip * a.group + slot % a.group;
+  // (1) requests, oldest first (the vector-memory counter retires in order: whoever waits for the residual stream below has
+  // waited for the DMA in front of it)
+  {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const char* src = reinterpret_cast<const char*>(a.wq + (long)h * 64 * D) + tid * 16;
+    char* dst = reinterpret_cast<char*>(wq_s) + wave * 1024;             // wave-uniform base; a lane lands at + 16 lane
+#pragma unroll
+    for (int k = 0; k < WQ_BYTES / WQ_ROUND; ++k)
+      __builtin_amdgcn_global_load_lds(src + k * WQ_ROUND, (lds_ptr)(dst + k * WQ_ROUND), 16, 0, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
   FdParams<D, NP> par;
   par.request(a.in);
   FdInput<D, NP, 1> fin;
   fin.request(a.in, a.rows, row);
+  const int g = lane >> 4, c = lane & 15;
+  const int jrow = 4 * wave + g;
+  const float bq = a.bq[h * 64 + jrow];
+  __builtin_amdgcn_sched_barrier(0);
   const int Tn = a.n_keys;
   const int c8 = lane & 7, r8 = lane >> 3;
   const int per = (Tn + FD_WAVES - 1) / FD_WAVES;
   const int k_lo = wave * per, k_hi = min(Tn, k_lo + per);
   const int k_last = max(k_hi - 1, 0);
   // the clip's keys of this head: [Tn][64] f16, contiguous; values Tn * D halves further on.  Uniform bases (scalar
-  // registers) + one 32-bit byte offset per lane and slot, the same for a key and its value (64-bit addresses per
-  // slot, kept from the key loads to the value loads, went to scratch)
+  // registers) + one 32-bit byte offset per lane and slot, the same for a key and its value
   const char* Kb = reinterpret_cast<const char*>(a.xkv + (long)clip * a.clip_stride + (long)h * 64 * Tn);
   const char* Vb = Kb + (long)Tn * D * 2;
-  unsigned off[FX_SLOTS];
-#pragma unroll
-  for (int i = 0; i < FX_SLOTS; ++i) off[i] = (unsigned)((min(k_lo + 8 * i + r8, k_last) * 64 + 8 * c8) * 2);
   half8 kr[FX_SLOTS], vr[FX_SLOTS];
+  auto kv_off = [&](int i) { return (unsigned)((min(k_lo + 8 * i + r8, k_last) * 64 + 8 * c8) * 2); };
 #pragma unroll
   for (int i = 0; i < FX_SLOTS; ++i) {
-    const half8* p = reinterpret_cast<const half8*>(Kb + off[i]);
-    kr[i] = STREAM_KV ? __builtin_nontemporal_load(p) : *p;
+    const half8* pk = reinterpret_cast<const half8*>(Kb + kv_off(i));
+    kr[i] = STREAM_KV ? __builtin_nontemporal_load(pk) : *pk;
   }
-  const int g = lane >> 4, c = lane & 15;
-  const int jrow = 4 * wave + g;
-  half8 wq[PPL];
-  {
-    const _Float16* wh = a.wq + (long)h * 64 * D;                       // uniform
-#pragma unroll
-    for (int j = 0; j < PPL; ++j) wq[j] = ldu<half8>(wh, 2u * (unsigned)(jrow * D + 8 * c + 128 * j));
-  }
-  const float bq = a.bq[h * 64 + jrow];
   __builtin_amdgcn_sched_barrier(0);
+  // every wave waits for ITS part of the DMA (the counter retires in order: at most the FX_SLOTS key requests may be pending;
+  // waves 6 - 15 read no residual-stream value and would otherwise reach the barrier with their DMA in flight)
+  static_assert(FX_SLOTS == 12, "the wait below counts the key requests");
+  __builtin_amdgcn_s_waitcnt(0x0F7C);       // vmcnt(12), nothing else waited for
+  // (2) residual stream + LayerNorm (its first barrier is behind every wave's wait above: the weights are in LDS).  The
+  // keys are still arriving (192 KB per workgroup: several microseconds at the rate a CU gets while the chip streams) when
+  // the row's registers are free and the values are requested behind them -- the memory pipe does not drain in between.
   par.stage(gb);
   fin.finish(a.in, par.b, a.rows, row, h == 0, xs, gb, xn);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < FX_SLOTS; ++i) {
+    const half8* pv = reinterpret_cast<const half8*>(Vb + kv_off(i));
+    vr[i] = STREAM_KV ? __builtin_nontemporal_load(pv) : *pv;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // (3) q of the head, weights from LDS
   {
     float v = 0.f;
 #pragma unroll
-    for (int j = 0; j < PPL; ++j) v = dot8(wq[j], *reinterpret_cast<const half8*>(xn + 8 * c + 128 * j), v);
+    for (int j = 0; j < PPL; ++j)
+      v = dot8(*reinterpret_cast<const half8*>(wq_s + jrow * D + 8 * c + 128 * j), *reinterpret_cast<const half8*>(xn + 8 * c + 128 * j), v);
     v = sum16(v) + bq;
     if (c == 0) q_s[jrow] = v;
   }
   fd_bar();
   HeadOut<D> ho;
-  fd_attend<FX_SLOTS>(kr, vr, q_s, k_lo, k_hi, a.attn16, part_o, part_m, part_l, att_h,
-                      [&] {
-                        __builtin_amdgcn_sched_barrier(0);          // (or the scheduler hoists these loads above the scores: 96 registers again)
-#pragma unroll
-                        for (int i = 0; i < FX_SLOTS; ++i) {
-                          const half8* p = reinterpret_cast<const half8*>(Vb + off[i]);
-                          vr[i] = STREAM_KV ? __builtin_nontemporal_load(p) : *p;
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                      },
-                      [&] { ho.request(a.wo, h * 64); });
+  fd_attend<FX_SLOTS>(kr, vr, q_s, k_lo, k_hi, a.attn16, part_o, part_m, part_l, att_h, [] {}, [&] { ho.request(a.wo, h * 64); });
   ho.finish(att_h, po);
   fd_bar();
   fd_store_partial<D, 1>(po, a.part_out, a.rows, row, h);

@@ -57,7 +57,8 @@ def test_recording_text_equals_the_chunk_by_chunk_loop(engine, timestamps):
     if timestamps:
         # segments carry recording time: chunk k's lie in [30 k, 30 (k + 1)] s; windows likewise in frames
         segs, wins = full[3], full[4]
-        assert segs and all(0.0 <= a <= b <= x.size / 16000 + 0.02 for a, b, _ in segs)
+        # (a random-init model puts timestamps anywhere in a chunk's 30 s, also behind the end of the 7.3 s tail chunk)
+        assert segs and all(0.0 <= a <= b <= 21 * 30.0 + 0.02 for a, b, _ in segs)
         assert [s[0] for s in segs] == sorted(s[0] for s in segs)
         assert max(w["seek"] for w in wins) >= 20 * 3000
     # empty recording: empty text, no call-back (commands/transcription.rs:190-194)

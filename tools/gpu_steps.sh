@@ -3,13 +3,14 @@
 # step is started after one: the box may be unhealthy), any other failure is recorded and the call goes on.
 cd "$(dirname "${BASH_SOURCE[0]}")/.."
 export TMPDIR=/tmp
-mkdir -p gpurun_out
+GO=$PWD/gpurun_out          # absolute: a caller may cd (rocprofv3 wants /tmp) between steps
+mkdir -p $GO
 step() {
   local secs=$1 log=$2; shift 2
-  echo "== $(date +%T) $*" >> gpurun_out/$log
-  timeout -k 10 $secs "$@" >> gpurun_out/$log 2>&1
+  echo "== $(date +%T) $*" >> $GO/$log
+  timeout -k 10 $secs "$@" >> $GO/$log 2>&1
   local rc=$?
-  echo "== rc $rc" >> gpurun_out/$log
+  echo "== rc $rc" >> $GO/$log
   echo "[$(date +%T)] rc $rc: $*"
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "step timed out or was killed: ending the call"; exit $rc; fi
   return 0
