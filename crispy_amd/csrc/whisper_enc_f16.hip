@@ -18,6 +18,7 @@
 //                          maximum scales every probability of a row by the same power of two, which f16 rounding does
 //                          not see), so the 32 accumulator rescales per tile are rare.
 #include "api_util.h"
+#include <type_traits>
 #include "asr_common.h"
 
 #include <cstdlib>
@@ -688,20 +689,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void a
     *reinterpret_cast<uint4*>(&Ks[0][kso]) = rk;
     __syncthreads();
   }
-  // this thread's row of the NEXT K tile: a pointer stepped by 32 rows per trip (the clamp to the last row only matters
-  // in the last tile; recomputing min(k0 + krow, T - 1) * ld per trip was nine vector instructions of 64-bit arithmetic
-  // in a loop whose vector pipe is the bottleneck)
-  const _Float16* knext = kaddr(n_tiles > 1 ? 32 : 0);
-  const long kstep = 32 * ld;
-  for (int it = 0; it < n_tiles; ++it) {
-    const int k0 = it * 32, buf = it & 1;
+  // ---- main pass.  Round 6 instruction diet (profiles/r06_attn_enc_pmc.json: the SIMD's vector issue port is 87 % busy, 107
+  // vector instructions per tile and wave; every one that goes is ~0.8 % of the kernel), all of it bit-identical:
+  //   * the loop is unrolled by the two staging buffers, so every LDS address is a register + an immediate (was: three
+  //     v_add per tile and the scalar arithmetic that fed them);
+  //   * the staging loads go through a wave-uniform base (scalar registers, stepped by scalar adds) + one 32-bit byte offset
+  //     per thread, instead of a 64-bit pointer per thread stepped and clamped with vector instructions;
+  //   * max(a, b) of two values the compiler cannot prove canonical (raw matrix-core results, the two halves of a lane swap)
+  //     costs two canonicalising v_max x, x in front of the v_max; written as max(max(-3e38, a), b) it is ONE v_max3, which
+  //     takes its operands as they are (twice per tile);
+  //   * the tile's probability sum starts from its first pair instead of from 0.
+  const char* Kbase = reinterpret_cast<const char*>(Kp);                // uniform in (clip, head)
+  const char* Vbase = reinterpret_cast<const char*>(Vp);
+  const unsigned kvo = (unsigned)((krow * (int)ld + kch * 8) * 2);      // this thread's piece of a K tile, from the tile's first row
+  const int t_last = n_tiles - 1;
+  const unsigned kvo_last = (unsigned)(((min(t_last * 32 + krow, T - 1) - t_last * 32) * (int)ld + kch * 8) * 2);   // rows past T - 1: the last row again
+  const unsigned vvo = (unsigned)((vrow * ENC_TP + vch * 8) * 2);
+  const long ktile_bytes = 32 * ld * 2;
+  const float nlarge = -3.0e38f;          // below every score (masked keys are -3e38 too)
+  auto tile = [&](auto bufc, int it) {
+    constexpr int buf = decltype(bufc)::value;
+    const int k0 = it * 32;
     {
-      const int kn = min(it + 1, n_tiles - 1) * 32;      // the last trip re-requests its own tile (never used)
-      rk = *reinterpret_cast<const uint4*>(knext);
-      rv = *reinterpret_cast<const uint4*>(vg + kn);
-      // rows of tile it + 2: unclamped while that tile is not the last one (all its rows < T), else through kaddr
-      if (it + 2 < n_tiles - 1) knext += kstep;
-      else knext = kaddr(min(it + 2, n_tiles - 1) * 32);
+      const int tn = min(it + 1, t_last);               // the last trip re-requests its own tile (never used)
+      rk = *reinterpret_cast<const uint4*>(Kbase + (long)tn * ktile_bytes + (tn == t_last ? kvo_last : kvo));
+      unsigned vo = vvo;
+      asm volatile("" : "+v"(vo));                      // (or the loop-invariant Vbase + vvo is hoisted as a 64-bit vector pointer and stepped with vector adds)
+      rv = *reinterpret_cast<const uint4*>(Vbase + (long)tn * 64 + vo);
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- S^T tile: rows = keys (li), columns = queries ----
@@ -719,13 +733,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void a
       for (int r = 0; r < 16; ++r)
         if (k0 + acc_row_e(r, lane) >= T) s[r] = -3e38f;
     }
-    float mloc = fmaxf(fmaxf(s[0], s[1]), s[2]);
+    float mloc = nlarge;
 #pragma unroll
-    for (int r = 3; r < 15; r += 2) mloc = fmaxf(fmaxf(mloc, s[r]), s[r + 1]);
-    mloc = fmaxf(mloc, s[15]) * sc;
+    for (int r = 0; r < 16; r += 2) mloc = fmaxf(fmaxf(mloc, s[r]), s[r + 1]);      // eight v_max3, the first against a constant
+    mloc *= sc;
     {
       const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mloc), __float_as_uint(mloc), false, false);
-      mloc = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      mloc = fmaxf(fmaxf(nlarge, __uint_as_float(sw[0])), __uint_as_float(sw[1]));
     }
     // Raise the reference exponent only when it is exceeded by more than 2^6 (p <= 128 fits f16 with room to spare),
     // and keep it an INTEGER: 2^(t - m) with integer m has the mantissa of 2^t, so the f16 rounding of a probability
@@ -750,7 +764,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void a
         p0 = __builtin_amdgcn_exp2f(fmaf(s[r], sc, -m_run));
         p1 = __builtin_amdgcn_exp2f(fmaf(s[r + 1], sc, -m_run));
       }
-      psum += p0 + p1;
+      psum = r == 0 ? p0 + p1 : psum + (p0 + p1);      // (0 + x == x exactly: the sum of round 5, one instruction shorter)
       const half2v pp = __builtin_convertvector(float2v{p0, p1}, half2v);
       ph[r >> 3][r & 7] = pp[0];
       ph[r >> 3][(r & 7) + 1] = pp[1];
@@ -781,6 +795,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void a
     *reinterpret_cast<uint2*>(&Vs[buf ^ 1][vso]) = make_uint2(rv.x, rv.y);
     *reinterpret_cast<uint2*>(&Vs[buf ^ 1][vso + 4]) = make_uint2(rv.z, rv.w);
     __syncthreads();
+  };
+  {
+    int it = 0;
+    for (; it + 1 < n_tiles; it += 2) {
+      tile(std::integral_constant<int, 0>{}, it);
+      tile(std::integral_constant<int, 1>{}, it + 1);
+    }
+    if (it < n_tiles) tile(std::integral_constant<int, 0>{}, it);
   }
   // ---- normalise; lane (li = query, lh) holds O[q][d] for d = acc_row(r) (+ 32 for o1): 8-byte stores ----
   {
