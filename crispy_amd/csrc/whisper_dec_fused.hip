@@ -38,7 +38,6 @@
 // LayerNorm in f32, its output rounded to f16 against f16 weights, f32 accumulation; q . k with the f32 query against the f16
 // cache (mode 2: the query and the normalised probabilities rounded to f16, AttnRows::attn16); attention output and GELU'd
 // hidden units rounded to f16 against f16 weights.  Oracle: oracle/whisper_oracle.py DecoderCache(f16=True, ln16=True).
-#include "api_util.h"
 #include "asr_common.h"
 #include "fd_ln.h"
 
@@ -428,23 +427,10 @@ __global__ __launch_bounds__(FD_THREADS) void fused_self_kernel(FusedSelfArgs a)
 }
 
 // ---- cross-attention block of one (row, head) ----------------------------------------------------------------------
-// Two forms of the same arithmetic (a row's bits are the same in both; which one runs is a matter of speed only):
-//  * EARLY_V = false (rounds 5; steps of few rows): the cross-q weights of the head in registers, the keys requested in the
-//    kernel's first instructions, the values behind the scores into the registers the keys leave ("both at once do not fit
-//    beside the projections: 48 + 48 of 128 registers") -- the shortest chain at one clip;
-//  * EARLY_V = true (round 6; steps of many rows): keys AND values in flight together.  A workgroup's 384 KB used to come in
-//    two bursts with the CU's memory pipe idle between them and during the projections: 4.9 TB/s where attn_dec_x16_kernel,
-//    which requests both up front, streams at 6.05.  What makes room: the cross-q weights (64 x D f16) do not pass through
-//    registers -- an LDS DMA (global_load_lds) behind the residual-stream requests, read from LDS by the projection; the
-//    values are requested right behind the LayerNorm, when the row's registers are free and the keys are still arriving.
 constexpr int FX_SLOTS = 12;                // 16 waves x 12 slots x 8 keys >= 1536 encoder positions
-template <int D, int NP, bool STREAM_KV, bool EARLY_V>
+template <int D, int NP, bool STREAM_KV>
 __global__ __launch_bounds__(FD_THREADS) void fused_cross_kernel(FusedCrossArgs a) {
   constexpr int PPL = D / 128;
-  constexpr int WQ_BYTES = 64 * D * 2, WQ_ROUND = FD_THREADS * 16;      // one DMA instruction per thread moves 16 KB per workgroup
-  static_assert(WQ_BYTES % WQ_ROUND == 0, "whole DMA rounds");
-  constexpr int N_DMA = WQ_BYTES / WQ_ROUND;
-  __shared__ __attribute__((aligned(16))) _Float16 wq_s[EARLY_V ? 64 * D : 8];        // cross-q weights of this head, as memory holds them
   __shared__ __attribute__((aligned(16))) float xs[D];
   __shared__ __attribute__((aligned(16))) float gb[2 * D];      // LayerNorm gamma | beta
   __shared__ __attribute__((aligned(16))) _Float16 xn[D];
@@ -453,8 +439,7 @@ __global__ __launch_bounds__(FD_THREADS) void fused_cross_kernel(FusedCrossArgs 
   __shared__ float part_m[FD_WAVES], part_l[FD_WAVES];
   __shared__ __attribute__((aligned(16))) _Float16 att_h[64];
   __shared__ __attribute__((aligned(16))) float po[D];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   // Workgroup -> (row, head).  The `group` rows of a clip (the best-of decoders of a fallback pass) read the SAME keys and
   // values: they are placed on one XCD, one after the other in its dispatch order (workgroups are dealt round-robin over
   // the 8 XCDs: MI355X_MICROARCH.md, observed -- for speed only), so that the clip's K | V of this head comes from HBM once
@@ -465,26 +450,10 @@ __global__ __launch_bounds__(FD_THREADS) void fused_cross_kernel(FusedCrossArgs 
   if (gi >= (a.rows / a.group) * H) return;                            // the padding of the last round of eight
   const int clip = gi / H, h = gi % H;
   const int row = clip * a.group + slot % a.group;
-  // (1) requests.  The vector-memory counter retires in order, so what the LayerNorm waits for goes first
   FdParams<D, NP> par;
   par.request(a.in);
   FdInput<D, NP, 1> fin;
   fin.request(a.in, a.rows, row);
-  const int g = lane >> 4, c = lane & 15;
-  const int jrow = 4 * wave + g;
-  float bq;
-  if constexpr (EARLY_V) {
-    // four biases per wave, wave-uniform addresses: scalar loads into scalar registers (their own counter, no vector register
-    // held across the key and value requests -- with one the allocator spilled, and a reload from scratch waits for every
-    // pending vector-memory request, the values included)
-    const float* bw = a.bq + h * 64 + 4 * wave;
-    const float b0 = bw[0], b1 = bw[1], b2 = bw[2], b3 = bw[3];
-    bq = g == 0 ? b0 : g == 1 ? b1 : g == 2 ? b2 : b3;
-  } else {
-    bq = a.bq[h * 64 + jrow];
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  half8 wq[EARLY_V ? 1 : PPL];
   const int Tn = a.n_keys;
   const int c8 = lane & 7, r8 = lane >> 3;
   const int per = (Tn + FD_WAVES - 1) / FD_WAVES;
@@ -495,71 +464,31 @@ __global__ __launch_bounds__(FD_THREADS) void fused_cross_kernel(FusedCrossArgs 
   // slot, kept from the key loads to the value loads, went to scratch)
   const char* Kb = reinterpret_cast<const char*>(a.xkv + (long)clip * a.clip_stride + (long)h * 64 * Tn);
   const char* Vb = Kb + (long)Tn * D * 2;
-  unsigned off[EARLY_V ? 1 : FX_SLOTS];
-  auto kv_off = [&](int i) { return (unsigned)((min(k_lo + 8 * i + r8, k_last) * 64 + 8 * c8) * 2); };
-  if constexpr (!EARLY_V) {
+  unsigned off[FX_SLOTS];
 #pragma unroll
-    for (int i = 0; i < FX_SLOTS; ++i) off[i] = kv_off(i);
-  }
+  for (int i = 0; i < FX_SLOTS; ++i) off[i] = (unsigned)((min(k_lo + 8 * i + r8, k_last) * 64 + 8 * c8) * 2);
   half8 kr[FX_SLOTS], vr[FX_SLOTS];
 #pragma unroll
   for (int i = 0; i < FX_SLOTS; ++i) {
-    const half8* p = reinterpret_cast<const half8*>(Kb + (EARLY_V ? kv_off(i) : off[i]));
+    const half8* p = reinterpret_cast<const half8*>(Kb + off[i]);
     kr[i] = STREAM_KV ? __builtin_nontemporal_load(p) : *p;
   }
-  if constexpr (!EARLY_V) {
+  const int g = lane >> 4, c = lane & 15;
+  const int jrow = 4 * wave + g;
+  half8 wq[PPL];
+  {
     const _Float16* wh = a.wq + (long)h * 64 * D;                       // uniform
 #pragma unroll
     for (int j = 0; j < PPL; ++j) wq[j] = ldu<half8>(wh, 2u * (unsigned)(jrow * D + 8 * c + 128 * j));
   }
+  const float bq = a.bq[h * 64 + jrow];
   __builtin_amdgcn_sched_barrier(0);
-  // (2) residual stream + LayerNorm
   par.stage(gb);
   fin.finish(a.in, par.b, a.rows, row, h == 0, xs, gb, xn);
-  if constexpr (EARLY_V) {
-    // the keys are still arriving (192 KB per workgroup: several microseconds at the rate a CU gets while the chip streams)
-    // when the row's registers are free: the weights' DMA and the values go out behind them -- the memory pipe does not
-    // drain in between.  (The DMA sits behind the LayerNorm because the compiler waits for EVERY pending request in front of
-    // the first LDS access that follows an LDS DMA -- in front of the LayerNorm that was a wait for all the keys.)
-    __builtin_amdgcn_sched_barrier(0);
-    {
-      typedef __attribute__((address_space(3))) void* lds_ptr;
-      const char* src = reinterpret_cast<const char*>(a.wq + (long)h * 64 * D) + tid * 16;
-      char* dst = reinterpret_cast<char*>(wq_s) + wave * 1024;             // wave-uniform base; a lane lands at + 16 lane
-#pragma unroll
-      for (int k = 0; k < N_DMA; ++k)
-        __builtin_amdgcn_global_load_lds(src + k * WQ_ROUND, (lds_ptr)(dst + k * WQ_ROUND), 16, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < FX_SLOTS; ++i) {
-      const half8* p = reinterpret_cast<const half8*>(Vb + kv_off(i));
-      vr[i] = STREAM_KV ? __builtin_nontemporal_load(p) : *p;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // every wave waits for ITS part of the DMA: only the FX_SLOTS value requests are younger (the counter retires in order:
-    // the keys, older still, have landed too -- the scores need them next anyway)
-    static_assert(FX_SLOTS == 12, "the wait below counts the value requests");
-    __builtin_amdgcn_s_waitcnt(0x0F7C);      // vmcnt(12), nothing else waited for
-    __builtin_amdgcn_s_barrier();            // (bare, as in gemm_hd_kernel: a fence here makes the compiler wait for the values too)
-  }
-  // (3) q of the head
   {
     float v = 0.f;
-    if constexpr (EARLY_V) {
-      // the DMA'd weights, read by instructions the compiler does not see as LDS reads of a DMA target (it would wait for every
-      // pending request in front of them; the explicit wait and the barrier above are what orders them)
-      typedef __attribute__((address_space(3))) void* lds_ptr;
-      const unsigned wa = (unsigned)(size_t)(lds_ptr)wq_s + (unsigned)((jrow * D + 8 * c) * 2);
 #pragma unroll
-      for (int j = 0; j < PPL; ++j) {
-        half8 w;
-        asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(wa), "n"(256 * j));
-        v = dot8(w, *reinterpret_cast<const half8*>(xn + 8 * c + 128 * j), v);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < PPL; ++j) v = dot8(wq[j], *reinterpret_cast<const half8*>(xn + 8 * c + 128 * j), v);
-    }
+    for (int j = 0; j < PPL; ++j) v = dot8(wq[j], *reinterpret_cast<const half8*>(xn + 8 * c + 128 * j), v);
     v = sum16(v) + bq;
     if (c == 0) q_s[jrow] = v;
   }
@@ -567,15 +496,13 @@ __global__ __launch_bounds__(FD_THREADS) void fused_cross_kernel(FusedCrossArgs 
   HeadOut<D> ho;
   fd_attend<FX_SLOTS>(kr, vr, q_s, k_lo, k_hi, a.attn16, part_o, part_m, part_l, att_h,
                       [&] {
-                        if constexpr (!EARLY_V) {
-                          __builtin_amdgcn_sched_barrier(0);          // (or the scheduler hoists these loads above the scores: 96 registers again)
+                        __builtin_amdgcn_sched_barrier(0);          // (or the scheduler hoists these loads above the scores: 96 registers again)
 #pragma unroll
-                          for (int i = 0; i < FX_SLOTS; ++i) {
-                            const half8* p = reinterpret_cast<const half8*>(Vb + off[i]);
-                            vr[i] = STREAM_KV ? __builtin_nontemporal_load(p) : *p;
-                          }
-                          __builtin_amdgcn_sched_barrier(0);
+                        for (int i = 0; i < FX_SLOTS; ++i) {
+                          const half8* p = reinterpret_cast<const half8*>(Vb + off[i]);
+                          vr[i] = STREAM_KV ? __builtin_nontemporal_load(p) : *p;
                         }
+                        __builtin_amdgcn_sched_barrier(0);
                       },
                       [&] { ho.request(a.wo, h * 64); });
   ho.finish(att_h, po);
@@ -755,19 +682,15 @@ hipError_t fused_cross(const FusedCrossArgs& a, hipStream_t s) {
   if (a.group < 1 || a.rows % a.group != 0) return hipErrorInvalidValue;
   const int n_groups = (a.rows / a.group) * (a.D / 64);               // (clip, head) pairs; eight of them per round of the XCDs
   const dim3 grid((unsigned)(8 * a.group * ((n_groups + 7) / 8))), block(FD_THREADS);
-  // keys and values in flight together once the launch is more than two rounds of the CUs (a stream), the short chain below
-  // that; same bits either way.  CRISPY_FX_EARLYV=0|1 (developer build) forces one form for the A/B.
-  bool early = (long)a.rows * (a.D / 64) > 2 * 256;
-  if (const char* e = dev_env("CRISPY_FX_EARLYV")) early = e[0] == '1';
-#define FX_LAUNCH(DD, NPP) do { \
-    if (early) { if (a.stream_kv) hipLaunchKernelGGL((fused_cross_kernel<DD, NPP, true, true>), grid, block, 0, s, a); \
-                 else hipLaunchKernelGGL((fused_cross_kernel<DD, NPP, false, true>), grid, block, 0, s, a); } \
-    else { if (a.stream_kv) hipLaunchKernelGGL((fused_cross_kernel<DD, NPP, true, false>), grid, block, 0, s, a); \
-           else hipLaunchKernelGGL((fused_cross_kernel<DD, NPP, false, false>), grid, block, 0, s, a); } } while (0)
-  if (a.D == 384) FX_LAUNCH(384, 6);
-  else if (a.D == 512) FX_LAUNCH(512, 8);
-  else return hipErrorInvalidValue;
-#undef FX_LAUNCH
+  if (a.D == 384) {
+    if (a.stream_kv) hipLaunchKernelGGL((fused_cross_kernel<384, 6, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((fused_cross_kernel<384, 6, false>), grid, block, 0, s, a);
+  } else if (a.D == 512) {
+    if (a.stream_kv) hipLaunchKernelGGL((fused_cross_kernel<512, 8, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((fused_cross_kernel<512, 8, false>), grid, block, 0, s, a);
+  } else {
+    return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 

@@ -122,7 +122,7 @@ def test_recording_in_one_call_against_one_call_per_chunk_timed(engine):
     t1 = time.perf_counter()
     once = transcribe_recording(engine, x, **kw)
     t2 = time.perf_counter()
-    assert once == serial and len(serial) > 1000
+    assert once == serial and len(serial) > 500
     ratio = (t1 - t0) / (t2 - t1)
     print(f"{x.size / 16000:.0f} s of audio, whisper_full per chunk: chunk by chunk {1e3 * (t1 - t0):.1f} ms, one call {1e3 * (t2 - t1):.1f} ms = {ratio:.1f} x")
     assert ratio >= 6.0, ratio
