@@ -166,6 +166,27 @@ hipError_t attn_decoder_kv16(const float* q, long ldq, const void* kv, long kv_b
                              long koff, long voff, int n_keys_base, const int* pos_dev, float* out, long ldo, int B, int heads,
                              hipStream_t s, int max_keys = 0,     // max_keys: upper bound of n_keys_base + *pos_dev (0: n_keys_base)
                              AttnRows rows = AttnRows());
+// ---- decode-step projections of the catalog widths at a few rows (whisper_dec_gemv.hip): matrix-vector products over dense
+// f16 rows or resident ggml blocks, LayerNorm computed in the consumer, every weight byte of a row requested at once ----
+constexpr int GEMV_MAX_M = 4;
+constexpr int GEMV_QKV = 0;        // LN(x) . [Wq | Wk | Wv]^T + b: q -> out (f32 [M][ldo]); k | v -> the f16 cache row of this position
+constexpr int GEMV_RES = 1;        // out = x . W^T + b + res (f32; out may alias res)
+constexpr int GEMV_F32 = 2;        // out = LN(x) . W^T + b (f32)
+constexpr int GEMV_GELU16 = 3;     // out16 = f16(gelu_ggml(LN(x) . W^T + b))
+struct GemvArgs {
+  const float* x; const _Float16* x16; long ldx;   // activation rows: f32 (x16 null) or f16
+  const float *ln_g, *ln_b;                         // LayerNorm of x in front of the product (null: none)
+  const _Float16* w16;                              // dense f16 weights [N][K] row-major, or null:
+  const unsigned char* wq[3]; int wq_type, wq_rows; //   ggml blocks (asr_quant.h), rows [p wq_rows, (p + 1) wq_rows) from wq[p]
+  const float* bias;                                // [N] or null
+  float* out; _Float16* out16; long ldo;
+  const float* res;                                 // GEMV_RES
+  _Float16* kv; long kv_row_stride; int pos; const int* pos_dev;   // GEMV_QKV: cache of this layer, row stride per clip, position
+  int M, N, K;
+};
+bool gemv_dec_supported(int D, int rows);
+hipError_t gemv_dec(const GemvArgs& g, int epi, hipStream_t s);
+
 // ---- fused decode step (whisper_dec_fused.hip): a generated token's layer in three launches -------------------------
 // The residual stream entering a block: x = x_in + bias + part[0] + ... + part[n - 1] (n fixed per kernel: heads or 4 D / 128),
 // written to x_out by the row's first workgroup; LayerNorm (ln_g, ln_b) of it feeds the block's first product as f16.

@@ -1176,6 +1176,35 @@ bool self_kv_half(const crispy_asr* h, int rows) {
   return rows <= SKINNY_MAX_M && h->hp.n_text_state % 128 == 0 && h->enc_precision == 1 && h->dec_max_keys > 0 && h->dec_max_keys <= 512;
 }
 
+// A step of 1 .. GEMV_MAX_M rows of a catalog-width model (768 / 1024 / 1280) in precision mode 1: the projections as
+// matrix-vector products with the LayerNorm computed in the consumer (whisper_dec_gemv.hip) -- 8 launches per layer
+// instead of 11, spread over N / 8 workgroups instead of N / 32.  Dense f16 copies or resident blocks of ONE ggml type per
+// projection; anything else (a mixed file's dense tensors, precision mode 0, more rows, the multi-position prompt) stays on
+// the skinny kernels.  CRISPY_ASR_GEMV=0 (developer build) turns it off for the A/B.
+bool gemv_ref_ok(const QRef& r) {
+  if (r.n <= 0) return false;
+  const int tt = r.t[0]->ttype;
+  if (tt != QT_Q4_0 && tt != QT_Q4_1 && tt != QT_Q5_0 && tt != QT_Q5_1 && tt != QT_Q8_0) return false;
+  for (int i = 1; i < r.n; ++i)
+    if (r.t[i]->ttype != tt || r.t[i]->n != r.t[0]->n || r.t[i]->cols != r.t[0]->cols) return false;
+  return true;
+}
+bool gemv_step_ok(const crispy_asr* h, int rows) {
+  const char* e = dev_env("CRISPY_ASR_GEMV");       // read per call: a test flips it inside one process (the captured steps are keyed by
+  const bool off = e && e[0] == '0';                // the handle, and the two arms of the test use two handles)
+  if (off || h->enc_precision != 1 || !h->dec_ln16 || !gemv_dec_supported(h->hp.n_text_state, rows) || !self_kv_half(h, rows)) return false;
+  for (const DecLayer& L : h->dec) {
+    if (h->resident) {
+      if (!(gemv_ref_ok(L.r_qkv) && L.r_qkv.n == 3 && gemv_ref_ok(L.r_out) && gemv_ref_ok(L.r_xq) && gemv_ref_ok(L.r_xout) &&
+            gemv_ref_ok(L.r_fc1) && gemv_ref_ok(L.r_fc2)))
+        return false;
+    } else if (!(L.qkv_wh && L.out_wh && L.xq_wh && L.xout_wh && L.fc1_wh && L.fc2_wh)) {
+      return false;
+    }
+  }
+  return true;
+}
+
 // one decoder step for all clips: token ids in h->d_tok; leaves logits in h->d_logits.
 // dev_pos = false: the position is the host value `pos` (prompt tokens).
 // dev_pos = true : the position is read from h->d_counters[0] by the kernels, so the identical launch
@@ -1261,10 +1290,57 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
     HIP_TRY(gemm_f32_nt(g, 1, s));
     return CRISPY_OK;
   };
+  const bool use_gemv = P == 1 && gemv_step_ok(h, batch);
   for (size_t l = 0; l < h->dec.size(); ++l) {
     const DecLayer& L = h->dec[l];
     float* selfkv = h->d_selfkv + l * (size_t)clips * C * 2 * dt;
     const float* xkv = h->d_xkv + l * xclips * Tn * 2 * dt;
+    if (use_gemv) {
+      _Float16* kvh = reinterpret_cast<_Float16*>(h->d_selfkv) + l * (size_t)clips * C * 2 * dt;
+      _Float16* hid = reinterpret_cast<_Float16*>(h->d_dh);                  // GELU'd hidden units as the f16 fc2 multiplies
+      auto weights = [&](GemvArgs& a, const void* dense16, const QRef& r) {
+        if (!h->resident) { a.w16 = reinterpret_cast<const _Float16*>(dense16); return; }
+        for (int i = 0; i < 3; ++i) a.wq[i] = r.t[i < r.n ? i : 0]->d;
+        a.wq_type = r.t[0]->ttype;
+        a.wq_rows = (int)(r.t[0]->n / (size_t)r.t[0]->cols);
+      };
+      self_rows.attn16 = h->dec_attn16 ? 1 : 0;
+      {
+        GemvArgs a{};
+        a.x = h->d_dx; a.ldx = dt; a.ln_g = L.ln1_w; a.ln_b = L.ln1_b; weights(a, L.qkv_wh, L.r_qkv); a.bias = L.qkv_b;
+        a.out = h->d_dq; a.ldo = dt; a.kv = kvh; a.kv_row_stride = (long)C * 2 * dt; a.pos = pos; a.pos_dev = pos_dev;
+        a.M = batch; a.N = 3 * dt; a.K = dt;
+        HIP_TRY(gemv_dec(a, GEMV_QKV, s));
+      }
+      HIP_TRY(attn_decoder_kv16(h->d_dq, dt, kvh, (long)C * 2 * dt, 2L * dt, 64, 0, dt, dev_pos ? 1 : pos + 1, pos_dev, h->d_datt, dt,
+                                batch, H, s, h->dec_max_keys, self_rows));
+      auto residual_proj = [&](const float* x32, const _Float16* x16, long ldx, const void* dense16, const QRef& r, const float* bias, int K) -> int {
+        GemvArgs a{};
+        a.x = x32; a.x16 = x16; a.ldx = ldx; weights(a, dense16, r); a.bias = bias;
+        a.out = h->d_dx; a.res = h->d_dx; a.ldo = dt; a.M = batch; a.N = dt; a.K = K;
+        HIP_TRY(gemv_dec(a, GEMV_RES, s));
+        return CRISPY_OK;
+      };
+      if ((qrc = residual_proj(h->d_datt, nullptr, dt, L.out_wh, L.r_out, L.out_b, dt)) != CRISPY_OK) return qrc;
+      {
+        GemvArgs a{};
+        a.x = h->d_dx; a.ldx = dt; a.ln_g = L.lnx_w; a.ln_b = L.lnx_b; weights(a, L.xq_wh, L.r_xq); a.bias = L.xq_b;
+        a.out = h->d_dq; a.ldo = dt; a.M = batch; a.N = dt; a.K = dt;
+        HIP_TRY(gemv_dec(a, GEMV_F32, s));
+      }
+      HIP_TRY(attn_decoder_kv16(h->d_dq, dt, reinterpret_cast<const char*>(h->d_xkv_h) + l * xclips * Tn * 2 * dt * 2,
+                                (long)Tn * 2 * dt, 64, 64L * Tn, 0, (long)Tn * dt, Tn, nullptr, h->d_datt, dt, batch, H, s, 0,
+                                cross_rows));
+      if ((qrc = residual_proj(h->d_datt, nullptr, dt, L.xout_wh, L.r_xout, L.xout_b, dt)) != CRISPY_OK) return qrc;
+      {
+        GemvArgs a{};
+        a.x = h->d_dx; a.ldx = dt; a.ln_g = L.ln2_w; a.ln_b = L.ln2_b; weights(a, L.fc1_wh, L.r_fc1); a.bias = L.fc1_b;
+        a.out16 = hid; a.ldo = 4L * dt; a.M = batch; a.N = 4 * dt; a.K = dt;
+        HIP_TRY(gemv_dec(a, GEMV_GELU16, s));
+      }
+      if ((qrc = residual_proj(nullptr, hid, 4L * dt, L.fc2_wh, L.r_fc2, L.fc2_b, 4 * dt)) != CRISPY_OK) return qrc;
+      continue;
+    }
     // causal self-attention against the cache; k | v of this position go straight into the cache row (b, pos)
     float* kv_dst = selfkv + (dev_pos ? 0 : (size_t)pos * 2 * dt);
     // mode 1: the self K|V cache is f16, as whisper.cpp's kv_self is (it aliases the f32 cache: every decode call

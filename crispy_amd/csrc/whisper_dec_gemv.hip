@@ -1,0 +1,286 @@
+// whisper_dec_gemv.hip -- the projections of a generated token's decoder step for the CATALOG widths (768 / 1024 / 1280:
+// small, medium, large-v3 / turbo -- src-tauri/src/managers/model.rs:74-148), dense f16 or resident ggml blocks, at the
+// reference's call shape: one chunk at a time (engine.transcribe, managers/transcription.rs:183-185), i.e. 1 .. 4 rows.
+//
+// Round 5 ran these steps through the 32 x 32-tile "skinny" kernels (whisper_kernels.hip): N / 32 workgroups -- 32 of the
+// chip's 256 CUs for a 1024-wide projection -- each walking K in chunks of 32 per wave, plus a LayerNorm launch in front of
+// three of the six projections: 11 launches per layer, 4.5 - 6 us each whatever they do (15 us for fc2, K = 4096 walked by
+// 16 waves), 1.75 - 1.94 ms per token on Whisper-medium (profiles/r06_decode_medium_*).  A step of one row is a
+// matrix-VECTOR product per projection; what it needs is every weight byte requested at once, from as many CUs as there are:
+//
+//   * one weight row per HALF-WAVE, a lane owns whole 32-weight blocks of it (= one ggml block of a resident model; 64
+//     contiguous bytes of a dense f16 row): every request of the row is issued in the kernel's first instructions;
+//   * 8 weight rows per 256-thread workgroup: N / 8 workgroups (128 for a 1024-wide projection, 512 for fc1);
+//   * the LayerNorm in front of q | k | v, cross-q and fc1 is computed by every workgroup itself (a row is <= 1280 floats:
+//     cheaper than the launch it replaces), the activation rows live in LDS as f16 -- ggml's mul_mat operand;
+//   * resident blocks are de-quantised in registers with the loader's operations in the loader's order (asr_quant.h), then
+//     rounded to f16: a resident model and the same file inflated at load run the SAME instructions behind the fetch, lane
+//     for lane and block for block, so they agree bit for bit (tests/test_gpu_resident.py, test_catalog_models_at_full_depth);
+//   * a row's arithmetic involves that row alone: its bits do not depend on how many rows share the step.
+//
+// Arithmetic = ggml's for these products [UPSTREAM-RECALL: mul_mat converts its f32 operand to the f16 of the weight]: the
+// f32 activation (or LayerNorm output) rounded to f16 against f16 weights, f32 accumulation (v_dot2_f32_f16 chains of 16
+// pairs per block, blocks of a lane in K order, then a fixed shuffle tree over the 32 lanes of the row).
+#include "asr_common.h"
+#include "asr_quant.h"
+
+namespace crispy {
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+
+constexpr int GV_THREADS = 256;
+constexpr int GV_ROWS = 8;                      // weight rows per workgroup: two per wave, one per half-wave
+constexpr int GV_XB = 40;                       // halves between two 32-element blocks of an activation row in LDS (32 + 8: a
+                                                // half-wave's 64-byte reads, one block per lane, spread over all banks)
+
+__device__ __forceinline__ float gv_dot8(const half8 a, const half8 b, float acc) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    acc = __builtin_amdgcn_fdot2(half2v{a[2 * i], a[2 * i + 1]}, half2v{b[2 * i], b[2 * i + 1]}, acc, false);
+  return acc;
+}
+
+// ---- one block of 32 weights of one row: requested as raw registers, decoded to 4 x half8 (k order) at the point of use ----
+template <int TT> struct GvBlock {                  // ggml block (asr_quant.h)
+  static constexpr int BB = quant_block_bytes(TT);
+  static constexpr int NWD = (BB + 3) / 4;          // (the last dword may reach 2 bytes past the block: tensors are padded)
+  unsigned w[NWD];
+  __device__ __forceinline__ void request(const unsigned char* row, int kb) {
+    const unsigned char* b = row + (long)kb * BB;
+#pragma unroll
+    for (int i = 0; i < NWD; ++i) w[i] = q_u32(b + 4 * i);
+  }
+  __device__ __forceinline__ unsigned byte_at(int off) const {      // byte `off` of the block (compile-time off)
+    return (w[off >> 2] >> (8 * (off & 3))) & 0xffu;
+  }
+  __device__ __forceinline__ float half_at(int off) const {         // f16 at byte `off` (even)
+    const unsigned short u = (unsigned short)((w[off >> 2] >> (8 * (off & 3))) & 0xffffu);
+    _Float16 h;
+    __builtin_memcpy(&h, &u, 2);
+    return (float)h;
+  }
+  __device__ __forceinline__ unsigned dword_at(int off) const {     // 32 bits from byte `off` (2-byte aligned)
+    if ((off & 3) == 0) return w[off >> 2];
+    return (w[off >> 2] >> 16) | (w[(off >> 2) + 1] << 16);
+  }
+  __device__ __forceinline__ void decode(half8 (&h)[4]) const {
+#pragma clang fp contract(off)
+    float y[32];
+    const float d = half_at(0);
+    if (TT == QT_Q8_0) {
+#pragma unroll
+      for (int j = 0; j < 32; ++j) y[j] = (float)(int)(signed char)byte_at(2 + j) * d;
+    } else {
+      constexpr bool has_m = TT == QT_Q4_1 || TT == QT_Q5_1, has_h = TT == QT_Q5_0 || TT == QT_Q5_1;
+      const float m = has_m ? half_at(2) : 0.f;
+      constexpr int off_h = has_m ? 4 : 2;
+      const unsigned qh = has_h ? dword_at(off_h) : 0u;
+      constexpr int off_q = off_h + (has_h ? 4 : 0);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const unsigned v = byte_at(off_q + j);
+        int x0 = (int)(v & 0x0fu), x1 = (int)(v >> 4);
+        if (has_h) { x0 |= (int)((qh >> j) & 1u) << 4; x1 |= (int)((qh >> (j + 16)) & 1u) << 4; }
+        if (TT == QT_Q4_0) { y[j] = (float)(x0 - 8) * d; y[j + 16] = (float)(x1 - 8) * d; }
+        else if (TT == QT_Q5_0) { y[j] = (float)(x0 - 16) * d; y[j + 16] = (float)(x1 - 16) * d; }
+        else { y[j] = (float)x0 * d + m; y[j + 16] = (float)x1 * d + m; }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) h[i][e] = (_Float16)y[8 * i + e];
+  }
+};
+template <> struct GvBlock<-1> {                    // dense f16 row: 64 bytes
+  static constexpr int BB = 64;
+  half8 h4[4];
+  __device__ __forceinline__ void request(const unsigned char* row, int kb) {
+    const half8* p = reinterpret_cast<const half8*>(row + (long)kb * 64);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h4[i] = p[i];
+  }
+  __device__ __forceinline__ void decode(half8 (&h)[4]) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h[i] = h4[i];
+  }
+};
+
+// K -> LDS index of an activation row held as f16 in blocks of 32 with 8 halves of padding
+__device__ __forceinline__ int gv_idx(int c) { return (c >> 5) * GV_XB + (c & 31); }
+
+// One wave, one row: f16(LayerNorm(x)) into the padded LDS row.  Two passes over registers, a lane holds columns lane + 64 q
+// (layernorm_h_kernel's arithmetic: the sum, then the sum of squared deviations, shuffle trees of the same shape).
+template <int D>
+__device__ __forceinline__ void gv_layernorm_wave(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  _Float16* out, int lane) {
+  constexpr int PER = D / 64;
+  float e[PER], gm[PER], bt[PER], s = 0.f;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) { e[q] = x[lane + 64 * q]; gm[q] = gamma[lane + 64 * q]; bt[q] = beta[lane + 64 * q]; }
+#pragma unroll
+  for (int q = 0; q < PER; ++q) s += e[q];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  const float mean = s / (float)D;
+  float s2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) { const float d = e[q] - mean; s2 = fmaf(d, d, s2); }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s2 += __shfl_xor(s2, off, 64);
+  const float rstd = 1.f / sqrtf(s2 / (float)D + 1e-5f);
+#pragma unroll
+  for (int q = 0; q < PER; ++q) out[gv_idx(lane + 64 * q)] = (_Float16)((e[q] - mean) * rstd * gm[q] + bt[q]);
+}
+
+// TT: -1 dense f16 rows, else the ggml type.  K: length of a weight row.  LN: the activation is LayerNorm(x) (K = model width).
+// EPI: GEMV_QKV / GEMV_RES / GEMV_F32 / GEMV_GELU16 (asr_common.h).
+template <int TT, int K, bool LN, int EPI>
+__global__ __launch_bounds__(GV_THREADS) void gemv_dec_kernel(GemvArgs g) {
+  constexpr int KB = K / 32;                      // blocks per weight row
+  constexpr int NPASS = (KB + 31) / 32;           // blocks per lane (lane hl of the half-wave owns blocks hl, hl + 32, ...)
+  __shared__ __attribute__((aligned(16))) _Float16 xs[GEMV_MAX_M][KB * GV_XB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hl = lane & 31, half = lane >> 5;
+  const int n = blockIdx.x * GV_ROWS + 2 * wave + half;              // this half-wave's weight row (N is a multiple of 8)
+  const int M = g.M;
+  // (1) every weight byte of the row, requested first
+  const unsigned char* wrow;
+  if (TT < 0) {
+    wrow = reinterpret_cast<const unsigned char*>(g.w16) + (long)n * K * 2;
+  } else {
+    const int p = n / g.wq_rows;                                      // part of a row-fused matrix (q | k | v: three tensors)
+    const unsigned char* base = p == 0 ? g.wq[0] : (p == 1 ? g.wq[1] : g.wq[2]);
+    wrow = base + (long)(n - p * g.wq_rows) * KB * GvBlock<TT>::BB;
+  }
+  GvBlock<TT> blk[NPASS];
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+    const int kb = min(hl + 32 * ps, KB - 1);                         // lanes past the row's end: its last block again, weight 0 below
+    blk[ps].request(wrow, kb);
+  }
+  const float bias = g.bias ? g.bias[n] : 0.f;
+  __builtin_amdgcn_sched_barrier(0);
+  // (2) the activation rows as f16 in LDS
+  if (LN) {
+    if (wave < M) gv_layernorm_wave<K>(g.x + (long)wave * g.ldx, g.ln_g, g.ln_b, xs[wave], lane);
+  } else {
+    for (int m = 0; m < M; ++m) {
+      if (g.x16) {
+        const _Float16* xr = g.x16 + (long)m * g.ldx;
+        for (int c = tid; c < K; c += GV_THREADS) xs[m][gv_idx(c)] = xr[c];
+      } else {
+        const float* xr = g.x + (long)m * g.ldx;
+        for (int c = tid; c < K; c += GV_THREADS) xs[m][gv_idx(c)] = (_Float16)xr[c];
+      }
+    }
+  }
+  __syncthreads();
+  // (3) the products: a lane's blocks in K order, 16 dot2 per block and row
+  float acc[GEMV_MAX_M];
+#pragma unroll
+  for (int m = 0; m < GEMV_MAX_M; ++m) acc[m] = 0.f;
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+    const int kb = hl + 32 * ps;
+    half8 w[4];
+    blk[ps].decode(w);
+    if (kb < KB) {
+#pragma unroll
+      for (int m = 0; m < GEMV_MAX_M; ++m) {
+        if (m < M) {
+          const half8* xp = reinterpret_cast<const half8*>(&xs[m][kb * GV_XB]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[m] = gv_dot8(w[i], xp[i], acc[m]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < GEMV_MAX_M; ++m) {
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) acc[m] += __shfl_xor(acc[m], off, 64);      // within the half-wave: fixed tree
+  }
+  // (4) epilogue: lane 0 of the half-wave owns output column n of every row
+  if (hl == 0) {
+#pragma unroll
+    for (int m = 0; m < GEMV_MAX_M; ++m) {
+      if (m >= M) break;
+      float v = acc[m] + bias;
+      if (EPI == GEMV_QKV) {
+        const int D = K;
+        if (n < D) {
+          g.out[(long)m * g.ldo + n] = v;
+        } else {                                                       // k | v of this position into the f16 cache row
+          const long pos = g.pos_dev ? (long)*g.pos_dev : (long)g.pos;
+          g.kv[(long)m * g.kv_row_stride + pos * (2L * D) + (n - D)] = (_Float16)v;
+        }
+      } else if (EPI == GEMV_RES) {
+        g.out[(long)m * g.ldo + n] = v + g.res[(long)m * g.ldo + n];
+      } else if (EPI == GEMV_F32) {
+        g.out[(long)m * g.ldo + n] = v;
+      } else {
+        g.out16[(long)m * g.ldo + n] = (_Float16)gelu_ggml(v);
+      }
+    }
+  }
+}
+
+template <int TT, int K, bool LN, int EPI>
+hipError_t gv_launch(const GemvArgs& g, hipStream_t s) {
+  hipLaunchKernelGGL((gemv_dec_kernel<TT, K, LN, EPI>), dim3(g.N / GV_ROWS), dim3(GV_THREADS), 0, s, g);
+  return hipGetLastError();
+}
+template <int K, bool LN, int EPI>
+hipError_t gv_by_type(const GemvArgs& g, hipStream_t s) {
+  if (g.w16) return gv_launch<-1, K, LN, EPI>(g, s);
+  switch (g.wq_type) {
+    case QT_Q4_0: return gv_launch<QT_Q4_0, K, LN, EPI>(g, s);
+    case QT_Q4_1: return gv_launch<QT_Q4_1, K, LN, EPI>(g, s);
+    case QT_Q5_0: return gv_launch<QT_Q5_0, K, LN, EPI>(g, s);
+    case QT_Q5_1: return gv_launch<QT_Q5_1, K, LN, EPI>(g, s);
+    case QT_Q8_0: return gv_launch<QT_Q8_0, K, LN, EPI>(g, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+template <bool LN, int EPI>
+hipError_t gv_by_width(const GemvArgs& g, hipStream_t s) {
+  switch (g.K) {
+    case 768: return gv_by_type<768, LN, EPI>(g, s);
+    case 1024: return gv_by_type<1024, LN, EPI>(g, s);
+    case 1280: return gv_by_type<1280, LN, EPI>(g, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace
+
+bool gemv_dec_supported(int D, int rows) { return (D == 768 || D == 1024 || D == 1280) && rows >= 1 && rows <= GEMV_MAX_M; }
+
+hipError_t gemv_dec(const GemvArgs& g, int epi, hipStream_t s) {
+  if (g.M < 1 || g.M > GEMV_MAX_M || g.N % GV_ROWS != 0 || (!g.w16 && !g.wq[0])) return hipErrorInvalidValue;
+  if (!g.w16 && (g.wq_rows <= 0 || g.wq_rows % GV_ROWS != 0)) return hipErrorInvalidValue;
+  const bool ln = g.ln_g != nullptr;
+  switch (epi) {
+    case GEMV_QKV: return ln ? gv_by_width<true, GEMV_QKV>(g, s) : hipErrorInvalidValue;
+    case GEMV_F32: return ln ? gv_by_width<true, GEMV_F32>(g, s) : hipErrorInvalidValue;
+    case GEMV_GELU16: return ln ? gv_by_width<true, GEMV_GELU16>(g, s) : hipErrorInvalidValue;
+    case GEMV_RES:
+      if (ln) return hipErrorInvalidValue;
+      switch (g.K) {                    // out-projections (K = D) and fc2 (K = 4 D)
+        case 768: return gv_by_type<768, false, GEMV_RES>(g, s);
+        case 1024: return gv_by_type<1024, false, GEMV_RES>(g, s);
+        case 1280: return gv_by_type<1280, false, GEMV_RES>(g, s);
+        case 3072: return gv_by_type<3072, false, GEMV_RES>(g, s);
+        case 4096: return gv_by_type<4096, false, GEMV_RES>(g, s);
+        case 5120: return gv_by_type<5120, false, GEMV_RES>(g, s);
+        default: return hipErrorInvalidValue;
+      }
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace crispy

@@ -1,0 +1,110 @@
+"""The decode step of the catalog widths (768 / 1024 / 1280: small, medium, large-v3 -- src-tauri/src/managers/model.rs:74-148)
+at the reference's call shape, one chunk at a time (managers/transcription.rs:183-185): `whisper_dec_gemv.hip` -- the six
+projections of a layer as matrix-vector products over dense f16 rows or resident ggml blocks, LayerNorm computed in the
+consumer, 8 launches per layer instead of 11.
+
+ * against the oracle of precision mode 1 (oracle/whisper_oracle.py DecoderCache(f16=True): ggml's mul_mat arithmetic) at the
+   mode's bar, and against the same step through the skinny kernels (developer build, CRISPY_ASR_GEMV=0) -- two implementations
+   of one arithmetic, not bit-identical, both at the bar;
+ * a resident quantised engine == the same file inflated at load, ids and picked-logit BYTES (same instructions behind the
+   weight fetch), for every ggml type the catalog uses;
+ * a row's bits do not depend on the rows it shares a step with (1 row == row 2 of 3)."""
+import numpy as np
+import pytest
+
+from tests.native_variant import library_variant
+
+pytestmark = pytest.mark.gpu
+
+
+def _hp(d, layers=2):
+    from crispy_amd.whisper_weights import HParams
+    return HParams(n_audio_state=d, n_audio_head=d // 64, n_audio_layer=1, n_text_state=d, n_text_head=d // 64, n_text_layer=layers)
+
+
+@pytest.mark.parametrize("d", [768, 1024, 1280])
+def test_gemv_step_against_the_oracle_and_the_skinny_kernels(d):
+    import torch
+    from crispy_amd.asr import WhisperModel
+    from crispy_amd.whisper_weights import synthetic_whisper_weights
+    from oracle import whisper_oracle as WO
+    hp = _hp(d)
+    W = synthetic_whisper_weights(hp, 5)
+    rng = np.random.default_rng(d)
+    B, n_new = 3, 8
+    enc = (rng.standard_normal((B, 1500, d)) * 0.8).astype(np.float32)
+    prompt = WO.default_prompt(hp.n_vocab, no_timestamps=True)
+    d_enc = torch.from_numpy(enc).to("cuda:0")
+    torch.cuda.synchronize()
+    m = WhisperModel(hp, W)
+    try:
+        m.set_precision(1)
+        tg, _, lg = m.decode_greedy_device(d_enc.data_ptr(), B, prompt, n_new)
+        tg2, _, lg2 = m.decode_greedy_device(d_enc.data_ptr(), B, prompt, n_new)
+        solo, _, lsolo = m.decode_greedy_device(d_enc[2:3].contiguous().data_ptr(), 1, prompt, n_new)
+    finally:
+        m.close()
+    assert np.array_equal(tg, tg2) and lg.tobytes() == lg2.tobytes()                  # deterministic
+    assert np.array_equal(solo[0], tg[2]) and lsolo[0].tobytes() == lg[2].tobytes()    # alone = in the step, bit for bit
+    with library_variant("dev", {"CRISPY_ASR_GEMV": "0"}):
+        ms = WhisperModel(hp, W)
+        try:
+            ms.set_precision(1)
+            ts, _, ls = ms.decode_greedy_device(d_enc.data_ptr(), B, prompt, n_new)
+        finally:
+            ms.close()
+    best = np.zeros((B, n_new)); margin = np.zeros((B, n_new)); ids = np.zeros((B, n_new), np.int64)
+    for b in range(B):
+        dc = WO.DecoderCache(W, hp, enc[b], f16=True)
+        for t in prompt[:-1]:
+            dc.step(t)
+        tok = prompt[-1]
+        for i in range(n_new):
+            l = dc.step(tok)
+            tok = int(tg[b][i])
+            best[b, i] = l[tok]
+            top = np.partition(l, -2)[-2:]
+            margin[b, i] = top[1] - top[0]
+            ids[b, i] = int(np.argmax(l))
+    scale = np.abs(best).max()
+    eg = (lg - best) / scale
+    same = tg == ts
+    es = (ls - best)[same] / scale
+    print(f"d {d}: gemv rms {np.sqrt(np.mean(eg ** 2)):.2e} worst {np.abs(eg).max():.2e}; skinny rms {np.sqrt(np.mean(es ** 2)):.2e} "
+          f"worst {np.abs(es).max():.2e}; forms agree on {int(same.sum())} of {same.size} picks")
+    assert np.sqrt(np.mean(eg ** 2)) < 1.6e-4 and np.abs(eg).max() < 5e-4
+    assert np.sqrt(np.mean(es ** 2)) < 1.6e-4 and np.abs(es).max() < 5e-4
+    resolved = margin > 1e-3 * scale
+    assert resolved.sum() >= B * n_new // 2
+    assert np.array_equal(tg[resolved], ids[resolved]) and np.array_equal(ts[resolved], ids[resolved])
+
+
+@pytest.mark.parametrize("d,kind", [(1024, "q4_1"), (1280, "q5_0"), (768, "q8_0"), (768, "q4_0"), (1024, "q5_1")])
+def test_resident_blocks_equal_the_inflated_file_through_the_gemv_step(tmp_path, d, kind):
+    """medium ships as q4_1, large-v3 as q5_0 (managers/model.rs:99,137); the other ggml types for completeness."""
+    import torch
+    from crispy_amd.asr import WhisperEngine
+    from crispy_amd.ggml_io import synthetic_vocab, write_ggml_quantized
+    from crispy_amd.mel_filters import whisper_mel_filters
+    from crispy_amd.whisper_weights import synthetic_whisper_weights
+    hp = _hp(d)
+    W = synthetic_whisper_weights(hp, 7, sensitive=True)
+    path = str(tmp_path / f"w{d}-{kind}.bin")
+    write_ggml_quantized(path, hp, W, whisper_mel_filters(80), synthetic_vocab(hp.n_vocab), kind)
+    rng = np.random.default_rng(d + len(kind))
+    B, n_new = 2, 10
+    d_enc = torch.from_numpy((rng.standard_normal((B, 1500, d)) * 0.8).astype(np.float32)).to("cuda:0")
+    torch.cuda.synchronize()
+    prompt = [50258, 50259, 50359, 50363]
+    res = WhisperEngine(path, resident=True)
+    inf = WhisperEngine(path)
+    try:
+        inf.set_precision(1)
+        tr, _, lr = res.decode_greedy_device(d_enc.data_ptr(), B, prompt, n_new)
+        ti, _, li = inf.decode_greedy_device(d_enc.data_ptr(), B, prompt, n_new)
+        t1, _, l1 = res.decode_greedy_device(d_enc[1:2].contiguous().data_ptr(), 1, prompt, n_new)
+    finally:
+        res.close(); inf.close()
+    assert np.array_equal(tr, ti) and lr.tobytes() == li.tobytes(), (tr, ti)
+    assert np.array_equal(t1[0], tr[1]) and l1[0].tobytes() == lr[1].tobytes()
+    assert len({tuple(t) for t in tr.tolist()}) == B
