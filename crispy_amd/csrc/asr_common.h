@@ -173,6 +173,10 @@ constexpr int GEMV_QKV = 0;        // LN(x) . [Wq | Wk | Wv]^T + b: q -> out (f3
 constexpr int GEMV_RES = 1;        // out = x . W^T + b + res (f32; out may alias res)
 constexpr int GEMV_F32 = 2;        // out = LN(x) . W^T + b (f32)
 constexpr int GEMV_GELU16 = 3;     // out16 = f16(gelu_ggml(LN(x) . W^T + b))
+constexpr int GEMV_RES_MERGE = 4;  // GEMV_RES whose activation is the cross-attention output as gemv_xattn left it: xpart, merged in the prologue
+constexpr int XA_PARTS = 4;        // workgroups per (row, head) of gemv_xattn: each attends a quarter of the clip's keys
+constexpr int XA_SLOTS = 12;       // x 8 keys per wave, 4 waves: 384 keys per part
+constexpr int XA_PART_FLOATS = 66; // a part's partial soft-max: maximum, sum, 64 weighted value sums (unnormalised)
 struct GemvArgs {
   const float* x; const _Float16* x16; long ldx;   // activation rows: f32 (x16 null) or f16
   const float *ln_g, *ln_b;                         // LayerNorm of x in front of the product (null: none)
@@ -182,8 +186,19 @@ struct GemvArgs {
   float* out; _Float16* out16; long ldo;
   const float* res;                                 // GEMV_RES
   _Float16* kv; long kv_row_stride; int pos; const int* pos_dev;   // GEMV_QKV: cache of this layer, row stride per clip, position
+  const float* xpart;                               // GEMV_RES_MERGE: [M][K / 64][XA_PARTS][XA_PART_FLOATS]
   int M, N, K;
 };
+// [LayerNorm -> cross q of a head -> attention over a quarter of the clip's keys] for rows <= GEMV_MAX_M: partial soft-maxes into `part`
+struct XattnArgs {
+  const float* x; long ldx; const float *ln_g, *ln_b;
+  const _Float16* w16; const unsigned char* wq; int wq_type;       // cross-q weights [D][D]: dense f16 rows or ggml blocks
+  const float* bq;
+  const _Float16* xkv; long clip_stride; int n_keys, group;        // the layer's cross K | V (f16, head-major), rows per clip
+  float* part;
+  int rows, D;
+};
+hipError_t gemv_xattn(const XattnArgs& a, hipStream_t s);
 bool gemv_dec_supported(int D, int rows);
 hipError_t gemv_dec(const GemvArgs& g, int epi, hipStream_t s);
 

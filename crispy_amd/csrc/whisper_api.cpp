@@ -99,7 +99,8 @@ struct crispy_asr {
   bool ln16_ready = false;
   bool fused_path = true;                    // generated tokens through the fused step kernels when the model allows (CRISPY_ASR_DECODE=stages: never)
   float* d_fx[3] = {nullptr, nullptr, nullptr};      // fused step: residual stream after the self / cross / MLP input sums [rows][dt]
-  float* d_fpart[3] = {nullptr, nullptr, nullptr};   // fused step: partial rows of the self / cross out-projection [heads][rows][dt], MLP [dt / 32][rows][dt]
+  float* d_fpart[3] = {nullptr, nullptr, nullptr};
+  float* d_gvpart = nullptr;                 // gemv step (catalog widths): partial soft-maxes of the cross-attention [GEMV_MAX_M][heads][XA_PARTS][XA_PART_FLOATS]   // fused step: partial rows of the self / cross out-projection [heads][rows][dt], MLP [dt / 32][rows][dt]
   bool half_ready = false;                   // every f16 weight copy of mode 1 exists (set after the last one and a stream sync)
   int xcd_swizzle = 1;                       // mode 1 GEMMs: column tiles of a row tile on one XCD (CRISPY_ASR_XCD=0 turns it off)
   std::vector<EncLayer> enc;
@@ -367,6 +368,7 @@ void free_dec_ws(crispy_asr* h) {
   if (h->d_beam_parent) { (void)hipFree(h->d_beam_parent); h->d_beam_parent = nullptr; }
   if (h->d_temperature) { (void)hipFree(h->d_temperature); h->d_temperature = nullptr; }
   if (h->d_row_off) { (void)hipFree(h->d_row_off); h->d_row_off = nullptr; }
+  if (h->d_gvpart) { (void)hipFree(h->d_gvpart); h->d_gvpart = nullptr; }
   for (int i = 0; i < 3; ++i) {
     if (h->d_fx[i]) { (void)hipFree(h->d_fx[i]); h->d_fx[i] = nullptr; }
     if (h->d_fpart[i]) { (void)hipFree(h->d_fpart[i]); h->d_fpart[i] = nullptr; }
@@ -1057,6 +1059,8 @@ int reserve_dec(crispy_asr* h, int batch, int xclips = 0) {
       HIP_TRY(hipMalloc(&h->d_fpart[i], (i == 2 ? dt / 32 : dt / 64) * B * dt * sizeof(float)));
     }
   }
+  if (gemv_dec_supported((int)dt, 1))
+    HIP_TRY(hipMalloc(&h->d_gvpart, (size_t)GEMV_MAX_M * (dt / 64) * XA_PARTS * XA_PART_FLOATS * sizeof(float)));
   h->dcap_batch = batch;
   h->dcap_xclips = xclips;
   return CRISPY_OK;
@@ -1322,16 +1326,32 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
         return CRISPY_OK;
       };
       if ((qrc = residual_proj(h->d_datt, nullptr, dt, L.out_wh, L.r_out, L.out_b, dt)) != CRISPY_OK) return qrc;
-      {
+      if (!cross_rows.attn16 && h->d_gvpart && Tn <= XA_PARTS * 4 * XA_SLOTS * 8) {
+        // [LayerNorm -> cross q of a head -> attention over a quarter of the keys] in one launch of heads x XA_PARTS workgroups,
+        // the partial soft-maxes merged by the output projection's prologue: two launches where the step had three
+        XattnArgs xa{};
+        xa.x = h->d_dx; xa.ldx = dt; xa.ln_g = L.lnx_w; xa.ln_b = L.lnx_b; xa.bq = L.xq_b;
+        if (h->resident) { xa.wq = L.r_xq.t[0]->d; xa.wq_type = L.r_xq.t[0]->ttype; }
+        else xa.w16 = reinterpret_cast<const _Float16*>(L.xq_wh);
+        xa.xkv = reinterpret_cast<const _Float16*>(h->d_xkv_h) + l * xclips * Tn * 2 * dt; xa.clip_stride = (long)Tn * 2 * dt;
+        xa.n_keys = Tn; xa.group = xg; xa.part = h->d_gvpart; xa.rows = batch; xa.D = dt;
+        HIP_TRY(gemv_xattn(xa, s));
         GemvArgs a{};
-        a.x = h->d_dx; a.ldx = dt; a.ln_g = L.lnx_w; a.ln_b = L.lnx_b; weights(a, L.xq_wh, L.r_xq); a.bias = L.xq_b;
-        a.out = h->d_dq; a.ldo = dt; a.M = batch; a.N = dt; a.K = dt;
-        HIP_TRY(gemv_dec(a, GEMV_F32, s));
+        a.xpart = h->d_gvpart; weights(a, L.xout_wh, L.r_xout); a.bias = L.xout_b;
+        a.out = h->d_dx; a.res = h->d_dx; a.ldo = dt; a.M = batch; a.N = dt; a.K = dt;
+        HIP_TRY(gemv_dec(a, GEMV_RES_MERGE, s));
+      } else {
+        {
+          GemvArgs a{};
+          a.x = h->d_dx; a.ldx = dt; a.ln_g = L.lnx_w; a.ln_b = L.lnx_b; weights(a, L.xq_wh, L.r_xq); a.bias = L.xq_b;
+          a.out = h->d_dq; a.ldo = dt; a.M = batch; a.N = dt; a.K = dt;
+          HIP_TRY(gemv_dec(a, GEMV_F32, s));
+        }
+        HIP_TRY(attn_decoder_kv16(h->d_dq, dt, reinterpret_cast<const char*>(h->d_xkv_h) + l * xclips * Tn * 2 * dt * 2,
+                                  (long)Tn * 2 * dt, 64, 64L * Tn, 0, (long)Tn * dt, Tn, nullptr, h->d_datt, dt, batch, H, s, 0,
+                                  cross_rows));
+        if ((qrc = residual_proj(h->d_datt, nullptr, dt, L.xout_wh, L.r_xout, L.xout_b, dt)) != CRISPY_OK) return qrc;
       }
-      HIP_TRY(attn_decoder_kv16(h->d_dq, dt, reinterpret_cast<const char*>(h->d_xkv_h) + l * xclips * Tn * 2 * dt * 2,
-                                (long)Tn * 2 * dt, 64, 64L * Tn, 0, (long)Tn * dt, Tn, nullptr, h->d_datt, dt, batch, H, s, 0,
-                                cross_rows));
-      if ((qrc = residual_proj(h->d_datt, nullptr, dt, L.xout_wh, L.r_xout, L.xout_b, dt)) != CRISPY_OK) return qrc;
       {
         GemvArgs a{};
         a.x = h->d_dx; a.ldx = dt; a.ln_g = L.ln2_w; a.ln_b = L.ln2_b; weights(a, L.fc1_wh, L.r_fc1); a.bias = L.fc1_b;

@@ -167,6 +167,25 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_dec_kernel(GemvArgs g) {
   // (2) the activation rows as f16 in LDS
   if (LN) {
     if (wave < M) gv_layernorm_wave<K>(g.x + (long)wave * g.ldx, g.ln_g, g.ln_b, xs[wave], lane);
+  } else if (EPI == GEMV_RES_MERGE) {
+    // the activation is the cross-attention output, still in XA_PARTS partial soft-maxes per head (gv_xattn_kernel): merged
+    // here, in a fixed order, by every workgroup for itself (17 KB of partials per row against the launch it saves)
+    for (int m = 0; m < M; ++m) {
+      for (int c = tid; c < K; c += GV_THREADS) {
+        const float* ph = g.xpart + ((long)m * (K / 64) + (c >> 6)) * (XA_PARTS * XA_PART_FLOATS);
+        float mx = ph[0];
+#pragma unroll
+        for (int j = 1; j < XA_PARTS; ++j) mx = fmaxf(mx, ph[j * XA_PART_FLOATS]);
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int j = 0; j < XA_PARTS; ++j) {
+          const float scl = __expf(ph[j * XA_PART_FLOATS] - mx);         // an empty part has m = -1e30: scale 0
+          num = fmaf(ph[j * XA_PART_FLOATS + 2 + (c & 63)], scl, num);
+          den = fmaf(ph[j * XA_PART_FLOATS + 1], scl, den);
+        }
+        xs[m][gv_idx(c)] = (_Float16)(num / den);
+      }
+    }
   } else {
     for (int m = 0; m < M; ++m) {
       if (g.x16) {
@@ -218,7 +237,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_dec_kernel(GemvArgs g) {
           const long pos = g.pos_dev ? (long)*g.pos_dev : (long)g.pos;
           g.kv[(long)m * g.kv_row_stride + pos * (2L * D) + (n - D)] = (_Float16)v;
         }
-      } else if (EPI == GEMV_RES) {
+      } else if (EPI == GEMV_RES || EPI == GEMV_RES_MERGE) {
         g.out[(long)m * g.ldo + n] = v + g.res[(long)m * g.ldo + n];
       } else if (EPI == GEMV_F32) {
         g.out[(long)m * g.ldo + n] = v;
@@ -226,6 +245,141 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_dec_kernel(GemvArgs g) {
         g.out16[(long)m * g.ldo + n] = (_Float16)gelu_ggml(v);
       }
     }
+  }
+}
+
+// ---- cross-attention of a step of few rows: [LayerNorm -> q of one head -> attention over a QUARTER of the clip's keys] ----
+// Round 5's pair for this -- a cross-q projection launch, then one workgroup per head streaming the head's 384 KB of K | V
+// (10.5 us at width 1024: sixteen CUs pull everything) -- becomes one launch of H x XA_PARTS workgroups: every workgroup
+// normalises the row and projects its head's 64 query values itself (the weights of 64 rows: 128 KB dense, 40 KB as q4_1),
+// attends its quarter of the keys and leaves an UNNORMALISED partial soft-max (maximum, sum, 64 weighted value sums) that
+// the output projection merges in its prologue (GEMV_RES_MERGE).  Partition inside a workgroup: 4 waves x 12 slots x 8 keys
+// (8 lanes per key row of 64 halves), the arithmetic of attn_dec_x16_kernel per wave; merges in fixed order.
+template <int TT, int D>
+__global__ __launch_bounds__(GV_THREADS) void gv_xattn_kernel(XattnArgs a) {
+  constexpr int KB = D / 32, NPASS = (KB + 31) / 32;
+  constexpr int RBATCH = NPASS == 1 ? 8 : 4;              // weight rows of a half-wave in flight together (<= 8 blocks per lane)
+  constexpr int XW = GV_THREADS / 64;                     // waves
+  __shared__ __attribute__((aligned(16))) _Float16 xs[KB * GV_XB];
+  __shared__ __attribute__((aligned(16))) float q_s[64];
+  __shared__ __attribute__((aligned(16))) float part_o[XW][64];
+  __shared__ float part_m[XW], part_l[XW];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hl = lane & 31, hw = 2 * wave + (lane >> 5);            // half-wave 0 .. 7
+  const int h = blockIdx.x / XA_PARTS, part = blockIdx.x % XA_PARTS, row = blockIdx.y;
+  const int clip = row / a.group;
+  // (1) this workgroup's keys and values, requested first: wave w takes keys [k_lo, k_hi) of the part
+  const int Tn = a.n_keys;
+  const int per_p = (Tn + XA_PARTS - 1) / XA_PARTS;
+  const int p_lo = part * per_p, p_hi = min(Tn, p_lo + per_p);
+  const int per = (max(p_hi - p_lo, 0) + XW - 1) / XW;
+  const int k_lo = p_lo + wave * per, k_hi = min(p_hi, k_lo + per);
+  const int k_last = min(max(k_hi - 1, 0), Tn - 1);
+  const int c8 = lane & 7, r8 = lane >> 3;
+  const char* Kb = reinterpret_cast<const char*>(a.xkv + (long)clip * a.clip_stride + (long)h * 64 * Tn);
+  const char* Vb = Kb + (long)Tn * D * 2;
+  half8 kr[XA_SLOTS], vr[XA_SLOTS];
+#pragma unroll
+  for (int i = 0; i < XA_SLOTS; ++i) {
+    const unsigned off = (unsigned)((min(k_lo + 8 * i + r8, k_last) * 64 + 8 * c8) * 2);
+    kr[i] = *reinterpret_cast<const half8*>(Kb + off);
+    vr[i] = *reinterpret_cast<const half8*>(Vb + off);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // (2) LayerNorm of the row (wave 0), then q of the head: half-wave hw owns rows 8 hw .. 8 hw + 7 of the head's 64
+  if (wave == 0) gv_layernorm_wave<D>(a.x + (long)row * a.ldx, a.ln_g, a.ln_b, xs, lane);
+  __syncthreads();
+#pragma unroll
+  for (int rb = 0; rb < 8; rb += RBATCH) {
+    GvBlock<TT> blk[RBATCH * NPASS];
+#pragma unroll
+    for (int i = 0; i < RBATCH; ++i) {
+      const int n = h * 64 + 8 * hw + rb + i;
+      const unsigned char* wrow = TT < 0 ? reinterpret_cast<const unsigned char*>(a.w16) + (long)n * D * 2
+                                         : a.wq + (long)n * KB * GvBlock<TT>::BB;
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) blk[i * NPASS + ps].request(wrow, min(hl + 32 * ps, KB - 1));
+    }
+#pragma unroll
+    for (int i = 0; i < RBATCH; ++i) {
+      float acc = 0.f;
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const int kb = hl + 32 * ps;
+        half8 w[4];
+        blk[i * NPASS + ps].decode(w);
+        if (kb < KB) {
+          const half8* xp = reinterpret_cast<const half8*>(&xs[kb * GV_XB]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = gv_dot8(w[e], xp[e], acc);
+        }
+      }
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+      if (hl == 0) q_s[8 * hw + rb + i] = acc + a.bq[h * 64 + 8 * hw + rb + i];
+    }
+  }
+  __syncthreads();
+  // (3) scores, soft-max weights and weighted value sums of this wave's keys (attn_dec_x16_kernel's arithmetic)
+  float qv[8];
+  {
+    const float4 q0 = *reinterpret_cast<const float4*>(q_s + 8 * c8);
+    const float4 q1 = *reinterpret_cast<const float4*>(q_s + 8 * c8 + 4);
+    qv[0] = q0.x; qv[1] = q0.y; qv[2] = q0.z; qv[3] = q0.w;
+    qv[4] = q1.x; qv[5] = q1.y; qv[6] = q1.z; qv[7] = q1.w;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qv[e] *= 0.125f;
+  }
+  float sc[XA_SLOTS], mloc = -1e30f;
+#pragma unroll
+  for (int i = 0; i < XA_SLOTS; ++i) {
+    float v = (float)kr[i][0] * qv[0];
+#pragma unroll
+    for (int e = 1; e < 8; ++e) v = fmaf((float)kr[i][e], qv[e], v);
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+    sc[i] = k_lo + 8 * i + r8 < k_hi ? v : -1e30f;
+    mloc = fmaxf(mloc, sc[i]);
+  }
+#pragma unroll
+  for (int off = 8; off <= 32; off <<= 1) mloc = fmaxf(mloc, __shfl_xor(mloc, off, 64));
+  float lsum = 0.f, acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int i = 0; i < XA_SLOTS; ++i) {
+    const float pw = k_lo + 8 * i + r8 < k_hi ? __expf(sc[i] - mloc) : 0.f;
+    lsum += pw;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = fmaf(pw, (float)vr[i][e], acc[e]);
+  }
+#pragma unroll
+  for (int off = 8; off <= 32; off <<= 1) {
+    lsum += __shfl_xor(lsum, off, 64);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += __shfl_xor(acc[e], off, 64);
+  }
+  if (r8 == 0) {
+    *reinterpret_cast<float4*>(&part_o[wave][8 * c8]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *reinterpret_cast<float4*>(&part_o[wave][8 * c8 + 4]) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  }
+  if (lane == 0) { part_m[wave] = mloc; part_l[wave] = lsum; }
+  __syncthreads();
+  // (4) the four waves' partials into one (still unnormalised), for the output projection to merge with the other parts
+  if (wave == 0) {
+    float m = part_m[0];
+#pragma unroll
+    for (int w = 1; w < XW; ++w) m = fmaxf(m, part_m[w]);
+    float o = 0.f, l = 0.f;
+#pragma unroll
+    for (int w = 0; w < XW; ++w) {
+      const float scl = __expf(part_m[w] - m);
+      o = fmaf(part_o[w][lane], scl, o);
+      l = fmaf(part_l[w], scl, l);
+    }
+    float* dst = a.part + (((long)row * (D / 64) + h) * XA_PARTS + part) * XA_PART_FLOATS;
+    dst[2 + lane] = o;
+    if (lane == 0) { dst[0] = m; dst[1] = l; }
   }
 }
 
@@ -260,6 +414,34 @@ hipError_t gv_by_width(const GemvArgs& g, hipStream_t s) {
 
 bool gemv_dec_supported(int D, int rows) { return (D == 768 || D == 1024 || D == 1280) && rows >= 1 && rows <= GEMV_MAX_M; }
 
+namespace {
+template <int TT>
+hipError_t xa_by_width(const XattnArgs& a, hipStream_t s) {
+  const dim3 grid((unsigned)(a.D / 64 * XA_PARTS), (unsigned)a.rows), block(GV_THREADS);
+  switch (a.D) {
+    case 768: hipLaunchKernelGGL((gv_xattn_kernel<TT, 768>), grid, block, 0, s, a); break;
+    case 1024: hipLaunchKernelGGL((gv_xattn_kernel<TT, 1024>), grid, block, 0, s, a); break;
+    case 1280: hipLaunchKernelGGL((gv_xattn_kernel<TT, 1280>), grid, block, 0, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+}  // namespace
+
+hipError_t gemv_xattn(const XattnArgs& a, hipStream_t s) {
+  if (a.rows < 1 || a.rows > GEMV_MAX_M || a.group < 1 || a.n_keys < 1 || a.n_keys > XA_PARTS * (GV_THREADS / 64) * XA_SLOTS * 8 || (!a.w16 && !a.wq))
+    return hipErrorInvalidValue;
+  if (a.w16) return xa_by_width<-1>(a, s);
+  switch (a.wq_type) {
+    case QT_Q4_0: return xa_by_width<QT_Q4_0>(a, s);
+    case QT_Q4_1: return xa_by_width<QT_Q4_1>(a, s);
+    case QT_Q5_0: return xa_by_width<QT_Q5_0>(a, s);
+    case QT_Q5_1: return xa_by_width<QT_Q5_1>(a, s);
+    case QT_Q8_0: return xa_by_width<QT_Q8_0>(a, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 hipError_t gemv_dec(const GemvArgs& g, int epi, hipStream_t s) {
   if (g.M < 1 || g.M > GEMV_MAX_M || g.N % GV_ROWS != 0 || (!g.w16 && !g.wq[0])) return hipErrorInvalidValue;
   if (!g.w16 && (g.wq_rows <= 0 || g.wq_rows % GV_ROWS != 0)) return hipErrorInvalidValue;
@@ -268,6 +450,14 @@ hipError_t gemv_dec(const GemvArgs& g, int epi, hipStream_t s) {
     case GEMV_QKV: return ln ? gv_by_width<true, GEMV_QKV>(g, s) : hipErrorInvalidValue;
     case GEMV_F32: return ln ? gv_by_width<true, GEMV_F32>(g, s) : hipErrorInvalidValue;
     case GEMV_GELU16: return ln ? gv_by_width<true, GEMV_GELU16>(g, s) : hipErrorInvalidValue;
+    case GEMV_RES_MERGE:
+      if (ln || !g.xpart) return hipErrorInvalidValue;
+      switch (g.K) {
+        case 768: return gv_by_type<768, false, GEMV_RES_MERGE>(g, s);
+        case 1024: return gv_by_type<1024, false, GEMV_RES_MERGE>(g, s);
+        case 1280: return gv_by_type<1280, false, GEMV_RES_MERGE>(g, s);
+        default: return hipErrorInvalidValue;
+      }
     case GEMV_RES:
       if (ln) return hipErrorInvalidValue;
       switch (g.K) {                    // out-projections (K = D) and fc2 (K = 4 D)

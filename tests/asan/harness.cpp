@@ -47,6 +47,9 @@ hipError_t fused_cross(const FusedCrossArgs&, hipStream_t) { return hipSuccess; 
 hipError_t fused_mlp(const FusedMlpArgs&, hipStream_t) { return hipSuccess; }
 hipError_t fused_finish(const FusedFinishArgs&, hipStream_t) { return hipSuccess; }
 hipError_t gemm_f32_nt(const GemmArgs&, int, hipStream_t) { return hipSuccess; }
+bool gemv_dec_supported(int, int) { return false; }
+hipError_t gemv_dec(const GemvArgs&, int, hipStream_t) { return hipSuccess; }
+hipError_t gemv_xattn(const XattnArgs&, hipStream_t) { return hipSuccess; }
 bool skinny_q_supported(const GemmArgs&, int) { return false; }
 hipError_t gemm_skinny_q(const GemmArgs&, hipStream_t) { return hipSuccess; }
 hipError_t gemm_hh(const HGemmArgs&, int, int, hipStream_t) { return hipSuccess; }
