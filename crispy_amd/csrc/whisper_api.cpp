@@ -181,6 +181,7 @@ struct crispy_asr {
 namespace {
 
 int build_ts_masks(crispy_asr* h);   // defined with the timestamp-mode code below
+bool gemv_ref_ok(const QRef& r);     // defined with the decode steps below
 int transcribe_batch_impl(crispy_asr* h, const float* const* pcm, const size_t* n, int batch, const crispy_asr_opts* opts,
                           crispy_asr_result** results, const volatile int* cancel);
 
@@ -629,6 +630,21 @@ int finalize_resident(crispy_asr* h) {
     h->tok_emb_hp = packed;
   }
   if ((rc = make_conv_halves(h)) != CRISPY_OK) return rc;
+  // One matrix per decoder layer is kept de-quantised as well: the cross-q projection, as f16 (the values the blocks
+  // de-quantise to at the point of use: same bits).  The matrix-vector decode step computes a head's query in every one of the
+  // workgroups that share the head's keys (whisper_dec_gemv.hip: gv_xattn_kernel), and de-quantising it four times over cost
+  // large-v3-q5_0 more than the launch the fusion saves (1.78 -> 1.92 ms per token); 1 / 14 of the decoder's weights, + 7 % memory.
+  if (gemv_dec_supported(dt, 1)) {
+    for (DecLayer& L : h->dec) {
+      if (!gemv_ref_ok(L.r_xq)) continue;
+      void* p = nullptr;
+      HIP_TRY(hipMalloc(&p, (size_t)dt * dt * 2));
+      h->derived.push_back(reinterpret_cast<float*>(p));
+      h->derived_bytes += (size_t)dt * dt * 2;
+      HIP_TRY(dequant_blocks(L.r_xq.t[0]->d, L.r_xq.t[0]->ttype, (long)((size_t)dt * dt / 32), dt, p, 1, nullptr, h->stream));
+      L.xq_wh = p;
+    }
+  }
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->half_ready = true;
   h->enc_precision = 1;
@@ -1331,8 +1347,8 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
         // the partial soft-maxes merged by the output projection's prologue: two launches where the step had three
         XattnArgs xa{};
         xa.x = h->d_dx; xa.ldx = dt; xa.ln_g = L.lnx_w; xa.ln_b = L.lnx_b; xa.bq = L.xq_b;
-        if (h->resident) { xa.wq = L.r_xq.t[0]->d; xa.wq_type = L.r_xq.t[0]->ttype; }
-        else xa.w16 = reinterpret_cast<const _Float16*>(L.xq_wh);
+        if (L.xq_wh) xa.w16 = reinterpret_cast<const _Float16*>(L.xq_wh);      // (a resident model keeps this one matrix as f16 too: finalize_resident)
+        else { xa.wq = L.r_xq.t[0]->d; xa.wq_type = L.r_xq.t[0]->ttype; }
         xa.xkv = reinterpret_cast<const _Float16*>(h->d_xkv_h) + l * xclips * Tn * 2 * dt; xa.clip_stride = (long)Tn * 2 * dt;
         xa.n_keys = Tn; xa.group = xg; xa.part = h->d_gvpart; xa.rows = batch; xa.D = dt;
         HIP_TRY(gemv_xattn(xa, s));

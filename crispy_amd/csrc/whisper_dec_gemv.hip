@@ -65,6 +65,10 @@ template <int TT> struct GvBlock {                  // ggml block (asr_quant.h)
     if ((off & 3) == 0) return w[off >> 2];
     return (w[off >> 2] >> 16) | (w[(off >> 2) + 1] << 16);
   }
+  // The 32 weights as f16, computed with the loader's operations in the loader's order (int -> float, one multiply, one add,
+  // each rounded on its own: asr_quant.h q_block), arranged for few instructions: the sixteen quant bytes as four aligned
+  // dwords, low and high nibbles masked four at a time, a q5 block's fifth bits spread onto them by one multiply per four
+  // elements, bytes converted by v_cvt_f32_ubyteN; (float)(x - 8) is written (float)x - 8.0f (both exact).
   __device__ __forceinline__ void decode(half8 (&h)[4]) const {
 #pragma clang fp contract(off)
     float y[32];
@@ -78,14 +82,21 @@ template <int TT> struct GvBlock {                  // ggml block (asr_quant.h)
       constexpr int off_h = has_m ? 4 : 2;
       const unsigned qh = has_h ? dword_at(off_h) : 0u;
       constexpr int off_q = off_h + (has_h ? 4 : 0);
+      constexpr float zero = TT == QT_Q4_0 ? 8.f : 16.f;            // q4_0 / q5_0: the integer offset
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const unsigned v = byte_at(off_q + j);
-        int x0 = (int)(v & 0x0fu), x1 = (int)(v >> 4);
-        if (has_h) { x0 |= (int)((qh >> j) & 1u) << 4; x1 |= (int)((qh >> (j + 16)) & 1u) << 4; }
-        if (TT == QT_Q4_0) { y[j] = (float)(x0 - 8) * d; y[j + 16] = (float)(x1 - 8) * d; }
-        else if (TT == QT_Q5_0) { y[j] = (float)(x0 - 16) * d; y[j + 16] = (float)(x1 - 16) * d; }
-        else { y[j] = (float)x0 * d + m; y[j + 16] = (float)x1 * d + m; }
+      for (int i = 0; i < 4; ++i) {
+        const unsigned q = dword_at(off_q + 4 * i);                  // elements 4 i .. 4 i + 3 (low nibbles) and 16 + 4 i .. (high)
+        unsigned lo = q & 0x0f0f0f0fu, hi = (q >> 4) & 0x0f0f0f0fu;
+        if (has_h) {
+          lo |= ((((qh >> (4 * i)) & 0xfu) * 0x00204081u) & 0x01010101u) << 4;
+          hi |= ((((qh >> (16 + 4 * i)) & 0xfu) * 0x00204081u) & 0x01010101u) << 4;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x0 = (float)((lo >> (8 * e)) & 0xffu), x1 = (float)((hi >> (8 * e)) & 0xffu);
+          if (has_m) { y[4 * i + e] = x0 * d + m; y[16 + 4 * i + e] = x1 * d + m; }
+          else { y[4 * i + e] = (x0 - zero) * d; y[16 + 4 * i + e] = (x1 - zero) * d; }
+        }
       }
     }
 #pragma unroll
@@ -287,20 +298,22 @@ __global__ __launch_bounds__(GV_THREADS) void gv_xattn_kernel(XattnArgs a) {
     vr[i] = *reinterpret_cast<const half8*>(Vb + off);
   }
   __builtin_amdgcn_sched_barrier(0);
-  // (2) LayerNorm of the row (wave 0), then q of the head: half-wave hw owns rows 8 hw .. 8 hw + 7 of the head's 64
+  // (2) q of the head: half-wave hw owns rows 8 hw .. 8 hw + 7 of the head's 64; their weights (the first RBATCH rows' at
+  // least) are requested here, in front of the LayerNorm (wave 0) they will be multiplied with
+  auto wrow_of = [&](int r) {
+    const int n = h * 64 + 8 * hw + r;
+    return TT < 0 ? reinterpret_cast<const unsigned char*>(a.w16) + (long)n * D * 2 : a.wq + (long)n * KB * GvBlock<TT>::BB;
+  };
+  GvBlock<TT> blk[RBATCH * NPASS];
+#pragma unroll
+  for (int i = 0; i < RBATCH; ++i)
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) blk[i * NPASS + ps].request(wrow_of(i), min(hl + 32 * ps, KB - 1));
+  __builtin_amdgcn_sched_barrier(0);
   if (wave == 0) gv_layernorm_wave<D>(a.x + (long)row * a.ldx, a.ln_g, a.ln_b, xs, lane);
   __syncthreads();
 #pragma unroll
   for (int rb = 0; rb < 8; rb += RBATCH) {
-    GvBlock<TT> blk[RBATCH * NPASS];
-#pragma unroll
-    for (int i = 0; i < RBATCH; ++i) {
-      const int n = h * 64 + 8 * hw + rb + i;
-      const unsigned char* wrow = TT < 0 ? reinterpret_cast<const unsigned char*>(a.w16) + (long)n * D * 2
-                                         : a.wq + (long)n * KB * GvBlock<TT>::BB;
-#pragma unroll
-      for (int ps = 0; ps < NPASS; ++ps) blk[i * NPASS + ps].request(wrow, min(hl + 32 * ps, KB - 1));
-    }
 #pragma unroll
     for (int i = 0; i < RBATCH; ++i) {
       float acc = 0.f;
@@ -309,6 +322,7 @@ __global__ __launch_bounds__(GV_THREADS) void gv_xattn_kernel(XattnArgs a) {
         const int kb = hl + 32 * ps;
         half8 w[4];
         blk[i * NPASS + ps].decode(w);
+        if (rb + RBATCH < 8) blk[i * NPASS + ps].request(wrow_of(rb + RBATCH + i), min(kb, KB - 1));      // the next batch into the registers just read
         if (kb < KB) {
           const half8* xp = reinterpret_cast<const half8*>(&xs[kb * GV_XB]);
 #pragma unroll
