@@ -175,7 +175,7 @@ constexpr int GEMV_F32 = 2;        // out = LN(x) . W^T + b (f32)
 constexpr int GEMV_GELU16 = 3;     // out16 = f16(gelu_ggml(LN(x) . W^T + b))
 constexpr int GEMV_RES_MERGE = 4;  // GEMV_RES whose activation is the cross-attention output as gemv_xattn left it: xpart, merged in the prologue
 constexpr int XA_PARTS = 4;        // workgroups per (row, head) of gemv_xattn: each attends a quarter of the clip's keys
-constexpr int XA_SLOTS = 12;       // x 8 keys per wave, 4 waves: 384 keys per part
+constexpr int XA_SLOTS = 3;        // x 8 keys per wave, 16 waves: 384 keys per part
 constexpr int XA_PART_FLOATS = 66; // a part's partial soft-max: maximum, sum, 64 weighted value sums (unnormalised)
 struct GemvArgs {
   const float* x; const _Float16* x16; long ldx;   // activation rows: f32 (x16 null) or f16

@@ -1342,7 +1342,7 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
         return CRISPY_OK;
       };
       if ((qrc = residual_proj(h->d_datt, nullptr, dt, L.out_wh, L.r_out, L.out_b, dt)) != CRISPY_OK) return qrc;
-      if (!cross_rows.attn16 && h->d_gvpart && Tn <= XA_PARTS * 4 * XA_SLOTS * 8) {
+      if (!cross_rows.attn16 && h->d_gvpart && Tn <= XA_PARTS * 16 * XA_SLOTS * 8) {
         // [LayerNorm -> cross q of a head -> attention over a quarter of the keys] in one launch of heads x XA_PARTS workgroups,
         // the partial soft-maxes merged by the output projection's prologue: two launches where the step had three
         XattnArgs xa{};

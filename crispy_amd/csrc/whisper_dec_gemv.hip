@@ -124,13 +124,18 @@ __device__ __forceinline__ int gv_idx(int c) { return (c >> 5) * GV_XB + (c & 31
 
 // One wave, one row: f16(LayerNorm(x)) into the padded LDS row.  Two passes over registers, a lane holds columns lane + 64 q
 // (layernorm_h_kernel's arithmetic: the sum, then the sum of squared deviations, shuffle trees of the same shape).
-template <int D>
+// EARLY_GB: gamma and beta requested with the row (3 D / 64 registers: the 256-thread kernels have them to spare); else read
+// when they are multiplied (the 1024-thread cross kernel lives in 128 registers).
+template <int D, bool EARLY_GB = true>
 __device__ __forceinline__ void gv_layernorm_wave(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                   _Float16* out, int lane) {
   constexpr int PER = D / 64;
-  float e[PER], gm[PER], bt[PER], s = 0.f;
+  float e[PER], gm[EARLY_GB ? PER : 1], bt[EARLY_GB ? PER : 1], s = 0.f;
 #pragma unroll
-  for (int q = 0; q < PER; ++q) { e[q] = x[lane + 64 * q]; gm[q] = gamma[lane + 64 * q]; bt[q] = beta[lane + 64 * q]; }
+  for (int q = 0; q < PER; ++q) {
+    e[q] = x[lane + 64 * q];
+    if (EARLY_GB) { gm[q] = gamma[lane + 64 * q]; bt[q] = beta[lane + 64 * q]; }
+  }
 #pragma unroll
   for (int q = 0; q < PER; ++q) s += e[q];
 #pragma unroll
@@ -143,7 +148,10 @@ __device__ __forceinline__ void gv_layernorm_wave(const float* __restrict__ x, c
   for (int off = 32; off > 0; off >>= 1) s2 += __shfl_xor(s2, off, 64);
   const float rstd = 1.f / sqrtf(s2 / (float)D + 1e-5f);
 #pragma unroll
-  for (int q = 0; q < PER; ++q) out[gv_idx(lane + 64 * q)] = (_Float16)((e[q] - mean) * rstd * gm[q] + bt[q]);
+  for (int q = 0; q < PER; ++q) {
+    const float g = EARLY_GB ? gm[q] : gamma[lane + 64 * q], b = EARLY_GB ? bt[q] : beta[lane + 64 * q];
+    out[gv_idx(lane + 64 * q)] = (_Float16)((e[q] - mean) * rstd * g + b);
+  }
 }
 
 // TT: -1 dense f16 rows, else the ggml type.  K: length of a weight row.  LN: the activation is LayerNorm(x) (K = model width).
@@ -264,20 +272,24 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_dec_kernel(GemvArgs g) {
 // (10.5 us at width 1024: sixteen CUs pull everything) -- becomes one launch of H x XA_PARTS workgroups: every workgroup
 // normalises the row and projects its head's 64 query values itself (the weights of 64 rows: 128 KB dense, 40 KB as q4_1),
 // attends its quarter of the keys and leaves an UNNORMALISED partial soft-max (maximum, sum, 64 weighted value sums) that
-// the output projection merges in its prologue (GEMV_RES_MERGE).  Partition inside a workgroup: 4 waves x 12 slots x 8 keys
-// (8 lanes per key row of 64 halves), the arithmetic of attn_dec_x16_kernel per wave; merges in fixed order.
+// the output projection merges in its prologue (GEMV_RES_MERGE).  Partition inside a workgroup: 16 waves x 3 slots x 8 keys
+// (8 lanes per key row of 64 halves), the arithmetic of attn_dec_x16_kernel per wave; merges in fixed order.  (First built
+// with 4 waves x 12 slots: 11 us per launch -- a wave's chain of 12 score / value slots and 8 query rows is what the launch
+// lasts, so the chains were cut by four.)
+constexpr int XA_THREADS = 1024;                          // 16 waves: a part's 375 keys are 3 slots of 8 per wave, its 64 query rows 2 per half-wave
 template <int TT, int D>
-__global__ __launch_bounds__(GV_THREADS) void gv_xattn_kernel(XattnArgs a) {
+__global__ __launch_bounds__(XA_THREADS) void gv_xattn_kernel(XattnArgs a) {
   constexpr int KB = D / 32, NPASS = (KB + 31) / 32;
-  constexpr int RBATCH = NPASS == 1 ? 8 : 4;              // weight rows of a half-wave in flight together (<= 8 blocks per lane)
-  constexpr int XW = GV_THREADS / 64;                     // waves
+  constexpr int XW = XA_THREADS / 64;                     // waves
+  constexpr int RPH = 64 / (2 * XW);                      // query rows per half-wave
+  static_assert(XW * XA_SLOTS * 8 >= 384 && RPH == 2, "partition");
   __shared__ __attribute__((aligned(16))) _Float16 xs[KB * GV_XB];
   __shared__ __attribute__((aligned(16))) float q_s[64];
   __shared__ __attribute__((aligned(16))) float part_o[XW][64];
   __shared__ float part_m[XW], part_l[XW];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hl = lane & 31, hw = 2 * wave + (lane >> 5);            // half-wave 0 .. 7
+  const int hl = lane & 31, hw = 2 * wave + (lane >> 5);            // half-wave 0 .. 31
   const int h = blockIdx.x / XA_PARTS, part = blockIdx.x % XA_PARTS, row = blockIdx.y;
   const int clip = row / a.group;
   // (1) this workgroup's keys and values, requested first: wave w takes keys [k_lo, k_hi) of the part
@@ -297,41 +309,50 @@ __global__ __launch_bounds__(GV_THREADS) void gv_xattn_kernel(XattnArgs a) {
     kr[i] = *reinterpret_cast<const half8*>(Kb + off);
     vr[i] = *reinterpret_cast<const half8*>(Vb + off);
   }
-  __builtin_amdgcn_sched_barrier(0);
-  // (2) q of the head: half-wave hw owns rows 8 hw .. 8 hw + 7 of the head's 64; their weights (the first RBATCH rows' at
-  // least) are requested here, in front of the LayerNorm (wave 0) they will be multiplied with
-  auto wrow_of = [&](int r) {
-    const int n = h * 64 + 8 * hw + r;
-    return TT < 0 ? reinterpret_cast<const unsigned char*>(a.w16) + (long)n * D * 2 : a.wq + (long)n * KB * GvBlock<TT>::BB;
-  };
-  GvBlock<TT> blk[RBATCH * NPASS];
+  // (2) q of the head: half-wave hw owns rows 2 hw, 2 hw + 1 of the head's 64; their weights are requested here, in front
+  // of the LayerNorm (wave 0) they will be multiplied with
+  // (width 1280: two blocks per lane and row -- with the LayerNorm's twenty values per lane that is more than the 128 registers
+  // of a 16-wave workgroup hold, so there the row is normalised first and wave 0 requests its weights behind it)
+  constexpr bool LN_FIRST = NPASS > 1;
+  if (LN_FIRST && wave == 0) gv_layernorm_wave<D, false>(a.x + (long)row * a.ldx, a.ln_g, a.ln_b, xs, lane);
+  GvBlock<TT> blk[RPH * NPASS];
 #pragma unroll
-  for (int i = 0; i < RBATCH; ++i)
+  for (int i = 0; i < RPH; ++i) {
+    const int n = h * 64 + RPH * hw + i;
+    const unsigned char* wrow = TT < 0 ? reinterpret_cast<const unsigned char*>(a.w16) + (long)n * D * 2 : a.wq + (long)n * KB * GvBlock<TT>::BB;
 #pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) blk[i * NPASS + ps].request(wrow_of(i), min(hl + 32 * ps, KB - 1));
+    for (int ps = 0; ps < NPASS; ++ps) blk[i * NPASS + ps].request(wrow, min(hl + 32 * ps, KB - 1));
+  }
+  float bq[RPH];
+#pragma unroll
+  for (int i = 0; i < RPH; ++i) bq[i] = a.bq[h * 64 + RPH * hw + i];
   __builtin_amdgcn_sched_barrier(0);
-  if (wave == 0) gv_layernorm_wave<D>(a.x + (long)row * a.ldx, a.ln_g, a.ln_b, xs, lane);
+  if (!LN_FIRST && wave == 0) gv_layernorm_wave<D, false>(a.x + (long)row * a.ldx, a.ln_g, a.ln_b, xs, lane);
   __syncthreads();
+  {
+    float acc[RPH];
 #pragma unroll
-  for (int rb = 0; rb < 8; rb += RBATCH) {
-#pragma unroll
-    for (int i = 0; i < RBATCH; ++i) {
-      float acc = 0.f;
+    for (int i = 0; i < RPH; ++i) {
+      acc[i] = 0.f;
 #pragma unroll
       for (int ps = 0; ps < NPASS; ++ps) {
         const int kb = hl + 32 * ps;
         half8 w[4];
         blk[i * NPASS + ps].decode(w);
-        if (rb + RBATCH < 8) blk[i * NPASS + ps].request(wrow_of(rb + RBATCH + i), min(kb, KB - 1));      // the next batch into the registers just read
         if (kb < KB) {
           const half8* xp = reinterpret_cast<const half8*>(&xs[kb * GV_XB]);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc = gv_dot8(w[e], xp[e], acc);
+          for (int e = 0; e < 4; ++e) acc[i] = gv_dot8(w[e], xp[e], acc[i]);
         }
       }
+    }
 #pragma unroll
-      for (int off = 16; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-      if (hl == 0) q_s[8 * hw + rb + i] = acc + a.bq[h * 64 + 8 * hw + rb + i];
+    for (int off = 16; off > 0; off >>= 1)
+#pragma unroll
+      for (int i = 0; i < RPH; ++i) acc[i] += __shfl_xor(acc[i], off, 64);
+    if (hl == 0) {
+#pragma unroll
+      for (int i = 0; i < RPH; ++i) q_s[RPH * hw + i] = acc[i] + bq[i];
     }
   }
   __syncthreads();
@@ -431,7 +452,7 @@ bool gemv_dec_supported(int D, int rows) { return (D == 768 || D == 1024 || D ==
 namespace {
 template <int TT>
 hipError_t xa_by_width(const XattnArgs& a, hipStream_t s) {
-  const dim3 grid((unsigned)(a.D / 64 * XA_PARTS), (unsigned)a.rows), block(GV_THREADS);
+  const dim3 grid((unsigned)(a.D / 64 * XA_PARTS), (unsigned)a.rows), block(XA_THREADS);
   switch (a.D) {
     case 768: hipLaunchKernelGGL((gv_xattn_kernel<TT, 768>), grid, block, 0, s, a); break;
     case 1024: hipLaunchKernelGGL((gv_xattn_kernel<TT, 1024>), grid, block, 0, s, a); break;
@@ -443,7 +464,7 @@ hipError_t xa_by_width(const XattnArgs& a, hipStream_t s) {
 }  // namespace
 
 hipError_t gemv_xattn(const XattnArgs& a, hipStream_t s) {
-  if (a.rows < 1 || a.rows > GEMV_MAX_M || a.group < 1 || a.n_keys < 1 || a.n_keys > XA_PARTS * (GV_THREADS / 64) * XA_SLOTS * 8 || (!a.w16 && !a.wq))
+  if (a.rows < 1 || a.rows > GEMV_MAX_M || a.group < 1 || a.n_keys < 1 || a.n_keys > XA_PARTS * (XA_THREADS / 64) * XA_SLOTS * 8 || (!a.w16 && !a.wq))
     return hipErrorInvalidValue;
   if (a.w16) return xa_by_width<-1>(a, s);
   switch (a.wq_type) {
