@@ -27,6 +27,9 @@
 #include "../../crispy_amd/csrc/asr_api.cpp"
 #include "../../crispy_amd/csrc/crispy_api.cpp"
 #include "../../crispy_amd/csrc/whisper_api.cpp"
+#include "../../crispy_amd/csrc/ggml_load.cpp"
+#include "../../crispy_amd/csrc/decode_steps.cpp"
+#include "../../crispy_amd/csrc/whisper_full.cpp"
 
 // ---- the launchers: there is no device -------------------------------------------------------------------------------
 namespace crispy {
