@@ -207,6 +207,241 @@ bool gemv_step_ok(const crispy_asr* h, int rows) {
   return true;
 }
 
+// ---- one decoder step through the un-fused kernels: what is the same for every layer of the step, then one function per block ----
+struct StepCtx {
+  crispy_asr* h;
+  hipStream_t s;
+  int clips, P, rows, pos;             // rows = clips x P
+  bool dev_pos;
+  const int* pos_dev;                  // h->d_counters with a device position, else null
+  bool fold;                           // the skinny kernels (<= SKINNY_MAX_M rows): LayerNorm folded in (mode 0) or a launch of its own (modes 1 / 2)
+  AttnRows self_rows, cross_rows;
+  int xg;                              // sequences (rows with a self K|V cache of their own) per audio clip
+  size_t xclips;
+  int dt, H, Tn, C;
+};
+
+// (un-folded path only) f32 weights of a projection: the dense tensor, or -- resident model -- the blocks de-quantised into the
+// scratch slot in front of the product
+const float* step_w32(const StepCtx& c, const float* dense, const QRef& r, const float* gamma, int* rc) {
+  if (!c.h->resident) return dense;
+  const void* o = nullptr;
+  const int e = dq(c.h, r, false, gamma, c.s, &o);
+  if (e != CRISPY_OK) *rc = e;
+  return reinterpret_cast<const float*>(o);
+}
+
+// One projection of the folded path.  Dense model: W = the f32 (gamma-folded) tensor or its f16 copy.  Resident model:
+// the skinny kernel reads the ggml blocks itself and de-quantises in registers (gemm_skinny_q); shapes it has no form
+// for (and dense tensors of a mixed file) go through the scratch slot and the dense kernel -- f32 x gamma for the
+// LayerNorm-folded projections (fold_ln's W' = W . diag(gamma), element for element), f16 for the plain ones.
+int step_proj(const StepCtx& c, GemmArgs g, const float* dense32, const void* dense16, const QRef& r, const float* gamma, bool half) {
+  crispy_asr* h = c.h;
+  g.w_half = half ? 1 : 0;
+  if (!h->resident) {
+    g.W = half ? reinterpret_cast<const float*>(dense16) : dense32;
+    HIP_TRY(gemm_f32_nt(g, 1, c.s));
+    return CRISPY_OK;
+  }
+  bool blocks = r.n > 0 && r.t[0]->ttype != QT_F32;
+  for (int i = 1; i < r.n; ++i) blocks = blocks && r.t[i]->ttype == r.t[0]->ttype && r.t[i]->n == r.t[0]->n;
+  if (blocks && skinny_q_supported(g, 1)) {
+    g.W = nullptr;
+    for (int i = 0; i < 3; ++i) g.wq[i] = r.t[i < r.n ? i : 0]->d;
+    g.wq_type = r.t[0]->ttype;
+    g.wq_rows = (int)(r.t[0]->n / (size_t)r.t[0]->cols);
+    g.wq_gamma = gamma;
+    HIP_TRY(gemm_skinny_q(g, c.s));
+    return CRISPY_OK;
+  }
+  const void* o = nullptr;
+  const int e = dq(h, r, half, gamma, c.s, &o);
+  if (e != CRISPY_OK) return e;
+  g.W = reinterpret_cast<const float*>(o);
+  HIP_TRY(gemm_f32_nt(g, 1, c.s));
+  return CRISPY_OK;
+}
+
+// A layer of a step of 1 .. GEMV_MAX_M rows of a catalog-width model: matrix-vector products (whisper_dec_gemv.hip), 7 launches
+int layer_gemv(StepCtx& c, size_t l) {
+  crispy_asr* h = c.h;
+  hipStream_t s = c.s;
+  const DecLayer& L = h->dec[l];
+  const int dt = c.dt, batch = c.rows;
+  _Float16* kvh = reinterpret_cast<_Float16*>(h->d_selfkv) + l * (size_t)c.clips * c.C * 2 * dt;
+  _Float16* hid = reinterpret_cast<_Float16*>(h->d_dh);                  // GELU'd hidden units as the f16 fc2 multiplies
+  auto weights = [&](GemvArgs& a, const void* dense16, const QRef& r) {
+    if (!h->resident) { a.w16 = reinterpret_cast<const _Float16*>(dense16); return; }
+    for (int i = 0; i < 3; ++i) a.wq[i] = r.t[i < r.n ? i : 0]->d;
+    a.wq_type = r.t[0]->ttype;
+    a.wq_rows = (int)(r.t[0]->n / (size_t)r.t[0]->cols);
+  };
+  auto residual_proj = [&](const float* x32, const _Float16* x16, long ldx, const void* dense16, const QRef& r, const float* bias, int K) -> int {
+    GemvArgs a{};
+    a.x = x32; a.x16 = x16; a.ldx = ldx; weights(a, dense16, r); a.bias = bias;
+    a.out = h->d_dx; a.res = h->d_dx; a.ldo = dt; a.M = batch; a.N = dt; a.K = K;
+    HIP_TRY(gemv_dec(a, GEMV_RES, s));
+    return CRISPY_OK;
+  };
+  int rc;
+  c.self_rows.attn16 = h->dec_attn16 ? 1 : 0;
+  {
+    GemvArgs a{};
+    a.x = h->d_dx; a.ldx = dt; a.ln_g = L.ln1_w; a.ln_b = L.ln1_b; weights(a, L.qkv_wh, L.r_qkv); a.bias = L.qkv_b;
+    a.out = h->d_dq; a.ldo = dt; a.kv = kvh; a.kv_row_stride = (long)c.C * 2 * dt; a.pos = c.pos; a.pos_dev = c.pos_dev;
+    a.M = batch; a.N = 3 * dt; a.K = dt;
+    HIP_TRY(gemv_dec(a, GEMV_QKV, s));
+  }
+  HIP_TRY(attn_decoder_kv16(h->d_dq, dt, kvh, (long)c.C * 2 * dt, 2L * dt, 64, 0, dt, c.dev_pos ? 1 : c.pos + 1, c.pos_dev, h->d_datt, dt,
+                            batch, c.H, s, h->dec_max_keys, c.self_rows));
+  if ((rc = residual_proj(h->d_datt, nullptr, dt, L.out_wh, L.r_out, L.out_b, dt)) != CRISPY_OK) return rc;
+  if (!c.cross_rows.attn16 && h->d_gvpart && c.Tn <= XA_PARTS * 16 * XA_SLOTS * 8) {
+    // [LayerNorm -> cross q of a head -> attention over a quarter of the keys] in one launch of heads x XA_PARTS workgroups,
+    // the partial soft-maxes merged by the output projection's prologue: two launches where the step had three
+    XattnArgs xa{};
+    xa.x = h->d_dx; xa.ldx = dt; xa.ln_g = L.lnx_w; xa.ln_b = L.lnx_b; xa.bq = L.xq_b;
+    if (L.xq_wh) xa.w16 = reinterpret_cast<const _Float16*>(L.xq_wh);      // (a resident model keeps this one matrix as f16 too: finalize_resident)
+    else { xa.wq = L.r_xq.t[0]->d; xa.wq_type = L.r_xq.t[0]->ttype; }
+    xa.xkv = reinterpret_cast<const _Float16*>(h->d_xkv_h) + l * c.xclips * c.Tn * 2 * dt; xa.clip_stride = (long)c.Tn * 2 * dt;
+    xa.n_keys = c.Tn; xa.group = c.xg; xa.part = h->d_gvpart; xa.rows = batch; xa.D = dt;
+    HIP_TRY(gemv_xattn(xa, s));
+    GemvArgs a{};
+    a.xpart = h->d_gvpart; weights(a, L.xout_wh, L.r_xout); a.bias = L.xout_b;
+    a.out = h->d_dx; a.res = h->d_dx; a.ldo = dt; a.M = batch; a.N = dt; a.K = dt;
+    HIP_TRY(gemv_dec(a, GEMV_RES_MERGE, s));
+  } else {
+    {
+      GemvArgs a{};
+      a.x = h->d_dx; a.ldx = dt; a.ln_g = L.lnx_w; a.ln_b = L.lnx_b; weights(a, L.xq_wh, L.r_xq); a.bias = L.xq_b;
+      a.out = h->d_dq; a.ldo = dt; a.M = batch; a.N = dt; a.K = dt;
+      HIP_TRY(gemv_dec(a, GEMV_F32, s));
+    }
+    HIP_TRY(attn_decoder_kv16(h->d_dq, dt, reinterpret_cast<const char*>(h->d_xkv_h) + l * c.xclips * c.Tn * 2 * dt * 2,
+                              (long)c.Tn * 2 * dt, 64, 64L * c.Tn, 0, (long)c.Tn * dt, c.Tn, nullptr, h->d_datt, dt, batch, c.H, s, 0,
+                              c.cross_rows));
+    if ((rc = residual_proj(h->d_datt, nullptr, dt, L.xout_wh, L.r_xout, L.xout_b, dt)) != CRISPY_OK) return rc;
+  }
+  {
+    GemvArgs a{};
+    a.x = h->d_dx; a.ldx = dt; a.ln_g = L.ln2_w; a.ln_b = L.ln2_b; weights(a, L.fc1_wh, L.r_fc1); a.bias = L.fc1_b;
+    a.out16 = hid; a.ldo = 4L * dt; a.M = batch; a.N = 4 * dt; a.K = dt;
+    HIP_TRY(gemv_dec(a, GEMV_GELU16, s));
+  }
+  return residual_proj(nullptr, hid, 4L * dt, L.fc2_wh, L.r_fc2, L.fc2_b, 4 * dt);
+}
+
+// causal self-attention block of a layer on the skinny / tiled kernels: k | v of this position go straight into the cache row
+int layer_self_block(StepCtx& c, size_t l) {
+  crispy_asr* h = c.h;
+  hipStream_t s = c.s;
+  const DecLayer& L = h->dec[l];
+  const int dt = c.dt, C = c.C, batch = c.rows, pos = c.pos, P = c.P, clips = c.clips;
+  const bool dev_pos = c.dev_pos;
+  float* selfkv = h->d_selfkv + l * (size_t)clips * C * 2 * dt;
+  float* kv_dst = selfkv + (dev_pos ? 0 : (size_t)pos * 2 * dt);
+  // mode 1: the self K|V cache is f16, as whisper.cpp's kv_self is (it aliases the f32 cache: every decode call
+  // starts with its own prefill); the projection stores halves, the attention requests all its keys up front
+  const bool kv16 = self_kv_half(h, batch);
+  _Float16* selfkv_h = reinterpret_cast<_Float16*>(h->d_selfkv) + l * (size_t)clips * C * 2 * dt;
+  c.self_rows.attn16 = kv16 && h->dec_attn16 ? 1 : 0;
+  int qrc = CRISPY_OK;
+  if (c.fold) {
+    // precision modes 1 / 2: LayerNorm as a launch of its own, its output rounded to f16 on the way into the f16 matrix cores
+    // against f16 weights (ggml's mul_mat arithmetic for these products too); mode 0: LayerNorm folded in, f32 operands
+    const bool ln16 = h->dec_ln16;
+    if (ln16) HIP_TRY(layernorm_f32(h->d_dx, L.ln1_w, L.ln1_b, h->d_dxn, batch, dt, s));
+    GemmArgs g = gemm(ln16 ? h->d_dxn : h->d_dx, dt, nullptr, dt, h->d_dq, dt, ln16 ? L.qkv_b : nullptr, batch, 3 * dt, dt);
+    if (!ln16) { g.ln_s = L.qkv_ls; g.ln_c = L.qkv_lc; }
+    g.C2 = kv_dst; g.ldc2 = (long)C * 2 * dt; g.n_split = dt;
+    if (kv16) { g.C2 = reinterpret_cast<float*>(selfkv_h + (dev_pos ? 0 : (size_t)pos * 2 * dt)); g.c2_half = 1; }
+    if (dev_pos) { g.c_off_dev = h->d_counters; g.c_off_scale = 2L * dt; }
+    // P rows per clip: k | v of row (clip, j) belongs in cache row (clip, pos + j) -- one clip's P rows are adjacent there,
+    // but clips are C rows apart.  One clip: the rows land directly (row stride 2 dt).  Several: staged in the MLP's
+    // hidden buffer (free until fc1) and scattered by one strided copy.
+    const bool stage_kv = P > 1 && clips > 1;
+    if (P > 1) { g.ldc2 = 2L * dt; if (stage_kv) g.C2 = h->d_dh; }
+    if ((qrc = step_proj(c, g, L.qkv_lw, L.qkv_wh, L.r_qkv, ln16 ? nullptr : L.ln1_w, ln16)) != CRISPY_OK) return qrc;
+    if (stage_kv) {
+      const size_t esz = kv16 ? 2 : 4;
+      void* dst = kv16 ? static_cast<void*>(selfkv_h + (size_t)pos * 2 * dt) : static_cast<void*>(selfkv + (size_t)pos * 2 * dt);
+      HIP_TRY(hipMemcpy2DAsync(dst, (size_t)C * 2 * dt * esz, h->d_dh, (size_t)P * 2 * dt * esz, (size_t)P * 2 * dt * esz,
+                               (size_t)clips, hipMemcpyDeviceToDevice, s));
+    }
+  } else {
+    HIP_TRY(layernorm_f32(h->d_dx, L.ln1_w, L.ln1_b, h->d_dxn, batch, dt, s));
+    const float* qkv_w = step_w32(c, L.qkv_w, L.r_qkv, nullptr, &qrc);
+    if (qrc != CRISPY_OK) return qrc;
+    HIP_TRY(gemm_f32_nt(gemm(h->d_dxn, dt, qkv_w, dt, h->d_dq, dt, L.qkv_b, batch, dt, dt), 1, s));
+    GemmArgs g = gemm(h->d_dxn, dt, qkv_w + (size_t)dt * dt, dt, kv_dst, (long)C * 2 * dt, L.qkv_b + dt, batch, 2 * dt, dt);
+    if (dev_pos) { g.c_off_dev = h->d_counters; g.c_off_scale = 2L * dt; }
+    HIP_TRY(gemm_f32_nt(g, 1, s));
+  }
+  if (kv16)
+    HIP_TRY(attn_decoder_kv16(h->d_dq, dt, selfkv_h, (long)C * 2 * dt, 2L * dt, 64, 0, dt, dev_pos ? 1 : pos + 1, c.pos_dev,
+                              h->d_datt, dt, batch, c.H, s, h->dec_max_keys, c.self_rows));
+  else
+    HIP_TRY(attn_decoder_f32(h->d_dq, dt, selfkv, (long)C * 2 * dt, 2L * dt, 64, 0, dt, dev_pos ? 1 : pos + 1, c.pos_dev,
+                             h->d_datt, dt, batch, c.H, s, c.self_rows));
+  // mode 1: the projections that have no LayerNorm in front (attention outputs, the MLP's second GEMM) in ggml's
+  // arithmetic -- f16 weights, the f32 activation rounded to f16 on the way into the matrix cores, f32 accumulation
+  const bool wh = c.fold && h->enc_precision == 1 && (L.out_wh || h->resident);
+  GemmArgs g = gemm(h->d_datt, dt, L.out_w, dt, h->d_dx, dt, L.out_b, batch, dt, dt);
+  g.residual = h->d_dx; g.ldr = dt;
+  return step_proj(c, g, L.out_w, L.out_wh, L.r_out, nullptr, wh);
+}
+
+// cross-attention block over the encoder output (K | V precomputed once per clip), then the MLP
+int layer_cross_and_mlp(StepCtx& c, size_t l) {
+  crispy_asr* h = c.h;
+  hipStream_t s = c.s;
+  const DecLayer& L = h->dec[l];
+  const int dt = c.dt, Tn = c.Tn, batch = c.rows;
+  const float* xkv = h->d_xkv + l * c.xclips * Tn * 2 * dt;
+  const bool ln16 = h->dec_ln16;
+  const bool wh = c.fold && h->enc_precision == 1 && (L.out_wh || h->resident);
+  int qrc = CRISPY_OK;
+  if (c.fold) {
+    if (ln16) HIP_TRY(layernorm_f32(h->d_dx, L.lnx_w, L.lnx_b, h->d_dxn, batch, dt, s));
+    GemmArgs g = gemm(ln16 ? h->d_dxn : h->d_dx, dt, nullptr, dt, h->d_dq, dt, ln16 ? L.xq_b : nullptr, batch, dt, dt);
+    if (!ln16) { g.ln_s = L.xq_ls; g.ln_c = L.xq_lc; }
+    if ((qrc = step_proj(c, g, L.xq_lw, L.xq_wh, L.r_xq, ln16 ? nullptr : L.lnx_w, ln16)) != CRISPY_OK) return qrc;
+  } else {
+    HIP_TRY(layernorm_f32(h->d_dx, L.lnx_w, L.lnx_b, h->d_dxn, batch, dt, s));
+    const float* xq_w = step_w32(c, L.xq_w, L.r_xq, nullptr, &qrc);
+    if (qrc != CRISPY_OK) return qrc;
+    HIP_TRY(gemm_f32_nt(gemm(h->d_dxn, dt, xq_w, dt, h->d_dq, dt, L.xq_b, batch, dt, dt), 1, s));
+  }
+  if (h->enc_precision == 1)
+    HIP_TRY(attn_decoder_kv16(h->d_dq, dt, reinterpret_cast<const char*>(h->d_xkv_h) + l * c.xclips * Tn * 2 * dt * 2,
+                              (long)Tn * 2 * dt, 64, 64L * Tn, 0, (long)Tn * dt, Tn, nullptr, h->d_datt, dt, batch, c.H, s, 0,
+                              c.cross_rows));
+  else
+    HIP_TRY(attn_decoder_f32(h->d_dq, dt, xkv, (long)Tn * 2 * dt, 64, 64L * Tn, 0, (long)Tn * dt, Tn, nullptr, h->d_datt, dt,
+                             batch, c.H, s, c.cross_rows));
+  {
+    GemmArgs g = gemm(h->d_datt, dt, L.xout_w, dt, h->d_dx, dt, L.xout_b, batch, dt, dt);
+    g.residual = h->d_dx; g.ldr = dt;
+    if ((qrc = step_proj(c, g, L.xout_w, L.xout_wh, L.r_xout, nullptr, wh)) != CRISPY_OK) return qrc;
+  }
+  // MLP
+  if (c.fold) {
+    if (ln16) HIP_TRY(layernorm_f32(h->d_dx, L.ln2_w, L.ln2_b, h->d_dxn, batch, dt, s));
+    GemmArgs g = gemm(ln16 ? h->d_dxn : h->d_dx, dt, nullptr, dt, h->d_dh, 4L * dt, ln16 ? L.fc1_b : nullptr, batch, 4 * dt, dt);
+    if (!ln16) { g.ln_s = L.fc1_ls; g.ln_c = L.fc1_lc; }
+    g.gelu = h->enc_precision == 1 ? 2 : 1;      // mode 1: ggml's GELU (asr_common.h: gelu_ggml)
+    if ((qrc = step_proj(c, g, L.fc1_lw, L.fc1_wh, L.r_fc1, ln16 ? nullptr : L.ln2_w, ln16)) != CRISPY_OK) return qrc;
+  } else {
+    HIP_TRY(layernorm_f32(h->d_dx, L.ln2_w, L.ln2_b, h->d_dxn, batch, dt, s));
+    GemmArgs g = gemm(h->d_dxn, dt, step_w32(c, L.fc1_w, L.r_fc1, nullptr, &qrc), dt, h->d_dh, 4L * dt, L.fc1_b, batch, 4 * dt, dt);
+    if (qrc != CRISPY_OK) return qrc;
+    g.gelu = h->enc_precision == 1 ? 2 : 1;
+    HIP_TRY(gemm_f32_nt(g, 1, s));
+  }
+  GemmArgs g = gemm(h->d_dh, 4L * dt, L.fc2_w, 4L * dt, h->d_dx, dt, L.fc2_b, batch, dt, 4 * dt);
+  g.residual = h->d_dx; g.ldr = dt;
+  return step_proj(c, g, L.fc2_w, L.fc2_wh, L.r_fc2, nullptr, wh);
+}
+
 // one decoder step for all clips: token ids in h->d_tok; leaves logits in h->d_logits.
 // dev_pos = false: the position is the host value `pos` (prompt tokens).
 // dev_pos = true : the position is read from h->d_counters[0] by the kernels, so the identical launch
@@ -218,26 +453,27 @@ bool gemv_step_ok(const crispy_asr* h, int rows) {
 // own key count), so the result is bit-identical to P steps -- at the cost of one.
 int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logits, hipStream_t s, bool embedded = false,
                  int P = 1) {
-  const int dt = h->hp.n_text_state, H = h->hp.n_text_head, Tn = h->hp.n_audio_ctx, C = h->hp.n_text_ctx;
-  const int* pos_dev = dev_pos ? h->d_counters : nullptr;
+  const int dt = h->hp.n_text_state, Tn = h->hp.n_audio_ctx;
   const int clips = batch;
   if (P < 1) P = 1;
   // a generated token (its embedding written by the pick, its position on the device): the fused step kernels
   if (P == 1 && dev_pos && embedded && want_logits && fused_step_ok(h, clips)) return decoder_step_fused(h, clips, s);
-  batch = clips * P;                   // rows of this step
-  // <= SKINNY_MAX_M clips: the projections run on the skinny kernel (row blocks of 32 clips), which folds the preceding LayerNorm in and writes q and
-  // k|v of the self-attention block from one launch (17 launches fewer per step on Whisper-tiny)
-  const bool fold = batch <= SKINNY_MAX_M && dt % 128 == 0;
-  if (P > 1 && (!fold || dev_pos || embedded))
+  StepCtx c{};
+  c.h = h; c.s = s; c.clips = clips; c.P = P; c.rows = clips * P; c.pos = pos; c.dev_pos = dev_pos;
+  c.pos_dev = dev_pos ? h->d_counters : nullptr;
+  c.dt = dt; c.H = h->hp.n_text_head; c.Tn = Tn; c.C = h->hp.n_text_ctx;
+  // <= SKINNY_MAX_M rows: the projections run on the skinny kernel (row blocks of 32), which writes q and k|v of the
+  // self-attention block from one launch and, in mode 0, folds the preceding LayerNorm in
+  c.fold = c.rows <= SKINNY_MAX_M && dt % 128 == 0;
+  if (P > 1 && (!c.fold || dev_pos || embedded))
     return fail(CRISPY_ERR_INVALID_ARG, "decoder_step: a multi-position step needs the folded path and a host position");
-  AttnRows self_rows, cross_rows;
-  self_rows.group = P; self_rows.key_step = P > 1 ? 1 : 0;
-  self_rows.key_off = h->cur_row_off;        // left-padded prompts (decode_ts): every clip's keys start at its own cache row
-  const int xg = h->cur_xgroup;              // sequences (rows with a self K|V cache of their own) per audio clip
-  const size_t xclips = (size_t)(clips / xg);
-  cross_rows.group = P * xg;
+  c.self_rows.group = P; c.self_rows.key_step = P > 1 ? 1 : 0;
+  c.self_rows.key_off = h->cur_row_off;      // left-padded prompts (decode_ts): every clip's keys start at its own cache row
+  c.xg = h->cur_xgroup;
+  c.xclips = (size_t)(clips / c.xg);
+  c.cross_rows.group = P * c.xg;
   // precision mode 2: q and the normalised probabilities rounded to f16 inside the attentions over the f16 caches
-  cross_rows.attn16 = h->dec_attn16 && h->enc_precision == 1 ? 1 : 0;
+  c.cross_rows.attn16 = h->dec_attn16 && h->enc_precision == 1 ? 1 : 0;
   // The cross K|V of all layers and clips against the 256 MB Infinity Cache: while it fits, it is what stays cached from
   // step to step (plain loads: 16 tiny clips = 147 MB, 6.8 ms per call against 7.0 non-temporal); beyond that it is a
   // one-pass stream that only evicts the decoder's weights from the L2s, and is requested non-temporally
@@ -245,217 +481,24 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
   // (not in a multi-position prompt step: the P rows of a clip read the same K|V one after the other, and the repeats are
   // served by the Infinity Cache only if the first read allocates there: 2.06 vs 2.18 ms for the prompt of 128 clips)
   static const bool prompt_nt = dev_env("CRISPY_XKV_PROMPT_NT") != nullptr;      // developer A/B (tools/ab_prompt_nt.sh)
-  cross_rows.stream_kv = (P == 1 || prompt_nt) && xclips * h->dec.size() * Tn * 2 * dt * (h->enc_precision == 1 ? 2 : 4) > ((size_t)256 << 20) ? 1 : 0;
+  c.cross_rows.stream_kv = (P == 1 || prompt_nt) && c.xclips * h->dec.size() * Tn * 2 * dt * (h->enc_precision == 1 ? 2 : 4) > ((size_t)256 << 20) ? 1 : 0;
   if (!embedded) {    // (a fused pick has written the residual stream already)
     if (h->resident)
-      HIP_TRY(embed_tokens_q(h->d_tok, h->q_tok_emb->d, h->q_tok_emb->ttype, h->dec_pos, pos, pos_dev, h->d_dx, batch, dt, s, P,
+      HIP_TRY(embed_tokens_q(h->d_tok, h->q_tok_emb->d, h->q_tok_emb->ttype, h->dec_pos, pos, c.pos_dev, h->d_dx, c.rows, dt, s, P,
                              h->cur_row_off));
     else
-      HIP_TRY(embed_tokens_f32(h->d_tok, h->tok_emb, h->dec_pos, pos, pos_dev, h->d_dx, batch, dt, s, P, h->cur_row_off));
+      HIP_TRY(embed_tokens_f32(h->d_tok, h->tok_emb, h->dec_pos, pos, c.pos_dev, h->d_dx, c.rows, dt, s, P, h->cur_row_off));
   }
-  // resident quantised model: every weight operand is de-quantised into the scratch slot in front of its product --
-  // f32 x gamma for the LayerNorm-folded projections (fold_ln's W' = W . diag(gamma), element for element), f16 for the
-  // plain ones, plain f32 on the un-folded path of very large batches
-  int qrc = CRISPY_OK;
-  auto w32 = [&](const float* dense, const QRef& r, const float* gamma) -> const float* {     // (un-folded path only)
-    if (!h->resident) return dense;
-    const void* o = nullptr;
-    const int e = dq(h, r, false, gamma, s, &o);
-    if (e != CRISPY_OK) qrc = e;
-    return reinterpret_cast<const float*>(o);
-  };
-  // One projection of the folded path.  Dense model: W = the f32 (gamma-folded) tensor or its f16 copy.  Resident model:
-  // the skinny kernel reads the ggml blocks itself and de-quantises in registers (gemm_skinny_q); shapes it has no form
-  // for (and dense tensors of a mixed file) go through the scratch slot and the dense kernel.
-  auto proj = [&](GemmArgs g, const float* dense32, const void* dense16, const QRef& r, const float* gamma, bool half) -> int {
-    g.w_half = half ? 1 : 0;
-    if (!h->resident) {
-      g.W = half ? reinterpret_cast<const float*>(dense16) : dense32;
-      HIP_TRY(gemm_f32_nt(g, 1, s));
-      return CRISPY_OK;
-    }
-    bool blocks = r.n > 0 && r.t[0]->ttype != QT_F32;
-    for (int i = 1; i < r.n; ++i) blocks = blocks && r.t[i]->ttype == r.t[0]->ttype && r.t[i]->n == r.t[0]->n;
-    if (blocks && skinny_q_supported(g, 1)) {
-      g.W = nullptr;
-      for (int i = 0; i < 3; ++i) g.wq[i] = r.t[i < r.n ? i : 0]->d;
-      g.wq_type = r.t[0]->ttype;
-      g.wq_rows = (int)(r.t[0]->n / (size_t)r.t[0]->cols);
-      g.wq_gamma = gamma;
-      HIP_TRY(gemm_skinny_q(g, s));
-      return CRISPY_OK;
-    }
-    const void* o = nullptr;
-    const int e = dq(h, r, half, gamma, s, &o);
-    if (e != CRISPY_OK) return e;
-    g.W = reinterpret_cast<const float*>(o);
-    HIP_TRY(gemm_f32_nt(g, 1, s));
-    return CRISPY_OK;
-  };
-  const bool use_gemv = P == 1 && gemv_step_ok(h, batch);
+  const bool use_gemv = P == 1 && gemv_step_ok(h, c.rows);
   for (size_t l = 0; l < h->dec.size(); ++l) {
-    const DecLayer& L = h->dec[l];
-    float* selfkv = h->d_selfkv + l * (size_t)clips * C * 2 * dt;
-    const float* xkv = h->d_xkv + l * xclips * Tn * 2 * dt;
+    int rc;
     if (use_gemv) {
-      _Float16* kvh = reinterpret_cast<_Float16*>(h->d_selfkv) + l * (size_t)clips * C * 2 * dt;
-      _Float16* hid = reinterpret_cast<_Float16*>(h->d_dh);                  // GELU'd hidden units as the f16 fc2 multiplies
-      auto weights = [&](GemvArgs& a, const void* dense16, const QRef& r) {
-        if (!h->resident) { a.w16 = reinterpret_cast<const _Float16*>(dense16); return; }
-        for (int i = 0; i < 3; ++i) a.wq[i] = r.t[i < r.n ? i : 0]->d;
-        a.wq_type = r.t[0]->ttype;
-        a.wq_rows = (int)(r.t[0]->n / (size_t)r.t[0]->cols);
-      };
-      self_rows.attn16 = h->dec_attn16 ? 1 : 0;
-      {
-        GemvArgs a{};
-        a.x = h->d_dx; a.ldx = dt; a.ln_g = L.ln1_w; a.ln_b = L.ln1_b; weights(a, L.qkv_wh, L.r_qkv); a.bias = L.qkv_b;
-        a.out = h->d_dq; a.ldo = dt; a.kv = kvh; a.kv_row_stride = (long)C * 2 * dt; a.pos = pos; a.pos_dev = pos_dev;
-        a.M = batch; a.N = 3 * dt; a.K = dt;
-        HIP_TRY(gemv_dec(a, GEMV_QKV, s));
-      }
-      HIP_TRY(attn_decoder_kv16(h->d_dq, dt, kvh, (long)C * 2 * dt, 2L * dt, 64, 0, dt, dev_pos ? 1 : pos + 1, pos_dev, h->d_datt, dt,
-                                batch, H, s, h->dec_max_keys, self_rows));
-      auto residual_proj = [&](const float* x32, const _Float16* x16, long ldx, const void* dense16, const QRef& r, const float* bias, int K) -> int {
-        GemvArgs a{};
-        a.x = x32; a.x16 = x16; a.ldx = ldx; weights(a, dense16, r); a.bias = bias;
-        a.out = h->d_dx; a.res = h->d_dx; a.ldo = dt; a.M = batch; a.N = dt; a.K = K;
-        HIP_TRY(gemv_dec(a, GEMV_RES, s));
-        return CRISPY_OK;
-      };
-      if ((qrc = residual_proj(h->d_datt, nullptr, dt, L.out_wh, L.r_out, L.out_b, dt)) != CRISPY_OK) return qrc;
-      if (!cross_rows.attn16 && h->d_gvpart && Tn <= XA_PARTS * 16 * XA_SLOTS * 8) {
-        // [LayerNorm -> cross q of a head -> attention over a quarter of the keys] in one launch of heads x XA_PARTS workgroups,
-        // the partial soft-maxes merged by the output projection's prologue: two launches where the step had three
-        XattnArgs xa{};
-        xa.x = h->d_dx; xa.ldx = dt; xa.ln_g = L.lnx_w; xa.ln_b = L.lnx_b; xa.bq = L.xq_b;
-        if (L.xq_wh) xa.w16 = reinterpret_cast<const _Float16*>(L.xq_wh);      // (a resident model keeps this one matrix as f16 too: finalize_resident)
-        else { xa.wq = L.r_xq.t[0]->d; xa.wq_type = L.r_xq.t[0]->ttype; }
-        xa.xkv = reinterpret_cast<const _Float16*>(h->d_xkv_h) + l * xclips * Tn * 2 * dt; xa.clip_stride = (long)Tn * 2 * dt;
-        xa.n_keys = Tn; xa.group = xg; xa.part = h->d_gvpart; xa.rows = batch; xa.D = dt;
-        HIP_TRY(gemv_xattn(xa, s));
-        GemvArgs a{};
-        a.xpart = h->d_gvpart; weights(a, L.xout_wh, L.r_xout); a.bias = L.xout_b;
-        a.out = h->d_dx; a.res = h->d_dx; a.ldo = dt; a.M = batch; a.N = dt; a.K = dt;
-        HIP_TRY(gemv_dec(a, GEMV_RES_MERGE, s));
-      } else {
-        {
-          GemvArgs a{};
-          a.x = h->d_dx; a.ldx = dt; a.ln_g = L.lnx_w; a.ln_b = L.lnx_b; weights(a, L.xq_wh, L.r_xq); a.bias = L.xq_b;
-          a.out = h->d_dq; a.ldo = dt; a.M = batch; a.N = dt; a.K = dt;
-          HIP_TRY(gemv_dec(a, GEMV_F32, s));
-        }
-        HIP_TRY(attn_decoder_kv16(h->d_dq, dt, reinterpret_cast<const char*>(h->d_xkv_h) + l * xclips * Tn * 2 * dt * 2,
-                                  (long)Tn * 2 * dt, 64, 64L * Tn, 0, (long)Tn * dt, Tn, nullptr, h->d_datt, dt, batch, H, s, 0,
-                                  cross_rows));
-        if ((qrc = residual_proj(h->d_datt, nullptr, dt, L.xout_wh, L.r_xout, L.xout_b, dt)) != CRISPY_OK) return qrc;
-      }
-      {
-        GemvArgs a{};
-        a.x = h->d_dx; a.ldx = dt; a.ln_g = L.ln2_w; a.ln_b = L.ln2_b; weights(a, L.fc1_wh, L.r_fc1); a.bias = L.fc1_b;
-        a.out16 = hid; a.ldo = 4L * dt; a.M = batch; a.N = 4 * dt; a.K = dt;
-        HIP_TRY(gemv_dec(a, GEMV_GELU16, s));
-      }
-      if ((qrc = residual_proj(nullptr, hid, 4L * dt, L.fc2_wh, L.r_fc2, L.fc2_b, 4 * dt)) != CRISPY_OK) return qrc;
-      continue;
-    }
-    // causal self-attention against the cache; k | v of this position go straight into the cache row (b, pos)
-    float* kv_dst = selfkv + (dev_pos ? 0 : (size_t)pos * 2 * dt);
-    // mode 1: the self K|V cache is f16, as whisper.cpp's kv_self is (it aliases the f32 cache: every decode call
-    // starts with its own prefill); the projection stores halves, the attention requests all its keys up front
-    const bool kv16 = self_kv_half(h, batch);
-    _Float16* selfkv_h = reinterpret_cast<_Float16*>(h->d_selfkv) + l * (size_t)clips * C * 2 * dt;
-    self_rows.attn16 = kv16 && h->dec_attn16 ? 1 : 0;
-    if (fold) {
-      // precision mode 2: LayerNorm as a launch of its own, its output rounded to f16 on the way into the f16 matrix cores
-      // against f16 weights (ggml's mul_mat arithmetic for these products too); modes 0 / 1: LayerNorm folded in, f32 operands
-      const bool ln16 = h->dec_ln16;
-      if (ln16) HIP_TRY(layernorm_f32(h->d_dx, L.ln1_w, L.ln1_b, h->d_dxn, batch, dt, s));
-      GemmArgs g = gemm(ln16 ? h->d_dxn : h->d_dx, dt, nullptr, dt, h->d_dq, dt, ln16 ? L.qkv_b : nullptr, batch, 3 * dt, dt);
-      if (!ln16) { g.ln_s = L.qkv_ls; g.ln_c = L.qkv_lc; }
-      g.C2 = kv_dst; g.ldc2 = (long)C * 2 * dt; g.n_split = dt;
-      if (kv16) { g.C2 = reinterpret_cast<float*>(selfkv_h + (dev_pos ? 0 : (size_t)pos * 2 * dt)); g.c2_half = 1; }
-      if (dev_pos) { g.c_off_dev = h->d_counters; g.c_off_scale = 2L * dt; }
-      // P rows per clip: k | v of row (clip, j) belongs in cache row (clip, pos + j) -- one clip's P rows are adjacent there,
-      // but clips are C rows apart.  One clip: the rows land directly (row stride 2 dt).  Several: staged in the MLP's
-      // hidden buffer (free until fc1) and scattered by one strided copy.
-      const bool stage_kv = P > 1 && clips > 1;
-      if (P > 1) { g.ldc2 = 2L * dt; if (stage_kv) g.C2 = h->d_dh; }
-      if ((qrc = proj(g, L.qkv_lw, L.qkv_wh, L.r_qkv, ln16 ? nullptr : L.ln1_w, ln16)) != CRISPY_OK) return qrc;
-      if (stage_kv) {
-        const size_t esz = kv16 ? 2 : 4;
-        void* dst = kv16 ? static_cast<void*>(selfkv_h + (size_t)pos * 2 * dt) : static_cast<void*>(selfkv + (size_t)pos * 2 * dt);
-        HIP_TRY(hipMemcpy2DAsync(dst, (size_t)C * 2 * dt * esz, h->d_dh, (size_t)P * 2 * dt * esz, (size_t)P * 2 * dt * esz,
-                                 (size_t)clips, hipMemcpyDeviceToDevice, s));
-      }
+      rc = layer_gemv(c, l);
     } else {
-      HIP_TRY(layernorm_f32(h->d_dx, L.ln1_w, L.ln1_b, h->d_dxn, batch, dt, s));
-      const float* qkv_w = w32(L.qkv_w, L.r_qkv, nullptr);
-      if (qrc != CRISPY_OK) return qrc;
-      HIP_TRY(gemm_f32_nt(gemm(h->d_dxn, dt, qkv_w, dt, h->d_dq, dt, L.qkv_b, batch, dt, dt), 1, s));
-      GemmArgs g = gemm(h->d_dxn, dt, qkv_w + (size_t)dt * dt, dt, kv_dst, (long)C * 2 * dt, L.qkv_b + dt, batch, 2 * dt, dt);
-      if (dev_pos) { g.c_off_dev = h->d_counters; g.c_off_scale = 2L * dt; }
-      HIP_TRY(gemm_f32_nt(g, 1, s));
+      rc = layer_self_block(c, l);
+      if (rc == CRISPY_OK) rc = layer_cross_and_mlp(c, l);
     }
-    if (kv16)
-      HIP_TRY(attn_decoder_kv16(h->d_dq, dt, selfkv_h, (long)C * 2 * dt, 2L * dt, 64, 0, dt, dev_pos ? 1 : pos + 1, pos_dev,
-                                h->d_datt, dt, batch, H, s, h->dec_max_keys, self_rows));
-    else
-      HIP_TRY(attn_decoder_f32(h->d_dq, dt, selfkv, (long)C * 2 * dt, 2L * dt, 64, 0, dt, dev_pos ? 1 : pos + 1, pos_dev,
-                               h->d_datt, dt, batch, H, s, self_rows));
-    // mode 1: the projections that have no LayerNorm in front (attention outputs, the MLP's second GEMM) in ggml's
-    // arithmetic -- f16 weights, the f32 activation rounded to f16 on the way into the matrix cores, f32 accumulation
-    const bool wh = fold && h->enc_precision == 1 && (L.out_wh || h->resident);
-    {
-      GemmArgs g = gemm(h->d_datt, dt, L.out_w, dt, h->d_dx, dt, L.out_b, batch, dt, dt);
-      g.residual = h->d_dx; g.ldr = dt;
-      if ((qrc = proj(g, L.out_w, L.out_wh, L.r_out, nullptr, wh)) != CRISPY_OK) return qrc;
-    }
-    // cross-attention over the encoder output (K | V precomputed once per clip)
-    if (fold) {
-      const bool ln16 = h->dec_ln16;
-      if (ln16) HIP_TRY(layernorm_f32(h->d_dx, L.lnx_w, L.lnx_b, h->d_dxn, batch, dt, s));
-      GemmArgs g = gemm(ln16 ? h->d_dxn : h->d_dx, dt, nullptr, dt, h->d_dq, dt, ln16 ? L.xq_b : nullptr, batch, dt, dt);
-      if (!ln16) { g.ln_s = L.xq_ls; g.ln_c = L.xq_lc; }
-      if ((qrc = proj(g, L.xq_lw, L.xq_wh, L.r_xq, ln16 ? nullptr : L.lnx_w, ln16)) != CRISPY_OK) return qrc;
-    } else {
-      HIP_TRY(layernorm_f32(h->d_dx, L.lnx_w, L.lnx_b, h->d_dxn, batch, dt, s));
-      const float* xq_w = w32(L.xq_w, L.r_xq, nullptr);
-      if (qrc != CRISPY_OK) return qrc;
-      HIP_TRY(gemm_f32_nt(gemm(h->d_dxn, dt, xq_w, dt, h->d_dq, dt, L.xq_b, batch, dt, dt), 1, s));
-    }
-    if (h->enc_precision == 1)
-      HIP_TRY(attn_decoder_kv16(h->d_dq, dt, reinterpret_cast<const char*>(h->d_xkv_h) + l * xclips * Tn * 2 * dt * 2,
-                                (long)Tn * 2 * dt, 64, 64L * Tn, 0, (long)Tn * dt, Tn, nullptr, h->d_datt, dt, batch, H, s, 0,
-                                cross_rows));
-    else
-      HIP_TRY(attn_decoder_f32(h->d_dq, dt, xkv, (long)Tn * 2 * dt, 64, 64L * Tn, 0, (long)Tn * dt, Tn, nullptr, h->d_datt, dt,
-                               batch, H, s, cross_rows));
-    {
-      GemmArgs g = gemm(h->d_datt, dt, L.xout_w, dt, h->d_dx, dt, L.xout_b, batch, dt, dt);
-      g.residual = h->d_dx; g.ldr = dt;
-      if ((qrc = proj(g, L.xout_w, L.xout_wh, L.r_xout, nullptr, wh)) != CRISPY_OK) return qrc;
-    }
-    // MLP
-    if (fold) {
-      const bool ln16 = h->dec_ln16;
-      if (ln16) HIP_TRY(layernorm_f32(h->d_dx, L.ln2_w, L.ln2_b, h->d_dxn, batch, dt, s));
-      GemmArgs g = gemm(ln16 ? h->d_dxn : h->d_dx, dt, nullptr, dt, h->d_dh, 4L * dt, ln16 ? L.fc1_b : nullptr, batch, 4 * dt, dt);
-      if (!ln16) { g.ln_s = L.fc1_ls; g.ln_c = L.fc1_lc; }
-      g.gelu = h->enc_precision == 1 ? 2 : 1;      // mode 1: ggml's GELU (asr_common.h: gelu_ggml)
-      if ((qrc = proj(g, L.fc1_lw, L.fc1_wh, L.r_fc1, ln16 ? nullptr : L.ln2_w, ln16)) != CRISPY_OK) return qrc;
-    } else {
-      HIP_TRY(layernorm_f32(h->d_dx, L.ln2_w, L.ln2_b, h->d_dxn, batch, dt, s));
-      GemmArgs g = gemm(h->d_dxn, dt, w32(L.fc1_w, L.r_fc1, nullptr), dt, h->d_dh, 4L * dt, L.fc1_b, batch, 4 * dt, dt);
-      if (qrc != CRISPY_OK) return qrc;
-      g.gelu = h->enc_precision == 1 ? 2 : 1;
-      HIP_TRY(gemm_f32_nt(g, 1, s));
-    }
-    {
-      GemmArgs g = gemm(h->d_dh, 4L * dt, L.fc2_w, 4L * dt, h->d_dx, dt, L.fc2_b, batch, dt, 4 * dt);
-      g.residual = h->d_dx; g.ldr = dt;
-      if ((qrc = proj(g, L.fc2_w, L.fc2_wh, L.r_fc2, nullptr, wh)) != CRISPY_OK) return qrc;
-    }
+    if (rc != CRISPY_OK) return rc;
   }
   if (want_logits) {
     if (P == 1) return decoder_logits(h, clips, s);
@@ -753,6 +796,92 @@ double canonical(std::mt19937& g) {
   return u < 1.0 ? u : std::nextafter(1.0, 0.0);
 }
 
+// one decoder of a beam pass: its sequence so far and whisper_full's bookkeeping over it
+struct BeamSeq {
+  std::vector<int> toks, tids;
+  std::vector<float> plog;
+  double sum_all = 0.0;
+  bool has_ts = false, failed = false, completed = false;
+  int seek_delta = 3000, result_len = 0;
+  TsState st;
+};
+// what the pick kernel drew for every row of the step: n_cand candidates each (id, timestamp id, log-probability)
+struct BeamDraw {
+  int n_cand;
+  std::vector<int> tok, tid;
+  std::vector<float> plog;
+};
+
+// Step i of one clip (decoders seq[r0 .. r0 + n_dec)): sort its candidates, deal them to the live decoders, then completion /
+// failure of every live decoder on its new last token.  parent[r] = the row decoder r's sequence came from; *moved: some
+// decoder took another's sequence (their cache rows must follow); *any_live: a decoder of this clip goes on.
+int beam_advance_clip(const crispy_asr* h, const Special& sp, int rules, int r0, int n_dec, int i, int max_new, const BeamDraw& dr,
+                      std::vector<BeamSeq>& seq, std::vector<int>& parent, bool* moved, bool* any_live) {
+  struct Cand { int j, k; double sum; };
+  const int n_cand = dr.n_cand;
+  std::vector<Cand> cands;
+  for (int j = 0; j < n_dec; ++j) {
+    const BeamSeq& q = seq[r0 + j];
+    if (q.completed || q.failed) continue;
+    for (int k = 0; k < n_cand; ++k) {
+      const size_t x = (size_t)(r0 + j) * n_cand + k;
+      if (dr.tok[x] < 0 || dr.tok[x] >= h->hp.n_vocab) return fail(CRISPY_ERR_HIP, "beam decode: candidate id %d", dr.tok[x]);
+      cands.push_back(Cand{j, k, q.sum_all + (double)dr.plog[x]});
+    }
+  }
+  if (cands.empty()) return CRISPY_OK;
+  std::stable_sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) {
+    if (a.sum != b.sum) return a.sum > b.sum;
+    return a.j < b.j;
+  });
+  auto tok_of = [&](const Cand& x) { return dr.tok[(size_t)(r0 + x.j) * n_cand + x.k]; };
+  auto same = [&](const Cand& a, const Cand& b) {      // whisper_sequence_tokens_equal of the two candidates' sequences
+    return tok_of(a) == tok_of(b) && (a.j == b.j || seq[r0 + a.j].toks == seq[r0 + b.j].toks);
+  };
+  std::vector<BeamSeq> next(seq.begin() + r0, seq.begin() + r0 + n_dec);
+  size_t cur_c = 0;
+  for (int j = 0; j < n_dec; ++j) {
+    if (seq[r0 + j].completed || seq[r0 + j].failed) continue;
+    if (cur_c >= cands.size()) cur_c = 0;
+    const Cand cur = cands[cur_c++];
+    while (cands.size() > cur_c && i > 0 && same(cands[cur_c], cur)) ++cur_c;
+    const size_t x = (size_t)(r0 + cur.j) * n_cand + cur.k;
+    BeamSeq q = seq[r0 + cur.j];
+    q.toks.push_back(dr.tok[x]); q.tids.push_back(dr.tid[x]); q.plog.push_back(dr.plog[x]);
+    q.sum_all = cur.sum;
+    // the rules' view of the sequence (the pick kernel's ts_commit)
+    q.st.prev = q.st.last; q.st.last = dr.tok[x]; q.st.n += 1;
+    if (rules == TS_RULES_OPENAI ? dr.tok[x] >= sp.beg : dr.tok[x] > sp.beg) q.st.last_ts = dr.tok[x];
+    next[j] = std::move(q);
+    parent[r0 + j] = r0 + cur.j;
+    *moved = *moved || cur.j != j;
+  }
+  std::move(next.begin(), next.end(), seq.begin() + r0);
+  // completion / failure of every live decoder on its new last token
+  for (int j = 0; j < n_dec; ++j) {
+    BeamSeq& d = seq[r0 + j];
+    if (d.completed || d.failed) continue;
+    const int t = d.toks.back();
+    const int sk = d.st.seek, se = d.st.seek_end;
+    if (t > sp.beg) {
+      const int sd = 2 * (t - sp.beg);
+      if (d.has_ts && d.seek_delta > sd && d.result_len < i) { d.failed = true; continue; }      // "do not allow to go back in time"
+      d.seek_delta = sd; d.result_len = i + 1; d.has_ts = true;
+    }
+    if (t == h->eot || (d.has_ts && sk + d.seek_delta + TS_DELTA_MIN >= se)) {
+      if (d.result_len == 0) {
+        if (sk + d.seek_delta + TS_DELTA_MIN >= se) d.result_len = i + 1;
+        else { d.failed = true; continue; }
+      }
+      d.completed = true;
+      continue;
+    }
+    if (i == max_new - 1 && (d.result_len == 0 || d.seek_delta < 1500)) { d.failed = true; continue; }
+    *any_live = true;
+  }
+  return CRISPY_OK;
+}
+
 // One pass of whisper_full's BEAM_SEARCH strategy over one window per clip [UPSTREAM-RECALL: whisper_full_with_state,
 // whisper_sample_token_topk; restated in oracle/whisper_oracle.py: decode_temperature(beam_size=)].  Every clip has n_dec
 // decoders (rows [c n_dec, (c + 1) n_dec): beam_size of them at temperature 0, best_of above) over ONE cross K | V.  Per step:
@@ -818,15 +947,7 @@ int decode_beam(crispy_asr* h, const float* d_enc, int n_clips, int n_dec, int n
     HIP_TRY(hipMalloc(&h->d_beam_kv, need));
     h->beam_kv_bytes = need;
   }
-  struct Seq {
-    std::vector<int> toks, tids;
-    std::vector<float> plog;
-    double sum_all = 0.0;
-    bool has_ts = false, failed = false, completed = false;
-    int seek_delta = 3000, result_len = 0;
-    TsState st;
-  };
-  std::vector<Seq> seq((size_t)rows);
+  std::vector<BeamSeq> seq((size_t)rows);
   for (int r = 0; r < rows; ++r) {
     const int c = r / n_dec;
     seq[r].st = TsState{-1, -1, 0, -1, 0, seek ? seek[c] : 0, seek_end ? seek_end[c] : (1 << 30), 0};
@@ -835,12 +956,12 @@ int decode_beam(crispy_asr* h, const float* d_enc, int n_clips, int n_dec, int n
   pa.u_all = h->d_u_all;
   pa.n_cand = n_cand;
   pa.cand_tok = h->d_tokens_all; pa.cand_plog = h->d_plog_all; pa.cand_tid = h->d_tids_all;
-  const int delta_min = TS_DELTA_MIN;
   std::vector<double> u((size_t)rows * n_cand);
   std::vector<TsState> st((size_t)rows);
-  std::vector<int> c_tok((size_t)rows * n_cand), c_tid((size_t)rows * n_cand), parent((size_t)rows), feed((size_t)rows);
-  std::vector<float> c_plog((size_t)rows * n_cand);
-  struct Cand { int j, k; double sum; };
+  BeamDraw dr;
+  dr.n_cand = n_cand;
+  dr.tok.resize((size_t)rows * n_cand); dr.tid.resize((size_t)rows * n_cand); dr.plog.resize((size_t)rows * n_cand);
+  std::vector<int> parent((size_t)rows), feed((size_t)rows);
   for (int i = 0; i < max_new; ++i) {
     for (int r = 0; r < rows; ++r) {
       const bool live = !(seq[r].completed || seq[r].failed);
@@ -851,74 +972,15 @@ int decode_beam(crispy_asr* h, const float* d_enc, int n_clips, int n_dec, int n
     HIP_TRY(hipMemcpyAsync(h->d_u_all, u.data(), u.size() * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(h->d_ts_state, st.data(), st.size() * sizeof(TsState), hipMemcpyHostToDevice, s));
     HIP_TRY(ts_pick(pa, rows, s));
-    HIP_TRY(hipMemcpyAsync(c_tok.data(), h->d_tokens_all, c_tok.size() * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(c_tid.data(), h->d_tids_all, c_tid.size() * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(c_plog.data(), h->d_plog_all, c_plog.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(dr.tok.data(), h->d_tokens_all, dr.tok.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(dr.tid.data(), h->d_tids_all, dr.tid.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(dr.plog.data(), h->d_plog_all, dr.plog.size() * sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     bool moved = false, any_live = false;
     for (int r = 0; r < rows; ++r) parent[r] = r;
     for (int c = 0; c < n_clips; ++c) {
-      const int r0 = c * n_dec;
-      std::vector<Cand> cands;
-      for (int j = 0; j < n_dec; ++j) {
-        const Seq& q = seq[r0 + j];
-        if (q.completed || q.failed) continue;
-        for (int k = 0; k < n_cand; ++k) {
-          const size_t x = (size_t)(r0 + j) * n_cand + k;
-          if (c_tok[x] < 0 || c_tok[x] >= h->hp.n_vocab) return fail(CRISPY_ERR_HIP, "beam decode: candidate id %d", c_tok[x]);
-          cands.push_back(Cand{j, k, q.sum_all + (double)c_plog[x]});
-        }
-      }
-      if (cands.empty()) continue;
-      std::stable_sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) {
-        if (a.sum != b.sum) return a.sum > b.sum;
-        return a.j < b.j;
-      });
-      auto tok_of = [&](const Cand& x) { return c_tok[(size_t)(r0 + x.j) * n_cand + x.k]; };
-      auto same = [&](const Cand& a, const Cand& b) {      // whisper_sequence_tokens_equal of the two candidates' sequences
-        return tok_of(a) == tok_of(b) && (a.j == b.j || seq[r0 + a.j].toks == seq[r0 + b.j].toks);
-      };
-      std::vector<Seq> next(seq.begin() + r0, seq.begin() + r0 + n_dec);
-      size_t cur_c = 0;
-      for (int j = 0; j < n_dec; ++j) {
-        if (seq[r0 + j].completed || seq[r0 + j].failed) continue;
-        if (cur_c >= cands.size()) cur_c = 0;
-        const Cand cur = cands[cur_c++];
-        while (cands.size() > cur_c && i > 0 && same(cands[cur_c], cur)) ++cur_c;
-        const size_t x = (size_t)(r0 + cur.j) * n_cand + cur.k;
-        Seq q = seq[r0 + cur.j];
-        q.toks.push_back(c_tok[x]); q.tids.push_back(c_tid[x]); q.plog.push_back(c_plog[x]);
-        q.sum_all = cur.sum;
-        // the rules' view of the sequence (the pick kernel's ts_commit)
-        q.st.prev = q.st.last; q.st.last = c_tok[x]; q.st.n += 1;
-        if (rules == TS_RULES_OPENAI ? c_tok[x] >= sp.beg : c_tok[x] > sp.beg) q.st.last_ts = c_tok[x];
-        next[j] = std::move(q);
-        parent[r0 + j] = r0 + cur.j;
-        moved = moved || cur.j != j;
-      }
-      std::move(next.begin(), next.end(), seq.begin() + r0);
-      // completion / failure of every live decoder on its new last token
-      for (int j = 0; j < n_dec; ++j) {
-        Seq& d = seq[r0 + j];
-        if (d.completed || d.failed) continue;
-        const int t = d.toks.back();
-        const int sk = d.st.seek, se = d.st.seek_end;
-        if (t > sp.beg) {
-          const int sd = 2 * (t - sp.beg);
-          if (d.has_ts && d.seek_delta > sd && d.result_len < i) { d.failed = true; continue; }      // "do not allow to go back in time"
-          d.seek_delta = sd; d.result_len = i + 1; d.has_ts = true;
-        }
-        if (t == h->eot || (d.has_ts && sk + d.seek_delta + delta_min >= se)) {
-          if (d.result_len == 0) {
-            if (sk + d.seek_delta + delta_min >= se) d.result_len = i + 1;
-            else { d.failed = true; continue; }
-          }
-          d.completed = true;
-          continue;
-        }
-        if (i == max_new - 1 && (d.result_len == 0 || d.seek_delta < 1500)) { d.failed = true; continue; }
-        any_live = true;
-      }
+      rc = beam_advance_clip(h, sp, rules, c * n_dec, n_dec, i, max_new, dr, seq, parent, &moved, &any_live);
+      if (rc != CRISPY_OK) return rc;
     }
     if (!any_live || i == max_new - 1) break;
     if (moved && i > 0) {
@@ -935,7 +997,7 @@ int decode_beam(crispy_asr* h, const float* d_enc, int n_clips, int n_dec, int n
   HIP_TRY(hipMemcpyAsync(nosp.data(), h->d_nosp, nosp.size() * sizeof(float), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   for (int r = 0; r < rows; ++r) {
-    const Seq& q = seq[r];
+    const BeamSeq& q = seq[r];
     const int n = std::min<int>((int)q.toks.size(), max_new);
     for (int i = 0; i < max_new; ++i) {
       tokens_out[(size_t)r * max_new + i] = i < n ? q.toks[i] : h->eot;

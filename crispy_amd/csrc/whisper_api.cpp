@@ -672,35 +672,15 @@ int crispy_asr_set_precision(crispy_asr* h, int mode) try {
   return CRISPY_OK;
 } CRISPY_CATCH_RET("crispy_asr_set_precision")
 
-int crispy_asr_encode_device(crispy_asr* h, const float* d_mel_t, int batch, float* d_out, void* hip_stream) try {
-  if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_encode_device: NULL handle");
-  if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_encode_device: model not finalized");
-  if (batch < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_encode_device: batch < 0");
-  if (batch == 0) return CRISPY_OK;
-  if (!d_mel_t || !d_out) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_encode_device: NULL argument");
-  HIP_TRY(hipSetDevice(h->device));
-  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
-  int rc = reserve_enc(h, batch);
-  if (rc != CRISPY_OK) return rc;
-  // A resident quantised model de-quantises every weight into ONE scratch slot in front of its product; decode, cross K|V
-  // and the LayerNorm folding fill it on the handle's own stream.  A caller's stream is not ordered against that one, so
-  // an encode enqueued here while a decode of the same handle is still in flight would overwrite weights in use
-  // (ADVICE r3): order the two explicitly -- this encode starts after everything enqueued on the handle's stream so far,
-  // and the handle's stream continues after it.
-  struct ScratchOrder {
-    crispy_asr* h; hipStream_t s; bool on;
-    ~ScratchOrder() {
-      if (on && hipEventRecord(h->ev_scratch, s) == hipSuccess) (void)hipStreamWaitEvent(h->stream, h->ev_scratch, 0);
-    }
-  } scratch_order{h, s, false};
-  if (h->resident && s != h->stream) {
-    if (!h->ev_scratch) HIP_TRY(hipEventCreateWithFlags(&h->ev_scratch, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(h->ev_scratch, h->stream));
-    HIP_TRY(hipStreamWaitEvent(s, h->ev_scratch, 0));
-    scratch_order.on = true;
-  }
-  const int d = h->hp.n_audio_state, Tn = h->hp.n_audio_ctx, nm = h->hp.n_mels, H = h->hp.n_audio_head;
-  const long rows = (long)batch * Tn;
+}  // extern "C"
+
+namespace crispy {
+namespace asr {
+namespace {
+
+// the convolution stem: padded frame-major mel -> residual stream h->w_x [batch * 1500][d] (GELU, positional embedding added)
+int encode_stem(crispy_asr* h, const float* d_mel_t, int batch, hipStream_t s) {
+  const int d = h->hp.n_audio_state, Tn = h->hp.n_audio_ctx, nm = h->hp.n_mels;
   if (h->enc_precision == 1) {
     // The convolution stem on the f16 matrix cores too (ggml runs a convolution as im2col in f16 x f16 kernel): the
     // frame-major mel is rounded to f16 once, conv1 writes GELU(h1) as f16 (it only feeds conv2), conv2 reads it as
@@ -750,57 +730,70 @@ int crispy_asr_encode_device(crispy_asr* h, const float* d_mel_t, int batch, flo
       HIP_TRY(gemm_f32_nt(g, batch, s));
     }
   }
-  if (h->enc_precision == 1) {
-    // whisper.cpp's numerics with the bytes halved: every activation that only feeds a matrix product is stored as the
-    // f16 value the product would round it to anyway (LayerNorm output, q | k, V^T, attention output, MLP hidden
-    // layer); the residual stream stays f32.  The f16 buffers alias the f32 workspace of the default mode.
-    void* xn_h = h->w_xn;                                                   // [rows][d] f16
-    void* qk_h = h->w_qkv;                                                  // [rows][2 d] f16
-    void* vt_h = reinterpret_cast<_Float16*>(h->w_qkv) + rows * 2L * d;     // [batch][d][ENC_TP] f16
-    void* att_h = h->w_att;                                                 // [rows][d] f16
-    void* hid_h = h->w_h;                                                   // [rows][4 d] f16
-    const int swz = h->xcd_swizzle;
-    auto hg = [&](const void* A, long lda, const void* W, long ldw, void* C, long ldc, const float* bias, int N, int K) {
-      HGemmArgs g{};
-      g.A = reinterpret_cast<const _Float16*>(A); g.lda = lda; g.W = reinterpret_cast<const _Float16*>(W); g.ldw = ldw;
-      g.C = C; g.ldc = ldc; g.bias = bias; g.M = (int)rows; g.N = N; g.K = K; g.vt_T = Tn; g.xcd_swizzle = swz;
-      return g;
-    };
-    // f16 weights of a product: the resident copy, or -- resident quantised model -- the blocks de-quantised into the
-    // scratch slot right here (the previous product has finished with the slot: same stream)
-    auto w16 = [&](const void* dense, const QRef& r, const void** out) -> int {
-      if (!h->resident) { *out = dense; return CRISPY_OK; }
-      return dq(h, r, true, nullptr, s, out);
-    };
-    for (const EncLayer& L : h->enc) {
-      const void* w = nullptr;
-      HIP_TRY(layernorm_f16out(h->w_x, L.ln1_w, L.ln1_b, xn_h, rows, d, s));
-      if ((rc = w16(L.qkv_wh, L.r_qkv, &w)) != CRISPY_OK) return rc;
-      HIP_TRY(gemm_hh(hg(xn_h, d, w, d, qk_h, 2L * d, L.qkv_b, 2 * d, d), HGEMM_F16, 1, s));
-      HIP_TRY(gemm_hh(hg(xn_h, d, reinterpret_cast<const _Float16*>(w) + 2L * d * d, d, vt_h, 0, L.qkv_b + 2 * d, d, d),
-                      HGEMM_VT, 1, s));
-      HIP_TRY(attn_encoder_h(qk_h, vt_h, att_h, batch, Tn, d, H, s, h->dec_attn16 ? 1 : 0));     // mode 2: ggml's rounding points inside the attention
-      {
-        if ((rc = w16(L.out_wh, L.r_out, &w)) != CRISPY_OK) return rc;
-        HGemmArgs g = hg(att_h, d, w, d, h->w_x, d, L.out_b, d, d);
-        g.residual = h->w_x; g.ldr = d;
-        HIP_TRY(gemm_hh(g, HGEMM_RES, 1, s));
-      }
-      HIP_TRY(layernorm_f16out(h->w_x, L.ln2_w, L.ln2_b, xn_h, rows, d, s));
-      {
-        if ((rc = w16(L.fc1_wh, L.r_fc1, &w)) != CRISPY_OK) return rc;
-        HGemmArgs g = hg(xn_h, d, w, d, hid_h, 4L * d, L.fc1_b, 4 * d, d);
-        g.gelu = 1;
-        HIP_TRY(gemm_hh(g, HGEMM_F16, 1, s));
-      }
-      {
-        if ((rc = w16(L.fc2_wh, L.r_fc2, &w)) != CRISPY_OK) return rc;
-        HGemmArgs g = hg(hid_h, 4L * d, w, 4L * d, h->w_x, d, L.fc2_b, d, 4 * d);
-        g.residual = h->w_x; g.ldr = d;
-        HIP_TRY(gemm_hh(g, HGEMM_RES, 1, s));
-      }
+  return CRISPY_OK;
+}
+
+// the encoder layers over h->w_x in precision mode 1
+int encode_layers_f16(crispy_asr* h, int batch, hipStream_t s) {
+  const int d = h->hp.n_audio_state, Tn = h->hp.n_audio_ctx, H = h->hp.n_audio_head;
+  const long rows = (long)batch * Tn;
+  int rc = CRISPY_OK;
+  // whisper.cpp's numerics with the bytes halved: every activation that only feeds a matrix product is stored as the
+  // f16 value the product would round it to anyway (LayerNorm output, q | k, V^T, attention output, MLP hidden
+  // layer); the residual stream stays f32.  The f16 buffers alias the f32 workspace of the default mode.
+  void* xn_h = h->w_xn;                                                   // [rows][d] f16
+  void* qk_h = h->w_qkv;                                                  // [rows][2 d] f16
+  void* vt_h = reinterpret_cast<_Float16*>(h->w_qkv) + rows * 2L * d;     // [batch][d][ENC_TP] f16
+  void* att_h = h->w_att;                                                 // [rows][d] f16
+  void* hid_h = h->w_h;                                                   // [rows][4 d] f16
+  const int swz = h->xcd_swizzle;
+  auto hg = [&](const void* A, long lda, const void* W, long ldw, void* C, long ldc, const float* bias, int N, int K) {
+    HGemmArgs g{};
+    g.A = reinterpret_cast<const _Float16*>(A); g.lda = lda; g.W = reinterpret_cast<const _Float16*>(W); g.ldw = ldw;
+    g.C = C; g.ldc = ldc; g.bias = bias; g.M = (int)rows; g.N = N; g.K = K; g.vt_T = Tn; g.xcd_swizzle = swz;
+    return g;
+  };
+  // f16 weights of a product: the resident copy, or -- resident quantised model -- the blocks de-quantised into the
+  // scratch slot right here (the previous product has finished with the slot: same stream)
+  auto w16 = [&](const void* dense, const QRef& r, const void** out) -> int {
+    if (!h->resident) { *out = dense; return CRISPY_OK; }
+    return dq(h, r, true, nullptr, s, out);
+  };
+  for (const EncLayer& L : h->enc) {
+    const void* w = nullptr;
+    HIP_TRY(layernorm_f16out(h->w_x, L.ln1_w, L.ln1_b, xn_h, rows, d, s));
+    if ((rc = w16(L.qkv_wh, L.r_qkv, &w)) != CRISPY_OK) return rc;
+    HIP_TRY(gemm_hh(hg(xn_h, d, w, d, qk_h, 2L * d, L.qkv_b, 2 * d, d), HGEMM_F16, 1, s));
+    HIP_TRY(gemm_hh(hg(xn_h, d, reinterpret_cast<const _Float16*>(w) + 2L * d * d, d, vt_h, 0, L.qkv_b + 2 * d, d, d),
+                    HGEMM_VT, 1, s));
+    HIP_TRY(attn_encoder_h(qk_h, vt_h, att_h, batch, Tn, d, H, s, h->dec_attn16 ? 1 : 0));     // mode 2: ggml's rounding points inside the attention
+    {
+      if ((rc = w16(L.out_wh, L.r_out, &w)) != CRISPY_OK) return rc;
+      HGemmArgs g = hg(att_h, d, w, d, h->w_x, d, L.out_b, d, d);
+      g.residual = h->w_x; g.ldr = d;
+      HIP_TRY(gemm_hh(g, HGEMM_RES, 1, s));
     }
-  } else
+    HIP_TRY(layernorm_f16out(h->w_x, L.ln2_w, L.ln2_b, xn_h, rows, d, s));
+    {
+      if ((rc = w16(L.fc1_wh, L.r_fc1, &w)) != CRISPY_OK) return rc;
+      HGemmArgs g = hg(xn_h, d, w, d, hid_h, 4L * d, L.fc1_b, 4 * d, d);
+      g.gelu = 1;
+      HIP_TRY(gemm_hh(g, HGEMM_F16, 1, s));
+    }
+    {
+      if ((rc = w16(L.fc2_wh, L.r_fc2, &w)) != CRISPY_OK) return rc;
+      HGemmArgs g = hg(hid_h, 4L * d, w, 4L * d, h->w_x, d, L.fc2_b, d, 4 * d);
+      g.residual = h->w_x; g.ldr = d;
+      HIP_TRY(gemm_hh(g, HGEMM_RES, 1, s));
+    }
+  }
+  return CRISPY_OK;
+}
+
+// ... and in precision mode 0 (f32 operands)
+int encode_layers_f32(crispy_asr* h, int batch, hipStream_t s) {
+  const int d = h->hp.n_audio_state, Tn = h->hp.n_audio_ctx, H = h->hp.n_audio_head;
+  const long rows = (long)batch * Tn;
   for (const EncLayer& L : h->enc) {
     HIP_TRY(layernorm_f32(h->w_x, L.ln1_w, L.ln1_b, h->w_xn, rows, d, s));
     HIP_TRY(gemm_f32_nt(gemm(h->w_xn, d, L.qkv_w, d, h->w_qkv, 3L * d, L.qkv_b, (int)rows, 3 * d, d), 1, s));
@@ -822,6 +815,47 @@ int crispy_asr_encode_device(crispy_asr* h, const float* d_mel_t, int batch, flo
       HIP_TRY(gemm_f32_nt(g, 1, s));
     }
   }
+  return CRISPY_OK;
+}
+
+}  // namespace
+}  // namespace asr
+}  // namespace crispy
+
+extern "C" {
+
+int crispy_asr_encode_device(crispy_asr* h, const float* d_mel_t, int batch, float* d_out, void* hip_stream) try {
+  if (!h) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_encode_device: NULL handle");
+  if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_encode_device: model not finalized");
+  if (batch < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_encode_device: batch < 0");
+  if (batch == 0) return CRISPY_OK;
+  if (!d_mel_t || !d_out) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_encode_device: NULL argument");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
+  int rc = reserve_enc(h, batch);
+  if (rc != CRISPY_OK) return rc;
+  // A resident quantised model de-quantises every weight into ONE scratch slot in front of its product; decode, cross K|V
+  // and the LayerNorm folding fill it on the handle's own stream.  A caller's stream is not ordered against that one, so
+  // an encode enqueued here while a decode of the same handle is still in flight would overwrite weights in use
+  // (ADVICE r3): order the two explicitly -- this encode starts after everything enqueued on the handle's stream so far,
+  // and the handle's stream continues after it.
+  struct ScratchOrder {
+    crispy_asr* h; hipStream_t s; bool on;
+    ~ScratchOrder() {
+      if (on && hipEventRecord(h->ev_scratch, s) == hipSuccess) (void)hipStreamWaitEvent(h->stream, h->ev_scratch, 0);
+    }
+  } scratch_order{h, s, false};
+  if (h->resident && s != h->stream) {
+    if (!h->ev_scratch) HIP_TRY(hipEventCreateWithFlags(&h->ev_scratch, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(h->ev_scratch, h->stream));
+    HIP_TRY(hipStreamWaitEvent(s, h->ev_scratch, 0));
+    scratch_order.on = true;
+  }
+  rc = encode_stem(h, d_mel_t, batch, s);
+  if (rc == CRISPY_OK) rc = h->enc_precision == 1 ? encode_layers_f16(h, batch, s) : encode_layers_f32(h, batch, s);
+  if (rc != CRISPY_OK) return rc;
+  const long rows = (long)batch * h->hp.n_audio_ctx;
+  const int d = h->hp.n_audio_state;
   HIP_TRY(layernorm_f32(h->w_x, h->ln_post_w, h->ln_post_b, d_out, rows, d, s));
   return CRISPY_OK;
 } CRISPY_CATCH_RET("crispy_asr_encode_device")

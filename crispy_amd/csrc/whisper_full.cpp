@@ -212,21 +212,108 @@ namespace crispy {
 namespace asr {
 namespace {
 
-// cancel (nullable): polled at the top of every round of the seek loop -- a set flag ends the call with
-// CRISPY_ERR_CANCELLED and no results (crispy_asr_transcribe_recording: commands/transcription.rs:251,359,402)
-int transcribe_batch_impl(crispy_asr* h, const float* const* pcm, const size_t* n, int batch, const crispy_asr_opts* opts,
-                          crispy_asr_result** results, const volatile int* cancel) {
-  if (!h || !results) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: NULL argument");
-  if (batch < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: batch < 0");
-  for (int i = 0; i < batch; ++i) results[i] = nullptr;
-  if (batch == 0) return CRISPY_OK;
-  if (!pcm || !n) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: NULL argument");
-  if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_transcribe_batch: model not finalized");
+// ---- engine.transcribe for a batch of chunks: one object per call, one short method per step of whisper_full ----
+// (Round 6: this was one 400-line function.  The statements are the same; what each group of them is FOR is now its name.)
+
+// the pass whisper_full ends up accepting for one active clip of a round
+struct Accepted {
+  std::vector<int> toks, tids, prompt;
+  std::vector<float> plog;
+  DecoderPass d;
+  float nosp = 0.f, temperature = 0.f;
+  int decoder = 0;
+  bool have = false;
+};
+
+// what one decode of a group of clips (n_dec rows each) returned
+struct GroupPicks {
+  int max_new = 0;
+  std::vector<int> toks, tids, n_out;
+  std::vector<float> plog, nosp;
+  std::vector<std::vector<int>> prompts;      // per row
+};
+
+class BatchCall {
+ public:
+  BatchCall(crispy_asr* h_, const float* const* pcm_, const size_t* n_, int batch_, const crispy_asr_opts* opts_, const volatile int* cancel_)
+      : h(h_), pcm(pcm_), n(n_), batch(batch_), opts(opts_), cancel(cancel_), sp(special_tokens(h_)) {}
+  ~BatchCall() {
+    for (auto* r : impl) delete r;
+    if (d_enc_rep) (void)hipFree(d_enc_rep);
+  }
+  int prepare();                       // argument checks, which clips are live, the prompt, one result object per clip
+  int run();                           // everything on the device
+  void release(crispy_asr_result** results) {      // hands the results over (the destructor then has nothing to delete)
+    for (int i = 0; i < batch; ++i) {
+      publish(impl[i]);
+      results[i] = &impl[i]->pub;
+      impl[i] = nullptr;
+    }
+  }
+
+ private:
+  int check_options() const;
+  int upload_and_encode();
+  int decode_plain();                  // no_timestamps = 1: one window, plain greedy arg-max
+  int setup_ladder();                  // thresholds, temperatures, masks, generators, the widest pass's workspace
+  int seek_loop();
+  int decode_round(const std::vector<int>& act, std::vector<Accepted>& acc);
+  int decode_group(const std::vector<int>& act, const std::vector<int>& grp, float t_cur, int n_dec, GroupPicks& out);
+  bool evaluate_clip(int a, int k, int c, float t_cur, bool last_temp, int n_dec, const GroupPicks& g, Accepted& A);
+  void finish_window(int k, const Accepted& A);
+  std::vector<int> build_prompt(int k, int lang_tok, float t_cur) const;
+  int reserve_enc_rep(int n_clips);
+
+  crispy_asr* h;
+  const float* const* pcm;
+  const size_t* n;
+  int batch;
+  const crispy_asr_opts* opts;
+  const volatile int* cancel;
+  const Special sp;
+  std::vector<crispy_asr_result_impl*> impl;
+  std::vector<int> live, lens, lang, prompt;
+  size_t stride = 1;
+  int nb = 0, max_new = 0, n_init = 0;
+  bool timestamps = true, detect = false;
+  // whisper_full's parameters (0 in crispy_asr_opts = whisper.cpp's default)
+  float entropy_thold = 2.4f, logprob_thold = -1.0f, no_speech_thold = 0.6f;
+  int best_of = 5, beam = 0;
+  bool use_past = true;
+  std::vector<float> temps;
+  const unsigned char *ts_mask = nullptr, *ts_mask_first = nullptr;
+  // per live clip
+  std::vector<int> seek, seek_end;
+  std::vector<std::vector<int>> past;
+  std::vector<std::vector<std::mt19937>> rngs;
+  // the encoder outputs of a group of fallback clips, gathered (one per clip).  The group size changes from pass to pass
+  // (every pending clip in one group at n_dec == 1, kLadderRowsMax / n_dec otherwise): kept by capacity and regrown -- round 5
+  // sized it from the first group that needed it, and a later, larger group overflowed it
+  float* d_enc_rep = nullptr;
+  int enc_rep_clips = 0;
+  size_t enc_clip = 0;
+};
+
+int BatchCall::check_options() const {
+  if (!opts) return CRISPY_OK;
+  if (opts->beam_size < 0 || opts->beam_size > TS_MAX_CAND)
+    return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: beam_size %d; 0 .. %d (WHISPER_MAX_DECODERS)", opts->beam_size, TS_MAX_CAND);
+  if (opts->beam_size > 1 && !timestamps)
+    return fail(CRISPY_ERR_UNSUPPORTED, "crispy_asr_transcribe_batch: beam search runs inside whisper_full's window loop (timestamps on)");
+  if (opts->n_initial_prompt < 0 || (opts->n_initial_prompt > 0 && !opts->initial_prompt))
+    return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: initial_prompt is NULL or its count negative");
+  if (opts->carry_context && batch != 1)
+    return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: carry_context needs a single-chunk call (batch %d)", batch);
+  for (int i = 0; i < opts->n_initial_prompt; ++i)
+    if (opts->initial_prompt[i] < 0 || opts->initial_prompt[i] >= h->hp.n_vocab)
+      return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: initial prompt token %d out of range", opts->initial_prompt[i]);
+  return CRISPY_OK;
+}
+
+int BatchCall::prepare() {
   // empty clips produce empty results without touching the GPU (managers/transcription.rs:175-177); so do clips
   // shorter than 1 s = 100 mel frames, which whisper.cpp's whisper_full refuses ("input is too short", returns no
   // segments) [UPSTREAM-RECALL] -- the 168 samples the 48 -> 16 kHz resampler leaves past a 30 s chunk are such a clip
-  std::vector<int> live;
-  size_t stride = 1;
   for (int i = 0; i < batch; ++i) {
     if (n[i] > 480000)
       return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: clip %d has %zu samples; the caller chunks at 480000 "
@@ -238,379 +325,385 @@ int transcribe_batch_impl(crispy_asr* h, const float* const* pcm, const size_t* 
       if (n[i] > stride) stride = n[i];
     }
   }
-  std::vector<crispy_asr_result_impl*> impl(batch, nullptr);
-  auto cleanup = [&]() { for (auto* r : impl) delete r; for (int i = 0; i < batch; ++i) results[i] = nullptr; };
+  impl.assign((size_t)batch, nullptr);
   for (int i = 0; i < batch; ++i) {
     impl[i] = new (std::nothrow) crispy_asr_result_impl();
-    if (!impl[i]) { cleanup(); return fail(CRISPY_ERR_OOM, "crispy_asr_transcribe_batch: host allocation failed"); }
+    if (!impl[i]) return fail(CRISPY_ERR_OOM, "crispy_asr_transcribe_batch: host allocation failed");
   }
-  const int nb = (int)live.size();
-  if (nb > 0) {
-    const Special sp = special_tokens(h);
-    const bool timestamps = !(opts && opts->no_timestamps) && sp.beg + 1501 <= h->hp.n_vocab;
-    if (opts && (opts->beam_size < 0 || opts->beam_size > TS_MAX_CAND)) {
-      cleanup();
-      return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: beam_size %d; 0 .. %d (WHISPER_MAX_DECODERS)", opts->beam_size, TS_MAX_CAND);
-    }
-    if (opts && opts->beam_size > 1 && !timestamps) {
-      cleanup();
-      return fail(CRISPY_ERR_UNSUPPORTED, "crispy_asr_transcribe_batch: beam search runs inside whisper_full's window loop (timestamps on)");
-    }
-    if (opts && (opts->n_initial_prompt < 0 || (opts->n_initial_prompt > 0 && !opts->initial_prompt))) {
-      cleanup();
-      return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: initial_prompt is NULL or its count negative");
-    }
-    if (opts && opts->carry_context && batch != 1) {
-      cleanup();
-      return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: carry_context needs a single-chunk call (batch %d)", batch);
-    }
-    if (opts)
-      for (int i = 0; i < opts->n_initial_prompt; ++i)
-        if (opts->initial_prompt[i] < 0 || opts->initial_prompt[i] >= h->hp.n_vocab) {
-          cleanup();
-          return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: initial prompt token %d out of range", opts->initial_prompt[i]);
-        }
-    std::vector<int> prompt = {sp.sot};
-    if (sp.multilingual) {
-      prompt.push_back(opts && opts->language_token > 0 ? opts->language_token : sp.lang0);   // <|en|>
-      prompt.push_back(opts && opts->translate ? sp.translate : sp.transcribe);
-    }
-    if (!timestamps) prompt.push_back(sp.not_);
-    int max_new = opts && opts->max_new_tokens > 0 ? opts->max_new_tokens
-                                                   : (timestamps ? h->hp.n_text_ctx / 2 - 4 : h->hp.n_text_ctx / 2);
-    if ((int)prompt.size() + max_new > h->hp.n_text_ctx) max_new = h->hp.n_text_ctx - (int)prompt.size();
-    std::vector<int> lens(nb), lang(nb, 0);
-    for (int k = 0; k < nb; ++k) lens[k] = (int)n[live[k]];
-    const bool detect = sp.multilingual && !(opts && opts->language_token > 0);
-    auto run = [&]() -> int {
-      HIP_TRY(hipSetDevice(h->device));
-      int rc = reserve_enc(h, nb);
-      if (rc != CRISPY_OK) return rc;
-      if (!h->w_pcm || (long)stride > h->cap_pcm_stride) {
-        if (h->w_pcm) (void)hipFree(h->w_pcm);
-        h->w_pcm = nullptr;
-        HIP_TRY(hipMalloc(&h->w_pcm, (size_t)h->cap_batch * stride * sizeof(float)));
-        h->cap_pcm_stride = (long)stride;
-      }
-      // every clip straight from the caller's memory into its row (no packed host copy: for the 21 chunks of a ten-minute
-      // recording that was 40 MB zero-filled, copied and then copied again); what lies behind a clip's end in its row is
-      // never read -- the log-mel takes n_samples per clip
-      for (int k = 0; k < nb; ++k)
-        HIP_TRY(hipMemcpyAsync(h->w_pcm + (size_t)k * stride, pcm[live[k]], (size_t)lens[k] * sizeof(float), hipMemcpyHostToDevice, h->stream));
-      rc = crispy_mel_compute_device(h->mel, h->w_pcm, (long)stride, lens.data(), nb, nullptr, h->w_melt, h->stream);
-      if (rc != CRISPY_OK) return rc;
-      rc = crispy_asr_encode_device(h, h->w_melt, nb, h->w_enc, h->stream);
-      if (rc != CRISPY_OK) return rc;
-      if (detect) {
-        rc = crispy_asr_detect_language_device(h, h->w_enc, nb, lang.data());
-        if (rc != CRISPY_OK) return rc;
-      } else if (sp.multilingual) {
-        std::fill(lang.begin(), lang.end(), prompt[1]);
-      }
-      for (int k = 0; k < nb; ++k) impl[live[k]]->language_token = lang[k];
-      if (!timestamps) {
-        std::vector<int> toks((size_t)nb * max_new), n_out(nb, 0);
-        rc = crispy_asr_decode_greedy_lang_device(h, h->w_enc, nb, prompt.data(), (int)prompt.size(),
-                                                  detect ? lang.data() : nullptr, max_new, toks.data(), n_out.data(), nullptr);
-        if (rc != CRISPY_OK) return rc;
-        for (int k = 0; k < nb; ++k) {
-          crispy_asr_result_impl* r = impl[live[k]];
-          r->tokens.assign(toks.begin() + (size_t)k * max_new, toks.begin() + (size_t)k * max_new + n_out[k]);
-          for (int t : r->tokens)
-            if (t < h->eot && t < (int)h->vocab.size()) r->text += h->vocab[t];
-        }
-        return CRISPY_OK;
-      }
-      // ---- whisper_full's seek loop, all clips in lock step ----
-      // [UPSTREAM-RECALL: whisper_full_with_state].  Per round every clip that has audio left decodes one window:
-      //   * prompt = (<|startofprev|> + the last min(n_text_ctx / 2, |past|) tokens of the text so far) + the usual prompt;
-      //     the past is dropped when fewer than 5 s of audio are left ("a very short segment ... tends to confuse the
-      //     decoder") and for a re-decode at a temperature >= 0.5; after a window: past = the past part of its prompt + its
-      //     kept tokens (nothing from a window dropped as silence);
-      //   * the temperature ladder: greedy at `temperature`, all clips of the round as ONE batch (their prompts differ in
-      //     length: decode_ts left-pads); a clip whose window fails is decoded again at the next temperature with
-      //     best_of sampling decoders (rows of one batch over copies of its encoder output), until one passes or the
-      //     ladder ends;
-      //   * no-speech rule, segments, and how far the window advances (the last closed timestamp pair, the whole
-      //     window after a single closing timestamp).
-      const int delta_min = TS_DELTA_MIN;
-      std::vector<int> seek(nb, 0), seek_end(nb);
-      for (int k = 0; k < nb; ++k) seek_end[k] = 1 + (lens[k] + 200 - 400) / 160;      // whisper.cpp's mel.n_len_org
-      const float t0 = opts ? opts->temperature : 0.f;
-      const float t_inc = !opts || opts->temperature_inc == 0.f ? 0.2f : opts->temperature_inc;
-      const float entropy_thold = !opts || opts->entropy_thold == 0.f ? 2.4f : opts->entropy_thold;
-      const float logprob_thold = !opts || opts->logprob_thold == 0.f ? -1.0f : opts->logprob_thold;
-      const float no_speech_thold = !opts || opts->no_speech_thold == 0.f ? 0.6f : opts->no_speech_thold;
-      const int best_of = std::max(1, !opts || opts->best_of == 0 ? 5 : opts->best_of);
-      if (best_of > 8) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: best_of %d > 8 (WHISPER_MAX_DECODERS)", best_of);
-      std::vector<float> temps;
-      if (t_inc > 0.f) for (float t = t0; t < 1.0f + 1e-6f; t += t_inc) temps.push_back(t);
-      else temps.push_back(t0);
-      if (temps.empty()) temps.push_back(t0);
-      const bool use_past = !(opts && opts->no_prev_text);
-      // The conditioning text a chunk starts with [UPSTREAM-RECALL: whisper_full_with_state, prompt_past]: nothing
-      // (no_context = true, whisper.cpp's default); with carry_context what the previous call on this handle ended with;
-      // the caller's initial prompt rotated in front of that.
-      std::vector<std::vector<int>> past(nb);
-      {
-        std::vector<int> start;
-        if (opts && opts->n_initial_prompt > 0) start.assign(opts->initial_prompt, opts->initial_prompt + opts->n_initial_prompt);
-        if (opts && opts->carry_context) start.insert(start.end(), h->prompt_past.begin(), h->prompt_past.end());
-        for (int k = 0; k < nb; ++k) past[k] = start;
-      }
-      const unsigned char *ts_mask = h->d_ts_mask, *ts_mask_first = h->d_ts_mask_first;
-      if (opts && opts->suppress_nst) {
-        rc = build_nst_masks(h);
-        if (rc != CRISPY_OK) return rc;
-        ts_mask = h->d_ts_mask_nst; ts_mask_first = h->d_ts_mask_first_nst;
-      }
-      // whisper.cpp's BEAM_SEARCH strategy (beam_size > 1): beam_size decoders at temperature 0, best_of above, every pass through
-      // decode_beam (candidates drawn per decoder, sorted, dealt; see there); 0 / 1: the GREEDY strategy
-      const int beam = opts && opts->beam_size > 1 ? opts->beam_size : 0;
-      std::vector<std::vector<std::mt19937>> rngs(nb);
-      for (int k = 0; k < nb; ++k)
-        for (int j = 0; j < std::max(best_of, beam); ++j) rngs[k].emplace_back((unsigned)j);
-      const int n_init = (int)prompt.size();
-      const size_t enc_clip = (size_t)h->hp.n_audio_ctx * h->hp.n_audio_state;
-      // rows of one fallback decode: whole clips x best_of
-      const int kLadderRows = kLadderRowsMax;
-      // the decoder workspace for the widest pass of this call, taken once: growing it between the greedy pass and the
-      // first fallback pass freed every buffer and dropped the captured steps.  Widest = the most rows any pass
-      // of the ladder can have: the beam pass at temperature 0 (groups of kLadderRows / beam clips x beam rows) and the
-      // best_of passes above it (kLadderRows / best_of clips x best_of rows) -- ADVICE r5: with beam < best_of the beam
-      // pass is the wider one.
-      {
-        auto pass_rows = [&](int n_dec) { return std::min(nb * n_dec, std::max(1, kLadderRows / n_dec) * n_dec); };
-        int rows_max = nb;
-        if (temps.size() > 1 && best_of > 1) rows_max = std::max(rows_max, pass_rows(best_of));
-        if (beam > 1) rows_max = std::max(rows_max, pass_rows(beam));
-        if (rows_max > nb) {
-          rc = reserve_dec(h, rows_max, nb);
-          if (rc != CRISPY_OK) return rc;
-        }
-      }
-      // the encoder outputs of a group of fallback clips, gathered (one per clip).  The group size changes from pass to pass
-      // (every pending clip in one group at n_dec == 1, kLadderRows / n_dec otherwise): the buffer is kept by capacity and
-      // regrown -- round 5 sized it from the first group that needed it, and a later, larger group overflowed it
-      float* d_enc_rep = nullptr;
-      int enc_rep_clips = 0;
-      struct RepGuard { float** p; ~RepGuard() { if (*p) (void)hipFree(*p); } } rep_guard{&d_enc_rep};
-      auto reserve_enc_rep = [&](int n_clips) -> int {
-        if (n_clips <= enc_rep_clips) return CRISPY_OK;
-        if (d_enc_rep) {                                    // copies into / decodes from the old buffer may be in flight
-          HIP_TRY(hipStreamSynchronize(h->stream));
-          (void)hipFree(d_enc_rep);
-          d_enc_rep = nullptr; enc_rep_clips = 0;
-        }
-        HIP_TRY(hipMalloc(&d_enc_rep, (size_t)n_clips * enc_clip * sizeof(float)));
-        enc_rep_clips = n_clips;
-        return CRISPY_OK;
-      };
-      auto build_prompt = [&](int k, int lang_tok, float t_cur) {
-        std::vector<int> p;
-        if (use_past && !past[k].empty() && t_cur < 0.5f) {
-          int n_take = std::min<int>(h->hp.n_text_ctx / 2, (int)past[k].size());
-          n_take = std::min(n_take, h->hp.n_text_ctx - max_new - n_init - 1);
-          if (n_take > 0) {
-            p.push_back(sp.prev);
-            p.insert(p.end(), past[k].end() - n_take, past[k].end());
-          }
-        }
-        p.insert(p.end(), prompt.begin(), prompt.end());
-        if (sp.multilingual) p[p.size() - n_init + 1] = lang_tok;
-        return p;
-      };
-      // whisper.cpp loops until seek + delta_min >= seek_end.  Every round advances every active clip by seek_delta >= 2
-      // (a closed pair ends on a timestamp strictly above <|0.00|>, otherwise the delta is the whole window), so
-      // 1500 rounds cover any 30 s clip; running out of them is reported, never a silently shorter transcript.
-      const int kMaxRounds = 1501;
-      for (int round = 0;; ++round) {
-        if (round >= kMaxRounds)
-          return fail(CRISPY_ERR_HIP, "crispy_asr_transcribe_batch: seek loop did not terminate after %d windows", kMaxRounds);
-        if (cancel && *cancel) return fail(CRISPY_ERR_CANCELLED, "transcription cancelled by the caller");
-        std::vector<int> act;
-        for (int k = 0; k < nb; ++k)
-          if (seek_end[k] >= delta_min && seek[k] + delta_min < seek_end[k]) act.push_back(k);   // < 100 ms left: whisper.cpp stops
-        if (act.empty()) break;
-        const int na = (int)act.size();
-        if (!(round == 0 && na == nb)) {     // round 0 with every clip active: the encoder output is already there
-          std::vector<int> sk(na);
-          for (int a = 0; a < na; ++a) sk[a] = seek[act[a]];
-          rc = crispy_mel_window_device(h->mel, act.data(), sk.data(), na, nullptr, h->w_melt, h->stream);
-          if (rc != CRISPY_OK) return rc;
-          rc = crispy_asr_encode_device(h, h->w_melt, na, h->w_enc, h->stream);
-          if (rc != CRISPY_OK) return rc;
-        }
-        for (int a = 0; a < na; ++a) {
-          const int k = act[a];
-          if (seek[k] > 0 && seek[k] + 500 >= seek_end[k]) past[k].clear();
-        }
-        // per active clip: the pass whisper_full ends up accepting
-        struct Accepted {
-          std::vector<int> toks, tids, prompt;
-          std::vector<float> plog;
-          DecoderPass d;
-          float nosp = 0.f, temperature = 0.f;
-          int decoder = 0;
-          bool have = false;
-        };
-        std::vector<Accepted> acc((size_t)na);
-        std::vector<int> pending((size_t)na);
-        for (int a = 0; a < na; ++a) pending[a] = a;
-        for (size_t it = 0; it < temps.size() && !pending.empty(); ++it) {
-          const float t_cur = temps[it];
-          const bool last_temp = it + 1 == temps.size();
-          const int n_dec = t_cur > 0.f ? best_of : (beam ? beam : 1);
-          std::vector<int> still;
-          // Groups of clips decoded together, n_dec rows each (rows [c n_dec, (c + 1) n_dec) of a group are the decoders of its
-          // clip c: one cross K|V per clip, decode_ts's xgroup).  At temperature 0 that is every pending clip in one group, one
-          // row each, straight off h->w_enc while nothing has dropped out; above it the pending clips x best_of, in groups of
-          // at most kLadderRows rows -- ALL of them side by side, not one clip after the other (a batch in
-          // which a third of the windows fall back used to decode them one by one, five rows at a time).
-          const int per_group = n_dec == 1 && !beam ? (int)pending.size() : std::max(1, kLadderRows / n_dec);
-          std::vector<std::vector<int>> groups;
-          for (size_t g0 = 0; g0 < pending.size(); g0 += (size_t)per_group)
-            groups.emplace_back(pending.begin() + g0, pending.begin() + std::min(pending.size(), g0 + (size_t)per_group));
-          for (const std::vector<int>& grp : groups) {
-            const int n_clips = (int)grp.size(), rows = n_clips * n_dec;
-            const float* d_enc = h->w_enc;
-            bool contiguous = true;               // the group's clips are w_enc's first n_clips, in order
-            for (int c = 0; c < n_clips; ++c) contiguous = contiguous && grp[c] == c;
-            if (!contiguous) {                    // one copy per CLIP (its decoders share it)
-              rc = reserve_enc_rep(n_clips);
-              if (rc != CRISPY_OK) return rc;
-              for (int c = 0; c < n_clips; ++c)
-                HIP_TRY(hipMemcpyAsync(d_enc_rep + (size_t)c * enc_clip, h->w_enc + (size_t)grp[c] * enc_clip, enc_clip * sizeof(float),
-                                       hipMemcpyDeviceToDevice, h->stream));
-              d_enc = d_enc_rep;
-            }
-            std::vector<std::vector<int>> prompts((size_t)rows);
-            std::vector<int> r_seek(rows), r_end(rows);
-            for (int r = 0; r < rows; ++r) {
-              const int k = act[grp[r / n_dec]];
-              prompts[r] = build_prompt(k, lang[k], t_cur);
-              r_seek[r] = seek[k]; r_end[r] = seek_end[k];
-            }
-            std::vector<double> u;
-            if (t_cur > 0.f && !beam) {   // the variates decoder j of clip k would draw, from a copy of ITS generator
-              u.resize((size_t)max_new * rows);
-              for (int r = 0; r < rows; ++r) {
-                std::mt19937 g = rngs[act[grp[r / n_dec]]][r % n_dec];
-                for (int i = 0; i < max_new; ++i) u[(size_t)i * rows + r] = canonical(g);
-              }
-            }
-            std::vector<int> toks((size_t)rows * max_new), tids((size_t)rows * max_new), n_out(rows, 0);
-            std::vector<float> plog((size_t)rows * max_new), nosp(rows, 0.f);
-            if (beam) {
-              std::vector<std::vector<int>> clip_prompts((size_t)n_clips);
-              std::vector<int> c_seek(n_clips), c_end(n_clips);
-              std::vector<std::mt19937*> row_rng((size_t)rows);
-              for (int c = 0; c < n_clips; ++c) {
-                const int k = act[grp[c]];
-                clip_prompts[c] = prompts[(size_t)c * n_dec];
-                c_seek[c] = seek[k]; c_end[c] = seek_end[k];
-                for (int j = 0; j < n_dec; ++j) row_rng[(size_t)c * n_dec + j] = &rngs[k][j];
-              }
-              rc = decode_beam(h, d_enc, n_clips, n_dec, beam, clip_prompts, TS_RULES_WCPP, c_seek.data(), c_end.data(), max_new, ts_mask,
-                               ts_mask_first, t_cur, row_rng, toks.data(), tids.data(), plog.data(), nosp.data(), n_out.data());
-            } else {
-              rc = decode_ts(h, d_enc, rows, prompts, TS_RULES_WCPP, r_seek.data(), r_end.data(), max_new, ts_mask,
-                             ts_mask_first, t_cur, t_cur > 0.f ? u.data() : nullptr, toks.data(), tids.data(), plog.data(),
-                             nosp.data(), n_out.data(), n_dec);
-            }
-            if (rc != CRISPY_OK) return rc;
-            // evaluate: per clip of the group, its n_dec decoders
-            for (int c = 0; c < n_clips; ++c) {
-              const int a = grp[c], k = act[a];
-              std::vector<DecoderPass> decs((size_t)n_dec);
-              for (int j = 0; j < n_dec; ++j) {
-                const int r = c * n_dec + j;
-                DecoderPass& d = decs[j];
-                d.toks = toks.data() + (size_t)r * max_new;
-                d.tids = tids.data() + (size_t)r * max_new;
-                d.plog = plog.data() + (size_t)r * max_new;
-                d.n = n_out[r];
-                replay_decoder(d, max_new, sp.beg, h->eot, seek[k], seek_end[k], delta_min);
-                if (t_cur > 0.f && !beam) rngs[k][j].discard(2ull * (unsigned long long)d.n);      // what it drew: two per pick (a beam pass drew from the generators themselves)
-              }
-              // rank the sequences that did not fail (whisper.cpp: "rank the resulting sequences and select the best one")
-              int best = acc[a].have ? acc[a].decoder : 0;      // best_decoder_id survives a pass in which every decoder failed
-              if (best >= n_dec) best = 0;
-              double best_score = -INFINITY;
-              for (int j = 0; j < n_dec; ++j) {
-                DecoderPass& d = decs[j];
-                if (d.failed) continue;
-                score_decoder(d);
-                if (d.result_len > 32 && d.entropy < entropy_thold) { d.failed = true; continue; }
-                if (best_score < d.score) { best_score = d.score; best = j; }
-              }
-              const DecoderPass& bd = decs[best];
-              const float clip_nosp = nosp[c * n_dec];          // every decoder of a clip saw the same prompt logits
-              bool success = true;
-              if (!last_temp && (bd.failed || (bd.avg_logprobs < logprob_thold && clip_nosp < no_speech_thold)))
-                success = false;
-              Accepted& A = acc[a];
-              const int r = c * n_dec + best;
-              A.toks.assign(toks.begin() + (size_t)r * max_new, toks.begin() + (size_t)r * max_new + bd.n);
-              A.tids.assign(tids.begin() + (size_t)r * max_new, tids.begin() + (size_t)r * max_new + bd.n);
-              A.plog.assign(plog.begin() + (size_t)r * max_new, plog.begin() + (size_t)r * max_new + bd.n);
-              A.d = bd;
-              A.d.toks = A.toks.data(); A.d.tids = A.tids.data(); A.d.plog = A.plog.data();
-              A.prompt = prompts[r];
-              A.nosp = clip_nosp;
-              A.temperature = t_cur;
-              A.decoder = best;
-              A.have = true;
-              if (!success) still.push_back(a);
-            }
-          }
-          pending.swap(still);
-        }
-        for (int a = 0; a < na; ++a) {
-          const int k = act[a];
-          crispy_asr_result_impl* r = impl[live[k]];
-          const Accepted& A = acc[a];
-          const DecoderPass& d = A.d;
-          // a decoder that failed before the ranking keeps all its tokens (only ranked sequences are cut to result_len)
-          const int n_cur = d.scored ? d.result_len : d.n;
-          const bool is_no_speech = A.nosp > no_speech_thold && d.avg_logprobs < logprob_thold;
-          {
-            std::vector<int> np;
-            if (A.prompt.front() == sp.prev) np.assign(A.prompt.begin() + 1, A.prompt.end() - n_init);
-            if (!is_no_speech) np.insert(np.end(), A.toks.begin(), A.toks.begin() + d.result_len);
-            past[k].swap(np);
-          }
-          int seek_delta = d.seek_delta;
-          if (n_cur > 0 && !is_no_speech) {
-            window_segments(h, A.toks.data(), A.tids.data(), n_cur, sp.beg, seek[k], seek_delta, r);
-            for (int i = 0; i < n_cur; ++i)
-              if (A.toks[i] != h->eot) r->tokens.push_back(A.toks[i]);
-          }
-          // a single closing timestamp: nothing is left to say in this chunk [UPSTREAM-RECALL: whisper.cpp PR 2629]
-          if (n_cur > 1 && A.toks[n_cur - 2] < sp.beg && A.toks[n_cur - 1] > sp.beg)
-            seek_delta = std::min(seek_end[k] - seek[k], 3000);
-          crispy_asr_window w{};
-          w.seek = seek[k]; w.seek_advance = seek_delta; w.n_tokens = is_no_speech ? 0 : n_cur; w.decoder = A.decoder;
-          w.failed = d.failed ? 1 : 0; w.no_speech = is_no_speech ? 1 : 0; w.temperature = A.temperature;
-          w.no_speech_prob = A.nosp; w.avg_logprob = (float)d.avg_logprobs; w.entropy = (float)d.entropy;
-          r->wins.push_back(w);
-          seek[k] += seek_delta;
-        }
-      }
-      for (int k = 0; k < nb; ++k) {
-        crispy_asr_result_impl* r = impl[live[k]];
-        for (const std::string& t : r->seg_text) r->text += t;
-      }
-      if (batch == 1) h->prompt_past = past[0];      // whisper.cpp keeps prompt_past in the state; the next call uses it only with carry_context
-      return CRISPY_OK;
-    };
-    const int rc = run();
-    if (rc != CRISPY_OK) { cleanup(); return rc; }
+  nb = (int)live.size();
+  if (nb == 0) return CRISPY_OK;
+  timestamps = !(opts && opts->no_timestamps) && sp.beg + 1501 <= h->hp.n_vocab;
+  const int rc = check_options();
+  if (rc != CRISPY_OK) return rc;
+  prompt = {sp.sot};
+  if (sp.multilingual) {
+    prompt.push_back(opts && opts->language_token > 0 ? opts->language_token : sp.lang0);   // <|en|>
+    prompt.push_back(opts && opts->translate ? sp.translate : sp.transcribe);
   }
-  for (int i = 0; i < batch; ++i) {
-    publish(impl[i]);
-    results[i] = &impl[i]->pub;
+  if (!timestamps) prompt.push_back(sp.not_);
+  n_init = (int)prompt.size();
+  max_new = opts && opts->max_new_tokens > 0 ? opts->max_new_tokens : (timestamps ? h->hp.n_text_ctx / 2 - 4 : h->hp.n_text_ctx / 2);
+  if (n_init + max_new > h->hp.n_text_ctx) max_new = h->hp.n_text_ctx - n_init;
+  lens.resize(nb);
+  lang.assign(nb, 0);
+  for (int k = 0; k < nb; ++k) lens[k] = (int)n[live[k]];
+  detect = sp.multilingual && !(opts && opts->language_token > 0);
+  enc_clip = (size_t)h->hp.n_audio_ctx * h->hp.n_audio_state;
+  return CRISPY_OK;
+}
+
+int BatchCall::upload_and_encode() {
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = reserve_enc(h, nb);
+  if (rc != CRISPY_OK) return rc;
+  if (!h->w_pcm || (long)stride > h->cap_pcm_stride) {
+    if (h->w_pcm) (void)hipFree(h->w_pcm);
+    h->w_pcm = nullptr;
+    HIP_TRY(hipMalloc(&h->w_pcm, (size_t)h->cap_batch * stride * sizeof(float)));
+    h->cap_pcm_stride = (long)stride;
   }
+  // every clip straight from the caller's memory into its row (no packed host copy: for the 21 chunks of a ten-minute
+  // recording that was 40 MB zero-filled, copied and then copied again); what lies behind a clip's end in its row is
+  // never read -- the log-mel takes n_samples per clip
+  for (int k = 0; k < nb; ++k)
+    HIP_TRY(hipMemcpyAsync(h->w_pcm + (size_t)k * stride, pcm[live[k]], (size_t)lens[k] * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  rc = crispy_mel_compute_device(h->mel, h->w_pcm, (long)stride, lens.data(), nb, nullptr, h->w_melt, h->stream);
+  if (rc != CRISPY_OK) return rc;
+  rc = crispy_asr_encode_device(h, h->w_melt, nb, h->w_enc, h->stream);
+  if (rc != CRISPY_OK) return rc;
+  if (detect) {
+    rc = crispy_asr_detect_language_device(h, h->w_enc, nb, lang.data());
+    if (rc != CRISPY_OK) return rc;
+  } else if (sp.multilingual) {
+    std::fill(lang.begin(), lang.end(), prompt[1]);
+  }
+  for (int k = 0; k < nb; ++k) impl[live[k]]->language_token = lang[k];
+  return CRISPY_OK;
+}
+
+int BatchCall::decode_plain() {
+  std::vector<int> toks((size_t)nb * max_new), n_out(nb, 0);
+  const int rc = crispy_asr_decode_greedy_lang_device(h, h->w_enc, nb, prompt.data(), n_init, detect ? lang.data() : nullptr, max_new,
+                                                      toks.data(), n_out.data(), nullptr);
+  if (rc != CRISPY_OK) return rc;
+  for (int k = 0; k < nb; ++k) {
+    crispy_asr_result_impl* r = impl[live[k]];
+    r->tokens.assign(toks.begin() + (size_t)k * max_new, toks.begin() + (size_t)k * max_new + n_out[k]);
+    for (int t : r->tokens)
+      if (t < h->eot && t < (int)h->vocab.size()) r->text += h->vocab[t];
+  }
+  return CRISPY_OK;
+}
+
+int BatchCall::run() {
+  if (nb == 0) return CRISPY_OK;
+  int rc = upload_and_encode();
+  if (rc != CRISPY_OK) return rc;
+  if (!timestamps) return decode_plain();
+  rc = setup_ladder();
+  if (rc != CRISPY_OK) return rc;
+  rc = seek_loop();
+  if (rc != CRISPY_OK) return rc;
+  for (int k = 0; k < nb; ++k) {
+    crispy_asr_result_impl* r = impl[live[k]];
+    for (const std::string& t : r->seg_text) r->text += t;
+  }
+  if (batch == 1) h->prompt_past = past[0];      // whisper.cpp keeps prompt_past in the state; the next call uses it only with carry_context
+  return CRISPY_OK;
+}
+
+// ---- whisper_full's seek loop, all clips in lock step ----
+// [UPSTREAM-RECALL: whisper_full_with_state].  Per round every clip that has audio left decodes one window:
+//   * prompt = (<|startofprev|> + the last min(n_text_ctx / 2, |past|) tokens of the text so far) + the usual prompt;
+//     the past is dropped when fewer than 5 s of audio are left ("a very short segment ... tends to confuse the
+//     decoder") and for a re-decode at a temperature >= 0.5; after a window: past = the past part of its prompt + its
+//     kept tokens (nothing from a window dropped as silence);
+//   * the temperature ladder: greedy at `temperature`, all clips of the round as ONE batch (their prompts differ in
+//     length: decode_ts left-pads); a clip whose window fails is decoded again at the next temperature with
+//     best_of sampling decoders (rows of one batch over copies of its encoder output), until one passes or the
+//     ladder ends;
+//   * no-speech rule, segments, and how far the window advances (the last closed timestamp pair, the whole
+//     window after a single closing timestamp).
+int BatchCall::setup_ladder() {
+  seek.assign(nb, 0);
+  seek_end.resize(nb);
+  for (int k = 0; k < nb; ++k) seek_end[k] = 1 + (lens[k] + 200 - 400) / 160;      // whisper.cpp's mel.n_len_org
+  const float t0 = opts ? opts->temperature : 0.f;
+  const float t_inc = !opts || opts->temperature_inc == 0.f ? 0.2f : opts->temperature_inc;
+  entropy_thold = !opts || opts->entropy_thold == 0.f ? 2.4f : opts->entropy_thold;
+  logprob_thold = !opts || opts->logprob_thold == 0.f ? -1.0f : opts->logprob_thold;
+  no_speech_thold = !opts || opts->no_speech_thold == 0.f ? 0.6f : opts->no_speech_thold;
+  best_of = std::max(1, !opts || opts->best_of == 0 ? 5 : opts->best_of);
+  if (best_of > 8) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: best_of %d > 8 (WHISPER_MAX_DECODERS)", best_of);
+  if (t_inc > 0.f) for (float t = t0; t < 1.0f + 1e-6f; t += t_inc) temps.push_back(t);
+  else temps.push_back(t0);
+  if (temps.empty()) temps.push_back(t0);
+  use_past = !(opts && opts->no_prev_text);
+  // The conditioning text a chunk starts with [UPSTREAM-RECALL: whisper_full_with_state, prompt_past]: nothing
+  // (no_context = true, whisper.cpp's default); with carry_context what the previous call on this handle ended with;
+  // the caller's initial prompt rotated in front of that.
+  past.assign(nb, {});
+  {
+    std::vector<int> start;
+    if (opts && opts->n_initial_prompt > 0) start.assign(opts->initial_prompt, opts->initial_prompt + opts->n_initial_prompt);
+    if (opts && opts->carry_context) start.insert(start.end(), h->prompt_past.begin(), h->prompt_past.end());
+    for (int k = 0; k < nb; ++k) past[k] = start;
+  }
+  ts_mask = h->d_ts_mask; ts_mask_first = h->d_ts_mask_first;
+  if (opts && opts->suppress_nst) {
+    const int rc = build_nst_masks(h);
+    if (rc != CRISPY_OK) return rc;
+    ts_mask = h->d_ts_mask_nst; ts_mask_first = h->d_ts_mask_first_nst;
+  }
+  // whisper.cpp's BEAM_SEARCH strategy (beam_size > 1): beam_size decoders at temperature 0, best_of above, every pass through
+  // decode_beam (candidates drawn per decoder, sorted, dealt; see there); 0 / 1: the GREEDY strategy
+  beam = opts && opts->beam_size > 1 ? opts->beam_size : 0;
+  rngs.assign(nb, {});
+  for (int k = 0; k < nb; ++k)
+    for (int j = 0; j < std::max(best_of, beam); ++j) rngs[k].emplace_back((unsigned)j);
+  // the decoder workspace for the widest pass of this call, taken once: growing it between the greedy pass and the
+  // first fallback pass freed every buffer and dropped the captured steps.  Widest = the most rows any pass
+  // of the ladder can have: the beam pass at temperature 0 (groups of kLadderRowsMax / beam clips x beam rows) and the
+  // best_of passes above it (kLadderRowsMax / best_of clips x best_of rows) -- ADVICE r5: with beam < best_of the beam
+  // pass is the wider one.
+  auto pass_rows = [&](int n_dec) { return std::min(nb * n_dec, std::max(1, kLadderRowsMax / n_dec) * n_dec); };
+  int rows_max = nb;
+  if (temps.size() > 1 && best_of > 1) rows_max = std::max(rows_max, pass_rows(best_of));
+  if (beam > 1) rows_max = std::max(rows_max, pass_rows(beam));
+  if (rows_max > nb) return reserve_dec(h, rows_max, nb);
+  return CRISPY_OK;
+}
+
+int BatchCall::reserve_enc_rep(int n_clips) {
+  if (n_clips <= enc_rep_clips) return CRISPY_OK;
+  if (d_enc_rep) {                                    // copies into / decodes from the old buffer may be in flight
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    (void)hipFree(d_enc_rep);
+    d_enc_rep = nullptr; enc_rep_clips = 0;
+  }
+  HIP_TRY(hipMalloc(&d_enc_rep, (size_t)n_clips * enc_clip * sizeof(float)));
+  enc_rep_clips = n_clips;
+  return CRISPY_OK;
+}
+
+std::vector<int> BatchCall::build_prompt(int k, int lang_tok, float t_cur) const {
+  std::vector<int> p;
+  if (use_past && !past[k].empty() && t_cur < 0.5f) {
+    int n_take = std::min<int>(h->hp.n_text_ctx / 2, (int)past[k].size());
+    n_take = std::min(n_take, h->hp.n_text_ctx - max_new - n_init - 1);
+    if (n_take > 0) {
+      p.push_back(sp.prev);
+      p.insert(p.end(), past[k].end() - n_take, past[k].end());
+    }
+  }
+  p.insert(p.end(), prompt.begin(), prompt.end());
+  if (sp.multilingual) p[p.size() - n_init + 1] = lang_tok;
+  return p;
+}
+
+int BatchCall::seek_loop() {
+  // whisper.cpp loops until seek + delta_min >= seek_end.  Every round advances every active clip by seek_delta >= 2
+  // (a closed pair ends on a timestamp strictly above <|0.00|>, otherwise the delta is the whole window), so
+  // 1500 rounds cover any 30 s clip; running out of them is reported, never a silently shorter transcript.
+  const int kMaxRounds = 1501;
+  for (int round = 0;; ++round) {
+    if (round >= kMaxRounds)
+      return fail(CRISPY_ERR_HIP, "crispy_asr_transcribe_batch: seek loop did not terminate after %d windows", kMaxRounds);
+    if (cancel && *cancel) return fail(CRISPY_ERR_CANCELLED, "transcription cancelled by the caller");
+    std::vector<int> act;
+    for (int k = 0; k < nb; ++k)
+      if (seek_end[k] >= TS_DELTA_MIN && seek[k] + TS_DELTA_MIN < seek_end[k]) act.push_back(k);   // < 100 ms left: whisper.cpp stops
+    if (act.empty()) return CRISPY_OK;
+    const int na = (int)act.size();
+    if (!(round == 0 && na == nb)) {     // round 0 with every clip active: the encoder output is already there
+      std::vector<int> sk(na);
+      for (int a = 0; a < na; ++a) sk[a] = seek[act[a]];
+      int rc = crispy_mel_window_device(h->mel, act.data(), sk.data(), na, nullptr, h->w_melt, h->stream);
+      if (rc != CRISPY_OK) return rc;
+      rc = crispy_asr_encode_device(h, h->w_melt, na, h->w_enc, h->stream);
+      if (rc != CRISPY_OK) return rc;
+    }
+    for (int a = 0; a < na; ++a) {
+      const int k = act[a];
+      if (seek[k] > 0 && seek[k] + 500 >= seek_end[k]) past[k].clear();
+    }
+    std::vector<Accepted> acc((size_t)na);
+    const int rc = decode_round(act, acc);
+    if (rc != CRISPY_OK) return rc;
+    for (int a = 0; a < na; ++a) finish_window(act[a], acc[a]);
+  }
+}
+
+// the temperature ladder of one round: per active clip, the pass whisper_full ends up accepting
+int BatchCall::decode_round(const std::vector<int>& act, std::vector<Accepted>& acc) {
+  const int na = (int)act.size();
+  std::vector<int> pending((size_t)na);
+  for (int a = 0; a < na; ++a) pending[a] = a;
+  for (size_t it = 0; it < temps.size() && !pending.empty(); ++it) {
+    const float t_cur = temps[it];
+    const bool last_temp = it + 1 == temps.size();
+    const int n_dec = t_cur > 0.f ? best_of : (beam ? beam : 1);
+    std::vector<int> still;
+    // Groups of clips decoded together, n_dec rows each (rows [c n_dec, (c + 1) n_dec) of a group are the decoders of its
+    // clip c: one cross K|V per clip, decode_ts's xgroup).  At temperature 0 that is every pending clip in one group, one
+    // row each, straight off h->w_enc while nothing has dropped out; above it the pending clips x best_of, in groups of
+    // at most kLadderRowsMax rows -- ALL of them side by side, not one clip after the other (a batch in
+    // which a third of the windows fall back used to decode them one by one, five rows at a time).
+    const int per_group = n_dec == 1 && !beam ? (int)pending.size() : std::max(1, kLadderRowsMax / n_dec);
+    for (size_t g0 = 0; g0 < pending.size(); g0 += (size_t)per_group) {
+      const std::vector<int> grp(pending.begin() + g0, pending.begin() + std::min(pending.size(), g0 + (size_t)per_group));
+      GroupPicks picks;
+      const int rc = decode_group(act, grp, t_cur, n_dec, picks);
+      if (rc != CRISPY_OK) return rc;
+      for (int c = 0; c < (int)grp.size(); ++c) {
+        const int a = grp[c];
+        if (!evaluate_clip(a, act[a], c, t_cur, last_temp, n_dec, picks, acc[a])) still.push_back(a);
+      }
+    }
+    pending.swap(still);
+  }
+  return CRISPY_OK;
+}
+
+// one decode of the clips act[grp[c]], n_dec rows each, at t_cur
+int BatchCall::decode_group(const std::vector<int>& act, const std::vector<int>& grp, float t_cur, int n_dec, GroupPicks& out) {
+  const int n_clips = (int)grp.size(), rows = n_clips * n_dec;
+  const float* d_enc = h->w_enc;
+  bool contiguous = true;               // the group's clips are w_enc's first n_clips, in order
+  for (int c = 0; c < n_clips; ++c) contiguous = contiguous && grp[c] == c;
+  int rc;
+  if (!contiguous) {                    // one copy per CLIP (its decoders share it)
+    rc = reserve_enc_rep(n_clips);
+    if (rc != CRISPY_OK) return rc;
+    for (int c = 0; c < n_clips; ++c)
+      HIP_TRY(hipMemcpyAsync(d_enc_rep + (size_t)c * enc_clip, h->w_enc + (size_t)grp[c] * enc_clip, enc_clip * sizeof(float),
+                             hipMemcpyDeviceToDevice, h->stream));
+    d_enc = d_enc_rep;
+  }
+  out.max_new = max_new;
+  out.prompts.assign((size_t)rows, {});
+  std::vector<int> r_seek(rows), r_end(rows);
+  for (int r = 0; r < rows; ++r) {
+    const int k = act[grp[r / n_dec]];
+    out.prompts[r] = build_prompt(k, lang[k], t_cur);
+    r_seek[r] = seek[k]; r_end[r] = seek_end[k];
+  }
+  std::vector<double> u;
+  if (t_cur > 0.f && !beam) {   // the variates decoder j of clip k would draw, from a copy of ITS generator
+    u.resize((size_t)max_new * rows);
+    for (int r = 0; r < rows; ++r) {
+      std::mt19937 g = rngs[act[grp[r / n_dec]]][r % n_dec];
+      for (int i = 0; i < max_new; ++i) u[(size_t)i * rows + r] = canonical(g);
+    }
+  }
+  out.toks.assign((size_t)rows * max_new, 0); out.tids.assign((size_t)rows * max_new, 0); out.n_out.assign(rows, 0);
+  out.plog.assign((size_t)rows * max_new, 0.f); out.nosp.assign(rows, 0.f);
+  if (beam) {
+    std::vector<std::vector<int>> clip_prompts((size_t)n_clips);
+    std::vector<int> c_seek(n_clips), c_end(n_clips);
+    std::vector<std::mt19937*> row_rng((size_t)rows);
+    for (int c = 0; c < n_clips; ++c) {
+      const int k = act[grp[c]];
+      clip_prompts[c] = out.prompts[(size_t)c * n_dec];
+      c_seek[c] = seek[k]; c_end[c] = seek_end[k];
+      for (int j = 0; j < n_dec; ++j) row_rng[(size_t)c * n_dec + j] = &rngs[k][j];
+    }
+    return decode_beam(h, d_enc, n_clips, n_dec, beam, clip_prompts, TS_RULES_WCPP, c_seek.data(), c_end.data(), max_new, ts_mask,
+                       ts_mask_first, t_cur, row_rng, out.toks.data(), out.tids.data(), out.plog.data(), out.nosp.data(), out.n_out.data());
+  }
+  return decode_ts(h, d_enc, rows, out.prompts, TS_RULES_WCPP, r_seek.data(), r_end.data(), max_new, ts_mask, ts_mask_first, t_cur,
+                   t_cur > 0.f ? u.data() : nullptr, out.toks.data(), out.tids.data(), out.plog.data(), out.nosp.data(), out.n_out.data(), n_dec);
+}
+
+// clip k (active index a, clip c of the group): replay its n_dec decoders, rank them, record the best as the accepted pass;
+// returns whether whisper_full is satisfied with it at this temperature
+bool BatchCall::evaluate_clip(int a, int k, int c, float t_cur, bool last_temp, int n_dec, const GroupPicks& g, Accepted& A) {
+  (void)a;
+  const int mn = g.max_new;
+  std::vector<DecoderPass> decs((size_t)n_dec);
+  for (int j = 0; j < n_dec; ++j) {
+    const int r = c * n_dec + j;
+    DecoderPass& d = decs[j];
+    d.toks = g.toks.data() + (size_t)r * mn;
+    d.tids = g.tids.data() + (size_t)r * mn;
+    d.plog = g.plog.data() + (size_t)r * mn;
+    d.n = g.n_out[r];
+    replay_decoder(d, mn, sp.beg, h->eot, seek[k], seek_end[k], TS_DELTA_MIN);
+    if (t_cur > 0.f && !beam) rngs[k][j].discard(2ull * (unsigned long long)d.n);      // what it drew: two per pick (a beam pass drew from the generators themselves)
+  }
+  // rank the sequences that did not fail (whisper.cpp: "rank the resulting sequences and select the best one")
+  int best = A.have ? A.decoder : 0;      // best_decoder_id survives a pass in which every decoder failed
+  if (best >= n_dec) best = 0;
+  double best_score = -INFINITY;
+  for (int j = 0; j < n_dec; ++j) {
+    DecoderPass& d = decs[j];
+    if (d.failed) continue;
+    score_decoder(d);
+    if (d.result_len > 32 && d.entropy < entropy_thold) { d.failed = true; continue; }
+    if (best_score < d.score) { best_score = d.score; best = j; }
+  }
+  const DecoderPass& bd = decs[best];
+  const float clip_nosp = g.nosp[c * n_dec];          // every decoder of a clip saw the same prompt logits
+  const bool success = last_temp || !(bd.failed || (bd.avg_logprobs < logprob_thold && clip_nosp < no_speech_thold));
+  const int r = c * n_dec + best;
+  A.toks.assign(g.toks.begin() + (size_t)r * mn, g.toks.begin() + (size_t)r * mn + bd.n);
+  A.tids.assign(g.tids.begin() + (size_t)r * mn, g.tids.begin() + (size_t)r * mn + bd.n);
+  A.plog.assign(g.plog.begin() + (size_t)r * mn, g.plog.begin() + (size_t)r * mn + bd.n);
+  A.d = bd;
+  A.d.toks = A.toks.data(); A.d.tids = A.tids.data(); A.d.plog = A.plog.data();
+  A.prompt = g.prompts[r];
+  A.nosp = clip_nosp;
+  A.temperature = t_cur;
+  A.decoder = best;
+  A.have = true;
+  return success;
+}
+
+// the accepted pass of clip k's window into its result: conditioning text, segments, tokens, the window record, the seek advance
+void BatchCall::finish_window(int k, const Accepted& A) {
+  crispy_asr_result_impl* r = impl[live[k]];
+  const DecoderPass& d = A.d;
+  // a decoder that failed before the ranking keeps all its tokens (only ranked sequences are cut to result_len)
+  const int n_cur = d.scored ? d.result_len : d.n;
+  const bool is_no_speech = A.nosp > no_speech_thold && d.avg_logprobs < logprob_thold;
+  {
+    std::vector<int> np;
+    if (A.prompt.front() == sp.prev) np.assign(A.prompt.begin() + 1, A.prompt.end() - n_init);
+    if (!is_no_speech) np.insert(np.end(), A.toks.begin(), A.toks.begin() + d.result_len);
+    past[k].swap(np);
+  }
+  int seek_delta = d.seek_delta;
+  if (n_cur > 0 && !is_no_speech) {
+    window_segments(h, A.toks.data(), A.tids.data(), n_cur, sp.beg, seek[k], seek_delta, r);
+    for (int i = 0; i < n_cur; ++i)
+      if (A.toks[i] != h->eot) r->tokens.push_back(A.toks[i]);
+  }
+  // a single closing timestamp: nothing is left to say in this chunk [UPSTREAM-RECALL: whisper.cpp PR 2629]
+  if (n_cur > 1 && A.toks[n_cur - 2] < sp.beg && A.toks[n_cur - 1] > sp.beg)
+    seek_delta = std::min(seek_end[k] - seek[k], 3000);
+  crispy_asr_window w{};
+  w.seek = seek[k]; w.seek_advance = seek_delta; w.n_tokens = is_no_speech ? 0 : n_cur; w.decoder = A.decoder;
+  w.failed = d.failed ? 1 : 0; w.no_speech = is_no_speech ? 1 : 0; w.temperature = A.temperature;
+  w.no_speech_prob = A.nosp; w.avg_logprob = (float)d.avg_logprobs; w.entropy = (float)d.entropy;
+  r->wins.push_back(w);
+  seek[k] += seek_delta;
+}
+
+// cancel (nullable): polled at the top of every round of the seek loop -- a set flag ends the call with
+// CRISPY_ERR_CANCELLED and no results (crispy_asr_transcribe_recording: commands/transcription.rs:251,359,402)
+int transcribe_batch_impl(crispy_asr* h, const float* const* pcm, const size_t* n, int batch, const crispy_asr_opts* opts,
+                          crispy_asr_result** results, const volatile int* cancel) {
+  if (!h || !results) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: NULL argument");
+  if (batch < 0) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: batch < 0");
+  for (int i = 0; i < batch; ++i) results[i] = nullptr;
+  if (batch == 0) return CRISPY_OK;
+  if (!pcm || !n) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: NULL argument");
+  if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_transcribe_batch: model not finalized");
+  BatchCall call(h, pcm, n, batch, opts, cancel);
+  int rc = call.prepare();
+  if (rc == CRISPY_OK) rc = call.run();
+  if (rc != CRISPY_OK) return rc;            // (the call object owns every result it made: nothing reaches the caller)
+  call.release(results);
   return CRISPY_OK;
 }
 
