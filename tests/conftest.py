@@ -10,6 +10,21 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # A GPU run writes straight to the terminal (as with -s).  When the ROCm runtime kills the process -- a memory fault of a
+    # kernel ends in abort() -- what it says goes to file descriptor 2, and under pytest's per-test capture that text died
+    # with the process: round 6 lost the one message that would have named the faulting address of an abort seen once in
+    # three runs (NOTEBOOK 10.6).  The numbers the tests print (error levels, measured ratios) are wanted in the log anyway.
+    expr = getattr(config.option, "markexpr", "") or ""
+    if "gpu" in expr and "not gpu" not in expr:
+        capman = config.pluginmanager.getplugin("capturemanager")
+        if capman is not None:
+            try:
+                capman.stop_global_capturing()
+                capman._method = "no"
+                capman.start_global_capturing()
+            except Exception:
+                if getattr(capman, "_global_capturing", None) is None:
+                    capman.start_global_capturing()
 
 
 @pytest.fixture(scope="session")

@@ -14,11 +14,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _wcpp_masks(hp):
-    from oracle import whisper_oracle as WO
-    sp = WO.special_tokens(hp.n_vocab)
-    sup = [sp["sot"], sp["nosp"], sp["translate"], sp["transcribe"], sp["prev"], sp["solm"]]
-    sup += list(range(sp["lang0"], sp["lang0"] + sp["n_lang"]))
-    return sp, sorted(sup), [220, sp["eot"]]
+    from tests.oracle_cases import wcpp_masks
+    return wcpp_masks(hp)
 
 
 def _engine_file(tmp_path_factory, hp, W, tag):
@@ -171,13 +168,11 @@ def _scripts(hp):
 
 
 def _ref(W, hp, n_samples, eng, mode, **kw):
-    """The oracle's whisper_full on a scripted model (its decoder ignores the audio: the encoder pass is skipped)."""
-    from oracle import whisper_oracle as WO
-    sp, sup, sup_first = _wcpp_masks(hp)
-    enc0 = np.zeros((hp.n_audio_ctx, hp.n_audio_state))
-    return WO.transcribe_timestamps(W, hp, lambda seek: None, n_samples, [sp["sot"], sp["lang0"], sp["transcribe"]],
-                                    WO.RULES_WCPP, eng.token_text, suppress=sup, suppress_first=sup_first, f16=(mode == 1),
-                                    fallback=True, encoder=lambda mel: enc0, **kw)
+    """The oracle's whisper_full on a scripted model (its decoder ignores the audio: the encoder pass is skipped).  It depends on
+    the seeded weights and the options only, and it is 1 300 float64 decoder steps for the ladder model: its result is committed
+    (tests/oracle_cases.py, tests/oracle_cache.py, tests/golden/make_oracle_cache.py) and recomputed when the inputs change."""
+    from tests.oracle_cases import scripted_ref
+    return scripted_ref(W, hp, n_samples, mode, **kw)
 
 
 def _same_windows(got, ref, tol_lp, what):
@@ -212,12 +207,9 @@ def test_temperature_ladder_on_a_scripted_model(oracle, tmp_path_factory, mode):
     from tests.scripted_model import script_rows, scripted_whisper_weights
     hp = HParams.tiny()
     sp, BEG, EOT = _scripts(hp)
-    X, Y, REP = 1234, 2345, 777
-    beta = 1.0 - 1.0 * np.sqrt(2.0) / hp.n_text_state            # logit(X) - logit(Y) = 1 at gain 100
-    bare = [BEG, 1001, [(X, 1.0), (Y, beta)], 1003, BEG + 300, BEG + 300, EOT]
-    rows = script_rows(2, bare)
-    rows.update(script_rows(9, [BEG] + [REP] * 40 + [BEG + 100, BEG + 100, EOT]))
-    W = scripted_whisper_weights(hp, rows, gain=100.0)
+    from tests import oracle_cases as OC
+    X, Y, REP = OC.X_TOK, OC.Y_TOK, OC.REP_TOK
+    W = OC.ladder_model(hp)
     eng = WhisperEngine(_engine_file(tmp_path_factory, hp, W, f"ladder{mode}"))
     eng.set_precision(mode)
     x = synth_audio.clip16k_np(80, 16000 * 13)
@@ -239,9 +231,7 @@ def test_temperature_ladder_on_a_scripted_model(oracle, tmp_path_factory, mode):
         return        # the rest is decision logic that does not depend on the arithmetic: mode 0 runs it (the oracle's 1 300
                       # float64 decoder steps of it are 25 s of a GPU suite with a time limit)
     # ... and a model that repeats itself whatever the prompt
-    rows = script_rows(2, [BEG] + [REP] * 40 + [BEG + 100, BEG + 100, EOT])
-    rows.update(script_rows(46, [BEG] + [REP] * 40 + [BEG + 100, BEG + 100, EOT]))      # window 2: 1 + 43 + 3 tokens of prompt
-    W = scripted_whisper_weights(hp, rows, gain=100.0)
+    W = OC.repeat_model(hp)
     eng = WhisperEngine(_engine_file(tmp_path_factory, hp, W, f"repeat{mode}"))
     eng.set_precision(mode)
     x = synth_audio.clip16k_np(81, 16000 * 4)
@@ -277,8 +267,8 @@ def test_silent_and_noisy_chunks_give_no_text_under_the_no_speech_rule(oracle, t
     from tests.scripted_model import script_rows, scripted_whisper_weights
     hp = HParams.tiny()
     sp, BEG, EOT = _scripts(hp)
-    rows = script_rows(2, [[(BEG, 1.0), (sp["nosp"], 1.0)], 1001, BEG + 1400, BEG + 1400, EOT])
-    W = scripted_whisper_weights(hp, rows, gain=1.0, boost={sp["nosp"]: 6.0})
+    from tests import oracle_cases as OC
+    W = OC.nospeech_model(hp)
     eng = WhisperEngine(_engine_file(tmp_path_factory, hp, W, f"nosp{mode}"))
     eng.set_precision(mode)
     rng = np.random.default_rng(9)
@@ -502,11 +492,9 @@ def test_beam_search_on_a_scripted_model(oracle, tmp_path_factory):
     from tests.scripted_model import script_rows, scripted_whisper_weights
     hp = HParams.tiny()
     sp, BEG, EOT = _scripts(hp)
-    X, Y, REP = 1234, 2345, 777
-    beta = 1.0 - 1.0 * np.sqrt(2.0) / hp.n_text_state
-    rows = script_rows(2, [BEG, 1001, [(X, 1.0), (Y, beta)], 1003, BEG + 300, BEG + 300, EOT])
-    rows.update(script_rows(9, [BEG] + [REP] * 40 + [BEG + 100, BEG + 100, EOT]))
-    W = scripted_whisper_weights(hp, rows, gain=100.0)
+    from tests import oracle_cases as OC
+    X, Y, REP = OC.X_TOK, OC.Y_TOK, OC.REP_TOK
+    W = OC.ladder_model(hp)
     eng = WhisperEngine(_engine_file(tmp_path_factory, hp, W, "beam"))
     x = synth_audio.clip16k_np(80, 16000 * 13)
     text, segs, toks = eng.transcribe_segments(x, language_token=sp["lang0"], beam_size=3)
