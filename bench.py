@@ -407,12 +407,11 @@ def asr_leg(local_rank: int, clips: int = 64, new_tokens: int = 32, ggml_path: s
         # clip after clip: ~64 x the single-clip time by construction)
         from crispy_amd.asr import transcribe_batch
         clips = [np.ascontiguousarray(pcm[i % pcm.shape[0]].cpu().numpy()[:16000 * 28]) for i in range(64)]
-        eng = type("E", (), {"_h": model._h})()
-        transcribe_batch(eng, clips, timestamps=True)
+        transcribe_batch(model, clips, timestamps=True)
         ts = []
         for _ in range(2):
             t0 = time.perf_counter()
-            res = transcribe_batch(eng, clips, timestamps=True, with_segments=True)
+            res = transcribe_batch(model, clips, timestamps=True, with_segments=True)
             ts.append(time.perf_counter() - t0)
         out["batch_ladder"] = {"clips": 64, "ms": float(np.median(ts)) * 1e3, "single_clip_ms": out["ms"],
                                "ratio_to_single_clip": float(np.median(ts)) * 1e3 / out["ms"],

@@ -90,13 +90,12 @@ int crispy_mel_create(const float* filters, int n_mel, int device, crispy_mel** 
     for (int k = 0; k < MEL_BINS; ++k)
       if (filters[m * MEL_BINS + k] != 0.f) { if (k0 < 0) k0 = k; k1 = k; }
     const int len = k0 < 0 ? 0 : k1 - k0 + 1;
-    if (off + len > MEL_MAX_MELS * 64) {
+    if (len > 64 || off + len > MEL_FW_MAX) {
       delete tab;
-      return fail(CRISPY_ERR_BAD_MODEL, "crispy_mel_create: filter bank is not triangular-sparse");
+      return fail(CRISPY_ERR_BAD_MODEL, "crispy_mel_create: filter bank is not triangular-sparse (a filter spans %d bins of at most 64, "
+                  "the bank %d of at most %d)", len, off + len, MEL_FW_MAX);
     }
-    tab->f_start[m] = k0 < 0 ? 0 : k0;
-    tab->f_len[m] = len;
-    tab->f_off[m] = off;
+    tab->f_meta[m] = (k0 < 0 ? 0 : k0) | len << 8 | off << 16;
     for (int q = 0; q < len; ++q) tab->f_w[off + q] = filters[m * MEL_BINS + k0 + q];
     off += len;
   }

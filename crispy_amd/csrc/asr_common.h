@@ -31,11 +31,12 @@ constexpr int MEL_RAW_FRAMES = MEL_TILE * MEL_TILES;   // all of them are kept: 
 constexpr int MEL_BINS = 201;
 constexpr int MEL_MAX_MELS = 128;
 
+constexpr int MEL_FW_MAX = 1024;   // non-zero taps of a whole filter bank: the tables of a workgroup live in LDS
 struct MelTables {
   float hann[400];
   float2 w400[400];                // exp(-2 pi i k / 400)
-  int f_start[MEL_MAX_MELS], f_len[MEL_MAX_MELS], f_off[MEL_MAX_MELS];
-  float f_w[MEL_MAX_MELS * 64];    // concatenated non-zero filter weights
+  int f_meta[MEL_MAX_MELS];        // per mel bin: first FFT bin | taps << 8 | offset into f_w << 16
+  float f_w[MEL_FW_MAX];           // concatenated non-zero filter weights (Whisper's banks: 391 / 394 of them)
 };
 
 struct MelArgs {
@@ -320,20 +321,50 @@ struct TsPickArgs {
   float* x_scratch;                    // sampling: [B][TS_SCRATCH_ROW] floats, the rule-filtered row between the kernel's passes
   StepFuse fuse;
   // beam search (whisper_sample_token_topk [UPSTREAM-RECALL]): n_cand > 0 -- every row that is not done draws n_cand ids
-  // from ITS distribution with the variates u_all[b][0 .. n_cand) and records them (id, log-probability, most probable
-  // timestamp) in cand_*[b][n_cand]; nothing is committed: which candidate a decoder continues with is the host's
-  // decision (whisper_api.cpp: decode_beam), which writes the rows' states back before the next step.
+  // from ITS distribution with the variates u_all[step][b][0 .. n_cand) and records them (id, log-probability, most probable
+  // timestamp) in cand_*[b][n_cand]; nothing is committed: which candidate a decoder continues with is decided by
+  // beam_advance (below), which writes the rows' states before the next step.
   int n_cand;
   int* cand_tok; float* cand_plog; int* cand_tid;
 };
 constexpr int TS_MAX_CAND = 8;          // = WHISPER_MAX_DECODERS
 constexpr int TS_SCRATCH_ROW = 7 * 8192;  // ts_sample_kernel: TS_NB blocks of TS_BLK ids per row
 hipError_t ts_pick(const TsPickArgs& a, int B, hipStream_t s);
-// Beam search: row r of a self K | V cache [layers][rows][row_bytes] continues the sequence of row parent[r] -- the bytes
-// [off, off + len) of every layer's row parent[r] become row r's (rows with parent[r] == r are left alone).  Two launches
-// through `scratch` [layers][rows][len] (a row may be somebody's parent and somebody else's child).  len % 16 == 0.
-hipError_t beam_kv_reorder(void* kv, void* scratch, const int* parent_dev, int layers, int rows, long row_bytes, long off, long len,
-                           hipStream_t s);
+// Beam search: row r of a self K | V cache [layers][rows][row_bytes] continues the sequence of row parent[r] -- the cache rows
+// of the positions generated so far, [counters[4], counters[0]) (read on the device: part of a captured step), of every
+// layer's row parent[r] become row r's (rows with parent[r] == r are left alone).  Two launches through `scratch`
+// [layers][rows][counters[5] * pos_bytes] (a row may be somebody's parent and somebody else's child).  pos_bytes % 16 == 0.
+hipError_t beam_kv_reorder(void* kv, void* scratch, const int* parent_dev, int layers, int rows, long row_bytes, long pos_bytes,
+                           const int* counters, hipStream_t s);
+// One step of whisper_full's BEAM_SEARCH strategy, decided on the device (one wave per clip) so that the step is captured
+// and replayed like a greedy one: the candidates the pick kernel drew for the clip's live decoders (TsPickArgs::n_cand) are
+// sorted by the sum of all log-probabilities (ties: decoder, draw) and dealt to the live decoders, skipping repeats of the
+// sequence just dealt; a decoder takes its candidate's sequence and bookkeeping (BeamRow, TsState), then completion / failure
+// on its new last token.  A step's record (id, timestamp id, log-probability, the row the sequence came from) goes to
+// rec_*[step][row]: the host walks the parents back from every row's end (BeamRow::n) once the pass is over.
+// eqid: two live decoders of a clip hold the same token sequence exactly when their eqid are equal (all equal before the
+// first step; afterwards the first decoder dealt the same (parent class, id) this step) -- whisper_sequence_tokens_equal
+// without the sequences.  fuse.x != nullptr: the kernel also embeds every row's next input (its new id, EOT once ended) at
+// the step's position and moves the counters on, as a fused pick does.
+struct BeamRow {
+  double sum_all;                      // sum of the log-probabilities of all its tokens
+  int has_ts, failed, completed, seek_delta, result_len;
+  int n;                               // tokens in its sequence
+  int eqid, pad;
+};
+struct BeamArgs {
+  TsState* st;                         // [rows]
+  BeamRow* row;                        // [rows]
+  const int* cand_tok; const int* cand_tid; const float* cand_plog;      // [rows][n_cand]
+  int n_dec, n_cand, rows, beg, eot, rules, delta_min;
+  int* rec_tok; int* rec_tid; float* rec_plog; int* rec_parent;         // [max_new][rows]
+  int* parent;                         // [rows] for this step's beam_kv_reorder
+  int* feed;                           // [rows] the next decoder step's input ids
+  int* done_count;                     // decoders that have ended
+  const int* counters;                 // {position of the previous step, index of this step, ticket, -, first generated cache row, max_new}
+  StepFuse fuse;
+};
+hipError_t beam_advance(const BeamArgs& a, int n_clips, hipStream_t s);
 // p_out[b] = softmax(logits[b])[token] over the whole, unfiltered row (whisper_full's no_speech_prob)
 hipError_t softmax_prob_f32(const float* logits, int V, long ld, int token, float* p_out, int B, hipStream_t s);
 

@@ -41,7 +41,7 @@ int reserve_dec(crispy_asr* h, int batch, int xclips) {
   HIP_TRY(hipMalloc(&h->d_best, B * C * sizeof(float)));
   HIP_TRY(hipMalloc(&h->d_tok, R * sizeof(int)));
   HIP_TRY(hipMalloc(&h->d_tokens_all, B * C * sizeof(int)));
-  HIP_TRY(hipMalloc(&h->d_counters, 4 * sizeof(int)));      // position, pick index, ticket of the fused pick, spare
+  HIP_TRY(hipMalloc(&h->d_counters, 8 * sizeof(int)));      // position, pick index, ticket of the fused pick, spare; beam pass: first generated cache row, max_new
   HIP_TRY(hipMalloc(&h->d_ts_state, B * sizeof(TsState)));
   HIP_TRY(hipMalloc(&h->d_tids_all, B * C * sizeof(int)));
   HIP_TRY(hipMalloc(&h->d_done_count, sizeof(int)));
@@ -54,6 +54,9 @@ int reserve_dec(crispy_asr* h, int batch, int xclips) {
   HIP_TRY(hipMalloc(&h->d_temperature, sizeof(float)));
   HIP_TRY(hipMalloc(&h->d_row_off, B * sizeof(int)));
   HIP_TRY(hipMalloc(&h->d_beam_parent, B * sizeof(int)));
+  HIP_TRY(hipMalloc(&h->d_beam_row, B * sizeof(BeamRow)));
+  HIP_TRY(hipMalloc(&h->d_beam_cand, B * 3 * TS_MAX_CAND * sizeof(int)));
+  HIP_TRY(hipMalloc(&h->d_beam_rec_parent, B * C * sizeof(int)));
   if (fused_decode_supported((int)dt, 1, (int)Tn)) {
     for (int i = 0; i < 3; ++i) {
       HIP_TRY(hipMalloc(&h->d_fx[i], B * dt * sizeof(float)));
@@ -796,105 +799,23 @@ double canonical(std::mt19937& g) {
   return u < 1.0 ? u : std::nextafter(1.0, 0.0);
 }
 
-// one decoder of a beam pass: its sequence so far and whisper_full's bookkeeping over it
-struct BeamSeq {
-  std::vector<int> toks, tids;
-  std::vector<float> plog;
-  double sum_all = 0.0;
-  bool has_ts = false, failed = false, completed = false;
-  int seek_delta = 3000, result_len = 0;
-  TsState st;
-};
-// what the pick kernel drew for every row of the step: n_cand candidates each (id, timestamp id, log-probability)
-struct BeamDraw {
-  int n_cand;
-  std::vector<int> tok, tid;
-  std::vector<float> plog;
-};
-
-// Step i of one clip (decoders seq[r0 .. r0 + n_dec)): sort its candidates, deal them to the live decoders, then completion /
-// failure of every live decoder on its new last token.  parent[r] = the row decoder r's sequence came from; *moved: some
-// decoder took another's sequence (their cache rows must follow); *any_live: a decoder of this clip goes on.
-int beam_advance_clip(const crispy_asr* h, const Special& sp, int rules, int r0, int n_dec, int i, int max_new, const BeamDraw& dr,
-                      std::vector<BeamSeq>& seq, std::vector<int>& parent, bool* moved, bool* any_live) {
-  struct Cand { int j, k; double sum; };
-  const int n_cand = dr.n_cand;
-  std::vector<Cand> cands;
-  for (int j = 0; j < n_dec; ++j) {
-    const BeamSeq& q = seq[r0 + j];
-    if (q.completed || q.failed) continue;
-    for (int k = 0; k < n_cand; ++k) {
-      const size_t x = (size_t)(r0 + j) * n_cand + k;
-      if (dr.tok[x] < 0 || dr.tok[x] >= h->hp.n_vocab) return fail(CRISPY_ERR_HIP, "beam decode: candidate id %d", dr.tok[x]);
-      cands.push_back(Cand{j, k, q.sum_all + (double)dr.plog[x]});
-    }
-  }
-  if (cands.empty()) return CRISPY_OK;
-  std::stable_sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) {
-    if (a.sum != b.sum) return a.sum > b.sum;
-    return a.j < b.j;
-  });
-  auto tok_of = [&](const Cand& x) { return dr.tok[(size_t)(r0 + x.j) * n_cand + x.k]; };
-  auto same = [&](const Cand& a, const Cand& b) {      // whisper_sequence_tokens_equal of the two candidates' sequences
-    return tok_of(a) == tok_of(b) && (a.j == b.j || seq[r0 + a.j].toks == seq[r0 + b.j].toks);
-  };
-  std::vector<BeamSeq> next(seq.begin() + r0, seq.begin() + r0 + n_dec);
-  size_t cur_c = 0;
-  for (int j = 0; j < n_dec; ++j) {
-    if (seq[r0 + j].completed || seq[r0 + j].failed) continue;
-    if (cur_c >= cands.size()) cur_c = 0;
-    const Cand cur = cands[cur_c++];
-    while (cands.size() > cur_c && i > 0 && same(cands[cur_c], cur)) ++cur_c;
-    const size_t x = (size_t)(r0 + cur.j) * n_cand + cur.k;
-    BeamSeq q = seq[r0 + cur.j];
-    q.toks.push_back(dr.tok[x]); q.tids.push_back(dr.tid[x]); q.plog.push_back(dr.plog[x]);
-    q.sum_all = cur.sum;
-    // the rules' view of the sequence (the pick kernel's ts_commit)
-    q.st.prev = q.st.last; q.st.last = dr.tok[x]; q.st.n += 1;
-    if (rules == TS_RULES_OPENAI ? dr.tok[x] >= sp.beg : dr.tok[x] > sp.beg) q.st.last_ts = dr.tok[x];
-    next[j] = std::move(q);
-    parent[r0 + j] = r0 + cur.j;
-    *moved = *moved || cur.j != j;
-  }
-  std::move(next.begin(), next.end(), seq.begin() + r0);
-  // completion / failure of every live decoder on its new last token
-  for (int j = 0; j < n_dec; ++j) {
-    BeamSeq& d = seq[r0 + j];
-    if (d.completed || d.failed) continue;
-    const int t = d.toks.back();
-    const int sk = d.st.seek, se = d.st.seek_end;
-    if (t > sp.beg) {
-      const int sd = 2 * (t - sp.beg);
-      if (d.has_ts && d.seek_delta > sd && d.result_len < i) { d.failed = true; continue; }      // "do not allow to go back in time"
-      d.seek_delta = sd; d.result_len = i + 1; d.has_ts = true;
-    }
-    if (t == h->eot || (d.has_ts && sk + d.seek_delta + TS_DELTA_MIN >= se)) {
-      if (d.result_len == 0) {
-        if (sk + d.seek_delta + TS_DELTA_MIN >= se) d.result_len = i + 1;
-        else { d.failed = true; continue; }
-      }
-      d.completed = true;
-      continue;
-    }
-    if (i == max_new - 1 && (d.result_len == 0 || d.seek_delta < 1500)) { d.failed = true; continue; }
-    *any_live = true;
-  }
-  return CRISPY_OK;
-}
-
 // One pass of whisper_full's BEAM_SEARCH strategy over one window per clip [UPSTREAM-RECALL: whisper_full_with_state,
 // whisper_sample_token_topk; restated in oracle/whisper_oracle.py: decode_temperature(beam_size=)].  Every clip has n_dec
 // decoders (rows [c n_dec, (c + 1) n_dec): beam_size of them at temperature 0, best_of above) over ONE cross K | V.  Per step:
 //   * every decoder that is neither completed nor failed DRAWS n_cand ids from its distribution (std::discrete_distribution
 //     over the probabilities the rules leave at this temperature, n_cand variates from the decoder's own generator -- the
-//     device pick kernel in its candidate form) -> candidates (decoder, sequence + id, sum of ALL log-probabilities);
+//     pick kernel in its candidate form) -> candidates (decoder, sequence + id, sum of ALL log-probabilities);
 //   * the clip's candidates are sorted by that sum (descending; ties: decoder index) and dealt to the live decoders in
 //     order, skipping candidates whose token sequence equals the one just dealt (not at the first step); a decoder takes
-//     the candidate's sequence, window state and -- on the device -- the self K | V rows of the decoder it came from;
-//   * completion / failure bookkeeping as in the sampling pass; the next decoder step feeds every live row its last id.
-// The host decides between steps (one round trip per token: this is the strategy's structure, not a captured loop).
-// rng[r]: the generator of row r's decoder; it advances by n_cand variates per step the decoder is live.
-// Outputs as decode_ts: the sequence every decoder ENDS with.
+//     the candidate's sequence, window state and the self K | V rows of the decoder it came from; completion / failure
+//     bookkeeping as in the sampling pass (beam_advance_kernel, one wave per clip; beam_kv_reorder);
+//   * the next decoder step feeds every live row its last id.
+// All of it on the device: a step is captured and replayed like a greedy one (pick, deal, cache reorder, decoder step), four
+// per graph launch, the host asking every 8 tokens whether every decoder has ended.  What the generators would have yielded is
+// drawn ahead: rng[r] is the generator of row r's decoder, a decoder consumes n_cand variates per step it is live, so its
+// variates of step i are the i-th n_cand of its stream whatever the other decoders do; the generators themselves are
+// moved on afterwards by what their decoders consumed.
+// Outputs as decode_ts: the sequence every decoder ENDS with (the steps' records walked back through the parents).
 int decode_beam(crispy_asr* h, const float* d_enc, int n_clips, int n_dec, int n_cand, const std::vector<std::vector<int>>& clip_prompts,
                 int rules, const int* seek, const int* seek_end, int max_new, const unsigned char* mask, const unsigned char* mask_first,
                 float temperature, const std::vector<std::mt19937*>& rng, int* tokens_out, int* tids_out, float* plog_out,
@@ -903,7 +824,7 @@ int decode_beam(crispy_asr* h, const float* d_enc, int n_clips, int n_dec, int n
   hipStream_t s = h->stream;
   const int rows = n_clips * n_dec;
   if (n_clips < 1 || n_dec < 1 || n_dec > TS_MAX_CAND || n_cand < 1 || n_cand > TS_MAX_CAND || (int)clip_prompts.size() != n_clips ||
-      (int)rng.size() != rows)
+      (int)rng.size() != rows || max_new < 1)
     return fail(CRISPY_ERR_INVALID_ARG, "beam decode: %d clips x %d decoders, %d candidates", n_clips, n_dec, n_cand);
   int n_rows = 0;
   for (const auto& p : clip_prompts) {
@@ -925,6 +846,27 @@ int decode_beam(crispy_asr* h, const float* d_enc, int n_clips, int n_dec, int n
     off[r] = n_rows - (int)p.size();
     std::copy(p.begin(), p.end(), tok_mat.begin() + (size_t)r * n_rows + off[r]);
   }
+  // the bytes of a row's cache the decoders of a clip can differ in (the generated positions), and the variates of the pass:
+  // both grow with the pass, and a captured step holds their addresses
+  const size_t esz = self_kv_half(h, rows) ? 2 : 4;
+  const size_t row_bytes = (size_t)C * 2 * dt * esz, pos_bytes = (size_t)2 * dt * esz;
+  const size_t need_kv = (size_t)L * rows * (size_t)max_new * pos_bytes, need_u = (size_t)max_new * rows * n_cand * sizeof(double);
+  if (need_kv > h->beam_kv_bytes || need_u > h->beam_u_bytes) {
+    HIP_TRY(hipStreamSynchronize(s));
+    h->drop_graphs();
+    if (need_kv > h->beam_kv_bytes) {
+      if (h->d_beam_kv) (void)hipFree(h->d_beam_kv);
+      h->d_beam_kv = nullptr; h->beam_kv_bytes = 0;
+      HIP_TRY(hipMalloc(&h->d_beam_kv, need_kv));
+      h->beam_kv_bytes = need_kv;
+    }
+    if (need_u > h->beam_u_bytes) {
+      if (h->d_beam_u) (void)hipFree(h->d_beam_u);
+      h->d_beam_u = nullptr; h->beam_u_bytes = 0;
+      HIP_TRY(hipMalloc(&h->d_beam_u, need_u));
+      h->beam_u_bytes = need_u;
+    }
+  }
   HIP_TRY(hipMemcpyAsync(h->d_row_off, off.data(), sizeof(int) * rows, hipMemcpyHostToDevice, s));
   HIP_TRY(hipStreamSynchronize(s));
   struct OffGuard { crispy_asr* h; ~OffGuard() { h->cur_row_off = nullptr; h->cur_xgroup = 1; } } guard{h};
@@ -936,76 +878,87 @@ int decode_beam(crispy_asr* h, const float* d_enc, int n_clips, int n_dec, int n
   const Special sp = special_tokens(h);
   HIP_TRY(softmax_prob_f32(h->d_logits, h->hp.n_vocab, logits_ld(h), sp.nosp, h->d_nosp, rows, s));
   const float t_eff = temperature > 0.f ? temperature : 1.0f;       // temperature 0: the logits as they are (x / 1)
-  HIP_TRY(hipMemcpyAsync(h->d_temperature, &t_eff, sizeof(float), hipMemcpyHostToDevice, s));
-  // the bytes of a row's cache the decoders of a clip can differ in: the generated positions
-  const size_t esz = self_kv_half(h, rows) ? 2 : 4;
-  const size_t row_bytes = (size_t)C * 2 * dt * esz, pos_bytes = (size_t)2 * dt * esz;
-  const size_t need = (size_t)L * rows * (size_t)max_new * pos_bytes;
-  if (need > h->beam_kv_bytes) {
-    if (h->d_beam_kv) (void)hipFree(h->d_beam_kv);
-    h->d_beam_kv = nullptr; h->beam_kv_bytes = 0;
-    HIP_TRY(hipMalloc(&h->d_beam_kv, need));
-    h->beam_kv_bytes = need;
+  // u[step][row][k]: variate step * n_cand + k of the row's generator (a copy draws; the generator is moved on below)
+  std::vector<double> u((size_t)max_new * rows * n_cand);
+  for (int r = 0; r < rows; ++r) {
+    std::mt19937 g = *rng[r];
+    for (int i = 0; i < max_new; ++i)
+      for (int k = 0; k < n_cand; ++k) u[((size_t)i * rows + r) * n_cand + k] = canonical(g);
   }
-  std::vector<BeamSeq> seq((size_t)rows);
+  std::vector<TsState> st((size_t)rows);
+  std::vector<BeamRow> br((size_t)rows);
   for (int r = 0; r < rows; ++r) {
     const int c = r / n_dec;
-    seq[r].st = TsState{-1, -1, 0, -1, 0, seek ? seek[c] : 0, seek_end ? seek_end[c] : (1 << 30), 0};
+    st[r] = TsState{-1, -1, 0, -1, 0, seek ? seek[c] : 0, seek_end ? seek_end[c] : (1 << 30), 0};
+    br[r] = BeamRow{0.0, 0, 0, 0, 3000, 0, 0, 0, 0};
   }
+  // {position of the previous step, index of the next pick, ticket, spare, first generated cache row, max_new}
+  const int counters[6] = {pos - 1, 0, 0, 0, pos, max_new};
+  HIP_TRY(hipMemcpyAsync(h->d_counters, counters, sizeof(counters), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->d_ts_state, st.data(), sizeof(TsState) * rows, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->d_beam_row, br.data(), sizeof(BeamRow) * rows, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(h->d_done_count, 0, sizeof(int), s));
+  HIP_TRY(hipMemcpyAsync(h->d_temperature, &t_eff, sizeof(float), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->d_beam_u, u.data(), u.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));
   TsPickArgs pa = ts_args(h, rules, mask, mask_first);
-  pa.u_all = h->d_u_all;
+  pa.u_all = h->d_beam_u;
   pa.n_cand = n_cand;
-  pa.cand_tok = h->d_tokens_all; pa.cand_plog = h->d_plog_all; pa.cand_tid = h->d_tids_all;
-  std::vector<double> u((size_t)rows * n_cand);
-  std::vector<TsState> st((size_t)rows);
-  BeamDraw dr;
-  dr.n_cand = n_cand;
-  dr.tok.resize((size_t)rows * n_cand); dr.tid.resize((size_t)rows * n_cand); dr.plog.resize((size_t)rows * n_cand);
-  std::vector<int> parent((size_t)rows), feed((size_t)rows);
-  for (int i = 0; i < max_new; ++i) {
-    for (int r = 0; r < rows; ++r) {
-      const bool live = !(seq[r].completed || seq[r].failed);
-      for (int k = 0; k < n_cand; ++k) u[(size_t)r * n_cand + k] = live ? canonical(*rng[r]) : 0.5;
-      st[r] = seq[r].st;
-      st[r].done = live ? 0 : 1;
-    }
-    HIP_TRY(hipMemcpyAsync(h->d_u_all, u.data(), u.size() * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(h->d_ts_state, st.data(), st.size() * sizeof(TsState), hipMemcpyHostToDevice, s));
-    HIP_TRY(ts_pick(pa, rows, s));
-    HIP_TRY(hipMemcpyAsync(dr.tok.data(), h->d_tokens_all, dr.tok.size() * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(dr.tid.data(), h->d_tids_all, dr.tid.size() * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(dr.plog.data(), h->d_plog_all, dr.plog.size() * sizeof(float), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    bool moved = false, any_live = false;
-    for (int r = 0; r < rows; ++r) parent[r] = r;
-    for (int c = 0; c < n_clips; ++c) {
-      rc = beam_advance_clip(h, sp, rules, c * n_dec, n_dec, i, max_new, dr, seq, parent, &moved, &any_live);
-      if (rc != CRISPY_OK) return rc;
-    }
-    if (!any_live || i == max_new - 1) break;
-    if (moved && i > 0) {
-      HIP_TRY(hipMemcpyAsync(h->d_beam_parent, parent.data(), sizeof(int) * rows, hipMemcpyHostToDevice, s));
-      HIP_TRY(beam_kv_reorder(h->d_selfkv, h->d_beam_kv, h->d_beam_parent, L, rows, (long)row_bytes, (long)((size_t)pos * pos_bytes),
-                              (long)((size_t)i * pos_bytes), s));
-    }
-    for (int r = 0; r < rows; ++r) feed[r] = (seq[r].completed || seq[r].failed || seq[r].toks.empty()) ? h->eot : seq[r].toks.back();
-    HIP_TRY(hipMemcpyAsync(h->d_tok, feed.data(), sizeof(int) * rows, hipMemcpyHostToDevice, s));
-    rc = decoder_step(h, rows, pos + i, false, true, s);
+  pa.cand_tok = h->d_beam_cand; pa.cand_tid = h->d_beam_cand + (size_t)h->dcap_batch * TS_MAX_CAND;
+  pa.cand_plog = reinterpret_cast<float*>(h->d_beam_cand + 2 * (size_t)h->dcap_batch * TS_MAX_CAND);
+  BeamArgs ba{};
+  ba.st = h->d_ts_state; ba.row = h->d_beam_row;
+  ba.cand_tok = pa.cand_tok; ba.cand_tid = pa.cand_tid; ba.cand_plog = pa.cand_plog;
+  ba.n_dec = n_dec; ba.n_cand = n_cand; ba.rows = rows; ba.beg = sp.beg; ba.eot = h->eot; ba.rules = rules; ba.delta_min = TS_DELTA_MIN;
+  ba.rec_tok = h->d_tokens_all; ba.rec_tid = h->d_tids_all; ba.rec_plog = h->d_plog_all; ba.rec_parent = h->d_beam_rec_parent;
+  ba.parent = h->d_beam_parent; ba.feed = h->d_tok; ba.done_count = h->d_done_count; ba.counters = h->d_counters;
+  int steps_run = 1;
+  if (max_new > 1) {
+    const crispy_asr::TsKey key{h->dec_max_keys <= 128 ? 0 : h->dec_max_keys <= 256 ? 1 : 2, 16 + n_cand, rows, n_dec, rules, mask, 1};
+    BeamArgs bf = ba;                       // the deal of a replay also embeds the rows' next inputs and moves the counters on
+    bf.fuse = step_fuse(h);
+    int ran = 0;
+    rc = run_steps(h, key, rows, max_new - 1, [&]() -> int {
+      HIP_TRY(ts_pick(pa, rows, s));
+      HIP_TRY(beam_advance(bf, n_clips, s));
+      HIP_TRY(beam_kv_reorder(h->d_selfkv, h->d_beam_kv, h->d_beam_parent, L, rows, (long)row_bytes, (long)pos_bytes, h->d_counters, s));
+      return decoder_step(h, rows, 0, true, true, s, true);
+    }, &ran);
     if (rc != CRISPY_OK) return rc;
+    steps_run += ran;
   }
-  std::vector<float> nosp(rows);
+  HIP_TRY(ts_pick(pa, rows, s));            // the last step needs no further decoder step
+  HIP_TRY(beam_advance(ba, n_clips, s));
+  std::vector<int> rec_tok((size_t)steps_run * rows), rec_tid((size_t)steps_run * rows), rec_par((size_t)steps_run * rows);
+  std::vector<float> rec_plog((size_t)steps_run * rows), nosp(rows);
+  HIP_TRY(hipMemcpyAsync(rec_tok.data(), h->d_tokens_all, rec_tok.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(rec_tid.data(), h->d_tids_all, rec_tid.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(rec_par.data(), h->d_beam_rec_parent, rec_par.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(rec_plog.data(), h->d_plog_all, rec_plog.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(br.data(), h->d_beam_row, sizeof(BeamRow) * rows, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(nosp.data(), h->d_nosp, nosp.size() * sizeof(float), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   for (int r = 0; r < rows; ++r) {
-    const BeamSeq& q = seq[r];
-    const int n = std::min<int>((int)q.toks.size(), max_new);
+    const int n = br[r].n;
+    if (n < 0 || n > steps_run || n > max_new) return fail(CRISPY_ERR_HIP, "beam decode: row %d ends with %d tokens after %d steps", r, n, steps_run);
     for (int i = 0; i < max_new; ++i) {
-      tokens_out[(size_t)r * max_new + i] = i < n ? q.toks[i] : h->eot;
-      if (tids_out) tids_out[(size_t)r * max_new + i] = i < n ? q.tids[i] : sp.beg;
-      if (plog_out) plog_out[(size_t)r * max_new + i] = i < n ? q.plog[i] : 0.f;
+      tokens_out[(size_t)r * max_new + i] = h->eot;
+      if (tids_out) tids_out[(size_t)r * max_new + i] = sp.beg;
+      if (plog_out) plog_out[(size_t)r * max_new + i] = 0.f;
+    }
+    int row = r;
+    for (int i = n - 1; i >= 0; --i) {       // token i was dealt to `row` at step i, from the decoder rec_par names
+      const size_t x = (size_t)i * rows + row;
+      if (row / n_dec != r / n_dec || rec_tok[x] < 0 || rec_tok[x] >= h->hp.n_vocab)
+        return fail(CRISPY_ERR_HIP, "beam decode: the record of row %d, step %d is not a decoder of its clip", r, i);
+      tokens_out[(size_t)r * max_new + i] = rec_tok[x];
+      if (tids_out) tids_out[(size_t)r * max_new + i] = rec_tid[x];
+      if (plog_out) plog_out[(size_t)r * max_new + i] = rec_plog[x];
+      row = rec_par[x];
     }
     if (nosp_out) nosp_out[r] = nosp[r];
     if (n_out) n_out[r] = n;
+    rng[r]->discard(2ull * (unsigned long long)n_cand * (unsigned long long)n);      // a decoder was live for exactly the steps that dealt it a token
   }
   return CRISPY_OK;
 }

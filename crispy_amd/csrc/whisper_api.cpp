@@ -195,6 +195,10 @@ void free_dec_ws(crispy_asr* h) {
   if (h->d_ts_x) { (void)hipFree(h->d_ts_x); h->d_ts_x = nullptr; }
   if (h->d_beam_kv) { (void)hipFree(h->d_beam_kv); h->d_beam_kv = nullptr; h->beam_kv_bytes = 0; }
   if (h->d_beam_parent) { (void)hipFree(h->d_beam_parent); h->d_beam_parent = nullptr; }
+  if (h->d_beam_row) { (void)hipFree(h->d_beam_row); h->d_beam_row = nullptr; }
+  if (h->d_beam_cand) { (void)hipFree(h->d_beam_cand); h->d_beam_cand = nullptr; }
+  if (h->d_beam_rec_parent) { (void)hipFree(h->d_beam_rec_parent); h->d_beam_rec_parent = nullptr; }
+  if (h->d_beam_u) { (void)hipFree(h->d_beam_u); h->d_beam_u = nullptr; h->beam_u_bytes = 0; }
   if (h->d_temperature) { (void)hipFree(h->d_temperature); h->d_temperature = nullptr; }
   if (h->d_row_off) { (void)hipFree(h->d_row_off); h->d_row_off = nullptr; }
   if (h->d_gvpart) { (void)hipFree(h->d_gvpart); h->d_gvpart = nullptr; }

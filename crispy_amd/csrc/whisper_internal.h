@@ -173,6 +173,10 @@ struct crispy_asr {
   const int* cur_row_off = nullptr;          // d_row_off while a window decode is running, else nullptr (decoder_step reads it)
   void* d_beam_kv = nullptr; size_t beam_kv_bytes = 0;      // beam search: the rows' cache bytes in flight between parents and children
   int* d_beam_parent = nullptr;              // [dcap_batch]
+  crispy::BeamRow* d_beam_row = nullptr;             // [dcap_batch] a decoder's bookkeeping (beam_advance_kernel)
+  int* d_beam_cand = nullptr;                // [3][dcap_batch][TS_MAX_CAND] the candidates of a step: ids, timestamp ids, log-probabilities
+  int* d_beam_rec_parent = nullptr;          // [n_text_ctx][dcap_batch] the row a step's sequence came from
+  double* d_beam_u = nullptr; size_t beam_u_bytes = 0;      // [max_new][rows][n_cand] the variates of a beam pass
   int cur_xgroup = 1;                        // rows per audio clip while a window decode is running: the best-of decoders of a clip are
                                              // rows of their own (own self K|V cache) over ONE cross K|V (decode_ts)
   void drop_graphs() {
@@ -201,8 +205,9 @@ long logits_ld(const crispy_asr* h);
 int reserve_dec(crispy_asr* h, int batch, int xclips = 0);
 bool gemv_ref_ok(const QRef& r);
 // rows of one group of fallback passes (whole clips x best_of); a grouping choice only -- every row's bits are those of
-// its clip decoded alone
-constexpr int kLadderRowsMax = 128;
+// its clip decoded alone.  The widest step the decode kernels take (SKINNY_MAX_M): a row costs less in a wide step (2.3 us at
+// 512 rows against 2.6 at 128, Whisper-tiny), and 64 clips x best_of 5 are one group instead of three.
+constexpr int kLadderRowsMax = 512;
 struct Special {
   int sot, lang0, n_lang, n_lang_slots, translate, transcribe, solm, prev, nosp, not_, beg;
   bool multilingual;

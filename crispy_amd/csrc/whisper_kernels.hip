@@ -1052,7 +1052,7 @@ __device__ __forceinline__ unsigned load_u32_unaligned(const unsigned char* p) {
   return v;
 }
 // the tail of a fused pick: embedding of the pick for the next step, then the counters by the last workgroup to finish
-__device__ __forceinline__ void step_fuse_tail(const StepFuse& f, int tok, int pos, int step, int b, int tid) {
+__device__ __forceinline__ void step_fuse_embed(const StepFuse& f, int tok, int pos, int b, int tid) {
   const int pe = f.row_off ? pos - f.row_off[b] : pos;    // cache row `pos` is position pos - row_off[b] of a left-padded clip
   if (f.tok_emb_q) {
     for (int c = tid; c < f.D; c += (int)blockDim.x)
@@ -1060,6 +1060,8 @@ __device__ __forceinline__ void step_fuse_tail(const StepFuse& f, int tok, int p
   } else {
     for (int c = tid; c < f.D; c += (int)blockDim.x) f.x[(long)b * f.D + c] = f.tok_emb[(long)tok * f.D + c] + f.pos_emb[(long)pe * f.D + c];
   }
+}
+__device__ __forceinline__ void step_fuse_ticket(const StepFuse& f, int pos, int step, int tid) {
   if (tid == 0) {
     // No fence: nothing of this kernel is read by another workgroup of it -- the ticket only elects the workgroup that
     // stores the counters, every workgroup has consumed the old values long before its own increment, and the
@@ -1072,6 +1074,10 @@ __device__ __forceinline__ void step_fuse_tail(const StepFuse& f, int tok, int p
       f.counters[2] = 0;
     }
   }
+}
+__device__ __forceinline__ void step_fuse_tail(const StepFuse& f, int tok, int pos, int step, int b, int tid) {
+  step_fuse_embed(f, tok, pos, b, tid);
+  step_fuse_ticket(f, pos, step, tid);
 }
 
 __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, const unsigned char* __restrict__ mask,
@@ -1440,7 +1446,7 @@ __global__ __launch_bounds__(TS_THREADS) void ts_sample_kernel(TsPickArgs a) {
   const float T = *a.temperature;
   const double u = n_cand > 0 ? 0.0 : a.u_all[(long)step * gridDim.x + b];
   if (tid == 0) { s_tok = -1; s_last = -1; }
-  if (tid < n_cand) { s_ctok[tid] = -1; s_cu[tid] = a.u_all[(long)b * n_cand + tid]; }
+  if (tid < n_cand) { s_ctok[tid] = -1; s_cu[tid] = a.u_all[((long)step * gridDim.x + b) * n_cand + tid]; }
   // ---- pass 1: maxima of the text / special ids and of the timestamps ----
   float tv = -INFINITY, xv = -INFINITY;
   int xi = 0x7fffffff;
@@ -1756,18 +1762,132 @@ __global__ __launch_bounds__(64 * AD_WAVES) void attn_dec_x16g_kernel(const floa
   }
 }
 
-// beam_kv_reorder: phase 0 gathers the parents' bytes into scratch, phase 1 scatters them into the rows
+// beam_kv_reorder: phase 0 gathers the parents' bytes into scratch, phase 1 scatters them into the rows.  The bytes are the
+// cache rows of the positions generated so far, [counters[4], counters[0]) -- read on the device: the launch is part of a
+// captured step; counters[5] = max_new of the pass, the scratch rows' pitch in positions.
 __global__ __launch_bounds__(256) void beam_kv_copy_kernel(char* __restrict__ kv, char* __restrict__ scratch, const int* __restrict__ parent,
-                                                           int rows, long row_bytes, long off, long len, int phase) {
+                                                           int rows, long row_bytes, long pos_bytes, const int* __restrict__ counters,
+                                                           int phase) {
   const int r = blockIdx.x, l = blockIdx.y;
   const int p = parent[r];
   if (p == r) return;
-  char* row = kv + ((long)l * rows + (phase == 0 ? p : r)) * row_bytes + off;
-  char* tmp = scratch + ((long)l * rows + r) * len;
+  const int pos0 = counters[4];
+  const long len = (long)(counters[0] - pos0) * pos_bytes, scratch_stride = (long)counters[5] * pos_bytes;
+  char* row = kv + ((long)l * rows + (phase == 0 ? p : r)) * row_bytes + (long)pos0 * pos_bytes;
+  char* tmp = scratch + ((long)l * rows + r) * scratch_stride;
   for (long x = 16L * (blockIdx.z * 256 + threadIdx.x); x < len; x += 16L * 256 * gridDim.z) {
     if (phase == 0) *reinterpret_cast<uint4*>(tmp + x) = *reinterpret_cast<const uint4*>(row + x);
     else *reinterpret_cast<uint4*>(row + x) = *reinterpret_cast<const uint4*>(tmp + x);
   }
+}
+
+// One step of whisper_full's beam search for one clip (BeamArgs, asr_common.h): one wave, lane = candidate (decoder j, draw k).
+__global__ __launch_bounds__(64) void beam_advance_kernel(BeamArgs a) {
+  __shared__ BeamRow s_row[TS_MAX_CAND];
+  __shared__ TsState s_st[TS_MAX_CAND];
+  __shared__ double s_sum[64];
+  __shared__ int s_tok[64], s_tid[64], s_sorted[64], s_deal[TS_MAX_CAND], s_feed[TS_MAX_CAND];
+  __shared__ float s_plog[64];
+  const int c = blockIdx.x, lane = threadIdx.x;
+  const int n_dec = a.n_dec, n_cand = a.n_cand, r0 = c * n_dec;
+  const int step = a.counters[1], pos = a.counters[0] + 1;
+  if (lane < n_dec) { s_row[lane] = a.row[r0 + lane]; s_st[lane] = a.st[r0 + lane]; }
+  __syncthreads();
+  // the candidates of the clip's live decoders and the sum of ALL log-probabilities each would have
+  const int j = lane / n_cand, k = lane - j * n_cand;
+  const bool valid = j < n_dec && !(s_row[j < n_dec ? j : 0].completed || s_row[j < n_dec ? j : 0].failed);
+  int tok = -1, tid = 0;
+  float plog = 0.f;
+  double sum = 0.0;
+  if (valid) {
+    const long x = (long)(r0 + j) * n_cand + k;
+    tok = a.cand_tok[x]; tid = a.cand_tid[x]; plog = a.cand_plog[x];
+    sum = s_row[j].sum_all + (double)plog;
+  }
+  s_tok[lane] = tok; s_tid[lane] = tid; s_plog[lane] = plog; s_sum[lane] = sum;
+  const unsigned long long vmask = __ballot(valid);
+  const int n_valid = __popcll(vmask);
+  // std::stable_sort by (sum descending, decoder ascending) over candidates pushed decoder-major: position = the number of
+  // candidates that come first = those with a larger sum, or an equal one and a smaller lane
+  int rank = 0;
+  for (int l = 0; l < 64; ++l) {
+    const double sl = __shfl(sum, l, 64);
+    if (((vmask >> l) & 1ull) && (sl > sum || (sl == sum && l < lane))) ++rank;
+  }
+  if (valid) s_sorted[rank] = lane;
+  __syncthreads();
+  // deal the sorted candidates to the live decoders, skipping repeats of the sequence just dealt (not at the first step):
+  // two candidates are the same sequence when their ids are equal and their decoders' sequences are (BeamRow::eqid)
+  if (lane == 0) {
+    int cur_c = 0;
+    for (int d = 0; d < n_dec; ++d) {
+      s_deal[d] = -1;
+      if (s_row[d].completed || s_row[d].failed || n_valid == 0) continue;
+      if (cur_c >= n_valid) cur_c = 0;
+      const int cur = s_sorted[cur_c++];
+      const int cj = cur / n_cand;
+      while (cur_c < n_valid && step > 0) {
+        const int nx = s_sorted[cur_c], nj = nx / n_cand;
+        if (!(s_tok[nx] == s_tok[cur] && (nj == cj || s_row[nj].eqid == s_row[cj].eqid))) break;
+        ++cur_c;
+      }
+      s_deal[d] = cur;
+    }
+  }
+  __syncthreads();
+  int died = 0;
+  if (lane < n_dec) {
+    const int r = r0 + lane, cur = s_deal[lane];
+    int feed = a.eot;
+    if (cur < 0) {                               // ended in an earlier step: keeps its sequence and its cache rows
+      a.parent[r] = r;
+    } else {
+      const int pj = cur / n_cand, t = s_tok[cur];
+      BeamRow q = s_row[pj];
+      TsState st = s_st[pj];
+      q.sum_all = s_sum[cur];
+      q.n += 1;
+      st.prev = st.last; st.last = t; st.n += 1;                   // the rules' view of the sequence (the pick kernel's ts_commit)
+      if (a.rules == TS_RULES_OPENAI ? t >= a.beg : t > a.beg) st.last_ts = t;
+      // the sequence's class among the decoders dealt this step: the first decoder dealt the same parent class and id
+      int eq = lane;
+      for (int d = 0; d < lane; ++d) {
+        const int od = s_deal[d];
+        if (od >= 0 && s_tok[od] == t && s_row[od / n_cand].eqid == s_row[pj].eqid) { eq = d; break; }
+      }
+      q.eqid = eq;
+      const long x = (long)step * a.rows + r;
+      a.rec_tok[x] = t; a.rec_tid[x] = s_tid[cur]; a.rec_plog[x] = s_plog[cur]; a.rec_parent[x] = r0 + pj;
+      a.parent[r] = r0 + pj;
+      // completion / failure on the new last token (whisper_full's bookkeeping of a decoder)
+      bool live = true;
+      if (t > a.beg) {
+        const int sd = 2 * (t - a.beg);
+        if (q.has_ts && q.seek_delta > sd && q.result_len < step) { q.failed = 1; live = false; }      // "do not allow to go back in time"
+        else { q.seek_delta = sd; q.result_len = step + 1; q.has_ts = 1; }
+      }
+      if (live && (t == a.eot || (q.has_ts && st.seek + q.seek_delta + a.delta_min >= st.seek_end))) {
+        if (q.result_len == 0) {
+          if (st.seek + q.seek_delta + a.delta_min >= st.seek_end) q.result_len = step + 1;
+          else { q.failed = 1; live = false; }
+        }
+        if (live) { q.completed = 1; live = false; }
+      }
+      if (live && step == a.counters[5] - 1 && (q.result_len == 0 || q.seek_delta < 1500)) { q.failed = 1; live = false; }
+      st.done = live ? 0 : 1;
+      if (live) feed = t; else died = 1;
+      a.row[r] = q;
+      a.st[r] = st;
+    }
+    a.feed[r] = feed;
+    s_feed[lane] = feed;
+  }
+  const int n_died = __popcll(__ballot(died != 0));
+  if (lane == 0 && n_died) atomicAdd(a.done_count, n_died);
+  if (!a.fuse.x) return;
+  __syncthreads();
+  for (int d = 0; d < n_dec; ++d) step_fuse_embed(a.fuse, s_feed[d], pos, r0 + d, lane);
+  step_fuse_ticket(a.fuse, pos, step, lane);
 }
 
 // p_out[b] = softmax(row b)[token]: one 1024-thread block per row, two passes (maximum, sum of exponentials)
@@ -2019,14 +2139,20 @@ hipError_t softmax_prob_f32(const float* logits, int V, long ld, int token, floa
   return hipGetLastError();
 }
 
-hipError_t beam_kv_reorder(void* kv, void* scratch, const int* parent_dev, int layers, int rows, long row_bytes, long off, long len,
-                           hipStream_t s) {
-  if (len <= 0) return hipSuccess;
-  if (len % 16 != 0 || off % 16 != 0 || row_bytes % 16 != 0 || off + len > row_bytes) return hipErrorInvalidValue;
-  const unsigned z = (unsigned)std::min<long>(16, (len + 16 * 256 - 1) / (16 * 256));
+hipError_t beam_kv_reorder(void* kv, void* scratch, const int* parent_dev, int layers, int rows, long row_bytes, long pos_bytes,
+                           const int* counters, hipStream_t s) {
+  if (pos_bytes % 16 != 0 || row_bytes % 16 != 0) return hipErrorInvalidValue;
   for (int phase = 0; phase < 2; ++phase)
-    hipLaunchKernelGGL(beam_kv_copy_kernel, dim3(rows, layers, z), dim3(256), 0, s, reinterpret_cast<char*>(kv),
-                       reinterpret_cast<char*>(scratch), parent_dev, rows, row_bytes, off, len, phase);
+    hipLaunchKernelGGL(beam_kv_copy_kernel, dim3(rows, layers, 8), dim3(256), 0, s, reinterpret_cast<char*>(kv),
+                       reinterpret_cast<char*>(scratch), parent_dev, rows, row_bytes, pos_bytes, counters, phase);
+  return hipGetLastError();
+}
+
+hipError_t beam_advance(const BeamArgs& a, int n_clips, hipStream_t s) {
+  if (a.n_dec < 1 || a.n_dec > TS_MAX_CAND || a.n_cand < 1 || a.n_cand > TS_MAX_CAND || a.n_dec * a.n_cand > 64 || n_clips < 1 ||
+      a.rows != n_clips * a.n_dec)
+    return hipErrorInvalidValue;
+  hipLaunchKernelGGL(beam_advance_kernel, dim3(n_clips), dim3(64), 0, s, a);
   return hipGetLastError();
 }
 

@@ -69,7 +69,8 @@ hipError_t rs_prep(const float*, long, long, float, int, float*, int, int, hipSt
 hipError_t rs_prep_split(const float*, long, long, float, int, void*, int, int, hipStream_t) { return hipSuccess; }
 hipError_t softmax_prob_f32(const float*, int, long, int, float*, int, hipStream_t) { return hipSuccess; }
 hipError_t ts_pick(const TsPickArgs&, int, hipStream_t) { return hipSuccess; }
-hipError_t beam_kv_reorder(void*, void*, const int*, int, int, long, long, long, hipStream_t) { return hipSuccess; }
+hipError_t beam_kv_reorder(void*, void*, const int*, int, int, long, long, const int*, hipStream_t) { return hipSuccess; }
+hipError_t beam_advance(const BeamArgs&, int, hipStream_t) { return hipSuccess; }
 hipError_t rn_launch_frames(const RnArgs&, hipStream_t, int) { return hipSuccess; }
 hipError_t rn_launch_highpass(const RnArgs&, hipStream_t, bool) { return hipSuccess; }
 hipError_t rn_launch_roll_history(const RnArgs&, hipStream_t) { return hipSuccess; }
