@@ -334,6 +334,41 @@ def test_fallback_passes_of_a_batch_run_side_by_side_and_equal_the_single_calls(
     eng.close()
 
 
+@pytest.mark.parametrize("opts", [dict(best_of=5), dict(beam_size=3, best_of=4)], ids=["best_of_5", "beam_3_best_of_4"])
+def test_a_clip_whose_rows_share_one_copy_of_its_keys_decodes_as_alone(tmp_path_factory, opts):
+    """Round 6: once the (clip, head) pairs of a fallback / beam pass fill the chip on their own (>= 256 of them), the cross
+    block takes the rows of a clip in ONE workgroup over one copy of the clip's K | V (`fused_cross_rows_kernel`), not a
+    workgroup per row -- per row the same instructions, so the same bits.  120 clips of the ladder model (fifteen of each of
+    the eight lengths of the test above: about half of them have a window that walks the ladder together) against single
+    calls, which run the workgroup-per-row form."""
+    from crispy_amd import synth_audio
+    from crispy_amd.asr import WhisperEngine, transcribe_batch
+    from crispy_amd.whisper_weights import HParams
+    from tests.scripted_model import script_rows, scripted_whisper_weights
+    hp = HParams.tiny()
+    sp, BEG, EOT = _scripts(hp)
+    X, Y, REP = 1234, 2345, 777
+    beta = 1.0 - 1.0 * np.sqrt(2.0) / hp.n_text_state
+    rows = script_rows(2, [BEG, 1001, [(X, 1.0), (Y, beta)], 1003, BEG + 300, BEG + 300, EOT])
+    rows.update(script_rows(9, [BEG] + [REP] * 40 + [BEG + 100, BEG + 100, EOT]))
+    W = scripted_whisper_weights(hp, rows, gain=100.0)
+    eng = WhisperEngine(_engine_file(tmp_path_factory, hp, W, "ladder-rows"))
+    eng.set_precision(1)
+    base = synth_audio.clip16k_np(80, 16000 * 13)
+    lengths = (13, 7, 12, 3, 13, 10, 5, 12)
+    clips = [base[:16000 * lengths[i % 8]] for i in range(120)]
+    kw = dict(language_token=sp["lang0"], timestamps=True, with_segments=True, **opts)
+    got = transcribe_batch(eng, clips, **kw)
+    laddered = sum(any(w["temperature"] > 0 for w in r[4]) for r in got)
+    print(f"{opts}: {laddered} of {len(clips)} clips walked the ladder")
+    assert laddered >= 43, laddered                                 # 43 clips x 6 heads >= 256: the rows form ran in the fallback passes
+    for c in range(8):
+        solo = transcribe_batch(eng, [clips[c]], **kw)[0]
+        assert got[c] == solo, (c, got[c][4], solo[4])
+        assert all(got[c + 8 * k] == solo for k in range(1, 15)), c
+    eng.close()
+
+
 def test_fallback_groups_that_grow_between_passes_stay_inside_their_buffers(tmp_path_factory):
     """the gathered encoder outputs of a group of fallback clips were allocated once per call, sized by the
     FIRST group that needed them -- and the group size changes from pass to pass: 128 / beam clips at temperature 0, 128 /
