@@ -13,7 +13,7 @@ def pytest_configure(config):
     # A GPU run writes straight to the terminal (as with -s).  When the ROCm runtime kills the process -- a memory fault of a
     # kernel ends in abort() -- what it says goes to file descriptor 2, and under pytest's per-test capture that text died
     # with the process: round 6 lost the one message that would have named the faulting address of an abort seen once in
-    # three runs (NOTEBOOK 10.6).  The numbers the tests print (error levels, measured ratios) are wanted in the log anyway.
+    # several runs (NOTEBOOK 10.10).  The numbers the tests print (error levels, measured ratios) are wanted in the log anyway.
     expr = getattr(config.option, "markexpr", "") or ""
     if "gpu" in expr and "not gpu" not in expr:
         capman = config.pluginmanager.getplugin("capturemanager")
