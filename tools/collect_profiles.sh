@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 out=$PWD/gpurun_out
 mkdir -p $out
 # the driver's own step counts, so that (average launch) x (launches per step) of the dominant kernel can be held against ms_per_step
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_trace -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-live-traffic --no-latency --no-cfg45 --sustain-seconds 0 > $out/${tag}_trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_trace -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-live-traffic --no-latency --no-cfg45 --no-host-fed --sustain-seconds 0 > $out/${tag}_trace.log 2>&1
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" "SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
            "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_INSTS_SMEM SQ_WAVES" \
