@@ -152,7 +152,7 @@ int decoder_step_fused(crispy_asr* h, int rows, hipStream_t s) {
     b.wo = reinterpret_cast<const _Float16*>(L.xout_wh);
     b.xkv = reinterpret_cast<const _Float16*>(h->d_xkv_h) + l * xclips * Tn * 2 * dt; b.clip_stride = (long)Tn * 2 * dt;
     b.n_keys = Tn; b.group = h->cur_xgroup; b.attn16 = attn16;
-    b.stream_kv = stream_kv;       // (with a workgroup per row the rows of a clip share its K | V through the XCD's L2: fused_cross decides)
+    b.stream_kv = h->cur_xgroup > 1 ? 0 : stream_kv;      // the rows of a clip share its K | V through the XCD's L2: plain loads
     b.part_out = pb; b.rows = rows; b.D = dt;
     HIP_TRY(fused_cross(b, s));
     FusedMlpArgs m{};

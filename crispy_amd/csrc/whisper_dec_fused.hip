@@ -194,14 +194,11 @@ __device__ __forceinline__ void fd_merge(const float (*part_o)[64], const float*
   }
   att_h[lane] = (_Float16)(attn16 ? o : o / l);
 }
-// fd_attend in its two halves: the scores of a wave's key slots against the query (and their maximum over the wave), then --
-// with the values in registers -- the wave's partial (max, sum, P.V) and the merge.  fused_cross_rows_kernel runs the first half
-// for every row of a clip over the keys, parks the scores in LDS, and the second half for every row over the values: per row
-// the instructions of fd_attend, so a row's bits do not depend on the form.
-template <int SLOTS>
-__device__ __forceinline__ void fd_scores(const half8 (&kr)[SLOTS], const float* q_s, int k_lo, int k_hi, int attn16, float (&sc)[SLOTS],
-                                          float& mloc) {
-  const int lane = threadIdx.x & 63;
+template <int SLOTS, bool MERGE = true, class AfterScores, class Mid>
+__device__ __forceinline__ void fd_attend(const half8 (&kr)[SLOTS], half8 (&vr)[SLOTS], const float* q_s, int k_lo, int k_hi,
+                                          int attn16, float (*part_o)[64], float* part_m, float* part_l, _Float16* att_h,
+                                          AfterScores after_scores, Mid mid) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int c = lane & 7, r = lane >> 3;
   float qv[8];
   {
@@ -216,7 +213,8 @@ __device__ __forceinline__ void fd_scores(const half8 (&kr)[SLOTS], const float*
 #pragma unroll
     for (int e = 0; e < 8; ++e) qv[e] *= 0.125f;
   }
-  mloc = -1e30f;
+  float sc[SLOTS];
+  float mloc = -1e30f;
 #pragma unroll
   for (int i = 0; i < SLOTS; ++i) {
     float v = (float)kr[i][0] * qv[0];
@@ -227,12 +225,7 @@ __device__ __forceinline__ void fd_scores(const half8 (&kr)[SLOTS], const float*
     sc[i] = valid ? v : -1e30f;
     mloc = fmaxf(mloc, sc[i]);
   }
-}
-template <int SLOTS, bool MERGE = true, class Mid>
-__device__ __forceinline__ void fd_pv(const half8 (&vr)[SLOTS], const float (&sc)[SLOTS], float mloc, int k_lo, int k_hi, int attn16,
-                                      float (*part_o)[64], float* part_m, float* part_l, _Float16* att_h, Mid mid) {
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int c = lane & 7, r = lane >> 3;
+  after_scores();
 #pragma unroll
   for (int off = 8; off <= 32; off <<= 1) mloc = fmaxf(mloc, __shfl_xor(mloc, off, 64));
   float lsum = 0.f;
@@ -285,16 +278,6 @@ __device__ __forceinline__ void fd_pv(const half8 (&vr)[SLOTS], const float (&sc
     if (wave == 0) fd_merge(part_o, part_m, part_l, attn16, att_h);
     fd_bar();
   }
-}
-template <int SLOTS, bool MERGE = true, class AfterScores, class Mid>
-__device__ __forceinline__ void fd_attend(const half8 (&kr)[SLOTS], half8 (&vr)[SLOTS], const float* q_s, int k_lo, int k_hi,
-                                          int attn16, float (*part_o)[64], float* part_m, float* part_l, _Float16* att_h,
-                                          AfterScores after_scores, Mid mid) {
-  float sc[SLOTS];
-  float mloc;
-  fd_scores<SLOTS>(kr, q_s, k_lo, k_hi, attn16, sc, mloc);
-  after_scores();
-  fd_pv<SLOTS, MERGE>(vr, sc, mloc, k_lo, k_hi, attn16, part_o, part_m, part_l, att_h, mid);
 }
 
 // po [RB][D] -> part_out[slice][row0 + r][:]
@@ -527,257 +510,6 @@ __global__ __launch_bounds__(FD_THREADS) void fused_cross_kernel(FusedCrossArgs 
   fd_store_partial<D, 1>(po, a.part_out, a.rows, row, h);
 }
 
-// ---- cross-attention block of one (clip, head), ALL rows of the clip ------------------------------------------------------
-// The rows of a clip (the best-of / beam decoders of a fallback pass) attend over the same keys and values.  With a workgroup
-// per row each of them pulls the clip's 384 KB of K | V of the head through its CU's L2 port and converts it to f32 on its
-// own: 64 clips x 5 rows, 81 us per launch against 30 for one row per clip.  Here one workgroup takes the G rows TOGETHER over
-// one copy in registers: the residual streams of all rows assembled and normalised side by side (G waves), q of all rows,
-// then the keys (a slot's eight conversions once per two rows; the scores parked in LDS, 6 KB per row), the values into the
-// registers the keys leave, the rows' soft-max / P.V chains, their merges on G waves, their out-projections, G partial rows.
-// Six workgroup barriers for all rows instead of six per row.  Per row the operations of fused_cross_kernel in its order
-// (fd_scores / fd_pv), so a row's bits do not depend on the form (tests/test_gpu_decision.py: a clip of a batch of 80 == the
-// clip alone).  Measured: 81 -> 76 us per launch at 64 clips x 5 rows -- NOT the 2 x the byte count promised: the block is
-// bound by its vector instructions (per row and wave ~170 for the scores, ~190 for P.V and its 27 shuffles; sixteen waves
-// share a CU whichever workgroup they belong to), and only the conversions and the barriers are shared between rows.  The
-// step beyond is the scores and P.V of the rows of a clip as 16-row tiles on the matrix cores -- another summation order,
-// i.e. for every decode attention at once or not at all (NOTEBOOK 10.9).  Chosen when the (clip, head) pairs alone fill
-// the chip (fused_cross); below that the workgroup-per-row form is faster (16 clips x beam 5: 277 against 331 us a position).
-constexpr int FXR_MAX = 5;                  // rows of a clip per workgroup: whisper.cpp's best_of / beam_size default (6 KB of scores each)
-template <int D, int NP, int G, bool STREAM_KV>
-__global__ __launch_bounds__(FD_THREADS) void fused_cross_rows_kernel(FusedCrossArgs a) {
-  constexpr int PPL = D / 128;
-  constexpr int H = D / 64;
-  __shared__ __attribute__((aligned(16))) float xs[G * D];      // the residual streams; later the rows' partial out-projections (po)
-  __shared__ __attribute__((aligned(16))) float gb[2 * D];      // LayerNorm gamma | beta
-  __shared__ __attribute__((aligned(16))) _Float16 xn[G * D];
-  __shared__ __attribute__((aligned(16))) float q_s[G][64];
-  __shared__ __attribute__((aligned(16))) float sc_s[G][FD_WAVES][FX_SLOTS][8];      // a row's scores [wave][slot][key]; a wave's 96 floats
-                                                                                       // later hold its partial P.V (64 floats)
-  __shared__ float part_m[G][FD_WAVES], part_l[G][FD_WAVES];
-  __shared__ __attribute__((aligned(16))) _Float16 att_h[G][64];
-  float* po = xs;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int gi = blockIdx.x;
-  const int clip = gi / H, h = gi % H;
-  const int row0 = clip * G;
-  FdParams<D, NP> par;
-  par.request(a.in);
-  FdInput<D, NP, G> fin;
-  fin.request(a.in, a.rows, row0);
-  const int Tn = a.n_keys;
-  const int c8 = lane & 7, r8 = lane >> 3;
-  const int per = (Tn + FD_WAVES - 1) / FD_WAVES;
-  const int k_lo = wave * per, k_hi = min(Tn, k_lo + per);
-  const int k_last = max(k_hi - 1, 0);
-  const char* Kb = reinterpret_cast<const char*>(a.xkv + (long)clip * a.clip_stride + (long)h * 64 * Tn);
-  const char* Vb = Kb + (long)Tn * D * 2;
-  // a slot's byte offset is computed where it is used (twice): twelve registers less between the two passes
-  auto slot_off = [&](int i) { return (unsigned)((min(k_lo + 8 * i + r8, k_last) * 64 + 8 * c8) * 2); };
-  half8 kr[FX_SLOTS];
-#pragma unroll
-  for (int i = 0; i < FX_SLOTS; ++i) {
-    const half8* p = reinterpret_cast<const half8*>(Kb + slot_off(i));
-    kr[i] = STREAM_KV ? __builtin_nontemporal_load(p) : *p;
-  }
-  const int g16 = lane >> 4, c = lane & 15;
-  const int jrow = 4 * wave + g16;
-  half8 wq[PPL];
-  {
-    const _Float16* wh = a.wq + (long)h * 64 * D;                       // uniform
-#pragma unroll
-    for (int j = 0; j < PPL; ++j) wq[j] = ldu<half8>(wh, 2u * (unsigned)(jrow * D + 8 * c + 128 * j));
-  }
-  const float bq = a.bq[h * 64 + jrow];
-  __builtin_amdgcn_sched_barrier(0);
-  par.stage(gb);
-  fin.finish(a.in, par.b, a.rows, row0, h == 0, xs, gb, xn);
-  // ---- q of every row ----
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    float v = 0.f;
-#pragma unroll
-    for (int j = 0; j < PPL; ++j) v = dot8(wq[j], *reinterpret_cast<const half8*>(xn + g * D + 8 * c + 128 * j), v);
-    v = sum16(v) + bq;
-    if (c == 0) q_s[g][jrow] = v;
-  }
-  fd_bar();
-  // ---- the keys: fd_scores for every row, GC rows per pass over the registers (all G at once do not fit beside the keys) ----
-  constexpr int GC = 2;
-  float mloc[G];
-#pragma unroll
-  for (int g0 = 0; g0 < G; g0 += GC) {
-    constexpr int dummy = 0; (void)dummy;
-    float qv[GC][8];
-#pragma unroll
-    for (int gg = 0; gg < GC; ++gg) {
-      const int g = g0 + gg < G ? g0 + gg : G - 1;
-      const float4 q0 = *reinterpret_cast<const float4*>(&q_s[g][8 * c8]);
-      const float4 q1 = *reinterpret_cast<const float4*>(&q_s[g][8 * c8 + 4]);
-      qv[gg][0] = q0.x; qv[gg][1] = q0.y; qv[gg][2] = q0.z; qv[gg][3] = q0.w;
-      qv[gg][4] = q1.x; qv[gg][5] = q1.y; qv[gg][6] = q1.z; qv[gg][7] = q1.w;
-      if (a.attn16) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) qv[gg][e] = (float)(_Float16)qv[gg][e];
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) qv[gg][e] *= 0.125f;
-      if (g0 + gg < G) mloc[g0 + gg] = -1e30f;
-    }
-#pragma unroll
-    for (int i = 0; i < FX_SLOTS; ++i) {
-      asm volatile("" : "+v"(kr[i]));        // (or the conversions of the second pass are kept from the first: 96 registers)
-      float kf[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) kf[e] = (float)kr[i][e];
-      const bool valid = k_lo + 8 * i + r8 < k_hi;
-#pragma unroll
-      for (int gg = 0; gg < GC; ++gg) {
-        if (g0 + gg < G) {
-          const int g = g0 + gg;
-          float v = kf[0] * qv[gg][0];
-#pragma unroll
-          for (int e = 1; e < 8; ++e) v = fmaf(kf[e], qv[gg][e], v);
-          v = sum8(v);
-          const float sc = valid ? v : -1e30f;
-          mloc[g] = fmaxf(mloc[g], sc);
-          if (c8 == 0) sc_s[g][wave][i][r8] = sc;
-        }
-      }
-    }
-  }
-  // ---- the values, into the registers the keys leave ----
-  __builtin_amdgcn_sched_barrier(0);
-  half8 vr[FX_SLOTS];
-#pragma unroll
-  for (int i = 0; i < FX_SLOTS; ++i) {
-    const half8* p = reinterpret_cast<const half8*>(Vb + slot_off(i));
-    vr[i] = STREAM_KV ? __builtin_nontemporal_load(p) : *p;
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  // ---- one pass over the values: fd_pv for every row ----
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-#pragma unroll
-    for (int off = 8; off <= 32; off <<= 1) mloc[g] = fmaxf(mloc[g], __shfl_xor(mloc[g], off, 64));
-  }
-  float inv16[G];
-#pragma unroll
-  for (int g = 0; g < G; ++g) inv16[g] = 0.f;
-  if (a.attn16) {               // the soft-max in full, normalised, THEN rounded: needs every row's maximum and sum first
-    if (lane == 0) {
-#pragma unroll
-      for (int g = 0; g < G; ++g) part_m[g][wave] = mloc[g];
-    }
-    fd_bar();
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      float m = part_m[g][0];
-#pragma unroll
-      for (int w = 1; w < FD_WAVES; ++w) m = fmaxf(m, part_m[g][w]);
-      mloc[g] = m;
-      float ls = 0.f;
-#pragma unroll
-      for (int i = 0; i < FX_SLOTS; ++i) ls += k_lo + 8 * i + r8 < k_hi ? __expf(sc_s[g][wave][i][r8] - mloc[g]) : 0.f;
-#pragma unroll
-      for (int off = 8; off <= 32; off <<= 1) ls += __shfl_xor(ls, off, 64);
-      if (lane == 0) part_l[g][wave] = ls;
-    }
-    fd_bar();
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      float l = 0.f;
-#pragma unroll
-      for (int w = 0; w < FD_WAVES; ++w) l += part_l[g][w];
-      inv16[g] = 1.f / l;
-    }
-    fd_bar();
-  }
-  HeadOut<D> ho;
-#pragma unroll
-  for (int g0 = 0; g0 < G; g0 += GC) {
-    float lsum[GC], acc[GC][8];
-#pragma unroll
-    for (int gg = 0; gg < GC; ++gg) {
-      lsum[gg] = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc[gg][e] = 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < FX_SLOTS; ++i) {
-      asm volatile("" : "+v"(vr[i]));
-      float vf[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) vf[e] = (float)vr[i][e];
-      const bool valid = k_lo + 8 * i + r8 < k_hi;
-#pragma unroll
-      for (int gg = 0; gg < GC; ++gg) {
-        if (g0 + gg < G) {
-          const int g = g0 + gg;
-          float pw = valid ? __expf(sc_s[g][wave][i][r8] - mloc[g]) : 0.f;
-          if (a.attn16) pw = (float)(_Float16)(pw * inv16[g]);
-          lsum[gg] += pw;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) acc[gg][e] = fmaf(pw, vf[e], acc[gg][e]);
-        }
-      }
-    }
-    if (g0 + GC >= G) ho.request(a.wo, h * 64);      // behind the last pass over the values
-#pragma unroll
-    for (int gg = 0; gg < GC; ++gg) {
-      if (g0 + gg < G) {
-        const int g = g0 + gg;
-#pragma unroll
-        for (int off = 8; off <= 32; off <<= 1) {
-          lsum[gg] += __shfl_xor(lsum[gg], off, 64);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) acc[gg][e] += __shfl_xor(acc[gg][e], off, 64);
-        }
-        // the wave's partial P.V over its own scores of the row (read for the last time above, by this wave alone)
-        float* pout = &sc_s[g][wave][0][0];
-        if (r8 == 0) {
-          *reinterpret_cast<float4*>(pout + 8 * c8) = make_float4(acc[gg][0], acc[gg][1], acc[gg][2], acc[gg][3]);
-          *reinterpret_cast<float4*>(pout + 8 * c8 + 4) = make_float4(acc[gg][4], acc[gg][5], acc[gg][6], acc[gg][7]);
-        }
-        if (lane == 0) { part_m[g][wave] = mloc[g]; part_l[g][wave] = lsum[gg]; }
-      }
-    }
-  }
-  fd_bar();
-  if (wave < G) {               // fd_merge of row `wave` (its partials are 96 floats apart)
-    float m = part_m[wave][0];
-#pragma unroll
-    for (int w = 1; w < FD_WAVES; ++w) m = fmaxf(m, part_m[wave][w]);
-    float o = 0.f, l = 0.f;
-#pragma unroll
-    for (int w = 0; w < FD_WAVES; ++w) {
-      const float scl = __expf(part_m[wave][w] - m);
-      o = fmaf((&sc_s[wave][w][0][0])[lane], scl, o);
-      l = fmaf(part_l[wave][w], scl, l);
-    }
-    att_h[wave][lane] = (_Float16)(a.attn16 ? o : o / l);
-  }
-  fd_bar();
-#pragma unroll
-  for (int g = 0; g < G; ++g) ho.finish(att_h[g], po + g * D);
-  fd_bar();
-  fd_store_partial<D, G>(po, a.part_out, a.rows, row0, h);
-}
-template <int D, int NP>
-hipError_t cross_rows_launch(const FusedCrossArgs& a, int n_groups, hipStream_t s) {
-  const dim3 grid((unsigned)n_groups), block(FD_THREADS);
-#define FD_XROWS(G) do { if (a.stream_kv) hipLaunchKernelGGL((fused_cross_rows_kernel<D, NP, G, true>), grid, block, 0, s, a); \
-                         else hipLaunchKernelGGL((fused_cross_rows_kernel<D, NP, G, false>), grid, block, 0, s, a); } while (0)
-  switch (a.group) {
-    case 2: FD_XROWS(2); break;
-    case 3: FD_XROWS(3); break;
-    case 4: FD_XROWS(4); break;
-    case 5: FD_XROWS(5); break;
-    default: return hipErrorInvalidValue;
-  }
-#undef FD_XROWS
-  return hipGetLastError();
-}
-
 // ---- MLP block: 128 hidden units of RB rows ---------------------------------------------------------------------------
 // RB rows share the chunk's weights in registers and go through the block together (see fused_self_kernel): waves 0 - 7
 // hold one 16-row tile of fc1 each over all of K, waves 8 - 15 the D / 16 tiles of fc2 over the chunk's 128 columns.
@@ -948,24 +680,13 @@ hipError_t fused_self(const FusedSelfArgs& a, bool first, hipStream_t s) {
 hipError_t fused_cross(const FusedCrossArgs& a, hipStream_t s) {
   if (a.rows <= 0) return hipSuccess;
   if (a.group < 1 || a.rows % a.group != 0) return hipErrorInvalidValue;
-  const int n_groups = (a.rows / a.group) * (a.D / 64);               // (clip, head) pairs
-  const dim3 block(FD_THREADS);
-  // several rows per clip and enough (clip, head) pairs to fill the chip on their own: one workgroup per pair takes the clip's
-  // rows over one copy of its K | V (same bits per row; 64 clips x 5 rows: 81 -> 76 us per launch)
-  if (a.group > 1 && a.group <= FXR_MAX && n_groups >= 256) {
-    if (a.D == 384) return cross_rows_launch<384, 6>(a, n_groups, s);
-    if (a.D == 512) return cross_rows_launch<512, 8>(a, n_groups, s);
-    return hipErrorInvalidValue;
-  }
-  // one workgroup per (row, head), eight (clip, head) pairs per round of the XCDs; the rows of a clip share its K | V through
-  // their XCD's L2: plain loads for them whatever the size
-  const bool nt = a.group == 1 && a.stream_kv;
-  const dim3 grid((unsigned)(8 * a.group * ((n_groups + 7) / 8)));
+  const int n_groups = (a.rows / a.group) * (a.D / 64);               // (clip, head) pairs; eight of them per round of the XCDs
+  const dim3 grid((unsigned)(8 * a.group * ((n_groups + 7) / 8))), block(FD_THREADS);
   if (a.D == 384) {
-    if (nt) hipLaunchKernelGGL((fused_cross_kernel<384, 6, true>), grid, block, 0, s, a);
+    if (a.stream_kv) hipLaunchKernelGGL((fused_cross_kernel<384, 6, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((fused_cross_kernel<384, 6, false>), grid, block, 0, s, a);
   } else if (a.D == 512) {
-    if (nt) hipLaunchKernelGGL((fused_cross_kernel<512, 8, true>), grid, block, 0, s, a);
+    if (a.stream_kv) hipLaunchKernelGGL((fused_cross_kernel<512, 8, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((fused_cross_kernel<512, 8, false>), grid, block, 0, s, a);
   } else {
     return hipErrorInvalidValue;
