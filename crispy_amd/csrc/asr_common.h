@@ -169,7 +169,8 @@ hipError_t attn_decoder_kv16(const float* q, long ldq, const void* kv, long kv_b
                              AttnRows rows = AttnRows());
 // ---- decode-step projections of the catalog widths at a few rows (whisper_dec_gemv.hip): matrix-vector products over dense
 // f16 rows or resident ggml blocks, LayerNorm computed in the consumer, every weight byte of a row requested at once ----
-constexpr int GEMV_MAX_M = 4;
+constexpr int GEMV_MAX_M = 4;        // rows a workgroup takes through its weight rows together
+constexpr int GEMV_MAX_ROWS = 512;   // rows of a step (gridDim.y chunks of GEMV_MAX_M: a row's arithmetic is that of a step of its own)
 constexpr int GEMV_QKV = 0;        // LN(x) . [Wq | Wk | Wv]^T + b: q -> out (f32 [M][ldo]); k | v -> the f16 cache row of this position
 constexpr int GEMV_RES = 1;        // out = x . W^T + b + res (f32; out may alias res)
 constexpr int GEMV_F32 = 2;        // out = LN(x) . W^T + b (f32)
@@ -190,7 +191,7 @@ struct GemvArgs {
   const float* xpart;                               // GEMV_RES_MERGE: [M][K / 64][XA_PARTS][XA_PART_FLOATS]
   int M, N, K;
 };
-// [LayerNorm -> cross q of a head -> attention over a quarter of the clip's keys] for rows <= GEMV_MAX_M: partial soft-maxes into `part`
+// [LayerNorm -> cross q of a head -> attention over a quarter of the clip's keys], one workgroup per (row, head, quarter): partial soft-maxes into `part`
 struct XattnArgs {
   const float* x; long ldx; const float *ln_g, *ln_b;
   const _Float16* w16; const unsigned char* wq; int wq_type;       // cross-q weights [D][D]: dense f16 rows or ggml blocks

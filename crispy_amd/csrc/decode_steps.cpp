@@ -64,7 +64,7 @@ int reserve_dec(crispy_asr* h, int batch, int xclips) {
     }
   }
   if (gemv_dec_supported((int)dt, 1))
-    HIP_TRY(hipMalloc(&h->d_gvpart, (size_t)GEMV_MAX_M * (dt / 64) * XA_PARTS * XA_PART_FLOATS * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_gvpart, (size_t)std::min<size_t>(B, GEMV_MAX_ROWS) * (dt / 64) * XA_PARTS * XA_PART_FLOATS * sizeof(float)));
   h->dcap_batch = batch;
   h->dcap_xclips = xclips;
   return CRISPY_OK;
@@ -181,11 +181,14 @@ bool self_kv_half(const crispy_asr* h, int rows) {
   return rows <= SKINNY_MAX_M && h->hp.n_text_state % 128 == 0 && h->enc_precision == 1 && h->dec_max_keys > 0 && h->dec_max_keys <= 512;
 }
 
-// A step of 1 .. GEMV_MAX_M rows of a catalog-width model (768 / 1024 / 1280) in precision mode 1: the projections as
-// matrix-vector products with the LayerNorm computed in the consumer (whisper_dec_gemv.hip) -- 8 launches per layer
-// instead of 11, spread over N / 8 workgroups instead of N / 32.  Dense f16 copies or resident blocks of ONE ggml type per
-// projection; anything else (a mixed file's dense tensors, precision mode 0, more rows, the multi-position prompt) stays on
-// the skinny kernels.  CRISPY_ASR_GEMV=0 (developer build) turns it off for the A/B.
+// A generated-token step of a catalog-width model (768 / 1024 / 1280) in precision mode 1, at ANY row count: the projections as
+// matrix-vector products with the LayerNorm computed in the consumer (whisper_dec_gemv.hip) -- 7 launches per layer
+// instead of 11, N / 8 workgroups per four rows instead of N / 32.  Every row count, because a row's arithmetic there is the
+// arithmetic of the row decoded alone: one clip, one answer whatever the batch (a form that switched to the skinny kernels
+// above four rows would add a row's partial sums in another order -- the hazard round 5 had at 128 rows for the small models).
+// Dense f16 copies or resident blocks of ONE ggml type per projection; anything else (a mixed file's dense tensors, precision
+// mode 0, the multi-position prompt -- whose form does not depend on the batch either) stays on the skinny kernels.
+// CRISPY_ASR_GEMV=0 (developer build) turns it off for the A/B.
 bool gemv_ref_ok(const QRef& r) {
   if (r.n <= 0) return false;
   const int tt = r.t[0]->ttype;
@@ -265,7 +268,7 @@ int step_proj(const StepCtx& c, GemmArgs g, const float* dense32, const void* de
   return CRISPY_OK;
 }
 
-// A layer of a step of 1 .. GEMV_MAX_M rows of a catalog-width model: matrix-vector products (whisper_dec_gemv.hip), 7 launches
+// A layer of a generated-token step of a catalog-width model: matrix-vector products (whisper_dec_gemv.hip), 7 launches
 int layer_gemv(StepCtx& c, size_t l) {
   crispy_asr* h = c.h;
   hipStream_t s = c.s;
@@ -288,9 +291,22 @@ int layer_gemv(StepCtx& c, size_t l) {
   };
   int rc;
   c.self_rows.attn16 = h->dec_attn16 ? 1 : 0;
+  // The LayerNorm in front of q | k | v and fc1: up to GEMV_MAX_M rows every workgroup normalises them itself (no launch); beyond,
+  // a workgroup would normalise ALL rows, four per pass -- one launch of the same arithmetic (layernorm_h_kernel: the
+  // instructions gv_layernorm_wave mirrors; tests/test_gpu_gemv_decode.py: row 0 of 130 == the row alone, bytes) writes
+  // them as f16 once and the products read those
+  const bool ln_launch = batch > GEMV_MAX_M;
+  _Float16* xn16 = reinterpret_cast<_Float16*>(h->d_dxn);
+  auto normalised = [&](GemvArgs& a, const float* g_, const float* b_) -> int {
+    if (!ln_launch) { a.x = h->d_dx; a.ldx = dt; a.ln_g = g_; a.ln_b = b_; return CRISPY_OK; }
+    HIP_TRY(layernorm_f16out(h->d_dx, g_, b_, xn16, batch, dt, s));
+    a.x16 = xn16; a.ldx = dt;
+    return CRISPY_OK;
+  };
   {
     GemvArgs a{};
-    a.x = h->d_dx; a.ldx = dt; a.ln_g = L.ln1_w; a.ln_b = L.ln1_b; weights(a, L.qkv_wh, L.r_qkv); a.bias = L.qkv_b;
+    if ((rc = normalised(a, L.ln1_w, L.ln1_b)) != CRISPY_OK) return rc;
+    weights(a, L.qkv_wh, L.r_qkv); a.bias = L.qkv_b;
     a.out = h->d_dq; a.ldo = dt; a.kv = kvh; a.kv_row_stride = (long)c.C * 2 * dt; a.pos = c.pos; a.pos_dev = c.pos_dev;
     a.M = batch; a.N = 3 * dt; a.K = dt;
     HIP_TRY(gemv_dec(a, GEMV_QKV, s));
@@ -326,7 +342,8 @@ int layer_gemv(StepCtx& c, size_t l) {
   }
   {
     GemvArgs a{};
-    a.x = h->d_dx; a.ldx = dt; a.ln_g = L.ln2_w; a.ln_b = L.ln2_b; weights(a, L.fc1_wh, L.r_fc1); a.bias = L.fc1_b;
+    if ((rc = normalised(a, L.ln2_w, L.ln2_b)) != CRISPY_OK) return rc;
+    weights(a, L.fc1_wh, L.r_fc1); a.bias = L.fc1_b;
     a.out16 = hid; a.ldo = 4L * dt; a.M = batch; a.N = 4 * dt; a.K = dt;
     HIP_TRY(gemv_dec(a, GEMV_GELU16, s));
   }
@@ -492,7 +509,9 @@ int decoder_step(crispy_asr* h, int batch, int pos, bool dev_pos, bool want_logi
     else
       HIP_TRY(embed_tokens_f32(h->d_tok, h->tok_emb, h->dec_pos, pos, c.pos_dev, h->d_dx, c.rows, dt, s, P, h->cur_row_off));
   }
-  const bool use_gemv = P == 1 && gemv_step_ok(h, c.rows);
+  // generated tokens only (device position): a prompt position is a row of a multi-position step or -- when batch x P does not
+  // divide the prompt -- a single-position step of the SAME skinny kernels, whatever the batch
+  const bool use_gemv = P == 1 && dev_pos && gemv_step_ok(h, c.rows);
   for (size_t l = 0; l < h->dec.size(); ++l) {
     int rc;
     if (use_gemv) {
@@ -799,6 +818,47 @@ double canonical(std::mt19937& g) {
   return u < 1.0 ? u : std::nextafter(1.0, 0.0);
 }
 
+// The end of a beam pass: the steps' records [step][row] (id, timestamp id, log-probability, the row the sequence came from)
+// walked back from every row's last token -- token i of a row was dealt at step i, to the row the later record names as its
+// parent -- and the decoders' generators moved on by what they consumed.
+int beam_collect(crispy_asr* h, int rows, int n_dec, int n_cand, int max_new, int steps_run, const Special& sp,
+                 const std::vector<std::mt19937*>& rng, int* tokens_out, int* tids_out, float* plog_out, float* nosp_out, int* n_out) {
+  hipStream_t s = h->stream;
+  std::vector<BeamRow> br((size_t)rows);
+  std::vector<int> rec_tok((size_t)steps_run * rows), rec_tid((size_t)steps_run * rows), rec_par((size_t)steps_run * rows);
+  std::vector<float> rec_plog((size_t)steps_run * rows), nosp(rows);
+  HIP_TRY(hipMemcpyAsync(rec_tok.data(), h->d_tokens_all, rec_tok.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(rec_tid.data(), h->d_tids_all, rec_tid.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(rec_par.data(), h->d_beam_rec_parent, rec_par.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(rec_plog.data(), h->d_plog_all, rec_plog.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(br.data(), h->d_beam_row, sizeof(BeamRow) * rows, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(nosp.data(), h->d_nosp, nosp.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  for (int r = 0; r < rows; ++r) {
+    const int n = br[r].n;
+    if (n < 0 || n > steps_run || n > max_new) return fail(CRISPY_ERR_HIP, "beam decode: row %d ends with %d tokens after %d steps", r, n, steps_run);
+    for (int i = 0; i < max_new; ++i) {
+      tokens_out[(size_t)r * max_new + i] = h->eot;
+      if (tids_out) tids_out[(size_t)r * max_new + i] = sp.beg;
+      if (plog_out) plog_out[(size_t)r * max_new + i] = 0.f;
+    }
+    int row = r;
+    for (int i = n - 1; i >= 0; --i) {       // token i was dealt to `row` at step i, from the decoder rec_par names
+      const size_t x = (size_t)i * rows + row;
+      if (row / n_dec != r / n_dec || rec_tok[x] < 0 || rec_tok[x] >= h->hp.n_vocab)
+        return fail(CRISPY_ERR_HIP, "beam decode: the record of row %d, step %d is not a decoder of its clip", r, i);
+      tokens_out[(size_t)r * max_new + i] = rec_tok[x];
+      if (tids_out) tids_out[(size_t)r * max_new + i] = rec_tid[x];
+      if (plog_out) plog_out[(size_t)r * max_new + i] = rec_plog[x];
+      row = rec_par[x];
+    }
+    if (nosp_out) nosp_out[r] = nosp[r];
+    if (n_out) n_out[r] = n;
+    rng[r]->discard(2ull * (unsigned long long)n_cand * (unsigned long long)n);      // a decoder was live for exactly the steps that dealt it a token
+  }
+  return CRISPY_OK;
+}
+
 // One pass of whisper_full's BEAM_SEARCH strategy over one window per clip [UPSTREAM-RECALL: whisper_full_with_state,
 // whisper_sample_token_topk; restated in oracle/whisper_oracle.py: decode_temperature(beam_size=)].  Every clip has n_dec
 // decoders (rows [c n_dec, (c + 1) n_dec): beam_size of them at temperature 0, best_of above) over ONE cross K | V.  Per step:
@@ -929,38 +989,7 @@ int decode_beam(crispy_asr* h, const float* d_enc, int n_clips, int n_dec, int n
   }
   HIP_TRY(ts_pick(pa, rows, s));            // the last step needs no further decoder step
   HIP_TRY(beam_advance(ba, n_clips, s));
-  std::vector<int> rec_tok((size_t)steps_run * rows), rec_tid((size_t)steps_run * rows), rec_par((size_t)steps_run * rows);
-  std::vector<float> rec_plog((size_t)steps_run * rows), nosp(rows);
-  HIP_TRY(hipMemcpyAsync(rec_tok.data(), h->d_tokens_all, rec_tok.size() * sizeof(int), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(rec_tid.data(), h->d_tids_all, rec_tid.size() * sizeof(int), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(rec_par.data(), h->d_beam_rec_parent, rec_par.size() * sizeof(int), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(rec_plog.data(), h->d_plog_all, rec_plog.size() * sizeof(float), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(br.data(), h->d_beam_row, sizeof(BeamRow) * rows, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(nosp.data(), h->d_nosp, nosp.size() * sizeof(float), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  for (int r = 0; r < rows; ++r) {
-    const int n = br[r].n;
-    if (n < 0 || n > steps_run || n > max_new) return fail(CRISPY_ERR_HIP, "beam decode: row %d ends with %d tokens after %d steps", r, n, steps_run);
-    for (int i = 0; i < max_new; ++i) {
-      tokens_out[(size_t)r * max_new + i] = h->eot;
-      if (tids_out) tids_out[(size_t)r * max_new + i] = sp.beg;
-      if (plog_out) plog_out[(size_t)r * max_new + i] = 0.f;
-    }
-    int row = r;
-    for (int i = n - 1; i >= 0; --i) {       // token i was dealt to `row` at step i, from the decoder rec_par names
-      const size_t x = (size_t)i * rows + row;
-      if (row / n_dec != r / n_dec || rec_tok[x] < 0 || rec_tok[x] >= h->hp.n_vocab)
-        return fail(CRISPY_ERR_HIP, "beam decode: the record of row %d, step %d is not a decoder of its clip", r, i);
-      tokens_out[(size_t)r * max_new + i] = rec_tok[x];
-      if (tids_out) tids_out[(size_t)r * max_new + i] = rec_tid[x];
-      if (plog_out) plog_out[(size_t)r * max_new + i] = rec_plog[x];
-      row = rec_par[x];
-    }
-    if (nosp_out) nosp_out[r] = nosp[r];
-    if (n_out) n_out[r] = n;
-    rng[r]->discard(2ull * (unsigned long long)n_cand * (unsigned long long)n);      // a decoder was live for exactly the steps that dealt it a token
-  }
-  return CRISPY_OK;
+  return beam_collect(h, rows, n_dec, n_cand, max_new, steps_run, sp, rng, tokens_out, tids_out, plog_out, nosp_out, n_out);
 }
 
 // pick a token from the current logits (step-aware suppression), record it, run the next step on it,

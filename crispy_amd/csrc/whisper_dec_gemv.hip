@@ -165,7 +165,10 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_dec_kernel(GemvArgs g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hl = lane & 31, half = lane >> 5;
   const int n = blockIdx.x * GV_ROWS + 2 * wave + half;              // this half-wave's weight row (N is a multiple of 8)
-  const int M = g.M;
+  // Steps of more than GEMV_MAX_M rows: the workgroup takes the rows four at a time over the SAME decoded weights (blockIdx.y
+  // deals the chunks when the weight-row blocks alone do not fill the chip).  A row's arithmetic is what it is in a step of
+  // its own -- one clip, one answer at every batch size: the reason the wide steps of the catalog widths run here too and
+  // not on the MFMA tiles of the skinny kernels.
   // (1) every weight byte of the row, requested first
   const unsigned char* wrow;
   if (TT < 0) {
@@ -183,87 +186,118 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_dec_kernel(GemvArgs g) {
   }
   const float bias = g.bias ? g.bias[n] : 0.f;
   __builtin_amdgcn_sched_barrier(0);
-  // (2) the activation rows as f16 in LDS
-  if (LN) {
-    if (wave < M) gv_layernorm_wave<K>(g.x + (long)wave * g.ldx, g.ln_g, g.ln_b, xs[wave], lane);
-  } else if (EPI == GEMV_RES_MERGE) {
-    // the activation is the cross-attention output, still in XA_PARTS partial soft-maxes per head (gv_xattn_kernel): merged
-    // here, in a fixed order, by every workgroup for itself (17 KB of partials per row against the launch it saves)
-    for (int m = 0; m < M; ++m) {
-      for (int c = tid; c < K; c += GV_THREADS) {
-        const float* ph = g.xpart + ((long)m * (K / 64) + (c >> 6)) * (XA_PARTS * XA_PART_FLOATS);
-        float mx = ph[0];
-#pragma unroll
-        for (int j = 1; j < XA_PARTS; ++j) mx = fmaxf(mx, ph[j * XA_PART_FLOATS]);
-        float num = 0.f, den = 0.f;
-#pragma unroll
-        for (int j = 0; j < XA_PARTS; ++j) {
-          const float scl = __expf(ph[j * XA_PART_FLOATS] - mx);         // an empty part has m = -1e30: scale 0
-          num = fmaf(ph[j * XA_PART_FLOATS + 2 + (c & 63)], scl, num);
-          den = fmaf(ph[j * XA_PART_FLOATS + 1], scl, den);
-        }
-        xs[m][gv_idx(c)] = (_Float16)(num / den);
-      }
-    }
-  } else {
-    for (int m = 0; m < M; ++m) {
-      if (g.x16) {
-        const _Float16* xr = g.x16 + (long)m * g.ldx;
-        for (int c = tid; c < K; c += GV_THREADS) xs[m][gv_idx(c)] = xr[c];
-      } else {
-        const float* xr = g.x + (long)m * g.ldx;
-        for (int c = tid; c < K; c += GV_THREADS) xs[m][gv_idx(c)] = (_Float16)xr[c];
-      }
-    }
-  }
-  __syncthreads();
-  // (3) the products: a lane's blocks in K order, 16 dot2 per block and row
-  float acc[GEMV_MAX_M];
-#pragma unroll
-  for (int m = 0; m < GEMV_MAX_M; ++m) acc[m] = 0.f;
-#pragma unroll
-  for (int ps = 0; ps < NPASS; ++ps) {
-    const int kb = hl + 32 * ps;
-    half8 w[4];
-    blk[ps].decode(w);
-    if (kb < KB) {
+  half8 w[NPASS][4];
+  bool decoded = false;
+  // plain activation rows (f16 behind a LayerNorm launch, the GELU'd hidden units, f32 attention outputs): the NEXT chunk's
+  // values are requested before this chunk's products, so that a wide step does not wait a global round trip per four rows
+  constexpr bool PLAIN = !LN && EPI != GEMV_RES_MERGE;
+  constexpr int XPT = (K + GV_THREADS - 1) / GV_THREADS;          // columns per thread and row: c = tid + GV_THREADS q
+  _Float16 nx[PLAIN ? GEMV_MAX_M : 1][PLAIN ? XPT : 1];
+  auto fetch = [&](int r0) {
+    if constexpr (PLAIN) {
+      const int M = min(GEMV_MAX_M, g.M - r0);
 #pragma unroll
       for (int m = 0; m < GEMV_MAX_M; ++m) {
-        if (m < M) {
-          const half8* xp = reinterpret_cast<const half8*>(&xs[m][kb * GV_XB]);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc[m] = gv_dot8(w[i], xp[i], acc[m]);
+        for (int q = 0; q < XPT; ++q) {
+          const int c = min(tid + GV_THREADS * q, K - 1);
+          const long at = (long)(r0 + min(m, M - 1)) * g.ldx + c;
+          nx[m][q] = g.x16 ? g.x16[at] : (_Float16)g.x[at];
         }
       }
     }
-  }
+  };
+  const int r_step = GEMV_MAX_M * (int)gridDim.y;
+  if (blockIdx.y * GEMV_MAX_M < g.M) fetch(blockIdx.y * GEMV_MAX_M);
+  for (int r0 = blockIdx.y * GEMV_MAX_M; r0 < g.M; r0 += r_step) {
+    const int M = min(GEMV_MAX_M, g.M - r0);
+    // (2) the chunk's activation rows as f16 in LDS
+    if (LN) {
+      if (wave < M) gv_layernorm_wave<K>(g.x + (long)(r0 + wave) * g.ldx, g.ln_g, g.ln_b, xs[wave], lane);
+    } else if (EPI == GEMV_RES_MERGE) {
+      // the activation is the cross-attention output, still in XA_PARTS partial soft-maxes per head (gv_xattn_kernel): merged
+      // here, in a fixed order, by every workgroup for itself (17 KB of partials per row against the launch it saves)
+      for (int m = 0; m < M; ++m) {
+        for (int c = tid; c < K; c += GV_THREADS) {
+          const float* ph = g.xpart + ((long)(r0 + m) * (K / 64) + (c >> 6)) * (XA_PARTS * XA_PART_FLOATS);
+          float mx = ph[0];
 #pragma unroll
-  for (int m = 0; m < GEMV_MAX_M; ++m) {
+          for (int j = 1; j < XA_PARTS; ++j) mx = fmaxf(mx, ph[j * XA_PART_FLOATS]);
+          float num = 0.f, den = 0.f;
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1) acc[m] += __shfl_xor(acc[m], off, 64);      // within the half-wave: fixed tree
-  }
-  // (4) epilogue: lane 0 of the half-wave owns output column n of every row
-  if (hl == 0) {
+          for (int j = 0; j < XA_PARTS; ++j) {
+            const float scl = __expf(ph[j * XA_PART_FLOATS] - mx);         // an empty part has m = -1e30: scale 0
+            num = fmaf(ph[j * XA_PART_FLOATS + 2 + (c & 63)], scl, num);
+            den = fmaf(ph[j * XA_PART_FLOATS + 1], scl, den);
+          }
+          xs[m][gv_idx(c)] = (_Float16)(num / den);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < GEMV_MAX_M; ++m) {
+#pragma unroll
+        for (int q = 0; q < XPT; ++q) {
+          const int c = tid + GV_THREADS * q;
+          if (m < M && c < K) xs[m][gv_idx(c)] = nx[m][q];
+        }
+      }
+      if (r0 + r_step < g.M) fetch(r0 + r_step);
+    }
+    __syncthreads();
+    if (!decoded) {
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) blk[ps].decode(w[ps]);
+      decoded = true;
+    }
+    // (3) the products: a lane's blocks in K order, 16 dot2 per block and row
+    float acc[GEMV_MAX_M];
+#pragma unroll
+    for (int m = 0; m < GEMV_MAX_M; ++m) acc[m] = 0.f;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int kb = hl + 32 * ps;
+      if (kb < KB) {
+#pragma unroll
+        for (int m = 0; m < GEMV_MAX_M; ++m) {
+          if (m < M) {
+            const half8* xp = reinterpret_cast<const half8*>(&xs[m][kb * GV_XB]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[m] = gv_dot8(w[ps][i], xp[i], acc[m]);
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int m = 0; m < GEMV_MAX_M; ++m) {
-      if (m >= M) break;
-      float v = acc[m] + bias;
-      if (EPI == GEMV_QKV) {
-        const int D = K;
-        if (n < D) {
-          g.out[(long)m * g.ldo + n] = v;
-        } else {                                                       // k | v of this position into the f16 cache row
-          const long pos = g.pos_dev ? (long)*g.pos_dev : (long)g.pos;
-          g.kv[(long)m * g.kv_row_stride + pos * (2L * D) + (n - D)] = (_Float16)v;
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) acc[m] += __shfl_xor(acc[m], off, 64);      // within the half-wave: fixed tree
+    }
+    // (4) epilogue: lane 0 of the half-wave owns output column n of every row
+    if (hl == 0) {
+#pragma unroll
+      for (int m = 0; m < GEMV_MAX_M; ++m) {
+        if (m >= M) break;
+        const long row = r0 + m;
+        float v = acc[m] + bias;
+        if (EPI == GEMV_QKV) {
+          const int D = K;
+          if (n < D) {
+            g.out[row * g.ldo + n] = v;
+          } else {                                                       // k | v of this position into the f16 cache row
+            const long pos = g.pos_dev ? (long)*g.pos_dev : (long)g.pos;
+            g.kv[row * g.kv_row_stride + pos * (2L * D) + (n - D)] = (_Float16)v;
+          }
+        } else if (EPI == GEMV_RES || EPI == GEMV_RES_MERGE) {
+          g.out[row * g.ldo + n] = v + g.res[row * g.ldo + n];
+        } else if (EPI == GEMV_F32) {
+          g.out[row * g.ldo + n] = v;
+        } else {
+          g.out16[row * g.ldo + n] = (_Float16)gelu_ggml(v);
         }
-      } else if (EPI == GEMV_RES || EPI == GEMV_RES_MERGE) {
-        g.out[(long)m * g.ldo + n] = v + g.res[(long)m * g.ldo + n];
-      } else if (EPI == GEMV_F32) {
-        g.out[(long)m * g.ldo + n] = v;
-      } else {
-        g.out16[(long)m * g.ldo + n] = (_Float16)gelu_ggml(v);
       }
     }
+    __syncthreads();                                                   // xs is rewritten by the next chunk
   }
 }
 
@@ -420,7 +454,10 @@ __global__ __launch_bounds__(XA_THREADS) void gv_xattn_kernel(XattnArgs a) {
 
 template <int TT, int K, bool LN, int EPI>
 hipError_t gv_launch(const GemvArgs& g, hipStream_t s) {
-  hipLaunchKernelGGL((gemv_dec_kernel<TT, K, LN, EPI>), dim3(g.N / GV_ROWS), dim3(GV_THREADS), 0, s, g);
+  // the rows' chunks of four over gridDim.y only as far as the weight-row blocks alone leave the chip empty (~ 1024 workgroups)
+  const int chunks = (g.M + GEMV_MAX_M - 1) / GEMV_MAX_M, xb = g.N / GV_ROWS;
+  const int gy = std::max(1, std::min(chunks, (1024 + xb - 1) / xb));
+  hipLaunchKernelGGL((gemv_dec_kernel<TT, K, LN, EPI>), dim3(xb, gy), dim3(GV_THREADS), 0, s, g);
   return hipGetLastError();
 }
 template <int K, bool LN, int EPI>
@@ -447,7 +484,7 @@ hipError_t gv_by_width(const GemvArgs& g, hipStream_t s) {
 
 }  // namespace
 
-bool gemv_dec_supported(int D, int rows) { return (D == 768 || D == 1024 || D == 1280) && rows >= 1 && rows <= GEMV_MAX_M; }
+bool gemv_dec_supported(int D, int rows) { return (D == 768 || D == 1024 || D == 1280) && rows >= 1 && rows <= GEMV_MAX_ROWS; }
 
 namespace {
 template <int TT>
@@ -464,7 +501,7 @@ hipError_t xa_by_width(const XattnArgs& a, hipStream_t s) {
 }  // namespace
 
 hipError_t gemv_xattn(const XattnArgs& a, hipStream_t s) {
-  if (a.rows < 1 || a.rows > GEMV_MAX_M || a.group < 1 || a.n_keys < 1 || a.n_keys > XA_PARTS * (XA_THREADS / 64) * XA_SLOTS * 8 || (!a.w16 && !a.wq))
+  if (a.rows < 1 || a.rows > GEMV_MAX_ROWS || a.group < 1 || a.n_keys < 1 || a.n_keys > XA_PARTS * (XA_THREADS / 64) * XA_SLOTS * 8 || (!a.w16 && !a.wq))
     return hipErrorInvalidValue;
   if (a.w16) return xa_by_width<-1>(a, s);
   switch (a.wq_type) {
@@ -478,13 +515,13 @@ hipError_t gemv_xattn(const XattnArgs& a, hipStream_t s) {
 }
 
 hipError_t gemv_dec(const GemvArgs& g, int epi, hipStream_t s) {
-  if (g.M < 1 || g.M > GEMV_MAX_M || g.N % GV_ROWS != 0 || (!g.w16 && !g.wq[0])) return hipErrorInvalidValue;
+  if (g.M < 1 || g.M > GEMV_MAX_ROWS || g.N % GV_ROWS != 0 || (!g.w16 && !g.wq[0])) return hipErrorInvalidValue;
   if (!g.w16 && (g.wq_rows <= 0 || g.wq_rows % GV_ROWS != 0)) return hipErrorInvalidValue;
   const bool ln = g.ln_g != nullptr;
   switch (epi) {
-    case GEMV_QKV: return ln ? gv_by_width<true, GEMV_QKV>(g, s) : hipErrorInvalidValue;
+    case GEMV_QKV: return ln ? gv_by_width<true, GEMV_QKV>(g, s) : (g.x16 ? gv_by_width<false, GEMV_QKV>(g, s) : hipErrorInvalidValue);
     case GEMV_F32: return ln ? gv_by_width<true, GEMV_F32>(g, s) : hipErrorInvalidValue;
-    case GEMV_GELU16: return ln ? gv_by_width<true, GEMV_GELU16>(g, s) : hipErrorInvalidValue;
+    case GEMV_GELU16: return ln ? gv_by_width<true, GEMV_GELU16>(g, s) : (g.x16 ? gv_by_width<false, GEMV_GELU16>(g, s) : hipErrorInvalidValue);
     case GEMV_RES_MERGE:
       if (ln || !g.xpart) return hipErrorInvalidValue;
       switch (g.K) {

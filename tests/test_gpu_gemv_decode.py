@@ -110,3 +110,46 @@ def test_resident_blocks_equal_the_inflated_file_through_the_gemv_step(tmp_path,
     assert np.array_equal(tr, ti) and lr.tobytes() == li.tobytes(), (tr, ti)
     assert np.array_equal(t1[0], tr[1]) and l1[0].tobytes() == lr[1].tobytes()
     assert len({tuple(t) for t in tr.tolist()}) == B
+
+
+@pytest.mark.parametrize("d,kind", [(768, None), (1024, "q4_1")])
+def test_a_row_of_a_catalog_width_decodes_to_the_same_bits_in_any_batch(tmp_path, d, kind):
+    """One clip, one answer for the models the app loads: a generated token's step of a catalog width runs the matrix-vector
+    kernels at EVERY row count (gridDim.y takes the rows four at a time), not the skinny MFMA tiles above four rows -- so a
+    clip's ids and picked-logit bytes are the same alone, as row 5 of 6, and in batches of 37 and 130 (the reference decodes
+    one chunk per call, managers/transcription.rs:183-185; `crispy_asr_transcribe_recording` decodes up to 128 at once and
+    has to say the same).  Dense f16 (small's width) and resident q4_1 blocks (medium's width and type)."""
+    import torch
+    from crispy_amd.asr import WhisperEngine, WhisperModel
+    from crispy_amd.ggml_io import synthetic_vocab, write_ggml_quantized
+    from crispy_amd.mel_filters import whisper_mel_filters
+    from crispy_amd.whisper_weights import synthetic_whisper_weights
+    hp = _hp(d)
+    W = synthetic_whisper_weights(hp, 11, sensitive=True)
+    if kind:
+        path = str(tmp_path / f"w{d}-{kind}.bin")
+        write_ggml_quantized(path, hp, W, whisper_mel_filters(80), synthetic_vocab(hp.n_vocab), kind)
+        m = WhisperEngine(path, resident=True)
+    else:
+        m = WhisperModel(hp, W)
+        m.set_precision(1)
+    rng = np.random.default_rng(d)
+    n_new = 6
+    base = (rng.standard_normal((6, 1500, d)) * 0.8).astype(np.float32)
+    prompt = [50258, 50259, 50359, 50363]
+    try:
+        ref = {}
+        for B in (1, 6, 37, 130):
+            enc = np.ascontiguousarray(base[np.arange(B) % 6])
+            d_enc = torch.from_numpy(enc).to("cuda:0")
+            torch.cuda.synchronize()
+            t, _, l = m.decode_greedy_device(d_enc.data_ptr(), B, prompt, n_new)
+            for r in range(B):
+                key = r % 6
+                if key not in ref:
+                    ref[key] = (t[r].copy(), l[r].tobytes())
+                assert np.array_equal(t[r], ref[key][0]) and l[r].tobytes() == ref[key][1], (B, r)
+            del d_enc
+        assert len({tuple(v[0].tolist()) for v in ref.values()}) >= 3      # the six clips do not all decode alike
+    finally:
+        m.close()
