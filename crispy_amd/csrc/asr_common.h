@@ -196,6 +196,7 @@ struct XattnArgs {
   const float* x; long ldx; const float *ln_g, *ln_b;
   const _Float16* w16; const unsigned char* wq; int wq_type;       // cross-q weights [D][D]: dense f16 rows or ggml blocks
   const float* bq;
+  const float* q; long ldq;                                        // wide steps: q of every row [rows][ldq], projected by ONE gemv_dec launch (else null)
   const _Float16* xkv; long clip_stride; int n_keys, group;        // the layer's cross K | V (f16, head-major), rows per clip
   float* part;
   int rows, D;

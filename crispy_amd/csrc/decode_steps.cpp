@@ -318,9 +318,20 @@ int layer_gemv(StepCtx& c, size_t l) {
     // [LayerNorm -> cross q of a head -> attention over a quarter of the keys] in one launch of heads x XA_PARTS workgroups,
     // the partial soft-maxes merged by the output projection's prologue: two launches where the step had three
     XattnArgs xa{};
-    xa.x = h->d_dx; xa.ldx = dt; xa.ln_g = L.lnx_w; xa.ln_b = L.lnx_b; xa.bq = L.xq_b;
-    if (L.xq_wh) xa.w16 = reinterpret_cast<const _Float16*>(L.xq_wh);      // (a resident model keeps this one matrix as f16 too: finalize_resident)
-    else { xa.wq = L.r_xq.t[0]->d; xa.wq_type = L.r_xq.t[0]->ttype; }
+    if (ln_launch) {
+      // a wide step: q of all rows from one launch (the cross kernel's own q products, bit for bit; per (row, head, quarter)
+      // workgroup they were 128 KB of weights each -- half of a 64-row step)
+      GemvArgs a{};
+      if ((rc = normalised(a, L.lnx_w, L.lnx_b)) != CRISPY_OK) return rc;
+      if (L.xq_wh) a.w16 = reinterpret_cast<const _Float16*>(L.xq_wh); else weights(a, nullptr, L.r_xq);
+      a.bias = L.xq_b; a.out = h->d_dq; a.ldo = dt; a.M = batch; a.N = dt; a.K = dt;
+      HIP_TRY(gemv_dec(a, GEMV_F32, s));
+      xa.q = h->d_dq; xa.ldq = dt;
+    } else {
+      xa.x = h->d_dx; xa.ldx = dt; xa.ln_g = L.lnx_w; xa.ln_b = L.lnx_b; xa.bq = L.xq_b;
+      if (L.xq_wh) xa.w16 = reinterpret_cast<const _Float16*>(L.xq_wh);      // (a resident model keeps this one matrix as f16 too: finalize_resident)
+      else { xa.wq = L.r_xq.t[0]->d; xa.wq_type = L.r_xq.t[0]->ttype; }
+    }
     xa.xkv = reinterpret_cast<const _Float16*>(h->d_xkv_h) + l * c.xclips * c.Tn * 2 * dt; xa.clip_stride = (long)c.Tn * 2 * dt;
     xa.n_keys = c.Tn; xa.group = c.xg; xa.part = h->d_gvpart; xa.rows = batch; xa.D = dt;
     HIP_TRY(gemv_xattn(xa, s));
