@@ -1,14 +1,15 @@
 """The decode step of the catalog widths (768 / 1024 / 1280: small, medium, large-v3 -- src-tauri/src/managers/model.rs:74-148)
-at the reference's call shape, one chunk at a time (managers/transcription.rs:183-185): `whisper_dec_gemv.hip` -- the six
-projections of a layer as matrix-vector products over dense f16 rows or resident ggml blocks, LayerNorm computed in the
-consumer, 8 launches per layer instead of 11.
+at the reference's call shape, one chunk at a time (managers/transcription.rs:183-185), and at every other batch size:
+`whisper_dec_gemv.hip` -- the six projections of a layer as matrix-vector products over dense f16 rows or resident ggml blocks,
+LayerNorm computed in the consumer, 7 launches per layer instead of 11.
 
  * against the oracle of precision mode 1 (oracle/whisper_oracle.py DecoderCache(f16=True): ggml's mul_mat arithmetic) at the
    mode's bar, and against the same step through the skinny kernels (developer build, CRISPY_ASR_GEMV=0) -- two implementations
    of one arithmetic, not bit-identical, both at the bar;
  * a resident quantised engine == the same file inflated at load, ids and picked-logit BYTES (same instructions behind the
    weight fetch), for every ggml type the catalog uses;
- * a row's bits do not depend on the rows it shares a step with (1 row == row 2 of 3)."""
+ * a row's bits do not depend on the rows it shares a step with: 1 row == row 2 of 3, and == the row in batches of 6, 37 and
+   130 (wide steps take the rows four at a time through the same kernels)."""
 import numpy as np
 import pytest
 
