@@ -699,11 +699,22 @@ int transcribe_batch_impl(crispy_asr* h, const float* const* pcm, const size_t* 
   if (batch == 0) return CRISPY_OK;
   if (!pcm || !n) return fail(CRISPY_ERR_INVALID_ARG, "crispy_asr_transcribe_batch: NULL argument");
   if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_transcribe_batch: model not finalized");
-  BatchCall call(h, pcm, n, batch, opts, cancel);
-  int rc = call.prepare();
-  if (rc == CRISPY_OK) rc = call.run();
-  if (rc != CRISPY_OK) return rc;            // (the call object owns every result it made: nothing reaches the caller)
-  call.release(results);
+  // At most kOneAnswerClips clips decode in lock step: that is the widest step the decode kernels take in the forms whose
+  // arithmetic per row is the row's alone (SKINNY_MAX_M rows); a wider batch would put its greedy pass on other kernels and a
+  // clip's last bits -- at a near tie its text -- would depend on whether 500 or 600 chunks were handed over.  More clips
+  // are taken in turns; the results are released together or not at all.
+  constexpr int kOneAnswerClips = SKINNY_MAX_M;
+  for (int b0 = 0; b0 < batch; b0 += kOneAnswerClips) {
+    const int nb = std::min(kOneAnswerClips, batch - b0);
+    BatchCall call(h, pcm + b0, n + b0, nb, opts, cancel);
+    int rc = call.prepare();
+    if (rc == CRISPY_OK) rc = call.run();
+    if (rc != CRISPY_OK) {                   // (the call object owns every result it made; the earlier turns' are given back)
+      for (int i = 0; i < b0; ++i) { crispy_asr_free_result(results[i]); results[i] = nullptr; }
+      return rc;
+    }
+    call.release(results + b0);
+  }
   return CRISPY_OK;
 }
 
@@ -767,7 +778,7 @@ int crispy_asr_transcribe_recording(crispy_asr* h, const float* pcm16k, size_t n
   if (!h->finalized) return fail(CRISPY_ERR_BAD_MODEL, "crispy_asr_transcribe_recording: model not finalized");
   constexpr size_t kChunk = 480000;                        // 30 s at 16 kHz (commands/transcription.rs:175-176)
   const size_t n_chunks = (n + kChunk - 1) / kChunk;       // the last partial chunk is passed as it is (the engine pads)
-  const size_t group = max_batch > 0 ? (size_t)max_batch : 128;
+  const size_t group = max_batch > 0 ? (size_t)max_batch : 128;       // (more than SKINNY_MAX_M are taken in turns by the batch call)
   crispy_asr_result_impl* R = new (std::nothrow) crispy_asr_result_impl();
   if (!R) return fail(CRISPY_ERR_OOM, "crispy_asr_transcribe_recording: host allocation failed");
   struct Own { crispy_asr_result_impl* r; ~Own() { delete r; } } own{R};

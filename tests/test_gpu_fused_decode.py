@@ -161,3 +161,25 @@ def test_a_row_decodes_to_the_same_bits_in_batches_of_1_70_129_and_512(model, mo
         assert l.tobytes() == l512[:rows].tobytes(), rows
     assert np.array_equal(t300[0], t512[300]) and l300[0].tobytes() == l512[300].tobytes()
     assert len({tuple(r) for r in t512.tolist()}) > 32           # the rows are different sequences, not one repeated (67 on random-init weights)
+
+
+def test_a_batch_call_of_more_than_512_clips_takes_them_in_turns_and_says_the_same():
+    """`crispy_asr_transcribe_batch` decodes at most 512 clips in lock step -- the widest step of the forms whose arithmetic per
+    row is the row's alone -- and takes a larger batch in turns: clip 0, 511, 512 and 519 of a 520-clip call come out as from a
+    call of their own (tokens and language; a 600-chunk recording says what 600 single calls say)."""
+    from crispy_amd import synth_audio
+    from crispy_amd.asr import WhisperModel, transcribe_batch
+    from crispy_amd.whisper_weights import HParams, synthetic_whisper_weights
+    hp = HParams.tiny()
+    m = WhisperModel(hp, synthetic_whisper_weights(hp, 4, sensitive=True))
+    try:
+        m.set_precision(1)
+        clips = [synth_audio.clip16k_np(300 + (i % 7), 16000 * 2 + 160 * (i % 5)) for i in range(520)]
+        kw = dict(max_new_tokens=6, timestamps=False)
+        got = transcribe_batch(m, clips, **kw)
+        assert len(got) == 520
+        for c in (0, 511, 512, 519):
+            assert got[c] == transcribe_batch(m, [clips[c]], **kw)[0], c
+        assert len({tuple(g[1]) for g in got}) >= 3
+    finally:
+        m.close()
