@@ -502,7 +502,7 @@ int crispy_asr_transcribe(crispy_asr *h, const float *pcm16k, size_t n, const cr
 /* The same for `batch` chunks at once (pcm[i]: host pointer to n[i] <= 480000 samples, n[i] == 0 allowed):
  * one log-mel + encoder + language-detection + decoder pass over all clips (more than 512: in turns of 512).  results[batch]
  * receives one library-owned result per clip (free each); on failure every results[i] is NULL.  A clip's result is the result
- * of crispy_asr_transcribe on it alone, bit for bit, whatever the batch (precision modes 1 / 2; every model width). */
+ * of crispy_asr_transcribe on it alone, bit for bit, whatever the batch (every precision mode, every model width). */
 int crispy_asr_transcribe_batch(crispy_asr *h, const float *const *pcm, const size_t *n, int batch,
                                 const crispy_asr_opts *opts, crispy_asr_result **results);
 void crispy_asr_free_result(crispy_asr_result *r);
