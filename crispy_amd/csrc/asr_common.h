@@ -191,12 +191,10 @@ struct GemvArgs {
   const float* xpart;                               // GEMV_RES_MERGE: [M][K / 64][XA_PARTS][XA_PART_FLOATS]
   int M, N, K;
 };
-// [LayerNorm -> cross q of a head -> attention over a quarter of the clip's keys], one workgroup per (row, head, quarter): partial soft-maxes into `part`
+// cross-attention of q (one gemv_dec launch, GEMV_F32) over a quarter of the clip's keys, one workgroup per (row, head, quarter):
+// partial soft-maxes into `part`
 struct XattnArgs {
-  const float* x; long ldx; const float *ln_g, *ln_b;
-  const _Float16* w16; const unsigned char* wq; int wq_type;       // cross-q weights [D][D]: dense f16 rows or ggml blocks
-  const float* bq;
-  const float* q; long ldq;                                        // wide steps: q of every row [rows][ldq], projected by ONE gemv_dec launch (else null)
+  const float* q; long ldq;                                        // [rows][ldq]
   const _Float16* xkv; long clip_stride; int n_keys, group;        // the layer's cross K | V (f16, head-major), rows per clip
   float* part;
   int rows, D;

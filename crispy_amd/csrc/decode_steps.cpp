@@ -182,8 +182,8 @@ bool self_kv_half(const crispy_asr* h, int rows) {
 }
 
 // A generated-token step of a catalog-width model (768 / 1024 / 1280) in precision mode 1, at ANY row count: the projections as
-// matrix-vector products with the LayerNorm computed in the consumer (whisper_dec_gemv.hip) -- 7 launches per layer
-// instead of 11, N / 8 workgroups per four rows instead of N / 32.  Every row count, because a row's arithmetic there is the
+// matrix-vector products with the LayerNorm computed in the consumer (whisper_dec_gemv.hip) -- 8 launches per layer
+// instead of 11, every one at the ~5 us of a dependent launch, N / 8 workgroups instead of N / 32.  Every row count, because a row's arithmetic there is the
 // arithmetic of the row decoded alone: one clip, one answer whatever the batch (a form that switched to the skinny kernels
 // above four rows would add a row's partial sums in another order -- the hazard round 5 had at 128 rows for the small models).
 // Dense f16 copies or resident blocks of ONE ggml type per projection; anything else (a mixed file's dense tensors, precision
@@ -268,7 +268,7 @@ int step_proj(const StepCtx& c, GemmArgs g, const float* dense32, const void* de
   return CRISPY_OK;
 }
 
-// A layer of a generated-token step of a catalog-width model: matrix-vector products (whisper_dec_gemv.hip), 7 launches
+// A layer of a generated-token step of a catalog-width model: matrix-vector products (whisper_dec_gemv.hip), 8 launches
 int layer_gemv(StepCtx& c, size_t l) {
   crispy_asr* h = c.h;
   hipStream_t s = c.s;
@@ -315,22 +315,18 @@ int layer_gemv(StepCtx& c, size_t l) {
                             batch, c.H, s, h->dec_max_keys, c.self_rows));
   if ((rc = residual_proj(h->d_datt, nullptr, dt, L.out_wh, L.r_out, L.out_b, dt)) != CRISPY_OK) return rc;
   if (!c.cross_rows.attn16 && h->d_gvpart && c.Tn <= XA_PARTS * 16 * XA_SLOTS * 8) {
-    // [LayerNorm -> cross q of a head -> attention over a quarter of the keys] in one launch of heads x XA_PARTS workgroups,
-    // the partial soft-maxes merged by the output projection's prologue: two launches where the step had three
+    // cross q (one launch), attention over a quarter of the keys per workgroup (heads x XA_PARTS of them per row), the partial
+    // soft-maxes merged by the output projection's prologue
     XattnArgs xa{};
-    if (ln_launch) {
-      // a wide step: q of all rows from one launch (the cross kernel's own q products, bit for bit; per (row, head, quarter)
-      // workgroup they were 128 KB of weights each -- half of a 64-row step)
+    {
+      // q of all rows from one launch (projected inside the cross kernel, per (row, head, quarter) workgroup, it was 128 KB of
+      // weights each: 13.5 - 16 us per launch at one row, half of a 64-row step)
       GemvArgs a{};
       if ((rc = normalised(a, L.lnx_w, L.lnx_b)) != CRISPY_OK) return rc;
-      if (L.xq_wh) a.w16 = reinterpret_cast<const _Float16*>(L.xq_wh); else weights(a, nullptr, L.r_xq);
+      if (L.xq_wh) a.w16 = reinterpret_cast<const _Float16*>(L.xq_wh); else weights(a, nullptr, L.r_xq);      // (a resident model keeps this one matrix as f16 too: finalize_resident)
       a.bias = L.xq_b; a.out = h->d_dq; a.ldo = dt; a.M = batch; a.N = dt; a.K = dt;
       HIP_TRY(gemv_dec(a, GEMV_F32, s));
       xa.q = h->d_dq; xa.ldq = dt;
-    } else {
-      xa.x = h->d_dx; xa.ldx = dt; xa.ln_g = L.lnx_w; xa.ln_b = L.lnx_b; xa.bq = L.xq_b;
-      if (L.xq_wh) xa.w16 = reinterpret_cast<const _Float16*>(L.xq_wh);      // (a resident model keeps this one matrix as f16 too: finalize_resident)
-      else { xa.wq = L.r_xq.t[0]->d; xa.wq_type = L.r_xq.t[0]->ttype; }
     }
     xa.xkv = reinterpret_cast<const _Float16*>(h->d_xkv_h) + l * c.xclips * c.Tn * 2 * dt; xa.clip_stride = (long)c.Tn * 2 * dt;
     xa.n_keys = c.Tn; xa.group = c.xg; xa.part = h->d_gvpart; xa.rows = batch; xa.D = dt;

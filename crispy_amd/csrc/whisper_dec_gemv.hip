@@ -301,29 +301,26 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_dec_kernel(GemvArgs g) {
   }
 }
 
-// ---- cross-attention of a step of few rows: [LayerNorm -> q of one head -> attention over a QUARTER of the clip's keys] ----
-// Round 5's pair for this -- a cross-q projection launch, then one workgroup per head streaming the head's 384 KB of K | V
-// (10.5 us at width 1024: sixteen CUs pull everything) -- becomes one launch of H x XA_PARTS workgroups: every workgroup
-// normalises the row and projects its head's 64 query values itself (the weights of 64 rows: 128 KB dense, 40 KB as q4_1),
-// attends its quarter of the keys and leaves an UNNORMALISED partial soft-max (maximum, sum, 64 weighted value sums) that
-// the output projection merges in its prologue (GEMV_RES_MERGE).  Partition inside a workgroup: 16 waves x 3 slots x 8 keys
-// (8 lanes per key row of 64 halves), the arithmetic of attn_dec_x16_kernel per wave; merges in fixed order.  (First built
-// with 4 waves x 12 slots: 11 us per launch -- a wave's chain of 12 score / value slots and 8 query rows is what the launch
-// lasts, so the chains were cut by four.)
-constexpr int XA_THREADS = 1024;                          // 16 waves: a part's 375 keys are 3 slots of 8 per wave, its 64 query rows 2 per half-wave
-template <int TT, int D, bool QIN = false>
+// ---- cross-attention of a decode step: q of one (row, head) against a QUARTER of the clip's keys ----
+// Round 5's cross block here -- one workgroup per head streaming the head's 384 KB of K | V (10.5 us at width 1024: sixteen
+// CUs pull everything) -- becomes H x XA_PARTS workgroups per row: every workgroup attends its quarter of the keys and leaves an
+// UNNORMALISED partial soft-max (maximum, sum, 64 weighted value sums) that the output projection merges in its prologue
+// (GEMV_RES_MERGE).  Partition inside a workgroup: 16 waves x 3 slots x 8 keys (8 lanes per key row of 64 halves), the
+// arithmetic of attn_dec_x16_kernel per wave; merges in fixed order.  (First built with 4 waves x 12 slots: 11 us per launch
+// -- a wave's chain of 12 score / value slots is what the launch lasts, so the chains were cut by four.)
+// q comes from a gemv_dec launch of its own (GEMV_F32 over LayerNorm(x)).  The first form projected it here, each workgroup its
+// head's 64 rows behind its own LayerNorm, to save that launch -- and read the head's weights (128 KB as f16) once per quarter:
+// 13.5 - 16 us per launch at ONE row against 5 + ~6 for the pair (medium-q4_1: 1.13 -> 1.01 ms per position), 178 us at 64 rows.
+constexpr int XA_THREADS = 1024;                          // 16 waves: a part's 375 keys are 3 slots of 8 per wave
+template <int D>
 __global__ __launch_bounds__(XA_THREADS) void gv_xattn_kernel(XattnArgs a) {
-  constexpr int KB = D / 32, NPASS = (KB + 31) / 32;
   constexpr int XW = XA_THREADS / 64;                     // waves
-  constexpr int RPH = 64 / (2 * XW);                      // query rows per half-wave
-  static_assert(XW * XA_SLOTS * 8 >= 384 && RPH == 2, "partition");
-  __shared__ __attribute__((aligned(16))) _Float16 xs[KB * GV_XB];
+  static_assert(XW * XA_SLOTS * 8 >= 384, "partition");
   __shared__ __attribute__((aligned(16))) float q_s[64];
   __shared__ __attribute__((aligned(16))) float part_o[XW][64];
   __shared__ float part_m[XW], part_l[XW];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hl = lane & 31, hw = 2 * wave + (lane >> 5);            // half-wave 0 .. 31
   const int h = blockIdx.x / XA_PARTS, part = blockIdx.x % XA_PARTS, row = blockIdx.y;
   const int clip = row / a.group;
   // (1) this workgroup's keys and values, requested first: wave w takes keys [k_lo, k_hi) of the part
@@ -343,61 +340,9 @@ __global__ __launch_bounds__(XA_THREADS) void gv_xattn_kernel(XattnArgs a) {
     kr[i] = *reinterpret_cast<const half8*>(Kb + off);
     vr[i] = *reinterpret_cast<const half8*>(Vb + off);
   }
-  if constexpr (QIN) {
-    // a wide step: q of every row came from ONE matrix-vector launch (gemv_dec, GEMV_F32: the products below, bit for bit) --
-    // with a workgroup per (row, head, quarter) projecting its own q, a step of 64 rows spent half its time re-reading the
-    // cross-q weights (128 KB per workgroup)
-    if (tid < 64) q_s[tid] = a.q[(long)row * a.ldq + h * 64 + tid];
-    __syncthreads();
-  } else {
-    // (2) q of the head: half-wave hw owns rows 2 hw, 2 hw + 1 of the head's 64; their weights are requested here, in front
-    // of the LayerNorm (wave 0) they will be multiplied with
-    // (width 1280: two blocks per lane and row -- with the LayerNorm's twenty values per lane that is more than the 128 registers
-    // of a 16-wave workgroup hold, so there the row is normalised first and wave 0 requests its weights behind it)
-    constexpr bool LN_FIRST = NPASS > 1;
-    if (LN_FIRST && wave == 0) gv_layernorm_wave<D, false>(a.x + (long)row * a.ldx, a.ln_g, a.ln_b, xs, lane);
-    GvBlock<TT> blk[RPH * NPASS];
-  #pragma unroll
-    for (int i = 0; i < RPH; ++i) {
-      const int n = h * 64 + RPH * hw + i;
-      const unsigned char* wrow = TT < 0 ? reinterpret_cast<const unsigned char*>(a.w16) + (long)n * D * 2 : a.wq + (long)n * KB * GvBlock<TT>::BB;
-  #pragma unroll
-      for (int ps = 0; ps < NPASS; ++ps) blk[i * NPASS + ps].request(wrow, min(hl + 32 * ps, KB - 1));
-    }
-    float bq[RPH];
-  #pragma unroll
-    for (int i = 0; i < RPH; ++i) bq[i] = a.bq[h * 64 + RPH * hw + i];
-    __builtin_amdgcn_sched_barrier(0);
-    if (!LN_FIRST && wave == 0) gv_layernorm_wave<D, false>(a.x + (long)row * a.ldx, a.ln_g, a.ln_b, xs, lane);
-    __syncthreads();
-    {
-      float acc[RPH];
-  #pragma unroll
-      for (int i = 0; i < RPH; ++i) {
-        acc[i] = 0.f;
-  #pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-          const int kb = hl + 32 * ps;
-          half8 w[4];
-          blk[i * NPASS + ps].decode(w);
-          if (kb < KB) {
-            const half8* xp = reinterpret_cast<const half8*>(&xs[kb * GV_XB]);
-  #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i] = gv_dot8(w[e], xp[e], acc[i]);
-          }
-        }
-      }
-  #pragma unroll
-      for (int off = 16; off > 0; off >>= 1)
-  #pragma unroll
-        for (int i = 0; i < RPH; ++i) acc[i] += __shfl_xor(acc[i], off, 64);
-      if (hl == 0) {
-  #pragma unroll
-        for (int i = 0; i < RPH; ++i) q_s[RPH * hw + i] = acc[i] + bq[i];
-      }
-    }
-    __syncthreads();
-  }
+  // (2) q of the head
+  if (tid < 64) q_s[tid] = a.q[(long)row * a.ldq + h * 64 + tid];
+  __syncthreads();
   // (3) scores, soft-max weights and weighted value sums of this wave's keys (attn_dec_x16_kernel's arithmetic)
   float qv[8];
   {
@@ -495,43 +440,19 @@ hipError_t gv_by_width(const GemvArgs& g, hipStream_t s) {
 bool gemv_dec_supported(int D, int rows) { return (D == 768 || D == 1024 || D == 1280) && rows >= 1 && rows <= GEMV_MAX_ROWS; }
 
 namespace {
-template <int TT>
-hipError_t xa_by_width(const XattnArgs& a, hipStream_t s) {
-  const dim3 grid((unsigned)(a.D / 64 * XA_PARTS), (unsigned)a.rows), block(XA_THREADS);
-  if (a.q) {
-    if constexpr (TT == -1) {
-      switch (a.D) {
-        case 768: hipLaunchKernelGGL((gv_xattn_kernel<-1, 768, true>), grid, block, 0, s, a); break;
-        case 1024: hipLaunchKernelGGL((gv_xattn_kernel<-1, 1024, true>), grid, block, 0, s, a); break;
-        case 1280: hipLaunchKernelGGL((gv_xattn_kernel<-1, 1280, true>), grid, block, 0, s, a); break;
-        default: return hipErrorInvalidValue;
-      }
-      return hipGetLastError();
-    }
-    return hipErrorInvalidValue;
-  }
-  switch (a.D) {
-    case 768: hipLaunchKernelGGL((gv_xattn_kernel<TT, 768>), grid, block, 0, s, a); break;
-    case 1024: hipLaunchKernelGGL((gv_xattn_kernel<TT, 1024>), grid, block, 0, s, a); break;
-    case 1280: hipLaunchKernelGGL((gv_xattn_kernel<TT, 1280>), grid, block, 0, s, a); break;
-    default: return hipErrorInvalidValue;
-  }
-  return hipGetLastError();
-}
 }  // namespace
 
 hipError_t gemv_xattn(const XattnArgs& a, hipStream_t s) {
-  if (a.rows < 1 || a.rows > GEMV_MAX_ROWS || a.group < 1 || a.n_keys < 1 || a.n_keys > XA_PARTS * (XA_THREADS / 64) * XA_SLOTS * 8 || (!a.w16 && !a.wq && !a.q))
+  if (a.rows < 1 || a.rows > GEMV_MAX_ROWS || a.group < 1 || a.n_keys < 1 || a.n_keys > XA_PARTS * (XA_THREADS / 64) * XA_SLOTS * 8 || !a.q)
     return hipErrorInvalidValue;
-  if (a.w16 || a.q) return xa_by_width<-1>(a, s);
-  switch (a.wq_type) {
-    case QT_Q4_0: return xa_by_width<QT_Q4_0>(a, s);
-    case QT_Q4_1: return xa_by_width<QT_Q4_1>(a, s);
-    case QT_Q5_0: return xa_by_width<QT_Q5_0>(a, s);
-    case QT_Q5_1: return xa_by_width<QT_Q5_1>(a, s);
-    case QT_Q8_0: return xa_by_width<QT_Q8_0>(a, s);
+  const dim3 grid((unsigned)(a.D / 64 * XA_PARTS), (unsigned)a.rows), block(XA_THREADS);
+  switch (a.D) {
+    case 768: hipLaunchKernelGGL((gv_xattn_kernel<768>), grid, block, 0, s, a); break;
+    case 1024: hipLaunchKernelGGL((gv_xattn_kernel<1024>), grid, block, 0, s, a); break;
+    case 1280: hipLaunchKernelGGL((gv_xattn_kernel<1280>), grid, block, 0, s, a); break;
     default: return hipErrorInvalidValue;
   }
+  return hipGetLastError();
 }
 
 hipError_t gemv_dec(const GemvArgs& g, int epi, hipStream_t s) {

@@ -1,7 +1,7 @@
 """The decode step of the catalog widths (768 / 1024 / 1280: small, medium, large-v3 -- src-tauri/src/managers/model.rs:74-148)
 at the reference's call shape, one chunk at a time (managers/transcription.rs:183-185), and at every other batch size:
 `whisper_dec_gemv.hip` -- the six projections of a layer as matrix-vector products over dense f16 rows or resident ggml blocks,
-LayerNorm computed in the consumer, 7 launches per layer instead of 11.
+LayerNorm computed in the consumer, 8 launches per layer instead of 11.
 
  * against the oracle of precision mode 1 (oracle/whisper_oracle.py DecoderCache(f16=True): ggml's mul_mat arithmetic) at the
    mode's bar, and against the same step through the skinny kernels (developer build, CRISPY_ASR_GEMV=0) -- two implementations
