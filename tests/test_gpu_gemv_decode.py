@@ -113,13 +113,13 @@ def test_resident_blocks_equal_the_inflated_file_through_the_gemv_step(tmp_path,
     assert len({tuple(t) for t in tr.tolist()}) == B
 
 
-@pytest.mark.parametrize("d,kind", [(768, None), (1024, "q4_1")])
+@pytest.mark.parametrize("d,kind", [(768, None), (1024, "q4_1"), (1280, "q5_0")])
 def test_a_row_of_a_catalog_width_decodes_to_the_same_bits_in_any_batch(tmp_path, d, kind):
     """One clip, one answer for the models the app loads: a generated token's step of a catalog width runs the matrix-vector
     kernels at EVERY row count (gridDim.y takes the rows four at a time), not the skinny MFMA tiles above four rows -- so a
     clip's ids and picked-logit bytes are the same alone, as row 5 of 6, and in batches of 37 and 130 (the reference decodes
     one chunk per call, managers/transcription.rs:183-185; `crispy_asr_transcribe_recording` decodes up to 128 at once and
-    has to say the same).  Dense f16 (small's width) and resident q4_1 blocks (medium's width and type)."""
+    has to say the same).  Dense f16 (small's width), resident q4_1 blocks (medium's width and type) and resident q5_0 blocks (large-v3's)."""
     import torch
     from crispy_amd.asr import WhisperEngine, WhisperModel
     from crispy_amd.ggml_io import synthetic_vocab, write_ggml_quantized
