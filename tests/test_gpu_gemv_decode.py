@@ -154,3 +154,32 @@ def test_a_row_of_a_catalog_width_decodes_to_the_same_bits_in_any_batch(tmp_path
         assert len({tuple(v[0].tolist()) for v in ref.values()}) >= 3      # the six clips do not all decode alike
     finally:
         m.close()
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(beam_size=3)], ids=["ladder_best_of_5", "beam_3"])
+def test_fallback_and_beam_passes_of_a_catalog_width_do_not_depend_on_the_batch(tmp_path, opts):
+    """whisper_full's fallback passes (five sampling decoders per clip over one cross K | V) and its beam search through the
+    matrix-vector step: rows of a clip share its keys (`XattnArgs::group`), a pass of three clips is a step of 15 rows -- the
+    wide form (LayerNorms and cross q as launches of their own, rows four at a time) -- a pass of one clip a step of 5.  On
+    random-init weights every window walks the ladder.  Each clip of a 3-clip call == the clip alone: text, tokens, segments,
+    window decisions."""
+    from crispy_amd import synth_audio
+    from crispy_amd.asr import WhisperEngine, transcribe_batch
+    from crispy_amd.ggml_io import synthetic_vocab, write_ggml
+    from crispy_amd.mel_filters import whisper_mel_filters
+    from crispy_amd.whisper_weights import synthetic_whisper_weights
+    hp = _hp(768)
+    W = synthetic_whisper_weights(hp, 21, sensitive=True)
+    path = str(tmp_path / "w768.bin")
+    write_ggml(path, hp, W, whisper_mel_filters(80), synthetic_vocab(hp.n_vocab), f16=True)
+    eng = WhisperEngine(path)
+    try:
+        eng.set_precision(1)
+        clips = [synth_audio.clip16k_np(500 + i, 16000 * (4 + 2 * i)) for i in range(3)]
+        kw = dict(timestamps=True, with_segments=True, max_new_tokens=24, **opts)
+        got = transcribe_batch(eng, clips, **kw)
+        assert any(w["temperature"] > 0 for r in got for w in r[4]) or opts        # the ladder ran (or this is the beam case)
+        for c in range(3):
+            assert got[c] == transcribe_batch(eng, [clips[c]], **kw)[0], c
+    finally:
+        eng.close()
